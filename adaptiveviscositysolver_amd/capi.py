@@ -1,0 +1,134 @@
+"""ctypes binding of the C ABI in include/avs.h (libavs_hip.so, built in-tree for gfx950).
+
+This is plumbing only: it declares the prototypes, turns avs_status into exceptions and offers
+small helpers to hand torch / numpy buffers across the boundary.  It fails loudly when the HIP
+library is missing -- there is no CPU fallback of any kind in the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libavs_hip.so")
+
+MAX_LEVELS = 8
+EDGE_STENCIL_CAP, CENTER_STENCIL_CAP = 32, 8
+EDGE_BOUNDARY_CAP, CENTER_BOUNDARY_CAP = 4, 2
+UNIQUE_ID_BYTES = 128
+
+OK, EINVAL, ENOMEM, EHIP, ERCCL, EINTERNAL, ESTATE = range(7)
+STATUS_NAMES = {0: "AVS_OK", 1: "AVS_EINVAL", 2: "AVS_ENOMEM", 3: "AVS_EHIP", 4: "AVS_ERCCL",
+                5: "AVS_EINTERNAL", 6: "AVS_ESTATE"}
+MEM_HOST, MEM_DEVICE = 0, 1
+INACTIVE, ACTIVE, UP, DOWN = 0, 1, 2, 3
+UNASSIGNED, SOLIDBOUNDARY, OUTSIDE = -1, -2, -3
+INDEX_VELOCITY, INDEX_EDGE, INDEX_CENTER = 0, 1, 2
+(FIELD_CENTER_WEIGHTS, FIELD_EDGE_WEIGHTS, FIELD_FACE_WEIGHTS, FIELD_VISCOSITY, FIELD_DENSITY,
+ FIELD_VELOCITY, FIELD_SOLID_VELOCITY) = range(7)
+
+# every symbol include/avs.h declares (checked by tests/test_capi_symbols.py)
+EXPORTED_SYMBOLS = [
+    "avs_last_error", "avs_version", "avs_create", "avs_destroy", "avs_set_labels",
+    "avs_set_index_field", "avs_set_dof_counts", "avs_set_scalar_field", "avs_build_stencils",
+    "avs_build_initial_guess", "avs_build_system", "avs_assemble", "avs_solve",
+    "avs_get_assembly_info", "avs_get_solution", "avs_get_initial_guess", "avs_get_csr",
+    "avs_get_edge_stencils", "avs_get_center_stencils", "avs_pcg_csr", "avs_spmv_csr",
+    "avs_bench_spmv", "avs_dist_get_unique_id", "avs_dist_init", "avs_dist_partition",
+    "avs_dist_solve", "avs_dist_get_solution",
+]
+
+
+class AvsError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+class Desc(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("dx", C.c_double),
+                ("dt", C.c_double), ("levels", C.c_int32), ("use_enhanced_gradients", C.c_int32),
+                ("device", C.c_int32), ("stream", C.c_void_p)]
+
+
+class SolveInfo(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("error", C.c_double),
+                ("rhs_norm2", C.c_double), ("n", C.c_int64), ("nnz", C.c_int64),
+                ("solve_ms", C.c_double), ("spmv_ms", C.c_double)]
+
+
+class AssemblyInfo(C.Structure):
+    _fields_ = [("n_velocity", C.c_int64), ("n_edge", C.c_int64), ("n_center", C.c_int64),
+                ("nnz", C.c_int64), ("raw_triplets", C.c_int64), ("stencil_ms", C.c_double),
+                ("guess_ms", C.c_double), ("system_ms", C.c_double), ("csr_ms", C.c_double)]
+
+
+_lib = None
+
+
+def load():
+    """Load libavs_hip.so; raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_float
+    L.avs_last_error.restype = C.c_char_p
+    L.avs_version.restype = C.c_char_p
+    L.avs_create.argtypes = [C.POINTER(Desc), C.POINTER(vp)]
+    L.avs_destroy.argtypes = [vp]
+    L.avs_destroy.restype = None
+    L.avs_set_labels.argtypes = [vp, i32, vp, i32]
+    L.avs_set_index_field.argtypes = [vp, i32, i32, i32, vp, i32]
+    L.avs_set_dof_counts.argtypes = [vp, i64, i64, i64]
+    L.avs_set_scalar_field.argtypes = [vp, i32, i32, vp, f32, i32]
+    L.avs_build_stencils.argtypes = [vp]
+    L.avs_build_initial_guess.argtypes = [vp]
+    L.avs_build_system.argtypes = [vp]
+    L.avs_assemble.argtypes = [vp, C.POINTER(AssemblyInfo)]
+    L.avs_solve.argtypes = [vp, f64, i32, C.POINTER(SolveInfo)]
+    L.avs_get_assembly_info.argtypes = [vp, C.POINTER(AssemblyInfo)]
+    L.avs_get_solution.argtypes = [vp, vp, i64, i32]
+    L.avs_get_initial_guess.argtypes = [vp, vp, i64, i32]
+    L.avs_get_csr.argtypes = [vp, vp, vp, vp, vp, i32]
+    L.avs_get_edge_stencils.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32]
+    L.avs_get_center_stencils.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32]
+    L.avs_pcg_csr.argtypes = [i64, vp, vp, vp, vp, vp, f64, i32, i32, i32, vp, C.POINTER(SolveInfo)]
+    L.avs_spmv_csr.argtypes = [i64, vp, vp, vp, vp, vp, i32, i32, vp]
+    L.avs_bench_spmv.argtypes = [vp, i32, i32, C.POINTER(f64)]
+    L.avs_dist_get_unique_id.argtypes = [vp]
+    L.avs_dist_init.argtypes = [vp, vp, i32, i32]
+    L.avs_dist_partition.argtypes = [vp]
+    L.avs_dist_solve.argtypes = [vp, f64, i32, C.POINTER(SolveInfo)]
+    L.avs_dist_get_solution.argtypes = [vp, vp, i64, i32]
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(L, name)
+        if name not in ("avs_last_error", "avs_version", "avs_destroy"):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != OK:
+        raise AvsError(status, load().avs_last_error().decode("utf-8", "replace"))
+
+
+def ptr_of(buf):
+    """(pointer, memspace) of a numpy array or a torch tensor (contiguous)."""
+    if buf is None:
+        return None, MEM_HOST
+    if isinstance(buf, np.ndarray):
+        if not buf.flags["C_CONTIGUOUS"]:
+            raise ValueError("numpy buffer must be C contiguous")
+        return buf.ctypes.data, MEM_HOST
+    # torch tensor
+    if not buf.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return buf.data_ptr(), (MEM_DEVICE if buf.is_cuda else MEM_HOST)

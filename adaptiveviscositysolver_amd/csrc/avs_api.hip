@@ -1,0 +1,504 @@
+// avs_api.hip -- the extern "C" surface declared in include/avs.h.
+// Context management, input upload, phase orchestration, read-back.  No kernels here.
+#include <cmath>
+#include <new>
+
+#include "avs_internal.hpp"
+
+namespace avs {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// phase drivers implemented in avs_assembly.hip
+avs_status build_dof_tables(avs_ctx *c);
+avs_status build_stencils(avs_ctx *c);
+avs_status build_initial_guess(avs_ctx *c);
+avs_status build_system(avs_ctx *c);
+
+static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+static void grid_res(const avs_desc &d, int kind /*0 face,1 edge,2 centre*/, int level, int axis, int r[3])
+{
+    r[0] = d.nx >> level;
+    r[1] = d.ny >> level;
+    r[2] = d.nz >> level;
+    if (kind == 0) r[axis] += 1;
+    else if (kind == 1) {
+        r[0] += (axis != 0);
+        r[1] += (axis != 1);
+        r[2] += (axis != 2);
+    }
+}
+static size_t vol3(const int r[3]) { return (size_t)r[0] * (size_t)r[1] * (size_t)r[2]; }
+
+struct Timer {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t s;
+    explicit Timer(hipStream_t st) : s(st)
+    {
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+    }
+    ~Timer()
+    {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+    void start() { (void)hipEventRecord(a, s); }
+    double stop()
+    {
+        (void)hipEventRecord(b, s);
+        (void)hipEventSynchronize(b);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, a, b);
+        return ms;
+    }
+};
+
+} // namespace avs
+
+using namespace avs;
+
+avs::PyramidView avs_ctx::view() const
+{
+    PyramidView P{};
+    P.levels = desc.levels;
+    P.n[0] = desc.nx;
+    P.n[1] = desc.ny;
+    P.n[2] = desc.nz;
+    P.enhanced = desc.use_enhanced_gradients;
+    P.dx = desc.dx;
+    P.dt = desc.dt;
+    for (int l = 0; l < AVS_MAX_LEVELS; ++l) {
+        P.labels[l] = labels[l].p;
+        P.cidx[l] = cidx[l].p;
+        for (int a = 0; a < 3; ++a) {
+            P.vidx[l][a] = vidx[l][a].p;
+            P.eidx[l][a] = eidx[l][a].p;
+        }
+    }
+    auto fv = [](const Field &f) { return FieldView{f.buf.p, f.cval, f.is_const ? 1 : 0}; };
+    P.centerw = fv(centerw);
+    P.visc = fv(visc);
+    P.dens = fv(dens);
+    for (int a = 0; a < 3; ++a) {
+        P.edgew[a] = fv(edgew[a]);
+        P.facew[a] = fv(facew[a]);
+        P.vel[a] = fv(vel[a]);
+        P.solidvel[a] = fv(solidvel[a]);
+    }
+    return P;
+}
+
+extern "C" {
+
+const char *avs_last_error(void) { return avs::g_err; }
+const char *avs_version(void) { return "avs-mi355x 0.1 (gfx950)"; }
+
+avs_status avs_create(const avs_desc *d, avs_ctx **out)
+{
+    AVS_REQUIRE(d && out, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(is_pow2(d->nx) && is_pow2(d->ny) && is_pow2(d->nz), AVS_EINVAL,
+                "base resolution must be a power of two per axis (got %d %d %d)", d->nx, d->ny, d->nz);
+    AVS_REQUIRE(d->levels >= 1 && d->levels <= AVS_MAX_LEVELS, AVS_EINVAL, "levels must be in [1, %d]", AVS_MAX_LEVELS);
+    AVS_REQUIRE((d->nx >> (d->levels - 1)) >= 1 && (d->ny >> (d->levels - 1)) >= 1 && (d->nz >> (d->levels - 1)) >= 1,
+                AVS_EINVAL, "too many levels for this resolution");
+    AVS_REQUIRE(d->dx > 0. && std::isfinite(d->dx) && std::isfinite(d->dt), AVS_EINVAL, "dx must be positive and finite");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    AVS_REQUIRE(e == hipSuccess && ndev > 0, AVS_EHIP, "no HIP device available (%s)", hipGetErrorString(e));
+    AVS_REQUIRE(d->device >= 0 && d->device < ndev, AVS_EINVAL, "device %d out of range (%d devices)", d->device, ndev);
+    AVS_HIP(hipSetDevice(d->device));
+    avs_ctx *c = new (std::nothrow) avs_ctx();
+    AVS_REQUIRE(c, AVS_ENOMEM, "out of host memory");
+    c->desc = *d;
+    if (d->stream) c->stream = reinterpret_cast<hipStream_t>(d->stream);
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete c;
+            set_error("hipStreamCreate failed");
+            return AVS_EHIP;
+        }
+        c->own_stream = true;
+    }
+    // defaults = what an absent Houdini field means in the synthetic harness
+    c->visc.cval = 1.f;
+    c->dens.cval = 1.f;
+    for (int a = 0; a < 3; ++a) c->facew[a].cval = 1.f;
+    *out = c;
+    return AVS_OK;
+}
+
+void avs_destroy(avs_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->desc.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    extern void avs_dist_release(avs_ctx *);
+    avs_dist_release(c);
+    pcg_destroy(c->pcg);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static void invalidate(avs_ctx *c, bool tables)
+{
+    if (tables) c->tables_ready = false;
+    c->stencils_ready = c->guess_ready = c->system_ready = c->solved = false;
+}
+
+avs_status avs_set_labels(avs_ctx *c, int32_t level, const int8_t *labels, avs_memspace where)
+{
+    AVS_REQUIRE(c && labels, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(level >= 0 && level < c->desc.levels, AVS_EINVAL, "level %d out of range", level);
+    AVS_HIP(hipSetDevice(c->desc.device));
+    int r[3];
+    grid_res(c->desc, 2, level, 0, r);
+    AVS_TRY(c->labels[level].alloc(vol3(r)));
+    AVS_HIP(copy_in(c->labels[level].p, labels, vol3(r), where, c->stream));
+    if (where == AVS_MEM_HOST) AVS_HIP(hipStreamSynchronize(c->stream));
+    c->have_labels[level] = true;
+    invalidate(c, false);
+    return AVS_OK;
+}
+
+avs_status avs_set_index_field(avs_ctx *c, avs_index_kind kind, int32_t level, int32_t axis, const int32_t *idx,
+                               avs_memspace where)
+{
+    AVS_REQUIRE(c && idx, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(level >= 0 && level < c->desc.levels, AVS_EINVAL, "level %d out of range", level);
+    AVS_REQUIRE(kind == AVS_INDEX_CENTER || (axis >= 0 && axis < 3), AVS_EINVAL, "axis %d out of range", axis);
+    AVS_HIP(hipSetDevice(c->desc.device));
+    int r[3];
+    DevBuf<int32_t> *buf;
+    bool *have;
+    switch (kind) {
+    case AVS_INDEX_VELOCITY: grid_res(c->desc, 0, level, axis, r); buf = &c->vidx[level][axis]; have = &c->have_vidx[level][axis]; break;
+    case AVS_INDEX_EDGE: grid_res(c->desc, 1, level, axis, r); buf = &c->eidx[level][axis]; have = &c->have_eidx[level][axis]; break;
+    case AVS_INDEX_CENTER: grid_res(c->desc, 2, level, 0, r); buf = &c->cidx[level]; have = &c->have_cidx[level]; break;
+    default: set_error("unknown index kind %d", (int)kind); return AVS_EINVAL;
+    }
+    AVS_TRY(buf->alloc(vol3(r)));
+    AVS_HIP(copy_in(buf->p, idx, vol3(r) * sizeof(int32_t), where, c->stream));
+    if (where == AVS_MEM_HOST) AVS_HIP(hipStreamSynchronize(c->stream));
+    *have = true;
+    invalidate(c, true);
+    return AVS_OK;
+}
+
+avs_status avs_set_dof_counts(avs_ctx *c, int64_t nv, int64_t ne, int64_t nc)
+{
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(nv >= 0 && ne >= 0 && nc >= 0 && nv < INT32_MAX && ne < INT32_MAX && nc < INT32_MAX / 3, AVS_EINVAL,
+                "DOF counts out of range");
+    c->n_vel = nv;
+    c->n_edge = ne;
+    c->n_center = nc;
+    invalidate(c, true);
+    return AVS_OK;
+}
+
+avs_status avs_set_scalar_field(avs_ctx *c, avs_field_kind kind, int32_t axis, const float *data, float constant,
+                                avs_memspace where)
+{
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    int r[3];
+    avs_ctx::Field *f = nullptr;
+    const bool vec = (kind == AVS_FIELD_EDGE_WEIGHTS || kind == AVS_FIELD_FACE_WEIGHTS || kind == AVS_FIELD_VELOCITY ||
+                      kind == AVS_FIELD_SOLID_VELOCITY);
+    AVS_REQUIRE(!vec || (axis >= 0 && axis < 3), AVS_EINVAL, "axis %d out of range", axis);
+    switch (kind) {
+    case AVS_FIELD_CENTER_WEIGHTS: grid_res(c->desc, 2, 0, 0, r); f = &c->centerw; break;
+    case AVS_FIELD_EDGE_WEIGHTS: grid_res(c->desc, 1, 0, axis, r); f = &c->edgew[axis]; break;
+    case AVS_FIELD_FACE_WEIGHTS: grid_res(c->desc, 0, 0, axis, r); f = &c->facew[axis]; break;
+    case AVS_FIELD_VISCOSITY: grid_res(c->desc, 2, 0, 0, r); f = &c->visc; break;
+    case AVS_FIELD_DENSITY: grid_res(c->desc, 2, 0, 0, r); f = &c->dens; break;
+    case AVS_FIELD_VELOCITY: grid_res(c->desc, 0, 0, axis, r); f = &c->vel[axis]; break;
+    case AVS_FIELD_SOLID_VELOCITY: grid_res(c->desc, 0, 0, axis, r); f = &c->solidvel[axis]; break;
+    default: set_error("unknown field kind %d", (int)kind); return AVS_EINVAL;
+    }
+    if (!data) {
+        f->buf.release();
+        f->is_const = true;
+        f->cval = constant;
+    } else {
+        AVS_TRY(f->buf.alloc(vol3(r)));
+        AVS_HIP(copy_in(f->buf.p, data, vol3(r) * sizeof(float), where, c->stream));
+        if (where == AVS_MEM_HOST) AVS_HIP(hipStreamSynchronize(c->stream));
+        f->is_const = false;
+    }
+    invalidate(c, false);
+    return AVS_OK;
+}
+
+avs_status avs_build_stencils(avs_ctx *c)
+{
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    return build_stencils(c);
+}
+avs_status avs_build_initial_guess(avs_ctx *c)
+{
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    return build_initial_guess(c);
+}
+avs_status avs_build_system(avs_ctx *c)
+{
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    return build_system(c);
+}
+
+avs_status avs_assemble(avs_ctx *c, avs_assembly_info *info)
+{
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    Timer t(c->stream);
+    t.start();
+    AVS_TRY(build_stencils(c)); // includes the dof tables
+    c->ainfo.stencil_ms = t.stop();
+    t.start();
+    AVS_TRY(build_initial_guess(c));
+    c->ainfo.guess_ms = t.stop();
+    t.start();
+    AVS_TRY(build_system(c));
+    c->ainfo.system_ms = t.stop();
+    c->ainfo.csr_ms = 0.;
+    c->ainfo.n_velocity = c->n_vel;
+    c->ainfo.n_edge = c->n_edge;
+    c->ainfo.n_center = c->n_center;
+    c->ainfo.nnz = c->nnz;
+    c->ainfo.raw_triplets = c->nraw;
+    if (info) *info = c->ainfo;
+    return AVS_OK;
+}
+
+avs_status avs_get_assembly_info(avs_ctx *c, avs_assembly_info *info)
+{
+    AVS_REQUIRE(c && info, AVS_EINVAL, "null argument");
+    c->ainfo.n_velocity = c->n_vel;
+    c->ainfo.n_edge = c->n_edge;
+    c->ainfo.n_center = c->n_center;
+    c->ainfo.nnz = c->nnz;
+    c->ainfo.raw_triplets = c->nraw;
+    *info = c->ainfo;
+    return AVS_OK;
+}
+
+static CsrView csr_of(avs_ctx *c)
+{
+    CsrView A;
+    A.n = c->n_vel;
+    A.nnz = c->nnz;
+    A.row_ptr = c->row_ptr.p;
+    A.col = c->col.p;
+    A.val = c->val.p;
+    return A;
+}
+
+avs_status avs_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_info *info)
+{
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->system_ready, AVS_ESTATE, "avs_assemble must succeed before avs_solve");
+    AVS_REQUIRE(tol >= 0. && max_iters >= 0, AVS_EINVAL, "tolerance / max_iterations out of range");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    const int64_t n = c->n_vel;
+    if (c->pcg == nullptr) AVS_TRY(pcg_create(&c->pcg, n, n, c->stream));
+    AVS_TRY(c->x.alloc((size_t)n));
+    // solveWithGuess(rhs, viscositySolution): warm start from the restricted velocity (cpp:627)
+    AVS_HIP(hipMemcpyAsync(c->x.p, c->x0.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    avs_solve_info local{};
+    AVS_TRY(pcg_solve(c->pcg, csr_of(c), c->rhs.p, c->x.p, tol, max_iters, c->stream, &local, nullptr));
+    if (info) *info = local;
+    c->solved = true;
+    return AVS_OK;
+}
+
+static avs_status get_vec(avs_ctx *c, const double *src, int64_t have, double *dst, int64_t n, avs_memspace where)
+{
+    AVS_REQUIRE(dst, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(n == have, AVS_EINVAL, "vector length mismatch: caller passed %lld, system has %lld", (long long)n, (long long)have);
+    AVS_HIP(hipSetDevice(c->desc.device));
+    AVS_HIP(copy_out(dst, src, (size_t)n * sizeof(double), where, c->stream));
+    AVS_HIP(hipStreamSynchronize(c->stream));
+    return AVS_OK;
+}
+
+avs_status avs_get_solution(avs_ctx *c, double *x, int64_t n, avs_memspace where)
+{
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->solved, AVS_ESTATE, "no solution: call avs_solve first");
+    return get_vec(c, c->x.p, c->n_vel, x, n, where);
+}
+
+avs_status avs_get_initial_guess(avs_ctx *c, double *x0, int64_t n, avs_memspace where)
+{
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->guess_ready, AVS_ESTATE, "no initial guess: call avs_build_initial_guess / avs_assemble first");
+    return get_vec(c, c->x0.p, c->n_vel, x0, n, where);
+}
+
+avs_status avs_get_csr(avs_ctx *c, int32_t *row_ptr, int32_t *col, double *val, double *rhs, avs_memspace where)
+{
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->system_ready, AVS_ESTATE, "no system: call avs_assemble first");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    hipStream_t s = c->stream;
+    if (row_ptr) AVS_HIP(copy_out(row_ptr, c->row_ptr.p, ((size_t)c->n_vel + 1) * sizeof(int32_t), where, s));
+    if (col) AVS_HIP(copy_out(col, c->col.p, (size_t)c->nnz * sizeof(int32_t), where, s));
+    if (val) AVS_HIP(copy_out(val, c->val.p, (size_t)c->nnz * sizeof(double), where, s));
+    if (rhs) AVS_HIP(copy_out(rhs, c->rhs.p, (size_t)c->n_vel * sizeof(double), where, s));
+    AVS_HIP(hipStreamSynchronize(s));
+    return AVS_OK;
+}
+
+static avs_status get_stencils(avs_ctx *c, bool edge, int32_t *cnt, int32_t *idx, double *coef, int32_t *bcnt,
+                               double *bval, double *weight, avs_memspace where)
+{
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->stencils_ready, AVS_ESTATE, "no stencils: call avs_build_stencils / avs_assemble first");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    hipStream_t s = c->stream;
+    const size_t ns = edge ? (size_t)c->n_edge : (size_t)c->n_center * 3;
+    const size_t nw = edge ? (size_t)c->n_edge : (size_t)c->n_center;
+    const size_t cap = edge ? AVS_EDGE_STENCIL_CAP : AVS_CENTER_STENCIL_CAP;
+    const size_t bcap = edge ? AVS_EDGE_BOUNDARY_CAP : AVS_CENTER_BOUNDARY_CAP;
+    if (cnt) AVS_HIP(copy_out(cnt, edge ? c->e_cnt.p : c->c_cnt.p, ns * sizeof(int32_t), where, s));
+    if (idx) AVS_HIP(copy_out(idx, edge ? c->e_idx.p : c->c_idx.p, ns * cap * sizeof(int32_t), where, s));
+    if (coef) AVS_HIP(copy_out(coef, edge ? c->e_coef.p : c->c_coef.p, ns * cap * sizeof(double), where, s));
+    if (bcnt) AVS_HIP(copy_out(bcnt, edge ? c->e_bcnt.p : c->c_bcnt.p, ns * sizeof(int32_t), where, s));
+    if (bval) AVS_HIP(copy_out(bval, edge ? c->e_bval.p : c->c_bval.p, ns * bcap * sizeof(double), where, s));
+    if (weight) AVS_HIP(copy_out(weight, edge ? c->e_w.p : c->c_w.p, nw * sizeof(double), where, s));
+    AVS_HIP(hipStreamSynchronize(s));
+    return AVS_OK;
+}
+
+avs_status avs_get_edge_stencils(avs_ctx *c, int32_t *cnt, int32_t *idx, double *coef, int32_t *bcnt, double *bval,
+                                 double *weight, avs_memspace where)
+{
+    return get_stencils(c, true, cnt, idx, coef, bcnt, bval, weight, where);
+}
+avs_status avs_get_center_stencils(avs_ctx *c, int32_t *cnt, int32_t *idx, double *coef, int32_t *bcnt, double *bval,
+                                   double *weight, avs_memspace where)
+{
+    return get_stencils(c, false, cnt, idx, coef, bcnt, bval, weight, where);
+}
+
+// ---------------------------------------------------------------------------------------------
+// seam A: solve only
+// ---------------------------------------------------------------------------------------------
+avs_status avs_pcg_csr(int64_t n, const int32_t *row_ptr, const int32_t *col, const double *val, const double *b,
+                       double *x, double tol, int32_t max_iters, avs_memspace where, int32_t device, void *stream,
+                       avs_solve_info *info)
+{
+    AVS_REQUIRE(n >= 0 && row_ptr && b && x && (n == 0 || (col && val)), AVS_EINVAL, "null argument");
+    AVS_REQUIRE(tol >= 0. && max_iters >= 0, AVS_EINVAL, "tolerance / max_iterations out of range");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    AVS_REQUIRE(e == hipSuccess && ndev > 0, AVS_EHIP, "no HIP device available (%s)", hipGetErrorString(e));
+    AVS_REQUIRE(device >= 0 && device < ndev, AVS_EINVAL, "device %d out of range", device);
+    AVS_HIP(hipSetDevice(device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    bool own = false;
+    if (!s) {
+        AVS_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        own = true;
+    }
+    avs_status rc = AVS_OK;
+    PcgWork *w = nullptr;
+    {
+        DevBuf<int32_t> d_rp, d_col;
+        DevBuf<double> d_val, d_b, d_x;
+        CsrView A;
+        A.n = n;
+        const double *bp = b;
+        double *xp = x;
+        int32_t nnz = 0;
+        do {
+            if (where == AVS_MEM_HOST) {
+                nnz = row_ptr[n];
+                if ((rc = d_rp.alloc((size_t)n + 1)) || (rc = d_col.alloc((size_t)nnz)) || (rc = d_val.alloc((size_t)nnz)) ||
+                    (rc = d_b.alloc((size_t)n)) || (rc = d_x.alloc((size_t)n)))
+                    break;
+                if (hipMemcpyAsync(d_rp.p, row_ptr, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+                    hipMemcpyAsync(d_col.p, col, (size_t)nnz * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+                    hipMemcpyAsync(d_val.p, val, (size_t)nnz * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+                    hipMemcpyAsync(d_b.p, b, (size_t)n * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+                    hipMemcpyAsync(d_x.p, x, (size_t)n * 8, hipMemcpyHostToDevice, s) != hipSuccess) {
+                    set_error("host -> device copy failed");
+                    rc = AVS_EHIP;
+                    break;
+                }
+                A.row_ptr = d_rp.p; A.col = d_col.p; A.val = d_val.p;
+                bp = d_b.p; xp = d_x.p;
+            } else {
+                if (hipMemcpyAsync(&nnz, row_ptr + n, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                    hipStreamSynchronize(s) != hipSuccess) {
+                    set_error("device -> host copy failed");
+                    rc = AVS_EHIP;
+                    break;
+                }
+                A.row_ptr = row_ptr; A.col = col; A.val = val;
+            }
+            A.nnz = nnz;
+            if ((rc = pcg_create(&w, n, n, s))) break;
+            if ((rc = pcg_solve(w, A, bp, xp, tol, max_iters, s, info, nullptr))) break;
+            if (where == AVS_MEM_HOST) {
+                if (hipMemcpyAsync(x, xp, (size_t)n * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                    hipStreamSynchronize(s) != hipSuccess) {
+                    set_error("device -> host copy failed");
+                    rc = AVS_EHIP;
+                }
+            }
+        } while (0);
+        (void)hipStreamSynchronize(s);
+    }
+    pcg_destroy(w);
+    if (own) (void)hipStreamDestroy(s);
+    return rc;
+}
+
+avs_status avs_spmv_csr(int64_t n, const int32_t *row_ptr, const int32_t *col, const double *val, const double *x,
+                        double *y, int32_t variant, int32_t repeats, void *stream)
+{
+    AVS_REQUIRE(n >= 0 && row_ptr && x && y, AVS_EINVAL, "null argument");
+    CsrView A;
+    A.n = n;
+    A.nnz = 0;
+    A.row_ptr = row_ptr;
+    A.col = col;
+    A.val = val;
+    for (int i = 0; i < (repeats > 0 ? repeats : 1); ++i)
+        AVS_TRY(spmv_launch(A, x, y, variant, reinterpret_cast<hipStream_t>(stream)));
+    return AVS_OK;
+}
+
+avs_status avs_bench_spmv(avs_ctx *c, int32_t variant, int32_t repeats, double *ms_per_launch)
+{
+    AVS_REQUIRE(c && ms_per_launch, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->system_ready, AVS_ESTATE, "no system: call avs_assemble first");
+    AVS_REQUIRE(repeats > 0, AVS_EINVAL, "repeats must be positive");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    const int64_t n = c->n_vel;
+    DevBuf<double> y;
+    AVS_TRY(y.alloc((size_t)n));
+    CsrView A = csr_of(c);
+    Timer t(c->stream);
+    AVS_TRY(spmv_launch(A, c->x0.p, y.p, variant, c->stream)); // warm-up
+    t.start();
+    for (int i = 0; i < repeats; ++i) AVS_TRY(spmv_launch(A, c->x0.p, y.p, variant, c->stream));
+    *ms_per_launch = t.stop() / repeats;
+    return AVS_OK;
+}
+
+} // extern "C"

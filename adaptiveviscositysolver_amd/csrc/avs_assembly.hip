@@ -1,0 +1,913 @@
+// avs_assembly.hip -- on-device assembly of the variational viscosity system over the octree.
+//
+// Replaces cpp:418-594 + Eigen's setFromTriplets (cpp:613-614) of the reference
+// (HDK_AdaptiveViscosity.cpp).  The reference sweeps every voxel of every (level, axis) grid and
+// chases nested heap lists; here every kernel is launched per DOF / per stress through
+// "dof -> (level, axis, i, j, k)" tables, so lanes are never idle on empty voxels and global ids
+// keep the reference's tile-major order (neighbouring lanes touch neighbouring voxels).
+//
+//   K0  k_dof_table        index grids -> dof tables (+ max id validation)
+//   K1  k_edge_stencils    getEdgeStressFaces + edgeOctreeVolumes + weights   cpp:1717-1908, 2004-2160
+//   K2  k_center_stencils  getCenterStressFaces + weights                    cpp:1910-1963, 2162-2289
+//   K3  k_initial_guess    buildVelocityMappingPartial                       cpp:2291-2402
+//   K4  k_rows<false>      dry run of the row sweep: raw triplets per row    cpp:2459-2777
+//   K5  exclusive scan     wave64 shuffle scan -> raw offsets / row pointers
+//   K6  k_rows<true>       row sweep; every row is kept sorted and duplicate-free while it is
+//                          emitted (insert-or-add, left fold in emission order = exactly what
+//                          setFromTriplets does for one (row, col))          cpp:2404-2457, 613-614
+//   K7  k_compact          rows -> final CSR, coalesced 16-lane copies
+//
+// Rows are independent (a gather): no atomics anywhere.  All arithmetic is done in the reference's
+// order with one rounding per operation (compile with -ffp-contract=off), so the CSR values, the
+// right-hand side and the initial guess are bit-identical to the CPU oracle.
+#include "avs_internal.hpp"
+
+namespace avs {
+
+static constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------------------------
+// lattice helpers (device)
+// ---------------------------------------------------------------------------------------------
+struct I3 {
+    int v[3];
+    __device__ __forceinline__ int &operator[](int a) { return v[a]; }
+    __device__ __forceinline__ const int &operator[](int a) const { return v[a]; }
+};
+
+__device__ __forceinline__ I3 cell_res(const PyramidView &P, int l)
+{
+    return I3{{P.n[0] >> l, P.n[1] >> l, P.n[2] >> l}};
+}
+__device__ __forceinline__ I3 face_res(const PyramidView &P, int l, int a)
+{
+    I3 r = cell_res(P, l);
+    r[a] += 1;
+    return r;
+}
+__device__ __forceinline__ I3 edge_res(const PyramidView &P, int l, int a)
+{
+    I3 r = cell_res(P, l);
+    r[0] += (a != 0);
+    r[1] += (a != 1);
+    r[2] += (a != 2);
+    return r;
+}
+__device__ __forceinline__ size_t lin(const I3 &r, const I3 &p)
+{
+    return (size_t)p[0] + (size_t)r[0] * ((size_t)p[1] + (size_t)r[1] * (size_t)p[2]);
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ float lerp32(float a, float b, float t)
+{
+    const float s = 1.0f - t;
+    const float pa = a * s;
+    const float pb = b * t;
+    return pa + pb;
+}
+
+// SIM_RawField::getValue restated in exact index space: P2 = position in half fine cells,
+// off2[a] = 1 where the lattice is cell-centred along a.  fp32, x then y then z.
+__device__ float sample_f32(const FieldView &F, const I3 &r, const I3 &off2, const I3 &P2)
+{
+    if (F.is_const) return F.cval;
+    int i0[3], i1[3];
+    float t[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int q2 = P2[a] - off2[a];
+        const int fl = q2 >> 1;
+        t[a] = (q2 & 1) ? 0.5f : 0.0f;
+        i0[a] = clampi(fl, 0, r[a] - 1);
+        i1[a] = clampi(fl + 1, 0, r[a] - 1);
+    }
+    const float *d = F.data;
+    const size_t sx = 1, sy = (size_t)r[0], sz = (size_t)r[0] * (size_t)r[1];
+    const float c00 = lerp32(d[i0[0] * sx + i0[1] * sy + i0[2] * sz], d[i1[0] * sx + i0[1] * sy + i0[2] * sz], t[0]);
+    const float c10 = lerp32(d[i0[0] * sx + i1[1] * sy + i0[2] * sz], d[i1[0] * sx + i1[1] * sy + i0[2] * sz], t[0]);
+    const float c01 = lerp32(d[i0[0] * sx + i0[1] * sy + i1[2] * sz], d[i1[0] * sx + i0[1] * sy + i1[2] * sz], t[0]);
+    const float c11 = lerp32(d[i0[0] * sx + i1[1] * sy + i1[2] * sz], d[i1[0] * sx + i1[1] * sy + i1[2] * sz], t[0]);
+    const float c0 = lerp32(c00, c10, t[1]);
+    const float c1 = lerp32(c01, c11, t[1]);
+    return lerp32(c0, c1, t[2]);
+}
+
+__device__ __forceinline__ float field_at(const FieldView &F, const I3 &r, const I3 &p)
+{
+    return F.is_const ? F.cval : F.data[lin(r, p)];
+}
+
+__device__ __forceinline__ I3 pos2_center(int l, const I3 &p)
+{
+    return I3{{(2 * p[0] + 1) << l, (2 * p[1] + 1) << l, (2 * p[2] + 1) << l}};
+}
+__device__ __forceinline__ I3 pos2_face(int l, int axis, const I3 &p)
+{
+    I3 o;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) o[a] = (a == axis) ? ((2 * p[a]) << l) : ((2 * p[a] + 1) << l);
+    return o;
+}
+__device__ __forceinline__ I3 pos2_edge(int l, int axis, const I3 &p)
+{
+    I3 o;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) o[a] = (a == axis) ? ((2 * p[a] + 1) << l) : ((2 * p[a]) << l);
+    return o;
+}
+__device__ __forceinline__ I3 off_face(int a) { return I3{{a != 0, a != 1, a != 2}}; }
+
+__device__ __forceinline__ int32_t vidx_at(const PyramidView &P, int l, int a, const I3 &f)
+{
+    return P.vidx[l][a][lin(face_res(P, l, a), f)];
+}
+__device__ __forceinline__ int32_t eidx_at(const PyramidView &P, int l, int a, const I3 &e)
+{
+    return P.eidx[l][a][lin(edge_res(P, l, a), e)];
+}
+__device__ __forceinline__ int label_at(const PyramidView &P, int l, const I3 &c)
+{
+    return P.labels[l][lin(cell_res(P, l), c)];
+}
+
+// oct.h:94-106 / 108-117 / 126-142
+__device__ __forceinline__ I3 child_face(const I3 &f, int axis, int ci)
+{
+    I3 o{{2 * f[0], 2 * f[1], 2 * f[2]}};
+    if (ci & 1) ++o[(axis + 1) % 3];
+    if (ci & 2) ++o[(axis + 2) % 3];
+    return o;
+}
+__device__ __forceinline__ I3 half3(const I3 &f) { return I3{{f[0] / 2, f[1] / 2, f[2] / 2}}; }
+
+// ---------------------------------------------------------------------------------------------
+// K0: dof tables
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_dof_table(const int32_t *__restrict__ grid, I3 r, int level, int axis,
+                                                      int32_t *__restrict__ table, int64_t ndof, int *err)
+{
+    const size_t total = (size_t)r[0] * r[1] * r[2];
+    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+        const int32_t id = grid[o];
+        if (id >= 0) {
+            if ((int64_t)id >= ndof) { *err = 1; continue; }
+            const int i = (int)(o % r[0]);
+            const size_t q = o / r[0];
+            const int j = (int)(q % r[1]);
+            const int k = (int)(q / r[1]);
+            int4 rec = make_int4(level | (axis << 8), i, j, k);
+            reinterpret_cast<int4 *>(table)[id] = rec;
+        } else if (id < AVS_OUTSIDE) *err = 2;
+    }
+}
+
+// every dof id in [0, n) must have been written exactly once: table is pre-filled with -1
+__global__ __launch_bounds__(kBlock) void k_check_table(const int32_t *__restrict__ table, int64_t ndof, int *err)
+{
+    for (int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x; d < ndof; d += (int64_t)gridDim.x * kBlock)
+        if (table[4 * d] < 0) *err = 3;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: edge stress stencils
+// ---------------------------------------------------------------------------------------------
+struct StencilWriter {
+    int32_t *idx;
+    double *coef;
+    int64_t stride; // = number of stencils
+    int64_t s;      // stencil id
+    int cap, cnt, overflow;
+    __device__ __forceinline__ void push(int32_t id, double c)
+    {
+        if (cnt < cap) {
+            idx[(size_t)cnt * stride + s] = id;
+            coef[(size_t)cnt * stride + s] = c;
+            ++cnt;
+        } else overflow = 1;
+    }
+};
+
+__global__ __launch_bounds__(kBlock) void k_edge_stencils(PyramidView P, const int32_t *__restrict__ edof,
+                                                          StencilView S, int *err)
+{
+    const int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (id >= S.count) return;
+    const int4 rec = reinterpret_cast<const int4 *>(edof)[id];
+    const int level = rec.x & 0xff, axis = rec.x >> 8;
+    const I3 edge{{rec.y, rec.z, rec.w}};
+    const double dx = P.dx * (double)(1 << level); // cpp:1733
+    const double vdx0 = (double)(1 << level);      // cpp:2014 (fine-voxel units)
+
+    // pass 1 (cpp:1740-1787) fused with edgeOctreeVolumes (cpp:2019-2054): both classify the same
+    // four faces.  UT_Vector3 accumulators are fp32 in the reference.
+    bool atTransition[3] = {false, false, false}, faceOutside[3] = {false, false, false};
+    float gdx[3] = {0.f, 0.f, 0.f};
+    float vdx[3] = {0.f, 0.f, 0.f};
+    vdx[axis] = (float)vdx0;
+    int32_t fidx[3][2]; // velocity index of the 4 slots, [faceAxis][direction]; INT32_MIN = out of bounds
+#pragma unroll
+    for (int fa = 0; fa < 3; ++fa) {
+        if (fa == axis) continue;
+        const int ga = 3 - fa - axis;
+        const I3 fr = face_res(P, level, fa);
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            I3 face = edge;
+            if (dir == 0) --face[ga]; // HDKedgeToFace, util.h:151-167
+            int32_t vi;
+            if (face[ga] < 0 || face[ga] >= fr[ga]) {
+                vi = INT32_MIN;
+                gdx[ga] = (float)((double)gdx[ga] + .5 * dx);
+                vdx[ga] = (float)((double)vdx[ga] + .5 * vdx0);
+                faceOutside[ga] = true;
+            } else {
+                vi = P.vidx[level][fa][lin(fr, face)];
+                if (vi >= 0) {
+                    gdx[ga] = (float)((double)gdx[ga] + .5 * dx);
+                    vdx[ga] = (float)((double)vdx[ga] + .5 * vdx0);
+                } else if (vi == AVS_OUTSIDE || vi == AVS_SOLIDBOUNDARY) {
+                    gdx[ga] = (float)((double)gdx[ga] + .5 * dx);
+                    vdx[ga] = (float)((double)vdx[ga] + .5 * vdx0);
+                    faceOutside[ga] = true;
+                } else {
+                    gdx[ga] = (float)((double)gdx[ga] + dx);
+                    vdx[ga] = (float)((double)vdx[ga] + vdx0);
+                    if (P.enhanced) atTransition[ga] = true;
+                }
+            }
+            fidx[fa][dir] = vi;
+        }
+    }
+
+    StencilWriter w{S.idx, S.coef, S.count, id, AVS_EDGE_STENCIL_CAP, 0, 0};
+    int bcnt = 0;
+    int bad = 0;
+    // pass 2 (cpp:1789-1907)
+#pragma unroll
+    for (int fa = 0; fa < 3; ++fa) {
+        if (fa == axis) continue;
+        const int ga = 3 - fa - axis;
+        const I3 fr = face_res(P, level, fa);
+        const double g = (double)gdx[ga];
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            const int32_t vi = fidx[fa][dir];
+            if (vi == INT32_MIN) continue;
+            I3 face = edge;
+            if (dir == 0) --face[ga];
+            const double sign = (dir == 0) ? -1. : 1.;
+            if (vi >= 0) {
+                if (atTransition[ga] && !faceOutside[ga]) { // cpp:1814-1824
+                    I3 sib = face;
+                    sib[axis] += (edge[axis] % 2 == 0) ? 1 : -1;
+                    const int32_t si = P.vidx[level][fa][lin(fr, sib)];
+                    if (si < 0) bad = 1; // assert cpp:1820
+                    w.push(si, .25 * sign / g);
+                    w.push(vi, .25 * sign / g);
+                } else w.push(vi, .5 * sign / g); // cpp:1827
+            } else if (vi == AVS_UNASSIGNED) {
+                if (level + 1 >= P.levels) { bad = 1; continue; }
+                if (edge[fa] % 2 != 0) { // dangling edge inside a coarse cell, cpp:1835-1884
+#pragma unroll
+                    for (int oi = 0; oi < 2; ++oi) {
+                        I3 of = face;
+                        of[fa] += oi == 0 ? -1 : 1;
+                        const I3 pf = half3(of);
+                        const int32_t pi = vidx_at(P, level + 1, fa, pf);
+                        if (pi >= 0) w.push(pi, .25 * sign / g);
+                        else if (pi == AVS_UNASSIGNED) {
+                            for (int ci = 0; ci < 4; ++ci) {
+                                const I3 cf = child_face(pf, fa, ci);
+                                const int32_t cvi = P.vidx[level][fa][lin(fr, cf)];
+                                if (cvi >= 0) w.push(cvi, .0625 * sign / g);
+                                else bad = 1; // assert(false) cpp:1878
+                            }
+                        }
+                    }
+                } else { // cpp:1886-1894
+                    const int32_t pi = vidx_at(P, level + 1, fa, half3(face));
+                    if (pi < 0) bad = 1;
+                    w.push(pi, .5 * sign / g);
+                }
+            } else if (vi == AVS_SOLIDBOUNDARY) { // cpp:1896-1905 (component = EDGE axis: reference quirk)
+                const double lv = (double)sample_f32(P.solidvel[axis], face_res(P, 0, axis), off_face(axis),
+                                                     pos2_face(level, fa, face));
+                if (bcnt < AVS_EDGE_BOUNDARY_CAP) S.bval[(size_t)bcnt++ * S.count + id] = .5 * sign * lv / g;
+            }
+        }
+    }
+    S.cnt[id] = w.cnt;
+    S.bcnt[id] = bcnt;
+
+    // weight, cpp:2124-2155
+    float vol = vdx[0] * vdx[1];
+    vol = vol * vdx[2];
+    double wgt;
+    if (level == 0) {
+        wgt = (double)field_at(P.edgew[axis], edge_res(P, 0, axis), edge);
+        if (wgt == 1.) wgt = (double)vol;
+    } else wgt = (double)vol;
+    if (P.visc.is_const) wgt *= (double)P.visc.cval;
+    else wgt *= (double)sample_f32(P.visc, cell_res(P, 0), I3{{1, 1, 1}}, pos2_edge(level, axis, edge));
+    S.weight[id] = 4. * P.dt * wgt;
+    if (w.overflow || bad) *err = w.overflow ? 4 : 5;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: centre stress stencils (3 lists per active cell) + weight
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_center_stencils(PyramidView P, const int32_t *__restrict__ cdof,
+                                                            StencilView S, int *err)
+{
+    const int64_t nc = S.count / 3;
+    const int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (id >= nc) return;
+    const int4 rec = reinterpret_cast<const int4 *>(cdof)[id];
+    const int level = rec.x & 0xff;
+    const I3 cell{{rec.y, rec.z, rec.w}};
+    const double dx = P.dx * (double)(1 << level); // cpp:1923
+    int bad = 0;
+#pragma unroll
+    for (int axis = 0; axis < 3; ++axis) {
+        const int64_t sid = id + nc * axis; // cpp:2186, 2207
+        StencilWriter w{S.idx, S.coef, S.count, sid, AVS_CENTER_STENCIL_CAP, 0, 0};
+        int bcnt = 0;
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            I3 face = cell;
+            if (dir == 1) ++face[axis];
+            const double sign = (dir == 0) ? -1. : 1.;
+            const int32_t vi = vidx_at(P, level, axis, face);
+            if (vi >= 0) w.push(vi, sign / dx);
+            else if (vi == AVS_UNASSIGNED) { // cpp:1937-1951
+                if (level == 0) { bad = 1; continue; }
+                for (int ci = 0; ci < 4; ++ci) {
+                    const int32_t cvi = vidx_at(P, level - 1, axis, child_face(face, axis, ci));
+                    if (cvi < 0) bad = 1;
+                    w.push(cvi, .25 * sign / dx);
+                }
+            } else if (vi == AVS_SOLIDBOUNDARY) { // cpp:1952-1961
+                const double lv = (double)sample_f32(P.solidvel[axis], face_res(P, 0, axis), off_face(axis),
+                                                     pos2_face(level, axis, face));
+                if (bcnt < AVS_CENTER_BOUNDARY_CAP) S.bval[(size_t)bcnt++ * S.count + sid] = sign * lv / dx;
+            }
+        }
+        S.cnt[sid] = w.cnt;
+        S.bcnt[sid] = bcnt;
+        if (w.overflow) bad = 1;
+    }
+    double wgt;
+    if (level == 0) wgt = (double)field_at(P.centerw, cell_res(P, 0), cell); // cpp:2271-2272
+    else {
+        const double d = (double)(1 << level);
+        wgt = d * d * d;
+    }
+    if (P.visc.is_const) wgt *= (double)P.visc.cval;
+    else wgt *= (double)sample_f32(P.visc, cell_res(P, 0), I3{{1, 1, 1}}, pos2_center(level, cell));
+    S.weight[id] = 2. * P.dt * wgt; // cpp:2284
+    if (bad) *err = 6;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: initial guess = restriction of the regular-grid face velocity (cpp:2291-2402).
+// The reference pops a FIFO queue of (face, weight, level); the leaves come out in lexicographic
+// (child, in-axis offset) order per level, which is the order of the mixed-radix counter below.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_initial_guess(PyramidView P, const int32_t *__restrict__ vdof, int64_t n,
+                                                          double *__restrict__ x0)
+{
+    const int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (id >= n) return;
+    const int4 rec = reinterpret_cast<const int4 *>(vdof)[id];
+    const int level = rec.x & 0xff, axis = rec.x >> 8;
+    const I3 face{{rec.y, rec.z, rec.w}};
+    const I3 vr = face_res(P, 0, axis);
+    const FieldView &V = P.vel[axis];
+    if (level == 0) {
+        x0[id] = 1.0 * (double)field_at(V, vr, face); // weight 1 (cpp:2347, 2373)
+        return;
+    }
+    const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+    int64_t leaves = 1;
+    for (int l = 0; l < level; ++l) leaves *= 12;
+    double acc = 0.;
+    for (int64_t code = 0; code < leaves; ++code) {
+        // digits, most significant first: (child, offset) of the step from level -> level-1, ...
+        I3 f = face;
+        float wgt = 1.f;
+        int64_t div = leaves;
+        for (int l = 0; l < level; ++l) {
+            div /= 12;
+            const int digit = (int)((code / div) % 12);
+            const int ci = digit / 3, off = digit % 3 - 1;
+            f[0] *= 2; f[1] *= 2; f[2] *= 2;
+            if (ci & 1) ++f[a1];
+            if (ci & 2) ++f[a2];
+            f[axis] += off;
+            const double rw = (off == 0) ? (1. / 8.) : (1. / 16.); // cpp:2323
+            wgt = (float)(rw * (double)wgt);                       // fpreal32 myWeight, cpp:2318
+        }
+        I3 fc{{clampi(f[0], 0, vr[0] - 1), clampi(f[1], 0, vr[1] - 1), clampi(f[2], 0, vr[2] - 1)}};
+        acc += (double)wgt * (double)field_at(V, vr, fc);
+    }
+    x0[id] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4 / K6: the row sweep
+// ---------------------------------------------------------------------------------------------
+struct RowAcc {
+    int n;          // EMIT: unique entries so far; dry run: raw entries
+    int32_t *col;   // row storage (sorted, unique) in the raw arrays
+    double *val;
+    double diag, rhs;
+    int bad;
+};
+
+template <bool EMIT>
+__device__ __forceinline__ void row_push(RowAcc &ra, int32_t c, double v)
+{
+    if (!EMIT) {
+        ++ra.n;
+        return;
+    }
+    int j = ra.n - 1;
+    while (j >= 0 && ra.col[j] > c) --j;
+    if (j >= 0 && ra.col[j] == c) { // duplicate: left fold in emission order (setFromTriplets)
+        ra.val[j] = ra.val[j] + v;
+        return;
+    }
+    for (int m = ra.n - 1; m > j; --m) {
+        ra.col[m + 1] = ra.col[m];
+        ra.val[m + 1] = ra.val[m];
+    }
+    ra.col[j + 1] = c;
+    ra.val[j + 1] = v;
+    ++ra.n;
+}
+
+// applyToMatrix, cpp:2404-2457
+template <bool EMIT>
+__device__ void apply_stencil(RowAcc &ra, double coefficient, int32_t vi, int cnt, const int32_t *__restrict__ idx,
+                              const double *__restrict__ coef, int64_t stride, int bcnt,
+                              const double *__restrict__ bval)
+{
+    bool found = false;
+    for (int i = 0; i < cnt; ++i)
+        if (idx[(size_t)i * stride] == vi) {
+            coefficient *= coef[(size_t)i * stride];
+            found = true;
+            break;
+        }
+    if (!found) ra.bad = 1; // assert(foundSelf) cpp:2436
+    for (int i = 0; i < cnt; ++i) {
+        const int32_t j = idx[(size_t)i * stride];
+        if (EMIT) {
+            const double element = coefficient * coef[(size_t)i * stride];
+            if (j == vi) ra.diag += element;
+            else row_push<true>(ra, j, element);
+        } else if (j != vi) ++ra.n;
+    }
+    if (EMIT)
+        for (int i = 0; i < bcnt; ++i) ra.rhs -= coefficient * bval[(size_t)i * stride];
+}
+
+template <bool EMIT>
+__device__ __forceinline__ void apply_edge(RowAcc &ra, int32_t vi, int32_t eid, const StencilView &E)
+{
+    apply_stencil<EMIT>(ra, EMIT ? E.weight[eid] : 0., vi, E.cnt[eid], E.idx + eid, E.coef + eid, E.count,
+                        E.bcnt[eid], E.bval + eid);
+}
+template <bool EMIT>
+__device__ __forceinline__ void apply_center(RowAcc &ra, int32_t vi, int32_t cid, int axis, const StencilView &C)
+{
+    const int64_t nc = C.count / 3;
+    const int64_t sid = cid + nc * axis;
+    apply_stencil<EMIT>(ra, EMIT ? C.weight[cid] : 0., vi, C.cnt[sid], C.idx + sid, C.coef + sid, C.count,
+                        C.bcnt[sid], C.bval + sid);
+}
+
+// faceOctreeVolumes, cpp:1965-2002
+__device__ double face_octree_volume(const PyramidView &P, int level, int axis, const I3 &face, int &bad)
+{
+    const I3 cr = cell_res(P, level);
+    const double dx = (double)(1 << level);
+    double g = 0.;
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+        I3 cell = face;
+        if (dir == 0) --cell[axis];
+        if (cell[axis] < 0 || cell[axis] >= cr[axis]) g += .5 * dx;
+        else {
+            const int lb = P.labels[level][lin(cr, cell)];
+            if (lb == AVS_ACTIVE || lb == AVS_INACTIVE) g += .5 * dx;
+            else if (level + 1 < P.levels && label_at(P, level + 1, half3(cell)) == AVS_ACTIVE) g += dx;
+            else bad = 1; // assert(false) cpp:1996
+        }
+    }
+    return dx * dx * g;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(kBlock) void k_rows(PyramidView P, const int32_t *__restrict__ vdof, int64_t n,
+                                                 StencilView E, StencilView C, const double *__restrict__ x0,
+                                                 const int32_t *__restrict__ rawptr, int32_t *__restrict__ raw_col,
+                                                 double *__restrict__ raw_val, int32_t *__restrict__ row_count,
+                                                 double *__restrict__ rhs, int *err)
+{
+    const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (row >= n) return;
+    const int32_t vi = (int32_t)row;
+    const int4 rec = reinterpret_cast<const int4 *>(vdof)[row];
+    const int level = rec.x & 0xff, axis = rec.x >> 8;
+    const I3 face{{rec.y, rec.z, rec.w}};
+    const I3 cr = cell_res(P, level);
+    const I3 fr = face_res(P, level, axis);
+    RowAcc ra{0, nullptr, nullptr, 0., 0., 0};
+    if (EMIT) {
+        ra.col = raw_col + rawptr[row];
+        ra.val = raw_val + rawptr[row];
+    }
+
+    // centre stresses + inset T-junction edge stresses of the two axial cells, cpp:2547-2650
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+        I3 cell = face;
+        if (dir == 0) --cell[axis];
+        if (cell[axis] < 0 || cell[axis] >= cr[axis]) continue;
+        I3 sc = cell;
+        int sl = level;
+        if (P.labels[level][lin(cr, cell)] != AVS_ACTIVE) { // face grading: the parent is the leaf
+            sc = half3(cell);
+            sl = level + 1;
+            if (sl >= P.levels) { ra.bad = 1; continue; }
+        }
+        const int32_t ci = P.cidx[sl][lin(cell_res(P, sl), sc)];
+        if (ci >= 0) apply_center<EMIT>(ra, vi, ci, axis, C);
+#pragma unroll
+        for (int fa = 0; fa < 3; ++fa) {
+            if (fa == axis) continue;
+            const int ea = 3 - fa - axis;
+#pragma unroll
+            for (int fd = 0; fd < 2; ++fd) {
+                I3 af = sc;
+                if (fd == 1) ++af[fa];
+                if (vidx_at(P, sl, fa, af) != AVS_UNASSIGNED) continue;
+                if (sl == 0) { ra.bad = 1; continue; }
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) { // getChildEdgeInFace, oct.h:126-142
+                    I3 e{{2 * af[0], 2 * af[1], 2 * af[2]}};
+                    if (ii == 1) ++e[ea];
+                    ++e[axis]; // 3 - faceAxis - edgeAxis == axis
+                    const int32_t ei = eidx_at(P, sl - 1, ea, e);
+                    if (ei >= 0) apply_edge<EMIT>(ra, vi, ei, E);
+                }
+            }
+        }
+    }
+    // the four edges around the face, cpp:2652-2745
+#pragma unroll
+    for (int ea = 0; ea < 3; ++ea) {
+        if (ea == axis) continue;
+        const int ta = 3 - ea - axis;
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            I3 e = face;
+            if (dir == 1) ++e[ta]; // HDKfaceToEdge, util.h:115-131
+            const int32_t ei = eidx_at(P, level, ea, e);
+            if (ei >= 0) {
+                if (P.enhanced) { // cpp:2664-2697
+                    I3 af = face;
+                    af[ta] += (dir == 0) ? -1 : 1;
+                    if (af[ta] >= 0 && af[ta] < fr[ta] && P.vidx[level][axis][lin(fr, af)] == AVS_UNASSIGNED) {
+                        I3 se = e;
+                        se[ea] += (e[ea] % 2 == 0) ? 1 : -1;
+                        const int32_t sei = eidx_at(P, level, ea, se);
+                        if (sei < 0) ra.bad = 1; // assert cpp:2680
+                        else apply_edge<EMIT>(ra, vi, sei, E);
+                    }
+                }
+                apply_edge<EMIT>(ra, vi, ei, E);
+            } else if (ei == AVS_UNASSIGNED && level > 0) { // cpp:2714-2742
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci) {
+                    I3 ce{{2 * e[0], 2 * e[1], 2 * e[2]}};
+                    if (ci > 0) ++ce[ea];
+                    const int32_t cei = eidx_at(P, level - 1, ea, ce);
+                    if (cei >= 0) apply_edge<EMIT>(ra, vi, cei, E);
+                }
+            }
+        }
+    }
+    // mass term and right-hand side, cpp:2748-2772
+    if (EMIT) {
+        double fw;
+        int bad = 0;
+        if (level == 0) {
+            fw = (double)field_at(P.facew[axis], face_res(P, 0, axis), face);
+            if (fw == 1.) fw = face_octree_volume(P, level, axis, face, bad);
+        } else fw = face_octree_volume(P, level, axis, face, bad);
+        if (bad) ra.bad = 1;
+        if (P.dens.is_const) fw *= (double)P.dens.cval;
+        else fw *= (double)sample_f32(P.dens, cell_res(P, 0), I3{{1, 1, 1}}, pos2_face(level, axis, face));
+        row_push<true>(ra, vi, fw + ra.diag);
+        ra.rhs += fw * x0[row];
+        rhs[row] = ra.rhs;
+    } else ++ra.n;
+    row_count[row] = ra.n;
+    if (ra.bad) *err = 7;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K7: compaction rows -> CSR.  16 lanes per row: consecutive rows are consecutive in both arrays,
+// so a wave reads and writes (nearly) contiguous memory.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_compact(int64_t n, const int32_t *__restrict__ rawptr,
+                                                    const int32_t *__restrict__ row_ptr,
+                                                    const int32_t *__restrict__ raw_col, const double *__restrict__ raw_val,
+                                                    int32_t *__restrict__ col, double *__restrict__ val)
+{
+    const int sub = threadIdx.x & 15;
+    const int64_t group = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 4;
+    const int64_t ngroups = ((int64_t)gridDim.x * kBlock) >> 4;
+    for (int64_t row = group; row < n; row += ngroups) {
+        const int src = rawptr[row], dst = row_ptr[row], len = row_ptr[row + 1] - dst;
+        for (int k = sub; k < len; k += 16) {
+            col[dst + k] = raw_col[src + k];
+            val[dst + k] = raw_val[src + k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5: exclusive scan (int32), three phases, wave64 shuffles inside the block
+// ---------------------------------------------------------------------------------------------
+static constexpr int kScanItems = 8;
+static constexpr int kScanTile = kBlock * kScanItems;
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int *lds_wave /*[4]*/, int &block_total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += u;
+    }
+    __syncthreads();
+    if (lane == 63) lds_wave[wave] = inc;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        if (w < wave) base += lds_wave[w];
+    block_total = lds_wave[0] + lds_wave[1] + lds_wave[2] + lds_wave[3];
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_sums(const int32_t *__restrict__ in, int64_t n, int32_t *__restrict__ sums)
+{
+    __shared__ int lds[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i)
+        if (base + i < n) s += in[base + i];
+    int total;
+    (void)block_exclusive_scan(s, lds, total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of the block sums in place; sums[nb] = grand total
+__global__ __launch_bounds__(kBlock) void k_scan_top(int32_t *__restrict__ sums, int64_t nb)
+{
+    __shared__ int lds[4];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t start = 0; start < nb; start += kBlock) {
+        const int64_t i = start + threadIdx.x;
+        const int v = (i < nb) ? sums[i] : 0;
+        int total;
+        const int ex = block_exclusive_scan(v, lds, total);
+        const int c = carry;
+        if (i < nb) sums[i] = c + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[nb] = carry;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_apply(const int32_t *__restrict__ in, int32_t *__restrict__ out, int64_t n,
+                                                       const int32_t *__restrict__ sums, int64_t nb)
+{
+    __shared__ int lds[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int v[kScanItems];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        v[i] = (base + i < n) ? in[base + i] : 0;
+        s += v[i];
+    }
+    int total;
+    int ex = block_exclusive_scan(s, lds, total) + sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        if (base + i < n) out[base + i] = ex;
+        ex += v[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = sums[nb];
+}
+
+size_t scan_tmp_elems(int64_t n) { return (size_t)((n + kScanTile - 1) / kScanTile) + 2; }
+
+avs_status exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t *tmp, size_t tmp_elems,
+                              hipStream_t stream)
+{
+    const int64_t nb = (n + kScanTile - 1) / kScanTile;
+    AVS_REQUIRE(tmp_elems >= (size_t)nb + 1, AVS_EINTERNAL, "scan scratch too small");
+    if (n == 0) {
+        AVS_HIP(hipMemsetAsync(out, 0, sizeof(int32_t), stream));
+        return AVS_OK;
+    }
+    hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(kBlock), 0, stream, in, n, tmp);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, stream, tmp, nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(kBlock), 0, stream, in, out, n, tmp, nb);
+    AVS_HIP(hipGetLastError());
+    return AVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side phase drivers (called from avs_api.hip)
+// ---------------------------------------------------------------------------------------------
+static inline unsigned grid_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock > 0 ? (n + kBlock - 1) / kBlock : 1); }
+
+static avs_status read_err(int *d_err, hipStream_t stream, int *out)
+{
+    AVS_HIP(hipMemcpyAsync(out, d_err, sizeof(int), hipMemcpyDeviceToHost, stream));
+    AVS_HIP(hipStreamSynchronize(stream));
+    return AVS_OK;
+}
+
+avs_status build_dof_tables(avs_ctx *c)
+{
+    hipStream_t st = c->stream;
+    const int L = c->desc.levels;
+    AVS_REQUIRE(c->n_vel >= 0 && c->n_edge >= 0 && c->n_center >= 0, AVS_ESTATE, "avs_set_dof_counts was not called");
+    for (int l = 0; l < L; ++l) {
+        AVS_REQUIRE(c->have_labels[l] && c->have_cidx[l], AVS_ESTATE, "labels / centre indices of level %d missing", l);
+        for (int a = 0; a < 3; ++a)
+            AVS_REQUIRE(c->have_vidx[l][a] && c->have_eidx[l][a], AVS_ESTATE, "index grids of level %d axis %d missing", l, a);
+    }
+    AVS_TRY(c->vdof.alloc((size_t)c->n_vel * 4));
+    AVS_TRY(c->edof.alloc((size_t)c->n_edge * 4));
+    AVS_TRY(c->cdof.alloc((size_t)c->n_center * 4));
+    AVS_HIP(hipMemsetAsync(c->vdof.p, 0xff, c->vdof.n * sizeof(int32_t), st));
+    AVS_HIP(hipMemsetAsync(c->edof.p, 0xff, c->edof.n * sizeof(int32_t), st));
+    AVS_HIP(hipMemsetAsync(c->cdof.p, 0xff, c->cdof.n * sizeof(int32_t), st));
+    DevBuf<int> err;
+    AVS_TRY(err.alloc(1));
+    AVS_HIP(hipMemsetAsync(err.p, 0, sizeof(int), st));
+    PyramidView P = c->view();
+    for (int l = 0; l < L; ++l) {
+        const int cr[3] = {P.n[0] >> l, P.n[1] >> l, P.n[2] >> l};
+        for (int a = 0; a < 3; ++a) {
+            I3 fr{{cr[0], cr[1], cr[2]}};
+            fr.v[a] += 1;
+            I3 er{{cr[0] + (a != 0), cr[1] + (a != 1), cr[2] + (a != 2)}};
+            const size_t nf = (size_t)fr.v[0] * fr.v[1] * fr.v[2], ne = (size_t)er.v[0] * er.v[1] * er.v[2];
+            hipLaunchKernelGGL(k_dof_table, dim3(grid_for((int64_t)nf) < 8192 ? grid_for((int64_t)nf) : 8192), dim3(kBlock), 0, st,
+                               c->vidx[l][a].p, fr, l, a, c->vdof.p, c->n_vel, err.p);
+            hipLaunchKernelGGL(k_dof_table, dim3(grid_for((int64_t)ne) < 8192 ? grid_for((int64_t)ne) : 8192), dim3(kBlock), 0, st,
+                               c->eidx[l][a].p, er, l, a, c->edof.p, c->n_edge, err.p);
+        }
+        I3 r{{cr[0], cr[1], cr[2]}};
+        const size_t ncell = (size_t)cr[0] * cr[1] * cr[2];
+        hipLaunchKernelGGL(k_dof_table, dim3(grid_for((int64_t)ncell) < 8192 ? grid_for((int64_t)ncell) : 8192), dim3(kBlock), 0, st,
+                           c->cidx[l].p, r, l, 0, c->cdof.p, c->n_center, err.p);
+    }
+    if (c->n_vel) hipLaunchKernelGGL(k_check_table, dim3(grid_for(c->n_vel) < 8192 ? grid_for(c->n_vel) : 8192), dim3(kBlock), 0, st, c->vdof.p, c->n_vel, err.p);
+    if (c->n_edge) hipLaunchKernelGGL(k_check_table, dim3(grid_for(c->n_edge) < 8192 ? grid_for(c->n_edge) : 8192), dim3(kBlock), 0, st, c->edof.p, c->n_edge, err.p);
+    if (c->n_center) hipLaunchKernelGGL(k_check_table, dim3(grid_for(c->n_center) < 8192 ? grid_for(c->n_center) : 8192), dim3(kBlock), 0, st, c->cdof.p, c->n_center, err.p);
+    AVS_HIP(hipGetLastError());
+    int e = 0;
+    AVS_TRY(read_err(err.p, st, &e));
+    AVS_REQUIRE(e == 0, AVS_EINVAL,
+                e == 1 ? "an index grid holds an id >= the declared DOF count"
+                       : (e == 2 ? "an index grid holds a value below AVS_OUTSIDE"
+                                 : "declared DOF counts exceed the ids present in the index grids"));
+    c->tables_ready = true;
+    return AVS_OK;
+}
+
+static StencilView edge_view(avs_ctx *c)
+{
+    return StencilView{c->n_edge, c->e_cnt.p, c->e_idx.p, c->e_bcnt.p, c->e_coef.p, c->e_bval.p, c->e_w.p};
+}
+static StencilView center_view(avs_ctx *c)
+{
+    return StencilView{c->n_center * 3, c->c_cnt.p, c->c_idx.p, c->c_bcnt.p, c->c_coef.p, c->c_bval.p, c->c_w.p};
+}
+
+avs_status build_stencils(avs_ctx *c)
+{
+    hipStream_t st = c->stream;
+    if (!c->tables_ready) AVS_TRY(build_dof_tables(c));
+    const size_t ne = (size_t)c->n_edge, n3 = (size_t)c->n_center * 3;
+    AVS_TRY(c->e_cnt.alloc(ne));
+    AVS_TRY(c->e_bcnt.alloc(ne));
+    AVS_TRY(c->e_w.alloc(ne));
+    AVS_TRY(c->e_idx.alloc(ne * AVS_EDGE_STENCIL_CAP));
+    AVS_TRY(c->e_coef.alloc(ne * AVS_EDGE_STENCIL_CAP));
+    AVS_TRY(c->e_bval.alloc(ne * AVS_EDGE_BOUNDARY_CAP));
+    AVS_TRY(c->c_cnt.alloc(n3));
+    AVS_TRY(c->c_bcnt.alloc(n3));
+    AVS_TRY(c->c_w.alloc((size_t)c->n_center));
+    AVS_TRY(c->c_idx.alloc(n3 * AVS_CENTER_STENCIL_CAP));
+    AVS_TRY(c->c_coef.alloc(n3 * AVS_CENTER_STENCIL_CAP));
+    AVS_TRY(c->c_bval.alloc(n3 * AVS_CENTER_BOUNDARY_CAP));
+    // unused slots read back as (-1, 0.0) like the oracle's
+    AVS_HIP(hipMemsetAsync(c->e_idx.p, 0xff, c->e_idx.n * sizeof(int32_t), st));
+    AVS_HIP(hipMemsetAsync(c->e_coef.p, 0, c->e_coef.n * sizeof(double), st));
+    AVS_HIP(hipMemsetAsync(c->e_bval.p, 0, c->e_bval.n * sizeof(double), st));
+    AVS_HIP(hipMemsetAsync(c->c_idx.p, 0xff, c->c_idx.n * sizeof(int32_t), st));
+    AVS_HIP(hipMemsetAsync(c->c_coef.p, 0, c->c_coef.n * sizeof(double), st));
+    AVS_HIP(hipMemsetAsync(c->c_bval.p, 0, c->c_bval.n * sizeof(double), st));
+    DevBuf<int> err;
+    AVS_TRY(err.alloc(1));
+    AVS_HIP(hipMemsetAsync(err.p, 0, sizeof(int), st));
+    PyramidView P = c->view();
+    if (c->n_edge) hipLaunchKernelGGL(k_edge_stencils, dim3(grid_for(c->n_edge)), dim3(kBlock), 0, st, P, c->edof.p, edge_view(c), err.p);
+    if (c->n_center) hipLaunchKernelGGL(k_center_stencils, dim3(grid_for(c->n_center)), dim3(kBlock), 0, st, P, c->cdof.p, center_view(c), err.p);
+    AVS_HIP(hipGetLastError());
+    int e = 0;
+    AVS_TRY(read_err(err.p, st, &e));
+    AVS_REQUIRE(e == 0, AVS_EINTERNAL, "stencil construction hit a reference assert (code %d): the index pyramids are inconsistent", e);
+    c->stencils_ready = true;
+    return AVS_OK;
+}
+
+avs_status build_initial_guess(avs_ctx *c)
+{
+    if (!c->tables_ready) AVS_TRY(build_dof_tables(c));
+    AVS_TRY(c->x0.alloc((size_t)c->n_vel));
+    if (c->n_vel) hipLaunchKernelGGL(k_initial_guess, dim3(grid_for(c->n_vel)), dim3(kBlock), 0, c->stream, c->view(), c->vdof.p, c->n_vel, c->x0.p);
+    AVS_HIP(hipGetLastError());
+    c->guess_ready = true;
+    return AVS_OK;
+}
+
+avs_status build_system(avs_ctx *c)
+{
+    hipStream_t st = c->stream;
+    AVS_REQUIRE(c->stencils_ready && c->guess_ready, AVS_ESTATE, "build the stencils and the initial guess first");
+    const int64_t n = c->n_vel;
+    AVS_REQUIRE(n < (int64_t)INT32_MAX, AVS_EINVAL, "too many DOFs for int32 columns");
+    DevBuf<int32_t> row_count, rawptr, scan_tmp, raw_col;
+    DevBuf<double> raw_val;
+    DevBuf<int> err;
+    AVS_TRY(row_count.alloc((size_t)n + 1));
+    AVS_TRY(rawptr.alloc((size_t)n + 1));
+    AVS_TRY(scan_tmp.alloc(scan_tmp_elems(n)));
+    AVS_TRY(err.alloc(1));
+    AVS_TRY(c->rhs.alloc((size_t)n));
+    AVS_TRY(c->row_ptr.alloc((size_t)n + 1));
+    AVS_HIP(hipMemsetAsync(err.p, 0, sizeof(int), st));
+    PyramidView P = c->view();
+    StencilView E = edge_view(c), C = center_view(c);
+    // K4 dry run -> raw triplet counts
+    if (n) hipLaunchKernelGGL((k_rows<false>), dim3(grid_for(n)), dim3(kBlock), 0, st, P, c->vdof.p, n, E, C, c->x0.p,
+                              (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr, row_count.p, (double *)nullptr, err.p);
+    AVS_TRY(exclusive_scan_i32(row_count.p, rawptr.p, n, scan_tmp.p, scan_tmp.n, st));
+    int32_t nraw = 0;
+    AVS_HIP(hipMemcpyAsync(&nraw, rawptr.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipStreamSynchronize(st));
+    AVS_REQUIRE(nraw >= 0, AVS_EINVAL, "raw triplet count overflows int32");
+    c->nraw = nraw;
+    AVS_TRY(raw_col.alloc((size_t)nraw));
+    AVS_TRY(raw_val.alloc((size_t)nraw));
+    // K6 emit (rows stay sorted + merged) -> unique counts
+    if (n) hipLaunchKernelGGL((k_rows<true>), dim3(grid_for(n)), dim3(kBlock), 0, st, P, c->vdof.p, n, E, C, c->x0.p,
+                              (const int32_t *)rawptr.p, raw_col.p, raw_val.p, row_count.p, c->rhs.p, err.p);
+    AVS_TRY(exclusive_scan_i32(row_count.p, c->row_ptr.p, n, scan_tmp.p, scan_tmp.n, st));
+    int32_t nnz = 0;
+    AVS_HIP(hipMemcpyAsync(&nnz, c->row_ptr.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    int e = 0;
+    AVS_TRY(read_err(err.p, st, &e));
+    AVS_REQUIRE(e == 0, AVS_EINTERNAL, "row assembly hit a reference assert (code %d): stencils and index pyramids disagree", e);
+    c->nnz = nnz;
+    AVS_TRY(c->col.alloc((size_t)nnz));
+    AVS_TRY(c->val.alloc((size_t)nnz));
+    if (n) hipLaunchKernelGGL(k_compact, dim3(8192), dim3(kBlock), 0, st, n, (const int32_t *)rawptr.p, (const int32_t *)c->row_ptr.p,
+                              (const int32_t *)raw_col.p, (const double *)raw_val.p, c->col.p, c->val.p);
+    AVS_HIP(hipGetLastError());
+    AVS_HIP(hipStreamSynchronize(st)); // raw buffers are freed on return
+    c->system_ready = true;
+    c->solved = false;
+    return AVS_OK;
+}
+
+} // namespace avs

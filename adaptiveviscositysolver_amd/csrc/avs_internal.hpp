@@ -1,0 +1,197 @@
+// Internal declarations shared by the HIP translation units of libavs_hip.so.
+// Nothing in here crosses the C ABI (include/avs.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "avs.h"
+
+namespace avs {
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing: thread-local message + status codes, never exceptions across the ABI
+// ---------------------------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+
+#define AVS_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (call);                                                               \
+        if (e__ != hipSuccess) {                                                               \
+            ::avs::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+            return AVS_EHIP;                                                                   \
+        }                                                                                      \
+    } while (0)
+
+#define AVS_TRY(call)                       \
+    do {                                    \
+        avs_status s__ = (call);            \
+        if (s__ != AVS_OK) return s__;      \
+    } while (0)
+
+#define AVS_REQUIRE(cond, status, ...)      \
+    do {                                    \
+        if (!(cond)) {                      \
+            ::avs::set_error(__VA_ARGS__);  \
+            return (status);                \
+        }                                   \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// device buffer with explicit lifetime (hipMalloc/hipFree), sized in elements
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    avs_status alloc(size_t count)
+    {
+        if (count == n && p) return AVS_OK;
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+            return AVS_ENOMEM;
+        }
+        n = count;
+        return AVS_OK;
+    }
+};
+
+// copy helper honouring avs_memspace on the "outside" end
+inline hipError_t copy_in(void *dst_dev, const void *src, size_t bytes, avs_memspace where, hipStream_t s)
+{
+    return hipMemcpyAsync(dst_dev, src, bytes,
+                          where == AVS_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s);
+}
+inline hipError_t copy_out(void *dst, const void *src_dev, size_t bytes, avs_memspace where, hipStream_t s)
+{
+    return hipMemcpyAsync(dst, src_dev, bytes,
+                          where == AVS_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// device-side view of the inputs (passed to kernels by value: < 1 KiB of kernarg)
+// ---------------------------------------------------------------------------------------------
+struct FieldView {
+    const float *data;
+    float cval;
+    int is_const;
+};
+
+struct PyramidView {
+    int levels;
+    int n[3];
+    int enhanced;
+    double dx, dt;
+    const int8_t *labels[AVS_MAX_LEVELS];
+    const int32_t *vidx[AVS_MAX_LEVELS][3];
+    const int32_t *eidx[AVS_MAX_LEVELS][3];
+    const int32_t *cidx[AVS_MAX_LEVELS];
+    FieldView centerw, edgew[3], facew[3], visc, dens, vel[3], solidvel[3];
+};
+
+struct StencilView { // SoA, entry k of stencil s at [k*count + s]
+    int64_t count;
+    int32_t *cnt, *idx, *bcnt;
+    double *coef, *bval;
+    double *weight; // edge: per stencil; centre: per cell (count/3)
+};
+
+// ---------------------------------------------------------------------------------------------
+// CSR system resident in HBM
+// ---------------------------------------------------------------------------------------------
+struct CsrView {
+    int64_t n = 0, nnz = 0;
+    const int32_t *row_ptr = nullptr;
+    const int32_t *col = nullptr;
+    const double *val = nullptr;
+};
+
+// PCG work space + device scalars (see avs_pcg.hip)
+struct PcgWork;
+
+avs_status pcg_create(PcgWork **w, int64_t n, int64_t n_ext, hipStream_t stream);
+void pcg_destroy(PcgWork *w);
+
+// Jacobi-PCG in Eigen's operation order; x holds the initial guess, returns the solution.
+// Optional halo hook (multi-GPU) is wired by avs_dist.hip through PcgDist.
+struct PcgDist; // opaque: halo exchange + all-reduce
+avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, double tol, int max_iters,
+                     hipStream_t stream, avs_solve_info *info, PcgDist *dist);
+
+// SpMV launchers (variant 0 = default)
+avs_status spmv_launch(const CsrView &A, const double *x, double *y, int variant, hipStream_t stream);
+int spmv_default_variant(const CsrView &A);
+
+// scan (exclusive, int32 -> int32, n+1 outputs: out[n] = total)
+avs_status exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t *block_tmp, size_t block_tmp_elems,
+                              hipStream_t stream);
+size_t scan_tmp_elems(int64_t n);
+
+// multi-GPU hooks called from pcg_solve (implemented in avs_dist.hip)
+avs_status dist_halo_exchange(PcgDist *d, double *p_ext, hipStream_t stream);
+avs_status dist_allreduce(PcgDist *d, double *dev_scalars, int count, hipStream_t stream);
+
+} // namespace avs
+
+// ---------------------------------------------------------------------------------------------
+// the context behind the opaque avs_ctx
+// ---------------------------------------------------------------------------------------------
+struct avs_ctx {
+    avs_desc desc{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    // inputs
+    avs::DevBuf<int8_t> labels[AVS_MAX_LEVELS];
+    avs::DevBuf<int32_t> vidx[AVS_MAX_LEVELS][3], eidx[AVS_MAX_LEVELS][3], cidx[AVS_MAX_LEVELS];
+    bool have_labels[AVS_MAX_LEVELS] = {};
+    bool have_vidx[AVS_MAX_LEVELS][3] = {}, have_eidx[AVS_MAX_LEVELS][3] = {}, have_cidx[AVS_MAX_LEVELS] = {};
+    struct Field {
+        avs::DevBuf<float> buf;
+        float cval = 0.f;
+        bool is_const = true;
+    };
+    Field centerw, edgew[3], facew[3], visc, dens, vel[3], solidvel[3];
+    int64_t n_vel = -1, n_edge = -1, n_center = -1;
+
+    // dof tables: 4 x int32 per dof (level | axis << 8, i, j, k)
+    avs::DevBuf<int32_t> vdof, edof, cdof;
+    bool tables_ready = false;
+
+    // stencils
+    avs::DevBuf<int32_t> e_cnt, e_idx, e_bcnt, c_cnt, c_idx, c_bcnt;
+    avs::DevBuf<double> e_coef, e_bval, e_w, c_coef, c_bval, c_w;
+    bool stencils_ready = false;
+
+    // system
+    avs::DevBuf<double> x0, rhs, val, x;
+    avs::DevBuf<int32_t> row_ptr, col;
+    int64_t nnz = 0, nraw = 0;
+    bool guess_ready = false, system_ready = false, solved = false;
+    avs_assembly_info ainfo{};
+
+    avs::PcgWork *pcg = nullptr;
+    avs::PcgDist *dist = nullptr;
+
+    avs::PyramidView view() const;
+};

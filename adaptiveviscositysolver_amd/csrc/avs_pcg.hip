@@ -1,0 +1,478 @@
+// avs_pcg.hip -- device-resident Jacobi-PCG + CSR SpMV for gfx950 (MI355X).
+//
+// Replaces cpp:611-643 of the reference (HDK_AdaptiveViscosity.cpp): Eigen's
+// ConjugateGradient<SparseMatrix<double>, Lower|Upper> with DiagonalPreconditioner and
+// solveWithGuess.  The iteration follows Eigen 3.3/3.4 ConjugateGradient.h operation by operation
+// (SURVEY.md 8(c)); only the order of additions inside dot products differs (block-wise tree).
+//
+// Roofline: every kernel here is HBM-bound.  Algorithmic bytes per SpMV launch:
+//   12*nnz + 4*(n+1) + 16*n      (fp64 values, int32 columns / row pointers)
+//
+// SpMV kernels
+//   variant 1  "stream": a 256-thread workgroup owns 256 consecutive rows.  Phase 1 streams the
+//              rows' (val, col) pairs with fully coalesced loads, gathers x[col] and parks the
+//              products in LDS; phase 2: one thread per row adds its LDS segment left to right
+//              (the same order as the CPU oracle => bit-identical y).  Row stride ~15 doubles is
+//              bank-conflict-free for ds_read_b64 (30*t mod 64 distinct for t < 32).
+//   variant 2-4 "vector": 4 / 8 / 16 lanes per row, shuffle reduction.
+//
+// CG scalars never leave the device.  The host enqueues iterations in chunks and polls a
+// `done` flag once per chunk; kernels of iterations enqueued past convergence exit immediately, so
+// the iteration count and the solution are exactly those of the sequential algorithm.
+#include "avs_internal.hpp"
+
+namespace avs {
+
+static constexpr int kBlock = 256;
+static constexpr int kVecGrid = 2048;        // grid-stride vector kernels: 8 blocks per CU
+static constexpr int kStreamCap = 4096;      // LDS products per tile (32 KiB)
+static constexpr int kChunk = 32;            // iterations enqueued between host polls
+
+struct PcgScalars {
+    double rho;        // absNew = r.z
+    double pAp;
+    double rr;         // residualNorm2
+    double alpha, beta;
+    double threshold, rhs_norm2;
+    double red[4];     // reduction staging (all-reduced in multi-GPU mode)
+    int iter;          // completed iterations (Eigen's i)
+    int done;          // 1: converged, 3: rhs == 0 (x := 0)
+};
+
+struct PcgWork {
+    int64_t n = 0, n_ext = 0;
+    DevBuf<double> r, p, t, invd, partial;
+    DevBuf<PcgScalars> sc;
+    PcgScalars *host_sc = nullptr; // pinned
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    size_t npartial = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// block reduction helpers (wave64 shuffles, then LDS across the 4 waves of a 256-thread block)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ double block_sum(double v, double *lds4)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) lds4[wave] = v;
+    __syncthreads();
+    double s = 0.;
+    if (threadIdx.x == 0) s = ((lds4[0] + lds4[1]) + lds4[2]) + lds4[3];
+    return s; // valid in thread 0
+}
+
+// ---------------------------------------------------------------------------------------------
+// SpMV: stream variant
+// ---------------------------------------------------------------------------------------------
+template <bool DOT>
+__global__ __launch_bounds__(kBlock) void k_spmv_stream(CsrView A, const double *__restrict__ x,
+                                                        double *__restrict__ y,
+                                                        double *__restrict__ partial,
+                                                        const PcgScalars *sc)
+{
+    if (DOT && sc && sc->done) return;
+    __shared__ double prod[kStreamCap];
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * kBlock;
+    const int64_t row = row0 + tid;
+    const int64_t rlast = (row0 + kBlock < A.n) ? row0 + kBlock : A.n;
+    const int s_blk = A.row_ptr[row0];
+    const int e_blk = A.row_ptr[rlast];
+    int rs = 0, re = 0;
+    if (row < A.n) {
+        rs = A.row_ptr[row];
+        re = A.row_ptr[row + 1];
+    }
+    double sum = 0.;
+    for (int ts = s_blk; ts < e_blk; ts += kStreamCap) {
+        const int te = (ts + kStreamCap < e_blk) ? ts + kStreamCap : e_blk;
+        // phase 1: coalesced stream of (val, col), gather x, products to LDS.  4 independent
+        // loads per thread in flight per trip.
+        int k = ts + tid;
+        for (; k + 3 * kBlock < te; k += 4 * kBlock) {
+            const double v0 = A.val[k], v1 = A.val[k + kBlock], v2 = A.val[k + 2 * kBlock], v3 = A.val[k + 3 * kBlock];
+            const int c0 = A.col[k], c1 = A.col[k + kBlock], c2 = A.col[k + 2 * kBlock], c3 = A.col[k + 3 * kBlock];
+            const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+            prod[k - ts] = v0 * x0;
+            prod[k - ts + kBlock] = v1 * x1;
+            prod[k - ts + 2 * kBlock] = v2 * x2;
+            prod[k - ts + 3 * kBlock] = v3 * x3;
+        }
+        for (; k < te; k += kBlock) prod[k - ts] = A.val[k] * x[A.col[k]];
+        __syncthreads();
+        // phase 2: each row adds its part of the tile, left to right
+        const int a = rs > ts ? rs : ts;
+        const int b = re < te ? re : te;
+        for (int j = a; j < b; ++j) sum += prod[j - ts];
+        __syncthreads();
+    }
+    if (row < A.n) y[row] = sum;
+    if (DOT) {
+        double d = (row < A.n) ? sum * x[row] : 0.;
+        d = block_sum(d, red);
+        if (tid == 0) partial[blockIdx.x] = d;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SpMV: vector variants (LPR lanes per row)
+// ---------------------------------------------------------------------------------------------
+template <int LPR, bool DOT>
+__global__ __launch_bounds__(kBlock) void k_spmv_vec(CsrView A, const double *__restrict__ x,
+                                                     double *__restrict__ y,
+                                                     double *__restrict__ partial,
+                                                     const PcgScalars *sc)
+{
+    if (DOT && sc && sc->done) return;
+    __shared__ double red[4];
+    const int sub = threadIdx.x % LPR;
+    const int64_t group = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LPR;
+    const int64_t ngroups = (int64_t)gridDim.x * kBlock / LPR;
+    double dot = 0.;
+    for (int64_t row = group; row < A.n; row += ngroups) {
+        const int s = A.row_ptr[row], e = A.row_ptr[row + 1];
+        double sum = 0.;
+        for (int k = s + sub; k < e; k += LPR) sum += A.val[k] * x[A.col[k]];
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, LPR);
+        if (sub == 0) {
+            y[row] = sum;
+            if (DOT) dot += sum * x[row];
+        }
+    }
+    if (DOT) {
+        dot = block_sum(dot, red);
+        if (threadIdx.x == 0) partial[blockIdx.x] = dot;
+    }
+}
+
+static inline int stream_grid(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
+
+int spmv_default_variant(const CsrView &) { return 1; }
+
+template <bool DOT>
+static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, double *partial,
+                                const PcgScalars *sc, int variant, hipStream_t stream, int *nblocks)
+{
+    if (variant == 0) variant = spmv_default_variant(A);
+    if (A.n <= 0) { if (nblocks) *nblocks = 0; return AVS_OK; }
+    int g;
+    switch (variant) {
+    case 1:
+        g = stream_grid(A.n);
+        hipLaunchKernelGGL((k_spmv_stream<DOT>), dim3(g), dim3(kBlock), 0, stream, A, x, y, partial, sc);
+        break;
+    case 2:
+        g = kVecGrid * 4;
+        hipLaunchKernelGGL((k_spmv_vec<4, DOT>), dim3(g), dim3(kBlock), 0, stream, A, x, y, partial, sc);
+        break;
+    case 3:
+        g = kVecGrid * 4;
+        hipLaunchKernelGGL((k_spmv_vec<8, DOT>), dim3(g), dim3(kBlock), 0, stream, A, x, y, partial, sc);
+        break;
+    case 4:
+        g = kVecGrid * 4;
+        hipLaunchKernelGGL((k_spmv_vec<16, DOT>), dim3(g), dim3(kBlock), 0, stream, A, x, y, partial, sc);
+        break;
+    default:
+        set_error("unknown SpMV variant %d", variant);
+        return AVS_EINVAL;
+    }
+    if (nblocks) *nblocks = g;
+    AVS_HIP(hipGetLastError());
+    return AVS_OK;
+}
+
+avs_status spmv_launch(const CsrView &A, const double *x, double *y, int variant, hipStream_t stream)
+{
+    return spmv_dispatch<false>(A, x, y, nullptr, nullptr, variant, stream, nullptr);
+}
+
+static size_t max_partials(int64_t n)
+{
+    size_t a = (size_t)stream_grid(n), b = (size_t)kVecGrid * 4;
+    return 2 * (a > b ? a : b) + 16;
+}
+
+// ---------------------------------------------------------------------------------------------
+// vector kernels
+// ---------------------------------------------------------------------------------------------
+// DiagonalPreconditioner::factorize: invdiag(j) = A(j,j) != 0 ? 1/A(j,j) : 1
+__global__ __launch_bounds__(kBlock) void k_inv_diag(CsrView A, double *__restrict__ invd)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= A.n) return;
+    double d = 0.;
+    for (int k = A.row_ptr[i]; k < A.row_ptr[i + 1]; ++k)
+        if (A.col[k] == (int32_t)i) d = A.val[k];
+    invd[i] = (d != 0.) ? 1. / d : 1.;
+}
+
+// r = b - t ; partials: [0..g) b.b, [g..2g) r.r
+__global__ __launch_bounds__(kBlock) void k_init_residual(int64_t n, const double *__restrict__ b,
+                                                          const double *__restrict__ t,
+                                                          double *__restrict__ r, double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    double bb = 0., rr = 0.;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double bi = b[i];
+        const double ri = bi - t[i];
+        r[i] = ri;
+        bb += bi * bi;
+        rr += ri * ri;
+    }
+    bb = block_sum(bb, red);
+    rr = block_sum(rr, red);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = bb;
+        partial[gridDim.x + blockIdx.x] = rr;
+    }
+}
+
+// p = invd * r ; partial r.p
+__global__ __launch_bounds__(kBlock) void k_init_p(int64_t n, const double *__restrict__ r,
+                                                   const double *__restrict__ invd, double *__restrict__ p,
+                                                   double *__restrict__ x, double *__restrict__ partial,
+                                                   const PcgScalars *sc)
+{
+    __shared__ double red[4];
+    const int done = sc->done;
+    double rz = 0.;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        if (done == 3) { x[i] = 0.; continue; } // rhsNorm2 == 0 -> x.setZero()
+        if (done) continue;
+        const double ri = r[i];
+        const double zi = invd[i] * ri;
+        p[i] = zi;
+        rz += ri * zi;
+    }
+    rz = block_sum(rz, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = rz;
+}
+
+// x += alpha p ; r -= alpha t ; partials: r.r and r.(invd r)
+__global__ __launch_bounds__(kBlock) void k_update_xr(int64_t n, double *__restrict__ x, double *__restrict__ r,
+                                                      const double *__restrict__ p, const double *__restrict__ t,
+                                                      const double *__restrict__ invd, const PcgScalars *sc,
+                                                      double *__restrict__ partial)
+{
+    if (sc->done) return;
+    __shared__ double red[4];
+    const double alpha = sc->alpha;
+    double rr = 0., rz = 0.;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        x[i] += alpha * p[i];
+        const double ri = r[i] - alpha * t[i];
+        r[i] = ri;
+        rr += ri * ri;
+        rz += ri * (invd[i] * ri);
+    }
+    rr = block_sum(rr, red);
+    rz = block_sum(rz, red);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = rr;
+        partial[gridDim.x + blockIdx.x] = rz;
+    }
+}
+
+// p = invd r + beta p
+__global__ __launch_bounds__(kBlock) void k_update_p(int64_t n, double *__restrict__ p, const double *__restrict__ r,
+                                                     const double *__restrict__ invd, const PcgScalars *sc)
+{
+    if (sc->done) return;
+    const double beta = sc->beta;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        p[i] = invd[i] * r[i] + beta * p[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// scalar stages.  One 256-thread block sums `nb` partials of `nred` interleaved arrays in a fixed
+// order (deterministic), then (optionally) applies the scalar update.
+// ---------------------------------------------------------------------------------------------
+enum ScalarOp { OP_NONE = 0, OP_INIT = 1, OP_RHO0 = 2, OP_ALPHA = 3, OP_BETA = 4 };
+
+__device__ void apply_scalar_op(PcgScalars *sc, int op, double tol)
+{
+    switch (op) {
+    case OP_INIT: { // red[0] = b.b, red[1] = r.r
+        sc->rhs_norm2 = sc->red[0];
+        sc->rr = sc->red[1];
+        sc->iter = 0;
+        if (sc->red[0] == 0.) { sc->done = 3; sc->rr = 0.; break; }
+        double thr = tol * tol * sc->red[0];
+        const double considerAsZero = 2.2250738585072014e-308;
+        if (thr < considerAsZero) thr = considerAsZero;
+        sc->threshold = thr;
+        sc->done = (sc->red[1] < thr) ? 1 : 0;
+        break;
+    }
+    case OP_RHO0:
+        if (!sc->done) sc->rho = sc->red[0];
+        break;
+    case OP_ALPHA:
+        if (!sc->done) { sc->pAp = sc->red[0]; sc->alpha = sc->rho / sc->red[0]; }
+        break;
+    case OP_BETA:
+        if (!sc->done) {
+            sc->rr = sc->red[0];
+            if (sc->red[0] < sc->threshold) sc->done = 1; // Eigen: break before i++
+            else {
+                const double absOld = sc->rho;
+                sc->rho = sc->red[1];
+                sc->beta = sc->red[1] / absOld;
+                sc->iter += 1;
+            }
+        }
+        break;
+    default: break;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_reduce(const double *__restrict__ partial, int nb, int nred,
+                                                   PcgScalars *sc, int op, double tol, int skip_if_done)
+{
+    if (skip_if_done && sc->done) return;
+    __shared__ double red[4];
+    for (int q = 0; q < nred; ++q) {
+        double s = 0.;
+        for (int i = threadIdx.x; i < nb; i += kBlock) s += partial[(size_t)q * nb + i];
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) sc->red[q] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && op != OP_NONE) apply_scalar_op(sc, op, tol);
+}
+
+__global__ void k_scalar(PcgScalars *sc, int op, double tol)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) apply_scalar_op(sc, op, tol);
+}
+
+// ---------------------------------------------------------------------------------------------
+avs_status pcg_create(PcgWork **out, int64_t n, int64_t n_ext, hipStream_t)
+{
+    PcgWork *w = new (std::nothrow) PcgWork();
+    AVS_REQUIRE(w, AVS_ENOMEM, "out of host memory");
+    w->n = n;
+    w->n_ext = n_ext;
+    w->npartial = max_partials(n);
+    avs_status s;
+    if ((s = w->r.alloc((size_t)n)) || (s = w->p.alloc((size_t)n_ext)) || (s = w->t.alloc((size_t)n)) ||
+        (s = w->invd.alloc((size_t)n)) || (s = w->partial.alloc(w->npartial)) || (s = w->sc.alloc(1))) {
+        delete w;
+        return s;
+    }
+    if (hipHostMalloc(reinterpret_cast<void **>(&w->host_sc), sizeof(PcgScalars)) != hipSuccess ||
+        hipEventCreate(&w->ev0) != hipSuccess || hipEventCreate(&w->ev1) != hipSuccess) {
+        set_error("pinned host / event allocation failed");
+        pcg_destroy(w);
+        return AVS_EHIP;
+    }
+    *out = w;
+    return AVS_OK;
+}
+
+void pcg_destroy(PcgWork *w)
+{
+    if (!w) return;
+    if (w->host_sc) (void)hipHostFree(w->host_sc);
+    if (w->ev0) (void)hipEventDestroy(w->ev0);
+    if (w->ev1) (void)hipEventDestroy(w->ev1);
+    delete w;
+}
+
+static avs_status reduce_stage(PcgWork *w, int nb, int nred, int op, double tol, int skip_if_done,
+                               hipStream_t stream, PcgDist *dist)
+{
+    if (!dist) {
+        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, stream, w->partial.p, nb, nred, w->sc.p, op, tol, skip_if_done);
+    } else {
+        // local sums -> RCCL all-reduce of sc->red[0..nred) -> scalar update
+        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, stream, w->partial.p, nb, nred, w->sc.p, (int)OP_NONE, tol, 0);
+        AVS_TRY(dist_allreduce(dist, reinterpret_cast<double *>(reinterpret_cast<char *>(w->sc.p) + offsetof(PcgScalars, red)), nred, stream));
+        hipLaunchKernelGGL(k_scalar, dim3(1), dim3(64), 0, stream, w->sc.p, op, tol);
+    }
+    AVS_HIP(hipGetLastError());
+    return AVS_OK;
+}
+
+avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, double tol, int max_iters,
+                     hipStream_t stream, avs_solve_info *info, PcgDist *dist)
+{
+    const int64_t n = A.n;
+    AVS_REQUIRE(w && w->n == n, AVS_EINVAL, "pcg workspace does not match the system size");
+    const int vgrid = (int)((n + kBlock - 1) / kBlock < kVecGrid ? (n + kBlock - 1) / kBlock : kVecGrid);
+    const int g = vgrid > 0 ? vgrid : 1;
+    const int rowgrid = (int)((n + kBlock - 1) / kBlock) > 0 ? (int)((n + kBlock - 1) / kBlock) : 1;
+    const int variant = spmv_default_variant(A);
+    double *p = w->p.p, *r = w->r.p, *t = w->t.p, *invd = w->invd.p, *partial = w->partial.p;
+    PcgScalars *sc = w->sc.p;
+
+    AVS_HIP(hipMemsetAsync(sc, 0, sizeof(PcgScalars), stream));
+    hipLaunchKernelGGL(k_inv_diag, dim3(rowgrid), dim3(kBlock), 0, stream, A, invd);
+    AVS_HIP(hipEventRecord(w->ev0, stream));
+
+    // residual = rhs - mat * x
+    if (dist) {
+        // x must be visible in its extended form for the product: stage it through p
+        AVS_HIP(hipMemcpyAsync(p, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        AVS_TRY(dist_halo_exchange(dist, p, stream));
+        AVS_TRY(spmv_dispatch<false>(A, p, t, nullptr, nullptr, variant, stream, nullptr));
+    } else {
+        AVS_TRY(spmv_dispatch<false>(A, x, t, nullptr, nullptr, variant, stream, nullptr));
+    }
+    hipLaunchKernelGGL(k_init_residual, dim3(g), dim3(kBlock), 0, stream, n, b, t, r, partial);
+    AVS_TRY(reduce_stage(w, g, 2, OP_INIT, tol, 0, stream, dist));
+    hipLaunchKernelGGL(k_init_p, dim3(g), dim3(kBlock), 0, stream, n, r, invd, p, x, partial, sc);
+    AVS_TRY(reduce_stage(w, g, 1, OP_RHO0, tol, 0, stream, dist));
+    AVS_HIP(hipGetLastError());
+
+    int enqueued = 0;
+    bool finished = false;
+    while (!finished) {
+        AVS_HIP(hipMemcpyAsync(w->host_sc, sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, stream));
+        AVS_HIP(hipStreamSynchronize(stream));
+        if (w->host_sc->done || enqueued >= max_iters) break;
+        const int chunk = (max_iters - enqueued) < kChunk ? (max_iters - enqueued) : kChunk;
+        for (int c = 0; c < chunk; ++c) {
+            int nb = 0;
+            if (dist) AVS_TRY(dist_halo_exchange(dist, p, stream));
+            AVS_TRY(spmv_dispatch<true>(A, p, t, partial, sc, variant, stream, &nb)); // tmp = A p ; p.tmp
+            AVS_TRY(reduce_stage(w, nb, 1, OP_ALPHA, tol, 1, stream, dist));
+            hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(kBlock), 0, stream, n, x, r, p, t, invd, sc, partial);
+            AVS_TRY(reduce_stage(w, g, 2, OP_BETA, tol, 1, stream, dist));
+            hipLaunchKernelGGL(k_update_p, dim3(g), dim3(kBlock), 0, stream, n, p, r, invd, sc);
+        }
+        AVS_HIP(hipGetLastError());
+        enqueued += chunk;
+    }
+    AVS_HIP(hipEventRecord(w->ev1, stream));
+    AVS_HIP(hipEventSynchronize(w->ev1));
+    float ms = 0.f;
+    AVS_HIP(hipEventElapsedTime(&ms, w->ev0, w->ev1));
+    if (info) {
+        const PcgScalars &h = *w->host_sc;
+        info->iterations = h.iter;
+        info->converged = (h.done != 0) ? 1 : 0;
+        info->rhs_norm2 = h.rhs_norm2;
+        info->error = (h.done == 3 || h.rhs_norm2 == 0.) ? 0. : sqrt(h.rr / h.rhs_norm2);
+        info->n = n;
+        info->nnz = A.nnz;
+        info->solve_ms = ms;
+        info->spmv_ms = 0.;
+    }
+    return AVS_OK;
+}
+
+} // namespace avs

@@ -1,0 +1,185 @@
+"""Host-side driver of the hot path: mirrors the phase sequence of
+HDK_AdaptiveViscosity::solveGasSubclass between cpp:418 and cpp:653, calling only the C ABI
+(include/avs.h).  Buffers are numpy arrays (host) or torch tensors (host or HBM); torch is used
+for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class ViscositySolve:
+    """One adaptive-viscosity solve on one MI355X.
+
+    Typical use (same order as the reference):
+        s = ViscositySolve(res, dx, dt, levels)          # cpp:126-275
+        s.set_pyramid(pyramid); s.set_scene_fields(scene) # outputs of cpp:233-416
+        info = s.assemble()                               # cpp:418-594, 613-614
+        sol = s.solve(tol, max_iters)                     # cpp:618-630
+        x = s.solution()                                  # viscositySolution, consumed by cpp:661-707
+    """
+
+    def __init__(self, res, dx, dt, levels, use_enhanced_gradients=True, device=0, stream=None):
+        self.lib = capi.load()
+        self.res = tuple(int(r) for r in res)
+        d = capi.Desc(self.res[0], self.res[1], self.res[2], float(dx), float(dt), int(levels),
+                      int(bool(use_enhanced_gradients)), int(device), C.c_void_p(stream or 0))
+        h = C.c_void_p()
+        capi.check(self.lib.avs_create(C.byref(d), C.byref(h)))
+        self.h = h
+        self.levels = int(levels)
+        self.counts = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.avs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- inputs ---------------------------------------------------------------------------
+    def set_labels(self, level, labels):
+        p, where = capi.ptr_of(labels)
+        capi.check(self.lib.avs_set_labels(self.h, level, p, where))
+
+    def set_index_field(self, kind, level, axis, idx):
+        p, where = capi.ptr_of(idx)
+        capi.check(self.lib.avs_set_index_field(self.h, kind, level, axis, p, where))
+
+    def set_dof_counts(self, nv, ne, nc):
+        capi.check(self.lib.avs_set_dof_counts(self.h, nv, ne, nc))
+        self.counts = (int(nv), int(ne), int(nc))
+
+    def set_field(self, kind, axis=0, data=None, const=0.0):
+        p, where = capi.ptr_of(data)
+        capi.check(self.lib.avs_set_scalar_field(self.h, kind, axis, p, float(const), where))
+
+    def set_pyramid(self, pyr):
+        """Upload a prepass.Pyramid (labels, index pyramids, counts, integration weights)."""
+        def c(t, dtype):
+            if isinstance(t, np.ndarray):
+                return np.ascontiguousarray(t, dtype=dtype)
+            import torch
+            tdt = {np.int8: torch.int8, np.int32: torch.int32, np.float32: torch.float32}[dtype]
+            return t.to(tdt).contiguous()
+        for l in range(pyr.levels):
+            self.set_labels(l, c(pyr.labels[l], np.int8))
+            for a in range(3):
+                self.set_index_field(capi.INDEX_VELOCITY, l, a, c(pyr.vidx[l][a], np.int32))
+                self.set_index_field(capi.INDEX_EDGE, l, a, c(pyr.eidx[l][a], np.int32))
+            self.set_index_field(capi.INDEX_CENTER, l, 0, c(pyr.cidx[l], np.int32))
+        self.set_dof_counts(pyr.n_velocity, pyr.n_edge, pyr.n_center)
+        self.set_field(capi.FIELD_CENTER_WEIGHTS, 0, c(pyr.center_weights, np.float32))
+        for a in range(3):
+            self.set_field(capi.FIELD_EDGE_WEIGHTS, a, c(pyr.edge_weights[a], np.float32))
+            self.set_field(capi.FIELD_FACE_WEIGHTS, a, c(pyr.face_weights[a], np.float32))
+
+    def set_scene_fields(self, scene):
+        """viscosity / density / velocity / solid velocity of a scenes.Scene."""
+        def put(kind, axis, v):
+            if isinstance(v, (int, float)):
+                self.set_field(kind, axis, None, float(v))
+            else:
+                self.set_field(kind, axis, v.contiguous() if hasattr(v, "contiguous") else np.ascontiguousarray(v))
+        put(capi.FIELD_VISCOSITY, 0, scene.viscosity)
+        put(capi.FIELD_DENSITY, 0, scene.density)
+        for a in range(3):
+            put(capi.FIELD_VELOCITY, a, scene.velocity[a])
+            if scene.solid_velocity is None:
+                self.set_field(capi.FIELD_SOLID_VELOCITY, a, None, 0.0)
+            else:
+                put(capi.FIELD_SOLID_VELOCITY, a, scene.solid_velocity[a])
+
+    # ---- hot path -------------------------------------------------------------------------
+    def build_stencils(self):
+        capi.check(self.lib.avs_build_stencils(self.h))
+
+    def build_initial_guess(self):
+        capi.check(self.lib.avs_build_initial_guess(self.h))
+
+    def build_system(self):
+        capi.check(self.lib.avs_build_system(self.h))
+
+    def assemble(self):
+        info = capi.AssemblyInfo()
+        capi.check(self.lib.avs_assemble(self.h, C.byref(info)))
+        self.ainfo = info
+        return info
+
+    def solve(self, tol=1e-3, max_iters=2500):
+        info = capi.SolveInfo()
+        capi.check(self.lib.avs_solve(self.h, float(tol), int(max_iters), C.byref(info)))
+        return info
+
+    def bench_spmv(self, variant=0, repeats=100):
+        ms = C.c_double()
+        capi.check(self.lib.avs_bench_spmv(self.h, variant, repeats, C.byref(ms)))
+        return ms.value
+
+    # ---- outputs (numpy, host) ------------------------------------------------------------
+    def info(self):
+        info = capi.AssemblyInfo()
+        capi.check(self.lib.avs_get_assembly_info(self.h, C.byref(info)))
+        return info
+
+    def solution(self):
+        n = self.info().n_velocity
+        x = np.empty(n, np.float64)
+        capi.check(self.lib.avs_get_solution(self.h, x.ctypes.data, n, capi.MEM_HOST))
+        return x
+
+    def initial_guess(self):
+        n = self.info().n_velocity
+        x = np.empty(n, np.float64)
+        capi.check(self.lib.avs_get_initial_guess(self.h, x.ctypes.data, n, capi.MEM_HOST))
+        return x
+
+    def csr(self):
+        i = self.info()
+        rp = np.empty(i.n_velocity + 1, np.int32)
+        col = np.empty(i.nnz, np.int32)
+        val = np.empty(i.nnz, np.float64)
+        rhs = np.empty(i.n_velocity, np.float64)
+        capi.check(self.lib.avs_get_csr(self.h, rp.ctypes.data, col.ctypes.data, val.ctypes.data,
+                                        rhs.ctypes.data, capi.MEM_HOST))
+        return rp, col, val, rhs
+
+    def _stencils(self, fn, ns, nw, cap, bcap):
+        cnt = np.empty(ns, np.int32); idx = np.empty((cap, ns), np.int32)
+        coef = np.empty((cap, ns), np.float64); bcnt = np.empty(ns, np.int32)
+        bval = np.empty((bcap, ns), np.float64); w = np.empty(nw, np.float64)
+        capi.check(fn(self.h, cnt.ctypes.data, idx.ctypes.data, coef.ctypes.data, bcnt.ctypes.data,
+                      bval.ctypes.data, w.ctypes.data, capi.MEM_HOST))
+        return dict(cnt=cnt, idx=idx, coef=coef, bcnt=bcnt, bval=bval, weight=w)
+
+    def edge_stencils(self):
+        ne = self.info().n_edge
+        return self._stencils(self.lib.avs_get_edge_stencils, ne, ne, capi.EDGE_STENCIL_CAP, capi.EDGE_BOUNDARY_CAP)
+
+    def center_stencils(self):
+        nc = self.info().n_center
+        return self._stencils(self.lib.avs_get_center_stencils, 3 * nc, nc, capi.CENTER_STENCIL_CAP,
+                              capi.CENTER_BOUNDARY_CAP)
+
+
+def pcg_csr(row_ptr, col, val, b, x0, tol=1e-3, max_iters=2500, device=0):
+    """Seam A (avs_pcg_csr) on host numpy arrays."""
+    lib = capi.load()
+    rp = np.ascontiguousarray(row_ptr, np.int32)
+    cl = np.ascontiguousarray(col, np.int32)
+    vl = np.ascontiguousarray(val, np.float64)
+    bb = np.ascontiguousarray(b, np.float64)
+    x = np.array(x0, np.float64, copy=True)
+    info = capi.SolveInfo()
+    capi.check(lib.avs_pcg_csr(len(bb), rp.ctypes.data, cl.ctypes.data, vl.ctypes.data, bb.ctypes.data,
+                               x.ctypes.data, float(tol), int(max_iters), capi.MEM_HOST, device, None,
+                               C.byref(info)))
+    return x, info

@@ -1,0 +1,200 @@
+/*
+ * avs.h -- C ABI of the MI355X-native adaptive variational viscosity hot path.
+ *
+ * Drop-in boundary.  The reference is a Houdini GAS micro-solver whose only
+ * entry point is HDK_AdaptiveViscosity::solveGasSubclass (HDK_AdaptiveViscosity.cpp:126,
+ * "cpp:" below).  The proprietary HDK cannot be compiled against here, so the seam sits
+ * INSIDE that function: everything between cpp:418 ("Precompute stress gradients") and
+ * cpp:653 (end of "Solve Linear System") is replaced by the calls declared in this header.
+ * INTEGRATION.md shows the shim a maintainer adds on the Houdini side.
+ *
+ * Conventions
+ *   - plain C types only; the library never throws; every call returns avs_status and
+ *     avs_last_error() gives a thread-local message for the last failure.
+ *   - all grids are dense, x fastest ("i + rx*(j + ry*k)"), with the sample resolutions of
+ *     SIM_RawField::init (HDK_Utilities.h:13-16; cpp:314-321, 370-392):
+ *       centre (nx,ny,nz)>>level; face a: +1 on a; edge a: +1 on the two other axes.
+ *     HDK's exint (int64) index voxels are int32 here, fp32 label voxels are int8.
+ *   - pointers are host or device memory as told by avs_memspace; the library copies on
+ *     every set_* (the caller keeps ownership, as Houdini does: cpp:29-34, no state survives).
+ *   - one avs_ctx is used by one host thread at a time; different contexts are independent.
+ *   - base resolution must be a power of two per axis (the reference pads to powers of two,
+ *     HDK_OctreeGrid.cpp:18-24; power-of-two input means no padding).
+ */
+#ifndef AVS_H
+#define AVS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVS_MAX_LEVELS 8
+#define AVS_EDGE_STENCIL_CAP 32   /* getEdgeStressFaces emits <= 4 slots x 8 faces, cpp:1789-1907 */
+#define AVS_CENTER_STENCIL_CAP 8  /* getCenterStressFaces emits <= 2 x 4 faces, cpp:1925-1962 */
+#define AVS_EDGE_BOUNDARY_CAP 4
+#define AVS_CENTER_BOUNDARY_CAP 2
+
+typedef enum {
+    AVS_OK = 0,
+    AVS_EINVAL = 1,    /* bad argument / inconsistent inputs (reference: addError + return false, cpp:152-229) */
+    AVS_ENOMEM = 2,
+    AVS_EHIP = 3,      /* a HIP runtime call failed */
+    AVS_ERCCL = 4,     /* an RCCL call failed */
+    AVS_EINTERNAL = 5, /* a reference assert() would have fired (e.g. foundSelf, cpp:2436) */
+    AVS_ESTATE = 6     /* call sequence violated (e.g. solve before assemble) */
+} avs_status;
+
+typedef enum { AVS_MEM_HOST = 0, AVS_MEM_DEVICE = 1 } avs_memspace;
+
+/* HDK_OctreeGrid::OctreeCellLabel, HDK_OctreeGrid.h:33-39 */
+typedef enum { AVS_INACTIVE = 0, AVS_ACTIVE = 1, AVS_UP = 2, AVS_DOWN = 3 } avs_cell_label;
+
+/* index sentinels, HDK_Utilities.h:18-21; values >= 0 are DOF / stress ids */
+#define AVS_UNASSIGNED (-1)
+#define AVS_SOLIDBOUNDARY (-2)
+#define AVS_OUTSIDE (-3)
+
+/* index pyramids created at cpp:337-393 */
+typedef enum {
+    AVS_INDEX_VELOCITY = 0, /* octreeVelocityIndices[level][axis]  (face lattice) */
+    AVS_INDEX_EDGE = 1,     /* edgeStressIndices[level][axis]      (edge lattice) */
+    AVS_INDEX_CENTER = 2    /* centerStressIndices[level]          (centre lattice; axis ignored) */
+} avs_index_kind;
+
+/* fp32 level-0 fields read by the hot path */
+typedef enum {
+    AVS_FIELD_CENTER_WEIGHTS = 0, /* centerIntegrationWeights (cpp:239)            centre */
+    AVS_FIELD_EDGE_WEIGHTS = 1,   /* edgeIntegrationWeights[axis] (cpp:240)        edge a */
+    AVS_FIELD_FACE_WEIGHTS = 2,   /* "faceWeights" vector field (cpp:144)          face a */
+    AVS_FIELD_VISCOSITY = 3,      /* "viscosity" (cpp:203)                         centre */
+    AVS_FIELD_DENSITY = 4,        /* GAS_NAME_DENSITY (cpp:218)                    centre */
+    AVS_FIELD_VELOCITY = 5,       /* GAS_NAME_VELOCITY component (cpp:139)         face a */
+    AVS_FIELD_SOLID_VELOCITY = 6  /* GAS_NAME_COLLISIONVELOCITY component (cpp:142) face a */
+} avs_field_kind;
+
+typedef struct {
+    int32_t nx, ny, nz;             /* level-0 resolution, powers of two */
+    double dx;                      /* level-0 voxel size (getVoxelSize().maxComponent(), cpp:242) */
+    double dt;                      /* timestep (cpp:130) */
+    int32_t levels;                 /* octreeLabels.getOctreeLevels() (cpp:275), 1..AVS_MAX_LEVELS */
+    int32_t use_enhanced_gradients; /* getUseEnhancedGradients() (cpp:438) */
+    int32_t device;                 /* HIP device ordinal */
+    void *stream;                   /* hipStream_t to enqueue on; NULL = the library creates one */
+} avs_desc;
+
+typedef struct {
+    int32_t iterations; /* solver.iterations() (cpp:629) */
+    int32_t converged;  /* 1 if |r|^2 < tol^2 |b|^2 was reached; non-convergence is NOT an error (cpp:645-652) */
+    double error;       /* solver.error() = sqrt(|r|^2/|b|^2) (cpp:630) */
+    double rhs_norm2;
+    int64_t n;          /* octreeVelocityDOFCount */
+    int64_t nnz;
+    double solve_ms;    /* HIP-event time of the PCG loop */
+    double spmv_ms;     /* mean HIP-event time of one SpMV launch during this solve (0 if not sampled) */
+} avs_solve_info;
+
+typedef struct {
+    int64_t n_velocity, n_edge, n_center; /* DOF / stress counts */
+    int64_t nnz;                          /* after duplicate merging */
+    int64_t raw_triplets;                 /* before merging (= size of the reference's triplet list) */
+    double stencil_ms, guess_ms, system_ms, csr_ms; /* HIP-event times of the phases */
+} avs_assembly_info;
+
+typedef struct avs_ctx avs_ctx;
+
+const char *avs_last_error(void);
+const char *avs_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Context.  Replaces the stack-allocated temporaries of solveGasSubclass (cpp:429-470, 507-551).
+ * ---------------------------------------------------------------------------------------- */
+avs_status avs_create(const avs_desc *desc, avs_ctx **out);
+void avs_destroy(avs_ctx *ctx);
+
+/* ------------------------------------------------------------------------------------------
+ * Inputs of the hot path (produced by cpp:233-416 in the reference).
+ * ---------------------------------------------------------------------------------------- */
+/* octreeLabels.getGridLabels(level), HDK_OctreeGrid.h:144-148 */
+avs_status avs_set_labels(avs_ctx *ctx, int32_t level, const int8_t *labels, avs_memspace where);
+/* one grid of the three index pyramids, cpp:337-393 */
+avs_status avs_set_index_field(avs_ctx *ctx, avs_index_kind kind, int32_t level, int32_t axis,
+                               const int32_t *indices, avs_memspace where);
+/* octreeVelocityDOFCount / edgeStressDOFCount / centerStressDOFCount, cpp:355-357, 395-408.
+ * Validated against the uploaded grids (max id + 1). */
+avs_status avs_set_dof_counts(avs_ctx *ctx, int64_t n_velocity, int64_t n_edge, int64_t n_center);
+/* data == NULL selects the constant-field fast path (field()->isConstant, cpp:2090, 2248, 2501) */
+avs_status avs_set_scalar_field(avs_ctx *ctx, avs_field_kind kind, int32_t axis, const float *data,
+                                float constant, avs_memspace where);
+
+/* ------------------------------------------------------------------------------------------
+ * Hot path part 1: assembly (cpp:418-594 + setFromTriplets cpp:613-614).
+ * avs_assemble runs all phases; the single phases are exported for parity tests and for
+ * hosts that want Houdini perf-monitor scopes per phase (cpp:441, 473, 516, 554).
+ * ---------------------------------------------------------------------------------------- */
+avs_status avs_build_stencils(avs_ctx *ctx);      /* buildEdgeStressStencils + buildCenterStress{Stencils,Weights}, cpp:443-498 */
+avs_status avs_build_initial_guess(avs_ctx *ctx); /* buildVelocityMapping, cpp:518-528 */
+avs_status avs_build_system(avs_ctx *ctx);        /* buildOctreeSystemFromStencils + triplet merge, cpp:577-593, 613-614 */
+avs_status avs_assemble(avs_ctx *ctx, avs_assembly_info *info /* may be NULL */);
+
+/* ------------------------------------------------------------------------------------------
+ * Hot path part 2: solve.  Eigen::ConjugateGradient<SparseMatrix<SolveType>, Lower|Upper>
+ * with DiagonalPreconditioner, solveWithGuess(rhs, restrictedVelocity) (cpp:618-630).
+ * ---------------------------------------------------------------------------------------- */
+avs_status avs_solve(avs_ctx *ctx, double tolerance, int32_t max_iterations, avs_solve_info *info);
+
+/* ------------------------------------------------------------------------------------------
+ * Outputs.  avs_get_solution is what cpp:661-707 consumes (viscositySolution).
+ * The others exist for parity tests.  Any pointer may be NULL to skip that array.
+ * ---------------------------------------------------------------------------------------- */
+avs_status avs_get_assembly_info(avs_ctx *ctx, avs_assembly_info *info);
+avs_status avs_get_solution(avs_ctx *ctx, double *x, int64_t n, avs_memspace where);
+avs_status avs_get_initial_guess(avs_ctx *ctx, double *x0, int64_t n, avs_memspace where);
+avs_status avs_get_csr(avs_ctx *ctx, int32_t *row_ptr /* n+1 */, int32_t *col, double *val,
+                       double *rhs, avs_memspace where);
+/* SoA stencil records: entry k of stencil s lives at [k * count + s].
+ * edge:   count = n_edge,     cap AVS_EDGE_STENCIL_CAP,   boundary cap AVS_EDGE_BOUNDARY_CAP
+ * centre: count = 3*n_center (list id = cell id + n_center*axis, cpp:2186), weights n_center */
+avs_status avs_get_edge_stencils(avs_ctx *ctx, int32_t *cnt, int32_t *idx, double *coef,
+                                 int32_t *bcnt, double *bval, double *weight, avs_memspace where);
+avs_status avs_get_center_stencils(avs_ctx *ctx, int32_t *cnt, int32_t *idx, double *coef,
+                                   int32_t *bcnt, double *bval, double *weight, avs_memspace where);
+
+/* ------------------------------------------------------------------------------------------
+ * Seam A: only the solve (replaces cpp:611-643).  CSR with int32 row pointers/columns, fp64
+ * values; x_inout holds the initial guess on entry and the solution on return.
+ * ---------------------------------------------------------------------------------------- */
+avs_status avs_pcg_csr(int64_t n, const int32_t *row_ptr, const int32_t *col, const double *val,
+                       const double *b, double *x_inout, double tolerance, int32_t max_iterations,
+                       avs_memspace where, int32_t device, void *stream, avs_solve_info *info);
+
+/* One SpMV y = A x on device-resident CSR (measurement entry: the graded kernel).
+ * `variant` selects the kernel (0 = library default).  Enqueues `repeats` launches. */
+avs_status avs_spmv_csr(int64_t n, const int32_t *row_ptr, const int32_t *col, const double *val,
+                        const double *x, double *y, int32_t variant, int32_t repeats, void *stream);
+/* SpMV on the system owned by ctx (after avs_assemble), same kernel the solver uses;
+ * returns the mean HIP-event time per launch in *ms_per_launch. */
+avs_status avs_bench_spmv(avs_ctx *ctx, int32_t variant, int32_t repeats, double *ms_per_launch);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU (no reference counterpart).  One process per GPU.  Every rank holds
+ * the global system description only for its own row block [row_begin, row_end); halo values
+ * of p are exchanged with RCCL send/recv, CG scalars with RCCL all-reduce.
+ * The unique id is created on rank 0 and broadcast by the host program (e.g. torch.distributed).
+ * ---------------------------------------------------------------------------------------- */
+#define AVS_UNIQUE_ID_BYTES 128
+avs_status avs_dist_get_unique_id(uint8_t id[AVS_UNIQUE_ID_BYTES]);
+avs_status avs_dist_init(avs_ctx *ctx, const uint8_t id[AVS_UNIQUE_ID_BYTES], int32_t rank,
+                         int32_t world_size);
+/* Partition the assembled system by contiguous row blocks balanced by nnz; every rank calls it
+ * after avs_assemble on an identical (replicated) pyramid, keeps its own block and frees the rest. */
+avs_status avs_dist_partition(avs_ctx *ctx);
+avs_status avs_dist_solve(avs_ctx *ctx, double tolerance, int32_t max_iterations, avs_solve_info *info);
+/* gathers the full solution on every rank */
+avs_status avs_dist_get_solution(avs_ctx *ctx, double *x, int64_t n, avs_memspace where);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVS_H */
