@@ -142,8 +142,7 @@ void avs_destroy(avs_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->desc.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    extern void avs_dist_release(avs_ctx *);
-    avs_dist_release(c);
+    avs::dist_release(c);
     pcg_destroy(c->pcg);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -6,9 +6,8 @@ namespace avs {
 struct PcgDist {};
 avs_status dist_halo_exchange(PcgDist *, double *, hipStream_t) { set_error("multi-GPU layer not initialised"); return AVS_ESTATE; }
 avs_status dist_allreduce(PcgDist *, double *, int, hipStream_t) { set_error("multi-GPU layer not initialised"); return AVS_ESTATE; }
+void dist_release(avs_ctx *) {}
 } // namespace avs
-
-void avs_dist_release(avs_ctx *) {}
 
 extern "C" {
 avs_status avs_dist_get_unique_id(uint8_t *) { avs::set_error("multi-GPU layer not built yet"); return AVS_ESTATE; }

@@ -13,6 +13,7 @@
 
 #include "avs.h"
 
+struct avs_ctx;
 namespace avs {
 
 // ---------------------------------------------------------------------------------------------
@@ -150,6 +151,7 @@ size_t scan_tmp_elems(int64_t n);
 // multi-GPU hooks called from pcg_solve (implemented in avs_dist.hip)
 avs_status dist_halo_exchange(PcgDist *d, double *p_ext, hipStream_t stream);
 avs_status dist_allreduce(PcgDist *d, double *dev_scalars, int count, hipStream_t stream);
+void dist_release(struct ::avs_ctx *c);
 
 } // namespace avs
 

@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """libavs_hip.so, built in-tree (hipcc cross-compiles without a GPU)."""
+    from adaptiveviscositysolver_amd import capi
+    if not os.path.exists(capi.LIB_PATH):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "adaptiveviscositysolver_amd", "csrc"), "-j8"])
+    return capi.load()

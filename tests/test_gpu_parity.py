@@ -1,0 +1,180 @@
+"""GPU parity tests proper: HIP path (through the C ABI) vs the CPU oracle on identical inputs.
+
+Bars (BASELINE.json north_star): integer work (DOF ids, CSR pattern, stencil indices) bit-exact;
+velocity field within 1e-5 relative L2 with both solvers run to a tight tolerance.  Because the
+assembly kernels follow the reference's operation order with one rounding per operation, the
+fp64 stencil coefficients, weights, CSR values, rhs and initial guess are ALSO required bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from adaptiveviscositysolver_amd import ViscositySolve, capi, pcg_csr, prepass, scenes
+from util import oracle_for_scene, oracle_from_pyramid, rel_l2
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SCENES = {
+    "beam32": lambda dev: scenes.fat_beam(32, 3, device=dev),
+    "beam64_L2": lambda dev: scenes.fat_beam(64, 2, device=dev),              # BASELINE configs[0]
+    "beam64_L3_wall": lambda dev: scenes.fat_beam(64, 3, wall=True, device=dev),
+    "beam64_varvisc": lambda dev: scenes.fat_beam(64, 4, variable_viscosity=True, device=dev),
+    "sphere64": lambda dev: scenes.sphere(64, 4, device=dev),
+    "sheet64": lambda dev: scenes.thin_sheet(64, 3, thickness_cells=12, device=dev),
+    "beam_noncubic": lambda dev: scenes.fat_beam(64, 3, res=(64, 32, 32), device=dev),
+}
+
+
+def gpu_solve_for(sc, pyr, enhanced=True):
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, use_enhanced_gradients=enhanced, device=0)
+    s.set_pyramid(pyr)
+    s.set_scene_fields(sc)
+    return s
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_assembly_bit_exact(name, dev, built_lib):
+    sc = SCENES[name](dev)
+    pyr = prepass.build_pyramid(sc)
+    s = gpu_solve_for(sc, pyr)
+    ai = s.assemble()
+    sc_h = SCENES[name]("cpu")
+    o = oracle_for_scene(sc_h)
+    o.prepass()
+    # the pre-pass run on the GPU (torch) must reproduce the oracle's integer pyramids
+    assert pyr.levels == o.levels
+    assert (pyr.n_velocity, pyr.n_edge, pyr.n_center) == (o.count(0), o.count(1), o.count(2))
+    for l in range(o.levels):
+        assert np.array_equal(pyr.labels[l].cpu().numpy(), o.labels(l))
+        for a in range(3):
+            assert np.array_equal(pyr.vidx[l][a].cpu().numpy(), o.index(O.I_VELOCITY, l, a))
+            assert np.array_equal(pyr.eidx[l][a].cpu().numpy(), o.index(O.I_EDGE, l, a))
+        assert np.array_equal(pyr.cidx[l].cpu().numpy(), o.index(O.I_CENTER, l))
+    o.hot_path()
+    # stencils
+    for got, want in ((s.edge_stencils(), o.edge_stencils()), (s.center_stencils(), o.center_stencils())):
+        for k in ("cnt", "idx", "bcnt"):
+            assert np.array_equal(got[k], want[k]), k
+        for k in ("coef", "bval", "weight"):
+            assert np.array_equal(got[k], want[k]), k
+    assert np.array_equal(s.initial_guess(), o.initial_guess())
+    rp, col, val, rhs = s.csr()
+    A = o.csr()
+    assert ai.n_velocity == A.n and ai.nnz == len(A.col) and ai.raw_triplets == o.raw_triplets
+    assert np.array_equal(rp, A.row_ptr.astype(np.int32))
+    assert np.array_equal(col, A.col)
+    assert np.array_equal(val, A.val)
+    assert np.array_equal(rhs, A.rhs)
+
+
+@pytest.mark.parametrize("name", ["beam32", "beam64_L3_wall", "beam64_varvisc", "sphere64"])
+def test_solve_matches_oracle(name, dev, built_lib):
+    sc = SCENES[name](dev)
+    pyr = prepass.build_pyramid(sc)
+    s = gpu_solve_for(sc, pyr)
+    s.assemble()
+    tol = 1e-10  # tight: at 1e-3 two correct CGs may differ by 1e-3 (SURVEY 7 "hard parts")
+    info = s.solve(tol, 5000)
+    x = s.solution()
+    o = oracle_from_pyramid(SCENES[name]("cpu"), pyr)
+    o.hot_path()
+    xo, io = o.solve(tol, 5000)
+    assert info.converged == 1
+    assert abs(info.iterations - io.iterations) <= 3, (info.iterations, io.iterations)
+    assert rel_l2(x, xo) < 1e-5          # north_star tolerance
+    assert info.error <= tol
+    # default tolerance run: iteration counts agree within a few
+    info3 = s.solve(1e-3, 2500)
+    _, io3 = o.solve(1e-3, 2500)
+    assert abs(info3.iterations - io3.iterations) <= 3, (info3.iterations, io3.iterations)
+
+
+def test_enhanced_gradients_off(dev, built_lib):
+    sc = scenes.sphere(64, 4, device=dev)
+    sc.use_enhanced_gradients = False
+    pyr = prepass.build_pyramid(sc)
+    s = gpu_solve_for(sc, pyr, enhanced=False)
+    s.assemble()
+    sc_h = scenes.sphere(64, 4)
+    sc_h.use_enhanced_gradients = False
+    o = oracle_from_pyramid(sc_h, pyr)
+    o.hot_path()
+    rp, col, val, rhs = s.csr()
+    A = o.csr()
+    assert np.array_equal(rp, A.row_ptr.astype(np.int32)) and np.array_equal(col, A.col)
+    assert np.array_equal(val, A.val) and np.array_equal(rhs, A.rhs)
+
+
+def test_rigid_translation_is_a_fixed_point(dev, built_lib):
+    """D u = 0 for a rigid translation => A u = M u, b = M u, x0 = u: zero iterations."""
+    sc = scenes.sphere(64, 4, device=dev)
+    sc.velocity = scenes.constant_velocity(sc.res, (0.25, -1.5, 0.75), device=dev)
+    pyr = prepass.build_pyramid(sc)
+    s = gpu_solve_for(sc, pyr)
+    s.assemble()
+    info = s.solve(1e-8, 100)
+    assert info.iterations == 0 and info.converged == 1
+    x = s.solution()
+    assert np.array_equal(x, s.initial_guess())
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+def test_spmv_variants(variant, dev, built_lib):
+    sc = scenes.fat_beam(64, 3, device=dev)
+    pyr = prepass.build_pyramid(sc)
+    s = gpu_solve_for(sc, pyr)
+    s.assemble()
+    rp, col, val, rhs = s.csr()
+    n = len(rhs)
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal(n)
+    want = O.spmv_csr(rp.astype(np.int64), col, val, x)
+    lib = capi.load()
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d_rp, d_col, d_val, d_x = t(rp), t(col), t(val), t(x)
+    d_y = torch.zeros(n, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    capi.check(lib.avs_spmv_csr(n, d_rp.data_ptr(), d_col.data_ptr(), d_val.data_ptr(), d_x.data_ptr(),
+                                d_y.data_ptr(), variant, 1, stream))
+    torch.cuda.synchronize()
+    got = d_y.cpu().numpy()
+    if variant == 1:   # stream kernel sums each row left to right like the oracle: bit-exact
+        assert np.array_equal(got, want)
+    else:
+        assert np.allclose(got, want, rtol=1e-13, atol=1e-9 * np.abs(want).max())
+
+
+def test_seam_a_pcg_csr_host_arrays(dev, built_lib):
+    sc = scenes.fat_beam(32, 3)
+    o = oracle_for_scene(sc)
+    o.prepass()
+    o.hot_path()
+    A = o.csr()
+    x0 = o.initial_guess()
+    x, info = pcg_csr(A.row_ptr, A.col, A.val, A.rhs, x0, 1e-10, 5000)
+    xo, io = o.solve(1e-10, 5000)
+    assert info.converged == 1 and abs(info.iterations - io.iterations) <= 3
+    assert rel_l2(x, xo) < 1e-5
+    # zero right-hand side => x = 0, 0 iterations (Eigen: x.setZero())
+    xz, iz = pcg_csr(A.row_ptr, A.col, A.val, np.zeros_like(A.rhs), x0, 1e-3, 10)
+    assert iz.iterations == 0 and not xz.any()
+
+
+def test_error_paths(dev, built_lib):
+    with pytest.raises(capi.AvsError) as e:
+        ViscositySolve((48, 32, 32), 1 / 32, 0.01, 2)
+    assert e.value.status == capi.EINVAL
+    s = ViscositySolve((32, 32, 32), 1 / 32, 0.01, 2)
+    with pytest.raises(capi.AvsError) as e:
+        s.solve()
+    assert e.value.status == capi.ESTATE
+    with pytest.raises(capi.AvsError) as e:
+        s.assemble()
+    assert e.value.status == capi.ESTATE

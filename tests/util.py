@@ -1,0 +1,58 @@
+"""Shared helpers for tests / smoke / bench cpu_baseline: scene -> oracle, comparisons."""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import oracle as O  # noqa: E402
+
+
+def _np(t):
+    return t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+
+
+def oracle_for_scene(sc, enhanced=None):
+    """CPU oracle loaded with the fields of a scenes.Scene (host tensors)."""
+    o = O.Oracle(*sc.res, sc.dx, sc.dt, sc.levels,
+                 sc.use_enhanced_gradients if enhanced is None else enhanced)
+    o.set_field(O.F_LIQUID, _np(sc.liquid))
+    if sc.solid is not None:
+        o.set_field(O.F_SOLID, _np(sc.solid))
+    for kind, v in ((O.F_VISCOSITY, sc.viscosity), (O.F_DENSITY, sc.density)):
+        if isinstance(v, (int, float)):
+            o.set_field(kind, None, float(v))
+        else:
+            o.set_field(kind, _np(v))
+    for a in range(3):
+        o.set_field(O.F_VELOCITY + a, _np(sc.velocity[a]))
+        if sc.solid_velocity is not None:
+            o.set_field(O.F_SOLIDVEL + a, _np(sc.solid_velocity[a]))
+    return o
+
+
+def oracle_from_pyramid(sc, pyr):
+    """Oracle whose hot-path INPUTS are taken from a prepass.Pyramid (instead of its own pre-pass)."""
+    o = oracle_for_scene(sc)
+    o.set_levels(pyr.levels)
+    o.set_field(O.F_CENTERW, _np(pyr.center_weights))
+    for a in range(3):
+        o.set_field(O.F_EDGEW + a, _np(pyr.edge_weights[a]))
+        o.set_field(O.F_FACEW + a, _np(pyr.face_weights[a]))
+    for l in range(pyr.levels):
+        o.set_labels(l, _np(pyr.labels[l]))
+        for a in range(3):
+            o.set_index(O.I_VELOCITY, l, a, _np(pyr.vidx[l][a]))
+            o.set_index(O.I_EDGE, l, a, _np(pyr.eidx[l][a]))
+        o.set_index(O.I_CENTER, l, 0, _np(pyr.cidx[l]))
+    o.finalize_indices()
+    return o
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300))
