@@ -122,7 +122,7 @@ avs_status avs_create(const avs_desc *d, avs_ctx **out)
     c->desc = *d;
     if (d->stream) c->stream = reinterpret_cast<hipStream_t>(d->stream);
     else {
-        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        if (hipStreamCreate(&c->stream) != hipSuccess) { // blocking: ordered after work on the null stream
             delete c;
             set_error("hipStreamCreate failed");
             return AVS_EHIP;
@@ -410,7 +410,7 @@ avs_status avs_pcg_csr(int64_t n, const int32_t *row_ptr, const int32_t *col, co
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     bool own = false;
     if (!s) {
-        AVS_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        AVS_HIP(hipStreamCreate(&s));
         own = true;
     }
     avs_status rc = AVS_OK;

@@ -45,6 +45,7 @@ struct PcgWork {
     DevBuf<PcgScalars> sc;
     PcgScalars *host_sc = nullptr; // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t evA[kChunk] = {}, evB[kChunk] = {}; // per-launch SpMV timing inside the solve
     size_t npartial = 0;
 };
 
@@ -379,6 +380,12 @@ avs_status pcg_create(PcgWork **out, int64_t n, int64_t n_ext, hipStream_t)
         pcg_destroy(w);
         return AVS_EHIP;
     }
+    for (int i = 0; i < kChunk; ++i)
+        if (hipEventCreate(&w->evA[i]) != hipSuccess || hipEventCreate(&w->evB[i]) != hipSuccess) {
+            set_error("event allocation failed");
+            pcg_destroy(w);
+            return AVS_EHIP;
+        }
     *out = w;
     return AVS_OK;
 }
@@ -389,6 +396,10 @@ void pcg_destroy(PcgWork *w)
     if (w->host_sc) (void)hipHostFree(w->host_sc);
     if (w->ev0) (void)hipEventDestroy(w->ev0);
     if (w->ev1) (void)hipEventDestroy(w->ev1);
+    for (int i = 0; i < kChunk; ++i) {
+        if (w->evA[i]) (void)hipEventDestroy(w->evA[i]);
+        if (w->evB[i]) (void)hipEventDestroy(w->evB[i]);
+    }
     delete w;
 }
 
@@ -438,17 +449,34 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
     AVS_TRY(reduce_stage(w, g, 1, OP_RHO0, tol, 0, stream, dist));
     AVS_HIP(hipGetLastError());
 
-    int enqueued = 0;
+    int enqueued = 0, last_chunk = 0;
+    double spmv_ms_sum = 0.;
+    int spmv_samples = 0;
+    const bool sample = (info != nullptr);
     bool finished = false;
     while (!finished) {
         AVS_HIP(hipMemcpyAsync(w->host_sc, sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, stream));
         AVS_HIP(hipStreamSynchronize(stream));
+        if (sample && last_chunk > 0) {
+            // SpMV launches that really ran: iterations 0..iter (the one that detected convergence included)
+            const int ran = w->host_sc->iter + (w->host_sc->done == 1 ? 1 : 0);
+            const int first = enqueued - last_chunk;
+            for (int c2 = 0; c2 < last_chunk && first + c2 < ran; ++c2) {
+                float ems = 0.f;
+                if (hipEventElapsedTime(&ems, w->evA[c2], w->evB[c2]) == hipSuccess) {
+                    spmv_ms_sum += ems;
+                    ++spmv_samples;
+                }
+            }
+        }
         if (w->host_sc->done || enqueued >= max_iters) break;
         const int chunk = (max_iters - enqueued) < kChunk ? (max_iters - enqueued) : kChunk;
         for (int c = 0; c < chunk; ++c) {
             int nb = 0;
             if (dist) AVS_TRY(dist_halo_exchange(dist, p, stream));
+            if (sample) AVS_HIP(hipEventRecord(w->evA[c], stream));
             AVS_TRY(spmv_dispatch<true>(A, p, t, partial, sc, variant, stream, &nb)); // tmp = A p ; p.tmp
+            if (sample) AVS_HIP(hipEventRecord(w->evB[c], stream));
             AVS_TRY(reduce_stage(w, nb, 1, OP_ALPHA, tol, 1, stream, dist));
             hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(kBlock), 0, stream, n, x, r, p, t, invd, sc, partial);
             AVS_TRY(reduce_stage(w, g, 2, OP_BETA, tol, 1, stream, dist));
@@ -456,6 +484,7 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
         }
         AVS_HIP(hipGetLastError());
         enqueued += chunk;
+        last_chunk = chunk;
     }
     AVS_HIP(hipEventRecord(w->ev1, stream));
     AVS_HIP(hipEventSynchronize(w->ev1));
@@ -470,7 +499,7 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
         info->n = n;
         info->nnz = A.nnz;
         info->solve_ms = ms;
-        info->spmv_ms = 0.;
+        info->spmv_ms = spmv_samples ? spmv_ms_sum / spmv_samples : 0.;
     }
     return AVS_OK;
 }

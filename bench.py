@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""bench.py -- the hot path (assemble + Jacobi-PCG solve) on the BASELINE.json headline workload.
+
+A "step" is one full pass of the hot path (cpp:418-653 of the reference) over one synthetic
+input: on-device assembly of the octree viscosity system + the CG solve at the reference's
+default tolerance (1e-3, max 2500 iterations).  Inputs (SDF, weights, label / index pyramids,
+velocity) are synthesised in HBM before the timed region.
+
+  metric  : CG iterations per second (whole job) -- BASELINE.json "CG iterations/sec + SpMV GB/s"
+  roofline: the SpMV kernel (k_spmv_stream), algorithmic bytes 12*nnz + 4*(n+1) + 16*n per launch
+             over the mean HIP-event duration of the SpMV launches inside the
+            timed solves; peak = 8 TB/s HBM (MI355X_MICROARCH.md)
+  cpu_baseline: the CPU oracle's PCG (port of the Eigen algorithm) on the same CSR system, a
+            bounded number of iterations on the host cores of this box (rank 0, N=1 only)
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 under torch.distributed.run.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBPS = 8000.0  # MI355X spec; 6290 GB/s is the measured-achievable copy rate
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=512, help="base grid resolution (512 = BASELINE headline)")
+    ap.add_argument("--levels", type=int, default=4)
+    ap.add_argument("--tol", type=float, default=1e-3)
+    ap.add_argument("--max-iters", type=int, default=2500)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(solver, tol, budget_s):
+    """Oracle PCG (kind 'port') on the same system, bounded iteration count, all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle as O
+    rp, col, val, rhs = solver.csr()
+    x0 = solver.initial_guess()
+    rp64 = rp.astype(np.int64)
+    threads = max(1, min(O.max_threads(), os.cpu_count() or 1))
+    _, probe = O.pcg_csr(rp64, col, val, rhs, x0, tol, 3, threads)   # 3 iterations to size the sample
+    per_iter = max(probe.seconds / 3.0, 1e-6)
+    iters = int(max(5, min(2500, budget_s / per_iter)))
+    _, info = O.pcg_csr(rp64, col, val, rhs, x0, tol, iters, threads)
+    done = max(info.iterations, 1)
+    return {"value": done / info.seconds, "unit": "iter/s", "cores": threads, "kind": "port",
+            "sample": f"{done} PCG iterations of the same {len(rhs)}-row system (OpenMP, all vector ops parallel), "
+                      f"{info.seconds:.1f} s; spmv share {info.spmv_seconds / max(info.seconds, 1e-9):.2f}"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from adaptiveviscositysolver_amd import ViscositySolve, prepass, scenes
+
+    # ---- synthetic input, resident in HBM before the timed region -------------------------
+    sc = scenes.fat_beam(a.n, a.levels, device=dev)
+    pyr = prepass.build_pyramid(sc)
+    solver = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=local_rank)
+    solver.set_pyramid(pyr)
+    solver.set_scene_fields(sc)
+    levels = pyr.levels
+    del pyr
+    torch.cuda.empty_cache()
+    if world > 1:
+        solver.dist_init(rank, world)
+
+    def step():
+        solver.assemble()
+        if world > 1:
+            solver.dist_partition()
+            return solver.dist_solve(a.tol, a.max_iters)
+        return solver.solve(a.tol, a.max_iters)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    iters_total = 0
+    spmv_ms = []
+    solve_ms = []
+    for _ in range(a.steps):
+        info = step()
+        iters_total += info.iterations
+        spmv_ms.append(info.spmv_ms)
+        solve_ms.append(info.solve_ms)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ai = solver.info()
+        n, nnz = int(info.n if world == 1 else ai.n_velocity), int(ai.nnz)
+        bytes_spmv = 12 * nnz + 4 * (n + 1) + 16 * n          # whole system (all ranks together)
+        mean_spmv_ms = float(np.mean(spmv_ms))
+        # per-launch algorithmic bytes on THIS rank's block of rows
+        local_bytes = bytes_spmv if world == 1 else float(getattr(solver, "local_spmv_bytes", bytes_spmv / world))
+        achieved = local_bytes / (mean_spmv_ms * 1e-3) / 1e9 if mean_spmv_ms > 0 else 0.0
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+        if os.path.exists(prof):
+            try:
+                rec = json.load(open(prof))
+                if rec.get("n") == n and rec.get("nnz") == nnz:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "cg_iterations_per_sec",
+            "value": iters_total / elapsed,
+            "unit": "iter/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"fat_beam {a.n}^3 base grid, {levels}-level octree, uniform viscosity 1e4, "
+                                   f"assemble + Jacobi-PCG tol {a.tol:g}",
+                       "n_dofs": n, "nnz": nnz, "cg_iterations_per_step": iters_total // a.steps,
+                       "parallelism": f"row-block x{world}" if world > 1 else "single"},
+            "roofline": {"bound": "hbm", "kernel": "k_spmv_stream<DOT>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": local_bytes, "mean_launch_us": mean_spmv_ms * 1e3,
+                         "frac_of_achievable_6290": achieved / 6290.0},
+            "solve_only_iter_per_s": iters_total / (sum(solve_ms) * 1e-3),
+            "assembly_ms": {"stencils": ai.stencil_ms, "initial_guess": ai.guess_ms, "system": ai.system_ms},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(solver, a.tol, a.cpu_seconds)
+            out["speedup_vs_cpu_baseline"] = out["solve_only_iter_per_s"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
