@@ -125,6 +125,127 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(CsrView A, const double 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// SpMV: generic tile kernel for tuning.  One block = BLK rows; knobs: LDS capacity CAP, 16-B/8-B
+// vector streaming (VEC), XCD-contiguous tile ownership (XCD: block b -> XCD b % 8 by the observed
+// dispatch rule; each XCD then owns a contiguous eighth of the rows so x gathers of neighbouring
+// tiles share one L2 -- used for speed only, never for correctness).
+// ---------------------------------------------------------------------------------------------
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef int i2_t __attribute__((ext_vector_type(2)));
+
+template <bool NT, typename T>
+__device__ __forceinline__ T stream_load(const T *p)
+{
+    if (NT) return __builtin_nontemporal_load(p); // read once: do not let the stream evict x from L2
+    return *p;
+}
+
+template <int BLK, int CAP, bool DOT, bool VEC, bool XCD, bool NT>
+__global__ __launch_bounds__(BLK) void k_spmv_tile(CsrView A, const double *__restrict__ x,
+                                                   double *__restrict__ y, double *__restrict__ partial,
+                                                   const PcgScalars *sc, int chunk)
+{
+    if (DOT && sc && sc->done) return;
+    __shared__ double prod[CAP + 2];
+    __shared__ double red[BLK / 64];
+    const int tid = threadIdx.x;
+    int64_t tile = blockIdx.x;
+    if (XCD) {
+        const int64_t ntiles = gridDim.x;
+        if (chunk <= 0) { // each XCD owns one contiguous eighth
+            const int64_t per = ntiles >> 3, rem = ntiles & 7;
+            const int q = blockIdx.x & 7;
+            const int64_t slot = blockIdx.x >> 3;
+            tile = (int64_t)q * per + (q < rem ? q : rem) + slot;
+        } else { // XCDs take turns on chunks of `chunk` consecutive tiles (one moving window)
+            const int64_t super = (int64_t)chunk * 8;
+            const int64_t full = (ntiles / super) * super; // tail keeps the identity mapping
+            if (tile < full) {
+                const int64_t sb = tile / super, r = tile % super;
+                const int q = (int)(r & 7);
+                const int64_t slot = r >> 3;
+                tile = sb * super + (int64_t)q * chunk + slot;
+            }
+        }
+    }
+    const int64_t row0 = tile * BLK;
+    const int64_t row = row0 + tid;
+    const int64_t rlast = (row0 + BLK < A.n) ? row0 + BLK : A.n;
+    const int s_blk = A.row_ptr[row0];
+    const int e_blk = A.row_ptr[rlast];
+    int rs = 0, re = 0;
+    if (row < A.n) {
+        rs = A.row_ptr[row];
+        re = A.row_ptr[row + 1];
+    }
+    double sum = 0.;
+    for (int ts = s_blk; ts < e_blk; ts += CAP) {
+        const int te = (ts + CAP < e_blk) ? ts + CAP : e_blk;
+        int base;
+        if (VEC) {
+            base = ts & ~1;          // even => 16-B aligned doubles, 8-B aligned ints
+            const int te2 = te & ~1; // pairs fully below te
+            int k = base + 2 * tid;
+            for (; k + 2 * BLK < te2; k += 4 * BLK) {
+                const d2_t v0 = stream_load<NT>(reinterpret_cast<const d2_t *>(A.val + k));
+                const d2_t v1 = stream_load<NT>(reinterpret_cast<const d2_t *>(A.val + k + 2 * BLK));
+                const i2_t c0 = stream_load<NT>(reinterpret_cast<const i2_t *>(A.col + k));
+                const i2_t c1 = stream_load<NT>(reinterpret_cast<const i2_t *>(A.col + k + 2 * BLK));
+                const double x00 = x[c0.x], x01 = x[c0.y], x10 = x[c1.x], x11 = x[c1.y];
+                prod[k - base] = v0.x * x00;
+                prod[k - base + 1] = v0.y * x01;
+                prod[k - base + 2 * BLK] = v1.x * x10;
+                prod[k - base + 2 * BLK + 1] = v1.y * x11;
+            }
+            for (; k < te2; k += 2 * BLK) {
+                const d2_t v0 = stream_load<NT>(reinterpret_cast<const d2_t *>(A.val + k));
+                const i2_t c0 = stream_load<NT>(reinterpret_cast<const i2_t *>(A.col + k));
+                prod[k - base] = v0.x * x[c0.x];
+                prod[k - base + 1] = v0.y * x[c0.y];
+            }
+            if (tid == 0 && (te & 1)) prod[te - 1 - base] = A.val[te - 1] * x[A.col[te - 1]];
+        } else {
+            base = ts;
+            int k = ts + tid;
+            for (; k + 3 * BLK < te; k += 4 * BLK) {
+                const double v0 = stream_load<NT>(A.val + k), v1 = stream_load<NT>(A.val + k + BLK),
+                             v2 = stream_load<NT>(A.val + k + 2 * BLK), v3 = stream_load<NT>(A.val + k + 3 * BLK);
+                const int c0 = stream_load<NT>(A.col + k), c1 = stream_load<NT>(A.col + k + BLK),
+                          c2 = stream_load<NT>(A.col + k + 2 * BLK), c3 = stream_load<NT>(A.col + k + 3 * BLK);
+                const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+                prod[k - ts] = v0 * x0;
+                prod[k - ts + BLK] = v1 * x1;
+                prod[k - ts + 2 * BLK] = v2 * x2;
+                prod[k - ts + 3 * BLK] = v3 * x3;
+            }
+            for (; k < te; k += BLK) prod[k - ts] = stream_load<NT>(A.val + k) * x[stream_load<NT>(A.col + k)];
+        }
+        __syncthreads();
+        const int a = rs > ts ? rs : ts;
+        const int b = re < te ? re : te;
+        for (int j = a; j < b; ++j) sum += prod[j - base];
+        __syncthreads();
+    }
+    if (row < A.n) {
+        if (NT) __builtin_nontemporal_store(sum, y + row);
+        else y[row] = sum;
+    }
+    if (DOT) {
+        double d = (row < A.n) ? sum * x[row] : 0.;
+        d = wave_sum(d);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = d;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.;
+            for (int w = 0; w < BLK / 64; ++w) t += red[w];
+            partial[blockIdx.x] = t;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // SpMV: vector variants (LPR lanes per row)
 // ---------------------------------------------------------------------------------------------
@@ -159,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_vec(CsrView A, const double *__
 
 static inline int stream_grid(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
 
-int spmv_default_variant(const CsrView &) { return 1; }
+int spmv_default_variant(const CsrView &) { return 16; } // NT + 16-B vector stream + 16-tile XCD chunks (profiles/r01_spmv_variants.md)
 
 template <bool DOT>
 static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, double *partial,
@@ -185,6 +306,27 @@ static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, do
         g = kVecGrid * 4;
         hipLaunchKernelGGL((k_spmv_vec<16, DOT>), dim3(g), dim3(kBlock), 0, stream, A, x, y, partial, sc);
         break;
+#define AVS_TILE_CASE(ID, BLK, CAP, VEC, XCD, CHUNK, NT)                                                                  \
+    case ID:                                                                                                   \
+        g = (int)((A.n + BLK - 1) / BLK);                                                                      \
+        hipLaunchKernelGGL((k_spmv_tile<BLK, CAP, DOT, VEC, XCD, NT>), dim3(g), dim3(BLK), 0, stream, A, x, y, partial, sc, CHUNK); \
+        break;
+        AVS_TILE_CASE(5, 256, 4096, false, true, 0, false)
+        AVS_TILE_CASE(6, 256, 4096, true, false, 0, false)
+        AVS_TILE_CASE(7, 256, 2048, false, false, 0, false)
+        AVS_TILE_CASE(8, 128, 2048, false, false, 0, false)
+        AVS_TILE_CASE(9, 512, 8192, false, false, 0, false)
+        AVS_TILE_CASE(10, 256, 2048, true, false, 0, false)
+        AVS_TILE_CASE(11, 256, 2048, true, true, 2, false)
+        AVS_TILE_CASE(12, 256, 2048, true, true, 4, false)
+        AVS_TILE_CASE(13, 256, 2048, true, true, 16, false)
+        AVS_TILE_CASE(14, 256, 2048, true, false, 0, true)
+        AVS_TILE_CASE(15, 256, 2048, true, true, 4, true)
+        AVS_TILE_CASE(16, 256, 2048, true, true, 16, true)
+        AVS_TILE_CASE(17, 256, 2048, true, true, 64, true)
+        AVS_TILE_CASE(18, 256, 4096, true, true, 4, true)
+        AVS_TILE_CASE(19, 256, 2048, false, false, 0, true)
+#undef AVS_TILE_CASE
     default:
         set_error("unknown SpMV variant %d", variant);
         return AVS_EINVAL;
@@ -201,7 +343,7 @@ avs_status spmv_launch(const CsrView &A, const double *x, double *y, int variant
 
 static size_t max_partials(int64_t n)
 {
-    size_t a = (size_t)stream_grid(n), b = (size_t)kVecGrid * 4;
+    size_t a = (size_t)((n + 127) / 128), b = (size_t)kVecGrid * 4;
     return 2 * (a > b ? a : b) + 16;
 }
 
@@ -340,16 +482,31 @@ __device__ void apply_scalar_op(PcgScalars *sc, int op, double tol)
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_reduce(const double *__restrict__ partial, int nb, int nred,
-                                                   PcgScalars *sc, int op, double tol, int skip_if_done)
+static constexpr int kRedBlock = 1024;
+__global__ __launch_bounds__(kRedBlock) void k_reduce(const double *__restrict__ partial, int nb, int nred,
+                                                      PcgScalars *sc, int op, double tol, int skip_if_done)
 {
     if (skip_if_done && sc->done) return;
-    __shared__ double red[4];
+    __shared__ double red[kRedBlock / 64];
     for (int q = 0; q < nred; ++q) {
-        double s = 0.;
-        for (int i = threadIdx.x; i < nb; i += kBlock) s += partial[(size_t)q * nb + i];
-        s = block_sum(s, red);
-        if (threadIdx.x == 0) sc->red[q] = s;
+        const double *src = partial + (size_t)q * nb;
+        double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
+        int i = threadIdx.x;
+        for (; i + 3 * kRedBlock < nb; i += 4 * kRedBlock) { // 4 independent loads in flight
+            const double a = src[i], b = src[i + kRedBlock], c = src[i + 2 * kRedBlock], d = src[i + 3 * kRedBlock];
+            s0 += a; s1 += b; s2 += c; s3 += d;
+        }
+        for (; i < nb; i += kRedBlock) s0 += src[i];
+        double s = wave_sum((s0 + s1) + (s2 + s3));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.;
+#pragma unroll
+            for (int w = 0; w < kRedBlock / 64; ++w) t += red[w];
+            sc->red[q] = t;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0 && op != OP_NONE) apply_scalar_op(sc, op, tol);
@@ -407,10 +564,10 @@ static avs_status reduce_stage(PcgWork *w, int nb, int nred, int op, double tol,
                                hipStream_t stream, PcgDist *dist)
 {
     if (!dist) {
-        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, stream, w->partial.p, nb, nred, w->sc.p, op, tol, skip_if_done);
+        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kRedBlock), 0, stream, w->partial.p, nb, nred, w->sc.p, op, tol, skip_if_done);
     } else {
         // local sums -> RCCL all-reduce of sc->red[0..nred) -> scalar update
-        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, stream, w->partial.p, nb, nred, w->sc.p, (int)OP_NONE, tol, 0);
+        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kRedBlock), 0, stream, w->partial.p, nb, nred, w->sc.p, (int)OP_NONE, tol, 0);
         AVS_TRY(dist_allreduce(dist, reinterpret_cast<double *>(reinterpret_cast<char *>(w->sc.p) + offsetof(PcgScalars, red)), nred, stream));
         hipLaunchKernelGGL(k_scalar, dim3(1), dim3(64), 0, stream, w->sc.p, op, tol);
     }

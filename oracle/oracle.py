@@ -108,7 +108,7 @@ class Csr:
 
     def to_scipy(self):
         import scipy.sparse as sp
-        return sp.csr_matrix((self.val, self.col, self.row_ptr), shape=(self.n, self.n))
+        return sp.csr_matrix((self.val, self.col.astype(np.int64), self.row_ptr.astype(np.int64)), shape=(self.n, self.n))
 
 
 class Oracle:

@@ -1,0 +1,67 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/avs.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from adaptiveviscositysolver_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "avs.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(avs_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert header_functions() == sorted(capi.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_symbol(built_lib):
+    raw = ctypes.CDLL(capi.LIB_PATH)
+    for name in header_functions():
+        assert hasattr(raw, name), name
+    assert b"gfx950" in built_lib.avs_version()
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """sizeof of the ctypes mirrors == sizeof in C (gcc compiles include/avs.h as plain C)."""
+    import subprocess
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "avs.h"\nint main(void){printf("%zu %zu %zu\\n", '
+                   'sizeof(avs_desc), sizeof(avs_solve_info), sizeof(avs_assembly_info));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert sizes == [ctypes.sizeof(capi.Desc), ctypes.sizeof(capi.SolveInfo), ctypes.sizeof(capi.AssemblyInfo)]
+
+
+def test_no_cpu_fallback_without_gpu(built_lib):
+    """On a box without a GPU the product must fail loudly (AVS_EHIP), never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from adaptiveviscositysolver_amd import ViscositySolve
+    with pytest.raises(capi.AvsError) as e:
+        ViscositySolve((32, 32, 32), 1 / 32, 0.01, 2)
+    assert e.value.status == capi.EHIP
+    import numpy as np
+    from adaptiveviscositysolver_amd import pcg_csr
+    with pytest.raises(capi.AvsError):
+        pcg_csr(np.array([0, 1], np.int32), np.array([0], np.int32), np.array([1.0]), np.array([1.0]), np.array([0.0]))
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, "adaptiveviscositysolver_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in text.lower().replace("the oracle", "").replace("cpu oracle", "") or \
+                    "import" not in "".join(l for l in text.splitlines() if "oracle" in l.lower()), f
+    for line in open(os.path.join(ROOT, "include", "avs.h")):
+        assert "oracle" not in line.lower()

@@ -125,7 +125,7 @@ def test_rigid_translation_is_a_fixed_point(dev, built_lib):
     assert np.array_equal(x, s.initial_guess())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19])
 def test_spmv_variants(variant, dev, built_lib):
     sc = scenes.fat_beam(64, 3, device=dev)
     pyr = prepass.build_pyramid(sc)
@@ -145,7 +145,7 @@ def test_spmv_variants(variant, dev, built_lib):
                                 d_y.data_ptr(), variant, 1, stream))
     torch.cuda.synchronize()
     got = d_y.cpu().numpy()
-    if variant == 1:   # stream kernel sums each row left to right like the oracle: bit-exact
+    if variant not in (2, 3, 4):   # stream kernels sums each row left to right like the oracle: bit-exact
         assert np.array_equal(got, want)
     else:
         assert np.allclose(got, want, rtol=1e-13, atol=1e-9 * np.abs(want).max())
