@@ -36,9 +36,12 @@ EXPORTED_SYMBOLS = [
     "avs_build_initial_guess", "avs_build_system", "avs_assemble", "avs_solve",
     "avs_get_assembly_info", "avs_get_solution", "avs_get_initial_guess", "avs_get_csr",
     "avs_get_edge_stencils", "avs_get_center_stencils", "avs_pcg_csr", "avs_spmv_csr",
-    "avs_bench_spmv", "avs_dist_get_unique_id", "avs_dist_init", "avs_dist_partition",
-    "avs_dist_solve", "avs_dist_get_solution",
+    "avs_bench_spmv", "avs_get_dof_table", "avs_plan_owners", "avs_plan_create", "avs_plan_get_sizes",
+    "avs_plan_get_arrays", "avs_plan_destroy", "avs_dist_get_unique_id", "avs_dist_init",
+    "avs_local_group_create", "avs_local_group_destroy", "avs_dist_init_local", "avs_dist_partition",
+    "avs_dist_get_plan_sizes", "avs_dist_solve", "avs_dist_get_solution",
 ]
+_VOID_RETURN = ("avs_last_error", "avs_version", "avs_destroy", "avs_plan_destroy", "avs_local_group_destroy")
 
 
 class AvsError(RuntimeError):
@@ -57,6 +60,11 @@ class SolveInfo(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("error", C.c_double),
                 ("rhs_norm2", C.c_double), ("n", C.c_int64), ("nnz", C.c_int64),
                 ("solve_ms", C.c_double), ("spmv_ms", C.c_double)]
+
+
+class PlanSizes(C.Structure):
+    _fields_ = [("n_own", C.c_int64), ("n_halo", C.c_int64), ("nnz_local", C.c_int64), ("n_send", C.c_int64),
+                ("n_peers", C.c_int32)]
 
 
 class AssemblyInfo(C.Structure):
@@ -102,14 +110,26 @@ def load():
     L.avs_pcg_csr.argtypes = [i64, vp, vp, vp, vp, vp, f64, i32, i32, i32, vp, C.POINTER(SolveInfo)]
     L.avs_spmv_csr.argtypes = [i64, vp, vp, vp, vp, vp, i32, i32, vp]
     L.avs_bench_spmv.argtypes = [vp, i32, i32, C.POINTER(f64)]
+    L.avs_get_dof_table.argtypes = [vp, i32, vp, i32]
+    L.avs_plan_owners.argtypes = [i64, vp, vp, i32, i32, i32, i32, vp]
+    L.avs_plan_create.argtypes = [i64, vp, vp, vp, i32, i32, C.POINTER(vp)]
+    L.avs_plan_get_sizes.argtypes = [vp, C.POINTER(PlanSizes)]
+    L.avs_plan_get_arrays.argtypes = [vp] + [vp] * 9
+    L.avs_plan_destroy.argtypes = [vp]
+    L.avs_plan_destroy.restype = None
     L.avs_dist_get_unique_id.argtypes = [vp]
     L.avs_dist_init.argtypes = [vp, vp, i32, i32]
-    L.avs_dist_partition.argtypes = [vp]
+    L.avs_local_group_create.argtypes = [i32, C.POINTER(vp)]
+    L.avs_local_group_destroy.argtypes = [vp]
+    L.avs_local_group_destroy.restype = None
+    L.avs_dist_init_local.argtypes = [vp, vp, i32]
+    L.avs_dist_partition.argtypes = [vp, i32]
+    L.avs_dist_get_plan_sizes.argtypes = [vp, C.POINTER(PlanSizes)]
     L.avs_dist_solve.argtypes = [vp, f64, i32, C.POINTER(SolveInfo)]
     L.avs_dist_get_solution.argtypes = [vp, vp, i64, i32]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
-        if name not in ("avs_last_error", "avs_version", "avs_destroy"):
+        if name not in _VOID_RETURN:
             fn.restype = C.c_int
     _lib = L
     return L
@@ -132,3 +152,42 @@ def ptr_of(buf):
     if not buf.is_contiguous():
         raise ValueError("tensor must be contiguous")
     return buf.data_ptr(), (MEM_DEVICE if buf.is_cuda else MEM_HOST)
+
+
+# --------------------------------------------------------------------------------------------
+# host-side partition planner (no GPU needed)
+# --------------------------------------------------------------------------------------------
+def plan_owners(dof_table, row_ptr, levels, cut_axis, extent_fine, world_size):
+    """owner rank per velocity DOF (spatial slabs balanced by nnz)."""
+    L = load()
+    tab = np.ascontiguousarray(dof_table, np.int32)
+    rp = np.ascontiguousarray(row_ptr, np.int32)
+    n = len(rp) - 1
+    owner = np.empty(n, np.int32)
+    check(L.avs_plan_owners(n, tab.ctypes.data, rp.ctypes.data, levels, cut_axis, extent_fine, world_size,
+                            owner.ctypes.data))
+    return owner
+
+
+def plan_create(row_ptr, col, owner, rank, world_size):
+    """dict with the local structures of `rank` (see avs_plan_get_arrays)."""
+    L = load()
+    rp = np.ascontiguousarray(row_ptr, np.int32)
+    cl = np.ascontiguousarray(col, np.int32)
+    ow = np.ascontiguousarray(owner, np.int32)
+    h = C.c_void_p()
+    check(L.avs_plan_create(len(rp) - 1, rp.ctypes.data, cl.ctypes.data, ow.ctypes.data, rank, world_size, C.byref(h)))
+    try:
+        sz = PlanSizes()
+        check(L.avs_plan_get_sizes(h, C.byref(sz)))
+        a = dict(own_global=np.empty(sz.n_own, np.int32), halo_global=np.empty(sz.n_halo, np.int32),
+                 row_ptr_local=np.empty(sz.n_own + 1, np.int32), col_local=np.empty(sz.nnz_local, np.int32),
+                 val_src=np.empty(sz.nnz_local, np.int32), peers=np.empty(sz.n_peers, np.int32),
+                 send_counts=np.empty(sz.n_peers, np.int32), recv_counts=np.empty(sz.n_peers, np.int32),
+                 send_idx=np.empty(sz.n_send, np.int32))
+        check(L.avs_plan_get_arrays(h, *[a[k].ctypes.data for k in
+                                         ("own_global", "halo_global", "row_ptr_local", "col_local", "val_src",
+                                          "peers", "send_counts", "recv_counts", "send_idx")]))
+    finally:
+        L.avs_plan_destroy(h)
+    return a

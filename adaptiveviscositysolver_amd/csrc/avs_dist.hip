@@ -1,18 +1,416 @@
-// avs_dist.hip -- multi-GPU layer: RCCL halo exchange + all-reduce.  Placeholder
-// until the partitioned solver lands; every entry point reports AVS_ESTATE.
+// avs_dist.hip -- multi-GPU layer of the PCG solve (no reference counterpart).
+//
+// One rank = one GPU = one process.  Each rank keeps the rows of the faces in its spatial slab
+// (avs_partition.cpp), numbered [owned | halo grouped by owner].  Per CG iteration:
+//   C1 halo exchange  pack owned p entries (k_pack) -> ncclSend / ncclRecv inside one group, the
+//                     receive lands directly in the halo tail of p (no unpack kernel);
+//   C2 all-reduce     ncclAllReduce(sum) of 1-2 fp64 scalars, in place in the device scalar block.
+// Both are enqueued on the solver's stream: no host synchronisation inside the iteration.
+// Messages are tiny (tens of KB / 8-16 B): the cost is launch + link latency, not xGMI bandwidth.
+//
+// For single-GPU testing the same code path runs over an in-process transport: "virtual ranks"
+// (one avs_ctx and one host thread each, sharing one device) exchange through device-to-device
+// copies and a host-side rendezvous.  Slow, but it executes the identical partition / halo /
+// reduction logic and is what tests/test_gpu_dist.py checks against the single-rank solve.
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <mutex>
+#include <new>
+
 #include "avs_internal.hpp"
 
+struct avs_local_group {
+    int world = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    long generation = 0;
+    std::vector<avs::PcgDist *> members;
+    std::vector<double> red; // world x 4 staging for all-reduce
+    bool failed = false;
+
+    void barrier()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        const long gen = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return generation != gen; });
+        }
+    }
+};
+
 namespace avs {
-struct PcgDist {};
-avs_status dist_halo_exchange(PcgDist *, double *, hipStream_t) { set_error("multi-GPU layer not initialised"); return AVS_ESTATE; }
-avs_status dist_allreduce(PcgDist *, double *, int, hipStream_t) { set_error("multi-GPU layer not initialised"); return AVS_ESTATE; }
-void dist_release(avs_ctx *) {}
+
+struct PcgDist {
+    int rank = 0, world = 1;
+    ncclComm_t comm = nullptr;
+    avs_local_group *group = nullptr;
+    int device = 0;
+
+    // plan
+    int64_t n_global = 0, n_own = 0, n_halo = 0, n_send = 0, nnz_local = 0;
+    std::vector<int32_t> peers, send_counts, recv_counts, send_offs, recv_offs;
+    DevBuf<int32_t> send_idx, own_global;
+    DevBuf<double> sendbuf;
+
+    // local system
+    DevBuf<int32_t> row_ptr, col;
+    DevBuf<double> val, rhs, x0, x;
+    PcgWork *pcg = nullptr;
+    bool partitioned = false, solved = false;
+};
+
+#define AVS_NCCL(call)                                                                                   \
+    do {                                                                                                 \
+        ncclResult_t r__ = (call);                                                                       \
+        if (r__ != ncclSuccess) {                                                                        \
+            ::avs::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, ncclGetErrorString(r__));      \
+            return AVS_ERCCL;                                                                            \
+        }                                                                                                \
+    } while (0)
+
+__global__ __launch_bounds__(256) void k_pack(const double *__restrict__ p, const int32_t *__restrict__ idx,
+                                              double *__restrict__ out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = p[idx[i]];
+}
+
+__global__ __launch_bounds__(256) void k_scatter_own(const double *__restrict__ x, const int32_t *__restrict__ own_global,
+                                                     double *__restrict__ full, int64_t n_own)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_own) full[own_global[i]] = x[i];
+}
+
+__global__ __launch_bounds__(256) void k_gather_i(const double *__restrict__ src, const int32_t *__restrict__ idx,
+                                                  double *__restrict__ dst, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+// C1: p_ext = [owned | halo]; fills the halo tail from the peers' owned entries
+avs_status dist_halo_exchange(PcgDist *d, double *p_ext, hipStream_t stream)
+{
+    if (d->world == 1) return AVS_OK;
+    if (d->n_send)
+        hipLaunchKernelGGL(k_pack, dim3((unsigned)((d->n_send + 255) / 256)), dim3(256), 0, stream, p_ext, d->send_idx.p,
+                           d->sendbuf.p, d->n_send);
+    if (d->comm) {
+        AVS_NCCL(ncclGroupStart());
+        for (size_t i = 0; i < d->peers.size(); ++i) {
+            if (d->send_counts[i])
+                AVS_NCCL(ncclSend(d->sendbuf.p + d->send_offs[i], (size_t)d->send_counts[i], ncclDouble, d->peers[i], d->comm, stream));
+            if (d->recv_counts[i])
+                AVS_NCCL(ncclRecv(p_ext + d->n_own + d->recv_offs[i], (size_t)d->recv_counts[i], ncclDouble, d->peers[i], d->comm, stream));
+        }
+        AVS_NCCL(ncclGroupEnd());
+        return AVS_OK;
+    }
+    // in-process transport
+    avs_local_group *g = d->group;
+    AVS_REQUIRE(g, AVS_ESTATE, "multi-GPU layer not initialised");
+    AVS_HIP(hipStreamSynchronize(stream)); // my send buffer is packed
+    g->barrier();
+    for (size_t i = 0; i < d->peers.size(); ++i) {
+        if (!d->recv_counts[i]) continue;
+        PcgDist *peer = g->members[(size_t)d->peers[i]];
+        // where does the peer keep what it sends to me?
+        int64_t off = -1;
+        for (size_t j = 0; j < peer->peers.size(); ++j)
+            if (peer->peers[j] == d->rank) off = peer->send_offs[j];
+        AVS_REQUIRE(off >= 0, AVS_EINTERNAL, "peer %d has no send list for rank %d", d->peers[i], d->rank);
+        AVS_HIP(hipMemcpyAsync(p_ext + d->n_own + d->recv_offs[i], peer->sendbuf.p + off,
+                               (size_t)d->recv_counts[i] * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    }
+    AVS_HIP(hipStreamSynchronize(stream));
+    g->barrier(); // nobody repacks before everybody has copied
+    return AVS_OK;
+}
+
+// C2: in-place sum of `count` doubles (count <= 4) over all ranks
+avs_status dist_allreduce(PcgDist *d, double *dev, int count, hipStream_t stream)
+{
+    if (d->world == 1) return AVS_OK;
+    if (d->comm) {
+        AVS_NCCL(ncclAllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, d->comm, stream));
+        return AVS_OK;
+    }
+    avs_local_group *g = d->group;
+    AVS_REQUIRE(g && count <= 4, AVS_ESTATE, "multi-GPU layer not initialised");
+    double h[4] = {0, 0, 0, 0};
+    AVS_HIP(hipMemcpyAsync(h, dev, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, stream));
+    AVS_HIP(hipStreamSynchronize(stream));
+    for (int k = 0; k < count; ++k) g->red[(size_t)d->rank * 4 + k] = h[k];
+    g->barrier();
+    double s[4] = {0, 0, 0, 0};
+    for (int r = 0; r < g->world; ++r) // fixed rank order: every rank computes identical sums
+        for (int k = 0; k < count; ++k) s[k] += g->red[(size_t)r * 4 + k];
+    g->barrier();
+    AVS_HIP(hipMemcpyAsync(dev, s, (size_t)count * sizeof(double), hipMemcpyHostToDevice, stream));
+    AVS_HIP(hipStreamSynchronize(stream));
+    return AVS_OK;
+}
+
+void dist_release(avs_ctx *c)
+{
+    PcgDist *d = c->dist;
+    if (!d) return;
+    pcg_destroy(d->pcg);
+    if (d->comm) (void)ncclCommDestroy(d->comm);
+    delete d;
+    c->dist = nullptr;
+}
+
 } // namespace avs
 
+using namespace avs;
+
 extern "C" {
-avs_status avs_dist_get_unique_id(uint8_t *) { avs::set_error("multi-GPU layer not built yet"); return AVS_ESTATE; }
-avs_status avs_dist_init(avs_ctx *, const uint8_t *, int32_t, int32_t) { avs::set_error("multi-GPU layer not built yet"); return AVS_ESTATE; }
-avs_status avs_dist_partition(avs_ctx *) { avs::set_error("multi-GPU layer not built yet"); return AVS_ESTATE; }
-avs_status avs_dist_solve(avs_ctx *, double, int32_t, avs_solve_info *) { avs::set_error("multi-GPU layer not built yet"); return AVS_ESTATE; }
-avs_status avs_dist_get_solution(avs_ctx *, double *, int64_t, avs_memspace) { avs::set_error("multi-GPU layer not built yet"); return AVS_ESTATE; }
+
+avs_status avs_get_dof_table(avs_ctx *c, avs_index_kind kind, int32_t *table, avs_memspace where)
+{
+    AVS_REQUIRE(c && table, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->tables_ready, AVS_ESTATE, "dof tables not built: call avs_assemble first");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    const DevBuf<int32_t> &t = kind == AVS_INDEX_VELOCITY ? c->vdof : (kind == AVS_INDEX_EDGE ? c->edof : c->cdof);
+    const int64_t n = kind == AVS_INDEX_VELOCITY ? c->n_vel : (kind == AVS_INDEX_EDGE ? c->n_edge : c->n_center);
+    AVS_HIP(copy_out(table, t.p, (size_t)n * 4 * sizeof(int32_t), where, c->stream));
+    AVS_HIP(hipStreamSynchronize(c->stream));
+    return AVS_OK;
 }
+
+avs_status avs_dist_get_unique_id(uint8_t id[AVS_UNIQUE_ID_BYTES])
+{
+    AVS_REQUIRE(id, AVS_EINVAL, "null argument");
+    static_assert(sizeof(ncclUniqueId) <= AVS_UNIQUE_ID_BYTES, "unique id does not fit");
+    ncclUniqueId u;
+    AVS_NCCL(ncclGetUniqueId(&u));
+    memset(id, 0, AVS_UNIQUE_ID_BYTES);
+    memcpy(id, &u, sizeof(u));
+    return AVS_OK;
+}
+
+static avs_status new_dist(avs_ctx *c, int rank, int world)
+{
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(world >= 1 && world <= 32 && rank >= 0 && rank < world, AVS_EINVAL, "rank %d / world %d out of range", rank, world);
+    dist_release(c);
+    c->dist = new (std::nothrow) PcgDist();
+    AVS_REQUIRE(c->dist, AVS_ENOMEM, "out of host memory");
+    c->dist->rank = rank;
+    c->dist->world = world;
+    c->dist->device = c->desc.device;
+    return AVS_OK;
+}
+
+avs_status avs_dist_init(avs_ctx *c, const uint8_t id[AVS_UNIQUE_ID_BYTES], int32_t rank, int32_t world)
+{
+    AVS_REQUIRE(c && id, AVS_EINVAL, "null argument");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    AVS_TRY(new_dist(c, rank, world));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    AVS_NCCL(ncclCommInitRank(&c->dist->comm, world, u, rank));
+    return AVS_OK;
+}
+
+avs_status avs_local_group_create(int32_t world, avs_local_group **out)
+{
+    AVS_REQUIRE(out && world >= 1 && world <= 32, AVS_EINVAL, "bad argument");
+    avs_local_group *g = new (std::nothrow) avs_local_group();
+    AVS_REQUIRE(g, AVS_ENOMEM, "out of host memory");
+    g->world = world;
+    g->members.assign((size_t)world, nullptr);
+    g->red.assign((size_t)world * 4, 0.);
+    *out = g;
+    return AVS_OK;
+}
+
+void avs_local_group_destroy(avs_local_group *g) { delete g; }
+
+avs_status avs_dist_init_local(avs_ctx *c, avs_local_group *g, int32_t rank)
+{
+    AVS_REQUIRE(c && g, AVS_EINVAL, "null argument");
+    AVS_TRY(new_dist(c, rank, g->world));
+    c->dist->group = g;
+    std::lock_guard<std::mutex> lk(g->m);
+    g->members[(size_t)rank] = c->dist;
+    return AVS_OK;
+}
+
+avs_status avs_dist_partition(avs_ctx *c, int32_t cut_axis)
+{
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->dist, AVS_ESTATE, "call avs_dist_init / avs_dist_init_local first");
+    AVS_REQUIRE(c->system_ready, AVS_ESTATE, "avs_assemble must succeed before avs_dist_partition");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    PcgDist *d = c->dist;
+    hipStream_t st = c->stream;
+    const int64_t n = c->n_vel, nnz = c->nnz;
+    if (cut_axis < 0) { // longest axis
+        cut_axis = 0;
+        if (c->desc.ny > c->desc.nx) cut_axis = 1;
+        if (c->desc.nz > (cut_axis == 0 ? c->desc.nx : c->desc.ny)) cut_axis = 2;
+    }
+    AVS_REQUIRE(cut_axis <= 2, AVS_EINVAL, "cut_axis out of range");
+    const int extent = cut_axis == 0 ? c->desc.nx : (cut_axis == 1 ? c->desc.ny : c->desc.nz);
+
+    // pattern + dof table to the host, plan there (pure integer work, avs_partition.cpp)
+    std::vector<int32_t> h_rp((size_t)n + 1), h_col((size_t)nnz), h_tab((size_t)n * 4), h_owner((size_t)n);
+    AVS_HIP(hipMemcpyAsync(h_rp.data(), c->row_ptr.p, h_rp.size() * 4, hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipMemcpyAsync(h_col.data(), c->col.p, h_col.size() * 4, hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipMemcpyAsync(h_tab.data(), c->vdof.p, h_tab.size() * 4, hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipStreamSynchronize(st));
+    AVS_TRY(avs_plan_owners(n, h_tab.data(), h_rp.data(), c->desc.levels, cut_axis, extent, d->world, h_owner.data()));
+    avs_plan *plan = nullptr;
+    AVS_TRY(avs_plan_create(n, h_rp.data(), h_col.data(), h_owner.data(), d->rank, d->world, &plan));
+    avs_plan_sizes sz{};
+    avs_plan_get_sizes(plan, &sz);
+    std::vector<int32_t> own((size_t)sz.n_own), rpl((size_t)sz.n_own + 1), cl((size_t)sz.nnz_local), vs((size_t)sz.nnz_local),
+        peers((size_t)sz.n_peers), sc((size_t)sz.n_peers), rc((size_t)sz.n_peers), sidx((size_t)sz.n_send);
+    avs_plan_get_arrays(plan, own.data(), nullptr, rpl.data(), cl.data(), vs.data(), peers.data(), sc.data(), rc.data(), sidx.data());
+    avs_plan_destroy(plan);
+
+    d->n_global = n;
+    d->n_own = sz.n_own;
+    d->n_halo = sz.n_halo;
+    d->n_send = sz.n_send;
+    d->nnz_local = sz.nnz_local;
+    d->peers = peers;
+    d->send_counts = sc;
+    d->recv_counts = rc;
+    d->send_offs.assign(peers.size(), 0);
+    d->recv_offs.assign(peers.size(), 0);
+    {
+        int32_t so = 0, ro = 0;
+        for (size_t i = 0; i < peers.size(); ++i) {
+            d->send_offs[i] = so;
+            d->recv_offs[i] = ro;
+            so += sc[i];
+            ro += rc[i];
+        }
+    }
+    // upload the local system
+    AVS_TRY(d->own_global.alloc((size_t)sz.n_own));
+    AVS_TRY(d->send_idx.alloc((size_t)sz.n_send));
+    AVS_TRY(d->sendbuf.alloc((size_t)sz.n_send));
+    AVS_TRY(d->row_ptr.alloc((size_t)sz.n_own + 1));
+    AVS_TRY(d->col.alloc((size_t)sz.nnz_local));
+    AVS_TRY(d->val.alloc((size_t)sz.nnz_local));
+    AVS_TRY(d->rhs.alloc((size_t)sz.n_own));
+    AVS_TRY(d->x0.alloc((size_t)sz.n_own));
+    AVS_TRY(d->x.alloc((size_t)sz.n_own));
+    DevBuf<int32_t> d_vs;
+    AVS_TRY(d_vs.alloc((size_t)sz.nnz_local));
+    AVS_HIP(hipMemcpyAsync(d->own_global.p, own.data(), own.size() * 4, hipMemcpyHostToDevice, st));
+    if (sz.n_send) AVS_HIP(hipMemcpyAsync(d->send_idx.p, sidx.data(), sidx.size() * 4, hipMemcpyHostToDevice, st));
+    AVS_HIP(hipMemcpyAsync(d->row_ptr.p, rpl.data(), rpl.size() * 4, hipMemcpyHostToDevice, st));
+    if (sz.nnz_local) {
+        AVS_HIP(hipMemcpyAsync(d->col.p, cl.data(), cl.size() * 4, hipMemcpyHostToDevice, st));
+        AVS_HIP(hipMemcpyAsync(d_vs.p, vs.data(), vs.size() * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_gather_i, dim3((unsigned)((sz.nnz_local + 255) / 256)), dim3(256), 0, st, c->val.p, d_vs.p, d->val.p, sz.nnz_local);
+    }
+    if (sz.n_own) {
+        const unsigned g = (unsigned)((sz.n_own + 255) / 256);
+        hipLaunchKernelGGL(k_gather_i, dim3(g), dim3(256), 0, st, c->rhs.p, d->own_global.p, d->rhs.p, sz.n_own);
+        hipLaunchKernelGGL(k_gather_i, dim3(g), dim3(256), 0, st, c->x0.p, d->own_global.p, d->x0.p, sz.n_own);
+    }
+    AVS_HIP(hipGetLastError());
+    AVS_HIP(hipStreamSynchronize(st));
+    pcg_destroy(d->pcg);
+    d->pcg = nullptr;
+    AVS_TRY(pcg_create(&d->pcg, sz.n_own, sz.n_own + sz.n_halo, st));
+    d->partitioned = true;
+    d->solved = false;
+    return AVS_OK;
+}
+
+avs_status avs_dist_get_plan_sizes(avs_ctx *c, avs_plan_sizes *s)
+{
+    AVS_REQUIRE(c && s, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->dist && c->dist->partitioned, AVS_ESTATE, "call avs_dist_partition first");
+    s->n_own = c->dist->n_own;
+    s->n_halo = c->dist->n_halo;
+    s->nnz_local = c->dist->nnz_local;
+    s->n_send = c->dist->n_send;
+    s->n_peers = (int32_t)c->dist->peers.size();
+    return AVS_OK;
+}
+
+avs_status avs_dist_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_info *info)
+{
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->dist && c->dist->partitioned, AVS_ESTATE, "call avs_dist_partition first");
+    AVS_REQUIRE(tol >= 0. && max_iters >= 0, AVS_EINVAL, "tolerance / max_iterations out of range");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    PcgDist *d = c->dist;
+    AVS_HIP(hipMemcpyAsync(d->x.p, d->x0.p, (size_t)d->n_own * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    CsrView A;
+    A.n = d->n_own;
+    A.nnz = d->nnz_local;
+    A.row_ptr = d->row_ptr.p;
+    A.col = d->col.p;
+    A.val = d->val.p;
+    avs_solve_info local{};
+    AVS_TRY(pcg_solve(d->pcg, A, d->rhs.p, d->x.p, tol, max_iters, c->stream, &local, d));
+    local.n = d->n_global;
+    if (info) *info = local;
+    d->solved = true;
+    return AVS_OK;
+}
+
+avs_status avs_dist_get_solution(avs_ctx *c, double *x, int64_t n, avs_memspace where)
+{
+    AVS_REQUIRE(c && x, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->dist && c->dist->solved, AVS_ESTATE, "no solution: call avs_dist_solve first");
+    PcgDist *d = c->dist;
+    AVS_REQUIRE(n == d->n_global, AVS_EINVAL, "vector length mismatch");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    hipStream_t st = c->stream;
+    DevBuf<double> full;
+    AVS_TRY(full.alloc((size_t)n));
+    AVS_HIP(hipMemsetAsync(full.p, 0, (size_t)n * sizeof(double), st));
+    if (d->n_own)
+        hipLaunchKernelGGL(k_scatter_own, dim3((unsigned)((d->n_own + 255) / 256)), dim3(256), 0, st, d->x.p, d->own_global.p, full.p, d->n_own);
+    if (d->world > 1) {
+        if (d->comm) AVS_NCCL(ncclAllReduce(full.p, full.p, (size_t)n, ncclDouble, ncclSum, d->comm, st));
+        else {
+            // in-process: sum the host copies in rank order
+            avs_local_group *g = d->group;
+            std::vector<double> mine((size_t)n);
+            AVS_HIP(hipMemcpyAsync(mine.data(), full.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+            AVS_HIP(hipStreamSynchronize(st));
+            static std::mutex gm;
+            static std::vector<double> acc;
+            g->barrier();
+            {
+                std::lock_guard<std::mutex> lk(gm);
+                if (acc.size() != (size_t)n) acc.assign((size_t)n, 0.);
+                if (d->rank == 0) std::fill(acc.begin(), acc.end(), 0.);
+            }
+            g->barrier();
+            for (int r = 0; r < g->world; ++r) { // each owner writes disjoint entries; order is irrelevant
+                if (r == d->rank) {
+                    std::lock_guard<std::mutex> lk(gm);
+                    for (int64_t i = 0; i < n; ++i) acc[(size_t)i] += mine[(size_t)i];
+                }
+                g->barrier();
+            }
+            AVS_HIP(hipMemcpyAsync(full.p, acc.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+            AVS_HIP(hipStreamSynchronize(st));
+            g->barrier();
+        }
+    }
+    AVS_HIP(copy_out(x, full.p, (size_t)n * sizeof(double), where, st));
+    AVS_HIP(hipStreamSynchronize(st));
+    return AVS_OK;
+}
+
+} // extern "C"

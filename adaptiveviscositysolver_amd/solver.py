@@ -119,6 +119,52 @@ class ViscositySolve:
         capi.check(self.lib.avs_solve(self.h, float(tol), int(max_iters), C.byref(info)))
         return info
 
+    # ---- multi-GPU ---------------------------------------------------------------------------
+    def dist_init(self, rank, world):
+        """RCCL communicator: the unique id is made on rank 0 and broadcast with torch.distributed."""
+        import torch
+        import torch.distributed as dist
+        ident = torch.zeros(capi.UNIQUE_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_uint8 * capi.UNIQUE_ID_BYTES)()
+            capi.check(self.lib.avs_dist_get_unique_id(buf))
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        t = ident.to(dev)
+        dist.broadcast(t, src=0)
+        raw = bytes(t.cpu().tolist())
+        buf = (C.c_uint8 * capi.UNIQUE_ID_BYTES).from_buffer_copy(raw)
+        capi.check(self.lib.avs_dist_init(self.h, buf, rank, world))
+
+    def dist_init_local(self, group, rank):
+        capi.check(self.lib.avs_dist_init_local(self.h, group, rank))
+
+    def dist_partition(self, cut_axis=-1):
+        capi.check(self.lib.avs_dist_partition(self.h, cut_axis))
+        sz = capi.PlanSizes()
+        capi.check(self.lib.avs_dist_get_plan_sizes(self.h, C.byref(sz)))
+        self.plan_sizes = sz
+        self.local_spmv_bytes = 12 * sz.nnz_local + 4 * (sz.n_own + 1) + 16 * sz.n_own
+        return sz
+
+    def dist_solve(self, tol=1e-3, max_iters=2500):
+        info = capi.SolveInfo()
+        capi.check(self.lib.avs_dist_solve(self.h, float(tol), int(max_iters), C.byref(info)))
+        return info
+
+    def dist_solution(self):
+        n = self.info().n_velocity
+        x = np.empty(n, np.float64)
+        capi.check(self.lib.avs_dist_get_solution(self.h, x.ctypes.data, n, capi.MEM_HOST))
+        return x
+
+    def dof_table(self, kind=capi.INDEX_VELOCITY):
+        i = self.info()
+        n = {capi.INDEX_VELOCITY: i.n_velocity, capi.INDEX_EDGE: i.n_edge, capi.INDEX_CENTER: i.n_center}[kind]
+        t = np.empty((n, 4), np.int32)
+        capi.check(self.lib.avs_get_dof_table(self.h, kind, t.ctypes.data, capi.MEM_HOST))
+        return t
+
     def bench_spmv(self, variant=0, repeats=100):
         ms = C.c_double()
         capi.check(self.lib.avs_bench_spmv(self.h, variant, repeats, C.byref(ms)))

@@ -1,10 +1,12 @@
 #!/usr/bin/env python
 """bench.py -- the hot path (assemble + Jacobi-PCG solve) on the BASELINE.json headline workload.
 
-A "step" is one full pass of the hot path (cpp:418-653 of the reference) over one synthetic
-input: on-device assembly of the octree viscosity system + the CG solve at the reference's
-default tolerance (1e-3, max 2500 iterations).  Inputs (SDF, weights, label / index pyramids,
-velocity) are synthesised in HBM before the timed region.
+A "step" is one Jacobi-PCG solve of the assembled octree viscosity system from the reference's
+warm start (restricted velocity) to the reference's default tolerance (1e-3, max 2500 iterations)
+-- BASELINE.md section 3: "CG iterations/s = iterations / solve wall-clock (device-resident loop,
+including reductions and, multi-GPU, halo + all-reduce)".  The system is assembled on the device
+(cpp:418-594 of the reference) once before the timed region; its time is reported in
+"assembly_ms" / "hot_path_ms" (= assembly + one solve).  Inputs are synthesised in HBM.
 
   metric  : CG iterations per second (whole job) -- BASELINE.json "CG iterations/sec + SpMV GB/s"
   roofline: the SpMV kernel (k_spmv_stream), algorithmic bytes 12*nnz + 4*(n+1) + 16*n per launch
@@ -43,6 +45,7 @@ def parse():
     ap.add_argument("--max-iters", type=int, default=2500)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="run the partitioned path even with one rank")
     return ap.parse_args()
 
 
@@ -90,13 +93,28 @@ def main():
     levels = pyr.levels
     del pyr
     torch.cuda.empty_cache()
-    if world > 1:
-        solver.dist_init(rank, world)
+    use_dist = world > 1 or a.force_dist
+    torch.cuda.synchronize()
+    t_as = time.perf_counter()
+    solver.assemble()
+    torch.cuda.synchronize()
+    assemble_wall_ms = (time.perf_counter() - t_as) * 1e3
+    partition_ms = 0.0
+    if use_dist:
+        if world > 1:
+            solver.dist_init(rank, world)
+        else:
+            import ctypes as C
+            from adaptiveviscositysolver_amd import capi
+            buf = (C.c_uint8 * capi.UNIQUE_ID_BYTES)()
+            capi.check(solver.lib.avs_dist_get_unique_id(buf))
+            capi.check(solver.lib.avs_dist_init(solver.h, buf, 0, 1))
+        t_p = time.perf_counter()
+        solver.dist_partition()
+        partition_ms = (time.perf_counter() - t_p) * 1e3
 
     def step():
-        solver.assemble()
-        if world > 1:
-            solver.dist_partition()
+        if use_dist:
             return solver.dist_solve(a.tol, a.max_iters)
         return solver.solve(a.tol, a.max_iters)
 
@@ -126,11 +144,11 @@ def main():
 
     if rank == 0:
         ai = solver.info()
-        n, nnz = int(info.n if world == 1 else ai.n_velocity), int(ai.nnz)
+        n, nnz = int(ai.n_velocity), int(ai.nnz)
         bytes_spmv = 12 * nnz + 4 * (n + 1) + 16 * n          # whole system (all ranks together)
         mean_spmv_ms = float(np.mean(spmv_ms))
         # per-launch algorithmic bytes on THIS rank's block of rows
-        local_bytes = bytes_spmv if world == 1 else float(getattr(solver, "local_spmv_bytes", bytes_spmv / world))
+        local_bytes = float(solver.local_spmv_bytes) if use_dist else bytes_spmv
         achieved = local_bytes / (mean_spmv_ms * 1e-3) / 1e9 if mean_spmv_ms > 0 else 0.0
         traffic = None
         prof = os.path.join(ROOT, "profiles", "spmv_traffic.json")
@@ -155,19 +173,22 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"fat_beam {a.n}^3 base grid, {levels}-level octree, uniform viscosity 1e4, "
-                                   f"assemble + Jacobi-PCG tol {a.tol:g}",
+                                   f"Jacobi-PCG solve to tol {a.tol:g} (warm start)",
                        "n_dofs": n, "nnz": nnz, "cg_iterations_per_step": iters_total // a.steps,
                        "parallelism": f"row-block x{world}" if world > 1 else "single"},
             "roofline": {"bound": "hbm", "kernel": "k_spmv_stream<DOT>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": local_bytes, "mean_launch_us": mean_spmv_ms * 1e3,
                          "frac_of_achievable_6290": achieved / 6290.0},
-            "solve_only_iter_per_s": iters_total / (sum(solve_ms) * 1e-3),
-            "assembly_ms": {"stencils": ai.stencil_ms, "initial_guess": ai.guess_ms, "system": ai.system_ms},
+            "solve_event_iter_per_s": iters_total / (sum(solve_ms) * 1e-3),
+            "assembly_ms": {"stencils": ai.stencil_ms, "initial_guess": ai.guess_ms, "system": ai.system_ms,
+                            "wall": assemble_wall_ms},
+            "partition_ms": partition_ms,
+            "hot_path_ms": assemble_wall_ms + partition_ms + elapsed / a.steps * 1e3,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(solver, a.tol, a.cpu_seconds)
-            out["speedup_vs_cpu_baseline"] = out["solve_only_iter_per_s"] / out["cpu_baseline"]["value"]
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -177,21 +177,61 @@ avs_status avs_spmv_csr(int64_t n, const int32_t *row_ptr, const int32_t *col, c
  * returns the mean HIP-event time per launch in *ms_per_launch. */
 avs_status avs_bench_spmv(avs_ctx *ctx, int32_t variant, int32_t repeats, double *ms_per_launch);
 
+/* dof -> lattice location tables built by the library from the index pyramids:
+ * 4 x int32 per DOF = (level | axis << 8, i, j, k).  kind selects velocity / edge / centre. */
+avs_status avs_get_dof_table(avs_ctx *ctx, avs_index_kind kind, int32_t *table, avs_memspace where);
+
 /* ------------------------------------------------------------------------------------------
- * Multi-GPU (no reference counterpart).  One process per GPU.  Every rank holds
- * the global system description only for its own row block [row_begin, row_end); halo values
- * of p are exchanged with RCCL send/recv, CG scalars with RCCL all-reduce.
- * The unique id is created on rank 0 and broadcast by the host program (e.g. torch.distributed).
+ * Multi-GPU (the reference is single-process, so nothing here has a counterpart).
+ * One process per GPU.  The octree is cut into spatial slabs along one axis (cuts on multiples of
+ * 2^(levels-1) fine cells); every rank owns the rows of the faces inside its slab, renumbered
+ * locally as [owned | halo grouped by owner]; per CG iteration the halo entries of p travel by
+ * RCCL send/recv and the CG scalars by RCCL all-reduce, both enqueued on the solver's stream.
+ *
+ * Part 1 -- host-side planner (pure integer work on host arrays, usable without a GPU).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct avs_plan avs_plan;
+typedef struct {
+    int64_t n_own, n_halo, nnz_local, n_send;
+    int32_t n_peers;
+} avs_plan_sizes;
+
+/* owner rank of every velocity DOF: slabs along cut_axis balanced by row nnz */
+avs_status avs_plan_owners(int64_t n, const int32_t *dof_table, const int32_t *row_ptr, int32_t levels,
+                           int32_t cut_axis, int32_t extent_fine, int32_t world_size, int32_t *owner_out);
+/* local structures of `rank`: owned rows, halo columns, local CSR pattern, send lists */
+avs_status avs_plan_create(int64_t n, const int32_t *row_ptr, const int32_t *col, const int32_t *owner, int32_t rank,
+                           int32_t world_size, avs_plan **out);
+avs_status avs_plan_get_sizes(const avs_plan *plan, avs_plan_sizes *sizes);
+/* own_global[n_own], halo_global[n_halo] (grouped by owner rank, ascending id), row_ptr_local[n_own+1],
+ * col_local[nnz_local] (local ids: < n_own owned, else n_own + halo position), val_src[nnz_local]
+ * (position of the entry in the global val array), peers[n_peers], send_counts / recv_counts[n_peers],
+ * send_idx[n_send] (owned local ids, peer after peer).  Any pointer may be NULL. */
+avs_status avs_plan_get_arrays(const avs_plan *plan, int32_t *own_global, int32_t *halo_global, int32_t *row_ptr_local,
+                               int32_t *col_local, int32_t *val_src, int32_t *peers, int32_t *send_counts,
+                               int32_t *recv_counts, int32_t *send_idx);
+void avs_plan_destroy(avs_plan *plan);
+
+/* ------------------------------------------------------------------------------------------
+ * Part 2 -- device side.  Transport is RCCL (one process per GPU; the unique id is created on rank
+ * 0 and broadcast by the host program, e.g. through torch.distributed) or, for single-GPU testing,
+ * an in-process group of "virtual ranks" (one avs_ctx + one host thread each, same device).
  * ---------------------------------------------------------------------------------------- */
 #define AVS_UNIQUE_ID_BYTES 128
 avs_status avs_dist_get_unique_id(uint8_t id[AVS_UNIQUE_ID_BYTES]);
-avs_status avs_dist_init(avs_ctx *ctx, const uint8_t id[AVS_UNIQUE_ID_BYTES], int32_t rank,
-                         int32_t world_size);
-/* Partition the assembled system by contiguous row blocks balanced by nnz; every rank calls it
- * after avs_assemble on an identical (replicated) pyramid, keeps its own block and frees the rest. */
-avs_status avs_dist_partition(avs_ctx *ctx);
+avs_status avs_dist_init(avs_ctx *ctx, const uint8_t id[AVS_UNIQUE_ID_BYTES], int32_t rank, int32_t world_size);
+
+typedef struct avs_local_group avs_local_group;
+avs_status avs_local_group_create(int32_t world_size, avs_local_group **out);
+void avs_local_group_destroy(avs_local_group *group);
+avs_status avs_dist_init_local(avs_ctx *ctx, avs_local_group *group, int32_t rank);
+
+/* Every rank calls it after avs_assemble on an identical (replicated) pyramid: keeps its slab of
+ * the system (cut along `cut_axis`, -1 = longest axis) and builds halo / send lists. */
+avs_status avs_dist_partition(avs_ctx *ctx, int32_t cut_axis);
+avs_status avs_dist_get_plan_sizes(avs_ctx *ctx, avs_plan_sizes *sizes);
 avs_status avs_dist_solve(avs_ctx *ctx, double tolerance, int32_t max_iterations, avs_solve_info *info);
-/* gathers the full solution on every rank */
+/* gathers the full solution (global DOF order) on every rank */
 avs_status avs_dist_get_solution(avs_ctx *ctx, double *x, int64_t n, avs_memspace where);
 
 #ifdef __cplusplus

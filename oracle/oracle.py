@@ -289,8 +289,9 @@ def spmv_csr(row_ptr, col, val, x, threads=1):
     cl = np.ascontiguousarray(col, dtype=np.int32)
     vl = np.ascontiguousarray(val, dtype=np.float64)
     xx = np.ascontiguousarray(x, dtype=np.float64)
-    y = np.empty_like(xx)
-    _chk(L.orc_spmv_csr(len(xx), _p(rp), _p(cl), _p(vl), _p(xx), _p(y), threads), "spmv_csr")
+    n = len(rp) - 1                      # rows; x may be longer ([owned | halo] in the partitioned case)
+    y = np.empty(n, dtype=np.float64)
+    _chk(L.orc_spmv_csr(n, _p(rp), _p(cl), _p(vl), _p(xx), _p(y), threads), "spmv_csr")
     return y
 
 

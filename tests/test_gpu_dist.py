@@ -1,0 +1,88 @@
+"""Multi-GPU code path on ONE GPU: virtual ranks (one avs_ctx + one host thread each, in-process
+transport) run avs_dist_partition / avs_dist_solve and must reproduce the single-rank solve.
+The only thing not exercised is the RCCL transport itself (world_size-1 init is checked)."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from adaptiveviscositysolver_amd import ViscositySolve, capi, prepass, scenes
+from util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def make_solver(sc, pyr):
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
+    s.set_pyramid(pyr)
+    s.set_scene_fields(sc)
+    s.assemble()
+    return s
+
+
+@pytest.mark.parametrize("world,cut_axis", [(2, -1), (4, 0), (3, 2)])
+def test_virtual_ranks_match_single_solve(world, cut_axis, built_lib):
+    dev = torch.device("cuda:0")
+    sc = scenes.fat_beam(64, 3, variable_viscosity=True, device=dev)
+    pyr = prepass.build_pyramid(sc)
+    ref = make_solver(sc, pyr)
+    tol = 1e-10
+    iref = ref.solve(tol, 5000)
+    xref = ref.solution()
+    lib = capi.load()
+    grp = C.c_void_p()
+    capi.check(lib.avs_local_group_create(world, C.byref(grp)))
+    solvers = [make_solver(sc, pyr) for _ in range(world)]
+    results, errors = [None] * world, []
+
+    def run(r):
+        try:
+            s = solvers[r]
+            s.dist_init_local(grp, r)
+            sz = s.dist_partition(cut_axis)
+            info = s.dist_solve(tol, 5000)
+            x = s.dist_solution()
+            results[r] = (info.iterations, info.converged, info.error, x, sz.n_own, sz.n_halo, sz.n_peers)
+        except Exception as e:  # pragma: no cover
+            errors.append((r, e))
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert all(r is not None for r in results)
+    n_total = sum(r[4] for r in results)
+    assert n_total == len(xref)
+    for it, conv, err, x, n_own, n_halo, n_peers in results:
+        assert conv == 1 and err <= tol
+        assert abs(it - iref.iterations) <= 3
+        assert rel_l2(x, xref) < 1e-8
+        assert n_halo > 0 and n_peers >= 1
+        assert n_halo < 0.5 * n_own          # slabs: the halo is a surface term
+    assert len({r[0] for r in results}) == 1  # every rank reports the same iteration count
+    for s in solvers:
+        s.close()
+    lib.avs_local_group_destroy(grp)
+
+
+def test_rccl_world_size_one(built_lib):
+    """RCCL transport with a single rank: communicator creation, partition, solve."""
+    dev = torch.device("cuda:0")
+    sc = scenes.fat_beam(32, 3, device=dev)
+    pyr = prepass.build_pyramid(sc)
+    s = make_solver(sc, pyr)
+    ref = s.solve(1e-8, 5000)
+    xref = s.solution()
+    lib = capi.load()
+    buf = (C.c_uint8 * capi.UNIQUE_ID_BYTES)()
+    capi.check(lib.avs_dist_get_unique_id(buf))
+    capi.check(lib.avs_dist_init(s.h, buf, 0, 1))
+    sz = s.dist_partition()
+    assert sz.n_halo == 0 and sz.n_peers == 0 and sz.n_own == len(xref)
+    info = s.dist_solve(1e-8, 5000)
+    assert info.iterations == ref.iterations
+    assert np.array_equal(s.dist_solution(), xref)
