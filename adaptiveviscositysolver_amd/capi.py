@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "avs_build_initial_guess", "avs_build_system", "avs_assemble", "avs_solve",
     "avs_get_assembly_info", "avs_get_solution", "avs_get_initial_guess", "avs_get_csr",
     "avs_get_edge_stencils", "avs_get_center_stencils", "avs_pcg_csr", "avs_spmv_csr",
-    "avs_bench_spmv", "avs_get_dof_table", "avs_plan_owners", "avs_plan_create", "avs_plan_get_sizes",
+    "avs_bench_spmv", "avs_bench_stream", "avs_get_dof_table", "avs_plan_owners", "avs_plan_create", "avs_plan_get_sizes",
     "avs_plan_get_arrays", "avs_plan_destroy", "avs_dist_get_unique_id", "avs_dist_init",
     "avs_local_group_create", "avs_local_group_destroy", "avs_dist_init_local", "avs_dist_partition",
     "avs_dist_get_plan_sizes", "avs_dist_solve", "avs_dist_get_solution",
@@ -110,6 +110,7 @@ def load():
     L.avs_pcg_csr.argtypes = [i64, vp, vp, vp, vp, vp, f64, i32, i32, i32, vp, C.POINTER(SolveInfo)]
     L.avs_spmv_csr.argtypes = [i64, vp, vp, vp, vp, vp, i32, i32, vp]
     L.avs_bench_spmv.argtypes = [vp, i32, i32, C.POINTER(f64)]
+    L.avs_bench_stream.argtypes = [i32, i64, i32, i32, C.POINTER(f64)]
     L.avs_get_dof_table.argtypes = [vp, i32, vp, i32]
     L.avs_plan_owners.argtypes = [i64, vp, vp, i32, i32, i32, i32, vp]
     L.avs_plan_create.argtypes = [i64, vp, vp, vp, i32, i32, C.POINTER(vp)]

@@ -1,6 +1,7 @@
 // avs_api.hip -- the extern "C" surface declared in include/avs.h.
 // Context management, input upload, phase orchestration, read-back.  No kernels here.
 #include <cmath>
+#include <cstdlib>
 #include <new>
 
 #include "avs_internal.hpp"
@@ -272,7 +273,11 @@ avs_status avs_assemble(avs_ctx *c, avs_assembly_info *info)
     t.start();
     AVS_TRY(build_system(c));
     c->ainfo.system_ms = t.stop();
-    c->ainfo.csr_ms = 0.;
+    t.start();
+    c->reordered = false;
+    if (const char *e = getenv("AVS_BRICK_SHIFT")) c->brick_shift = atoi(e);
+    if (c->brick_shift >= 0) AVS_TRY(build_reordered_system(c, c->brick_shift));
+    c->ainfo.csr_ms = t.stop();
     c->ainfo.n_velocity = c->n_vel;
     c->ainfo.n_edge = c->n_edge;
     c->ainfo.n_center = c->n_center;
@@ -299,9 +304,9 @@ static CsrView csr_of(avs_ctx *c)
     CsrView A;
     A.n = c->n_vel;
     A.nnz = c->nnz;
-    A.row_ptr = c->row_ptr.p;
-    A.col = c->col.p;
-    A.val = c->val.p;
+    A.row_ptr = c->reordered ? c->p_row_ptr.p : c->row_ptr.p;
+    A.col = c->reordered ? c->p_col.p : c->col.p;
+    A.val = c->reordered ? c->p_val.p : c->val.p;
     return A;
 }
 
@@ -314,10 +319,17 @@ avs_status avs_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_info *
     const int64_t n = c->n_vel;
     if (c->pcg == nullptr) AVS_TRY(pcg_create(&c->pcg, n, n, c->stream));
     AVS_TRY(c->x.alloc((size_t)n));
-    // solveWithGuess(rhs, viscositySolution): warm start from the restricted velocity (cpp:627)
-    AVS_HIP(hipMemcpyAsync(c->x.p, c->x0.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     avs_solve_info local{};
-    AVS_TRY(pcg_solve(c->pcg, csr_of(c), c->rhs.p, c->x.p, tol, max_iters, c->stream, &local, nullptr));
+    // solveWithGuess(rhs, viscositySolution): warm start from the restricted velocity (cpp:627)
+    if (c->reordered) {
+        AVS_TRY(c->p_x.alloc((size_t)n));
+        AVS_HIP(hipMemcpyAsync(c->p_x.p, c->p_x0.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        AVS_TRY(pcg_solve(c->pcg, csr_of(c), c->p_rhs.p, c->p_x.p, tol, max_iters, c->stream, &local, nullptr));
+        AVS_TRY(unpermute(c, c->p_x.p, c->x.p)); // back to the reference's DOF numbering
+    } else {
+        AVS_HIP(hipMemcpyAsync(c->x.p, c->x0.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        AVS_TRY(pcg_solve(c->pcg, csr_of(c), c->rhs.p, c->x.p, tol, max_iters, c->stream, &local, nullptr));
+    }
     if (info) *info = local;
     c->solved = true;
     return AVS_OK;
@@ -493,10 +505,43 @@ avs_status avs_bench_spmv(avs_ctx *c, int32_t variant, int32_t repeats, double *
     AVS_TRY(y.alloc((size_t)n));
     CsrView A = csr_of(c);
     Timer t(c->stream);
-    AVS_TRY(spmv_launch(A, c->x0.p, y.p, variant, c->stream)); // warm-up
+    const double *xin = c->reordered ? c->p_x0.p : c->x0.p;
+    const bool dot = variant >= 100; // 100 + id: the fused-dot form the solver launches
+    if (dot) variant -= 100;
+    DevBuf<double> partial;
+    if (dot) AVS_TRY(partial.alloc(spmv_partial_elems(n)));
+    AVS_TRY(dot ? spmv_dot_launch(A, xin, y.p, partial.p, variant, c->stream) : spmv_launch(A, xin, y.p, variant, c->stream)); // warm-up
     t.start();
-    for (int i = 0; i < repeats; ++i) AVS_TRY(spmv_launch(A, c->x0.p, y.p, variant, c->stream));
+    for (int i = 0; i < repeats; ++i)
+        AVS_TRY(dot ? spmv_dot_launch(A, xin, y.p, partial.p, variant, c->stream) : spmv_launch(A, xin, y.p, variant, c->stream));
     *ms_per_launch = t.stop() / repeats;
+    return AVS_OK;
+}
+
+
+// Measured stream ceilings (mode 0: read-only 16 B/lane, 1: read-only non-temporal, 2: copy) on
+// `bytes` of HBM; returns GB/s of bytes MOVED (copy counts read + write).
+avs_status avs_bench_stream(int32_t mode, int64_t bytes, int32_t repeats, int32_t device, double *gbps)
+{
+    AVS_REQUIRE(gbps && bytes >= 1024 && repeats > 0, AVS_EINVAL, "bad argument");
+    AVS_HIP(hipSetDevice(device));
+    const int64_t n = bytes / 8;
+    DevBuf<double> a, b, sink;
+    AVS_TRY(a.alloc((size_t)n));
+    AVS_TRY(sink.alloc(8));
+    if (mode == 2) AVS_TRY(b.alloc((size_t)n));
+    hipStream_t st;
+    AVS_HIP(hipStreamCreate(&st));
+    AVS_HIP(hipMemsetAsync(a.p, 0x11, (size_t)n * 8, st));
+    Timer t(st);
+    const int grid = 256 * 8;
+    avs_status rc = stream_probe(mode, a.p, b.p, n, sink.p, grid, st);
+    t.start();
+    for (int i = 0; i < repeats && rc == AVS_OK; ++i) rc = stream_probe(mode, a.p, b.p, n, sink.p, grid, st);
+    const double ms = t.stop() / repeats;
+    (void)hipStreamDestroy(st);
+    if (rc != AVS_OK) return rc;
+    *gbps = (mode == 2 ? 2.0 : 1.0) * (double)n * 8.0 / (ms * 1e-3) / 1e9;
     return AVS_OK;
 }
 

@@ -62,7 +62,7 @@ struct PcgDist {
     DevBuf<int32_t> row_ptr, col;
     DevBuf<double> val, rhs, x0, x;
     PcgWork *pcg = nullptr;
-    bool partitioned = false, solved = false;
+    bool partitioned = false, solved = false, reordered = false;
 };
 
 #define AVS_NCCL(call)                                                                                   \
@@ -263,11 +263,22 @@ avs_status avs_dist_partition(avs_ctx *c, int32_t cut_axis)
     const int extent = cut_axis == 0 ? c->desc.nx : (cut_axis == 1 ? c->desc.ny : c->desc.nz);
 
     // pattern + dof table to the host, plan there (pure integer work, avs_partition.cpp)
+    // the solve works on the brick-major numbering when it exists (avs_reorder.hip): partition THAT system,
+    // so every rank's local rows keep the brick locality; results are mapped back in avs_dist_get_solution
+    const bool ro = c->reordered;
+    const int32_t *g_rp = ro ? c->p_row_ptr.p : c->row_ptr.p, *g_col = ro ? c->p_col.p : c->col.p;
+    const double *g_val = ro ? c->p_val.p : c->val.p, *g_rhs = ro ? c->p_rhs.p : c->rhs.p, *g_x0 = ro ? c->p_x0.p : c->x0.p;
     std::vector<int32_t> h_rp((size_t)n + 1), h_col((size_t)nnz), h_tab((size_t)n * 4), h_owner((size_t)n);
-    AVS_HIP(hipMemcpyAsync(h_rp.data(), c->row_ptr.p, h_rp.size() * 4, hipMemcpyDeviceToHost, st));
-    AVS_HIP(hipMemcpyAsync(h_col.data(), c->col.p, h_col.size() * 4, hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipMemcpyAsync(h_rp.data(), g_rp, h_rp.size() * 4, hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipMemcpyAsync(h_col.data(), g_col, h_col.size() * 4, hipMemcpyDeviceToHost, st));
     AVS_HIP(hipMemcpyAsync(h_tab.data(), c->vdof.p, h_tab.size() * 4, hipMemcpyDeviceToHost, st));
     AVS_HIP(hipStreamSynchronize(st));
+    if (ro) { // dof table in the new numbering
+        std::vector<int32_t> h_perm((size_t)n), t2((size_t)n * 4);
+        AVS_HIP(hipMemcpy(h_perm.data(), c->perm.p, h_perm.size() * 4, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; ++i) memcpy(&t2[(size_t)i * 4], &h_tab[(size_t)h_perm[(size_t)i] * 4], 16);
+        h_tab.swap(t2);
+    }
     AVS_TRY(avs_plan_owners(n, h_tab.data(), h_rp.data(), c->desc.levels, cut_axis, extent, d->world, h_owner.data()));
     avs_plan *plan = nullptr;
     AVS_TRY(avs_plan_create(n, h_rp.data(), h_col.data(), h_owner.data(), d->rank, d->world, &plan));
@@ -315,12 +326,12 @@ avs_status avs_dist_partition(avs_ctx *c, int32_t cut_axis)
     if (sz.nnz_local) {
         AVS_HIP(hipMemcpyAsync(d->col.p, cl.data(), cl.size() * 4, hipMemcpyHostToDevice, st));
         AVS_HIP(hipMemcpyAsync(d_vs.p, vs.data(), vs.size() * 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_gather_i, dim3((unsigned)((sz.nnz_local + 255) / 256)), dim3(256), 0, st, c->val.p, d_vs.p, d->val.p, sz.nnz_local);
+        hipLaunchKernelGGL(k_gather_i, dim3((unsigned)((sz.nnz_local + 255) / 256)), dim3(256), 0, st, g_val, d_vs.p, d->val.p, sz.nnz_local);
     }
     if (sz.n_own) {
         const unsigned g = (unsigned)((sz.n_own + 255) / 256);
-        hipLaunchKernelGGL(k_gather_i, dim3(g), dim3(256), 0, st, c->rhs.p, d->own_global.p, d->rhs.p, sz.n_own);
-        hipLaunchKernelGGL(k_gather_i, dim3(g), dim3(256), 0, st, c->x0.p, d->own_global.p, d->x0.p, sz.n_own);
+        hipLaunchKernelGGL(k_gather_i, dim3(g), dim3(256), 0, st, g_rhs, d->own_global.p, d->rhs.p, sz.n_own);
+        hipLaunchKernelGGL(k_gather_i, dim3(g), dim3(256), 0, st, g_x0, d->own_global.p, d->x0.p, sz.n_own);
     }
     AVS_HIP(hipGetLastError());
     AVS_HIP(hipStreamSynchronize(st));
@@ -328,6 +339,7 @@ avs_status avs_dist_partition(avs_ctx *c, int32_t cut_axis)
     d->pcg = nullptr;
     AVS_TRY(pcg_create(&d->pcg, sz.n_own, sz.n_own + sz.n_halo, st));
     d->partitioned = true;
+    d->reordered = ro;
     d->solved = false;
     return AVS_OK;
 }
@@ -407,6 +419,14 @@ avs_status avs_dist_get_solution(avs_ctx *c, double *x, int64_t n, avs_memspace 
             AVS_HIP(hipStreamSynchronize(st));
             g->barrier();
         }
+    }
+    if (d->reordered) { // back to the reference's DOF numbering
+        DevBuf<double> ref;
+        AVS_TRY(ref.alloc((size_t)n));
+        AVS_TRY(unpermute(c, full.p, ref.p));
+        AVS_HIP(copy_out(x, ref.p, (size_t)n * sizeof(double), where, st));
+        AVS_HIP(hipStreamSynchronize(st));
+        return AVS_OK;
     }
     AVS_HIP(copy_out(x, full.p, (size_t)n * sizeof(double), where, st));
     AVS_HIP(hipStreamSynchronize(st));

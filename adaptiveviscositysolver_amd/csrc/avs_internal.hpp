@@ -142,6 +142,9 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
 // SpMV launchers (variant 0 = default)
 avs_status spmv_launch(const CsrView &A, const double *x, double *y, int variant, hipStream_t stream);
 int spmv_default_variant(const CsrView &A);
+avs_status spmv_dot_launch(const CsrView &A, const double *x, double *y, double *partial, int variant, hipStream_t stream);
+size_t spmv_partial_elems(int64_t n);
+avs_status stream_probe(int mode, const double *a, double *b, int64_t n, double *sink, int grid, hipStream_t st);
 
 // scan (exclusive, int32 -> int32, n+1 outputs: out[n] = total)
 avs_status exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t *block_tmp, size_t block_tmp_elems,
@@ -152,6 +155,8 @@ size_t scan_tmp_elems(int64_t n);
 avs_status dist_halo_exchange(PcgDist *d, double *p_ext, hipStream_t stream);
 avs_status dist_allreduce(PcgDist *d, double *dev_scalars, int count, hipStream_t stream);
 void dist_release(struct ::avs_ctx *c);
+avs_status build_reordered_system(struct ::avs_ctx *c, int brick_shift);
+avs_status unpermute(struct ::avs_ctx *c, const double *xp, double *x);
 
 } // namespace avs
 
@@ -190,6 +195,12 @@ struct avs_ctx {
     avs::DevBuf<int32_t> row_ptr, col;
     int64_t nnz = 0, nraw = 0;
     bool guess_ready = false, system_ready = false, solved = false;
+
+    // brick-major copy of the system used by the solve (avs_reorder.hip); perm: new -> old
+    avs::DevBuf<int32_t> perm, inv, p_row_ptr, p_col;
+    avs::DevBuf<double> p_val, p_rhs, p_x0, p_x;
+    bool reordered = false;
+    int brick_shift = 3; // 8^3 fine cells per brick; < 0 disables the renumbering
     avs_assembly_info ainfo{};
 
     avs::PcgWork *pcg = nullptr;

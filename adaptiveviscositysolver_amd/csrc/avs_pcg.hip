@@ -278,9 +278,45 @@ __global__ __launch_bounds__(kBlock) void k_spmv_vec(CsrView A, const double *__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// stream ceilings of this chip for the access widths the SpMV uses (measurement helpers)
+// ---------------------------------------------------------------------------------------------
+template <bool NT, int MODE>
+__global__ __launch_bounds__(kBlock) void k_stream_probe(const d2_t *__restrict__ a, d2_t *__restrict__ b, int64_t n2,
+                                                         double *__restrict__ sink)
+{
+    double acc = 0.;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    for (; i + 3 * stride < n2; i += 4 * stride) {
+        const d2_t v0 = stream_load<NT>(a + i), v1 = stream_load<NT>(a + i + stride), v2 = stream_load<NT>(a + i + 2 * stride),
+                   v3 = stream_load<NT>(a + i + 3 * stride);
+        if (MODE == 1) { b[i] = v0; b[i + stride] = v1; b[i + 2 * stride] = v2; b[i + 3 * stride] = v3; }
+        else acc += (v0.x + v0.y) + (v1.x + v1.y) + (v2.x + v2.y) + (v3.x + v3.y);
+    }
+    for (; i < n2; i += stride) {
+        const d2_t v0 = stream_load<NT>(a + i);
+        if (MODE == 1) b[i] = v0; else acc += v0.x + v0.y;
+    }
+    if (MODE == 0 && acc == 1.2345e300) sink[0] = acc; // keep the loads alive
+}
+
+avs_status stream_probe(int mode, const double *a, double *b, int64_t n, double *sink, int grid, hipStream_t st)
+{
+    const int64_t n2 = n / 2;
+    switch (mode) {
+    case 0: hipLaunchKernelGGL((k_stream_probe<false, 0>), dim3(grid), dim3(kBlock), 0, st, (const d2_t *)a, (d2_t *)b, n2, sink); break;
+    case 1: hipLaunchKernelGGL((k_stream_probe<true, 0>), dim3(grid), dim3(kBlock), 0, st, (const d2_t *)a, (d2_t *)b, n2, sink); break;
+    case 2: hipLaunchKernelGGL((k_stream_probe<false, 1>), dim3(grid), dim3(kBlock), 0, st, (const d2_t *)a, (d2_t *)b, n2, sink); break;
+    default: set_error("unknown stream probe mode %d", mode); return AVS_EINVAL;
+    }
+    AVS_HIP(hipGetLastError());
+    return AVS_OK;
+}
+
 static inline int stream_grid(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
 
-int spmv_default_variant(const CsrView &) { return 16; } // NT + 16-B vector stream + 16-tile XCD chunks (profiles/r01_spmv_variants.md)
+int spmv_default_variant(const CsrView &) { return 24; } // 512 rows/WG, 32 KiB LDS, 16-B vector + non-temporal stream (profiles/r01_spmv_variants.md)
 
 template <bool DOT>
 static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, double *partial,
@@ -326,6 +362,11 @@ static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, do
         AVS_TILE_CASE(17, 256, 2048, true, true, 64, true)
         AVS_TILE_CASE(18, 256, 4096, true, true, 4, true)
         AVS_TILE_CASE(19, 256, 2048, false, false, 0, true)
+        AVS_TILE_CASE(20, 256, 2048, true, true, 2, true)
+        AVS_TILE_CASE(21, 256, 2048, true, true, 8, true)
+        AVS_TILE_CASE(22, 128, 1024, true, false, 0, true)
+        AVS_TILE_CASE(23, 128, 2048, true, false, 0, true)
+        AVS_TILE_CASE(24, 512, 4096, true, false, 0, true)
 #undef AVS_TILE_CASE
     default:
         set_error("unknown SpMV variant %d", variant);
@@ -336,11 +377,21 @@ static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, do
     return AVS_OK;
 }
 
+static size_t max_partials(int64_t n);
+
 avs_status spmv_launch(const CsrView &A, const double *x, double *y, int variant, hipStream_t stream)
 {
     return spmv_dispatch<false>(A, x, y, nullptr, nullptr, variant, stream, nullptr);
 }
 
+// the form used inside the PCG loop: y = A x and per-block partials of x.y
+avs_status spmv_dot_launch(const CsrView &A, const double *x, double *y, double *partial, int variant, hipStream_t stream)
+{
+    return spmv_dispatch<true>(A, x, y, partial, nullptr, variant, stream, nullptr);
+}
+size_t spmv_partial_elems(int64_t n) { return max_partials(n); }
+
+static size_t max_partials(int64_t n);
 static size_t max_partials(int64_t n)
 {
     size_t a = (size_t)((n + 127) / 128), b = (size_t)kVecGrid * 4;

@@ -1,0 +1,121 @@
+// avs_reorder.hip -- brick-major renumbering of the assembled system for the solve.
+//
+// The reference numbers DOFs (level, axis, 16^3 tile, voxel) (cpp:1566-1593): the u, v and w rows of
+// one spatial tile are millions of ids apart, so the x entries a row-tile gathers are shared with row
+// tiles that run at a completely different time (and on another XCD) -- PMC shows the x vector being
+// pulled ~6x through the L2s (profiles/spmv_traffic.json).  For the solve only, rows/columns are
+// renumbered brick-major: all DOFs (every level, every axis) whose face position falls in one B^3 brick
+// of fine cells become contiguous, in reference-id order inside the brick (stable sort).  The in-row
+// entry order is NOT changed, so every row sum is still the reference's left-to-right sum
+// (bit-identical y); inputs and outputs of the C ABI stay in the reference's numbering.
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "avs_internal.hpp"
+
+namespace avs {
+
+static constexpr int kBlock = 256;
+
+__global__ __launch_bounds__(kBlock) void k_brick_keys(const int32_t *__restrict__ vdof, int64_t n, int nx, int ny, int nz,
+                                                       int shift, uint32_t *__restrict__ keys, int32_t *__restrict__ ids)
+{
+    const int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (d >= n) return;
+    const int4 rec = reinterpret_cast<const int4 *>(vdof)[d];
+    const int level = rec.x & 0xff;
+    int px = rec.y << level, py = rec.z << level, pz = rec.w << level;
+    px = px < nx ? px : nx - 1;
+    py = py < ny ? py : ny - 1;
+    pz = pz < nz ? pz : nz - 1;
+    const uint32_t bx = (uint32_t)(px >> shift), by = (uint32_t)(py >> shift), bz = (uint32_t)(pz >> shift);
+    const uint32_t nbx = (uint32_t)((nx + (1 << shift) - 1) >> shift), nby = (uint32_t)((ny + (1 << shift) - 1) >> shift);
+    keys[d] = (bz * nby + by) * nbx + bx;
+    ids[d] = (int32_t)d;
+}
+
+__global__ __launch_bounds__(kBlock) void k_invert(const int32_t *__restrict__ perm, int64_t n, int32_t *__restrict__ inv,
+                                                   const int32_t *__restrict__ row_ptr, int32_t *__restrict__ len_new)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int32_t old = perm[i];
+    inv[old] = (int32_t)i;
+    len_new[i] = row_ptr[old + 1] - row_ptr[old];
+}
+
+__global__ __launch_bounds__(kBlock) void k_permute_rows(int64_t n, const int32_t *__restrict__ perm, const int32_t *__restrict__ inv,
+                                                         const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+                                                         const double *__restrict__ val, const int32_t *__restrict__ row_ptr_new,
+                                                         int32_t *__restrict__ col_new, double *__restrict__ val_new)
+{
+    const int sub = threadIdx.x & 15;
+    const int64_t group = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 4;
+    const int64_t ngroups = ((int64_t)gridDim.x * kBlock) >> 4;
+    for (int64_t row = group; row < n; row += ngroups) {
+        const int src = row_ptr[perm[row]], dst = row_ptr_new[row], len = row_ptr_new[row + 1] - dst;
+        for (int k = sub; k < len; k += 16) {
+            col_new[dst + k] = inv[col[src + k]];
+            val_new[dst + k] = val[src + k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather_d(const double *__restrict__ src, const int32_t *__restrict__ idx,
+                                                     double *__restrict__ dst, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+static inline unsigned grid_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock > 0 ? (n + kBlock - 1) / kBlock : 1); }
+
+// builds c->perm / c->inv and the permuted system (c->p_*)
+avs_status build_reordered_system(avs_ctx *c, int brick_shift)
+{
+    hipStream_t st = c->stream;
+    const int64_t n = c->n_vel, nnz = c->nnz;
+    AVS_REQUIRE(c->system_ready, AVS_ESTATE, "system not assembled");
+    DevBuf<uint32_t> keys_in, keys_out;
+    DevBuf<int32_t> ids_in, len_new, scan_tmp;
+    AVS_TRY(keys_in.alloc((size_t)n));
+    AVS_TRY(keys_out.alloc((size_t)n));
+    AVS_TRY(ids_in.alloc((size_t)n));
+    AVS_TRY(len_new.alloc((size_t)n + 1));
+    AVS_TRY(scan_tmp.alloc(scan_tmp_elems(n)));
+    AVS_TRY(c->perm.alloc((size_t)n));
+    AVS_TRY(c->inv.alloc((size_t)n));
+    AVS_TRY(c->p_row_ptr.alloc((size_t)n + 1));
+    AVS_TRY(c->p_col.alloc((size_t)nnz));
+    AVS_TRY(c->p_val.alloc((size_t)nnz));
+    AVS_TRY(c->p_rhs.alloc((size_t)n));
+    AVS_TRY(c->p_x0.alloc((size_t)n));
+    if (n == 0) { c->reordered = true; return AVS_OK; }
+    hipLaunchKernelGGL(k_brick_keys, dim3(grid_for(n)), dim3(kBlock), 0, st, c->vdof.p, n, c->desc.nx, c->desc.ny, c->desc.nz,
+                       brick_shift, keys_in.p, ids_in.p);
+    size_t tmp_bytes = 0;
+    AVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in.p, keys_out.p, ids_in.p, c->perm.p, (size_t)n, 0, 32, st));
+    DevBuf<char> tmp;
+    AVS_TRY(tmp.alloc(tmp_bytes));
+    AVS_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_in.p, keys_out.p, ids_in.p, c->perm.p, (size_t)n, 0, 32, st)); // stable
+    hipLaunchKernelGGL(k_invert, dim3(grid_for(n)), dim3(kBlock), 0, st, c->perm.p, n, c->inv.p, c->row_ptr.p, len_new.p);
+    AVS_TRY(exclusive_scan_i32(len_new.p, c->p_row_ptr.p, n, scan_tmp.p, scan_tmp.n, st));
+    hipLaunchKernelGGL(k_permute_rows, dim3(8192), dim3(kBlock), 0, st, n, c->perm.p, c->inv.p, c->row_ptr.p, c->col.p, c->val.p,
+                       c->p_row_ptr.p, c->p_col.p, c->p_val.p);
+    hipLaunchKernelGGL(k_gather_d, dim3(grid_for(n)), dim3(kBlock), 0, st, c->rhs.p, c->perm.p, c->p_rhs.p, n);
+    hipLaunchKernelGGL(k_gather_d, dim3(grid_for(n)), dim3(kBlock), 0, st, c->x0.p, c->perm.p, c->p_x0.p, n);
+    AVS_HIP(hipGetLastError());
+    AVS_HIP(hipStreamSynchronize(st)); // temporaries die here
+    c->reordered = true;
+    return AVS_OK;
+}
+
+// x (reference numbering) = xp[inv]
+avs_status unpermute(avs_ctx *c, const double *xp, double *x)
+{
+    const int64_t n = c->n_vel;
+    if (n) hipLaunchKernelGGL(k_gather_d, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, xp, c->inv.p, x, n);
+    AVS_HIP(hipGetLastError());
+    return AVS_OK;
+}
+
+} // namespace avs

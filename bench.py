@@ -77,7 +77,8 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if world > 1 or under_launcher:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -101,8 +102,8 @@ def main():
     assemble_wall_ms = (time.perf_counter() - t_as) * 1e3
     partition_ms = 0.0
     if use_dist:
-        if world > 1:
-            solver.dist_init(rank, world)
+        if world > 1 or under_launcher:
+            solver.dist_init(rank, world)      # RCCL id made on rank 0, broadcast with torch.distributed
         else:
             import ctypes as C
             from adaptiveviscositysolver_amd import capi
@@ -119,7 +120,7 @@ def main():
         return solver.solve(a.tol, a.max_iters)
 
     def barrier():
-        if world > 1:
+        if world > 1 or under_launcher:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -190,7 +191,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(solver, a.tol, a.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or under_launcher:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -177,6 +177,10 @@ avs_status avs_spmv_csr(int64_t n, const int32_t *row_ptr, const int32_t *col, c
  * returns the mean HIP-event time per launch in *ms_per_launch. */
 avs_status avs_bench_spmv(avs_ctx *ctx, int32_t variant, int32_t repeats, double *ms_per_launch);
 
+/* Measured stream ceilings of the device for the access pattern of the SpMV's matrix stream
+ * (mode 0: read-only 16 B/lane, 1: read-only non-temporal, 2: copy); GB/s of bytes moved. */
+avs_status avs_bench_stream(int32_t mode, int64_t bytes, int32_t repeats, int32_t device, double *gbps);
+
 /* dof -> lattice location tables built by the library from the index pyramids:
  * 4 x int32 per DOF = (level | axis << 8, i, j, k).  kind selects velocity / edge / centre. */
 avs_status avs_get_dof_table(avs_ctx *ctx, avs_index_kind kind, int32_t *table, avs_memspace where);

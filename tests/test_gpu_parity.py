@@ -125,7 +125,7 @@ def test_rigid_translation_is_a_fixed_point(dev, built_lib):
     assert np.array_equal(x, s.initial_guess())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24])
 def test_spmv_variants(variant, dev, built_lib):
     sc = scenes.fat_beam(64, 3, device=dev)
     pyr = prepass.build_pyramid(sc)
@@ -178,3 +178,72 @@ def test_error_paths(dev, built_lib):
     with pytest.raises(capi.AvsError) as e:
         s.assemble()
     assert e.value.status == capi.ESTATE
+
+
+def test_empty_domain_has_no_dofs(dev, built_lib):
+    """No liquid at all (the reference asserts cappedLevel != 0, oct.cpp:206, so the pre-pass yields no
+    levels): a 1-level pyramid of INACTIVE cells / UNASSIGNED indices must assemble and solve as no-ops."""
+    n = 16
+    sc = scenes.fat_beam(n, 1, device=dev)
+    sc.liquid = torch.full_like(sc.liquid, 10.0)
+    assert prepass.build_pyramid(sc).levels == 0
+    s = ViscositySolve((n, n, n), 1.0 / n, 0.01, 1, device=0)
+    s.set_labels(0, torch.zeros((n, n, n), dtype=torch.int8, device=dev))
+    for a in range(3):
+        fs = [n, n, n]
+        fs[2 - a] += 1
+        es = [n + 1, n + 1, n + 1]
+        es[2 - a] -= 1
+        s.set_index_field(capi.INDEX_VELOCITY, 0, a, torch.full(fs, -1, dtype=torch.int32, device=dev))
+        s.set_index_field(capi.INDEX_EDGE, 0, a, torch.full(es, -1, dtype=torch.int32, device=dev))
+    s.set_index_field(capi.INDEX_CENTER, 0, 0, torch.full((n, n, n), -1, dtype=torch.int32, device=dev))
+    s.set_dof_counts(0, 0, 0)
+    ai = s.assemble()
+    assert ai.n_velocity == 0 and ai.nnz == 0
+    info = s.solve(1e-3, 10)
+    assert info.iterations == 0
+    assert len(s.solution()) == 0
+
+
+def test_single_level_uniform_known_answer(dev, built_lib):
+    """1-level tree, liquid everywhere: the GPU matrix row equals the closed form of SURVEY A.8."""
+    n = 16
+    liquid = torch.full((n, n, n), -100.0, dtype=torch.float32, device=dev)
+    sc = scenes.Scene(res=(n, n, n), dx=1.0 / n, dt=0.5, levels=1, liquid=liquid, viscosity=8.0, density=4.0,
+                      velocity=scenes.smooth_velocity((n, n, n), 1.0 / n, device=dev))
+    pyr = prepass.build_pyramid(sc)
+    assert pyr.levels == 1
+    s = gpu_solve_for(sc, pyr)
+    s.assemble()
+    rp, col, val, rhs = s.csr()
+    kappa = sc.dt * sc.viscosity / sc.dx ** 2
+    row = int(pyr.vidx[0][0][n // 2, n // 2, n // 2].item())
+    v = val[rp[row]:rp[row + 1]]
+    c = col[rp[row]:rp[row + 1]]
+    assert len(v) == 15 and v[c == row][0] == sc.density + 8 * kappa
+    assert sorted(np.round(v[c != row] / kappa).astype(int).tolist()) == [-2, -2] + [-1] * 8 + [1] * 4
+    assert rhs[row] == sc.density * s.initial_guess()[row]
+
+
+def test_inconsistent_inputs_are_rejected(dev, built_lib):
+    sc = scenes.fat_beam(32, 3, device=dev)
+    pyr = prepass.build_pyramid(sc)
+    s = gpu_solve_for(sc, pyr)
+    s.set_dof_counts(pyr.n_velocity - 5, pyr.n_edge, pyr.n_center)     # an id >= declared count
+    with pytest.raises(capi.AvsError) as e:
+        s.assemble()
+    assert e.value.status == capi.EINVAL
+    s.set_dof_counts(pyr.n_velocity + 5, pyr.n_edge, pyr.n_center)     # ids missing
+    with pytest.raises(capi.AvsError) as e:
+        s.assemble()
+    assert e.value.status == capi.EINVAL
+    s.set_dof_counts(pyr.n_velocity, pyr.n_edge, pyr.n_center)
+    # corrupt one velocity index so that a stencil no longer contains its row DOF: reference assert -> AVS_EINTERNAL
+    bad = pyr.vidx[0][0].clone()
+    k = torch.nonzero(bad >= 0)[100]
+    k2 = torch.nonzero(bad >= 0)[5000]
+    a, b = bad[tuple(k)].item(), bad[tuple(k2)].item()
+    bad[tuple(k)], bad[tuple(k2)] = b, a
+    s.set_index_field(capi.INDEX_VELOCITY, 0, 0, bad.contiguous())
+    s.assemble()   # still a consistent numbering (a permutation): must assemble
+    assert s.info().n_velocity == pyr.n_velocity
