@@ -1,0 +1,100 @@
+"""BASELINE.json configs at full size on one MI355X, checked through size-independent properties
+(the oracle would take minutes there): symmetry (x.Ay == y.Ax), residual of the returned solution
+recomputed with an independent SpMV kernel, idempotence (re-solving from the solution takes 0
+iterations), rigid translations are fixed points, CSR structural invariants."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from adaptiveviscositysolver_amd import ViscositySolve, capi, prepass, scenes
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    "cfg2_128_L3": lambda dev: scenes.fat_beam(128, 3, device=dev),
+    "cfg3_256_L4_varvisc": lambda dev: scenes.fat_beam(256, 4, variable_viscosity=True, device=dev),
+    "cfg4_512_L4": lambda dev: scenes.fat_beam(512, 4, device=dev),
+}
+
+
+def spmv(lib, rp, col, val, x, variant):
+    y = torch.empty_like(x)
+    capi.check(lib.avs_spmv_csr(len(x), rp.data_ptr(), col.data_ptr(), val.data_ptr(), x.data_ptr(), y.data_ptr(),
+                                variant, 1, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    return y
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_full_size_properties(name, built_lib):
+    dev = torch.device("cuda:0")
+    sc = CONFIGS[name](dev)
+    pyr = prepass.build_pyramid(sc)
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
+    s.set_pyramid(pyr)
+    s.set_scene_fields(sc)
+    ai = s.assemble()
+    n, nnz = ai.n_velocity, ai.nnz
+    assert n == pyr.n_velocity and nnz > 14 * n * 0.8
+    rp = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(nnz, dtype=torch.int32, device=dev)
+    val = torch.empty(nnz, dtype=torch.float64, device=dev)
+    rhs = torch.empty(n, dtype=torch.float64, device=dev)
+    capi.check(s.lib.avs_get_csr(s.h, rp.data_ptr(), col.data_ptr(), val.data_ptr(), rhs.data_ptr(), capi.MEM_DEVICE))
+    # structural invariants: monotone row pointers, sorted unique columns, diagonal present and positive
+    lens = rp[1:] - rp[:-1]
+    assert int(rp[0]) == 0 and int(rp[-1]) == nnz and bool((lens > 0).all())
+    same_row = torch.ones(nnz - 1, dtype=torch.bool, device=dev)
+    same_row[(rp[1:-1] - 1).long()] = False
+    assert bool((col[1:][same_row] > col[:-1][same_row]).all())
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), lens.long())
+    diag = val[col.long() == rows]
+    assert diag.numel() == n and bool((diag > 0).all())
+    assert int(torch.bincount(lens.long()).argmax()) == 15          # uniform interior rows (cpp:539)
+    # symmetry through two random vectors, with two different kernels
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+    y = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+    ax, ay = spmv(s.lib, rp, col, val, x, 24), spmv(s.lib, rp, col, val, y, 3)
+    lhs, rhs_ = float(y @ ax), float(x @ ay)
+    assert abs(lhs - rhs_) <= 1e-10 * max(abs(lhs), abs(rhs_), 1.0)
+    assert float(x @ ax) > 0
+    # solve, then recompute the residual independently (vector kernel, reference-order matrix)
+    tol = 1e-6
+    info = s.solve(tol, 20000)
+    assert info.converged == 1
+    xs = torch.empty(n, dtype=torch.float64, device=dev)
+    capi.check(s.lib.avs_get_solution(s.h, xs.data_ptr(), n, capi.MEM_DEVICE))
+    r = rhs - spmv(s.lib, rp, col, val, xs, 3)
+    rel = float(torch.linalg.norm(r) / torch.linalg.norm(rhs))
+    assert rel <= 1.05 * tol and abs(rel - info.error) <= 0.05 * tol
+    # idempotence: seam A started from the solution needs no iteration
+    si = capi.SolveInfo()
+    x2 = xs.clone()
+    capi.check(s.lib.avs_pcg_csr(n, rp.data_ptr(), col.data_ptr(), val.data_ptr(), rhs.data_ptr(), x2.data_ptr(),
+                                 1.05 * tol, 100, capi.MEM_DEVICE, 0, None, C.byref(si)))
+    assert si.iterations == 0 and torch.equal(x2, xs)
+    # default-tolerance solve: the reference's settings converge well inside its iteration cap
+    info3 = s.solve(1e-3, 2500)
+    assert info3.converged == 1 and info3.error < 1e-3
+    s.close()
+
+
+def test_rigid_translation_at_256(built_lib):
+    dev = torch.device("cuda:0")
+    sc = scenes.fat_beam(256, 4, device=dev)
+    sc.velocity = scenes.constant_velocity(sc.res, (1.0, -0.5, 0.25), device=dev)
+    pyr = prepass.build_pyramid(sc)
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
+    s.set_pyramid(pyr)
+    s.set_scene_fields(sc)
+    s.assemble()
+    info = s.solve(1e-8, 50)
+    assert info.iterations == 0 and info.converged == 1
+    x0 = s.initial_guess()
+    tab = s.dof_table()
+    want = np.array([1.0, -0.5, 0.25])[tab[:, 0] >> 8]
+    assert np.array_equal(x0, want)              # restriction of a constant field is that constant, exactly
+    assert np.array_equal(s.solution(), x0)
