@@ -177,7 +177,7 @@ def main():
                                    f"Jacobi-PCG solve to tol {a.tol:g} (warm start)",
                        "n_dofs": n, "nnz": nnz, "cg_iterations_per_step": iters_total // a.steps,
                        "parallelism": f"row-block x{world}" if world > 1 else "single"},
-            "roofline": {"bound": "hbm", "kernel": "k_spmv_stream<DOT>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": "k_spmv_tile<512,4096,DOT,VEC,NT> on the brick-major system", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": local_bytes, "mean_launch_us": mean_spmv_ms * 1e3,
                          "frac_of_achievable_6290": achieved / 6290.0},
