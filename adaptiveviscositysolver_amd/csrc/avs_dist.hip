@@ -15,6 +15,7 @@
 #include <rccl/rccl.h>
 
 #include <condition_variable>
+#include <cstdlib>
 #include <mutex>
 #include <new>
 
@@ -156,6 +157,14 @@ avs_status dist_allreduce(PcgDist *d, double *dev, int count, hipStream_t stream
     AVS_HIP(hipMemcpyAsync(dev, s, (size_t)count * sizeof(double), hipMemcpyHostToDevice, stream));
     AVS_HIP(hipStreamSynchronize(stream));
     return AVS_OK;
+}
+
+// world > 1: one all-reduce per iteration instead of two (AVS_DIST_CG=standard keeps Eigen's loop)
+bool dist_wants_single_reduction(PcgDist *d)
+{
+    if (!d || d->world <= 1) return false;
+    const char *e = getenv("AVS_DIST_CG");
+    return !(e && strcmp(e, "standard") == 0);
 }
 
 void dist_release(avs_ctx *c)

@@ -155,6 +155,7 @@ size_t scan_tmp_elems(int64_t n);
 avs_status dist_halo_exchange(PcgDist *d, double *p_ext, hipStream_t stream);
 avs_status dist_allreduce(PcgDist *d, double *dev_scalars, int count, hipStream_t stream);
 void dist_release(struct ::avs_ctx *c);
+bool dist_wants_single_reduction(PcgDist *d);
 avs_status build_reordered_system(struct ::avs_ctx *c, int brick_shift);
 avs_status unpermute(struct ::avs_ctx *c, const double *xp, double *x);
 

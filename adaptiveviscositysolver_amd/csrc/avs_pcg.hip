@@ -42,6 +42,7 @@ struct PcgScalars {
 struct PcgWork {
     int64_t n = 0, n_ext = 0;
     DevBuf<double> r, p, t, invd, partial;
+    DevBuf<double> s, u; // single-reduction variant (multi-GPU): s = A p recurrence, u = M^-1 r with halo tail
     DevBuf<PcgScalars> sc;
     PcgScalars *host_sc = nullptr; // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -395,7 +396,7 @@ static size_t max_partials(int64_t n);
 static size_t max_partials(int64_t n)
 {
     size_t a = (size_t)((n + 127) / 128), b = (size_t)kVecGrid * 4;
-    return 2 * (a > b ? a : b) + 16;
+    return 2 * (a > b ? a : b) + 4 * (size_t)kVecGrid + 16;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, double *__restr
 // scalar stages.  One 256-thread block sums `nb` partials of `nred` interleaved arrays in a fixed
 // order (deterministic), then (optionally) applies the scalar update.
 // ---------------------------------------------------------------------------------------------
-enum ScalarOp { OP_NONE = 0, OP_INIT = 1, OP_RHO0 = 2, OP_ALPHA = 3, OP_BETA = 4 };
+enum ScalarOp { OP_NONE = 0, OP_INIT = 1, OP_RHO0 = 2, OP_ALPHA = 3, OP_BETA = 4, OP_SR_INIT = 5, OP_SR_STEP = 6 };
 
 __device__ void apply_scalar_op(PcgScalars *sc, int op, double tol)
 {
@@ -540,13 +541,43 @@ __device__ void apply_scalar_op(PcgScalars *sc, int op, double tol)
             }
         }
         break;
+    case OP_SR_INIT: { // red = [b.b, r.u, r.r, w.u]
+        sc->rhs_norm2 = sc->red[0];
+        sc->rr = sc->red[2];
+        sc->iter = 0;
+        if (sc->red[0] == 0.) { sc->done = 3; sc->rr = 0.; break; }
+        double thr = tol * tol * sc->red[0];
+        const double considerAsZero = 2.2250738585072014e-308;
+        if (thr < considerAsZero) thr = considerAsZero;
+        sc->threshold = thr;
+        if (sc->red[2] < thr) { sc->done = 1; break; }
+        sc->done = 0;
+        sc->rho = sc->red[1];
+        sc->alpha = sc->red[1] / sc->red[3];
+        sc->beta = 0.;
+        break;
+    }
+    case OP_SR_STEP: // red = [r.u, r.r, w.u] after x, r were updated with the current alpha
+        if (!sc->done) {
+            sc->rr = sc->red[1];
+            if (sc->red[1] < sc->threshold) sc->done = 1; // x is already updated: plain "converged"
+            else {
+                const double gamma_old = sc->rho, gamma = sc->red[0], delta = sc->red[2];
+                const double beta = gamma / gamma_old;
+                sc->alpha = gamma / (delta - beta * gamma / sc->alpha);
+                sc->beta = beta;
+                sc->rho = gamma;
+                sc->iter += 1;
+            }
+        }
+        break;
     default: break;
     }
 }
 
 static constexpr int kRedBlock = 1024;
 __global__ __launch_bounds__(kRedBlock) void k_reduce(const double *__restrict__ partial, int nb, int nred,
-                                                      PcgScalars *sc, int op, double tol, int skip_if_done)
+                                                      PcgScalars *sc, int op, double tol, int skip_if_done, int red_off = 0)
 {
     if (skip_if_done && sc->done) {
         if (threadIdx.x == 0 && op == OP_ALPHA && sc->done == 2) sc->done = 1;
@@ -570,7 +601,7 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce(const double *__restrict__
             double t = 0.;
 #pragma unroll
             for (int w = 0; w < kRedBlock / 64; ++w) t += red[w];
-            sc->red[q] = t;
+            sc->red[red_off + q] = t;
         }
     }
     __syncthreads();
@@ -580,6 +611,162 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce(const double *__restrict__
 __global__ void k_scalar(PcgScalars *sc, int op, double tol)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) apply_scalar_op(sc, op, tol);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Single-reduction PCG (Chronopoulos & Gear 1989) -- used when the solve is partitioned over several
+// GPUs: the same Krylov iterates in exact arithmetic, but gamma = r.u, delta = w.u and |r|^2 are
+// all-reduced together, so an iteration has ONE all-reduce and ONE halo exchange (of u = M^-1 r)
+// instead of two all-reduces + one exchange.  Costs one more vector (s = A p by recurrence): 12 n
+// doubles of vector traffic instead of 10 n -- irrelevant once the solve is latency-bound.
+//   u = M^-1 r ; w = A u ; p = u + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_sr_init(int64_t n, const double *__restrict__ b, const double *__restrict__ t,
+                                                    const double *__restrict__ invd, double *__restrict__ r,
+                                                    double *__restrict__ u, double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    double bb = 0., ru = 0., rr = 0.;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double bi = b[i];
+        const double ri = bi - t[i];
+        const double ui = invd[i] * ri;
+        r[i] = ri;
+        u[i] = ui;
+        bb += bi * bi;
+        ru += ri * ui;
+        rr += ri * ri;
+    }
+    bb = block_sum(bb, red);
+    ru = block_sum(ru, red);
+    rr = block_sum(rr, red);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = bb;
+        partial[gridDim.x + blockIdx.x] = ru;
+        partial[2 * gridDim.x + blockIdx.x] = rr;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_sr_update(int64_t n, double *__restrict__ x, double *__restrict__ r,
+                                                      double *__restrict__ p, double *__restrict__ s,
+                                                      double *__restrict__ u, const double *__restrict__ w,
+                                                      const double *__restrict__ invd, const PcgScalars *sc,
+                                                      double *__restrict__ partial)
+{
+    const int done = sc->done;
+    if (done == 3) {
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) x[i] = 0.;
+        return;
+    }
+    if (done) return;
+    __shared__ double red[4];
+    const double alpha = sc->alpha, beta = sc->beta;
+    double ru = 0., rr = 0.;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double pi = u[i] + beta * p[i];
+        const double si = w[i] + beta * s[i];
+        p[i] = pi;
+        s[i] = si;
+        x[i] += alpha * pi;
+        const double ri = r[i] - alpha * si;
+        r[i] = ri;
+        const double ui = invd[i] * ri;
+        u[i] = ui;
+        ru += ri * ui;
+        rr += ri * ri;
+    }
+    ru = block_sum(ru, red);
+    rr = block_sum(rr, red);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = ru;
+        partial[gridDim.x + blockIdx.x] = rr;
+    }
+}
+
+static avs_status pcg_solve_single_reduction(PcgWork *w, const CsrView &A, const double *b, double *x, double tol,
+                                             int max_iters, hipStream_t stream, avs_solve_info *info, PcgDist *dist)
+{
+    const int64_t n = A.n;
+    const int g = (int)((n + kBlock - 1) / kBlock < kVecGrid ? ((n + kBlock - 1) / kBlock > 0 ? (n + kBlock - 1) / kBlock : 1) : kVecGrid);
+    const int rowgrid = (int)((n + kBlock - 1) / kBlock) > 0 ? (int)((n + kBlock - 1) / kBlock) : 1;
+    const int variant = spmv_default_variant(A);
+    AVS_TRY(w->s.alloc((size_t)n));
+    AVS_TRY(w->u.alloc((size_t)w->n_ext));
+    double *p = w->p.p, *r = w->r.p, *wv = w->t.p, *sv = w->s.p, *u = w->u.p, *invd = w->invd.p;
+    double *pvec = w->partial.p;                        // 3 * g vector-kernel partials
+    double *pspmv = w->partial.p + 4 * (size_t)kVecGrid; // SpMV partials behind them
+    PcgScalars *sc = w->sc.p;
+    auto red_of = [&](int k) { return reinterpret_cast<double *>(reinterpret_cast<char *>(sc) + offsetof(PcgScalars, red)) + k; };
+
+    AVS_HIP(hipMemsetAsync(sc, 0, sizeof(PcgScalars), stream));
+    AVS_HIP(hipMemsetAsync(p, 0, (size_t)w->n_ext * sizeof(double), stream));
+    AVS_HIP(hipMemsetAsync(sv, 0, (size_t)n * sizeof(double), stream));
+    hipLaunchKernelGGL(k_inv_diag, dim3(rowgrid), dim3(kBlock), 0, stream, A, invd);
+    AVS_HIP(hipEventRecord(w->ev0, stream));
+    // r = b - A x (x staged through u for the halo), u = M^-1 r, w = A u
+    AVS_HIP(hipMemcpyAsync(u, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    AVS_TRY(dist_halo_exchange(dist, u, stream));
+    AVS_TRY(spmv_dispatch<false>(A, u, wv, nullptr, nullptr, variant, stream, nullptr));
+    hipLaunchKernelGGL(k_sr_init, dim3(g), dim3(kBlock), 0, stream, n, b, wv, invd, r, u, pvec);
+    AVS_TRY(dist_halo_exchange(dist, u, stream));
+    int nb = 0;
+    AVS_TRY(spmv_dispatch<true>(A, u, wv, pspmv, nullptr, variant, stream, &nb));
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kRedBlock), 0, stream, pvec, g, 3, sc, (int)OP_NONE, tol, 0, 0);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kRedBlock), 0, stream, pspmv, nb, 1, sc, (int)OP_NONE, tol, 0, 3);
+    AVS_TRY(dist_allreduce(dist, red_of(0), 4, stream));
+    hipLaunchKernelGGL(k_scalar, dim3(1), dim3(64), 0, stream, sc, (int)OP_SR_INIT, tol);
+    AVS_HIP(hipGetLastError());
+
+    int enqueued = 0, last_chunk = 0, spmv_samples = 0;
+    double spmv_ms_sum = 0.;
+    while (true) {
+        AVS_HIP(hipMemcpyAsync(w->host_sc, sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, stream));
+        AVS_HIP(hipStreamSynchronize(stream));
+        if (info && last_chunk > 0) {
+            const int ran = w->host_sc->iter + (w->host_sc->done ? 1 : 0);
+            const int first = enqueued - last_chunk;
+            for (int c2 = 0; c2 < last_chunk && first + c2 < ran; ++c2) {
+                float ems = 0.f;
+                if (hipEventElapsedTime(&ems, w->evA[c2], w->evB[c2]) == hipSuccess) { spmv_ms_sum += ems; ++spmv_samples; }
+            }
+        }
+        if (w->host_sc->done || enqueued >= max_iters) break;
+        const int chunk = (max_iters - enqueued) < kChunk ? (max_iters - enqueued) : kChunk;
+        for (int c = 0; c < chunk; ++c) {
+            hipLaunchKernelGGL(k_sr_update, dim3(g), dim3(kBlock), 0, stream, n, x, r, p, sv, u, wv, invd, sc, pvec);
+            AVS_TRY(dist_halo_exchange(dist, u, stream));
+            if (info) AVS_HIP(hipEventRecord(w->evA[c], stream));
+            AVS_TRY(spmv_dispatch<true>(A, u, wv, pspmv, sc, variant, stream, &nb));
+            if (info) AVS_HIP(hipEventRecord(w->evB[c], stream));
+            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kRedBlock), 0, stream, pvec, g, 2, sc, (int)OP_NONE, tol, 0, 0);
+            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kRedBlock), 0, stream, pspmv, nb, 1, sc, (int)OP_NONE, tol, 0, 2);
+            AVS_TRY(dist_allreduce(dist, red_of(0), 3, stream));
+            hipLaunchKernelGGL(k_scalar, dim3(1), dim3(64), 0, stream, sc, (int)OP_SR_STEP, tol);
+        }
+        AVS_HIP(hipGetLastError());
+        enqueued += chunk;
+        last_chunk = chunk;
+    }
+    if (w->host_sc->done == 3) { // rhs == 0: x := 0
+        hipLaunchKernelGGL(k_sr_update, dim3(g), dim3(kBlock), 0, stream, n, x, r, p, sv, u, wv, invd, sc, pvec);
+    }
+    AVS_HIP(hipEventRecord(w->ev1, stream));
+    AVS_HIP(hipEventSynchronize(w->ev1));
+    float ms = 0.f;
+    AVS_HIP(hipEventElapsedTime(&ms, w->ev0, w->ev1));
+    if (info) {
+        const PcgScalars &h = *w->host_sc;
+        info->iterations = h.iter;
+        info->converged = (h.done != 0) ? 1 : 0;
+        info->rhs_norm2 = h.rhs_norm2;
+        info->error = (h.done == 3 || h.rhs_norm2 == 0.) ? 0. : sqrt(h.rr / h.rhs_norm2);
+        info->n = n;
+        info->nnz = A.nnz;
+        info->solve_ms = ms;
+        info->spmv_ms = spmv_samples ? spmv_ms_sum / spmv_samples : 0.;
+    }
+    return AVS_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -645,6 +832,8 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
 {
     const int64_t n = A.n;
     AVS_REQUIRE(w && w->n == n, AVS_EINVAL, "pcg workspace does not match the system size");
+    if (dist && dist_wants_single_reduction(dist))
+        return pcg_solve_single_reduction(w, A, b, x, tol, max_iters, stream, info, dist);
     const int vgrid = (int)((n + kBlock - 1) / kBlock < kVecGrid ? (n + kBlock - 1) / kBlock : kVecGrid);
     const int g = vgrid > 0 ? vgrid : 1;
     const int rowgrid = (int)((n + kBlock - 1) / kBlock) > 0 ? (int)((n + kBlock - 1) / kBlock) : 1;
