@@ -14,6 +14,7 @@
 // reduction logic and is what tests/test_gpu_dist.py checks against the single-rank solve.
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <cstdlib>
 #include <mutex>
@@ -64,6 +65,12 @@ struct PcgDist {
     DevBuf<double> val, rhs, x0, x;
     PcgWork *pcg = nullptr;
     bool partitioned = false, solved = false, reordered = false;
+
+    // overlap of the exchange with the interior rows
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_halo = nullptr;
+    DevBuf<int32_t> tiles_int, tiles_bnd;
+    int n_tiles_int = 0, n_tiles_bnd = 0;
 };
 
 #define AVS_NCCL(call)                                                                                   \
@@ -135,6 +142,31 @@ avs_status dist_halo_exchange(PcgDist *d, double *p_ext, hipStream_t stream)
     return AVS_OK;
 }
 
+bool dist_tile_lists(PcgDist *d, const int32_t **t_int, int *n_int, const int32_t **t_bnd, int *n_bnd)
+{
+    if (!d || d->world <= 1 || !d->comm_stream || d->n_tiles_int + d->n_tiles_bnd == 0) return false;
+    const char *e = getenv("AVS_DIST_OVERLAP");
+    if (e && atoi(e) == 0) return false;
+    *t_int = d->tiles_int.p; *n_int = d->n_tiles_int;
+    *t_bnd = d->tiles_bnd.p; *n_bnd = d->n_tiles_bnd;
+    return true;
+}
+
+// exchange on the communication stream, ordered after everything enqueued on main_stream so far
+avs_status dist_halo_begin(PcgDist *d, double *p_ext, hipStream_t main_stream)
+{
+    AVS_HIP(hipEventRecord(d->ev_ready, main_stream));
+    AVS_HIP(hipStreamWaitEvent(d->comm_stream, d->ev_ready, 0));
+    AVS_TRY(dist_halo_exchange(d, p_ext, d->comm_stream));
+    AVS_HIP(hipEventRecord(d->ev_halo, d->comm_stream));
+    return AVS_OK;
+}
+avs_status dist_halo_end(PcgDist *d, hipStream_t main_stream)
+{
+    AVS_HIP(hipStreamWaitEvent(main_stream, d->ev_halo, 0));
+    return AVS_OK;
+}
+
 // C2: in-place sum of `count` doubles (count <= 4) over all ranks
 avs_status dist_allreduce(PcgDist *d, double *dev, int count, hipStream_t stream)
 {
@@ -173,6 +205,9 @@ void dist_release(avs_ctx *c)
     if (!d) return;
     pcg_destroy(d->pcg);
     if (d->comm) (void)ncclCommDestroy(d->comm);
+    if (d->comm_stream) (void)hipStreamDestroy(d->comm_stream);
+    if (d->ev_ready) (void)hipEventDestroy(d->ev_ready);
+    if (d->ev_halo) (void)hipEventDestroy(d->ev_halo);
     delete d;
     c->dist = nullptr;
 }
@@ -344,6 +379,29 @@ avs_status avs_dist_partition(avs_ctx *c, int32_t cut_axis)
     }
     AVS_HIP(hipGetLastError());
     AVS_HIP(hipStreamSynchronize(st));
+    // tiles of the local SpMV that read no halo column can run while the halo is in flight
+    {
+        const int T = spmv_tile_rows();
+        const int64_t ntiles = (sz.n_own + T - 1) / T;
+        std::vector<int32_t> ti, tb;
+        for (int64_t t = 0; t < ntiles; ++t) {
+            const int64_t r0 = t * T, r1 = std::min<int64_t>(r0 + T, sz.n_own);
+            bool touches = false;
+            for (int32_t k = rpl[(size_t)r0]; k < rpl[(size_t)r1] && !touches; ++k) touches = cl[(size_t)k] >= sz.n_own;
+            (touches ? tb : ti).push_back((int32_t)t);
+        }
+        d->n_tiles_int = (int)ti.size();
+        d->n_tiles_bnd = (int)tb.size();
+        AVS_TRY(d->tiles_int.alloc(ti.size()));
+        AVS_TRY(d->tiles_bnd.alloc(tb.size()));
+        if (!ti.empty()) AVS_HIP(hipMemcpy(d->tiles_int.p, ti.data(), ti.size() * 4, hipMemcpyHostToDevice));
+        if (!tb.empty()) AVS_HIP(hipMemcpy(d->tiles_bnd.p, tb.data(), tb.size() * 4, hipMemcpyHostToDevice));
+        if (!d->comm_stream) {
+            AVS_HIP(hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking));
+            AVS_HIP(hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming));
+            AVS_HIP(hipEventCreateWithFlags(&d->ev_halo, hipEventDisableTiming));
+        }
+    }
     pcg_destroy(d->pcg);
     d->pcg = nullptr;
     AVS_TRY(pcg_create(&d->pcg, sz.n_own, sz.n_own + sz.n_halo, st));
@@ -362,6 +420,15 @@ avs_status avs_dist_get_plan_sizes(avs_ctx *c, avs_plan_sizes *s)
     s->nnz_local = c->dist->nnz_local;
     s->n_send = c->dist->n_send;
     s->n_peers = (int32_t)c->dist->peers.size();
+    return AVS_OK;
+}
+
+avs_status avs_dist_get_overlap_tiles(avs_ctx *c, int32_t *interior, int32_t *boundary)
+{
+    AVS_REQUIRE(c && interior && boundary, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->dist && c->dist->partitioned, AVS_ESTATE, "call avs_dist_partition first");
+    *interior = c->dist->n_tiles_int;
+    *boundary = c->dist->n_tiles_bnd;
     return AVS_OK;
 }
 

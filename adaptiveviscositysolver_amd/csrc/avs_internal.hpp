@@ -156,6 +156,11 @@ avs_status dist_halo_exchange(PcgDist *d, double *p_ext, hipStream_t stream);
 avs_status dist_allreduce(PcgDist *d, double *dev_scalars, int count, hipStream_t stream);
 void dist_release(struct ::avs_ctx *c);
 bool dist_wants_single_reduction(PcgDist *d);
+// overlap support: tile lists (interior / halo-touching 512-row tiles) and a split exchange
+bool dist_tile_lists(PcgDist *d, const int32_t **t_int, int *n_int, const int32_t **t_bnd, int *n_bnd);
+avs_status dist_halo_begin(PcgDist *d, double *p_ext, hipStream_t main_stream);
+avs_status dist_halo_end(PcgDist *d, hipStream_t main_stream);
+int spmv_tile_rows();
 avs_status build_reordered_system(struct ::avs_ctx *c, int brick_shift);
 avs_status unpermute(struct ::avs_ctx *c, const double *xp, double *x);
 

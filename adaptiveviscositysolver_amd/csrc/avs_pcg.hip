@@ -146,13 +146,13 @@ __device__ __forceinline__ T stream_load(const T *p)
 template <int BLK, int CAP, bool DOT, bool VEC, bool XCD, bool NT>
 __global__ __launch_bounds__(BLK) void k_spmv_tile(CsrView A, const double *__restrict__ x,
                                                    double *__restrict__ y, double *__restrict__ partial,
-                                                   const PcgScalars *sc, int chunk)
+                                                   const PcgScalars *sc, int chunk, const int32_t *__restrict__ tiles = nullptr)
 {
     if (DOT && sc && sc->done) return;
     __shared__ double prod[CAP + 2];
     __shared__ double red[BLK / 64];
     const int tid = threadIdx.x;
-    int64_t tile = blockIdx.x;
+    int64_t tile = tiles ? (int64_t)tiles[blockIdx.x] : (int64_t)blockIdx.x; // tile lists: interior / halo-touching subsets
     if (XCD) {
         const int64_t ntiles = gridDim.x;
         if (chunk <= 0) { // each XCD owns one contiguous eighth
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_tile(CsrView A, const double *__re
         if (tid == 0) {
             double t = 0.;
             for (int w = 0; w < BLK / 64; ++w) t += red[w];
-            partial[blockIdx.x] = t;
+            partial[tiles ? tile : (int64_t)blockIdx.x] = t;
         }
     }
 }
@@ -383,6 +383,20 @@ static size_t max_partials(int64_t n);
 avs_status spmv_launch(const CsrView &A, const double *x, double *y, int variant, hipStream_t stream)
 {
     return spmv_dispatch<false>(A, x, y, nullptr, nullptr, variant, stream, nullptr);
+}
+
+// default kernel restricted to a list of 512-row tiles (multi-GPU overlap: interior tiles run while the halo
+// travels); partial[tile] receives the tile's share of x.y, so several launches fill one partial array
+static constexpr int kTileRows = 512;
+int spmv_tile_rows() { return kTileRows; }
+avs_status spmv_dot_tiles(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc,
+                          const int32_t *tiles, int ntiles, hipStream_t stream)
+{
+    if (ntiles <= 0) return AVS_OK;
+    hipLaunchKernelGGL((k_spmv_tile<kTileRows, 4096, true, true, false, true>), dim3(ntiles), dim3(kTileRows), 0, stream, A, x, y,
+                       partial, sc, 0, tiles);
+    AVS_HIP(hipGetLastError());
+    return AVS_OK;
 }
 
 // the form used inside the PCG loop: y = A x and per-block partials of x.y
@@ -735,10 +749,24 @@ static avs_status pcg_solve_single_reduction(PcgWork *w, const CsrView &A, const
         const int chunk = (max_iters - enqueued) < kChunk ? (max_iters - enqueued) : kChunk;
         for (int c = 0; c < chunk; ++c) {
             hipLaunchKernelGGL(k_sr_update, dim3(g), dim3(kBlock), 0, stream, n, x, r, p, sv, u, wv, invd, sc, pvec);
-            AVS_TRY(dist_halo_exchange(dist, u, stream));
-            if (info) AVS_HIP(hipEventRecord(w->evA[c], stream));
-            AVS_TRY(spmv_dispatch<true>(A, u, wv, pspmv, sc, variant, stream, &nb));
-            if (info) AVS_HIP(hipEventRecord(w->evB[c], stream));
+            const int32_t *t_int = nullptr, *t_bnd = nullptr;
+            int n_int = 0, n_bnd = 0;
+            if (variant == 24 && dist_tile_lists(dist, &t_int, &n_int, &t_bnd, &n_bnd)) {
+                // overlap: the exchange runs on the communication stream while the tiles that touch no halo
+                // column are multiplied; the halo-touching tiles follow once the halo has landed
+                AVS_TRY(dist_halo_begin(dist, u, stream));
+                if (info) AVS_HIP(hipEventRecord(w->evA[c], stream));
+                AVS_TRY(spmv_dot_tiles(A, u, wv, pspmv, sc, t_int, n_int, stream));
+                AVS_TRY(dist_halo_end(dist, stream));
+                AVS_TRY(spmv_dot_tiles(A, u, wv, pspmv, sc, t_bnd, n_bnd, stream));
+                if (info) AVS_HIP(hipEventRecord(w->evB[c], stream));
+                nb = n_int + n_bnd;
+            } else {
+                AVS_TRY(dist_halo_exchange(dist, u, stream));
+                if (info) AVS_HIP(hipEventRecord(w->evA[c], stream));
+                AVS_TRY(spmv_dispatch<true>(A, u, wv, pspmv, sc, variant, stream, &nb));
+                if (info) AVS_HIP(hipEventRecord(w->evB[c], stream));
+            }
             hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kRedBlock), 0, stream, pvec, g, 2, sc, (int)OP_NONE, tol, 0, 0);
             hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kRedBlock), 0, stream, pspmv, nb, 1, sc, (int)OP_NONE, tol, 0, 2);
             AVS_TRY(dist_allreduce(dist, red_of(0), 3, stream));

@@ -145,6 +145,9 @@ class ViscositySolve:
         capi.check(self.lib.avs_dist_get_plan_sizes(self.h, C.byref(sz)))
         self.plan_sizes = sz
         self.local_spmv_bytes = 12 * sz.nnz_local + 4 * (sz.n_own + 1) + 16 * sz.n_own
+        ti, tb = C.c_int32(), C.c_int32()
+        capi.check(self.lib.avs_dist_get_overlap_tiles(self.h, C.byref(ti), C.byref(tb)))
+        self.overlap_tiles = (ti.value, tb.value)
         return sz
 
     def dist_solve(self, tol=1e-3, max_iters=2500):

@@ -234,6 +234,8 @@ avs_status avs_dist_init_local(avs_ctx *ctx, avs_local_group *group, int32_t ran
  * the system (cut along `cut_axis`, -1 = longest axis) and builds halo / send lists. */
 avs_status avs_dist_partition(avs_ctx *ctx, int32_t cut_axis);
 avs_status avs_dist_get_plan_sizes(avs_ctx *ctx, avs_plan_sizes *sizes);
+/* number of 512-row SpMV tiles that read no halo column (they run while the halo is in flight) / that do */
+avs_status avs_dist_get_overlap_tiles(avs_ctx *ctx, int32_t *interior, int32_t *boundary);
 avs_status avs_dist_solve(avs_ctx *ctx, double tolerance, int32_t max_iterations, avs_solve_info *info);
 /* gathers the full solution (global DOF order) on every rank */
 avs_status avs_dist_get_solution(avs_ctx *ctx, double *x, int64_t n, avs_memspace where);

@@ -35,7 +35,7 @@ def test_virtual_ranks_match_single_solve(world, cut_axis, built_lib):
     grp = C.c_void_p()
     capi.check(lib.avs_local_group_create(world, C.byref(grp)))
     solvers = [make_solver(sc, pyr) for _ in range(world)]
-    results, errors = [None] * world, []
+    results, errors, tiles = [None] * world, [], [None] * world
 
     def run(r):
         try:
@@ -45,6 +45,7 @@ def test_virtual_ranks_match_single_solve(world, cut_axis, built_lib):
             info = s.dist_solve(tol, 5000)
             x = s.dist_solution()
             results[r] = (info.iterations, info.converged, info.error, x, sz.n_own, sz.n_halo, sz.n_peers)
+            tiles[r] = s.overlap_tiles
         except Exception as e:  # pragma: no cover
             errors.append((r, e))
 
@@ -64,6 +65,8 @@ def test_virtual_ranks_match_single_solve(world, cut_axis, built_lib):
         assert n_halo > 0 and n_peers >= 1
         assert n_halo < 0.5 * n_own          # slabs: the halo is a surface term
     assert len({r[0] for r in results}) == 1  # every rank reports the same iteration count
+    for ti, tb in tiles:                      # the halo exchange overlaps the tiles that read no halo column
+        assert tb >= 1 and ti + tb == -(-results[tiles.index((ti, tb))][4] // 512)
     for s in solvers:
         s.close()
     lib.avs_local_group_destroy(grp)
