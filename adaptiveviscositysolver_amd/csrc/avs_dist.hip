@@ -50,7 +50,9 @@ namespace avs {
 
 struct PcgDist {
     int rank = 0, world = 1;
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;     // all-reduces (solver stream)
+    ncclComm_t comm_p2p = nullptr; // halo send/recv (communication stream): a communicator of its own, so that
+                                   // operations in flight on two streams never share one communicator
     avs_local_group *group = nullptr;
     int device = 0;
 
@@ -71,6 +73,7 @@ struct PcgDist {
     hipEvent_t ev_ready = nullptr, ev_halo = nullptr;
     DevBuf<int32_t> tiles_int, tiles_bnd;
     int n_tiles_int = 0, n_tiles_bnd = 0;
+    bool no_overlap = false;
 };
 
 #define AVS_NCCL(call)                                                                                   \
@@ -114,9 +117,9 @@ avs_status dist_halo_exchange(PcgDist *d, double *p_ext, hipStream_t stream)
         AVS_NCCL(ncclGroupStart());
         for (size_t i = 0; i < d->peers.size(); ++i) {
             if (d->send_counts[i])
-                AVS_NCCL(ncclSend(d->sendbuf.p + d->send_offs[i], (size_t)d->send_counts[i], ncclDouble, d->peers[i], d->comm, stream));
+                AVS_NCCL(ncclSend(d->sendbuf.p + d->send_offs[i], (size_t)d->send_counts[i], ncclDouble, d->peers[i], d->comm_p2p, stream));
             if (d->recv_counts[i])
-                AVS_NCCL(ncclRecv(p_ext + d->n_own + d->recv_offs[i], (size_t)d->recv_counts[i], ncclDouble, d->peers[i], d->comm, stream));
+                AVS_NCCL(ncclRecv(p_ext + d->n_own + d->recv_offs[i], (size_t)d->recv_counts[i], ncclDouble, d->peers[i], d->comm_p2p, stream));
         }
         AVS_NCCL(ncclGroupEnd());
         return AVS_OK;
@@ -144,7 +147,7 @@ avs_status dist_halo_exchange(PcgDist *d, double *p_ext, hipStream_t stream)
 
 bool dist_tile_lists(PcgDist *d, const int32_t **t_int, int *n_int, const int32_t **t_bnd, int *n_bnd)
 {
-    if (!d || d->world <= 1 || !d->comm_stream || d->n_tiles_int + d->n_tiles_bnd == 0) return false;
+    if (!d || d->world <= 1 || d->no_overlap || !d->comm_stream || d->n_tiles_int + d->n_tiles_bnd == 0) return false;
     const char *e = getenv("AVS_DIST_OVERLAP");
     if (e && atoi(e) == 0) return false;
     *t_int = d->tiles_int.p; *n_int = d->n_tiles_int;
@@ -204,6 +207,7 @@ void dist_release(avs_ctx *c)
     PcgDist *d = c->dist;
     if (!d) return;
     pcg_destroy(d->pcg);
+    if (d->comm_p2p && d->comm_p2p != d->comm) (void)ncclCommDestroy(d->comm_p2p);
     if (d->comm) (void)ncclCommDestroy(d->comm);
     if (d->comm_stream) (void)hipStreamDestroy(d->comm_stream);
     if (d->ev_ready) (void)hipEventDestroy(d->ev_ready);
@@ -262,6 +266,12 @@ avs_status avs_dist_init(avs_ctx *c, const uint8_t id[AVS_UNIQUE_ID_BYTES], int3
     ncclUniqueId u;
     memcpy(&u, id, sizeof(u));
     AVS_NCCL(ncclCommInitRank(&c->dist->comm, world, u, rank));
+    // second communicator for the point-to-point traffic (same ranks); without it the exchange shares
+    // `comm` and stays on the solver stream (no overlap)
+    if (ncclCommSplit(c->dist->comm, 0, rank, &c->dist->comm_p2p, nullptr) != ncclSuccess || !c->dist->comm_p2p) {
+        c->dist->comm_p2p = c->dist->comm;
+        c->dist->no_overlap = true;
+    }
     return AVS_OK;
 }
 
