@@ -12,9 +12,9 @@
 //   K3  k_initial_guess    buildVelocityMappingPartial                       cpp:2291-2402
 //   K4  k_rows<false>      dry run of the row sweep: raw triplets per row    cpp:2459-2777
 //   K5  exclusive scan     wave64 shuffle scan -> raw offsets / row pointers
-//   K6  k_rows<true>       row sweep; every row is kept sorted and duplicate-free while it is
-//                          emitted (insert-or-add, left fold in emission order = exactly what
-//                          setFromTriplets does for one (row, col))          cpp:2404-2457, 613-614
+//   K6  k_rows<true>       row sweep, raw triplets in emission order                   cpp:2404-2457
+//   K6b k_sort_rows        per row (one half-wave, in registers): stable sort by column + left fold of
+//                          duplicates in emission order = setFromTriplets for one row  cpp:613-614
 //   K7  k_compact          rows -> final CSR, coalesced 16-lane copies
 //
 // Rows are independent (a gather): no atomics anywhere.  All arithmetic is done in the reference's
@@ -418,8 +418,8 @@ __global__ __launch_bounds__(kBlock) void k_initial_guess(PyramidView P, const i
 // K4 / K6: the row sweep
 // ---------------------------------------------------------------------------------------------
 struct RowAcc {
-    int n;          // EMIT: unique entries so far; dry run: raw entries
-    int32_t *col;   // row storage (sorted, unique) in the raw arrays
+    int n;          // raw entries so far
+    int32_t *col;   // row storage in the raw arrays (emission order)
     double *val;
     double diag, rhs;
     int bad;
@@ -428,22 +428,10 @@ struct RowAcc {
 template <bool EMIT>
 __device__ __forceinline__ void row_push(RowAcc &ra, int32_t c, double v)
 {
-    if (!EMIT) {
-        ++ra.n;
-        return;
+    if (EMIT) { // raw triplet, emission order (what the reference push_backs, cpp:2447)
+        ra.col[ra.n] = c;
+        ra.val[ra.n] = v;
     }
-    int j = ra.n - 1;
-    while (j >= 0 && ra.col[j] > c) --j;
-    if (j >= 0 && ra.col[j] == c) { // duplicate: left fold in emission order (setFromTriplets)
-        ra.val[j] = ra.val[j] + v;
-        return;
-    }
-    for (int m = ra.n - 1; m > j; --m) {
-        ra.col[m + 1] = ra.col[m];
-        ra.val[m + 1] = ra.val[m];
-    }
-    ra.col[j + 1] = c;
-    ra.val[j + 1] = v;
     ++ra.n;
 }
 
@@ -617,6 +605,184 @@ __global__ __launch_bounds__(kBlock) void k_rows(PyramidView P, const int32_t *_
     } else ++ra.n;
     row_count[row] = ra.n;
     if (ra.bad) *err = 7;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6b: Eigen::SparseMatrix::setFromTriplets for one row (cpp:613-614): stable sort by column, duplicates
+// summed left to right in emission order.  One half-wave (32 lanes) per row, everything in registers:
+// lane l holds raw entry l; its rank is counted with 32-wide shuffles; the first occurrence of a column
+// folds the later ones in order; firsts write (col, sum) at their unique rank, in place.  Rows longer
+// than 32 raw entries (rare transition rows) are handled serially by lane 0 (insert-or-add).
+// ---------------------------------------------------------------------------------------------
+__device__ void sort_row_serial(int32_t *col, double *val, int n, int &unique)
+{
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        const int32_t c = col[i];
+        const double v = val[i];
+        int j = m - 1;
+        while (j >= 0 && col[j] > c) --j;
+        if (j >= 0 && col[j] == c) {
+            val[j] = val[j] + v;
+            continue;
+        }
+        for (int k = m - 1; k > j; --k) {
+            col[k + 1] = col[k];
+            val[k + 1] = val[k];
+        }
+        col[j + 1] = c;
+        val[j + 1] = v;
+        ++m;
+    }
+    unique = m;
+}
+
+// value of lane (q + 32*half) for every lane of that half; q is wave-uniform => two v_readlane, no LDS crossbar
+__device__ __forceinline__ int half_bcast(int v, int q, bool hi)
+{
+    const int lo = __builtin_amdgcn_readlane(v, q);
+    const int up = __builtin_amdgcn_readlane(v, q + 32);
+    return hi ? up : lo;
+}
+__device__ __forceinline__ double half_bcast(double v, int q, bool hi)
+{
+    const int l = half_bcast(__double2loint(v), q, hi);
+    const int h = half_bcast(__double2hiint(v), q, hi);
+    return __hiloint2double(h, l);
+}
+
+static constexpr int kLongCap = 1024; // raw entries of one row staged in LDS by k_sort_long_rows
+
+// rows with more than 32 raw entries (transition rows): every wave scans 64 consecutive rows, and each long
+// one among them is processed by the whole wave with the row staged in LDS (no list, no atomics)
+__global__ __launch_bounds__(64) void k_sort_long_rows(int64_t n, const int32_t *__restrict__ rawptr, int32_t *__restrict__ raw_col,
+                                                       double *__restrict__ raw_val, int32_t *__restrict__ row_count)
+{
+    __shared__ int32_t lc[kLongCap];
+    __shared__ double lv[kLongCap];
+    __shared__ unsigned char lf[kLongCap];
+    const int lane = threadIdx.x;
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < n; base += (int64_t)gridDim.x * 64) {
+        const int64_t my = base + lane;
+        const int myR = (my < n) ? rawptr[my + 1] - rawptr[my] : 0;
+        unsigned long long todo = __ballot(myR > 32);
+        while (todo) {
+            const int which = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int64_t row = base + which;
+            const int s = rawptr[row];
+            const int R = rawptr[row + 1] - s;
+            if (R > kLongCap) { // practically unreachable; keep the exact semantics anyway
+                if (lane == 0) {
+                    int unique = 0;
+                    sort_row_serial(raw_col + s, raw_val + s, R, unique);
+                    row_count[row] = unique;
+                }
+                continue;
+            }
+            __syncthreads();
+            for (int e = lane; e < R; e += 64) {
+                lc[e] = raw_col[s + e];
+                lv[e] = raw_val[s + e];
+            }
+            __syncthreads();
+            for (int e = lane; e < R; e += 64) {
+                const int32_t c = lc[e];
+                bool first = true;
+                for (int q = 0; q < e; ++q)
+                    if (lc[q] == c) { first = false; break; }
+                lf[e] = first ? 1 : 0;
+            }
+            __syncthreads();
+            int mine = 0;
+            for (int e = lane; e < R; e += 64) {
+                if (!lf[e]) continue;
+                const int32_t c = lc[e];
+                int urank = 0;
+                double sum = lv[e];
+                for (int q = 0; q < R; ++q) {
+                    const int32_t cq = lc[q];
+                    if (lf[q] && cq < c) ++urank;
+                    if (q > e && cq == c) sum = sum + lv[q]; // left fold in emission order
+                }
+                raw_col[s + urank] = c; // every read of this row comes from LDS: in place is safe
+                raw_val[s + urank] = sum;
+                ++mine;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+            if (lane == 0) row_count[row] = mine;
+        }
+    }
+}
+
+static constexpr int kSortRowsPerHalf = 4; // rows handled per half-wave: 4x the loads in flight (the kernel is latency-bound)
+
+__global__ __launch_bounds__(kBlock) void k_sort_rows(int64_t n, const int32_t *__restrict__ rawptr, int32_t *__restrict__ raw_col,
+                                                      double *__restrict__ raw_val, int32_t *__restrict__ row_count)
+{
+    constexpr int K = kSortRowsPerHalf;
+    const int lane = threadIdx.x & 31;
+    const bool hi = (threadIdx.x & 32) != 0;
+    const int64_t row0 = (((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 5) * K;
+    int s[K], Rs[K];
+    int32_t c[K];
+    double v[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int64_t row = row0 + j;
+        const bool live = row < n;
+        s[j] = live ? rawptr[row] : 0;
+        const int R = live ? rawptr[row + 1] - s[j] : 0;
+        Rs[j] = (R <= 32) ? R : 0; // longer rows: k_sort_long_rows
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) { // all loads of the K rows are in flight together
+        c[j] = INT32_MAX;
+        v[j] = 0.;
+        if (lane < Rs[j]) {
+            c[j] = raw_col[s[j] + lane];
+            v[j] = raw_val[s[j] + lane];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        // wave-uniform trip count: the longer of the two rows sharing this wave
+        const int trip = max(__builtin_amdgcn_readlane(Rs[j], 0), __builtin_amdgcn_readlane(Rs[j], 32));
+        // pass 1: how many columns are smaller, and does an earlier entry carry my column?
+        int below = 0;
+        bool first = lane < Rs[j];
+        for (int q = 0; q < trip; ++q) {
+            const int32_t cq = half_bcast(c[j], q, hi);
+            if (q < Rs[j]) {
+                below += (cq < c[j]);
+                if (q < lane && cq == c[j]) first = false;
+            }
+        }
+        const unsigned long long firsts = __ballot(first);
+        const unsigned long long actives = __ballot(lane < Rs[j]);
+        int urank = below;
+        double sum = v[j];
+        if (firsts != actives) {
+            // duplicates somewhere in this wave (transition rows): rank among FIRST occurrences only, and
+            // fold the later duplicates into the first one, left to right in emission order
+            urank = 0;
+            const unsigned fmask = hi ? (unsigned)(firsts >> 32) : (unsigned)firsts;
+            for (int q = 0; q < trip; ++q) {
+                const int32_t cq = half_bcast(c[j], q, hi);
+                const double vq = half_bcast(v[j], q, hi);
+                if (q < Rs[j]) {
+                    if (((fmask >> q) & 1u) && cq < c[j]) ++urank;
+                    if (first && q > lane && cq == c[j]) sum = sum + vq;
+                }
+            }
+        }
+        if (first) { // all reads of this row happened above: writing in place is safe
+            raw_col[s[j] + urank] = c[j];
+            raw_val[s[j] + urank] = sum;
+        }
+        if (lane == 0 && Rs[j] > 0) row_count[row0 + j] = __popc(hi ? (unsigned)(firsts >> 32) : (unsigned)firsts);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -889,9 +1055,15 @@ avs_status build_system(avs_ctx *c)
     c->nraw = nraw;
     AVS_TRY(raw_col.alloc((size_t)nraw));
     AVS_TRY(raw_val.alloc((size_t)nraw));
-    // K6 emit (rows stay sorted + merged) -> unique counts
-    if (n) hipLaunchKernelGGL((k_rows<true>), dim3(grid_for(n)), dim3(kBlock), 0, st, P, c->vdof.p, n, E, C, c->x0.p,
-                              (const int32_t *)rawptr.p, raw_col.p, raw_val.p, row_count.p, c->rhs.p, err.p);
+    // K6 emit raw triplets, K6b per-row stable sort + duplicate merge -> unique counts
+    if (n) {
+        hipLaunchKernelGGL((k_rows<true>), dim3(grid_for(n)), dim3(kBlock), 0, st, P, c->vdof.p, n, E, C, c->x0.p,
+                           (const int32_t *)rawptr.p, raw_col.p, raw_val.p, row_count.p, c->rhs.p, err.p);
+        hipLaunchKernelGGL(k_sort_rows, dim3(grid_for((n + kSortRowsPerHalf - 1) / kSortRowsPerHalf * 32)), dim3(kBlock), 0, st, n,
+                           (const int32_t *)rawptr.p, raw_col.p, raw_val.p, row_count.p);
+        hipLaunchKernelGGL(k_sort_long_rows, dim3(8192), dim3(64), 0, st, n, (const int32_t *)rawptr.p, raw_col.p, raw_val.p,
+                           row_count.p);
+    }
     AVS_TRY(exclusive_scan_i32(row_count.p, c->row_ptr.p, n, scan_tmp.p, scan_tmp.n, st));
     int32_t nnz = 0;
     AVS_HIP(hipMemcpyAsync(&nnz, c->row_ptr.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
