@@ -36,12 +36,15 @@ EXPORTED_SYMBOLS = [
     "avs_build_initial_guess", "avs_build_system", "avs_assemble", "avs_solve",
     "avs_get_assembly_info", "avs_get_solution", "avs_get_initial_guess", "avs_get_csr",
     "avs_get_edge_stencils", "avs_get_center_stencils", "avs_pcg_csr", "avs_spmv_csr",
-    "avs_bench_spmv", "avs_bench_stream", "avs_get_dof_table", "avs_plan_owners", "avs_plan_create", "avs_plan_get_sizes",
+    "avs_bench_spmv", "avs_bench_stream", "avs_prepass_create", "avs_prepass_destroy", "avs_prepass_run",
+    "avs_prepass_get_info", "avs_prepass_get_labels", "avs_prepass_get_mask", "avs_prepass_get_index",
+    "avs_prepass_get_weights", "avs_prepass_apply", "avs_get_dof_table", "avs_plan_owners", "avs_plan_create", "avs_plan_get_sizes",
     "avs_plan_get_arrays", "avs_plan_destroy", "avs_dist_get_unique_id", "avs_dist_init",
     "avs_local_group_create", "avs_local_group_destroy", "avs_dist_init_local", "avs_dist_partition",
     "avs_dist_get_plan_sizes", "avs_dist_get_overlap_tiles", "avs_dist_solve", "avs_dist_get_solution",
 ]
-_VOID_RETURN = ("avs_last_error", "avs_version", "avs_destroy", "avs_plan_destroy", "avs_local_group_destroy")
+_VOID_RETURN = ("avs_last_error", "avs_version", "avs_destroy", "avs_plan_destroy", "avs_local_group_destroy",
+                "avs_prepass_destroy")
 
 
 class AvsError(RuntimeError):
@@ -65,6 +68,18 @@ class SolveInfo(C.Structure):
 class PlanSizes(C.Structure):
     _fields_ = [("n_own", C.c_int64), ("n_halo", C.c_int64), ("nnz_local", C.c_int64), ("n_send", C.c_int64),
                 ("n_peers", C.c_int32)]
+
+
+class PrepassDesc(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("dx", C.c_double),
+                ("desired_levels", C.c_int32), ("n_super", C.c_int32), ("extrapolation_scale", C.c_double),
+                ("device", C.c_int32), ("stream", C.c_void_p)]
+
+
+class PrepassInfo(C.Structure):
+    _fields_ = [("levels", C.c_int32), ("n_velocity", C.c_int64), ("n_edge", C.c_int64), ("n_center", C.c_int64),
+                ("weights_ms", C.c_double), ("octree_ms", C.c_double), ("classify_ms", C.c_double),
+                ("number_ms", C.c_double)]
 
 
 class AssemblyInfo(C.Structure):
@@ -111,6 +126,16 @@ def load():
     L.avs_spmv_csr.argtypes = [i64, vp, vp, vp, vp, vp, i32, i32, vp]
     L.avs_bench_spmv.argtypes = [vp, i32, i32, C.POINTER(f64)]
     L.avs_bench_stream.argtypes = [i32, i64, i32, i32, C.POINTER(f64)]
+    L.avs_prepass_create.argtypes = [C.POINTER(PrepassDesc), C.POINTER(vp)]
+    L.avs_prepass_destroy.argtypes = [vp]
+    L.avs_prepass_destroy.restype = None
+    L.avs_prepass_run.argtypes = [vp, vp, vp, i32]
+    L.avs_prepass_get_info.argtypes = [vp, C.POINTER(PrepassInfo)]
+    L.avs_prepass_get_labels.argtypes = [vp, i32, vp, i32]
+    L.avs_prepass_get_mask.argtypes = [vp, vp, i32]
+    L.avs_prepass_get_index.argtypes = [vp, i32, i32, i32, vp, i32]
+    L.avs_prepass_get_weights.argtypes = [vp, i32, i32, vp, i32]
+    L.avs_prepass_apply.argtypes = [vp, vp]
     L.avs_get_dof_table.argtypes = [vp, i32, vp, i32]
     L.avs_plan_owners.argtypes = [i64, vp, vp, i32, i32, i32, i32, vp]
     L.avs_plan_create.argtypes = [i64, vp, vp, vp, i32, i32, C.POINTER(vp)]

@@ -1,0 +1,786 @@
+// avs_prepass.hip -- the steps of solveGasSubclass BEFORE the hot path, on the device
+// (SURVEY.md 8(f) "next #1 / #4"; reference: HDK_AdaptiveViscosity.cpp "cpp:", HDK_OctreeGrid.cpp "oct.cpp:").
+//
+//   P1 k_sdf_weights     integration weights (cpp:712-766; HDK computeSDFWeightsSampled is not in the
+//                        reference tree: fraction of n^3 sub-samples with interpolated SDF < 0, defined in
+//                        oracle/avs_oracle.c and restated identically here, fp32, x then y then z)
+//   P2 k_mask_labels     refinement mask + level-0 labels (cpp:815-867, oct.cpp:383-388)
+//   P3 k_oct_*           label pyramid, three passes per level (oct.cpp:93-189) + top level (oct.cpp:843-875)
+//   P4 k_mark_*/k_classify_*  tile occupancy + face / edge / centre classification (cpp:886-1443)
+//   P5 k_flags_tilemajor + scan + k_apply_ids   serial numbering in HDK 16^3 tile order (cpp:1566-1593,
+//                        1635-1660, 1688-1712) as an exclusive scan over the tile-major flag sequence
+//
+// Every per-voxel rule is a gather from the finer / same level: one thread per output voxel (or per
+// parent cell), no atomics, deterministic.  All integer outputs are bit-identical to the oracle and
+// to the tensor-op restatement in prepass.py (tests/test_gpu_prepass.py).
+#include <cmath>
+#include <new>
+
+#include "avs_device_common.hpp"
+
+namespace avs {
+
+static constexpr int kBlock = 256;
+static constexpr int kTile = 16;
+static constexpr int kMaxSuper = 8;
+
+struct SubConsts { // per axis: integer cell offset and fp32 fraction of every sub-sample
+    int di[3][kMaxSuper];
+    float fr[3][kMaxSuper];
+    int n;
+};
+
+struct Grid3 {
+    int r[3];
+    __host__ __device__ size_t vol() const { return (size_t)r[0] * r[1] * r[2]; }
+};
+
+__device__ __forceinline__ size_t lin3(const Grid3 &g, int i, int j, int k)
+{
+    return (size_t)i + (size_t)g.r[0] * ((size_t)j + (size_t)g.r[1] * (size_t)k);
+}
+
+static inline unsigned grid_for(size_t n, unsigned cap = 1u << 20)
+{
+    size_t b = (n + kBlock - 1) / kBlock;
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+// ---------------------------------------------------------------------------------------------
+// P1: weights
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_sdf_weights(const float *__restrict__ sdf, Grid3 src, Grid3 tgt, SubConsts sc,
+                                                        float *__restrict__ out)
+{
+    const size_t total = tgt.vol();
+    const int n = sc.n;
+    const float n3 = (float)(n * n * n);
+    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+        int p[3];
+        p[0] = (int)(o % tgt.r[0]);
+        const size_t q = o / tgt.r[0];
+        p[1] = (int)(q % tgt.r[1]);
+        p[2] = (int)(q / tgt.r[1]);
+        // exact shortcut: interpolation preserves the sign, so an all-negative (all non-negative)
+        // neighbourhood gives n^3 (0)
+        int lo[3], hi[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = clampi(p[a] + sc.di[a][0], 0, src.r[a] - 1);
+            hi[a] = clampi(p[a] + sc.di[a][n - 1] + 1, 0, src.r[a] - 1);
+        }
+        bool allneg = true, allpos = true;
+        for (int kk = lo[2]; kk <= hi[2]; ++kk)
+            for (int jj = lo[1]; jj <= hi[1]; ++jj)
+                for (int ii = lo[0]; ii <= hi[0]; ++ii) {
+                    const float v = sdf[lin3(src, ii, jj, kk)];
+                    if (v < 0.f) allpos = false;
+                    else allneg = false;
+                }
+        int count;
+        if (allneg) count = n * n * n;
+        else if (allpos) count = 0;
+        else {
+            count = 0;
+            for (int sz = 0; sz < n; ++sz)
+                for (int sy = 0; sy < n; ++sy)
+                    for (int sx = 0; sx < n; ++sx) {
+                        const int s3[3] = {sx, sy, sz};
+                        int i0[3], i1[3];
+                        float t[3];
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            const int b = p[a] + sc.di[a][s3[a]];
+                            i0[a] = clampi(b, 0, src.r[a] - 1);
+                            i1[a] = clampi(b + 1, 0, src.r[a] - 1);
+                            t[a] = sc.fr[a][s3[a]];
+                        }
+                        const float c00 = lerp32(sdf[lin3(src, i0[0], i0[1], i0[2])], sdf[lin3(src, i1[0], i0[1], i0[2])], t[0]);
+                        const float c10 = lerp32(sdf[lin3(src, i0[0], i1[1], i0[2])], sdf[lin3(src, i1[0], i1[1], i0[2])], t[0]);
+                        const float c01 = lerp32(sdf[lin3(src, i0[0], i0[1], i1[2])], sdf[lin3(src, i1[0], i0[1], i1[2])], t[0]);
+                        const float c11 = lerp32(sdf[lin3(src, i0[0], i1[1], i1[2])], sdf[lin3(src, i1[0], i1[1], i1[2])], t[0]);
+                        const float c0 = lerp32(c00, c10, t[1]);
+                        const float c1 = lerp32(c01, c11, t[1]);
+                        if (lerp32(c0, c1, t[2]) < 0.f) ++count;
+                    }
+        }
+        out[o] = (float)count / n3;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// P2: mask + base labels
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_mask_labels(const float *__restrict__ liquid, const float *__restrict__ solid,
+                                                        size_t n, double dx, double extrapolation, int8_t *__restrict__ mask,
+                                                        int8_t *__restrict__ labels)
+{
+    const double inner = dx * 2., outer = 3. * dx; // cpp:259-262 (fine bandwidth getter mismatch => 2)
+    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < n; o += (size_t)gridDim.x * kBlock) {
+        const double sdf = (double)liquid[o];
+        int m;
+        if (sdf > 0 && sdf < outer) m = 0;
+        else if (sdf <= 0.) {
+            if (sdf > -inner) m = 0;
+            else {
+                const double s = solid ? (double)solid[o] : -1.0;
+                m = (s > (-inner - extrapolation)) ? 0 : -1;
+            }
+        } else m = 1;
+        mask[o] = (int8_t)m;
+        labels[o] = (int8_t)(m == 0 ? AVS_ACTIVE : (m < 0 ? AVS_UP : AVS_INACTIVE)); // oct.cpp:383-388
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// P3: octree passes, one thread per PARENT cell (reads / writes only its own 8 children and itself)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void parent_coords(size_t o, const Grid3 &pg, int &i, int &j, int &k)
+{
+    i = (int)(o % pg.r[0]);
+    const size_t q = o / pg.r[0];
+    j = (int)(q % pg.r[1]);
+    k = (int)(q / pg.r[1]);
+}
+
+// pass 1 (oct.cpp:395-565): UP with an ACTIVE sibling -> ACTIVE; a parent with an ACTIVE child -> DOWN
+__global__ __launch_bounds__(kBlock) void k_oct_pass1(int8_t *__restrict__ lab, Grid3 g, int8_t *__restrict__ par, Grid3 pg)
+{
+    const size_t total = pg.vol();
+    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+        int i, j, k;
+        parent_coords(o, pg, i, j, k);
+        bool any = false;
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci)
+            any |= lab[lin3(g, 2 * i + (ci & 1), 2 * j + ((ci >> 1) & 1), 2 * k + ((ci >> 2) & 1))] == AVS_ACTIVE;
+        if (!any) continue;
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) {
+            const size_t c = lin3(g, 2 * i + (ci & 1), 2 * j + ((ci >> 1) & 1), 2 * k + ((ci >> 2) & 1));
+            if (lab[c] == AVS_UP) lab[c] = AVS_ACTIVE;
+        }
+        par[o] = AVS_DOWN;
+    }
+}
+
+// pass 2 (oct.cpp:657-754): DOWN children -> parent DOWN (list applied first, oct.cpp:145), then face
+// grading: an UP child with an ACTIVE face neighbour -> parent ACTIVE (oct.cpp:162)
+__global__ __launch_bounds__(kBlock) void k_oct_pass2(const int8_t *__restrict__ lab, Grid3 g, int8_t *__restrict__ par, Grid3 pg)
+{
+    const size_t total = pg.vol();
+    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+        int i, j, k;
+        parent_coords(o, pg, i, j, k);
+        bool down = false, grade = false;
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) {
+            const int c[3] = {2 * i + (ci & 1), 2 * j + ((ci >> 1) & 1), 2 * k + ((ci >> 2) & 1)};
+            const int8_t l = lab[lin3(g, c[0], c[1], c[2])];
+            if (l == AVS_DOWN) down = true;
+            if (l == AVS_UP) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int d = -1; d <= 1; d += 2) {
+                        int q[3] = {c[0], c[1], c[2]};
+                        q[a] += d;
+                        if (q[a] < 0 || q[a] >= g.r[a]) continue;
+                        if (lab[lin3(g, q[0], q[1], q[2])] == AVS_ACTIVE) grade = true;
+                    }
+            }
+        }
+        if (grade) par[o] = AVS_ACTIVE;
+        else if (down) par[o] = AVS_DOWN;
+    }
+}
+
+// pass 3 (oct.cpp:757-840): an UP child under a still INACTIVE parent -> parent UP
+__global__ __launch_bounds__(kBlock) void k_oct_pass3(const int8_t *__restrict__ lab, Grid3 g, int8_t *__restrict__ par, Grid3 pg)
+{
+    const size_t total = pg.vol();
+    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+        if (par[o] != AVS_INACTIVE) continue;
+        int i, j, k;
+        parent_coords(o, pg, i, j, k);
+        bool up = false;
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci)
+            up |= lab[lin3(g, 2 * i + (ci & 1), 2 * j + ((ci >> 1) & 1), 2 * k + ((ci >> 2) & 1))] == AVS_UP;
+        if (up) par[o] = AVS_UP;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_oct_top(int8_t *__restrict__ lab, size_t n)
+{
+    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < n; o += (size_t)gridDim.x * kBlock)
+        if (lab[o] == AVS_UP) lab[o] = AVS_ACTIVE;
+}
+
+__global__ __launch_bounds__(kBlock) void k_any_active(const int8_t *__restrict__ lab, size_t n, int *__restrict__ flag)
+{
+    bool any = false;
+    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < n; o += (size_t)gridDim.x * kBlock) any |= lab[o] == AVS_ACTIVE;
+    if (__ballot(any) && (threadIdx.x & 63) == 0) *flag = 1; // benign race: every writer stores 1
+}
+
+// ---------------------------------------------------------------------------------------------
+// P4: tile occupancy + classification
+// ---------------------------------------------------------------------------------------------
+struct TileGrid {
+    int tr[3];
+    __host__ __device__ size_t vol() const { return (size_t)tr[0] * tr[1] * tr[2]; }
+};
+__device__ __forceinline__ size_t tile_of(const TileGrid &t, int i, int j, int k)
+{
+    return (size_t)(i / kTile) + (size_t)t.tr[0] * ((size_t)(j / kTile) + (size_t)t.tr[1] * (size_t)(k / kTile));
+}
+
+// kind 0: faces (both directions along `axis`) of hit cells, cpp:887-1000; kind 1: the 4 `axis` edges, cpp:1003-1057
+__global__ __launch_bounds__(kBlock) void k_mark_tiles(const int8_t *__restrict__ lab, const float *__restrict__ liquid, double occ_sdf,
+                                                       Grid3 cg, int kind, int axis, TileGrid tg, uint8_t *__restrict__ occ)
+{
+    const size_t total = cg.vol();
+    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+        const bool hit = liquid ? ((double)liquid[o] < occ_sdf) : (lab[o] == AVS_ACTIVE);
+        if (!hit) continue;
+        int c[3];
+        c[0] = (int)(o % cg.r[0]);
+        const size_t q = o / cg.r[0];
+        c[1] = (int)(q % cg.r[1]);
+        c[2] = (int)(q / cg.r[1]);
+        if (kind == 0) {
+            for (int d = 0; d < 2; ++d) {
+                int f[3] = {c[0], c[1], c[2]};
+                f[axis] += d;
+                occ[tile_of(tg, f[0], f[1], f[2])] = 1;
+            }
+        } else {
+            for (int ei = 0; ei < 4; ++ei) {
+                int e[3] = {c[0], c[1], c[2]};
+                if (ei & 1) ++e[(axis + 1) % 3];
+                if (ei & 2) ++e[(axis + 2) % 3];
+                occ[tile_of(tg, e[0], e[1], e[2])] = 1;
+            }
+        }
+    }
+}
+
+struct ClassifyArgs {
+    int n[3]; // level-0 resolution
+    int level, axis;
+    double extrapolation;
+    const int8_t *lab;
+    const float *centerw, *edgew[3], *solid;
+};
+
+// classifyOctreeVelocityFacesPartial, cpp:1167-1323
+__global__ __launch_bounds__(kBlock) void k_classify_velocity(ClassifyArgs A, Grid3 fg, TileGrid tg, const uint8_t *__restrict__ occ,
+                                                              int32_t *__restrict__ out)
+{
+    const int l = A.level, axis = A.axis;
+    const Grid3 cg{{A.n[0] >> l, A.n[1] >> l, A.n[2] >> l}};
+    const Grid3 c0{{A.n[0], A.n[1], A.n[2]}};
+    const size_t total = fg.vol();
+    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+        int f[3];
+        f[0] = (int)(o % fg.r[0]);
+        const size_t q = o / fg.r[0];
+        f[1] = (int)(q % fg.r[1]);
+        f[2] = (int)(q / fg.r[1]);
+        int32_t v = AVS_UNASSIGNED;
+        if (occ[tile_of(tg, f[0], f[1], f[2])]) { // constant tiles are never visited (cpp:1197)
+            int b[3] = {f[0], f[1], f[2]};
+            --b[axis];
+            if (b[axis] < 0 || f[axis] >= cg.r[axis]) { // cpp:1210-1215
+                if (l == 0) v = AVS_OUTSIDE;
+            } else {
+                const int bl = A.lab[lin3(cg, b[0], b[1], b[2])], fl = A.lab[lin3(cg, f[0], f[1], f[2])];
+                if (l == 0) {
+                    if (bl == AVS_ACTIVE && fl == AVS_ACTIVE) { // cpp:1232-1272
+                        bool active = A.centerw[lin3(c0, b[0], b[1], b[2])] > 0.f || A.centerw[lin3(c0, f[0], f[1], f[2])] > 0.f;
+                        for (int ea = 0; ea < 3 && !active; ++ea) {
+                            if (ea == axis) continue;
+                            Grid3 eg = c0;
+                            eg.r[0] += (ea != 0);
+                            eg.r[1] += (ea != 1);
+                            eg.r[2] += (ea != 2);
+                            const int oa = 3 - axis - ea;
+                            for (int d = 0; d < 2; ++d) {
+                                int e[3] = {f[0], f[1], f[2]};
+                                e[oa] += d;
+                                if (A.edgew[ea][lin3(eg, e[0], e[1], e[2])] > 0.f) { active = true; break; }
+                            }
+                        }
+                        if (active) {
+                            // solidSurface.getValue(face position) = average of the two axial cells (exact index space)
+                            const float s = A.solid ? lerp32(A.solid[lin3(c0, b[0], b[1], b[2])], A.solid[lin3(c0, f[0], f[1], f[2])], 0.5f) : -1.f;
+                            v = ((double)s > -A.extrapolation) ? AVS_SOLIDBOUNDARY : 0;
+                        } else v = AVS_OUTSIDE;
+                    } else if (bl == AVS_INACTIVE || fl == AVS_INACTIVE) v = AVS_OUTSIDE;
+                    else if ((bl == AVS_UP && fl == AVS_ACTIVE) || (bl == AVS_ACTIVE && fl == AVS_UP)) v = 0;
+                } else if ((bl == AVS_ACTIVE && fl == AVS_ACTIVE) || (bl == AVS_UP && fl == AVS_ACTIVE) || (bl == AVS_ACTIVE && fl == AVS_UP))
+                    v = 0; // cpp:1301-1319
+            }
+        }
+        out[o] = v;
+    }
+}
+
+// classifyEdgeStressesPartial, cpp:1325-1405
+__global__ __launch_bounds__(kBlock) void k_classify_edges(ClassifyArgs A, Grid3 eg, TileGrid tg, const uint8_t *__restrict__ occ,
+                                                           int32_t *__restrict__ out)
+{
+    const int l = A.level, axis = A.axis;
+    const Grid3 cg{{A.n[0] >> l, A.n[1] >> l, A.n[2] >> l}};
+    const size_t total = eg.vol();
+    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+        int e[3];
+        e[0] = (int)(o % eg.r[0]);
+        const size_t q = o / eg.r[0];
+        e[1] = (int)(q % eg.r[1]);
+        e[2] = (int)(q / eg.r[1]);
+        int32_t v = AVS_UNASSIGNED;
+        if (occ[tile_of(tg, e[0], e[1], e[2])]) {
+            bool active = false;
+            for (int ci = 0; ci < 4; ++ci) { // HDKedgeToCell, util.h:169-185
+                int c[3] = {e[0], e[1], e[2]};
+                if (!(ci & 1)) --c[(axis + 1) % 3];
+                if (!(ci & 2)) --c[(axis + 2) % 3];
+                if (c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] >= cg.r[0] || c[1] >= cg.r[1] || c[2] >= cg.r[2]) {
+                    v = AVS_OUTSIDE;
+                    break; // isStressActive keeps whatever it was (cpp:1368-1369)
+                }
+                const int lb = A.lab[lin3(cg, c[0], c[1], c[2])];
+                if (lb == AVS_DOWN) { active = false; break; }
+                if (lb == AVS_ACTIVE) active = true;
+            }
+            if (active) v = (l == 0) ? ((A.edgew[axis][o] > 0.f) ? 0 : AVS_OUTSIDE) : 0;
+        }
+        out[o] = v;
+    }
+}
+
+// classifyCenterStressesPartial, cpp:1407-1443
+__global__ __launch_bounds__(kBlock) void k_classify_centers(const int8_t *__restrict__ lab, const float *__restrict__ centerw, int level,
+                                                             size_t n, int32_t *__restrict__ out)
+{
+    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < n; o += (size_t)gridDim.x * kBlock)
+        out[o] = (lab[o] == AVS_ACTIVE && (level != 0 || centerw[o] > 0.f)) ? 0 : AVS_UNASSIGNED;
+}
+
+// ---------------------------------------------------------------------------------------------
+// P5: numbering in HDK tile order = exclusive scan over the tile-major flag sequence
+// ---------------------------------------------------------------------------------------------
+// position of voxel (i, j, k) in the "for each 16^3 tile (x fastest), for each voxel (x fastest)" sweep
+__device__ __forceinline__ size_t tilemajor_pos(const Grid3 &g, int i, int j, int k)
+{
+    const int tx = i / kTile, ty = j / kTile, tz = k / kTile;
+    const int ex = min(kTile, g.r[0] - kTile * tx), ey = min(kTile, g.r[1] - kTile * ty), ez = min(kTile, g.r[2] - kTile * tz);
+    const int lx = i - kTile * tx, ly = j - kTile * ty, lz = k - kTile * tz;
+    return (size_t)g.r[0] * g.r[1] * kTile * tz + (size_t)g.r[0] * kTile * ty * ez + (size_t)kTile * tx * ey * ez +
+           ((size_t)lz * ey + ly) * ex + lx;
+}
+
+__global__ __launch_bounds__(kBlock) void k_flags_tilemajor(const int32_t *__restrict__ grid, Grid3 g, int32_t *__restrict__ flags)
+{
+    const size_t total = g.vol();
+    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+        const int i = (int)(o % g.r[0]);
+        const size_t q = o / g.r[0];
+        flags[tilemajor_pos(g, i, (int)(q % g.r[1]), (int)(q / g.r[1]))] = (grid[o] == 0) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_apply_ids(int32_t *__restrict__ grid, Grid3 g, const int32_t *__restrict__ ids,
+                                                      const long long *__restrict__ base)
+{
+    const size_t total = g.vol();
+    const int32_t b = (int32_t)*base;
+    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+        if (grid[o] != 0) continue;
+        const int i = (int)(o % g.r[0]);
+        const size_t q = o / g.r[0];
+        grid[o] = b + ids[tilemajor_pos(g, i, (int)(q % g.r[1]), (int)(q / g.r[1]))];
+    }
+}
+
+__global__ void k_bump_base(long long *base, const int32_t *total)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *base += *total;
+}
+
+} // namespace avs
+
+// ---------------------------------------------------------------------------------------------
+// host object
+// ---------------------------------------------------------------------------------------------
+using namespace avs;
+
+struct avs_prepass {
+    avs_prepass_desc desc{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int levels = 0; // after capping
+    int max_levels = 0;
+    DevBuf<float> liquid, solid, centerw, edgew[3], facew[3];
+    bool have_solid = false;
+    DevBuf<int8_t> mask, labels[AVS_MAX_LEVELS];
+    DevBuf<int32_t> vidx[AVS_MAX_LEVELS][3], eidx[AVS_MAX_LEVELS][3], cidx[AVS_MAX_LEVELS];
+    int64_t counts[3] = {0, 0, 0};
+    double ms[4] = {0, 0, 0, 0};
+    bool ready = false;
+};
+
+static void pp_res(const avs_prepass_desc &d, int kind, int level, int axis, int r[3])
+{
+    r[0] = d.nx >> level;
+    r[1] = d.ny >> level;
+    r[2] = d.nz >> level;
+    if (kind == 0) r[axis] += 1;
+    else if (kind == 1) {
+        r[0] += (axis != 0);
+        r[1] += (axis != 1);
+        r[2] += (axis != 2);
+    }
+}
+static Grid3 g3(const int r[3]) { return Grid3{{r[0], r[1], r[2]}}; }
+
+static void sub_consts(int n, bool centered, int s, int *di, float *fr)
+{
+    // identical expression to oracle/avs_oracle.c subsample_consts (evaluated in double, rounded once)
+    const double d = ((centered ? 0.5 : 0.0) - 0.5) + (((double)s + 0.5) / (double)n - 0.5);
+    const double fl = std::floor(d);
+    *di = (int)fl;
+    *fr = (float)(d - fl);
+}
+
+static avs_status run_weights(avs_prepass *p, const bool centered[3], const int tr[3], float *out)
+{
+    SubConsts sc{};
+    sc.n = p->desc.n_super;
+    for (int a = 0; a < 3; ++a)
+        for (int s = 0; s < sc.n; ++s) sub_consts(sc.n, centered[a], s, &sc.di[a][s], &sc.fr[a][s]);
+    int sr[3];
+    pp_res(p->desc, 2, 0, 0, sr);
+    hipLaunchKernelGGL(k_sdf_weights, dim3(grid_for(g3(tr).vol())), dim3(kBlock), 0, p->stream, p->liquid.p, g3(sr), g3(tr), sc, out);
+    AVS_HIP(hipGetLastError());
+    return AVS_OK;
+}
+
+struct EvTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t s;
+    explicit EvTimer(hipStream_t st) : s(st) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
+    ~EvTimer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    void start() { (void)hipEventRecord(a, s); }
+    double stop() { (void)hipEventRecord(b, s); (void)hipEventSynchronize(b); float ms = 0.f; (void)hipEventElapsedTime(&ms, a, b); return ms; }
+};
+
+extern "C" {
+
+avs_status avs_prepass_create(const avs_prepass_desc *d, avs_prepass **out)
+{
+    AVS_REQUIRE(d && out, AVS_EINVAL, "null argument");
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    AVS_REQUIRE(pow2(d->nx) && pow2(d->ny) && pow2(d->nz), AVS_EINVAL, "base resolution must be a power of two per axis");
+    AVS_REQUIRE(d->desired_levels >= 1 && d->desired_levels <= AVS_MAX_LEVELS, AVS_EINVAL, "desired_levels out of range");
+    AVS_REQUIRE(d->n_super >= 1 && d->n_super <= kMaxSuper, AVS_EINVAL, "n_super must be in [1, %d]", kMaxSuper);
+    AVS_REQUIRE(d->dx > 0., AVS_EINVAL, "dx must be positive");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    AVS_REQUIRE(e == hipSuccess && ndev > 0, AVS_EHIP, "no HIP device available (%s)", hipGetErrorString(e));
+    AVS_REQUIRE(d->device >= 0 && d->device < ndev, AVS_EINVAL, "device out of range");
+    AVS_HIP(hipSetDevice(d->device));
+    avs_prepass *p = new (std::nothrow) avs_prepass();
+    AVS_REQUIRE(p, AVS_ENOMEM, "out of host memory");
+    p->desc = *d;
+    if (d->stream) p->stream = reinterpret_cast<hipStream_t>(d->stream);
+    else {
+        if (hipStreamCreate(&p->stream) != hipSuccess) { delete p; set_error("hipStreamCreate failed"); return AVS_EHIP; }
+        p->own_stream = true;
+    }
+    // level cap, oct.cpp:32-40
+    int L = d->desired_levels;
+    for (int n : {d->nx, d->ny, d->nz}) {
+        int lg = 0;
+        while ((1 << (lg + 1)) <= n) ++lg;
+        if (lg < L) L = lg;
+    }
+    p->max_levels = L < 1 ? 1 : L;
+    *out = p;
+    return AVS_OK;
+}
+
+void avs_prepass_destroy(avs_prepass *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->desc.device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *solid, avs_memspace where)
+{
+    AVS_REQUIRE(p && liquid, AVS_EINVAL, "null argument");
+    AVS_HIP(hipSetDevice(p->desc.device));
+    hipStream_t st = p->stream;
+    const avs_prepass_desc &d = p->desc;
+    int r0[3];
+    pp_res(d, 2, 0, 0, r0);
+    const size_t n0 = g3(r0).vol();
+    const double extrapolation = d.dx * d.extrapolation_scale; // cpp:243
+    p->ready = false;
+    EvTimer t(st);
+
+    AVS_TRY(p->liquid.alloc(n0));
+    AVS_HIP(copy_in(p->liquid.p, liquid, n0 * sizeof(float), where, st));
+    p->have_solid = solid != nullptr;
+    if (solid) {
+        AVS_TRY(p->solid.alloc(n0));
+        AVS_HIP(copy_in(p->solid.p, solid, n0 * sizeof(float), where, st));
+    }
+    if (where == AVS_MEM_HOST) AVS_HIP(hipStreamSynchronize(st));
+
+    // ---- P1 weights ------------------------------------------------------------------------
+    t.start();
+    {
+        const bool cc[3] = {true, true, true};
+        AVS_TRY(p->centerw.alloc(n0));
+        AVS_TRY(run_weights(p, cc, r0, p->centerw.p));
+        for (int a = 0; a < 3; ++a) {
+            int er[3], fr[3];
+            pp_res(d, 1, 0, a, er);
+            pp_res(d, 0, 0, a, fr);
+            const bool ce[3] = {a == 0, a == 1, a == 2};
+            const bool cf[3] = {a != 0, a != 1, a != 2};
+            AVS_TRY(p->edgew[a].alloc(g3(er).vol()));
+            AVS_TRY(run_weights(p, ce, er, p->edgew[a].p));
+            AVS_TRY(p->facew[a].alloc(g3(fr).vol()));
+            AVS_TRY(run_weights(p, cf, fr, p->facew[a].p));
+        }
+    }
+    p->ms[0] = t.stop();
+
+    // ---- P2 + P3 octree --------------------------------------------------------------------
+    t.start();
+    const int L = p->max_levels;
+    AVS_TRY(p->mask.alloc(n0));
+    for (int l = 0; l < L; ++l) {
+        int r[3];
+        pp_res(d, 2, l, 0, r);
+        AVS_TRY(p->labels[l].alloc(g3(r).vol()));
+        AVS_HIP(hipMemsetAsync(p->labels[l].p, 0, g3(r).vol(), st)); // INACTIVE, oct.cpp:59,69
+    }
+    hipLaunchKernelGGL(k_mask_labels, dim3(grid_for(n0)), dim3(kBlock), 0, st, p->liquid.p, solid ? p->solid.p : nullptr, n0, d.dx,
+                       extrapolation, p->mask.p, p->labels[0].p);
+    for (int l = 0; l < L - 1; ++l) {
+        int r[3], rp[3];
+        pp_res(d, 2, l, 0, r);
+        pp_res(d, 2, l + 1, 0, rp);
+        const unsigned g = grid_for(g3(rp).vol());
+        hipLaunchKernelGGL(k_oct_pass1, dim3(g), dim3(kBlock), 0, st, p->labels[l].p, g3(r), p->labels[l + 1].p, g3(rp));
+        hipLaunchKernelGGL(k_oct_pass2, dim3(g), dim3(kBlock), 0, st, p->labels[l].p, g3(r), p->labels[l + 1].p, g3(rp));
+        hipLaunchKernelGGL(k_oct_pass3, dim3(g), dim3(kBlock), 0, st, p->labels[l].p, g3(r), p->labels[l + 1].p, g3(rp));
+    }
+    {
+        int r[3];
+        pp_res(d, 2, L - 1, 0, r);
+        hipLaunchKernelGGL(k_oct_top, dim3(grid_for(g3(r).vol())), dim3(kBlock), 0, st, p->labels[L - 1].p, g3(r).vol());
+    }
+    // cap at the first level without ACTIVE cells, oct.cpp:198-211
+    DevBuf<int> flags;
+    AVS_TRY(flags.alloc(AVS_MAX_LEVELS));
+    AVS_HIP(hipMemsetAsync(flags.p, 0, AVS_MAX_LEVELS * sizeof(int), st));
+    for (int l = 0; l < L; ++l) {
+        int r[3];
+        pp_res(d, 2, l, 0, r);
+        hipLaunchKernelGGL(k_any_active, dim3(grid_for(g3(r).vol(), 4096)), dim3(kBlock), 0, st, p->labels[l].p, g3(r).vol(), flags.p + l);
+    }
+    AVS_HIP(hipGetLastError());
+    int hflags[AVS_MAX_LEVELS] = {};
+    AVS_HIP(hipMemcpyAsync(hflags, flags.p, sizeof(hflags), hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipStreamSynchronize(st));
+    int capped = 0;
+    while (capped < L && hflags[capped]) ++capped;
+    p->levels = capped;
+    p->ms[1] = t.stop();
+    for (int k = 0; k < 3; ++k) p->counts[k] = 0;
+    if (capped == 0) { // no liquid in the refinement band: nothing to solve (the reference asserts here, oct.cpp:206)
+        p->ms[2] = p->ms[3] = 0.;
+        p->ready = true;
+        return AVS_OK;
+    }
+
+    // ---- P4 classification -----------------------------------------------------------------
+    t.start();
+    const double occ_sdf = 2. * d.dx; // cpp:907
+    size_t max_vol = 0;
+    for (int l = 0; l < capped; ++l) {
+        int cr[3];
+        pp_res(d, 2, l, 0, cr);
+        for (int a = 0; a < 3; ++a) {
+            for (int kind = 0; kind < 2; ++kind) {
+                int gr[3];
+                pp_res(d, kind, l, a, gr);
+                DevBuf<int32_t> &buf = kind == 0 ? p->vidx[l][a] : p->eidx[l][a];
+                AVS_TRY(buf.alloc(g3(gr).vol()));
+                if (g3(gr).vol() > max_vol) max_vol = g3(gr).vol();
+                TileGrid tg{{(gr[0] + kTile - 1) / kTile, (gr[1] + kTile - 1) / kTile, (gr[2] + kTile - 1) / kTile}};
+                DevBuf<uint8_t> occ;
+                AVS_TRY(occ.alloc(tg.vol()));
+                AVS_HIP(hipMemsetAsync(occ.p, 0, tg.vol(), st));
+                const float *liq = (kind == 0 && l == 0) ? p->liquid.p : nullptr;
+                hipLaunchKernelGGL(k_mark_tiles, dim3(grid_for(g3(cr).vol())), dim3(kBlock), 0, st, p->labels[l].p, liq, occ_sdf, g3(cr), kind, a, tg, occ.p);
+                ClassifyArgs A{};
+                A.n[0] = d.nx; A.n[1] = d.ny; A.n[2] = d.nz;
+                A.level = l;
+                A.axis = a;
+                A.extrapolation = extrapolation;
+                A.lab = p->labels[l].p;
+                A.centerw = p->centerw.p;
+                for (int b = 0; b < 3; ++b) A.edgew[b] = p->edgew[b].p;
+                A.solid = solid ? p->solid.p : nullptr;
+                if (kind == 0) hipLaunchKernelGGL(k_classify_velocity, dim3(grid_for(g3(gr).vol())), dim3(kBlock), 0, st, A, g3(gr), tg, (const uint8_t *)occ.p, buf.p);
+                else hipLaunchKernelGGL(k_classify_edges, dim3(grid_for(g3(gr).vol())), dim3(kBlock), 0, st, A, g3(gr), tg, (const uint8_t *)occ.p, buf.p);
+                AVS_HIP(hipGetLastError());
+                AVS_HIP(hipStreamSynchronize(st)); // occ dies here
+            }
+        }
+        AVS_TRY(p->cidx[l].alloc(g3(cr).vol()));
+        if (g3(cr).vol() > max_vol) max_vol = g3(cr).vol();
+        hipLaunchKernelGGL(k_classify_centers, dim3(grid_for(g3(cr).vol())), dim3(kBlock), 0, st, p->labels[l].p, p->centerw.p, l, g3(cr).vol(), p->cidx[l].p);
+    }
+    AVS_HIP(hipGetLastError());
+    p->ms[2] = t.stop();
+
+    // ---- P5 numbering ----------------------------------------------------------------------
+    t.start();
+    DevBuf<int32_t> fl, ids, scan_tmp;
+    DevBuf<long long> base;
+    AVS_TRY(fl.alloc(max_vol + 1));
+    AVS_TRY(ids.alloc(max_vol + 1));
+    AVS_TRY(scan_tmp.alloc(scan_tmp_elems((int64_t)max_vol)));
+    AVS_TRY(base.alloc(3));
+    AVS_HIP(hipMemsetAsync(base.p, 0, 3 * sizeof(long long), st));
+    for (int kind = 0; kind < 3; ++kind)
+        for (int l = 0; l < capped; ++l)
+            for (int a = 0; a < (kind == 2 ? 1 : 3); ++a) {
+                int gr[3];
+                pp_res(d, kind, l, a, gr);
+                const size_t nv = g3(gr).vol();
+                int32_t *grid = kind == 0 ? p->vidx[l][a].p : (kind == 1 ? p->eidx[l][a].p : p->cidx[l].p);
+                hipLaunchKernelGGL(k_flags_tilemajor, dim3(grid_for(nv)), dim3(kBlock), 0, st, (const int32_t *)grid, g3(gr), fl.p);
+                AVS_TRY(exclusive_scan_i32(fl.p, ids.p, (int64_t)nv, scan_tmp.p, scan_tmp.n, st));
+                hipLaunchKernelGGL(k_apply_ids, dim3(grid_for(nv)), dim3(kBlock), 0, st, grid, g3(gr), (const int32_t *)ids.p, (const long long *)(base.p + kind));
+                hipLaunchKernelGGL(k_bump_base, dim3(1), dim3(64), 0, st, base.p + kind, (const int32_t *)(ids.p + nv));
+            }
+    AVS_HIP(hipGetLastError());
+    long long hb[3] = {0, 0, 0};
+    AVS_HIP(hipMemcpyAsync(hb, base.p, sizeof(hb), hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < 3; ++k) p->counts[k] = hb[k];
+    p->ms[3] = t.stop();
+    p->ready = true;
+    return AVS_OK;
+}
+
+avs_status avs_prepass_get_info(avs_prepass *p, avs_prepass_info *info)
+{
+    AVS_REQUIRE(p && info, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(p->ready, AVS_ESTATE, "call avs_prepass_run first");
+    info->levels = p->levels;
+    info->n_velocity = p->counts[0];
+    info->n_edge = p->counts[1];
+    info->n_center = p->counts[2];
+    info->weights_ms = p->ms[0];
+    info->octree_ms = p->ms[1];
+    info->classify_ms = p->ms[2];
+    info->number_ms = p->ms[3];
+    return AVS_OK;
+}
+
+avs_status avs_prepass_get_labels(avs_prepass *p, int32_t level, int8_t *out, avs_memspace where)
+{
+    AVS_REQUIRE(p && out, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(p->ready && level >= 0 && level < p->levels, AVS_EINVAL, "level out of range");
+    AVS_HIP(hipSetDevice(p->desc.device));
+    int r[3];
+    pp_res(p->desc, 2, level, 0, r);
+    AVS_HIP(copy_out(out, p->labels[level].p, g3(r).vol(), where, p->stream));
+    AVS_HIP(hipStreamSynchronize(p->stream));
+    return AVS_OK;
+}
+
+avs_status avs_prepass_get_mask(avs_prepass *p, int8_t *out, avs_memspace where)
+{
+    AVS_REQUIRE(p && out, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(p->ready, AVS_ESTATE, "call avs_prepass_run first");
+    AVS_HIP(hipSetDevice(p->desc.device));
+    int r[3];
+    pp_res(p->desc, 2, 0, 0, r);
+    AVS_HIP(copy_out(out, p->mask.p, g3(r).vol(), where, p->stream));
+    AVS_HIP(hipStreamSynchronize(p->stream));
+    return AVS_OK;
+}
+
+avs_status avs_prepass_get_index(avs_prepass *p, avs_index_kind kind, int32_t level, int32_t axis, int32_t *out, avs_memspace where)
+{
+    AVS_REQUIRE(p && out, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(p->ready && level >= 0 && level < p->levels && axis >= 0 && axis < 3, AVS_EINVAL, "level / axis out of range");
+    AVS_HIP(hipSetDevice(p->desc.device));
+    int r[3];
+    pp_res(p->desc, (int)kind, level, axis, r);
+    const int32_t *src = kind == AVS_INDEX_VELOCITY ? p->vidx[level][axis].p : (kind == AVS_INDEX_EDGE ? p->eidx[level][axis].p : p->cidx[level].p);
+    AVS_HIP(copy_out(out, src, g3(r).vol() * sizeof(int32_t), where, p->stream));
+    AVS_HIP(hipStreamSynchronize(p->stream));
+    return AVS_OK;
+}
+
+avs_status avs_prepass_get_weights(avs_prepass *p, avs_field_kind kind, int32_t axis, float *out, avs_memspace where)
+{
+    AVS_REQUIRE(p && out, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(p->ready && axis >= 0 && axis < 3, AVS_EINVAL, "not ready / axis out of range");
+    AVS_HIP(hipSetDevice(p->desc.device));
+    int r[3];
+    const float *src;
+    switch (kind) {
+    case AVS_FIELD_CENTER_WEIGHTS: pp_res(p->desc, 2, 0, 0, r); src = p->centerw.p; break;
+    case AVS_FIELD_EDGE_WEIGHTS: pp_res(p->desc, 1, 0, axis, r); src = p->edgew[axis].p; break;
+    case AVS_FIELD_FACE_WEIGHTS: pp_res(p->desc, 0, 0, axis, r); src = p->facew[axis].p; break;
+    default: set_error("not a weight field"); return AVS_EINVAL;
+    }
+    AVS_HIP(copy_out(out, src, g3(r).vol() * sizeof(float), where, p->stream));
+    AVS_HIP(hipStreamSynchronize(p->stream));
+    return AVS_OK;
+}
+
+avs_status avs_prepass_apply(avs_prepass *p, avs_ctx *ctx)
+{
+    AVS_REQUIRE(p && ctx, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(p->ready && p->levels >= 1, AVS_ESTATE, "pre-pass has no levels (no liquid in the refinement band)");
+    AVS_REQUIRE(ctx->desc.levels == p->levels && ctx->desc.nx == p->desc.nx && ctx->desc.ny == p->desc.ny && ctx->desc.nz == p->desc.nz &&
+                    ctx->desc.device == p->desc.device,
+                AVS_EINVAL, "context (levels %d) does not match the pre-pass (levels %d)", ctx->desc.levels, p->levels);
+    AVS_HIP(hipStreamSynchronize(p->stream));
+    for (int l = 0; l < p->levels; ++l) {
+        AVS_TRY(avs_set_labels(ctx, l, p->labels[l].p, AVS_MEM_DEVICE));
+        for (int a = 0; a < 3; ++a) {
+            AVS_TRY(avs_set_index_field(ctx, AVS_INDEX_VELOCITY, l, a, p->vidx[l][a].p, AVS_MEM_DEVICE));
+            AVS_TRY(avs_set_index_field(ctx, AVS_INDEX_EDGE, l, a, p->eidx[l][a].p, AVS_MEM_DEVICE));
+        }
+        AVS_TRY(avs_set_index_field(ctx, AVS_INDEX_CENTER, l, 0, p->cidx[l].p, AVS_MEM_DEVICE));
+    }
+    AVS_TRY(avs_set_dof_counts(ctx, p->counts[0], p->counts[1], p->counts[2]));
+    AVS_TRY(avs_set_scalar_field(ctx, AVS_FIELD_CENTER_WEIGHTS, 0, p->centerw.p, 0.f, AVS_MEM_DEVICE));
+    for (int a = 0; a < 3; ++a) {
+        AVS_TRY(avs_set_scalar_field(ctx, AVS_FIELD_EDGE_WEIGHTS, a, p->edgew[a].p, 0.f, AVS_MEM_DEVICE));
+        AVS_TRY(avs_set_scalar_field(ctx, AVS_FIELD_FACE_WEIGHTS, a, p->facew[a].p, 0.f, AVS_MEM_DEVICE));
+    }
+    AVS_HIP(hipStreamSynchronize(ctx->stream));
+    return AVS_OK;
+}
+
+} // extern "C"

@@ -232,3 +232,72 @@ def pcg_csr(row_ptr, col, val, b, x0, tol=1e-3, max_iters=2500, device=0):
                                x.ctypes.data, float(tol), int(max_iters), capi.MEM_HOST, device, None,
                                C.byref(info)))
     return x, info
+
+
+class DevicePrepass:
+    """Pre-pass on the GPU (avs_prepass_*): liquid / solid SDF -> weights, label pyramid, index pyramids."""
+
+    def __init__(self, res, dx, levels, n_super=3, extrapolation=0.5, device=0, stream=None):
+        self.lib = capi.load()
+        self.res = tuple(int(r) for r in res)
+        d = capi.PrepassDesc(self.res[0], self.res[1], self.res[2], float(dx), int(levels), int(n_super),
+                             float(extrapolation), int(device), C.c_void_p(stream or 0))
+        h = C.c_void_p()
+        capi.check(self.lib.avs_prepass_create(C.byref(d), C.byref(h)))
+        self.h = h
+        self.info = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.avs_prepass_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, liquid, solid=None):
+        pl, wl = capi.ptr_of(liquid)
+        ps, ws = capi.ptr_of(solid)
+        if solid is not None and ws != wl:
+            raise ValueError("liquid and solid must live in the same memory space")
+        capi.check(self.lib.avs_prepass_run(self.h, pl, ps, wl))
+        info = capi.PrepassInfo()
+        capi.check(self.lib.avs_prepass_get_info(self.h, C.byref(info)))
+        self.info = info
+        return info
+
+    def apply(self, solver):
+        capi.check(self.lib.avs_prepass_apply(self.h, solver.h))
+        solver.counts = (self.info.n_velocity, self.info.n_edge, self.info.n_center)
+
+    def _shape(self, kind, level, axis):
+        r = [self.res[0] >> level, self.res[1] >> level, self.res[2] >> level]
+        if kind == 0:
+            r[axis] += 1
+        elif kind == 1:
+            r = [r[a] + (a != axis) for a in range(3)]
+        return (r[2], r[1], r[0])
+
+    def labels(self, level):
+        out = np.empty(self._shape(2, level, 0), np.int8)
+        capi.check(self.lib.avs_prepass_get_labels(self.h, level, out.ctypes.data, capi.MEM_HOST))
+        return out
+
+    def mask(self):
+        out = np.empty(self._shape(2, 0, 0), np.int8)
+        capi.check(self.lib.avs_prepass_get_mask(self.h, out.ctypes.data, capi.MEM_HOST))
+        return out
+
+    def index(self, kind, level, axis=0):
+        out = np.empty(self._shape(kind, level, axis), np.int32)
+        capi.check(self.lib.avs_prepass_get_index(self.h, kind, level, axis, out.ctypes.data, capi.MEM_HOST))
+        return out
+
+    def weights(self, kind, axis=0):
+        k = {capi.FIELD_CENTER_WEIGHTS: 2, capi.FIELD_EDGE_WEIGHTS: 1, capi.FIELD_FACE_WEIGHTS: 0}[kind]
+        out = np.empty(self._shape(k, 0, axis), np.float32)
+        capi.check(self.lib.avs_prepass_get_weights(self.h, kind, axis, out.ctypes.data, capi.MEM_HOST))
+        return out

@@ -83,16 +83,20 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from adaptiveviscositysolver_amd import ViscositySolve, prepass, scenes
+    from adaptiveviscositysolver_amd import DevicePrepass, ViscositySolve, scenes
 
     # ---- synthetic input, resident in HBM before the timed region -------------------------
+    # analytic SDF + velocity (torch), then the device pre-pass (HIP): weights, octree, classification, numbering
     sc = scenes.fat_beam(a.n, a.levels, device=dev)
-    pyr = prepass.build_pyramid(sc)
-    solver = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=local_rank)
-    solver.set_pyramid(pyr)
+    pp = DevicePrepass(sc.res, sc.dx, sc.levels, device=local_rank)
+    pinfo = pp.run(sc.liquid, sc.solid)
+    levels = pinfo.levels
+    solver = ViscositySolve(sc.res, sc.dx, sc.dt, levels, device=local_rank)
+    pp.apply(solver)
     solver.set_scene_fields(sc)
-    levels = pyr.levels
-    del pyr
+    prepass_ms = {"weights": pinfo.weights_ms, "octree": pinfo.octree_ms, "classify": pinfo.classify_ms,
+                  "numbering": pinfo.number_ms}
+    pp.close()
     torch.cuda.empty_cache()
     use_dist = world > 1 or a.force_dist
     torch.cuda.synchronize()
@@ -184,6 +188,7 @@ def main():
             "solve_event_iter_per_s": iters_total / (sum(solve_ms) * 1e-3),
             "assembly_ms": {"stencils": ai.stencil_ms, "initial_guess": ai.guess_ms, "system": ai.system_ms,
                             "wall": assemble_wall_ms},
+            "prepass_ms": prepass_ms,
             "partition_ms": partition_ms,
             "hot_path_ms": assemble_wall_ms + partition_ms + elapsed / a.steps * 1e3,
         }

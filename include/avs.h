@@ -177,6 +177,40 @@ avs_status avs_spmv_csr(int64_t n, const int32_t *row_ptr, const int32_t *col, c
  * returns the mean HIP-event time per launch in *ms_per_launch. */
 avs_status avs_bench_spmv(avs_ctx *ctx, int32_t variant, int32_t repeats, double *ms_per_launch);
 
+/* ------------------------------------------------------------------------------------------
+ * Pre-pass on the device (SURVEY 8(f) "next #1/#4"): what solveGasSubclass computes BEFORE the hot
+ * path -- integration weights (cpp:712-766), refinement mask (cpp:815-867), octree label pyramid
+ * (HDK_OctreeGrid.cpp:4-243), classification (cpp:1087-1443) and serial numbering in HDK tile
+ * order (cpp:1445-1715) -- from the liquid / solid SDFs (centre lattice, fp32, x fastest).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct avs_prepass avs_prepass;
+typedef struct {
+    int32_t nx, ny, nz;         /* powers of two */
+    double dx;
+    int32_t desired_levels;     /* getOctreeLevels(), cpp:263 */
+    int32_t n_super;            /* getNumberSuperSamples(), cpp:756 (default 3) */
+    double extrapolation_scale; /* getExtrapolation(), cpp:243 (default 0.5) */
+    int32_t device;
+    void *stream;
+} avs_prepass_desc;
+typedef struct {
+    int32_t levels;                       /* after capping, HDK_OctreeGrid.cpp:198-211; 0 = no liquid */
+    int64_t n_velocity, n_edge, n_center; /* cpp:395-408 */
+    double weights_ms, octree_ms, classify_ms, number_ms;
+} avs_prepass_info;
+avs_status avs_prepass_create(const avs_prepass_desc *desc, avs_prepass **out);
+void avs_prepass_destroy(avs_prepass *pp);
+avs_status avs_prepass_run(avs_prepass *pp, const float *liquid_sdf, const float *solid_sdf /* NULL: none */, avs_memspace where);
+avs_status avs_prepass_get_info(avs_prepass *pp, avs_prepass_info *info);
+avs_status avs_prepass_get_labels(avs_prepass *pp, int32_t level, int8_t *out, avs_memspace where);
+avs_status avs_prepass_get_mask(avs_prepass *pp, int8_t *out, avs_memspace where);
+avs_status avs_prepass_get_index(avs_prepass *pp, avs_index_kind kind, int32_t level, int32_t axis, int32_t *out, avs_memspace where);
+avs_status avs_prepass_get_weights(avs_prepass *pp, avs_field_kind kind /* CENTER / EDGE / FACE weights */, int32_t axis, float *out,
+                                   avs_memspace where);
+/* hands labels, index pyramids, DOF counts and the three weight fields to a solve context created with
+ * levels == info.levels on the same device (device-to-device copies) */
+avs_status avs_prepass_apply(avs_prepass *pp, avs_ctx *ctx);
+
 /* Measured stream ceilings of the device for the access pattern of the SpMV's matrix stream
  * (mode 0: read-only 16 B/lane, 1: read-only non-temporal, 2: copy); GB/s of bytes moved. */
 avs_status avs_bench_stream(int32_t mode, int64_t bytes, int32_t repeats, int32_t device, double *gbps);
