@@ -38,7 +38,8 @@ EXPORTED_SYMBOLS = [
     "avs_get_edge_stencils", "avs_get_center_stencils", "avs_pcg_csr", "avs_spmv_csr",
     "avs_bench_spmv", "avs_bench_stream", "avs_prepass_create", "avs_prepass_destroy", "avs_prepass_run",
     "avs_prepass_get_info", "avs_prepass_get_labels", "avs_prepass_get_mask", "avs_prepass_get_index",
-    "avs_prepass_get_weights", "avs_prepass_apply", "avs_get_dof_table", "avs_plan_owners", "avs_plan_create", "avs_plan_get_sizes",
+    "avs_prepass_get_weights", "avs_prepass_get_regular_index", "avs_prepass_apply", "avs_set_regular_index_field",
+    "avs_transfer_to_regular_grid", "avs_get_node_grid", "avs_get_dof_table", "avs_plan_owners", "avs_plan_create", "avs_plan_get_sizes",
     "avs_plan_get_arrays", "avs_plan_destroy", "avs_dist_get_unique_id", "avs_dist_init",
     "avs_local_group_create", "avs_local_group_destroy", "avs_dist_init_local", "avs_dist_partition",
     "avs_dist_get_plan_sizes", "avs_dist_get_overlap_tiles", "avs_dist_solve", "avs_dist_get_solution",
@@ -78,7 +79,7 @@ class PrepassDesc(C.Structure):
 
 class PrepassInfo(C.Structure):
     _fields_ = [("levels", C.c_int32), ("n_velocity", C.c_int64), ("n_edge", C.c_int64), ("n_center", C.c_int64),
-                ("weights_ms", C.c_double), ("octree_ms", C.c_double), ("classify_ms", C.c_double),
+                ("n_regular", C.c_int64), ("weights_ms", C.c_double), ("octree_ms", C.c_double), ("classify_ms", C.c_double),
                 ("number_ms", C.c_double)]
 
 
@@ -136,6 +137,10 @@ def load():
     L.avs_prepass_get_index.argtypes = [vp, i32, i32, i32, vp, i32]
     L.avs_prepass_get_weights.argtypes = [vp, i32, i32, vp, i32]
     L.avs_prepass_apply.argtypes = [vp, vp]
+    L.avs_prepass_get_regular_index.argtypes = [vp, i32, vp, i32]
+    L.avs_set_regular_index_field.argtypes = [vp, i32, vp, i32]
+    L.avs_transfer_to_regular_grid.argtypes = [vp, vp, vp, vp, i32]
+    L.avs_get_node_grid.argtypes = [vp, i32, vp, vp, vp, vp, i32]
     L.avs_get_dof_table.argtypes = [vp, i32, vp, i32]
     L.avs_plan_owners.argtypes = [i64, vp, vp, i32, i32, i32, i32, vp]
     L.avs_plan_create.argtypes = [i64, vp, vp, vp, i32, i32, C.POINTER(vp)]

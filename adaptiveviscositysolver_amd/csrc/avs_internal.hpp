@@ -202,6 +202,14 @@ struct avs_ctx {
     int64_t nnz = 0, nraw = 0;
     bool guess_ready = false, system_ready = false, solved = false;
 
+    // post-solve transfer (avs_post.hip): regular-grid classification + interpolator work fields
+    avs::DevBuf<int32_t> ridx[3];
+    bool have_ridx[3] = {};
+    avs::DevBuf<float> post_vel[AVS_MAX_LEVELS][3], post_nval[AVS_MAX_LEVELS][3], post_nw[AVS_MAX_LEVELS][3];
+    avs::DevBuf<int32_t> post_nf[AVS_MAX_LEVELS];
+    avs::DevBuf<int8_t> post_nlab[AVS_MAX_LEVELS];
+    bool post_ready = false;
+
     // brick-major copy of the system used by the solve (avs_reorder.hip); perm: new -> old
     avs::DevBuf<int32_t> perm, inv, p_row_ptr, p_col;
     avs::DevBuf<double> p_val, p_rhs, p_x0, p_x;

@@ -1,0 +1,458 @@
+// avs_post.hip -- post-solve transfer of the octree solution to the regular MAC grid, on the device
+// (SURVEY.md 8(f) "next #2"; reference cpp:655-707 = setOctreeVelocity cpp:2779-2813,
+// HDK_OctreeVectorFieldInterpolator interp.h:30-138 / interp.cpp:118-845, applyVelocitiesToRegularGrid
+// cpp:2815-2894; "interp.cpp:" = Source/HDK_OctreeVectorFieldInterpolator.cpp).
+//
+//   T1 k_scatter_velocity   solution -> per-level fp32 face fields (one thread per DOF)
+//   T2 k_nodes_sample       setActiveNodes + sampleActiveNodes fused (one thread per node)
+//   T3 k_nodes_bubble       even nodes hand their sums to the co-located parent node (level by level)
+//   T4 k_nodes_finish       T-junction / split-edge nodes: ghost faces from the coarse side
+//   T5 k_nodes_normalize    value / weight
+//   T6 k_nodes_distribute   dependent nodes copy the parent's value (top-down)
+//   T7 k_apply_regular      per regular face: direct copy / solid velocity / interpSPGrid
+//
+// Node values and weights are fp32 fields in the reference (SIM_RawField) with fpreal (double)
+// arithmetic in between; the same conversions are made at the same places so results are bit-identical
+// to the oracle.  Sample positions are lattice points: index-space arithmetic is exact.
+#include <cmath>
+
+#include "avs_device_common.hpp"
+
+namespace avs {
+
+static constexpr int kBlock = 256;
+
+struct PostView {
+    int levels;
+    float *vel[AVS_MAX_LEVELS][3];  // octreeVelocity[level][axis]
+    float *nval[AVS_MAX_LEVELS][3]; // myNodeValues
+    float *nw[AVS_MAX_LEVELS][3];   // nodeWeights
+    int32_t *nf[AVS_MAX_LEVELS];    // nodeFlags
+    int8_t *nlab[AVS_MAX_LEVELS];   // myNodeLabels: 0 inactive, 1 active, 2 dependent
+};
+
+__device__ __forceinline__ I3 node_res(const PyramidView &P, int l)
+{
+    return I3{{(P.n[0] >> l) + 1, (P.n[1] >> l) + 1, (P.n[2] >> l) + 1}};
+}
+__device__ __forceinline__ I3 unlin(const I3 &r, size_t o)
+{
+    I3 p;
+    p[0] = (int)(o % r[0]);
+    const size_t q = o / r[0];
+    p[1] = (int)(q % r[1]);
+    p[2] = (int)(q / r[1]);
+    return p;
+}
+// HDKnodeToFace, util.h:187-203
+__device__ __forceinline__ I3 node_to_face(const I3 &n, int fa, int fi)
+{
+    I3 f = n;
+    if (!(fi & 1)) --f[(fa + 1) % 3];
+    if (!(fi & 2)) --f[(fa + 2) % 3];
+    return f;
+}
+__device__ __forceinline__ I3 clamp3(const I3 &p, const I3 &r)
+{
+    return I3{{clampi(p[0], 0, r[0] - 1), clampi(p[1], 0, r[1] - 1), clampi(p[2], 0, r[2] - 1)}};
+}
+__device__ __forceinline__ int32_t vidx_clamped(const PyramidView &P, int l, int a, const I3 &f)
+{
+    const I3 r = face_res(P, l, a);
+    return P.vidx[l][a][lin(r, clamp3(f, r))]; // the reference reads out of bounds next to the domain border
+}
+__device__ __forceinline__ float vel_clamped(const PyramidView &P, const PostView &W, int l, int a, const I3 &f)
+{
+    const I3 r = face_res(P, l, a);
+    return W.vel[l][a][lin(r, clamp3(f, r))];
+}
+
+// T1 -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_scatter_velocity(PyramidView P, PostView W, const int32_t *__restrict__ vdof, int64_t n,
+                                                            const double *__restrict__ x)
+{
+    const int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (id >= n) return;
+    const int4 rec = reinterpret_cast<const int4 *>(vdof)[id];
+    const int level = rec.x & 0xff, axis = rec.x >> 8;
+    W.vel[level][axis][lin(face_res(P, level, axis), I3{{rec.y, rec.z, rec.w}})] = (float)x[id]; // cpp:2808
+}
+
+// T2: interp.cpp:118-188 + 190-286 ------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_nodes_sample(PyramidView P, PostView W, int l)
+{
+    const I3 nr = node_res(P, l);
+    const size_t total = (size_t)nr[0] * nr[1] * nr[2];
+    const double weight = (double)(1 << (P.levels - l - 1));
+    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+        const I3 node = unlin(nr, o);
+        bool active = false, inactive = false;
+        for (int fa = 0; !inactive && fa < 3; ++fa) {
+            const I3 fr = face_res(P, l, fa);
+            const int b1 = (fa + 1) % 3, b2 = (fa + 2) % 3;
+            for (int fi = 0; fi < 4; ++fi) {
+                const I3 f = node_to_face(node, fa, fi);
+                if (f[b1] < 0 || f[b2] < 0 || f[b1] >= fr[b1] || f[b2] >= fr[b2]) { inactive = true; continue; }
+                const int32_t vi = P.vidx[l][fa][lin(fr, f)];
+                if (vi >= 0) active = true;
+                else if (vi == AVS_SOLIDBOUNDARY || vi == AVS_OUTSIDE) { inactive = true; break; }
+            }
+        }
+        if (!(active && !inactive)) continue; // labels / values / weights / flags were zero-filled
+        W.nlab[l][o] = 1;
+        int32_t flag = 0;
+        for (int fa = 0; fa < 3; ++fa) {
+            const I3 fr = face_res(P, l, fa);
+            double av = 0., aw = 0.;
+            for (int fi = 0; fi < 4; ++fi) {
+                const size_t fo = lin(fr, node_to_face(node, fa, fi)); // active nodes have all 12 faces in bounds
+                const int32_t vi = P.vidx[l][fa][fo];
+                if (vi >= 0) {
+                    av += weight * (double)W.vel[l][fa][fo];
+                    aw += weight;
+                    flag += 1 << (fa * 4 + fi);
+                } else if (vi != AVS_UNASSIGNED) {
+                    aw += weight;
+                    flag += 1 << (fa * 4 + fi);
+                }
+            }
+            W.nval[l][fa][o] = (float)av;
+            W.nw[l][fa][o] = (float)aw;
+        }
+        W.nf[l][o] = flag;
+    }
+}
+
+// T3: interp.cpp:288-355; one thread per node of level l+1 (its co-located child is node 2*p) ------
+__global__ __launch_bounds__(kBlock) void k_nodes_bubble(PyramidView P, PostView W, int l)
+{
+    const I3 nr = node_res(P, l), pr = node_res(P, l + 1);
+    const size_t total = (size_t)pr[0] * pr[1] * pr[2];
+    for (size_t po = (size_t)blockIdx.x * kBlock + threadIdx.x; po < total; po += (size_t)gridDim.x * kBlock) {
+        if (W.nlab[l + 1][po] != 1) continue;
+        const I3 par = unlin(pr, po);
+        const I3 node{{2 * par[0], 2 * par[1], 2 * par[2]}};
+        const size_t no = lin(nr, node);
+        if (W.nlab[l][no] != 1) continue;
+        W.nf[l + 1][po] = W.nf[l][no] + W.nf[l + 1][po];
+        for (int a = 0; a < 3; ++a) {
+            W.nw[l + 1][a][po] = (float)((double)W.nw[l][a][no] + (double)W.nw[l + 1][a][po]);
+            W.nval[l + 1][a][po] = (float)((double)W.nval[l][a][no] + (double)W.nval[l + 1][a][po]);
+        }
+        W.nlab[l][no] = 2; // DEPENDENTNODE
+    }
+}
+
+// T4: interp.cpp:357-567 ------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_nodes_finish(PyramidView P, PostView W, int l)
+{
+    const I3 nr = node_res(P, l);
+    const size_t total = (size_t)nr[0] * nr[1] * nr[2];
+    const int L = P.levels;
+    const double weight = (double)(1 << (L - l - 1));
+    for (size_t no = (size_t)blockIdx.x * kBlock + threadIdx.x; no < total; no += (size_t)gridDim.x * kBlock) {
+        if (W.nlab[l][no] != 1) continue;
+        int32_t flag = W.nf[l][no];
+        if (flag == 0xFFF) continue;
+        const I3 node = unlin(nr, no);
+        int32_t temp = flag;
+        for (int bit = 0; flag != 0xFFF && bit < 12; ++bit, temp >>= 1) {
+            if (temp & 1) continue;
+            const int fa = bit / 4, fi = bit % 4;
+            const I3 face = node_to_face(node, fa, fi);
+            bool found = false;
+            if (node[fa] % 2 == 0) { // a face one level up may sit exactly here, interp.cpp:441-467
+                const I3 pf = half3(face);
+                const size_t pfo = lin(face_res(P, l + 1, fa), pf);
+                if (P.vidx[l + 1][fa][pfo] >= 0) {
+                    const double ghost = (double)W.vel[l + 1][fa][pfo];
+                    double v = (double)W.nval[l][fa][no];
+                    v += weight * ghost;
+                    W.nval[l][fa][no] = (float)v;
+                    double ww = (double)W.nw[l][fa][no];
+                    ww += weight;
+                    W.nw[l][fa][no] = (float)ww;
+                    flag += 1 << bit;
+                    found = true;
+                }
+            }
+            if (!found) { // interpolate a ghost face inside the active coarse cell, interp.cpp:469-552
+                I3 cell = face; // HDKfaceToCell(face, faceAxis, 1)
+                int sl = l;
+                for (;;) {
+                    const I3 cr = cell_res(P, sl);
+                    if (P.labels[sl][lin(cr, clamp3(cell, cr))] == AVS_ACTIVE || sl + 1 >= L) break;
+                    cell = half3(cell);
+                    ++sl;
+                }
+                const double ip = (double)((long long)face[fa] << l) / (double)(1 << sl);
+                const double iw = ip - floor(ip);
+                double ghost = 0.;
+                for (int dir = 0; dir < 2; ++dir) {
+                    I3 of = cell;
+                    if (dir == 1) ++of[fa];
+                    const double lw = dir == 0 ? 1. - iw : iw;
+                    const int32_t oi = vidx_clamped(P, sl, fa, of);
+                    if (oi >= 0) ghost += lw * (double)vel_clamped(P, W, sl, fa, of);
+                    else if (oi == AVS_UNASSIGNED && sl > 0) {
+                        for (int ci = 0; ci < 4; ++ci) {
+                            const I3 cf = child_face(of, fa, ci);
+                            if (vidx_clamped(P, sl - 1, fa, cf) >= 0) ghost += .25 * lw * (double)vel_clamped(P, W, sl - 1, fa, cf);
+                        }
+                    }
+                }
+                double v = (double)W.nval[l][fa][no];
+                v += weight * ghost;
+                W.nval[l][fa][no] = (float)v;
+                double ww = (double)W.nw[l][fa][no];
+                ww += weight;
+                W.nw[l][fa][no] = (float)ww;
+                flag += 1 << bit;
+            }
+        }
+        W.nf[l][no] = flag;
+    }
+}
+
+// T5: interp.cpp:569-613 ------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_nodes_normalize(PyramidView P, PostView W, int l)
+{
+    const I3 nr = node_res(P, l);
+    const size_t total = (size_t)nr[0] * nr[1] * nr[2];
+    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+        if (W.nlab[l][o] != 1) continue;
+        for (int a = 0; a < 3; ++a) W.nval[l][a][o] = (float)((double)W.nval[l][a][o] / (double)W.nw[l][a][o]);
+    }
+}
+
+// T6: interp.cpp:615-658 ------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_nodes_distribute(PyramidView P, PostView W, int l)
+{
+    const I3 nr = node_res(P, l), pr = node_res(P, l + 1);
+    const size_t total = (size_t)nr[0] * nr[1] * nr[2];
+    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+        if (W.nlab[l][o] != 2) continue;
+        const size_t po = lin(pr, half3(unlin(nr, o)));
+        for (int a = 0; a < 3; ++a) W.nval[l][a][o] = W.nval[l + 1][a][po];
+        W.nlab[l][o] = 1;
+    }
+}
+
+// interpSPGrid, interp.cpp:660-845; P2 = sample position in half fine cells -----------------------
+__device__ double interp_sp_grid(const PyramidView &P, const PostView &W, const I3 &P2, int axis)
+{
+    const int L = P.levels;
+    I3 cell{{P2[0] >> 1, P2[1] >> 1, P2[2] >> 1}}; // floor(indexPoint) on the level-0 node lattice
+    for (int level = 0; level < L; ++level) {
+        const I3 cr = cell_res(P, level);
+        if (P.labels[level][lin(cr, clamp3(cell, cr))] == AVS_ACTIVE) {
+            const double scale = (double)(1 << (level + 1)); // half fine cells per cell of this level
+            double ifp[3];
+            I3 face;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                ifp[a] = (double)P2[a] / scale - (a == axis ? 0. : .5); // posToIndex on the face lattice
+                face[a] = (int)floor(ifp[a]);
+            }
+            bool transition = false;
+            for (int fi = 0; fi < 8 && !transition; ++fi) // HDKcellToNode(face, fi), interp.cpp:683-698
+                transition = vidx_clamped(P, level, axis, I3{{face[0] + (fi & 1), face[1] + ((fi >> 1) & 1), face[2] + ((fi >> 2) & 1)}}) == AVS_UNASSIGNED;
+            if (!transition) { // trilinear over the 8 faces, interp.cpp:700-728
+                double iw[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    iw[a] = ifp[a] - (double)face[a];
+                    iw[a] = iw[a] < 0. ? 0. : (iw[a] > 1. ? 1. : iw[a]);
+                }
+                double v = 0.;
+                for (int fi = 0; fi < 8; ++fi) {
+                    const I3 nf{{face[0] + (fi & 1), face[1] + ((fi >> 1) & 1), face[2] + ((fi >> 2) & 1)}};
+                    double wt = 1.;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) wt *= (nf[a] - face[a] == 0) ? (1. - iw[a]) : iw[a];
+                    v += wt * (double)vel_clamped(P, W, level, axis, nf);
+                }
+                return v;
+            }
+            // node-based interpolation with the bubble correction, interp.cpp:730-836
+            double ciw = (double)P2[axis] / scale - (double)cell[axis];
+            ciw = ciw < 0. ? 0. : (ciw > 1. ? 1. : ciw);
+            const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+            double fiv[2] = {0., 0.};
+            for (int dir = 0; dir < 2; ++dir) {
+                I3 af = cell;
+                if (dir == 1) ++af[axis];
+                int fl = level;
+                if (vidx_clamped(P, level, axis, af) == AVS_UNASSIGNED && level > 0) { // project onto the child face
+                    const double cs = (double)(1 << level);
+                    const double cip1 = (double)P2[a1] / cs, cip2 = (double)P2[a2] / cs;
+                    for (int ci = 0; ci < 4; ++ci) {
+                        const I3 cf = child_face(af, axis, ci);
+                        if ((double)cf[a1] <= cip1 && (double)cf[a2] <= cip2 && (double)(cf[a1] + 1) >= cip1 && (double)(cf[a2] + 1) >= cip2) {
+                            fl = level - 1;
+                            af = cf;
+                            break;
+                        }
+                    }
+                }
+                const double ns = (double)(1 << (fl + 1));
+                const double inp1 = (double)P2[a1] / ns, inp2 = (double)P2[a2] / ns;
+                const double fw0 = inp1 - floor(inp1), fw1 = inp2 - floor(inp2);
+                const double fvel = (double)vel_clamped(P, W, fl, axis, af);
+                const I3 nr = node_res(P, fl);
+                double avg = 0.;
+                for (int ni = 0; ni < 4; ++ni) { // HDKfaceToNode, util.h:133-149
+                    I3 nd = af;
+                    if (ni & 1) ++nd[a1];
+                    if (ni & 2) ++nd[a2];
+                    double wt = 1.;
+                    wt *= (nd[a1] - af[a1] == 0) ? (1. - fw0) : fw0;
+                    wt *= (nd[a2] - af[a2] == 0) ? (1. - fw1) : fw1;
+                    const double nv = (double)W.nval[fl][axis][lin(nr, clamp3(nd, nr))];
+                    avg += nv;
+                    fiv[dir] += nv * wt;
+                }
+                const double m3 = 1. - fw0, m4 = 1. - fw1;
+                double mm = m3 < m4 ? m3 : m4;
+                mm = fw1 < mm ? fw1 : mm;
+                mm = fw0 < mm ? fw0 : mm;
+                fiv[dir] += 2. * (fvel - .25 * avg) * mm;
+            }
+            return (1. - ciw) * fiv[0] + ciw * fiv[1];
+        }
+        cell = half3(cell);
+    }
+    return 0.; // reference: assert(false)
+}
+
+// T7: cpp:2815-2894 -----------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_apply_regular(PyramidView P, PostView W, int axis, const int32_t *__restrict__ ridx,
+                                                          const double *__restrict__ x, float *__restrict__ out)
+{
+    const I3 fr = face_res(P, 0, axis);
+    const size_t total = (size_t)fr[0] * fr[1] * fr[2];
+    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+        const int32_t ri = ridx[o];
+        if (ri >= 0) {
+            const int32_t oi = P.vidx[0][axis][o];
+            if (oi >= 0) out[o] = (float)x[oi];
+            else if (oi == AVS_SOLIDBOUNDARY) out[o] = sample_f32(P.solidvel[axis], fr, off_face(axis), pos2_face(0, axis, unlin(fr, o)));
+            else if (oi == AVS_UNASSIGNED) out[o] = (float)interp_sp_grid(P, W, pos2_face(0, axis, unlin(fr, o)), axis);
+        } else if (ri == AVS_SOLIDBOUNDARY)
+            out[o] = sample_f32(P.solidvel[axis], fr, off_face(axis), pos2_face(0, axis, unlin(fr, o)));
+    }
+}
+
+static inline unsigned grid_for(size_t n, unsigned cap = 1u << 20)
+{
+    size_t b = (n + kBlock - 1) / kBlock;
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+} // namespace avs
+
+using namespace avs;
+
+extern "C" {
+
+// regularVelocityIndices[axis], cpp:303-329: >= 0 regular DOF, AVS_SOLIDBOUNDARY, else untouched
+avs_status avs_set_regular_index_field(avs_ctx *c, int32_t axis, const int32_t *idx, avs_memspace where)
+{
+    AVS_REQUIRE(c && idx, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(axis >= 0 && axis < 3, AVS_EINVAL, "axis out of range");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    int r[3] = {c->desc.nx, c->desc.ny, c->desc.nz};
+    r[axis] += 1;
+    const size_t n = (size_t)r[0] * r[1] * r[2];
+    AVS_TRY(c->ridx[axis].alloc(n));
+    AVS_HIP(copy_in(c->ridx[axis].p, idx, n * sizeof(int32_t), where, c->stream));
+    if (where == AVS_MEM_HOST) AVS_HIP(hipStreamSynchronize(c->stream));
+    c->have_ridx[axis] = true;
+    return AVS_OK;
+}
+
+avs_status avs_transfer_to_regular_grid(avs_ctx *c, float *out_x, float *out_y, float *out_z, avs_memspace where)
+{
+    AVS_REQUIRE(c && out_x && out_y && out_z, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->solved, AVS_ESTATE, "no solution: call avs_solve first");
+    AVS_REQUIRE(c->have_ridx[0] && c->have_ridx[1] && c->have_ridx[2], AVS_ESTATE, "regular-grid index fields missing (avs_set_regular_index_field)");
+    AVS_REQUIRE(c->tables_ready, AVS_ESTATE, "dof tables missing");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    hipStream_t st = c->stream;
+    const int L = c->desc.levels;
+    PyramidView P = c->view();
+    PostView W{};
+    W.levels = L;
+    // allocate + zero the per-level fields (makeConstant(0) / INACTIVENODE, interp.h:65-81, cpp:688)
+    for (int l = 0; l < L; ++l) {
+        const size_t nn = (size_t)((c->desc.nx >> l) + 1) * ((c->desc.ny >> l) + 1) * ((c->desc.nz >> l) + 1);
+        AVS_TRY(c->post_nlab[l].alloc(nn));
+        AVS_TRY(c->post_nf[l].alloc(nn));
+        AVS_HIP(hipMemsetAsync(c->post_nlab[l].p, 0, nn, st));
+        AVS_HIP(hipMemsetAsync(c->post_nf[l].p, 0, nn * sizeof(int32_t), st));
+        W.nlab[l] = c->post_nlab[l].p;
+        W.nf[l] = c->post_nf[l].p;
+        for (int a = 0; a < 3; ++a) {
+            int fr[3] = {c->desc.nx >> l, c->desc.ny >> l, c->desc.nz >> l};
+            fr[a] += 1;
+            const size_t nf = (size_t)fr[0] * fr[1] * fr[2];
+            AVS_TRY(c->post_vel[l][a].alloc(nf));
+            AVS_TRY(c->post_nval[l][a].alloc(nn));
+            AVS_TRY(c->post_nw[l][a].alloc(nn));
+            AVS_HIP(hipMemsetAsync(c->post_vel[l][a].p, 0, nf * sizeof(float), st));
+            AVS_HIP(hipMemsetAsync(c->post_nval[l][a].p, 0, nn * sizeof(float), st));
+            AVS_HIP(hipMemsetAsync(c->post_nw[l][a].p, 0, nn * sizeof(float), st));
+            W.vel[l][a] = c->post_vel[l][a].p;
+            W.nval[l][a] = c->post_nval[l][a].p;
+            W.nw[l][a] = c->post_nw[l][a].p;
+        }
+    }
+    const int64_t n = c->n_vel;
+    if (n) hipLaunchKernelGGL(k_scatter_velocity, dim3(grid_for((size_t)n)), dim3(kBlock), 0, st, P, W, c->vdof.p, n, c->x.p);
+    auto nodes = [&](int l) { return (size_t)((c->desc.nx >> l) + 1) * ((c->desc.ny >> l) + 1) * ((c->desc.nz >> l) + 1); };
+    for (int l = 0; l < L; ++l) hipLaunchKernelGGL(k_nodes_sample, dim3(grid_for(nodes(l))), dim3(kBlock), 0, st, P, W, l);
+    for (int l = 0; l < L - 1; ++l) hipLaunchKernelGGL(k_nodes_bubble, dim3(grid_for(nodes(l + 1))), dim3(kBlock), 0, st, P, W, l);
+    for (int l = 0; l < L - 1; ++l) hipLaunchKernelGGL(k_nodes_finish, dim3(grid_for(nodes(l))), dim3(kBlock), 0, st, P, W, l);
+    for (int l = 0; l < L; ++l) hipLaunchKernelGGL(k_nodes_normalize, dim3(grid_for(nodes(l))), dim3(kBlock), 0, st, P, W, l);
+    for (int l = L - 2; l >= 0; --l) hipLaunchKernelGGL(k_nodes_distribute, dim3(grid_for(nodes(l))), dim3(kBlock), 0, st, P, W, l);
+    AVS_HIP(hipGetLastError());
+    float *outs[3] = {out_x, out_y, out_z};
+    for (int a = 0; a < 3; ++a) {
+        int fr[3] = {c->desc.nx, c->desc.ny, c->desc.nz};
+        fr[a] += 1;
+        const size_t nf = (size_t)fr[0] * fr[1] * fr[2];
+        DevBuf<float> out;
+        AVS_TRY(out.alloc(nf));
+        // the regular velocity field is updated in place in the reference: start from the input velocity
+        if (c->vel[a].is_const) {
+            std::vector<float> h(nf, c->vel[a].cval);
+            AVS_HIP(hipMemcpyAsync(out.p, h.data(), nf * sizeof(float), hipMemcpyHostToDevice, st));
+            AVS_HIP(hipStreamSynchronize(st));
+        } else AVS_HIP(hipMemcpyAsync(out.p, c->vel[a].buf.p, nf * sizeof(float), hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_apply_regular, dim3(grid_for(nf)), dim3(kBlock), 0, st, P, W, a, (const int32_t *)c->ridx[a].p,
+                           (const double *)c->x.p, out.p);
+        AVS_HIP(hipGetLastError());
+        AVS_HIP(copy_out(outs[a], out.p, nf * sizeof(float), where, st));
+        AVS_HIP(hipStreamSynchronize(st));
+    }
+    c->post_ready = true;
+    return AVS_OK;
+}
+
+// node grids after all passes (parity tests): labels int8, values fp32, (n+1)^3 per level
+avs_status avs_get_node_grid(avs_ctx *c, int32_t level, int8_t *labels, float *vx, float *vy, float *vz, avs_memspace where)
+{
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->post_ready && level >= 0 && level < c->desc.levels, AVS_ESTATE, "call avs_transfer_to_regular_grid first");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    const size_t nn = (size_t)((c->desc.nx >> level) + 1) * ((c->desc.ny >> level) + 1) * ((c->desc.nz >> level) + 1);
+    if (labels) AVS_HIP(copy_out(labels, c->post_nlab[level].p, nn, where, c->stream));
+    float *o[3] = {vx, vy, vz};
+    for (int a = 0; a < 3; ++a)
+        if (o[a]) AVS_HIP(copy_out(o[a], c->post_nval[level][a].p, nn * sizeof(float), where, c->stream));
+    AVS_HIP(hipStreamSynchronize(c->stream));
+    return AVS_OK;
+}
+
+} // extern "C"

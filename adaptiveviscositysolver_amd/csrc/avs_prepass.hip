@@ -328,6 +328,46 @@ __global__ __launch_bounds__(kBlock) void k_classify_velocity(ClassifyArgs A, Gr
     }
 }
 
+// classifyRegularVelocityFacesPartial, cpp:1087-1165 (no octree labels involved)
+__global__ __launch_bounds__(kBlock) void k_classify_regular(ClassifyArgs A, Grid3 fg, TileGrid tg, const uint8_t *__restrict__ occ,
+                                                             int32_t *__restrict__ out)
+{
+    const int axis = A.axis;
+    const Grid3 c0{{A.n[0], A.n[1], A.n[2]}};
+    const size_t total = fg.vol();
+    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+        int f[3];
+        f[0] = (int)(o % fg.r[0]);
+        const size_t q = o / fg.r[0];
+        f[1] = (int)(q % fg.r[1]);
+        f[2] = (int)(q / fg.r[1]);
+        int32_t v = AVS_UNASSIGNED;
+        int b[3] = {f[0], f[1], f[2]};
+        --b[axis];
+        if (occ[tile_of(tg, f[0], f[1], f[2])] && b[axis] >= 0 && f[axis] < c0.r[axis]) {
+            bool active = A.centerw[lin3(c0, b[0], b[1], b[2])] > 0.f || A.centerw[lin3(c0, f[0], f[1], f[2])] > 0.f;
+            for (int ea = 0; ea < 3 && !active; ++ea) {
+                if (ea == axis) continue;
+                Grid3 eg = c0;
+                eg.r[0] += (ea != 0);
+                eg.r[1] += (ea != 1);
+                eg.r[2] += (ea != 2);
+                const int oa = 3 - axis - ea;
+                for (int d = 0; d < 2; ++d) {
+                    int e[3] = {f[0], f[1], f[2]};
+                    e[oa] += d;
+                    if (A.edgew[ea][lin3(eg, e[0], e[1], e[2])] > 0.f) { active = true; break; }
+                }
+            }
+            if (active) {
+                const float s = A.solid ? lerp32(A.solid[lin3(c0, b[0], b[1], b[2])], A.solid[lin3(c0, f[0], f[1], f[2])], 0.5f) : -1.f;
+                v = ((double)s > -A.extrapolation) ? AVS_SOLIDBOUNDARY : 0;
+            }
+        }
+        out[o] = v;
+    }
+}
+
 // classifyEdgeStressesPartial, cpp:1325-1405
 __global__ __launch_bounds__(kBlock) void k_classify_edges(ClassifyArgs A, Grid3 eg, TileGrid tg, const uint8_t *__restrict__ occ,
                                                            int32_t *__restrict__ out)
@@ -427,8 +467,8 @@ struct avs_prepass {
     DevBuf<float> liquid, solid, centerw, edgew[3], facew[3];
     bool have_solid = false;
     DevBuf<int8_t> mask, labels[AVS_MAX_LEVELS];
-    DevBuf<int32_t> vidx[AVS_MAX_LEVELS][3], eidx[AVS_MAX_LEVELS][3], cidx[AVS_MAX_LEVELS];
-    int64_t counts[3] = {0, 0, 0};
+    DevBuf<int32_t> vidx[AVS_MAX_LEVELS][3], eidx[AVS_MAX_LEVELS][3], cidx[AVS_MAX_LEVELS], ridx[3];
+    int64_t counts[4] = {0, 0, 0, 0}; // velocity, edge, centre, regular
     double ms[4] = {0, 0, 0, 0};
     bool ready = false;
 };
@@ -607,7 +647,7 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     while (capped < L && hflags[capped]) ++capped;
     p->levels = capped;
     p->ms[1] = t.stop();
-    for (int k = 0; k < 3; ++k) p->counts[k] = 0;
+    for (int k = 0; k < 4; ++k) p->counts[k] = 0;
     if (capped == 0) { // no liquid in the refinement band: nothing to solve (the reference asserts here, oct.cpp:206)
         p->ms[2] = p->ms[3] = 0.;
         p->ready = true;
@@ -653,6 +693,29 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         if (g3(cr).vol() > max_vol) max_vol = g3(cr).vol();
         hipLaunchKernelGGL(k_classify_centers, dim3(grid_for(g3(cr).vol())), dim3(kBlock), 0, st, p->labels[l].p, p->centerw.p, l, g3(cr).vol(), p->cidx[l].p);
     }
+    for (int a = 0; a < 3; ++a) { // regular-grid faces, cpp:1457-1481
+        int gr[3], cr[3];
+        pp_res(d, 0, 0, a, gr);
+        pp_res(d, 2, 0, 0, cr);
+        AVS_TRY(p->ridx[a].alloc(g3(gr).vol()));
+        TileGrid tg{{(gr[0] + kTile - 1) / kTile, (gr[1] + kTile - 1) / kTile, (gr[2] + kTile - 1) / kTile}};
+        DevBuf<uint8_t> occ;
+        AVS_TRY(occ.alloc(tg.vol()));
+        AVS_HIP(hipMemsetAsync(occ.p, 0, tg.vol(), st));
+        hipLaunchKernelGGL(k_mark_tiles, dim3(grid_for(g3(cr).vol())), dim3(kBlock), 0, st, p->labels[0].p, p->liquid.p, occ_sdf, g3(cr), 0, a, tg, occ.p);
+        ClassifyArgs A{};
+        A.n[0] = d.nx; A.n[1] = d.ny; A.n[2] = d.nz;
+        A.level = 0;
+        A.axis = a;
+        A.extrapolation = extrapolation;
+        A.lab = p->labels[0].p;
+        A.centerw = p->centerw.p;
+        for (int b = 0; b < 3; ++b) A.edgew[b] = p->edgew[b].p;
+        A.solid = solid ? p->solid.p : nullptr;
+        hipLaunchKernelGGL(k_classify_regular, dim3(grid_for(g3(gr).vol())), dim3(kBlock), 0, st, A, g3(gr), tg, (const uint8_t *)occ.p, p->ridx[a].p);
+        AVS_HIP(hipGetLastError());
+        AVS_HIP(hipStreamSynchronize(st));
+    }
     AVS_HIP(hipGetLastError());
     p->ms[2] = t.stop();
 
@@ -663,8 +726,8 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     AVS_TRY(fl.alloc(max_vol + 1));
     AVS_TRY(ids.alloc(max_vol + 1));
     AVS_TRY(scan_tmp.alloc(scan_tmp_elems((int64_t)max_vol)));
-    AVS_TRY(base.alloc(3));
-    AVS_HIP(hipMemsetAsync(base.p, 0, 3 * sizeof(long long), st));
+    AVS_TRY(base.alloc(4));
+    AVS_HIP(hipMemsetAsync(base.p, 0, 4 * sizeof(long long), st));
     for (int kind = 0; kind < 3; ++kind)
         for (int l = 0; l < capped; ++l)
             for (int a = 0; a < (kind == 2 ? 1 : 3); ++a) {
@@ -677,11 +740,20 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
                 hipLaunchKernelGGL(k_apply_ids, dim3(grid_for(nv)), dim3(kBlock), 0, st, grid, g3(gr), (const int32_t *)ids.p, (const long long *)(base.p + kind));
                 hipLaunchKernelGGL(k_bump_base, dim3(1), dim3(64), 0, st, base.p + kind, (const int32_t *)(ids.p + nv));
             }
+    for (int a = 0; a < 3; ++a) { // regular grid: one counter over the three axes, cpp:1486-1509
+        int gr[3];
+        pp_res(d, 0, 0, a, gr);
+        const size_t nv = g3(gr).vol();
+        hipLaunchKernelGGL(k_flags_tilemajor, dim3(grid_for(nv)), dim3(kBlock), 0, st, (const int32_t *)p->ridx[a].p, g3(gr), fl.p);
+        AVS_TRY(exclusive_scan_i32(fl.p, ids.p, (int64_t)nv, scan_tmp.p, scan_tmp.n, st));
+        hipLaunchKernelGGL(k_apply_ids, dim3(grid_for(nv)), dim3(kBlock), 0, st, p->ridx[a].p, g3(gr), (const int32_t *)ids.p, (const long long *)(base.p + 3));
+        hipLaunchKernelGGL(k_bump_base, dim3(1), dim3(64), 0, st, base.p + 3, (const int32_t *)(ids.p + nv));
+    }
     AVS_HIP(hipGetLastError());
-    long long hb[3] = {0, 0, 0};
+    long long hb[4] = {0, 0, 0, 0};
     AVS_HIP(hipMemcpyAsync(hb, base.p, sizeof(hb), hipMemcpyDeviceToHost, st));
     AVS_HIP(hipStreamSynchronize(st));
-    for (int k = 0; k < 3; ++k) p->counts[k] = hb[k];
+    for (int k = 0; k < 4; ++k) p->counts[k] = hb[k];
     p->ms[3] = t.stop();
     p->ready = true;
     return AVS_OK;
@@ -695,6 +767,7 @@ avs_status avs_prepass_get_info(avs_prepass *p, avs_prepass_info *info)
     info->n_velocity = p->counts[0];
     info->n_edge = p->counts[1];
     info->n_center = p->counts[2];
+    info->n_regular = p->counts[3];
     info->weights_ms = p->ms[0];
     info->octree_ms = p->ms[1];
     info->classify_ms = p->ms[2];
@@ -739,6 +812,18 @@ avs_status avs_prepass_get_index(avs_prepass *p, avs_index_kind kind, int32_t le
     return AVS_OK;
 }
 
+avs_status avs_prepass_get_regular_index(avs_prepass *p, int32_t axis, int32_t *out, avs_memspace where)
+{
+    AVS_REQUIRE(p && out, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(p->ready && p->levels >= 1 && axis >= 0 && axis < 3, AVS_EINVAL, "not ready / axis out of range");
+    AVS_HIP(hipSetDevice(p->desc.device));
+    int r[3];
+    pp_res(p->desc, 0, 0, axis, r);
+    AVS_HIP(copy_out(out, p->ridx[axis].p, g3(r).vol() * sizeof(int32_t), where, p->stream));
+    AVS_HIP(hipStreamSynchronize(p->stream));
+    return AVS_OK;
+}
+
 avs_status avs_prepass_get_weights(avs_prepass *p, avs_field_kind kind, int32_t axis, float *out, avs_memspace where)
 {
     AVS_REQUIRE(p && out, AVS_EINVAL, "null argument");
@@ -778,6 +863,7 @@ avs_status avs_prepass_apply(avs_prepass *p, avs_ctx *ctx)
     for (int a = 0; a < 3; ++a) {
         AVS_TRY(avs_set_scalar_field(ctx, AVS_FIELD_EDGE_WEIGHTS, a, p->edgew[a].p, 0.f, AVS_MEM_DEVICE));
         AVS_TRY(avs_set_scalar_field(ctx, AVS_FIELD_FACE_WEIGHTS, a, p->facew[a].p, 0.f, AVS_MEM_DEVICE));
+        AVS_TRY(avs_set_regular_index_field(ctx, a, p->ridx[a].p, AVS_MEM_DEVICE));
     }
     AVS_HIP(hipStreamSynchronize(ctx->stream));
     return AVS_OK;

@@ -209,6 +209,29 @@ class ViscositySolve:
                       bval.ctypes.data, w.ctypes.data, capi.MEM_HOST))
         return dict(cnt=cnt, idx=idx, coef=coef, bcnt=bcnt, bval=bval, weight=w)
 
+    # ---- post-solve transfer (cpp:655-707) -------------------------------------------------
+    def set_regular_index_field(self, axis, idx):
+        p, where = capi.ptr_of(idx)
+        capi.check(self.lib.avs_set_regular_index_field(self.h, axis, p, where))
+
+    def transfer_to_regular_grid(self):
+        """Regular MAC-grid velocity (3 fp32 face grids, host) after the solve."""
+        nx, ny, nz = self.res
+        outs = [np.empty((nz, ny, nx + 1), np.float32), np.empty((nz, ny + 1, nx), np.float32),
+                np.empty((nz + 1, ny, nx), np.float32)]
+        capi.check(self.lib.avs_transfer_to_regular_grid(self.h, outs[0].ctypes.data, outs[1].ctypes.data,
+                                                         outs[2].ctypes.data, capi.MEM_HOST))
+        return outs
+
+    def node_grid(self, level):
+        nx, ny, nz = (r >> level for r in self.res)
+        shp = (nz + 1, ny + 1, nx + 1)
+        lab = np.empty(shp, np.int8)
+        v = [np.empty(shp, np.float32) for _ in range(3)]
+        capi.check(self.lib.avs_get_node_grid(self.h, level, lab.ctypes.data, v[0].ctypes.data, v[1].ctypes.data,
+                                              v[2].ctypes.data, capi.MEM_HOST))
+        return lab, v
+
     def edge_stencils(self):
         ne = self.info().n_edge
         return self._stencils(self.lib.avs_get_edge_stencils, ne, ne, capi.EDGE_STENCIL_CAP, capi.EDGE_BOUNDARY_CAP)
@@ -294,6 +317,11 @@ class DevicePrepass:
     def index(self, kind, level, axis=0):
         out = np.empty(self._shape(kind, level, axis), np.int32)
         capi.check(self.lib.avs_prepass_get_index(self.h, kind, level, axis, out.ctypes.data, capi.MEM_HOST))
+        return out
+
+    def regular_index(self, axis):
+        out = np.empty(self._shape(0, 0, axis), np.int32)
+        capi.check(self.lib.avs_prepass_get_regular_index(self.h, axis, out.ctypes.data, capi.MEM_HOST))
         return out
 
     def weights(self, kind, axis=0):

@@ -162,6 +162,19 @@ avs_status avs_get_center_stencils(avs_ctx *ctx, int32_t *cnt, int32_t *idx, dou
                                    int32_t *bcnt, double *bval, double *weight, avs_memspace where);
 
 /* ------------------------------------------------------------------------------------------
+ * Post-solve transfer (SURVEY 8(f) "next #2"): what cpp:655-707 does with viscositySolution --
+ * setOctreeVelocity (cpp:2779-2813), HDK_OctreeVectorFieldInterpolator (node values, T-junction
+ * aware; HDK_OctreeVectorFieldInterpolator.cpp:118-845) and applyVelocitiesToRegularGrid
+ * (cpp:2815-2894): the regular MAC-grid velocity Houdini reads back.
+ * ---------------------------------------------------------------------------------------- */
+/* regularVelocityIndices[axis] (cpp:303-329): >= 0 regular DOF, AVS_SOLIDBOUNDARY, else untouched face */
+avs_status avs_set_regular_index_field(avs_ctx *ctx, int32_t axis, const int32_t *indices, avs_memspace where);
+/* out_*: face lattices of the base grid; faces that are not regular DOFs keep the input velocity */
+avs_status avs_transfer_to_regular_grid(avs_ctx *ctx, float *out_x, float *out_y, float *out_z, avs_memspace where);
+/* interpolator node grids after all passes, (n+1)^3 per level: labels (0 inactive, 1 active), values fp32 */
+avs_status avs_get_node_grid(avs_ctx *ctx, int32_t level, int8_t *labels, float *vx, float *vy, float *vz, avs_memspace where);
+
+/* ------------------------------------------------------------------------------------------
  * Seam A: only the solve (replaces cpp:611-643).  CSR with int32 row pointers/columns, fp64
  * values; x_inout holds the initial guess on entry and the solution on return.
  * ---------------------------------------------------------------------------------------- */
@@ -196,6 +209,7 @@ typedef struct {
 typedef struct {
     int32_t levels;                       /* after capping, HDK_OctreeGrid.cpp:198-211; 0 = no liquid */
     int64_t n_velocity, n_edge, n_center; /* cpp:395-408 */
+    int64_t n_regular;                    /* regularVelocityDOFcount, cpp:323 */
     double weights_ms, octree_ms, classify_ms, number_ms;
 } avs_prepass_info;
 avs_status avs_prepass_create(const avs_prepass_desc *desc, avs_prepass **out);
@@ -205,9 +219,11 @@ avs_status avs_prepass_get_info(avs_prepass *pp, avs_prepass_info *info);
 avs_status avs_prepass_get_labels(avs_prepass *pp, int32_t level, int8_t *out, avs_memspace where);
 avs_status avs_prepass_get_mask(avs_prepass *pp, int8_t *out, avs_memspace where);
 avs_status avs_prepass_get_index(avs_prepass *pp, avs_index_kind kind, int32_t level, int32_t axis, int32_t *out, avs_memspace where);
+/* regularVelocityIndices[axis] (cpp:1445-1512) */
+avs_status avs_prepass_get_regular_index(avs_prepass *pp, int32_t axis, int32_t *out, avs_memspace where);
 avs_status avs_prepass_get_weights(avs_prepass *pp, avs_field_kind kind /* CENTER / EDGE / FACE weights */, int32_t axis, float *out,
                                    avs_memspace where);
-/* hands labels, index pyramids, DOF counts and the three weight fields to a solve context created with
+/* hands labels, index pyramids, DOF counts, regular-grid indices and the three weight fields to a solve context created with
  * levels == info.levels on the same device (device-to-device copies) */
 avs_status avs_prepass_apply(avs_prepass *pp, avs_ctx *ctx);
 

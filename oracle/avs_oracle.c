@@ -56,6 +56,11 @@ struct orc_ctx {
     int32_t *c_cnt, *c_idx, *c_bcnt; /* 3*ncenter lists */
     double *c_coef, *c_bval, *c_w;   /* c_w: ncenter */
 
+    int32_t *ridx[3];
+    int64_t nregular;
+    int8_t *nlab[ORC_MAX_LEVELS];
+    float *nval[ORC_MAX_LEVELS][3];
+
     double *x0, *rhs;
     int64_t *row_ptr;
     int32_t *col;
@@ -303,6 +308,8 @@ void orc_destroy(orc_ctx *c)
     }
     free(c->mask);
     for (int l = 0; l < ORC_MAX_LEVELS; ++l) free(c->labels[l]);
+    for (int a = 0; a < 3; ++a) free(c->ridx[a]);
+    for (int l = 0; l < ORC_MAX_LEVELS; ++l) { free(c->nlab[l]); for (int a = 0; a < 3; ++a) free(c->nval[l][a]); }
     free_indices(c);
     free_stencils(c);
     free_system(c);
@@ -1640,6 +1647,469 @@ int orc_get_csr(orc_ctx *c, int64_t *row_ptr, int32_t *col, double *val, double 
     if (col) memcpy(col, c->col, (size_t)c->nnz * sizeof(int32_t));
     if (val) memcpy(val, c->val, (size_t)c->nnz * sizeof(double));
     if (rhs) memcpy(rhs, c->rhs, (size_t)c->nvel * sizeof(double));
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* post-solve transfer                                                                  */
+/* ------------------------------------------------------------------------------------ */
+/* buildRegularVelocityIndices, cpp:1445-1512 + classifyRegularVelocityFacesPartial cpp:1087-1165 */
+int orc_build_regular_indices(orc_ctx *c, double extrapolation_scale)
+{
+    const double extrapolation = c->dx * extrapolation_scale;
+    const double occ_sdf = 2. * c->dx;
+    int r0[3];
+    cell_res(c, 0, r0);
+    int64_t next = 0;
+    for (int axis = 0; axis < 3; ++axis) {
+        int fr[3];
+        face_res(c, 0, axis, fr);
+        free(c->ridx[axis]);
+        int32_t *g = c->ridx[axis] = alloc_idx(fr);
+        if (!g) return 2;
+        tilemask tm;
+        if (tm_init(&tm, fr)) return 2;
+        for (int k = 0; k < r0[2]; ++k)
+            for (int j = 0; j < r0[1]; ++j)
+                for (int i = 0; i < r0[0]; ++i) {
+                    int p[3] = {i, j, k};
+                    if (!((double)fget(&c->liquid, r0, p) < occ_sdf)) continue;
+                    for (int d = 0; d < 2; ++d) {
+                        int f[3];
+                        cell_to_face(p, axis, d, f);
+                        tm_mark(&tm, f);
+                    }
+                }
+        for (int k = 0; k < fr[2]; ++k)
+            for (int j = 0; j < fr[1]; ++j)
+                for (int i = 0; i < fr[0]; ++i) {
+                    int f[3] = {i, j, k};
+                    if (!tm_get(&tm, f)) continue;
+                    int bc[3], fc[3];
+                    face_to_cell(f, axis, 0, bc);
+                    face_to_cell(f, axis, 1, fc);
+                    if (bc[axis] < 0 || fc[axis] >= r0[axis]) continue; /* cpp:1124-1125 */
+                    int active = fget(&c->centerw, r0, bc) > 0.f || fget(&c->centerw, r0, fc) > 0.f;
+                    for (int ea = 0; ea < 3 && !active; ++ea) {
+                        if (ea == axis) continue;
+                        int er[3];
+                        edge_res(c, 0, ea, er);
+                        for (int d = 0; d < 2; ++d) {
+                            int e[3];
+                            face_to_edge(f, axis, ea, d, e);
+                            if (fget(&c->edgew[ea], er, e) > 0.f) { active = 1; break; }
+                        }
+                    }
+                    if (active) {
+                        int P2[3];
+                        pos2_face(0, axis, f, P2);
+                        float s = sample_f32(&c->solid, r0, OFF_CENTER, P2);
+                        g[lin(fr, f)] = ((double)s > -extrapolation) ? ORC_SOLIDBOUNDARY : ORC_FLUID;
+                    }
+                }
+        free(tm.occ);
+        next = number_grid(g, fr, next); /* cpp:1486-1509: one counter over the three axes */
+    }
+    c->nregular = next;
+    return 0;
+}
+int64_t orc_regular_count(orc_ctx *c) { return c->nregular; }
+int orc_get_regular_index(orc_ctx *c, int axis, int32_t *out)
+{
+    if (axis < 0 || axis > 2 || !c->ridx[axis]) return 1;
+    int fr[3];
+    face_res(c, 0, axis, fr);
+    memcpy(out, c->ridx[axis], vol(fr) * sizeof(int32_t));
+    return 0;
+}
+int orc_set_regular_index(orc_ctx *c, int axis, const int32_t *idx)
+{
+    if (axis < 0 || axis > 2) return 1;
+    int fr[3];
+    face_res(c, 0, axis, fr);
+    free(c->ridx[axis]);
+    c->ridx[axis] = (int32_t *)malloc(vol(fr) * sizeof(int32_t));
+    if (!c->ridx[axis]) return 2;
+    memcpy(c->ridx[axis], idx, vol(fr) * sizeof(int32_t));
+    return 0;
+}
+
+static inline void node_res(const orc_ctx *c, int l, int r[3])
+{
+    cell_res(c, l, r);
+    r[0] += 1; r[1] += 1; r[2] += 1;
+}
+/* HDKnodeToFace, util.h:187-203 */
+static inline void node_to_face(const int n[3], int faceAxis, int fi, int f[3])
+{
+    f[0] = n[0]; f[1] = n[1]; f[2] = n[2];
+    for (int o = 0; o < 2; ++o)
+        if (!(fi & (1 << o))) --f[(faceAxis + 1 + o) % 3];
+}
+
+typedef struct {
+    float *vel[ORC_MAX_LEVELS][3]; /* octreeVelocity[level][axis], cpp:664-691 */
+    float *nw[ORC_MAX_LEVELS][3];  /* nodeWeights */
+    int32_t *nf[ORC_MAX_LEVELS];   /* nodeFlags */
+} postwork;
+
+static inline int32_t vidx_clamped(const orc_ctx *c, int l, int a, const int f[3])
+{
+    int r[3], q[3];
+    face_res(c, l, a, r);
+    for (int d = 0; d < 3; ++d) q[d] = clampi(f[d], 0, r[d] - 1); /* the reference reads out of bounds near the domain border */
+    return c->vidx[l][a][lin(r, q)];
+}
+static inline float vel_clamped(const orc_ctx *c, const postwork *w, int l, int a, const int f[3])
+{
+    int r[3], q[3];
+    face_res(c, l, a, r);
+    for (int d = 0; d < 3; ++d) q[d] = clampi(f[d], 0, r[d] - 1);
+    return w->vel[l][a][lin(r, q)];
+}
+
+/* interpSPGrid, interp.cpp:660-845; P2 = sample position in half fine cells (exact) */
+static double interp_sp_grid(const orc_ctx *c, const postwork *w, const int P2[3], int axis)
+{
+    const int L = c->levels;
+    int cell[3] = {floordiv2(P2[0]), floordiv2(P2[1]), floordiv2(P2[2])}; /* floor(indexPoint), node lattice level 0 */
+    for (int level = 0; level < L; ++level) {
+        int cr[3];
+        cell_res(c, level, cr);
+        int cc[3] = {clampi(cell[0], 0, cr[0] - 1), clampi(cell[1], 0, cr[1] - 1), clampi(cell[2], 0, cr[2] - 1)};
+        if (c->labels[level][lin(cr, cc)] == ORC_ACTIVE) {
+            const double scale = (double)(1 << (level + 1)); /* half fine cells per level-`level` cell */
+            double ifp[3];
+            int face[3];
+            for (int a = 0; a < 3; ++a) {
+                ifp[a] = (double)P2[a] / scale - (a == axis ? 0. : .5); /* posToIndex on the face lattice */
+                face[a] = (int)floor(ifp[a]);
+            }
+            int transition = 0;
+            for (int fi = 0; fi < 8 && !transition; ++fi) { /* HDKcellToNode(face, fi), interp.cpp:683-698 */
+                int nf[3] = {face[0] + (fi & 1), face[1] + ((fi >> 1) & 1), face[2] + ((fi >> 2) & 1)};
+                if (vidx_clamped(c, level, axis, nf) == ORC_UNASSIGNED) transition = 1;
+            }
+            if (!transition) { /* interp.cpp:700-728 */
+                double iw[3];
+                for (int a = 0; a < 3; ++a) {
+                    iw[a] = ifp[a] - (double)face[a];
+                    iw[a] = iw[a] < 0. ? 0. : (iw[a] > 1. ? 1. : iw[a]);
+                }
+                double v = 0;
+                for (int fi = 0; fi < 8; ++fi) {
+                    int nf[3] = {face[0] + (fi & 1), face[1] + ((fi >> 1) & 1), face[2] + ((fi >> 2) & 1)};
+                    double wt = 1.;
+                    for (int a = 0; a < 3; ++a) wt *= (nf[a] - face[a] == 0) ? (1. - iw[a]) : iw[a];
+                    v += wt * (double)vel_clamped(c, w, level, axis, nf);
+                }
+                return v;
+            }
+            /* interp.cpp:730-836 */
+            double ciw = (double)P2[axis] / scale - (double)cell[axis];
+            ciw = ciw < 0. ? 0. : (ciw > 1. ? 1. : ciw);
+            const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+            double fiv[2] = {0., 0.};
+            for (int dir = 0; dir < 2; ++dir) {
+                int af[3];
+                cell_to_face(cell, axis, dir, af);
+                int fl = level;
+                if (vidx_clamped(c, level, axis, af) == ORC_UNASSIGNED && level > 0) { /* project onto a child face */
+                    const double cs = (double)(1 << level);
+                    const double cip1 = (double)P2[a1] / cs, cip2 = (double)P2[a2] / cs; /* node lattice of level-1 */
+                    for (int ci = 0; ci < 4; ++ci) {
+                        int cf[3];
+                        child_face(af, axis, ci, cf);
+                        if ((double)cf[a1] <= cip1 && (double)cf[a2] <= cip2 && (double)(cf[a1] + 1) >= cip1 && (double)(cf[a2] + 1) >= cip2) {
+                            fl = level - 1;
+                            af[0] = cf[0]; af[1] = cf[1]; af[2] = cf[2];
+                            break;
+                        }
+                    }
+                }
+                const double ns = (double)(1 << (fl + 1));
+                double inp1 = (double)P2[a1] / ns, inp2 = (double)P2[a2] / ns;
+                double fw[2] = {inp1 - floor(inp1), inp2 - floor(inp2)};
+                const double fvel = (double)vel_clamped(c, w, fl, axis, af);
+                int nr[3];
+                node_res(c, fl, nr);
+                double avg = 0;
+                for (int ni = 0; ni < 4; ++ni) { /* HDKfaceToNode, util.h:133-149 */
+                    int nd[3] = {af[0], af[1], af[2]};
+                    if (ni & 1) ++nd[a1];
+                    if (ni & 2) ++nd[a2];
+                    double wt = 1.;
+                    wt *= (nd[a1] - af[a1] == 0) ? (1. - fw[0]) : fw[0];
+                    wt *= (nd[a2] - af[a2] == 0) ? (1. - fw[1]) : fw[1];
+                    int q[3] = {clampi(nd[0], 0, nr[0] - 1), clampi(nd[1], 0, nr[1] - 1), clampi(nd[2], 0, nr[2] - 1)};
+                    const double nv = (double)c->nval[fl][axis][lin(nr, q)];
+                    avg += nv;
+                    fiv[dir] += nv * wt;
+                }
+                double m = fw[0];
+                double m2 = fw[1];
+                double m3 = 1. - fw[0], m4 = 1 - fw[1];
+                double mm = m3 < m4 ? m3 : m4;          /* SYSmin(1 - w0, 1 - w1) */
+                mm = m2 < mm ? m2 : mm;                 /* SYSmin(w1, ...) */
+                mm = m < mm ? m : mm;                   /* SYSmin(w0, ...) */
+                fiv[dir] += 2. * (fvel - .25 * avg) * mm;
+            }
+            return (1. - ciw) * fiv[0] + ciw * fiv[1];
+        }
+        cell[0] = cell[0] / 2; cell[1] = cell[1] / 2; cell[2] = cell[2] / 2; /* getParentCell */
+    }
+    return 0.; /* reference: assert(false) */
+}
+
+int orc_transfer_to_regular_grid(orc_ctx *c, const double *solution, float *out_x, float *out_y, float *out_z)
+{
+    if (!c->vdof || !c->ridx[0] || !c->ridx[1] || !c->ridx[2]) return 3;
+    const int L = c->levels;
+    postwork w;
+    memset(&w, 0, sizeof(w));
+    int rc = 0;
+    /* setOctreeVelocity, cpp:2779-2813 (fp32 fields, 0 elsewhere) */
+    for (int l = 0; l < L; ++l) {
+        int nr[3];
+        node_res(c, l, nr);
+        free(c->nlab[l]);
+        c->nlab[l] = (int8_t *)calloc(vol(nr), 1);
+        w.nf[l] = (int32_t *)calloc(vol(nr), sizeof(int32_t));
+        for (int a = 0; a < 3; ++a) {
+            int fr[3];
+            face_res(c, l, a, fr);
+            w.vel[l][a] = (float *)calloc(vol(fr), sizeof(float));
+            free(c->nval[l][a]);
+            c->nval[l][a] = (float *)calloc(vol(nr), sizeof(float));
+            w.nw[l][a] = (float *)calloc(vol(nr), sizeof(float));
+            if (!w.vel[l][a] || !c->nval[l][a] || !w.nw[l][a]) rc = 2;
+            if (rc) continue;
+            size_t n = vol(fr);
+            for (size_t o = 0; o < n; ++o) {
+                int32_t id = c->vidx[l][a][o];
+                if (id >= 0) w.vel[l][a][o] = (float)solution[id];
+            }
+        }
+        if (!c->nlab[l] || !w.nf[l]) rc = 2;
+    }
+    if (rc) goto done;
+    /* setActiveNodes (interp.cpp:118-188) + sampleActiveNodes (interp.cpp:190-286) */
+    for (int l = 0; l < L; ++l) {
+        int nr[3];
+        node_res(c, l, nr);
+        const double weight = (double)(1 << (L - l - 1));
+        for (int k = 0; k < nr[2]; ++k)
+            for (int j = 0; j < nr[1]; ++j)
+                for (int i = 0; i < nr[0]; ++i) {
+                    int node[3] = {i, j, k};
+                    int active = 0, inactive = 0;
+                    for (int fa = 0; !inactive && fa < 3; ++fa) {
+                        int fr[3];
+                        face_res(c, l, fa, fr);
+                        const int b1 = (fa + 1) % 3, b2 = (fa + 2) % 3;
+                        for (int fi = 0; fi < 4; ++fi) {
+                            int f[3];
+                            node_to_face(node, fa, fi, f);
+                            if (f[b1] < 0 || f[b2] < 0 || f[b1] >= fr[b1] || f[b2] >= fr[b2]) { inactive = 1; continue; }
+                            int32_t vi = c->vidx[l][fa][lin(fr, f)];
+                            if (vi >= 0) active = 1;
+                            else if (vi == ORC_SOLIDBOUNDARY || vi == ORC_OUTSIDE) { inactive = 1; break; }
+                        }
+                    }
+                    if (!(active && !inactive)) continue;
+                    const size_t no = lin(nr, node);
+                    c->nlab[l][no] = 1;
+                    int32_t flag = 0;
+                    for (int fa = 0; fa < 3; ++fa) {
+                        int fr[3];
+                        face_res(c, l, fa, fr);
+                        double av = 0., aw = 0.;
+                        for (int fi = 0; fi < 4; ++fi) {
+                            int f[3];
+                            node_to_face(node, fa, fi, f);
+                            int32_t vi = c->vidx[l][fa][lin(fr, f)]; /* active nodes have all 12 faces in bounds */
+                            if (vi >= 0) {
+                                av += weight * (double)w.vel[l][fa][lin(fr, f)];
+                                aw += weight;
+                                flag += 1 << (fa * 4 + fi);
+                            } else if (vi != ORC_UNASSIGNED) {
+                                aw += weight;
+                                flag += 1 << (fa * 4 + fi);
+                            }
+                        }
+                        c->nval[l][fa][no] = (float)av;
+                        w.nw[l][fa][no] = (float)aw;
+                    }
+                    w.nf[l][no] = flag;
+                }
+    }
+    /* bubbleActiveNodeValues, interp.cpp:288-355 */
+    for (int l = 0; l < L - 1; ++l) {
+        int nr[3], pr[3];
+        node_res(c, l, nr);
+        node_res(c, l + 1, pr);
+        for (int k = 0; k < nr[2]; k += 2)
+            for (int j = 0; j < nr[1]; j += 2)
+                for (int i = 0; i < nr[0]; i += 2) {
+                    int node[3] = {i, j, k}, par[3] = {i / 2, j / 2, k / 2};
+                    const size_t no = lin(nr, node), po = lin(pr, par);
+                    if (c->nlab[l][no] != 1 || c->nlab[l + 1][po] != 1) continue;
+                    w.nf[l + 1][po] = w.nf[l][no] + w.nf[l + 1][po];
+                    for (int a = 0; a < 3; ++a) {
+                        w.nw[l + 1][a][po] = (float)((double)w.nw[l][a][no] + (double)w.nw[l + 1][a][po]);
+                        c->nval[l + 1][a][po] = (float)((double)c->nval[l][a][no] + (double)c->nval[l + 1][a][po]);
+                    }
+                    c->nlab[l][no] = 2; /* DEPENDENTNODE */
+                }
+    }
+    /* finishIncompleteNodes, interp.cpp:357-567 */
+    for (int l = 0; l < L - 1; ++l) {
+        int nr[3];
+        node_res(c, l, nr);
+        const double weight = (double)(1 << (L - l - 1));
+        for (int k = 0; k < nr[2]; ++k)
+            for (int j = 0; j < nr[1]; ++j)
+                for (int i = 0; i < nr[0]; ++i) {
+                    int node[3] = {i, j, k};
+                    const size_t no = lin(nr, node);
+                    if (c->nlab[l][no] != 1) continue;
+                    int32_t flag = w.nf[l][no];
+                    if (flag == 0xFFF) continue;
+                    int32_t temp = flag;
+                    for (int bit = 0; flag != 0xFFF && bit < 12; ++bit, temp >>= 1) {
+                        if (temp & 1) continue;
+                        const int fa = bit / 4, fi = bit % 4;
+                        int face[3];
+                        node_to_face(node, fa, fi, face);
+                        int found = 0;
+                        if (node[fa] % 2 == 0) {
+                            int pf[3] = {face[0] / 2, face[1] / 2, face[2] / 2};
+                            int pr[3];
+                            face_res(c, l + 1, fa, pr);
+                            if (c->vidx[l + 1][fa][lin(pr, pf)] >= 0) {
+                                double ghost = (double)w.vel[l + 1][fa][lin(pr, pf)];
+                                double v = (double)c->nval[l][fa][no];
+                                v += weight * ghost;
+                                c->nval[l][fa][no] = (float)v;
+                                double ww = (double)w.nw[l][fa][no];
+                                ww += weight;
+                                w.nw[l][fa][no] = (float)ww;
+                                flag += 1 << bit;
+                                found = 1;
+                            }
+                        }
+                        if (!found) {
+                            int cell[3] = {face[0], face[1], face[2]}; /* HDKfaceToCell(face, faceAxis, 1) */
+                            int sl = l;
+                            for (;;) {
+                                int cr[3];
+                                cell_res(c, sl, cr);
+                                int cc[3] = {clampi(cell[0], 0, cr[0] - 1), clampi(cell[1], 0, cr[1] - 1), clampi(cell[2], 0, cr[2] - 1)};
+                                if (c->labels[sl][lin(cr, cc)] == ORC_ACTIVE || sl + 1 >= L) break;
+                                cell[0] /= 2; cell[1] /= 2; cell[2] /= 2;
+                                ++sl;
+                            }
+                            /* fractional position of the face along faceAxis inside the level-sl cell */
+                            const double ip = (double)((int64_t)face[fa] << l) / (double)(1 << sl);
+                            const double iw = ip - floor(ip);
+                            double ghost = 0.;
+                            for (int dir = 0; dir < 2; ++dir) {
+                                int of[3];
+                                cell_to_face(cell, fa, dir, of);
+                                const double lw = dir == 0 ? 1. - iw : iw;
+                                int32_t oi = vidx_clamped(c, sl, fa, of);
+                                if (oi >= 0) ghost += lw * (double)vel_clamped(c, &w, sl, fa, of);
+                                else if (oi == ORC_UNASSIGNED && sl > 0) {
+                                    for (int ci = 0; ci < 4; ++ci) {
+                                        int cf[3];
+                                        child_face(of, fa, ci, cf);
+                                        if (vidx_clamped(c, sl - 1, fa, cf) >= 0)
+                                            ghost += .25 * lw * (double)vel_clamped(c, &w, sl - 1, fa, cf);
+                                    }
+                                }
+                            }
+                            double v = (double)c->nval[l][fa][no];
+                            v += weight * ghost;
+                            c->nval[l][fa][no] = (float)v;
+                            double ww = (double)w.nw[l][fa][no];
+                            ww += weight;
+                            w.nw[l][fa][no] = (float)ww;
+                            flag += 1 << bit;
+                        }
+                    }
+                    w.nf[l][no] = flag;
+                }
+    }
+    /* normalizeActiveNodes, interp.cpp:569-613 */
+    for (int l = 0; l < L; ++l) {
+        int nr[3];
+        node_res(c, l, nr);
+        size_t n = vol(nr);
+        for (size_t o = 0; o < n; ++o)
+            if (c->nlab[l][o] == 1)
+                for (int a = 0; a < 3; ++a)
+                    c->nval[l][a][o] = (float)((double)c->nval[l][a][o] / (double)w.nw[l][a][o]);
+    }
+    /* distributeNodeValuesDown, interp.cpp:615-658 */
+    for (int l = L - 2; l >= 0; --l) {
+        int nr[3], pr[3];
+        node_res(c, l, nr);
+        node_res(c, l + 1, pr);
+        for (int k = 0; k < nr[2]; ++k)
+            for (int j = 0; j < nr[1]; ++j)
+                for (int i = 0; i < nr[0]; ++i) {
+                    int node[3] = {i, j, k};
+                    const size_t no = lin(nr, node);
+                    if (c->nlab[l][no] != 2) continue;
+                    int par[3] = {i / 2, j / 2, k / 2};
+                    for (int a = 0; a < 3; ++a) c->nval[l][a][no] = c->nval[l + 1][a][lin(pr, par)];
+                    c->nlab[l][no] = 1;
+                }
+    }
+    /* applyVelocitiesToRegularGrid, cpp:2815-2894 */
+    {
+        float *outs[3] = {out_x, out_y, out_z};
+        for (int axis = 0; axis < 3; ++axis) {
+            int fr[3], off[3];
+            face_res(c, 0, axis, fr);
+            off_face(axis, off);
+            orc_get_field(c, ORC_F_VELOCITY + axis, outs[axis]);
+#pragma omp parallel for collapse(2) schedule(static)
+            for (int k = 0; k < fr[2]; ++k)
+                for (int j = 0; j < fr[1]; ++j)
+                    for (int i = 0; i < fr[0]; ++i) {
+                        int f[3] = {i, j, k};
+                        const size_t o = lin(fr, f);
+                        const int32_t ri = c->ridx[axis][o];
+                        int P2[3];
+                        pos2_face(0, axis, f, P2);
+                        if (ri >= 0) {
+                            const int32_t oi = c->vidx[0][axis][o];
+                            if (oi >= 0) outs[axis][o] = (float)solution[oi];
+                            else if (oi == ORC_SOLIDBOUNDARY) outs[axis][o] = sample_f32(&c->solidvel[axis], fr, off, P2);
+                            else if (oi == ORC_UNASSIGNED) outs[axis][o] = (float)interp_sp_grid(c, &w, P2, axis);
+                        } else if (ri == ORC_SOLIDBOUNDARY)
+                            outs[axis][o] = sample_f32(&c->solidvel[axis], fr, off, P2);
+                    }
+        }
+    }
+done:
+    for (int l = 0; l < L; ++l) {
+        free(w.nf[l]);
+        for (int a = 0; a < 3; ++a) { free(w.vel[l][a]); free(w.nw[l][a]); }
+    }
+    return rc;
+}
+
+int orc_get_node_grid(orc_ctx *c, int level, int8_t *labels, float *vx, float *vy, float *vz)
+{
+    if (level < 0 || level >= c->levels || !c->nlab[level]) return 1;
+    int nr[3];
+    node_res(c, level, nr);
+    if (labels) memcpy(labels, c->nlab[level], vol(nr));
+    float *o[3] = {vx, vy, vz};
+    for (int a = 0; a < 3; ++a)
+        if (o[a]) memcpy(o[a], c->nval[level][a], vol(nr) * sizeof(float));
     return 0;
 }
 

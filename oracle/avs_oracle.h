@@ -115,6 +115,21 @@ int orc_spmv_csr(int64_t n, const int64_t *row_ptr, const int32_t *col, const do
                  const double *x, double *y, int threads);
 int orc_solve(orc_ctx *c, double tol, int max_iters, int threads, double *x_out, orc_pcg_info *info);
 
+/* ---- post-solve transfer (cpp:655-707) ---------------------------------
+ * regular-grid face classification + numbering (cpp:1087-1165, 1445-1512), then setOctreeVelocity
+ * (cpp:2779-2813), HDK_OctreeVectorFieldInterpolator (interp.h:30-138, interp.cpp:118-845) and
+ * applyVelocitiesToRegularGrid (cpp:2815-2894).  Positions are handled in exact index space (every
+ * sample point is a lattice point); where HDK's fp32 position round trip would decide a tie (a face
+ * lying exactly on a cell boundary) the forward cell is taken.  PARITY UNPINNED like the rest. */
+int orc_build_regular_indices(orc_ctx *c, double extrapolation_scale);
+int64_t orc_regular_count(orc_ctx *c);
+int orc_get_regular_index(orc_ctx *c, int axis, int32_t *out);
+int orc_set_regular_index(orc_ctx *c, int axis, const int32_t *idx);
+/* out[a]: face lattice a of the base grid, starts as a copy of the input velocity */
+int orc_transfer_to_regular_grid(orc_ctx *c, const double *solution, float *out_x, float *out_y, float *out_z);
+/* node grids of the interpolator after all passes, for parity tests: labels int8, values fp32 */
+int orc_get_node_grid(orc_ctx *c, int level, int8_t *labels, float *vx, float *vy, float *vz);
+
 int orc_max_threads(void);
 
 #ifdef __cplusplus

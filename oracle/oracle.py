@@ -84,6 +84,13 @@ def lib():
         L.orc_pcg_csr.argtypes = [i64, vp, vp, vp, vp, vp, f64, i32, i32, C.POINTER(PcgInfo)]
         L.orc_spmv_csr.argtypes = [i64, vp, vp, vp, vp, vp, i32]
         L.orc_solve.argtypes = [vp, f64, i32, i32, vp, C.POINTER(PcgInfo)]
+        L.orc_build_regular_indices.argtypes = [vp, f64]
+        L.orc_regular_count.restype = i64
+        L.orc_regular_count.argtypes = [vp]
+        L.orc_get_regular_index.argtypes = [vp, i32, vp]
+        L.orc_set_regular_index.argtypes = [vp, i32, vp]
+        L.orc_transfer_to_regular_grid.argtypes = [vp, vp, vp, vp, vp]
+        L.orc_get_node_grid.argtypes = [vp, i32, vp, vp, vp, vp]
         L.orc_max_threads.restype = i32
         _lib = L
     return _lib
@@ -261,6 +268,41 @@ class Oracle:
     @property
     def raw_triplets(self):
         return int(self.L.orc_raw_triplets(self.h))
+
+    # ---- post-solve transfer ---------------------------------------------------------
+    def build_regular_indices(self, extrapolation=0.5):
+        _chk(self.L.orc_build_regular_indices(self.h, extrapolation), "build_regular_indices")
+
+    @property
+    def regular_count(self):
+        return int(self.L.orc_regular_count(self.h))
+
+    def regular_index(self, axis):
+        r = self.grid_res(I_VELOCITY, 0, axis)
+        out = np.empty(r[0] * r[1] * r[2], dtype=np.int32)
+        _chk(self.L.orc_get_regular_index(self.h, axis, _p(out)), "get_regular_index")
+        return out.reshape(r[2], r[1], r[0])
+
+    def set_regular_index(self, axis, idx):
+        a = np.ascontiguousarray(np.asarray(idx, dtype=np.int32)).ravel()
+        _chk(self.L.orc_set_regular_index(self.h, axis, _p(a)), "set_regular_index")
+
+    def transfer_to_regular_grid(self, solution):
+        x = np.ascontiguousarray(solution, dtype=np.float64)
+        outs = []
+        for a in range(3):
+            r = self.grid_res(I_VELOCITY, 0, a)
+            outs.append(np.empty((r[2], r[1], r[0]), dtype=np.float32))
+        _chk(self.L.orc_transfer_to_regular_grid(self.h, _p(x), _p(outs[0]), _p(outs[1]), _p(outs[2])), "transfer")
+        return outs
+
+    def node_grid(self, level):
+        r = self.grid_res(I_CENTER, level)
+        shp = (r[2] + 1, r[1] + 1, r[0] + 1)
+        lab = np.empty(shp, np.int8)
+        v = [np.empty(shp, np.float32) for _ in range(3)]
+        _chk(self.L.orc_get_node_grid(self.h, level, _p(lab), _p(v[0]), _p(v[1]), _p(v[2])), "get_node_grid")
+        return lab, v
 
     def solve(self, tol=1e-3, max_iters=2500, threads=1):
         x = np.empty(self.count(I_VELOCITY), np.float64)
