@@ -12,6 +12,9 @@
 //   buildVelocityMapping                 cpp:518-528  buildVelocityMapping()
 //   buildOctreeSystemFromStencils + setFromTriplets   buildOctreeSystemFromStencils()  cpp:577-593, 613-614
 //   ConjugateGradient::solveWithGuess    cpp:618-630  solveConjugateGradient(tol, maxIterations)
+//   regularVelocityIndices               cpp:303-329  setRegularVelocityIndices(axis, ...)
+//   setOctreeVelocity + interpolator +
+//   applyVelocitiesToRegularGrid         cpp:661-707  applyVelocitiesToRegularGrid(u, v, w)
 //
 // Header-only; needs only include/avs.h and -lavs_hip.  Errors of the C ABI become std::runtime_error
 // (the reference returns false after addError; Houdini-side glue is in INTEGRATION.md).
@@ -95,6 +98,16 @@ public:
         std::vector<double> x((size_t)myDofs);
         check(avs_get_solution(myCtx, x.data(), myDofs, AVS_MEM_HOST), "avs_get_solution");
         return x;
+    }
+    // ---- post-solve transfer, cpp:655-707 ----------------------------------------------------------
+    void setRegularVelocityIndices(int axis, const int32_t *idx)
+    {
+        check(avs_set_regular_index_field(myCtx, axis, idx, AVS_MEM_HOST), "regular index field");
+    }
+    // u: (nx+1)*ny*nz, v: nx*(ny+1)*nz, w: nx*ny*(nz+1) floats, x fastest
+    void applyVelocitiesToRegularGrid(float *u, float *v, float *w)
+    {
+        check(avs_transfer_to_regular_grid(myCtx, u, v, w, AVS_MEM_HOST), "applyVelocitiesToRegularGrid");
     }
     int octreeLevels() const { return myLevels; }
     avs_ctx *handle() const { return myCtx; }

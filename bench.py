@@ -89,7 +89,8 @@ def main():
     # analytic SDF + velocity (torch), then the device pre-pass (HIP): weights, octree, classification, numbering
     sc = scenes.fat_beam(a.n, a.levels, device=dev)
     pp = DevicePrepass(sc.res, sc.dx, sc.levels, device=local_rank)
-    pinfo = pp.run(sc.liquid, sc.solid)
+    pp.run(sc.liquid, sc.solid)          # first pass: code-object load + first-touch of the big buffers
+    pinfo = pp.run(sc.liquid, sc.solid)  # reported times are the second (steady-state) pass
     levels = pinfo.levels
     solver = ViscositySolve(sc.res, sc.dx, sc.dt, levels, device=local_rank)
     pp.apply(solver)
@@ -99,6 +100,7 @@ def main():
     pp.close()
     torch.cuda.empty_cache()
     use_dist = world > 1 or a.force_dist
+    solver.assemble()                    # warm-up pass (same reason), then the timed one
     torch.cuda.synchronize()
     t_as = time.perf_counter()
     solver.assemble()
@@ -147,6 +149,20 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    transfer_ms = None
+    if not use_dist:
+        # post-solve transfer to the regular MAC grid (cpp:655-707), outputs stay in HBM
+        outs = [torch.empty_like(v) for v in sc.velocity]
+        import ctypes as C
+        from adaptiveviscositysolver_amd import capi
+        capi.check(solver.lib.avs_transfer_to_regular_grid(solver.h, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
+                                                           capi.MEM_DEVICE))
+        torch.cuda.synchronize()
+        t_tr = time.perf_counter()
+        capi.check(solver.lib.avs_transfer_to_regular_grid(solver.h, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
+                                                           capi.MEM_DEVICE))
+        torch.cuda.synchronize()
+        transfer_ms = (time.perf_counter() - t_tr) * 1e3
     if rank == 0:
         ai = solver.info()
         n, nnz = int(ai.n_velocity), int(ai.nnz)
@@ -191,6 +207,8 @@ def main():
             "prepass_ms": prepass_ms,
             "partition_ms": partition_ms,
             "hot_path_ms": assemble_wall_ms + partition_ms + elapsed / a.steps * 1e3,
+            "transfer_to_regular_grid_ms": transfer_ms,
+            "end_to_end_ms": (sum(prepass_ms.values()) + assemble_wall_ms + elapsed / a.steps * 1e3 + transfer_ms) if transfer_ms else None,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(solver, a.tol, a.cpu_seconds)

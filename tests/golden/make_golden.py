@@ -29,9 +29,11 @@ def build(name):
     sc = CASES[name]()
     o = oracle_for_scene(sc)
     o.prepass()
+    o.build_regular_indices()
     o.hot_path()
     A = o.csr()
     x, info = o.solve(1e-10, 5000)
+    out = o.transfer_to_regular_grid(x)
     d = dict(res=np.array(sc.res), dx=sc.dx, dt=sc.dt, levels=o.levels, counts=np.array([o.count(k) for k in range(3)]),
              liquid=sc.liquid.numpy(), velocity_x=sc.velocity[0].numpy(), velocity_y=sc.velocity[1].numpy(),
              velocity_z=sc.velocity[2].numpy(),
@@ -41,6 +43,8 @@ def build(name):
              centerw=o.get_field(O.F_CENTERW), row_ptr=A.row_ptr.astype(np.int32), col=A.col, val=A.val, rhs=A.rhs,
              x0=o.initial_guess(), x=x, iterations=info.iterations)
     for a in range(3):
+        d[f"ridx{a}"] = o.regular_index(a)
+        d[f"out{a}"] = out[a]
         d[f"edgew{a}"] = o.get_field(O.F_EDGEW + a)
         d[f"facew{a}"] = o.get_field(O.F_FACEW + a)
     for l in range(o.levels):

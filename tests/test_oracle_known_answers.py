@@ -241,3 +241,48 @@ def test_velocity_and_stress_label_invariants():
             assert lo == start and hi == start + cnt - 1
             start += cnt
         assert start == o.count(kind)
+
+
+# ---- post-solve transfer (cpp:655-707) ---------------------------------------------------------
+def test_transfer_reproduces_rigid_translation_exactly():
+    """Interpolation weights sum to one: a constant field survives setOctreeVelocity -> node values ->
+    interpSPGrid -> regular grid bit for bit (no solid)."""
+    sc = scenes.fat_beam(64, 4)
+    cv = (0.5, -2.0, 1.25)
+    sc.velocity = scenes.constant_velocity(sc.res, cv)
+    o = oracle_for_scene(sc)
+    o.prepass()
+    o.build_regular_indices()
+    o.hot_path()
+    x, info = o.solve(1e-8, 50)
+    assert info.iterations == 0
+    out = o.transfer_to_regular_grid(x)
+    for a in range(3):
+        assert np.array_equal(out[a], np.full_like(out[a], cv[a]))
+
+
+def test_transfer_touches_only_regular_dofs_and_copies_level0_faces():
+    sc = scenes.sphere(32, 3)
+    o = oracle_for_scene(sc)
+    o.prepass()
+    o.build_regular_indices()
+    o.hot_path()
+    x, _ = o.solve(1e-10, 5000)
+    out = o.transfer_to_regular_grid(x)
+    total = 0
+    for a in range(3):
+        ri, oi = o.regular_index(a), o.index(O.I_VELOCITY, 0, a)
+        vin = sc.velocity[a].numpy()
+        assert np.array_equal(out[a][ri == O.UNASSIGNED], vin[ri == O.UNASSIGNED])       # untouched faces
+        direct = (ri >= 0) & (oi >= 0)
+        assert np.array_equal(out[a][direct], x[oi[direct]].astype(np.float32))           # cpp:2856-2857
+        interp = (ri >= 0) & (oi == O.UNASSIGNED)
+        assert interp.sum() > 0 and np.isfinite(out[a][interp]).all()
+        lo, hi = x.min(), x.max()
+        assert out[a][interp].min() >= lo - 1e-6 and out[a][interp].max() <= hi + 1e-6   # convex-ish combination + bubble
+        total += int((ri >= 0).sum())
+    assert total == o.regular_count
+    # node labels: every node is inactive or active after distributeNodeValuesDown (no DEPENDENT left)
+    for l in range(o.levels):
+        lab, _ = o.node_grid(l)
+        assert set(np.unique(lab)) <= {0, 1}
