@@ -25,8 +25,22 @@ CASES = {
 }
 
 
-def build(name):
-    sc = CASES[name]()
+def scene_from_fixture(g):
+    """Scene rebuilt from the INPUT arrays stored in a fixture (no re-generation: transcendental functions
+    in the scene generators may differ in the last bit between CPU types)."""
+    import torch
+    res = tuple(int(v) for v in g["res"])
+    visc = g["viscosity"]
+    return scenes.Scene(res=res, dx=float(g["dx"]), dt=float(g["dt"]), levels=int(g["desired_levels"]),
+                        liquid=torch.from_numpy(np.array(g["liquid"])),
+                        solid=(None if g["solid"].size == 0 else torch.from_numpy(np.array(g["solid"]))),
+                        viscosity=(float(visc) if visc.ndim == 0 else torch.from_numpy(np.array(visc))),
+                        density=float(g["density"]),
+                        velocity=[torch.from_numpy(np.array(g[f"velocity_{ax}"])) for ax in "xyz"])
+
+
+def build(name, fixture=None):
+    sc = CASES[name]() if fixture is None else scene_from_fixture(fixture)
     o = oracle_for_scene(sc)
     o.prepass()
     o.build_regular_indices()
@@ -34,7 +48,7 @@ def build(name):
     A = o.csr()
     x, info = o.solve(1e-10, 5000)
     out = o.transfer_to_regular_grid(x)
-    d = dict(res=np.array(sc.res), dx=sc.dx, dt=sc.dt, levels=o.levels, counts=np.array([o.count(k) for k in range(3)]),
+    d = dict(res=np.array(sc.res), dx=sc.dx, dt=sc.dt, levels=o.levels, desired_levels=sc.levels, counts=np.array([o.count(k) for k in range(3)]),
              liquid=sc.liquid.numpy(), velocity_x=sc.velocity[0].numpy(), velocity_y=sc.velocity[1].numpy(),
              velocity_z=sc.velocity[2].numpy(),
              viscosity=(np.float32(sc.viscosity) if isinstance(sc.viscosity, float) else sc.viscosity.numpy()),
