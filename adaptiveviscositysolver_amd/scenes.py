@@ -131,3 +131,18 @@ def sphere(n, levels, radius=0.3, device="cpu", dt=1.0 / 60.0, viscosity=100.0):
     vel = smooth_velocity(res, dx, device=device)
     return Scene(res=res, dx=dx, dt=dt, levels=levels, liquid=liquid, viscosity=viscosity,
                  density=1000.0, velocity=vel, name=f"sphere_{n}_L{levels}")
+
+
+def to_device(scene, device):
+    """Same scene with every tensor moved to `device` (bit-identical inputs on host and in HBM: parity
+    tests generate once on the host instead of trusting sin / sqrt to agree across devices)."""
+    import copy
+    mv = lambda t: t.to(device) if isinstance(t, torch.Tensor) else t
+    out = copy.copy(scene)
+    out.liquid = mv(scene.liquid)
+    out.solid = mv(scene.solid)
+    out.viscosity = mv(scene.viscosity)
+    out.density = mv(scene.density)
+    out.velocity = [mv(v) for v in scene.velocity]
+    out.solid_velocity = None if scene.solid_velocity is None else [mv(v) for v in scene.solid_velocity]
+    return out

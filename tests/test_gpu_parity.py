@@ -41,7 +41,7 @@ def dev():
 
 @pytest.mark.parametrize("name", list(SCENES))
 def test_assembly_bit_exact(name, dev, built_lib):
-    sc = SCENES[name](dev)
+    sc = scenes.to_device(SCENES[name]("cpu"), dev)
     pyr = prepass.build_pyramid(sc)
     s = gpu_solve_for(sc, pyr)
     ai = s.assemble()
@@ -76,7 +76,7 @@ def test_assembly_bit_exact(name, dev, built_lib):
 
 @pytest.mark.parametrize("name", ["beam32", "beam64_L3_wall", "beam64_varvisc", "sphere64"])
 def test_solve_matches_oracle(name, dev, built_lib):
-    sc = SCENES[name](dev)
+    sc = scenes.to_device(SCENES[name]("cpu"), dev)
     pyr = prepass.build_pyramid(sc)
     s = gpu_solve_for(sc, pyr)
     s.assemble()

@@ -36,7 +36,7 @@ def gpu_pipeline(sc):
 @pytest.mark.parametrize("name", list(CASES))
 def test_transfer_matches_oracle(name, built_lib):
     dev = torch.device("cuda:0")
-    sc = CASES[name](dev)
+    sc = scenes.to_device(CASES[name]("cpu"), dev)
     pp, info, s = gpu_pipeline(sc)
     o = oracle_for_scene(CASES[name]("cpu"))
     o.prepass()

@@ -24,7 +24,7 @@ CASES = {
 @pytest.mark.parametrize("name", list(CASES))
 def test_device_prepass_matches_oracle(name, built_lib):
     dev = torch.device("cuda:0")
-    sc = CASES[name](dev)
+    sc = scenes.to_device(CASES[name]("cpu"), dev)
     pp = DevicePrepass(sc.res, sc.dx, sc.levels)
     info = pp.run(sc.liquid, sc.solid)
     o = oracle_for_scene(CASES[name]("cpu"))
