@@ -506,15 +506,13 @@ avs_status avs_dist_get_solution(avs_ctx *c, double *x, int64_t n, avs_memspace 
             g->barrier();
         }
     }
-    if (d->reordered) { // back to the reference's DOF numbering
-        DevBuf<double> ref;
-        AVS_TRY(ref.alloc((size_t)n));
-        AVS_TRY(unpermute(c, full.p, ref.p));
-        AVS_HIP(copy_out(x, ref.p, (size_t)n * sizeof(double), where, st));
-        AVS_HIP(hipStreamSynchronize(st));
-        return AVS_OK;
-    }
-    AVS_HIP(copy_out(x, full.p, (size_t)n * sizeof(double), where, st));
+    // the gathered vector also becomes the context's solution (reference numbering), so that
+    // avs_get_solution / avs_transfer_to_regular_grid work on every rank after a partitioned solve
+    AVS_TRY(c->x.alloc((size_t)n));
+    if (d->reordered) AVS_TRY(unpermute(c, full.p, c->x.p)); // back to the reference's DOF numbering
+    else AVS_HIP(hipMemcpyAsync(c->x.p, full.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    c->solved = true;
+    AVS_HIP(copy_out(x, c->x.p, (size_t)n * sizeof(double), where, st));
     AVS_HIP(hipStreamSynchronize(st));
     return AVS_OK;
 }

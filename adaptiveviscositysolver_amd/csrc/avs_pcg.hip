@@ -27,6 +27,7 @@ static constexpr int kBlock = 256;
 static constexpr int kVecGrid = 2048;        // grid-stride vector kernels: 8 blocks per CU
 static constexpr int kStreamCap = 4096;      // LDS products per tile (32 KiB)
 static constexpr int kChunk = 32;            // iterations enqueued between host polls
+static constexpr int kSampleEvery = 4;       // SpMV launches bracketed by HIP events: every 4th (events are not free)
 
 struct PcgScalars {
     double rho;        // absNew = r.z
@@ -900,7 +901,7 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
             // SpMV launches that really ran: iterations 0..iter (the one that detected convergence included)
             const int ran = w->host_sc->iter + ((w->host_sc->done == 1 || w->host_sc->done == 2) ? 1 : 0);
             const int first = enqueued - last_chunk;
-            for (int c2 = 0; c2 < last_chunk && first + c2 < ran; ++c2) {
+            for (int c2 = 0; c2 < last_chunk && first + c2 < ran; c2 += kSampleEvery) {
                 float ems = 0.f;
                 if (hipEventElapsedTime(&ems, w->evA[c2], w->evB[c2]) == hipSuccess) {
                     spmv_ms_sum += ems;
@@ -913,9 +914,10 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
         for (int c = 0; c < chunk; ++c) {
             int nb = 0;
             if (dist) AVS_TRY(dist_halo_exchange(dist, p, stream));
-            if (sample) AVS_HIP(hipEventRecord(w->evA[c], stream));
+            const bool timed = sample && (c % kSampleEvery == 0);
+            if (timed) AVS_HIP(hipEventRecord(w->evA[c], stream));
             AVS_TRY(spmv_dispatch<true>(A, p, t, partial, sc, variant, stream, &nb)); // tmp = A p ; p.tmp
-            if (sample) AVS_HIP(hipEventRecord(w->evB[c], stream));
+            if (timed) AVS_HIP(hipEventRecord(w->evB[c], stream));
             AVS_TRY(reduce_stage(w, nb, 1, OP_ALPHA, tol, 1, stream, dist));
             hipLaunchKernelGGL(k_update_r, dim3(g), dim3(kBlock), 0, stream, n, r, t, invd, sc, partial);
             AVS_TRY(reduce_stage(w, g, 2, OP_BETA, tol, 1, stream, dist));

@@ -18,6 +18,8 @@ def make_solver(sc, pyr):
     s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
     s.set_pyramid(pyr)
     s.set_scene_fields(sc)
+    for a in range(3):   # every regular face a DOF candidate: enough for the transfer smoke check below
+        s.set_regular_index_field(a, torch.where(pyr.vidx[0][a] == -3, torch.full_like(pyr.vidx[0][a], -1), torch.zeros_like(pyr.vidx[0][a])).contiguous())
     s.assemble()
     return s
 
@@ -35,7 +37,7 @@ def test_virtual_ranks_match_single_solve(world, cut_axis, built_lib):
     grp = C.c_void_p()
     capi.check(lib.avs_local_group_create(world, C.byref(grp)))
     solvers = [make_solver(sc, pyr) for _ in range(world)]
-    results, errors, tiles = [None] * world, [], [None] * world
+    results, errors, tiles, transfers = [None] * world, [], [None] * world, []
 
     def run(r):
         try:
@@ -44,6 +46,8 @@ def test_virtual_ranks_match_single_solve(world, cut_axis, built_lib):
             sz = s.dist_partition(cut_axis)
             info = s.dist_solve(tol, 5000)
             x = s.dist_solution()
+            if r == 0:   # the gathered solution feeds the post-solve transfer on any rank
+                transfers.append(s.transfer_to_regular_grid())
             results[r] = (info.iterations, info.converged, info.error, x, sz.n_own, sz.n_halo, sz.n_peers)
             tiles[r] = s.overlap_tiles
         except Exception as e:  # pragma: no cover
@@ -65,6 +69,9 @@ def test_virtual_ranks_match_single_solve(world, cut_axis, built_lib):
         assert n_halo > 0 and n_peers >= 1
         assert n_halo < 0.5 * n_own          # slabs: the halo is a surface term
     assert len({r[0] for r in results}) == 1  # every rank reports the same iteration count
+    ref_out = ref.transfer_to_regular_grid()
+    for a in range(3):
+        assert np.allclose(transfers[0][a], ref_out[a], rtol=0, atol=1e-6 * max(1.0, float(np.abs(ref_out[a]).max())))
     for ti, tb in tiles:                      # the halo exchange overlaps the tiles that read no halo column
         assert tb >= 1 and ti + tb == -(-results[tiles.index((ti, tb))][4] // 512)
     for s in solvers:
