@@ -50,63 +50,75 @@ static inline unsigned grid_for(size_t n, unsigned cap = 1u << 20)
 // ---------------------------------------------------------------------------------------------
 // P1: weights
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_sdf_weights(const float *__restrict__ sdf, Grid3 src, Grid3 tgt, SubConsts sc,
-                                                        float *__restrict__ out)
+// One 512-thread workgroup = one 8x8x8 brick of target samples.  The SDF cells the brick can touch
+// (di = -2 .. +1 around every sample => an 11^3 window, clamped at the border) are staged in LDS once:
+// the sign shortcut and the 27 trilinear sub-samples then read LDS only (64x fewer global reads).
+static constexpr int kWB = 8;             // brick edge
+static constexpr int kWH = kWB + 3;       // staged window edge: offsets -2 .. kWB
+__global__ __launch_bounds__(kWB *kWB *kWB) void k_sdf_weights(const float *__restrict__ sdf, Grid3 src, Grid3 tgt, SubConsts sc,
+                                                              float *__restrict__ out)
 {
-    const size_t total = tgt.vol();
+    __shared__ float win[kWH * kWH * kWH];
     const int n = sc.n;
     const float n3 = (float)(n * n * n);
-    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
-        int p[3];
-        p[0] = (int)(o % tgt.r[0]);
-        const size_t q = o / tgt.r[0];
-        p[1] = (int)(q % tgt.r[1]);
-        p[2] = (int)(q / tgt.r[1]);
-        // exact shortcut: interpolation preserves the sign, so an all-negative (all non-negative)
-        // neighbourhood gives n^3 (0)
-        int lo[3], hi[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            lo[a] = clampi(p[a] + sc.di[a][0], 0, src.r[a] - 1);
-            hi[a] = clampi(p[a] + sc.di[a][n - 1] + 1, 0, src.r[a] - 1);
-        }
-        bool allneg = true, allpos = true;
-        for (int kk = lo[2]; kk <= hi[2]; ++kk)
-            for (int jj = lo[1]; jj <= hi[1]; ++jj)
-                for (int ii = lo[0]; ii <= hi[0]; ++ii) {
-                    const float v = sdf[lin3(src, ii, jj, kk)];
-                    if (v < 0.f) allpos = false;
-                    else allneg = false;
-                }
-        int count;
-        if (allneg) count = n * n * n;
-        else if (allpos) count = 0;
-        else {
-            count = 0;
-            for (int sz = 0; sz < n; ++sz)
-                for (int sy = 0; sy < n; ++sy)
-                    for (int sx = 0; sx < n; ++sx) {
-                        const int s3[3] = {sx, sy, sz};
-                        int i0[3], i1[3];
-                        float t[3];
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) {
-                            const int b = p[a] + sc.di[a][s3[a]];
-                            i0[a] = clampi(b, 0, src.r[a] - 1);
-                            i1[a] = clampi(b + 1, 0, src.r[a] - 1);
-                            t[a] = sc.fr[a][s3[a]];
-                        }
-                        const float c00 = lerp32(sdf[lin3(src, i0[0], i0[1], i0[2])], sdf[lin3(src, i1[0], i0[1], i0[2])], t[0]);
-                        const float c10 = lerp32(sdf[lin3(src, i0[0], i1[1], i0[2])], sdf[lin3(src, i1[0], i1[1], i0[2])], t[0]);
-                        const float c01 = lerp32(sdf[lin3(src, i0[0], i0[1], i1[2])], sdf[lin3(src, i1[0], i0[1], i1[2])], t[0]);
-                        const float c11 = lerp32(sdf[lin3(src, i0[0], i1[1], i1[2])], sdf[lin3(src, i1[0], i1[1], i1[2])], t[0]);
-                        const float c0 = lerp32(c00, c10, t[1]);
-                        const float c1 = lerp32(c01, c11, t[1]);
-                        if (lerp32(c0, c1, t[2]) < 0.f) ++count;
-                    }
-        }
-        out[o] = (float)count / n3;
+    const int bx = (tgt.r[0] + kWB - 1) / kWB, by = (tgt.r[1] + kWB - 1) / kWB;
+    const int b = blockIdx.x;
+    const int o0[3] = {(b % bx) * kWB, ((b / bx) % by) * kWB, (b / (bx * by)) * kWB};
+    // window cell (wx, wy, wz) holds sdf at clamp(o0 - 2 + w): clamping here reproduces the clamped reads below
+    for (int w = threadIdx.x; w < kWH * kWH * kWH; w += kWB * kWB * kWB) {
+        const int wx = w % kWH, wy = (w / kWH) % kWH, wz = w / (kWH * kWH);
+        win[w] = sdf[lin3(src, clampi(o0[0] - 2 + wx, 0, src.r[0] - 1), clampi(o0[1] - 2 + wy, 0, src.r[1] - 1),
+                          clampi(o0[2] - 2 + wz, 0, src.r[2] - 1))];
     }
+    __syncthreads();
+    const int t = threadIdx.x;
+    const int p[3] = {o0[0] + t % kWB, o0[1] + (t / kWB) % kWB, o0[2] + t / (kWB * kWB)};
+    if (p[0] >= tgt.r[0] || p[1] >= tgt.r[1] || p[2] >= tgt.r[2]) return;
+    // window index of source cell c along axis a: clamp first (as the reference read does), then shift
+    auto wi = [&](int a, int c) { return clampi(c, 0, src.r[a] - 1) - (o0[a] - 2); };
+    // NB: clamp(c) lies inside the window because c in [o0-2, o0+kWB] and the window itself was filled with
+    // clamped coordinates; when clamping moves c the value is identical to the window's clamped fill.
+    auto at = [&](int cx, int cy, int cz) {
+        const int ix = clampi(cx - (o0[0] - 2), 0, kWH - 1), iy = clampi(cy - (o0[1] - 2), 0, kWH - 1), iz = clampi(cz - (o0[2] - 2), 0, kWH - 1);
+        return win[ix + kWH * (iy + kWH * iz)];
+    };
+    (void)wi;
+    int lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = p[a] + sc.di[a][0];
+        hi[a] = p[a] + sc.di[a][n - 1] + 1;
+    }
+    // exact shortcut: interpolation preserves the sign, so an all-negative (all non-negative) neighbourhood
+    // gives n^3 (0).  Unclamped coordinates: `at` maps them to the same values the clamped reads return.
+    bool allneg = true, allpos = true;
+    for (int kk = lo[2]; kk <= hi[2]; ++kk)
+        for (int jj = lo[1]; jj <= hi[1]; ++jj)
+            for (int ii = lo[0]; ii <= hi[0]; ++ii) {
+                const float v = at(ii, jj, kk);
+                if (v < 0.f) allpos = false;
+                else allneg = false;
+            }
+    int count;
+    if (allneg) count = n * n * n;
+    else if (allpos) count = 0;
+    else {
+        count = 0;
+        for (int sz = 0; sz < n; ++sz)
+            for (int sy = 0; sy < n; ++sy)
+                for (int sx = 0; sx < n; ++sx) {
+                    const int bx0 = p[0] + sc.di[0][sx], by0 = p[1] + sc.di[1][sy], bz0 = p[2] + sc.di[2][sz];
+                    const float tx = sc.fr[0][sx], ty = sc.fr[1][sy], tz = sc.fr[2][sz];
+                    const float c00 = lerp32(at(bx0, by0, bz0), at(bx0 + 1, by0, bz0), tx);
+                    const float c10 = lerp32(at(bx0, by0 + 1, bz0), at(bx0 + 1, by0 + 1, bz0), tx);
+                    const float c01 = lerp32(at(bx0, by0, bz0 + 1), at(bx0 + 1, by0, bz0 + 1), tx);
+                    const float c11 = lerp32(at(bx0, by0 + 1, bz0 + 1), at(bx0 + 1, by0 + 1, bz0 + 1), tx);
+                    const float c0 = lerp32(c00, c10, ty);
+                    const float c1 = lerp32(c01, c11, ty);
+                    if (lerp32(c0, c1, tz) < 0.f) ++count;
+                }
+    }
+    out[lin3(tgt, p[0], p[1], p[2])] = (float)count / n3;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -504,7 +516,8 @@ static avs_status run_weights(avs_prepass *p, const bool centered[3], const int 
         for (int s = 0; s < sc.n; ++s) sub_consts(sc.n, centered[a], s, &sc.di[a][s], &sc.fr[a][s]);
     int sr[3];
     pp_res(p->desc, 2, 0, 0, sr);
-    hipLaunchKernelGGL(k_sdf_weights, dim3(grid_for(g3(tr).vol())), dim3(kBlock), 0, p->stream, p->liquid.p, g3(sr), g3(tr), sc, out);
+    const unsigned nb = (unsigned)(((tr[0] + kWB - 1) / kWB) * ((tr[1] + kWB - 1) / kWB) * ((tr[2] + kWB - 1) / kWB));
+    hipLaunchKernelGGL(k_sdf_weights, dim3(nb), dim3(kWB * kWB * kWB), 0, p->stream, p->liquid.p, g3(sr), g3(tr), sc, out);
     AVS_HIP(hipGetLastError());
     return AVS_OK;
 }
