@@ -307,6 +307,11 @@ static CsrView csr_of(avs_ctx *c)
     A.row_ptr = c->reordered ? c->p_row_ptr.p : c->row_ptr.p;
     A.col = c->reordered ? c->p_col.p : c->col.p;
     A.val = c->reordered ? c->p_val.p : c->val.p;
+    if (c->reordered && c->v_table_size > 0) {
+        A.codes = c->v_codes.p;
+        A.table = c->v_table.p;
+        A.table_size = c->v_table_size;
+    }
     return A;
 }
 

@@ -125,6 +125,10 @@ struct CsrView {
     const int32_t *row_ptr = nullptr;
     const int32_t *col = nullptr;
     const double *val = nullptr;
+    // value-indexed form (lossless): val[k] == table[codes[k]]; used by the SpMV when codes != nullptr
+    const uint16_t *codes = nullptr;
+    const double *table = nullptr;
+    int table_size = 0;
 };
 
 // PCG work space + device scalars (see avs_pcg.hip)
@@ -163,6 +167,8 @@ avs_status dist_halo_end(PcgDist *d, hipStream_t main_stream);
 int spmv_tile_rows();
 avs_status build_reordered_system(struct ::avs_ctx *c, int brick_shift);
 avs_status unpermute(struct ::avs_ctx *c, const double *xp, double *x);
+// builds the value dictionary of `val` (nnz entries); *table_size = 0 when there are more than 65536 distinct values
+avs_status build_value_index(const double *val, int64_t nnz, DevBuf<uint16_t> &codes, DevBuf<double> &table, int *table_size, hipStream_t st);
 
 } // namespace avs
 
@@ -213,6 +219,10 @@ struct avs_ctx {
     // brick-major copy of the system used by the solve (avs_reorder.hip); perm: new -> old
     avs::DevBuf<int32_t> perm, inv, p_row_ptr, p_col;
     avs::DevBuf<double> p_val, p_rhs, p_x0, p_x;
+    // value dictionary of the solve matrix (avs_reorder.hip): at most 65536 distinct doubles
+    avs::DevBuf<uint16_t> v_codes;
+    avs::DevBuf<double> v_table;
+    int v_table_size = 0; // 0 = matrix not value-indexed (too many distinct values)
     bool reordered = false;
     int brick_shift = 3; // 8^3 fine cells per brick; < 0 disables the renumbering
     avs_assembly_info ainfo{};

@@ -281,6 +281,111 @@ __global__ __launch_bounds__(kBlock) void k_spmv_vec(CsrView A, const double *__
 }
 
 // ---------------------------------------------------------------------------------------------
+// SpMV on the value-indexed matrix (CsrView::codes / table): same tile structure as k_spmv_tile, but the
+// stream is (uint16 code, int32 col) = 6 B per non-zero instead of 12 B, and the value comes from the
+// dictionary -- staged in LDS when it has at most TBL entries (the uniform-coefficient case: ~100
+// entries), read through L1/L2 otherwise.  val == table[code] bit for bit, so products, their order and
+// the row sums are those of the plain kernel.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+
+template <int BLK, int CAP, bool DOT, int TBL>
+__global__ __launch_bounds__(BLK) void k_spmv_tile_vi(CsrView A, const double *__restrict__ x, double *__restrict__ y,
+                                                      double *__restrict__ partial, const PcgScalars *sc,
+                                                      const int32_t *__restrict__ tiles)
+{
+    if (DOT && sc && sc->done) return;
+    __shared__ double prod[CAP + 2];
+    __shared__ double red[BLK / 64];
+    __shared__ double tbl[TBL > 0 ? TBL : 1];
+    const int tid = threadIdx.x;
+    if (TBL > 0) {
+        for (int i = tid; i < A.table_size; i += BLK) tbl[i] = A.table[i];
+        __syncthreads();
+    }
+    const double *__restrict__ gtab = A.table;
+    auto value = [&](unsigned code) -> double { return TBL > 0 ? tbl[code] : gtab[code]; };
+    const int64_t tile = tiles ? (int64_t)tiles[blockIdx.x] : (int64_t)blockIdx.x;
+    const int64_t row0 = tile * BLK;
+    const int64_t row = row0 + tid;
+    const int64_t rlast = (row0 + BLK < A.n) ? row0 + BLK : A.n;
+    const int s_blk = A.row_ptr[row0];
+    const int e_blk = A.row_ptr[rlast];
+    int rs = 0, re = 0;
+    if (row < A.n) {
+        rs = A.row_ptr[row];
+        re = A.row_ptr[row + 1];
+    }
+    double sum = 0.;
+    for (int ts = s_blk; ts < e_blk; ts += CAP) {
+        const int te = (ts + CAP < e_blk) ? ts + CAP : e_blk;
+        const int base = ts & ~1;  // even => 4-B aligned code pairs, 8-B aligned column pairs
+        const int te2 = te & ~1;   // pairs fully below te
+        int k = base + 2 * tid;
+        for (; k + 6 * BLK < te2; k += 8 * BLK) { // 4 pairs = 8 non-zeros per lane in flight
+            const us2_t q0 = stream_load<true>(reinterpret_cast<const us2_t *>(A.codes + k));
+            const us2_t q1 = stream_load<true>(reinterpret_cast<const us2_t *>(A.codes + k + 2 * BLK));
+            const us2_t q2 = stream_load<true>(reinterpret_cast<const us2_t *>(A.codes + k + 4 * BLK));
+            const us2_t q3 = stream_load<true>(reinterpret_cast<const us2_t *>(A.codes + k + 6 * BLK));
+            const i2_t c0 = stream_load<true>(reinterpret_cast<const i2_t *>(A.col + k));
+            const i2_t c1 = stream_load<true>(reinterpret_cast<const i2_t *>(A.col + k + 2 * BLK));
+            const i2_t c2 = stream_load<true>(reinterpret_cast<const i2_t *>(A.col + k + 4 * BLK));
+            const i2_t c3 = stream_load<true>(reinterpret_cast<const i2_t *>(A.col + k + 6 * BLK));
+            const double x00 = x[c0.x], x01 = x[c0.y], x10 = x[c1.x], x11 = x[c1.y];
+            const double x20 = x[c2.x], x21 = x[c2.y], x30 = x[c3.x], x31 = x[c3.y];
+            prod[k - base] = value(q0.x) * x00;
+            prod[k - base + 1] = value(q0.y) * x01;
+            prod[k - base + 2 * BLK] = value(q1.x) * x10;
+            prod[k - base + 2 * BLK + 1] = value(q1.y) * x11;
+            prod[k - base + 4 * BLK] = value(q2.x) * x20;
+            prod[k - base + 4 * BLK + 1] = value(q2.y) * x21;
+            prod[k - base + 6 * BLK] = value(q3.x) * x30;
+            prod[k - base + 6 * BLK + 1] = value(q3.y) * x31;
+        }
+        for (; k < te2; k += 2 * BLK) {
+            const us2_t q0 = stream_load<true>(reinterpret_cast<const us2_t *>(A.codes + k));
+            const i2_t c0 = stream_load<true>(reinterpret_cast<const i2_t *>(A.col + k));
+            prod[k - base] = value(q0.x) * x[c0.x];
+            prod[k - base + 1] = value(q0.y) * x[c0.y];
+        }
+        if (tid == 0 && (te & 1)) prod[te - 1 - base] = value(A.codes[te - 1]) * x[A.col[te - 1]];
+        __syncthreads();
+        const int a = rs > ts ? rs : ts;
+        const int b = re < te ? re : te;
+        for (int j = a; j < b; ++j) sum += prod[j - base];
+        __syncthreads();
+    }
+    if (row < A.n) __builtin_nontemporal_store(sum, y + row);
+    if (DOT) {
+        double d = (row < A.n) ? sum * x[row] : 0.;
+        d = wave_sum(d);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = d;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.;
+            for (int w = 0; w < BLK / 64; ++w) t += red[w];
+            partial[tile] = t; // tile == blockIdx.x without a tile list
+        }
+    }
+}
+
+static constexpr int kViLdsTable = 2048; // dictionary entries staged in LDS (16 KiB)
+
+template <bool DOT>
+static avs_status spmv_vi_launch(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc,
+                                 const int32_t *tiles, int ntiles, hipStream_t stream)
+{
+    if (ntiles <= 0) return AVS_OK;
+    if (A.table_size <= kViLdsTable)
+        hipLaunchKernelGGL((k_spmv_tile_vi<512, 4096, DOT, kViLdsTable>), dim3(ntiles), dim3(512), 0, stream, A, x, y, partial, sc, tiles);
+    else
+        hipLaunchKernelGGL((k_spmv_tile_vi<512, 4096, DOT, 0>), dim3(ntiles), dim3(512), 0, stream, A, x, y, partial, sc, tiles);
+    AVS_HIP(hipGetLastError());
+    return AVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // stream ceilings of this chip for the access widths the SpMV uses (measurement helpers)
 // ---------------------------------------------------------------------------------------------
 template <bool NT, int MODE>
@@ -324,8 +429,13 @@ template <bool DOT>
 static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, double *partial,
                                 const PcgScalars *sc, int variant, hipStream_t stream, int *nblocks)
 {
-    if (variant == 0) variant = spmv_default_variant(A);
     if (A.n <= 0) { if (nblocks) *nblocks = 0; return AVS_OK; }
+    if (A.codes && (variant == 0 || variant == spmv_default_variant(A))) { // value-indexed matrix: 6 B per non-zero
+        const int nt = (int)((A.n + 511) / 512);
+        if (nblocks) *nblocks = nt;
+        return spmv_vi_launch<DOT>(A, x, y, partial, sc, nullptr, nt, stream);
+    }
+    if (variant == 0) variant = spmv_default_variant(A);
     int g;
     switch (variant) {
     case 1:
@@ -394,6 +504,7 @@ avs_status spmv_dot_tiles(const CsrView &A, const double *x, double *y, double *
                           const int32_t *tiles, int ntiles, hipStream_t stream)
 {
     if (ntiles <= 0) return AVS_OK;
+    if (A.codes) return spmv_vi_launch<true>(A, x, y, partial, sc, tiles, ntiles, stream);
     hipLaunchKernelGGL((k_spmv_tile<kTileRows, 4096, true, true, false, true>), dim3(ntiles), dim3(kTileRows), 0, stream, A, x, y,
                        partial, sc, 0, tiles);
     AVS_HIP(hipGetLastError());
@@ -424,7 +535,7 @@ __global__ __launch_bounds__(kBlock) void k_inv_diag(CsrView A, double *__restri
     if (i >= A.n) return;
     double d = 0.;
     for (int k = A.row_ptr[i]; k < A.row_ptr[i + 1]; ++k)
-        if (A.col[k] == (int32_t)i) d = A.val[k];
+        if (A.col[k] == (int32_t)i) d = A.codes ? A.table[A.codes[k]] : A.val[k];
     invd[i] = (d != 0.) ? 1. / d : 1.;
 }
 

@@ -10,6 +10,10 @@
 // (bit-identical y); inputs and outputs of the C ABI stay in the reference's numbering.
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
 #include "avs_internal.hpp"
 
 namespace avs {
@@ -105,7 +109,120 @@ avs_status build_reordered_system(avs_ctx *c, int brick_shift)
     hipLaunchKernelGGL(k_gather_d, dim3(grid_for(n)), dim3(kBlock), 0, st, c->x0.p, c->perm.p, c->p_x0.p, n);
     AVS_HIP(hipGetLastError());
     AVS_HIP(hipStreamSynchronize(st)); // temporaries die here
+    AVS_TRY(build_value_index(c->p_val.p, nnz, c->v_codes, c->v_table, &c->v_table_size, st));
     c->reordered = true;
+    return AVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Value-indexed CSR ("CSR-VI"): the matrix of this problem is made of very few distinct numbers --
+// products of a handful of weights, spacings and control-volume fractions (110 distinct values on the
+// 512^3 uniform-viscosity beam, 7.7 k with the variable-viscosity field) -- so the 8-byte value stream
+// of the SpMV is replaced by a 2-byte code stream into a table of doubles.  Lossless: val[k] ==
+// table[codes[k]] bit for bit, products and row sums are unchanged.  More than 65536 distinct values
+// => no dictionary (plain CSR).
+// ---------------------------------------------------------------------------------------------
+static constexpr int kHashBits = 18; // 262144 slots for <= 65536 keys
+static constexpr unsigned long long kEmpty = 0xFFFFFFFFFFFFFFFFull; // a NaN pattern: never a matrix value
+
+__device__ __forceinline__ unsigned hash64(unsigned long long k)
+{
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    return (unsigned)k & ((1u << kHashBits) - 1);
+}
+
+__global__ __launch_bounds__(kBlock) void k_vi_insert(const double *__restrict__ val, int64_t nnz, unsigned long long *__restrict__ slots,
+                                                      int *__restrict__ count)
+{
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * kBlock) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(val[k]);
+        unsigned h = hash64(key);
+        for (int probe = 0; probe < (1 << kHashBits); ++probe) {
+            const unsigned long long cur = slots[h]; // hot keys: plain read hit, no atomic
+            if (cur == key) break;
+            if (cur == kEmpty) {
+                const unsigned long long old = atomicCAS(&slots[h], kEmpty, key);
+                if (old == kEmpty) { atomicAdd(count, 1); break; }
+                if (old == key) break;
+            }
+            if (*count > 65536) return; // too many distinct values: give up early
+            h = (h + 1) & ((1u << kHashBits) - 1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_vi_collect(const unsigned long long *__restrict__ slots, unsigned long long *__restrict__ keys,
+                                                       int *__restrict__ cursor)
+{
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (1u << kHashBits)) return;
+    const unsigned long long k = slots[i];
+    if (k != kEmpty) {
+        const int at = atomicAdd(cursor, 1);
+        if (at < 65536) keys[at] = k;
+    }
+}
+
+// slot -> code: after the host sorted the keys, every table entry finds its slot again
+__global__ __launch_bounds__(kBlock) void k_vi_assign(const unsigned long long *__restrict__ slots, const double *__restrict__ table, int n,
+                                                      uint16_t *__restrict__ slot_code)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = (unsigned long long)__double_as_longlong(table[i]);
+    unsigned h = hash64(key);
+    while (slots[h] != key) h = (h + 1) & ((1u << kHashBits) - 1);
+    slot_code[h] = (uint16_t)i;
+}
+
+__global__ __launch_bounds__(kBlock) void k_vi_encode(const double *__restrict__ val, int64_t nnz, const unsigned long long *__restrict__ slots,
+                                                      const uint16_t *__restrict__ slot_code, uint16_t *__restrict__ codes)
+{
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * kBlock) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(val[k]);
+        unsigned h = hash64(key);
+        while (slots[h] != key) h = (h + 1) & ((1u << kHashBits) - 1);
+        codes[k] = slot_code[h];
+    }
+}
+
+avs_status build_value_index(const double *val, int64_t nnz, DevBuf<uint16_t> &codes, DevBuf<double> &table, int *table_size,
+                             hipStream_t st)
+{
+    *table_size = 0;
+    if (nnz == 0) return AVS_OK;
+    if (const char *e = getenv("AVS_VALUE_INDEX"))
+        if (atoi(e) == 0) return AVS_OK;
+    DevBuf<unsigned long long> slots, keys;
+    DevBuf<uint16_t> slot_code;
+    DevBuf<int> counters;
+    AVS_TRY(slots.alloc(1u << kHashBits));
+    AVS_TRY(keys.alloc(65536));
+    AVS_TRY(slot_code.alloc(1u << kHashBits));
+    AVS_TRY(counters.alloc(2));
+    AVS_HIP(hipMemsetAsync(slots.p, 0xFF, sizeof(unsigned long long) << kHashBits, st));
+    AVS_HIP(hipMemsetAsync(counters.p, 0, 2 * sizeof(int), st));
+    hipLaunchKernelGGL(k_vi_insert, dim3(8192), dim3(kBlock), 0, st, val, nnz, slots.p, counters.p);
+    int h_count[2] = {0, 0};
+    AVS_HIP(hipMemcpyAsync(h_count, counters.p, sizeof(h_count), hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipStreamSynchronize(st));
+    if (h_count[0] > 65536) return AVS_OK; // plain CSR
+    const int nkeys = h_count[0];
+    hipLaunchKernelGGL(k_vi_collect, dim3((1u << kHashBits) / kBlock), dim3(kBlock), 0, st, slots.p, keys.p, counters.p + 1);
+    std::vector<unsigned long long> h_keys((size_t)nkeys);
+    AVS_HIP(hipMemcpyAsync(h_keys.data(), keys.p, (size_t)nkeys * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipStreamSynchronize(st));
+    std::sort(h_keys.begin(), h_keys.end()); // deterministic codes whatever the insertion order was
+    AVS_TRY(table.alloc((size_t)nkeys));
+    AVS_TRY(codes.alloc((size_t)nnz));
+    AVS_HIP(hipMemcpyAsync(table.p, h_keys.data(), (size_t)nkeys * sizeof(double), hipMemcpyHostToDevice, st)); // same bit patterns
+    hipLaunchKernelGGL(k_vi_assign, dim3(grid_for(nkeys)), dim3(kBlock), 0, st, slots.p, table.p, nkeys, slot_code.p);
+    hipLaunchKernelGGL(k_vi_encode, dim3(8192), dim3(kBlock), 0, st, val, nnz, slots.p, slot_code.p, codes.p);
+    AVS_HIP(hipGetLastError());
+    AVS_HIP(hipStreamSynchronize(st)); // temporaries die here; h_keys must outlive the upload
+    *table_size = nkeys;
     return AVS_OK;
 }
 
