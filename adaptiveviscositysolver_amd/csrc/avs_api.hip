@@ -311,6 +311,10 @@ static CsrView csr_of(avs_ctx *c)
         A.codes = c->v_codes.p;
         A.table = c->v_table.p;
         A.table_size = c->v_table_size;
+        if (c->v_col_bits > 0) {
+            A.packed = c->v_packed.p;
+            A.col_bits = c->v_col_bits;
+        }
     }
     return A;
 }
@@ -499,6 +503,14 @@ avs_status avs_spmv_csr(int64_t n, const int32_t *row_ptr, const int32_t *col, c
     return AVS_OK;
 }
 
+namespace {
+__global__ void k_count_bit_diff(int64_t n, const double *__restrict__ a, const double *__restrict__ b, unsigned long long *cnt)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && __double_as_longlong(a[i]) != __double_as_longlong(b[i])) atomicAdd(cnt, 1ull);
+}
+} // namespace
+
 avs_status avs_bench_spmv(avs_ctx *c, int32_t variant, int32_t repeats, double *ms_per_launch)
 {
     AVS_REQUIRE(c && ms_per_launch, AVS_EINVAL, "null argument");
@@ -520,6 +532,23 @@ avs_status avs_bench_spmv(avs_ctx *c, int32_t variant, int32_t repeats, double *
     for (int i = 0; i < repeats; ++i)
         AVS_TRY(dot ? spmv_dot_launch(A, xin, y.p, partial.p, variant, c->stream) : spmv_launch(A, xin, y.p, variant, c->stream));
     *ms_per_launch = t.stop() / repeats;
+    // every variant must reproduce the plain 12-B CSR kernel bit for bit (same products, same left-to-right row sums)
+    if (n > 0) {
+        DevBuf<double> yref;
+        DevBuf<unsigned long long> cnt;
+        AVS_TRY(yref.alloc((size_t)n));
+        AVS_TRY(cnt.alloc(1));
+        AVS_HIP(hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), c->stream));
+        CsrView P = A;
+        P.codes = nullptr;
+        P.packed = nullptr;
+        AVS_TRY(spmv_launch(P, xin, yref.p, 14, c->stream));
+        hipLaunchKernelGGL(k_count_bit_diff, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, y.p, yref.p, cnt.p);
+        unsigned long long h = 0;
+        AVS_HIP(hipMemcpyAsync(&h, cnt.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        AVS_HIP(hipStreamSynchronize(c->stream));
+        if (h) { set_error("SpMV variant %d differs from the plain CSR kernel in %llu rows", variant, h); return AVS_EINTERNAL; }
+    }
     return AVS_OK;
 }
 

@@ -65,6 +65,10 @@ struct PcgDist {
     // local system
     DevBuf<int32_t> row_ptr, col;
     DevBuf<double> val, rhs, x0, x;
+    DevBuf<uint16_t> codes;   // value-indexed form of the local rows (shares the context's value table)
+    DevBuf<uint32_t> packed;
+    int col_bits = 0;
+    bool value_indexed = false;
     PcgWork *pcg = nullptr;
     bool partitioned = false, solved = false, reordered = false;
 
@@ -99,8 +103,9 @@ __global__ __launch_bounds__(256) void k_scatter_own(const double *__restrict__ 
     if (i < n_own) full[own_global[i]] = x[i];
 }
 
-__global__ __launch_bounds__(256) void k_gather_i(const double *__restrict__ src, const int32_t *__restrict__ idx,
-                                                  double *__restrict__ dst, int64_t n)
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_i(const T *__restrict__ src, const int32_t *__restrict__ idx,
+                                                  T *__restrict__ dst, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = src[idx[i]];
@@ -380,12 +385,22 @@ avs_status avs_dist_partition(avs_ctx *c, int32_t cut_axis)
     if (sz.nnz_local) {
         AVS_HIP(hipMemcpyAsync(d->col.p, cl.data(), cl.size() * 4, hipMemcpyHostToDevice, st));
         AVS_HIP(hipMemcpyAsync(d_vs.p, vs.data(), vs.size() * 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_gather_i, dim3((unsigned)((sz.nnz_local + 255) / 256)), dim3(256), 0, st, g_val, d_vs.p, d->val.p, sz.nnz_local);
+        hipLaunchKernelGGL(k_gather_i<double>, dim3((unsigned)((sz.nnz_local + 255) / 256)), dim3(256), 0, st, g_val, d_vs.p, d->val.p, sz.nnz_local);
+    }
+    d->value_indexed = false;
+    d->col_bits = 0;
+    if (ro && c->v_table_size > 0 && sz.nnz_local) { // local values are a subset of the global ones: same table, gathered codes
+        AVS_TRY(d->codes.alloc((size_t)sz.nnz_local));
+        hipLaunchKernelGGL(k_gather_i<uint16_t>, dim3((unsigned)((sz.nnz_local + 255) / 256)), dim3(256), 0, st, c->v_codes.p, d_vs.p,
+                           d->codes.p, sz.nnz_local);
+        AVS_TRY(build_packed_index(d->codes.p, d->col.p, sz.nnz_local, (int64_t)sz.n_own + sz.n_halo, c->v_table_size, d->packed,
+                                   &d->col_bits, st));
+        d->value_indexed = true;
     }
     if (sz.n_own) {
         const unsigned g = (unsigned)((sz.n_own + 255) / 256);
-        hipLaunchKernelGGL(k_gather_i, dim3(g), dim3(256), 0, st, g_rhs, d->own_global.p, d->rhs.p, sz.n_own);
-        hipLaunchKernelGGL(k_gather_i, dim3(g), dim3(256), 0, st, g_x0, d->own_global.p, d->x0.p, sz.n_own);
+        hipLaunchKernelGGL(k_gather_i<double>, dim3(g), dim3(256), 0, st, g_rhs, d->own_global.p, d->rhs.p, sz.n_own);
+        hipLaunchKernelGGL(k_gather_i<double>, dim3(g), dim3(256), 0, st, g_x0, d->own_global.p, d->x0.p, sz.n_own);
     }
     AVS_HIP(hipGetLastError());
     AVS_HIP(hipStreamSynchronize(st));
@@ -456,6 +471,15 @@ avs_status avs_dist_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_i
     A.row_ptr = d->row_ptr.p;
     A.col = d->col.p;
     A.val = d->val.p;
+    if (d->value_indexed) {
+        A.codes = d->codes.p;
+        A.table = c->v_table.p;
+        A.table_size = c->v_table_size;
+        if (d->col_bits > 0) {
+            A.packed = d->packed.p;
+            A.col_bits = d->col_bits;
+        }
+    }
     avs_solve_info local{};
     AVS_TRY(pcg_solve(d->pcg, A, d->rhs.p, d->x.p, tol, max_iters, c->stream, &local, d));
     local.n = d->n_global;

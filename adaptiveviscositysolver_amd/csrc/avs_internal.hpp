@@ -129,6 +129,9 @@ struct CsrView {
     const uint16_t *codes = nullptr;
     const double *table = nullptr;
     int table_size = 0;
+    // packed form: packed[k] = codes[k] << col_bits | col[k] (4 B per non-zero) when bits(n) + bits(table) <= 32
+    const uint32_t *packed = nullptr;
+    int col_bits = 0;
 };
 
 // PCG work space + device scalars (see avs_pcg.hip)
@@ -169,6 +172,9 @@ avs_status build_reordered_system(struct ::avs_ctx *c, int brick_shift);
 avs_status unpermute(struct ::avs_ctx *c, const double *xp, double *x);
 // builds the value dictionary of `val` (nnz entries); *table_size = 0 when there are more than 65536 distinct values
 avs_status build_value_index(const double *val, int64_t nnz, DevBuf<uint16_t> &codes, DevBuf<double> &table, int *table_size, hipStream_t st);
+// packs (code, column) into one 32-bit word per non-zero when both fit; *col_bits = 0 when they do not (or AVS_VALUE_PACK=0)
+avs_status build_packed_index(const uint16_t *codes, const int32_t *col, int64_t nnz, int64_t n_cols, int table_size,
+                              DevBuf<uint32_t> &packed, int *col_bits, hipStream_t st);
 
 } // namespace avs
 
@@ -223,6 +229,8 @@ struct avs_ctx {
     avs::DevBuf<uint16_t> v_codes;
     avs::DevBuf<double> v_table;
     int v_table_size = 0; // 0 = matrix not value-indexed (too many distinct values)
+    avs::DevBuf<uint32_t> v_packed;
+    int v_col_bits = 0;   // 0 = not packed
     bool reordered = false;
     int brick_shift = 3; // 8^3 fine cells per brick; < 0 disables the renumbering
     avs_assembly_info ainfo{};

@@ -287,24 +287,33 @@ __global__ __launch_bounds__(kBlock) void k_spmv_vec(CsrView A, const double *__
 // entries), read through L1/L2 otherwise.  val == table[code] bit for bit, so products, their order and
 // the row sums are those of the plain kernel.
 // ---------------------------------------------------------------------------------------------
-typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+// Every lane issues ALL of its quad loads for the pass (8-B code quad + 16-B column quad, or one 16-B quad of
+// packed words), then ALL 4*U gathers of x, before the first product is formed; products are parked with 16-B LDS
+// stores.  Row sums stay left-to-right (oracle order).  U = CAP / (4 BLK) = 2 with 32 waves per CU is the measured
+// optimum (profiles/r01_spmv_variants.md): U = 4 needs 70 VGPRs and twice the LDS, which halves the resident waves.
+typedef unsigned short us4_t __attribute__((ext_vector_type(4)));
+typedef int i4_t __attribute__((ext_vector_type(4)));
 
-template <int BLK, int CAP, bool DOT, int TBL>
-__global__ __launch_bounds__(BLK) void k_spmv_tile_vi(CsrView A, const double *__restrict__ x, double *__restrict__ y,
-                                                      double *__restrict__ partial, const PcgScalars *sc,
-                                                      const int32_t *__restrict__ tiles)
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+
+template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK>
+__global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__restrict__ x, double *__restrict__ y,
+                                                  double *__restrict__ partial, const PcgScalars *sc,
+                                                  const int32_t *__restrict__ tiles)
 {
     if (DOT && sc && sc->done) return;
-    __shared__ double prod[CAP + 2];
-    __shared__ double red[BLK / 64];
-    __shared__ double tbl[TBL > 0 ? TBL : 1];
+    constexpr int U = CAP / (4 * BLK); // quads per lane per pass
+    static_assert(U >= 1 && U * 4 * BLK == CAP, "CAP must be a multiple of 4*BLK");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *prod = smem;                 // CAP + 4
+    double *tbl = smem + CAP + 4;        // table_size (LTAB only)
     const int tid = threadIdx.x;
-    if (TBL > 0) {
+    if (LTAB) {
         for (int i = tid; i < A.table_size; i += BLK) tbl[i] = A.table[i];
         __syncthreads();
     }
     const double *__restrict__ gtab = A.table;
-    auto value = [&](unsigned code) -> double { return TBL > 0 ? tbl[code] : gtab[code]; };
+    auto value = [&](unsigned code) -> double { return LTAB ? tbl[code] : gtab[code]; };
     const int64_t tile = tiles ? (int64_t)tiles[blockIdx.x] : (int64_t)blockIdx.x;
     const int64_t row0 = tile * BLK;
     const int64_t row = row0 + tid;
@@ -319,36 +328,59 @@ __global__ __launch_bounds__(BLK) void k_spmv_tile_vi(CsrView A, const double *_
     double sum = 0.;
     for (int ts = s_blk; ts < e_blk; ts += CAP) {
         const int te = (ts + CAP < e_blk) ? ts + CAP : e_blk;
-        const int base = ts & ~1;  // even => 4-B aligned code pairs, 8-B aligned column pairs
-        const int te2 = te & ~1;   // pairs fully below te
-        int k = base + 2 * tid;
-        for (; k + 6 * BLK < te2; k += 8 * BLK) { // 4 pairs = 8 non-zeros per lane in flight
-            const us2_t q0 = stream_load<true>(reinterpret_cast<const us2_t *>(A.codes + k));
-            const us2_t q1 = stream_load<true>(reinterpret_cast<const us2_t *>(A.codes + k + 2 * BLK));
-            const us2_t q2 = stream_load<true>(reinterpret_cast<const us2_t *>(A.codes + k + 4 * BLK));
-            const us2_t q3 = stream_load<true>(reinterpret_cast<const us2_t *>(A.codes + k + 6 * BLK));
-            const i2_t c0 = stream_load<true>(reinterpret_cast<const i2_t *>(A.col + k));
-            const i2_t c1 = stream_load<true>(reinterpret_cast<const i2_t *>(A.col + k + 2 * BLK));
-            const i2_t c2 = stream_load<true>(reinterpret_cast<const i2_t *>(A.col + k + 4 * BLK));
-            const i2_t c3 = stream_load<true>(reinterpret_cast<const i2_t *>(A.col + k + 6 * BLK));
-            const double x00 = x[c0.x], x01 = x[c0.y], x10 = x[c1.x], x11 = x[c1.y];
-            const double x20 = x[c2.x], x21 = x[c2.y], x30 = x[c3.x], x31 = x[c3.y];
-            prod[k - base] = value(q0.x) * x00;
-            prod[k - base + 1] = value(q0.y) * x01;
-            prod[k - base + 2 * BLK] = value(q1.x) * x10;
-            prod[k - base + 2 * BLK + 1] = value(q1.y) * x11;
-            prod[k - base + 4 * BLK] = value(q2.x) * x20;
-            prod[k - base + 4 * BLK + 1] = value(q2.y) * x21;
-            prod[k - base + 6 * BLK] = value(q3.x) * x30;
-            prod[k - base + 6 * BLK + 1] = value(q3.y) * x31;
+        const int base = ts & ~3; // 8-B aligned code quads, 16-B aligned column quads
+        const int te4 = te & ~3;  // quads fully below te
+        u4_t q[U]; // value codes (PACK: packed words, split below)
+        i4_t c[U];
+        double xv[U][4];
+        const unsigned cmask = PACK ? ((1u << A.col_bits) - 1u) : 0u;
+        const int cbits = PACK ? A.col_bits : 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = base + 4 * (tid + u * BLK);
+            q[u] = u4_t{0, 0, 0, 0};
+            c[u] = i4_t{0, 0, 0, 0};
+            if (kk < te4) {
+                if (PACK) {
+                    q[u] = stream_load<true>(reinterpret_cast<const u4_t *>(A.packed + kk));
+                } else {
+                    const us4_t h = stream_load<true>(reinterpret_cast<const us4_t *>(A.codes + kk));
+                    q[u] = u4_t{h.x, h.y, h.z, h.w};
+                    c[u] = stream_load<true>(reinterpret_cast<const i4_t *>(A.col + kk));
+                }
+            }
         }
-        for (; k < te2; k += 2 * BLK) {
-            const us2_t q0 = stream_load<true>(reinterpret_cast<const us2_t *>(A.codes + k));
-            const i2_t c0 = stream_load<true>(reinterpret_cast<const i2_t *>(A.col + k));
-            prod[k - base] = value(q0.x) * x[c0.x];
-            prod[k - base + 1] = value(q0.y) * x[c0.y];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = base + 4 * (tid + u * BLK);
+            if (kk < te4) {
+                if (PACK) {
+                    c[u] = i4_t{(int)(q[u].x & cmask), (int)(q[u].y & cmask), (int)(q[u].z & cmask), (int)(q[u].w & cmask)};
+                    q[u] = u4_t{q[u].x >> cbits, q[u].y >> cbits, q[u].z >> cbits, q[u].w >> cbits};
+                }
+                xv[u][0] = x[c[u].x];
+                xv[u][1] = x[c[u].y];
+                xv[u][2] = x[c[u].z];
+                xv[u][3] = x[c[u].w];
+            }
         }
-        if (tid == 0 && (te & 1)) prod[te - 1 - base] = value(A.codes[te - 1]) * x[A.col[te - 1]];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = base + 4 * (tid + u * BLK);
+            if (kk < te4) {
+                d2_t lo, hi;
+                lo.x = value(q[u].x) * xv[u][0];
+                lo.y = value(q[u].y) * xv[u][1];
+                hi.x = value(q[u].z) * xv[u][2];
+                hi.y = value(q[u].w) * xv[u][3];
+                *reinterpret_cast<d2_t *>(prod + (kk - base)) = lo;
+                *reinterpret_cast<d2_t *>(prod + (kk - base) + 2) = hi;
+            }
+        }
+        if (tid < te - te4) { // ragged end of the pass (at most 3 entries; entries below ts are never summed)
+            const int kk = te4 + tid;
+            prod[kk - base] = value(A.codes[kk]) * x[A.col[kk]]; // the unpacked arrays stay resident
+        }
         __syncthreads();
         const int a = rs > ts ? rs : ts;
         const int b = re < te ? re : te;
@@ -359,30 +391,41 @@ __global__ __launch_bounds__(BLK) void k_spmv_tile_vi(CsrView A, const double *_
     if (DOT) {
         double d = (row < A.n) ? sum * x[row] : 0.;
         d = wave_sum(d);
-        __syncthreads();
-        if ((tid & 63) == 0) red[tid >> 6] = d;
-        __syncthreads();
-        if (tid == 0) {
-            double t = 0.;
-            for (int w = 0; w < BLK / 64; ++w) t += red[w];
-            partial[tile] = t; // tile == blockIdx.x without a tile list
-        }
+        if ((tid & 63) == 0) partial[tile * (BLK / 64) + (tid >> 6)] = d; // one partial per wave: no block barrier
     }
 }
 
 static constexpr int kViLdsTable = 2048; // dictionary entries staged in LDS (16 KiB)
+static constexpr int kTileRows = 512;    // rows per workgroup of the default kernels (also the unit of the dist tile lists)
+static constexpr int kTileCap = 4096;    // products parked per pass
 
-template <bool DOT>
-static avs_status spmv_vi_launch(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc,
-                                 const int32_t *tiles, int ntiles, hipStream_t stream)
+template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK>
+static avs_status spmv_vi2_launch_t(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc,
+                                    const int32_t *tiles, int ntiles, size_t lds, hipStream_t stream)
 {
-    if (ntiles <= 0) return AVS_OK;
-    if (A.table_size <= kViLdsTable)
-        hipLaunchKernelGGL((k_spmv_tile_vi<512, 4096, DOT, kViLdsTable>), dim3(ntiles), dim3(512), 0, stream, A, x, y, partial, sc, tiles);
-    else
-        hipLaunchKernelGGL((k_spmv_tile_vi<512, 4096, DOT, 0>), dim3(ntiles), dim3(512), 0, stream, A, x, y, partial, sc, tiles);
+    static bool attr = false; // one flag per instantiation
+    if (!attr && lds > 48 * 1024) {
+        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024 - 4096));
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK>), dim3(ntiles), dim3(BLK), lds, stream, A, x, y, partial, sc, tiles);
     AVS_HIP(hipGetLastError());
     return AVS_OK;
+}
+
+template <int BLK, int CAP, bool DOT>
+static avs_status spmv_vi2_launch(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc,
+                                  const int32_t *tiles, int ntiles, hipStream_t stream)
+{
+    if (ntiles <= 0) return AVS_OK;
+    const bool ltab = A.table_size <= kViLdsTable;
+    const bool pack = A.packed != nullptr;
+    const size_t lds = (size_t)(CAP + 4 + (ltab ? ((A.table_size + 1) & ~1) : 0)) * sizeof(double);
+    if (ltab && pack) return spmv_vi2_launch_t<BLK, CAP, DOT, true, true>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
+    if (ltab) return spmv_vi2_launch_t<BLK, CAP, DOT, true, false>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
+    if (pack) return spmv_vi2_launch_t<BLK, CAP, DOT, false, true>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
+    return spmv_vi2_launch_t<BLK, CAP, DOT, false, false>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -430,10 +473,33 @@ static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, do
                                 const PcgScalars *sc, int variant, hipStream_t stream, int *nblocks)
 {
     if (A.n <= 0) { if (nblocks) *nblocks = 0; return AVS_OK; }
-    if (A.codes && (variant == 0 || variant == spmv_default_variant(A))) { // value-indexed matrix: 6 B per non-zero
-        const int nt = (int)((A.n + 511) / 512);
-        if (nblocks) *nblocks = nt;
-        return spmv_vi_launch<DOT>(A, x, y, partial, sc, nullptr, nt, stream);
+    if (A.codes && (variant == 0 || variant == spmv_default_variant(A))) { // value-indexed matrix: 6 or 4 B per non-zero
+        const int nt = (int)((A.n + kTileRows - 1) / kTileRows);
+        if (nblocks) *nblocks = nt * (kTileRows / 64);
+        return spmv_vi2_launch<kTileRows, kTileCap, DOT>(A, x, y, partial, sc, nullptr, nt, stream);
+    }
+    if (A.codes && variant >= 31 && variant <= 42) {
+#define AVS_VI2_CASE(ID, BLK, CAP)                                                                              \
+    case ID: {                                                                                                  \
+        const int nt = (int)((A.n + BLK - 1) / BLK);                                                            \
+        if (nblocks) *nblocks = nt * (BLK / 64);                                                                \
+        return spmv_vi2_launch<BLK, CAP, DOT>(A, x, y, partial, sc, nullptr, nt, stream);                       \
+    }
+        switch (variant) {
+            AVS_VI2_CASE(31, 256, 4096)
+            AVS_VI2_CASE(32, 512, 8192)
+            AVS_VI2_CASE(33, 512, 4096)
+            AVS_VI2_CASE(34, 128, 2048)
+            AVS_VI2_CASE(35, 256, 8192)
+            AVS_VI2_CASE(36, 1024, 8192)
+            AVS_VI2_CASE(37, 256, 2048)
+            AVS_VI2_CASE(38, 512, 2048)
+            AVS_VI2_CASE(39, 256, 1024)
+            AVS_VI2_CASE(40, 128, 1024)
+            AVS_VI2_CASE(41, 1024, 4096)
+            AVS_VI2_CASE(42, 128, 512)
+        }
+#undef AVS_VI2_CASE
     }
     if (variant == 0) variant = spmv_default_variant(A);
     int g;
@@ -498,13 +564,12 @@ avs_status spmv_launch(const CsrView &A, const double *x, double *y, int variant
 
 // default kernel restricted to a list of 512-row tiles (multi-GPU overlap: interior tiles run while the halo
 // travels); partial[tile] receives the tile's share of x.y, so several launches fill one partial array
-static constexpr int kTileRows = 512;
 int spmv_tile_rows() { return kTileRows; }
 avs_status spmv_dot_tiles(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc,
                           const int32_t *tiles, int ntiles, hipStream_t stream)
 {
     if (ntiles <= 0) return AVS_OK;
-    if (A.codes) return spmv_vi_launch<true>(A, x, y, partial, sc, tiles, ntiles, stream);
+    if (A.codes) return spmv_vi2_launch<kTileRows, kTileCap, true>(A, x, y, partial, sc, tiles, ntiles, stream);
     hipLaunchKernelGGL((k_spmv_tile<kTileRows, 4096, true, true, false, true>), dim3(ntiles), dim3(kTileRows), 0, stream, A, x, y,
                        partial, sc, 0, tiles);
     AVS_HIP(hipGetLastError());
@@ -521,7 +586,7 @@ size_t spmv_partial_elems(int64_t n) { return max_partials(n); }
 static size_t max_partials(int64_t n);
 static size_t max_partials(int64_t n)
 {
-    size_t a = (size_t)((n + 127) / 128), b = (size_t)kVecGrid * 4;
+    size_t a = (size_t)((n + 63) / 64) + 16, b = (size_t)kVecGrid * 4; // up to one partial per wave of rows
     return 2 * (a > b ? a : b) + 4 * (size_t)kVecGrid + 16;
 }
 
@@ -872,7 +937,7 @@ static avs_status pcg_solve_single_reduction(PcgWork *w, const CsrView &A, const
                 AVS_TRY(dist_halo_end(dist, stream));
                 AVS_TRY(spmv_dot_tiles(A, u, wv, pspmv, sc, t_bnd, n_bnd, stream));
                 if (info) AVS_HIP(hipEventRecord(w->evB[c], stream));
-                nb = n_int + n_bnd;
+                nb = (n_int + n_bnd) * (A.codes ? kTileRows / 64 : 1); // the value-indexed kernel leaves one partial per wave
             } else {
                 AVS_TRY(dist_halo_exchange(dist, u, stream));
                 if (info) AVS_HIP(hipEventRecord(w->evA[c], stream));
