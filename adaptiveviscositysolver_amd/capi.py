@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "avs_last_error", "avs_version", "avs_create", "avs_destroy", "avs_set_labels",
     "avs_set_index_field", "avs_set_dof_counts", "avs_set_scalar_field", "avs_build_stencils",
     "avs_build_initial_guess", "avs_build_system", "avs_assemble", "avs_solve",
-    "avs_get_assembly_info", "avs_get_solution", "avs_get_initial_guess", "avs_get_csr",
+    "avs_get_assembly_info", "avs_get_matrix_format", "avs_get_solution", "avs_get_initial_guess", "avs_get_csr",
     "avs_get_edge_stencils", "avs_get_center_stencils", "avs_pcg_csr", "avs_spmv_csr",
     "avs_bench_spmv", "avs_bench_stream", "avs_prepass_create", "avs_prepass_destroy", "avs_prepass_run",
     "avs_prepass_get_info", "avs_prepass_get_labels", "avs_prepass_get_mask", "avs_prepass_get_index",
@@ -89,6 +89,11 @@ class AssemblyInfo(C.Structure):
                 ("guess_ms", C.c_double), ("system_ms", C.c_double), ("csr_ms", C.c_double)]
 
 
+class MatrixFormat(C.Structure):
+    _fields_ = [("reordered", C.c_int32), ("value_table_size", C.c_int32), ("column_bits", C.c_int32),
+                ("bytes_per_nonzero", C.c_int32)]
+
+
 _lib = None
 
 
@@ -118,6 +123,7 @@ def load():
     L.avs_assemble.argtypes = [vp, C.POINTER(AssemblyInfo)]
     L.avs_solve.argtypes = [vp, f64, i32, C.POINTER(SolveInfo)]
     L.avs_get_assembly_info.argtypes = [vp, C.POINTER(AssemblyInfo)]
+    L.avs_get_matrix_format.argtypes = [vp, C.POINTER(MatrixFormat)]
     L.avs_get_solution.argtypes = [vp, vp, i64, i32]
     L.avs_get_initial_guess.argtypes = [vp, vp, i64, i32]
     L.avs_get_csr.argtypes = [vp, vp, vp, vp, vp, i32]

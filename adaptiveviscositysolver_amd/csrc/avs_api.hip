@@ -287,6 +287,18 @@ avs_status avs_assemble(avs_ctx *c, avs_assembly_info *info)
     return AVS_OK;
 }
 
+avs_status avs_get_matrix_format(avs_ctx *c, avs_matrix_format *fmt)
+{
+    AVS_REQUIRE(c && fmt, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->system_ready, AVS_ESTATE, "no system: call avs_assemble first");
+    const bool vi = c->reordered && c->v_table_size > 0;
+    fmt->reordered = c->reordered ? 1 : 0;
+    fmt->value_table_size = vi ? c->v_table_size : 0;
+    fmt->column_bits = vi ? c->v_col_bits : 0;
+    fmt->bytes_per_nonzero = !vi ? 12 : (c->v_col_bits > 0 ? 4 : 6);
+    return AVS_OK;
+}
+
 avs_status avs_get_assembly_info(avs_ctx *c, avs_assembly_info *info)
 {
     AVS_REQUIRE(c && info, AVS_EINVAL, "null argument");

@@ -163,7 +163,7 @@ avs_status dist_halo_exchange(PcgDist *d, double *p_ext, hipStream_t stream);
 avs_status dist_allreduce(PcgDist *d, double *dev_scalars, int count, hipStream_t stream);
 void dist_release(struct ::avs_ctx *c);
 bool dist_wants_single_reduction(PcgDist *d);
-// overlap support: tile lists (interior / halo-touching 512-row tiles) and a split exchange
+// overlap support: tile lists (interior / halo-touching spmv_tile_rows()-row tiles) and a split exchange
 bool dist_tile_lists(PcgDist *d, const int32_t **t_int, int *n_int, const int32_t **t_bnd, int *n_bnd);
 avs_status dist_halo_begin(PcgDist *d, double *p_ext, hipStream_t main_stream);
 avs_status dist_halo_end(PcgDist *d, hipStream_t main_stream);

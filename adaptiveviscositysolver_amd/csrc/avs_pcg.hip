@@ -296,7 +296,7 @@ typedef int i4_t __attribute__((ext_vector_type(4)));
 
 typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 
-template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK>
+template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, bool XCD = false>
 __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__restrict__ x, double *__restrict__ y,
                                                   double *__restrict__ partial, const PcgScalars *sc,
                                                   const int32_t *__restrict__ tiles)
@@ -306,24 +306,32 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
     static_assert(U >= 1 && U * 4 * BLK == CAP, "CAP must be a multiple of 4*BLK");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *prod = smem;                 // CAP + 4
-    double *tbl = smem + CAP + 4;        // table_size (LTAB only)
+    int *arrived = reinterpret_cast<int *>(smem + CAP + 4 + 15);
+    double *tbl = smem + CAP + 4 + 16;                     // table_size (LTAB only)
     const int tid = threadIdx.x;
-    if (LTAB) {
+    if (DOT && tid == 0) *arrived = 0;
+    if (LTAB)
         for (int i = tid; i < A.table_size; i += BLK) tbl[i] = A.table[i];
-        __syncthreads();
-    }
+    if (DOT || LTAB) __syncthreads();
     const double *__restrict__ gtab = A.table;
     auto value = [&](unsigned code) -> double { return LTAB ? tbl[code] : gtab[code]; };
-    const int64_t tile = tiles ? (int64_t)tiles[blockIdx.x] : (int64_t)blockIdx.x;
+    int64_t tile = tiles ? (int64_t)tiles[blockIdx.x] : (int64_t)blockIdx.x;
+    if (XCD) { // workgroup b runs on XCD b % 8: give every XCD (its own L2) one contiguous eighth of the rows
+        const int64_t nt = (A.n + BLK - 1) / BLK, per = (nt + 7) / 8;
+        tile = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if ((int64_t)(blockIdx.x >> 3) >= per || tile >= nt) return;
+    }
     const int64_t row0 = tile * BLK;
     const int64_t row = row0 + tid;
     const int64_t rlast = (row0 + BLK < A.n) ? row0 + BLK : A.n;
     const int s_blk = A.row_ptr[row0];
     const int e_blk = A.row_ptr[rlast];
     int rs = 0, re = 0;
+    double xr = 0.;
     if (row < A.n) {
         rs = A.row_ptr[row];
         re = A.row_ptr[row + 1];
+        if (DOT) xr = x[row]; // early: its latency hides behind the passes
     }
     double sum = 0.;
     for (int ts = s_blk; ts < e_blk; ts += CAP) {
@@ -387,41 +395,62 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
         for (int j = a; j < b; ++j) sum += prod[j - base];
         __syncthreads();
     }
-    if (row < A.n) __builtin_nontemporal_store(sum, y + row);
     if (DOT) {
-        double d = (row < A.n) ? sum * x[row] : 0.;
-        d = wave_sum(d);
-        if ((tid & 63) == 0) partial[tile * (BLK / 64) + (tid >> 6)] = d; // one partial per wave: no block barrier
+        // x.y of the tile without a block barrier and without a wave reduction on every wave's critical path: each
+        // lane parks its term in LDS (prod[] is free after the loop's closing barrier), and the wave that arrives LAST
+        // folds all BLK terms -- lane l sums terms l, l+64, ... in order, then one wave tree: a fixed order whatever
+        // the arrival order was.
+        volatile double *term = prod;
+        term[tid] = (row < A.n) ? sum * xr : 0.;
+        // LDS-only fences: a full workgroup fence would also wait for this wave's outstanding global loads/stores
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        int before = 0;
+        if ((tid & 63) == 0) before = __hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        before = __builtin_amdgcn_readfirstlane(before);
+        if (before == BLK / 64 - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            double t = 0.;
+#pragma unroll
+            for (int w = 0; w < BLK / 64; ++w) t += term[(tid & 63) + 64 * w];
+            t = wave_sum(t);
+            if ((tid & 63) == 0) partial[tile] = t; // tile == blockIdx.x without a tile list
+        }
     }
+    if (row < A.n) __builtin_nontemporal_store(sum, y + row);
 }
 
 static constexpr int kViLdsTable = 2048; // dictionary entries staged in LDS (16 KiB)
-static constexpr int kTileRows = 512;    // rows per workgroup of the default kernels (also the unit of the dist tile lists)
-static constexpr int kTileCap = 4096;    // products parked per pass
+static constexpr int kTileRows = 256;    // rows per workgroup of the value-indexed kernel and of the dist tile lists
+static constexpr int kTileCap = 2048;    // products parked per pass (U = 2 quads per lane; 17 KiB of LDS => 32 waves per CU)
 
-template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK>
+template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, bool XCD = false>
 static avs_status spmv_vi2_launch_t(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc,
                                     const int32_t *tiles, int ntiles, size_t lds, hipStream_t stream)
 {
     static bool attr = false; // one flag per instantiation
     if (!attr && lds > 48 * 1024) {
-        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, XCD>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024 - 4096));
         attr = true;
     }
-    hipLaunchKernelGGL((k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK>), dim3(ntiles), dim3(BLK), lds, stream, A, x, y, partial, sc, tiles);
+    const int grid = XCD ? 8 * ((ntiles + 7) / 8) : ntiles;
+    hipLaunchKernelGGL((k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, XCD>), dim3(grid), dim3(BLK), lds, stream, A, x, y, partial, sc, tiles);
     AVS_HIP(hipGetLastError());
     return AVS_OK;
 }
 
-template <int BLK, int CAP, bool DOT>
+template <int BLK, int CAP, bool DOT, bool XCD = false>
 static avs_status spmv_vi2_launch(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc,
                                   const int32_t *tiles, int ntiles, hipStream_t stream)
 {
     if (ntiles <= 0) return AVS_OK;
     const bool ltab = A.table_size <= kViLdsTable;
     const bool pack = A.packed != nullptr;
-    const size_t lds = (size_t)(CAP + 4 + (ltab ? ((A.table_size + 1) & ~1) : 0)) * sizeof(double);
+    if (XCD) { // experiment: only the common instantiation
+        const size_t l = (size_t)(CAP + 4 + 16 + ((A.table_size + 1) & ~1)) * sizeof(double);
+        if (ltab && pack && !tiles) return spmv_vi2_launch_t<BLK, CAP, DOT, true, true, true>(A, x, y, partial, sc, tiles, ntiles, l, stream);
+    }
+    const size_t lds = (size_t)(CAP + 4 + 16 + (ltab ? ((A.table_size + 1) & ~1) : 0)) * sizeof(double);
     if (ltab && pack) return spmv_vi2_launch_t<BLK, CAP, DOT, true, true>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
     if (ltab) return spmv_vi2_launch_t<BLK, CAP, DOT, true, false>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
     if (pack) return spmv_vi2_launch_t<BLK, CAP, DOT, false, true>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
@@ -475,29 +504,31 @@ static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, do
     if (A.n <= 0) { if (nblocks) *nblocks = 0; return AVS_OK; }
     if (A.codes && (variant == 0 || variant == spmv_default_variant(A))) { // value-indexed matrix: 6 or 4 B per non-zero
         const int nt = (int)((A.n + kTileRows - 1) / kTileRows);
-        if (nblocks) *nblocks = nt * (kTileRows / 64);
+        if (nblocks) *nblocks = nt;
         return spmv_vi2_launch<kTileRows, kTileCap, DOT>(A, x, y, partial, sc, nullptr, nt, stream);
     }
-    if (A.codes && variant >= 31 && variant <= 42) {
-#define AVS_VI2_CASE(ID, BLK, CAP)                                                                              \
+    if (A.codes && variant >= 31 && variant <= 44) {
+#define AVS_VI2_CASE(ID, BLK, CAP, XCD)                                                                              \
     case ID: {                                                                                                  \
         const int nt = (int)((A.n + BLK - 1) / BLK);                                                            \
-        if (nblocks) *nblocks = nt * (BLK / 64);                                                                \
-        return spmv_vi2_launch<BLK, CAP, DOT>(A, x, y, partial, sc, nullptr, nt, stream);                       \
+        if (nblocks) *nblocks = nt;                                                                             \
+        return spmv_vi2_launch<BLK, CAP, DOT, XCD>(A, x, y, partial, sc, nullptr, nt, stream);                  \
     }
         switch (variant) {
-            AVS_VI2_CASE(31, 256, 4096)
-            AVS_VI2_CASE(32, 512, 8192)
-            AVS_VI2_CASE(33, 512, 4096)
-            AVS_VI2_CASE(34, 128, 2048)
-            AVS_VI2_CASE(35, 256, 8192)
-            AVS_VI2_CASE(36, 1024, 8192)
-            AVS_VI2_CASE(37, 256, 2048)
-            AVS_VI2_CASE(38, 512, 2048)
-            AVS_VI2_CASE(39, 256, 1024)
-            AVS_VI2_CASE(40, 128, 1024)
-            AVS_VI2_CASE(41, 1024, 4096)
-            AVS_VI2_CASE(42, 128, 512)
+            AVS_VI2_CASE(31, 256, 4096, false)
+            AVS_VI2_CASE(32, 512, 8192, false)
+            AVS_VI2_CASE(33, 512, 4096, false)
+            AVS_VI2_CASE(34, 128, 2048, false)
+            AVS_VI2_CASE(35, 256, 8192, false)
+            AVS_VI2_CASE(36, 1024, 8192, false)
+            AVS_VI2_CASE(37, 256, 2048, false)
+            AVS_VI2_CASE(38, 512, 2048, false)
+            AVS_VI2_CASE(39, 256, 1024, false)
+            AVS_VI2_CASE(40, 128, 1024, false)
+            AVS_VI2_CASE(41, 1024, 4096, false)
+            AVS_VI2_CASE(42, 128, 512, false)
+            AVS_VI2_CASE(43, 512, 4096, true)
+            AVS_VI2_CASE(44, 256, 2048, true)
         }
 #undef AVS_VI2_CASE
     }
@@ -562,7 +593,7 @@ avs_status spmv_launch(const CsrView &A, const double *x, double *y, int variant
     return spmv_dispatch<false>(A, x, y, nullptr, nullptr, variant, stream, nullptr);
 }
 
-// default kernel restricted to a list of 512-row tiles (multi-GPU overlap: interior tiles run while the halo
+// default kernel restricted to a list of kTileRows-row tiles (multi-GPU overlap: interior tiles run while the halo
 // travels); partial[tile] receives the tile's share of x.y, so several launches fill one partial array
 int spmv_tile_rows() { return kTileRows; }
 avs_status spmv_dot_tiles(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc,
@@ -570,7 +601,7 @@ avs_status spmv_dot_tiles(const CsrView &A, const double *x, double *y, double *
 {
     if (ntiles <= 0) return AVS_OK;
     if (A.codes) return spmv_vi2_launch<kTileRows, kTileCap, true>(A, x, y, partial, sc, tiles, ntiles, stream);
-    hipLaunchKernelGGL((k_spmv_tile<kTileRows, 4096, true, true, false, true>), dim3(ntiles), dim3(kTileRows), 0, stream, A, x, y,
+    hipLaunchKernelGGL((k_spmv_tile<kTileRows, 2048, true, true, false, true>), dim3(ntiles), dim3(kTileRows), 0, stream, A, x, y,
                        partial, sc, 0, tiles);
     AVS_HIP(hipGetLastError());
     return AVS_OK;
@@ -937,7 +968,7 @@ static avs_status pcg_solve_single_reduction(PcgWork *w, const CsrView &A, const
                 AVS_TRY(dist_halo_end(dist, stream));
                 AVS_TRY(spmv_dot_tiles(A, u, wv, pspmv, sc, t_bnd, n_bnd, stream));
                 if (info) AVS_HIP(hipEventRecord(w->evB[c], stream));
-                nb = (n_int + n_bnd) * (A.codes ? kTileRows / 64 : 1); // the value-indexed kernel leaves one partial per wave
+                nb = n_int + n_bnd;
             } else {
                 AVS_TRY(dist_halo_exchange(dist, u, stream));
                 if (info) AVS_HIP(hipEventRecord(w->evA[c], stream));

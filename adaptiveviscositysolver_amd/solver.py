@@ -173,6 +173,12 @@ class ViscositySolve:
         capi.check(self.lib.avs_bench_spmv(self.h, variant, repeats, C.byref(ms)))
         return ms.value
 
+    def matrix_format(self):
+        """Storage form the solver's SpMV streams (12 / 6 / 4 bytes per non-zero), see avs_matrix_format."""
+        fmt = capi.MatrixFormat()
+        capi.check(self.lib.avs_get_matrix_format(self.h, C.byref(fmt)))
+        return fmt
+
     # ---- outputs (numpy, host) ------------------------------------------------------------
     def info(self):
         info = capi.AssemblyInfo()

@@ -1,0 +1,94 @@
+"""The solver's SpMV streams one of three LOSSLESS storage forms of the assembled matrix (avs_matrix_format):
+12 B/non-zero plain CSR, 6 B value-indexed, 4 B packed.  Every form must give the products and row sums of
+plain CSR bit for bit (avs_bench_spmv checks that on the device and fails otherwise), and the solve behind
+each form must agree with the CPU oracle.  The scenes below are chosen so that every kernel instantiation
+(table in LDS / table in global memory) x (packed / unpacked) and the no-dictionary fallback are exercised.
+"""
+import numpy as np
+import pytest
+import torch
+
+from adaptiveviscositysolver_amd import ViscositySolve, prepass, scenes
+from util import oracle_from_pyramid, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(kind):
+    sc = scenes.fat_beam(64, 3)
+    if kind == "uniform":
+        return sc
+    g = torch.Generator().manual_seed(11)
+    shape = (sc.res[2], sc.res[1], sc.res[0])
+    if kind == "levels":   # a handful of viscosities -> a dictionary of a few thousand matrix values
+        pal = torch.tensor([120.0, 250.0, 380.0, 510.0, 640.0, 770.0, 900.0, 1030.0], dtype=torch.float32)
+        sc.viscosity = pal[torch.randint(0, len(pal), shape, generator=g)].contiguous()
+    elif kind == "noise":  # every cell its own viscosity -> more than 65536 distinct matrix values
+        sc.viscosity = (100.0 + 900.0 * torch.rand(shape, generator=g, dtype=torch.float32)).contiguous()
+    return sc
+
+
+CASES = [
+    # scene,   environment,                 expected bytes per non-zero, table in LDS?
+    ("uniform", {}, 4, True),
+    ("uniform", {"AVS_VALUE_PACK": "0"}, 6, True),
+    ("uniform", {"AVS_VALUE_INDEX": "0"}, 12, None),
+    ("levels", {}, 4, False),
+    ("levels", {"AVS_VALUE_PACK": "0"}, 6, False),
+    ("noise", {}, 12, None),
+]
+
+
+@pytest.mark.parametrize("kind,env,want_bytes,lds_table", CASES)
+def test_storage_forms_are_lossless(kind, env, want_bytes, lds_table, monkeypatch, built_lib):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sc = _scene(kind)
+    pyr = prepass.build_pyramid(sc)
+    dsc = scenes.to_device(sc, torch.device("cuda:0"))
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
+    s.set_pyramid(pyr)
+    s.set_scene_fields(dsc)
+    ai = s.assemble()
+    fmt = s.matrix_format()
+    assert fmt.reordered == 1
+    assert fmt.bytes_per_nonzero == want_bytes, (fmt.value_table_size, fmt.column_bits)
+    if want_bytes == 12:
+        assert fmt.value_table_size == 0 and fmt.column_bits == 0
+    else:
+        assert 0 < fmt.value_table_size <= 65536
+        assert (fmt.value_table_size <= 2048) == lds_table, fmt.value_table_size
+        assert (fmt.column_bits > 0) == (want_bytes == 4)
+        if want_bytes == 4:
+            assert (1 << fmt.column_bits) >= ai.n_velocity
+            assert fmt.column_bits + int(np.ceil(np.log2(fmt.value_table_size))) <= 32
+    # bit-for-bit against the plain kernel, plain and fused-dot launch forms (raises AvsError on a mismatch)
+    s.bench_spmv(0, 2)
+    s.bench_spmv(100, 2)
+    # and the solve behind this form agrees with the oracle's
+    o = oracle_from_pyramid(sc, pyr)
+    o.hot_path()
+    xo, oi = o.solve(1e-10, 4000)
+    info = s.solve(1e-10, 4000)
+    assert info.converged == 1
+    assert abs(info.iterations - oi.iterations) <= 2
+    assert rel_l2(s.solution(), xo) < 1e-8
+
+
+def test_reference_numbered_csr_is_untouched(built_lib):
+    """The renumbering / value index / packing are internal to the solver: what avs_get_csr hands back is still the
+    matrix of the reference numbering, bit-exact against the oracle (the dictionary's own exactness --
+    table[code[k]] == val[k] -- is what avs_bench_spmv's device-side comparison above establishes)."""
+    sc = scenes.fat_beam(32, 3)
+    pyr = prepass.build_pyramid(sc)
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
+    s.set_pyramid(pyr)
+    s.set_scene_fields(scenes.to_device(sc, torch.device("cuda:0")))
+    s.assemble()
+    assert s.matrix_format().bytes_per_nonzero == 4
+    o = oracle_from_pyramid(sc, pyr)
+    o.hot_path()
+    rp, col, val, rhs = s.csr()
+    oc = o.csr()
+    assert np.array_equal(rp, oc.row_ptr) and np.array_equal(col, oc.col)
+    assert np.array_equal(val, oc.val) and np.array_equal(rhs, oc.rhs)

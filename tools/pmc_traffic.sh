@@ -1,11 +1,11 @@
 # HBM-side traffic of the default SpMV kernel, per MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE in SEPARATE
 # --pmc passes (kernel filter: counter collection serialises every profiled dispatch), plus the request-size split.
 cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT
-run() { name=$1; shift; timeout 200 rocprofv3 --kernel-include-regex "spmv|k_update_p" --pmc "$@" --output-format csv -d $R/gpurun_out/trf_$name -o p -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/trf_$name.log 2>&1; echo "pass $name rc=$?"; }
+run() { name=$1; shift; timeout 200 rocprofv3 --kernel-include-regex "spmv|k_update_r" --pmc "$@" --output-format csv -d $R/gpurun_out/trf_$name -o p -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/trf_$name.log 2>&1; echo "pass $name rc=$?"; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run req TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum
-cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/trf_stats -o r01b -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/trf_stats.log 2>&1
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/trf_stats -o r01e -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/trf_stats.log 2>&1
 cd $R && rm -f gpurun_out/trf_stats/*kernel_trace.csv && python - <<'PY'
 import csv, collections, glob, json
 out = {}
