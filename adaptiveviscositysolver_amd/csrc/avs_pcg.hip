@@ -43,6 +43,8 @@ struct PcgScalars {
 struct PcgWork {
     int64_t n = 0, n_ext = 0;
     DevBuf<double> r, p, t, invd, partial;
+    DevBuf<uint16_t> dcode;  // value-indexed matrix: code of every row's diagonal entry ...
+    DevBuf<double> invtab;   // ... into the table of inverted values (2 B instead of 8 B per row and vector pass)
     DevBuf<double> s, u; // single-reduction variant (multi-GPU): s = A p recurrence, u = M^-1 r with halo tail
     DevBuf<PcgScalars> sc;
     PcgScalars *host_sc = nullptr; // pinned
@@ -296,7 +298,7 @@ typedef int i4_t __attribute__((ext_vector_type(4)));
 
 typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 
-template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, bool XCD = false>
+template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK>
 __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__restrict__ x, double *__restrict__ y,
                                                   double *__restrict__ partial, const PcgScalars *sc,
                                                   const int32_t *__restrict__ tiles)
@@ -315,12 +317,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
     if (DOT || LTAB) __syncthreads();
     const double *__restrict__ gtab = A.table;
     auto value = [&](unsigned code) -> double { return LTAB ? tbl[code] : gtab[code]; };
-    int64_t tile = tiles ? (int64_t)tiles[blockIdx.x] : (int64_t)blockIdx.x;
-    if (XCD) { // workgroup b runs on XCD b % 8: give every XCD (its own L2) one contiguous eighth of the rows
-        const int64_t nt = (A.n + BLK - 1) / BLK, per = (nt + 7) / 8;
-        tile = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
-        if ((int64_t)(blockIdx.x >> 3) >= per || tile >= nt) return;
-    }
+    const int64_t tile = tiles ? (int64_t)tiles[blockIdx.x] : (int64_t)blockIdx.x;
     const int64_t row0 = tile * BLK;
     const int64_t row = row0 + tid;
     const int64_t rlast = (row0 + BLK < A.n) ? row0 + BLK : A.n;
@@ -423,33 +420,28 @@ static constexpr int kViLdsTable = 2048; // dictionary entries staged in LDS (16
 static constexpr int kTileRows = 256;    // rows per workgroup of the value-indexed kernel and of the dist tile lists
 static constexpr int kTileCap = 2048;    // products parked per pass (U = 2 quads per lane; 17 KiB of LDS => 32 waves per CU)
 
-template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, bool XCD = false>
+template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK>
 static avs_status spmv_vi2_launch_t(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc,
                                     const int32_t *tiles, int ntiles, size_t lds, hipStream_t stream)
 {
     static bool attr = false; // one flag per instantiation
     if (!attr && lds > 48 * 1024) {
-        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, XCD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024 - 4096));
         attr = true;
     }
-    const int grid = XCD ? 8 * ((ntiles + 7) / 8) : ntiles;
-    hipLaunchKernelGGL((k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, XCD>), dim3(grid), dim3(BLK), lds, stream, A, x, y, partial, sc, tiles);
+    hipLaunchKernelGGL((k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK>), dim3(ntiles), dim3(BLK), lds, stream, A, x, y, partial, sc, tiles);
     AVS_HIP(hipGetLastError());
     return AVS_OK;
 }
 
-template <int BLK, int CAP, bool DOT, bool XCD = false>
+template <int BLK, int CAP, bool DOT>
 static avs_status spmv_vi2_launch(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc,
                                   const int32_t *tiles, int ntiles, hipStream_t stream)
 {
     if (ntiles <= 0) return AVS_OK;
     const bool ltab = A.table_size <= kViLdsTable;
     const bool pack = A.packed != nullptr;
-    if (XCD) { // experiment: only the common instantiation
-        const size_t l = (size_t)(CAP + 4 + 16 + ((A.table_size + 1) & ~1)) * sizeof(double);
-        if (ltab && pack && !tiles) return spmv_vi2_launch_t<BLK, CAP, DOT, true, true, true>(A, x, y, partial, sc, tiles, ntiles, l, stream);
-    }
     const size_t lds = (size_t)(CAP + 4 + 16 + (ltab ? ((A.table_size + 1) & ~1) : 0)) * sizeof(double);
     if (ltab && pack) return spmv_vi2_launch_t<BLK, CAP, DOT, true, true>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
     if (ltab) return spmv_vi2_launch_t<BLK, CAP, DOT, true, false>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
@@ -507,28 +499,23 @@ static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, do
         if (nblocks) *nblocks = nt;
         return spmv_vi2_launch<kTileRows, kTileCap, DOT>(A, x, y, partial, sc, nullptr, nt, stream);
     }
-    if (A.codes && variant >= 31 && variant <= 44) {
-#define AVS_VI2_CASE(ID, BLK, CAP, XCD)                                                                              \
+    if (A.codes && variant >= 31 && variant <= 40) {
+#define AVS_VI2_CASE(ID, BLK, CAP)                                                                              \
     case ID: {                                                                                                  \
         const int nt = (int)((A.n + BLK - 1) / BLK);                                                            \
         if (nblocks) *nblocks = nt;                                                                             \
-        return spmv_vi2_launch<BLK, CAP, DOT, XCD>(A, x, y, partial, sc, nullptr, nt, stream);                  \
+        return spmv_vi2_launch<BLK, CAP, DOT>(A, x, y, partial, sc, nullptr, nt, stream);                       \
     }
-        switch (variant) {
-            AVS_VI2_CASE(31, 256, 4096, false)
-            AVS_VI2_CASE(32, 512, 8192, false)
-            AVS_VI2_CASE(33, 512, 4096, false)
-            AVS_VI2_CASE(34, 128, 2048, false)
-            AVS_VI2_CASE(35, 256, 8192, false)
-            AVS_VI2_CASE(36, 1024, 8192, false)
-            AVS_VI2_CASE(37, 256, 2048, false)
-            AVS_VI2_CASE(38, 512, 2048, false)
-            AVS_VI2_CASE(39, 256, 1024, false)
-            AVS_VI2_CASE(40, 128, 1024, false)
-            AVS_VI2_CASE(41, 1024, 4096, false)
-            AVS_VI2_CASE(42, 128, 512, false)
-            AVS_VI2_CASE(43, 512, 4096, true)
-            AVS_VI2_CASE(44, 256, 2048, true)
+        switch (variant) { // geometry sweep of the value-indexed kernel (profiles/r01_spmv_variants.md)
+            AVS_VI2_CASE(31, 256, 4096)
+            AVS_VI2_CASE(32, 512, 8192)
+            AVS_VI2_CASE(33, 512, 4096)
+            AVS_VI2_CASE(34, 128, 2048)
+            AVS_VI2_CASE(36, 1024, 8192)
+            AVS_VI2_CASE(37, 256, 2048)
+            AVS_VI2_CASE(38, 512, 2048)
+            AVS_VI2_CASE(39, 256, 1024)
+            AVS_VI2_CASE(40, 128, 1024)
         }
 #undef AVS_VI2_CASE
     }
@@ -678,11 +665,28 @@ __global__ __launch_bounds__(kBlock) void k_init_p(int64_t n, const double *__re
     if (threadIdx.x == 0) partial[blockIdx.x] = rz;
 }
 
+// value-indexed matrix: invd[i] == invtab[dcode[i]], where invtab[c] = 1 / table[c] (1 for a zero) and the extra
+// entry invtab[table_size] = 1 stands for "no diagonal entry" -- the same doubles k_inv_diag writes
+__global__ __launch_bounds__(kBlock) void k_inv_diag_coded(CsrView A, uint16_t *__restrict__ dcode, double *__restrict__ invtab)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i <= A.table_size) {
+        const double d = i < A.table_size ? A.table[i] : 0.;
+        invtab[i] = (d != 0.) ? 1. / d : 1.;
+    }
+    if (i >= A.n) return;
+    unsigned code = (unsigned)A.table_size;
+    for (int k = A.row_ptr[i]; k < A.row_ptr[i + 1]; ++k)
+        if (A.col[k] == (int32_t)i) code = A.codes[k];
+    dcode[i] = (uint16_t)code;
+}
+
 // r -= alpha t ; partials: r.r and r.(invd r).  (x += alpha p rides along with the p update below:
 // one vector pass less per iteration -- 10 n instead of 11 n doubles of traffic.)
+template <bool CODED>
 __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, double *__restrict__ r, const double *__restrict__ t,
-                                                     const double *__restrict__ invd, const PcgScalars *sc,
-                                                     double *__restrict__ partial)
+                                                     const double *__restrict__ invd, const uint16_t *__restrict__ dcode,
+                                                     const PcgScalars *sc, double *__restrict__ partial)
 {
     if (sc->done) return;
     __shared__ double red[4];
@@ -692,7 +696,7 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, double *__restri
         const double ri = r[i] - alpha * t[i];
         r[i] = ri;
         rr += ri * ri;
-        rz += ri * (invd[i] * ri);
+        rz += ri * ((CODED ? invd[dcode[i]] : invd[i]) * ri);
     }
     rr = block_sum(rr, red);
     rz = block_sum(rz, red);
@@ -704,9 +708,10 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, double *__restri
 
 // x += alpha p (Eigen does this before the convergence test, so it also runs in the iteration that
 // converges: done == 2 = "converged, x update pending"); then p = invd r + beta p unless converged.
+template <bool CODED>
 __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, double *__restrict__ x, double *__restrict__ p,
                                                       const double *__restrict__ r, const double *__restrict__ invd,
-                                                      const PcgScalars *sc)
+                                                      const uint16_t *__restrict__ dcode, const PcgScalars *sc)
 {
     const int done = sc->done;
     if (done == 1 || done == 3) return;
@@ -719,7 +724,7 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, double *__restr
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const double pi = p[i];
         x[i] += alpha * pi;
-        p[i] = invd[i] * r[i] + beta * pi;
+        p[i] = (CODED ? invd[dcode[i]] : invd[i]) * r[i] + beta * pi;
     }
 }
 
@@ -1079,6 +1084,14 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
 
     AVS_HIP(hipMemsetAsync(sc, 0, sizeof(PcgScalars), stream));
     hipLaunchKernelGGL(k_inv_diag, dim3(rowgrid), dim3(kBlock), 0, stream, A, invd);
+    // few distinct values: the two vector kernels of the loop read a 2-B diagonal code instead of the 8-B inverse
+    const bool coded = A.codes && A.table_size <= kViLdsTable;
+    if (coded) {
+        if (!w->dcode.p) AVS_TRY(w->dcode.alloc((size_t)n));
+        if (!w->invtab.p) AVS_TRY(w->invtab.alloc((size_t)kViLdsTable + 1));
+        const int cg = (int)(((n > A.table_size + 1 ? n : A.table_size + 1) + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(k_inv_diag_coded, dim3(cg), dim3(kBlock), 0, stream, A, w->dcode.p, w->invtab.p);
+    }
     AVS_HIP(hipEventRecord(w->ev0, stream));
 
     // residual = rhs - mat * x
@@ -1126,9 +1139,11 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
             AVS_TRY(spmv_dispatch<true>(A, p, t, partial, sc, variant, stream, &nb)); // tmp = A p ; p.tmp
             if (timed) AVS_HIP(hipEventRecord(w->evB[c], stream));
             AVS_TRY(reduce_stage(w, nb, 1, OP_ALPHA, tol, 1, stream, dist));
-            hipLaunchKernelGGL(k_update_r, dim3(g), dim3(kBlock), 0, stream, n, r, t, invd, sc, partial);
+            if (coded) hipLaunchKernelGGL(k_update_r<true>, dim3(g), dim3(kBlock), 0, stream, n, r, t, w->invtab.p, w->dcode.p, sc, partial);
+            else hipLaunchKernelGGL(k_update_r<false>, dim3(g), dim3(kBlock), 0, stream, n, r, t, invd, nullptr, sc, partial);
             AVS_TRY(reduce_stage(w, g, 2, OP_BETA, tol, 1, stream, dist));
-            hipLaunchKernelGGL(k_update_xp, dim3(g), dim3(kBlock), 0, stream, n, x, p, r, invd, sc);
+            if (coded) hipLaunchKernelGGL(k_update_xp<true>, dim3(g), dim3(kBlock), 0, stream, n, x, p, r, w->invtab.p, w->dcode.p, sc);
+            else hipLaunchKernelGGL(k_update_xp<false>, dim3(g), dim3(kBlock), 0, stream, n, x, p, r, invd, nullptr, sc);
         }
         AVS_HIP(hipGetLastError());
         enqueued += chunk;
