@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <new>
 
@@ -221,6 +222,387 @@ void dist_release(avs_ctx *c)
     c->dist = nullptr;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Device-side partition planner: the same plan avs_partition.cpp builds on the host (slabs on multiples of
+// 2^(levels-1) fine cells balanced by non-zeros, local numbering [owned ascending | halo grouped by owner,
+// ascending], ascending send lists), but from the CSR that already lives in HBM: flag + exclusive scan +
+// scatter, one pass over the rows for the halo / "needed by" marks.  Only O(planes) + O(world) scalars visit
+// the host.  AVS_DIST_PLAN=host selects the host planner (tests compare the two array for array).
+// ---------------------------------------------------------------------------------------------
+constexpr int kPlanLdsPlanes = 2048;
+
+__device__ __forceinline__ int plane_of_dof(const int32_t *__restrict__ vdof, int64_t src, int axis, int extent, int shift)
+{
+    const int32_t *t = vdof + 4 * src;
+    const int level = t[0] & 0xff;
+    int64_t pos = (int64_t)t[1 + axis] << level;
+    if (pos >= extent) pos = extent - 1;
+    return (int)(pos >> shift);
+}
+
+// plane of every row + per-plane weights (non-zeros + 2 per row, as the host planner)
+__global__ __launch_bounds__(256) void k_plan_planes(int64_t n, const int32_t *__restrict__ vdof, const int32_t *__restrict__ perm,
+                                                     const int32_t *__restrict__ row_ptr, int axis, int extent, int shift,
+                                                     int nplanes, uint16_t *__restrict__ plane, unsigned long long *__restrict__ weight)
+{
+    __shared__ unsigned long long h[kPlanLdsPlanes];
+    const bool lds = nplanes <= kPlanLdsPlanes;
+    if (lds) {
+        for (int i = threadIdx.x; i < nplanes; i += 256) h[i] = 0ull;
+        __syncthreads();
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int pl = plane_of_dof(vdof, perm ? perm[i] : i, axis, extent, shift);
+        plane[i] = (uint16_t)pl;
+        const unsigned long long w = (unsigned long long)(row_ptr[i + 1] - row_ptr[i]) + 2ull;
+        atomicAdd(lds ? &h[pl] : &weight[pl], w);
+    }
+    if (lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nplanes; i += 256)
+            if (h[i]) atomicAdd(&weight[i], h[i]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_plan_owner(int64_t n, const uint16_t *__restrict__ plane, const int32_t *__restrict__ plane_owner,
+                                                    int rank, uint8_t *__restrict__ owner, int32_t *__restrict__ own_flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int q = plane_owner[plane[i]];
+    owner[i] = (uint8_t)q;
+    own_flag[i] = q == rank;
+}
+
+// one pass over all rows: my rows mark the foreign columns they read (halo), foreign rows mark which of my
+// columns their owner needs (bit q)
+__global__ __launch_bounds__(256) void k_plan_mark(int64_t n, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+                                                   const uint8_t *__restrict__ owner, int rank, uint8_t *__restrict__ is_halo,
+                                                   uint32_t *__restrict__ needed_by)
+{
+    const int sub = threadIdx.x & 15;
+    const int64_t group = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int64_t ngroups = ((int64_t)gridDim.x * 256) >> 4;
+    for (int64_t r = group; r < n; r += ngroups) {
+        const int q = owner[r];
+        const int s = row_ptr[r], e = row_ptr[r + 1];
+        for (int k = s + sub; k < e; k += 16) {
+            const int32_t c = col[k];
+            const int oc = owner[c];
+            if (q == rank) {
+                if (oc != rank) is_halo[c] = 1; // same value from every writer
+            } else if (oc == rank) {
+                const uint32_t bit = 1u << q;
+                if (!(needed_by[c] & bit)) atomicOr(&needed_by[c], bit);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_plan_flag_halo(int64_t n, const uint8_t *__restrict__ is_halo, const uint8_t *__restrict__ owner,
+                                                        int q, int32_t *__restrict__ f)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) f[i] = is_halo[i] && owner[i] == q;
+}
+
+__global__ __launch_bounds__(256) void k_plan_flag_send(int64_t n, const uint8_t *__restrict__ owner, int rank,
+                                                        const uint32_t *__restrict__ needed_by, int q, int32_t *__restrict__ f)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) f[i] = owner[i] == rank && ((needed_by[i] >> q) & 1u);
+}
+
+// flagged i -> out[pos[i]] = (map ? map[i] : i); g2l[i] = base + pos[i] when g2l is given
+__global__ __launch_bounds__(256) void k_plan_scatter(int64_t n, const int32_t *__restrict__ f, const int32_t *__restrict__ pos,
+                                                      const int32_t *__restrict__ map, int32_t *__restrict__ out,
+                                                      int32_t *__restrict__ g2l, int32_t base)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !f[i]) return;
+    out[pos[i]] = map ? map[i] : (int32_t)i;
+    if (g2l) g2l[i] = base + pos[i];
+}
+
+__global__ __launch_bounds__(256) void k_plan_local_len(int64_t n_own, const int32_t *__restrict__ own_global,
+                                                        const int32_t *__restrict__ row_ptr, int32_t *__restrict__ len)
+{
+    const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (l > n_own) return;
+    len[l] = l < n_own ? row_ptr[own_global[l] + 1] - row_ptr[own_global[l]] : 0;
+}
+
+// local rows: columns through global -> local, values (and value codes) copied, in-row order unchanged;
+// tile_bnd[tile] = 1 when a row of the tile reads a halo column
+__global__ __launch_bounds__(256) void k_plan_local_rows(int64_t n_own, const int32_t *__restrict__ own_global,
+                                                         const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+                                                         const double *__restrict__ val, const uint16_t *__restrict__ codes,
+                                                         const int32_t *__restrict__ g2l, const int32_t *__restrict__ row_ptr_l,
+                                                         int32_t *__restrict__ col_l, double *__restrict__ val_l,
+                                                         uint16_t *__restrict__ codes_l, int tile_rows, int32_t *__restrict__ tile_bnd)
+{
+    const int sub = threadIdx.x & 15;
+    const int64_t group = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int64_t ngroups = ((int64_t)gridDim.x * 256) >> 4;
+    for (int64_t l = group; l < n_own; l += ngroups) {
+        const int src = row_ptr[own_global[l]], dst = row_ptr_l[l], len = row_ptr_l[l + 1] - dst;
+        bool touches = false;
+        for (int k = sub; k < len; k += 16) {
+            const int32_t lc = g2l[col[src + k]];
+            col_l[dst + k] = lc;
+            val_l[dst + k] = val[src + k];
+            if (codes) codes_l[dst + k] = codes[src + k];
+            touches |= lc >= n_own;
+        }
+        if (touches) tile_bnd[l / tile_rows] = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_plan_not(int64_t n, const int32_t *__restrict__ f, int32_t *__restrict__ g)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) g[i] = !f[i];
+}
+
+static inline unsigned grid256(int64_t n) { return (unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1); }
+
+// exclusive scan of 0/1 flags + their total (one small read-back)
+static avs_status scan_flags(const int32_t *f, int32_t *pos, int64_t n, DevBuf<int32_t> &tmp, int64_t *total, hipStream_t st)
+{
+    *total = 0;
+    if (n == 0) return AVS_OK;
+    AVS_TRY(exclusive_scan_i32(f, pos, n, tmp.p, tmp.n, st));
+    int32_t last[2] = {0, 0};
+    AVS_HIP(hipMemcpyAsync(&last[0], pos + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipMemcpyAsync(&last[1], f + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipStreamSynchronize(st));
+    *total = (int64_t)last[0] + last[1];
+    return AVS_OK;
+}
+
+// fills the plan and the local system of `d` from the context's (brick-major when `ro`) system
+static avs_status plan_on_device(avs_ctx *c, PcgDist *d, int cut_axis, int extent, bool ro)
+{
+    hipStream_t st = c->stream;
+    const int64_t n = c->n_vel;
+    const int rank = d->rank, world = d->world;
+    AVS_REQUIRE(world <= 32, AVS_EINVAL, "at most 32 ranks");
+    const int32_t *g_rp = ro ? c->p_row_ptr.p : c->row_ptr.p, *g_col = ro ? c->p_col.p : c->col.p;
+    const double *g_val = ro ? c->p_val.p : c->val.p;
+    const bool vi = ro && c->v_table_size > 0;
+    const int shift = c->desc.levels - 1;
+    const int nplanes = (extent + (1 << shift) - 1) >> shift;
+    AVS_REQUIRE(nplanes <= 65535, AVS_EINVAL, "too many cut planes");
+
+    DevBuf<uint16_t> plane;
+    DevBuf<unsigned long long> weight;
+    DevBuf<int32_t> plane_owner, flag, pos, g2l, scan_tmp, halo_tmp;
+    DevBuf<uint8_t> owner, is_halo;
+    DevBuf<uint32_t> needed_by;
+    AVS_TRY(plane.alloc((size_t)n));
+    AVS_TRY(weight.alloc((size_t)nplanes));
+    AVS_TRY(plane_owner.alloc((size_t)nplanes));
+    AVS_TRY(flag.alloc((size_t)n + 1));
+    AVS_TRY(pos.alloc((size_t)n + 1));
+    AVS_TRY(g2l.alloc((size_t)n));
+    AVS_TRY(scan_tmp.alloc(scan_tmp_elems(n + 1)));
+    AVS_TRY(owner.alloc((size_t)n));
+    AVS_TRY(is_halo.alloc((size_t)n));
+    AVS_TRY(needed_by.alloc((size_t)n));
+    AVS_HIP(hipMemsetAsync(weight.p, 0, (size_t)nplanes * sizeof(unsigned long long), st));
+    AVS_HIP(hipMemsetAsync(is_halo.p, 0, (size_t)n, st));
+    AVS_HIP(hipMemsetAsync(needed_by.p, 0, (size_t)n * sizeof(uint32_t), st));
+    AVS_HIP(hipMemsetAsync(g2l.p, 0xFF, (size_t)n * sizeof(int32_t), st));
+
+    // 1. slabs: per-plane weights -> (host, O(planes)) greedy cuts -> owner of every row
+    hipLaunchKernelGGL(k_plan_planes, dim3(2048), dim3(256), 0, st, n, c->vdof.p, ro ? c->perm.p : nullptr, g_rp, cut_axis, extent,
+                       shift, nplanes, plane.p, weight.p);
+    std::vector<unsigned long long> h_w((size_t)nplanes);
+    AVS_HIP(hipMemcpyAsync(h_w.data(), weight.p, h_w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipStreamSynchronize(st));
+    std::vector<int64_t> h_w64(h_w.begin(), h_w.end());
+    std::vector<int> h_po((size_t)nplanes);
+    plane_owners_from_weights(h_w64.data(), nplanes, world, h_po.data());
+    AVS_HIP(hipMemcpyAsync(plane_owner.p, h_po.data(), h_po.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_plan_owner, dim3(grid256(n)), dim3(256), 0, st, n, plane.p, plane_owner.p, rank, owner.p, flag.p);
+
+    // 2. owned rows, ascending
+    int64_t n_own = 0;
+    AVS_TRY(scan_flags(flag.p, pos.p, n, scan_tmp, &n_own, st));
+    AVS_TRY(d->own_global.alloc((size_t)n_own));
+    hipLaunchKernelGGL(k_plan_scatter, dim3(grid256(n)), dim3(256), 0, st, n, flag.p, pos.p, (const int32_t *)nullptr, d->own_global.p,
+                       g2l.p, 0);
+
+    // 3. halo / needed-by marks
+    hipLaunchKernelGGL(k_plan_mark, dim3(8192), dim3(256), 0, st, n, g_rp, g_col, owner.p, rank, is_halo.p, needed_by.p);
+
+    // 4. halo numbering (grouped by owner) and send lists (ascending owned entries each peer reads)
+    std::vector<int64_t> recv_cnt((size_t)world, 0), send_cnt((size_t)world, 0);
+    AVS_TRY(halo_tmp.alloc((size_t)n)); // halo ids are only needed to number them; the list itself is not kept
+    int64_t n_halo = 0;
+    for (int q = 0; q < world; ++q) {
+        if (q == rank) continue;
+        hipLaunchKernelGGL(k_plan_flag_halo, dim3(grid256(n)), dim3(256), 0, st, n, is_halo.p, owner.p, q, flag.p);
+        AVS_TRY(scan_flags(flag.p, pos.p, n, scan_tmp, &recv_cnt[(size_t)q], st));
+        if (recv_cnt[(size_t)q])
+            hipLaunchKernelGGL(k_plan_scatter, dim3(grid256(n)), dim3(256), 0, st, n, flag.p, pos.p, (const int32_t *)nullptr,
+                               halo_tmp.p, g2l.p, (int32_t)(n_own + n_halo));
+        n_halo += recv_cnt[(size_t)q];
+    }
+    int64_t n_send = 0;
+    for (int q = 0; q < world; ++q) { // first pass: counts, so that send_idx can be allocated once
+        if (q == rank) continue;
+        hipLaunchKernelGGL(k_plan_flag_send, dim3(grid256(n)), dim3(256), 0, st, n, owner.p, rank, needed_by.p, q, flag.p);
+        AVS_TRY(scan_flags(flag.p, pos.p, n, scan_tmp, &send_cnt[(size_t)q], st));
+        n_send += send_cnt[(size_t)q];
+    }
+    AVS_TRY(d->send_idx.alloc((size_t)n_send));
+    AVS_TRY(d->sendbuf.alloc((size_t)n_send));
+    {
+        int64_t off = 0;
+        for (int q = 0; q < world; ++q) {
+            if (q == rank || !send_cnt[(size_t)q]) continue;
+            hipLaunchKernelGGL(k_plan_flag_send, dim3(grid256(n)), dim3(256), 0, st, n, owner.p, rank, needed_by.p, q, flag.p);
+            AVS_TRY(exclusive_scan_i32(flag.p, pos.p, n, scan_tmp.p, scan_tmp.n, st));
+            hipLaunchKernelGGL(k_plan_scatter, dim3(grid256(n)), dim3(256), 0, st, n, flag.p, pos.p, (const int32_t *)g2l.p,
+                               d->send_idx.p + off, (int32_t *)nullptr, 0);
+            off += send_cnt[(size_t)q];
+        }
+    }
+    d->peers.clear();
+    d->send_counts.clear();
+    d->recv_counts.clear();
+    for (int q = 0; q < world; ++q)
+        if (q != rank && (send_cnt[(size_t)q] || recv_cnt[(size_t)q])) {
+            d->peers.push_back(q);
+            d->send_counts.push_back((int32_t)send_cnt[(size_t)q]);
+            d->recv_counts.push_back((int32_t)recv_cnt[(size_t)q]);
+        }
+
+    // 5. local CSR
+    AVS_TRY(d->row_ptr.alloc((size_t)n_own + 1));
+    hipLaunchKernelGGL(k_plan_local_len, dim3(grid256(n_own + 1)), dim3(256), 0, st, n_own, d->own_global.p, g_rp, flag.p);
+    AVS_TRY(exclusive_scan_i32(flag.p, d->row_ptr.p, n_own + 1, scan_tmp.p, scan_tmp.n, st));
+    int32_t nnz_local = 0;
+    AVS_HIP(hipMemcpyAsync(&nnz_local, d->row_ptr.p + n_own, 4, hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipStreamSynchronize(st));
+    AVS_TRY(d->col.alloc((size_t)nnz_local));
+    AVS_TRY(d->val.alloc((size_t)nnz_local));
+    if (vi) AVS_TRY(d->codes.alloc((size_t)nnz_local));
+    const int T = spmv_tile_rows();
+    const int64_t ntiles = (n_own + T - 1) / T;
+    DevBuf<int32_t> tile_bnd, tile_int, tile_pos;
+    AVS_TRY(tile_bnd.alloc((size_t)ntiles + 1));
+    AVS_TRY(tile_int.alloc((size_t)ntiles + 1));
+    AVS_TRY(tile_pos.alloc((size_t)ntiles + 1));
+    AVS_HIP(hipMemsetAsync(tile_bnd.p, 0, ((size_t)ntiles + 1) * 4, st));
+    if (n_own)
+        hipLaunchKernelGGL(k_plan_local_rows, dim3(8192), dim3(256), 0, st, n_own, d->own_global.p, g_rp, g_col, g_val,
+                           vi ? c->v_codes.p : (const uint16_t *)nullptr, g2l.p, d->row_ptr.p, d->col.p, d->val.p,
+                           vi ? d->codes.p : (uint16_t *)nullptr, T, tile_bnd.p);
+
+    // 6. tile lists for the overlap of the exchange with the interior rows
+    int64_t n_bnd = 0, n_int = 0;
+    AVS_TRY(scan_flags(tile_bnd.p, tile_pos.p, ntiles, scan_tmp, &n_bnd, st));
+    AVS_TRY(d->tiles_bnd.alloc((size_t)n_bnd));
+    if (n_bnd)
+        hipLaunchKernelGGL(k_plan_scatter, dim3(grid256(ntiles)), dim3(256), 0, st, ntiles, tile_bnd.p, tile_pos.p, (const int32_t *)nullptr,
+                           d->tiles_bnd.p, (int32_t *)nullptr, 0);
+    if (ntiles) hipLaunchKernelGGL(k_plan_not, dim3(grid256(ntiles)), dim3(256), 0, st, ntiles, tile_bnd.p, tile_int.p);
+    AVS_TRY(scan_flags(tile_int.p, tile_pos.p, ntiles, scan_tmp, &n_int, st));
+    AVS_TRY(d->tiles_int.alloc((size_t)n_int));
+    if (n_int)
+        hipLaunchKernelGGL(k_plan_scatter, dim3(grid256(ntiles)), dim3(256), 0, st, ntiles, tile_int.p, tile_pos.p, (const int32_t *)nullptr,
+                           d->tiles_int.p, (int32_t *)nullptr, 0);
+    AVS_HIP(hipGetLastError());
+    AVS_HIP(hipStreamSynchronize(st)); // temporaries die here
+    d->n_tiles_int = (int)n_int;
+    d->n_tiles_bnd = (int)n_bnd;
+    d->n_own = n_own;
+    d->n_halo = n_halo;
+    d->n_send = n_send;
+    d->nnz_local = nnz_local;
+    return AVS_OK;
+}
+
+
+// the host planner (avs_partition.cpp) on a downloaded copy of the pattern: reference for the device planner
+static avs_status plan_on_host(avs_ctx *c, PcgDist *d, int cut_axis, int extent, bool ro)
+{
+    hipStream_t st = c->stream;
+    const int64_t n = c->n_vel, nnz = c->nnz;
+    const int32_t *g_rp = ro ? c->p_row_ptr.p : c->row_ptr.p, *g_col = ro ? c->p_col.p : c->col.p;
+    const double *g_val = ro ? c->p_val.p : c->val.p;
+    std::vector<int32_t> h_rp((size_t)n + 1), h_col((size_t)nnz), h_tab((size_t)n * 4), h_owner((size_t)n);
+    AVS_HIP(hipMemcpyAsync(h_rp.data(), g_rp, h_rp.size() * 4, hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipMemcpyAsync(h_col.data(), g_col, h_col.size() * 4, hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipMemcpyAsync(h_tab.data(), c->vdof.p, h_tab.size() * 4, hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipStreamSynchronize(st));
+    if (ro) { // dof table in the new numbering
+        std::vector<int32_t> h_perm((size_t)n), t2((size_t)n * 4);
+        AVS_HIP(hipMemcpy(h_perm.data(), c->perm.p, h_perm.size() * 4, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; ++i) memcpy(&t2[(size_t)i * 4], &h_tab[(size_t)h_perm[(size_t)i] * 4], 16);
+        h_tab.swap(t2);
+    }
+    AVS_TRY(avs_plan_owners(n, h_tab.data(), h_rp.data(), c->desc.levels, cut_axis, extent, d->world, h_owner.data()));
+    avs_plan *plan = nullptr;
+    AVS_TRY(avs_plan_create(n, h_rp.data(), h_col.data(), h_owner.data(), d->rank, d->world, &plan));
+    avs_plan_sizes sz{};
+    avs_plan_get_sizes(plan, &sz);
+    std::vector<int32_t> own((size_t)sz.n_own), rpl((size_t)sz.n_own + 1), cl((size_t)sz.nnz_local), vs((size_t)sz.nnz_local),
+        peers((size_t)sz.n_peers), sc((size_t)sz.n_peers), rc((size_t)sz.n_peers), sidx((size_t)sz.n_send);
+    avs_plan_get_arrays(plan, own.data(), nullptr, rpl.data(), cl.data(), vs.data(), peers.data(), sc.data(), rc.data(), sidx.data());
+    avs_plan_destroy(plan);
+    d->n_own = sz.n_own;
+    d->n_halo = sz.n_halo;
+    d->n_send = sz.n_send;
+    d->nnz_local = sz.nnz_local;
+    d->peers = peers;
+    d->send_counts = sc;
+    d->recv_counts = rc;
+    AVS_TRY(d->own_global.alloc((size_t)sz.n_own));
+    AVS_TRY(d->send_idx.alloc((size_t)sz.n_send));
+    AVS_TRY(d->sendbuf.alloc((size_t)sz.n_send));
+    AVS_TRY(d->row_ptr.alloc((size_t)sz.n_own + 1));
+    AVS_TRY(d->col.alloc((size_t)sz.nnz_local));
+    AVS_TRY(d->val.alloc((size_t)sz.nnz_local));
+    DevBuf<int32_t> d_vs;
+    AVS_TRY(d_vs.alloc((size_t)sz.nnz_local));
+    AVS_HIP(hipMemcpyAsync(d->own_global.p, own.data(), own.size() * 4, hipMemcpyHostToDevice, st));
+    if (sz.n_send) AVS_HIP(hipMemcpyAsync(d->send_idx.p, sidx.data(), sidx.size() * 4, hipMemcpyHostToDevice, st));
+    AVS_HIP(hipMemcpyAsync(d->row_ptr.p, rpl.data(), rpl.size() * 4, hipMemcpyHostToDevice, st));
+    if (sz.nnz_local) {
+        AVS_HIP(hipMemcpyAsync(d->col.p, cl.data(), cl.size() * 4, hipMemcpyHostToDevice, st));
+        AVS_HIP(hipMemcpyAsync(d_vs.p, vs.data(), vs.size() * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_gather_i<double>, dim3(grid256(sz.nnz_local)), dim3(256), 0, st, g_val, d_vs.p, d->val.p, sz.nnz_local);
+        if (ro && c->v_table_size > 0) {
+            AVS_TRY(d->codes.alloc((size_t)sz.nnz_local));
+            hipLaunchKernelGGL(k_gather_i<uint16_t>, dim3(grid256(sz.nnz_local)), dim3(256), 0, st, c->v_codes.p, d_vs.p, d->codes.p,
+                               sz.nnz_local);
+        }
+    }
+    AVS_HIP(hipGetLastError());
+    AVS_HIP(hipStreamSynchronize(st));
+    // tiles of the local SpMV that read no halo column can run while the halo is in flight
+    const int T = spmv_tile_rows();
+    const int64_t ntiles = (sz.n_own + T - 1) / T;
+    std::vector<int32_t> ti, tb;
+    for (int64_t t = 0; t < ntiles; ++t) {
+        const int64_t r0 = t * T, r1 = std::min<int64_t>(r0 + T, sz.n_own);
+        bool touches = false;
+        for (int32_t k = rpl[(size_t)r0]; k < rpl[(size_t)r1] && !touches; ++k) touches = cl[(size_t)k] >= sz.n_own;
+        (touches ? tb : ti).push_back((int32_t)t);
+    }
+    d->n_tiles_int = (int)ti.size();
+    d->n_tiles_bnd = (int)tb.size();
+    AVS_TRY(d->tiles_int.alloc(ti.size()));
+    AVS_TRY(d->tiles_bnd.alloc(tb.size()));
+    if (!ti.empty()) AVS_HIP(hipMemcpy(d->tiles_int.p, ti.data(), ti.size() * 4, hipMemcpyHostToDevice));
+    if (!tb.empty()) AVS_HIP(hipMemcpy(d->tiles_bnd.p, tb.data(), tb.size() * 4, hipMemcpyHostToDevice));
+    return AVS_OK;
+}
+
 } // namespace avs
 
 using namespace avs;
@@ -312,7 +694,7 @@ avs_status avs_dist_partition(avs_ctx *c, int32_t cut_axis)
     AVS_HIP(hipSetDevice(c->desc.device));
     PcgDist *d = c->dist;
     hipStream_t st = c->stream;
-    const int64_t n = c->n_vel, nnz = c->nnz;
+    const int64_t n = c->n_vel;
     if (cut_axis < 0) { // longest axis
         cut_axis = 0;
         if (c->desc.ny > c->desc.nx) cut_axis = 1;
@@ -321,82 +703,41 @@ avs_status avs_dist_partition(avs_ctx *c, int32_t cut_axis)
     AVS_REQUIRE(cut_axis <= 2, AVS_EINVAL, "cut_axis out of range");
     const int extent = cut_axis == 0 ? c->desc.nx : (cut_axis == 1 ? c->desc.ny : c->desc.nz);
 
-    // pattern + dof table to the host, plan there (pure integer work, avs_partition.cpp)
     // the solve works on the brick-major numbering when it exists (avs_reorder.hip): partition THAT system,
     // so every rank's local rows keep the brick locality; results are mapped back in avs_dist_get_solution
     const bool ro = c->reordered;
-    const int32_t *g_rp = ro ? c->p_row_ptr.p : c->row_ptr.p, *g_col = ro ? c->p_col.p : c->col.p;
-    const double *g_val = ro ? c->p_val.p : c->val.p, *g_rhs = ro ? c->p_rhs.p : c->rhs.p, *g_x0 = ro ? c->p_x0.p : c->x0.p;
-    std::vector<int32_t> h_rp((size_t)n + 1), h_col((size_t)nnz), h_tab((size_t)n * 4), h_owner((size_t)n);
-    AVS_HIP(hipMemcpyAsync(h_rp.data(), g_rp, h_rp.size() * 4, hipMemcpyDeviceToHost, st));
-    AVS_HIP(hipMemcpyAsync(h_col.data(), g_col, h_col.size() * 4, hipMemcpyDeviceToHost, st));
-    AVS_HIP(hipMemcpyAsync(h_tab.data(), c->vdof.p, h_tab.size() * 4, hipMemcpyDeviceToHost, st));
-    AVS_HIP(hipStreamSynchronize(st));
-    if (ro) { // dof table in the new numbering
-        std::vector<int32_t> h_perm((size_t)n), t2((size_t)n * 4);
-        AVS_HIP(hipMemcpy(h_perm.data(), c->perm.p, h_perm.size() * 4, hipMemcpyDeviceToHost));
-        for (int64_t i = 0; i < n; ++i) memcpy(&t2[(size_t)i * 4], &h_tab[(size_t)h_perm[(size_t)i] * 4], 16);
-        h_tab.swap(t2);
-    }
-    AVS_TRY(avs_plan_owners(n, h_tab.data(), h_rp.data(), c->desc.levels, cut_axis, extent, d->world, h_owner.data()));
-    avs_plan *plan = nullptr;
-    AVS_TRY(avs_plan_create(n, h_rp.data(), h_col.data(), h_owner.data(), d->rank, d->world, &plan));
-    avs_plan_sizes sz{};
-    avs_plan_get_sizes(plan, &sz);
-    std::vector<int32_t> own((size_t)sz.n_own), rpl((size_t)sz.n_own + 1), cl((size_t)sz.nnz_local), vs((size_t)sz.nnz_local),
-        peers((size_t)sz.n_peers), sc((size_t)sz.n_peers), rc((size_t)sz.n_peers), sidx((size_t)sz.n_send);
-    avs_plan_get_arrays(plan, own.data(), nullptr, rpl.data(), cl.data(), vs.data(), peers.data(), sc.data(), rc.data(), sidx.data());
-    avs_plan_destroy(plan);
-
-    d->n_global = n;
-    d->n_own = sz.n_own;
-    d->n_halo = sz.n_halo;
-    d->n_send = sz.n_send;
-    d->nnz_local = sz.nnz_local;
-    d->peers = peers;
-    d->send_counts = sc;
-    d->recv_counts = rc;
-    d->send_offs.assign(peers.size(), 0);
-    d->recv_offs.assign(peers.size(), 0);
-    {
-        int32_t so = 0, ro = 0;
-        for (size_t i = 0; i < peers.size(); ++i) {
-            d->send_offs[i] = so;
-            d->recv_offs[i] = ro;
-            so += sc[i];
-            ro += rc[i];
-        }
-    }
-    // upload the local system
-    AVS_TRY(d->own_global.alloc((size_t)sz.n_own));
-    AVS_TRY(d->send_idx.alloc((size_t)sz.n_send));
-    AVS_TRY(d->sendbuf.alloc((size_t)sz.n_send));
-    AVS_TRY(d->row_ptr.alloc((size_t)sz.n_own + 1));
-    AVS_TRY(d->col.alloc((size_t)sz.nnz_local));
-    AVS_TRY(d->val.alloc((size_t)sz.nnz_local));
-    AVS_TRY(d->rhs.alloc((size_t)sz.n_own));
-    AVS_TRY(d->x0.alloc((size_t)sz.n_own));
-    AVS_TRY(d->x.alloc((size_t)sz.n_own));
-    DevBuf<int32_t> d_vs;
-    AVS_TRY(d_vs.alloc((size_t)sz.nnz_local));
-    AVS_HIP(hipMemcpyAsync(d->own_global.p, own.data(), own.size() * 4, hipMemcpyHostToDevice, st));
-    if (sz.n_send) AVS_HIP(hipMemcpyAsync(d->send_idx.p, sidx.data(), sidx.size() * 4, hipMemcpyHostToDevice, st));
-    AVS_HIP(hipMemcpyAsync(d->row_ptr.p, rpl.data(), rpl.size() * 4, hipMemcpyHostToDevice, st));
-    if (sz.nnz_local) {
-        AVS_HIP(hipMemcpyAsync(d->col.p, cl.data(), cl.size() * 4, hipMemcpyHostToDevice, st));
-        AVS_HIP(hipMemcpyAsync(d_vs.p, vs.data(), vs.size() * 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_gather_i<double>, dim3((unsigned)((sz.nnz_local + 255) / 256)), dim3(256), 0, st, g_val, d_vs.p, d->val.p, sz.nnz_local);
-    }
+    const double *g_rhs = ro ? c->p_rhs.p : c->rhs.p, *g_x0 = ro ? c->p_x0.p : c->x0.p;
+    const char *mode = getenv("AVS_DIST_PLAN");
+    const bool host_plan = mode && strcmp(mode, "host") == 0;
     d->value_indexed = false;
     d->col_bits = 0;
+    if (host_plan) AVS_TRY(plan_on_host(c, d, cut_axis, extent, ro));
+    else AVS_TRY(plan_on_device(c, d, cut_axis, extent, ro));
+    avs_plan_sizes sz{};
+    sz.n_own = d->n_own;
+    sz.n_halo = d->n_halo;
+    sz.nnz_local = d->nnz_local;
+    sz.n_send = d->n_send;
+    d->n_global = n;
+    d->send_offs.assign(d->peers.size(), 0);
+    d->recv_offs.assign(d->peers.size(), 0);
+    {
+        int32_t so = 0, ro2 = 0;
+        for (size_t i = 0; i < d->peers.size(); ++i) {
+            d->send_offs[i] = so;
+            d->recv_offs[i] = ro2;
+            so += d->send_counts[i];
+            ro2 += d->recv_counts[i];
+        }
+    }
     if (ro && c->v_table_size > 0 && sz.nnz_local) { // local values are a subset of the global ones: same table, gathered codes
-        AVS_TRY(d->codes.alloc((size_t)sz.nnz_local));
-        hipLaunchKernelGGL(k_gather_i<uint16_t>, dim3((unsigned)((sz.nnz_local + 255) / 256)), dim3(256), 0, st, c->v_codes.p, d_vs.p,
-                           d->codes.p, sz.nnz_local);
         AVS_TRY(build_packed_index(d->codes.p, d->col.p, sz.nnz_local, (int64_t)sz.n_own + sz.n_halo, c->v_table_size, d->packed,
                                    &d->col_bits, st));
         d->value_indexed = true;
     }
+    AVS_TRY(d->rhs.alloc((size_t)sz.n_own));
+    AVS_TRY(d->x0.alloc((size_t)sz.n_own));
+    AVS_TRY(d->x.alloc((size_t)sz.n_own));
     if (sz.n_own) {
         const unsigned g = (unsigned)((sz.n_own + 255) / 256);
         hipLaunchKernelGGL(k_gather_i<double>, dim3(g), dim3(256), 0, st, g_rhs, d->own_global.p, d->rhs.p, sz.n_own);
@@ -404,28 +745,10 @@ avs_status avs_dist_partition(avs_ctx *c, int32_t cut_axis)
     }
     AVS_HIP(hipGetLastError());
     AVS_HIP(hipStreamSynchronize(st));
-    // tiles of the local SpMV that read no halo column can run while the halo is in flight
-    {
-        const int T = spmv_tile_rows();
-        const int64_t ntiles = (sz.n_own + T - 1) / T;
-        std::vector<int32_t> ti, tb;
-        for (int64_t t = 0; t < ntiles; ++t) {
-            const int64_t r0 = t * T, r1 = std::min<int64_t>(r0 + T, sz.n_own);
-            bool touches = false;
-            for (int32_t k = rpl[(size_t)r0]; k < rpl[(size_t)r1] && !touches; ++k) touches = cl[(size_t)k] >= sz.n_own;
-            (touches ? tb : ti).push_back((int32_t)t);
-        }
-        d->n_tiles_int = (int)ti.size();
-        d->n_tiles_bnd = (int)tb.size();
-        AVS_TRY(d->tiles_int.alloc(ti.size()));
-        AVS_TRY(d->tiles_bnd.alloc(tb.size()));
-        if (!ti.empty()) AVS_HIP(hipMemcpy(d->tiles_int.p, ti.data(), ti.size() * 4, hipMemcpyHostToDevice));
-        if (!tb.empty()) AVS_HIP(hipMemcpy(d->tiles_bnd.p, tb.data(), tb.size() * 4, hipMemcpyHostToDevice));
-        if (!d->comm_stream) {
-            AVS_HIP(hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking));
-            AVS_HIP(hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming));
-            AVS_HIP(hipEventCreateWithFlags(&d->ev_halo, hipEventDisableTiming));
-        }
+    if (!d->comm_stream) {
+        AVS_HIP(hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking));
+        AVS_HIP(hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming));
+        AVS_HIP(hipEventCreateWithFlags(&d->ev_halo, hipEventDisableTiming));
     }
     pcg_destroy(d->pcg);
     d->pcg = nullptr;
@@ -445,6 +768,33 @@ avs_status avs_dist_get_plan_sizes(avs_ctx *c, avs_plan_sizes *s)
     s->nnz_local = c->dist->nnz_local;
     s->n_send = c->dist->n_send;
     s->n_peers = (int32_t)c->dist->peers.size();
+    return AVS_OK;
+}
+
+avs_status avs_dist_get_plan_arrays(avs_ctx *c, int32_t *own_global, int32_t *row_ptr_local, int32_t *col_local, int32_t *send_idx,
+                                    int32_t *peers, int32_t *send_counts, int32_t *recv_counts, int32_t *tiles_interior,
+                                    int32_t *tiles_boundary)
+{
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->dist && c->dist->partitioned, AVS_ESTATE, "call avs_dist_partition first");
+    PcgDist *d = c->dist;
+    AVS_HIP(hipSetDevice(c->desc.device));
+    auto down = [&](int32_t *dst, const int32_t *src, size_t count) -> avs_status {
+        if (dst && count) AVS_HIP(hipMemcpy(dst, src, count * sizeof(int32_t), hipMemcpyDeviceToHost));
+        return AVS_OK;
+    };
+    AVS_HIP(hipStreamSynchronize(c->stream));
+    AVS_TRY(down(own_global, d->own_global.p, (size_t)d->n_own));
+    AVS_TRY(down(row_ptr_local, d->row_ptr.p, (size_t)d->n_own + 1));
+    AVS_TRY(down(col_local, d->col.p, (size_t)d->nnz_local));
+    AVS_TRY(down(send_idx, d->send_idx.p, (size_t)d->n_send));
+    AVS_TRY(down(tiles_interior, d->tiles_int.p, (size_t)d->n_tiles_int));
+    AVS_TRY(down(tiles_boundary, d->tiles_bnd.p, (size_t)d->n_tiles_bnd));
+    for (size_t i = 0; i < d->peers.size(); ++i) {
+        if (peers) peers[i] = d->peers[i];
+        if (send_counts) send_counts[i] = d->send_counts[i];
+        if (recv_counts) recv_counts[i] = d->recv_counts[i];
+    }
     return AVS_OK;
 }
 

@@ -157,6 +157,7 @@ avs_status stream_probe(int mode, const double *a, double *b, int64_t n, double 
 avs_status exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t *block_tmp, size_t block_tmp_elems,
                               hipStream_t stream);
 size_t scan_tmp_elems(int64_t n);
+void plane_owners_from_weights(const int64_t *weight, int nplanes, int world_size, int *plane_owner); // avs_partition.cpp
 
 // multi-GPU hooks called from pcg_solve (implemented in avs_dist.hip)
 avs_status dist_halo_exchange(PcgDist *d, double *p_ext, hipStream_t stream);

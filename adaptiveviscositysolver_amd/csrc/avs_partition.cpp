@@ -19,7 +19,27 @@
 
 namespace avs {
 void set_error(const char *fmt, ...);
+
+// greedy prefix cuts over the planes' weights: rank r owns a contiguous run of planes.  Shared by the host planner
+// below and the device planner (avs_dist.hip), so both cut the domain at the same places.
+void plane_owners_from_weights(const int64_t *weight, int nplanes, int world_size, int *plane_owner)
+{
+    int64_t total = 0;
+    for (int p = 0; p < nplanes; ++p) total += weight[p];
+    int64_t acc = 0;
+    int r = 0;
+    for (int p = 0; p < nplanes; ++p) {
+        // move to the next rank once this rank's share is reached, keeping at least one plane for
+        // every remaining rank when there are enough planes
+        const int64_t target = (total * (r + 1)) / world_size;
+        const int planes_left = nplanes - p;
+        const int ranks_left = world_size - r;
+        if (r < world_size - 1 && ((acc >= target && acc > 0) || planes_left < ranks_left)) ++r;
+        plane_owner[p] = r;
+        acc += weight[p];
+    }
 }
+} // namespace avs
 
 struct avs_plan {
     int32_t rank = 0, world = 1;
@@ -52,24 +72,8 @@ avs_status avs_plan_owners(int64_t n, const int32_t *dof_table, const int32_t *r
     };
     std::vector<int64_t> weight((size_t)nplanes, 0); // rows weighted by their nnz (SpMV cost)
     for (int64_t d = 0; d < n; ++d) weight[(size_t)plane_of(d)] += (int64_t)(row_ptr[d + 1] - row_ptr[d]) + 2;
-    int64_t total = 0;
-    for (int64_t w : weight) total += w;
-    // greedy prefix cuts: rank r owns planes [cut[r], cut[r+1])
     std::vector<int> plane_owner((size_t)nplanes, 0);
-    int64_t acc = 0;
-    int r = 0;
-    for (int p = 0; p < nplanes; ++p) {
-        // move to the next rank once this rank's share is reached, keeping at least one plane for
-        // every remaining rank when there are enough planes
-        const int64_t target = (total * (r + 1)) / world_size;
-        const int planes_left = nplanes - p;
-        const int ranks_left = world_size - r;
-        if (r < world_size - 1 && ((acc >= target && acc > 0) || planes_left < ranks_left)) {
-            ++r;
-        }
-        plane_owner[(size_t)p] = r;
-        acc += weight[(size_t)p];
-    }
+    avs::plane_owners_from_weights(weight.data(), nplanes, world_size, plane_owner.data());
     for (int64_t d = 0; d < n; ++d) owner_out[d] = plane_owner[(size_t)plane_of(d)];
     return AVS_OK;
 }

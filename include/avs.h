@@ -292,11 +292,19 @@ void avs_local_group_destroy(avs_local_group *group);
 avs_status avs_dist_init_local(avs_ctx *ctx, avs_local_group *group, int32_t rank);
 
 /* Every rank calls it after avs_assemble on an identical (replicated) pyramid: keeps its slab of
- * the system (cut along `cut_axis`, -1 = longest axis) and builds halo / send lists. */
+ * the system (cut along `cut_axis`, -1 = longest axis) and builds halo / send lists.  The plan is built on the
+ * device from the CSR in HBM; AVS_DIST_PLAN=host runs the host planner above on a downloaded copy instead
+ * (identical arrays, kept as the reference for tests). */
 avs_status avs_dist_partition(avs_ctx *ctx, int32_t cut_axis);
 avs_status avs_dist_get_plan_sizes(avs_ctx *ctx, avs_plan_sizes *sizes);
-/* number of 512-row SpMV tiles that read no halo column (they run while the halo is in flight) / that do */
+/* number of 256-row SpMV tiles that read no halo column (they run while the halo is in flight) / that do */
 avs_status avs_dist_get_overlap_tiles(avs_ctx *ctx, int32_t *interior, int32_t *boundary);
+/* the plan's arrays, copied to host memory (parity tests; sizes from avs_dist_get_plan_sizes / _overlap_tiles;
+ * any pointer may be NULL): own_global[n_own], row_ptr_local[n_own+1], col_local[nnz_local], send_idx[n_send],
+ * peers / send_counts / recv_counts[n_peers], tiles_interior[], tiles_boundary[] */
+avs_status avs_dist_get_plan_arrays(avs_ctx *ctx, int32_t *own_global, int32_t *row_ptr_local, int32_t *col_local,
+                                    int32_t *send_idx, int32_t *peers, int32_t *send_counts, int32_t *recv_counts,
+                                    int32_t *tiles_interior, int32_t *tiles_boundary);
 avs_status avs_dist_solve(avs_ctx *ctx, double tolerance, int32_t max_iterations, avs_solve_info *info);
 /* gathers the full solution (global DOF order) on every rank */
 avs_status avs_dist_get_solution(avs_ctx *ctx, double *x, int64_t n, avs_memspace where);

@@ -96,3 +96,42 @@ def test_rccl_world_size_one(built_lib):
     info = s.dist_solve(1e-10, 5000)
     assert abs(info.iterations - ref.iterations) <= 1
     assert rel_l2(s.dist_solution(), xref) < 1e-8
+
+
+def _plan_arrays(s):
+    lib = s.lib
+    sz = s.plan_sizes
+    ti, tb = s.overlap_tiles
+    arr = lambda n: np.empty(int(n), np.int32)
+    own, rpl, cl, sidx = arr(sz.n_own), arr(sz.n_own + 1), arr(sz.nnz_local), arr(sz.n_send)
+    peers, sc_, rc = arr(sz.n_peers), arr(sz.n_peers), arr(sz.n_peers)
+    tint, tbnd = arr(ti), arr(tb)
+    capi.check(lib.avs_dist_get_plan_arrays(s.h, *[a.ctypes.data for a in (own, rpl, cl, sidx, peers, sc_, rc, tint, tbnd)]))
+    return dict(own=own, row_ptr=rpl, col=cl, send_idx=sidx, peers=peers, send_counts=sc_, recv_counts=rc,
+                tiles_int=tint, tiles_bnd=tbnd, sizes=(sz.n_own, sz.n_halo, sz.nnz_local, sz.n_send, sz.n_peers))
+
+
+@pytest.mark.parametrize("world,cut_axis,scene", [(2, -1, "beam"), (4, 0, "beam"), (3, 2, "sphere"), (8, 0, "beam")])
+def test_device_planner_equals_host_planner(world, cut_axis, scene, built_lib, monkeypatch):
+    """avs_dist_partition builds the plan on the device; AVS_DIST_PLAN=host runs avs_partition.cpp on a downloaded
+    copy of the pattern.  Every array of every rank must be identical (integer work: bit-exact)."""
+    dev = torch.device("cuda:0")
+    sc = scenes.fat_beam(64, 3, device=dev) if scene == "beam" else scenes.sphere(64, 4, device=dev)
+    pyr = prepass.build_pyramid(sc)
+    s = make_solver(sc, pyr)
+    lib = capi.load()
+    for r in range(world):
+        plans = []
+        for mode in ("device", "host"):
+            monkeypatch.setenv("AVS_DIST_PLAN", mode)
+            grp = C.c_void_p()
+            capi.check(lib.avs_local_group_create(world, C.byref(grp)))
+            s.dist_init_local(grp, r)          # planning needs no peer: each rank plans from the replicated system
+            s.dist_partition(cut_axis)
+            plans.append(_plan_arrays(s))
+            lib.avs_local_group_destroy(grp)
+        dev_plan, host_plan = plans
+        assert dev_plan["sizes"] == host_plan["sizes"], (r, dev_plan["sizes"], host_plan["sizes"])
+        for k in ("own", "row_ptr", "col", "send_idx", "peers", "send_counts", "recv_counts", "tiles_int", "tiles_bnd"):
+            assert np.array_equal(dev_plan[k], host_plan[k]), (r, k)
+    s.close()
