@@ -65,15 +65,26 @@ __global__ __launch_bounds__(kWB *kWB *kWB) void k_sdf_weights(const float *__re
     const int b = blockIdx.x;
     const int o0[3] = {(b % bx) * kWB, ((b / bx) % by) * kWB, (b / (bx * by)) * kWB};
     // window cell (wx, wy, wz) holds sdf at clamp(o0 - 2 + w): clamping here reproduces the clamped reads below
+    int seen_neg = 0, seen_pos = 0;
     for (int w = threadIdx.x; w < kWH * kWH * kWH; w += kWB * kWB * kWB) {
         const int wx = w % kWH, wy = (w / kWH) % kWH, wz = w / (kWH * kWH);
-        win[w] = sdf[lin3(src, clampi(o0[0] - 2 + wx, 0, src.r[0] - 1), clampi(o0[1] - 2 + wy, 0, src.r[1] - 1),
-                          clampi(o0[2] - 2 + wz, 0, src.r[2] - 1))];
+        const float v = sdf[lin3(src, clampi(o0[0] - 2 + wx, 0, src.r[0] - 1), clampi(o0[1] - 2 + wy, 0, src.r[1] - 1),
+                                 clampi(o0[2] - 2 + wz, 0, src.r[2] - 1))];
+        win[w] = v;
+        if (v < 0.f) seen_neg = 1;
+        else seen_pos = 1;
     }
-    __syncthreads();
+    // brick-level form of the exact sign shortcut below: a window of one sign gives every sample of the brick n^3 / 0
+    // (away from the surface that is almost every brick, and it saves the per-sample 4^3 scan of the window)
+    const int any_neg = __syncthreads_or(seen_neg);
+    const int any_pos = __syncthreads_or(seen_pos);
     const int t = threadIdx.x;
     const int p[3] = {o0[0] + t % kWB, o0[1] + (t / kWB) % kWB, o0[2] + t / (kWB * kWB)};
     if (p[0] >= tgt.r[0] || p[1] >= tgt.r[1] || p[2] >= tgt.r[2]) return;
+    if (!any_pos || !any_neg) {
+        out[lin3(tgt, p[0], p[1], p[2])] = (float)(any_neg ? n * n * n : 0) / n3;
+        return;
+    }
     // window index of source cell c along axis a: clamp first (as the reference read does), then shift
     auto wi = [&](int a, int c) { return clampi(c, 0, src.r[a] - 1) - (o0[a] - 2); };
     // NB: clamp(c) lies inside the window because c in [o0-2, o0+kWB] and the window itself was filled with
@@ -435,27 +446,76 @@ __device__ __forceinline__ size_t tilemajor_pos(const Grid3 &g, int i, int j, in
            ((size_t)lz * ey + ly) * ex + lx;
 }
 
-__global__ __launch_bounds__(kBlock) void k_flags_tilemajor(const int32_t *__restrict__ grid, Grid3 g, int32_t *__restrict__ flags)
+// The sweep visits tiles x-fastest and voxels x-fastest inside a tile, so the id of a flagged voxel is
+//   base + (flagged voxels in earlier tiles) + (flagged voxels earlier in its own tile).
+// One 256-thread workgroup per tile; in step z = 0..15 thread t reads voxel (lx, ly, lz) = (t & 15, t >> 4, z) of the tile:
+// 16 coalesced 64-B rows per step, and (step, thread) order == sweep order inside the tile.  k_tile_counts -> exclusive
+// scan over the tiles -> k_tile_ids: the grid is read twice and written where flagged (12 B per voxel instead of the
+// 28 B of flag array + full-lattice scan + apply).
+__device__ __forceinline__ unsigned tile_flags(const int32_t *__restrict__ grid, const Grid3 &g, int ntx, int nty, size_t *first,
+                                               size_t *zstride)
 {
-    const size_t total = g.vol();
-    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
-        const int i = (int)(o % g.r[0]);
-        const size_t q = o / g.r[0];
-        flags[tilemajor_pos(g, i, (int)(q % g.r[1]), (int)(q / g.r[1]))] = (grid[o] == 0) ? 1 : 0;
+    const int tile = blockIdx.x, t = threadIdx.x;
+    const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
+    const int i = tx * kTile + (t & (kTile - 1)), j = ty * kTile + (t >> 4);
+    *zstride = (size_t)g.r[0] * g.r[1];
+    *first = lin3(g, i, j, tz * kTile);
+    unsigned bits = 0u; // bit z: voxel (i, j, tz*16 + z) is a DOF
+    if (i < g.r[0] && j < g.r[1]) {
+        const int ez = min(kTile, g.r[2] - kTile * tz);
+        int32_t v[kTile];
+#pragma unroll
+        for (int z = 0; z < kTile; ++z) v[z] = z < ez ? grid[*first + (size_t)z * *zstride] : -1;
+#pragma unroll
+        for (int z = 0; z < kTile; ++z) bits |= (v[z] == 0 ? 1u : 0u) << z;
     }
+    return bits;
 }
 
-__global__ __launch_bounds__(kBlock) void k_apply_ids(int32_t *__restrict__ grid, Grid3 g, const int32_t *__restrict__ ids,
-                                                      const long long *__restrict__ base)
+__global__ __launch_bounds__(kBlock) void k_tile_counts(const int32_t *__restrict__ grid, Grid3 g, int ntx, int nty,
+                                                        int32_t *__restrict__ tile_count)
 {
-    const size_t total = g.vol();
-    const int32_t b = (int32_t)*base;
-    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
-        if (grid[o] != 0) continue;
-        const int i = (int)(o % g.r[0]);
-        const size_t q = o / g.r[0];
-        grid[o] = b + ids[tilemajor_pos(g, i, (int)(q % g.r[1]), (int)(q / g.r[1]))];
+    __shared__ int red[kBlock / 64];
+    size_t first, zs;
+    int cnt = __popc(tile_flags(grid, g, ntx, nty, &first, &zs));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_count[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(kBlock) void k_tile_ids(int32_t *__restrict__ grid, Grid3 g, int ntx, int nty,
+                                                     const int32_t *__restrict__ tile_off, const long long *__restrict__ base)
+{
+    __shared__ int cnt[kTile * (kBlock / 64)]; // flagged voxels of (step z, wave w), then their exclusive prefix
+    size_t first, zs;
+    const unsigned bits = tile_flags(grid, g, ntx, nty, &first, &zs);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long below[kTile]; // ballot of step z restricted to the lanes below this one
+#pragma unroll
+    for (int z = 0; z < kTile; ++z) {
+        const unsigned long long m = __ballot((bits >> z) & 1u);
+        if (lane == 0) cnt[z * (kBlock / 64) + wave] = __popcll(m);
+        below[z] = m & ((1ull << lane) - 1ull);
     }
+    __syncthreads();
+    if (wave == 0) { // exclusive scan of the 64 (step, wave) counters, in sweep order
+        const int c = cnt[lane];
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        cnt[lane] = incl - c;
+    }
+    __syncthreads();
+    if (!bits) return;
+    const int32_t id0 = (int32_t)*base + tile_off[blockIdx.x];
+#pragma unroll
+    for (int z = 0; z < kTile; ++z)
+        if ((bits >> z) & 1u) grid[first + (size_t)z * zs] = id0 + cnt[z * (kBlock / 64) + wave] + __popcll(below[z]);
 }
 
 __global__ void k_bump_base(long long *base, const int32_t *total)
@@ -736,31 +796,36 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     t.start();
     DevBuf<int32_t> fl, ids, scan_tmp;
     DevBuf<long long> base;
-    AVS_TRY(fl.alloc(max_vol + 1));
-    AVS_TRY(ids.alloc(max_vol + 1));
-    AVS_TRY(scan_tmp.alloc(scan_tmp_elems((int64_t)max_vol)));
+    // per-tile counters only: every lattice has at most (n/16 + 1)^3 tiles
+    const size_t max_tiles = (size_t)(d.nx / kTile + 2) * (size_t)(d.ny / kTile + 2) * (size_t)(d.nz / kTile + 2);
+    (void)max_vol;
+    AVS_TRY(fl.alloc(max_tiles + 1));
+    AVS_TRY(ids.alloc(max_tiles + 1));
+    AVS_TRY(scan_tmp.alloc(scan_tmp_elems((int64_t)max_tiles + 1)));
     AVS_TRY(base.alloc(4));
     AVS_HIP(hipMemsetAsync(base.p, 0, 4 * sizeof(long long), st));
+    auto number = [&](int32_t *grid, const int gr[3], int counter) -> avs_status {
+        const Grid3 g = g3(gr);
+        const int ntx = (gr[0] + kTile - 1) / kTile, nty = (gr[1] + kTile - 1) / kTile, ntz = (gr[2] + kTile - 1) / kTile;
+        const int64_t nt = (int64_t)ntx * nty * ntz;
+        hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)nt), dim3(kBlock), 0, st, (const int32_t *)grid, g, ntx, nty, fl.p);
+        AVS_TRY(exclusive_scan_i32(fl.p, ids.p, nt, scan_tmp.p, scan_tmp.n, st));
+        hipLaunchKernelGGL(k_tile_ids, dim3((unsigned)nt), dim3(kBlock), 0, st, grid, g, ntx, nty, (const int32_t *)ids.p,
+                           (const long long *)(base.p + counter));
+        hipLaunchKernelGGL(k_bump_base, dim3(1), dim3(64), 0, st, base.p + counter, (const int32_t *)(ids.p + nt));
+        return AVS_OK;
+    };
     for (int kind = 0; kind < 3; ++kind)
         for (int l = 0; l < capped; ++l)
             for (int a = 0; a < (kind == 2 ? 1 : 3); ++a) {
                 int gr[3];
                 pp_res(d, kind, l, a, gr);
-                const size_t nv = g3(gr).vol();
-                int32_t *grid = kind == 0 ? p->vidx[l][a].p : (kind == 1 ? p->eidx[l][a].p : p->cidx[l].p);
-                hipLaunchKernelGGL(k_flags_tilemajor, dim3(grid_for(nv)), dim3(kBlock), 0, st, (const int32_t *)grid, g3(gr), fl.p);
-                AVS_TRY(exclusive_scan_i32(fl.p, ids.p, (int64_t)nv, scan_tmp.p, scan_tmp.n, st));
-                hipLaunchKernelGGL(k_apply_ids, dim3(grid_for(nv)), dim3(kBlock), 0, st, grid, g3(gr), (const int32_t *)ids.p, (const long long *)(base.p + kind));
-                hipLaunchKernelGGL(k_bump_base, dim3(1), dim3(64), 0, st, base.p + kind, (const int32_t *)(ids.p + nv));
+                AVS_TRY(number(kind == 0 ? p->vidx[l][a].p : (kind == 1 ? p->eidx[l][a].p : p->cidx[l].p), gr, kind));
             }
     for (int a = 0; a < 3; ++a) { // regular grid: one counter over the three axes, cpp:1486-1509
         int gr[3];
         pp_res(d, 0, 0, a, gr);
-        const size_t nv = g3(gr).vol();
-        hipLaunchKernelGGL(k_flags_tilemajor, dim3(grid_for(nv)), dim3(kBlock), 0, st, (const int32_t *)p->ridx[a].p, g3(gr), fl.p);
-        AVS_TRY(exclusive_scan_i32(fl.p, ids.p, (int64_t)nv, scan_tmp.p, scan_tmp.n, st));
-        hipLaunchKernelGGL(k_apply_ids, dim3(grid_for(nv)), dim3(kBlock), 0, st, p->ridx[a].p, g3(gr), (const int32_t *)ids.p, (const long long *)(base.p + 3));
-        hipLaunchKernelGGL(k_bump_base, dim3(1), dim3(64), 0, st, base.p + 3, (const int32_t *)(ids.p + nv));
+        AVS_TRY(number(p->ridx[a].p, gr, 3));
     }
     AVS_HIP(hipGetLastError());
     long long hb[4] = {0, 0, 0, 0};
