@@ -287,6 +287,8 @@ avs_status avs_assemble(avs_ctx *c, avs_assembly_info *info)
     return AVS_OK;
 }
 
+int32_t avs_spmv_tile_rows(void) { return spmv_tile_rows(); }
+
 avs_status avs_get_matrix_format(avs_ctx *c, avs_matrix_format *fmt)
 {
     AVS_REQUIRE(c && fmt, AVS_EINVAL, "null argument");

@@ -47,6 +47,8 @@ struct PcgWork {
     DevBuf<double> invtab;   // ... into the table of inverted values (2 B instead of 8 B per row and vector pass)
     DevBuf<double> s, u; // single-reduction variant (multi-GPU): s = A p recurrence, u = M^-1 r with halo tail
     DevBuf<PcgScalars> sc;
+    DevBuf<double> stage;          // multi-block reduction: kRedBlocks x 4 block sums ...
+    DevBuf<unsigned> ticket;       // ... and the arrival counter (reset by the last block)
     PcgScalars *host_sc = nullptr; // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t evA[kChunk] = {}, evB[kChunk] = {}; // per-launch SpMV timing inside the solve
@@ -60,6 +62,27 @@ __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// wave64 sum without the LDS crossbar: inclusive scan inside every row of 16 lanes (row_shr 1, 2, 4, 8), then
+// row_bcast15 / row_bcast31 carry the row totals forward; lane 63 ends up with the sum of all 64 lanes (fixed order)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(hi, lo); // lanes without a source (or masked rows) add +0.0
+}
+
+__device__ __forceinline__ double wave_sum_dpp(double v) // result in lane 63
+{
+    v = dpp_add<0x111, 0xf>(v); // row_shr:1
+    v = dpp_add<0x112, 0xf>(v); // row_shr:2
+    v = dpp_add<0x114, 0xf>(v); // row_shr:4
+    v = dpp_add<0x118, 0xf>(v); // row_shr:8
+    v = dpp_add<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3
     return v;
 }
 
@@ -298,7 +321,7 @@ typedef int i4_t __attribute__((ext_vector_type(4)));
 
 typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 
-template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK>
+template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, int WIN = 0>
 __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__restrict__ x, double *__restrict__ y,
                                                   double *__restrict__ partial, const PcgScalars *sc,
                                                   const int32_t *__restrict__ tiles)
@@ -307,20 +330,41 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
     constexpr int U = CAP / (4 * BLK); // quads per lane per pass
     static_assert(U >= 1 && U * 4 * BLK == CAP, "CAP must be a multiple of 4*BLK");
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    static_assert(WIN == 0 || (WIN >= BLK && WIN % BLK == 0), "window = a whole number of tiles");
     double *prod = smem;                 // CAP + 4
-    int *arrived = reinterpret_cast<int *>(smem + CAP + 4 + 15);
-    double *tbl = smem + CAP + 4 + 16;                     // table_size (LTAB only)
+    double *xs = smem + CAP + 4;                           // WIN entries of x around the tile's rows
+    double *tbl = smem + CAP + 4 + WIN;                    // table_size (LTAB only)
     const int tid = threadIdx.x;
-    if (DOT && tid == 0) *arrived = 0;
-    if (LTAB)
-        for (int i = tid; i < A.table_size; i += BLK) tbl[i] = A.table[i];
-    if (DOT || LTAB) __syncthreads();
     const double *__restrict__ gtab = A.table;
     auto value = [&](unsigned code) -> double { return LTAB ? tbl[code] : gtab[code]; };
     const int64_t tile = tiles ? (int64_t)tiles[blockIdx.x] : (int64_t)blockIdx.x;
     const int64_t row0 = tile * BLK;
     const int64_t row = row0 + tid;
     const int64_t rlast = (row0 + BLK < A.n) ? row0 + BLK : A.n;
+    // x window: 43 % (WIN = 256) / 58 % (512) of a tile's columns lie within WIN entries of its rows in the brick-major
+    // numbering; those gathers are served from LDS instead of one L1 access each
+    int w0 = 0;
+    unsigned wlen = 0;
+    if (WIN > 0) {
+        const int64_t lo = row0 - (WIN - BLK) / 2;
+        w0 = (int)(lo > 0 ? lo : 0);
+        const int64_t left = A.n - w0;
+        wlen = (unsigned)(left < WIN ? left : WIN);
+#pragma unroll
+        for (int i = 0; i < WIN / BLK; ++i) {
+            const unsigned o = (unsigned)(tid + i * BLK);
+            if (o < wlen) xs[o] = x[(int64_t)w0 + o];
+        }
+    }
+    auto gather = [&](int col) -> double {
+        if (WIN > 0) {
+            const unsigned off = (unsigned)(col - w0);
+            if (off < wlen) return xs[off];
+        }
+        return x[col];
+    };
+    if (LTAB)
+        for (int i = tid; i < A.table_size; i += BLK) tbl[i] = A.table[i];
     const int s_blk = A.row_ptr[row0];
     const int e_blk = A.row_ptr[rlast];
     int rs = 0, re = 0;
@@ -328,8 +372,10 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
     if (row < A.n) {
         rs = A.row_ptr[row];
         re = A.row_ptr[row + 1];
-        if (DOT) xr = x[row]; // early: its latency hides behind the passes
+        if (DOT && WIN == 0) xr = x[row]; // early: its latency hides behind the passes
     }
+    if (LTAB || WIN > 0) __syncthreads();
+    if (DOT && WIN > 0 && row < A.n) xr = xs[(int)(row - w0)]; // the tile's own rows are always inside the window
     double sum = 0.;
     for (int ts = s_blk; ts < e_blk; ts += CAP) {
         const int te = (ts + CAP < e_blk) ? ts + CAP : e_blk;
@@ -363,10 +409,10 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
                     c[u] = i4_t{(int)(q[u].x & cmask), (int)(q[u].y & cmask), (int)(q[u].z & cmask), (int)(q[u].w & cmask)};
                     q[u] = u4_t{q[u].x >> cbits, q[u].y >> cbits, q[u].z >> cbits, q[u].w >> cbits};
                 }
-                xv[u][0] = x[c[u].x];
-                xv[u][1] = x[c[u].y];
-                xv[u][2] = x[c[u].z];
-                xv[u][3] = x[c[u].w];
+                xv[u][0] = gather(c[u].x);
+                xv[u][1] = gather(c[u].y);
+                xv[u][2] = gather(c[u].z);
+                xv[u][3] = gather(c[u].w);
             }
         }
 #pragma unroll
@@ -393,60 +439,47 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
         __syncthreads();
     }
     if (DOT) {
-        // x.y of the tile without a block barrier and without a wave reduction on every wave's critical path: each
-        // lane parks its term in LDS (prod[] is free after the loop's closing barrier), and the wave that arrives LAST
-        // folds all BLK terms -- lane l sums terms l, l+64, ... in order, then one wave tree: a fixed order whatever
-        // the arrival order was.
-        volatile double *term = prod;
-        term[tid] = (row < A.n) ? sum * xr : 0.;
-        // LDS-only fences: a full workgroup fence would also wait for this wave's outstanding global loads/stores
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        int before = 0;
-        if ((tid & 63) == 0) before = __hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        before = __builtin_amdgcn_readfirstlane(before);
-        if (before == BLK / 64 - 1) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-            double t = 0.;
-#pragma unroll
-            for (int w = 0; w < BLK / 64; ++w) t += term[(tid & 63) + 64 * w];
-            t = wave_sum(t);
-            if ((tid & 63) == 0) partial[tile] = t; // tile == blockIdx.x without a tile list
-        }
+        // x.y: one partial per WAVE, reduced with DPP row shifts / broadcasts -- no LDS traffic, no barrier, no atomic.
+        // (Measured: parking the terms in LDS and letting the last-arriving wave fold them cost 9-10 us per launch, two
+        // dependent LDS round trips at the end of every wave's life while the LDS pipe is busy; a block barrier 15 us.)
+        const double d = wave_sum_dpp((row < A.n) ? sum * xr : 0.);
+        if ((tid & 63) == 63) partial[tile * (BLK / 64) + (tid >> 6)] = d;
     }
     if (row < A.n) __builtin_nontemporal_store(sum, y + row);
 }
 
 static constexpr int kViLdsTable = 2048; // dictionary entries staged in LDS (16 KiB)
-static constexpr int kTileRows = 256;    // rows per workgroup of the value-indexed kernel and of the dist tile lists
-static constexpr int kTileCap = 2048;    // products parked per pass (U = 2 quads per lane; 17 KiB of LDS => 32 waves per CU)
+static constexpr int kTileRows = 512;    // rows per workgroup of the value-indexed kernel and of the dist tile lists
+static constexpr int kTileCap = 4096;    // products parked per pass (U = 2 quads per lane)
+static constexpr int kTileWin = 512;     // x entries staged in LDS (the tile's own rows): 38 KiB per workgroup => 32 waves per CU
 
-template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK>
+template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, int WIN = 0>
 static avs_status spmv_vi2_launch_t(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc,
                                     const int32_t *tiles, int ntiles, size_t lds, hipStream_t stream)
 {
     static bool attr = false; // one flag per instantiation
     if (!attr && lds > 48 * 1024) {
-        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, WIN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024 - 4096));
         attr = true;
     }
-    hipLaunchKernelGGL((k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK>), dim3(ntiles), dim3(BLK), lds, stream, A, x, y, partial, sc, tiles);
+    hipLaunchKernelGGL((k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, WIN>), dim3(ntiles), dim3(BLK), lds, stream, A, x, y, partial, sc, tiles);
     AVS_HIP(hipGetLastError());
     return AVS_OK;
 }
 
-template <int BLK, int CAP, bool DOT>
+template <int BLK, int CAP, bool DOT, int WIN = 0>
 static avs_status spmv_vi2_launch(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc,
                                   const int32_t *tiles, int ntiles, hipStream_t stream)
 {
     if (ntiles <= 0) return AVS_OK;
     const bool ltab = A.table_size <= kViLdsTable;
     const bool pack = A.packed != nullptr;
-    const size_t lds = (size_t)(CAP + 4 + 16 + (ltab ? ((A.table_size + 1) & ~1) : 0)) * sizeof(double);
-    if (ltab && pack) return spmv_vi2_launch_t<BLK, CAP, DOT, true, true>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
-    if (ltab) return spmv_vi2_launch_t<BLK, CAP, DOT, true, false>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
-    if (pack) return spmv_vi2_launch_t<BLK, CAP, DOT, false, true>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
-    return spmv_vi2_launch_t<BLK, CAP, DOT, false, false>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
+    const size_t lds = (size_t)(CAP + 4 + WIN + (ltab ? ((A.table_size + 1) & ~1) : 0)) * sizeof(double);
+    if (ltab && pack) return spmv_vi2_launch_t<BLK, CAP, DOT, true, true, WIN>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
+    if (ltab) return spmv_vi2_launch_t<BLK, CAP, DOT, true, false, WIN>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
+    if (pack) return spmv_vi2_launch_t<BLK, CAP, DOT, false, true, WIN>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
+    return spmv_vi2_launch_t<BLK, CAP, DOT, false, false, WIN>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -496,15 +529,15 @@ static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, do
     if (A.n <= 0) { if (nblocks) *nblocks = 0; return AVS_OK; }
     if (A.codes && (variant == 0 || variant == spmv_default_variant(A))) { // value-indexed matrix: 6 or 4 B per non-zero
         const int nt = (int)((A.n + kTileRows - 1) / kTileRows);
-        if (nblocks) *nblocks = nt;
-        return spmv_vi2_launch<kTileRows, kTileCap, DOT>(A, x, y, partial, sc, nullptr, nt, stream);
+        if (nblocks) *nblocks = nt * (kTileRows / 64);
+        return spmv_vi2_launch<kTileRows, kTileCap, DOT, kTileWin>(A, x, y, partial, sc, nullptr, nt, stream);
     }
-    if (A.codes && variant >= 31 && variant <= 40) {
-#define AVS_VI2_CASE(ID, BLK, CAP)                                                                              \
+    if (A.codes && variant >= 31 && variant <= 46) {
+#define AVS_VI2_CASE(ID, BLK, CAP, ...)                                                                         \
     case ID: {                                                                                                  \
         const int nt = (int)((A.n + BLK - 1) / BLK);                                                            \
-        if (nblocks) *nblocks = nt;                                                                             \
-        return spmv_vi2_launch<BLK, CAP, DOT>(A, x, y, partial, sc, nullptr, nt, stream);                       \
+        if (nblocks) *nblocks = nt * (BLK / 64);                                                                \
+        return spmv_vi2_launch<BLK, CAP, DOT, ##__VA_ARGS__>(A, x, y, partial, sc, nullptr, nt, stream);        \
     }
         switch (variant) { // geometry sweep of the value-indexed kernel (profiles/r01_spmv_variants.md)
             AVS_VI2_CASE(31, 256, 4096)
@@ -516,6 +549,12 @@ static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, do
             AVS_VI2_CASE(38, 512, 2048)
             AVS_VI2_CASE(39, 256, 1024)
             AVS_VI2_CASE(40, 128, 1024)
+            AVS_VI2_CASE(41, 256, 2048, 256)
+            AVS_VI2_CASE(42, 512, 4096, 512)
+            AVS_VI2_CASE(43, 256, 2048, 512)
+            AVS_VI2_CASE(44, 128, 1024, 128)
+            AVS_VI2_CASE(45, 128, 1024, 256)
+            AVS_VI2_CASE(46, 512, 4096, 1024)
         }
 #undef AVS_VI2_CASE
     }
@@ -587,8 +626,8 @@ avs_status spmv_dot_tiles(const CsrView &A, const double *x, double *y, double *
                           const int32_t *tiles, int ntiles, hipStream_t stream)
 {
     if (ntiles <= 0) return AVS_OK;
-    if (A.codes) return spmv_vi2_launch<kTileRows, kTileCap, true>(A, x, y, partial, sc, tiles, ntiles, stream);
-    hipLaunchKernelGGL((k_spmv_tile<kTileRows, 2048, true, true, false, true>), dim3(ntiles), dim3(kTileRows), 0, stream, A, x, y,
+    if (A.codes) return spmv_vi2_launch<kTileRows, kTileCap, true, kTileWin>(A, x, y, partial, sc, tiles, ntiles, stream);
+    hipLaunchKernelGGL((k_spmv_tile<kTileRows, 4096, true, true, false, true>), dim3(ntiles), dim3(kTileRows), 0, stream, A, x, y,
                        partial, sc, 0, tiles);
     AVS_HIP(hipGetLastError());
     return AVS_OK;
@@ -835,9 +874,72 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce(const double *__restrict__
     if (threadIdx.x == 0 && op != OP_NONE) apply_scalar_op(sc, op, tol);
 }
 
+// Same job with kRedBlocks workgroups for long partial arrays (the value-indexed SpMV leaves one partial per wave:
+// 116 k at 512^3): block b sums a fixed contiguous share, the block that arrives last folds the kRedBlocks sums in
+// block order and applies the scalar update -- the result does not depend on the arrival order.
+static constexpr int kRedBlocks = 8;
+__global__ __launch_bounds__(kRedBlock) void k_reduce_mb(const double *__restrict__ partial, int nb, int nred, PcgScalars *sc, int op,
+                                                        double tol, int skip_if_done, int red_off, double *__restrict__ stage,
+                                                        unsigned *__restrict__ ticket)
+{
+    if (skip_if_done && sc->done) { // every block sees a non-zero flag whether or not block 0 has already stepped it
+        if (blockIdx.x == 0 && threadIdx.x == 0 && op == OP_ALPHA && sc->done == 2) sc->done = 1;
+        return;
+    }
+    __shared__ double red[kRedBlock / 64];
+    __shared__ int last;
+    const int share = (nb + kRedBlocks - 1) / kRedBlocks;
+    const int lo = blockIdx.x * share, hi = (lo + share < nb) ? lo + share : nb;
+    for (int q = 0; q < nred; ++q) {
+        const double *src = partial + (size_t)q * nb;
+        double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
+        int i = lo + threadIdx.x;
+        for (; i + 3 * kRedBlock < hi; i += 4 * kRedBlock) {
+            const double a = src[i], b = src[i + kRedBlock], c = src[i + 2 * kRedBlock], d = src[i + 3 * kRedBlock];
+            s0 += a; s1 += b; s2 += c; s3 += d;
+        }
+        for (; i < hi; i += kRedBlock) s0 += src[i];
+        double s = wave_sum((s0 + s1) + (s2 + s3));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.;
+#pragma unroll
+            for (int w = 0; w < kRedBlock / 64; ++w) t += red[w];
+            __hip_atomic_store(stage + q * kRedBlocks + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == (unsigned)(kRedBlocks - 1);
+    }
+    __syncthreads();
+    if (!last || threadIdx.x != 0) return;
+    __threadfence();
+    for (int q = 0; q < nred; ++q) {
+        double t = 0.;
+        for (int b = 0; b < kRedBlocks; ++b) // the workgroups ran on different XCDs (L2s): agent-scope loads after the fence
+            t += __hip_atomic_load(stage + q * kRedBlocks + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sc->red[red_off + q] = t;
+    }
+    *ticket = 0u;
+    if (op != OP_NONE) apply_scalar_op(sc, op, tol);
+}
+
 __global__ void k_scalar(PcgScalars *sc, int op, double tol)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) apply_scalar_op(sc, op, tol);
+}
+
+static void reduce_launch(PcgWork *w, const double *partial, int nb, int nred, PcgScalars *sc, int op, double tol, int skip_if_done,
+                          int red_off, hipStream_t stream)
+{
+    if (nb >= 16384 && w->stage.p && w->ticket.p)
+        hipLaunchKernelGGL(k_reduce_mb, dim3(kRedBlocks), dim3(kRedBlock), 0, stream, partial, nb, nred, sc, op, tol, skip_if_done, red_off,
+                           w->stage.p, w->ticket.p);
+    else
+        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kRedBlock), 0, stream, partial, nb, nred, sc, op, tol, skip_if_done, red_off);
 }
 
 
@@ -939,8 +1041,8 @@ static avs_status pcg_solve_single_reduction(PcgWork *w, const CsrView &A, const
     AVS_TRY(dist_halo_exchange(dist, u, stream));
     int nb = 0;
     AVS_TRY(spmv_dispatch<true>(A, u, wv, pspmv, nullptr, variant, stream, &nb));
-    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kRedBlock), 0, stream, pvec, g, 3, sc, (int)OP_NONE, tol, 0, 0);
-    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kRedBlock), 0, stream, pspmv, nb, 1, sc, (int)OP_NONE, tol, 0, 3);
+    reduce_launch(w, pvec, g, 3, sc, (int)OP_NONE, tol, 0, 0, stream);
+    reduce_launch(w, pspmv, nb, 1, sc, (int)OP_NONE, tol, 0, 3, stream);
     AVS_TRY(dist_allreduce(dist, red_of(0), 4, stream));
     hipLaunchKernelGGL(k_scalar, dim3(1), dim3(64), 0, stream, sc, (int)OP_SR_INIT, tol);
     AVS_HIP(hipGetLastError());
@@ -973,15 +1075,15 @@ static avs_status pcg_solve_single_reduction(PcgWork *w, const CsrView &A, const
                 AVS_TRY(dist_halo_end(dist, stream));
                 AVS_TRY(spmv_dot_tiles(A, u, wv, pspmv, sc, t_bnd, n_bnd, stream));
                 if (info) AVS_HIP(hipEventRecord(w->evB[c], stream));
-                nb = n_int + n_bnd;
+                nb = (n_int + n_bnd) * (A.codes ? kTileRows / 64 : 1); // value-indexed kernel: one partial per wave
             } else {
                 AVS_TRY(dist_halo_exchange(dist, u, stream));
                 if (info) AVS_HIP(hipEventRecord(w->evA[c], stream));
                 AVS_TRY(spmv_dispatch<true>(A, u, wv, pspmv, sc, variant, stream, &nb));
                 if (info) AVS_HIP(hipEventRecord(w->evB[c], stream));
             }
-            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kRedBlock), 0, stream, pvec, g, 2, sc, (int)OP_NONE, tol, 0, 0);
-            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kRedBlock), 0, stream, pspmv, nb, 1, sc, (int)OP_NONE, tol, 0, 2);
+            reduce_launch(w, pvec, g, 2, sc, (int)OP_NONE, tol, 0, 0, stream);
+            reduce_launch(w, pspmv, nb, 1, sc, (int)OP_NONE, tol, 0, 2, stream);
             AVS_TRY(dist_allreduce(dist, red_of(0), 3, stream));
             hipLaunchKernelGGL(k_scalar, dim3(1), dim3(64), 0, stream, sc, (int)OP_SR_STEP, tol);
         }
@@ -1020,9 +1122,15 @@ avs_status pcg_create(PcgWork **out, int64_t n, int64_t n_ext, hipStream_t)
     w->npartial = max_partials(n);
     avs_status s;
     if ((s = w->r.alloc((size_t)n)) || (s = w->p.alloc((size_t)n_ext)) || (s = w->t.alloc((size_t)n)) ||
-        (s = w->invd.alloc((size_t)n)) || (s = w->partial.alloc(w->npartial)) || (s = w->sc.alloc(1))) {
+        (s = w->invd.alloc((size_t)n)) || (s = w->partial.alloc(w->npartial)) || (s = w->sc.alloc(1)) ||
+        (s = w->stage.alloc((size_t)kRedBlocks * 4)) || (s = w->ticket.alloc(1))) {
         delete w;
         return s;
+    }
+    if (hipMemset(w->ticket.p, 0, sizeof(unsigned)) != hipSuccess) {
+        set_error("hipMemset failed");
+        pcg_destroy(w);
+        return AVS_EHIP;
     }
     if (hipHostMalloc(reinterpret_cast<void **>(&w->host_sc), sizeof(PcgScalars)) != hipSuccess ||
         hipEventCreate(&w->ev0) != hipSuccess || hipEventCreate(&w->ev1) != hipSuccess) {
@@ -1057,10 +1165,10 @@ static avs_status reduce_stage(PcgWork *w, int nb, int nred, int op, double tol,
                                hipStream_t stream, PcgDist *dist)
 {
     if (!dist) {
-        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kRedBlock), 0, stream, w->partial.p, nb, nred, w->sc.p, op, tol, skip_if_done);
+        reduce_launch(w, w->partial.p, nb, nred, w->sc.p, op, tol, skip_if_done, 0, stream);
     } else {
         // local sums -> RCCL all-reduce of sc->red[0..nred) -> scalar update
-        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kRedBlock), 0, stream, w->partial.p, nb, nred, w->sc.p, (int)OP_NONE, tol, 0);
+        reduce_launch(w, w->partial.p, nb, nred, w->sc.p, (int)OP_NONE, tol, 0, 0, stream);
         AVS_TRY(dist_allreduce(dist, reinterpret_cast<double *>(reinterpret_cast<char *>(w->sc.p) + offsetof(PcgScalars, red)), nred, stream));
         hipLaunchKernelGGL(k_scalar, dim3(1), dim3(64), 0, stream, w->sc.p, op, tol);
     }

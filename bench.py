@@ -177,8 +177,8 @@ def main():
         bpn = int(fmt.bytes_per_nonzero)
         stored_bytes = local_bytes - (12 - bpn) * (local_bytes - 4 * (n + 1) - 16 * n) / 12.0 if not use_dist else None
         stored_rate = stored_bytes / (mean_spmv_ms * 1e-3) / 1e9 if stored_bytes and mean_spmv_ms > 0 else None
-        kernel = {4: "k_spmv_vi2<256,2048,DOT,LTAB,PACK> (4 B/nnz packed code|column, brick-major system)",
-                  6: "k_spmv_vi2<256,2048,DOT,LTAB> (6 B/nnz value-indexed, brick-major system)",
+        kernel = {4: "k_spmv_vi2<512,4096,DOT,LTAB,PACK,WIN=512> (4 B/nnz packed code|column, brick-major system)",
+                  6: "k_spmv_vi2<512,4096,DOT,LTAB,WIN=512> (6 B/nnz value-indexed, brick-major system)",
                   12: "k_spmv_tile<512,4096,DOT,VEC,NT> (12 B/nnz, brick-major system)"}[bpn]
         traffic = None
         prof = os.path.join(ROOT, "profiles", "spmv_traffic.json")

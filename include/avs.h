@@ -297,7 +297,9 @@ avs_status avs_dist_init_local(avs_ctx *ctx, avs_local_group *group, int32_t ran
  * (identical arrays, kept as the reference for tests). */
 avs_status avs_dist_partition(avs_ctx *ctx, int32_t cut_axis);
 avs_status avs_dist_get_plan_sizes(avs_ctx *ctx, avs_plan_sizes *sizes);
-/* number of 256-row SpMV tiles that read no halo column (they run while the halo is in flight) / that do */
+/* rows per SpMV tile (workgroup) of the solver's default kernel */
+int32_t avs_spmv_tile_rows(void);
+/* number of SpMV tiles that read no halo column (they run while the halo is in flight) / that do */
 avs_status avs_dist_get_overlap_tiles(avs_ctx *ctx, int32_t *interior, int32_t *boundary);
 /* the plan's arrays, copied to host memory (parity tests; sizes from avs_dist_get_plan_sizes / _overlap_tiles;
  * any pointer may be NULL): own_global[n_own], row_ptr_local[n_own+1], col_local[nnz_local], send_idx[n_send],

@@ -73,7 +73,7 @@ def test_virtual_ranks_match_single_solve(world, cut_axis, built_lib):
     for a in range(3):
         assert np.allclose(transfers[0][a], ref_out[a], rtol=0, atol=1e-6 * max(1.0, float(np.abs(ref_out[a]).max())))
     for ti, tb in tiles:                      # the halo exchange overlaps the tiles that read no halo column
-        assert tb >= 1 and ti + tb == -(-results[tiles.index((ti, tb))][4] // 256)   # 256-row SpMV tiles (kTileRows)
+        assert tb >= 1 and ti + tb == -(-results[tiles.index((ti, tb))][4] // lib.avs_spmv_tile_rows())
     for s in solvers:
         s.close()
     lib.avs_local_group_destroy(grp)
