@@ -5,7 +5,7 @@ run() { name=$1; shift; timeout 200 rocprofv3 --kernel-include-regex "spmv|k_upd
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run req TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum
-cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/trf_stats -o r01e -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/trf_stats.log 2>&1
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/trf_stats -o ${1:-r01h} -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/trf_stats.log 2>&1
 cd $R && rm -f gpurun_out/trf_stats/*kernel_trace.csv && python - <<'PY'
 import csv, collections, glob, json
 out = {}
