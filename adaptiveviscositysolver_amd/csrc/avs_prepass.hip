@@ -50,20 +50,30 @@ static inline unsigned grid_for(size_t n, unsigned cap = 1u << 20)
 // ---------------------------------------------------------------------------------------------
 // P1: weights
 // ---------------------------------------------------------------------------------------------
-// One 512-thread workgroup = one 8x8x8 brick of target samples.  The SDF cells the brick can touch
-// (di = -2 .. +1 around every sample => an 11^3 window, clamped at the border) are staged in LDS once:
-// the sign shortcut and the 27 trilinear sub-samples then read LDS only (64x fewer global reads).
+// One 512-thread workgroup = one 8x8x8 brick of sample indices, for ALL SEVEN weight fields at once (centre, 3 edge,
+// 3 face lattices differ only in which axes are cell-centred).  The SDF cells the brick can touch (di = -2 .. +1 around
+// every sample => an 11^3 window, clamped at the border) are staged in LDS once; the sign shortcuts and the 27 trilinear
+// sub-samples of every field then read LDS only.
 static constexpr int kWB = 8;             // brick edge
 static constexpr int kWH = kWB + 3;       // staged window edge: offsets -2 .. kWB
-__global__ __launch_bounds__(kWB *kWB *kWB) void k_sdf_weights(const float *__restrict__ sdf, Grid3 src, Grid3 tgt, SubConsts sc,
-                                                              float *__restrict__ out)
+static constexpr int kWFields = 7;
+
+struct WeightFields {
+    float *out[kWFields];
+    Grid3 tgt[kWFields];
+    int centered[kWFields]; // bit a: samples are cell-centred along axis a
+    int di[2][kMaxSuper];   // [centred?][sub-sample]: integer cell offset ...
+    float fr[2][kMaxSuper]; // ... and fp32 fraction (the same along every axis)
+    int n;
+};
+
+__global__ __launch_bounds__(kWB *kWB *kWB) void k_sdf_weights(const float *__restrict__ sdf, Grid3 src, Grid3 bricks, WeightFields F)
 {
     __shared__ float win[kWH * kWH * kWH];
-    const int n = sc.n;
+    const int n = F.n;
     const float n3 = (float)(n * n * n);
-    const int bx = (tgt.r[0] + kWB - 1) / kWB, by = (tgt.r[1] + kWB - 1) / kWB;
     const int b = blockIdx.x;
-    const int o0[3] = {(b % bx) * kWB, ((b / bx) % by) * kWB, (b / (bx * by)) * kWB};
+    const int o0[3] = {(b % bricks.r[0]) * kWB, ((b / bricks.r[0]) % bricks.r[1]) * kWB, (b / (bricks.r[0] * bricks.r[1])) * kWB};
     // window cell (wx, wy, wz) holds sdf at clamp(o0 - 2 + w): clamping here reproduces the clamped reads below
     int seen_neg = 0, seen_pos = 0;
     for (int w = threadIdx.x; w < kWH * kWH * kWH; w += kWB * kWB * kWB) {
@@ -80,56 +90,65 @@ __global__ __launch_bounds__(kWB *kWB *kWB) void k_sdf_weights(const float *__re
     const int any_pos = __syncthreads_or(seen_pos);
     const int t = threadIdx.x;
     const int p[3] = {o0[0] + t % kWB, o0[1] + (t / kWB) % kWB, o0[2] + t / (kWB * kWB)};
-    if (p[0] >= tgt.r[0] || p[1] >= tgt.r[1] || p[2] >= tgt.r[2]) return;
-    if (!any_pos || !any_neg) {
-        out[lin3(tgt, p[0], p[1], p[2])] = (float)(any_neg ? n * n * n : 0) / n3;
-        return;
-    }
-    // window index of source cell c along axis a: clamp first (as the reference read does), then shift
-    auto wi = [&](int a, int c) { return clampi(c, 0, src.r[a] - 1) - (o0[a] - 2); };
-    // NB: clamp(c) lies inside the window because c in [o0-2, o0+kWB] and the window itself was filled with
-    // clamped coordinates; when clamping moves c the value is identical to the window's clamped fill.
+    // NB: unclamped source coordinates c in [o0-2, o0+kWB] map to the window cell that was filled with the clamped
+    // coordinate, so `at` returns exactly what the reference's clamped read returns.
     auto at = [&](int cx, int cy, int cz) {
         const int ix = clampi(cx - (o0[0] - 2), 0, kWH - 1), iy = clampi(cy - (o0[1] - 2), 0, kWH - 1), iz = clampi(cz - (o0[2] - 2), 0, kWH - 1);
         return win[ix + kWH * (iy + kWH * iz)];
     };
-    (void)wi;
-    int lo[3], hi[3];
+    for (int f = 0; f < kWFields; ++f) {
+        const Grid3 tgt = F.tgt[f];
+        if (p[0] >= tgt.r[0] || p[1] >= tgt.r[1] || p[2] >= tgt.r[2]) continue;
+        float *out = F.out[f] + lin3(tgt, p[0], p[1], p[2]);
+        if (!any_pos || !any_neg) {
+            *out = (float)(any_neg ? n * n * n : 0) / n3;
+            continue;
+        }
+        const int *di[3];
+        const float *fr[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        lo[a] = p[a] + sc.di[a][0];
-        hi[a] = p[a] + sc.di[a][n - 1] + 1;
-    }
-    // exact shortcut: interpolation preserves the sign, so an all-negative (all non-negative) neighbourhood
-    // gives n^3 (0).  Unclamped coordinates: `at` maps them to the same values the clamped reads return.
-    bool allneg = true, allpos = true;
-    for (int kk = lo[2]; kk <= hi[2]; ++kk)
-        for (int jj = lo[1]; jj <= hi[1]; ++jj)
-            for (int ii = lo[0]; ii <= hi[0]; ++ii) {
-                const float v = at(ii, jj, kk);
-                if (v < 0.f) allpos = false;
-                else allneg = false;
-            }
-    int count;
-    if (allneg) count = n * n * n;
-    else if (allpos) count = 0;
-    else {
-        count = 0;
-        for (int sz = 0; sz < n; ++sz)
-            for (int sy = 0; sy < n; ++sy)
-                for (int sx = 0; sx < n; ++sx) {
-                    const int bx0 = p[0] + sc.di[0][sx], by0 = p[1] + sc.di[1][sy], bz0 = p[2] + sc.di[2][sz];
-                    const float tx = sc.fr[0][sx], ty = sc.fr[1][sy], tz = sc.fr[2][sz];
-                    const float c00 = lerp32(at(bx0, by0, bz0), at(bx0 + 1, by0, bz0), tx);
-                    const float c10 = lerp32(at(bx0, by0 + 1, bz0), at(bx0 + 1, by0 + 1, bz0), tx);
-                    const float c01 = lerp32(at(bx0, by0, bz0 + 1), at(bx0 + 1, by0, bz0 + 1), tx);
-                    const float c11 = lerp32(at(bx0, by0 + 1, bz0 + 1), at(bx0 + 1, by0 + 1, bz0 + 1), tx);
-                    const float c0 = lerp32(c00, c10, ty);
-                    const float c1 = lerp32(c01, c11, ty);
-                    if (lerp32(c0, c1, tz) < 0.f) ++count;
+        for (int a = 0; a < 3; ++a) {
+            const int c = (F.centered[f] >> a) & 1;
+            di[a] = F.di[c];
+            fr[a] = F.fr[c];
+        }
+        int lo[3], hi[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = p[a] + di[a][0];
+            hi[a] = p[a] + di[a][n - 1] + 1;
+        }
+        // exact shortcut: interpolation preserves the sign, so an all-negative (all non-negative) neighbourhood
+        // gives n^3 (0).
+        bool allneg = true, allpos = true;
+        for (int kk = lo[2]; kk <= hi[2]; ++kk)
+            for (int jj = lo[1]; jj <= hi[1]; ++jj)
+                for (int ii = lo[0]; ii <= hi[0]; ++ii) {
+                    const float v = at(ii, jj, kk);
+                    if (v < 0.f) allpos = false;
+                    else allneg = false;
                 }
+        int count;
+        if (allneg) count = n * n * n;
+        else if (allpos) count = 0;
+        else {
+            count = 0;
+            for (int sz = 0; sz < n; ++sz)
+                for (int sy = 0; sy < n; ++sy)
+                    for (int sx = 0; sx < n; ++sx) {
+                        const int bx0 = p[0] + di[0][sx], by0 = p[1] + di[1][sy], bz0 = p[2] + di[2][sz];
+                        const float tx = fr[0][sx], ty = fr[1][sy], tz = fr[2][sz];
+                        const float c00 = lerp32(at(bx0, by0, bz0), at(bx0 + 1, by0, bz0), tx);
+                        const float c10 = lerp32(at(bx0, by0 + 1, bz0), at(bx0 + 1, by0 + 1, bz0), tx);
+                        const float c01 = lerp32(at(bx0, by0, bz0 + 1), at(bx0 + 1, by0, bz0 + 1), tx);
+                        const float c11 = lerp32(at(bx0, by0 + 1, bz0 + 1), at(bx0 + 1, by0 + 1, bz0 + 1), tx);
+                        const float c0 = lerp32(c00, c10, ty);
+                        const float c1 = lerp32(c01, c11, ty);
+                        if (lerp32(c0, c1, tz) < 0.f) ++count;
+                    }
+        }
+        *out = (float)count / n3;
     }
-    out[lin3(tgt, p[0], p[1], p[2])] = (float)count / n3;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -568,16 +587,16 @@ static void sub_consts(int n, bool centered, int s, int *di, float *fr)
     *fr = (float)(d - fl);
 }
 
-static avs_status run_weights(avs_prepass *p, const bool centered[3], const int tr[3], float *out)
+// all seven weight fields in one launch: bricks cover the largest lattice (n + 1 samples per axis)
+static avs_status run_weights(avs_prepass *p, WeightFields &F)
 {
-    SubConsts sc{};
-    sc.n = p->desc.n_super;
-    for (int a = 0; a < 3; ++a)
-        for (int s = 0; s < sc.n; ++s) sub_consts(sc.n, centered[a], s, &sc.di[a][s], &sc.fr[a][s]);
+    F.n = p->desc.n_super;
+    for (int c = 0; c < 2; ++c)
+        for (int s = 0; s < F.n; ++s) sub_consts(F.n, c == 1, s, &F.di[c][s], &F.fr[c][s]);
     int sr[3];
     pp_res(p->desc, 2, 0, 0, sr);
-    const unsigned nb = (unsigned)(((tr[0] + kWB - 1) / kWB) * ((tr[1] + kWB - 1) / kWB) * ((tr[2] + kWB - 1) / kWB));
-    hipLaunchKernelGGL(k_sdf_weights, dim3(nb), dim3(kWB * kWB * kWB), 0, p->stream, p->liquid.p, g3(sr), g3(tr), sc, out);
+    const Grid3 bricks{{(sr[0] + 1 + kWB - 1) / kWB, (sr[1] + 1 + kWB - 1) / kWB, (sr[2] + 1 + kWB - 1) / kWB}};
+    hipLaunchKernelGGL(k_sdf_weights, dim3((unsigned)bricks.vol()), dim3(kWB * kWB * kWB), 0, p->stream, p->liquid.p, g3(sr), bricks, F);
     AVS_HIP(hipGetLastError());
     return AVS_OK;
 }
@@ -660,20 +679,26 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     // ---- P1 weights ------------------------------------------------------------------------
     t.start();
     {
-        const bool cc[3] = {true, true, true};
+        WeightFields F{};
+        int nf = 0;
+        auto add = [&](float *out, const int res[3], bool cx, bool cy, bool cz) {
+            F.out[nf] = out;
+            F.tgt[nf] = g3(res);
+            F.centered[nf] = (cx ? 1 : 0) | (cy ? 2 : 0) | (cz ? 4 : 0);
+            ++nf;
+        };
         AVS_TRY(p->centerw.alloc(n0));
-        AVS_TRY(run_weights(p, cc, r0, p->centerw.p));
+        add(p->centerw.p, r0, true, true, true);
         for (int a = 0; a < 3; ++a) {
             int er[3], fr[3];
             pp_res(d, 1, 0, a, er);
             pp_res(d, 0, 0, a, fr);
-            const bool ce[3] = {a == 0, a == 1, a == 2};
-            const bool cf[3] = {a != 0, a != 1, a != 2};
             AVS_TRY(p->edgew[a].alloc(g3(er).vol()));
-            AVS_TRY(run_weights(p, ce, er, p->edgew[a].p));
+            add(p->edgew[a].p, er, a == 0, a == 1, a == 2); // centred along the edge only
             AVS_TRY(p->facew[a].alloc(g3(fr).vol()));
-            AVS_TRY(run_weights(p, cf, fr, p->facew[a].p));
+            add(p->facew[a].p, fr, a != 0, a != 1, a != 2); // centred across the face
         }
+        AVS_TRY(run_weights(p, F));
     }
     p->ms[0] = t.stop();
 
