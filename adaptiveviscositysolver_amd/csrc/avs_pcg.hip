@@ -50,6 +50,11 @@ struct PcgWork {
     DevBuf<double> stage;          // multi-block reduction: kRedBlocks x 4 block sums ...
     DevBuf<unsigned> ticket;       // ... and the arrival counter (reset by the last block)
     PcgScalars *host_sc = nullptr; // pinned
+    // one chunk of kChunk iterations captured as a hipGraph (single-GPU loop): relaunched while the key matches
+    hipGraphExec_t graph = nullptr;
+    const void *graph_key[10] = {};
+    double graph_tol = 0.;
+    bool graph_broken = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t evA[kChunk] = {}, evB[kChunk] = {}; // per-launch SpMV timing inside the solve
     size_t npartial = 0;
@@ -1151,6 +1156,7 @@ avs_status pcg_create(PcgWork **out, int64_t n, int64_t n_ext, hipStream_t)
 void pcg_destroy(PcgWork *w)
 {
     if (!w) return;
+    if (w->graph) (void)hipGraphExecDestroy(w->graph);
     if (w->host_sc) (void)hipHostFree(w->host_sc);
     if (w->ev0) (void)hipEventDestroy(w->ev0);
     if (w->ev1) (void)hipEventDestroy(w->ev1);
@@ -1222,10 +1228,27 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
     int spmv_samples = 0;
     const bool sample = (info != nullptr);
     bool finished = false;
+    bool timed_chunk = true;
+    bool use_graph = !dist;
+    if (const char *e = getenv("AVS_PCG_GRAPH")) use_graph = use_graph && atoi(e) != 0;
+    auto enqueue_iteration = [&](int c, bool timed) -> avs_status {
+        int nb = 0;
+        if (dist) AVS_TRY(dist_halo_exchange(dist, p, stream));
+        if (timed) AVS_HIP(hipEventRecord(w->evA[c], stream));
+        AVS_TRY(spmv_dispatch<true>(A, p, t, partial, sc, variant, stream, &nb)); // tmp = A p ; p.tmp
+        if (timed) AVS_HIP(hipEventRecord(w->evB[c], stream));
+        AVS_TRY(reduce_stage(w, nb, 1, OP_ALPHA, tol, 1, stream, dist));
+        if (coded) hipLaunchKernelGGL(k_update_r<true>, dim3(g), dim3(kBlock), 0, stream, n, r, t, w->invtab.p, w->dcode.p, sc, partial);
+        else hipLaunchKernelGGL(k_update_r<false>, dim3(g), dim3(kBlock), 0, stream, n, r, t, invd, nullptr, sc, partial);
+        AVS_TRY(reduce_stage(w, g, 2, OP_BETA, tol, 1, stream, dist));
+        if (coded) hipLaunchKernelGGL(k_update_xp<true>, dim3(g), dim3(kBlock), 0, stream, n, x, p, r, w->invtab.p, w->dcode.p, sc);
+        else hipLaunchKernelGGL(k_update_xp<false>, dim3(g), dim3(kBlock), 0, stream, n, x, p, r, invd, nullptr, sc);
+        return AVS_OK;
+    };
     while (!finished) {
         AVS_HIP(hipMemcpyAsync(w->host_sc, sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, stream));
         AVS_HIP(hipStreamSynchronize(stream));
-        if (sample && last_chunk > 0) {
+        if (sample && last_chunk > 0 && timed_chunk) {
             // SpMV launches that really ran: iterations 0..iter (the one that detected convergence included)
             const int ran = w->host_sc->iter + ((w->host_sc->done == 1 || w->host_sc->done == 2) ? 1 : 0);
             const int first = enqueued - last_chunk;
@@ -1239,19 +1262,42 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
         }
         if (w->host_sc->done || enqueued >= max_iters) break;
         const int chunk = (max_iters - enqueued) < kChunk ? (max_iters - enqueued) : kChunk;
-        for (int c = 0; c < chunk; ++c) {
-            int nb = 0;
-            if (dist) AVS_TRY(dist_halo_exchange(dist, p, stream));
-            const bool timed = sample && (c % kSampleEvery == 0);
-            if (timed) AVS_HIP(hipEventRecord(w->evA[c], stream));
-            AVS_TRY(spmv_dispatch<true>(A, p, t, partial, sc, variant, stream, &nb)); // tmp = A p ; p.tmp
-            if (timed) AVS_HIP(hipEventRecord(w->evB[c], stream));
-            AVS_TRY(reduce_stage(w, nb, 1, OP_ALPHA, tol, 1, stream, dist));
-            if (coded) hipLaunchKernelGGL(k_update_r<true>, dim3(g), dim3(kBlock), 0, stream, n, r, t, w->invtab.p, w->dcode.p, sc, partial);
-            else hipLaunchKernelGGL(k_update_r<false>, dim3(g), dim3(kBlock), 0, stream, n, r, t, invd, nullptr, sc, partial);
-            AVS_TRY(reduce_stage(w, g, 2, OP_BETA, tol, 1, stream, dist));
-            if (coded) hipLaunchKernelGGL(k_update_xp<true>, dim3(g), dim3(kBlock), 0, stream, n, x, p, r, w->invtab.p, w->dcode.p, sc);
-            else hipLaunchKernelGGL(k_update_xp<false>, dim3(g), dim3(kBlock), 0, stream, n, x, p, r, invd, nullptr, sc);
+        // the first chunk is enqueued launch by launch with the SpMV timing events; later full chunks replay one captured
+        // hipGraph (5 kernel nodes per iteration): no per-launch host work, smaller gaps between the short kernels of small
+        // systems.  Kernels past convergence exit at once, so replaying a whole chunk is always safe.
+        const bool replay = use_graph && enqueued > 0 && chunk == kChunk && !w->graph_broken;
+        timed_chunk = !replay;
+        if (replay) {
+            const void *key[10] = {A.row_ptr, A.col, A.val, A.codes, A.packed, A.table, x, (const void *)(intptr_t)A.n,
+                                   (const void *)(intptr_t)(A.table_size * 64 + A.col_bits), (const void *)(intptr_t)(coded ? 1 : 0)};
+            if (w->graph && (memcmp(key, w->graph_key, sizeof(key)) != 0 || w->graph_tol != tol)) {
+                (void)hipGraphExecDestroy(w->graph);
+                w->graph = nullptr;
+            }
+            if (!w->graph) {
+                hipGraph_t gr = nullptr;
+                bool ok = hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+                if (ok) {
+                    for (int c = 0; c < kChunk && ok; ++c) ok = enqueue_iteration(c, false) == AVS_OK;
+                    ok = (hipStreamEndCapture(stream, &gr) == hipSuccess) && ok && gr;
+                }
+                if (ok) ok = hipGraphInstantiate(&w->graph, gr, nullptr, nullptr, 0) == hipSuccess;
+                if (gr) (void)hipGraphDestroy(gr);
+                if (!ok) { // fall back to plain launches for the rest of this workspace's life
+                    (void)hipGetLastError();
+                    w->graph = nullptr;
+                    w->graph_broken = true;
+                } else {
+                    memcpy(w->graph_key, key, sizeof(key));
+                    w->graph_tol = tol;
+                }
+            }
+        }
+        if (replay && w->graph) {
+            AVS_HIP(hipGraphLaunch(w->graph, stream));
+        } else {
+            timed_chunk = true;
+            for (int c = 0; c < chunk; ++c) AVS_TRY(enqueue_iteration(c, sample && (c % kSampleEvery == 0)));
         }
         AVS_HIP(hipGetLastError());
         enqueued += chunk;

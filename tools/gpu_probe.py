@@ -21,7 +21,12 @@ ap.add_argument("--torch-prepass", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 t0 = time.time()
-sc = scenes.thin_sheet(a.n, a.levels, thickness_cells=24, device=dev) if a.scene == "sheet" else scenes.fat_beam(a.n, a.levels, device=dev)
+if a.scene == "sheet":
+    sc = scenes.thin_sheet(a.n, a.levels, thickness_cells=24, device=dev)
+elif a.scene == "sphere":
+    sc = scenes.sphere(a.n, a.levels, device=dev)
+else:
+    sc = scenes.fat_beam(a.n, a.levels, variable_viscosity=(a.scene == "varvisc"), device=dev)
 torch.cuda.synchronize(); t1 = time.time()
 if a.torch_prepass:
     pyr = prepass.build_pyramid(sc)
@@ -50,4 +55,6 @@ for v in [int(x) for x in a.variants.split(",")]:
     ms = s.bench_spmv(v, a.repeats)
     print(f"spmv variant {v}: {ms*1e3:.1f} us  {bytes_spmv/ms/1e6:.1f} GB/s  ({bytes_spmv/ms/1e6/8000*100:.1f}% of 8 TB/s)", flush=True)
 info = s.solve(a.tol, 2500)
+fmt = s.matrix_format()
+print(f"matrix format: {fmt.bytes_per_nonzero} B/nnz, {fmt.value_table_size} distinct values, column bits {fmt.column_bits}", flush=True)
 print(f"solve tol {a.tol}: iters {info.iterations} conv {info.converged} err {info.error:.3e} {info.solve_ms:.2f} ms -> {info.iterations/info.solve_ms*1e3:.1f} it/s", flush=True)
