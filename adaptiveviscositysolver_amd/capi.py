@@ -57,7 +57,8 @@ class AvsError(RuntimeError):
 class Desc(C.Structure):
     _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("dx", C.c_double),
                 ("dt", C.c_double), ("levels", C.c_int32), ("use_enhanced_gradients", C.c_int32),
-                ("device", C.c_int32), ("stream", C.c_void_p)]
+                ("device", C.c_int32), ("stream", C.c_void_p),
+                ("field_nx", C.c_int32), ("field_ny", C.c_int32), ("field_nz", C.c_int32)]
 
 
 class SolveInfo(C.Structure):

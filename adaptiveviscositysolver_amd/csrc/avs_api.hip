@@ -113,6 +113,9 @@ avs_status avs_create(const avs_desc *d, avs_ctx **out)
     AVS_REQUIRE((d->nx >> (d->levels - 1)) >= 1 && (d->ny >> (d->levels - 1)) >= 1 && (d->nz >> (d->levels - 1)) >= 1,
                 AVS_EINVAL, "too many levels for this resolution");
     AVS_REQUIRE(d->dx > 0. && std::isfinite(d->dx) && std::isfinite(d->dt), AVS_EINVAL, "dx must be positive and finite");
+    AVS_REQUIRE(d->field_nx >= 0 && d->field_nx <= d->nx && d->field_ny >= 0 && d->field_ny <= d->ny && d->field_nz >= 0 &&
+                    d->field_nz <= d->nz,
+                AVS_EINVAL, "field resolution %d %d %d must lie in [0, octree resolution]", d->field_nx, d->field_ny, d->field_nz);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     AVS_REQUIRE(e == hipSuccess && ndev > 0, AVS_EHIP, "no HIP device available (%s)", hipGetErrorString(e));
@@ -121,6 +124,9 @@ avs_status avs_create(const avs_desc *d, avs_ctx **out)
     avs_ctx *c = new (std::nothrow) avs_ctx();
     AVS_REQUIRE(c, AVS_ENOMEM, "out of host memory");
     c->desc = *d;
+    if (c->desc.field_nx == 0) c->desc.field_nx = d->nx;
+    if (c->desc.field_ny == 0) c->desc.field_ny = d->ny;
+    if (c->desc.field_nz == 0) c->desc.field_nz = d->nz;
     if (d->stream) c->stream = reinterpret_cast<hipStream_t>(d->stream);
     else {
         if (hipStreamCreate(&c->stream) != hipSuccess) { // blocking: ordered after work on the null stream
@@ -206,6 +212,24 @@ avs_status avs_set_dof_counts(avs_ctx *c, int64_t nv, int64_t ne, int64_t nc)
     return AVS_OK;
 }
 
+namespace {
+// field on the simulation grid -> the padded level-0 lattice of the octree (desc.field_n* < desc.n*)
+__global__ __launch_bounds__(256) void k_pad_field(const float *__restrict__ in, int sx, int sy, int sz, float *__restrict__ out, int rx,
+                                                   int ry, int rz, int replicate)
+{
+    const size_t total = (size_t)rx * ry * rz;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int i = (int)(o % rx), j = (int)((o / rx) % ry), k = (int)(o / ((size_t)rx * ry));
+        float v = 0.f;
+        if (replicate || (i < sx && j < sy && k < sz)) {
+            const int ci = i < sx ? i : sx - 1, cj = j < sy ? j : sy - 1, ck = k < sz ? k : sz - 1;
+            v = in[(size_t)ci + (size_t)sx * ((size_t)cj + (size_t)sy * ck)];
+        }
+        out[o] = v;
+    }
+}
+} // namespace
+
 avs_status avs_set_scalar_field(avs_ctx *c, avs_field_kind kind, int32_t axis, const float *data, float constant,
                                 avs_memspace where)
 {
@@ -232,8 +256,23 @@ avs_status avs_set_scalar_field(avs_ctx *c, avs_field_kind kind, int32_t axis, c
         f->cval = constant;
     } else {
         AVS_TRY(f->buf.alloc(vol3(r)));
-        AVS_HIP(copy_in(f->buf.p, data, vol3(r) * sizeof(float), where, c->stream));
-        if (where == AVS_MEM_HOST) AVS_HIP(hipStreamSynchronize(c->stream));
+        // the caller's array has the SIMULATION grid's lattice: r minus the padding HDK_OctreeGrid::init added
+        const int s3[3] = {r[0] - (c->desc.nx - c->desc.field_nx), r[1] - (c->desc.ny - c->desc.field_ny),
+                           r[2] - (c->desc.nz - c->desc.field_nz)};
+        if (s3[0] == r[0] && s3[1] == r[1] && s3[2] == r[2]) {
+            AVS_HIP(copy_in(f->buf.p, data, vol3(r) * sizeof(float), where, c->stream));
+            if (where == AVS_MEM_HOST) AVS_HIP(hipStreamSynchronize(c->stream));
+        } else {
+            DevBuf<float> src;
+            AVS_TRY(src.alloc(vol3(s3)));
+            AVS_HIP(copy_in(src.p, data, vol3(s3) * sizeof(float), where, c->stream));
+            const int replicate = (kind == AVS_FIELD_VISCOSITY || kind == AVS_FIELD_DENSITY) ? 1 : 0;
+            const size_t blocks = (vol3(r) + 255) / 256;
+            hipLaunchKernelGGL(k_pad_field, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, c->stream,
+                               (const float *)src.p, s3[0], s3[1], s3[2], f->buf.p, r[0], r[1], r[2], replicate);
+            AVS_HIP(hipGetLastError());
+            AVS_HIP(hipStreamSynchronize(c->stream)); // src dies here
+        }
         f->is_const = false;
     }
     invalidate(c, false);

@@ -360,6 +360,8 @@ extern "C" {
 avs_status avs_set_regular_index_field(avs_ctx *c, int32_t axis, const int32_t *idx, avs_memspace where)
 {
     AVS_REQUIRE(c && idx, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->desc.field_nx == c->desc.nx && c->desc.field_ny == c->desc.ny && c->desc.field_nz == c->desc.nz, AVS_EINVAL,
+                "the post-solve transfer needs field_n* == n* (simulation grid == octree grid)");
     AVS_REQUIRE(axis >= 0 && axis < 3, AVS_EINVAL, "axis out of range");
     AVS_HIP(hipSetDevice(c->desc.device));
     int r[3] = {c->desc.nx, c->desc.ny, c->desc.nz};
@@ -375,6 +377,8 @@ avs_status avs_set_regular_index_field(avs_ctx *c, int32_t axis, const int32_t *
 avs_status avs_transfer_to_regular_grid(avs_ctx *c, float *out_x, float *out_y, float *out_z, avs_memspace where)
 {
     AVS_REQUIRE(c && out_x && out_y && out_z, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->desc.field_nx == c->desc.nx && c->desc.field_ny == c->desc.ny && c->desc.field_nz == c->desc.nz, AVS_EINVAL,
+                "the post-solve transfer needs field_n* == n* (simulation grid == octree grid)");
     AVS_REQUIRE(c->solved, AVS_ESTATE, "no solution: call avs_solve first");
     AVS_REQUIRE(c->have_ridx[0] && c->have_ridx[1] && c->have_ridx[2], AVS_ESTATE, "regular-grid index fields missing (avs_set_regular_index_field)");
     AVS_REQUIRE(c->tables_ready, AVS_ESTATE, "dof tables missing");

@@ -23,16 +23,20 @@ class ViscositySolve:
         x = s.solution()                                  # viscositySolution, consumed by cpp:661-707
     """
 
-    def __init__(self, res, dx, dt, levels, use_enhanced_gradients=True, device=0, stream=None):
+    def __init__(self, res, dx, dt, levels, use_enhanced_gradients=True, device=0, stream=None, field_res=None):
+        """`res`: octree (power-of-two) level-0 resolution; `field_res`: resolution of the simulation grid the scalar
+        fields live on when HDK_OctreeGrid::init had to pad it (oct.cpp:13-24); None = res."""
         self.lib = capi.load()
         self.res = tuple(int(r) for r in res)
+        fr = tuple(int(r) for r in field_res) if field_res is not None else (0, 0, 0)
         d = capi.Desc(self.res[0], self.res[1], self.res[2], float(dx), float(dt), int(levels),
-                      int(bool(use_enhanced_gradients)), int(device), C.c_void_p(stream or 0))
+                      int(bool(use_enhanced_gradients)), int(device), C.c_void_p(stream or 0), fr[0], fr[1], fr[2])
         h = C.c_void_p()
         capi.check(self.lib.avs_create(C.byref(d), C.byref(h)))
         self.h = h
         self.levels = int(levels)
         self.counts = None
+        self.field_res = tuple(fr[a] or self.res[a] for a in range(3))
 
     def close(self):
         if getattr(self, "h", None):
@@ -58,7 +62,23 @@ class ViscositySolve:
         capi.check(self.lib.avs_set_dof_counts(self.h, nv, ne, nc))
         self.counts = (int(nv), int(ne), int(nc))
 
+    def _field_lattice(self, kind, axis, res):
+        """(nz, ny, nx) of a level-0 scalar field's lattice on a grid of resolution `res` (x, y, z)."""
+        r = list(res)
+        if kind in (capi.FIELD_FACE_WEIGHTS, capi.FIELD_VELOCITY, capi.FIELD_SOLID_VELOCITY):
+            r[axis] += 1
+        elif kind == capi.FIELD_EDGE_WEIGHTS:
+            r = [r[b] + (1 if b != axis else 0) for b in range(3)]
+        return (r[2], r[1], r[0])
+
     def set_field(self, kind, axis=0, data=None, const=0.0):
+        if data is not None and self.field_res != self.res:
+            # the library expects the SIMULATION grid's lattice; crop arrays given on the padded octree lattice
+            full, want = self._field_lattice(kind, axis, self.res), self._field_lattice(kind, axis, self.field_res)
+            if tuple(data.shape) == full:
+                data = data[:want[0], :want[1], :want[2]]
+                data = data.contiguous() if hasattr(data, "contiguous") else np.ascontiguousarray(data)
+            assert tuple(data.shape) == want, (tuple(data.shape), want)
         p, where = capi.ptr_of(data)
         capi.check(self.lib.avs_set_scalar_field(self.h, kind, axis, p, float(const), where))
 

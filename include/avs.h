@@ -82,6 +82,13 @@ typedef struct {
     int32_t use_enhanced_gradients; /* getUseEnhancedGradients() (cpp:438) */
     int32_t device;                 /* HIP device ordinal */
     void *stream;                   /* hipStream_t to enqueue on; NULL = the library creates one */
+    /* Resolution of the simulation grid the level-0 SCALAR fields live on (weights, viscosity, density, velocities),
+     * i.e. before HDK_OctreeGrid::init stretched the octree grid to powers of two (oct.cpp:13-24).  0 = nx, ny, nz.
+     * Labels and index pyramids always use nx, ny, nz.  Samples of the padded lattice outside this grid belong to
+     * INACTIVE cells (oct.cpp:375-379) and are never read by an active row; the library fills them (viscosity /
+     * density by border replication, everything else with 0).  The optional pre-pass / post-transfer entry points
+     * require field_n* == n*. */
+    int32_t field_nx, field_ny, field_nz;
 } avs_desc;
 
 typedef struct {

@@ -247,3 +247,39 @@ def test_inconsistent_inputs_are_rejected(dev, built_lib):
     s.set_index_field(capi.INDEX_VELOCITY, 0, 0, bad.contiguous())
     s.assemble()   # still a consistent numbering (a permutation): must assemble
     assert s.info().n_velocity == pyr.n_velocity
+
+
+def test_fields_on_a_smaller_simulation_grid(dev, built_lib):
+    """HDK_OctreeGrid::init stretches the octree grid to powers of two (oct.cpp:13-24) while the scalar fields stay on
+    the simulation grid; cells outside it are INACTIVE (oct.cpp:375-379).  With avs_desc.field_n* the ABI takes the
+    fields at their own resolution.  Reference here: the oracle on fields given on the full 64^3 lattice -- whatever
+    lies outside the 48 x 40 x 24 simulation grid must not matter, so CSR, rhs, initial guess are bit-identical."""
+    n, field_res = 64, (48, 40, 24)
+    dx = 1.0 / n
+    liquid = scenes.box_sdf((n, n, n), dx, center=(24 * dx, 20 * dx, 12 * dx), half=(17 * dx, 13 * dx, 6.5 * dx))
+    x = (torch.arange(n, dtype=torch.float64) + 0.5) * dx
+    visc = (150.0 * (1.0 + 5.0 * x))[None, None, :].expand(n, n, n).to(torch.float32).contiguous()
+    sc = scenes.Scene(res=(n, n, n), dx=dx, dt=1.0 / 60.0, levels=3, liquid=liquid, viscosity=visc, density=900.0,
+                      velocity=scenes.smooth_velocity((n, n, n), dx, gravity_dt=0.1), name="corner_box")
+    pyr = prepass.build_pyramid(sc)
+    o = oracle_from_pyramid(sc, pyr)
+    o.hot_path()
+    want = o.csr()
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0, field_res=field_res)
+    s.set_pyramid(pyr)                                  # index pyramids at 64^3; weight fields cropped by set_field
+    s.set_scene_fields(scenes.to_device(sc, dev))       # viscosity / velocity arrays cropped likewise (device path)
+    s.assemble()
+    rp, col, val, rhs = s.csr()
+    assert np.array_equal(rp, want.row_ptr) and np.array_equal(col, want.col)
+    assert np.array_equal(val, want.val) and np.array_equal(rhs, want.rhs)
+    assert np.array_equal(s.initial_guess(), o.initial_guess())
+    info = s.solve(1e-10, 4000)
+    xo, oi = o.solve(1e-10, 4000)
+    assert info.converged == 1 and abs(info.iterations - oi.iterations) <= 2
+    assert rel_l2(s.solution(), xo) < 1e-8
+    # the post-solve transfer is defined on the padded grid only
+    with pytest.raises(capi.AvsError):
+        s.transfer_to_regular_grid()
+    s.close()
+    with pytest.raises(capi.AvsError):                  # a simulation grid larger than the octree grid is rejected
+        ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0, field_res=(65, 64, 64))
