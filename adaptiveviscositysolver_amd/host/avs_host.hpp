@@ -38,11 +38,14 @@ struct SolveResult {
 
 class AdaptiveViscosity {
 public:
+    // nx, ny, nz: padded octree resolution; fieldRes: the simulation grid the scalar fields live on (oct.cpp:13-24),
+    // nullptr = the same
     AdaptiveViscosity(int nx, int ny, int nz, double dx, double dt, int octreeLevels, bool useEnhancedGradients = true,
-                      int device = 0)
+                      int device = 0, const int *fieldRes = nullptr)
     {
         avs_desc d{};
         d.nx = nx; d.ny = ny; d.nz = nz;
+        if (fieldRes) { d.field_nx = fieldRes[0]; d.field_ny = fieldRes[1]; d.field_nz = fieldRes[2]; }
         d.dx = dx; d.dt = dt;
         d.levels = octreeLevels;
         d.use_enhanced_gradients = useEnhancedGradients ? 1 : 0;
