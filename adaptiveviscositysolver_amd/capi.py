@@ -42,7 +42,7 @@ EXPORTED_SYMBOLS = [
     "avs_transfer_to_regular_grid", "avs_get_node_grid", "avs_get_dof_table", "avs_plan_owners", "avs_plan_create", "avs_plan_get_sizes",
     "avs_plan_get_arrays", "avs_plan_destroy", "avs_dist_get_unique_id", "avs_dist_init",
     "avs_local_group_create", "avs_local_group_destroy", "avs_dist_init_local", "avs_dist_partition",
-    "avs_spmv_tile_rows", "avs_dist_get_plan_sizes", "avs_dist_get_overlap_tiles", "avs_dist_get_plan_arrays", "avs_dist_solve", "avs_dist_get_solution",
+    "avs_spmv_tile_rows", "avs_dist_assemble", "avs_dist_get_plan_sizes", "avs_dist_get_overlap_tiles", "avs_dist_get_plan_arrays", "avs_dist_solve", "avs_dist_get_solution",
 ]
 _VOID_RETURN = ("avs_last_error", "avs_version", "avs_destroy", "avs_plan_destroy", "avs_local_group_destroy",
                 "avs_prepass_destroy")
@@ -163,6 +163,7 @@ def load():
     L.avs_dist_init_local.argtypes = [vp, vp, i32]
     L.avs_dist_partition.argtypes = [vp, i32]
     L.avs_dist_get_plan_sizes.argtypes = [vp, C.POINTER(PlanSizes)]
+    L.avs_dist_assemble.argtypes = [vp, i32, C.POINTER(AssemblyInfo)]
     L.avs_spmv_tile_rows.argtypes = []
     L.avs_spmv_tile_rows.restype = i32
     L.avs_dist_get_overlap_tiles.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]

@@ -20,8 +20,6 @@ void set_error(const char *fmt, ...)
 
 // phase drivers implemented in avs_assembly.hip
 avs_status build_dof_tables(avs_ctx *c);
-avs_status build_stencils(avs_ctx *c);
-avs_status build_initial_guess(avs_ctx *c);
 avs_status build_system(avs_ctx *c);
 
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -40,29 +38,6 @@ static void grid_res(const avs_desc &d, int kind /*0 face,1 edge,2 centre*/, int
 }
 static size_t vol3(const int r[3]) { return (size_t)r[0] * (size_t)r[1] * (size_t)r[2]; }
 
-struct Timer {
-    hipEvent_t a = nullptr, b = nullptr;
-    hipStream_t s;
-    explicit Timer(hipStream_t st) : s(st)
-    {
-        (void)hipEventCreate(&a);
-        (void)hipEventCreate(&b);
-    }
-    ~Timer()
-    {
-        if (a) (void)hipEventDestroy(a);
-        if (b) (void)hipEventDestroy(b);
-    }
-    void start() { (void)hipEventRecord(a, s); }
-    double stop()
-    {
-        (void)hipEventRecord(b, s);
-        (void)hipEventSynchronize(b);
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, a, b);
-        return ms;
-    }
-};
 
 } // namespace avs
 
@@ -331,6 +306,7 @@ int32_t avs_spmv_tile_rows(void) { return spmv_tile_rows(); }
 avs_status avs_get_matrix_format(avs_ctx *c, avs_matrix_format *fmt)
 {
     AVS_REQUIRE(c && fmt, AVS_EINVAL, "null argument");
+    if (!c->system_ready && dist_matrix_format(c, fmt)) return AVS_OK; // avs_dist_assemble: the rank's own rows
     AVS_REQUIRE(c->system_ready, AVS_ESTATE, "no system: call avs_assemble first");
     const bool vi = c->reordered && c->v_table_size > 0;
     fmt->reordered = c->reordered ? 1 : 0;

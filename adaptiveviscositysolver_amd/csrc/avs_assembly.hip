@@ -387,12 +387,13 @@ __global__ __launch_bounds__(kBlock) void k_rows(PyramidView P, const int32_t *_
                                                  StencilView E, StencilView C, const double *__restrict__ x0,
                                                  const int32_t *__restrict__ rawptr, int32_t *__restrict__ raw_col,
                                                  double *__restrict__ raw_val, int32_t *__restrict__ row_count,
-                                                 double *__restrict__ rhs, int *err)
+                                                 double *__restrict__ rhs, int *err, const int32_t *__restrict__ ids)
 {
+    // `ids` (multi-GPU: the rows this rank owns) maps output row -> velocity DOF; nullptr = all DOFs in order
     const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (row >= n) return;
-    const int32_t vi = (int32_t)row;
-    const int4 rec = reinterpret_cast<const int4 *>(vdof)[row];
+    const int32_t vi = ids ? ids[row] : (int32_t)row;
+    const int4 rec = reinterpret_cast<const int4 *>(vdof)[vi];
     const int level = rec.x & 0xff, axis = rec.x >> 8;
     const I3 face{{rec.y, rec.z, rec.w}};
     const I3 cr = cell_res(P, level);
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(kBlock) void k_rows(PyramidView P, const int32_t *_
         if (P.dens.is_const) fw *= (double)P.dens.cval;
         else fw *= (double)sample_f32(P.dens, cell_res(P, 0), I3{{1, 1, 1}}, pos2_face(level, axis, face));
         row_push<true>(ra, vi, fw + ra.diag);
-        ra.rhs += fw * x0[row];
+        ra.rhs += fw * x0[vi]; // x0 is indexed by DOF
         rhs[row] = ra.rhs;
     } else ++ra.n;
     row_count[row] = ra.n;
@@ -911,12 +912,15 @@ avs_status build_initial_guess(avs_ctx *c)
     return AVS_OK;
 }
 
-avs_status build_system(avs_ctx *c)
+// rows `ids[0..m)` (velocity DOFs; nullptr = all, in order) -> CSR with reference-numbered columns + rhs.
+// Row-local work: a rank of a multi-GPU solve assembles only the rows it owns.
+avs_status assemble_rows(avs_ctx *c, const int32_t *ids, int64_t m, DevBuf<int32_t> &row_ptr, DevBuf<int32_t> &col, DevBuf<double> &val,
+                         DevBuf<double> &rhs, int64_t *nnz_out, int64_t *nraw_out)
 {
     hipStream_t st = c->stream;
     AVS_REQUIRE(c->stencils_ready && c->guess_ready, AVS_ESTATE, "build the stencils and the initial guess first");
-    const int64_t n = c->n_vel;
-    AVS_REQUIRE(n < (int64_t)INT32_MAX, AVS_EINVAL, "too many DOFs for int32 columns");
+    const int64_t n = m;
+    AVS_REQUIRE(c->n_vel < (int64_t)INT32_MAX, AVS_EINVAL, "too many DOFs for int32 columns");
     DevBuf<int32_t> row_count, rawptr, scan_tmp, raw_col;
     DevBuf<double> raw_val;
     DevBuf<int> err;
@@ -924,44 +928,72 @@ avs_status build_system(avs_ctx *c)
     AVS_TRY(rawptr.alloc((size_t)n + 1));
     AVS_TRY(scan_tmp.alloc(scan_tmp_elems(n)));
     AVS_TRY(err.alloc(1));
-    AVS_TRY(c->rhs.alloc((size_t)n));
-    AVS_TRY(c->row_ptr.alloc((size_t)n + 1));
+    AVS_TRY(rhs.alloc((size_t)n));
+    AVS_TRY(row_ptr.alloc((size_t)n + 1));
     AVS_HIP(hipMemsetAsync(err.p, 0, sizeof(int), st));
     PyramidView P = c->view();
     StencilView E = edge_view(c), C = center_view(c);
     // K4 dry run -> raw triplet counts
     if (n) hipLaunchKernelGGL((k_rows<false>), dim3(grid_for(n)), dim3(kBlock), 0, st, P, c->vdof.p, n, E, C, c->x0.p,
-                              (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr, row_count.p, (double *)nullptr, err.p);
+                              (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr, row_count.p, (double *)nullptr, err.p, ids);
     AVS_TRY(exclusive_scan_i32(row_count.p, rawptr.p, n, scan_tmp.p, scan_tmp.n, st));
     int32_t nraw = 0;
     AVS_HIP(hipMemcpyAsync(&nraw, rawptr.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     AVS_HIP(hipStreamSynchronize(st));
     AVS_REQUIRE(nraw >= 0, AVS_EINVAL, "raw triplet count overflows int32");
-    c->nraw = nraw;
+    if (nraw_out) *nraw_out = nraw;
     AVS_TRY(raw_col.alloc((size_t)nraw));
     AVS_TRY(raw_val.alloc((size_t)nraw));
     // K6 emit raw triplets, K6b per-row stable sort + duplicate merge -> unique counts
     if (n) {
         hipLaunchKernelGGL((k_rows<true>), dim3(grid_for(n)), dim3(kBlock), 0, st, P, c->vdof.p, n, E, C, c->x0.p,
-                           (const int32_t *)rawptr.p, raw_col.p, raw_val.p, row_count.p, c->rhs.p, err.p);
+                           (const int32_t *)rawptr.p, raw_col.p, raw_val.p, row_count.p, rhs.p, err.p, ids);
         hipLaunchKernelGGL(k_sort_rows, dim3(grid_for((n + kSortRowsPerHalf - 1) / kSortRowsPerHalf * 32)), dim3(kBlock), 0, st, n,
                            (const int32_t *)rawptr.p, raw_col.p, raw_val.p, row_count.p);
         hipLaunchKernelGGL(k_sort_long_rows, dim3(8192), dim3(64), 0, st, n, (const int32_t *)rawptr.p, raw_col.p, raw_val.p,
                            row_count.p);
     }
-    AVS_TRY(exclusive_scan_i32(row_count.p, c->row_ptr.p, n, scan_tmp.p, scan_tmp.n, st));
+    AVS_TRY(exclusive_scan_i32(row_count.p, row_ptr.p, n, scan_tmp.p, scan_tmp.n, st));
     int32_t nnz = 0;
-    AVS_HIP(hipMemcpyAsync(&nnz, c->row_ptr.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipMemcpyAsync(&nnz, row_ptr.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     int e = 0;
     AVS_TRY(read_err(err.p, st, &e));
     AVS_REQUIRE(e == 0, AVS_EINTERNAL, "row assembly hit a reference assert (code %d): stencils and index pyramids disagree", e);
-    c->nnz = nnz;
-    AVS_TRY(c->col.alloc((size_t)nnz));
-    AVS_TRY(c->val.alloc((size_t)nnz));
-    if (n) hipLaunchKernelGGL(k_compact, dim3(8192), dim3(kBlock), 0, st, n, (const int32_t *)rawptr.p, (const int32_t *)c->row_ptr.p,
-                              (const int32_t *)raw_col.p, (const double *)raw_val.p, c->col.p, c->val.p);
+    if (nnz_out) *nnz_out = nnz;
+    AVS_TRY(col.alloc((size_t)nnz));
+    AVS_TRY(val.alloc((size_t)nnz));
+    if (n) hipLaunchKernelGGL(k_compact, dim3(8192), dim3(kBlock), 0, st, n, (const int32_t *)rawptr.p, (const int32_t *)row_ptr.p,
+                              (const int32_t *)raw_col.p, (const double *)raw_val.p, col.p, val.p);
     AVS_HIP(hipGetLastError());
     AVS_HIP(hipStreamSynchronize(st)); // raw buffers are freed on return
+    return AVS_OK;
+}
+
+// raw (pre-merge) triplet count of every row: the cost weight the multi-GPU slab cuts are balanced with
+avs_status count_raw_rows(avs_ctx *c, DevBuf<int32_t> &counts)
+{
+    hipStream_t st = c->stream;
+    AVS_REQUIRE(c->stencils_ready, AVS_ESTATE, "build the stencils first");
+    const int64_t n = c->n_vel;
+    DevBuf<int> err;
+    AVS_TRY(err.alloc(1));
+    AVS_TRY(counts.alloc((size_t)n + 1));
+    AVS_HIP(hipMemsetAsync(err.p, 0, sizeof(int), st));
+    if (n) hipLaunchKernelGGL((k_rows<false>), dim3(grid_for(n)), dim3(kBlock), 0, st, c->view(), c->vdof.p, n, edge_view(c), center_view(c),
+                              (const double *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr, counts.p,
+                              (double *)nullptr, err.p, (const int32_t *)nullptr);
+    int e = 0;
+    AVS_TRY(read_err(err.p, st, &e));
+    AVS_REQUIRE(e == 0, AVS_EINTERNAL, "row assembly hit a reference assert (code %d)", e);
+    return AVS_OK;
+}
+
+avs_status build_system(avs_ctx *c)
+{
+    int64_t nnz = 0, nraw = 0;
+    AVS_TRY(assemble_rows(c, nullptr, c->n_vel, c->row_ptr, c->col, c->val, c->rhs, &nnz, &nraw));
+    c->nnz = nnz;
+    c->nraw = nraw;
     c->system_ready = true;
     c->solved = false;
     return AVS_OK;

@@ -68,6 +68,8 @@ struct PcgDist {
     DevBuf<double> val, rhs, x0, x;
     DevBuf<uint16_t> codes;   // value-indexed form of the local rows (shares the context's value table)
     DevBuf<uint32_t> packed;
+    DevBuf<double> table;     // own value table when the rank assembled its rows itself (avs_dist_assemble)
+    int table_size = 0;       // 0 = the context's table (partition of a replicated system)
     int col_bits = 0;
     bool value_indexed = false;
     PcgWork *pcg = nullptr;
@@ -527,6 +529,237 @@ static avs_status plan_on_device(avs_ctx *c, PcgDist *d, int cut_axis, int exten
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// Distributed assembly ("each GPU assembles the rows it owns").  Nothing global is built except what
+// is cheap and index-only: dof tables, stencils, restriction, the raw per-row triplet counts (slab weights) and the
+// brick-major permutation.  Each rank then assembles ITS rows (assemble_rows), renumbers their columns
+// reference id -> brick-major id -> local [owned | halo by owner], and derives its send lists from its own rows:
+// the matrix pattern is symmetric (every stress contributes d d^T), so "rank q reads my DOF i" <=> "my row i reads
+// a DOF of q".
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_da_planes(int64_t n, const int32_t *__restrict__ vdof, const int32_t *__restrict__ perm,
+                                                   const int32_t *__restrict__ raw_count, int axis, int extent, int shift, int nplanes,
+                                                   uint16_t *__restrict__ plane, unsigned long long *__restrict__ weight)
+{
+    __shared__ unsigned long long h[kPlanLdsPlanes];
+    const bool lds = nplanes <= kPlanLdsPlanes;
+    if (lds) {
+        for (int i = threadIdx.x; i < nplanes; i += 256) h[i] = 0ull;
+        __syncthreads();
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int32_t dof = perm[i];
+        const int pl = plane_of_dof(vdof, dof, axis, extent, shift);
+        plane[i] = (uint16_t)pl;
+        atomicAdd(lds ? &h[pl] : &weight[pl], (unsigned long long)raw_count[dof] + 2ull);
+    }
+    if (lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nplanes; i += 256)
+            if (h[i]) atomicAdd(&weight[i], h[i]);
+    }
+}
+
+// owned rows: columns reference id -> brick-major id (in place); marks halo columns and, per local row, the ranks
+// whose DOFs it reads (= the ranks that read this row's DOF)
+__global__ __launch_bounds__(256) void k_da_mark(int64_t n_own, const int32_t *__restrict__ row_ptr, int32_t *__restrict__ col,
+                                                 const int32_t *__restrict__ inv, const uint8_t *__restrict__ owner, int rank,
+                                                 uint8_t *__restrict__ is_halo, uint32_t *__restrict__ needed_by)
+{
+    const int sub = threadIdx.x & 15;
+    const int64_t group = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int64_t ngroups = ((int64_t)gridDim.x * 256) >> 4;
+    for (int64_t l = group; l < n_own; l += ngroups) {
+        uint32_t bits = 0u;
+        for (int k = row_ptr[l] + sub; k < row_ptr[l + 1]; k += 16) {
+            const int32_t cb = inv[col[k]];
+            col[k] = cb;
+            const int q = owner[cb];
+            if (q != rank) {
+                is_halo[cb] = 1; // same value from every writer
+                bits |= 1u << q;
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) bits |= __shfl_xor(bits, o, 16);
+        if (sub == 0) needed_by[l] = bits;
+    }
+}
+
+// brick-major column ids -> local ids; tile_bnd[tile] = 1 when a row of the tile reads a halo column
+__global__ __launch_bounds__(256) void k_da_localize(int64_t n_own, const int32_t *__restrict__ row_ptr, int32_t *__restrict__ col,
+                                                     const int32_t *__restrict__ g2l, int tile_rows, int32_t *__restrict__ tile_bnd)
+{
+    const int sub = threadIdx.x & 15;
+    const int64_t group = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int64_t ngroups = ((int64_t)gridDim.x * 256) >> 4;
+    for (int64_t l = group; l < n_own; l += ngroups) {
+        bool touches = false;
+        for (int k = row_ptr[l] + sub; k < row_ptr[l + 1]; k += 16) {
+            const int32_t lc = g2l[col[k]];
+            col[k] = lc;
+            touches |= lc >= n_own;
+        }
+        if (touches) tile_bnd[l / tile_rows] = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_da_flag_send(int64_t n_own, const uint32_t *__restrict__ needed_by, int q, int32_t *__restrict__ f)
+{
+    const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (l < n_own) f[l] = (needed_by[l] >> q) & 1u;
+}
+
+static avs_status dist_assemble_device(avs_ctx *c, PcgDist *d, int cut_axis, int extent)
+{
+    hipStream_t st = c->stream;
+    const int64_t n = c->n_vel;
+    const int rank = d->rank, world = d->world;
+    AVS_REQUIRE(world <= 32, AVS_EINVAL, "at most 32 ranks");
+    const int shift = c->desc.levels - 1;
+    const int nplanes = (extent + (1 << shift) - 1) >> shift;
+    AVS_REQUIRE(nplanes <= 65535, AVS_EINVAL, "too many cut planes");
+
+    // global, index-only: raw triplet count per row (weights) and the brick-major permutation
+    DevBuf<int32_t> raw_count;
+    AVS_TRY(count_raw_rows(c, raw_count));
+    AVS_TRY(build_brick_permutation(c, c->brick_shift));
+
+    DevBuf<uint16_t> plane;
+    DevBuf<unsigned long long> weight;
+    DevBuf<int32_t> plane_owner, flag, pos, g2l, scan_tmp, halo_tmp, ids;
+    DevBuf<uint8_t> owner, is_halo;
+    DevBuf<uint32_t> needed_by;
+    AVS_TRY(plane.alloc((size_t)n));
+    AVS_TRY(weight.alloc((size_t)nplanes));
+    AVS_TRY(plane_owner.alloc((size_t)nplanes));
+    AVS_TRY(flag.alloc((size_t)n + 1));
+    AVS_TRY(pos.alloc((size_t)n + 1));
+    AVS_TRY(g2l.alloc((size_t)n));
+    AVS_TRY(scan_tmp.alloc(scan_tmp_elems(n + 1)));
+    AVS_TRY(owner.alloc((size_t)n));
+    AVS_TRY(is_halo.alloc((size_t)n));
+    AVS_HIP(hipMemsetAsync(weight.p, 0, (size_t)nplanes * sizeof(unsigned long long), st));
+    AVS_HIP(hipMemsetAsync(is_halo.p, 0, (size_t)n, st));
+    AVS_HIP(hipMemsetAsync(g2l.p, 0xFF, (size_t)n * sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_da_planes, dim3(2048), dim3(256), 0, st, n, c->vdof.p, c->perm.p, raw_count.p, cut_axis, extent, shift, nplanes,
+                       plane.p, weight.p);
+    std::vector<unsigned long long> h_w((size_t)nplanes);
+    AVS_HIP(hipMemcpyAsync(h_w.data(), weight.p, h_w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipStreamSynchronize(st));
+    std::vector<int64_t> h_w64(h_w.begin(), h_w.end());
+    std::vector<int> h_po((size_t)nplanes);
+    plane_owners_from_weights(h_w64.data(), nplanes, world, h_po.data());
+    AVS_HIP(hipMemcpyAsync(plane_owner.p, h_po.data(), h_po.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_plan_owner, dim3(grid256(n)), dim3(256), 0, st, n, plane.p, plane_owner.p, rank, owner.p, flag.p);
+
+    // owned rows (ascending brick-major id) and the DOFs behind them
+    int64_t n_own = 0;
+    AVS_TRY(scan_flags(flag.p, pos.p, n, scan_tmp, &n_own, st));
+    AVS_TRY(d->own_global.alloc((size_t)n_own));
+    AVS_TRY(ids.alloc((size_t)n_own));
+    hipLaunchKernelGGL(k_plan_scatter, dim3(grid256(n)), dim3(256), 0, st, n, flag.p, pos.p, (const int32_t *)nullptr, d->own_global.p,
+                       g2l.p, 0);
+    if (n_own) hipLaunchKernelGGL(k_gather_i<int32_t>, dim3(grid256(n_own)), dim3(256), 0, st, c->perm.p, d->own_global.p, ids.p, n_own);
+
+    // this rank's rows, columns still in the reference numbering
+    int64_t nnz_local = 0;
+    AVS_TRY(assemble_rows(c, ids.p, n_own, d->row_ptr, d->col, d->val, d->rhs, &nnz_local, nullptr));
+    AVS_TRY(needed_by.alloc((size_t)n_own));
+    if (n_own) hipLaunchKernelGGL(k_da_mark, dim3(8192), dim3(256), 0, st, n_own, d->row_ptr.p, d->col.p, c->inv.p, owner.p, rank, is_halo.p,
+                                  needed_by.p);
+
+    // halo numbering (grouped by owner, ascending) and send lists (ascending owned rows that read a DOF of q)
+    std::vector<int64_t> recv_cnt((size_t)world, 0), send_cnt((size_t)world, 0);
+    AVS_TRY(halo_tmp.alloc((size_t)n));
+    int64_t n_halo = 0, n_send = 0;
+    for (int q = 0; q < world; ++q) {
+        if (q == rank) continue;
+        hipLaunchKernelGGL(k_plan_flag_halo, dim3(grid256(n)), dim3(256), 0, st, n, is_halo.p, owner.p, q, flag.p);
+        AVS_TRY(scan_flags(flag.p, pos.p, n, scan_tmp, &recv_cnt[(size_t)q], st));
+        if (recv_cnt[(size_t)q])
+            hipLaunchKernelGGL(k_plan_scatter, dim3(grid256(n)), dim3(256), 0, st, n, flag.p, pos.p, (const int32_t *)nullptr,
+                               halo_tmp.p, g2l.p, (int32_t)(n_own + n_halo));
+        n_halo += recv_cnt[(size_t)q];
+    }
+    for (int q = 0; q < world; ++q) {
+        if (q == rank || !n_own) continue;
+        hipLaunchKernelGGL(k_da_flag_send, dim3(grid256(n_own)), dim3(256), 0, st, n_own, needed_by.p, q, flag.p);
+        AVS_TRY(scan_flags(flag.p, pos.p, n_own, scan_tmp, &send_cnt[(size_t)q], st));
+        n_send += send_cnt[(size_t)q];
+    }
+    AVS_TRY(d->send_idx.alloc((size_t)n_send));
+    AVS_TRY(d->sendbuf.alloc((size_t)n_send));
+    {
+        int64_t off = 0;
+        for (int q = 0; q < world; ++q) {
+            if (q == rank || !send_cnt[(size_t)q]) continue;
+            hipLaunchKernelGGL(k_da_flag_send, dim3(grid256(n_own)), dim3(256), 0, st, n_own, needed_by.p, q, flag.p);
+            AVS_TRY(exclusive_scan_i32(flag.p, pos.p, n_own, scan_tmp.p, scan_tmp.n, st));
+            hipLaunchKernelGGL(k_plan_scatter, dim3(grid256(n_own)), dim3(256), 0, st, n_own, flag.p, pos.p, (const int32_t *)nullptr,
+                               d->send_idx.p + off, (int32_t *)nullptr, 0); // local row index == local DOF index
+            off += send_cnt[(size_t)q];
+        }
+    }
+    d->peers.clear();
+    d->send_counts.clear();
+    d->recv_counts.clear();
+    for (int q = 0; q < world; ++q)
+        if (q != rank && (send_cnt[(size_t)q] || recv_cnt[(size_t)q])) {
+            d->peers.push_back(q);
+            d->send_counts.push_back((int32_t)send_cnt[(size_t)q]);
+            d->recv_counts.push_back((int32_t)recv_cnt[(size_t)q]);
+        }
+
+    // local column ids + tile lists
+    const int T = spmv_tile_rows();
+    const int64_t ntiles = (n_own + T - 1) / T;
+    DevBuf<int32_t> tile_bnd, tile_int, tile_pos;
+    AVS_TRY(tile_bnd.alloc((size_t)ntiles + 1));
+    AVS_TRY(tile_int.alloc((size_t)ntiles + 1));
+    AVS_TRY(tile_pos.alloc((size_t)ntiles + 1));
+    AVS_HIP(hipMemsetAsync(tile_bnd.p, 0, ((size_t)ntiles + 1) * 4, st));
+    if (n_own) hipLaunchKernelGGL(k_da_localize, dim3(8192), dim3(256), 0, st, n_own, d->row_ptr.p, d->col.p, g2l.p, T, tile_bnd.p);
+    int64_t n_bnd = 0, n_int = 0;
+    AVS_TRY(scan_flags(tile_bnd.p, tile_pos.p, ntiles, scan_tmp, &n_bnd, st));
+    AVS_TRY(d->tiles_bnd.alloc((size_t)n_bnd));
+    if (n_bnd)
+        hipLaunchKernelGGL(k_plan_scatter, dim3(grid256(ntiles)), dim3(256), 0, st, ntiles, tile_bnd.p, tile_pos.p, (const int32_t *)nullptr,
+                           d->tiles_bnd.p, (int32_t *)nullptr, 0);
+    if (ntiles) hipLaunchKernelGGL(k_plan_not, dim3(grid256(ntiles)), dim3(256), 0, st, ntiles, tile_bnd.p, tile_int.p);
+    AVS_TRY(scan_flags(tile_int.p, tile_pos.p, ntiles, scan_tmp, &n_int, st));
+    AVS_TRY(d->tiles_int.alloc((size_t)n_int));
+    if (n_int)
+        hipLaunchKernelGGL(k_plan_scatter, dim3(grid256(ntiles)), dim3(256), 0, st, ntiles, tile_int.p, tile_pos.p, (const int32_t *)nullptr,
+                           d->tiles_int.p, (int32_t *)nullptr, 0);
+
+    // warm start of the owned DOFs
+    AVS_TRY(d->x0.alloc((size_t)n_own));
+    AVS_TRY(d->x.alloc((size_t)n_own));
+    if (n_own) hipLaunchKernelGGL(k_gather_i<double>, dim3(grid256(n_own)), dim3(256), 0, st, c->x0.p, ids.p, d->x0.p, n_own);
+    AVS_HIP(hipGetLastError());
+    AVS_HIP(hipStreamSynchronize(st)); // temporaries die here
+    d->n_tiles_int = (int)n_int;
+    d->n_tiles_bnd = (int)n_bnd;
+    d->n_own = n_own;
+    d->n_halo = n_halo;
+    d->n_send = n_send;
+    d->nnz_local = nnz_local;
+    return AVS_OK;
+}
+
+// storage form of the rank's local rows (avs_get_matrix_format when no global matrix exists)
+bool dist_matrix_format(avs_ctx *c, avs_matrix_format *fmt)
+{
+    PcgDist *d = c->dist;
+    if (!d || !d->partitioned) return false;
+    fmt->reordered = d->reordered ? 1 : 0;
+    fmt->value_table_size = d->value_indexed ? (d->table_size > 0 ? d->table_size : c->v_table_size) : 0;
+    fmt->column_bits = d->value_indexed ? d->col_bits : 0;
+    fmt->bytes_per_nonzero = !d->value_indexed ? 12 : (d->col_bits > 0 ? 4 : 6);
+    return true;
+}
+
 // the host planner (avs_partition.cpp) on a downloaded copy of the pattern: reference for the device planner
 static avs_status plan_on_host(avs_ctx *c, PcgDist *d, int cut_axis, int extent, bool ro)
 {
@@ -759,6 +992,79 @@ avs_status avs_dist_partition(avs_ctx *c, int32_t cut_axis)
     return AVS_OK;
 }
 
+avs_status avs_dist_assemble(avs_ctx *c, int32_t cut_axis, avs_assembly_info *info)
+{
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->dist, AVS_ESTATE, "call avs_dist_init / avs_dist_init_local first");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    PcgDist *d = c->dist;
+    hipStream_t st = c->stream;
+    if (cut_axis < 0) { // longest axis
+        cut_axis = 0;
+        if (c->desc.ny > c->desc.nx) cut_axis = 1;
+        if (c->desc.nz > (cut_axis == 0 ? c->desc.nx : c->desc.ny)) cut_axis = 2;
+    }
+    AVS_REQUIRE(cut_axis <= 2, AVS_EINVAL, "cut_axis out of range");
+    const int extent = cut_axis == 0 ? c->desc.nx : (cut_axis == 1 ? c->desc.ny : c->desc.nz);
+    Timer t(st);
+    avs_assembly_info ai{};
+    t.start();
+    AVS_TRY(build_stencils(c)); // dof tables + stencils: index-only and cheap, every rank builds all of them
+    ai.stencil_ms = t.stop();
+    t.start();
+    AVS_TRY(build_initial_guess(c));
+    ai.guess_ms = t.stop();
+    t.start();
+    c->system_ready = false; // no global matrix in this mode
+    c->reordered = false;
+    d->value_indexed = false;
+    d->col_bits = 0;
+    d->table_size = 0;
+    AVS_TRY(dist_assemble_device(c, d, cut_axis, extent));
+    ai.system_ms = t.stop();
+    t.start();
+    d->n_global = c->n_vel;
+    d->send_offs.assign(d->peers.size(), 0);
+    d->recv_offs.assign(d->peers.size(), 0);
+    {
+        int32_t so = 0, ro2 = 0;
+        for (size_t i = 0; i < d->peers.size(); ++i) {
+            d->send_offs[i] = so;
+            d->recv_offs[i] = ro2;
+            so += d->send_counts[i];
+            ro2 += d->recv_counts[i];
+        }
+    }
+    bool vi_on = true;
+    if (const char *e = getenv("AVS_VALUE_INDEX")) vi_on = atoi(e) != 0;
+    if (vi_on && d->nnz_local) { // the rank's own dictionary: its rows only hold a subset of the global values
+        AVS_TRY(build_value_index(d->val.p, d->nnz_local, d->codes, d->table, &d->table_size, st));
+        if (d->table_size > 0) {
+            AVS_TRY(build_packed_index(d->codes.p, d->col.p, d->nnz_local, d->n_own + d->n_halo, d->table_size, d->packed, &d->col_bits, st));
+            d->value_indexed = true;
+        }
+    }
+    if (!d->comm_stream) {
+        AVS_HIP(hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking));
+        AVS_HIP(hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming));
+        AVS_HIP(hipEventCreateWithFlags(&d->ev_halo, hipEventDisableTiming));
+    }
+    pcg_destroy(d->pcg);
+    d->pcg = nullptr;
+    AVS_TRY(pcg_create(&d->pcg, d->n_own, d->n_own + d->n_halo, st));
+    ai.csr_ms = t.stop();
+    d->partitioned = true;
+    d->reordered = true; // own_global holds brick-major ids: avs_dist_get_solution maps back through c->inv
+    d->solved = false;
+    ai.n_velocity = c->n_vel;
+    ai.n_edge = c->n_edge;
+    ai.n_center = c->n_center;
+    ai.nnz = d->nnz_local;
+    ai.raw_triplets = 0;
+    if (info) *info = ai;
+    return AVS_OK;
+}
+
 avs_status avs_dist_get_plan_sizes(avs_ctx *c, avs_plan_sizes *s)
 {
     AVS_REQUIRE(c && s, AVS_EINVAL, "null argument");
@@ -823,8 +1129,8 @@ avs_status avs_dist_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_i
     A.val = d->val.p;
     if (d->value_indexed) {
         A.codes = d->codes.p;
-        A.table = c->v_table.p;
-        A.table_size = c->v_table_size;
+        A.table = d->table_size > 0 ? d->table.p : c->v_table.p;
+        A.table_size = d->table_size > 0 ? d->table_size : c->v_table_size;
         if (d->col_bits > 0) {
             A.packed = d->packed.p;
             A.col_bits = d->col_bits;

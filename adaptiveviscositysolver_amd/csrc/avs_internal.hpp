@@ -120,6 +120,31 @@ struct StencilView { // SoA, entry k of stencil s at [k*count + s]
 // ---------------------------------------------------------------------------------------------
 // CSR system resident in HBM
 // ---------------------------------------------------------------------------------------------
+// HIP-event stopwatch on one stream
+struct Timer {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t s;
+    explicit Timer(hipStream_t st) : s(st)
+    {
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+    }
+    ~Timer()
+    {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+    void start() { (void)hipEventRecord(a, s); }
+    double stop()
+    {
+        (void)hipEventRecord(b, s);
+        (void)hipEventSynchronize(b);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, a, b);
+        return ms;
+    }
+};
+
 struct CsrView {
     int64_t n = 0, nnz = 0;
     const int32_t *row_ptr = nullptr;
@@ -157,6 +182,13 @@ avs_status stream_probe(int mode, const double *a, double *b, int64_t n, double 
 avs_status exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t *block_tmp, size_t block_tmp_elems,
                               hipStream_t stream);
 size_t scan_tmp_elems(int64_t n);
+bool dist_matrix_format(avs_ctx *c, avs_matrix_format *fmt); // avs_dist.hip: local rows of a partitioned / distributed system
+avs_status build_stencils(avs_ctx *c);
+avs_status build_initial_guess(avs_ctx *c);
+avs_status assemble_rows(avs_ctx *c, const int32_t *ids, int64_t m, DevBuf<int32_t> &row_ptr, DevBuf<int32_t> &col, DevBuf<double> &val,
+                         DevBuf<double> &rhs, int64_t *nnz_out, int64_t *nraw_out);
+avs_status count_raw_rows(avs_ctx *c, DevBuf<int32_t> &counts);
+avs_status build_brick_permutation(avs_ctx *c, int brick_shift); // c->perm / c->inv from the dof table alone
 void plane_owners_from_weights(const int64_t *weight, int nplanes, int world_size, int *plane_owner); // avs_partition.cpp
 
 // multi-GPU hooks called from pcg_solve (implemented in avs_dist.hip)

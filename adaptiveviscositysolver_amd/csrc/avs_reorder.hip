@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kBlock) void k_invert(const int32_t *__restrict__ p
     if (i >= n) return;
     const int32_t old = perm[i];
     inv[old] = (int32_t)i;
-    len_new[i] = row_ptr[old + 1] - row_ptr[old];
+    if (row_ptr) len_new[i] = row_ptr[old + 1] - row_ptr[old];
 }
 
 __global__ __launch_bounds__(kBlock) void k_permute_rows(int64_t n, const int32_t *__restrict__ perm, const int32_t *__restrict__ inv,
@@ -73,27 +73,19 @@ __global__ __launch_bounds__(kBlock) void k_gather_d(const double *__restrict__ 
 
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock > 0 ? (n + kBlock - 1) / kBlock : 1); }
 
-// builds c->perm / c->inv and the permuted system (c->p_*)
-avs_status build_reordered_system(avs_ctx *c, int brick_shift)
+// c->perm (new -> reference id) / c->inv from the dof table alone: stable radix sort of the brick keys
+avs_status build_brick_permutation(avs_ctx *c, int brick_shift)
 {
     hipStream_t st = c->stream;
-    const int64_t n = c->n_vel, nnz = c->nnz;
-    AVS_REQUIRE(c->system_ready, AVS_ESTATE, "system not assembled");
+    const int64_t n = c->n_vel;
     DevBuf<uint32_t> keys_in, keys_out;
-    DevBuf<int32_t> ids_in, len_new, scan_tmp;
+    DevBuf<int32_t> ids_in;
     AVS_TRY(keys_in.alloc((size_t)n));
     AVS_TRY(keys_out.alloc((size_t)n));
     AVS_TRY(ids_in.alloc((size_t)n));
-    AVS_TRY(len_new.alloc((size_t)n + 1));
-    AVS_TRY(scan_tmp.alloc(scan_tmp_elems(n)));
     AVS_TRY(c->perm.alloc((size_t)n));
     AVS_TRY(c->inv.alloc((size_t)n));
-    AVS_TRY(c->p_row_ptr.alloc((size_t)n + 1));
-    AVS_TRY(c->p_col.alloc((size_t)nnz));
-    AVS_TRY(c->p_val.alloc((size_t)nnz));
-    AVS_TRY(c->p_rhs.alloc((size_t)n));
-    AVS_TRY(c->p_x0.alloc((size_t)n));
-    if (n == 0) { c->reordered = true; return AVS_OK; }
+    if (n == 0) return AVS_OK;
     hipLaunchKernelGGL(k_brick_keys, dim3(grid_for(n)), dim3(kBlock), 0, st, c->vdof.p, n, c->desc.nx, c->desc.ny, c->desc.nz,
                        brick_shift, keys_in.p, ids_in.p);
     size_t tmp_bytes = 0;
@@ -101,6 +93,29 @@ avs_status build_reordered_system(avs_ctx *c, int brick_shift)
     DevBuf<char> tmp;
     AVS_TRY(tmp.alloc(tmp_bytes));
     AVS_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_in.p, keys_out.p, ids_in.p, c->perm.p, (size_t)n, 0, 32, st)); // stable
+    hipLaunchKernelGGL(k_invert, dim3(grid_for(n)), dim3(kBlock), 0, st, c->perm.p, n, c->inv.p, (const int32_t *)nullptr,
+                       (int32_t *)nullptr);
+    AVS_HIP(hipGetLastError());
+    AVS_HIP(hipStreamSynchronize(st)); // temporaries die here
+    return AVS_OK;
+}
+
+// builds c->perm / c->inv and the permuted system (c->p_*)
+avs_status build_reordered_system(avs_ctx *c, int brick_shift)
+{
+    hipStream_t st = c->stream;
+    const int64_t n = c->n_vel, nnz = c->nnz;
+    AVS_REQUIRE(c->system_ready, AVS_ESTATE, "system not assembled");
+    DevBuf<int32_t> len_new, scan_tmp;
+    AVS_TRY(len_new.alloc((size_t)n + 1));
+    AVS_TRY(scan_tmp.alloc(scan_tmp_elems(n)));
+    AVS_TRY(build_brick_permutation(c, brick_shift));
+    AVS_TRY(c->p_row_ptr.alloc((size_t)n + 1));
+    AVS_TRY(c->p_col.alloc((size_t)nnz));
+    AVS_TRY(c->p_val.alloc((size_t)nnz));
+    AVS_TRY(c->p_rhs.alloc((size_t)n));
+    AVS_TRY(c->p_x0.alloc((size_t)n));
+    if (n == 0) { c->reordered = true; return AVS_OK; }
     hipLaunchKernelGGL(k_invert, dim3(grid_for(n)), dim3(kBlock), 0, st, c->perm.p, n, c->inv.p, c->row_ptr.p, len_new.p);
     AVS_TRY(exclusive_scan_i32(len_new.p, c->p_row_ptr.p, n, scan_tmp.p, scan_tmp.n, st));
     hipLaunchKernelGGL(k_permute_rows, dim3(8192), dim3(kBlock), 0, st, n, c->perm.p, c->inv.p, c->row_ptr.p, c->col.p, c->val.p,

@@ -170,6 +170,19 @@ class ViscositySolve:
         self.overlap_tiles = (ti.value, tb.value)
         return sz
 
+    def dist_assemble(self, cut_axis=-1):
+        """Distributed assembly: this rank assembles only the rows of its slab (instead of assemble + dist_partition)."""
+        info = capi.AssemblyInfo()
+        capi.check(self.lib.avs_dist_assemble(self.h, cut_axis, C.byref(info)))
+        sz = capi.PlanSizes()
+        capi.check(self.lib.avs_dist_get_plan_sizes(self.h, C.byref(sz)))
+        self.plan_sizes = sz
+        self.local_spmv_bytes = 12 * sz.nnz_local + 4 * (sz.n_own + 1) + 16 * sz.n_own
+        ti, tb = C.c_int32(), C.c_int32()
+        capi.check(self.lib.avs_dist_get_overlap_tiles(self.h, C.byref(ti), C.byref(tb)))
+        self.overlap_tiles = (ti.value, tb.value)
+        return info
+
     def dist_solve(self, tol=1e-3, max_iters=2500):
         info = capi.SolveInfo()
         capi.check(self.lib.avs_dist_solve(self.h, float(tol), int(max_iters), C.byref(info)))

@@ -303,6 +303,13 @@ avs_status avs_dist_init_local(avs_ctx *ctx, avs_local_group *group, int32_t ran
  * device from the CSR in HBM; AVS_DIST_PLAN=host runs the host planner above on a downloaded copy instead
  * (identical arrays, kept as the reference for tests). */
 avs_status avs_dist_partition(avs_ctx *ctx, int32_t cut_axis);
+/* Distributed assembly ("each GPU assembles the rows it owns"): replaces avs_assemble + avs_dist_partition.
+ * Every rank builds the cheap index-only pieces for the whole octree (dof tables, stress stencils, restriction, raw
+ * triplet counts, brick-major permutation), picks the same slab cuts (balanced by raw triplet counts), then assembles,
+ * sorts and compresses ONLY its own rows, and derives halo / send lists from them (the pattern is symmetric).  No
+ * global matrix exists afterwards: avs_get_csr / avs_solve are unavailable, avs_dist_solve / avs_dist_get_solution work
+ * as after avs_dist_partition.  info->nnz is the LOCAL non-zero count. */
+avs_status avs_dist_assemble(avs_ctx *ctx, int32_t cut_axis, avs_assembly_info *info /* may be NULL */);
 avs_status avs_dist_get_plan_sizes(avs_ctx *ctx, avs_plan_sizes *sizes);
 /* rows per SpMV tile (workgroup) of the solver's default kernel */
 int32_t avs_spmv_tile_rows(void);
