@@ -260,10 +260,11 @@ __global__ __launch_bounds__(kBlock) void k_center_stencils(PyramidView P, const
 // (child, in-axis offset) order per level, which is the order of the mixed-radix counter below.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_initial_guess(PyramidView P, const int32_t *__restrict__ vdof, int64_t n,
-                                                          double *__restrict__ x0)
+                                                          double *__restrict__ x0, const int32_t *__restrict__ ids)
 {
-    const int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (id >= n) return;
+    const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= n) return;
+    const int64_t id = ids ? ids[slot] : slot; // multi-GPU: only the DOFs this rank owns (x0 stays indexed by DOF)
     const int4 rec = reinterpret_cast<const int4 *>(vdof)[id];
     const int level = rec.x & 0xff, axis = rec.x >> 8;
     const I3 face{{rec.y, rec.z, rec.w}};
@@ -906,7 +907,20 @@ avs_status build_initial_guess(avs_ctx *c)
 {
     if (!c->tables_ready) AVS_TRY(build_dof_tables(c));
     AVS_TRY(c->x0.alloc((size_t)c->n_vel));
-    if (c->n_vel) hipLaunchKernelGGL(k_initial_guess, dim3(grid_for(c->n_vel)), dim3(kBlock), 0, c->stream, c->view(), c->vdof.p, c->n_vel, c->x0.p);
+    if (c->n_vel) hipLaunchKernelGGL(k_initial_guess, dim3(grid_for(c->n_vel)), dim3(kBlock), 0, c->stream, c->view(), c->vdof.p, c->n_vel, c->x0.p,
+                                     (const int32_t *)nullptr);
+    AVS_HIP(hipGetLastError());
+    c->guess_ready = true;
+    return AVS_OK;
+}
+
+// restriction for the DOFs `ids[0..m)` only; the other entries of x0 are zero and must not be read
+avs_status build_initial_guess_rows(avs_ctx *c, const int32_t *ids, int64_t m)
+{
+    if (!c->tables_ready) AVS_TRY(build_dof_tables(c));
+    AVS_TRY(c->x0.alloc((size_t)c->n_vel));
+    AVS_HIP(hipMemsetAsync(c->x0.p, 0, (size_t)c->n_vel * sizeof(double), c->stream));
+    if (m) hipLaunchKernelGGL(k_initial_guess, dim3(grid_for(m)), dim3(kBlock), 0, c->stream, c->view(), c->vdof.p, m, c->x0.p, ids);
     AVS_HIP(hipGetLastError());
     c->guess_ready = true;
     return AVS_OK;

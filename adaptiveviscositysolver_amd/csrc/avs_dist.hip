@@ -662,7 +662,9 @@ static avs_status dist_assemble_device(avs_ctx *c, PcgDist *d, int cut_axis, int
                        g2l.p, 0);
     if (n_own) hipLaunchKernelGGL(k_gather_i<int32_t>, dim3(grid256(n_own)), dim3(256), 0, st, c->perm.p, d->own_global.p, ids.p, n_own);
 
-    // this rank's rows, columns still in the reference numbering
+    // restriction (warm start, also the mass term of the right-hand side) and rows of this rank only;
+    // columns still in the reference numbering
+    AVS_TRY(build_initial_guess_rows(c, ids.p, n_own));
     int64_t nnz_local = 0;
     AVS_TRY(assemble_rows(c, ids.p, n_own, d->row_ptr, d->col, d->val, d->rhs, &nnz_local, nullptr));
     AVS_TRY(needed_by.alloc((size_t)n_own));
@@ -1011,9 +1013,7 @@ avs_status avs_dist_assemble(avs_ctx *c, int32_t cut_axis, avs_assembly_info *in
     t.start();
     AVS_TRY(build_stencils(c)); // dof tables + stencils: index-only and cheap, every rank builds all of them
     ai.stencil_ms = t.stop();
-    t.start();
-    AVS_TRY(build_initial_guess(c));
-    ai.guess_ms = t.stop();
+    ai.guess_ms = 0.; // the restriction of the owned DOFs is part of system_ms here
     t.start();
     c->system_ready = false; // no global matrix in this mode
     c->reordered = false;

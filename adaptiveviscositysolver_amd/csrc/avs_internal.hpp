@@ -185,6 +185,7 @@ size_t scan_tmp_elems(int64_t n);
 bool dist_matrix_format(avs_ctx *c, avs_matrix_format *fmt); // avs_dist.hip: local rows of a partitioned / distributed system
 avs_status build_stencils(avs_ctx *c);
 avs_status build_initial_guess(avs_ctx *c);
+avs_status build_initial_guess_rows(avs_ctx *c, const int32_t *ids, int64_t m);
 avs_status assemble_rows(avs_ctx *c, const int32_t *ids, int64_t m, DevBuf<int32_t> &row_ptr, DevBuf<int32_t> &col, DevBuf<double> &val,
                          DevBuf<double> &rhs, int64_t *nnz_out, int64_t *nraw_out);
 avs_status count_raw_rows(avs_ctx *c, DevBuf<int32_t> &counts);
