@@ -202,3 +202,35 @@ def test_distributed_assembly_matches_single_solve(world, cut_axis, scene, built
         s.close()
     ref.close()
     lib.avs_local_group_destroy(grp)
+
+
+def test_distributed_assembly_call_order(built_lib):
+    """Call-sequence errors are reported, not crashed on (avs_status AVS_ESTATE)."""
+    dev = torch.device("cuda:0")
+    sc = scenes.fat_beam(32, 3, device=dev)
+    pyr = prepass.build_pyramid(sc)
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
+    s.set_pyramid(pyr)
+    s.set_scene_fields(sc)
+    with pytest.raises(capi.AvsError) as e:          # no communicator yet
+        s.dist_assemble()
+    assert e.value.status == capi.ESTATE
+    lib = capi.load()
+    grp = C.c_void_p()
+    capi.check(lib.avs_local_group_create(1, C.byref(grp)))
+    s.dist_init_local(grp, 0)
+    with pytest.raises(capi.AvsError) as e:          # nothing assembled: no partitioned system to solve
+        s.dist_solve(1e-6, 10)
+    assert e.value.status == capi.ESTATE
+    s.dist_assemble()
+    for call in (s.solve, s.csr, lambda: s.bench_spmv(0, 1)):   # the global matrix does not exist in this mode
+        with pytest.raises(capi.AvsError) as e:
+            call()
+        assert e.value.status == capi.ESTATE
+    info = s.dist_solve(1e-8, 2000)
+    assert info.converged == 1
+    s.assemble()                                     # back to the single-GPU path on the same context
+    ref = s.solve(1e-8, 2000)
+    assert abs(ref.iterations - info.iterations) <= 2
+    s.close()
+    lib.avs_local_group_destroy(grp)
