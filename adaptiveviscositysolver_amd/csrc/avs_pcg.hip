@@ -27,6 +27,7 @@ static constexpr int kBlock = 256;
 static constexpr int kVecGrid = 2048;        // grid-stride vector kernels: 8 blocks per CU
 static constexpr int kStreamCap = 4096;      // LDS products per tile (32 KiB)
 static constexpr int kChunk = 32;            // iterations enqueued between host polls
+static constexpr int kTimedChunkEvery = 8; // hipGraph replay: 1 chunk in 8 is enqueued launch by launch with timing events
 static constexpr int kSampleEvery = 4;       // SpMV launches bracketed by HIP events: every 4th (events are not free)
 
 struct PcgScalars {
@@ -1262,10 +1263,11 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
         }
         if (w->host_sc->done || enqueued >= max_iters) break;
         const int chunk = (max_iters - enqueued) < kChunk ? (max_iters - enqueued) : kChunk;
-        // the first chunk is enqueued launch by launch with the SpMV timing events; later full chunks replay one captured
+        // some chunks are enqueued launch by launch with the SpMV timing events; the other full chunks replay one captured
         // hipGraph (5 kernel nodes per iteration): no per-launch host work, smaller gaps between the short kernels of small
         // systems.  Kernels past convergence exit at once, so replaying a whole chunk is always safe.
-        const bool replay = use_graph && enqueued > 0 && chunk == kChunk && !w->graph_broken;
+        // every kTimedChunkEvery-th chunk stays a plain, timed one so that the SpMV samples cover the whole solve
+        const bool replay = use_graph && (enqueued / kChunk) % kTimedChunkEvery != 0 && chunk == kChunk && !w->graph_broken;
         timed_chunk = !replay;
         if (replay) {
             const void *key[10] = {A.row_ptr, A.col, A.val, A.codes, A.packed, A.table, x, (const void *)(intptr_t)A.n,
