@@ -283,3 +283,22 @@ def test_fields_on_a_smaller_simulation_grid(dev, built_lib):
     s.close()
     with pytest.raises(capi.AvsError):                  # a simulation grid larger than the octree grid is rejected
         ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0, field_res=(65, 64, 64))
+
+
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_solve_is_deterministic(graph, dev, built_lib, monkeypatch):
+    """All reductions use fixed orders (block partials folded in index order, multi-block fold in block order, DPP wave
+    sums): repeating a solve -- with or without hipGraph replay -- reproduces the solution bit for bit."""
+    monkeypatch.setenv("AVS_PCG_GRAPH", graph)
+    sc = scenes.fat_beam(128, 3, device=dev)          # 380 k rows: multi-block reduction and graph replay both active
+    pyr = prepass.build_pyramid(sc)
+    s = gpu_solve_for(sc, pyr)
+    s.assemble()
+    runs = []
+    for _ in range(3):
+        info = s.solve(1e-8, 5000)
+        runs.append((info.iterations, info.error, s.solution()))
+    for it, err, x in runs[1:]:
+        assert it == runs[0][0] and err == runs[0][1]
+        assert np.array_equal(x, runs[0][2])
+    s.close()
