@@ -938,6 +938,36 @@ __global__ void k_scalar(PcgScalars *sc, int op, double tol)
     if (threadIdx.x == 0 && blockIdx.x == 0) apply_scalar_op(sc, op, tol);
 }
 
+// two partial sets in one launch (multi-GPU loop: its iterations are launch-bound, every launch saved counts):
+// red[0 .. nredA) from A, red[nredA .. nredA + nredB) from B
+__global__ __launch_bounds__(kRedBlock) void k_reduce_pair(const double *__restrict__ pa, int nba, int nreda, const double *__restrict__ pb,
+                                                          int nbb, int nredb, PcgScalars *sc)
+{
+    __shared__ double red[kRedBlock / 64];
+    for (int q = 0; q < nreda + nredb; ++q) {
+        const bool first = q < nreda;
+        const int nb = first ? nba : nbb;
+        const double *src = first ? pa + (size_t)q * nba : pb + (size_t)(q - nreda) * nbb;
+        double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
+        int i = threadIdx.x;
+        for (; i + 3 * kRedBlock < nb; i += 4 * kRedBlock) {
+            const double a = src[i], b = src[i + kRedBlock], c = src[i + 2 * kRedBlock], d = src[i + 3 * kRedBlock];
+            s0 += a; s1 += b; s2 += c; s3 += d;
+        }
+        for (; i < nb; i += kRedBlock) s0 += src[i];
+        double s = wave_sum((s0 + s1) + (s2 + s3));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.;
+#pragma unroll
+            for (int w = 0; w < kRedBlock / 64; ++w) t += red[w];
+            sc->red[q] = t;
+        }
+    }
+}
+
 static void reduce_launch(PcgWork *w, const double *partial, int nb, int nred, PcgScalars *sc, int op, double tol, int skip_if_done,
                           int red_off, hipStream_t stream)
 {
@@ -983,20 +1013,45 @@ __global__ __launch_bounds__(kBlock) void k_sr_init(int64_t n, const double *__r
     }
 }
 
+// The scalar step of the previous iteration (OP_SR_STEP on the all-reduced sums) is folded into the start of this
+// kernel when `step` is set: every workgroup computes the same new scalars from state `in`, workgroup 0 stores them as
+// state `out` (a different PcgScalars: nobody reads what is being written) -- one launch less per iteration of a loop
+// that is launch-bound at 8 GPUs.  in == out and step == 0: scalars are used as they are.
 __global__ __launch_bounds__(kBlock) void k_sr_update(int64_t n, double *__restrict__ x, double *__restrict__ r,
                                                       double *__restrict__ p, double *__restrict__ s,
                                                       double *__restrict__ u, const double *__restrict__ w,
-                                                      const double *__restrict__ invd, const PcgScalars *sc,
-                                                      double *__restrict__ partial)
+                                                      const double *__restrict__ invd, const PcgScalars *in, PcgScalars *out,
+                                                      int step, double *__restrict__ partial)
 {
-    const int done = sc->done;
+    int done = in->done;
+    double alpha = in->alpha, beta = in->beta;
+    if (step) {
+        double rr = in->rr, rho = in->rho;
+        int iter = in->iter;
+        if (!done) { // OP_SR_STEP, red = [r.u, r.r, w.u]
+            rr = in->red[1];
+            if (in->red[1] < in->threshold) done = 1;
+            else {
+                const double gamma = in->red[0], delta = in->red[2];
+                const double b2 = gamma / rho;
+                alpha = gamma / (delta - b2 * gamma / alpha);
+                beta = b2;
+                rho = gamma;
+                iter += 1;
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            PcgScalars o = *in;
+            o.rr = rr; o.rho = rho; o.alpha = alpha; o.beta = beta; o.iter = iter; o.done = done;
+            *out = o;
+        }
+    }
     if (done == 3) {
         for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) x[i] = 0.;
         return;
     }
     if (done) return;
     __shared__ double red[4];
-    const double alpha = sc->alpha, beta = sc->beta;
     double ru = 0., rr = 0.;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const double pi = u[i] + beta * p[i];
@@ -1031,10 +1086,11 @@ static avs_status pcg_solve_single_reduction(PcgWork *w, const CsrView &A, const
     double *p = w->p.p, *r = w->r.p, *wv = w->t.p, *sv = w->s.p, *u = w->u.p, *invd = w->invd.p;
     double *pvec = w->partial.p;                        // 3 * g vector-kernel partials
     double *pspmv = w->partial.p + 4 * (size_t)kVecGrid; // SpMV partials behind them
-    PcgScalars *sc = w->sc.p;
-    auto red_of = [&](int k) { return reinterpret_cast<double *>(reinterpret_cast<char *>(sc) + offsetof(PcgScalars, red)) + k; };
+    PcgScalars *sc = w->sc.p; // two states, ping-pong: sc[cur] is current, k_sr_update writes sc[cur ^ 1]
+    int cur = 0;
+    auto red_of = [&](int k) { return reinterpret_cast<double *>(reinterpret_cast<char *>(sc + cur) + offsetof(PcgScalars, red)) + k; };
 
-    AVS_HIP(hipMemsetAsync(sc, 0, sizeof(PcgScalars), stream));
+    AVS_HIP(hipMemsetAsync(sc, 0, 2 * sizeof(PcgScalars), stream));
     AVS_HIP(hipMemsetAsync(p, 0, (size_t)w->n_ext * sizeof(double), stream));
     AVS_HIP(hipMemsetAsync(sv, 0, (size_t)n * sizeof(double), stream));
     hipLaunchKernelGGL(k_inv_diag, dim3(rowgrid), dim3(kBlock), 0, stream, A, invd);
@@ -1056,7 +1112,7 @@ static avs_status pcg_solve_single_reduction(PcgWork *w, const CsrView &A, const
     int enqueued = 0, last_chunk = 0, spmv_samples = 0;
     double spmv_ms_sum = 0.;
     while (true) {
-        AVS_HIP(hipMemcpyAsync(w->host_sc, sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, stream));
+        AVS_HIP(hipMemcpyAsync(w->host_sc, sc + cur, sizeof(PcgScalars), hipMemcpyDeviceToHost, stream));
         AVS_HIP(hipStreamSynchronize(stream));
         if (info && last_chunk > 0) {
             const int ran = w->host_sc->iter + (w->host_sc->done ? 1 : 0);
@@ -1069,7 +1125,13 @@ static avs_status pcg_solve_single_reduction(PcgWork *w, const CsrView &A, const
         if (w->host_sc->done || enqueued >= max_iters) break;
         const int chunk = (max_iters - enqueued) < kChunk ? (max_iters - enqueued) : kChunk;
         for (int c = 0; c < chunk; ++c) {
-            hipLaunchKernelGGL(k_sr_update, dim3(g), dim3(kBlock), 0, stream, n, x, r, p, sv, u, wv, invd, sc, pvec);
+            // first iteration of a chunk: scalars are final (SR_INIT or the explicit step below); afterwards the step of
+            // the previous iteration rides in k_sr_update, which moves the state to the other slot
+            const int step = c > 0 ? 1 : 0;
+            hipLaunchKernelGGL(k_sr_update, dim3(g), dim3(kBlock), 0, stream, n, x, r, p, sv, u, wv, invd, (const PcgScalars *)(sc + cur),
+                               sc + (step ? (cur ^ 1) : cur), step, pvec);
+            if (step) cur ^= 1;
+            const PcgScalars *now = sc + cur;
             const int32_t *t_int = nullptr, *t_bnd = nullptr;
             int n_int = 0, n_bnd = 0;
             if (variant == 24 && dist_tile_lists(dist, &t_int, &n_int, &t_bnd, &n_bnd)) {
@@ -1077,28 +1139,33 @@ static avs_status pcg_solve_single_reduction(PcgWork *w, const CsrView &A, const
                 // column are multiplied; the halo-touching tiles follow once the halo has landed
                 AVS_TRY(dist_halo_begin(dist, u, stream));
                 if (info) AVS_HIP(hipEventRecord(w->evA[c], stream));
-                AVS_TRY(spmv_dot_tiles(A, u, wv, pspmv, sc, t_int, n_int, stream));
+                AVS_TRY(spmv_dot_tiles(A, u, wv, pspmv, now, t_int, n_int, stream));
                 AVS_TRY(dist_halo_end(dist, stream));
-                AVS_TRY(spmv_dot_tiles(A, u, wv, pspmv, sc, t_bnd, n_bnd, stream));
+                AVS_TRY(spmv_dot_tiles(A, u, wv, pspmv, now, t_bnd, n_bnd, stream));
                 if (info) AVS_HIP(hipEventRecord(w->evB[c], stream));
                 nb = (n_int + n_bnd) * (A.codes ? kTileRows / 64 : 1); // value-indexed kernel: one partial per wave
             } else {
                 AVS_TRY(dist_halo_exchange(dist, u, stream));
                 if (info) AVS_HIP(hipEventRecord(w->evA[c], stream));
-                AVS_TRY(spmv_dispatch<true>(A, u, wv, pspmv, sc, variant, stream, &nb));
+                AVS_TRY(spmv_dispatch<true>(A, u, wv, pspmv, now, variant, stream, &nb));
                 if (info) AVS_HIP(hipEventRecord(w->evB[c], stream));
             }
-            reduce_launch(w, pvec, g, 2, sc, (int)OP_NONE, tol, 0, 0, stream);
-            reduce_launch(w, pspmv, nb, 1, sc, (int)OP_NONE, tol, 0, 2, stream);
+            if (nb < 16384) hipLaunchKernelGGL(k_reduce_pair, dim3(1), dim3(kRedBlock), 0, stream, pvec, g, 2, pspmv, nb, 1, sc + cur);
+            else {
+                reduce_launch(w, pvec, g, 2, sc + cur, (int)OP_NONE, tol, 0, 0, stream);
+                reduce_launch(w, pspmv, nb, 1, sc + cur, (int)OP_NONE, tol, 0, 2, stream);
+            }
             AVS_TRY(dist_allreduce(dist, red_of(0), 3, stream));
-            hipLaunchKernelGGL(k_scalar, dim3(1), dim3(64), 0, stream, sc, (int)OP_SR_STEP, tol);
         }
+        // the last iteration's step, explicitly: the host polls a final state
+        hipLaunchKernelGGL(k_scalar, dim3(1), dim3(64), 0, stream, sc + cur, (int)OP_SR_STEP, tol);
         AVS_HIP(hipGetLastError());
         enqueued += chunk;
         last_chunk = chunk;
     }
     if (w->host_sc->done == 3) { // rhs == 0: x := 0
-        hipLaunchKernelGGL(k_sr_update, dim3(g), dim3(kBlock), 0, stream, n, x, r, p, sv, u, wv, invd, sc, pvec);
+        hipLaunchKernelGGL(k_sr_update, dim3(g), dim3(kBlock), 0, stream, n, x, r, p, sv, u, wv, invd, (const PcgScalars *)(sc + cur), sc + cur, 0,
+                           pvec);
     }
     AVS_HIP(hipEventRecord(w->ev1, stream));
     AVS_HIP(hipEventSynchronize(w->ev1));
@@ -1128,7 +1195,7 @@ avs_status pcg_create(PcgWork **out, int64_t n, int64_t n_ext, hipStream_t)
     w->npartial = max_partials(n);
     avs_status s;
     if ((s = w->r.alloc((size_t)n)) || (s = w->p.alloc((size_t)n_ext)) || (s = w->t.alloc((size_t)n)) ||
-        (s = w->invd.alloc((size_t)n)) || (s = w->partial.alloc(w->npartial)) || (s = w->sc.alloc(1)) ||
+        (s = w->invd.alloc((size_t)n)) || (s = w->partial.alloc(w->npartial)) || (s = w->sc.alloc(2)) ||
         (s = w->stage.alloc((size_t)kRedBlocks * 4)) || (s = w->ticket.alloc(1))) {
         delete w;
         return s;
