@@ -1117,7 +1117,7 @@ static avs_status pcg_solve_single_reduction(PcgWork *w, const CsrView &A, const
         if (info && last_chunk > 0) {
             const int ran = w->host_sc->iter + (w->host_sc->done ? 1 : 0);
             const int first = enqueued - last_chunk;
-            for (int c2 = 0; c2 < last_chunk && first + c2 < ran; ++c2) {
+            for (int c2 = 0; c2 < last_chunk && first + c2 < ran; c2 += kSampleEvery) {
                 float ems = 0.f;
                 if (hipEventElapsedTime(&ems, w->evA[c2], w->evB[c2]) == hipSuccess) { spmv_ms_sum += ems; ++spmv_samples; }
             }
@@ -1128,6 +1128,7 @@ static avs_status pcg_solve_single_reduction(PcgWork *w, const CsrView &A, const
             // first iteration of a chunk: scalars are final (SR_INIT or the explicit step below); afterwards the step of
             // the previous iteration rides in k_sr_update, which moves the state to the other slot
             const int step = c > 0 ? 1 : 0;
+            const bool timed = info && (c % kSampleEvery == 0); // SpMV timing samples: every 4th iteration
             hipLaunchKernelGGL(k_sr_update, dim3(g), dim3(kBlock), 0, stream, n, x, r, p, sv, u, wv, invd, (const PcgScalars *)(sc + cur),
                                sc + (step ? (cur ^ 1) : cur), step, pvec);
             if (step) cur ^= 1;
@@ -1138,17 +1139,17 @@ static avs_status pcg_solve_single_reduction(PcgWork *w, const CsrView &A, const
                 // overlap: the exchange runs on the communication stream while the tiles that touch no halo
                 // column are multiplied; the halo-touching tiles follow once the halo has landed
                 AVS_TRY(dist_halo_begin(dist, u, stream));
-                if (info) AVS_HIP(hipEventRecord(w->evA[c], stream));
+                if (timed) AVS_HIP(hipEventRecord(w->evA[c], stream));
                 AVS_TRY(spmv_dot_tiles(A, u, wv, pspmv, now, t_int, n_int, stream));
                 AVS_TRY(dist_halo_end(dist, stream));
                 AVS_TRY(spmv_dot_tiles(A, u, wv, pspmv, now, t_bnd, n_bnd, stream));
-                if (info) AVS_HIP(hipEventRecord(w->evB[c], stream));
+                if (timed) AVS_HIP(hipEventRecord(w->evB[c], stream));
                 nb = (n_int + n_bnd) * (A.codes ? kTileRows / 64 : 1); // value-indexed kernel: one partial per wave
             } else {
                 AVS_TRY(dist_halo_exchange(dist, u, stream));
-                if (info) AVS_HIP(hipEventRecord(w->evA[c], stream));
+                if (timed) AVS_HIP(hipEventRecord(w->evA[c], stream));
                 AVS_TRY(spmv_dispatch<true>(A, u, wv, pspmv, now, variant, stream, &nb));
-                if (info) AVS_HIP(hipEventRecord(w->evB[c], stream));
+                if (timed) AVS_HIP(hipEventRecord(w->evB[c], stream));
             }
             if (nb < 16384) hipLaunchKernelGGL(k_reduce_pair, dim3(1), dim3(kRedBlock), 0, stream, pvec, g, 2, pspmv, nb, 1, sc + cur);
             else {
