@@ -467,7 +467,10 @@ avs_status avs_pcg_csr(int64_t n, const int32_t *row_ptr, const int32_t *col, co
     PcgWork *w = nullptr;
     {
         DevBuf<int32_t> d_rp, d_col;
-        DevBuf<double> d_val, d_b, d_x;
+        DevBuf<double> d_val, d_b, d_x, v_table;
+        DevBuf<uint16_t> v_codes;
+        DevBuf<uint32_t> v_packed;
+        int v_table_size = 0, v_col_bits = 0;
         CsrView A;
         A.n = n;
         const double *bp = b;
@@ -500,6 +503,21 @@ avs_status avs_pcg_csr(int64_t n, const int32_t *row_ptr, const int32_t *col, co
                 A.row_ptr = row_ptr; A.col = col; A.val = val;
             }
             A.nnz = nnz;
+            // the same lossless stream compression the assembled path gets (value dictionary, packed words); the
+            // caller's numbering is kept, so only the x locality of the brick-major order is missing
+            if (nnz > 0) {
+                if ((rc = build_value_index(A.val, nnz, v_codes, v_table, &v_table_size, s))) break;
+                if (v_table_size > 0) {
+                    A.codes = v_codes.p;
+                    A.table = v_table.p;
+                    A.table_size = v_table_size;
+                    if ((rc = build_packed_index(v_codes.p, A.col, nnz, n, v_table_size, v_packed, &v_col_bits, s))) break;
+                    if (v_col_bits > 0) {
+                        A.packed = v_packed.p;
+                        A.col_bits = v_col_bits;
+                    }
+                }
+            }
             if ((rc = pcg_create(&w, n, n, s))) break;
             if ((rc = pcg_solve(w, A, bp, xp, tol, max_iters, s, info, nullptr))) break;
             if (where == AVS_MEM_HOST) {
