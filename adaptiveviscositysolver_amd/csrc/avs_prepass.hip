@@ -756,6 +756,8 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     t.start();
     const double occ_sdf = 2. * d.dx; // cpp:907
     size_t max_vol = 0;
+    DevBuf<uint8_t> occ; // tile-occupancy flags of the lattice being classified
+    AVS_TRY(occ.alloc((size_t)(d.nx / kTile + 2) * (size_t)(d.ny / kTile + 2) * (size_t)(d.nz / kTile + 2)));
     for (int l = 0; l < capped; ++l) {
         int cr[3];
         pp_res(d, 2, l, 0, cr);
@@ -767,9 +769,7 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
                 AVS_TRY(buf.alloc(g3(gr).vol()));
                 if (g3(gr).vol() > max_vol) max_vol = g3(gr).vol();
                 TileGrid tg{{(gr[0] + kTile - 1) / kTile, (gr[1] + kTile - 1) / kTile, (gr[2] + kTile - 1) / kTile}};
-                DevBuf<uint8_t> occ;
-                AVS_TRY(occ.alloc(tg.vol()));
-                AVS_HIP(hipMemsetAsync(occ.p, 0, tg.vol(), st));
+                AVS_HIP(hipMemsetAsync(occ.p, 0, tg.vol(), st)); // one pooled buffer: the stream orders its reuse
                 const float *liq = (kind == 0 && l == 0) ? p->liquid.p : nullptr;
                 hipLaunchKernelGGL(k_mark_tiles, dim3(grid_for(g3(cr).vol())), dim3(kBlock), 0, st, p->labels[l].p, liq, occ_sdf, g3(cr), kind, a, tg, occ.p);
                 ClassifyArgs A{};
@@ -784,7 +784,6 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
                 if (kind == 0) hipLaunchKernelGGL(k_classify_velocity, dim3(grid_for(g3(gr).vol())), dim3(kBlock), 0, st, A, g3(gr), tg, (const uint8_t *)occ.p, buf.p);
                 else hipLaunchKernelGGL(k_classify_edges, dim3(grid_for(g3(gr).vol())), dim3(kBlock), 0, st, A, g3(gr), tg, (const uint8_t *)occ.p, buf.p);
                 AVS_HIP(hipGetLastError());
-                AVS_HIP(hipStreamSynchronize(st)); // occ dies here
             }
         }
         AVS_TRY(p->cidx[l].alloc(g3(cr).vol()));
@@ -797,8 +796,6 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         pp_res(d, 2, 0, 0, cr);
         AVS_TRY(p->ridx[a].alloc(g3(gr).vol()));
         TileGrid tg{{(gr[0] + kTile - 1) / kTile, (gr[1] + kTile - 1) / kTile, (gr[2] + kTile - 1) / kTile}};
-        DevBuf<uint8_t> occ;
-        AVS_TRY(occ.alloc(tg.vol()));
         AVS_HIP(hipMemsetAsync(occ.p, 0, tg.vol(), st));
         hipLaunchKernelGGL(k_mark_tiles, dim3(grid_for(g3(cr).vol())), dim3(kBlock), 0, st, p->labels[0].p, p->liquid.p, occ_sdf, g3(cr), 0, a, tg, occ.p);
         ClassifyArgs A{};
@@ -812,8 +809,8 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         A.solid = solid ? p->solid.p : nullptr;
         hipLaunchKernelGGL(k_classify_regular, dim3(grid_for(g3(gr).vol())), dim3(kBlock), 0, st, A, g3(gr), tg, (const uint8_t *)occ.p, p->ridx[a].p);
         AVS_HIP(hipGetLastError());
-        AVS_HIP(hipStreamSynchronize(st));
     }
+    AVS_HIP(hipStreamSynchronize(st)); // occ dies here
     AVS_HIP(hipGetLastError());
     p->ms[2] = t.stop();
 
