@@ -302,3 +302,19 @@ def test_solve_is_deterministic(graph, dev, built_lib, monkeypatch):
         assert it == runs[0][0] and err == runs[0][1]
         assert np.array_equal(x, runs[0][2])
     s.close()
+
+
+def test_graph_replay_equals_plain_launches(dev, built_lib, monkeypatch):
+    """Replaying captured hipGraph chunks runs the same kernels on the same data: identical iterations and solution."""
+    sc = scenes.fat_beam(64, 3, device=dev)
+    pyr = prepass.build_pyramid(sc)
+    s = gpu_solve_for(sc, pyr)
+    s.assemble()
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("AVS_PCG_GRAPH", mode)
+        info = s.solve(1e-9, 5000)
+        out[mode] = (info.iterations, s.solution())
+    assert out["1"][0] == out["0"][0] and out["1"][0] > 64      # several chunks: the graph really was replayed
+    assert np.array_equal(out["1"][1], out["0"][1])
+    s.close()
