@@ -1106,6 +1106,10 @@ static void edge_stress_faces(const orc_ctx *c, int level, int axis, const int e
                     st_push(s, vi, .25 * sign / g);
                 } else st_push(s, vi, .5 * sign / g); /* cpp:1827 */
             } else if (vi == ORC_UNASSIGNED) {
+                if (level + 1 >= c->levels) { /* the reference would index past its level array here (cpp:1853, 1888) */
+                    s->overflow = 2;
+                    continue;
+                }
                 if (edge[fa] % 2 != 0) { /* dangling edge, cpp:1835-1884 */
                     for (int oi = 0; oi < 2; ++oi) {
                         int offs = oi == 0 ? -1 : 1;

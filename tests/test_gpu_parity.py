@@ -318,3 +318,23 @@ def test_graph_replay_equals_plain_launches(dev, built_lib, monkeypatch):
     assert out["1"][0] == out["0"][0] and out["1"][0] > 64      # several chunks: the graph really was replayed
     assert np.array_equal(out["1"][1], out["0"][1])
     s.close()
+
+
+def test_state_the_reference_asserts_on_is_rejected(dev, built_lib):
+    """Same inputs as tests/test_oracle_known_answers.py::test_state_the_reference_asserts_on_is_rejected_not_crashed:
+    the device path reports AVS_EINTERNAL (addError + return false in the plugin), it neither crashes nor reads out
+    of bounds."""
+    from test_oracle_known_answers import leaving_box_scene
+    from adaptiveviscositysolver_amd import DevicePrepass
+    sc = leaving_box_scene()
+    dsc = scenes.to_device(sc, dev)
+    pp = DevicePrepass(sc.res, sc.dx, sc.levels)
+    pi = pp.run(dsc.liquid, dsc.solid)
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, device=0)
+    pp.apply(s)
+    s.set_scene_fields(dsc)
+    with pytest.raises(capi.AvsError) as e:
+        s.assemble()
+    assert e.value.status == capi.EINTERNAL
+    pp.close()
+    s.close()

@@ -286,3 +286,25 @@ def test_transfer_touches_only_regular_dofs_and_copies_level0_faces():
     for l in range(o.levels):
         lab, _ = o.node_grid(l)
         assert set(np.unique(lab)) <= {0, 1}
+
+
+def leaving_box_scene():
+    """Liquid that leaves the domain through its top border while the octree's top level is still coarsening there:
+    the reference indexes past its level arrays in getEdgeStressFaces (cpp:1853 / cpp:1888 with level + 1 ==
+    octreeLevels).  Found by tools/stress_parity.py (seed 7, case 21)."""
+    from adaptiveviscositysolver_amd import scenes
+    res, n = (64, 32, 64), 64
+    dx = 1.0 / n
+    liquid = scenes.box_sdf(res, dx, (0.4644382608195187, 0.2995961010117988, 0.6258390038916162),
+                            (0.18445403858748277, 0.17004666199877277, 0.3982372146871515))
+    solid = scenes.wall_sdf(res, dx, 0.2644382608195187)
+    return scenes.Scene(res=res, dx=dx, dt=0.02, levels=4, liquid=liquid, solid=solid, viscosity=1000.0, density=1000.0,
+                        velocity=scenes.smooth_velocity(res, dx, gravity_dt=0.1), name="leaving_box")
+
+
+def test_state_the_reference_asserts_on_is_rejected_not_crashed():
+    from util import oracle_for_scene
+    o = oracle_for_scene(leaving_box_scene())
+    o.prepass()
+    with pytest.raises(RuntimeError):
+        o.build_stencils()

@@ -1,0 +1,132 @@
+"""One-off stress: random scenes (boxes / spheres, walls, variable viscosity, 2-4 levels, enhanced gradients on/off),
+device pre-pass + HIP hot path vs the CPU oracle: index pyramids and CSR bit-exact, solution 1e-8, distributed assembly
+(2-3 virtual ranks) equal to the single solve."""
+import ctypes as C
+import os
+import sys
+import threading
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import faulthandler
+import numpy as np
+import torch
+faulthandler.enable()
+VERBOSE = os.environ.get('STRESS_VERBOSE')
+
+from adaptiveviscositysolver_amd import DevicePrepass, ViscositySolve, capi, scenes
+from util import oracle_for_scene, rel_l2
+from oracle import oracle as O
+
+count = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+dev = torch.device("cuda:0")
+lib = capi.load()
+bad = 0
+for case in range(count):
+    n = int(rng.choice([32, 64]))
+    res = (n, int(rng.choice([n, n // 2])), int(rng.choice([n, n // 2])))
+    levels = int(rng.integers(2, 5))
+    dx = 1.0 / n
+    size = np.array(res) * dx
+    c = size * rng.uniform(0.35, 0.65, 3)
+    if rng.random() < 0.5:
+        half = size * rng.uniform(0.15, 0.4, 3)
+        liquid = scenes.box_sdf(res, dx, tuple(c), tuple(half))
+    else:
+        rad = float(size.min() * rng.uniform(0.2, 0.42))
+        x, y, z = scenes._axes(res, "cpu")
+        d = torch.sqrt((((x + 0.5) * dx - c[0]) ** 2)[None, None, :] + (((y + 0.5) * dx - c[1]) ** 2)[None, :, None]
+                       + (((z + 0.5) * dx - c[2]) ** 2)[:, None, None])
+        liquid = (d - rad).to(torch.float32).contiguous()
+    solid = scenes.wall_sdf(res, dx, float(c[0] - 0.2 * size[0])) if rng.random() < 0.4 else None
+    visc = float(rng.uniform(1, 5000))
+    if rng.random() < 0.4:
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        visc = (50.0 + 500.0 * torch.rand((res[2], res[1], res[0]), generator=g)).to(torch.float32).contiguous()
+    sc = scenes.Scene(res=res, dx=dx, dt=float(rng.uniform(0.005, 0.05)), levels=levels, liquid=liquid, solid=solid, viscosity=visc,
+                      density=float(rng.uniform(1, 2000)), velocity=scenes.smooth_velocity(res, dx, gravity_dt=0.1),
+                      use_enhanced_gradients=bool(rng.random() < 0.7), name=f"stress{case}")
+    if VERBOSE: print(case, 'scene', res, 'levels', levels, 'solid', solid is not None, 'varvisc', not isinstance(visc, float), 'enh', sc.use_enhanced_gradients, flush=True)
+    o = oracle_for_scene(sc)
+    o.prepass()
+    if VERBOSE: print(case, 'oracle prepass done, levels', o.levels, flush=True)
+    if o.levels == 0:
+        print(case, "no active level, skipped")
+        continue
+    try:
+        o.hot_path()
+    except RuntimeError as e:
+        # a state the reference itself asserts on (e.g. liquid leaving through the domain border at the top level):
+        # the device path must reject it as well, with a status, not a crash
+        dsc = scenes.to_device(sc, dev)
+        pp = DevicePrepass(sc.res, sc.dx, sc.levels)
+        pi = pp.run(dsc.liquid, dsc.solid)
+        s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, use_enhanced_gradients=sc.use_enhanced_gradients, device=0)
+        pp.apply(s)
+        s.set_scene_fields(dsc)
+        try:
+            s.assemble()
+            print(case, "BAD: oracle rejected (", e, ") but the device path accepted", flush=True)
+            bad += 1
+        except capi.AvsError as ge:
+            print(case, "ok  both reject:", str(ge)[:90], flush=True)
+        pp.close(); s.close()
+        world = int(rng.integers(2, 4)); rng_axis = rng.integers(-1, 3)   # keep the random stream aligned
+        continue
+    oc = o.csr()
+    if VERBOSE: print(case, 'oracle hot path done', oc.n, flush=True)
+    dsc = scenes.to_device(sc, dev)
+    pp = DevicePrepass(sc.res, sc.dx, sc.levels)
+    pi = pp.run(dsc.liquid, dsc.solid)
+    ok = pi.levels == o.levels and pi.n_velocity == oc.n
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, use_enhanced_gradients=sc.use_enhanced_gradients, device=0)
+    pp.apply(s)
+    s.set_scene_fields(dsc)
+    if VERBOSE: print(case, 'device prepass done', pi.levels, pi.n_velocity, flush=True)
+    s.assemble()
+    if VERBOSE: print(case, 'device assemble done', flush=True)
+    rp, col, val, rhs = s.csr()
+    ok = ok and np.array_equal(rp, oc.row_ptr) and np.array_equal(col, oc.col) and np.array_equal(val, oc.val) and np.array_equal(rhs, oc.rhs)
+    info = s.solve(1e-10, 8000)
+    xo, oi = o.solve(1e-10, 8000)
+    x = s.solution()
+    ok = ok and info.converged == 1 and abs(info.iterations - oi.iterations) <= 3 and rel_l2(x, xo) < 1e-7
+    if VERBOSE: print(case, 'solves done', flush=True)
+    s.bench_spmv(0, 1)
+    if VERBOSE: print(case, 'spmv check done', flush=True)
+    # distributed assembly with virtual ranks
+    world = int(rng.integers(2, 4))
+    grp = C.c_void_p()
+    capi.check(lib.avs_local_group_create(world, C.byref(grp)))
+    ss = []
+    for _ in range(world):
+        t = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, use_enhanced_gradients=sc.use_enhanced_gradients, device=0)
+        pp.apply(t)
+        t.set_scene_fields(dsc)
+        ss.append(t)
+    outs, errs = [None] * world, []
+
+    def run(r):
+        try:
+            ss[r].dist_init_local(grp, r)
+            ss[r].dist_assemble(int(rng_axis))
+            di = ss[r].dist_solve(1e-10, 8000)
+            outs[r] = (di.iterations, di.converged, ss[r].dist_solution())
+        except Exception as e:
+            errs.append((r, e))
+
+    rng_axis = rng.integers(-1, 3)
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(300) for t in th]
+    ok = ok and not errs and all(v is not None and v[1] == 1 and abs(v[0] - info.iterations) <= 3 and rel_l2(v[2], x) < 1e-7 for v in outs)
+    for t in ss:
+        t.close()
+    lib.avs_local_group_destroy(grp)
+    pp.close()
+    s.close()
+    fmt = "ok " if ok else "BAD"
+    bad += not ok
+    print(case, fmt, res, "L", pi.levels, "n", oc.n, "nnz", len(oc.col), "iters", info.iterations, "world", world, errs if errs else "", flush=True)
+print("failures:", bad)
