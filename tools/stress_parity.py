@@ -1,4 +1,5 @@
-"""One-off stress: random scenes (boxes / spheres, walls, variable viscosity, 2-4 levels, enhanced gradients on/off),
+"""One-off stress (iteration counts near the fp64 floor of tol 1e-10 may differ by a few per cent between summation
+orders; solutions must still agree to 1e-7): random scenes (boxes / spheres, walls, variable viscosity, 2-4 levels, enhanced gradients on/off),
 device pre-pass + HIP hot path vs the CPU oracle: index pyramids and CSR bit-exact, solution 1e-8, distributed assembly
 (2-3 virtual ranks) equal to the single solve."""
 import ctypes as C
@@ -18,115 +19,138 @@ from adaptiveviscositysolver_amd import DevicePrepass, ViscositySolve, capi, sce
 from util import oracle_for_scene, rel_l2
 from oracle import oracle as O
 
-count = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-dev = torch.device("cuda:0")
-lib = capi.load()
-bad = 0
-for case in range(count):
-    n = int(rng.choice([32, 64]))
-    res = (n, int(rng.choice([n, n // 2])), int(rng.choice([n, n // 2])))
-    levels = int(rng.integers(2, 5))
-    dx = 1.0 / n
-    size = np.array(res) * dx
-    c = size * rng.uniform(0.35, 0.65, 3)
-    if rng.random() < 0.5:
-        half = size * rng.uniform(0.15, 0.4, 3)
-        liquid = scenes.box_sdf(res, dx, tuple(c), tuple(half))
-    else:
-        rad = float(size.min() * rng.uniform(0.2, 0.42))
-        x, y, z = scenes._axes(res, "cpu")
-        d = torch.sqrt((((x + 0.5) * dx - c[0]) ** 2)[None, None, :] + (((y + 0.5) * dx - c[1]) ** 2)[None, :, None]
-                       + (((z + 0.5) * dx - c[2]) ** 2)[:, None, None])
-        liquid = (d - rad).to(torch.float32).contiguous()
-    solid = scenes.wall_sdf(res, dx, float(c[0] - 0.2 * size[0])) if rng.random() < 0.4 else None
-    visc = float(rng.uniform(1, 5000))
-    if rng.random() < 0.4:
-        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
-        visc = (50.0 + 500.0 * torch.rand((res[2], res[1], res[0]), generator=g)).to(torch.float32).contiguous()
-    sc = scenes.Scene(res=res, dx=dx, dt=float(rng.uniform(0.005, 0.05)), levels=levels, liquid=liquid, solid=solid, viscosity=visc,
-                      density=float(rng.uniform(1, 2000)), velocity=scenes.smooth_velocity(res, dx, gravity_dt=0.1),
-                      use_enhanced_gradients=bool(rng.random() < 0.7), name=f"stress{case}")
-    if VERBOSE: print(case, 'scene', res, 'levels', levels, 'solid', solid is not None, 'varvisc', not isinstance(visc, float), 'enh', sc.use_enhanced_gradients, flush=True)
-    o = oracle_for_scene(sc)
-    o.prepass()
-    if VERBOSE: print(case, 'oracle prepass done, levels', o.levels, flush=True)
-    if o.levels == 0:
-        print(case, "no active level, skipped")
-        continue
-    try:
-        o.hot_path()
-    except RuntimeError as e:
-        # a state the reference itself asserts on (e.g. liquid leaving through the domain border at the top level):
-        # the device path must reject it as well, with a status, not a crash
+def run(count, seed, quiet=False):
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    lib = capi.load()
+    bad = 0
+    for case in range(count):
+        n = int(rng.choice([32, 64, 64, 128]))
+        res = (n, int(rng.choice([n, n // 2])), int(rng.choice([n, n // 2])))
+        levels = int(rng.integers(2, 5))
+        dx = 1.0 / n
+        size = np.array(res) * dx
+        c = size * rng.uniform(0.35, 0.65, 3)
+        if rng.random() < 0.5:
+            half = size * rng.uniform(0.04, 0.4, 3)
+            liquid = scenes.box_sdf(res, dx, tuple(c), tuple(half))
+        else:
+            rad = float(size.min() * rng.uniform(0.2, 0.42))
+            x, y, z = scenes._axes(res, "cpu")
+            d = torch.sqrt((((x + 0.5) * dx - c[0]) ** 2)[None, None, :] + (((y + 0.5) * dx - c[1]) ** 2)[None, :, None]
+                           + (((z + 0.5) * dx - c[2]) ** 2)[:, None, None])
+            liquid = (d - rad).to(torch.float32).contiguous()
+        solid = scenes.wall_sdf(res, dx, float(c[0] - 0.2 * size[0])) if rng.random() < 0.4 else None
+        visc = float(rng.uniform(1, 5000))
+        if rng.random() < 0.4:
+            g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+            visc = (50.0 + 500.0 * torch.rand((res[2], res[1], res[0]), generator=g)).to(torch.float32).contiguous()
+        sc = scenes.Scene(res=res, dx=dx, dt=float(rng.uniform(0.005, 0.05)), levels=levels, liquid=liquid, solid=solid, viscosity=visc,
+                          density=float(rng.uniform(1, 2000)), velocity=scenes.smooth_velocity(res, dx, gravity_dt=0.1),
+                          use_enhanced_gradients=bool(rng.random() < 0.7), name=f"stress{case}")
+        if VERBOSE: print(case, 'scene', res, 'levels', levels, 'solid', solid is not None, 'varvisc', not isinstance(visc, float), 'enh', sc.use_enhanced_gradients, flush=True)
+        o = oracle_for_scene(sc)
+        o.prepass()
+        if VERBOSE: print(case, 'oracle prepass done, levels', o.levels, flush=True)
+        if o.levels == 0:
+            print(case, "no active level, skipped")
+            continue
+        try:
+            o.hot_path()
+        except RuntimeError as e:
+            # a state the reference itself asserts on (e.g. liquid leaving through the domain border at the top level):
+            # the device path must reject it as well, with a status, not a crash
+            dsc = scenes.to_device(sc, dev)
+            pp = DevicePrepass(sc.res, sc.dx, sc.levels)
+            pi = pp.run(dsc.liquid, dsc.solid)
+            s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, use_enhanced_gradients=sc.use_enhanced_gradients, device=0)
+            pp.apply(s)
+            s.set_scene_fields(dsc)
+            try:
+                s.assemble()
+                print(case, "BAD: oracle rejected (", e, ") but the device path accepted", flush=True)
+                bad += 1
+            except capi.AvsError as ge:
+                print(case, "ok  both reject:", str(ge)[:90], flush=True)
+            pp.close(); s.close()
+            world = int(rng.integers(2, 4)); rng_axis = rng.integers(-1, 3)   # keep the random stream aligned
+            continue
+        oc = o.csr()
+        if VERBOSE: print(case, 'oracle hot path done', oc.n, flush=True)
         dsc = scenes.to_device(sc, dev)
         pp = DevicePrepass(sc.res, sc.dx, sc.levels)
         pi = pp.run(dsc.liquid, dsc.solid)
+        why = []
+        ok = pi.levels == o.levels and pi.n_velocity == oc.n
+        if not ok: why.append('prepass counts')
         s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, use_enhanced_gradients=sc.use_enhanced_gradients, device=0)
         pp.apply(s)
         s.set_scene_fields(dsc)
-        try:
-            s.assemble()
-            print(case, "BAD: oracle rejected (", e, ") but the device path accepted", flush=True)
-            bad += 1
-        except capi.AvsError as ge:
-            print(case, "ok  both reject:", str(ge)[:90], flush=True)
-        pp.close(); s.close()
-        world = int(rng.integers(2, 4)); rng_axis = rng.integers(-1, 3)   # keep the random stream aligned
-        continue
-    oc = o.csr()
-    if VERBOSE: print(case, 'oracle hot path done', oc.n, flush=True)
-    dsc = scenes.to_device(sc, dev)
-    pp = DevicePrepass(sc.res, sc.dx, sc.levels)
-    pi = pp.run(dsc.liquid, dsc.solid)
-    ok = pi.levels == o.levels and pi.n_velocity == oc.n
-    s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, use_enhanced_gradients=sc.use_enhanced_gradients, device=0)
-    pp.apply(s)
-    s.set_scene_fields(dsc)
-    if VERBOSE: print(case, 'device prepass done', pi.levels, pi.n_velocity, flush=True)
-    s.assemble()
-    if VERBOSE: print(case, 'device assemble done', flush=True)
-    rp, col, val, rhs = s.csr()
-    ok = ok and np.array_equal(rp, oc.row_ptr) and np.array_equal(col, oc.col) and np.array_equal(val, oc.val) and np.array_equal(rhs, oc.rhs)
-    info = s.solve(1e-10, 8000)
-    xo, oi = o.solve(1e-10, 8000)
-    x = s.solution()
-    ok = ok and info.converged == 1 and abs(info.iterations - oi.iterations) <= 3 and rel_l2(x, xo) < 1e-7
-    if VERBOSE: print(case, 'solves done', flush=True)
-    s.bench_spmv(0, 1)
-    if VERBOSE: print(case, 'spmv check done', flush=True)
-    # distributed assembly with virtual ranks
-    world = int(rng.integers(2, 4))
-    grp = C.c_void_p()
-    capi.check(lib.avs_local_group_create(world, C.byref(grp)))
-    ss = []
-    for _ in range(world):
-        t = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, use_enhanced_gradients=sc.use_enhanced_gradients, device=0)
-        pp.apply(t)
-        t.set_scene_fields(dsc)
-        ss.append(t)
-    outs, errs = [None] * world, []
+        if VERBOSE: print(case, 'device prepass done', pi.levels, pi.n_velocity, flush=True)
+        s.assemble()
+        if VERBOSE: print(case, 'device assemble done', flush=True)
+        rp, col, val, rhs = s.csr()
+        t_ = np.array_equal(rp, oc.row_ptr) and np.array_equal(col, oc.col) and np.array_equal(val, oc.val) and np.array_equal(rhs, oc.rhs)
+        if not t_: why.append('csr')
+        ok = ok and t_
+        info = s.solve(1e-10, 8000)
+        xo, oi = o.solve(1e-10, 8000)
+        x = s.solution()
+        t_ = info.converged == 1 and abs(info.iterations - oi.iterations) <= max(3, oi.iterations // 20) and rel_l2(x, xo) < 1e-7
+        if not t_: why.append(f'solve it {info.iterations} vs {oi.iterations} conv {info.converged} rel {rel_l2(x, xo):.2e}')
+        ok = ok and t_
+        if VERBOSE: print(case, 'solves done', flush=True)
+        s.bench_spmv(0, 1)
+        # post-solve transfer: regular-grid classification and the MAC-grid velocity from the SAME solution vector, bit for bit
+        o.build_regular_indices()
+        t_ = pi.n_regular == o.regular_count and all(np.array_equal(pp.regular_index(a), o.regular_index(a)) for a in range(3))
+        if not t_: why.append('regular index')
+        ok = ok and t_
+        got = s.transfer_to_regular_grid()
+        want = o.transfer_to_regular_grid(x)
+        t_ = all(np.array_equal(got[a], want[a]) for a in range(3))
+        if not t_: why.append('transfer ' + str([int((got[a] != want[a]).sum()) for a in range(3)]) + ' max ' + str(max(float(np.abs(got[a] - want[a]).max()) for a in range(3))))
+        ok = ok and t_
+        if VERBOSE: print(case, 'spmv check done', flush=True)
+        # distributed assembly with virtual ranks
+        world = int(rng.integers(2, 4))
+        grp = C.c_void_p()
+        capi.check(lib.avs_local_group_create(world, C.byref(grp)))
+        ss = []
+        for _ in range(world):
+            t = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, use_enhanced_gradients=sc.use_enhanced_gradients, device=0)
+            pp.apply(t)
+            t.set_scene_fields(dsc)
+            ss.append(t)
+        outs, errs = [None] * world, []
 
-    def run(r):
-        try:
-            ss[r].dist_init_local(grp, r)
-            ss[r].dist_assemble(int(rng_axis))
-            di = ss[r].dist_solve(1e-10, 8000)
-            outs[r] = (di.iterations, di.converged, ss[r].dist_solution())
-        except Exception as e:
-            errs.append((r, e))
+        def run(r):
+            try:
+                ss[r].dist_init_local(grp, r)
+                ss[r].dist_assemble(int(rng_axis))
+                di = ss[r].dist_solve(1e-10, 8000)
+                outs[r] = (di.iterations, di.converged, ss[r].dist_solution())
+            except Exception as e:
+                errs.append((r, e))
 
-    rng_axis = rng.integers(-1, 3)
-    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
-    [t.start() for t in th]
-    [t.join(300) for t in th]
-    ok = ok and not errs and all(v is not None and v[1] == 1 and abs(v[0] - info.iterations) <= 3 and rel_l2(v[2], x) < 1e-7 for v in outs)
-    for t in ss:
-        t.close()
-    lib.avs_local_group_destroy(grp)
-    pp.close()
-    s.close()
-    fmt = "ok " if ok else "BAD"
-    bad += not ok
-    print(case, fmt, res, "L", pi.levels, "n", oc.n, "nnz", len(oc.col), "iters", info.iterations, "world", world, errs if errs else "", flush=True)
-print("failures:", bad)
+        rng_axis = rng.integers(-1, 3)
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        [t.start() for t in th]
+        [t.join(300) for t in th]
+        t_ = not errs and all(v is not None and v[1] == 1 and abs(v[0] - info.iterations) <= max(3, info.iterations // 20) and rel_l2(v[2], x) < 1e-7 for v in outs)
+        if not t_: why.append('dist ' + str([(v[0], v[1], rel_l2(v[2], x)) if v else None for v in outs]))
+        ok = ok and t_
+        for t in ss:
+            t.close()
+        lib.avs_local_group_destroy(grp)
+        pp.close()
+        s.close()
+        fmt = "ok " if ok else "BAD"
+        bad += not ok
+        print(case, fmt, res, "L", pi.levels, "n", oc.n, "nnz", len(oc.col), "iters", info.iterations, "world", world, errs if errs else "", why if why else "", flush=True)
+    if not quiet: print("failures:", bad)
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 20, int(sys.argv[2]) if len(sys.argv) > 2 else 1) else 0)
