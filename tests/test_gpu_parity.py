@@ -338,3 +338,26 @@ def test_state_the_reference_asserts_on_is_rejected(dev, built_lib):
     assert e.value.status == capi.EINTERNAL
     pp.close()
     s.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 63, 64, 65, 513])
+def test_seam_a_tiny_systems(n, dev, built_lib):
+    """avs_pcg_csr on very small SPD systems (tridiagonal): the value-indexed / packed kernel's quad loads, ragged ends,
+    single tiles and partial waves; solution against numpy."""
+    rng = np.random.default_rng(n)
+    main = 4.0 + rng.integers(0, 3, n).astype(np.float64)
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        for j, v in ((i - 1, -1.0), (i, main[i]), (i + 1, -1.0)):
+            if 0 <= j < n:
+                rows.append(i); cols.append(j); vals.append(v)
+    rp = np.zeros(n + 1, np.int32)
+    np.add.at(rp, np.asarray(rows) + 1, 1)
+    rp = np.cumsum(rp).astype(np.int32)
+    col, val = np.asarray(cols, np.int32), np.asarray(vals, np.float64)
+    A = np.zeros((n, n))
+    A[rows, cols] = vals
+    b = rng.standard_normal(n)
+    x, info = pcg_csr(rp, col, val, b, np.zeros(n), 1e-12, 500)
+    assert info.converged == 1
+    assert np.allclose(A @ x, b, rtol=0, atol=1e-9 * max(1.0, np.abs(b).max()))
