@@ -25,9 +25,9 @@ def run(count, seed, quiet=False):
     lib = capi.load()
     bad = 0
     for case in range(count):
-        n = int(rng.choice([32, 64, 64, 128]))
+        n = int(rng.choice([128, 256] if os.environ.get('STRESS_LARGE') else [32, 64, 64, 128]))
         res = (n, int(rng.choice([n, n // 2])), int(rng.choice([n, n // 2])))
-        levels = int(rng.integers(2, 5))
+        levels = int(rng.integers(2, 6 if os.environ.get('STRESS_LARGE') else 5))
         dx = 1.0 / n
         size = np.array(res) * dx
         c = size * rng.uniform(0.35, 0.65, 3)
