@@ -131,6 +131,27 @@ def run(count, seed, quiet=False):
         if not t_: why.append('transfer ' + str([int((got[a] != want[a]).sum()) for a in range(3)]) + ' max ' + str(max(float(np.abs(got[a] - want[a]).max()) for a in range(3))))
         ok = ok and t_
         if VERBOSE: print(case, 'spmv check done', flush=True)
+        # device partition planner == host planner (every array of one random rank)
+        pw = int(rng.integers(2, 9))
+        pr = int(rng.integers(0, pw))
+        pax = int(rng.integers(-1, 3))
+        plans = []
+        for mode in ("device", "host"):
+            os.environ["AVS_DIST_PLAN"] = mode
+            g2 = C.c_void_p()
+            capi.check(lib.avs_local_group_create(pw, C.byref(g2)))
+            s.dist_init_local(g2, pr)
+            s.dist_partition(pax)
+            sz = s.plan_sizes
+            ti, tb = s.overlap_tiles
+            arrs = [np.empty(int(k), np.int32) for k in (sz.n_own, sz.n_own + 1, sz.nnz_local, sz.n_send, sz.n_peers, sz.n_peers, sz.n_peers, ti, tb)]
+            capi.check(lib.avs_dist_get_plan_arrays(s.h, *[a.ctypes.data for a in arrs]))
+            plans.append(arrs)
+            lib.avs_local_group_destroy(g2)
+        os.environ.pop("AVS_DIST_PLAN", None)
+        t_ = all(np.array_equal(a, b) for a, b in zip(*plans))
+        if not t_: why.append(f'planner world {pw} rank {pr} axis {pax}')
+        ok = ok and t_
         # distributed assembly with virtual ranks
         world = int(rng.integers(2, 4))
         grp = C.c_void_p()
