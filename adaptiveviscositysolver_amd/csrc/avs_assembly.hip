@@ -278,14 +278,13 @@ __global__ __launch_bounds__(kBlock) void k_initial_guess(PyramidView P, const i
     int64_t leaves = 1;
     for (int l = 0; l < level; ++l) leaves *= 12;
     double acc = 0.;
+    int digits[AVS_MAX_LEVELS] = {}; // odometer over the base-12 digits (no 64-bit divisions in the leaf loop)
     for (int64_t code = 0; code < leaves; ++code) {
         // digits, most significant first: (child, offset) of the step from level -> level-1, ...
         I3 f = face;
         float wgt = 1.f;
-        int64_t div = leaves;
         for (int l = 0; l < level; ++l) {
-            div /= 12;
-            const int digit = (int)((code / div) % 12);
+            const int digit = digits[l];
             const int ci = digit / 3, off = digit % 3 - 1;
             f[0] *= 2; f[1] *= 2; f[2] *= 2;
             if (ci & 1) ++f[a1];
@@ -296,6 +295,7 @@ __global__ __launch_bounds__(kBlock) void k_initial_guess(PyramidView P, const i
         }
         I3 fc{{clampi(f[0], 0, vr[0] - 1), clampi(f[1], 0, vr[1] - 1), clampi(f[2], 0, vr[2] - 1)}};
         acc += (double)wgt * (double)field_at(V, vr, fc);
+        for (int l = level - 1; l >= 0 && ++digits[l] == 12; --l) digits[l] = 0;
     }
     x0[id] = acc;
 }
