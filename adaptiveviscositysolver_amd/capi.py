@@ -43,6 +43,7 @@ EXPORTED_SYMBOLS = [
     "avs_plan_get_arrays", "avs_plan_destroy", "avs_dist_get_unique_id", "avs_dist_init",
     "avs_local_group_create", "avs_local_group_destroy", "avs_dist_init_local", "avs_dist_partition",
     "avs_spmv_tile_rows", "avs_dist_assemble", "avs_dist_get_plan_sizes", "avs_dist_get_overlap_tiles", "avs_dist_get_plan_arrays", "avs_dist_solve", "avs_dist_get_solution",
+    "avs_dist_get_info",
 ]
 _VOID_RETURN = ("avs_last_error", "avs_version", "avs_destroy", "avs_plan_destroy", "avs_local_group_destroy",
                 "avs_prepass_destroy")
@@ -88,6 +89,11 @@ class AssemblyInfo(C.Structure):
     _fields_ = [("n_velocity", C.c_int64), ("n_edge", C.c_int64), ("n_center", C.c_int64),
                 ("nnz", C.c_int64), ("raw_triplets", C.c_int64), ("stencil_ms", C.c_double),
                 ("guess_ms", C.c_double), ("system_ms", C.c_double), ("csr_ms", C.c_double)]
+
+
+class DistInfo(C.Structure):
+    _fields_ = [("world_size", C.c_int32), ("rccl_ranks", C.c_int32), ("transport", C.c_int32), ("graph_replay", C.c_int32),
+                ("launches_per_iteration", C.c_int32), ("collectives_per_iteration", C.c_int32)]
 
 
 class MatrixFormat(C.Structure):
@@ -170,6 +176,7 @@ def load():
     L.avs_dist_get_plan_arrays.argtypes = [vp] + [vp] * 9
     L.avs_dist_solve.argtypes = [vp, f64, i32, C.POINTER(SolveInfo)]
     L.avs_dist_get_solution.argtypes = [vp, vp, i64, i32]
+    L.avs_dist_get_info.argtypes = [vp, C.POINTER(DistInfo)]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
         if name not in _VOID_RETURN:

@@ -133,7 +133,7 @@ void avs_destroy(avs_ctx *c)
 static void invalidate(avs_ctx *c, bool tables)
 {
     if (tables) c->tables_ready = false;
-    c->stencils_ready = c->guess_ready = c->system_ready = c->solved = false;
+    c->stencils_ready = c->guess_ready = c->guess_partial = c->system_ready = c->solved = false;
 }
 
 avs_status avs_set_labels(avs_ctx *c, int32_t level, const int8_t *labels, avs_memspace where)
@@ -355,6 +355,10 @@ avs_status avs_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_info *
     AVS_REQUIRE(tol >= 0. && max_iters >= 0, AVS_EINVAL, "tolerance / max_iterations out of range");
     AVS_HIP(hipSetDevice(c->desc.device));
     const int64_t n = c->n_vel;
+    if (c->pcg && pcg_rows(c->pcg) != n) { // the context was re-assembled with another DOF count (next frame)
+        pcg_destroy(c->pcg);
+        c->pcg = nullptr;
+    }
     if (c->pcg == nullptr) AVS_TRY(pcg_create(&c->pcg, n, n, c->stream));
     AVS_TRY(c->x.alloc((size_t)n));
     avs_solve_info local{};

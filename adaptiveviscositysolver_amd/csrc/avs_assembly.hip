@@ -736,21 +736,21 @@ __global__ __launch_bounds__(kBlock) void k_scan_sums(const int32_t *__restrict_
 __global__ __launch_bounds__(kBlock) void k_scan_top(int32_t *__restrict__ sums, int64_t nb)
 {
     __shared__ int lds[4];
-    __shared__ int carry;
+    __shared__ long long carry; // 64-bit: a total beyond int32 is reported as -1 instead of wrapping (any number of times)
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     for (int64_t start = 0; start < nb; start += kBlock) {
         const int64_t i = start + threadIdx.x;
-        const int v = (i < nb) ? sums[i] : 0;
+        const int v = (i < nb) ? sums[i] : 0; // one tile's sum: <= kScanTile small counts, cannot wrap
         int total;
         const int ex = block_exclusive_scan(v, lds, total);
-        const int c = carry;
-        if (i < nb) sums[i] = c + ex;
+        const long long c = carry;
+        if (i < nb) sums[i] = (int)(c + ex);
         __syncthreads();
-        if (threadIdx.x == 0) carry = c + total;
+        if (threadIdx.x == 0) carry = c + (long long)(unsigned)total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) sums[nb] = carry;
+    if (threadIdx.x == 0) sums[nb] = carry > 2147483647ll ? -1 : (int)carry;
 }
 
 __global__ __launch_bounds__(kBlock) void k_scan_apply(const int32_t *__restrict__ in, int32_t *__restrict__ out, int64_t n,
@@ -911,6 +911,7 @@ avs_status build_initial_guess(avs_ctx *c)
                                      (const int32_t *)nullptr);
     AVS_HIP(hipGetLastError());
     c->guess_ready = true;
+    c->guess_partial = false;
     return AVS_OK;
 }
 
@@ -922,7 +923,8 @@ avs_status build_initial_guess_rows(avs_ctx *c, const int32_t *ids, int64_t m)
     AVS_HIP(hipMemsetAsync(c->x0.p, 0, (size_t)c->n_vel * sizeof(double), c->stream));
     if (m) hipLaunchKernelGGL(k_initial_guess, dim3(grid_for(m)), dim3(kBlock), 0, c->stream, c->view(), c->vdof.p, m, c->x0.p, ids);
     AVS_HIP(hipGetLastError());
-    c->guess_ready = true;
+    c->guess_ready = false; // avs_get_initial_guess / avs_build_system must not see a mostly-zero vector
+    c->guess_partial = true;
     return AVS_OK;
 }
 
@@ -932,7 +934,8 @@ avs_status assemble_rows(avs_ctx *c, const int32_t *ids, int64_t m, DevBuf<int32
                          DevBuf<double> &rhs, int64_t *nnz_out, int64_t *nraw_out)
 {
     hipStream_t st = c->stream;
-    AVS_REQUIRE(c->stencils_ready && c->guess_ready, AVS_ESTATE, "build the stencils and the initial guess first");
+    AVS_REQUIRE(c->stencils_ready && (c->guess_ready || (ids && c->guess_partial)), AVS_ESTATE,
+                "build the stencils and the initial guess first");
     const int64_t n = m;
     AVS_REQUIRE(c->n_vel < (int64_t)INT32_MAX, AVS_EINVAL, "too many DOFs for int32 columns");
     DevBuf<int32_t> row_count, rawptr, scan_tmp, raw_col;
@@ -954,7 +957,7 @@ avs_status assemble_rows(avs_ctx *c, const int32_t *ids, int64_t m, DevBuf<int32
     int32_t nraw = 0;
     AVS_HIP(hipMemcpyAsync(&nraw, rawptr.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     AVS_HIP(hipStreamSynchronize(st));
-    AVS_REQUIRE(nraw >= 0, AVS_EINVAL, "raw triplet count overflows int32");
+    AVS_REQUIRE(nraw >= 0, AVS_EINVAL, "raw triplet count exceeds int32 (the scan reports -1 for any total above INT32_MAX)");
     if (nraw_out) *nraw_out = nraw;
     AVS_TRY(raw_col.alloc((size_t)nraw));
     AVS_TRY(raw_val.alloc((size_t)nraw));
@@ -973,6 +976,7 @@ avs_status assemble_rows(avs_ctx *c, const int32_t *ids, int64_t m, DevBuf<int32
     int e = 0;
     AVS_TRY(read_err(err.p, st, &e));
     AVS_REQUIRE(e == 0, AVS_EINTERNAL, "row assembly hit a reference assert (code %d): stencils and index pyramids disagree", e);
+    AVS_REQUIRE(nnz >= 0, AVS_EINVAL, "non-zero count exceeds int32");
     if (nnz_out) *nnz_out = nnz;
     AVS_TRY(col.alloc((size_t)nnz));
     AVS_TRY(val.alloc((size_t)nnz));

@@ -1144,6 +1144,26 @@ avs_status avs_dist_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_i
     return AVS_OK;
 }
 
+avs_status avs_dist_get_info(avs_ctx *c, avs_dist_info *info)
+{
+    AVS_REQUIRE(c && info, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->dist, AVS_ESTATE, "call avs_dist_init / avs_dist_init_local first");
+    PcgDist *d = c->dist;
+    memset(info, 0, sizeof(*info));
+    info->world_size = d->world;
+    if (d->comm) {
+        int cnt = 0;
+        AVS_NCCL(ncclCommCount(d->comm, &cnt));
+        info->rccl_ranks = cnt;
+    }
+    info->transport = AVS_TRANSPORT_RCCL;
+    info->graph_replay = 0;
+    const bool sr = dist_wants_single_reduction(d);
+    info->launches_per_iteration = d->world == 1 ? 5 : (sr ? 5 : 8);
+    info->collectives_per_iteration = d->world == 1 ? 0 : (sr ? 2 : 3);
+    return AVS_OK;
+}
+
 avs_status avs_dist_get_solution(avs_ctx *c, double *x, int64_t n, avs_memspace where)
 {
     AVS_REQUIRE(c && x, AVS_EINVAL, "null argument");

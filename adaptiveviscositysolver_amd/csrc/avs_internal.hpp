@@ -164,6 +164,7 @@ struct PcgWork;
 
 avs_status pcg_create(PcgWork **w, int64_t n, int64_t n_ext, hipStream_t stream);
 void pcg_destroy(PcgWork *w);
+int64_t pcg_rows(const PcgWork *w); // rows the workspace was sized for (-1: none)
 
 // Jacobi-PCG in Eigen's operation order; x holds the initial guess, returns the solution.
 // Optional halo hook (multi-GPU) is wired by avs_dist.hip through PcgDist.
@@ -247,6 +248,7 @@ struct avs_ctx {
     avs::DevBuf<int32_t> row_ptr, col;
     int64_t nnz = 0, nraw = 0;
     bool guess_ready = false, system_ready = false, solved = false;
+    bool guess_partial = false; // x0 holds the restriction of SOME rows only (avs_dist_assemble): never handed out
 
     // post-solve transfer (avs_post.hip): regular-grid classification + interpolator work fields
     avs::DevBuf<int32_t> ridx[3];

@@ -463,12 +463,11 @@ template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, int WIN = 0>
 static avs_status spmv_vi2_launch_t(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc,
                                     const int32_t *tiles, int ntiles, size_t lds, hipStream_t stream)
 {
-    static bool attr = false; // one flag per instantiation
-    if (!attr && lds > 48 * 1024) {
+    // > 48 KiB of dynamic LDS (value table of ~1.5 k+ entries) needs the opt-in; it is a per-device function attribute, so it
+    // is set on every such launch (cheap, rare path) rather than cached in a process-wide flag
+    if (lds > 48 * 1024)
         AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, WIN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024 - 4096));
-        attr = true;
-    }
     hipLaunchKernelGGL((k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, WIN>), dim3(ntiles), dim3(BLK), lds, stream, A, x, y, partial, sc, tiles);
     AVS_HIP(hipGetLastError());
     return AVS_OK;
@@ -1221,6 +1220,8 @@ avs_status pcg_create(PcgWork **out, int64_t n, int64_t n_ext, hipStream_t)
     *out = w;
     return AVS_OK;
 }
+
+int64_t pcg_rows(const PcgWork *w) { return w ? w->n : -1; }
 
 void pcg_destroy(PcgWork *w)
 {

@@ -188,6 +188,15 @@ class ViscositySolve:
         capi.check(self.lib.avs_dist_solve(self.h, float(tol), int(max_iters), C.byref(info)))
         return info
 
+    def dist_comm_info(self):
+        """dict form of avs_dist_info (transport, RCCL rank count, launches / collectives per iteration)."""
+        di = capi.DistInfo()
+        capi.check(self.lib.avs_dist_get_info(self.h, C.byref(di)))
+        return {"world_size": int(di.world_size), "rccl_ranks": int(di.rccl_ranks),
+                "transport": {0: "rccl", 1: "direct"}.get(int(di.transport), str(di.transport)),
+                "graph_replay": bool(di.graph_replay), "launches_per_iteration": int(di.launches_per_iteration),
+                "rccl_calls_per_iteration": int(di.collectives_per_iteration)}
+
     def dist_solution(self):
         n = self.info().n_velocity
         x = np.empty(n, np.float64)
@@ -211,6 +220,14 @@ class ViscositySolve:
         fmt = capi.MatrixFormat()
         capi.check(self.lib.avs_get_matrix_format(self.h, C.byref(fmt)))
         return fmt
+
+    def spmv_kernel_name(self):
+        fmt = self.matrix_format()
+        bpn, tab = int(fmt.bytes_per_nonzero), int(fmt.value_table_size)
+        ltab = "LTAB" if 0 < tab <= 2048 else "GTAB"
+        return {4: f"k_spmv_vi2<512,4096,DOT,{ltab},PACK,WIN=512> (4 B/nnz packed code|column, brick-major system)",
+                6: f"k_spmv_vi2<512,4096,DOT,{ltab},WIN=512> (6 B/nnz value-indexed, brick-major system)",
+                12: "k_spmv_tile<512,4096,DOT,VEC,NT> (12 B/nnz, brick-major system)"}.get(bpn, f"{bpn} B/nnz")
 
     # ---- outputs (numpy, host) ------------------------------------------------------------
     def info(self):

@@ -9,77 +9,155 @@ including reductions and, multi-GPU, halo + all-reduce)".  The system is assembl
 "assembly_ms" / "hot_path_ms" (= assembly + one solve).  Inputs are synthesised in HBM.
 
   metric  : CG iterations per second (whole job) -- BASELINE.json "CG iterations/sec + SpMV GB/s"
-  roofline: the SpMV kernel (k_spmv_vi2 / k_spmv_tile), algorithmic bytes 12*nnz + 4*(n+1) + 16*n per launch
-            (fp64 value + int32 column) over the mean HIP-event duration of the SpMV
-            launches inside the timed solves; peak = 8 TB/s HBM (MI355X_MICROARCH.md).  The solver
-            streams a LOSSLESS compressed form of the matrix (4 or 6 B per non-zero), so
-            "achieved" is an effective rate; "stored_*" are the bytes the kernel really has to move.
-  cpu_baseline: the CPU oracle's PCG (port of the Eigen algorithm) on the same CSR system, a
-            bounded number of iterations on the host cores of this box (rank 0, N=1 only)
+  roofline: the SpMV kernel, algorithmic bytes 12*nnz + 4*(n+1) + 16*n per launch (SURVEY.md 8(d):
+            fp64 value + int32 column) over the mean HIP-event duration of the SpMV launches inside
+            the timed solves; peak = 8 TB/s HBM (MI355X_MICROARCH.md).  The solver streams a LOSSLESS
+            compressed form of the matrix (DESIGN.md 5), so "achieved" is an effective rate;
+            "stored_*" are the bytes the kernel really has to move.
+  cpu_baseline: the CPU oracle's PCG (port of the Eigen algorithm) on the same CSR system, run in a
+            clean subprocess on the host cores of this box (rank 0, N=1 only): both SURVEY 8(d)
+            variants, "eigen_faithful" (parallel SpMV, serial vector ops) and "all_parallel".
 
-Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 under torch.distributed.run.
+Workloads (--config): 4 = BASELINE configs[3] size on one GPU, 512^3 4-level fat beam, uniform
+viscosity (default, the headline); 3 = configs[2], 256^3 4-level, mu(x) = 200 (1 + 9x);
+5 = configs[4], 1024^3 5-level thin sheet.  --variable-viscosity switches the beam to mu(x).
+
+Launch: python bench.py [--gpus N --steps K --warmup W].  With N > 1 and no launcher environment the
+script starts its own ranks (python -m torch.distributed.run, 127.0.0.1); under torchrun it joins.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
 HBM_PEAK_GBPS = 8000.0  # MI355X spec; 6290 GB/s is the measured-achievable copy rate
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=512, help="base grid resolution (512 = BASELINE headline)")
-    ap.add_argument("--levels", type=int, default=4)
+    ap.add_argument("--config", type=int, default=4, choices=(3, 4, 5), help="BASELINE.json workload (see the docstring)")
+    ap.add_argument("--n", type=int, default=0, help="base grid resolution (0 = the config's)")
+    ap.add_argument("--levels", type=int, default=0)
+    ap.add_argument("--variable-viscosity", action="store_true", help="fat beam with mu(x) = 200 (1 + 9x)")
     ap.add_argument("--tol", type=float, default=1e-3)
     ap.add_argument("--max-iters", type=int, default=2500)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (both variants together)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the partitioned path even with one rank")
-    return ap.parse_args()
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only start the ranks, form the process group, all-reduce once and print a JSON line")
+    return ap.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` must work as typed (the driver's form)
+# ---------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(gpus, argv, port=None):
+    """the torch.distributed.run command that starts `gpus` ranks of this script on this node"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()),
+            os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(a, argv):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL / peer mappings across processes
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(launcher_command(a.gpus, argv), env=env)
+
+
+# ---------------------------------------------------------------------------------------------
+# cpu_baseline: clean subprocess, pinned threads, both SURVEY 8(d) variants
+# ---------------------------------------------------------------------------------------------
 def cpu_baseline(solver, tol, budget_s):
-    """Oracle PCG (kind 'port') on the same system, bounded iteration count, all host cores."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle import oracle as O
+    import numpy as np
     rp, col, val, rhs = solver.csr()
     x0 = solver.initial_guess()
-    rp64 = rp.astype(np.int64)
-    threads = max(1, min(O.max_threads(), os.cpu_count() or 1))
-    _, probe = O.pcg_csr(rp64, col, val, rhs, x0, tol, 3, threads)   # 3 iterations to size the sample
-    per_iter = max(probe.seconds / 3.0, 1e-6)
-    iters = int(max(5, min(2500, budget_s / per_iter)))
-    _, info = O.pcg_csr(rp64, col, val, rhs, x0, tol, iters, threads)
-    done = max(info.iterations, 1)
-    return {"value": done / info.seconds, "unit": "iter/s", "cores": threads, "kind": "port",
-            "sample": f"{done} PCG iterations of the same {len(rhs)}-row system (OpenMP, all vector ops parallel), "
-                      f"{info.seconds:.1f} s; spmv share {info.spmv_seconds / max(info.seconds, 1e-9):.2f}"}
+    cpus = sorted(os.sched_getaffinity(0))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from cpu_baseline import physical_cores   # the checker's helper; no compute
+    threads = max(1, physical_cores(cpus))     # one thread per physical core of the affinity mask
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    with tempfile.TemporaryDirectory(dir=base, prefix="avs_cpu_baseline_") as d:
+        for name, arr in (("row_ptr", rp), ("col", col), ("val", val), ("rhs", rhs), ("x0", x0)):
+            np.save(os.path.join(d, name + ".npy"), arr)
+        del rp, col, val
+        env = {k: v for k, v in os.environ.items() if not k.startswith(("OMP_", "GOMP_", "KMP_"))}
+        env.update(OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_DYNAMIC="false")
+        cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), d, repr(tol), repr(budget_s), str(threads)]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=budget_s * 6 + 300)
+    if res.returncode != 0:
+        raise RuntimeError("cpu_baseline subprocess failed: " + res.stderr[-2000:])
+    r = json.loads(res.stdout.strip().splitlines()[-1])
+    ef, apar = r["variants"]["eigen_faithful"], r["variants"]["all_parallel"]
+    return {
+        "value": ef["iter_per_s"], "unit": "iter/s", "cores": threads, "kind": "port",
+        "variant": "eigen_faithful (OpenMP row-parallel SpMV, serial dots/AXPYs: what Eigen::ConjugateGradient does, "
+                   "reference CMakeLists.txt:27-32)",
+        "cpu_model": r["cpu_model"], "logical_cpus_in_mask": len(cpus), "threads": threads,
+        "omp": "OMP_PROC_BIND=close OMP_PLACES=cores, clean subprocess (no torch / second OpenMP runtime loaded)",
+        "eigen_faithful": ef, "all_parallel": apar,
+        "sample": f"{ef['iterations']} + {apar['iterations']} PCG iterations (eigen_faithful + all_parallel) of the same "
+                  f"{r['n']}-row system, {ef['seconds']:.1f} + {apar['seconds']:.1f} s; SpMV {ef['spmv_gbps']:.0f} GB/s "
+                  f"(SURVEY 8(d) bytes) on {threads} threads"}
 
 
 def main():
-    a = parse()
+    argv = sys.argv[1:]
+    a = parse(argv)
+    under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if a.gpus > 1 and not under_launcher:
+        raise SystemExit(self_launch(a, argv))
+
+    import numpy as np
+    import torch
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if under_launcher and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} does not match WORLD_SIZE {world}")
+    have_gpu = torch.cuda.is_available()
+    if a.launch_check:
+        # the launch path up to (not including) avs_dist_init: ranks start, rendezvous on 127.0.0.1, one collective
+        import torch.distributed as dist
+        backend = "nccl" if have_gpu and torch.cuda.device_count() >= world else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1 or under_launcher:
+            if backend == "nccl":
+                torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world)
+            t = torch.tensor([rank + 1.0], device=(f"cuda:{local_rank}" if backend == "nccl" else "cpu"))
+            dist.all_reduce(t)
+            ok = float(t.item()) == world * (world + 1) / 2
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            ok = True
+        if rank == 0:
+            print(json.dumps({"launch_check": bool(ok), "n_gpus": world, "backend": backend}), flush=True)
+        raise SystemExit(0 if ok else 1)
+
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
     if world > 1 or under_launcher:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -89,7 +167,15 @@ def main():
 
     # ---- synthetic input, resident in HBM before the timed region -------------------------
     # analytic SDF + velocity (torch), then the device pre-pass (HIP): weights, octree, classification, numbering
-    sc = scenes.fat_beam(a.n, a.levels, device=dev)
+    if a.config == 5:
+        n0, lv = a.n or 1024, a.levels or 5
+        sc = scenes.thin_sheet(n0, lv, thickness_cells=32, device=dev)   # half-thickness 16 dx (SURVEY 8(d) Config 5)
+        wl = f"thin_sheet {n0}^3 base grid (half-thickness 16 dx), uniform viscosity 200"
+    else:
+        n0, lv = a.n or (256 if a.config == 3 else 512), a.levels or 4
+        varvisc = a.variable_viscosity or a.config == 3
+        sc = scenes.fat_beam(n0, lv, variable_viscosity=varvisc, device=dev)
+        wl = f"fat_beam {n0}^3 base grid, " + ("variable viscosity mu(x)=200(1+9x)" if varvisc else "uniform viscosity 1e4")
     pp = DevicePrepass(sc.res, sc.dx, sc.levels, device=local_rank)
     pp.run(sc.liquid, sc.solid)          # first pass: code-object load + first-touch of the big buffers
     pinfo = pp.run(sc.liquid, sc.solid)  # reported times are the second (steady-state) pass
@@ -161,7 +247,6 @@ def main():
     if not use_dist:
         # post-solve transfer to the regular MAC grid (cpp:655-707), outputs stay in HBM
         outs = [torch.empty_like(v) for v in sc.velocity]
-        import ctypes as C
         from adaptiveviscositysolver_amd import capi
         capi.check(solver.lib.avs_transfer_to_regular_grid(solver.h, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
                                                            capi.MEM_DEVICE))
@@ -172,12 +257,18 @@ def main():
         torch.cuda.synchronize()
         transfer_ms = (time.perf_counter() - t_tr) * 1e3
     nnz_total = None
+    per_rank = None
     if use_dist:
         nnz_total = int(dist_info.nnz)
+        sz = solver.plan_sizes
+        mine = [int(sz.n_own), int(sz.n_halo), int(sz.nnz_local), int(sz.n_send), int(sz.n_peers)]
+        per_rank = [mine]
         if world > 1:
-            tn = torch.tensor([nnz_total], dtype=torch.int64, device=dev)
-            torch.distributed.all_reduce(tn, op=torch.distributed.ReduceOp.SUM)
-            nnz_total = int(tn.item())
+            tn = torch.tensor(mine, dtype=torch.int64, device=dev)
+            allr = [torch.zeros_like(tn) for _ in range(world)]
+            torch.distributed.all_gather(allr, tn)
+            per_rank = [[int(v) for v in r.tolist()] for r in allr]
+            nnz_total = sum(r[2] for r in per_rank)
     if rank == 0:
         ai = dist_info if use_dist else solver.info()
         n, nnz = int(ai.n_velocity), (nnz_total if use_dist else int(ai.nnz))
@@ -190,16 +281,17 @@ def main():
         bpn = int(fmt.bytes_per_nonzero)
         stored_bytes = local_bytes - (12 - bpn) * (local_bytes - 4 * (n + 1) - 16 * n) / 12.0 if not use_dist else None
         stored_rate = stored_bytes / (mean_spmv_ms * 1e-3) / 1e9 if stored_bytes and mean_spmv_ms > 0 else None
-        kernel = {4: "k_spmv_vi2<512,4096,DOT,LTAB,PACK,WIN=512> (4 B/nnz packed code|column, brick-major system)",
-                  6: "k_spmv_vi2<512,4096,DOT,LTAB,WIN=512> (6 B/nnz value-indexed, brick-major system)",
-                  12: "k_spmv_tile<512,4096,DOT,VEC,NT> (12 B/nnz, brick-major system)"}[bpn]
-        traffic = None
+        kernel = solver.spmv_kernel_name() if hasattr(solver, "spmv_kernel_name") else f"{bpn} B/nnz"
+        traffic, traffic_source = None, None
         prof = os.path.join(ROOT, "profiles", "spmv_traffic.json")
         if os.path.exists(prof):
             try:
-                rec = json.load(open(prof))
-                if rec.get("n") == n and rec.get("nnz") == nnz and rec.get("bytes_per_nonzero", 12) == bpn:
-                    traffic = rec.get("hbm_bytes_per_launch")
+                recs = json.load(open(prof))
+                for rec in (recs if isinstance(recs, list) else [recs]):
+                    if rec.get("n") == n and rec.get("nnz") == nnz and rec.get("bytes_per_nonzero", 12) == bpn:
+                        traffic = rec.get("hbm_bytes_per_launch")
+                        traffic_source = ("profiles/spmv_traffic.json <- " + str(rec.get("source", "?")) +
+                                          " (PMC passes of an EARLIER run of this workload, not of this process)")
             except Exception:
                 traffic = None
         out = {
@@ -215,17 +307,18 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"fat_beam {a.n}^3 base grid, {levels}-level octree, uniform viscosity 1e4, "
-                                   f"Jacobi-PCG solve to tol {a.tol:g} (warm start)",
+            "config": {"workload": f"{wl}, {levels}-level octree, Jacobi-PCG solve to tol {a.tol:g} (warm start)",
+                       "baseline_config": a.config,
                        "n_dofs": n, "nnz": nnz, "cg_iterations_per_step": iters_total // a.steps,
                        "parallelism": (f"slab x{world}, distributed assembly" if use_dist else "single")},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": local_bytes, "mean_launch_us": mean_spmv_ms * 1e3,
                          "frac_of_achievable_6290": achieved / 6290.0,
                          "stored_bytes_per_nonzero": bpn, "stored_bytes_per_launch": stored_bytes,
                          "stored_rate_gbps": stored_rate,
                          "stored_frac": (stored_rate / HBM_PEAK_GBPS) if stored_rate else None,
+                         "value_table_size": int(fmt.value_table_size),
                          "note": "achieved/frac follow SURVEY 8(d) (12 B per non-zero); the matrix is streamed in a lossless "
                                  f"{bpn}-B form, so frac is an effective rate and may exceed 1 -- stored_* is the physical stream"},
             "solve_event_iter_per_s": iters_total / (sum(solve_ms) * 1e-3),
@@ -237,9 +330,13 @@ def main():
             "transfer_to_regular_grid_ms": transfer_ms,
             "end_to_end_ms": (sum(prepass_ms.values()) + assemble_wall_ms + elapsed / a.steps * 1e3 + transfer_ms) if transfer_ms else None,
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if use_dist:
+            out["dist"] = {"per_rank": [dict(zip(("n_own", "n_halo", "nnz_local", "n_send", "n_peers"), r)) for r in per_rank],
+                           **solver.dist_comm_info()}
+        if world == 1 and not a.no_cpu_baseline and not use_dist:
             out["cpu_baseline"] = cpu_baseline(solver, a.tol, a.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            out["speedup_vs_cpu_all_parallel"] = out["value"] / out["cpu_baseline"]["all_parallel"]["iter_per_s"]
         print(json.dumps(out), flush=True)
     if world > 1 or under_launcher:
         torch.distributed.barrier()

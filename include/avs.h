@@ -322,6 +322,22 @@ avs_status avs_dist_get_plan_arrays(avs_ctx *ctx, int32_t *own_global, int32_t *
                                     int32_t *send_idx, int32_t *peers, int32_t *send_counts, int32_t *recv_counts,
                                     int32_t *tiles_interior, int32_t *tiles_boundary);
 avs_status avs_dist_solve(avs_ctx *ctx, double tolerance, int32_t max_iterations, avs_solve_info *info);
+/* how the partitioned solve of this context communicates (filled after avs_dist_partition / avs_dist_assemble) */
+typedef enum {
+    AVS_TRANSPORT_RCCL = 0,   /* k_pack + ncclSend/ncclRecv halo exchange, ncclAllReduce of the CG scalars */
+    AVS_TRANSPORT_DIRECT = 1  /* peer-mapped comm blocks (IPC handles / peer access over xGMI): boundary entries are stored
+                                 straight into the neighbour's halo area, CG scalars by a flag-based all-gather; no RCCL call
+                                 inside the iteration */
+} avs_dist_transport;
+typedef struct {
+    int32_t world_size;
+    int32_t rccl_ranks;                /* ncclCommCount of the communicator; 0 = no RCCL communicator (in-process / hosted group) */
+    int32_t transport;                 /* avs_dist_transport the next avs_dist_solve will use */
+    int32_t graph_replay;              /* 1 = full chunks of iterations are replayed from a captured hipGraph */
+    int32_t launches_per_iteration;    /* kernel launches per CG iteration of the loop in use */
+    int32_t collectives_per_iteration; /* RCCL calls per CG iteration */
+} avs_dist_info;
+avs_status avs_dist_get_info(avs_ctx *ctx, avs_dist_info *info);
 /* gathers the full solution (global DOF order) on every rank */
 avs_status avs_dist_get_solution(avs_ctx *ctx, double *x, int64_t n, avs_memspace where);
 

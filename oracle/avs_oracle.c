@@ -2174,16 +2174,28 @@ static void *numa_copy(const void *src, size_t bytes, int threads)
 }
 
 static int orc_pcg_csr_impl(int64_t n, const int64_t *row_ptr, const int32_t *col, const double *val,
-                            const double *b, double *x, double tol, int max_iters, int threads,
+                            const double *b, double *x, double tol, int max_iters, int spmv_threads, int threads,
                             orc_pcg_info *info);
 
 int orc_pcg_csr(int64_t n, const int64_t *row_ptr, const int32_t *col, const double *val,
                 const double *b, double *x, double tol, int max_iters, int threads,
                 orc_pcg_info *info)
 {
-    if (threads < 1) threads = 1;
+    return orc_pcg_csr_ex(n, row_ptr, col, val, b, x, tol, max_iters, threads, threads, info);
+}
+
+/* spmv_threads: OpenMP threads of the row-parallel SpMV; vec_threads: threads of the dots / AXPYs.
+ * Eigen parallelises only the sparse product (Lower|Upper with OpenMP, reference CMakeLists.txt:27-32):
+ * "eigen_faithful" = (T, 1); "all_parallel" = (T, T). */
+int orc_pcg_csr_ex(int64_t n, const int64_t *row_ptr, const int32_t *col, const double *val,
+                   const double *b, double *x, double tol, int max_iters, int spmv_threads, int vec_threads,
+                   orc_pcg_info *info)
+{
+    if (spmv_threads < 1) spmv_threads = 1;
+    if (vec_threads < 1) vec_threads = 1;
+    const int threads = spmv_threads;
     if (threads == 1 || n < (1 << 20))
-        return orc_pcg_csr_impl(n, row_ptr, col, val, b, x, tol, max_iters, threads, info);
+        return orc_pcg_csr_impl(n, row_ptr, col, val, b, x, tol, max_iters, spmv_threads, vec_threads, info);
     /* large parallel runs (the bench's cpu_baseline): NUMA-local copies of the system.  Row blocks of
      * the static schedule own contiguous nnz ranges only approximately; good enough for streaming. */
     const int64_t nnz = row_ptr[n];
@@ -2194,7 +2206,7 @@ int orc_pcg_csr(int64_t n, const int64_t *row_ptr, const int32_t *col, const dou
     double *xx = (double *)numa_copy(x, (size_t)n * sizeof(double), threads);
     int rc = 2;
     if (rp && cl && vl && bb && xx) {
-        rc = orc_pcg_csr_impl(n, rp, cl, vl, bb, xx, tol, max_iters, threads, info);
+        rc = orc_pcg_csr_impl(n, rp, cl, vl, bb, xx, tol, max_iters, spmv_threads, vec_threads, info);
         memcpy(x, xx, (size_t)n * sizeof(double));
     }
     free(rp); free(cl); free(vl); free(bb); free(xx);
@@ -2202,22 +2214,23 @@ int orc_pcg_csr(int64_t n, const int64_t *row_ptr, const int32_t *col, const dou
 }
 
 static int orc_pcg_csr_impl(int64_t n, const int64_t *row_ptr, const int32_t *col, const double *val,
-                            const double *b, double *x, double tol, int max_iters, int threads,
+                            const double *b, double *x, double tol, int max_iters, int spmv_threads, int threads,
                             orc_pcg_info *info)
 {
-    if (threads < 1) threads = 1;
+    if (threads < 1) threads = 1; /* vector ops */
+    if (spmv_threads < 1) spmv_threads = 1;
     double *r = (double *)malloc((size_t)n * sizeof(double));
     double *p = (double *)malloc((size_t)n * sizeof(double));
     double *z = (double *)malloc((size_t)n * sizeof(double));
     double *tmp = (double *)malloc((size_t)n * sizeof(double));
     double *invd = (double *)malloc((size_t)n * sizeof(double));
     if (!r || !p || !z || !tmp || !invd) { free(r); free(p); free(z); free(tmp); free(invd); return 2; }
-    if (threads > 1) {
-#pragma omp parallel for schedule(static) num_threads(threads)
+    if (spmv_threads > 1) { /* first touch by the threads that stream the rows */
+#pragma omp parallel for schedule(static) num_threads(spmv_threads)
         for (int64_t i = 0; i < n; ++i) { r[i] = 0.; p[i] = 0.; z[i] = 0.; tmp[i] = 0.; invd[i] = 0.; }
     }
     /* DiagonalPreconditioner::factorize: invdiag = 1/A(j,j) if != 0 else 1 */
-#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
+#pragma omp parallel for schedule(static) num_threads(spmv_threads) if (spmv_threads > 1)
     for (int64_t i = 0; i < n; ++i) {
         double d = 0.;
         int have = 0;
@@ -2228,7 +2241,7 @@ static int orc_pcg_csr_impl(int64_t n, const int64_t *row_ptr, const int32_t *co
     double t0 = now_s(), tspmv = 0.;
     int iters = 0;
     double err = 0.;
-    orc_spmv_csr(n, row_ptr, col, val, x, tmp, threads);
+    orc_spmv_csr(n, row_ptr, col, val, x, tmp, spmv_threads);
     for (int64_t i = 0; i < n; ++i) r[i] = b[i] - tmp[i];
     double rhsNorm2 = dot_(n, b, b, threads);
     if (rhsNorm2 == 0.) {
@@ -2251,7 +2264,7 @@ static int orc_pcg_csr_impl(int64_t n, const int64_t *row_ptr, const int32_t *co
         int i = 0;
         while (i < max_iters) {
             double ts = now_s();
-            orc_spmv_csr(n, row_ptr, col, val, p, tmp, threads);
+            orc_spmv_csr(n, row_ptr, col, val, p, tmp, spmv_threads);
             tspmv += now_s() - ts;
             double alpha = absNew / dot_(n, p, tmp, threads);
             if (threads > 1) {
@@ -2288,7 +2301,7 @@ done:
         info->rhs_norm2 = rhsNorm2;
         info->seconds = now_s() - t0;
         info->spmv_seconds = tspmv;
-        info->threads = threads;
+        info->threads = spmv_threads;
     }
     free(r); free(p); free(z); free(tmp); free(invd);
     return 0;

@@ -111,6 +111,10 @@ typedef struct {
 int orc_pcg_csr(int64_t n, const int64_t *row_ptr, const int32_t *col, const double *val,
                 const double *b, double *x_inout, double tol, int max_iters, int threads,
                 orc_pcg_info *info);
+/* separate thread counts for the SpMV and for the vector operations ("eigen_faithful" = (T, 1), see the .c file) */
+int orc_pcg_csr_ex(int64_t n, const int64_t *row_ptr, const int32_t *col, const double *val,
+                   const double *b, double *x, double tol, int max_iters, int spmv_threads, int vec_threads,
+                   orc_pcg_info *info);
 int orc_spmv_csr(int64_t n, const int64_t *row_ptr, const int32_t *col, const double *val,
                  const double *x, double *y, int threads);
 int orc_solve(orc_ctx *c, double tol, int max_iters, int threads, double *x_out, orc_pcg_info *info);

@@ -1,0 +1,97 @@
+#!/usr/bin/env python
+"""cpu_baseline.py -- the CPU oracle's Jacobi-PCG timed on the host cores of this box.
+
+TEST INFRASTRUCTURE: executed only by bench.py's `cpu_baseline` leg, in a CLEAN subprocess (no torch,
+no second OpenMP runtime in the address space).  The parent sets OMP_PROC_BIND / OMP_PLACES /
+OMP_NUM_THREADS in the child's environment BEFORE the interpreter starts, so libgomp sees them.
+
+SURVEY.md 8(d) asks for two variants of the reference's CPU solve on the same CSR system:
+  eigen_faithful : OpenMP row-parallel SpMV, serial dots / AXPYs -- what Eigen::ConjugateGradient<..,
+                   Lower|Upper> does when built with -fopenmp (reference CMakeLists.txt:27-32)
+  all_parallel   : every vector operation parallel too (a generous baseline)
+
+usage: cpu_baseline.py <dir with row_ptr.npy col.npy val.npy rhs.npy x0.npy> <tol> <budget_seconds> <threads>
+prints one JSON object.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class PcgInfo(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("error", C.c_double), ("rhs_norm2", C.c_double),
+                ("seconds", C.c_double), ("spmv_seconds", C.c_double), ("threads", C.c_int)]
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def physical_cores(cpus):
+    """distinct (package, core) pairs among the logical CPUs of the affinity mask"""
+    seen = set()
+    for c in cpus:
+        try:
+            base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+            seen.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        except OSError:
+            seen.add(("?", c))
+    return len(seen)
+
+
+def main():
+    d, tol, budget, threads = sys.argv[1], float(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4])
+    L = C.CDLL(os.path.join(HERE, "libavs_oracle.so"))
+    vp = C.c_void_p
+    L.orc_pcg_csr_ex.argtypes = [C.c_int64, vp, vp, vp, vp, vp, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(PcgInfo)]
+    rp = np.load(os.path.join(d, "row_ptr.npy")).astype(np.int64)
+    col = np.load(os.path.join(d, "col.npy"))
+    val = np.load(os.path.join(d, "val.npy"))
+    rhs = np.load(os.path.join(d, "rhs.npy"))
+    x0 = np.load(os.path.join(d, "x0.npy"))
+    n, nnz = len(rhs), int(rp[-1])
+    spmv_bytes = 12 * nnz + 4 * (n + 1) + 16 * n      # SURVEY 8(d), same figure as the GPU roofline
+
+    def run(spmv_threads, vec_threads, iters):
+        x = x0.copy()
+        info = PcgInfo()
+        rc = L.orc_pcg_csr_ex(n, rp.ctypes.data, col.ctypes.data, val.ctypes.data, rhs.ctypes.data, x.ctypes.data,
+                              tol, iters, spmv_threads, vec_threads, C.byref(info))
+        if rc != 0:
+            raise RuntimeError(f"orc_pcg_csr_ex failed: {rc}")
+        return info
+
+    out = {"cpu_model": cpu_model(), "threads": threads, "n": n, "nnz": nnz, "variants": {}}
+    share = budget / 2.0
+    for name, vt in (("eigen_faithful", 1), ("all_parallel", threads)):
+        t0 = time.perf_counter()
+        probe = run(threads, vt, 3)
+        per_iter = max(probe.seconds / 3.0, 1e-6)
+        left = share - (time.perf_counter() - t0)
+        iters = int(max(3, min(2500, left / per_iter)))
+        info = run(threads, vt, iters)
+        done = max(info.iterations, 1)
+        per_spmv = info.spmv_seconds / done
+        out["variants"][name] = {
+            "iter_per_s": done / info.seconds, "iterations": done, "seconds": info.seconds,
+            "spmv_share": info.spmv_seconds / max(info.seconds, 1e-12),
+            "spmv_gbps": spmv_bytes / max(per_spmv, 1e-12) / 1e9, "spmv_threads": threads, "vector_threads": vt}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,8 +1,7 @@
-"""Pre-pass: everything solveGasSubclass does BEFORE the hot path (cpp:233-416), as tensor ops.
-
-This is input synthesis for the hot path -- SURVEY.md 8(f) "next #1/#4", out of the round-1
-kernel scope -- written on torch so that the 512^3 inputs are produced directly in HBM (bench.py)
-and the same code can be checked on the host against the CPU oracle (tests/test_prepass.py).
+"""TEST INFRASTRUCTURE: a second, independent restatement of the pre-pass (everything solveGasSubclass does
+BEFORE the hot path, cpp:233-416) as torch tensor ops.  It is not part of the product: the product's pre-pass is
+avs_prepass.hip behind avs_prepass_* (include/avs.h).  tests/test_prepass.py requires it to agree bit for bit with
+the C oracle's pre-pass on the CPU -- two implementations written differently that must produce the same integers.
 It restates:
   * integration weights    cpp:712-766  (HDK computeSDFWeightsSampled: unpinned, defined in
                            oracle/avs_oracle.c `weights_for_lattice`; same definition here)

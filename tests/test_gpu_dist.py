@@ -8,18 +8,18 @@ import numpy as np
 import pytest
 import torch
 
-from adaptiveviscositysolver_amd import ViscositySolve, capi, prepass, scenes
-from util import rel_l2
+from adaptiveviscositysolver_amd import ViscositySolve, capi, scenes
+from util import build_pyramid, feed, rel_l2
 
 pytestmark = pytest.mark.gpu
 
 
 def make_solver(sc, pyr):
     s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
-    s.set_pyramid(pyr)
+    feed(s, pyr)
     s.set_scene_fields(sc)
     for a in range(3):   # every regular face a DOF candidate: enough for the transfer smoke check below
-        s.set_regular_index_field(a, torch.where(pyr.vidx[0][a] == -3, torch.full_like(pyr.vidx[0][a], -1), torch.zeros_like(pyr.vidx[0][a])).contiguous())
+        s.set_regular_index_field(a, np.where(pyr.vidx[0][a] == -3, -1, 0).astype(np.int32))
     s.assemble()
     return s
 
@@ -28,7 +28,7 @@ def make_solver(sc, pyr):
 def test_virtual_ranks_match_single_solve(world, cut_axis, built_lib):
     dev = torch.device("cuda:0")
     sc = scenes.fat_beam(64, 3, variable_viscosity=True, device=dev)
-    pyr = prepass.build_pyramid(sc)
+    pyr = build_pyramid(sc)
     ref = make_solver(sc, pyr)
     tol = 1e-10
     iref = ref.solve(tol, 5000)
@@ -83,7 +83,7 @@ def test_rccl_world_size_one(built_lib):
     """RCCL transport with a single rank: communicator creation, partition, solve."""
     dev = torch.device("cuda:0")
     sc = scenes.fat_beam(32, 3, device=dev)
-    pyr = prepass.build_pyramid(sc)
+    pyr = build_pyramid(sc)
     s = make_solver(sc, pyr)
     ref = s.solve(1e-10, 5000)
     xref = s.solution()
@@ -117,7 +117,7 @@ def test_device_planner_equals_host_planner(world, cut_axis, scene, built_lib, m
     copy of the pattern.  Every array of every rank must be identical (integer work: bit-exact)."""
     dev = torch.device("cuda:0")
     sc = scenes.fat_beam(64, 3, device=dev) if scene == "beam" else scenes.sphere(64, 4, device=dev)
-    pyr = prepass.build_pyramid(sc)
+    pyr = build_pyramid(sc)
     s = make_solver(sc, pyr)
     lib = capi.load()
     for r in range(world):
@@ -146,7 +146,7 @@ def test_distributed_assembly_matches_single_solve(world, cut_axis, scene, built
     sc = {"beam": lambda: scenes.fat_beam(64, 3, device=dev),
           "varvisc": lambda: scenes.fat_beam(64, 3, variable_viscosity=True, device=dev),
           "sphere": lambda: scenes.sphere(64, 4, device=dev)}[scene]()
-    pyr = prepass.build_pyramid(sc)
+    pyr = build_pyramid(sc)
     ref = make_solver(sc, pyr)
     tol = 1e-10
     iref = ref.solve(tol, 5000)
@@ -158,7 +158,7 @@ def test_distributed_assembly_matches_single_solve(world, cut_axis, scene, built
     solvers = []
     for _ in range(world):
         s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
-        s.set_pyramid(pyr)
+        feed(s, pyr)
         s.set_scene_fields(sc)
         solvers.append(s)
     results, errors = [None] * world, []
@@ -208,9 +208,9 @@ def test_distributed_assembly_call_order(built_lib):
     """Call-sequence errors are reported, not crashed on (avs_status AVS_ESTATE)."""
     dev = torch.device("cuda:0")
     sc = scenes.fat_beam(32, 3, device=dev)
-    pyr = prepass.build_pyramid(sc)
+    pyr = build_pyramid(sc)
     s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
-    s.set_pyramid(pyr)
+    feed(s, pyr)
     s.set_scene_fields(sc)
     with pytest.raises(capi.AvsError) as e:          # no communicator yet
         s.dist_assemble()

@@ -8,8 +8,8 @@ import numpy as np
 import pytest
 import torch
 
-from adaptiveviscositysolver_amd import ViscositySolve, prepass, scenes
-from util import oracle_from_pyramid, rel_l2
+from adaptiveviscositysolver_amd import ViscositySolve, scenes
+from util import build_pyramid, feed, oracle_from_pyramid, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -44,10 +44,10 @@ def test_storage_forms_are_lossless(kind, env, want_bytes, lds_table, monkeypatc
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     sc = _scene(kind)
-    pyr = prepass.build_pyramid(sc)
+    pyr = build_pyramid(sc)
     dsc = scenes.to_device(sc, torch.device("cuda:0"))
     s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
-    s.set_pyramid(pyr)
+    feed(s, pyr)
     s.set_scene_fields(dsc)
     ai = s.assemble()
     fmt = s.matrix_format()
@@ -80,9 +80,9 @@ def test_reference_numbered_csr_is_untouched(built_lib):
     matrix of the reference numbering, bit-exact against the oracle (the dictionary's own exactness --
     table[code[k]] == val[k] -- is what avs_bench_spmv's device-side comparison above establishes)."""
     sc = scenes.fat_beam(32, 3)
-    pyr = prepass.build_pyramid(sc)
+    pyr = build_pyramid(sc)
     s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
-    s.set_pyramid(pyr)
+    feed(s, pyr)
     s.set_scene_fields(scenes.to_device(sc, torch.device("cuda:0")))
     s.assemble()
     assert s.matrix_format().bytes_per_nonzero == 4

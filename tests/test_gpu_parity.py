@@ -9,8 +9,8 @@ import numpy as np
 import pytest
 import torch
 
-from adaptiveviscositysolver_amd import ViscositySolve, capi, pcg_csr, prepass, scenes
-from util import oracle_for_scene, oracle_from_pyramid, rel_l2
+from adaptiveviscositysolver_amd import ViscositySolve, capi, pcg_csr, scenes
+from util import build_pyramid, feed, oracle_for_scene, oracle_from_pyramid, rel_l2
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -28,7 +28,7 @@ SCENES = {
 
 def gpu_solve_for(sc, pyr, enhanced=True):
     s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, use_enhanced_gradients=enhanced, device=0)
-    s.set_pyramid(pyr)
+    feed(s, pyr)
     s.set_scene_fields(sc)
     return s
 
@@ -42,21 +42,21 @@ def dev():
 @pytest.mark.parametrize("name", list(SCENES))
 def test_assembly_bit_exact(name, dev, built_lib):
     sc = scenes.to_device(SCENES[name]("cpu"), dev)
-    pyr = prepass.build_pyramid(sc)
+    pyr = build_pyramid(sc)
     s = gpu_solve_for(sc, pyr)
     ai = s.assemble()
     sc_h = SCENES[name]("cpu")
     o = oracle_for_scene(sc_h)
     o.prepass()
-    # the pre-pass run on the GPU (torch) must reproduce the oracle's integer pyramids
+    # the pre-pass run on the GPU (avs_prepass.hip) must reproduce the oracle's integer pyramids
     assert pyr.levels == o.levels
     assert (pyr.n_velocity, pyr.n_edge, pyr.n_center) == (o.count(0), o.count(1), o.count(2))
     for l in range(o.levels):
-        assert np.array_equal(pyr.labels[l].cpu().numpy(), o.labels(l))
+        assert np.array_equal(pyr.labels[l], o.labels(l))
         for a in range(3):
-            assert np.array_equal(pyr.vidx[l][a].cpu().numpy(), o.index(O.I_VELOCITY, l, a))
-            assert np.array_equal(pyr.eidx[l][a].cpu().numpy(), o.index(O.I_EDGE, l, a))
-        assert np.array_equal(pyr.cidx[l].cpu().numpy(), o.index(O.I_CENTER, l))
+            assert np.array_equal(pyr.vidx[l][a], o.index(O.I_VELOCITY, l, a))
+            assert np.array_equal(pyr.eidx[l][a], o.index(O.I_EDGE, l, a))
+        assert np.array_equal(pyr.cidx[l], o.index(O.I_CENTER, l))
     o.hot_path()
     # stencils
     for got, want in ((s.edge_stencils(), o.edge_stencils()), (s.center_stencils(), o.center_stencils())):
@@ -77,7 +77,7 @@ def test_assembly_bit_exact(name, dev, built_lib):
 @pytest.mark.parametrize("name", ["beam32", "beam64_L3_wall", "beam64_varvisc", "sphere64"])
 def test_solve_matches_oracle(name, dev, built_lib):
     sc = scenes.to_device(SCENES[name]("cpu"), dev)
-    pyr = prepass.build_pyramid(sc)
+    pyr = build_pyramid(sc)
     s = gpu_solve_for(sc, pyr)
     s.assemble()
     tol = 1e-10  # tight: at 1e-3 two correct CGs may differ by 1e-3 (SURVEY 7 "hard parts")
@@ -99,7 +99,7 @@ def test_solve_matches_oracle(name, dev, built_lib):
 def test_enhanced_gradients_off(dev, built_lib):
     sc = scenes.sphere(64, 4, device=dev)
     sc.use_enhanced_gradients = False
-    pyr = prepass.build_pyramid(sc)
+    pyr = build_pyramid(sc)
     s = gpu_solve_for(sc, pyr, enhanced=False)
     s.assemble()
     sc_h = scenes.sphere(64, 4)
@@ -116,7 +116,7 @@ def test_rigid_translation_is_a_fixed_point(dev, built_lib):
     """D u = 0 for a rigid translation => A u = M u, b = M u, x0 = u: zero iterations."""
     sc = scenes.sphere(64, 4, device=dev)
     sc.velocity = scenes.constant_velocity(sc.res, (0.25, -1.5, 0.75), device=dev)
-    pyr = prepass.build_pyramid(sc)
+    pyr = build_pyramid(sc)
     s = gpu_solve_for(sc, pyr)
     s.assemble()
     info = s.solve(1e-8, 100)
@@ -128,7 +128,7 @@ def test_rigid_translation_is_a_fixed_point(dev, built_lib):
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24])
 def test_spmv_variants(variant, dev, built_lib):
     sc = scenes.fat_beam(64, 3, device=dev)
-    pyr = prepass.build_pyramid(sc)
+    pyr = build_pyramid(sc)
     s = gpu_solve_for(sc, pyr)
     s.assemble()
     rp, col, val, rhs = s.csr()
@@ -186,7 +186,7 @@ def test_empty_domain_has_no_dofs(dev, built_lib):
     n = 16
     sc = scenes.fat_beam(n, 1, device=dev)
     sc.liquid = torch.full_like(sc.liquid, 10.0)
-    assert prepass.build_pyramid(sc).levels == 0
+    assert build_pyramid(sc).levels == 0
     s = ViscositySolve((n, n, n), 1.0 / n, 0.01, 1, device=0)
     s.set_labels(0, torch.zeros((n, n, n), dtype=torch.int8, device=dev))
     for a in range(3):
@@ -211,13 +211,13 @@ def test_single_level_uniform_known_answer(dev, built_lib):
     liquid = torch.full((n, n, n), -100.0, dtype=torch.float32, device=dev)
     sc = scenes.Scene(res=(n, n, n), dx=1.0 / n, dt=0.5, levels=1, liquid=liquid, viscosity=8.0, density=4.0,
                       velocity=scenes.smooth_velocity((n, n, n), 1.0 / n, device=dev))
-    pyr = prepass.build_pyramid(sc)
+    pyr = build_pyramid(sc)
     assert pyr.levels == 1
     s = gpu_solve_for(sc, pyr)
     s.assemble()
     rp, col, val, rhs = s.csr()
     kappa = sc.dt * sc.viscosity / sc.dx ** 2
-    row = int(pyr.vidx[0][0][n // 2, n // 2, n // 2].item())
+    row = int(pyr.vidx[0][0][n // 2, n // 2, n // 2])
     v = val[rp[row]:rp[row + 1]]
     c = col[rp[row]:rp[row + 1]]
     assert len(v) == 15 and v[c == row][0] == sc.density + 8 * kappa
@@ -227,7 +227,7 @@ def test_single_level_uniform_known_answer(dev, built_lib):
 
 def test_inconsistent_inputs_are_rejected(dev, built_lib):
     sc = scenes.fat_beam(32, 3, device=dev)
-    pyr = prepass.build_pyramid(sc)
+    pyr = build_pyramid(sc)
     s = gpu_solve_for(sc, pyr)
     s.set_dof_counts(pyr.n_velocity - 5, pyr.n_edge, pyr.n_center)     # an id >= declared count
     with pytest.raises(capi.AvsError) as e:
@@ -239,12 +239,12 @@ def test_inconsistent_inputs_are_rejected(dev, built_lib):
     assert e.value.status == capi.EINVAL
     s.set_dof_counts(pyr.n_velocity, pyr.n_edge, pyr.n_center)
     # corrupt one velocity index so that a stencil no longer contains its row DOF: reference assert -> AVS_EINTERNAL
-    bad = pyr.vidx[0][0].clone()
-    k = torch.nonzero(bad >= 0)[100]
-    k2 = torch.nonzero(bad >= 0)[5000]
-    a, b = bad[tuple(k)].item(), bad[tuple(k2)].item()
-    bad[tuple(k)], bad[tuple(k2)] = b, a
-    s.set_index_field(capi.INDEX_VELOCITY, 0, 0, bad.contiguous())
+    bad = pyr.vidx[0][0].copy()
+    k = tuple(np.argwhere(bad >= 0)[100])
+    k2 = tuple(np.argwhere(bad >= 0)[5000])
+    a, b = int(bad[k]), int(bad[k2])
+    bad[k], bad[k2] = b, a
+    s.set_index_field(capi.INDEX_VELOCITY, 0, 0, np.ascontiguousarray(bad))
     s.assemble()   # still a consistent numbering (a permutation): must assemble
     assert s.info().n_velocity == pyr.n_velocity
 
@@ -261,12 +261,12 @@ def test_fields_on_a_smaller_simulation_grid(dev, built_lib):
     visc = (150.0 * (1.0 + 5.0 * x))[None, None, :].expand(n, n, n).to(torch.float32).contiguous()
     sc = scenes.Scene(res=(n, n, n), dx=dx, dt=1.0 / 60.0, levels=3, liquid=liquid, viscosity=visc, density=900.0,
                       velocity=scenes.smooth_velocity((n, n, n), dx, gravity_dt=0.1), name="corner_box")
-    pyr = prepass.build_pyramid(sc)
+    pyr = build_pyramid(sc)
     o = oracle_from_pyramid(sc, pyr)
     o.hot_path()
     want = o.csr()
     s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0, field_res=field_res)
-    s.set_pyramid(pyr)                                  # index pyramids at 64^3; weight fields cropped by set_field
+    feed(s, pyr)                                  # index pyramids at 64^3; weight fields cropped by set_field
     s.set_scene_fields(scenes.to_device(sc, dev))       # viscosity / velocity arrays cropped likewise (device path)
     s.assemble()
     rp, col, val, rhs = s.csr()
@@ -291,7 +291,7 @@ def test_solve_is_deterministic(graph, dev, built_lib, monkeypatch):
     sums): repeating a solve -- with or without hipGraph replay -- reproduces the solution bit for bit."""
     monkeypatch.setenv("AVS_PCG_GRAPH", graph)
     sc = scenes.fat_beam(128, 3, device=dev)          # 380 k rows: multi-block reduction and graph replay both active
-    pyr = prepass.build_pyramid(sc)
+    pyr = build_pyramid(sc)
     s = gpu_solve_for(sc, pyr)
     s.assemble()
     runs = []
@@ -307,7 +307,7 @@ def test_solve_is_deterministic(graph, dev, built_lib, monkeypatch):
 def test_graph_replay_equals_plain_launches(dev, built_lib, monkeypatch):
     """Replaying captured hipGraph chunks runs the same kernels on the same data: identical iterations and solution."""
     sc = scenes.fat_beam(64, 3, device=dev)
-    pyr = prepass.build_pyramid(sc)
+    pyr = build_pyramid(sc)
     s = gpu_solve_for(sc, pyr)
     s.assemble()
     out = {}

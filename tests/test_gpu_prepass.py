@@ -5,9 +5,9 @@ import numpy as np
 import pytest
 import torch
 
-from adaptiveviscositysolver_amd import DevicePrepass, ViscositySolve, capi, prepass, scenes
+from adaptiveviscositysolver_amd import DevicePrepass, ViscositySolve, capi, scenes
 from oracle import oracle as O
-from util import oracle_for_scene
+from util import build_pyramid, feed, oracle_for_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -55,12 +55,13 @@ def test_device_prepass_matches_oracle(name, built_lib):
 
 
 def test_device_prepass_full_size_agrees_with_tensor_prepass(built_lib):
-    """512^3: the HIP pre-pass and the tensor-op pre-pass (both on the GPU) give identical pyramids."""
+    """512^3: the HIP pre-pass and the tensor-op restatement (tests/prepass_torch.py, run on the GPU) give identical pyramids."""
+    import prepass_torch
     dev = torch.device("cuda:0")
     sc = scenes.fat_beam(512, 4, device=dev)
     pp = DevicePrepass(sc.res, sc.dx, sc.levels)
     info = pp.run(sc.liquid, sc.solid)
-    pyr = prepass.build_pyramid(sc)
+    pyr = prepass_torch.build_pyramid(sc)
     assert info.levels == pyr.levels
     assert (info.n_velocity, info.n_edge, info.n_center) == (pyr.n_velocity, pyr.n_edge, pyr.n_center)
     lib = capi.load()

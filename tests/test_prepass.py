@@ -1,9 +1,10 @@
-"""The torch pre-pass (product-side input synthesis) against the oracle's C pre-pass: two independent
+"""The torch pre-pass (tests/prepass_torch.py, test infrastructure) against the oracle's C pre-pass: two independent
 restatements of cpp:712-1715 + HDK_OctreeGrid.cpp:4-920 must agree bit for bit."""
 import numpy as np
 import pytest
 
-from adaptiveviscositysolver_amd import prepass, scenes
+import prepass_torch as prepass
+from adaptiveviscositysolver_amd import scenes
 from oracle import oracle as O
 from util import oracle_for_scene
 

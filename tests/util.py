@@ -56,3 +56,67 @@ def oracle_from_pyramid(sc, pyr):
 
 def rel_l2(a, b):
     return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300))
+
+
+class DevicePyramid:
+    """Hot-path inputs produced by the PRODUCT pre-pass (avs_prepass.hip through the C ABI).  Array attributes
+    mirror prepass_torch.Pyramid (numpy, downloaded on first use) so that oracle_from_pyramid accepts both."""
+
+    def __init__(self, sc, device=0):
+        from adaptiveviscositysolver_amd import DevicePrepass, capi
+        self._capi = capi
+        self.pp = DevicePrepass(sc.res, sc.dx, sc.levels, device=device)
+        info = self.pp.run(sc.liquid, sc.solid)
+        self.info = info
+        self.levels = int(info.levels)
+        self.n_velocity, self.n_edge, self.n_center = int(info.n_velocity), int(info.n_edge), int(info.n_center)
+        self._cache = {}
+
+    def _get(self, key, fn):
+        if key not in self._cache:
+            self._cache[key] = fn()
+        return self._cache[key]
+
+    @property
+    def labels(self):
+        return self._get("labels", lambda: [self.pp.labels(l) for l in range(self.levels)])
+
+    @property
+    def vidx(self):
+        return self._get("vidx", lambda: [[self.pp.index(0, l, a) for a in range(3)] for l in range(self.levels)])
+
+    @property
+    def eidx(self):
+        return self._get("eidx", lambda: [[self.pp.index(1, l, a) for a in range(3)] for l in range(self.levels)])
+
+    @property
+    def cidx(self):
+        return self._get("cidx", lambda: [self.pp.index(2, l, 0) for l in range(self.levels)])
+
+    @property
+    def center_weights(self):
+        return self._get("cw", lambda: self.pp.weights(self._capi.FIELD_CENTER_WEIGHTS))
+
+    @property
+    def edge_weights(self):
+        return self._get("ew", lambda: [self.pp.weights(self._capi.FIELD_EDGE_WEIGHTS, a) for a in range(3)])
+
+    @property
+    def face_weights(self):
+        return self._get("fw", lambda: [self.pp.weights(self._capi.FIELD_FACE_WEIGHTS, a) for a in range(3)])
+
+    def apply(self, solver):
+        self.pp.apply(solver)
+
+
+def build_pyramid(sc, device=0):
+    """Pre-pass for a GPU test: the HIP pre-pass of the product (not the torch restatement)."""
+    return DevicePyramid(sc, device)
+
+
+def feed(solver, pyr):
+    """hand a pyramid (device pre-pass or prepass_torch.Pyramid) to a ViscositySolve"""
+    if hasattr(pyr, "apply"):
+        pyr.apply(solver)
+    else:
+        solver.set_pyramid(pyr)
