@@ -87,6 +87,21 @@ def self_launch(a, argv):
 # ---------------------------------------------------------------------------------------------
 # cpu_baseline: clean subprocess, pinned threads, both SURVEY 8(d) variants
 # ---------------------------------------------------------------------------------------------
+def cpu_quota():
+    """CPUs' worth of time the cgroup grants this container (None = unlimited): a 256-CPU affinity mask can sit on a small quota"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]            # cgroup v2
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())          # cgroup v1
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(solver, tol, budget_s):
     import numpy as np
     rp, col, val, rhs = solver.csr()
@@ -94,7 +109,12 @@ def cpu_baseline(solver, tol, budget_s):
     cpus = sorted(os.sched_getaffinity(0))
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from cpu_baseline import physical_cores   # the checker's helper; no compute
-    threads = max(1, physical_cores(cpus))     # one thread per physical core of the affinity mask
+    threads = max(1, physical_cores(cpus))     # one thread per physical core of the affinity mask ...
+    quota = cpu_quota()
+    if quota is not None:                      # ... but never more runnable threads than the cgroup's CPU quota pays for
+        threads = max(1, min(threads, int(quota)))
+    if os.environ.get("AVS_CPU_THREADS"):
+        threads = int(os.environ["AVS_CPU_THREADS"])
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     with tempfile.TemporaryDirectory(dir=base, prefix="avs_cpu_baseline_") as d:
         for name, arr in (("row_ptr", rp), ("col", col), ("val", val), ("rhs", rhs), ("x0", x0)):
@@ -112,7 +132,7 @@ def cpu_baseline(solver, tol, budget_s):
         "value": ef["iter_per_s"], "unit": "iter/s", "cores": threads, "kind": "port",
         "variant": "eigen_faithful (OpenMP row-parallel SpMV, serial dots/AXPYs: what Eigen::ConjugateGradient does, "
                    "reference CMakeLists.txt:27-32)",
-        "cpu_model": r["cpu_model"], "logical_cpus_in_mask": len(cpus), "threads": threads,
+        "cpu_model": r["cpu_model"], "logical_cpus_in_mask": len(cpus), "cgroup_cpu_quota": quota, "threads": threads,
         "omp": "OMP_PROC_BIND=close OMP_PLACES=cores, clean subprocess (no torch / second OpenMP runtime loaded)",
         "eigen_faithful": ef, "all_parallel": apar,
         "sample": f"{ef['iterations']} + {apar['iterations']} PCG iterations (eigen_faithful + all_parallel) of the same "

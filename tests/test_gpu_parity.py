@@ -261,7 +261,8 @@ def test_fields_on_a_smaller_simulation_grid(dev, built_lib):
     visc = (150.0 * (1.0 + 5.0 * x))[None, None, :].expand(n, n, n).to(torch.float32).contiguous()
     sc = scenes.Scene(res=(n, n, n), dx=dx, dt=1.0 / 60.0, levels=3, liquid=liquid, viscosity=visc, density=900.0,
                       velocity=scenes.smooth_velocity((n, n, n), dx, gravity_dt=0.1), name="corner_box")
-    pyr = build_pyramid(sc)
+    import prepass_torch
+    pyr = prepass_torch.build_pyramid(sc)          # pyramid on the padded 64^3 lattice (host tensors)
     o = oracle_from_pyramid(sc, pyr)
     o.hot_path()
     want = o.csr()
