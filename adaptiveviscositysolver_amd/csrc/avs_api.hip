@@ -308,11 +308,12 @@ avs_status avs_get_matrix_format(avs_ctx *c, avs_matrix_format *fmt)
     AVS_REQUIRE(c && fmt, AVS_EINVAL, "null argument");
     if (!c->system_ready && dist_matrix_format(c, fmt)) return AVS_OK; // avs_dist_assemble: the rank's own rows
     AVS_REQUIRE(c->system_ready, AVS_ESTATE, "no system: call avs_assemble first");
-    const bool vi = c->reordered && c->v_table_size > 0;
+    const bool vi = c->reordered && c->vi.table_size > 0;
     fmt->reordered = c->reordered ? 1 : 0;
-    fmt->value_table_size = vi ? c->v_table_size : 0;
-    fmt->column_bits = vi ? c->v_col_bits : 0;
-    fmt->bytes_per_nonzero = !vi ? 12 : (c->v_col_bits > 0 ? 4 : 6);
+    fmt->value_table_size = vi ? c->vi.table_size : 0;
+    fmt->column_bits = vi ? c->vi.col_bits : 0;
+    fmt->bytes_per_nonzero = vi ? c->vi.bytes_per_nonzero() : 12;
+    fmt->tile_local_tables = vi && c->vi.tile_tables ? 1 : 0;
     return AVS_OK;
 }
 
@@ -336,15 +337,7 @@ static CsrView csr_of(avs_ctx *c)
     A.row_ptr = c->reordered ? c->p_row_ptr.p : c->row_ptr.p;
     A.col = c->reordered ? c->p_col.p : c->col.p;
     A.val = c->reordered ? c->p_val.p : c->val.p;
-    if (c->reordered && c->v_table_size > 0) {
-        A.codes = c->v_codes.p;
-        A.table = c->v_table.p;
-        A.table_size = c->v_table_size;
-        if (c->v_col_bits > 0) {
-            A.packed = c->v_packed.p;
-            A.col_bits = c->v_col_bits;
-        }
-    }
+    if (c->reordered) c->vi.apply(A);
     return A;
 }
 
@@ -471,10 +464,8 @@ avs_status avs_pcg_csr(int64_t n, const int32_t *row_ptr, const int32_t *col, co
     PcgWork *w = nullptr;
     {
         DevBuf<int32_t> d_rp, d_col;
-        DevBuf<double> d_val, d_b, d_x, v_table;
-        DevBuf<uint16_t> v_codes;
-        DevBuf<uint32_t> v_packed;
-        int v_table_size = 0, v_col_bits = 0;
+        DevBuf<double> d_val, d_b, d_x;
+        ValueIndex vi;
         CsrView A;
         A.n = n;
         const double *bp = b;
@@ -510,17 +501,8 @@ avs_status avs_pcg_csr(int64_t n, const int32_t *row_ptr, const int32_t *col, co
             // the same lossless stream compression the assembled path gets (value dictionary, packed words); the
             // caller's numbering is kept, so only the x locality of the brick-major order is missing
             if (nnz > 0) {
-                if ((rc = build_value_index(A.val, nnz, v_codes, v_table, &v_table_size, s))) break;
-                if (v_table_size > 0) {
-                    A.codes = v_codes.p;
-                    A.table = v_table.p;
-                    A.table_size = v_table_size;
-                    if ((rc = build_packed_index(v_codes.p, A.col, nnz, n, v_table_size, v_packed, &v_col_bits, s))) break;
-                    if (v_col_bits > 0) {
-                        A.packed = v_packed.p;
-                        A.col_bits = v_col_bits;
-                    }
-                }
+                if ((rc = build_matrix_index(A.row_ptr, A.col, A.val, n, nnz, n, vi, s))) break;
+                vi.apply(A);
             }
             if ((rc = pcg_create(&w, n, n, s))) break;
             if ((rc = pcg_solve(w, A, bp, xp, tol, max_iters, s, info, nullptr))) break;

@@ -66,12 +66,7 @@ struct PcgDist {
     // local system
     DevBuf<int32_t> row_ptr, col;
     DevBuf<double> val, rhs, x0, x;
-    DevBuf<uint16_t> codes;   // value-indexed form of the local rows (shares the context's value table)
-    DevBuf<uint32_t> packed;
-    DevBuf<double> table;     // own value table when the rank assembled its rows itself (avs_dist_assemble)
-    int table_size = 0;       // 0 = the context's table (partition of a replicated system)
-    int col_bits = 0;
-    bool value_indexed = false;
+    ValueIndex vi;            // lossless storage form of the LOCAL rows (own dictionaries: the rank's rows hold a subset of the values)
     PcgWork *pcg = nullptr;
     bool partitioned = false, solved = false, reordered = false;
 
@@ -392,7 +387,7 @@ static avs_status plan_on_device(avs_ctx *c, PcgDist *d, int cut_axis, int exten
     AVS_REQUIRE(world <= 32, AVS_EINVAL, "at most 32 ranks");
     const int32_t *g_rp = ro ? c->p_row_ptr.p : c->row_ptr.p, *g_col = ro ? c->p_col.p : c->col.p;
     const double *g_val = ro ? c->p_val.p : c->val.p;
-    const bool vi = ro && c->v_table_size > 0;
+    const bool vi = false; // the local rows get their own dictionaries afterwards (build_matrix_index)
     const int shift = c->desc.levels - 1;
     const int nplanes = (extent + (1 << shift) - 1) >> shift;
     AVS_REQUIRE(nplanes <= 65535, AVS_EINVAL, "too many cut planes");
@@ -491,7 +486,6 @@ static avs_status plan_on_device(avs_ctx *c, PcgDist *d, int cut_axis, int exten
     AVS_HIP(hipStreamSynchronize(st));
     AVS_TRY(d->col.alloc((size_t)nnz_local));
     AVS_TRY(d->val.alloc((size_t)nnz_local));
-    if (vi) AVS_TRY(d->codes.alloc((size_t)nnz_local));
     const int T = spmv_tile_rows();
     const int64_t ntiles = (n_own + T - 1) / T;
     DevBuf<int32_t> tile_bnd, tile_int, tile_pos;
@@ -501,8 +495,8 @@ static avs_status plan_on_device(avs_ctx *c, PcgDist *d, int cut_axis, int exten
     AVS_HIP(hipMemsetAsync(tile_bnd.p, 0, ((size_t)ntiles + 1) * 4, st));
     if (n_own)
         hipLaunchKernelGGL(k_plan_local_rows, dim3(8192), dim3(256), 0, st, n_own, d->own_global.p, g_rp, g_col, g_val,
-                           vi ? c->v_codes.p : (const uint16_t *)nullptr, g2l.p, d->row_ptr.p, d->col.p, d->val.p,
-                           vi ? d->codes.p : (uint16_t *)nullptr, T, tile_bnd.p);
+                           (const uint16_t *)nullptr, g2l.p, d->row_ptr.p, d->col.p, d->val.p, (uint16_t *)nullptr, T, tile_bnd.p);
+    (void)vi;
 
     // 6. tile lists for the overlap of the exchange with the interior rows
     int64_t n_bnd = 0, n_int = 0;
@@ -756,9 +750,10 @@ bool dist_matrix_format(avs_ctx *c, avs_matrix_format *fmt)
     PcgDist *d = c->dist;
     if (!d || !d->partitioned) return false;
     fmt->reordered = d->reordered ? 1 : 0;
-    fmt->value_table_size = d->value_indexed ? (d->table_size > 0 ? d->table_size : c->v_table_size) : 0;
-    fmt->column_bits = d->value_indexed ? d->col_bits : 0;
-    fmt->bytes_per_nonzero = !d->value_indexed ? 12 : (d->col_bits > 0 ? 4 : 6);
+    fmt->value_table_size = d->vi.table_size;
+    fmt->column_bits = d->vi.col_bits;
+    fmt->bytes_per_nonzero = d->vi.bytes_per_nonzero();
+    fmt->tile_local_tables = d->vi.tile_tables ? 1 : 0;
     return true;
 }
 
@@ -811,11 +806,6 @@ static avs_status plan_on_host(avs_ctx *c, PcgDist *d, int cut_axis, int extent,
         AVS_HIP(hipMemcpyAsync(d->col.p, cl.data(), cl.size() * 4, hipMemcpyHostToDevice, st));
         AVS_HIP(hipMemcpyAsync(d_vs.p, vs.data(), vs.size() * 4, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_gather_i<double>, dim3(grid256(sz.nnz_local)), dim3(256), 0, st, g_val, d_vs.p, d->val.p, sz.nnz_local);
-        if (ro && c->v_table_size > 0) {
-            AVS_TRY(d->codes.alloc((size_t)sz.nnz_local));
-            hipLaunchKernelGGL(k_gather_i<uint16_t>, dim3(grid256(sz.nnz_local)), dim3(256), 0, st, c->v_codes.p, d_vs.p, d->codes.p,
-                               sz.nnz_local);
-        }
     }
     AVS_HIP(hipGetLastError());
     AVS_HIP(hipStreamSynchronize(st));
@@ -944,8 +934,7 @@ avs_status avs_dist_partition(avs_ctx *c, int32_t cut_axis)
     const double *g_rhs = ro ? c->p_rhs.p : c->rhs.p, *g_x0 = ro ? c->p_x0.p : c->x0.p;
     const char *mode = getenv("AVS_DIST_PLAN");
     const bool host_plan = mode && strcmp(mode, "host") == 0;
-    d->value_indexed = false;
-    d->col_bits = 0;
+    d->vi.clear();
     if (host_plan) AVS_TRY(plan_on_host(c, d, cut_axis, extent, ro));
     else AVS_TRY(plan_on_device(c, d, cut_axis, extent, ro));
     avs_plan_sizes sz{};
@@ -965,11 +954,8 @@ avs_status avs_dist_partition(avs_ctx *c, int32_t cut_axis)
             ro2 += d->recv_counts[i];
         }
     }
-    if (ro && c->v_table_size > 0 && sz.nnz_local) { // local values are a subset of the global ones: same table, gathered codes
-        AVS_TRY(build_packed_index(d->codes.p, d->col.p, sz.nnz_local, (int64_t)sz.n_own + sz.n_halo, c->v_table_size, d->packed,
-                                   &d->col_bits, st));
-        d->value_indexed = true;
-    }
+    if (ro && sz.nnz_local) // same lossless compression as the single-GPU solve, on the local rows
+        AVS_TRY(build_matrix_index(d->row_ptr.p, d->col.p, d->val.p, sz.n_own, sz.nnz_local, (int64_t)sz.n_own + sz.n_halo, d->vi, st));
     AVS_TRY(d->rhs.alloc((size_t)sz.n_own));
     AVS_TRY(d->x0.alloc((size_t)sz.n_own));
     AVS_TRY(d->x.alloc((size_t)sz.n_own));
@@ -1017,9 +1003,7 @@ avs_status avs_dist_assemble(avs_ctx *c, int32_t cut_axis, avs_assembly_info *in
     t.start();
     c->system_ready = false; // no global matrix in this mode
     c->reordered = false;
-    d->value_indexed = false;
-    d->col_bits = 0;
-    d->table_size = 0;
+    d->vi.clear();
     AVS_TRY(dist_assemble_device(c, d, cut_axis, extent));
     ai.system_ms = t.stop();
     t.start();
@@ -1035,15 +1019,8 @@ avs_status avs_dist_assemble(avs_ctx *c, int32_t cut_axis, avs_assembly_info *in
             ro2 += d->recv_counts[i];
         }
     }
-    bool vi_on = true;
-    if (const char *e = getenv("AVS_VALUE_INDEX")) vi_on = atoi(e) != 0;
-    if (vi_on && d->nnz_local) { // the rank's own dictionary: its rows only hold a subset of the global values
-        AVS_TRY(build_value_index(d->val.p, d->nnz_local, d->codes, d->table, &d->table_size, st));
-        if (d->table_size > 0) {
-            AVS_TRY(build_packed_index(d->codes.p, d->col.p, d->nnz_local, d->n_own + d->n_halo, d->table_size, d->packed, &d->col_bits, st));
-            d->value_indexed = true;
-        }
-    }
+    if (d->nnz_local) // the rank's own dictionaries: its rows only hold a subset of the global values
+        AVS_TRY(build_matrix_index(d->row_ptr.p, d->col.p, d->val.p, d->n_own, d->nnz_local, d->n_own + d->n_halo, d->vi, st));
     if (!d->comm_stream) {
         AVS_HIP(hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking));
         AVS_HIP(hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming));
@@ -1127,15 +1104,7 @@ avs_status avs_dist_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_i
     A.row_ptr = d->row_ptr.p;
     A.col = d->col.p;
     A.val = d->val.p;
-    if (d->value_indexed) {
-        A.codes = d->codes.p;
-        A.table = d->table_size > 0 ? d->table.p : c->v_table.p;
-        A.table_size = d->table_size > 0 ? d->table_size : c->v_table_size;
-        if (d->col_bits > 0) {
-            A.packed = d->packed.p;
-            A.col_bits = d->col_bits;
-        }
-    }
+    d->vi.apply(A);
     avs_solve_info local{};
     AVS_TRY(pcg_solve(d->pcg, A, d->rhs.p, d->x.p, tol, max_iters, c->stream, &local, d));
     local.n = d->n_global;

@@ -157,7 +157,36 @@ struct CsrView {
     // packed form: packed[k] = codes[k] << col_bits | col[k] (4 B per non-zero) when bits(n) + bits(table) <= 32
     const uint32_t *packed = nullptr;
     int col_bits = 0;
+    // tile-local dictionaries: the codes of the rows of SpMV tile t (spmv_tile_rows() rows) index
+    // table[tab_ptr[t] .. tab_ptr[t + 1]); table_size is then the total over all tiles
+    const int32_t *tab_ptr = nullptr;
 };
+
+// the lossless storage forms of one matrix's values (avs_reorder.hip), owned next to the CSR arrays
+struct ValueIndex {
+    DevBuf<uint16_t> codes;
+    DevBuf<double> table;
+    DevBuf<uint32_t> packed;
+    DevBuf<int32_t> tab_ptr;
+    int table_size = 0;  // 0 = plain CSR
+    int col_bits = 0;    // > 0 = packed words
+    bool tile_tables = false;
+    void clear() { table_size = 0; col_bits = 0; tile_tables = false; }
+    int bytes_per_nonzero() const { return table_size <= 0 ? 12 : (col_bits > 0 ? 4 : 6); }
+    void apply(CsrView &A) const
+    {
+        A.codes = nullptr; A.table = nullptr; A.table_size = 0; A.packed = nullptr; A.col_bits = 0; A.tab_ptr = nullptr;
+        if (table_size <= 0) return;
+        A.codes = codes.p; A.table = table.p; A.table_size = table_size;
+        if (col_bits > 0) { A.packed = packed.p; A.col_bits = col_bits; }
+        if (tile_tables) A.tab_ptr = tab_ptr.p;
+    }
+};
+// picks the most compact lossless form that fits: one dictionary of <= 2048 values (LDS-resident; packed 4-B words when the
+// bits allow), else tile-local dictionaries (values repeat inside a tile even when the matrix has 10^4..10^5 distinct
+// ones: smoothly varying viscosity), else one dictionary of <= 65536 values, else plain CSR
+avs_status build_matrix_index(const int32_t *row_ptr, const int32_t *col, const double *val, int64_t n, int64_t nnz, int64_t n_cols,
+                              ValueIndex &vi, hipStream_t st);
 
 // PCG work space + device scalars (see avs_pcg.hip)
 struct PcgWork;
@@ -262,11 +291,7 @@ struct avs_ctx {
     avs::DevBuf<int32_t> perm, inv, p_row_ptr, p_col;
     avs::DevBuf<double> p_val, p_rhs, p_x0, p_x;
     // value dictionary of the solve matrix (avs_reorder.hip): at most 65536 distinct doubles
-    avs::DevBuf<uint16_t> v_codes;
-    avs::DevBuf<double> v_table;
-    int v_table_size = 0; // 0 = matrix not value-indexed (too many distinct values)
-    avs::DevBuf<uint32_t> v_packed;
-    int v_col_bits = 0;   // 0 = not packed
+    avs::ValueIndex vi;
     bool reordered = false;
     int brick_shift = 3; // 8^3 fine cells per brick; < 0 disables the renumbering
     avs_assembly_info ainfo{};

@@ -327,7 +327,9 @@ typedef int i4_t __attribute__((ext_vector_type(4)));
 
 typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 
-template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, int WIN = 0>
+// TLT > 0: tile-local dictionaries (CsrView::tab_ptr): the tile's own table is staged in LDS (its first TLT entries; the rest
+// -- tiles with more distinct values than that -- is read through L1), codes are tile-local.
+template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, int WIN = 0, int TLT = 0>
 __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__restrict__ x, double *__restrict__ y,
                                                   double *__restrict__ partial, const PcgScalars *sc,
                                                   const int32_t *__restrict__ tiles)
@@ -335,15 +337,26 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
     if (DOT && sc && sc->done) return;
     constexpr int U = CAP / (4 * BLK); // quads per lane per pass
     static_assert(U >= 1 && U * 4 * BLK == CAP, "CAP must be a multiple of 4*BLK");
+    static_assert(TLT == 0 || (!LTAB && !PACK && BLK == 512), "tile tables: 6-B form, 512-row tiles");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     static_assert(WIN == 0 || (WIN >= BLK && WIN % BLK == 0), "window = a whole number of tiles");
     double *prod = smem;                 // CAP + 4
     double *xs = smem + CAP + 4;                           // WIN entries of x around the tile's rows
-    double *tbl = smem + CAP + 4 + WIN;                    // table_size (LTAB only)
+    double *tbl = smem + CAP + 4 + WIN;                    // table_size (LTAB) / TLT entries (tile tables)
     const int tid = threadIdx.x;
-    const double *__restrict__ gtab = A.table;
-    auto value = [&](unsigned code) -> double { return LTAB ? tbl[code] : gtab[code]; };
     const int64_t tile = tiles ? (int64_t)tiles[blockIdx.x] : (int64_t)blockIdx.x;
+    const double *__restrict__ gtab = A.table;
+    int tlen = A.table_size;
+    if (TLT > 0) {
+        const int t0 = A.tab_ptr[tile];
+        gtab = A.table + t0;
+        tlen = A.tab_ptr[tile + 1] - t0;
+        if (tlen > TLT) tlen = TLT;
+    }
+    auto value = [&](unsigned code) -> double {
+        if (TLT > 0) return code < (unsigned)TLT ? tbl[code] : gtab[code];
+        return LTAB ? tbl[code] : gtab[code];
+    };
     const int64_t row0 = tile * BLK;
     const int64_t row = row0 + tid;
     const int64_t rlast = (row0 + BLK < A.n) ? row0 + BLK : A.n;
@@ -369,8 +382,8 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
         }
         return x[col];
     };
-    if (LTAB)
-        for (int i = tid; i < A.table_size; i += BLK) tbl[i] = A.table[i];
+    if (LTAB || TLT > 0)
+        for (int i = tid; i < tlen; i += BLK) tbl[i] = gtab[i];
     const int s_blk = A.row_ptr[row0];
     const int e_blk = A.row_ptr[rlast];
     int rs = 0, re = 0;
@@ -380,7 +393,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
         re = A.row_ptr[row + 1];
         if (DOT && WIN == 0) xr = x[row]; // early: its latency hides behind the passes
     }
-    if (LTAB || WIN > 0) __syncthreads();
+    if (LTAB || WIN > 0 || TLT > 0) __syncthreads();
     if (DOT && WIN > 0 && row < A.n) xr = xs[(int)(row - w0)]; // the tile's own rows are always inside the window
     double sum = 0.;
     for (int ts = s_blk; ts < e_blk; ts += CAP) {
@@ -459,18 +472,30 @@ static constexpr int kTileRows = 512;    // rows per workgroup of the value-inde
 static constexpr int kTileCap = 4096;    // products parked per pass (U = 2 quads per lane)
 static constexpr int kTileWin = 512;     // x entries staged in LDS (the tile's own rows): 38 KiB per workgroup => 32 waves per CU
 
-template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, int WIN = 0>
+template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, int WIN = 0, int TLT = 0>
 static avs_status spmv_vi2_launch_t(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc,
                                     const int32_t *tiles, int ntiles, size_t lds, hipStream_t stream)
 {
     // > 48 KiB of dynamic LDS (value table of ~1.5 k+ entries) needs the opt-in; it is a per-device function attribute, so it
     // is set on every such launch (cheap, rare path) rather than cached in a process-wide flag
     if (lds > 48 * 1024)
-        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, WIN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, WIN, TLT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024 - 4096));
-    hipLaunchKernelGGL((k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, WIN>), dim3(ntiles), dim3(BLK), lds, stream, A, x, y, partial, sc, tiles);
+    hipLaunchKernelGGL((k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, WIN, TLT>), dim3(ntiles), dim3(BLK), lds, stream, A, x, y, partial, sc, tiles);
     AVS_HIP(hipGetLastError());
     return AVS_OK;
+}
+
+static constexpr int kTltLds = 1024;   // tile-table entries staged in LDS (8 KiB; tiles rarely hold more distinct values)
+
+// tile-local dictionaries: 512-row tiles, CAP products per pass, the tile's table next to the x window
+template <int CAP, bool DOT, int TCAP>
+static avs_status spmv_tlt_launch(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc,
+                                  const int32_t *tiles, int ntiles, hipStream_t stream)
+{
+    if (ntiles <= 0) return AVS_OK;
+    const size_t lds = (size_t)(CAP + 4 + kTileWin + TCAP) * sizeof(double);
+    return spmv_vi2_launch_t<kTileRows, CAP, DOT, false, false, kTileWin, TCAP>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
 }
 
 template <int BLK, int CAP, bool DOT, int WIN = 0>
@@ -478,6 +503,10 @@ static avs_status spmv_vi2_launch(const CsrView &A, const double *x, double *y, 
                                   const int32_t *tiles, int ntiles, hipStream_t stream)
 {
     if (ntiles <= 0) return AVS_OK;
+    if (A.tab_ptr) { // tile-local codes: only the tile-table kernel can decode them
+        if (BLK != kTileRows) { set_error("tile-local dictionaries need %d-row tiles", kTileRows); return AVS_EINVAL; }
+        return spmv_tlt_launch<kTileCap, DOT, kTltLds>(A, x, y, partial, sc, tiles, ntiles, stream);
+    }
     const bool ltab = A.table_size <= kViLdsTable;
     const bool pack = A.packed != nullptr;
     const size_t lds = (size_t)(CAP + 4 + WIN + (ltab ? ((A.table_size + 1) & ~1) : 0)) * sizeof(double);
@@ -537,7 +566,19 @@ static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, do
         if (nblocks) *nblocks = nt * (kTileRows / 64);
         return spmv_vi2_launch<kTileRows, kTileCap, DOT, kTileWin>(A, x, y, partial, sc, nullptr, nt, stream);
     }
-    if (A.codes && variant >= 31 && variant <= 46) {
+    if (A.tab_ptr && variant >= 51 && variant <= 56) { // geometry sweep of the tile-table kernel (profiles/r02_varvisc.md)
+        const int nt = (int)((A.n + kTileRows - 1) / kTileRows);
+        if (nblocks) *nblocks = nt * (kTileRows / 64);
+        switch (variant) {
+        case 51: return spmv_tlt_launch<4096, DOT, 1024>(A, x, y, partial, sc, nullptr, nt, stream);
+        case 52: return spmv_tlt_launch<2048, DOT, 2048>(A, x, y, partial, sc, nullptr, nt, stream);
+        case 53: return spmv_tlt_launch<4096, DOT, 2048>(A, x, y, partial, sc, nullptr, nt, stream);
+        case 54: return spmv_tlt_launch<2048, DOT, 1024>(A, x, y, partial, sc, nullptr, nt, stream);
+        case 55: return spmv_tlt_launch<4096, DOT, 512>(A, x, y, partial, sc, nullptr, nt, stream);
+        case 56: return spmv_tlt_launch<2048, DOT, 512>(A, x, y, partial, sc, nullptr, nt, stream);
+        }
+    }
+    if (A.codes && !A.tab_ptr && variant >= 31 && variant <= 46) {
 #define AVS_VI2_CASE(ID, BLK, CAP, ...)                                                                         \
     case ID: {                                                                                                  \
         const int nt = (int)((A.n + BLK - 1) / BLK);                                                            \
@@ -565,7 +606,7 @@ static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, do
     }
     if (variant == 0) variant = spmv_default_variant(A);
     int g;
-    switch (variant) {
+    switch (variant) { // the plain kernels below read A.val / A.col only
     case 1:
         g = stream_grid(A.n);
         hipLaunchKernelGGL((k_spmv_stream<DOT>), dim3(g), dim3(kBlock), 0, stream, A, x, y, partial, sc);
@@ -662,7 +703,7 @@ __global__ __launch_bounds__(kBlock) void k_inv_diag(CsrView A, double *__restri
     if (i >= A.n) return;
     double d = 0.;
     for (int k = A.row_ptr[i]; k < A.row_ptr[i + 1]; ++k)
-        if (A.col[k] == (int32_t)i) d = A.codes ? A.table[A.codes[k]] : A.val[k];
+        if (A.col[k] == (int32_t)i) d = A.val ? A.val[k] : A.table[(A.tab_ptr ? A.tab_ptr[i / kTileRows] : 0) + A.codes[k]];
     invd[i] = (d != 0.) ? 1. / d : 1.;
 }
 

@@ -124,10 +124,7 @@ avs_status build_reordered_system(avs_ctx *c, int brick_shift)
     hipLaunchKernelGGL(k_gather_d, dim3(grid_for(n)), dim3(kBlock), 0, st, c->x0.p, c->perm.p, c->p_x0.p, n);
     AVS_HIP(hipGetLastError());
     AVS_HIP(hipStreamSynchronize(st)); // temporaries die here
-    AVS_TRY(build_value_index(c->p_val.p, nnz, c->v_codes, c->v_table, &c->v_table_size, st));
-    c->v_col_bits = 0;
-    if (c->v_table_size > 0)
-        AVS_TRY(build_packed_index(c->v_codes.p, c->p_col.p, nnz, n, c->v_table_size, c->v_packed, &c->v_col_bits, st));
+    AVS_TRY(build_matrix_index(c->p_row_ptr.p, c->p_col.p, c->p_val.p, n, nnz, n, c->vi, st));
     c->reordered = true;
     return AVS_OK;
 }
@@ -281,6 +278,178 @@ avs_status unpermute(avs_ctx *c, const double *xp, double *x)
     const int64_t n = c->n_vel;
     if (n) hipLaunchKernelGGL(k_gather_d, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, xp, c->inv.p, x, n);
     AVS_HIP(hipGetLastError());
+    return AVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tile-local dictionaries.  With a smoothly varying viscosity every stress weight w_s differs, the matrix holds
+// 10^4..10^5 distinct doubles and ONE dictionary no longer fits in LDS (its look-ups then cost an L1 access each, like
+// the x gathers: 262 us per SpMV at 512^3 vs 276 us for plain 12-B CSR).  But inside one 512-row SpMV tile -- a third
+// of an 8^3 brick -- the same few hundred values repeat (mu varies little across 8 cells, the geometry factors are
+// the usual handful).  So every tile gets its own sorted-by-slot dictionary: 2-B tile-local codes + the tile's table
+// (8 B per distinct value, read once per launch into LDS).  Lossless like the global form: val[k] ==
+// table[tab_ptr[tile] + codes[k]] bit for bit.
+// One workgroup per tile builds an LDS hash set of the tile's values; pass 1 counts, pass 2 (after the scan of the
+// counts) writes tables and codes.  Code assignment follows slot order (it may differ between runs when two keys
+// collide; the VALUES behind the codes, and therefore every product and sum, do not).
+// ---------------------------------------------------------------------------------------------
+static constexpr int kTltRows = 512;       // == spmv_tile_rows()
+static constexpr int kTltSlots = 8192;     // LDS hash slots per tile (64 KiB)
+static constexpr int kTltMaxKeys = 6144;   // more distinct values in one tile: the form is pointless anyway
+
+__device__ __forceinline__ unsigned tlt_hash(unsigned long long k)
+{
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    return (unsigned)k & (kTltSlots - 1);
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(kTltRows) void k_tlt_build(int64_t n, const int32_t *__restrict__ row_ptr, const double *__restrict__ val,
+                                                        int32_t *__restrict__ tab_len, const int32_t *__restrict__ tab_ptr,
+                                                        double *__restrict__ table, uint16_t *__restrict__ codes, int *__restrict__ overflow)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long tlt_smem[];
+    unsigned long long *slots = tlt_smem;                                   // kTltSlots
+    uint16_t *rank = reinterpret_cast<uint16_t *>(tlt_smem + kTltSlots);   // kTltSlots (WRITE only)
+    __shared__ int count, wave_tot[kTltRows / 64];
+    const int tid = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    const int64_t row0 = tile * kTltRows, rlast = (row0 + kTltRows < n) ? row0 + kTltRows : n;
+    const int s = row_ptr[row0], e = row_ptr[rlast];
+    for (int i = tid; i < kTltSlots; i += kTltRows) slots[i] = kEmpty;
+    if (tid == 0) count = 0;
+    __syncthreads();
+    for (int k = s + tid; k < e; k += kTltRows) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(val[k]);
+        unsigned h = tlt_hash(key);
+        while (true) {
+            const unsigned long long cur = slots[h];
+            if (cur == key) break;
+            if (cur == kEmpty) {
+                const unsigned long long old = atomicCAS(&slots[h], kEmpty, key);
+                if (old == kEmpty) { atomicAdd(&count, 1); break; }
+                if (old == key) break;
+            }
+            if (*(volatile int *)&count > kTltMaxKeys) break; // give up: the caller drops the whole form
+            h = (h + 1) & (kTltSlots - 1);
+        }
+    }
+    __syncthreads();
+    const int distinct = count;
+    if (distinct > kTltMaxKeys) {
+        if (tid == 0) { *overflow = 1; if (!WRITE) tab_len[tile] = 0; }
+        return;
+    }
+    if (!WRITE) {
+        if (tid == 0) tab_len[tile] = distinct;
+        return;
+    }
+    // rank of every occupied slot in slot order: thread t owns slots [16 t, 16 t + 16)
+    constexpr int per = kTltSlots / kTltRows;
+    int mine = 0;
+#pragma unroll
+    for (int i = 0; i < per; ++i) mine += slots[tid * per + i] != kEmpty;
+    int inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(inc, o, 64);
+        if ((tid & 63) >= o) inc += u;
+    }
+    if ((tid & 63) == 63) wave_tot[tid >> 6] = inc;
+    __syncthreads();
+    int base = inc - mine;
+    for (int w = 0; w < (tid >> 6); ++w) base += wave_tot[w];
+    const int t0 = tab_ptr[tile];
+#pragma unroll
+    for (int i = 0; i < per; ++i) {
+        const unsigned long long key = slots[tid * per + i];
+        if (key != kEmpty) {
+            rank[tid * per + i] = (uint16_t)base;
+            table[t0 + base] = __longlong_as_double((long long)key);
+            ++base;
+        }
+    }
+    __syncthreads();
+    for (int k = s + tid; k < e; k += kTltRows) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(val[k]);
+        unsigned h = tlt_hash(key);
+        while (slots[h] != key) h = (h + 1) & (kTltSlots - 1);
+        codes[k] = rank[h];
+    }
+}
+
+static avs_status build_tile_tables(const int32_t *row_ptr, const double *val, int64_t n, int64_t nnz, ValueIndex &vi, bool *ok,
+                                    hipStream_t st)
+{
+    *ok = false;
+    if (n == 0 || nnz == 0) return AVS_OK;
+    if (const char *e = getenv("AVS_TILE_TABLES"))
+        if (atoi(e) == 0) return AVS_OK;
+    const int64_t ntiles = (n + kTltRows - 1) / kTltRows;
+    DevBuf<int32_t> tab_len, scan_tmp;
+    DevBuf<int> overflow;
+    AVS_TRY(tab_len.alloc((size_t)ntiles + 1));
+    AVS_TRY(vi.tab_ptr.alloc((size_t)ntiles + 1));
+    AVS_TRY(scan_tmp.alloc(scan_tmp_elems(ntiles + 1)));
+    AVS_TRY(overflow.alloc(1));
+    AVS_HIP(hipMemsetAsync(overflow.p, 0, sizeof(int), st));
+    const size_t lds = (size_t)kTltSlots * (sizeof(unsigned long long) + sizeof(uint16_t));
+    AVS_HIP(hipFuncSetAttribute((const void *)k_tlt_build<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    AVS_HIP(hipFuncSetAttribute((const void *)k_tlt_build<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_tlt_build<false>, dim3((unsigned)ntiles), dim3(kTltRows), lds, st, n, row_ptr, val, tab_len.p,
+                       (const int32_t *)nullptr, (double *)nullptr, (uint16_t *)nullptr, overflow.p);
+    AVS_TRY(exclusive_scan_i32(tab_len.p, vi.tab_ptr.p, ntiles, scan_tmp.p, scan_tmp.n, st));
+    int h_over = 0, total = 0;
+    AVS_HIP(hipMemcpyAsync(&h_over, overflow.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipMemcpyAsync(&total, vi.tab_ptr.p + ntiles, sizeof(int), hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipStreamSynchronize(st));
+    // worth it only while the tables stay a small share of the stream: 8 B per entry against 6 B saved per non-zero
+    if (h_over || total <= 0 || (int64_t)total * 8 > nnz * 2) return AVS_OK;
+    AVS_TRY(vi.table.alloc((size_t)total));
+    AVS_TRY(vi.codes.alloc((size_t)nnz));
+    hipLaunchKernelGGL(k_tlt_build<true>, dim3((unsigned)ntiles), dim3(kTltRows), lds, st, n, row_ptr, val, (int32_t *)nullptr,
+                       (const int32_t *)vi.tab_ptr.p, vi.table.p, vi.codes.p, overflow.p);
+    AVS_HIP(hipGetLastError());
+    AVS_HIP(hipStreamSynchronize(st)); // temporaries die here
+    vi.table_size = total;
+    vi.col_bits = 0;
+    vi.tile_tables = true;
+    *ok = true;
+    return AVS_OK;
+}
+
+avs_status build_matrix_index(const int32_t *row_ptr, const int32_t *col, const double *val, int64_t n, int64_t nnz, int64_t n_cols,
+                              ValueIndex &vi, hipStream_t st)
+{
+    vi.clear();
+    if (nnz == 0) return AVS_OK;
+    if (const char *e = getenv("AVS_VALUE_INDEX"))
+        if (atoi(e) == 0) return AVS_OK;
+    int global_size = 0;
+    AVS_TRY(build_value_index(val, nnz, vi.codes, vi.table, &global_size, st));
+    if (global_size > 0 && global_size <= 2048) { // LDS-resident dictionary (+ packed words when the bits allow)
+        vi.table_size = global_size;
+        AVS_TRY(build_packed_index(vi.codes.p, col, nnz, n_cols, global_size, vi.packed, &vi.col_bits, st));
+        return AVS_OK;
+    }
+    bool ok = false;
+    ValueIndex tiled;
+    AVS_TRY(build_tile_tables(row_ptr, val, n, nnz, tiled, &ok, st));
+    if (ok) {
+        std::swap(vi.codes.p, tiled.codes.p); std::swap(vi.codes.n, tiled.codes.n);
+        std::swap(vi.table.p, tiled.table.p); std::swap(vi.table.n, tiled.table.n);
+        std::swap(vi.tab_ptr.p, tiled.tab_ptr.p); std::swap(vi.tab_ptr.n, tiled.tab_ptr.n);
+        vi.table_size = tiled.table_size;
+        vi.col_bits = 0;
+        vi.tile_tables = true;
+        return AVS_OK;
+    }
+    if (global_size > 0) { // one big dictionary read through L1: still 6 B instead of 12 B per non-zero
+        vi.table_size = global_size;
+        AVS_TRY(build_packed_index(vi.codes.p, col, nnz, n_cols, global_size, vi.packed, &vi.col_bits, st));
+    }
     return AVS_OK;
 }
 

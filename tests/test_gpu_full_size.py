@@ -181,12 +181,21 @@ def test_headline_512_against_the_oracle(built_lib):
     feed(s, pyr)
     s.set_scene_fields(sc)
     ai = s.assemble()
-    threads = max(1, len(os.sched_getaffinity(0)))
+    sys_path = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+    sys.path.insert(0, sys_path)
+    from bench import cpu_quota
+    quota = cpu_quota()
+    threads = max(1, min(len(os.sched_getaffinity(0)) // 2, 64 if quota is None else int(quota)))
+    say = lambda *a: print(f"[{time.time() - t0:6.0f} s]", *a, flush=True)
+    say("gpu side assembled; oracle threads", threads, "quota", quota)
     o = oracle_for_scene(sc_h)
     o.prepass()
     assert (pyr.levels, pyr.n_velocity, pyr.n_edge, pyr.n_center) == (o.levels, o.count(0), o.count(1), o.count(2))
+    say("oracle pre-pass done")
     o.hot_path()
     t1 = time.time()
+    say("oracle hot path done")
     A = o.csr()
     rp, col, val, rhs = s.csr()
     assert ai.nnz == len(A.col) and ai.raw_triplets == o.raw_triplets
@@ -197,7 +206,9 @@ def test_headline_512_against_the_oracle(built_lib):
     # reference settings (tol 1e-3): the iteration count is the bench's "cg_iterations_per_step"
     i3 = s.solve(1e-3, 2500)
     x3 = s.solution()
+    say("CSR / rhs / x0 bit-exact; oracle solve 1e-3 ...")
     xo3, io3 = o.solve(1e-3, 2500, threads=threads)
+    say("oracle 1e-3 done", io3.iterations, "iterations,", io3.seconds, "s")
     assert i3.converged == 1 and abs(i3.iterations - io3.iterations) <= 3, (i3.iterations, io3.iterations)
     assert float(np.linalg.norm(x3 - xo3) / np.linalg.norm(xo3)) < 1e-5
     # tight tolerance: the velocity field itself (north_star: 1e-5 relative L2)

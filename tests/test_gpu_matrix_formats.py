@@ -1,5 +1,5 @@
-"""The solver's SpMV streams one of three LOSSLESS storage forms of the assembled matrix (avs_matrix_format):
-12 B/non-zero plain CSR, 6 B value-indexed, 4 B packed.  Every form must give the products and row sums of
+"""The solver's SpMV streams one of the LOSSLESS storage forms of the assembled matrix (avs_matrix_format):
+12 B/non-zero plain CSR, 6 B value-indexed (one dictionary, or one dictionary per 512-row tile), 4 B packed.  Every form must give the products and row sums of
 plain CSR bit for bit (avs_bench_spmv checks that on the device and fails otherwise), and the solve behind
 each form must agree with the CPU oracle.  The scenes below are chosen so that every kernel instantiation
 (table in LDS / table in global memory) x (packed / unpacked) and the no-dictionary fallback are exercised.
@@ -23,18 +23,23 @@ def _scene(kind):
     if kind == "levels":   # a handful of viscosities -> a dictionary of a few thousand matrix values
         pal = torch.tensor([120.0, 250.0, 380.0, 510.0, 640.0, 770.0, 900.0, 1030.0], dtype=torch.float32)
         sc.viscosity = pal[torch.randint(0, len(pal), shape, generator=g)].contiguous()
+    elif kind == "smooth":  # BASELINE configs[2]: mu(x) = 200 (1 + 9 x) -> thousands of distinct values, few per tile
+        return scenes.fat_beam(64, 3, variable_viscosity=True)
     elif kind == "noise":  # every cell its own viscosity -> more than 65536 distinct matrix values
         sc.viscosity = (100.0 + 900.0 * torch.rand(shape, generator=g, dtype=torch.float32)).contiguous()
     return sc
 
 
+NO_TILES = {"AVS_TILE_TABLES": "0"}
 CASES = [
-    # scene,   environment,                 expected bytes per non-zero, table in LDS?
+    # scene,   environment,                 expected bytes per non-zero, one table in LDS? ("tile" = tile-local tables)
     ("uniform", {}, 4, True),
     ("uniform", {"AVS_VALUE_PACK": "0"}, 6, True),
     ("uniform", {"AVS_VALUE_INDEX": "0"}, 12, None),
-    ("levels", {}, 4, False),
-    ("levels", {"AVS_VALUE_PACK": "0"}, 6, False),
+    ("levels", {}, 6, "tile"),
+    ("smooth", {}, 6, "tile"),
+    ("levels", NO_TILES, 4, False),
+    ("levels", {**NO_TILES, "AVS_VALUE_PACK": "0"}, 6, False),
     ("noise", {}, 12, None),
 ]
 
@@ -53,8 +58,15 @@ def test_storage_forms_are_lossless(kind, env, want_bytes, lds_table, monkeypatc
     fmt = s.matrix_format()
     assert fmt.reordered == 1
     assert fmt.bytes_per_nonzero == want_bytes, (fmt.value_table_size, fmt.column_bits)
+    assert fmt.tile_local_tables == (1 if lds_table == "tile" else 0)
     if want_bytes == 12:
         assert fmt.value_table_size == 0 and fmt.column_bits == 0
+    elif lds_table == "tile":
+        # the tables must stay a small share of the stream (8 B per entry vs 6 B saved per non-zero)
+        assert 0 < fmt.value_table_size * 8 <= ai.nnz * 2 and fmt.column_bits == 0
+        for variant in (51, 52, 53, 54, 55, 56):      # LDS geometries of the tile-table kernel
+            s.bench_spmv(variant, 1)
+            s.bench_spmv(100 + variant, 1)
     else:
         assert 0 < fmt.value_table_size <= 65536
         assert (fmt.value_table_size <= 2048) == lds_table, fmt.value_table_size
