@@ -18,6 +18,7 @@ MAX_LEVELS = 8
 EDGE_STENCIL_CAP, CENTER_STENCIL_CAP = 32, 8
 EDGE_BOUNDARY_CAP, CENTER_BOUNDARY_CAP = 4, 2
 UNIQUE_ID_BYTES = 128
+DIST_BLOB_BYTES = 512
 
 OK, EINVAL, ENOMEM, EHIP, ERCCL, EINTERNAL, ESTATE = range(7)
 STATUS_NAMES = {0: "AVS_OK", 1: "AVS_EINVAL", 2: "AVS_ENOMEM", 3: "AVS_EHIP", 4: "AVS_ERCCL",
@@ -43,7 +44,7 @@ EXPORTED_SYMBOLS = [
     "avs_plan_get_arrays", "avs_plan_destroy", "avs_dist_get_unique_id", "avs_dist_init",
     "avs_local_group_create", "avs_local_group_destroy", "avs_dist_init_local", "avs_dist_partition",
     "avs_spmv_tile_rows", "avs_dist_assemble", "avs_dist_get_plan_sizes", "avs_dist_get_overlap_tiles", "avs_dist_get_plan_arrays", "avs_dist_solve", "avs_dist_get_solution",
-    "avs_dist_get_info",
+    "avs_dist_get_info", "avs_dist_init_hosted", "avs_dist_export_blob", "avs_dist_import_blobs",
 ]
 _VOID_RETURN = ("avs_last_error", "avs_version", "avs_destroy", "avs_plan_destroy", "avs_local_group_destroy",
                 "avs_prepass_destroy")
@@ -177,6 +178,9 @@ def load():
     L.avs_dist_solve.argtypes = [vp, f64, i32, C.POINTER(SolveInfo)]
     L.avs_dist_get_solution.argtypes = [vp, vp, i64, i32]
     L.avs_dist_get_info.argtypes = [vp, C.POINTER(DistInfo)]
+    L.avs_dist_init_hosted.argtypes = [vp, i32, i32]
+    L.avs_dist_export_blob.argtypes = [vp, vp]
+    L.avs_dist_import_blobs.argtypes = [vp, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
         if name not in _VOID_RETURN:

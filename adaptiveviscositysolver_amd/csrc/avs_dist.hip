@@ -14,6 +14,8 @@
 // reduction logic and is what tests/test_gpu_dist.py checks against the single-rank solve.
 #include <rccl/rccl.h>
 
+#include <unistd.h>
+
 #include <algorithm>
 #include <condition_variable>
 #include <cstdlib>
@@ -31,6 +33,8 @@ struct avs_local_group {
     long generation = 0;
     std::vector<avs::PcgDist *> members;
     std::vector<double> red; // world x 4 staging for all-reduce
+    std::vector<uint8_t> blobs; // world x AVS_DIST_BLOB_BYTES: comm-block descriptors of the direct transport
+    int direct_votes = 0;       // members whose direct_connect succeeded (agreement: all or none)
     bool failed = false;
 
     void barrier()
@@ -69,6 +73,20 @@ struct PcgDist {
     ValueIndex vi;            // lossless storage form of the LOCAL rows (own dictionaries: the rank's rows hold a subset of the values)
     PcgWork *pcg = nullptr;
     bool partitioned = false, solved = false, reordered = false;
+
+    // direct transport (peer-mapped comm blocks), see avs_internal.hpp
+    int transport = AVS_TRANSPORT_RCCL;
+    bool hosted = false;          // neither RCCL communicator nor in-process group: the host program carries the blobs
+    void *comm_block = nullptr;
+    size_t comm_bytes = 0;
+    void *peer_block[kMaxRanks] = {};
+    bool peer_ipc[kMaxRanks] = {}; // mapped with hipIpcOpenMemHandle (to be closed)
+    DevBuf<DistDev> dd;
+    DevBuf<unsigned long long> epoch;
+    DevBuf<unsigned> tickets;
+    std::vector<uint8_t> blob;
+    bool direct_prepared = false, direct_ready = false;
+    bool direct_pending = false; // a new plan exists: the (collective) transport set-up runs at the next avs_dist_solve
 
     // overlap of the exchange with the interior rows
     hipStream_t comm_stream = nullptr;
@@ -205,10 +223,276 @@ bool dist_wants_single_reduction(PcgDist *d)
     return !(e && strcmp(e, "standard") == 0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Direct transport: set-up.  Each rank allocates its comm block (fine-grained device memory: header + halo area),
+// describes it in a blob (IPC handle, pid, raw pointer, where each peer's entries land), the blobs travel (RCCL
+// all-gather / in-process group / the host program), every rank maps its peers' blocks and fills its DistDev.
+// ---------------------------------------------------------------------------------------------
+struct DistBlob {
+    uint32_t magic;
+    int32_t rank, pid, device;
+    uint64_t raw_ptr, bytes;
+    int64_t n_halo;
+    int32_t recv_off_of[kMaxRanks]; // offset inside my halo area where rank q's entries land (-1: none)
+    int32_t recv_cnt_of[kMaxRanks];
+    hipIpcMemHandle_t handle;
+    int32_t have_handle;
+};
+static_assert(sizeof(DistBlob) <= AVS_DIST_BLOB_BYTES, "blob does not fit");
+constexpr uint32_t kBlobMagic = 0x41565342u; // "AVSB"
+constexpr size_t kHeaderBytes = (sizeof(CommHeader) + 255) & ~(size_t)255;
+
+static void direct_release(PcgDist *d)
+{
+    for (int q = 0; q < kMaxRanks; ++q) {
+        if (d->peer_block[q] && d->peer_ipc[q]) (void)hipIpcCloseMemHandle(d->peer_block[q]);
+        d->peer_block[q] = nullptr;
+        d->peer_ipc[q] = false;
+    }
+    if (d->comm_block) (void)hipFree(d->comm_block);
+    d->comm_block = nullptr;
+    d->comm_bytes = 0;
+    d->direct_prepared = d->direct_ready = false;
+    d->transport = AVS_TRANSPORT_RCCL;
+}
+
+// allocates the comm block for the current plan and fills d->blob
+static avs_status direct_prepare(avs_ctx *c, PcgDist *d)
+{
+    direct_release(d);
+    AVS_HIP(hipSetDevice(c->desc.device));
+    const size_t bytes = kHeaderBytes + (size_t)(d->n_halo > 0 ? d->n_halo : 1) * sizeof(double);
+    void *p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess || !p) {
+        (void)hipGetLastError();
+        set_error("direct transport: fine-grained allocation of %zu bytes failed (%s)", bytes, hipGetErrorString(e));
+        return AVS_ENOMEM;
+    }
+    d->comm_block = p;
+    d->comm_bytes = bytes;
+    AVS_HIP(hipMemset(p, 0, bytes));
+    DistBlob b;
+    memset(&b, 0, sizeof(b));
+    b.magic = kBlobMagic;
+    b.rank = d->rank;
+    b.pid = (int32_t)getpid();
+    b.device = c->desc.device;
+    b.raw_ptr = (uint64_t)(uintptr_t)p;
+    b.bytes = bytes;
+    b.n_halo = d->n_halo;
+    for (int q = 0; q < kMaxRanks; ++q) { b.recv_off_of[q] = -1; b.recv_cnt_of[q] = 0; }
+    for (size_t i = 0; i < d->peers.size(); ++i)
+        if (d->recv_counts[i] > 0) {
+            b.recv_off_of[d->peers[i]] = d->recv_offs[i];
+            b.recv_cnt_of[d->peers[i]] = d->recv_counts[i];
+        }
+    if (d->world > 1 && hipIpcGetMemHandle(&b.handle, p) == hipSuccess) b.have_handle = 1; // peers in this process need none
+    else (void)hipGetLastError();
+    d->blob.assign(AVS_DIST_BLOB_BYTES, 0);
+    memcpy(d->blob.data(), &b, sizeof(b));
+    AVS_TRY(d->dd.alloc(1));
+    AVS_TRY(d->epoch.alloc(1));
+    AVS_TRY(d->tickets.alloc(2));
+    AVS_HIP(hipMemset(d->epoch.p, 0, sizeof(unsigned long long)));
+    AVS_HIP(hipMemset(d->tickets.p, 0, 2 * sizeof(unsigned)));
+    d->direct_prepared = true;
+    return AVS_OK;
+}
+
+// maps the peers' blocks and fills the device-side descriptor; `blobs` = world x AVS_DIST_BLOB_BYTES in rank order
+static avs_status direct_connect(avs_ctx *c, PcgDist *d, const uint8_t *blobs)
+{
+    AVS_REQUIRE(d->direct_prepared, AVS_ESTATE, "direct transport: no comm block (assemble / partition first)");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    std::vector<DistBlob> all((size_t)d->world);
+    for (int q = 0; q < d->world; ++q) {
+        memcpy(&all[(size_t)q], blobs + (size_t)q * AVS_DIST_BLOB_BYTES, sizeof(DistBlob));
+        AVS_REQUIRE(all[(size_t)q].magic == kBlobMagic && all[(size_t)q].rank == q, AVS_EINVAL, "direct transport: blob %d is not rank %d's", q, q);
+    }
+    // what I send to q must be what q expects from me -- a mismatch fails here instead of hanging in the first exchange
+    for (int q = 0; q < d->world; ++q) {
+        if (q == d->rank) continue;
+        int mine = 0;
+        for (size_t i = 0; i < d->peers.size(); ++i)
+            if (d->peers[i] == q) mine = d->send_counts[i];
+        AVS_REQUIRE(mine == all[(size_t)q].recv_cnt_of[d->rank], AVS_EINTERNAL,
+                    "direct transport: rank %d sends %d entries to rank %d, which expects %d", d->rank, mine, q,
+                    all[(size_t)q].recv_cnt_of[d->rank]);
+    }
+    const int32_t my_pid = (int32_t)getpid();
+    for (int q = 0; q < d->world; ++q) {
+        if (q == d->rank) { d->peer_block[q] = d->comm_block; continue; }
+        const DistBlob &b = all[(size_t)q];
+        if (b.pid == my_pid) { // same process (in-process group): the pointer itself, peer access when on another GPU
+            if (b.device != c->desc.device) {
+                const hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                    set_error("direct transport: no peer access from device %d to %d (%s)", c->desc.device, b.device, hipGetErrorString(e));
+                    return AVS_EHIP;
+                }
+                (void)hipGetLastError();
+            }
+            d->peer_block[q] = (void *)(uintptr_t)b.raw_ptr;
+        } else {
+            AVS_REQUIRE(b.have_handle, AVS_EHIP, "direct transport: rank %d could not export its comm block", q);
+            void *m = nullptr;
+            const hipError_t e = hipIpcOpenMemHandle(&m, b.handle, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess || !m) {
+                (void)hipGetLastError();
+                set_error("direct transport: hipIpcOpenMemHandle(rank %d) failed: %s", q, hipGetErrorString(e));
+                return AVS_EHIP;
+            }
+            d->peer_block[q] = m;
+            d->peer_ipc[q] = true;
+        }
+    }
+    DistDev h;
+    memset(&h, 0, sizeof(h));
+    h.rank = d->rank;
+    h.world = d->world;
+    h.npeers = (int)d->peers.size();
+    h.n_own = d->n_own;
+    h.mine = (CommHeader *)d->comm_block;
+    h.my_halo = (const double *)((char *)d->comm_block + kHeaderBytes);
+    AVS_REQUIRE(h.npeers <= kMaxRanks, AVS_EINVAL, "too many peers");
+    for (int i = 0; i < h.npeers; ++i) {
+        const int q = d->peers[(size_t)i];
+        h.peer_rank[i] = q;
+        h.send_off[i] = d->send_offs[(size_t)i];
+        h.recv_cnt[i] = d->recv_counts[(size_t)i];
+        const int off = all[(size_t)q].recv_off_of[d->rank];
+        h.peer_halo_dst[i] = (double *)((char *)d->peer_block[q] + kHeaderBytes) + (off > 0 ? off : 0);
+        h.peer_hflag_dst[i] = &((CommHeader *)d->peer_block[q])->hflag[d->rank];
+    }
+    h.send_off[h.npeers] = (int)d->n_send;
+    for (int q = 0; q < d->world; ++q) {
+        CommHeader *hq = (CommHeader *)d->peer_block[q];
+        h.all_red_dst[q] = &hq->red[0][d->rank][0];
+        h.all_rflag_dst[q] = &hq->rflag[d->rank];
+    }
+    h.send_idx = d->send_idx.p;
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->desc.device) != hipSuccess || khz <= 0) {
+        (void)hipGetLastError();
+        khz = 100000; // 100 MHz constant clock
+    }
+    long long ms = 20000;
+    if (const char *e = getenv("AVS_DIST_TIMEOUT_MS")) ms = atoll(e) > 0 ? atoll(e) : ms;
+    h.timeout_ticks = (long long)khz * ms;
+    AVS_HIP(hipMemcpy(d->dd.p, &h, sizeof(h), hipMemcpyHostToDevice));
+    d->direct_ready = true;
+    d->transport = AVS_TRANSPORT_DIRECT;
+    return AVS_OK;
+}
+
+bool dist_direct_args(PcgDist *d, DirectArgs *out)
+{
+    if (!d || !d->direct_ready) return false;
+    out->dd = d->dd.p;
+    out->epoch = d->epoch.p;
+    out->push_ticket = d->tickets.p;
+    out->fin_ticket = d->tickets.p + 1;
+    out->n_send = (int)d->n_send;
+    out->npeers = (int)d->peers.size();
+    out->tiles_int = d->tiles_int.p;
+    out->tiles_bnd = d->tiles_bnd.p;
+    out->n_tiles_int = d->n_tiles_int;
+    out->n_tiles_bnd = d->n_tiles_bnd;
+    return true;
+}
+
+// after a plan exists: choose the transport, exchange the blobs, connect -- all ranks end up with the SAME transport
+static avs_status direct_setup(avs_ctx *c, PcgDist *d)
+{
+    const char *env = getenv("AVS_DIST_TRANSPORT");
+    const bool forced = env && strcmp(env, "direct") == 0;
+    const bool off = env && strcmp(env, "rccl") == 0;
+    direct_release(d);
+    if (d->hosted) { // the host program finishes the set-up (avs_dist_export_blob / avs_dist_import_blobs)
+        AVS_REQUIRE(!off, AVS_EINVAL, "a hosted group has no RCCL communicator: AVS_DIST_TRANSPORT=rccl is impossible");
+        return direct_prepare(c, d);
+    }
+    // in-process groups share one device's few hardware queues: a waiting kernel of one rank may sit in front of the kernel it
+    // waits for once there are more ranks than queues, so many virtual ranks keep the host-mediated transport by default
+    if (off || (d->group && d->world > 3 && !forced)) return AVS_OK;
+    avs_status st = direct_prepare(c, d);
+    std::vector<uint8_t> all((size_t)d->world * AVS_DIST_BLOB_BYTES, 0);
+    int ok = st == AVS_OK ? 1 : 0;
+    if (d->world == 1) {
+        if (ok) memcpy(all.data(), d->blob.data(), AVS_DIST_BLOB_BYTES);
+    } else if (d->group) {
+        avs_local_group *g = d->group;
+        {
+            std::lock_guard<std::mutex> lk(g->m);
+            if (g->blobs.size() != all.size()) g->blobs.assign(all.size(), 0);
+            if (ok) memcpy(g->blobs.data() + (size_t)d->rank * AVS_DIST_BLOB_BYTES, d->blob.data(), AVS_DIST_BLOB_BYTES);
+            else memset(g->blobs.data() + (size_t)d->rank * AVS_DIST_BLOB_BYTES, 0, AVS_DIST_BLOB_BYTES);
+        }
+        g->barrier();
+        {
+            std::lock_guard<std::mutex> lk(g->m);
+            all = g->blobs;
+        }
+        g->barrier();
+    } else if (d->comm) {
+        DevBuf<uint8_t> send, recv;
+        AVS_TRY(send.alloc(AVS_DIST_BLOB_BYTES));
+        AVS_TRY(recv.alloc(all.size()));
+        if (!ok) d->blob.assign(AVS_DIST_BLOB_BYTES, 0);
+        AVS_HIP(hipMemcpyAsync(send.p, d->blob.data(), AVS_DIST_BLOB_BYTES, hipMemcpyHostToDevice, c->stream));
+        AVS_NCCL(ncclAllGather(send.p, recv.p, AVS_DIST_BLOB_BYTES, ncclUint8, d->comm, c->stream));
+        AVS_HIP(hipMemcpyAsync(all.data(), recv.p, all.size(), hipMemcpyDeviceToHost, c->stream));
+        AVS_HIP(hipStreamSynchronize(c->stream));
+    } else {
+        return AVS_OK;
+    }
+    if (ok) {
+        st = direct_connect(c, d, all.data());
+        ok = st == AVS_OK ? 1 : 0;
+    }
+    // agreement: one rank that cannot connect sends everybody back to the RCCL transport
+    int all_ok = ok;
+    if (d->world > 1 && d->group) {
+        avs_local_group *g = d->group;
+        {
+            std::lock_guard<std::mutex> lk(g->m);
+            if (d->rank == 0) g->direct_votes = 0;
+        }
+        g->barrier();
+        {
+            std::lock_guard<std::mutex> lk(g->m);
+            g->direct_votes += ok;
+        }
+        g->barrier();
+        {
+            std::lock_guard<std::mutex> lk(g->m);
+            all_ok = g->direct_votes == d->world;
+        }
+        g->barrier();
+    } else if (d->world > 1 && d->comm) {
+        DevBuf<int> v;
+        AVS_TRY(v.alloc(1));
+        AVS_HIP(hipMemcpyAsync(v.p, &ok, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        AVS_NCCL(ncclAllReduce(v.p, v.p, 1, ncclInt32, ncclMin, d->comm, c->stream));
+        AVS_HIP(hipMemcpyAsync(&all_ok, v.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        AVS_HIP(hipStreamSynchronize(c->stream));
+    }
+    if (!all_ok) {
+        if (forced) {
+            if (ok) set_error("direct transport: another rank could not connect");
+            return st != AVS_OK ? st : AVS_ERCCL;
+        }
+        direct_release(d); // quietly: the RCCL / host-mediated transport takes over
+    }
+    return AVS_OK;
+}
+
 void dist_release(avs_ctx *c)
 {
     PcgDist *d = c->dist;
     if (!d) return;
+    direct_release(d);
     pcg_destroy(d->pcg);
     if (d->comm_p2p && d->comm_p2p != d->comm) (void)ncclCommDestroy(d->comm_p2p);
     if (d->comm) (void)ncclCommDestroy(d->comm);
@@ -911,6 +1195,29 @@ avs_status avs_dist_init_local(avs_ctx *c, avs_local_group *g, int32_t rank)
     return AVS_OK;
 }
 
+avs_status avs_dist_init_hosted(avs_ctx *c, int32_t rank, int32_t world)
+{
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
+    AVS_TRY(new_dist(c, rank, world));
+    c->dist->hosted = true;
+    return AVS_OK;
+}
+
+avs_status avs_dist_export_blob(avs_ctx *c, uint8_t blob[AVS_DIST_BLOB_BYTES])
+{
+    AVS_REQUIRE(c && blob, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->dist && c->dist->direct_prepared, AVS_ESTATE, "no comm block: call avs_dist_assemble / avs_dist_partition first");
+    memcpy(blob, c->dist->blob.data(), AVS_DIST_BLOB_BYTES);
+    return AVS_OK;
+}
+
+avs_status avs_dist_import_blobs(avs_ctx *c, const uint8_t *blobs)
+{
+    AVS_REQUIRE(c && blobs, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->dist, AVS_ESTATE, "call avs_dist_init_hosted first");
+    return direct_connect(c, c->dist, blobs);
+}
+
 avs_status avs_dist_partition(avs_ctx *c, int32_t cut_axis)
 {
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
@@ -974,6 +1281,9 @@ avs_status avs_dist_partition(avs_ctx *c, int32_t cut_axis)
     pcg_destroy(d->pcg);
     d->pcg = nullptr;
     AVS_TRY(pcg_create(&d->pcg, sz.n_own, sz.n_own + sz.n_halo, st));
+    direct_release(d);
+    d->direct_pending = true; // planning needs no peer; connecting the transport does, so it waits for avs_dist_solve
+    if (d->hosted) AVS_TRY(direct_setup(c, d)); // hosted group: only allocates the block and fills the blob (no collective)
     d->partitioned = true;
     d->reordered = ro;
     d->solved = false;
@@ -1029,6 +1339,9 @@ avs_status avs_dist_assemble(avs_ctx *c, int32_t cut_axis, avs_assembly_info *in
     pcg_destroy(d->pcg);
     d->pcg = nullptr;
     AVS_TRY(pcg_create(&d->pcg, d->n_own, d->n_own + d->n_halo, st));
+    direct_release(d);
+    d->direct_pending = true;
+    if (d->hosted) AVS_TRY(direct_setup(c, d));
     ai.csr_ms = t.stop();
     d->partitioned = true;
     d->reordered = true; // own_global holds brick-major ids: avs_dist_get_solution maps back through c->inv
@@ -1097,6 +1410,11 @@ avs_status avs_dist_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_i
     AVS_REQUIRE(tol >= 0. && max_iters >= 0, AVS_EINVAL, "tolerance / max_iterations out of range");
     AVS_HIP(hipSetDevice(c->desc.device));
     PcgDist *d = c->dist;
+    AVS_REQUIRE(!d->hosted || d->direct_ready, AVS_ESTATE, "hosted group: exchange the blobs first (avs_dist_export_blob / avs_dist_import_blobs)");
+    if (d->direct_pending && !d->hosted) { // first solve on this plan: every rank is here, connect the transport
+        AVS_TRY(direct_setup(c, d));
+        d->direct_pending = false;
+    }
     AVS_HIP(hipMemcpyAsync(d->x.p, d->x0.p, (size_t)d->n_own * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     CsrView A;
     A.n = d->n_own;
@@ -1125,7 +1443,14 @@ avs_status avs_dist_get_info(avs_ctx *c, avs_dist_info *info)
         AVS_NCCL(ncclCommCount(d->comm, &cnt));
         info->rccl_ranks = cnt;
     }
-    info->transport = AVS_TRANSPORT_RCCL;
+    info->transport = d->transport;
+    if (d->direct_ready) {
+        const char *e = getenv("AVS_PCG_GRAPH");
+        info->graph_replay = !(e && atoi(e) == 0);
+        info->launches_per_iteration = d->n_send > 0 ? 4 : 3; // update, push, interior tiles, halo tiles (+ gather + step)
+        info->collectives_per_iteration = 0;
+        return AVS_OK;
+    }
     info->graph_replay = 0;
     const bool sr = dist_wants_single_reduction(d);
     info->launches_per_iteration = d->world == 1 ? 5 : (sr ? 5 : 8);
@@ -1146,7 +1471,7 @@ avs_status avs_dist_get_solution(avs_ctx *c, double *x, int64_t n, avs_memspace 
     AVS_HIP(hipMemsetAsync(full.p, 0, (size_t)n * sizeof(double), st));
     if (d->n_own)
         hipLaunchKernelGGL(k_scatter_own, dim3((unsigned)((d->n_own + 255) / 256)), dim3(256), 0, st, d->x.p, d->own_global.p, full.p, d->n_own);
-    if (d->world > 1) {
+    if (d->world > 1 && !d->hosted) { // hosted group: the caller adds the per-rank vectors (owned entries are disjoint, the rest is 0)
         if (d->comm) AVS_NCCL(ncclAllReduce(full.p, full.p, (size_t)n, ncclDouble, ncclSum, d->comm, st));
         else {
             // in-process: sum the host copies in rank order

@@ -222,6 +222,46 @@ avs_status count_raw_rows(avs_ctx *c, DevBuf<int32_t> &counts);
 avs_status build_brick_permutation(avs_ctx *c, int brick_shift); // c->perm / c->inv from the dof table alone
 void plane_owners_from_weights(const int64_t *weight, int nplanes, int world_size, int *plane_owner); // avs_partition.cpp
 
+// ---------------------------------------------------------------------------------------------
+// Direct transport (avs_dist.hip): every rank owns one fine-grained "comm block" that its peers map (IPC handle across
+// processes, plain pointer inside one process): [flags + scalar staging | halo area].  A round of the distributed PCG =
+// push boundary entries into the peers' halo areas + epoch flag, SpMV (halo-touching tiles wait for the flags), then a
+// flag-based all-gather of the CG partial sums by the last workgroup to finish.  No RCCL call, no host involvement.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxRanks = 32;
+
+struct CommHeader {                               // start of every comm block (device memory, written by peers)
+    unsigned long long hflag[kMaxRanks];          // hflag[q]: epoch of the last halo rank q completed in my halo area
+    unsigned long long rflag[kMaxRanks];          // rflag[q]: epoch of rank q's latest partial sums
+    double red[2][kMaxRanks][4];                  // the partial sums, double-buffered by epoch parity
+};
+
+struct DistDev {                                  // device-resident, read-only for the kernels of one plan
+    int rank, world, npeers, n_send_blocks;
+    long long n_own;
+    CommHeader *mine;                             // my block (local address)
+    const double *my_halo;                        // my halo area (behind the header)
+    int peer_rank[kMaxRanks];
+    int send_off[kMaxRanks + 1];                  // segments of send_idx, peer after peer
+    int recv_cnt[kMaxRanks];
+    double *peer_halo_dst[kMaxRanks];             // where my entries for peer i start inside ITS halo area
+    unsigned long long *peer_hflag_dst[kMaxRanks]; // &peer i's hflag[my rank]
+    double *all_red_dst[kMaxRanks];               // &rank q's red[0][my rank][0] (q = 0 .. world-1, me included)
+    unsigned long long *all_rflag_dst[kMaxRanks]; // &rank q's rflag[my rank]
+    const int32_t *send_idx;
+    long long timeout_ticks;                      // wall_clock64() ticks a flag wait may take before it reports a fault
+};
+
+struct DirectArgs {                               // what pcg_solve_direct needs from the plan
+    const DistDev *dd = nullptr;                  // device pointer
+    unsigned long long *epoch = nullptr;          // device: completed rounds of this comm block
+    unsigned *push_ticket = nullptr, *fin_ticket = nullptr;
+    int n_send = 0, npeers = 0;
+    const int32_t *tiles_int = nullptr, *tiles_bnd = nullptr;
+    int n_tiles_int = 0, n_tiles_bnd = 0;
+};
+bool dist_direct_args(PcgDist *d, DirectArgs *out); // false: the direct transport is not connected
+
 // multi-GPU hooks called from pcg_solve (implemented in avs_dist.hip)
 avs_status dist_halo_exchange(PcgDist *d, double *p_ext, hipStream_t stream);
 avs_status dist_allreduce(PcgDist *d, double *dev_scalars, int count, hipStream_t stream);

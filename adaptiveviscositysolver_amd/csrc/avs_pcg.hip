@@ -39,7 +39,48 @@ struct PcgScalars {
     double red[4];     // reduction staging (all-reduced in multi-GPU mode)
     int iter;          // completed iterations (Eigen's i)
     int done;          // 1: converged, 2: converged in this iteration (x update pending), 3: rhs == 0 (x := 0)
+    int fault;         // direct transport: a peer's flag did not arrive in time (1: halo, 2: partial sums); done is set too
 };
+
+// ---------------------------------------------------------------------------------------------
+// direct transport helpers (DistDev / CommHeader: avs_internal.hpp).  Flags and everything a peer writes are accessed
+// with system-scope atomics / fences: the other end is another GPU (xGMI) or another process.
+// ---------------------------------------------------------------------------------------------
+struct HaloView {                        // by-value argument of the halo-touching SpMV launch
+    const DistDev *dd = nullptr;
+    const unsigned long long *epoch = nullptr; // completed rounds; this round's flags carry *epoch + 1
+    unsigned long long *epoch_w = nullptr;
+    unsigned *fin_ticket = nullptr;
+    PcgScalars *sc = nullptr;            // writable: the last workgroup applies the scalar step
+    const double *pvec = nullptr;        // partial sums of the preceding vector kernel: nred_vec arrays of g
+    const double *pspmv = nullptr;       // this SpMV's partial sums (all tiles, interior launch included)
+    int g = 0, nred_vec = 0, nb_spmv = 0, op = 0, n_bnd = 0;
+    double tol = 0.;
+};
+
+__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// bounded wait: a missing peer must not hang the GPU (the host turns the fault into AVS_ERCCL)
+__device__ __forceinline__ bool wait_flag(const unsigned long long *f, unsigned long long want, long long timeout, PcgScalars *sc, int code)
+{
+    if (ld_sys(f) >= want) return true;
+    const long long t0 = wall_clock64();
+    while (ld_sys(f) < want) {
+        if (wall_clock64() - t0 > timeout) {
+            __hip_atomic_store(&sc->fault, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sc->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return true;
+}
 
 struct PcgWork {
     int64_t n = 0, n_ext = 0;
@@ -102,6 +143,95 @@ __device__ __forceinline__ double block_sum(double v, double *lds4)
     double s = 0.;
     if (threadIdx.x == 0) s = ((lds4[0] + lds4[1]) + lds4[2]) + lds4[3];
     return s; // valid in thread 0
+}
+
+__device__ void apply_scalar_op(PcgScalars *sc, int op, double tol);
+
+// halo-touching tiles: wait until every peer's entries of this round have landed in my halo area
+__device__ __forceinline__ void halo_wait(const HaloView &hv)
+{
+    const DistDev *dd = hv.dd;
+    const int tid = threadIdx.x;
+    if (tid < dd->npeers && dd->recv_cnt[tid] > 0)
+        wait_flag(&dd->mine->hflag[dd->peer_rank[tid]], *hv.epoch + 1ull, dd->timeout_ticks, hv.sc, 1);
+    __syncthreads();
+}
+
+// Last workgroup of the halo-touching SpMV launch: fold the round's partial sums (fixed order), exchange them with every
+// rank through the comm blocks (each rank stores its 4 sums into every block, parity-buffered, then raises its flag),
+// add the contributions in RANK order -- every rank computes bit-identical scalars, so all ranks take the same
+// convergence decision in the same iteration -- and apply the scalar step.  Replaces k_reduce + ncclAllReduce + k_scalar.
+template <int BLK>
+__device__ void dist_finalize(const HaloView &hv)
+{
+    __shared__ double fin_red[BLK / 64];
+    __shared__ double fin_sum[4];
+    const DistDev *dd = hv.dd;
+    const int tid = threadIdx.x;
+    const int nred = hv.nred_vec + 1;
+    for (int q = 0; q < nred; ++q) {
+        const bool vec = q < hv.nred_vec;
+        const int nb = vec ? hv.g : hv.nb_spmv;
+        const double *src = vec ? hv.pvec + (size_t)q * hv.g : hv.pspmv;
+        double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
+        int i = tid;
+        for (; i + 3 * BLK < nb; i += 4 * BLK) {
+            const double a = src[i], b = src[i + BLK], c = src[i + 2 * BLK], d = src[i + 3 * BLK];
+            s0 += a; s1 += b; s2 += c; s3 += d;
+        }
+        for (; i < nb; i += BLK) s0 += src[i];
+        const double sw = wave_sum((s0 + s1) + (s2 + s3));
+        __syncthreads();
+        if ((tid & 63) == 0) fin_red[tid >> 6] = sw;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.;
+#pragma unroll
+            for (int w = 0; w < BLK / 64; ++w) t += fin_red[w];
+            fin_sum[q] = t;
+        }
+    }
+    if (tid == 0)
+        for (int q = nred; q < 4; ++q) fin_sum[q] = 0.;
+    __syncthreads();
+    const unsigned long long E = *hv.epoch + 1ull;
+    const int par = (int)(E & 1ull);
+    if (tid < dd->world) {
+        double *dst = dd->all_red_dst[tid] + (size_t)par * kMaxRanks * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) __hip_atomic_store(dst + k, fin_sum[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        st_sys(dd->all_rflag_dst[tid], E);
+        wait_flag(&dd->mine->rflag[tid], E, dd->timeout_ticks, hv.sc, 2);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence_system();
+        for (int k = 0; k < nred; ++k) {
+            double t = 0.;
+            for (int q = 0; q < dd->world; ++q)
+                t += __hip_atomic_load(&dd->mine->red[par][q][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            hv.sc->red[k] = t;
+        }
+        if (hv.op != 0) apply_scalar_op(hv.sc, hv.op, hv.tol);
+        *hv.epoch_w = E;
+        __hip_atomic_store(hv.fin_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ticket at the end of every workgroup of the halo-touching launch; the last one to arrive finalizes the round
+template <int BLK>
+__device__ __forceinline__ void halo_epilogue(const HaloView &hv)
+{
+    __shared__ int fin_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        fin_last = __hip_atomic_fetch_add(hv.fin_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!fin_last) return;
+    __threadfence();
+    dist_finalize<BLK>(hv);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -175,15 +305,27 @@ __device__ __forceinline__ T stream_load(const T *p)
     return *p;
 }
 
-template <int BLK, int CAP, bool DOT, bool VEC, bool XCD, bool NT>
-__global__ __launch_bounds__(BLK) void k_spmv_tile(CsrView A, const double *__restrict__ x,
+template <int BLK, int CAP, bool DOT, bool VEC, bool XCD, bool NT, bool HALO = false>
+__global__ __launch_bounds__(BLK) void k_spmv_tile(CsrView A, const double *__restrict__ xin,
                                                    double *__restrict__ y, double *__restrict__ partial,
-                                                   const PcgScalars *sc, int chunk, const int32_t *__restrict__ tiles = nullptr)
+                                                   const PcgScalars *sc, int chunk, const int32_t *__restrict__ tiles = nullptr,
+                                                   HaloView hv = HaloView())
 {
     if (DOT && sc && sc->done) return;
     __shared__ double prod[CAP + 2];
     __shared__ double red[BLK / 64];
     const int tid = threadIdx.x;
+    // halo-touching launch of the direct transport: columns >= n_own live in the comm block's halo area
+    struct Gather {
+        const double *x, *hx;
+        int n_own;
+        __device__ __forceinline__ double operator[](int c) const { return (HALO && c >= n_own) ? hx[c - n_own] : x[c]; }
+    };
+    const Gather x{xin, HALO ? hv.dd->my_halo : nullptr, HALO ? (int)hv.dd->n_own : 0};
+    if (HALO) {
+        halo_wait(hv);
+        if ((int)blockIdx.x >= hv.n_bnd) { halo_epilogue<BLK>(hv); return; } // extra workgroup of a rank without such tiles
+    }
     int64_t tile = tiles ? (int64_t)tiles[blockIdx.x] : (int64_t)blockIdx.x; // tile lists: interior / halo-touching subsets
     if (XCD) {
         const int64_t ntiles = gridDim.x;
@@ -266,7 +408,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_tile(CsrView A, const double *__re
         else y[row] = sum;
     }
     if (DOT) {
-        double d = (row < A.n) ? sum * x[row] : 0.;
+        double d = (row < A.n) ? sum * xin[row] : 0.;
         d = wave_sum(d);
         __syncthreads();
         if ((tid & 63) == 0) red[tid >> 6] = d;
@@ -277,6 +419,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_tile(CsrView A, const double *__re
             partial[tiles ? tile : (int64_t)blockIdx.x] = t;
         }
     }
+    if (HALO) halo_epilogue<BLK>(hv);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -329,12 +472,18 @@ typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 
 // TLT > 0: tile-local dictionaries (CsrView::tab_ptr): the tile's own table is staged in LDS (its first TLT entries; the rest
 // -- tiles with more distinct values than that -- is read through L1), codes are tile-local.
-template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, int WIN = 0, int TLT = 0>
+template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, int WIN = 0, int TLT = 0, bool HALO = false>
 __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__restrict__ x, double *__restrict__ y,
                                                   double *__restrict__ partial, const PcgScalars *sc,
-                                                  const int32_t *__restrict__ tiles)
+                                                  const int32_t *__restrict__ tiles, HaloView hv = HaloView())
 {
     if (DOT && sc && sc->done) return;
+    if (HALO) {
+        halo_wait(hv);
+        if ((int)blockIdx.x >= hv.n_bnd) { halo_epilogue<BLK>(hv); return; } // extra workgroup of a rank without such tiles
+    }
+    const double *__restrict__ hx = HALO ? hv.dd->my_halo : nullptr;
+    const int n_own_cols = HALO ? (int)hv.dd->n_own : 0;
     constexpr int U = CAP / (4 * BLK); // quads per lane per pass
     static_assert(U >= 1 && U * 4 * BLK == CAP, "CAP must be a multiple of 4*BLK");
     static_assert(TLT == 0 || (!LTAB && !PACK && BLK == 512), "tile tables: 6-B form, 512-row tiles");
@@ -380,6 +529,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
             const unsigned off = (unsigned)(col - w0);
             if (off < wlen) return xs[off];
         }
+        if (HALO && col >= n_own_cols) return hx[col - n_own_cols]; // the comm block's halo area (direct transport)
         return x[col];
     };
     if (LTAB || TLT > 0)
@@ -449,7 +599,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
         }
         if (tid < te - te4) { // ragged end of the pass (at most 3 entries; entries below ts are never summed)
             const int kk = te4 + tid;
-            prod[kk - base] = value(A.codes[kk]) * x[A.col[kk]]; // the unpacked arrays stay resident
+            prod[kk - base] = value(A.codes[kk]) * gather(A.col[kk]); // the unpacked arrays stay resident
         }
         __syncthreads();
         const int a = rs > ts ? rs : ts;
@@ -465,6 +615,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
         if ((tid & 63) == 63) partial[tile * (BLK / 64) + (tid >> 6)] = d;
     }
     if (row < A.n) __builtin_nontemporal_store(sum, y + row);
+    if (HALO) halo_epilogue<BLK>(hv);
 }
 
 static constexpr int kViLdsTable = 2048; // dictionary entries staged in LDS (16 KiB)
@@ -472,16 +623,17 @@ static constexpr int kTileRows = 512;    // rows per workgroup of the value-inde
 static constexpr int kTileCap = 4096;    // products parked per pass (U = 2 quads per lane)
 static constexpr int kTileWin = 512;     // x entries staged in LDS (the tile's own rows): 38 KiB per workgroup => 32 waves per CU
 
-template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, int WIN = 0, int TLT = 0>
+template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, int WIN = 0, int TLT = 0, bool HALO = false>
 static avs_status spmv_vi2_launch_t(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc,
-                                    const int32_t *tiles, int ntiles, size_t lds, hipStream_t stream)
+                                    const int32_t *tiles, int ntiles, size_t lds, hipStream_t stream, const HaloView &hv = HaloView())
 {
     // > 48 KiB of dynamic LDS (value table of ~1.5 k+ entries) needs the opt-in; it is a per-device function attribute, so it
     // is set on every such launch (cheap, rare path) rather than cached in a process-wide flag
     if (lds > 48 * 1024)
-        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, WIN, TLT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024 - 4096));
-    hipLaunchKernelGGL((k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, WIN, TLT>), dim3(ntiles), dim3(BLK), lds, stream, A, x, y, partial, sc, tiles);
+        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, WIN, TLT, HALO>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+    hipLaunchKernelGGL((k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, WIN, TLT, HALO>), dim3(ntiles), dim3(BLK), lds, stream, A, x, y, partial, sc,
+                       tiles, hv);
     AVS_HIP(hipGetLastError());
     return AVS_OK;
 }
@@ -675,6 +827,31 @@ avs_status spmv_dot_tiles(const CsrView &A, const double *x, double *y, double *
     if (A.codes) return spmv_vi2_launch<kTileRows, kTileCap, true, kTileWin>(A, x, y, partial, sc, tiles, ntiles, stream);
     hipLaunchKernelGGL((k_spmv_tile<kTileRows, 4096, true, true, false, true>), dim3(ntiles), dim3(kTileRows), 0, stream, A, x, y,
                        partial, sc, 0, tiles);
+    AVS_HIP(hipGetLastError());
+    return AVS_OK;
+}
+
+// halo-touching tiles of the direct transport (waits for the peers' entries, gathers halo columns from the comm block, the
+// last workgroup finalizes the round); `launch_blocks` >= ntiles: a rank without such tiles still needs one workgroup
+avs_status spmv_dot_tiles_halo(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc,
+                               const int32_t *tiles, int launch_blocks, const HaloView &hv, hipStream_t stream)
+{
+    if (A.codes) {
+        if (A.tab_ptr) {
+            const size_t lds = (size_t)(kTileCap + 4 + kTileWin + kTltLds) * sizeof(double);
+            return spmv_vi2_launch_t<kTileRows, kTileCap, true, false, false, kTileWin, kTltLds, true>(A, x, y, partial, sc, tiles, launch_blocks,
+                                                                                                   lds, stream, hv);
+        }
+        const bool ltab = A.table_size <= kViLdsTable;
+        const bool pack = A.packed != nullptr;
+        const size_t lds = (size_t)(kTileCap + 4 + kTileWin + (ltab ? ((A.table_size + 1) & ~1) : 0)) * sizeof(double);
+        if (ltab && pack) return spmv_vi2_launch_t<kTileRows, kTileCap, true, true, true, kTileWin, 0, true>(A, x, y, partial, sc, tiles, launch_blocks, lds, stream, hv);
+        if (ltab) return spmv_vi2_launch_t<kTileRows, kTileCap, true, true, false, kTileWin, 0, true>(A, x, y, partial, sc, tiles, launch_blocks, lds, stream, hv);
+        if (pack) return spmv_vi2_launch_t<kTileRows, kTileCap, true, false, true, kTileWin, 0, true>(A, x, y, partial, sc, tiles, launch_blocks, lds, stream, hv);
+        return spmv_vi2_launch_t<kTileRows, kTileCap, true, false, false, kTileWin, 0, true>(A, x, y, partial, sc, tiles, launch_blocks, lds, stream, hv);
+    }
+    hipLaunchKernelGGL((k_spmv_tile<kTileRows, 4096, true, true, false, true, true>), dim3(launch_blocks), dim3(kTileRows), 0, stream, A, x, y,
+                       partial, sc, 0, tiles, hv);
     AVS_HIP(hipGetLastError());
     return AVS_OK;
 }
@@ -1227,6 +1404,183 @@ static avs_status pcg_solve_single_reduction(PcgWork *w, const CsrView &A, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// Direct-transport loop (world >= 1): the single-reduction iteration above with NO RCCL call and no host work inside:
+//   k_sr_update   p, s, x, r, u + partials of r.u, |r|^2
+//   k_push        boundary entries of u -> the peers' halo areas, then the epoch flag (last block)
+//   SpMV interior tiles (run while the peers' entries travel)
+//   SpMV halo-touching tiles: wait for the flags, multiply, last workgroup: all-gather of the 3 sums + scalar step
+// = 4 launches per iteration, replayed from one hipGraph per chunk of kChunk iterations.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_push(const DistDev *__restrict__ dd, const double *__restrict__ v,
+                                              const unsigned long long *__restrict__ epoch, unsigned *__restrict__ ticket,
+                                              const PcgScalars *sc)
+{
+    if (sc->done) return;
+    const int np = dd->npeers;
+    const int n_send = dd->send_off[np];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n_send) {
+        int i = 0;
+        while (j >= dd->send_off[i + 1]) ++i;
+        dd->peer_halo_dst[i][j - dd->send_off[i]] = v[dd->send_idx[j]]; // a store over xGMI / into the peer process's block
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1) { // every block's stores are out: raise my flag in the blocks of the peers I feed
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            const unsigned long long E = *epoch + 1ull;
+            for (int i = 0; i < np; ++i)
+                if (dd->send_off[i + 1] > dd->send_off[i]) st_sys(dd->peer_hflag_dst[i], E);
+        }
+    }
+}
+
+avs_status spmv_dot_tiles(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc, const int32_t *tiles,
+                          int ntiles, hipStream_t stream);
+
+static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b, double *x, double tol, int max_iters,
+                                   hipStream_t stream, avs_solve_info *info, const DirectArgs &da)
+{
+    const int64_t n = A.n;
+    const int g = (int)((n + kBlock - 1) / kBlock < kVecGrid ? ((n + kBlock - 1) / kBlock > 0 ? (n + kBlock - 1) / kBlock : 1) : kVecGrid);
+    const int rowgrid = (int)((n + kBlock - 1) / kBlock) > 0 ? (int)((n + kBlock - 1) / kBlock) : 1;
+    AVS_TRY(w->s.alloc((size_t)n));
+    AVS_TRY(w->u.alloc((size_t)w->n_ext));
+    double *p = w->p.p, *r = w->r.p, *wv = w->t.p, *sv = w->s.p, *u = w->u.p, *invd = w->invd.p;
+    double *pvec = w->partial.p;                         // up to 3 * g vector-kernel partials
+    double *pspmv = w->partial.p + 4 * (size_t)kVecGrid; // SpMV partials behind them
+    PcgScalars *sc = w->sc.p;
+    const int ntiles = da.n_tiles_int + da.n_tiles_bnd;
+    const int nb_spmv = ntiles * (A.codes ? kTileRows / 64 : 1); // value-indexed kernel: one partial per wave
+    const int bnd_blocks = da.n_tiles_bnd > 0 ? da.n_tiles_bnd : 1;
+    const int push_blocks = da.n_send > 0 ? (da.n_send + 255) / 256 : 0;
+
+    AVS_HIP(hipMemsetAsync(sc, 0, 2 * sizeof(PcgScalars), stream));
+    AVS_HIP(hipMemsetAsync(p, 0, (size_t)w->n_ext * sizeof(double), stream));
+    AVS_HIP(hipMemsetAsync(sv, 0, (size_t)n * sizeof(double), stream));
+    hipLaunchKernelGGL(k_inv_diag, dim3(rowgrid), dim3(kBlock), 0, stream, A, invd);
+    AVS_HIP(hipEventRecord(w->ev0, stream));
+
+    // one round: exchange `vec`, wv = A vec (+ partials of vec.wv), fold `nred_vec` vector partial arrays + that one, step `op`
+    auto round = [&](const double *vec, int nred_vec, int op, hipEvent_t ea, hipEvent_t eb) -> avs_status {
+        if (push_blocks) hipLaunchKernelGGL(k_push, dim3(push_blocks), dim3(256), 0, stream, da.dd, vec, (const unsigned long long *)da.epoch,
+                                            da.push_ticket, (const PcgScalars *)sc);
+        if (ea) AVS_HIP(hipEventRecord(ea, stream));
+        AVS_TRY(spmv_dot_tiles(A, vec, wv, pspmv, sc, da.tiles_int, da.n_tiles_int, stream));
+        HaloView hv;
+        hv.dd = da.dd;
+        hv.epoch = da.epoch;
+        hv.epoch_w = da.epoch;
+        hv.fin_ticket = da.fin_ticket;
+        hv.sc = sc;
+        hv.pvec = pvec;
+        hv.pspmv = pspmv;
+        hv.g = g;
+        hv.nred_vec = nred_vec;
+        hv.nb_spmv = nb_spmv;
+        hv.op = op;
+        hv.n_bnd = da.n_tiles_bnd;
+        hv.tol = tol;
+        AVS_TRY(spmv_dot_tiles_halo(A, vec, wv, pspmv, sc, da.tiles_bnd, bnd_blocks, hv, stream));
+        if (eb) AVS_HIP(hipEventRecord(eb, stream));
+        return AVS_OK;
+    };
+    // r = b - A x (x staged through u for the exchange), u = M^-1 r, w = A u
+    AVS_HIP(hipMemcpyAsync(u, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    AVS_TRY(round(u, 0, (int)OP_NONE, nullptr, nullptr));
+    hipLaunchKernelGGL(k_sr_init, dim3(g), dim3(kBlock), 0, stream, n, b, wv, invd, r, u, pvec);
+    AVS_TRY(round(u, 3, (int)OP_SR_INIT, nullptr, nullptr));
+    AVS_HIP(hipGetLastError());
+
+    auto enqueue_iteration = [&](int c, bool timed) -> avs_status {
+        hipLaunchKernelGGL(k_sr_update, dim3(g), dim3(kBlock), 0, stream, n, x, r, p, sv, u, wv, invd, (const PcgScalars *)sc, sc, 0, pvec);
+        return round(u, 2, (int)OP_SR_STEP, timed ? w->evA[c] : nullptr, timed ? w->evB[c] : nullptr);
+    };
+    bool use_graph = true;
+    if (const char *e = getenv("AVS_PCG_GRAPH")) use_graph = atoi(e) != 0;
+    int enqueued = 0, last_chunk = 0, spmv_samples = 0;
+    double spmv_ms_sum = 0.;
+    bool timed_chunk = true;
+    while (true) {
+        AVS_HIP(hipMemcpyAsync(w->host_sc, sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, stream));
+        AVS_HIP(hipStreamSynchronize(stream));
+        if (w->host_sc->fault) {
+            set_error("direct transport: a peer's %s did not arrive within the time limit (rank stalled or dead?)",
+                      w->host_sc->fault == 1 ? "halo entries" : "partial sums");
+            return AVS_ERCCL;
+        }
+        if (info && last_chunk > 0 && timed_chunk) {
+            const int ran = w->host_sc->iter + (w->host_sc->done ? 1 : 0);
+            const int first = enqueued - last_chunk;
+            for (int c2 = 0; c2 < last_chunk && first + c2 < ran; c2 += kSampleEvery) {
+                float ems = 0.f;
+                if (hipEventElapsedTime(&ems, w->evA[c2], w->evB[c2]) == hipSuccess) { spmv_ms_sum += ems; ++spmv_samples; }
+            }
+        }
+        if (w->host_sc->done || enqueued >= max_iters) break;
+        const int chunk = (max_iters - enqueued) < kChunk ? (max_iters - enqueued) : kChunk;
+        const bool replay = use_graph && (enqueued / kChunk) % kTimedChunkEvery != 0 && chunk == kChunk && !w->graph_broken;
+        timed_chunk = !replay;
+        if (replay) {
+            const void *key[10] = {A.row_ptr, A.col, A.codes, A.packed, A.table, x, b, (const void *)da.dd, (const void *)(intptr_t)A.n,
+                                   (const void *)(intptr_t)(((int64_t)A.table_size << 8) + A.col_bits + 1000003ll * ntiles)};
+            if (w->graph && (memcmp(key, w->graph_key, sizeof(key)) != 0 || w->graph_tol != tol)) {
+                (void)hipGraphExecDestroy(w->graph);
+                w->graph = nullptr;
+            }
+            if (!w->graph) {
+                hipGraph_t gr = nullptr;
+                bool ok = hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+                if (ok) {
+                    for (int c = 0; c < kChunk && ok; ++c) ok = enqueue_iteration(c, false) == AVS_OK;
+                    ok = (hipStreamEndCapture(stream, &gr) == hipSuccess) && ok && gr;
+                }
+                if (ok) ok = hipGraphInstantiate(&w->graph, gr, nullptr, nullptr, 0) == hipSuccess;
+                if (gr) (void)hipGraphDestroy(gr);
+                if (!ok) {
+                    (void)hipGetLastError();
+                    w->graph = nullptr;
+                    w->graph_broken = true;
+                } else {
+                    memcpy(w->graph_key, key, sizeof(key));
+                    w->graph_tol = tol;
+                }
+            }
+        }
+        if (replay && w->graph) {
+            AVS_HIP(hipGraphLaunch(w->graph, stream));
+        } else {
+            timed_chunk = true;
+            for (int c = 0; c < chunk; ++c) AVS_TRY(enqueue_iteration(c, info && (c % kSampleEvery == 0)));
+        }
+        AVS_HIP(hipGetLastError());
+        enqueued += chunk;
+        last_chunk = chunk;
+    }
+    if (w->host_sc->done == 3) // rhs == 0: x := 0
+        hipLaunchKernelGGL(k_sr_update, dim3(g), dim3(kBlock), 0, stream, n, x, r, p, sv, u, wv, invd, (const PcgScalars *)sc, sc, 0, pvec);
+    AVS_HIP(hipEventRecord(w->ev1, stream));
+    AVS_HIP(hipEventSynchronize(w->ev1));
+    float ms = 0.f;
+    AVS_HIP(hipEventElapsedTime(&ms, w->ev0, w->ev1));
+    if (info) {
+        const PcgScalars &h = *w->host_sc;
+        info->iterations = h.iter;
+        info->converged = (h.done != 0) ? 1 : 0;
+        info->rhs_norm2 = h.rhs_norm2;
+        info->error = (h.done == 3 || h.rhs_norm2 == 0.) ? 0. : sqrt(h.rr / h.rhs_norm2);
+        info->n = n;
+        info->nnz = A.nnz;
+        info->solve_ms = ms;
+        info->spmv_ms = spmv_samples ? spmv_ms_sum / spmv_samples : 0.;
+    }
+    return AVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 avs_status pcg_create(PcgWork **out, int64_t n, int64_t n_ext, hipStream_t)
 {
     PcgWork *w = new (std::nothrow) PcgWork();
@@ -1298,6 +1652,10 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
 {
     const int64_t n = A.n;
     AVS_REQUIRE(w && w->n == n, AVS_EINVAL, "pcg workspace does not match the system size");
+    if (dist) {
+        DirectArgs da;
+        if (dist_direct_args(dist, &da)) return pcg_solve_direct(w, A, b, x, tol, max_iters, stream, info, da);
+    }
     if (dist && dist_wants_single_reduction(dist))
         return pcg_solve_single_reduction(w, A, b, x, tol, max_iters, stream, info, dist);
     const int vgrid = (int)((n + kBlock - 1) / kBlock < kVecGrid ? (n + kBlock - 1) / kBlock : kVecGrid);

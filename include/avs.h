@@ -296,6 +296,16 @@ void avs_plan_destroy(avs_plan *plan);
 avs_status avs_dist_get_unique_id(uint8_t id[AVS_UNIQUE_ID_BYTES]);
 avs_status avs_dist_init(avs_ctx *ctx, const uint8_t id[AVS_UNIQUE_ID_BYTES], int32_t rank, int32_t world_size);
 
+/* Hosted group: neither RCCL nor an in-process group -- the HOST PROGRAM carries the set-up data between the ranks (MPI, gloo,
+ * files ...).  Only the direct transport (below) works in such a group.  Sequence on every rank: avs_dist_init_hosted,
+ * avs_dist_assemble (or avs_assemble + avs_dist_partition), avs_dist_export_blob, exchange so that every rank holds all
+ * blobs in rank order, avs_dist_import_blobs, avs_dist_solve.  avs_dist_get_solution then returns this rank's owned entries
+ * (zeros elsewhere): the caller adds the per-rank vectors. */
+#define AVS_DIST_BLOB_BYTES 512
+avs_status avs_dist_init_hosted(avs_ctx *ctx, int32_t rank, int32_t world_size);
+avs_status avs_dist_export_blob(avs_ctx *ctx, uint8_t blob[AVS_DIST_BLOB_BYTES]);
+avs_status avs_dist_import_blobs(avs_ctx *ctx, const uint8_t *blobs /* world_size x AVS_DIST_BLOB_BYTES, rank order */);
+
 typedef struct avs_local_group avs_local_group;
 avs_status avs_local_group_create(int32_t world_size, avs_local_group **out);
 void avs_local_group_destroy(avs_local_group *group);
