@@ -413,9 +413,7 @@ static avs_status direct_setup(avs_ctx *c, PcgDist *d)
         AVS_REQUIRE(!off, AVS_EINVAL, "a hosted group has no RCCL communicator: AVS_DIST_TRANSPORT=rccl is impossible");
         return direct_prepare(c, d);
     }
-    // in-process groups share one device's few hardware queues: a waiting kernel of one rank may sit in front of the kernel it
-    // waits for once there are more ranks than queues, so many virtual ranks keep the host-mediated transport by default
-    if (off || (d->group && d->world > 3 && !forced)) return AVS_OK;
+    if (off) return AVS_OK;
     avs_status st = direct_prepare(c, d);
     std::vector<uint8_t> all((size_t)d->world * AVS_DIST_BLOB_BYTES, 0);
     int ok = st == AVS_OK ? 1 : 0;
@@ -445,6 +443,22 @@ static avs_status direct_setup(avs_ctx *c, PcgDist *d)
         AVS_HIP(hipMemcpyAsync(all.data(), recv.p, all.size(), hipMemcpyDeviceToHost, c->stream));
         AVS_HIP(hipStreamSynchronize(c->stream));
     } else {
+        return AVS_OK;
+    }
+    // Ranks of ONE process on ONE device (virtual ranks, a test set-up) share that device's few hardware queues: the
+    // waiting kernel of one rank can sit in the same queue in front of the kernel it waits for (measured:
+    // tools/probes/spin_probe.hip, only as many streams as hardware queues make progress).  Such groups keep the
+    // host-mediated transport unless AVS_DIST_TRANSPORT=direct insists.  Every rank sees the same blobs => same decision.
+    bool shared_device = false;
+    for (int a = 0; a < d->world && ok; ++a)
+        for (int b2 = a + 1; b2 < d->world; ++b2) {
+            DistBlob ba, bb;
+            memcpy(&ba, all.data() + (size_t)a * AVS_DIST_BLOB_BYTES, sizeof(ba));
+            memcpy(&bb, all.data() + (size_t)b2 * AVS_DIST_BLOB_BYTES, sizeof(bb));
+            if (ba.magic == kBlobMagic && bb.magic == kBlobMagic && ba.pid == bb.pid && ba.device == bb.device) shared_device = true;
+        }
+    if (shared_device && !forced) {
+        direct_release(d);
         return AVS_OK;
     }
     if (ok) {

@@ -1,4 +1,4 @@
-"""One rank of a HOSTED multi-process solve (tests/test_gpu_dist.py::test_two_processes_direct_transport).
+"""One rank of a HOSTED multi-process solve (tests/test_gpu_dist.py::test_processes_direct_transport).
 
 Real one-process-per-rank execution of the direct transport on a 1-GPU box: both processes use cuda:0, map each other's
 comm block through HIP IPC handles and run the flag-based halo exchange / all-gather between two processes.  The blobs
