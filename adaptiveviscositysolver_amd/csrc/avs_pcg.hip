@@ -53,19 +53,30 @@ struct HaloView {                        // by-value argument of the halo-touchi
     unsigned *fin_ticket = nullptr;
     PcgScalars *sc = nullptr;            // writable: the last workgroup applies the scalar step
     const double *pvec = nullptr;        // partial sums of the preceding vector kernel: nred_vec arrays of g
-    const double *pspmv = nullptr;       // this SpMV's partial sums (all tiles, interior launch included)
-    int g = 0, nred_vec = 0, nb_spmv = 0, op = 0, n_bnd = 0;
+    const double *pspmv = nullptr;       // this SpMV's partial sums, ppt per tile (interior launch included)
+    double *stage = nullptr;             // 2 x gridDim.x: per-workgroup sums of (a share of the interior tiles, its own tile)
+    const int32_t *tiles_int = nullptr;  // interior tile list (their partials are complete when this launch starts)
+    int n_int = 0, ppt = 1;
+    int g = 0, nred_vec = 0, op = 0, n_bnd = 0;
     double tol = 0.;
 };
 
+// Synchronisation recipe (no L2 write-back fences: a release fence at agent / system scope flushes every dirty line of the
+// XCD's L2 -- the vectors just written -- and measured 15 us per round):
+//   * everything a peer (or another XCD) must see is written with system- / agent-scope ATOMIC stores or exchanges: they
+//     write through to memory; everything read back is read with atomic loads, which bypass the caches;
+//   * "data before flag": the writer waits for its own stores to be acknowledged (s_waitcnt, what a workgroup-scope
+//     release fence compiles to) or uses exchanges, whose return value IS the acknowledgement, before the flag goes out.
 __device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p)
 {
-    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v)
 {
-    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+__device__ __forceinline__ double ld_sys_f64(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void wait_own_stores() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 // bounded wait: a missing peer must not hang the GPU (the host turns the fault into AVS_ERCCL)
 __device__ __forceinline__ bool wait_flag(const unsigned long long *f, unsigned long long want, long long timeout, PcgScalars *sc, int code)
 {
@@ -89,6 +100,7 @@ struct PcgWork {
     DevBuf<double> invtab;   // ... into the table of inverted values (2 B instead of 8 B per row and vector pass)
     DevBuf<double> s, u; // single-reduction variant (multi-GPU): s = A p recurrence, u = M^-1 r with halo tail
     DevBuf<PcgScalars> sc;
+    DevBuf<double> stage2;         // direct transport: per-workgroup SpMV sums of the halo-touching launch
     DevBuf<double> stage;          // multi-block reduction: kRedBlocks x 4 block sums ...
     DevBuf<unsigned> ticket;       // ... and the arrival counter (reset by the last block)
     PcgScalars *host_sc = nullptr; // pinned
@@ -162,6 +174,21 @@ __device__ __forceinline__ void halo_wait(const HaloView &hv)
 // add the contributions in RANK order -- every rank computes bit-identical scalars, so all ranks take the same
 // convergence decision in the same iteration -- and apply the scalar step.  Replaces k_reduce + ncclAllReduce + k_scalar.
 template <int BLK>
+__device__ __forceinline__ double block_fold(double v, double *lds) // fixed order: lanes (shuffle tree), then waves ascending; valid in thread 0
+{
+    const double sw = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = sw;
+    __syncthreads();
+    double t = 0.;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < BLK / 64; ++w) t += lds[w];
+    }
+    return t;
+}
+
+template <int BLK>
 __device__ void dist_finalize(const HaloView &hv)
 {
     __shared__ double fin_red[BLK / 64];
@@ -171,46 +198,44 @@ __device__ void dist_finalize(const HaloView &hv)
     const int nred = hv.nred_vec + 1;
     for (int q = 0; q < nred; ++q) {
         const bool vec = q < hv.nred_vec;
-        const int nb = vec ? hv.g : hv.nb_spmv;
-        const double *src = vec ? hv.pvec + (size_t)q * hv.g : hv.pspmv;
+        const int nb = vec ? hv.g : 2 * (int)gridDim.x; // the SpMV's sum: the per-workgroup stage values, in index order
+        const double *src = vec ? hv.pvec + (size_t)q * hv.g : hv.stage;
         double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
         int i = tid;
-        for (; i + 3 * BLK < nb; i += 4 * BLK) {
-            const double a = src[i], b = src[i + BLK], c = src[i + 2 * BLK], d = src[i + 3 * BLK];
-            s0 += a; s1 += b; s2 += c; s3 += d;
+        if (vec) { // written by the previous kernel
+            for (; i + 3 * BLK < nb; i += 4 * BLK) {
+                const double a = src[i], b = src[i + BLK], c = src[i + 2 * BLK], d = src[i + 3 * BLK];
+                s0 += a; s1 += b; s2 += c; s3 += d;
+            }
+            for (; i < nb; i += BLK) s0 += src[i];
+        } else { // written by workgroups of THIS launch on other XCDs: agent-scope atomic loads (cache-bypassing)
+            for (; i < nb; i += BLK) s0 += __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        for (; i < nb; i += BLK) s0 += src[i];
-        const double sw = wave_sum((s0 + s1) + (s2 + s3));
-        __syncthreads();
-        if ((tid & 63) == 0) fin_red[tid >> 6] = sw;
-        __syncthreads();
-        if (tid == 0) {
-            double t = 0.;
-#pragma unroll
-            for (int w = 0; w < BLK / 64; ++w) t += fin_red[w];
-            fin_sum[q] = t;
-        }
+        const double t = block_fold<BLK>((s0 + s1) + (s2 + s3), fin_red);
+        if (tid == 0) fin_sum[q] = t;
     }
     if (tid == 0)
         for (int q = nred; q < 4; ++q) fin_sum[q] = 0.;
     __syncthreads();
     const unsigned long long E = *hv.epoch + 1ull;
     const int par = (int)(E & 1ull);
+    if (tid < dd->world * 4) { // one lane per (rank, value): the exchanges travel in parallel, their return acknowledges them
+        const int q = tid >> 2, k = tid & 3;
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(dd->all_red_dst[q] + (size_t)par * kMaxRanks * 4 + k);
+        const unsigned long long old = __hip_atomic_exchange(dst, (unsigned long long)__double_as_longlong(fin_sum[k]), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_SYSTEM);
+        if (old == 0x7ff8dead7ff8deadull) fin_sum[0] = 0.; // never true: keeps the exchange's result (= its completion) alive
+    }
+    __syncthreads();
     if (tid < dd->world) {
-        double *dst = dd->all_red_dst[tid] + (size_t)par * kMaxRanks * 4;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) __hip_atomic_store(dst + k, fin_sum[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __threadfence_system();
         st_sys(dd->all_rflag_dst[tid], E);
         wait_flag(&dd->mine->rflag[tid], E, dd->timeout_ticks, hv.sc, 2);
     }
     __syncthreads();
     if (tid == 0) {
-        __threadfence_system();
         for (int k = 0; k < nred; ++k) {
             double t = 0.;
-            for (int q = 0; q < dd->world; ++q)
-                t += __hip_atomic_load(&dd->mine->red[par][q][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int q = 0; q < dd->world; ++q) t += ld_sys_f64(&dd->mine->red[par][q][k]);
             hv.sc->red[k] = t;
         }
         if (hv.op != 0) apply_scalar_op(hv.sc, hv.op, hv.tol);
@@ -220,17 +245,46 @@ __device__ void dist_finalize(const HaloView &hv)
 }
 
 // ticket at the end of every workgroup of the halo-touching launch; the last one to arrive finalizes the round
+// `tile` < 0: a workgroup without a tile (it only helps folding the interior partials)
 template <int BLK>
-__device__ __forceinline__ void halo_epilogue(const HaloView &hv)
+__device__ __forceinline__ void halo_epilogue(const HaloView &hv, int64_t tile)
 {
     __shared__ int fin_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0)
-        fin_last = __hip_atomic_fetch_add(hv.fin_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __shared__ double stage_red[BLK / 64];
+    // every workgroup folds a fixed share of the INTERIOR tiles' partial sums (complete: that launch has finished) and its own
+    // tile's; the last workgroup then adds the 2 x gridDim.x stage values in index order -- deterministic, and no single
+    // workgroup walks 10^5 partials
+    {
+        const int B = (int)gridDim.x, b = (int)blockIdx.x;
+        const int total = hv.n_int * hv.ppt;            // the interior launch left them contiguous, in launch order
+        const int share = (total + B - 1) / B;
+        const int lo = b * share, hi = (lo + share < total) ? lo + share : total;
+        double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
+        int i = lo + (int)threadIdx.x;
+        for (; i + 3 * BLK < hi; i += 4 * BLK) {
+            const double a = hv.pspmv[i], b2 = hv.pspmv[i + BLK], c = hv.pspmv[i + 2 * BLK], d = hv.pspmv[i + 3 * BLK];
+            s0 += a; s1 += b2; s2 += c; s3 += d;
+        }
+        for (; i < hi; i += BLK) s0 += hv.pspmv[i];
+        const double t_int = block_fold<BLK>((s0 + s1) + (s2 + s3), stage_red);
+        __syncthreads(); // this workgroup's own partial stores are visible to thread 0 below
+        if (threadIdx.x == 0) {
+            double t_own = 0.;
+            if (tile >= 0)
+                for (int w = 0; w < hv.ppt; ++w) t_own += hv.pspmv[(size_t)total + (size_t)b * hv.ppt + w];
+            // exchanges write through to memory and return only when done: the ticket below cannot overtake them
+            const unsigned long long o1 = __hip_atomic_exchange(reinterpret_cast<unsigned long long *>(hv.stage + b),
+                                                                (unsigned long long)__double_as_longlong(t_int), __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long o2 = __hip_atomic_exchange(reinterpret_cast<unsigned long long *>(hv.stage + B + b),
+                                                                (unsigned long long)__double_as_longlong(t_own), __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned inc = 1u + (unsigned)((o1 & o2) == 0x7ff8dead7ff8deadull); // data dependency; always 1
+            fin_last = __hip_atomic_fetch_add(hv.fin_ticket, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        }
+    }
     __syncthreads();
     if (!fin_last) return;
-    __threadfence();
     dist_finalize<BLK>(hv);
 }
 
@@ -319,12 +373,12 @@ __global__ __launch_bounds__(BLK) void k_spmv_tile(CsrView A, const double *__re
     struct Gather {
         const double *x, *hx;
         int n_own;
-        __device__ __forceinline__ double operator[](int c) const { return (HALO && c >= n_own) ? hx[c - n_own] : x[c]; }
+        __device__ __forceinline__ double operator[](int c) const { return (HALO && c >= n_own) ? ld_sys_f64(hx + (c - n_own)) : x[c]; }
     };
     const Gather x{xin, HALO ? hv.dd->my_halo : nullptr, HALO ? (int)hv.dd->n_own : 0};
     if (HALO) {
         halo_wait(hv);
-        if ((int)blockIdx.x >= hv.n_bnd) { halo_epilogue<BLK>(hv); return; } // extra workgroup of a rank without such tiles
+        if ((int)blockIdx.x >= hv.n_bnd) { halo_epilogue<BLK>(hv, -1); return; } // extra workgroup: folds partials only
     }
     int64_t tile = tiles ? (int64_t)tiles[blockIdx.x] : (int64_t)blockIdx.x; // tile lists: interior / halo-touching subsets
     if (XCD) {
@@ -416,10 +470,10 @@ __global__ __launch_bounds__(BLK) void k_spmv_tile(CsrView A, const double *__re
         if (tid == 0) {
             double t = 0.;
             for (int w = 0; w < BLK / 64; ++w) t += red[w];
-            partial[tiles ? tile : (int64_t)blockIdx.x] = t;
+            partial[blockIdx.x] = t; // slot = position in the launch (== tile without a tile list)
         }
     }
-    if (HALO) halo_epilogue<BLK>(hv);
+    if (HALO) halo_epilogue<BLK>(hv, tile);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -480,7 +534,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
     if (DOT && sc && sc->done) return;
     if (HALO) {
         halo_wait(hv);
-        if ((int)blockIdx.x >= hv.n_bnd) { halo_epilogue<BLK>(hv); return; } // extra workgroup of a rank without such tiles
+        if ((int)blockIdx.x >= hv.n_bnd) { halo_epilogue<BLK>(hv, -1); return; } // extra workgroup: folds partials only
     }
     const double *__restrict__ hx = HALO ? hv.dd->my_halo : nullptr;
     const int n_own_cols = HALO ? (int)hv.dd->n_own : 0;
@@ -529,7 +583,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
             const unsigned off = (unsigned)(col - w0);
             if (off < wlen) return xs[off];
         }
-        if (HALO && col >= n_own_cols) return hx[col - n_own_cols]; // the comm block's halo area (direct transport)
+        if (HALO && col >= n_own_cols) return ld_sys_f64(hx + (col - n_own_cols)); // the comm block's halo area, written by the peers
         return x[col];
     };
     if (LTAB || TLT > 0)
@@ -612,10 +666,10 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
         // (Measured: parking the terms in LDS and letting the last-arriving wave fold them cost 9-10 us per launch, two
         // dependent LDS round trips at the end of every wave's life while the LDS pipe is busy; a block barrier 15 us.)
         const double d = wave_sum_dpp((row < A.n) ? sum * xr : 0.);
-        if ((tid & 63) == 63) partial[tile * (BLK / 64) + (tid >> 6)] = d;
+        if ((tid & 63) == 63) partial[(int64_t)blockIdx.x * (BLK / 64) + (tid >> 6)] = d; // slot = position in the launch
     }
     if (row < A.n) __builtin_nontemporal_store(sum, y + row);
-    if (HALO) halo_epilogue<BLK>(hv);
+    if (HALO) halo_epilogue<BLK>(hv, tile);
 }
 
 static constexpr int kViLdsTable = 2048; // dictionary entries staged in LDS (16 KiB)
@@ -1359,7 +1413,7 @@ static avs_status pcg_solve_single_reduction(PcgWork *w, const CsrView &A, const
                 if (timed) AVS_HIP(hipEventRecord(w->evA[c], stream));
                 AVS_TRY(spmv_dot_tiles(A, u, wv, pspmv, now, t_int, n_int, stream));
                 AVS_TRY(dist_halo_end(dist, stream));
-                AVS_TRY(spmv_dot_tiles(A, u, wv, pspmv, now, t_bnd, n_bnd, stream));
+                AVS_TRY(spmv_dot_tiles(A, u, wv, pspmv + (size_t)n_int * (A.codes ? kTileRows / 64 : 1), now, t_bnd, n_bnd, stream));
                 if (timed) AVS_HIP(hipEventRecord(w->evB[c], stream));
                 nb = (n_int + n_bnd) * (A.codes ? kTileRows / 64 : 1); // value-indexed kernel: one partial per wave
             } else {
@@ -1422,15 +1476,15 @@ __global__ __launch_bounds__(256) void k_push(const DistDev *__restrict__ dd, co
     if (j < n_send) {
         int i = 0;
         while (j >= dd->send_off[i + 1]) ++i;
-        dd->peer_halo_dst[i][j - dd->send_off[i]] = v[dd->send_idx[j]]; // a store over xGMI / into the peer process's block
+        // a write-through store over xGMI / into the peer process's block
+        __hip_atomic_store(dd->peer_halo_dst[i] + (j - dd->send_off[i]), v[dd->send_idx[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __threadfence_system();
+    wait_own_stores(); // acknowledged by the destination before this wave reaches the barrier
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == gridDim.x - 1) { // every block's stores are out: raise my flag in the blocks of the peers I feed
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence_system();
             const unsigned long long E = *epoch + 1ull;
             for (int i = 0; i < np; ++i)
                 if (dd->send_off[i + 1] > dd->send_off[i]) st_sys(dd->peer_hflag_dst[i], E);
@@ -1454,8 +1508,12 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
     double *pspmv = w->partial.p + 4 * (size_t)kVecGrid; // SpMV partials behind them
     PcgScalars *sc = w->sc.p;
     const int ntiles = da.n_tiles_int + da.n_tiles_bnd;
-    const int nb_spmv = ntiles * (A.codes ? kTileRows / 64 : 1); // value-indexed kernel: one partial per wave
-    const int bnd_blocks = da.n_tiles_bnd > 0 ? da.n_tiles_bnd : 1;
+    const int ppt = A.codes ? kTileRows / 64 : 1; // value-indexed kernel: one partial per wave
+    // the halo-touching launch also folds the interior tiles' partials: enough workgroups that none walks more than ~8 k of them
+    int bnd_blocks = da.n_tiles_bnd > 0 ? da.n_tiles_bnd : 1;
+    const int want = (int)(((int64_t)da.n_tiles_int * ppt + 8191) / 8192);
+    if (bnd_blocks < want) bnd_blocks = want < 256 ? want : 256;
+    AVS_TRY(w->stage2.alloc(2 * (size_t)bnd_blocks));
     const int push_blocks = da.n_send > 0 ? (da.n_send + 255) / 256 : 0;
 
     AVS_HIP(hipMemsetAsync(sc, 0, 2 * sizeof(PcgScalars), stream));
@@ -1478,13 +1536,16 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
         hv.sc = sc;
         hv.pvec = pvec;
         hv.pspmv = pspmv;
+        hv.stage = w->stage2.p;
+        hv.tiles_int = da.tiles_int;
+        hv.n_int = da.n_tiles_int;
+        hv.ppt = ppt;
         hv.g = g;
         hv.nred_vec = nred_vec;
-        hv.nb_spmv = nb_spmv;
         hv.op = op;
         hv.n_bnd = da.n_tiles_bnd;
         hv.tol = tol;
-        AVS_TRY(spmv_dot_tiles_halo(A, vec, wv, pspmv, sc, da.tiles_bnd, bnd_blocks, hv, stream));
+        AVS_TRY(spmv_dot_tiles_halo(A, vec, wv, pspmv + (size_t)da.n_tiles_int * ppt, sc, da.tiles_bnd, bnd_blocks, hv, stream));
         if (eb) AVS_HIP(hipEventRecord(eb, stream));
         return AVS_OK;
     };

@@ -140,12 +140,30 @@ def cpu_baseline(solver, tol, budget_s):
                   f"(SURVEY 8(d) bytes) on {threads} threads"}
 
 
+_JSON_FD = None
+
+
+def emit(obj):
+    """the ONE JSON line on the real stdout (libraries -- RCCL prints its version banner -- write to fd 1, which points to stderr)"""
+    line = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
 def main():
+    global _JSON_FD
     argv = sys.argv[1:]
     a = parse(argv)
     under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
     if a.gpus > 1 and not under_launcher:
         raise SystemExit(self_launch(a, argv))
+    # keep stdout clean for the JSON line: everything else that writes to fd 1 (C libraries included) goes to stderr
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -173,7 +191,7 @@ def main():
         else:
             ok = True
         if rank == 0:
-            print(json.dumps({"launch_check": bool(ok), "n_gpus": world, "backend": backend}), flush=True)
+            emit({"launch_check": bool(ok), "n_gpus": world, "backend": backend})
         raise SystemExit(0 if ok else 1)
 
     torch.cuda.set_device(local_rank)
@@ -219,11 +237,54 @@ def main():
             buf = (C.c_uint8 * capi.UNIQUE_ID_BYTES)()
             capi.check(solver.lib.avs_dist_get_unique_id(buf))
             capi.check(solver.lib.avs_dist_init(solver.h, buf, 0, 1))
-        # distributed assembly: every rank assembles only the rows of its slab (no global matrix, no partition step)
-        solver.dist_assemble()               # warm-up pass, then the timed one
+        # reference for the check below: the single-GPU path on this rank's own GPU (every rank holds the whole pyramid)
+        solver.assemble()
+        ref = solver.solve(a.tol, a.max_iters)
+        x_ref = torch.empty(ref.n, dtype=torch.float64, device=dev)
+        from adaptiveviscositysolver_amd import capi as _capi
+        _capi.check(solver.lib.avs_get_solution(solver.h, x_ref.data_ptr(), ref.n, _capi.MEM_DEVICE))
+
+        def agree(flag):
+            if world == 1:
+                return bool(flag)
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+            return bool(t.item())
+
+        def try_transport(name):
+            """distributed assembly + one solve with the given transport, checked against the single-GPU solve of the same
+            system: converged, same iteration count (+-3 %), same velocity field.  All ranks reach the same verdict."""
+            if name:
+                os.environ["AVS_DIST_TRANSPORT"] = name
+            rec = {"requested": name or "auto"}
+            try:
+                solver.dist_assemble()
+                info = solver.dist_solve(a.tol, a.max_iters)
+                x = torch.empty(ref.n, dtype=torch.float64, device=dev)
+                _capi.check(solver.lib.avs_dist_get_solution(solver.h, x.data_ptr(), ref.n, _capi.MEM_DEVICE))
+                rel = float(torch.linalg.norm(x - x_ref) / torch.linalg.norm(x_ref))
+                rec.update(transport=solver.dist_comm_info()["transport"], iterations=int(info.iterations), converged=int(info.converged),
+                           reference_iterations=int(ref.iterations), rel_l2_vs_single_gpu=rel)
+                ok = bool(info.converged) and abs(info.iterations - ref.iterations) <= max(3, 0.03 * ref.iterations) and rel < 20 * a.tol
+            except Exception as e:   # a transport that cannot run here (peer mapping refused, a flag wait timed out ...)
+                rec["error"] = str(e)[:300]
+                ok = False
+            rec["ok"] = agree(ok)
+            return rec
+
+        # direct transport (peer-mapped comm blocks) first; the RCCL send/recv + all-reduce loop is the fallback
+        verification = [try_transport(os.environ.get("AVS_DIST_TRANSPORT", ""))]
+        if not verification[-1]["ok"] and verification[-1].get("transport") != "rccl":
+            verification.append(try_transport("rccl"))
+        if not verification[-1]["ok"]:
+            if rank == 0:
+                emit({"metric": "cg_iterations_per_sec", "value": 0.0, "unit": "iter/s", "n_gpus": world, "error":
+                      "no multi-GPU transport reproduced the single-GPU solve", "verification": verification})
+            raise SystemExit(3)
+        del x_ref
         torch.cuda.synchronize()
         t_as = time.perf_counter()
-        dist_info = solver.dist_assemble()
+        dist_info = solver.dist_assemble()   # the timed pass (the ones above warmed everything up)
         torch.cuda.synchronize()
         assemble_wall_ms = (time.perf_counter() - t_as) * 1e3
     else:
@@ -354,12 +415,12 @@ def main():
         }
         if use_dist:
             out["dist"] = {"per_rank": [dict(zip(("n_own", "n_halo", "nnz_local", "n_send", "n_peers"), r)) for r in per_rank],
-                           **solver.dist_comm_info()}
+                           **solver.dist_comm_info(), "verification": verification}
         if world == 1 and not a.no_cpu_baseline and not use_dist:
             out["cpu_baseline"] = cpu_baseline(solver, a.tol, a.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             out["speedup_vs_cpu_all_parallel"] = out["value"] / out["cpu_baseline"]["all_parallel"]["iter_per_s"]
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1 or under_launcher:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
