@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "avs_build_initial_guess", "avs_build_system", "avs_assemble", "avs_solve",
     "avs_get_assembly_info", "avs_get_matrix_format", "avs_get_solution", "avs_get_initial_guess", "avs_get_csr",
     "avs_get_edge_stencils", "avs_get_center_stencils", "avs_pcg_csr", "avs_spmv_csr",
-    "avs_bench_spmv", "avs_bench_stream", "avs_prepass_create", "avs_prepass_destroy", "avs_prepass_run",
+    "avs_bench_spmv", "avs_spmv_sell", "avs_bench_stream", "avs_prepass_create", "avs_prepass_destroy", "avs_prepass_run",
     "avs_prepass_get_info", "avs_prepass_get_labels", "avs_prepass_get_mask", "avs_prepass_get_index",
     "avs_prepass_get_weights", "avs_prepass_get_regular_index", "avs_prepass_apply", "avs_set_regular_index_field",
     "avs_transfer_to_regular_grid", "avs_get_node_grid", "avs_get_dof_table", "avs_plan_owners", "avs_plan_create", "avs_plan_get_sizes",
@@ -140,6 +140,7 @@ def load():
     L.avs_pcg_csr.argtypes = [i64, vp, vp, vp, vp, vp, f64, i32, i32, i32, vp, C.POINTER(SolveInfo)]
     L.avs_spmv_csr.argtypes = [i64, vp, vp, vp, vp, vp, i32, i32, vp]
     L.avs_bench_spmv.argtypes = [vp, i32, i32, C.POINTER(f64)]
+    L.avs_spmv_sell.argtypes = [i64, vp, vp, vp, vp, vp, i32, vp, C.POINTER(f64)]
     L.avs_bench_stream.argtypes = [i32, i64, i32, i32, C.POINTER(f64)]
     L.avs_prepass_create.argtypes = [C.POINTER(PrepassDesc), C.POINTER(vp)]
     L.avs_prepass_destroy.argtypes = [vp]

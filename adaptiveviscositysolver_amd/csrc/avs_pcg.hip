@@ -758,6 +758,36 @@ avs_status stream_probe(int mode, const double *a, double *b, int64_t n, double 
     return AVS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// SELL-C-sigma (C = 64 = one wavefront per slice) -- measurement only (BASELINE configs[4] asks for a blocked-ELL / SELL
+// experiment; tools/sell_experiment.py builds the layout and reports padding + time, profiles/r02_sell_experiment.md).
+// Slice s holds rows [64 s, 64 s + 64) of the sigma-sorted matrix, column-major: entry j of lane l at slice_ptr[s] + 64 j + l,
+// padded to the slice's longest row with (col 0, val 0.0).  Every load is a full coalesced 512-B / 256-B wave access.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_spmv_sell(int64_t nslices, const int64_t *__restrict__ slice_ptr, const int32_t *__restrict__ col,
+                                                   const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= nslices) return;
+    const int64_t b = slice_ptr[s], e = slice_ptr[s + 1];
+    double sum = 0.;
+    int64_t k = b + lane;
+    for (; k + 192 < e; k += 256) { // 4 entries per lane in flight
+        const double v0 = __builtin_nontemporal_load(val + k), v1 = __builtin_nontemporal_load(val + k + 64),
+                     v2 = __builtin_nontemporal_load(val + k + 128), v3 = __builtin_nontemporal_load(val + k + 192);
+        const int c0 = __builtin_nontemporal_load(col + k), c1 = __builtin_nontemporal_load(col + k + 64),
+                  c2 = __builtin_nontemporal_load(col + k + 128), c3 = __builtin_nontemporal_load(col + k + 192);
+        const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+        sum += v0 * x0;
+        sum += v1 * x1;
+        sum += v2 * x2;
+        sum += v3 * x3;
+    }
+    for (; k < e; k += 64) sum += __builtin_nontemporal_load(val + k) * x[__builtin_nontemporal_load(col + k)];
+    y[s * 64 + lane] = sum;
+}
+
 static inline int stream_grid(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
 
 int spmv_default_variant(const CsrView &) { return 24; } // 512 rows/WG, 32 KiB LDS, 16-B vector + non-temporal stream (profiles/r01_spmv_variants.md)
@@ -1852,4 +1882,27 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
     return AVS_OK;
 }
 
+avs_status spmv_sell_launch(int64_t nslices, const int64_t *slice_ptr, const int32_t *col, const double *val, const double *x, double *y,
+                            hipStream_t stream)
+{
+    if (nslices <= 0) return AVS_OK;
+    hipLaunchKernelGGL(k_spmv_sell, dim3((unsigned)((nslices + 3) / 4)), dim3(256), 0, stream, nslices, slice_ptr, col, val, x, y);
+    AVS_HIP(hipGetLastError());
+    return AVS_OK;
+}
+
 } // namespace avs
+
+extern "C" avs_status avs_spmv_sell(int64_t nslices, const int64_t *slice_ptr, const int32_t *col, const double *val, const double *x,
+                                    double *y, int32_t repeats, void *stream, double *ms_per_launch)
+{
+    AVS_REQUIRE(slice_ptr && col && val && x && y && repeats > 0, AVS_EINVAL, "bad argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    AVS_TRY(avs::spmv_sell_launch(nslices, slice_ptr, col, val, x, y, st)); // warm-up
+    avs::Timer t(st);
+    t.start();
+    for (int i = 0; i < repeats; ++i) AVS_TRY(avs::spmv_sell_launch(nslices, slice_ptr, col, val, x, y, st));
+    const double ms = t.stop() / repeats;
+    if (ms_per_launch) *ms_per_launch = ms;
+    return AVS_OK;
+}

@@ -207,6 +207,11 @@ avs_status avs_pcg_csr(int64_t n, const int32_t *row_ptr, const int32_t *col, co
  * `variant` selects the kernel (0 = library default).  Enqueues `repeats` launches. */
 avs_status avs_spmv_csr(int64_t n, const int32_t *row_ptr, const int32_t *col, const double *val,
                         const double *x, double *y, int32_t variant, int32_t repeats, void *stream);
+/* Measurement entry for the SELL-C-sigma experiment (C = 64: one wavefront per slice; BASELINE configs[4]): slice s holds 64
+ * consecutive rows column-major, entry j of lane l at slice_ptr[s] + 64 j + l, padded with (col 0, val 0.0); device pointers.
+ * y comes out in the slice (sigma-sorted) row order.  tools/sell_experiment.py builds the layout. */
+avs_status avs_spmv_sell(int64_t nslices, const int64_t *slice_ptr, const int32_t *col, const double *val, const double *x,
+                         double *y, int32_t repeats, void *stream, double *ms_per_launch);
 /* SpMV on the system owned by ctx (after avs_assemble), same kernel the solver uses;
  * returns the mean HIP-event time per launch in *ms_per_launch. */
 avs_status avs_bench_spmv(avs_ctx *ctx, int32_t variant, int32_t repeats, double *ms_per_launch);

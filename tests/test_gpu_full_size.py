@@ -246,3 +246,51 @@ def test_context_reuse_with_another_scene_size(built_lib):
         x = s.solution()
         assert np.linalg.norm(A @ x - rhs) <= 2e-8 * np.linalg.norm(rhs)
     assert len(set(counts)) == 3
+
+
+def test_config5_thin_sheet_1024_properties(built_lib):
+    """BASELINE configs[4]: 1024^3-equivalent, 5 requested levels, thin free-surface sheet (half-thickness 16 dx), on one GPU
+    end to end through the HIP pre-pass: structural invariants, symmetry through two kernels, independent residual of the
+    solve, default-tolerance convergence.  (25.7 M rows / 388 M non-zeros: the oracle would need tens of minutes.)"""
+    from adaptiveviscositysolver_amd import DevicePrepass
+    dev = torch.device("cuda:0")
+    sc = scenes.thin_sheet(1024, 5, thickness_cells=32, device=dev)
+    pp = DevicePrepass(sc.res, sc.dx, sc.levels)
+    pi = pp.run(sc.liquid, sc.solid)
+    assert pi.levels >= 3                                    # h >= 16 dx so that at least 3 levels appear (SURVEY 8(d))
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, device=0)
+    pp.apply(s)
+    s.set_scene_fields(sc)
+    pp.close()
+    ai = s.assemble()
+    n, nnz = ai.n_velocity, ai.nnz
+    assert n == pi.n_velocity and n > 10_000_000 and nnz > 14 * n * 0.8
+    rp = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(nnz, dtype=torch.int32, device=dev)
+    val = torch.empty(nnz, dtype=torch.float64, device=dev)
+    rhs = torch.empty(n, dtype=torch.float64, device=dev)
+    capi.check(s.lib.avs_get_csr(s.h, rp.data_ptr(), col.data_ptr(), val.data_ptr(), rhs.data_ptr(), capi.MEM_DEVICE))
+    lens = rp[1:] - rp[:-1]
+    assert int(rp[0]) == 0 and int(rp[-1]) == nnz and bool((lens > 0).all())
+    assert int(torch.bincount(lens.long()).argmax()) == 15
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+    y = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+    ax, ay = spmv(s.lib, rp, col, val, x, 24), spmv(s.lib, rp, col, val, y, 3)
+    lhs, rhs_ = float(y @ ax), float(x @ ay)
+    assert abs(lhs - rhs_) <= 1e-10 * max(abs(lhs), abs(rhs_), 1.0) and float(x @ ax) > 0
+    del x, y, ax, ay
+    s.bench_spmv(0, 2)                                       # compressed form == plain CSR bit for bit at this size too
+    info = s.solve(1e-3, 2500)
+    assert info.converged == 1 and info.error < 1e-3
+    tol = 1e-6
+    info6 = s.solve(tol, 20000)
+    assert info6.converged == 1
+    xs = torch.empty(n, dtype=torch.float64, device=dev)
+    capi.check(s.lib.avs_get_solution(s.h, xs.data_ptr(), n, capi.MEM_DEVICE))
+    r = rhs - spmv(s.lib, rp, col, val, xs, 3)
+    rel = float(torch.linalg.norm(r) / torch.linalg.norm(rhs))
+    assert rel <= 1.05 * tol and abs(rel - info6.error) <= 0.05 * tol
+    fmt = s.matrix_format()
+    print(f"config 5: levels {pi.levels}, n {n}, nnz {nnz}, {fmt.bytes_per_nonzero} B/nnz, iterations {info.iterations} (1e-3) / {info6.iterations} (1e-6)")
+    s.close()
