@@ -99,7 +99,8 @@ class DistInfo(C.Structure):
 
 class MatrixFormat(C.Structure):
     _fields_ = [("reordered", C.c_int32), ("value_table_size", C.c_int32), ("column_bits", C.c_int32),
-                ("bytes_per_nonzero", C.c_int32), ("tile_local_tables", C.c_int32)]
+                ("bytes_per_nonzero", C.c_int32), ("tile_local_tables", C.c_int32),
+                ("column_windows", C.c_int32)]
 
 
 _lib = None

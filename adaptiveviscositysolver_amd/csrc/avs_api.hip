@@ -314,6 +314,7 @@ avs_status avs_get_matrix_format(avs_ctx *c, avs_matrix_format *fmt)
     fmt->column_bits = vi ? c->vi.col_bits : 0;
     fmt->bytes_per_nonzero = vi ? c->vi.bytes_per_nonzero() : 12;
     fmt->tile_local_tables = vi && c->vi.tile_tables ? 1 : 0;
+    fmt->column_windows = vi && c->vi.col_windows ? 1 : 0;
     return AVS_OK;
 }
 

@@ -1052,6 +1052,7 @@ bool dist_matrix_format(avs_ctx *c, avs_matrix_format *fmt)
     fmt->column_bits = d->vi.col_bits;
     fmt->bytes_per_nonzero = d->vi.bytes_per_nonzero();
     fmt->tile_local_tables = d->vi.tile_tables ? 1 : 0;
+    fmt->column_windows = d->vi.col_windows ? 1 : 0;
     return true;
 }
 

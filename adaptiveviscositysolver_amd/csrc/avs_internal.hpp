@@ -160,7 +160,11 @@ struct CsrView {
     // tile-local dictionaries: the codes of the rows of SpMV tile t (spmv_tile_rows() rows) index
     // table[tab_ptr[t] .. tab_ptr[t + 1]); table_size is then the total over all tiles
     const int32_t *tab_ptr = nullptr;
+    // windowed columns: packed[k] = code << 20 | slot << 14 | offset, column = cbase[64 * tile + slot] + offset -- the columns a
+    // 512-row tile reads lie in a few 16384-wide windows of the brick-major numbering (col_bits is 0 in this form)
+    const int32_t *cbase = nullptr;
 };
+constexpr int kCwinOffBits = 14, kCwinSlotBits = 6, kCwinSlots = 1 << kCwinSlotBits, kCwinCodeBits = 32 - kCwinOffBits - kCwinSlotBits;
 
 // the lossless storage forms of one matrix's values (avs_reorder.hip), owned next to the CSR arrays
 struct ValueIndex {
@@ -168,18 +172,21 @@ struct ValueIndex {
     DevBuf<double> table;
     DevBuf<uint32_t> packed;
     DevBuf<int32_t> tab_ptr;
+    DevBuf<int32_t> cbase;   // windowed columns: 64 window bases per tile
     int table_size = 0;  // 0 = plain CSR
     int col_bits = 0;    // > 0 = packed words
     bool tile_tables = false;
-    void clear() { table_size = 0; col_bits = 0; tile_tables = false; }
-    int bytes_per_nonzero() const { return table_size <= 0 ? 12 : (col_bits > 0 ? 4 : 6); }
+    bool col_windows = false;
+    void clear() { table_size = 0; col_bits = 0; tile_tables = false; col_windows = false; }
+    int bytes_per_nonzero() const { return table_size <= 0 ? 12 : ((col_bits > 0 || col_windows) ? 4 : 6); }
     void apply(CsrView &A) const
     {
-        A.codes = nullptr; A.table = nullptr; A.table_size = 0; A.packed = nullptr; A.col_bits = 0; A.tab_ptr = nullptr;
+        A.codes = nullptr; A.table = nullptr; A.table_size = 0; A.packed = nullptr; A.col_bits = 0; A.tab_ptr = nullptr; A.cbase = nullptr;
         if (table_size <= 0) return;
         A.codes = codes.p; A.table = table.p; A.table_size = table_size;
         if (col_bits > 0) { A.packed = packed.p; A.col_bits = col_bits; }
         if (tile_tables) A.tab_ptr = tab_ptr.p;
+        if (col_windows) { A.packed = packed.p; A.cbase = cbase.p; A.col_bits = 0; }
     }
 };
 // picks the most compact lossless form that fits: one dictionary of <= 2048 values (LDS-resident; packed 4-B words when the

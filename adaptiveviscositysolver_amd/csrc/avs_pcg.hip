@@ -526,7 +526,8 @@ typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 
 // TLT > 0: tile-local dictionaries (CsrView::tab_ptr): the tile's own table is staged in LDS (its first TLT entries; the rest
 // -- tiles with more distinct values than that -- is read through L1), codes are tile-local.
-template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, int WIN = 0, int TLT = 0, bool HALO = false>
+// CWIN: windowed columns (CsrView::cbase): one 32-bit word per non-zero = code << 20 | window slot << 14 | offset.
+template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, int WIN = 0, int TLT = 0, bool HALO = false, bool CWIN = false>
 __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__restrict__ x, double *__restrict__ y,
                                                   double *__restrict__ partial, const PcgScalars *sc,
                                                   const int32_t *__restrict__ tiles, HaloView hv = HaloView())
@@ -540,14 +541,18 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
     const int n_own_cols = HALO ? (int)hv.dd->n_own : 0;
     constexpr int U = CAP / (4 * BLK); // quads per lane per pass
     static_assert(U >= 1 && U * 4 * BLK == CAP, "CAP must be a multiple of 4*BLK");
-    static_assert(TLT == 0 || (!LTAB && !PACK && BLK == 512), "tile tables: 6-B form, 512-row tiles");
+    static_assert(TLT == 0 || (!LTAB && !PACK && BLK == 512), "tile tables: 512-row tiles, no plain packing");
+    static_assert(!CWIN || (!PACK && BLK == 512), "windowed columns: 512-row tiles");
+    constexpr bool WORDS = PACK || CWIN; // the stream is one 32-bit word per non-zero
     extern __shared__ __attribute__((aligned(16))) double smem[];
     static_assert(WIN == 0 || (WIN >= BLK && WIN % BLK == 0), "window = a whole number of tiles");
     double *prod = smem;                 // CAP + 4
     double *xs = smem + CAP + 4;                           // WIN entries of x around the tile's rows
-    double *tbl = smem + CAP + 4 + WIN;                    // table_size (LTAB) / TLT entries (tile tables)
+    int *cb = reinterpret_cast<int *>(smem + CAP + 4 + WIN); // CWIN: the tile's 64 window bases
+    double *tbl = smem + CAP + 4 + WIN + (CWIN ? kCwinSlots / 2 : 0); // table_size (LTAB) / TLT entries (tile tables)
     const int tid = threadIdx.x;
     const int64_t tile = tiles ? (int64_t)tiles[blockIdx.x] : (int64_t)blockIdx.x;
+    if (CWIN && tid < kCwinSlots) cb[tid] = A.cbase[tile * kCwinSlots + tid];
     const double *__restrict__ gtab = A.table;
     int tlen = A.table_size;
     if (TLT > 0) {
@@ -597,7 +602,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
         re = A.row_ptr[row + 1];
         if (DOT && WIN == 0) xr = x[row]; // early: its latency hides behind the passes
     }
-    if (LTAB || WIN > 0 || TLT > 0) __syncthreads();
+    if (LTAB || WIN > 0 || TLT > 0 || CWIN) __syncthreads();
     if (DOT && WIN > 0 && row < A.n) xr = xs[(int)(row - w0)]; // the tile's own rows are always inside the window
     double sum = 0.;
     for (int ts = s_blk; ts < e_blk; ts += CAP) {
@@ -615,7 +620,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
             q[u] = u4_t{0, 0, 0, 0};
             c[u] = i4_t{0, 0, 0, 0};
             if (kk < te4) {
-                if (PACK) {
+                if (WORDS) {
                     q[u] = stream_load<true>(reinterpret_cast<const u4_t *>(A.packed + kk));
                 } else {
                     const us4_t h = stream_load<true>(reinterpret_cast<const us4_t *>(A.codes + kk));
@@ -631,6 +636,13 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
                 if (PACK) {
                     c[u] = i4_t{(int)(q[u].x & cmask), (int)(q[u].y & cmask), (int)(q[u].z & cmask), (int)(q[u].w & cmask)};
                     q[u] = u4_t{q[u].x >> cbits, q[u].y >> cbits, q[u].z >> cbits, q[u].w >> cbits};
+                }
+                if (CWIN) {
+                    constexpr unsigned om = (1u << kCwinOffBits) - 1u, sm = kCwinSlots - 1u;
+                    c[u] = i4_t{cb[(q[u].x >> kCwinOffBits) & sm] + (int)(q[u].x & om), cb[(q[u].y >> kCwinOffBits) & sm] + (int)(q[u].y & om),
+                                cb[(q[u].z >> kCwinOffBits) & sm] + (int)(q[u].z & om), cb[(q[u].w >> kCwinOffBits) & sm] + (int)(q[u].w & om)};
+                    constexpr int sh = kCwinOffBits + kCwinSlotBits;
+                    q[u] = u4_t{q[u].x >> sh, q[u].y >> sh, q[u].z >> sh, q[u].w >> sh};
                 }
                 xv[u][0] = gather(c[u].x);
                 xv[u][1] = gather(c[u].y);
@@ -677,17 +689,17 @@ static constexpr int kTileRows = 512;    // rows per workgroup of the value-inde
 static constexpr int kTileCap = 4096;    // products parked per pass (U = 2 quads per lane)
 static constexpr int kTileWin = 512;     // x entries staged in LDS (the tile's own rows): 38 KiB per workgroup => 32 waves per CU
 
-template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, int WIN = 0, int TLT = 0, bool HALO = false>
+template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, int WIN = 0, int TLT = 0, bool HALO = false, bool CWIN = false>
 static avs_status spmv_vi2_launch_t(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc,
                                     const int32_t *tiles, int ntiles, size_t lds, hipStream_t stream, const HaloView &hv = HaloView())
 {
     // > 48 KiB of dynamic LDS (value table of ~1.5 k+ entries) needs the opt-in; it is a per-device function attribute, so it
     // is set on every such launch (cheap, rare path) rather than cached in a process-wide flag
     if (lds > 48 * 1024)
-        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, WIN, TLT, HALO>,
+        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, WIN, TLT, HALO, CWIN>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
-    hipLaunchKernelGGL((k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, WIN, TLT, HALO>), dim3(ntiles), dim3(BLK), lds, stream, A, x, y, partial, sc,
-                       tiles, hv);
+    hipLaunchKernelGGL((k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, WIN, TLT, HALO, CWIN>), dim3(ntiles), dim3(BLK), lds, stream, A, x, y, partial,
+                       sc, tiles, hv);
     AVS_HIP(hipGetLastError());
     return AVS_OK;
 }
@@ -700,7 +712,8 @@ static avs_status spmv_tlt_launch(const CsrView &A, const double *x, double *y, 
                                   const int32_t *tiles, int ntiles, hipStream_t stream)
 {
     if (ntiles <= 0) return AVS_OK;
-    const size_t lds = (size_t)(CAP + 4 + kTileWin + TCAP) * sizeof(double);
+    const size_t lds = (size_t)(CAP + 4 + kTileWin + TCAP + (A.cbase ? kCwinSlots / 2 : 0)) * sizeof(double);
+    if (A.cbase) return spmv_vi2_launch_t<kTileRows, CAP, DOT, false, false, kTileWin, TCAP, false, true>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
     return spmv_vi2_launch_t<kTileRows, CAP, DOT, false, false, kTileWin, TCAP>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
 }
 
@@ -714,6 +727,11 @@ static avs_status spmv_vi2_launch(const CsrView &A, const double *x, double *y, 
         return spmv_tlt_launch<kTileCap, DOT, kTltLds>(A, x, y, partial, sc, tiles, ntiles, stream);
     }
     const bool ltab = A.table_size <= kViLdsTable;
+    if (A.cbase) { // windowed columns with ONE dictionary (it has at most 2048 entries, see build_matrix_index)
+        if (BLK != kTileRows || WIN != kTileWin || !ltab) { set_error("windowed columns need the default tile geometry"); return AVS_EINVAL; }
+        const size_t ldsw = (size_t)(kTileCap + 4 + kTileWin + kCwinSlots / 2 + ((A.table_size + 1) & ~1)) * sizeof(double);
+        return spmv_vi2_launch_t<kTileRows, kTileCap, DOT, true, false, kTileWin, 0, false, true>(A, x, y, partial, sc, tiles, ntiles, ldsw, stream);
+    }
     const bool pack = A.packed != nullptr;
     const size_t lds = (size_t)(CAP + 4 + WIN + (ltab ? ((A.table_size + 1) & ~1) : 0)) * sizeof(double);
     if (ltab && pack) return spmv_vi2_launch_t<BLK, CAP, DOT, true, true, WIN>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
@@ -814,7 +832,7 @@ static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, do
         case 56: return spmv_tlt_launch<2048, DOT, 512>(A, x, y, partial, sc, nullptr, nt, stream);
         }
     }
-    if (A.codes && !A.tab_ptr && variant >= 31 && variant <= 46) {
+    if (A.codes && !A.tab_ptr && !A.cbase && variant >= 31 && variant <= 46) {
 #define AVS_VI2_CASE(ID, BLK, CAP, ...)                                                                         \
     case ID: {                                                                                                  \
         const int nt = (int)((A.n + BLK - 1) / BLK);                                                            \
@@ -922,11 +940,19 @@ avs_status spmv_dot_tiles_halo(const CsrView &A, const double *x, double *y, dou
 {
     if (A.codes) {
         if (A.tab_ptr) {
-            const size_t lds = (size_t)(kTileCap + 4 + kTileWin + kTltLds) * sizeof(double);
+            const size_t lds = (size_t)(kTileCap + 4 + kTileWin + kTltLds + (A.cbase ? kCwinSlots / 2 : 0)) * sizeof(double);
+            if (A.cbase)
+                return spmv_vi2_launch_t<kTileRows, kTileCap, true, false, false, kTileWin, kTltLds, true, true>(A, x, y, partial, sc, tiles,
+                                                                                                             launch_blocks, lds, stream, hv);
             return spmv_vi2_launch_t<kTileRows, kTileCap, true, false, false, kTileWin, kTltLds, true>(A, x, y, partial, sc, tiles, launch_blocks,
                                                                                                    lds, stream, hv);
         }
         const bool ltab = A.table_size <= kViLdsTable;
+        if (A.cbase) {
+            const size_t ldsw = (size_t)(kTileCap + 4 + kTileWin + kCwinSlots / 2 + ((A.table_size + 1) & ~1)) * sizeof(double);
+            return spmv_vi2_launch_t<kTileRows, kTileCap, true, true, false, kTileWin, 0, true, true>(A, x, y, partial, sc, tiles, launch_blocks,
+                                                                                                  ldsw, stream, hv);
+        }
         const bool pack = A.packed != nullptr;
         const size_t lds = (size_t)(kTileCap + 4 + kTileWin + (ltab ? ((A.table_size + 1) & ~1) : 0)) * sizeof(double);
         if (ltab && pack) return spmv_vi2_launch_t<kTileRows, kTileCap, true, true, true, kTileWin, 0, true>(A, x, y, partial, sc, tiles, launch_blocks, lds, stream, hv);

@@ -420,6 +420,99 @@ static avs_status build_tile_tables(const int32_t *row_ptr, const double *val, i
     return AVS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Windowed columns.  In the brick-major numbering the columns a 512-row tile reads belong to its own and the neighbouring
+// bricks: a few runs of consecutive ids.  Cut the id range into aligned windows of 2^14 ids; a tile touches a handful of
+// them (<= 64 or the form is dropped).  A non-zero is then ONE 32-bit word: value code (12 bits, tile-local or global
+// dictionary) | window slot (6 bits) | offset in the window (14 bits), whatever the matrix size -- 25-bit columns
+// (1024^3) or thousands of distinct values (variable viscosity) no longer cost 6 B per non-zero.  Lossless: the word
+// decodes to exactly (col[k], val[k]).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kTltRows) void k_cwin_build(int64_t n, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+                                                         const uint16_t *__restrict__ codes, int32_t *__restrict__ cbase,
+                                                         uint32_t *__restrict__ words, int *__restrict__ overflow)
+{
+    __shared__ int keys[256];      // open-addressing set of col >> 14
+    __shared__ int sorted[kCwinSlots];
+    __shared__ int count;
+    const int tid = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    const int64_t row0 = tile * kTltRows, rlast = (row0 + kTltRows < n) ? row0 + kTltRows : n;
+    const int s = row_ptr[row0], e = row_ptr[rlast];
+    if (tid < 256) keys[tid] = -1;
+    if (tid == 0) count = 0;
+    __syncthreads();
+    for (int k = s + tid; k < e; k += kTltRows) {
+        const int key = col[k] >> kCwinOffBits;
+        unsigned h = ((unsigned)key * 2654435761u) >> 24;
+        for (int probe = 0; probe < 256; ++probe) {
+            const int cur = keys[h];
+            if (cur == key) break;
+            if (cur == -1) {
+                const int old = atomicCAS(&keys[h], -1, key);
+                if (old == -1) { atomicAdd(&count, 1); break; }
+                if (old == key) break;
+            }
+            h = (h + 1) & 255u;
+        }
+    }
+    __syncthreads();
+    const int m = count;
+    if (m > kCwinSlots) {
+        if (tid == 0) *overflow = 1;
+        return;
+    }
+    if (tid == 0) { // <= 64 keys: insertion sort by one thread is plenty
+        int c = 0;
+        for (int i = 0; i < 256; ++i)
+            if (keys[i] != -1) {
+                int j = c++;
+                const int v = keys[i];
+                while (j > 0 && sorted[j - 1] > v) { sorted[j] = sorted[j - 1]; --j; }
+                sorted[j] = v;
+            }
+        for (int i = c; i < kCwinSlots; ++i) sorted[i] = 0x7fffffff;
+    }
+    __syncthreads();
+    if (tid < kCwinSlots) cbase[tile * kCwinSlots + tid] = tid < m ? (sorted[tid] << kCwinOffBits) : 0;
+    for (int k = s + tid; k < e; k += kTltRows) {
+        const int c = col[k], key = c >> kCwinOffBits;
+        int lo = 0, hi = m - 1; // binary search in the sorted window list
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sorted[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        const unsigned code = codes[k];
+        if (code >= (1u << kCwinCodeBits)) { *overflow = 1; return; }
+        words[k] = (code << (kCwinOffBits + kCwinSlotBits)) | ((unsigned)lo << kCwinOffBits) | ((unsigned)c & ((1u << kCwinOffBits) - 1u));
+    }
+}
+
+static avs_status build_column_windows(const int32_t *row_ptr, const int32_t *col, int64_t n, int64_t nnz, ValueIndex &vi, hipStream_t st)
+{
+    vi.col_windows = false;
+    if (n == 0 || nnz == 0 || vi.table_size <= 0) return AVS_OK;
+    if (const char *e = getenv("AVS_COLUMN_WINDOWS"))
+        if (atoi(e) == 0) return AVS_OK;
+    const int64_t ntiles = (n + kTltRows - 1) / kTltRows;
+    DevBuf<int> overflow;
+    AVS_TRY(overflow.alloc(1));
+    AVS_HIP(hipMemsetAsync(overflow.p, 0, sizeof(int), st));
+    AVS_TRY(vi.cbase.alloc((size_t)ntiles * kCwinSlots));
+    AVS_TRY(vi.packed.alloc((size_t)nnz));
+    hipLaunchKernelGGL(k_cwin_build, dim3((unsigned)ntiles), dim3(kTltRows), 0, st, n, row_ptr, col, (const uint16_t *)vi.codes.p, vi.cbase.p,
+                       vi.packed.p, overflow.p);
+    AVS_HIP(hipGetLastError());
+    int h_over = 0;
+    AVS_HIP(hipMemcpyAsync(&h_over, overflow.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipStreamSynchronize(st));
+    if (!h_over) {
+        vi.col_windows = true;
+        vi.col_bits = 0;
+    }
+    return AVS_OK;
+}
+
 avs_status build_matrix_index(const int32_t *row_ptr, const int32_t *col, const double *val, int64_t n, int64_t nnz, int64_t n_cols,
                               ValueIndex &vi, hipStream_t st)
 {
@@ -432,6 +525,7 @@ avs_status build_matrix_index(const int32_t *row_ptr, const int32_t *col, const 
     if (global_size > 0 && global_size <= 2048) { // LDS-resident dictionary (+ packed words when the bits allow)
         vi.table_size = global_size;
         AVS_TRY(build_packed_index(vi.codes.p, col, nnz, n_cols, global_size, vi.packed, &vi.col_bits, st));
+        if (vi.col_bits == 0) AVS_TRY(build_column_windows(row_ptr, col, n, nnz, vi, st)); // e.g. 25-bit columns + 8-bit codes (1024^3)
         return AVS_OK;
     }
     bool ok = false;
@@ -444,6 +538,7 @@ avs_status build_matrix_index(const int32_t *row_ptr, const int32_t *col, const 
         vi.table_size = tiled.table_size;
         vi.col_bits = 0;
         vi.tile_tables = true;
+        AVS_TRY(build_column_windows(row_ptr, col, n, nnz, vi, st)); // 2-B tile-local code + windowed column = one word
         return AVS_OK;
     }
     if (global_size > 0) { // one big dictionary read through L1: still 6 B instead of 12 B per non-zero

@@ -225,9 +225,15 @@ class ViscositySolve:
         fmt = self.matrix_format()
         bpn, tab = int(fmt.bytes_per_nonzero), int(fmt.value_table_size)
         ltab = "LTAB" if 0 < tab <= 2048 else "GTAB"
+        cw = int(fmt.column_windows)
         if int(fmt.tile_local_tables):
-            return ("k_spmv_vi2<512,4096,DOT,WIN=512,TLT=1024> (6 B/nnz: 2-B tile-local value codes + int32 column, one value "
-                    f"dictionary per 512-row tile staged in LDS, {tab} table entries in total; brick-major system)")
+            form = ("4 B/nnz: tile-local value code | window slot | offset in one word" if cw else
+                    "6 B/nnz: 2-B tile-local value codes + int32 column")
+            return (f"k_spmv_vi2<512,4096,DOT,WIN=512,TLT=1024{',CWIN' if cw else ''}> ({form}; one value dictionary per 512-row tile "
+                    f"staged in LDS, {tab} table entries in total; brick-major system)")
+        if cw:
+            return (f"k_spmv_vi2<512,4096,DOT,{ltab},WIN=512,CWIN> (4 B/nnz: value code | window slot | offset in one word, "
+                    f"{tab}-entry dictionary; brick-major system)")
         return {4: f"k_spmv_vi2<512,4096,DOT,{ltab},PACK,WIN=512> (4 B/nnz packed code|column, brick-major system)",
                 6: f"k_spmv_vi2<512,4096,DOT,{ltab},WIN=512> (6 B/nnz value-indexed, brick-major system)",
                 12: "k_spmv_tile<512,4096,DOT,VEC,NT> (12 B/nnz, brick-major system)"}.get(bpn, f"{bpn} B/nnz")

@@ -363,6 +363,8 @@ def main():
         stored_bytes = local_bytes - (12 - bpn) * (local_bytes - 4 * (n + 1) - 16 * n) / 12.0 if not use_dist else None
         if stored_bytes and int(fmt.tile_local_tables):   # + the tile dictionaries (8 B per entry) and their offsets
             stored_bytes += 8 * int(fmt.value_table_size) + 4 * ((n + 511) // 512 + 1)
+        if stored_bytes and int(fmt.column_windows):      # + 64 window bases per tile
+            stored_bytes += 256 * ((n + 511) // 512)
         stored_rate = stored_bytes / (mean_spmv_ms * 1e-3) / 1e9 if stored_bytes and mean_spmv_ms > 0 else None
         kernel = solver.spmv_kernel_name() if hasattr(solver, "spmv_kernel_name") else f"{bpn} B/nnz"
         traffic, traffic_source = None, None
@@ -401,7 +403,7 @@ def main():
                          "stored_bytes_per_nonzero": bpn, "stored_bytes_per_launch": stored_bytes,
                          "stored_rate_gbps": stored_rate,
                          "stored_frac": (stored_rate / HBM_PEAK_GBPS) if stored_rate else None,
-                         "value_table_size": int(fmt.value_table_size), "tile_local_tables": bool(fmt.tile_local_tables),
+                         "value_table_size": int(fmt.value_table_size), "tile_local_tables": bool(fmt.tile_local_tables), "column_windows": bool(fmt.column_windows),
                          "note": "achieved/frac follow SURVEY 8(d) (12 B per non-zero); the matrix is streamed in a lossless "
                                  f"{bpn}-B form, so frac is an effective rate and may exceed 1 -- stored_* is the physical stream"},
             "solve_event_iter_per_s": iters_total / (sum(solve_ms) * 1e-3),

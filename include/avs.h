@@ -161,13 +161,15 @@ avs_status avs_get_assembly_info(avs_ctx *ctx, avs_assembly_info *info);
  * 6 B: uint16 code into a table of the matrix's distinct values + int32 column; 4 B: code and column
  * packed in one word, when bits(n) + bits(table) <= 32.  With more than 2048 distinct values the 6-B form keeps one
  * dictionary per SpMV tile (tile_local_tables): the values of a 512-row tile repeat even when the matrix as a whole
- * has 10^4..10^5 distinct ones (smoothly varying viscosity), and a tile's table fits in LDS. */
+ * has 10^4..10^5 distinct ones (smoothly varying viscosity), and a tile's table fits in LDS.  When code and column do not fit
+ * one word directly (many values, or more than 2^25 columns) the column is stored tile-relative (column_windows): 4 B again. */
 typedef struct avs_matrix_format {
     int32_t reordered;          /* 1 = rows/columns renumbered brick-major inside the solver */
     int32_t value_table_size;   /* distinct values; 0 = not value-indexed (> 65536 distinct values) */
     int32_t column_bits;        /* > 0 = packed form, columns in the low bits */
     int32_t bytes_per_nonzero;  /* 12, 6 or 4 */
     int32_t tile_local_tables;  /* 1 = one dictionary per 512-row SpMV tile (value_table_size = total entries, 8 B each, streamed once) */
+    int32_t column_windows;     /* 1 = 4-B words code | window slot | offset: a tile's columns lie in <= 64 windows of 2^14 ids (+ 256 B per tile) */
 } avs_matrix_format;
 avs_status avs_get_matrix_format(avs_ctx *ctx, avs_matrix_format *fmt);
 avs_status avs_get_solution(avs_ctx *ctx, double *x, int64_t n, avs_memspace where);

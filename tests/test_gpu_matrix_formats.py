@@ -31,13 +31,16 @@ def _scene(kind):
 
 
 NO_TILES = {"AVS_TILE_TABLES": "0"}
+NO_WIN = {"AVS_COLUMN_WINDOWS": "0"}
 CASES = [
     # scene,   environment,                 expected bytes per non-zero, one table in LDS? ("tile" = tile-local tables)
     ("uniform", {}, 4, True),
-    ("uniform", {"AVS_VALUE_PACK": "0"}, 6, True),
+    ("uniform", {"AVS_VALUE_PACK": "0"}, 4, "win"),          # code and column not packed directly -> windowed columns
+    ("uniform", {"AVS_VALUE_PACK": "0", **NO_WIN}, 6, True),
     ("uniform", {"AVS_VALUE_INDEX": "0"}, 12, None),
-    ("levels", {}, 6, "tile"),
-    ("smooth", {}, 6, "tile"),
+    ("levels", {}, 4, "tile"),                               # tile-local value codes + windowed columns in one word
+    ("smooth", {}, 4, "tile"),
+    ("smooth", NO_WIN, 6, "tile"),
     ("levels", NO_TILES, 4, False),
     ("levels", {**NO_TILES, "AVS_VALUE_PACK": "0"}, 6, False),
     ("noise", {}, 12, None),
@@ -61,7 +64,10 @@ def test_storage_forms_are_lossless(kind, env, want_bytes, lds_table, monkeypatc
     assert fmt.tile_local_tables == (1 if lds_table == "tile" else 0)
     if want_bytes == 12:
         assert fmt.value_table_size == 0 and fmt.column_bits == 0
+    elif lds_table == "win":
+        assert fmt.column_windows == 1 and fmt.column_bits == 0 and 0 < fmt.value_table_size <= 2048
     elif lds_table == "tile":
+        assert fmt.column_windows == (1 if want_bytes == 4 else 0)
         # the tables must stay a small share of the stream (8 B per entry vs 6 B saved per non-zero)
         assert 0 < fmt.value_table_size * 8 <= ai.nnz * 2 and fmt.column_bits == 0
         for variant in (51, 52, 53, 54, 55, 56):      # LDS geometries of the tile-table kernel
