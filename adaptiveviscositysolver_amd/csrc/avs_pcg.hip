@@ -544,6 +544,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
     static_assert(TLT == 0 || (!LTAB && !PACK && BLK == 512), "tile tables: 512-row tiles, no plain packing");
     static_assert(!CWIN || (!PACK && BLK == 512), "windowed columns: 512-row tiles");
     constexpr bool WORDS = PACK || CWIN; // the stream is one 32-bit word per non-zero
+    constexpr bool PREF = WORDS;         // prefetch the next pass's words during this one (4 dwords per quad; the 6-B form would need 6)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     static_assert(WIN == 0 || (WIN >= BLK && WIN % BLK == 0), "window = a whole number of tiles");
     double *prod = smem;                 // CAP + 4
@@ -591,10 +592,35 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
         if (HALO && col >= n_own_cols) return ld_sys_f64(hx + (col - n_own_cols)); // the comm block's halo area, written by the peers
         return x[col];
     };
-    if (LTAB || TLT > 0)
-        for (int i = tid; i < tlen; i += BLK) tbl[i] = gtab[i];
+    // the matrix stream of a pass: every lane's quads are requested in one go ...
+    u4_t qn[U]; // value codes (WORDS: whole words, split at use)
+    i4_t cn[U];
+    auto request = [&](int ts, int e_blk) {
+        const int te = (ts + CAP < e_blk) ? ts + CAP : e_blk;
+        const int base = ts & ~3, te4 = te & ~3;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = base + 4 * (tid + u * BLK);
+            qn[u] = u4_t{0, 0, 0, 0};
+            cn[u] = i4_t{0, 0, 0, 0};
+            if (kk < te4) {
+                if (WORDS) {
+                    qn[u] = stream_load<true>(reinterpret_cast<const u4_t *>(A.packed + kk));
+                } else {
+                    const us4_t h = stream_load<true>(reinterpret_cast<const us4_t *>(A.codes + kk));
+                    qn[u] = u4_t{h.x, h.y, h.z, h.w};
+                    cn[u] = stream_load<true>(reinterpret_cast<const i4_t *>(A.col + kk));
+                }
+            }
+        }
+    };
     const int s_blk = A.row_ptr[row0];
     const int e_blk = A.row_ptr[rlast];
+    // ... and the FIRST pass is requested before the tile's tables / x window are staged: their latency (two dependent global
+    // round trips for a tile-local dictionary) hides behind the stream instead of delaying it
+    request(s_blk, e_blk);
+    if (LTAB || TLT > 0)
+        for (int i = tid; i < tlen; i += BLK) tbl[i] = gtab[i];
     int rs = 0, re = 0;
     double xr = 0.;
     if (row < A.n) {
@@ -609,26 +635,17 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
         const int te = (ts + CAP < e_blk) ? ts + CAP : e_blk;
         const int base = ts & ~3; // 8-B aligned code quads, 16-B aligned column quads
         const int te4 = te & ~3;  // quads fully below te
-        u4_t q[U]; // value codes (PACK: packed words, split below)
+        u4_t q[U];
         i4_t c[U];
         double xv[U][4];
         const unsigned cmask = PACK ? ((1u << A.col_bits) - 1u) : 0u;
         const int cbits = PACK ? A.col_bits : 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int kk = base + 4 * (tid + u * BLK);
-            q[u] = u4_t{0, 0, 0, 0};
-            c[u] = i4_t{0, 0, 0, 0};
-            if (kk < te4) {
-                if (WORDS) {
-                    q[u] = stream_load<true>(reinterpret_cast<const u4_t *>(A.packed + kk));
-                } else {
-                    const us4_t h = stream_load<true>(reinterpret_cast<const us4_t *>(A.codes + kk));
-                    q[u] = u4_t{h.x, h.y, h.z, h.w};
-                    c[u] = stream_load<true>(reinterpret_cast<const i4_t *>(A.col + kk));
-                }
-            }
+            q[u] = qn[u];
+            c[u] = cn[u];
         }
+        if (PREF && te < e_blk) request(te, e_blk); // software pipeline: the next pass travels while this one is multiplied
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int kk = base + 4 * (tid + u * BLK);
@@ -667,6 +684,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
             const int kk = te4 + tid;
             prod[kk - base] = value(A.codes[kk]) * gather(A.col[kk]); // the unpacked arrays stay resident
         }
+        if (!PREF && te < e_blk) request(te, e_blk);
         __syncthreads();
         const int a = rs > ts ? rs : ts;
         const int b = re < te ? re : te;
