@@ -524,8 +524,8 @@ typedef int i4_t __attribute__((ext_vector_type(4)));
 
 typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 
-// TLT > 0: tile-local dictionaries (CsrView::tab_ptr): the tile's own table is staged in LDS (its first TLT entries; the rest
-// -- tiles with more distinct values than that -- is read through L1), codes are tile-local.
+// TLT > 0: tile-local dictionaries (CsrView::tab_ptr): the tile's own table is staged in LDS (its first TLT entries; a tile with
+// more distinct values takes a separate path that reads the rest through L1), codes are tile-local.
 // CWIN: windowed columns (CsrView::cbase): one 32-bit word per non-zero = code << 20 | window slot << 14 | offset.
 template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, int WIN = 0, int TLT = 0, bool HALO = false, bool CWIN = false>
 __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__restrict__ x, double *__restrict__ y,
@@ -562,10 +562,12 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
         tlen = A.tab_ptr[tile + 1] - t0;
         if (tlen > TLT) tlen = TLT;
     }
-    auto value = [&](unsigned code) -> double {
-        if (TLT > 0) return code < (unsigned)TLT ? tbl[code] : gtab[code];
-        return LTAB ? tbl[code] : gtab[code];
-    };
+    // Tile tables: the first TLT entries are in LDS.  The rare tile with more distinct values reads the rest through L1 -- on a
+    // path of its own (`big`, wave-uniform), so that the common tile carries no global load (and no s_waitcnt on it) per product.
+    bool big = false;
+    if (TLT > 0) big = (A.tab_ptr[tile + 1] - A.tab_ptr[tile]) > TLT;
+    auto value = [&](unsigned code) -> double { return (LTAB || TLT > 0) ? tbl[code] : gtab[code]; };
+    auto value_big = [&](unsigned code) -> double { return code < (unsigned)TLT ? tbl[code] : gtab[code]; };
     const int64_t row0 = tile * BLK;
     const int64_t row = row0 + tid;
     const int64_t rlast = (row0 + BLK < A.n) ? row0 + BLK : A.n;
@@ -667,23 +669,27 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
                 xv[u][3] = gather(c[u].w);
             }
         }
+        auto products = [&](auto val) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int kk = base + 4 * (tid + u * BLK);
-            if (kk < te4) {
-                d2_t lo, hi;
-                lo.x = value(q[u].x) * xv[u][0];
-                lo.y = value(q[u].y) * xv[u][1];
-                hi.x = value(q[u].z) * xv[u][2];
-                hi.y = value(q[u].w) * xv[u][3];
-                *reinterpret_cast<d2_t *>(prod + (kk - base)) = lo;
-                *reinterpret_cast<d2_t *>(prod + (kk - base) + 2) = hi;
+            for (int u = 0; u < U; ++u) {
+                const int kk = base + 4 * (tid + u * BLK);
+                if (kk < te4) {
+                    d2_t lo, hi;
+                    lo.x = val(q[u].x) * xv[u][0];
+                    lo.y = val(q[u].y) * xv[u][1];
+                    hi.x = val(q[u].z) * xv[u][2];
+                    hi.y = val(q[u].w) * xv[u][3];
+                    *reinterpret_cast<d2_t *>(prod + (kk - base)) = lo;
+                    *reinterpret_cast<d2_t *>(prod + (kk - base) + 2) = hi;
+                }
             }
-        }
-        if (tid < te - te4) { // ragged end of the pass (at most 3 entries; entries below ts are never summed)
-            const int kk = te4 + tid;
-            prod[kk - base] = value(A.codes[kk]) * gather(A.col[kk]); // the unpacked arrays stay resident
-        }
+            if (tid < te - te4) { // ragged end of the pass (at most 3 entries; entries below ts are never summed)
+                const int kk = te4 + tid;
+                prod[kk - base] = val(A.codes[kk]) * gather(A.col[kk]); // the unpacked arrays stay resident
+            }
+        };
+        if (TLT > 0 && big) products(value_big);
+        else products(value);
         if (!PREF && te < e_blk) request(te, e_blk);
         __syncthreads();
         const int a = rs > ts ? rs : ts;
@@ -838,7 +844,7 @@ static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, do
         if (nblocks) *nblocks = nt * (kTileRows / 64);
         return spmv_vi2_launch<kTileRows, kTileCap, DOT, kTileWin>(A, x, y, partial, sc, nullptr, nt, stream);
     }
-    if (A.tab_ptr && variant >= 51 && variant <= 56) { // geometry sweep of the tile-table kernel (profiles/r02_varvisc.md)
+    if (A.tab_ptr && variant >= 51 && variant <= 54) { // geometry sweep of the tile-table kernel (profiles/r02_varvisc.md)
         const int nt = (int)((A.n + kTileRows - 1) / kTileRows);
         if (nblocks) *nblocks = nt * (kTileRows / 64);
         switch (variant) {
@@ -846,8 +852,6 @@ static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, do
         case 52: return spmv_tlt_launch<2048, DOT, 2048>(A, x, y, partial, sc, nullptr, nt, stream);
         case 53: return spmv_tlt_launch<4096, DOT, 2048>(A, x, y, partial, sc, nullptr, nt, stream);
         case 54: return spmv_tlt_launch<2048, DOT, 1024>(A, x, y, partial, sc, nullptr, nt, stream);
-        case 55: return spmv_tlt_launch<4096, DOT, 512>(A, x, y, partial, sc, nullptr, nt, stream);
-        case 56: return spmv_tlt_launch<2048, DOT, 512>(A, x, y, partial, sc, nullptr, nt, stream);
         }
     }
     if (A.codes && !A.tab_ptr && !A.cbase && variant >= 31 && variant <= 46) {

@@ -294,8 +294,8 @@ avs_status unpermute(avs_ctx *c, const double *xp, double *x)
 // collide; the VALUES behind the codes, and therefore every product and sum, do not).
 // ---------------------------------------------------------------------------------------------
 static constexpr int kTltRows = 512;       // == spmv_tile_rows()
-static constexpr int kTltSlots = 8192;     // LDS hash slots per tile (64 KiB)
-static constexpr int kTltMaxKeys = 6144;   // more distinct values in one tile: the form is pointless anyway
+static constexpr int kTltSlots = 4096;     // LDS hash slots per tile (32 KiB)
+static constexpr int kTltMaxKeys = 3072;   // more distinct values in one tile: the form is pointless anyway (codes must stay < 4096)
 
 __device__ __forceinline__ unsigned tlt_hash(unsigned long long k)
 {
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(kTltRows) void k_tlt_build(int64_t n, const int32_t
         if (tid == 0) tab_len[tile] = distinct;
         return;
     }
-    // rank of every occupied slot in slot order: thread t owns slots [16 t, 16 t + 16)
+    // rank of every occupied slot in slot order: thread t owns slots [per t, per t + per)
     constexpr int per = kTltSlots / kTltRows;
     int mine = 0;
 #pragma unroll
