@@ -77,7 +77,8 @@ class PlanSizes(C.Structure):
 class PrepassDesc(C.Structure):
     _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("dx", C.c_double),
                 ("desired_levels", C.c_int32), ("n_super", C.c_int32), ("extrapolation_scale", C.c_double),
-                ("device", C.c_int32), ("stream", C.c_void_p)]
+                ("device", C.c_int32), ("stream", C.c_void_p),
+                ("field_nx", C.c_int32), ("field_ny", C.c_int32), ("field_nz", C.c_int32)]
 
 
 class PrepassInfo(C.Structure):

@@ -1,7 +1,10 @@
 // avs_api.hip -- the extern "C" surface declared in include/avs.h.
 // Context management, input upload, phase orchestration, read-back.  No kernels here.
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include <new>
 
 #include "avs_internal.hpp"
@@ -16,6 +19,40 @@ void set_error(const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        if (const char *e = getenv("AVS_ROCTX"))
+            if (atoi(e) == 0) return;
+        for (const char *lib : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            void *h = dlopen(lib, RTLD_LAZY | RTLD_GLOBAL);
+            if (!h) continue;
+            push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (push && pop) return;
+            push = nullptr;
+            pop = nullptr;
+        }
+    }
+};
+const Roctx &roctx()
+{
+    static Roctx r;
+    return r;
+}
+} // namespace
+void roctx_push(const char *name)
+{
+    if (roctx().push) (void)roctx().push(name);
+}
+void roctx_pop()
+{
+    if (roctx().pop) (void)roctx().pop();
 }
 
 // phase drivers implemented in avs_assembly.hip
@@ -187,15 +224,18 @@ avs_status avs_set_dof_counts(avs_ctx *c, int64_t nv, int64_t ne, int64_t nc)
     return AVS_OK;
 }
 
+} // extern "C"
+
 namespace {
-// field on the simulation grid -> the padded level-0 lattice of the octree (desc.field_n* < desc.n*)
-__global__ __launch_bounds__(256) void k_pad_field(const float *__restrict__ in, int sx, int sy, int sz, float *__restrict__ out, int rx,
-                                                   int ry, int rz, int replicate)
+// lattice (sx, sy, sz) -> (rx, ry, rz) >= it: outside, the border value (replicate) or `fill`
+template <typename T>
+__global__ __launch_bounds__(256) void k_pad_lattice(const T *__restrict__ in, int sx, int sy, int sz, T *__restrict__ out, int rx, int ry, int rz,
+                                                     int replicate, T fill)
 {
     const size_t total = (size_t)rx * ry * rz;
     for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
         const int i = (int)(o % rx), j = (int)((o / rx) % ry), k = (int)(o / ((size_t)rx * ry));
-        float v = 0.f;
+        T v = fill;
         if (replicate || (i < sx && j < sy && k < sz)) {
             const int ci = i < sx ? i : sx - 1, cj = j < sy ? j : sy - 1, ck = k < sz ? k : sz - 1;
             v = in[(size_t)ci + (size_t)sx * ((size_t)cj + (size_t)sy * ck)];
@@ -203,10 +243,56 @@ __global__ __launch_bounds__(256) void k_pad_field(const float *__restrict__ in,
         out[o] = v;
     }
 }
+__global__ __launch_bounds__(256) void k_crop_lattice(const float *__restrict__ in, int rx, int ry, int rz, float *__restrict__ out, int sx, int sy,
+                                                      int sz)
+{
+    const size_t total = (size_t)sx * sy * sz;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int i = (int)(o % sx), j = (int)((o / sx) % sy), k = (int)(o / ((size_t)sx * sy));
+        out[o] = in[(size_t)i + (size_t)rx * ((size_t)j + (size_t)ry * k)];
+    }
+}
+unsigned pad_grid(size_t n)
+{
+    const size_t b = (n + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b < 65536 ? b : 65536));
+}
 } // namespace
+
+namespace avs {
+avs_status pad_lattice_f32(const float *src, int sx, int sy, int sz, float *dst, int rx, int ry, int rz, bool replicate, float fill, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pad_lattice<float>, dim3(pad_grid((size_t)rx * ry * rz)), dim3(256), 0, st, src, sx, sy, sz, dst, rx, ry, rz,
+                       replicate ? 1 : 0, fill);
+    AVS_HIP(hipGetLastError());
+    return AVS_OK;
+}
+avs_status pad_lattice_i32(const int32_t *src, int sx, int sy, int sz, int32_t *dst, int rx, int ry, int rz, int32_t fill, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pad_lattice<int32_t>, dim3(pad_grid((size_t)rx * ry * rz)), dim3(256), 0, st, src, sx, sy, sz, dst, rx, ry, rz, 0, fill);
+    AVS_HIP(hipGetLastError());
+    return AVS_OK;
+}
+avs_status crop_lattice_f32(const float *src, int rx, int ry, int rz, float *dst, int sx, int sy, int sz, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_crop_lattice, dim3(pad_grid((size_t)sx * sy * sz)), dim3(256), 0, st, src, rx, ry, rz, dst, sx, sy, sz);
+    AVS_HIP(hipGetLastError());
+    return AVS_OK;
+}
+} // namespace avs
+
+extern "C" {
 
 avs_status avs_set_scalar_field(avs_ctx *c, avs_field_kind kind, int32_t axis, const float *data, float constant,
                                 avs_memspace where)
+{
+    return avs::set_scalar_field_lattice(c, kind, axis, data, constant, where, false);
+}
+
+} // extern "C"
+
+avs_status avs::set_scalar_field_lattice(avs_ctx *c, avs_field_kind kind, int32_t axis, const float *data, float constant, avs_memspace where,
+                                         bool padded_lattice)
 {
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_HIP(hipSetDevice(c->desc.device));
@@ -234,18 +320,19 @@ avs_status avs_set_scalar_field(avs_ctx *c, avs_field_kind kind, int32_t axis, c
         // the caller's array has the SIMULATION grid's lattice: r minus the padding HDK_OctreeGrid::init added
         const int s3[3] = {r[0] - (c->desc.nx - c->desc.field_nx), r[1] - (c->desc.ny - c->desc.field_ny),
                            r[2] - (c->desc.nz - c->desc.field_nz)};
-        if (s3[0] == r[0] && s3[1] == r[1] && s3[2] == r[2]) {
+        if (padded_lattice || (s3[0] == r[0] && s3[1] == r[1] && s3[2] == r[2])) {
             AVS_HIP(copy_in(f->buf.p, data, vol3(r) * sizeof(float), where, c->stream));
             if (where == AVS_MEM_HOST) AVS_HIP(hipStreamSynchronize(c->stream));
         } else {
             DevBuf<float> src;
-            AVS_TRY(src.alloc(vol3(s3)));
-            AVS_HIP(copy_in(src.p, data, vol3(s3) * sizeof(float), where, c->stream));
-            const int replicate = (kind == AVS_FIELD_VISCOSITY || kind == AVS_FIELD_DENSITY) ? 1 : 0;
-            const size_t blocks = (vol3(r) + 255) / 256;
-            hipLaunchKernelGGL(k_pad_field, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, c->stream,
-                               (const float *)src.p, s3[0], s3[1], s3[2], f->buf.p, r[0], r[1], r[2], replicate);
-            AVS_HIP(hipGetLastError());
+            const float *sp = data;
+            if (where == AVS_MEM_HOST) {
+                AVS_TRY(src.alloc(vol3(s3)));
+                AVS_HIP(copy_in(src.p, data, vol3(s3) * sizeof(float), where, c->stream));
+                sp = src.p;
+            }
+            const bool replicate = (kind == AVS_FIELD_VISCOSITY || kind == AVS_FIELD_DENSITY);
+            AVS_TRY(pad_lattice_f32(sp, s3[0], s3[1], s3[2], f->buf.p, r[0], r[1], r[2], replicate, 0.f, c->stream));
             AVS_HIP(hipStreamSynchronize(c->stream)); // src dies here
         }
         f->is_const = false;
@@ -253,6 +340,8 @@ avs_status avs_set_scalar_field(avs_ctx *c, avs_field_kind kind, int32_t axis, c
     invalidate(c, false);
     return AVS_OK;
 }
+
+extern "C" {
 
 avs_status avs_build_stencils(avs_ctx *c)
 {
@@ -279,19 +368,25 @@ avs_status avs_assemble(avs_ctx *c, avs_assembly_info *info)
     AVS_HIP(hipSetDevice(c->desc.device));
     Timer t(c->stream);
     t.start();
-    AVS_TRY(build_stencils(c)); // includes the dof tables
+    AVS_TRY(build_stencils(c)); // includes the dof tables; scopes "Build Edge / Cell Stress Stencils" inside
     c->ainfo.stencil_ms = t.stop();
     t.start();
-    AVS_TRY(build_initial_guess(c));
+    {
+        Scope sc("Interpolate Regular Grid Velocities at Octree Velocity Faces"); // cpp:516
+        AVS_TRY(build_initial_guess(c));
+    }
     c->ainfo.guess_ms = t.stop();
-    t.start();
-    AVS_TRY(build_system(c));
-    c->ainfo.system_ms = t.stop();
-    t.start();
-    c->reordered = false;
-    if (const char *e = getenv("AVS_BRICK_SHIFT")) c->brick_shift = atoi(e);
-    if (c->brick_shift >= 0) AVS_TRY(build_reordered_system(c, c->brick_shift));
-    c->ainfo.csr_ms = t.stop();
+    {
+        Scope sc("Build Octree Linear System"); // cpp:554 (+ setFromTriplets, cpp:613)
+        t.start();
+        AVS_TRY(build_system(c));
+        c->ainfo.system_ms = t.stop();
+        t.start();
+        c->reordered = false;
+        if (const char *e = getenv("AVS_BRICK_SHIFT")) c->brick_shift = atoi(e);
+        if (c->brick_shift >= 0) AVS_TRY(build_reordered_system(c, c->brick_shift));
+        c->ainfo.csr_ms = t.stop();
+    }
     c->ainfo.n_velocity = c->n_vel;
     c->ainfo.n_edge = c->n_edge;
     c->ainfo.n_center = c->n_center;
@@ -348,6 +443,7 @@ avs_status avs_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_info *
     AVS_REQUIRE(c->system_ready, AVS_ESTATE, "avs_assemble must succeed before avs_solve");
     AVS_REQUIRE(tol >= 0. && max_iters >= 0, AVS_EINVAL, "tolerance / max_iterations out of range");
     AVS_HIP(hipSetDevice(c->desc.device));
+    Scope scope("Solve Linear System"); // cpp:603
     const int64_t n = c->n_vel;
     if (c->pcg && pcg_rows(c->pcg) != n) { // the context was re-assembled with another DOF count (next frame)
         pcg_destroy(c->pcg);

@@ -893,8 +893,14 @@ avs_status build_stencils(avs_ctx *c)
     AVS_TRY(err.alloc(1));
     AVS_HIP(hipMemsetAsync(err.p, 0, sizeof(int), st));
     PyramidView P = c->view();
-    if (c->n_edge) hipLaunchKernelGGL(k_edge_stencils, dim3(grid_for(c->n_edge)), dim3(kBlock), 0, st, P, c->edof.p, edge_view(c), err.p);
-    if (c->n_center) hipLaunchKernelGGL(k_center_stencils, dim3(grid_for(c->n_center)), dim3(kBlock), 0, st, P, c->cdof.p, center_view(c), err.p);
+    if (c->n_edge) {
+        Scope sc("Build Edge Stress Stencils"); // cpp:441
+        hipLaunchKernelGGL(k_edge_stencils, dim3(grid_for(c->n_edge)), dim3(kBlock), 0, st, P, c->edof.p, edge_view(c), err.p);
+    }
+    if (c->n_center) {
+        Scope sc("Build Cell Stress Stencils"); // cpp:473
+        hipLaunchKernelGGL(k_center_stencils, dim3(grid_for(c->n_center)), dim3(kBlock), 0, st, P, c->cdof.p, center_view(c), err.p);
+    }
     AVS_HIP(hipGetLastError());
     int e = 0;
     AVS_TRY(read_err(err.p, st, &e));

@@ -1324,6 +1324,7 @@ avs_status avs_dist_assemble(avs_ctx *c, int32_t cut_axis, avs_assembly_info *in
     t.start();
     AVS_TRY(build_stencils(c)); // dof tables + stencils: index-only and cheap, every rank builds all of them
     ai.stencil_ms = t.stop();
+    Scope scope("Build Octree Linear System"); // cpp:554: here only this rank's rows
     ai.guess_ms = 0.; // the restriction of the owned DOFs is part of system_ms here
     t.start();
     c->system_ready = false; // no global matrix in this mode
@@ -1426,6 +1427,7 @@ avs_status avs_dist_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_i
     AVS_HIP(hipSetDevice(c->desc.device));
     PcgDist *d = c->dist;
     AVS_REQUIRE(!d->hosted || d->direct_ready, AVS_ESTATE, "hosted group: exchange the blobs first (avs_dist_export_blob / avs_dist_import_blobs)");
+    Scope scope("Solve Linear System"); // cpp:603
     if (d->direct_pending && !d->hosted) { // first solve on this plan: every rank is here, connect the transport
         AVS_TRY(direct_setup(c, d));
         d->direct_pending = false;

@@ -45,6 +45,33 @@ void set_error(const char *fmt, ...);
     } while (0)
 
 // ---------------------------------------------------------------------------------------------
+// roctx ranges named after the reference's perf-monitor scopes (UT_PerfMonAutoSolveEvent, cpp:306-874), so that a rocprofv3
+// --marker-trace timeline reads like Houdini's performance monitor.  The roctx library is looked up at run time (no link
+// dependency; AVS_ROCTX=0 disables).
+// ---------------------------------------------------------------------------------------------
+void roctx_push(const char *name);
+void roctx_pop();
+struct Scope {
+    explicit Scope(const char *name) { roctx_push(name); }
+    ~Scope() { roctx_pop(); }
+    Scope(const Scope &) = delete;
+    Scope &operator=(const Scope &) = delete;
+};
+struct PhaseScope { // consecutive phases of one function: next() closes the previous range, the destructor the last
+    bool open = false;
+    void next(const char *name)
+    {
+        if (open) roctx_pop();
+        roctx_push(name);
+        open = true;
+    }
+    ~PhaseScope()
+    {
+        if (open) roctx_pop();
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // device buffer with explicit lifetime (hipMalloc/hipFree), sized in elements
 // ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -269,6 +296,15 @@ struct DirectArgs {                               // what pcg_solve_direct needs
 };
 bool dist_direct_args(PcgDist *d, DirectArgs *out); // false: the direct transport is not connected
 
+// inputs already laid out on the PADDED octree lattice (what the device pre-pass produces): no crop / pad step (avs_api.hip, avs_post.hip)
+avs_status set_scalar_field_lattice(::avs_ctx *c, avs_field_kind kind, int32_t axis, const float *data, float constant, avs_memspace where,
+                                    bool padded_lattice);
+avs_status set_regular_index_lattice(::avs_ctx *c, int32_t axis, const int32_t *idx, avs_memspace where, bool padded_lattice);
+// field on a smaller lattice (sx, sy, sz) -> (rx, ry, rz): outside, the border value (replicate) or `fill`
+avs_status pad_lattice_f32(const float *src, int sx, int sy, int sz, float *dst, int rx, int ry, int rz, bool replicate, float fill, hipStream_t st);
+avs_status pad_lattice_i32(const int32_t *src, int sx, int sy, int sz, int32_t *dst, int rx, int ry, int rz, int32_t fill, hipStream_t st);
+avs_status crop_lattice_f32(const float *src, int rx, int ry, int rz, float *dst, int sx, int sy, int sz, hipStream_t st);
+
 // multi-GPU hooks called from pcg_solve (implemented in avs_dist.hip)
 avs_status dist_halo_exchange(PcgDist *d, double *p_ext, hipStream_t stream);
 avs_status dist_allreduce(PcgDist *d, double *dev_scalars, int count, hipStream_t stream);
@@ -332,6 +368,7 @@ struct avs_ctx {
     avs::DevBuf<float> post_vel[AVS_MAX_LEVELS][3], post_nval[AVS_MAX_LEVELS][3], post_nw[AVS_MAX_LEVELS][3];
     avs::DevBuf<int32_t> post_nf[AVS_MAX_LEVELS];
     avs::DevBuf<int8_t> post_nlab[AVS_MAX_LEVELS];
+    avs::DevBuf<float> post_out[3]; // staging of the regular-grid output (host destination or padded octree grid), kept across calls
     bool post_ready = false;
 
     // brick-major copy of the system used by the solve (avs_reorder.hip); perm: new -> old

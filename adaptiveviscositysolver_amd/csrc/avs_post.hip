@@ -15,6 +15,7 @@
 // arithmetic in between; the same conversions are made at the same places so results are bit-identical
 // to the oracle.  Sample positions are lattice points: index-space arithmetic is exact.
 #include <cmath>
+#include <cstring>
 
 #include "avs_device_common.hpp"
 
@@ -359,30 +360,50 @@ extern "C" {
 // regularVelocityIndices[axis], cpp:303-329: >= 0 regular DOF, AVS_SOLIDBOUNDARY, else untouched
 avs_status avs_set_regular_index_field(avs_ctx *c, int32_t axis, const int32_t *idx, avs_memspace where)
 {
+    return avs::set_regular_index_lattice(c, axis, idx, where, false);
+}
+
+} // extern "C"
+
+avs_status avs::set_regular_index_lattice(avs_ctx *c, int32_t axis, const int32_t *idx, avs_memspace where, bool padded_lattice)
+{
     AVS_REQUIRE(c && idx, AVS_EINVAL, "null argument");
-    AVS_REQUIRE(c->desc.field_nx == c->desc.nx && c->desc.field_ny == c->desc.ny && c->desc.field_nz == c->desc.nz, AVS_EINVAL,
-                "the post-solve transfer needs field_n* == n* (simulation grid == octree grid)");
     AVS_REQUIRE(axis >= 0 && axis < 3, AVS_EINVAL, "axis out of range");
     AVS_HIP(hipSetDevice(c->desc.device));
     int r[3] = {c->desc.nx, c->desc.ny, c->desc.nz};
+    int s3[3] = {c->desc.field_nx, c->desc.field_ny, c->desc.field_nz};
     r[axis] += 1;
-    const size_t n = (size_t)r[0] * r[1] * r[2];
+    s3[axis] += 1;
+    const size_t n = (size_t)r[0] * r[1] * r[2], ns = (size_t)s3[0] * s3[1] * s3[2];
     AVS_TRY(c->ridx[axis].alloc(n));
-    AVS_HIP(copy_in(c->ridx[axis].p, idx, n * sizeof(int32_t), where, c->stream));
-    if (where == AVS_MEM_HOST) AVS_HIP(hipStreamSynchronize(c->stream));
+    if (padded_lattice || n == ns) {
+        AVS_HIP(copy_in(c->ridx[axis].p, idx, n * sizeof(int32_t), where, c->stream));
+        if (where == AVS_MEM_HOST) AVS_HIP(hipStreamSynchronize(c->stream));
+    } else { // the regular grid is the simulation grid: faces of the padding are no regular DOFs (AVS_UNASSIGNED = untouched)
+        DevBuf<int32_t> src;
+        const int32_t *sp = idx;
+        if (where == AVS_MEM_HOST) {
+            AVS_TRY(src.alloc(ns));
+            AVS_HIP(copy_in(src.p, idx, ns * sizeof(int32_t), where, c->stream));
+            sp = src.p;
+        }
+        AVS_TRY(pad_lattice_i32(sp, s3[0], s3[1], s3[2], c->ridx[axis].p, r[0], r[1], r[2], AVS_UNASSIGNED, c->stream));
+        AVS_HIP(hipStreamSynchronize(c->stream));
+    }
     c->have_ridx[axis] = true;
     return AVS_OK;
 }
 
+extern "C" {
+
 avs_status avs_transfer_to_regular_grid(avs_ctx *c, float *out_x, float *out_y, float *out_z, avs_memspace where)
 {
     AVS_REQUIRE(c && out_x && out_y && out_z, AVS_EINVAL, "null argument");
-    AVS_REQUIRE(c->desc.field_nx == c->desc.nx && c->desc.field_ny == c->desc.ny && c->desc.field_nz == c->desc.nz, AVS_EINVAL,
-                "the post-solve transfer needs field_n* == n* (simulation grid == octree grid)");
     AVS_REQUIRE(c->solved, AVS_ESTATE, "no solution: call avs_solve first");
     AVS_REQUIRE(c->have_ridx[0] && c->have_ridx[1] && c->have_ridx[2], AVS_ESTATE, "regular-grid index fields missing (avs_set_regular_index_field)");
     AVS_REQUIRE(c->tables_ready, AVS_ESTATE, "dof tables missing");
     AVS_HIP(hipSetDevice(c->desc.device));
+    Scope scope("Apply Octree Solution to Regular Grid"); // cpp:662
     hipStream_t st = c->stream;
     const int L = c->desc.levels;
     PyramidView P = c->view();
@@ -422,24 +443,40 @@ avs_status avs_transfer_to_regular_grid(avs_ctx *c, float *out_x, float *out_y, 
     for (int l = L - 2; l >= 0; --l) hipLaunchKernelGGL(k_nodes_distribute, dim3(grid_for(nodes(l))), dim3(kBlock), 0, st, P, W, l);
     AVS_HIP(hipGetLastError());
     float *outs[3] = {out_x, out_y, out_z};
+    const bool padded = c->desc.field_nx != c->desc.nx || c->desc.field_ny != c->desc.ny || c->desc.field_nz != c->desc.nz;
     for (int a = 0; a < 3; ++a) {
         int fr[3] = {c->desc.nx, c->desc.ny, c->desc.nz};
+        int sr[3] = {c->desc.field_nx, c->desc.field_ny, c->desc.field_nz};
         fr[a] += 1;
-        const size_t nf = (size_t)fr[0] * fr[1] * fr[2];
-        DevBuf<float> out;
-        AVS_TRY(out.alloc(nf));
+        sr[a] += 1;
+        const size_t nf = (size_t)fr[0] * fr[1] * fr[2], ns = (size_t)sr[0] * sr[1] * sr[2];
+        // a device destination on an unpadded grid is written in place; otherwise through a staging grid kept in the context
+        float *work = outs[a];
+        if (where == AVS_MEM_HOST || padded) {
+            AVS_TRY(c->post_out[a].alloc(nf));
+            work = c->post_out[a].p;
+        }
         // the regular velocity field is updated in place in the reference: start from the input velocity
         if (c->vel[a].is_const) {
-            std::vector<float> h(nf, c->vel[a].cval);
-            AVS_HIP(hipMemcpyAsync(out.p, h.data(), nf * sizeof(float), hipMemcpyHostToDevice, st));
-            AVS_HIP(hipStreamSynchronize(st));
-        } else AVS_HIP(hipMemcpyAsync(out.p, c->vel[a].buf.p, nf * sizeof(float), hipMemcpyDeviceToDevice, st));
+            uint32_t bits;
+            memcpy(&bits, &c->vel[a].cval, sizeof(bits));
+            AVS_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(work), (int)bits, nf, st));
+        } else AVS_HIP(hipMemcpyAsync(work, c->vel[a].buf.p, nf * sizeof(float), hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_apply_regular, dim3(grid_for(nf)), dim3(kBlock), 0, st, P, W, a, (const int32_t *)c->ridx[a].p,
-                           (const double *)c->x.p, out.p);
+                           (const double *)c->x.p, work);
         AVS_HIP(hipGetLastError());
-        AVS_HIP(copy_out(outs[a], out.p, nf * sizeof(float), where, st));
-        AVS_HIP(hipStreamSynchronize(st));
+        if (padded) { // hand back the simulation grid's faces only
+            if (where == AVS_MEM_DEVICE) AVS_TRY(crop_lattice_f32(work, fr[0], fr[1], fr[2], outs[a], sr[0], sr[1], sr[2], st));
+            else {
+                DevBuf<float> crop;
+                AVS_TRY(crop.alloc(ns));
+                AVS_TRY(crop_lattice_f32(work, fr[0], fr[1], fr[2], crop.p, sr[0], sr[1], sr[2], st));
+                AVS_HIP(copy_out(outs[a], crop.p, ns * sizeof(float), where, st));
+                AVS_HIP(hipStreamSynchronize(st));
+            }
+        } else if (where == AVS_MEM_HOST) AVS_HIP(copy_out(outs[a], work, nf * sizeof(float), where, st));
     }
+    AVS_HIP(hipStreamSynchronize(st));
     c->post_ready = true;
     return AVS_OK;
 }

@@ -156,13 +156,15 @@ __global__ __launch_bounds__(kWB *kWB *kWB) void k_sdf_weights(const float *__re
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_mask_labels(const float *__restrict__ liquid, const float *__restrict__ solid,
                                                         size_t n, double dx, double extrapolation, int8_t *__restrict__ mask,
-                                                        int8_t *__restrict__ labels)
+                                                        int8_t *__restrict__ labels, Grid3 g, Grid3 sim)
 {
     const double inner = dx * 2., outer = 3. * dx; // cpp:259-262 (fine bandwidth getter mismatch => 2)
     for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < n; o += (size_t)gridDim.x * kBlock) {
         const double sdf = (double)liquid[o];
         int m;
-        if (sdf > 0 && sdf < outer) m = 0;
+        const int ci = (int)(o % g.r[0]), cj = (int)((o / g.r[0]) % g.r[1]), ck = (int)(o / ((size_t)g.r[0] * g.r[1]));
+        if (ci >= sim.r[0] || cj >= sim.r[1] || ck >= sim.r[2]) m = 1; // outside the simulation grid: stays INACTIVE (oct.cpp:375-379)
+        else if (sdf > 0 && sdf < outer) m = 0;
         else if (sdf <= 0.) {
             if (sdf > -inner) m = 0;
             else {
@@ -620,6 +622,8 @@ avs_status avs_prepass_create(const avs_prepass_desc *d, avs_prepass **out)
     AVS_REQUIRE(d->desired_levels >= 1 && d->desired_levels <= AVS_MAX_LEVELS, AVS_EINVAL, "desired_levels out of range");
     AVS_REQUIRE(d->n_super >= 1 && d->n_super <= kMaxSuper, AVS_EINVAL, "n_super must be in [1, %d]", kMaxSuper);
     AVS_REQUIRE(d->dx > 0., AVS_EINVAL, "dx must be positive");
+    AVS_REQUIRE(d->field_nx >= 0 && d->field_nx <= d->nx && d->field_ny >= 0 && d->field_ny <= d->ny && d->field_nz >= 0 && d->field_nz <= d->nz,
+                AVS_EINVAL, "simulation grid %d %d %d must lie in [0, octree grid]", d->field_nx, d->field_ny, d->field_nz);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     AVS_REQUIRE(e == hipSuccess && ndev > 0, AVS_EHIP, "no HIP device available (%s)", hipGetErrorString(e));
@@ -628,6 +632,9 @@ avs_status avs_prepass_create(const avs_prepass_desc *d, avs_prepass **out)
     avs_prepass *p = new (std::nothrow) avs_prepass();
     AVS_REQUIRE(p, AVS_ENOMEM, "out of host memory");
     p->desc = *d;
+    if (p->desc.field_nx == 0) p->desc.field_nx = d->nx;
+    if (p->desc.field_ny == 0) p->desc.field_ny = d->ny;
+    if (p->desc.field_nz == 0) p->desc.field_nz = d->nz;
     if (d->stream) p->stream = reinterpret_cast<hipStream_t>(d->stream);
     else {
         if (hipStreamCreate(&p->stream) != hipSuccess) { delete p; set_error("hipStreamCreate failed"); return AVS_EHIP; }
@@ -667,16 +674,35 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     p->ready = false;
     EvTimer t(st);
 
-    AVS_TRY(p->liquid.alloc(n0));
-    AVS_HIP(copy_in(p->liquid.p, liquid, n0 * sizeof(float), where, st));
+    // the SDFs arrive on the simulation grid; outside it they are read with clamped coordinates (border replication)
+    const int s0[3] = {d.field_nx, d.field_ny, d.field_nz};
+    const bool padded = s0[0] != r0[0] || s0[1] != r0[1] || s0[2] != r0[2];
+    const size_t ns = g3(s0).vol();
+    auto take = [&](DevBuf<float> &dst, const float *src) -> avs_status {
+        AVS_TRY(dst.alloc(n0));
+        if (!padded) {
+            AVS_HIP(copy_in(dst.p, src, n0 * sizeof(float), where, st));
+            return AVS_OK;
+        }
+        DevBuf<float> tmp;
+        const float *sp = src;
+        if (where == AVS_MEM_HOST) {
+            AVS_TRY(tmp.alloc(ns));
+            AVS_HIP(copy_in(tmp.p, src, ns * sizeof(float), where, st));
+            sp = tmp.p;
+        }
+        AVS_TRY(pad_lattice_f32(sp, s0[0], s0[1], s0[2], dst.p, r0[0], r0[1], r0[2], true, 0.f, st));
+        AVS_HIP(hipStreamSynchronize(st)); // tmp dies here
+        return AVS_OK;
+    };
+    AVS_TRY(take(p->liquid, liquid));
     p->have_solid = solid != nullptr;
-    if (solid) {
-        AVS_TRY(p->solid.alloc(n0));
-        AVS_HIP(copy_in(p->solid.p, solid, n0 * sizeof(float), where, st));
-    }
+    if (solid) AVS_TRY(take(p->solid, solid));
     if (where == AVS_MEM_HOST) AVS_HIP(hipStreamSynchronize(st));
 
     // ---- P1 weights ------------------------------------------------------------------------
+    PhaseScope phase;
+    phase.next("Compute Surface Weights"); // cpp:759 (+ "Compute Collision Weights", cpp:776: one fused launch here)
     t.start();
     {
         WeightFields F{};
@@ -703,6 +729,7 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     p->ms[0] = t.stop();
 
     // ---- P2 + P3 octree --------------------------------------------------------------------
+    phase.next("Build Octree"); // cpp:874 (+ "Build Mask for Octree", cpp:813)
     t.start();
     const int L = p->max_levels;
     AVS_TRY(p->mask.alloc(n0));
@@ -713,7 +740,7 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         AVS_HIP(hipMemsetAsync(p->labels[l].p, 0, g3(r).vol(), st)); // INACTIVE, oct.cpp:59,69
     }
     hipLaunchKernelGGL(k_mask_labels, dim3(grid_for(n0)), dim3(kBlock), 0, st, p->liquid.p, solid ? p->solid.p : nullptr, n0, d.dx,
-                       extrapolation, p->mask.p, p->labels[0].p);
+                       extrapolation, p->mask.p, p->labels[0].p, g3(r0), g3(s0));
     for (int l = 0; l < L - 1; ++l) {
         int r[3], rp[3];
         pp_res(d, 2, l, 0, r);
@@ -753,6 +780,7 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     }
 
     // ---- P4 classification -----------------------------------------------------------------
+    phase.next("Build Octree Velocity and Stress Labels"); // cpp:360 (+ "Build Regular Grid Velocity Labels", cpp:306)
     t.start();
     const double occ_sdf = 2. * d.dx; // cpp:907
     size_t max_vol = 0;
@@ -949,6 +977,9 @@ avs_status avs_prepass_apply(avs_prepass *p, avs_ctx *ctx)
     AVS_REQUIRE(ctx->desc.levels == p->levels && ctx->desc.nx == p->desc.nx && ctx->desc.ny == p->desc.ny && ctx->desc.nz == p->desc.nz &&
                     ctx->desc.device == p->desc.device,
                 AVS_EINVAL, "context (levels %d) does not match the pre-pass (levels %d)", ctx->desc.levels, p->levels);
+    AVS_REQUIRE(ctx->desc.field_nx == p->desc.field_nx && ctx->desc.field_ny == p->desc.field_ny && ctx->desc.field_nz == p->desc.field_nz,
+                AVS_EINVAL, "context and pre-pass disagree on the simulation grid (%d %d %d vs %d %d %d)", ctx->desc.field_nx,
+                ctx->desc.field_ny, ctx->desc.field_nz, p->desc.field_nx, p->desc.field_ny, p->desc.field_nz);
     AVS_HIP(hipStreamSynchronize(p->stream));
     for (int l = 0; l < p->levels; ++l) {
         AVS_TRY(avs_set_labels(ctx, l, p->labels[l].p, AVS_MEM_DEVICE));
@@ -959,11 +990,12 @@ avs_status avs_prepass_apply(avs_prepass *p, avs_ctx *ctx)
         AVS_TRY(avs_set_index_field(ctx, AVS_INDEX_CENTER, l, 0, p->cidx[l].p, AVS_MEM_DEVICE));
     }
     AVS_TRY(avs_set_dof_counts(ctx, p->counts[0], p->counts[1], p->counts[2]));
-    AVS_TRY(avs_set_scalar_field(ctx, AVS_FIELD_CENTER_WEIGHTS, 0, p->centerw.p, 0.f, AVS_MEM_DEVICE));
+    // weights and regular-grid indices live on the padded octree lattices here: handed over as they are
+    AVS_TRY(set_scalar_field_lattice(ctx, AVS_FIELD_CENTER_WEIGHTS, 0, p->centerw.p, 0.f, AVS_MEM_DEVICE, true));
     for (int a = 0; a < 3; ++a) {
-        AVS_TRY(avs_set_scalar_field(ctx, AVS_FIELD_EDGE_WEIGHTS, a, p->edgew[a].p, 0.f, AVS_MEM_DEVICE));
-        AVS_TRY(avs_set_scalar_field(ctx, AVS_FIELD_FACE_WEIGHTS, a, p->facew[a].p, 0.f, AVS_MEM_DEVICE));
-        AVS_TRY(avs_set_regular_index_field(ctx, a, p->ridx[a].p, AVS_MEM_DEVICE));
+        AVS_TRY(set_scalar_field_lattice(ctx, AVS_FIELD_EDGE_WEIGHTS, a, p->edgew[a].p, 0.f, AVS_MEM_DEVICE, true));
+        AVS_TRY(set_scalar_field_lattice(ctx, AVS_FIELD_FACE_WEIGHTS, a, p->facew[a].p, 0.f, AVS_MEM_DEVICE, true));
+        AVS_TRY(set_regular_index_lattice(ctx, a, p->ridx[a].p, AVS_MEM_DEVICE, true));
     }
     AVS_HIP(hipStreamSynchronize(ctx->stream));
     return AVS_OK;

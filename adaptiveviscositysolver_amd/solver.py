@@ -280,8 +280,8 @@ class ViscositySolve:
         capi.check(self.lib.avs_set_regular_index_field(self.h, axis, p, where))
 
     def transfer_to_regular_grid(self):
-        """Regular MAC-grid velocity (3 fp32 face grids, host) after the solve."""
-        nx, ny, nz = self.res
+        """Regular MAC-grid velocity (3 fp32 face grids of the simulation grid, host) after the solve."""
+        nx, ny, nz = self.field_res
         outs = [np.empty((nz, ny, nx + 1), np.float32), np.empty((nz, ny + 1, nx), np.float32),
                 np.empty((nz + 1, ny, nx), np.float32)]
         capi.check(self.lib.avs_transfer_to_regular_grid(self.h, outs[0].ctypes.data, outs[1].ctypes.data,
@@ -325,11 +325,15 @@ def pcg_csr(row_ptr, col, val, b, x0, tol=1e-3, max_iters=2500, device=0):
 class DevicePrepass:
     """Pre-pass on the GPU (avs_prepass_*): liquid / solid SDF -> weights, label pyramid, index pyramids."""
 
-    def __init__(self, res, dx, levels, n_super=3, extrapolation=0.5, device=0, stream=None):
+    def __init__(self, res, dx, levels, n_super=3, extrapolation=0.5, device=0, stream=None, field_res=None):
+        """`res`: octree (power-of-two) resolution; `field_res`: the simulation grid the SDFs live on when it is smaller
+        (HDK_OctreeGrid::init pads to powers of two, oct.cpp:10-24); None = res."""
         self.lib = capi.load()
         self.res = tuple(int(r) for r in res)
+        fr = tuple(int(r) for r in field_res) if field_res is not None else (0, 0, 0)
+        self.field_res = tuple(fr[a] or self.res[a] for a in range(3))
         d = capi.PrepassDesc(self.res[0], self.res[1], self.res[2], float(dx), int(levels), int(n_super),
-                             float(extrapolation), int(device), C.c_void_p(stream or 0))
+                             float(extrapolation), int(device), C.c_void_p(stream or 0), fr[0], fr[1], fr[2])
         h = C.c_void_p()
         capi.check(self.lib.avs_prepass_create(C.byref(d), C.byref(h)))
         self.h = h

@@ -86,8 +86,8 @@ typedef struct {
      * i.e. before HDK_OctreeGrid::init stretched the octree grid to powers of two (oct.cpp:13-24).  0 = nx, ny, nz.
      * Labels and index pyramids always use nx, ny, nz.  Samples of the padded lattice outside this grid belong to
      * INACTIVE cells (oct.cpp:375-379) and are never read by an active row; the library fills them (viscosity /
-     * density by border replication, everything else with 0).  The optional pre-pass / post-transfer entry points
-     * require field_n* == n*. */
+     * density by border replication, everything else with 0).  The pre-pass takes the same field_n* in its own descriptor;
+     * avs_set_regular_index_field / avs_transfer_to_regular_grid exchange arrays on the simulation grid's face lattices. */
     int32_t field_nx, field_ny, field_nz;
 } avs_desc;
 
@@ -190,9 +190,10 @@ avs_status avs_get_center_stencils(avs_ctx *ctx, int32_t *cnt, int32_t *idx, dou
  * aware; HDK_OctreeVectorFieldInterpolator.cpp:118-845) and applyVelocitiesToRegularGrid
  * (cpp:2815-2894): the regular MAC-grid velocity Houdini reads back.
  * ---------------------------------------------------------------------------------------- */
-/* regularVelocityIndices[axis] (cpp:303-329): >= 0 regular DOF, AVS_SOLIDBOUNDARY, else untouched face */
+/* regularVelocityIndices[axis] (cpp:303-329): >= 0 regular DOF, AVS_SOLIDBOUNDARY, else untouched face; on the face lattice
+ * of the SIMULATION grid (field_n*, + 1 on `axis`) */
 avs_status avs_set_regular_index_field(avs_ctx *ctx, int32_t axis, const int32_t *indices, avs_memspace where);
-/* out_*: face lattices of the base grid; faces that are not regular DOFs keep the input velocity */
+/* out_*: face lattices of the simulation grid (field_n*); faces that are not regular DOFs keep the input velocity */
 avs_status avs_transfer_to_regular_grid(avs_ctx *ctx, float *out_x, float *out_y, float *out_z, avs_memspace where);
 /* interpolator node grids after all passes, (n+1)^3 per level: labels (0 inactive, 1 active), values fp32 */
 avs_status avs_get_node_grid(avs_ctx *ctx, int32_t level, int8_t *labels, float *vx, float *vy, float *vz, avs_memspace where);
@@ -233,6 +234,12 @@ typedef struct {
     double extrapolation_scale; /* getExtrapolation(), cpp:243 (default 0.5) */
     int32_t device;
     void *stream;
+    /* Resolution of the SIMULATION grid the SDFs are given on when it is not a power of two per axis: nx, ny, nz are then the
+     * octree grid HDK_OctreeGrid::init stretches it to (smallest powers of two that contain it, oct.cpp:10-24), cells outside
+     * the simulation grid stay INACTIVE (oct.cpp:375-379).  0 = nx, ny, nz.  The SDFs are read with clamped coordinates outside
+     * their grid (SIM_RawField border behaviour); the liquid must not touch the border of the simulation grid.  All getters
+     * below return arrays on the (padded) octree lattices. */
+    int32_t field_nx, field_ny, field_nz;
 } avs_prepass_desc;
 typedef struct {
     int32_t levels;                       /* after capping, HDK_OctreeGrid.cpp:198-211; 0 = no liquid */

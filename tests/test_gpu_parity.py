@@ -278,9 +278,6 @@ def test_fields_on_a_smaller_simulation_grid(dev, built_lib):
     xo, oi = o.solve(1e-10, 4000)
     assert info.converged == 1 and abs(info.iterations - oi.iterations) <= 2
     assert rel_l2(s.solution(), xo) < 1e-8
-    # the post-solve transfer is defined on the padded grid only
-    with pytest.raises(capi.AvsError):
-        s.transfer_to_regular_grid()
     s.close()
     with pytest.raises(capi.AvsError):                  # a simulation grid larger than the octree grid is rejected
         ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0, field_res=(65, 64, 64))

@@ -95,3 +95,68 @@ def test_transfer_full_size_properties(built_lib):
         assert np.isfinite(out[a]).all()
         sel = ri >= 0
         assert out[a][sel].min() >= x.min() - 1e-3 and out[a][sel].max() <= x.max() + 1e-3
+
+
+def test_non_power_of_two_simulation_grid(built_lib):
+    """A 48 x 40 x 24 simulation grid (what a real Houdini frame looks like): HDK_OctreeGrid::init stretches the octree grid
+    to 64^3 (oct.cpp:10-24) and keeps every cell outside the simulation grid INACTIVE (oct.cpp:375-379).  The device pre-pass
+    takes the SDF on the simulation grid, the solve context the scalar fields, the transfer returns the simulation grid's
+    faces.  Reference: the oracle on the 64^3 lattice with analytic fields (nothing outside the 48 x 40 x 24 box may
+    matter): pyramid, regular-grid classification, CSR, rhs bit-exact; transfer bit-exact from the same solution vector."""
+    n, fres = 64, (48, 40, 24)
+    dx = 1.0 / n
+    liquid = scenes.box_sdf((n, n, n), dx, center=(24 * dx, 20 * dx, 12 * dx), half=(17 * dx, 13 * dx, 6.5 * dx))
+    xs = (torch.arange(n, dtype=torch.float64) + 0.5) * dx
+    visc = (150.0 * (1.0 + 5.0 * xs))[None, None, :].expand(n, n, n).to(torch.float32).contiguous()
+    sc = scenes.Scene(res=(n, n, n), dx=dx, dt=1.0 / 60.0, levels=3, liquid=liquid, viscosity=visc, density=900.0,
+                      velocity=scenes.smooth_velocity((n, n, n), dx, gravity_dt=0.1), name="corner_box")
+    o = oracle_for_scene(sc)
+    o.prepass()
+    o.build_regular_indices()
+    o.hot_path()
+    # device side: everything on the simulation grid
+    crop = lambda t, add=(0, 0, 0): t[:fres[2] + add[2], :fres[1] + add[1], :fres[0] + add[0]].contiguous()
+    pp = DevicePrepass((n, n, n), dx, 3, field_res=fres)
+    info = pp.run(crop(liquid).cuda(), None)
+    assert info.levels == o.levels and (info.n_velocity, info.n_edge, info.n_center) == (o.count(0), o.count(1), o.count(2))
+    assert info.n_regular == o.regular_count
+    for l in range(o.levels):
+        assert np.array_equal(pp.labels(l), o.labels(l)), l
+        for a in range(3):
+            assert np.array_equal(pp.index(capi.INDEX_VELOCITY, l, a), o.index(O.I_VELOCITY, l, a)), (l, a)
+            assert np.array_equal(pp.index(capi.INDEX_EDGE, l, a), o.index(O.I_EDGE, l, a)), (l, a)
+        assert np.array_equal(pp.index(capi.INDEX_CENTER, l), o.index(O.I_CENTER, l)), l
+    for a in range(3):
+        assert np.array_equal(pp.regular_index(a), o.regular_index(a)), a
+    s = ViscositySolve((n, n, n), dx, sc.dt, info.levels, device=0, field_res=fres)
+    pp.apply(s)
+    s.set_field(capi.FIELD_VISCOSITY, 0, crop(visc).cuda())
+    s.set_field(capi.FIELD_DENSITY, 0, None, 900.0)
+    for a in range(3):
+        add = tuple(1 if b == a else 0 for b in range(3))
+        s.set_field(capi.FIELD_VELOCITY, a, crop(sc.velocity[a], add).cuda())
+        s.set_field(capi.FIELD_SOLID_VELOCITY, a, None, 0.0)
+    s.assemble()
+    rp, col, val, rhs = s.csr()
+    A = o.csr()
+    assert np.array_equal(rp, A.row_ptr) and np.array_equal(col, A.col)
+    assert np.array_equal(val, A.val) and np.array_equal(rhs, A.rhs)
+    assert np.array_equal(s.initial_guess(), o.initial_guess())
+    sinfo = s.solve(1e-10, 4000)
+    xo, io = o.solve(1e-10, 4000)
+    assert sinfo.converged == 1 and abs(sinfo.iterations - io.iterations) <= 2
+    x = s.solution()
+    assert rel_l2(x, xo) < 1e-8
+    out = s.transfer_to_regular_grid()                       # host arrays on the simulation grid's face lattices
+    want = o.transfer_to_regular_grid(x)                     # oracle: 64^3 lattices, same solution vector
+    for a in range(3):
+        add = tuple(1 if b == a else 0 for b in range(3))
+        assert out[a].shape == (fres[2] + add[2], fres[1] + add[1], fres[0] + add[0])
+        assert np.array_equal(out[a], want[a][:fres[2] + add[2], :fres[1] + add[1], :fres[0] + add[0]]), a
+    # device destination: cropped on the device
+    outs = [torch.empty(o_.shape, dtype=torch.float32, device="cuda") for o_ in out]
+    capi.check(s.lib.avs_transfer_to_regular_grid(s.h, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), capi.MEM_DEVICE))
+    for a in range(3):
+        assert np.array_equal(outs[a].cpu().numpy(), out[a])
+    s.close()
+    pp.close()
