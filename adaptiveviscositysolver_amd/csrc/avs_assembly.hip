@@ -944,13 +944,13 @@ avs_status assemble_rows(avs_ctx *c, const int32_t *ids, int64_t m, DevBuf<int32
                 "build the stencils and the initial guess first");
     const int64_t n = m;
     AVS_REQUIRE(c->n_vel < (int64_t)INT32_MAX, AVS_EINVAL, "too many DOFs for int32 columns");
-    DevBuf<int32_t> row_count, rawptr, scan_tmp, raw_col;
-    DevBuf<double> raw_val;
-    DevBuf<int> err;
-    AVS_TRY(row_count.alloc((size_t)n + 1));
-    AVS_TRY(rawptr.alloc((size_t)n + 1));
-    AVS_TRY(scan_tmp.alloc(scan_tmp_elems(n)));
-    AVS_TRY(err.alloc(1));
+    DevBuf<int32_t> &row_count = c->scratch.row_count, &rawptr = c->scratch.rawptr, &scan_tmp = c->scratch.scan_tmp, &raw_col = c->scratch.raw_col;
+    DevBuf<double> &raw_val = c->scratch.raw_val;
+    DevBuf<int> &err = c->scratch.err;
+    AVS_TRY(row_count.reserve((size_t)n + 1));
+    AVS_TRY(rawptr.reserve((size_t)n + 1));
+    AVS_TRY(scan_tmp.reserve(scan_tmp_elems(n)));
+    AVS_TRY(err.reserve(1));
     AVS_TRY(rhs.alloc((size_t)n));
     AVS_TRY(row_ptr.alloc((size_t)n + 1));
     AVS_HIP(hipMemsetAsync(err.p, 0, sizeof(int), st));
@@ -965,8 +965,8 @@ avs_status assemble_rows(avs_ctx *c, const int32_t *ids, int64_t m, DevBuf<int32
     AVS_HIP(hipStreamSynchronize(st));
     AVS_REQUIRE(nraw >= 0, AVS_EINVAL, "raw triplet count exceeds int32 (the scan reports -1 for any total above INT32_MAX)");
     if (nraw_out) *nraw_out = nraw;
-    AVS_TRY(raw_col.alloc((size_t)nraw));
-    AVS_TRY(raw_val.alloc((size_t)nraw));
+    AVS_TRY(raw_col.reserve((size_t)nraw));
+    AVS_TRY(raw_val.reserve((size_t)nraw));
     // K6 emit raw triplets, K6b per-row stable sort + duplicate merge -> unique counts
     if (n) {
         hipLaunchKernelGGL((k_rows<true>), dim3(grid_for(n)), dim3(kBlock), 0, st, P, c->vdof.p, n, E, C, c->x0.p,
@@ -989,7 +989,7 @@ avs_status assemble_rows(avs_ctx *c, const int32_t *ids, int64_t m, DevBuf<int32
     if (n) hipLaunchKernelGGL(k_compact, dim3(8192), dim3(kBlock), 0, st, n, (const int32_t *)rawptr.p, (const int32_t *)row_ptr.p,
                               (const int32_t *)raw_col.p, (const double *)raw_val.p, col.p, val.p);
     AVS_HIP(hipGetLastError());
-    AVS_HIP(hipStreamSynchronize(st)); // raw buffers are freed on return
+    AVS_HIP(hipStreamSynchronize(st)); // the caller may read nnz-sized results right away; the raw buffers stay in the context
     return AVS_OK;
 }
 

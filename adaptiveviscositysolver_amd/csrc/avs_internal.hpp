@@ -88,6 +88,12 @@ struct DevBuf {
         p = nullptr;
         n = 0;
     }
+    // scratch that lives across calls: grows, never shrinks (n stays the capacity)
+    avs_status reserve(size_t count)
+    {
+        if (p && n >= count) return AVS_OK;
+        return alloc(count + count / 16);
+    }
     avs_status alloc(size_t count)
     {
         if (count == n && p) return AVS_OK;
@@ -379,6 +385,16 @@ struct avs_ctx {
     bool reordered = false;
     int brick_shift = 3; // 8^3 fine cells per brick; < 0 disables the renumbering
     avs_assembly_info ainfo{};
+
+    // scratch of the assembly kept between frames (raw triplets: 1.5 GB at 512^3 -- allocating and freeing it every call cost
+    // several ms of host time; with 288 GB of HBM it simply stays)
+    struct AsmScratch {
+        avs::DevBuf<int32_t> row_count, rawptr, scan_tmp, raw_col, len_new, ids_in;
+        avs::DevBuf<double> raw_val;
+        avs::DevBuf<uint32_t> keys_in, keys_out;
+        avs::DevBuf<char> sort_tmp;
+        avs::DevBuf<int> err;
+    } scratch;
 
     avs::PcgWork *pcg = nullptr;
     avs::PcgDist *dist = nullptr;

@@ -78,11 +78,11 @@ avs_status build_brick_permutation(avs_ctx *c, int brick_shift)
 {
     hipStream_t st = c->stream;
     const int64_t n = c->n_vel;
-    DevBuf<uint32_t> keys_in, keys_out;
-    DevBuf<int32_t> ids_in;
-    AVS_TRY(keys_in.alloc((size_t)n));
-    AVS_TRY(keys_out.alloc((size_t)n));
-    AVS_TRY(ids_in.alloc((size_t)n));
+    DevBuf<uint32_t> &keys_in = c->scratch.keys_in, &keys_out = c->scratch.keys_out;
+    DevBuf<int32_t> &ids_in = c->scratch.ids_in;
+    AVS_TRY(keys_in.reserve((size_t)n));
+    AVS_TRY(keys_out.reserve((size_t)n));
+    AVS_TRY(ids_in.reserve((size_t)n));
     AVS_TRY(c->perm.alloc((size_t)n));
     AVS_TRY(c->inv.alloc((size_t)n));
     if (n == 0) return AVS_OK;
@@ -90,13 +90,12 @@ avs_status build_brick_permutation(avs_ctx *c, int brick_shift)
                        brick_shift, keys_in.p, ids_in.p);
     size_t tmp_bytes = 0;
     AVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in.p, keys_out.p, ids_in.p, c->perm.p, (size_t)n, 0, 32, st));
-    DevBuf<char> tmp;
-    AVS_TRY(tmp.alloc(tmp_bytes));
+    DevBuf<char> &tmp = c->scratch.sort_tmp;
+    AVS_TRY(tmp.reserve(tmp_bytes));
     AVS_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_in.p, keys_out.p, ids_in.p, c->perm.p, (size_t)n, 0, 32, st)); // stable
     hipLaunchKernelGGL(k_invert, dim3(grid_for(n)), dim3(kBlock), 0, st, c->perm.p, n, c->inv.p, (const int32_t *)nullptr,
                        (int32_t *)nullptr);
     AVS_HIP(hipGetLastError());
-    AVS_HIP(hipStreamSynchronize(st)); // temporaries die here
     return AVS_OK;
 }
 
@@ -106,9 +105,9 @@ avs_status build_reordered_system(avs_ctx *c, int brick_shift)
     hipStream_t st = c->stream;
     const int64_t n = c->n_vel, nnz = c->nnz;
     AVS_REQUIRE(c->system_ready, AVS_ESTATE, "system not assembled");
-    DevBuf<int32_t> len_new, scan_tmp;
-    AVS_TRY(len_new.alloc((size_t)n + 1));
-    AVS_TRY(scan_tmp.alloc(scan_tmp_elems(n)));
+    DevBuf<int32_t> &len_new = c->scratch.len_new, &scan_tmp = c->scratch.scan_tmp;
+    AVS_TRY(len_new.reserve((size_t)n + 1));
+    AVS_TRY(scan_tmp.reserve(scan_tmp_elems(n)));
     AVS_TRY(build_brick_permutation(c, brick_shift));
     AVS_TRY(c->p_row_ptr.alloc((size_t)n + 1));
     AVS_TRY(c->p_col.alloc((size_t)nnz));
@@ -123,7 +122,6 @@ avs_status build_reordered_system(avs_ctx *c, int brick_shift)
     hipLaunchKernelGGL(k_gather_d, dim3(grid_for(n)), dim3(kBlock), 0, st, c->rhs.p, c->perm.p, c->p_rhs.p, n);
     hipLaunchKernelGGL(k_gather_d, dim3(grid_for(n)), dim3(kBlock), 0, st, c->x0.p, c->perm.p, c->p_x0.p, n);
     AVS_HIP(hipGetLastError());
-    AVS_HIP(hipStreamSynchronize(st)); // temporaries die here
     AVS_TRY(build_matrix_index(c->p_row_ptr.p, c->p_col.p, c->p_val.p, n, nnz, n, c->vi, st));
     c->reordered = true;
     return AVS_OK;
@@ -151,9 +149,16 @@ __device__ __forceinline__ unsigned hash64(unsigned long long k)
 __global__ __launch_bounds__(kBlock) void k_vi_insert(const double *__restrict__ val, int64_t nnz, unsigned long long *__restrict__ slots,
                                                       int *__restrict__ count)
 {
+    // keys this workgroup has already seen (direct-mapped, in LDS): the matrix holds few distinct values, so almost every
+    // look-up ends here instead of in a dependent read of the global table
+    __shared__ unsigned long long seen[1024];
+    for (int i = threadIdx.x; i < 1024; i += kBlock) seen[i] = kEmpty;
+    __syncthreads();
     for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * kBlock) {
         const unsigned long long key = (unsigned long long)__double_as_longlong(val[k]);
         unsigned h = hash64(key);
+        if (seen[h & 1023u] == key) continue;
+        seen[h & 1023u] = key; // it is (about to be) in the global table; a racing overwrite only costs a repeated look-up
         for (int probe = 0; probe < (1 << kHashBits); ++probe) {
             const unsigned long long cur = slots[h]; // hot keys: plain read hit, no atomic
             if (cur == key) break;
