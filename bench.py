@@ -373,7 +373,8 @@ def main():
             try:
                 recs = json.load(open(prof))
                 for rec in (recs if isinstance(recs, list) else [recs]):
-                    if rec.get("n") == n and rec.get("nnz") == nnz and rec.get("bytes_per_nonzero", 12) == bpn:
+                    if (traffic is None and "superseded_by" not in rec and rec.get("n") == n and rec.get("nnz") == nnz and
+                            rec.get("bytes_per_nonzero", 12) == bpn and bool(rec.get("tile_local_tables", False)) == bool(fmt.tile_local_tables)):
                         traffic = rec.get("hbm_bytes_per_launch")
                         traffic_source = ("profiles/spmv_traffic.json <- " + str(rec.get("source", "?")) +
                                           " (PMC passes of an EARLIER run of this workload, not of this process)")
