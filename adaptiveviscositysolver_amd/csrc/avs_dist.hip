@@ -82,6 +82,8 @@ struct PcgDist {
     void *peer_block[kMaxRanks] = {};
     bool peer_ipc[kMaxRanks] = {}; // mapped with hipIpcOpenMemHandle (to be closed)
     DevBuf<DistDev> dd;
+    DevBuf<int32_t> push_seg;
+    int push_grid = 0, push_chunk = 0;
     DevBuf<unsigned long long> epoch;
     DevBuf<unsigned> tickets;
     std::vector<uint8_t> blob;
@@ -300,6 +302,24 @@ static avs_status direct_prepare(avs_ctx *c, PcgDist *d)
     return AVS_OK;
 }
 
+// what I send to q must be what q expects from me (both sides derived their lists independently from the symmetric pattern):
+// a mismatch fails here, with a status, instead of hanging in the first exchange -- whatever the transport
+static avs_status check_exchange_counts(PcgDist *d, const uint8_t *blobs)
+{
+    for (int q = 0; q < d->world; ++q) {
+        if (q == d->rank) continue;
+        DistBlob b;
+        memcpy(&b, blobs + (size_t)q * AVS_DIST_BLOB_BYTES, sizeof(b));
+        if (b.magic != kBlobMagic) continue; // that rank could not prepare a block: nothing to compare with
+        int mine = 0;
+        for (size_t i = 0; i < d->peers.size(); ++i)
+            if (d->peers[i] == q) mine = d->send_counts[i];
+        AVS_REQUIRE(mine == b.recv_cnt_of[d->rank], AVS_EINTERNAL, "rank %d sends %d halo entries to rank %d, which expects %d", d->rank, mine, q,
+                    b.recv_cnt_of[d->rank]);
+    }
+    return AVS_OK;
+}
+
 // maps the peers' blocks and fills the device-side descriptor; `blobs` = world x AVS_DIST_BLOB_BYTES in rank order
 static avs_status direct_connect(avs_ctx *c, PcgDist *d, const uint8_t *blobs)
 {
@@ -310,16 +330,7 @@ static avs_status direct_connect(avs_ctx *c, PcgDist *d, const uint8_t *blobs)
         memcpy(&all[(size_t)q], blobs + (size_t)q * AVS_DIST_BLOB_BYTES, sizeof(DistBlob));
         AVS_REQUIRE(all[(size_t)q].magic == kBlobMagic && all[(size_t)q].rank == q, AVS_EINVAL, "direct transport: blob %d is not rank %d's", q, q);
     }
-    // what I send to q must be what q expects from me -- a mismatch fails here instead of hanging in the first exchange
-    for (int q = 0; q < d->world; ++q) {
-        if (q == d->rank) continue;
-        int mine = 0;
-        for (size_t i = 0; i < d->peers.size(); ++i)
-            if (d->peers[i] == q) mine = d->send_counts[i];
-        AVS_REQUIRE(mine == all[(size_t)q].recv_cnt_of[d->rank], AVS_EINTERNAL,
-                    "direct transport: rank %d sends %d entries to rank %d, which expects %d", d->rank, mine, q,
-                    all[(size_t)q].recv_cnt_of[d->rank]);
-    }
+    AVS_TRY(check_exchange_counts(d, blobs));
     const int32_t my_pid = (int32_t)getpid();
     for (int q = 0; q < d->world; ++q) {
         if (q == d->rank) { d->peer_block[q] = d->comm_block; continue; }
@@ -372,6 +383,32 @@ static avs_status direct_connect(avs_ctx *c, PcgDist *d, const uint8_t *blobs)
         h.all_rflag_dst[q] = &hq->rflag[d->rank];
     }
     h.send_idx = d->send_idx.p;
+    // segments of the send lists per workgroup of the fused update + push kernel (send lists are ascending local row ids)
+    {
+        sr_update_geometry((long long)d->n_own, &d->push_grid, &d->push_chunk);
+        const int G = d->push_grid;
+        std::vector<int32_t> sidx((size_t)d->n_send), seg((size_t)(h.npeers > 0 ? h.npeers : 1) * (size_t)(G + 1), 0);
+        if (d->n_send) AVS_HIP(hipMemcpy(sidx.data(), d->send_idx.p, sidx.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        std::vector<char> has((size_t)G, 0);
+        for (int i = 0; i < h.npeers; ++i) {
+            const int32_t *lo = sidx.data() + h.send_off[i], *hi = sidx.data() + h.send_off[i + 1];
+            for (int b = 0; b <= G; ++b) {
+                const long long first_row = (long long)b * d->push_chunk;
+                const int32_t *it = std::lower_bound(lo, hi, first_row, [](int32_t v, long long key) { return (long long)v < key; });
+                seg[(size_t)i * (G + 1) + b] = (int32_t)(it - sidx.data());
+            }
+            for (int b = 0; b < G; ++b)
+                if (seg[(size_t)i * (G + 1) + b + 1] > seg[(size_t)i * (G + 1) + b]) has[(size_t)b] = 1;
+        }
+        int nblocks = 0;
+        for (int b = 0; b < G; ++b) nblocks += has[(size_t)b];
+        h.n_send_blocks = nblocks;
+        AVS_TRY(d->push_seg.alloc(seg.size()));
+        AVS_HIP(hipMemcpy(d->push_seg.p, seg.data(), seg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        h.push_seg = d->push_seg.p;
+        h.push_grid = G;
+        h.push_chunk = d->push_chunk;
+    }
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->desc.device) != hipSuccess || khz <= 0) {
         (void)hipGetLastError();
@@ -395,6 +432,8 @@ bool dist_direct_args(PcgDist *d, DirectArgs *out)
     out->fin_ticket = d->tickets.p + 1;
     out->n_send = (int)d->n_send;
     out->npeers = (int)d->peers.size();
+    out->push_grid = d->push_grid;
+    out->push_chunk = d->push_chunk;
     out->tiles_int = d->tiles_int.p;
     out->tiles_bnd = d->tiles_bnd.p;
     out->n_tiles_int = d->n_tiles_int;
@@ -413,8 +452,7 @@ static avs_status direct_setup(avs_ctx *c, PcgDist *d)
         AVS_REQUIRE(!off, AVS_EINVAL, "a hosted group has no RCCL communicator: AVS_DIST_TRANSPORT=rccl is impossible");
         return direct_prepare(c, d);
     }
-    if (off) return AVS_OK;
-    avs_status st = direct_prepare(c, d);
+    avs_status st = direct_prepare(c, d); // the blobs also carry the send / receive counts every transport must agree on
     std::vector<uint8_t> all((size_t)d->world * AVS_DIST_BLOB_BYTES, 0);
     int ok = st == AVS_OK ? 1 : 0;
     if (d->world == 1) {
@@ -443,6 +481,11 @@ static avs_status direct_setup(avs_ctx *c, PcgDist *d)
         AVS_HIP(hipMemcpyAsync(all.data(), recv.p, all.size(), hipMemcpyDeviceToHost, c->stream));
         AVS_HIP(hipStreamSynchronize(c->stream));
     } else {
+        return AVS_OK;
+    }
+    if (d->world > 1) AVS_TRY(check_exchange_counts(d, all.data()));
+    if (off) { // RCCL transport requested: the comm block is not needed
+        direct_release(d);
         return AVS_OK;
     }
     // Ranks of ONE process on ONE device (virtual ranks, a test set-up) share that device's few hardware queues: the
@@ -1441,7 +1484,16 @@ avs_status avs_dist_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_i
     A.val = d->val.p;
     d->vi.apply(A);
     avs_solve_info local{};
-    AVS_TRY(pcg_solve(d->pcg, A, d->rhs.p, d->x.p, tol, max_iters, c->stream, &local, d));
+    const avs_status rc = pcg_solve(d->pcg, A, d->rhs.p, d->x.p, tol, max_iters, c->stream, &local, d);
+    if (rc != AVS_OK) {
+        // a peer's flag timed out: epochs / tickets of the comm blocks are no longer in step -- every rank sees the same fault
+        // (it waits for the same peer) and leaves the direct transport for this plan; the next solve uses the fallback
+        if (rc == AVS_ERCCL && d->direct_ready) {
+            (void)hipStreamSynchronize(c->stream);
+            direct_release(d);
+        }
+        return rc;
+    }
     local.n = d->n_global;
     if (info) *info = local;
     d->solved = true;
@@ -1464,7 +1516,7 @@ avs_status avs_dist_get_info(avs_ctx *c, avs_dist_info *info)
     if (d->direct_ready) {
         const char *e = getenv("AVS_PCG_GRAPH");
         info->graph_replay = !(e && atoi(e) == 0);
-        info->launches_per_iteration = d->n_send > 0 ? 4 : 3; // update, push, interior tiles, halo tiles (+ gather + step)
+        info->launches_per_iteration = 3; // update (+ push), interior tiles, halo tiles (+ all-gather + scalar step)
         info->collectives_per_iteration = 0;
         return AVS_OK;
     }

@@ -290,13 +290,20 @@ struct DistDev {                                  // device-resident, read-only 
     unsigned long long *all_rflag_dst[kMaxRanks]; // &rank q's rflag[my rank]
     const int32_t *send_idx;
     long long timeout_ticks;                      // wall_clock64() ticks a flag wait may take before it reports a fault
+    // fused update + push (k_sr_update_push): workgroup b of push_grid owns rows [b push_chunk, (b+1) push_chunk); the entries
+    // of peer i's send list inside that range are push_seg[i (push_grid + 1) + b .. + b + 1)
+    const int32_t *push_seg;
+    int push_grid, push_chunk;
 };
+// row ranges of the fused vector kernel: grid and rows per workgroup (a multiple of the block size) for n rows
+void sr_update_geometry(long long n, int *grid, int *chunk);
 
 struct DirectArgs {                               // what pcg_solve_direct needs from the plan
     const DistDev *dd = nullptr;                  // device pointer
     unsigned long long *epoch = nullptr;          // device: completed rounds of this comm block
     unsigned *push_ticket = nullptr, *fin_ticket = nullptr;
     int n_send = 0, npeers = 0;
+    int push_grid = 0, push_chunk = 0; // > 0: the DistDev carries push segments (fused update + push available)
     const int32_t *tiles_int = nullptr, *tiles_bnd = nullptr;
     int n_tiles_int = 0, n_tiles_bnd = 0;
 };

@@ -1537,12 +1537,85 @@ static avs_status pcg_solve_single_reduction(PcgWork *w, const CsrView &A, const
 
 // ---------------------------------------------------------------------------------------------
 // Direct-transport loop (world >= 1): the single-reduction iteration above with NO RCCL call and no host work inside:
-//   k_sr_update   p, s, x, r, u + partials of r.u, |r|^2
-//   k_push        boundary entries of u -> the peers' halo areas, then the epoch flag (last block)
+//   k_sr_update_push  p, s, x, r, u + partials of r.u, |r|^2; then the boundary entries of u -> the peers' halo areas and the
+//                     epoch flag (last pushing block).  (k_push does the same for the two set-up rounds.)
 //   SpMV interior tiles (run while the peers' entries travel)
 //   SpMV halo-touching tiles: wait for the flags, multiply, last workgroup: all-gather of the 3 sums + scalar step
-// = 4 launches per iteration, replayed from one hipGraph per chunk of kChunk iterations.
+// = 3 launches per iteration, replayed from one hipGraph per chunk of kChunk iterations.
 // ---------------------------------------------------------------------------------------------
+void sr_update_geometry(long long n, int *grid, int *chunk)
+{
+    long long g = (n + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if (g > kVecGrid) g = kVecGrid;
+    long long c = (n + g - 1) / g;
+    c = (c + kBlock - 1) / kBlock * kBlock;
+    if (c < kBlock) c = kBlock;
+    *chunk = (int)c;
+    *grid = (int)((n + c - 1) / c > 0 ? (n + c - 1) / c : 1);
+}
+
+// k_sr_update + k_push in one launch: workgroup b owns a CONTIGUOUS range of rows, updates them, and then stores those of its
+// new u entries that a peer reads straight into that peer's halo area; the last pushing workgroup raises the flags.
+__global__ __launch_bounds__(kBlock) void k_sr_update_push(int64_t n, double *__restrict__ x, double *__restrict__ r, double *__restrict__ p,
+                                                           double *__restrict__ s, double *__restrict__ u, const double *__restrict__ w,
+                                                           const double *__restrict__ invd, const PcgScalars *sc, double *__restrict__ partial,
+                                                           const DistDev *__restrict__ dd, const unsigned long long *__restrict__ epoch,
+                                                           unsigned *__restrict__ ticket)
+{
+    const int done = sc->done;
+    const int64_t lo = (int64_t)blockIdx.x * dd->push_chunk;
+    const int64_t hi = (lo + dd->push_chunk < n) ? lo + dd->push_chunk : n;
+    if (done == 3) {
+        for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) x[i] = 0.;
+        return;
+    }
+    if (done) return;
+    const double alpha = sc->alpha, beta = sc->beta;
+    __shared__ double red[4];
+    double ru = 0., rr = 0.;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+        const double pi = u[i] + beta * p[i];
+        const double si = w[i] + beta * s[i];
+        p[i] = pi;
+        s[i] = si;
+        x[i] += alpha * pi;
+        const double ri = r[i] - alpha * si;
+        r[i] = ri;
+        const double ui = invd[i] * ri;
+        u[i] = ui;
+        ru += ri * ui;
+        rr += ri * ri;
+    }
+    ru = block_sum(ru, red); // (barriers inside: every u of this range is written before the push below reads it)
+    rr = block_sum(rr, red);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = ru;
+        partial[gridDim.x + blockIdx.x] = rr;
+    }
+    const int np = dd->npeers, G = (int)gridDim.x, b = (int)blockIdx.x;
+    bool any = false;
+    for (int i = 0; i < np; ++i) {
+        const int a = dd->push_seg[i * (G + 1) + b], e = dd->push_seg[i * (G + 1) + b + 1];
+        double *dst = dd->peer_halo_dst[i] - dd->send_off[i];
+        for (int j = a + (int)threadIdx.x; j < e; j += kBlock)
+            __hip_atomic_store(dst + j, u[dd->send_idx[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        any = any || e > a;
+    }
+    if (!any) return; // block-uniform
+    wait_own_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == (unsigned)dd->n_send_blocks - 1u) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long E = *epoch + 1ull;
+            for (int i = 0; i < np; ++i)
+                if (dd->send_off[i + 1] > dd->send_off[i]) st_sys(dd->peer_hflag_dst[i], E);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_push(const DistDev *__restrict__ dd, const double *__restrict__ v,
                                               const unsigned long long *__restrict__ epoch, unsigned *__restrict__ ticket,
                                               const PcgScalars *sc)
@@ -1577,7 +1650,9 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
                                    hipStream_t stream, avs_solve_info *info, const DirectArgs &da)
 {
     const int64_t n = A.n;
-    const int g = (int)((n + kBlock - 1) / kBlock < kVecGrid ? ((n + kBlock - 1) / kBlock > 0 ? (n + kBlock - 1) / kBlock : 1) : kVecGrid);
+    int g = 1, chunk_rows = kBlock; // every vector kernel of this loop uses the fused kernel's geometry (same partial layout)
+    sr_update_geometry((long long)n, &g, &chunk_rows);
+    AVS_REQUIRE(g == da.push_grid && chunk_rows == da.push_chunk, AVS_EINTERNAL, "push segments were built for another geometry");
     const int rowgrid = (int)((n + kBlock - 1) / kBlock) > 0 ? (int)((n + kBlock - 1) / kBlock) : 1;
     AVS_TRY(w->s.alloc((size_t)n));
     AVS_TRY(w->u.alloc((size_t)w->n_ext));
@@ -1601,8 +1676,8 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
     AVS_HIP(hipEventRecord(w->ev0, stream));
 
     // one round: exchange `vec`, wv = A vec (+ partials of vec.wv), fold `nred_vec` vector partial arrays + that one, step `op`
-    auto round = [&](const double *vec, int nred_vec, int op, hipEvent_t ea, hipEvent_t eb) -> avs_status {
-        if (push_blocks) hipLaunchKernelGGL(k_push, dim3(push_blocks), dim3(256), 0, stream, da.dd, vec, (const unsigned long long *)da.epoch,
+    auto round = [&](const double *vec, int nred_vec, int op, hipEvent_t ea, hipEvent_t eb, bool push = true) -> avs_status {
+        if (push && push_blocks) hipLaunchKernelGGL(k_push, dim3(push_blocks), dim3(256), 0, stream, da.dd, vec, (const unsigned long long *)da.epoch,
                                             da.push_ticket, (const PcgScalars *)sc);
         if (ea) AVS_HIP(hipEventRecord(ea, stream));
         AVS_TRY(spmv_dot_tiles(A, vec, wv, pspmv, sc, da.tiles_int, da.n_tiles_int, stream));
@@ -1635,8 +1710,10 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
     AVS_HIP(hipGetLastError());
 
     auto enqueue_iteration = [&](int c, bool timed) -> avs_status {
-        hipLaunchKernelGGL(k_sr_update, dim3(g), dim3(kBlock), 0, stream, n, x, r, p, sv, u, wv, invd, (const PcgScalars *)sc, sc, 0, pvec);
-        return round(u, 2, (int)OP_SR_STEP, timed ? w->evA[c] : nullptr, timed ? w->evB[c] : nullptr);
+        // update and push in one launch (3 launches per iteration)
+        hipLaunchKernelGGL(k_sr_update_push, dim3(g), dim3(kBlock), 0, stream, n, x, r, p, sv, u, wv, invd, (const PcgScalars *)sc, pvec, da.dd,
+                           (const unsigned long long *)da.epoch, da.push_ticket);
+        return round(u, 2, (int)OP_SR_STEP, timed ? w->evA[c] : nullptr, timed ? w->evB[c] : nullptr, false);
     };
     bool use_graph = true;
     if (const char *e = getenv("AVS_PCG_GRAPH")) use_graph = atoi(e) != 0;
