@@ -1269,10 +1269,63 @@ avs_status avs_dist_export_blob(avs_ctx *c, uint8_t blob[AVS_DIST_BLOB_BYTES])
     return AVS_OK;
 }
 
+// Measurement aid (tools/loopback_scaling.py): ONE rank of a world-size-W partition runs alone on one GPU with its peers
+// looped back onto itself -- it pushes its boundary entries (into a scratch area of its own block), raises the flags its peers
+// would raise, and all-gathers with itself.  Its halo values stay 0, so it solves a different (still SPD) system; what is
+// representative is the TIME of an iteration of that rank's slab: real update + push + interior / halo-touching tiles +
+// finalisation with W contributions, minus the xGMI latency.  Never used by a solve that is meant to be right.
+static avs_status direct_connect_loopback(avs_ctx *c, PcgDist *d)
+{
+    AVS_REQUIRE(d->direct_prepared, AVS_ESTATE, "no comm block (assemble / partition first)");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    // re-allocate the block with a scratch tail for the pushes
+    const size_t bytes = kHeaderBytes + (size_t)((d->n_halo > 0 ? d->n_halo : 1) + (d->n_send > 0 ? d->n_send : 1)) * sizeof(double);
+    if (d->comm_block) (void)hipFree(d->comm_block);
+    d->comm_block = nullptr;
+    void *p = nullptr;
+    AVS_HIP(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained));
+    AVS_HIP(hipMemset(p, 0, bytes));
+    d->comm_block = p;
+    d->comm_bytes = bytes;
+    std::vector<uint8_t> blobs((size_t)d->world * AVS_DIST_BLOB_BYTES, 0);
+    for (int q = 0; q < d->world; ++q) { // every "peer" is me
+        DistBlob b;
+        memcpy(&b, d->blob.data(), sizeof(b));
+        b.rank = q;
+        b.raw_ptr = (uint64_t)(uintptr_t)p;
+        b.bytes = bytes;
+        for (int k = 0; k < kMaxRanks; ++k) { b.recv_off_of[k] = -1; b.recv_cnt_of[k] = 0; }
+        for (size_t i = 0; i < d->peers.size(); ++i)
+            if (d->peers[i] == q) { // what I send to q lands in the scratch tail, at my send offset
+                b.recv_off_of[d->rank] = (int32_t)(d->n_halo + d->send_offs[i]);
+                b.recv_cnt_of[d->rank] = d->send_counts[i];
+            }
+        memcpy(blobs.data() + (size_t)q * AVS_DIST_BLOB_BYTES, &b, sizeof(b));
+    }
+    AVS_TRY(direct_connect(c, d, blobs.data()));
+    // the flags my peers would raise are raised by my own push / finalisation
+    DistDev h;
+    AVS_HIP(hipMemcpy(&h, d->dd.p, sizeof(h), hipMemcpyDeviceToHost));
+    CommHeader *mine = (CommHeader *)d->comm_block;
+    for (int i = 0; i < h.npeers; ++i) h.peer_hflag_dst[i] = &mine->hflag[h.peer_rank[i]];
+    for (int q = 0; q < d->world; ++q) {
+        h.all_red_dst[q] = &mine->red[0][d->rank][0];
+        h.all_rflag_dst[q] = &mine->rflag[q];
+    }
+    // a peer that only sends to me (no entry from me to it) would never get its flag raised: give every receive a sender
+    for (int i = 0; i < h.npeers; ++i)
+        AVS_REQUIRE(h.recv_cnt[i] == 0 || h.send_off[i + 1] > h.send_off[i], AVS_EINTERNAL, "loopback: peer %d sends but does not receive", h.peer_rank[i]);
+    AVS_HIP(hipMemcpy(d->dd.p, &h, sizeof(h), hipMemcpyHostToDevice));
+    return AVS_OK;
+}
+
 avs_status avs_dist_import_blobs(avs_ctx *c, const uint8_t *blobs)
 {
-    AVS_REQUIRE(c && blobs, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->dist, AVS_ESTATE, "call avs_dist_init_hosted first");
+    if (const char *e = getenv("AVS_DIST_LOOPBACK"))
+        if (atoi(e) != 0) return direct_connect_loopback(c, c->dist);
+    AVS_REQUIRE(blobs, AVS_EINVAL, "null argument");
     return direct_connect(c, c->dist, blobs);
 }
 
