@@ -83,6 +83,7 @@ struct PcgDist {
     bool peer_ipc[kMaxRanks] = {}; // mapped with hipIpcOpenMemHandle (to be closed)
     DevBuf<DistDev> dd;
     DevBuf<int32_t> push_seg;
+    DevBuf<uint8_t> tile_flags;
     int push_grid = 0, push_chunk = 0;
     DevBuf<unsigned long long> epoch;
     DevBuf<unsigned> tickets;
@@ -409,6 +410,15 @@ static avs_status direct_connect(avs_ctx *c, PcgDist *d, const uint8_t *blobs)
         h.push_grid = G;
         h.push_chunk = d->push_chunk;
     }
+    { // per-tile flag: does the tile read halo columns? (from the plan's list of such tiles)
+        const int nt = d->n_tiles_int + d->n_tiles_bnd;
+        std::vector<uint8_t> f((size_t)(nt > 0 ? nt : 1), 0);
+        std::vector<int32_t> tb((size_t)d->n_tiles_bnd);
+        if (d->n_tiles_bnd) AVS_HIP(hipMemcpy(tb.data(), d->tiles_bnd.p, tb.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int32_t t : tb) f[(size_t)t] = 1;
+        AVS_TRY(d->tile_flags.alloc(f.size()));
+        AVS_HIP(hipMemcpy(d->tile_flags.p, f.data(), f.size(), hipMemcpyHostToDevice));
+    }
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->desc.device) != hipSuccess || khz <= 0) {
         (void)hipGetLastError();
@@ -438,6 +448,7 @@ bool dist_direct_args(PcgDist *d, DirectArgs *out)
     out->tiles_bnd = d->tiles_bnd.p;
     out->n_tiles_int = d->n_tiles_int;
     out->n_tiles_bnd = d->n_tiles_bnd;
+    out->tile_flags = d->tile_flags.p;
     return true;
 }
 
@@ -1654,7 +1665,7 @@ avs_status avs_dist_get_info(avs_ctx *c, avs_dist_info *info)
     if (d->direct_ready) {
         const char *e = getenv("AVS_PCG_GRAPH");
         info->graph_replay = !(e && atoi(e) == 0);
-        info->launches_per_iteration = 3; // update (+ push), interior tiles, halo tiles (+ all-gather + scalar step)
+        info->launches_per_iteration = 2; // update (+ push), SpMV over all tiles (+ all-gather + scalar step in its finalizer block)
         info->collectives_per_iteration = 0;
         return AVS_OK;
     }

@@ -306,6 +306,7 @@ struct DirectArgs {                               // what pcg_solve_direct needs
     int push_grid = 0, push_chunk = 0; // > 0: the DistDev carries push segments (fused update + push available)
     const int32_t *tiles_int = nullptr, *tiles_bnd = nullptr;
     int n_tiles_int = 0, n_tiles_bnd = 0;
+    const uint8_t *tile_flags = nullptr; // per tile: 1 = reads halo columns
 };
 bool dist_direct_args(PcgDist *d, DirectArgs *out); // false: the direct transport is not connected
 

@@ -46,20 +46,22 @@ struct PcgScalars {
 // direct transport helpers (DistDev / CommHeader: avs_internal.hpp).  Flags and everything a peer writes are accessed
 // with system-scope atomics / fences: the other end is another GPU (xGMI) or another process.
 // ---------------------------------------------------------------------------------------------
-struct HaloView {                        // by-value argument of the halo-touching SpMV launch
+struct HaloView {                        // by-value argument of the SpMV launch of the direct transport (all tiles + nfin finalizer blocks)
     const DistDev *dd = nullptr;
     const unsigned long long *epoch = nullptr; // completed rounds; this round's flags carry *epoch + 1
     unsigned long long *epoch_w = nullptr;
-    unsigned *fin_ticket = nullptr;
-    PcgScalars *sc = nullptr;            // writable: the last workgroup applies the scalar step
+    unsigned *fin_ticket = nullptr;      // finalizer blocks that have folded their share
+    PcgScalars *sc = nullptr;            // writable: the last finalizer applies the scalar step
     const double *pvec = nullptr;        // partial sums of the preceding vector kernel: nred_vec arrays of g
-    const double *pspmv = nullptr;       // this SpMV's partial sums, ppt per tile (interior launch included)
-    double *stage = nullptr;             // 2 x gridDim.x: per-workgroup sums of (a share of the interior tiles, its own tile)
-    const int32_t *tiles_int = nullptr;  // interior tile list (their partials are complete when this launch starts)
-    int n_int = 0, ppt = 1;
-    int g = 0, nred_vec = 0, op = 0, n_bnd = 0;
+    double *stage = nullptr;             // ntiles * ppt slots: x.Ax partial of every wave / tile, armed with kSentinel between rounds
+    double *stage2 = nullptr;            // nfin: the finalizer blocks' folded shares
+    const uint8_t *tile_bnd = nullptr;   // per tile: 1 = its rows read halo columns (wait for the peers' flags first)
+    int ntiles = 0, ppt = 1, nfin = 1;   // workgroups ntiles .. ntiles + nfin - 1 of the launch are the finalizers
+    int g = 0, nred_vec = 0, op = 0;
     double tol = 0.;
 };
+constexpr unsigned long long kSentinel = 0xFFFFFFFFFFFFFFFFull; // an all-ones NaN: never a partial sum
+constexpr int kFinShare = 16384;         // stage slots one finalizer block watches and folds
 
 // Synchronisation recipe (no L2 write-back fences: a release fence at agent / system scope flushes every dirty line of the
 // XCD's L2 -- the vectors just written -- and measured 15 us per round):
@@ -188,34 +190,46 @@ __device__ __forceinline__ double block_fold(double v, double *lds) // fixed ord
     return t;
 }
 
+// per-thread shares of the preceding vector kernel's partial arrays (plain loads: written by the previous launch)
 template <int BLK>
-__device__ void dist_finalize(const HaloView &hv)
+__device__ __forceinline__ void fold_vec_partials(const HaloView &hv, double acc[4])
 {
-    __shared__ double fin_red[BLK / 64];
+    for (int q = 0; q < hv.nred_vec; ++q) {
+        const double *src = hv.pvec + (size_t)q * hv.g;
+        double s0 = 0., s1 = 0.;
+        int i = threadIdx.x;
+        for (; i + BLK < hv.g; i += 2 * BLK) {
+            const double a = src[i], b = src[i + BLK];
+            s0 += a; s1 += b;
+        }
+        for (; i < hv.g; i += BLK) s0 += src[i];
+        acc[q] = s0 + s1;
+    }
+}
+
+// acc[0 .. nred_vec) = this thread's share of the vector partials, acc[nred_vec] = its share of the SpMV's x.Ax
+template <int BLK>
+__device__ void dist_finalize(const HaloView &hv, double acc[4])
+{
+    __shared__ double fin_red[4][BLK / 64];
     __shared__ double fin_sum[4];
+    __shared__ double fin_all[kMaxRanks * 4];
     const DistDev *dd = hv.dd;
     const int tid = threadIdx.x;
     const int nred = hv.nred_vec + 1;
-    for (int q = 0; q < nred; ++q) {
-        const bool vec = q < hv.nred_vec;
-        const int nb = vec ? hv.g : 2 * (int)gridDim.x; // the SpMV's sum: the per-workgroup stage values, in index order
-        const double *src = vec ? hv.pvec + (size_t)q * hv.g : hv.stage;
-        double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
-        int i = tid;
-        if (vec) { // written by the previous kernel
-            for (; i + 3 * BLK < nb; i += 4 * BLK) {
-                const double a = src[i], b = src[i + BLK], c = src[i + 2 * BLK], d = src[i + 3 * BLK];
-                s0 += a; s1 += b; s2 += c; s3 += d;
-            }
-            for (; i < nb; i += BLK) s0 += src[i];
-        } else { // written by workgroups of THIS launch on other XCDs: agent-scope atomic loads (cache-bypassing)
-            for (; i < nb; i += BLK) s0 += __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        const double t = block_fold<BLK>((s0 + s1) + (s2 + s3), fin_red);
-        if (tid == 0) fin_sum[q] = t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = wave_sum(acc[q]);
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fin_red[q][tid >> 6] = acc[q];
     }
-    if (tid == 0)
-        for (int q = nred; q < 4; ++q) fin_sum[q] = 0.;
+    __syncthreads();
+    if (tid < 4) { // fixed order: waves ascending
+        double t = 0.;
+#pragma unroll
+        for (int w = 0; w < BLK / 64; ++w) t += fin_red[tid][w];
+        fin_sum[tid] = tid < nred ? t : 0.;
+    }
     __syncthreads();
     const unsigned long long E = *hv.epoch + 1ull;
     const int par = (int)(E & 1ull);
@@ -232,10 +246,12 @@ __device__ void dist_finalize(const HaloView &hv)
         wait_flag(&dd->mine->rflag[tid], E, dd->timeout_ticks, hv.sc, 2);
     }
     __syncthreads();
+    if (tid < dd->world * 4) fin_all[tid] = ld_sys_f64(&dd->mine->red[par][tid >> 2][tid & 3]); // all contributions in parallel
+    __syncthreads();
     if (tid == 0) {
         for (int k = 0; k < nred; ++k) {
             double t = 0.;
-            for (int q = 0; q < dd->world; ++q) t += ld_sys_f64(&dd->mine->red[par][q][k]);
+            for (int q = 0; q < dd->world; ++q) t += fin_all[q * 4 + k]; // rank order: identical on every rank
             hv.sc->red[k] = t;
         }
         if (hv.op != 0) apply_scalar_op(hv.sc, hv.op, hv.tol);
@@ -244,48 +260,79 @@ __device__ void dist_finalize(const HaloView &hv)
     }
 }
 
-// ticket at the end of every workgroup of the halo-touching launch; the last one to arrive finalizes the round
-// `tile` < 0: a workgroup without a tile (it only helps folding the interior partials)
+// Finalizer block f of the SpMV launch (dispatched behind the tiles).  The tiles' waves drop their x.Ax partials into the stage
+// slots with fire-and-forget write-through stores -- no barrier, no ticket, nothing at the end of a tile's life.  A finalizer
+// watches its share of the slots until none holds the sentinel any more, folds the share in slot order, re-arms the slots for
+// the next round and takes a ticket; the last finalizer to arrive runs dist_finalize.
 template <int BLK>
-__device__ __forceinline__ void halo_epilogue(const HaloView &hv, int64_t tile)
+__device__ void halo_finalizer(const HaloView &hv, int f)
 {
-    __shared__ int fin_last;
-    __shared__ double stage_red[BLK / 64];
-    // every workgroup folds a fixed share of the INTERIOR tiles' partial sums (complete: that launch has finished) and its own
-    // tile's; the last workgroup then adds the 2 x gridDim.x stage values in index order -- deterministic, and no single
-    // workgroup walks 10^5 partials
-    {
-        const int B = (int)gridDim.x, b = (int)blockIdx.x;
-        const int total = hv.n_int * hv.ppt;            // the interior launch left them contiguous, in launch order
-        const int share = (total + B - 1) / B;
-        const int lo = b * share, hi = (lo + share < total) ? lo + share : total;
-        double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
-        int i = lo + (int)threadIdx.x;
-        for (; i + 3 * BLK < hi; i += 4 * BLK) {
-            const double a = hv.pspmv[i], b2 = hv.pspmv[i + BLK], c = hv.pspmv[i + 2 * BLK], d = hv.pspmv[i + 3 * BLK];
-            s0 += a; s1 += b2; s2 += c; s3 += d;
+    __shared__ double share_red[BLK / 64];
+    __shared__ int fin_is_last;
+    const int tid = threadIdx.x;
+    const int total = hv.ntiles * hv.ppt;
+    const int lo = f * kFinShare, hi = (lo + kFinShare < total) ? lo + kFinShare : total;
+    double acc[4] = {0., 0., 0., 0.};
+    if (hv.nfin == 1) fold_vec_partials<BLK>(hv, acc); // ready since the previous launch: folded while the tiles still run
+    // one pass checks and folds: lane-strided slots, 8 loads in flight per thread, fixed order => the sum is valid as soon as a pass
+    // meets no sentinel.  The last tiles dispatched are usually the last to finish: peek at the final slot before scanning.
+    const long long t0 = wall_clock64();
+    const unsigned long long *slots = reinterpret_cast<const unsigned long long *>(hv.stage);
+    double sum = 0.;
+    bool timed_out = false;
+    while (hi > lo) {
+        // (block-uniform decisions only: thread 0 looks, the barrier broadcasts)
+        const int ready = __syncthreads_or(tid == 0 && __hip_atomic_load(slots + (hi - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kSentinel);
+        if (ready) {
+            int missing = 0;
+            double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+            int i = lo + tid;
+            for (; i + 7 * BLK < hi; i += 8 * BLK) {
+                unsigned long long v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = __hip_atomic_load(slots + i + k * BLK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) missing |= v[k] == kSentinel;
+                a0 += __longlong_as_double((long long)v[0]); a1 += __longlong_as_double((long long)v[1]);
+                a2 += __longlong_as_double((long long)v[2]); a3 += __longlong_as_double((long long)v[3]);
+                a0 += __longlong_as_double((long long)v[4]); a1 += __longlong_as_double((long long)v[5]);
+                a2 += __longlong_as_double((long long)v[6]); a3 += __longlong_as_double((long long)v[7]);
+            }
+            for (; i < hi; i += BLK) {
+                const unsigned long long v = __hip_atomic_load(slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                missing |= v == kSentinel;
+                a0 += __longlong_as_double((long long)v);
+            }
+            sum = (a0 + a1) + (a2 + a3);
+            if (!__syncthreads_or(missing)) break;
         }
-        for (; i < hi; i += BLK) s0 += hv.pspmv[i];
-        const double t_int = block_fold<BLK>((s0 + s1) + (s2 + s3), stage_red);
-        __syncthreads(); // this workgroup's own partial stores are visible to thread 0 below
-        if (threadIdx.x == 0) {
-            double t_own = 0.;
-            if (tile >= 0)
-                for (int w = 0; w < hv.ppt; ++w) t_own += hv.pspmv[(size_t)total + (size_t)b * hv.ppt + w];
-            // exchanges write through to memory and return only when done: the ticket below cannot overtake them
-            const unsigned long long o1 = __hip_atomic_exchange(reinterpret_cast<unsigned long long *>(hv.stage + b),
-                                                                (unsigned long long)__double_as_longlong(t_int), __ATOMIC_RELAXED,
-                                                                __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long o2 = __hip_atomic_exchange(reinterpret_cast<unsigned long long *>(hv.stage + B + b),
-                                                                (unsigned long long)__double_as_longlong(t_own), __ATOMIC_RELAXED,
-                                                                __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned inc = 1u + (unsigned)((o1 & o2) == 0x7ff8dead7ff8deadull); // data dependency; always 1
-            fin_last = __hip_atomic_fetch_add(hv.fin_ticket, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-        }
+        if (__syncthreads_or(tid == 0 && wall_clock64() - t0 > hv.dd->timeout_ticks)) { timed_out = true; break; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (timed_out && tid == 0) {
+        __hip_atomic_store(&hv.sc->fault, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&hv.sc->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int k = lo + tid; k < hi; k += BLK) // re-arm for the next round (complete before the next launch starts)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(hv.stage) + k, kSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (hv.nfin == 1) { // the usual case of a partitioned solve (<= 2048 tiles per rank): no hand-over between finalizers
+        acc[hv.nred_vec] = sum;
+        dist_finalize<BLK>(hv, acc);
+        return;
+    }
+    const double t = block_fold<BLK>(sum, share_red);
+    if (tid == 0) {
+        __hip_atomic_store(hv.stage2 + f, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wait_own_stores();
+        fin_is_last = __hip_atomic_fetch_add(hv.fin_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)hv.nfin - 1u;
     }
     __syncthreads();
-    if (!fin_last) return;
-    dist_finalize<BLK>(hv);
+    if (!fin_is_last) return;
+    fold_vec_partials<BLK>(hv, acc);
+    double s2 = 0.; // the finalizer blocks' shares (a few dozen at most), lanes ascending
+    for (int i = tid; i < hv.nfin; i += BLK) s2 += __hip_atomic_load(hv.stage2 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    acc[hv.nred_vec] = s2;
+    dist_finalize<BLK>(hv, acc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -377,8 +424,8 @@ __global__ __launch_bounds__(BLK) void k_spmv_tile(CsrView A, const double *__re
     };
     const Gather x{xin, HALO ? hv.dd->my_halo : nullptr, HALO ? (int)hv.dd->n_own : 0};
     if (HALO) {
-        halo_wait(hv);
-        if ((int)blockIdx.x >= hv.n_bnd) { halo_epilogue<BLK>(hv, -1); return; } // extra workgroup: folds partials only
+        if ((int)blockIdx.x >= hv.ntiles) { halo_finalizer<BLK>(hv, (int)blockIdx.x - hv.ntiles); return; }
+        if (hv.tile_bnd[blockIdx.x]) halo_wait(hv); // block-uniform
     }
     int64_t tile = tiles ? (int64_t)tiles[blockIdx.x] : (int64_t)blockIdx.x; // tile lists: interior / halo-touching subsets
     if (XCD) {
@@ -470,10 +517,10 @@ __global__ __launch_bounds__(BLK) void k_spmv_tile(CsrView A, const double *__re
         if (tid == 0) {
             double t = 0.;
             for (int w = 0; w < BLK / 64; ++w) t += red[w];
-            partial[blockIdx.x] = t; // slot = position in the launch (== tile without a tile list)
+            if (!HALO) partial[blockIdx.x] = t; // slot = position in the launch (== tile without a tile list)
+            else __hip_atomic_store(hv.stage + tile, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // fire and forget, see halo_finalizer
         }
     }
-    if (HALO) halo_epilogue<BLK>(hv, tile);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -534,8 +581,8 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
 {
     if (DOT && sc && sc->done) return;
     if (HALO) {
-        halo_wait(hv);
-        if ((int)blockIdx.x >= hv.n_bnd) { halo_epilogue<BLK>(hv, -1); return; } // extra workgroup: folds partials only
+        if ((int)blockIdx.x >= hv.ntiles) { halo_finalizer<BLK>(hv, (int)blockIdx.x - hv.ntiles); return; }
+        if (hv.tile_bnd[blockIdx.x]) halo_wait(hv); // block-uniform
     }
     const double *__restrict__ hx = HALO ? hv.dd->my_halo : nullptr;
     const int n_own_cols = HALO ? (int)hv.dd->n_own : 0;
@@ -702,10 +749,13 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
         // (Measured: parking the terms in LDS and letting the last-arriving wave fold them cost 9-10 us per launch, two
         // dependent LDS round trips at the end of every wave's life while the LDS pipe is busy; a block barrier 15 us.)
         const double d = wave_sum_dpp((row < A.n) ? sum * xr : 0.);
-        if ((tid & 63) == 63) partial[(int64_t)blockIdx.x * (BLK / 64) + (tid >> 6)] = d; // slot = position in the launch
+        if ((tid & 63) == 63) {
+            if (!HALO) partial[(int64_t)blockIdx.x * (BLK / 64) + (tid >> 6)] = d; // slot = position in the launch
+            else // direct transport: write-through, fire and forget -- a finalizer block watches the slot (halo_finalizer)
+                __hip_atomic_store(hv.stage + tile * (BLK / 64) + (tid >> 6), d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (row < A.n) __builtin_nontemporal_store(sum, y + row);
-    if (HALO) halo_epilogue<BLK>(hv, tile);
 }
 
 static constexpr int kViLdsTable = 2048; // dictionary entries staged in LDS (16 KiB)
@@ -955,8 +1005,8 @@ avs_status spmv_dot_tiles(const CsrView &A, const double *x, double *y, double *
     return AVS_OK;
 }
 
-// halo-touching tiles of the direct transport (waits for the peers' entries, gathers halo columns from the comm block, the
-// last workgroup finalizes the round); `launch_blocks` >= ntiles: a rank without such tiles still needs one workgroup
+// the SpMV launch of the direct transport: all tiles (those flagged in hv.tile_bnd wait for the peers' entries and gather halo
+// columns from the comm block) + the finalizer block; launch_blocks = ntiles + 1
 avs_status spmv_dot_tiles_halo(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc,
                                const int32_t *tiles, int launch_blocks, const HaloView &hv, hipStream_t stream)
 {
@@ -1539,9 +1589,11 @@ static avs_status pcg_solve_single_reduction(PcgWork *w, const CsrView &A, const
 // Direct-transport loop (world >= 1): the single-reduction iteration above with NO RCCL call and no host work inside:
 //   k_sr_update_push  p, s, x, r, u + partials of r.u, |r|^2; then the boundary entries of u -> the peers' halo areas and the
 //                     epoch flag (last pushing block).  (k_push does the same for the two set-up rounds.)
-//   SpMV interior tiles (run while the peers' entries travel)
-//   SpMV halo-touching tiles: wait for the flags, multiply, last workgroup: all-gather of the 3 sums + scalar step
-// = 3 launches per iteration, replayed from one hipGraph per chunk of kChunk iterations.
+//   SpMV, all tiles   interior tiles run while the peers' entries travel; the tiles that read halo columns (the last ones) wait
+//                     for the flags; every wave drops its x.Ax partial into a stage slot (fire and forget); the finalizer blocks
+//                     (dispatched last) watch the slots, fold them, and the last one all-gathers the 3 sums with every rank and
+//                     applies the scalar step
+// = 2 launches per iteration, replayed from one hipGraph per chunk of kChunk iterations.
 // ---------------------------------------------------------------------------------------------
 void sr_update_geometry(long long n, int *grid, int *chunk)
 {
@@ -1658,15 +1710,13 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
     AVS_TRY(w->u.alloc((size_t)w->n_ext));
     double *p = w->p.p, *r = w->r.p, *wv = w->t.p, *sv = w->s.p, *u = w->u.p, *invd = w->invd.p;
     double *pvec = w->partial.p;                         // up to 3 * g vector-kernel partials
-    double *pspmv = w->partial.p + 4 * (size_t)kVecGrid; // SpMV partials behind them
     PcgScalars *sc = w->sc.p;
-    const int ntiles = da.n_tiles_int + da.n_tiles_bnd;
-    const int ppt = A.codes ? kTileRows / 64 : 1; // value-indexed kernel: one partial per wave
-    // the halo-touching launch also folds the interior tiles' partials: enough workgroups that none walks more than ~8 k of them
-    int bnd_blocks = da.n_tiles_bnd > 0 ? da.n_tiles_bnd : 1;
-    const int want = (int)(((int64_t)da.n_tiles_int * ppt + 8191) / 8192);
-    if (bnd_blocks < want) bnd_blocks = want < 256 ? want : 256;
-    AVS_TRY(w->stage2.alloc(2 * (size_t)bnd_blocks));
+    const int ntiles = da.n_tiles_int + da.n_tiles_bnd;  // == ceil(n / kTileRows)
+    const int ppt = A.codes ? kTileRows / 64 : 1;        // value-indexed kernel: one partial per wave
+    const int slots = ntiles * ppt;
+    const int nfin = slots > 0 ? (slots + kFinShare - 1) / kFinShare : 1;
+    AVS_TRY(w->stage2.alloc((size_t)(slots > 0 ? slots : 1) + (size_t)nfin));
+    AVS_HIP(hipMemsetAsync(w->stage2.p, 0xFF, (size_t)(slots > 0 ? slots : 1) * sizeof(double), stream)); // arm: kSentinel in every slot
     const int push_blocks = da.n_send > 0 ? (da.n_send + 255) / 256 : 0;
 
     AVS_HIP(hipMemsetAsync(sc, 0, 2 * sizeof(PcgScalars), stream));
@@ -1680,7 +1730,8 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
         if (push && push_blocks) hipLaunchKernelGGL(k_push, dim3(push_blocks), dim3(256), 0, stream, da.dd, vec, (const unsigned long long *)da.epoch,
                                             da.push_ticket, (const PcgScalars *)sc);
         if (ea) AVS_HIP(hipEventRecord(ea, stream));
-        AVS_TRY(spmv_dot_tiles(A, vec, wv, pspmv, sc, da.tiles_int, da.n_tiles_int, stream));
+        // ONE launch over all tiles + the finalizer block: tiles that read halo columns (flagged; the last ones of the [interior |
+        // halo-reading] row order) wait for the peers' flags, everything else multiplies while the halo travels
         HaloView hv;
         hv.dd = da.dd;
         hv.epoch = da.epoch;
@@ -1688,17 +1739,17 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
         hv.fin_ticket = da.fin_ticket;
         hv.sc = sc;
         hv.pvec = pvec;
-        hv.pspmv = pspmv;
         hv.stage = w->stage2.p;
-        hv.tiles_int = da.tiles_int;
-        hv.n_int = da.n_tiles_int;
+        hv.stage2 = w->stage2.p + (slots > 0 ? slots : 1);
+        hv.tile_bnd = da.tile_flags;
+        hv.ntiles = ntiles;
         hv.ppt = ppt;
+        hv.nfin = nfin;
         hv.g = g;
         hv.nred_vec = nred_vec;
         hv.op = op;
-        hv.n_bnd = da.n_tiles_bnd;
         hv.tol = tol;
-        AVS_TRY(spmv_dot_tiles_halo(A, vec, wv, pspmv + (size_t)da.n_tiles_int * ppt, sc, da.tiles_bnd, bnd_blocks, hv, stream));
+        AVS_TRY(spmv_dot_tiles_halo(A, vec, wv, nullptr, sc, nullptr, ntiles + nfin, hv, stream));
         if (eb) AVS_HIP(hipEventRecord(eb, stream));
         return AVS_OK;
     };
@@ -1743,6 +1794,7 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
         if (replay) {
             const void *key[10] = {A.row_ptr, A.col, A.codes, A.packed, A.table, x, b, (const void *)da.dd, (const void *)(intptr_t)A.n,
                                    (const void *)(intptr_t)(((int64_t)A.table_size << 8) + A.col_bits + 1000003ll * ntiles)};
+            (void)da.tiles_int;
             if (w->graph && (memcmp(key, w->graph_key, sizeof(key)) != 0 || w->graph_tol != tol)) {
                 (void)hipGraphExecDestroy(w->graph);
                 w->graph = nullptr;
