@@ -277,3 +277,27 @@ def test_distributed_assembly_call_order(built_lib):
     assert abs(ref.iterations - info.iterations) <= 2
     s.close()
     lib.avs_local_group_destroy(grp)
+
+
+def test_loopback_measurement_mode(built_lib, monkeypatch):
+    """AVS_DIST_LOOPBACK=1 (tools/loopback_scaling.py): one rank of a 4-way partition alone on the GPU, peers looped back onto
+    itself.  Not a correct solve (zero halo) -- only checked for what the tool relies on: the loop runs the requested number of
+    iterations through the direct transport with 2 launches per iteration and leaves finite numbers."""
+    monkeypatch.setenv("AVS_DIST_LOOPBACK", "1")
+    dev = torch.device("cuda:0")
+    sc = scenes.fat_beam(64, 3, device=dev)
+    pyr = build_pyramid(sc)
+    for rank in (0, 2):
+        s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
+        feed(s, pyr)
+        s.set_scene_fields(sc)
+        capi.check(s.lib.avs_dist_init_hosted(s.h, rank, 4))
+        s.dist_assemble()
+        capi.check(s.lib.avs_dist_import_blobs(s.h, None))
+        info = s.dist_solve(1e-30, 96)
+        ci = s.dist_comm_info()
+        assert info.iterations == 96 and info.converged == 0 and np.isfinite(info.error)
+        assert ci["transport"] == "direct" and ci["launches_per_iteration"] == 2 and ci["rccl_calls_per_iteration"] == 0
+        ti, tb = s.overlap_tiles
+        assert 0 < tb < ti            # [interior | halo-reading] row order: few halo-reading tiles
+        s.close()
