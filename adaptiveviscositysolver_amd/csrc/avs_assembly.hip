@@ -259,6 +259,40 @@ __global__ __launch_bounds__(kBlock) void k_center_stencils(PyramidView P, const
 // The reference pops a FIFO queue of (face, weight, level); the leaves come out in lexicographic
 // (child, in-axis offset) order per level, which is the order of the mixed-radix counter below.
 // ---------------------------------------------------------------------------------------------
+// the 12^ND leaves under face `f` (ND levels up), weight `wgt` so far: all gathers first, then the fold in the FIFO's order
+template <int ND>
+__device__ __forceinline__ void restrict_group(const FieldView &V, const I3 &vr, const I3 &f, float wgt, int axis, int a1, int a2, double &acc)
+{
+    constexpr int N = ND == 1 ? 12 : 144;
+    float leaf[N];
+#pragma unroll
+    for (int code = 0; code < N; ++code) {
+        I3 h = f;
+#pragma unroll
+        for (int d = ND - 1; d >= 0; --d) {
+            const int digit = d == 1 ? code / 12 : code % 12;
+            const int ci = digit / 3, off = digit % 3 - 1;
+            h[0] *= 2; h[1] *= 2; h[2] *= 2;
+            if (ci & 1) ++h[a1];
+            if (ci & 2) ++h[a2];
+            h[axis] += off;
+        }
+        I3 fc{{clampi(h[0], 0, vr[0] - 1), clampi(h[1], 0, vr[1] - 1), clampi(h[2], 0, vr[2] - 1)}};
+        leaf[code] = field_at(V, vr, fc);
+    }
+#pragma unroll
+    for (int code = 0; code < N; ++code) {
+        float w = wgt;
+#pragma unroll
+        for (int d = ND - 1; d >= 0; --d) {
+            const int digit = d == 1 ? code / 12 : code % 12;
+            const double rw = (digit % 3 == 1) ? (1. / 8.) : (1. / 16.); // cpp:2323
+            w = (float)(rw * (double)w);                                 // fpreal32 myWeight, cpp:2318
+        }
+        acc += (double)w * (double)leaf[code];
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_initial_guess(PyramidView P, const int32_t *__restrict__ vdof, int64_t n,
                                                           double *__restrict__ x0, const int32_t *__restrict__ ids)
 {
@@ -275,27 +309,33 @@ __global__ __launch_bounds__(kBlock) void k_initial_guess(PyramidView P, const i
         return;
     }
     const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
-    int64_t leaves = 1;
-    for (int l = 0; l < level; ++l) leaves *= 12;
     double acc = 0.;
-    int digits[AVS_MAX_LEVELS] = {}; // odometer over the base-12 digits (no 64-bit divisions in the leaf loop)
-    for (int64_t code = 0; code < leaves; ++code) {
-        // digits, most significant first: (child, offset) of the step from level -> level-1, ...
-        I3 f = face;
-        float wgt = 1.f;
-        for (int l = 0; l < level; ++l) {
-            const int digit = digits[l];
-            const int ci = digit / 3, off = digit % 3 - 1;
-            f[0] *= 2; f[1] *= 2; f[2] *= 2;
-            if (ci & 1) ++f[a1];
-            if (ci & 2) ++f[a2];
-            f[axis] += off;
-            const double rw = (off == 0) ? (1. / 8.) : (1. / 16.); // cpp:2323
-            wgt = (float)(rw * (double)wgt);                       // fpreal32 myWeight, cpp:2318
+    if (level == 1) {
+        restrict_group<1>(V, vr, face, 1.f, axis, a1, a2, acc);
+    } else {
+        // a level-L row walks 12^L leaves (1728 at level 3): the last TWO digits are unrolled, 144 independent gathers in
+        // flight, then the fold in the reference's order -- one dependent gather per leaf made this kernel as slow as its
+        // coarsest row (2.5 ms)
+        int64_t groups = 1;
+        for (int l = 2; l < level; ++l) groups *= 12;
+        int digits[AVS_MAX_LEVELS] = {}; // odometer over the leading base-12 digits (no 64-bit divisions in the leaf loop)
+        for (int64_t g = 0; g < groups; ++g) {
+            // digits, most significant first: (child, offset) of the step from level -> level-1, ...
+            I3 f = face;
+            float wgt = 1.f;
+            for (int l = 0; l + 2 < level; ++l) {
+                const int digit = digits[l];
+                const int ci = digit / 3, off = digit % 3 - 1;
+                f[0] *= 2; f[1] *= 2; f[2] *= 2;
+                if (ci & 1) ++f[a1];
+                if (ci & 2) ++f[a2];
+                f[axis] += off;
+                const double rw = (off == 0) ? (1. / 8.) : (1. / 16.); // cpp:2323
+                wgt = (float)(rw * (double)wgt);                       // fpreal32 myWeight, cpp:2318
+            }
+            restrict_group<2>(V, vr, f, wgt, axis, a1, a2, acc);
+            for (int l = level - 3; l >= 0 && ++digits[l] == 12; --l) digits[l] = 0;
         }
-        I3 fc{{clampi(f[0], 0, vr[0] - 1), clampi(f[1], 0, vr[1] - 1), clampi(f[2], 0, vr[2] - 1)}};
-        acc += (double)wgt * (double)field_at(V, vr, fc);
-        for (int l = level - 1; l >= 0 && ++digits[l] == 12; --l) digits[l] = 0;
     }
     x0[id] = acc;
 }
@@ -303,6 +343,8 @@ __global__ __launch_bounds__(kBlock) void k_initial_guess(PyramidView P, const i
 // ---------------------------------------------------------------------------------------------
 // K4 / K6: the row sweep
 // ---------------------------------------------------------------------------------------------
+static constexpr int kRawStride = 64; // raw triplets are stored transposed inside every wave of 64 rows (see k_rows / k_merge_rows)
+
 struct RowAcc {
     int n;          // raw entries so far
     int32_t *col;   // row storage in the raw arrays (emission order)
@@ -314,9 +356,9 @@ struct RowAcc {
 template <bool EMIT>
 __device__ __forceinline__ void row_push(RowAcc &ra, int32_t c, double v)
 {
-    if (EMIT) { // raw triplet, emission order (what the reference push_backs, cpp:2447)
-        ra.col[ra.n] = c;
-        ra.val[ra.n] = v;
+    if (EMIT) { // raw triplet, emission order (what the reference push_backs, cpp:2447); wave-transposed: entry k of the row
+        ra.col[(size_t)ra.n * kRawStride] = c; // of lane l lives at base + 64 k + l, so the k-th push of a wave is ONE coalesced store
+        ra.val[(size_t)ra.n * kRawStride] = v;
     }
     ++ra.n;
 }
@@ -400,9 +442,10 @@ __global__ __launch_bounds__(kBlock) void k_rows(PyramidView P, const int32_t *_
     const I3 cr = cell_res(P, level);
     const I3 fr = face_res(P, level, axis);
     RowAcc ra{0, nullptr, nullptr, 0., 0., 0};
-    if (EMIT) {
-        ra.col = raw_col + rawptr[row];
-        ra.val = raw_val + rawptr[row];
+    if (EMIT) { // rawptr: first slot of the row's WAVE (64 consecutive rows) in the transposed raw arrays
+        const size_t base = (size_t)rawptr[row >> 6] + (size_t)(row & 63);
+        ra.col = raw_col + base;
+        ra.val = raw_val + base;
     }
 
     // centre stresses + inset T-junction edge stresses of the two axial cells, cpp:2547-2650
@@ -490,207 +533,276 @@ __global__ __launch_bounds__(kBlock) void k_rows(PyramidView P, const int32_t *_
         ra.rhs += fw * x0[vi]; // x0 is indexed by DOF
         rhs[row] = ra.rhs;
     } else ++ra.n;
-    row_count[row] = ra.n;
+    if (EMIT) {
+        if (ra.n != row_count[row]) *err = 8; // the dry run and the emit pass must agree
+    } else row_count[row] = ra.n;
     if (ra.bad) *err = 7;
 }
 
 // ---------------------------------------------------------------------------------------------
-// K6b: Eigen::SparseMatrix::setFromTriplets for one row (cpp:613-614): stable sort by column, duplicates
-// summed left to right in emission order.  One half-wave (32 lanes) per row, everything in registers:
-// lane l holds raw entry l; its rank is counted with 32-wide shuffles; the first occurrence of a column
-// folds the later ones in order; firsts write (col, sum) at their unique rank, in place.  Rows longer
-// than 32 raw entries (rare transition rows) are handled serially by lane 0 (insert-or-add).
+// K6b + K7: Eigen::SparseMatrix::setFromTriplets (cpp:613-614) per row: stable sort by column, duplicates summed left to right in
+// emission order -- straight into the final CSR.
+//
+// Round 1 emitted the raw triplets row-contiguously (17 dependent 12-B stores per thread: 4x the bytes in partial-line
+// traffic), re-read them with a half-wave per row, sorted in registers, wrote them back and compacted: 9.7 ms at 512^3.  Now
+// the raw arrays are wave-transposed (entry k of lane l at wave_base + 64 k + l): the k-th push of a wave is one coalesced
+// store, and ONE thread per row can walk its entries with coalesced, cache-friendly loads.  A row has ~17 raw entries, so
+// the O(R^2) ranking below is a few hundred L1 hits per row:
+//   k_wave_slots   slots of a wave = 64 x its longest row
+//   k_unique_rows  first-occurrence mask of every row -> unique counts (row pointers by scan)
+//   k_merge_rows   rank among the first occurrences + left-to-right fold of the later duplicates; the wave's 64 merged rows are
+//                  contiguous in the CSR, so they are staged in LDS and written out with coalesced stores
+// Rows of <= 32 raw entries (all but a few transition rows) live in registers: independent coalesced loads, unrolled compares.
 // ---------------------------------------------------------------------------------------------
-__device__ void sort_row_serial(int32_t *col, double *val, int n, int &unique)
+__global__ __launch_bounds__(kBlock) void k_wave_slots(int64_t n, const int32_t *__restrict__ row_count, int32_t *__restrict__ wave_slots)
 {
+    const int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t nw = (n + 63) >> 6;
+    if (w > nw) return;
+    if (w == nw) { wave_slots[w] = 0; return; }
     int m = 0;
-    for (int i = 0; i < n; ++i) {
-        const int32_t c = col[i];
-        const double v = val[i];
-        int j = m - 1;
-        while (j >= 0 && col[j] > c) --j;
-        if (j >= 0 && col[j] == c) {
-            val[j] = val[j] + v;
-            continue;
-        }
-        for (int k = m - 1; k > j; --k) {
-            col[k + 1] = col[k];
-            val[k + 1] = val[k];
-        }
-        col[j + 1] = c;
-        val[j + 1] = v;
-        ++m;
+    for (int l = 0; l < 64; ++l) {
+        const int64_t r = w * 64 + l;
+        if (r < n) m = max(m, row_count[r]);
     }
-    unique = m;
+    wave_slots[w] = m * kRawStride;
 }
 
-// value of lane (q + 32*half) for every lane of that half; q is wave-uniform => two v_readlane, no LDS crossbar
-__device__ __forceinline__ int half_bcast(int v, int q, bool hi)
+// The common row (<= kFast raw entries) is handled entirely in registers by its own thread: all of its columns and values are
+// requested with independent, coalesced loads, then ranked / folded with fully unrolled compares -- no dependent load in any
+// loop.  A row of 33..64 raw entries (transition rows) is handled by its WHOLE WAVE: lane e holds raw entry e, ranks are
+// counted with v_readlane broadcasts (the algorithm of round 1's k_sort_rows, 64 lanes wide).  Rows of more than 64 raw
+// entries (practically unreachable) take a serial path.
+static constexpr int kFast = 32;
+
+__device__ __forceinline__ void load_cols(const int32_t *__restrict__ rc, int R, int32_t (&c)[kFast])
 {
-    const int lo = __builtin_amdgcn_readlane(v, q);
-    const int up = __builtin_amdgcn_readlane(v, q + 32);
-    return hi ? up : lo;
+#pragma unroll
+    for (int k = 0; k < kFast; ++k) c[k] = k < R ? rc[(size_t)k * kRawStride] : INT32_MAX;
 }
-__device__ __forceinline__ double half_bcast(double v, int q, bool hi)
+
+__device__ __forceinline__ unsigned first_mask_fast(const int32_t (&c)[kFast], int R)
 {
-    const int l = half_bcast(__double2loint(v), q, hi);
-    const int h = half_bcast(__double2hiint(v), q, hi);
+    unsigned mask = 0u;
+#pragma unroll
+    for (int k = 0; k < kFast; ++k) {
+        bool dup = false;
+#pragma unroll
+        for (int j = 0; j < k; ++j) dup |= c[j] == c[k];
+        if (k < R && !dup) mask |= 1u << k;
+    }
+    return mask;
+}
+
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const int u = __shfl_xor(v, o, 64);
+        v = u > v ? u : v;
+    }
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+__device__ __forceinline__ double lane_bcast(double v, int q) // q wave-uniform
+{
+    const int l = __builtin_amdgcn_readlane(__double2loint(v), q);
+    const int h = __builtin_amdgcn_readlane(__double2hiint(v), q);
     return __hiloint2double(h, l);
 }
 
-static constexpr int kLongCap = 1024; // raw entries of one row staged in LDS by k_sort_long_rows
-
-// rows with more than 32 raw entries (transition rows): every wave scans 64 consecutive rows, and each long
-// one among them is processed by the whole wave with the row staged in LDS (no list, no atomics)
-__global__ __launch_bounds__(64) void k_sort_long_rows(int64_t n, const int32_t *__restrict__ rawptr, int32_t *__restrict__ raw_col,
-                                                       double *__restrict__ raw_val, int32_t *__restrict__ row_count)
+// wave-cooperative: is raw entry `lane` of the row (c_e; INT32_MAX beyond R) the first occurrence of its column?
+__device__ __forceinline__ bool coop_first(int32_t c_e, int R, int lane)
 {
-    __shared__ int32_t lc[kLongCap];
-    __shared__ double lv[kLongCap];
-    __shared__ unsigned char lf[kLongCap];
-    const int lane = threadIdx.x;
-    for (int64_t base = (int64_t)blockIdx.x * 64; base < n; base += (int64_t)gridDim.x * 64) {
-        const int64_t my = base + lane;
-        const int myR = (my < n) ? rawptr[my + 1] - rawptr[my] : 0;
-        unsigned long long todo = __ballot(myR > 32);
-        while (todo) {
-            const int which = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const int64_t row = base + which;
-            const int s = rawptr[row];
-            const int R = rawptr[row + 1] - s;
-            if (R > kLongCap) { // practically unreachable; keep the exact semantics anyway
-                if (lane == 0) {
-                    int unique = 0;
-                    sort_row_serial(raw_col + s, raw_val + s, R, unique);
-                    row_count[row] = unique;
+    bool first = lane < R;
+    for (int q = 0; q < R; ++q) {
+        const int32_t cq = __builtin_amdgcn_readlane(c_e, q);
+        if (q < lane && cq == c_e) first = false;
+    }
+    return first;
+}
+
+static constexpr int32_t kDupBit = (int32_t)0x80000000u; // rows of > 64 raw entries: k_unique_rows marks the later duplicates
+static constexpr int32_t kColMask = 0x7fffffff;
+
+// rows of more than 64 raw entries (a coarse face surrounded by finer ones; a handful per scene): count the distinct columns
+// and mark every later duplicate with the sign bit, so that k_merge_rows does not have to search for first occurrences again
+__device__ int unique_mark_serial(int32_t *__restrict__ rc, int R)
+{
+    int u = 0;
+    for (int k = 0; k < R; ++k) {
+        const int32_t ck = rc[(size_t)k * kRawStride];
+        bool first = true;
+        for (int j = 0; j < k; ++j)
+            if ((rc[(size_t)j * kRawStride] & kColMask) == ck) { first = false; break; }
+        if (!first) rc[(size_t)k * kRawStride] = ck | kDupBit;
+        u += first;
+    }
+    return u;
+}
+
+__global__ __launch_bounds__(kBlock) void k_unique_rows(int64_t n, const int32_t *__restrict__ rawptr, int32_t *__restrict__ raw_col,
+                                                        const int32_t *__restrict__ row_count, int32_t *__restrict__ ucount)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (row == n) ucount[n] = 0;
+    const int R = row < n ? row_count[row] : 0;
+    const int64_t wrow0 = row - lane;
+    const size_t wbase = wrow0 < n ? (size_t)rawptr[wrow0 >> 6] : 0; // first raw slot of this wave (uniform)
+    if (row < n && R <= kFast) {
+        int32_t c[kFast];
+        load_cols(raw_col + wbase + lane, R, c);
+        ucount[row] = __popc(first_mask_fast(c, R));
+    } else if (row < n && R > 64) {
+        ucount[row] = unique_mark_serial(raw_col + wbase + lane, R);
+    }
+    unsigned long long todo = __ballot(row < n && R > kFast && R <= 64);
+    while (todo) { // wave-uniform loop over the rows that need the whole wave
+        const int which = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int Rr = __builtin_amdgcn_readlane(R, which);
+        const int32_t c_e = lane < Rr ? raw_col[wbase + (size_t)lane * kRawStride + which] : INT32_MAX;
+        const unsigned long long firsts = __ballot(coop_first(c_e, Rr, lane));
+        if (lane == which) ucount[row] = __popcll(firsts);
+    }
+}
+
+static constexpr int kMergeLds = 1088; // merged entries of one wave staged in LDS (64 rows x 17; interior rows have 15): 12.75 KiB per wave, 3 workgroups per CU
+
+__global__ __launch_bounds__(kBlock) void k_merge_rows(int64_t n, const int32_t *__restrict__ rawptr, const int32_t *__restrict__ raw_col,
+                                                       const double *__restrict__ raw_val, const int32_t *__restrict__ row_count,
+                                                       const int32_t *__restrict__ row_ptr, int32_t *__restrict__ col, double *__restrict__ val)
+{
+    __shared__ int32_t lcol[kBlock / 64][kMergeLds];
+    __shared__ double lval[kBlock / 64][kMergeLds];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t wrow0 = row - lane;                                   // first row of this wave
+    const int64_t wlast = (wrow0 + 64 < n) ? wrow0 + 64 : n;
+    const int seg0 = wrow0 < n ? row_ptr[wrow0] : 0;
+    const int seglen = wrow0 < n ? row_ptr[wlast] - seg0 : 0;
+    const bool staged = seglen <= kMergeLds;                            // wave-uniform
+    const size_t wbase = wrow0 < n ? (size_t)rawptr[wrow0 >> 6] : 0;    // first raw slot of this wave
+    const int R = row < n ? row_count[row] : 0;
+    const int dst0 = row < n ? row_ptr[row] : 0;
+    // output addressed by CSR position minus `ooff` (never form an LDS pointer below its array: LDS pointers are 32-bit)
+    int32_t *ocw = staged ? &lcol[wv][0] : col;
+    double *ovw = staged ? &lval[wv][0] : val;
+    const int ooff = staged ? seg0 : 0;
+    bool done = row >= n;
+    const int wmax = wave_max_i32((row < n && R <= kFast) ? R : 0); // longest register-path row of this wave (uniform)
+    if (row < n && R <= kFast) {
+        int32_t c[kFast];
+        double v[kFast];
+        load_cols(raw_col + wbase + lane, R, c);
+        const double *rv = raw_val + wbase + lane;
+#pragma unroll
+        for (int k = 0; k < kFast; ++k) v[k] = k < R ? rv[(size_t)k * kRawStride] : 0.;
+        // A neighbour face usually appears in several of the row's stress stencils: most rows DO carry duplicate columns.
+        // One triangular pass finds the first occurrences AND folds: every later duplicate k is added to ALL earlier entries j
+        // of the same column, in ascending k = emission order (v[k] is still the raw value then: it is only ever modified by
+        // pairs (k, k' > k)); the sums of non-first entries are simply not used.  Everything is indexed statically; the
+        // wave-uniform bound keeps the work at the wave's longest row instead of 32.
+        unsigned m = 0u;
+#pragma unroll
+        for (int k = 0; k < kFast; ++k) {
+            if (k < wmax) {
+                bool dup = false;
+#pragma unroll
+                for (int j = 0; j < k; ++j) {
+                    const bool eq = c[j] == c[k];
+                    dup |= eq;
+                    v[j] = eq ? v[j] + v[k] : v[j];
                 }
-                continue;
+                if (k < R && !dup) m |= 1u << k;
             }
-            __syncthreads();
-            for (int e = lane; e < R; e += 64) {
-                lc[e] = raw_col[s + e];
-                lv[e] = raw_val[s + e];
-            }
-            __syncthreads();
-            for (int e = lane; e < R; e += 64) {
-                const int32_t c = lc[e];
-                bool first = true;
-                for (int q = 0; q < e; ++q)
-                    if (lc[q] == c) { first = false; break; }
-                lf[e] = first ? 1 : 0;
-            }
-            __syncthreads();
-            int mine = 0;
-            for (int e = lane; e < R; e += 64) {
-                if (!lf[e]) continue;
-                const int32_t c = lc[e];
+        }
+#pragma unroll
+        for (int k = 0; k < kFast; ++k) c[k] = ((m >> k) & 1u) ? c[k] : INT32_MAX; // only first occurrences take part in the ranking
+#pragma unroll
+        for (int k = 0; k < kFast; ++k) {
+            if (k < wmax) {
                 int urank = 0;
-                double sum = lv[e];
-                for (int q = 0; q < R; ++q) {
-                    const int32_t cq = lc[q];
-                    if (lf[q] && cq < c) ++urank;
-                    if (q > e && cq == c) sum = sum + lv[q]; // left fold in emission order
+#pragma unroll
+                for (int j0 = 0; j0 < kFast; j0 += 8) {
+                    if (j0 < wmax) {
+#pragma unroll
+                        for (int j = j0; j < j0 + 8; ++j) urank += (int)(c[j] < c[k]);
+                    }
                 }
-                raw_col[s + urank] = c; // every read of this row comes from LDS: in place is safe
-                raw_val[s + urank] = sum;
-                ++mine;
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
-            if (lane == 0) row_count[row] = mine;
-        }
-    }
-}
-
-static constexpr int kSortRowsPerHalf = 4; // rows handled per half-wave: 4x the loads in flight (the kernel is latency-bound)
-
-__global__ __launch_bounds__(kBlock) void k_sort_rows(int64_t n, const int32_t *__restrict__ rawptr, int32_t *__restrict__ raw_col,
-                                                      double *__restrict__ raw_val, int32_t *__restrict__ row_count)
-{
-    constexpr int K = kSortRowsPerHalf;
-    const int lane = threadIdx.x & 31;
-    const bool hi = (threadIdx.x & 32) != 0;
-    const int64_t row0 = (((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 5) * K;
-    int s[K], Rs[K];
-    int32_t c[K];
-    double v[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        const int64_t row = row0 + j;
-        const bool live = row < n;
-        s[j] = live ? rawptr[row] : 0;
-        const int R = live ? rawptr[row + 1] - s[j] : 0;
-        Rs[j] = (R <= 32) ? R : 0; // longer rows: k_sort_long_rows
-    }
-#pragma unroll
-    for (int j = 0; j < K; ++j) { // all loads of the K rows are in flight together
-        c[j] = INT32_MAX;
-        v[j] = 0.;
-        if (lane < Rs[j]) {
-            c[j] = raw_col[s[j] + lane];
-            v[j] = raw_val[s[j] + lane];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        // wave-uniform trip count: the longer of the two rows sharing this wave
-        const int trip = max(__builtin_amdgcn_readlane(Rs[j], 0), __builtin_amdgcn_readlane(Rs[j], 32));
-        // pass 1: how many columns are smaller, and does an earlier entry carry my column?
-        int below = 0;
-        bool first = lane < Rs[j];
-        for (int q = 0; q < trip; ++q) {
-            const int32_t cq = half_bcast(c[j], q, hi);
-            if (q < Rs[j]) {
-                below += (cq < c[j]);
-                if (q < lane && cq == c[j]) first = false;
+                if ((m >> k) & 1u) {
+                    ocw[dst0 - ooff + urank] = c[k];
+                    ovw[dst0 - ooff + urank] = v[k];
+                }
             }
         }
+        done = true;
+    }
+    unsigned long long todo = __ballot(row < n && R > 64);
+    while (todo) { // rows of more than 64 raw entries, any length: the whole wave, 64 entries at a time against 64 at a time
+        const int which = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int Rr = __builtin_amdgcn_readlane(R, which);
+        const int dr = __builtin_amdgcn_readlane(dst0, which);
+        for (int a0 = 0; a0 < Rr; a0 += 64) {
+            const int e = a0 + lane;
+            const size_t at = wbase + (size_t)e * kRawStride + which;
+            const int32_t craw = e < Rr ? raw_col[at] : INT32_MAX;   // sign bit: a later duplicate (k_unique_rows)
+            const bool first = e < Rr && craw >= 0;
+            const int32_t c_e = craw & kColMask;
+            double sum = e < Rr ? raw_val[at] : 0.;
+            int urank = 0;
+            for (int b0 = 0; b0 < Rr; b0 += 64) {
+                const int eb = b0 + lane;
+                const size_t bt = wbase + (size_t)eb * kRawStride + which;
+                const int32_t cb = eb < Rr ? raw_col[bt] : INT32_MAX;
+                const double vb = eb < Rr ? raw_val[bt] : 0.;
+                const int nb = Rr - b0 < 64 ? Rr - b0 : 64;
+                for (int q = 0; q < nb; ++q) {
+                    const int32_t cq = __builtin_amdgcn_readlane(cb, q);
+                    const double vq = lane_bcast(vb, q);
+                    if (cq >= 0 && cq < c_e) ++urank;                                   // first occurrences only
+                    if (first && b0 + q > e && (cq & kColMask) == c_e) sum = sum + vq; // left fold in emission order
+                }
+            }
+            if (first) {
+                ocw[dr - ooff + urank] = c_e;
+                ovw[dr - ooff + urank] = sum;
+            }
+        }
+        if (lane == which) done = true;
+    }
+    todo = __ballot(!done);
+    while (todo) { // rows of 33..64 raw entries: the whole wave, lane e = raw entry e
+        const int which = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int Rr = __builtin_amdgcn_readlane(R, which);
+        const int dr = __builtin_amdgcn_readlane(dst0, which);
+        const size_t at = wbase + (size_t)lane * kRawStride + which;
+        const int32_t c_e = lane < Rr ? raw_col[at] : INT32_MAX;
+        const double v_e = lane < Rr ? raw_val[at] : 0.;
+        const bool first = coop_first(c_e, Rr, lane);
         const unsigned long long firsts = __ballot(first);
-        const unsigned long long actives = __ballot(lane < Rs[j]);
-        int urank = below;
-        double sum = v[j];
-        if (firsts != actives) {
-            // duplicates somewhere in this wave (transition rows): rank among FIRST occurrences only, and
-            // fold the later duplicates into the first one, left to right in emission order
-            urank = 0;
-            const unsigned fmask = hi ? (unsigned)(firsts >> 32) : (unsigned)firsts;
-            for (int q = 0; q < trip; ++q) {
-                const int32_t cq = half_bcast(c[j], q, hi);
-                const double vq = half_bcast(v[j], q, hi);
-                if (q < Rs[j]) {
-                    if (((fmask >> q) & 1u) && cq < c[j]) ++urank;
-                    if (first && q > lane && cq == c[j]) sum = sum + vq;
-                }
-            }
+        int urank = 0;
+        double sum = v_e;
+        for (int q = 0; q < Rr; ++q) {
+            const int32_t cq = __builtin_amdgcn_readlane(c_e, q);
+            const double vq = lane_bcast(v_e, q);
+            if (((firsts >> q) & 1ull) && cq < c_e) ++urank;
+            if (first && q > lane && cq == c_e) sum = sum + vq; // left fold in emission order
         }
-        if (first) { // all reads of this row happened above: writing in place is safe
-            raw_col[s[j] + urank] = c[j];
-            raw_val[s[j] + urank] = sum;
-        }
-        if (lane == 0 && Rs[j] > 0) row_count[row0 + j] = __popc(hi ? (unsigned)(firsts >> 32) : (unsigned)firsts);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K7: compaction rows -> CSR.  16 lanes per row: consecutive rows are consecutive in both arrays,
-// so a wave reads and writes (nearly) contiguous memory.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_compact(int64_t n, const int32_t *__restrict__ rawptr,
-                                                    const int32_t *__restrict__ row_ptr,
-                                                    const int32_t *__restrict__ raw_col, const double *__restrict__ raw_val,
-                                                    int32_t *__restrict__ col, double *__restrict__ val)
-{
-    const int sub = threadIdx.x & 15;
-    const int64_t group = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 4;
-    const int64_t ngroups = ((int64_t)gridDim.x * kBlock) >> 4;
-    for (int64_t row = group; row < n; row += ngroups) {
-        const int src = rawptr[row], dst = row_ptr[row], len = row_ptr[row + 1] - dst;
-        for (int k = sub; k < len; k += 16) {
-            col[dst + k] = raw_col[src + k];
-            val[dst + k] = raw_val[src + k];
+        if (first) {
+            ocw[dr - ooff + urank] = c_e;
+            ovw[dr - ooff + urank] = sum;
         }
     }
+    __syncthreads();
+    if (staged)
+        for (int e = lane; e < seglen; e += 64) { // the wave's 64 merged rows are contiguous in the CSR: coalesced stores
+            col[seg0 + e] = lcol[wv][e];
+            val[seg0 + e] = lval[wv][e];
+        }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -959,24 +1071,32 @@ avs_status assemble_rows(avs_ctx *c, const int32_t *ids, int64_t m, DevBuf<int32
     // K4 dry run -> raw triplet counts
     if (n) hipLaunchKernelGGL((k_rows<false>), dim3(grid_for(n)), dim3(kBlock), 0, st, P, c->vdof.p, n, E, C, c->x0.p,
                               (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr, row_count.p, (double *)nullptr, err.p, ids);
+    // raw total (reported) and the wave-transposed layout: a wave of 64 rows gets 64 x its longest row
     AVS_TRY(exclusive_scan_i32(row_count.p, rawptr.p, n, scan_tmp.p, scan_tmp.n, st));
     int32_t nraw = 0;
     AVS_HIP(hipMemcpyAsync(&nraw, rawptr.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    const int64_t nwaves = (n + 63) >> 6;
+    DevBuf<int32_t> &wslots = c->scratch.wave_slots;
+    AVS_TRY(wslots.reserve((size_t)nwaves + 1));
+    hipLaunchKernelGGL(k_wave_slots, dim3(grid_for(nwaves + 1)), dim3(kBlock), 0, st, n, (const int32_t *)row_count.p, wslots.p);
+    AVS_TRY(exclusive_scan_i32(wslots.p, rawptr.p, nwaves, scan_tmp.p, scan_tmp.n, st)); // rawptr now: first slot of every wave
+    int32_t nslots = 0;
+    AVS_HIP(hipMemcpyAsync(&nslots, rawptr.p + nwaves, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     AVS_HIP(hipStreamSynchronize(st));
-    AVS_REQUIRE(nraw >= 0, AVS_EINVAL, "raw triplet count exceeds int32 (the scan reports -1 for any total above INT32_MAX)");
+    AVS_REQUIRE(nraw >= 0 && nslots >= 0, AVS_EINVAL, "raw triplet count exceeds int32 (the scan reports -1 for any total above INT32_MAX)");
     if (nraw_out) *nraw_out = nraw;
-    AVS_TRY(raw_col.reserve((size_t)nraw));
-    AVS_TRY(raw_val.reserve((size_t)nraw));
-    // K6 emit raw triplets, K6b per-row stable sort + duplicate merge -> unique counts
+    AVS_TRY(raw_col.reserve((size_t)nslots));
+    AVS_TRY(raw_val.reserve((size_t)nslots));
+    // K6 emit (wave-transposed raw triplets), K6b first-occurrence masks -> unique counts
+    DevBuf<int32_t> &ucount = c->scratch.ucount;
+    AVS_TRY(ucount.reserve((size_t)n + 1));
     if (n) {
         hipLaunchKernelGGL((k_rows<true>), dim3(grid_for(n)), dim3(kBlock), 0, st, P, c->vdof.p, n, E, C, c->x0.p,
                            (const int32_t *)rawptr.p, raw_col.p, raw_val.p, row_count.p, rhs.p, err.p, ids);
-        hipLaunchKernelGGL(k_sort_rows, dim3(grid_for((n + kSortRowsPerHalf - 1) / kSortRowsPerHalf * 32)), dim3(kBlock), 0, st, n,
-                           (const int32_t *)rawptr.p, raw_col.p, raw_val.p, row_count.p);
-        hipLaunchKernelGGL(k_sort_long_rows, dim3(8192), dim3(64), 0, st, n, (const int32_t *)rawptr.p, raw_col.p, raw_val.p,
-                           row_count.p);
+        hipLaunchKernelGGL(k_unique_rows, dim3(grid_for(n + 1)), dim3(kBlock), 0, st, n, (const int32_t *)rawptr.p, (int32_t *)raw_col.p,
+                           (const int32_t *)row_count.p, ucount.p);
     }
-    AVS_TRY(exclusive_scan_i32(row_count.p, row_ptr.p, n, scan_tmp.p, scan_tmp.n, st));
+    AVS_TRY(exclusive_scan_i32(ucount.p, row_ptr.p, n, scan_tmp.p, scan_tmp.n, st));
     int32_t nnz = 0;
     AVS_HIP(hipMemcpyAsync(&nnz, row_ptr.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     int e = 0;
@@ -986,8 +1106,9 @@ avs_status assemble_rows(avs_ctx *c, const int32_t *ids, int64_t m, DevBuf<int32
     if (nnz_out) *nnz_out = nnz;
     AVS_TRY(col.alloc((size_t)nnz));
     AVS_TRY(val.alloc((size_t)nnz));
-    if (n) hipLaunchKernelGGL(k_compact, dim3(8192), dim3(kBlock), 0, st, n, (const int32_t *)rawptr.p, (const int32_t *)row_ptr.p,
-                              (const int32_t *)raw_col.p, (const double *)raw_val.p, col.p, val.p);
+    // K6b + K7: rank, fold, write the final CSR
+    if (n) hipLaunchKernelGGL(k_merge_rows, dim3(grid_for(n)), dim3(kBlock), 0, st, n, (const int32_t *)rawptr.p, (const int32_t *)raw_col.p,
+                              (const double *)raw_val.p, (const int32_t *)row_count.p, (const int32_t *)row_ptr.p, col.p, val.p);
     AVS_HIP(hipGetLastError());
     AVS_HIP(hipStreamSynchronize(st)); // the caller may read nnz-sized results right away; the raw buffers stay in the context
     return AVS_OK;
