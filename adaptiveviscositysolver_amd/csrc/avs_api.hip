@@ -516,6 +516,7 @@ static avs_status get_stencils(avs_ctx *c, bool edge, int32_t *cnt, int32_t *idx
     const size_t nw = edge ? (size_t)c->n_edge : (size_t)c->n_center;
     const size_t cap = edge ? AVS_EDGE_STENCIL_CAP : AVS_CENTER_STENCIL_CAP;
     const size_t bcap = edge ? AVS_EDGE_BOUNDARY_CAP : AVS_CENTER_BOUNDARY_CAP;
+    AVS_TRY(pad_stencils(c, edge));
     if (cnt) AVS_HIP(copy_out(cnt, edge ? c->e_cnt.p : c->c_cnt.p, ns * sizeof(int32_t), where, s));
     if (idx) AVS_HIP(copy_out(idx, edge ? c->e_idx.p : c->c_idx.p, ns * cap * sizeof(int32_t), where, s));
     if (coef) AVS_HIP(copy_out(coef, edge ? c->e_coef.p : c->c_coef.p, ns * cap * sizeof(double), where, s));

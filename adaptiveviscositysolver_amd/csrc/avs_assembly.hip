@@ -572,27 +572,12 @@ __global__ __launch_bounds__(kBlock) void k_wave_slots(int64_t n, const int32_t 
 // requested with independent, coalesced loads, then ranked / folded with fully unrolled compares -- no dependent load in any
 // loop.  A row of 33..64 raw entries (transition rows) is handled by its WHOLE WAVE: lane e holds raw entry e, ranks are
 // counted with v_readlane broadcasts (the algorithm of round 1's k_sort_rows, 64 lanes wide).  Rows of more than 64 raw
-// entries (practically unreachable) take a serial path.
+// entries (a coarse face surrounded by finer ones: a handful per scene, but a serial O(R^3) path for them took 15 ms) are
+// walked by the wave too, 64 entries at a time (k_unique_rows marks their later duplicates with the sign bit).
+// (A single-pass variant -- unique counts, row pointers by decoupled look-back and the merge in one kernel -- was measured
+// SLOWER, 3.5-3.7 ms against 0.86 + 1.95 ms: the waves of transition rows publish their counts late and every later
+// workgroup waits for them.)
 static constexpr int kFast = 32;
-
-__device__ __forceinline__ void load_cols(const int32_t *__restrict__ rc, int R, int32_t (&c)[kFast])
-{
-#pragma unroll
-    for (int k = 0; k < kFast; ++k) c[k] = k < R ? rc[(size_t)k * kRawStride] : INT32_MAX;
-}
-
-__device__ __forceinline__ unsigned first_mask_fast(const int32_t (&c)[kFast], int R)
-{
-    unsigned mask = 0u;
-#pragma unroll
-    for (int k = 0; k < kFast; ++k) {
-        bool dup = false;
-#pragma unroll
-        for (int j = 0; j < k; ++j) dup |= c[j] == c[k];
-        if (k < R && !dup) mask |= 1u << k;
-    }
-    return mask;
-}
 
 __device__ __forceinline__ int wave_max_i32(int v)
 {
@@ -602,6 +587,27 @@ __device__ __forceinline__ int wave_max_i32(int v)
         v = u > v ? u : v;
     }
     return __builtin_amdgcn_readfirstlane(v);
+}
+
+__device__ __forceinline__ void load_cols(const int32_t *__restrict__ rc, int R, int32_t (&c)[kFast])
+{
+#pragma unroll
+    for (int k = 0; k < kFast; ++k) c[k] = k < R ? rc[(size_t)k * kRawStride] : INT32_MAX;
+}
+
+__device__ __forceinline__ unsigned first_mask_fast(const int32_t (&c)[kFast], int R, int wmax /* wave-uniform, >= R */)
+{
+    unsigned mask = 0u;
+#pragma unroll
+    for (int k = 0; k < kFast; ++k) {
+        if (k < wmax) {
+            bool dup = false;
+#pragma unroll
+            for (int j = 0; j < k; ++j) dup |= c[j] == c[k];
+            if (k < R && !dup) mask |= 1u << k;
+        }
+    }
+    return mask;
 }
 
 __device__ __forceinline__ double lane_bcast(double v, int q) // q wave-uniform
@@ -625,22 +631,6 @@ __device__ __forceinline__ bool coop_first(int32_t c_e, int R, int lane)
 static constexpr int32_t kDupBit = (int32_t)0x80000000u; // rows of > 64 raw entries: k_unique_rows marks the later duplicates
 static constexpr int32_t kColMask = 0x7fffffff;
 
-// rows of more than 64 raw entries (a coarse face surrounded by finer ones; a handful per scene): count the distinct columns
-// and mark every later duplicate with the sign bit, so that k_merge_rows does not have to search for first occurrences again
-__device__ int unique_mark_serial(int32_t *__restrict__ rc, int R)
-{
-    int u = 0;
-    for (int k = 0; k < R; ++k) {
-        const int32_t ck = rc[(size_t)k * kRawStride];
-        bool first = true;
-        for (int j = 0; j < k; ++j)
-            if ((rc[(size_t)j * kRawStride] & kColMask) == ck) { first = false; break; }
-        if (!first) rc[(size_t)k * kRawStride] = ck | kDupBit;
-        u += first;
-    }
-    return u;
-}
-
 __global__ __launch_bounds__(kBlock) void k_unique_rows(int64_t n, const int32_t *__restrict__ rawptr, int32_t *__restrict__ raw_col,
                                                         const int32_t *__restrict__ row_count, int32_t *__restrict__ ucount)
 {
@@ -650,14 +640,37 @@ __global__ __launch_bounds__(kBlock) void k_unique_rows(int64_t n, const int32_t
     const int R = row < n ? row_count[row] : 0;
     const int64_t wrow0 = row - lane;
     const size_t wbase = wrow0 < n ? (size_t)rawptr[wrow0 >> 6] : 0; // first raw slot of this wave (uniform)
+    const int wmax = wave_max_i32((row < n && R <= kFast) ? R : 0);
     if (row < n && R <= kFast) {
         int32_t c[kFast];
         load_cols(raw_col + wbase + lane, R, c);
-        ucount[row] = __popc(first_mask_fast(c, R));
-    } else if (row < n && R > 64) {
-        ucount[row] = unique_mark_serial(raw_col + wbase + lane, R);
+        ucount[row] = __popc(first_mask_fast(c, R, wmax));
     }
-    unsigned long long todo = __ballot(row < n && R > kFast && R <= 64);
+    unsigned long long todo = __ballot(row < n && R > 64);
+    while (todo) { // longer rows (a coarse face surrounded by finer ones; a handful per scene): 64 entries at a time against the
+        const int which = __ffsll((long long)todo) - 1; // earlier ones; every later duplicate gets the sign bit, so that
+        todo &= todo - 1;                               // k_merge_rows does not have to search for first occurrences again
+        const int Rr = __builtin_amdgcn_readlane(R, which);
+        int count = 0;
+        for (int a0 = 0; a0 < Rr; a0 += 64) {
+            const int e = a0 + lane;
+            const size_t at = wbase + (size_t)e * kRawStride + which;
+            const int32_t c_e = e < Rr ? raw_col[at] : INT32_MAX;
+            bool first = e < Rr;
+            for (int b0 = 0; b0 <= a0; b0 += 64) {
+                const int32_t cb = b0 == a0 ? c_e : raw_col[wbase + (size_t)(b0 + lane) * kRawStride + which]; // earlier chunks are full
+                const int nb = Rr - b0 < 64 ? Rr - b0 : 64;
+                for (int q = 0; q < nb; ++q) {
+                    const int32_t cq = __builtin_amdgcn_readlane(cb, q);
+                    if (b0 + q < e && (cq & kColMask) == c_e) first = false; // (an earlier chunk may already carry its marks)
+                }
+            }
+            if (e < Rr && !first) raw_col[at] = c_e | kDupBit;
+            count += __popcll(__ballot(first));
+        }
+        if (lane == which) ucount[row] = count;
+    }
+    todo = __ballot(row < n && R > kFast && R <= 64);
     while (todo) { // wave-uniform loop over the rows that need the whole wave
         const int which = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
@@ -994,13 +1007,7 @@ avs_status build_stencils(avs_ctx *c)
     AVS_TRY(c->c_idx.alloc(n3 * AVS_CENTER_STENCIL_CAP));
     AVS_TRY(c->c_coef.alloc(n3 * AVS_CENTER_STENCIL_CAP));
     AVS_TRY(c->c_bval.alloc(n3 * AVS_CENTER_BOUNDARY_CAP));
-    // unused slots read back as (-1, 0.0) like the oracle's
-    AVS_HIP(hipMemsetAsync(c->e_idx.p, 0xff, c->e_idx.n * sizeof(int32_t), st));
-    AVS_HIP(hipMemsetAsync(c->e_coef.p, 0, c->e_coef.n * sizeof(double), st));
-    AVS_HIP(hipMemsetAsync(c->e_bval.p, 0, c->e_bval.n * sizeof(double), st));
-    AVS_HIP(hipMemsetAsync(c->c_idx.p, 0xff, c->c_idx.n * sizeof(int32_t), st));
-    AVS_HIP(hipMemsetAsync(c->c_coef.p, 0, c->c_coef.n * sizeof(double), st));
-    AVS_HIP(hipMemsetAsync(c->c_bval.p, 0, c->c_bval.n * sizeof(double), st));
+    // the slots beyond a stencil's count are never read by the row sweep; pad_stencils() fills them for a read-back
     DevBuf<int> err;
     AVS_TRY(err.alloc(1));
     AVS_HIP(hipMemsetAsync(err.p, 0, sizeof(int), st));
@@ -1018,6 +1025,31 @@ avs_status build_stencils(avs_ctx *c)
     AVS_TRY(read_err(err.p, st, &e));
     AVS_REQUIRE(e == 0, AVS_EINTERNAL, "stencil construction hit a reference assert (code %d): the index pyramids are inconsistent", e);
     c->stencils_ready = true;
+    return AVS_OK;
+}
+
+// unused slots read back as (-1, 0.0) like the oracle's: done when somebody asks for the stencils (avs_get_*_stencils), not in
+// every assembly (six memsets, 0.56 ms at 512^3)
+__global__ __launch_bounds__(kBlock) void k_pad_stencils(StencilView S, int cap, int bcap, int32_t *__restrict__ idx, double *__restrict__ coef,
+                                                         double *__restrict__ bval)
+{
+    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (s >= S.count) return;
+    for (int i = S.cnt[s]; i < cap; ++i) {
+        idx[(size_t)i * S.count + s] = -1;
+        coef[(size_t)i * S.count + s] = 0.;
+    }
+    for (int i = S.bcnt[s]; i < bcap; ++i) bval[(size_t)i * S.count + s] = 0.;
+}
+
+avs_status pad_stencils(avs_ctx *c, bool edge)
+{
+    StencilView S = edge ? edge_view(c) : center_view(c);
+    if (S.count == 0) return AVS_OK;
+    hipLaunchKernelGGL(k_pad_stencils, dim3(grid_for(S.count)), dim3(kBlock), 0, c->stream, S, edge ? AVS_EDGE_STENCIL_CAP : AVS_CENTER_STENCIL_CAP,
+                       edge ? AVS_EDGE_BOUNDARY_CAP : AVS_CENTER_BOUNDARY_CAP, edge ? c->e_idx.p : c->c_idx.p, edge ? c->e_coef.p : c->c_coef.p,
+                       edge ? c->e_bval.p : c->c_bval.p);
+    AVS_HIP(hipGetLastError());
     return AVS_OK;
 }
 

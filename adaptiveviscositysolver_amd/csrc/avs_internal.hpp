@@ -254,6 +254,7 @@ avs_status exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_
 size_t scan_tmp_elems(int64_t n);
 bool dist_matrix_format(avs_ctx *c, avs_matrix_format *fmt); // avs_dist.hip: local rows of a partitioned / distributed system
 avs_status build_stencils(avs_ctx *c);
+avs_status pad_stencils(avs_ctx *c, bool edge); // unused stencil slots := (-1, 0.0), before a read-back
 avs_status build_initial_guess(avs_ctx *c);
 avs_status build_initial_guess_rows(avs_ctx *c, const int32_t *ids, int64_t m);
 avs_status assemble_rows(avs_ctx *c, const int32_t *ids, int64_t m, DevBuf<int32_t> &row_ptr, DevBuf<int32_t> &col, DevBuf<double> &val,

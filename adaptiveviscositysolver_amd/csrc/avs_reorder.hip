@@ -149,35 +149,50 @@ __device__ __forceinline__ unsigned hash64(unsigned long long k)
 __global__ __launch_bounds__(kBlock) void k_vi_insert(const double *__restrict__ val, int64_t nnz, unsigned long long *__restrict__ slots,
                                                       int *__restrict__ count)
 {
-    // keys this workgroup has already seen (direct-mapped, in LDS): the matrix holds few distinct values, so almost every
-    // look-up ends here instead of in a dependent read of the global table
+    // Keys this workgroup has already seen (LDS, four probes): the matrix holds few distinct values, so almost every look-up ends
+    // here.  What has to stay rare is the GLOBAL look-up of a hot key: the 110 values of the headline matrix live in 110 lines
+    // of one L2 each, and atomics (or L2 reads) on one line serialize -- 8192 short-lived workgroups x 110 first sightings
+    // cost 1.5 ms.  Hence few, persistent workgroups (the launch), and an L1 invalidate after a compare-and-swap so that the
+    // CU's later first sightings of that key are plain L1 hits instead of another atomic on a stale "empty" line.
     __shared__ unsigned long long seen[1024];
     for (int i = threadIdx.x; i < 1024; i += kBlock) seen[i] = kEmpty;
     __syncthreads();
-    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * kBlock) {
-        const unsigned long long key = (unsigned long long)__double_as_longlong(val[k]);
-        unsigned h = hash64(key);
-        // four probes: with a direct-mapped filter two hot values that share a slot evict each other on every occurrence and
-        // send (nearly) every wave to the global table (1.5 ms on the headline matrix, whose 110 values collide 6 times)
-        bool hit = false;
+    constexpr int kU = 4; // values in flight per thread
+    for (int64_t k0 = (int64_t)blockIdx.x * kBlock * kU + threadIdx.x; k0 < nnz; k0 += (int64_t)gridDim.x * kBlock * kU) {
+        unsigned long long keys[kU];
 #pragma unroll
-        for (unsigned t = 0; t < 4u; ++t) {
-            const unsigned s = (h + t) & 1023u;
-            const unsigned long long cur = seen[s];
-            if (cur == key) { hit = true; break; }
-            if (cur == kEmpty) { seen[s] = key; break; } // it is (about to be) in the global table; losing a race only costs a repeated look-up
+        for (int u = 0; u < kU; ++u) {
+            const int64_t k = k0 + (int64_t)u * kBlock;
+            keys[u] = k < nnz ? (unsigned long long)__double_as_longlong(val[k]) : kEmpty;
         }
-        if (hit) continue;
-        for (int probe = 0; probe < (1 << kHashBits); ++probe) {
-            const unsigned long long cur = slots[h]; // hot keys: plain read hit, no atomic
-            if (cur == key) break;
-            if (cur == kEmpty) {
-                const unsigned long long old = atomicCAS(&slots[h], kEmpty, key);
-                if (old == kEmpty) { atomicAdd(count, 1); break; }
-                if (old == key) break;
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const unsigned long long key = keys[u];
+            if (key == kEmpty) continue;
+            unsigned h = hash64(key);
+            bool hit = false;
+#pragma unroll
+            for (unsigned t = 0; t < 4u; ++t) {
+                const unsigned s = (h + t) & 1023u;
+                const unsigned long long cur = seen[s];
+                if (cur == key) { hit = true; break; }
+                if (cur == kEmpty) { seen[s] = key; break; } // it is (about to be) in the global table; losing a race only costs a repeated look-up
             }
-            if (*count > 65536) return; // too many distinct values: give up early
-            h = (h + 1) & ((1u << kHashBits) - 1);
+            if (hit) continue;
+            for (int probe = 0; probe < (1 << kHashBits); ++probe) {
+                const unsigned long long cur = slots[h]; // plain read: an L1 hit for a key this CU has met before
+                if (cur == key) break;
+                if (cur == kEmpty) {
+                    const unsigned long long old = atomicCAS(&slots[h], kEmpty, key);
+                    if (old == kEmpty) atomicAdd(count, 1);
+                    if (old == kEmpty || old == key) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // drop the stale line from this CU's L1
+                        break;
+                    }
+                }
+                if (*count > 65536) return; // too many distinct values: give up early
+                h = (h + 1) & ((1u << kHashBits) - 1);
+            }
         }
     }
 }
@@ -233,7 +248,7 @@ avs_status build_value_index(const double *val, int64_t nnz, DevBuf<uint16_t> &c
     AVS_TRY(counters.alloc(2));
     AVS_HIP(hipMemsetAsync(slots.p, 0xFF, sizeof(unsigned long long) << kHashBits, st));
     AVS_HIP(hipMemsetAsync(counters.p, 0, 2 * sizeof(int), st));
-    hipLaunchKernelGGL(k_vi_insert, dim3(8192), dim3(kBlock), 0, st, val, nnz, slots.p, counters.p);
+    hipLaunchKernelGGL(k_vi_insert, dim3(1024), dim3(kBlock), 0, st, val, nnz, slots.p, counters.p); // persistent: see the kernel
     int h_count[2] = {0, 0};
     AVS_HIP(hipMemcpyAsync(h_count, counters.p, sizeof(h_count), hipMemcpyDeviceToHost, st));
     AVS_HIP(hipStreamSynchronize(st));
