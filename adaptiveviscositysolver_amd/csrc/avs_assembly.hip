@@ -26,6 +26,16 @@ namespace avs {
 
 static constexpr int kBlock = 256;
 
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const int u = __shfl_xor(v, o, 64);
+        v = u > v ? u : v;
+    }
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
 // ---------------------------------------------------------------------------------------------
 // K0: dof tables
 // ---------------------------------------------------------------------------------------------
@@ -259,85 +269,157 @@ __global__ __launch_bounds__(kBlock) void k_center_stencils(PyramidView P, const
 // The reference pops a FIFO queue of (face, weight, level); the leaves come out in lexicographic
 // (child, in-axis offset) order per level, which is the order of the mixed-radix counter below.
 // ---------------------------------------------------------------------------------------------
-// the 12^ND leaves under face `f` (ND levels up), weight `wgt` so far: all gathers first, then the fold in the FIFO's order
-template <int ND>
-__device__ __forceinline__ void restrict_group(const FieldView &V, const I3 &vr, const I3 &f, float wgt, int axis, int a1, int a2, double &acc)
+// the 12^ND leaves under face `f` (ND levels up): all gathers first ...
+__device__ __forceinline__ I3 child_face(const I3 &f, int digit, int axis, int a1, int a2) // digit = 3 * child + (offset + 1), cpp:2323
 {
-    constexpr int N = ND == 1 ? 12 : 144;
-    float leaf[N];
-#pragma unroll
-    for (int code = 0; code < N; ++code) {
-        I3 h = f;
-#pragma unroll
-        for (int d = ND - 1; d >= 0; --d) {
-            const int digit = d == 1 ? code / 12 : code % 12;
-            const int ci = digit / 3, off = digit % 3 - 1;
-            h[0] *= 2; h[1] *= 2; h[2] *= 2;
-            if (ci & 1) ++h[a1];
-            if (ci & 2) ++h[a2];
-            h[axis] += off;
-        }
-        I3 fc{{clampi(h[0], 0, vr[0] - 1), clampi(h[1], 0, vr[1] - 1), clampi(h[2], 0, vr[2] - 1)}};
-        leaf[code] = field_at(V, vr, fc);
-    }
-#pragma unroll
-    for (int code = 0; code < N; ++code) {
-        float w = wgt;
-#pragma unroll
-        for (int d = ND - 1; d >= 0; --d) {
-            const int digit = d == 1 ? code / 12 : code % 12;
-            const double rw = (digit % 3 == 1) ? (1. / 8.) : (1. / 16.); // cpp:2323
-            w = (float)(rw * (double)w);                                 // fpreal32 myWeight, cpp:2318
-        }
-        acc += (double)w * (double)leaf[code];
+    const int ci = digit / 3, off = digit % 3 - 1;
+    I3 h{{2 * f[0], 2 * f[1], 2 * f[2]}};
+    if (ci & 1) ++h[a1];
+    if (ci & 2) ++h[a2];
+    h[axis] += off;
+    return h;
+}
+
+__device__ __forceinline__ float leaf_at(const FieldView &V, const I3 &vr, const I3 &h)
+{
+    const I3 fc{{clampi(h[0], 0, vr[0] - 1), clampi(h[1], 0, vr[1] - 1), clampi(h[2], 0, vr[2] - 1)}};
+    return field_at(V, vr, fc);
+}
+
+__device__ __forceinline__ void gather_12(const FieldView &V, const I3 &vr, const I3 &f, int axis, int a1, int a2, float (&leaf)[12])
+{
+#pragma clang loop unroll(full)
+    for (int d = 0; d < 12; ++d) leaf[d] = leaf_at(V, vr, child_face(f, d, axis, a1, a2));
+}
+
+__device__ __forceinline__ void gather_144(const FieldView &V, const I3 &vr, const I3 &f, int axis, int a1, int a2, float (&leaf)[144])
+{
+#pragma clang loop unroll(full)
+    for (int d1 = 0; d1 < 12; ++d1) {
+        const I3 g = child_face(f, d1, axis, a1, a2);
+#pragma clang loop unroll(full)
+        for (int d0 = 0; d0 < 12; ++d0) leaf[d1 * 12 + d0] = leaf_at(V, vr, child_face(g, d0, axis, a1, a2));
     }
 }
 
+// ... then the fold in the FIFO's order (weight `wgt` so far; fpreal32 myWeight, cpp:2318)
+__device__ __forceinline__ float child_weight(float w, int digit)
+{
+    const double rw = (digit % 3 == 1) ? (1. / 8.) : (1. / 16.); // cpp:2323
+    return (float)(rw * (double)w);
+}
+
+__device__ __forceinline__ void fold_12(float wgt, const float (&leaf)[12], double &acc)
+{
+#pragma clang loop unroll(full)
+    for (int d = 0; d < 12; ++d) acc += (double)child_weight(wgt, d) * (double)leaf[d];
+}
+
+__device__ __forceinline__ void fold_144(float wgt, const float (&leaf)[144], double &acc)
+{
+#pragma clang loop unroll(full)
+    for (int d1 = 0; d1 < 12; ++d1) {
+        const float w1 = child_weight(wgt, d1);
+#pragma clang loop unroll(full)
+        for (int d0 = 0; d0 < 12; ++d0) acc += (double)child_weight(w1, d0) * (double)leaf[d1 * 12 + d0];
+    }
+}
+
+// A level-L row walks 12^L leaves (1728 at level 3) and the sum has to be taken in the FIFO's order.  One thread per row with
+// one dependent gather per leaf made this kernel as slow as its coarsest row (2.5 ms at 512^3, the chip idle: 106 k level-3
+// rows are 1.6 waves per SIMD).  Now levels 1 and 2 gather all their 12 / 144 leaves before folding, and a row of level >= 3
+// is spread over 4 lanes: lane t takes the t-th 144-leaf unit of the current four (144 gathers in flight in every lane), then
+// the four lanes fold one after the other, handing the running sum on -- the order of the additions is unchanged.  (The fold
+// is the serial part: with G lanes per row a wave spends G x the issue slots on it, so G stays small; 12 lanes: 0.90 ms.)
 __global__ __launch_bounds__(kBlock) void k_initial_guess(PyramidView P, const int32_t *__restrict__ vdof, int64_t n,
                                                           double *__restrict__ x0, const int32_t *__restrict__ ids)
 {
     const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (slot >= n) return;
-    const int64_t id = ids ? ids[slot] : slot; // multi-GPU: only the DOFs this rank owns (x0 stays indexed by DOF)
+    const int id = ids ? ids[slot] : (int)slot; // multi-GPU: only the DOFs this rank owns (x0 stays indexed by DOF)
     const int4 rec = reinterpret_cast<const int4 *>(vdof)[id];
     const int level = rec.x & 0xff, axis = rec.x >> 8;
+    if (level > 2) return; // k_initial_guess_coarse
     const I3 face{{rec.y, rec.z, rec.w}};
     const I3 vr = face_res(P, 0, axis);
     const FieldView &V = P.vel[axis];
+    const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
     if (level == 0) {
         x0[id] = 1.0 * (double)field_at(V, vr, face); // weight 1 (cpp:2347, 2373)
-        return;
-    }
-    const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
-    double acc = 0.;
-    if (level == 1) {
-        restrict_group<1>(V, vr, face, 1.f, axis, a1, a2, acc);
+    } else if (level == 1) {
+        float leaf[12];
+        double acc = 0.;
+        gather_12(V, vr, face, axis, a1, a2, leaf);
+        fold_12(1.f, leaf, acc);
+        x0[id] = acc;
     } else {
-        // a level-L row walks 12^L leaves (1728 at level 3): the last TWO digits are unrolled, 144 independent gathers in
-        // flight, then the fold in the reference's order -- one dependent gather per leaf made this kernel as slow as its
-        // coarsest row (2.5 ms)
-        int64_t groups = 1;
-        for (int l = 2; l < level; ++l) groups *= 12;
-        int digits[AVS_MAX_LEVELS] = {}; // odometer over the leading base-12 digits (no 64-bit divisions in the leaf loop)
-        for (int64_t g = 0; g < groups; ++g) {
-            // digits, most significant first: (child, offset) of the step from level -> level-1, ...
-            I3 f = face;
-            float wgt = 1.f;
-            for (int l = 0; l + 2 < level; ++l) {
-                const int digit = digits[l];
-                const int ci = digit / 3, off = digit % 3 - 1;
-                f[0] *= 2; f[1] *= 2; f[2] *= 2;
-                if (ci & 1) ++f[a1];
-                if (ci & 2) ++f[a2];
-                f[axis] += off;
-                const double rw = (off == 0) ? (1. / 8.) : (1. / 16.); // cpp:2323
-                wgt = (float)(rw * (double)wgt);                       // fpreal32 myWeight, cpp:2318
-            }
-            restrict_group<2>(V, vr, f, wgt, axis, a1, a2, acc);
-            for (int l = level - 3; l >= 0 && ++digits[l] == 12; --l) digits[l] = 0;
-        }
+        float leaf[144];
+        double acc = 0.;
+        gather_144(V, vr, face, axis, a1, a2, leaf);
+        fold_144(1.f, leaf, acc);
+        x0[id] = acc;
     }
-    x0[id] = acc;
+}
+
+__global__ __launch_bounds__(kBlock) void k_initial_guess_coarse(PyramidView P, const int32_t *__restrict__ vdof, int64_t n,
+                                                                 double *__restrict__ x0, const int32_t *__restrict__ ids)
+{
+    const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = slot < n;
+    const int id = valid ? (ids ? ids[slot] : (int)slot) : 0;
+    int4 rec = make_int4(0, 0, 0, 0);
+    if (valid) rec = reinterpret_cast<const int4 *>(vdof)[id];
+    const int level = rec.x & 0xff, axis = rec.x >> 8;
+    unsigned long long todo = __ballot(valid && level >= 3);
+    constexpr int G = 4;                  // lanes per row: sixteen rows at a time
+    const int s = lane / G, t = lane % G;
+    while (todo) {                        // wave-uniform
+        int src = -1;
+        for (int q = 0; q < 64 / G; ++q) {
+            const int w = todo ? __ffsll((long long)todo) - 1 : -1;
+            if (todo) todo &= todo - 1;
+            if (s == q) src = w;
+        }
+        const bool on = src >= 0;
+        const int from = on ? src : lane;
+        const int rlevel = __shfl(level, from, 64), raxis = __shfl(axis, from, 64), rid = __shfl(id, from, 64);
+        const I3 face{{__shfl(rec.y, from, 64), __shfl(rec.z, from, 64), __shfl(rec.w, from, 64)}};
+        const I3 vr = face_res(P, 0, raxis);
+        const FieldView &V = P.vel[raxis];
+        const int a1 = (raxis + 1) % 3, a2 = (raxis + 2) % 3;
+        unsigned units = 0; // 12^(level-2) units of 144 leaves
+        if (on) {
+            units = 12;
+            for (int l = 3; l < rlevel; ++l) units *= 12u;
+        }
+        const unsigned umax = (unsigned)wave_max_i32((int)units);
+        double carry = 0.;
+        for (unsigned u0 = 0; u0 < umax; u0 += G) { // G consecutive units of the row, one per lane
+            const unsigned unit = u0 + (unsigned)t;
+            const bool act = on && unit < units;
+            float leaf[144];
+            float wgt = 1.f;
+            I3 f = face;
+            if (act) {
+                // the leading level-2 digits of this lane's unit, most significant first: (child, offset) of every step down
+                unsigned pw = units / 12u; // weight of the most significant digit
+                for (int l = 0; l + 2 < rlevel; ++l) {
+                    const int digit = (int)((unit / pw) % 12u);
+                    pw = pw >= 12u ? pw / 12u : 1u;
+                    f = child_face(f, digit, raxis, a1, a2);
+                    wgt = child_weight(wgt, digit);
+                }
+            }
+            gather_144(V, vr, f, raxis, a1, a2, leaf); // idle lanes gather too (clamped, harmless): the array stays in registers
+            for (int r = 0; r < G; ++r) {              // the G units, in order: the running sum is handed from lane to lane
+                double mine = carry;
+                if (act && t == r) fold_144(wgt, leaf, mine);
+                carry = __shfl(mine, s * G + r, 64);
+            }
+        }
+        if (on && t == 0) x0[rid] = carry;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -578,16 +660,6 @@ __global__ __launch_bounds__(kBlock) void k_wave_slots(int64_t n, const int32_t 
 // SLOWER, 3.5-3.7 ms against 0.86 + 1.95 ms: the waves of transition rows publish their counts late and every later
 // workgroup waits for them.)
 static constexpr int kFast = 32;
-
-__device__ __forceinline__ int wave_max_i32(int v)
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const int u = __shfl_xor(v, o, 64);
-        v = u > v ? u : v;
-    }
-    return __builtin_amdgcn_readfirstlane(v);
-}
 
 __device__ __forceinline__ void load_cols(const int32_t *__restrict__ rc, int R, int32_t (&c)[kFast])
 {
@@ -1057,8 +1129,13 @@ avs_status build_initial_guess(avs_ctx *c)
 {
     if (!c->tables_ready) AVS_TRY(build_dof_tables(c));
     AVS_TRY(c->x0.alloc((size_t)c->n_vel));
-    if (c->n_vel) hipLaunchKernelGGL(k_initial_guess, dim3(grid_for(c->n_vel)), dim3(kBlock), 0, c->stream, c->view(), c->vdof.p, c->n_vel, c->x0.p,
-                                     (const int32_t *)nullptr);
+    if (c->n_vel) {
+        hipLaunchKernelGGL(k_initial_guess, dim3(grid_for(c->n_vel)), dim3(kBlock), 0, c->stream, c->view(), c->vdof.p, c->n_vel, c->x0.p,
+                           (const int32_t *)nullptr);
+        if (c->desc.levels > 3)
+            hipLaunchKernelGGL(k_initial_guess_coarse, dim3(grid_for(c->n_vel)), dim3(kBlock), 0, c->stream, c->view(), c->vdof.p, c->n_vel, c->x0.p,
+                               (const int32_t *)nullptr);
+    }
     AVS_HIP(hipGetLastError());
     c->guess_ready = true;
     c->guess_partial = false;
@@ -1071,7 +1148,11 @@ avs_status build_initial_guess_rows(avs_ctx *c, const int32_t *ids, int64_t m)
     if (!c->tables_ready) AVS_TRY(build_dof_tables(c));
     AVS_TRY(c->x0.alloc((size_t)c->n_vel));
     AVS_HIP(hipMemsetAsync(c->x0.p, 0, (size_t)c->n_vel * sizeof(double), c->stream));
-    if (m) hipLaunchKernelGGL(k_initial_guess, dim3(grid_for(m)), dim3(kBlock), 0, c->stream, c->view(), c->vdof.p, m, c->x0.p, ids);
+    if (m) {
+        hipLaunchKernelGGL(k_initial_guess, dim3(grid_for(m)), dim3(kBlock), 0, c->stream, c->view(), c->vdof.p, m, c->x0.p, ids);
+        if (c->desc.levels > 3)
+            hipLaunchKernelGGL(k_initial_guess_coarse, dim3(grid_for(m)), dim3(kBlock), 0, c->stream, c->view(), c->vdof.p, m, c->x0.p, ids);
+    }
     AVS_HIP(hipGetLastError());
     c->guess_ready = false; // avs_get_initial_guess / avs_build_system must not see a mostly-zero vector
     c->guess_partial = true;

@@ -146,7 +146,9 @@ __device__ __forceinline__ unsigned hash64(unsigned long long k)
     return (unsigned)k & ((1u << kHashBits) - 1);
 }
 
-__global__ __launch_bounds__(kBlock) void k_vi_insert(const double *__restrict__ val, int64_t nnz, unsigned long long *__restrict__ slots,
+static constexpr int kInsertBlock = 1024; // one LDS filter serves 16 waves: first sightings (global look-ups) per wave stay few
+
+__global__ __launch_bounds__(kInsertBlock) void k_vi_insert(const double *__restrict__ val, int64_t nnz, unsigned long long *__restrict__ slots,
                                                       int *__restrict__ count)
 {
     // Keys this workgroup has already seen (LDS, four probes): the matrix holds few distinct values, so almost every look-up ends
@@ -155,14 +157,14 @@ __global__ __launch_bounds__(kBlock) void k_vi_insert(const double *__restrict__
     // cost 1.5 ms.  Hence few, persistent workgroups (the launch), and an L1 invalidate after a compare-and-swap so that the
     // CU's later first sightings of that key are plain L1 hits instead of another atomic on a stale "empty" line.
     __shared__ unsigned long long seen[1024];
-    for (int i = threadIdx.x; i < 1024; i += kBlock) seen[i] = kEmpty;
+    for (int i = threadIdx.x; i < 1024; i += kInsertBlock) seen[i] = kEmpty;
     __syncthreads();
     constexpr int kU = 4; // values in flight per thread
-    for (int64_t k0 = (int64_t)blockIdx.x * kBlock * kU + threadIdx.x; k0 < nnz; k0 += (int64_t)gridDim.x * kBlock * kU) {
+    for (int64_t k0 = (int64_t)blockIdx.x * kInsertBlock * kU + threadIdx.x; k0 < nnz; k0 += (int64_t)gridDim.x * kInsertBlock * kU) {
         unsigned long long keys[kU];
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-            const int64_t k = k0 + (int64_t)u * kBlock;
+            const int64_t k = k0 + (int64_t)u * kInsertBlock;
             keys[u] = k < nnz ? (unsigned long long)__double_as_longlong(val[k]) : kEmpty;
         }
 #pragma unroll
@@ -248,7 +250,7 @@ avs_status build_value_index(const double *val, int64_t nnz, DevBuf<uint16_t> &c
     AVS_TRY(counters.alloc(2));
     AVS_HIP(hipMemsetAsync(slots.p, 0xFF, sizeof(unsigned long long) << kHashBits, st));
     AVS_HIP(hipMemsetAsync(counters.p, 0, 2 * sizeof(int), st));
-    hipLaunchKernelGGL(k_vi_insert, dim3(1024), dim3(kBlock), 0, st, val, nnz, slots.p, counters.p); // persistent: see the kernel
+    hipLaunchKernelGGL(k_vi_insert, dim3(256), dim3(kInsertBlock), 0, st, val, nnz, slots.p, counters.p); // persistent: see the kernel
     int h_count[2] = {0, 0};
     AVS_HIP(hipMemcpyAsync(h_count, counters.p, sizeof(h_count), hipMemcpyDeviceToHost, st));
     AVS_HIP(hipStreamSynchronize(st));
