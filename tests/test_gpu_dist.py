@@ -105,7 +105,7 @@ def test_rccl_world_size_one(built_lib):
     assert ci["launches_per_iteration"] == 2 and ci["graph_replay"]      # update (+ push), SpMV (+ finalizer block)
 
 
-@pytest.mark.parametrize("scene,world", [("beam", 2), ("varvisc", 2), ("beam128", 3)])
+@pytest.mark.parametrize("scene,world", [("beam", 2), ("varvisc", 2), ("beam128", 3), ("beam128", 8)])
 def test_processes_direct_transport(scene, world, tmp_path, built_lib):
     """One PROCESS per rank (both on cuda:0): comm blocks mapped through HIP IPC handles, halo entries stored straight into
     the neighbour's block, CG sums by flag-based all-gather -- no RCCL anywhere (hosted group, blobs through files)."""
