@@ -40,6 +40,8 @@ struct PcgScalars {
     int iter;          // completed iterations (Eigen's i)
     int done;          // 1: converged, 2: converged in this iteration (x update pending), 3: rhs == 0 (x := 0)
     int fault;         // direct transport: a peer's flag did not arrive in time (1: halo, 2: partial sums); done is set too
+    double rho_alt;    // single-GPU loop with the beta step fused into k_update_xp: r.z of odd iterations (rho: even ones), so
+                       // that the workgroups that still read the old value never race with the one that writes the new one
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1152,14 +1154,51 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, double *__restri
 
 // x += alpha p (Eigen does this before the convergence test, so it also runs in the iteration that
 // converges: done == 2 = "converged, x update pending"); then p = invd r + beta p unless converged.
-template <bool CODED>
+//
+// FUSED (single-GPU loop): the beta step -- sum of k_update_r's 2 g partial sums, convergence test, beta = r.z / old r.z --
+// is done HERE, by every workgroup for itself (8 + 8 loads per thread from L2, the same fixed order everywhere => the same
+// bits everywhere), instead of in a k_reduce launch of its own between the two vector kernels (4.9 us + a launch gap per
+// iteration).  Workgroup 0 publishes the scalars; the old r.z is read from the slot of this iteration's parity and the new
+// one written to the other slot, so a workgroup that starts late still reads what the early ones read.
+template <bool CODED, bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, double *__restrict__ x, double *__restrict__ p,
                                                       const double *__restrict__ r, const double *__restrict__ invd,
-                                                      const uint16_t *__restrict__ dcode, const PcgScalars *sc)
+                                                      const uint16_t *__restrict__ dcode, PcgScalars *sc,
+                                                      const double *__restrict__ partial = nullptr, int g = 0, int parity = 0)
 {
-    const int done = sc->done;
+    int done = sc->done;
     if (done == 1 || done == 3) return;
-    const double alpha = sc->alpha, beta = sc->beta;
+    const double alpha = sc->alpha;
+    double beta = FUSED ? 0. : sc->beta;
+    if (FUSED && done == 0) {
+        __shared__ double red[4], tot[2];
+        double rr = 0., rz = 0.;
+        for (int i = threadIdx.x; i < g; i += kBlock) {
+            rr += partial[i];
+            rz += partial[g + i];
+        }
+        rr = block_sum(rr, red);
+        rz = block_sum(rz, red);
+        if (threadIdx.x == 0) { tot[0] = rr; tot[1] = rz; }
+        __syncthreads();
+        rr = tot[0];
+        rz = tot[1];
+        const double absOld = parity ? sc->rho_alt : sc->rho;
+        if (rr < sc->threshold) done = 2; // Eigen: break before i++ (x += alpha p still pending)
+        else beta = rz / absOld;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { // what OP_BETA does
+            sc->red[0] = rr;
+            sc->red[1] = rz;
+            sc->rr = rr;
+            if (done == 2) sc->done = 2;
+            else {
+                if (parity) sc->rho = rz;
+                else sc->rho_alt = rz;
+                sc->beta = beta;
+                sc->iter += 1;
+            }
+        }
+    }
     if (done == 2) {
         for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
             x[i] += alpha * p[i];
@@ -1176,7 +1215,7 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, double *__restr
 // scalar stages.  One 256-thread block sums `nb` partials of `nred` interleaved arrays in a fixed
 // order (deterministic), then (optionally) applies the scalar update.
 // ---------------------------------------------------------------------------------------------
-enum ScalarOp { OP_NONE = 0, OP_INIT = 1, OP_RHO0 = 2, OP_ALPHA = 3, OP_BETA = 4, OP_SR_INIT = 5, OP_SR_STEP = 6 };
+enum ScalarOp { OP_NONE = 0, OP_INIT = 1, OP_RHO0 = 2, OP_ALPHA = 3, OP_BETA = 4, OP_SR_INIT = 5, OP_SR_STEP = 6, OP_ALPHA_ODD = 7 };
 
 __device__ void apply_scalar_op(PcgScalars *sc, int op, double tol)
 {
@@ -1197,8 +1236,9 @@ __device__ void apply_scalar_op(PcgScalars *sc, int op, double tol)
         if (!sc->done) sc->rho = sc->red[0];
         break;
     case OP_ALPHA:
+    case OP_ALPHA_ODD: // odd iteration of the fused loop: r.z lives in rho_alt
         if (sc->done == 2) sc->done = 1; // the pending x update of the converged iteration has run
-        else if (!sc->done) { sc->pAp = sc->red[0]; sc->alpha = sc->rho / sc->red[0]; }
+        else if (!sc->done) { sc->pAp = sc->red[0]; sc->alpha = (op == OP_ALPHA_ODD ? sc->rho_alt : sc->rho) / sc->red[0]; }
         break;
     case OP_BETA:
         if (!sc->done) {
@@ -1251,7 +1291,7 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce(const double *__restrict__
                                                       PcgScalars *sc, int op, double tol, int skip_if_done, int red_off = 0)
 {
     if (skip_if_done && sc->done) {
-        if (threadIdx.x == 0 && op == OP_ALPHA && sc->done == 2) sc->done = 1;
+        if (threadIdx.x == 0 && (op == OP_ALPHA || op == OP_ALPHA_ODD) && sc->done == 2) sc->done = 1;
         return;
     }
     __shared__ double red[kRedBlock / 64];
@@ -1280,15 +1320,15 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce(const double *__restrict__
 }
 
 // Same job with kRedBlocks workgroups for long partial arrays (the value-indexed SpMV leaves one partial per wave:
-// 116 k at 512^3): block b sums a fixed contiguous share, the block that arrives last folds the kRedBlocks sums in
-// block order and applies the scalar update -- the result does not depend on the arrival order.
-static constexpr int kRedBlocks = 8;
+// 116 k at 512^3): block b sums a fixed contiguous share (two loads per thread, one round trip), the block that arrives last
+// folds the kRedBlocks sums with a fixed tree and applies the scalar update -- the result does not depend on the arrival order.
+static constexpr int kRedBlocks = 64; // <= 64: the last block folds them with one wave
 __global__ __launch_bounds__(kRedBlock) void k_reduce_mb(const double *__restrict__ partial, int nb, int nred, PcgScalars *sc, int op,
                                                         double tol, int skip_if_done, int red_off, double *__restrict__ stage,
                                                         unsigned *__restrict__ ticket)
 {
     if (skip_if_done && sc->done) { // every block sees a non-zero flag whether or not block 0 has already stepped it
-        if (blockIdx.x == 0 && threadIdx.x == 0 && op == OP_ALPHA && sc->done == 2) sc->done = 1;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && (op == OP_ALPHA || op == OP_ALPHA_ODD) && sc->done == 2) sc->done = 1;
         return;
     }
     __shared__ double red[kRedBlock / 64];
@@ -1316,18 +1356,19 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce_mb(const double *__restric
         }
     }
     if (threadIdx.x == 0) {
-        __threadfence();
+        // the block sums went out as write-through (agent-scope) atomic stores: waiting for their acknowledgement orders them
+        // before the ticket -- an agent-scope release fence would also write back the XCD's dirty L2 (the y just computed)
+        wait_own_stores();
         last = atomicAdd(ticket, 1u) == (unsigned)(kRedBlocks - 1);
     }
     __syncthreads();
-    if (!last || threadIdx.x != 0) return;
-    __threadfence();
-    for (int q = 0; q < nred; ++q) {
-        double t = 0.;
-        for (int b = 0; b < kRedBlocks; ++b) // the workgroups ran on different XCDs (L2s): agent-scope loads after the fence
-            t += __hip_atomic_load(stage + q * kRedBlocks + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sc->red[red_off + q] = t;
+    if (!last || threadIdx.x >= 64) return;
+    for (int q = 0; q < nred; ++q) { // the workgroups ran on different XCDs (L2s): agent-scope atomic loads bypass the caches
+        const double v = threadIdx.x < kRedBlocks ? __hip_atomic_load(stage + q * kRedBlocks + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.;
+        const double t = wave_sum(v); // one load per lane, fixed summation tree: independent of the arrival order
+        if (threadIdx.x == 0) sc->red[red_off + q] = t;
     }
+    if (threadIdx.x != 0) return;
     *ticket = 0u;
     if (op != OP_NONE) apply_scalar_op(sc, op, tol);
 }
@@ -1968,18 +2009,29 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
     bool timed_chunk = true;
     bool use_graph = !dist;
     if (const char *e = getenv("AVS_PCG_GRAPH")) use_graph = use_graph && atoi(e) != 0;
+    bool fuse_beta = !dist; // multi-GPU (RCCL transport): the sums are all-reduced between the two vector kernels
+    if (const char *e = getenv("AVS_PCG_FUSE_BETA")) fuse_beta = fuse_beta && atoi(e) != 0;
+    static_assert(kChunk % 2 == 0, "the parity of an iteration is taken from its position in the chunk");
     auto enqueue_iteration = [&](int c, bool timed) -> avs_status {
         int nb = 0;
         if (dist) AVS_TRY(dist_halo_exchange(dist, p, stream));
         if (timed) AVS_HIP(hipEventRecord(w->evA[c], stream));
         AVS_TRY(spmv_dispatch<true>(A, p, t, partial, sc, variant, stream, &nb)); // tmp = A p ; p.tmp
         if (timed) AVS_HIP(hipEventRecord(w->evB[c], stream));
-        AVS_TRY(reduce_stage(w, nb, 1, OP_ALPHA, tol, 1, stream, dist));
+        // single GPU: the beta step rides in k_update_xp (4 launches per iteration); r.z alternates between two slots by the
+        // parity of the iteration -- every chunk starts at a multiple of kChunk (even), so c & 1 IS that parity
+        const int parity = fuse_beta ? (c & 1) : 0;
+        AVS_TRY(reduce_stage(w, nb, 1, parity ? OP_ALPHA_ODD : OP_ALPHA, tol, 1, stream, dist));
         if (coded) hipLaunchKernelGGL(k_update_r<true>, dim3(g), dim3(kBlock), 0, stream, n, r, t, w->invtab.p, w->dcode.p, sc, partial);
         else hipLaunchKernelGGL(k_update_r<false>, dim3(g), dim3(kBlock), 0, stream, n, r, t, invd, nullptr, sc, partial);
+        if (fuse_beta) {
+            if (coded) hipLaunchKernelGGL((k_update_xp<true, true>), dim3(g), dim3(kBlock), 0, stream, n, x, p, r, w->invtab.p, w->dcode.p, sc, partial, g, parity);
+            else hipLaunchKernelGGL((k_update_xp<false, true>), dim3(g), dim3(kBlock), 0, stream, n, x, p, r, invd, nullptr, sc, partial, g, parity);
+            return AVS_OK;
+        }
         AVS_TRY(reduce_stage(w, g, 2, OP_BETA, tol, 1, stream, dist));
-        if (coded) hipLaunchKernelGGL(k_update_xp<true>, dim3(g), dim3(kBlock), 0, stream, n, x, p, r, w->invtab.p, w->dcode.p, sc);
-        else hipLaunchKernelGGL(k_update_xp<false>, dim3(g), dim3(kBlock), 0, stream, n, x, p, r, invd, nullptr, sc);
+        if (coded) hipLaunchKernelGGL((k_update_xp<true, false>), dim3(g), dim3(kBlock), 0, stream, n, x, p, r, w->invtab.p, w->dcode.p, sc, nullptr, 0, 0);
+        else hipLaunchKernelGGL((k_update_xp<false, false>), dim3(g), dim3(kBlock), 0, stream, n, x, p, r, invd, nullptr, sc, nullptr, 0, 0);
         return AVS_OK;
     };
     while (!finished) {
@@ -2000,7 +2052,7 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
         if (w->host_sc->done || enqueued >= max_iters) break;
         const int chunk = (max_iters - enqueued) < kChunk ? (max_iters - enqueued) : kChunk;
         // some chunks are enqueued launch by launch with the SpMV timing events; the other full chunks replay one captured
-        // hipGraph (5 kernel nodes per iteration): no per-launch host work, smaller gaps between the short kernels of small
+        // hipGraph (4 kernel nodes per iteration): no per-launch host work, smaller gaps between the short kernels of small
         // systems.  Kernels past convergence exit at once, so replaying a whole chunk is always safe.
         // every kTimedChunkEvery-th chunk stays a plain, timed one so that the SpMV samples cover the whole solve
         const bool replay = use_graph && (enqueued / kChunk) % kTimedChunkEvery != 0 && chunk == kChunk && !w->graph_broken;

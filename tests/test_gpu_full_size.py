@@ -154,7 +154,9 @@ def test_distributed_assembly_at_512(built_lib):
     assert not errors, errors
     assert sum(o[2] for o in out) == nnz_ref and sum(o[3] for o in out) == iref.n
     for it, conv, _, n_own, bpn, x in out:
-        assert conv == 1 and abs(it - iref.iterations) <= 3
+        # ~1740 iterations to 1e-6: the count moves by a few with the summation order of the dot products (the single-GPU and
+        # the distributed loop fold their partial sums differently), so the check is 0.5 %, not equality
+        assert conv == 1 and abs(it - iref.iterations) <= max(3, iref.iterations // 200)
         assert 0.4 * iref.n < n_own < 0.6 * iref.n          # slabs balanced by raw triplet counts
         assert bpn == 4                                      # each rank's own dictionary, packed form
         assert float(torch.linalg.norm(x - xref) / torch.linalg.norm(xref)) < 1e-5
