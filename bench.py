@@ -16,7 +16,9 @@ including reductions and, multi-GPU, halo + all-reduce)".  The system is assembl
             "stored_*" are the bytes the kernel really has to move.
   cpu_baseline: the CPU oracle's PCG (port of the Eigen algorithm) on the same CSR system, run in a
             clean subprocess on the host cores of this box (rank 0, N=1 only): both SURVEY 8(d)
-            variants, "eigen_faithful" (parallel SpMV, serial vector ops) and "all_parallel".
+            variants, "eigen_faithful" (parallel SpMV, serial vector ops) and "all_parallel".  Its "assembly" entry is
+            the oracle's own OpenMP row-parallel assembly (stencils + restriction + CSR) of the same scene at 256^3,
+            in rows per second, next to "assembly_rows_per_s" of the device (SURVEY 8(d) "CPU assembly baseline").
 
 Workloads (--config): 4 = BASELINE configs[3] size on one GPU, 512^3 4-level fat beam, uniform
 viscosity (default, the headline); 3 = configs[2], 256^3 4-level, mu(x) = 200 (1 + 9x);
@@ -102,7 +104,7 @@ def cpu_quota():
         return None
 
 
-def cpu_baseline(solver, tol, budget_s):
+def cpu_baseline(solver, tol, budget_s, asm_scene=None):
     import numpy as np
     rp, col, val, rhs = solver.csr()
     x0 = solver.initial_guess()
@@ -120,6 +122,13 @@ def cpu_baseline(solver, tol, budget_s):
         for name, arr in (("row_ptr", rp), ("col", col), ("val", val), ("rhs", rhs), ("x0", x0)):
             np.save(os.path.join(d, name + ".npy"), arr)
         del rp, col, val
+        if asm_scene is not None:   # the oracle's own assembly, on a smaller instance of the scene (see oracle/cpu_baseline.py)
+            sc = asm_scene
+            np.save(os.path.join(d, "asm_liquid.npy"), sc.liquid.detach().cpu().numpy())
+            for ax in range(3):
+                np.save(os.path.join(d, f"asm_vel{ax}.npy"), sc.velocity[ax].detach().cpu().numpy())
+            json.dump({"res": list(sc.res), "dx": sc.dx, "dt": sc.dt, "levels": sc.levels, "viscosity": float(sc.viscosity),
+                       "density": float(sc.density), "name": sc.name}, open(os.path.join(d, "asm_meta.json"), "w"))
         env = {k: v for k, v in os.environ.items() if not k.startswith(("OMP_", "GOMP_", "KMP_"))}
         env.update(OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_DYNAMIC="false")
         cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), d, repr(tol), repr(budget_s), str(threads)]
@@ -134,7 +143,7 @@ def cpu_baseline(solver, tol, budget_s):
                    "reference CMakeLists.txt:27-32)",
         "cpu_model": r["cpu_model"], "logical_cpus_in_mask": len(cpus), "cgroup_cpu_quota": quota, "threads": threads,
         "omp": "OMP_PROC_BIND=close OMP_PLACES=cores, clean subprocess (no torch / second OpenMP runtime loaded)",
-        "eigen_faithful": ef, "all_parallel": apar,
+        "eigen_faithful": ef, "all_parallel": apar, "assembly": r.get("assembly"),
         "sample": f"{ef['iterations']} + {apar['iterations']} PCG iterations (eigen_faithful + all_parallel) of the same "
                   f"{r['n']}-row system, {ef['seconds']:.1f} + {apar['seconds']:.1f} s; SpMV {ef['spmv_gbps']:.0f} GB/s "
                   f"(SURVEY 8(d) bytes) on {threads} threads"}
@@ -420,7 +429,15 @@ def main():
             out["dist"] = {"per_rank": [dict(zip(("n_own", "n_halo", "nnz_local", "n_send", "n_peers"), r)) for r in per_rank],
                            **solver.dist_comm_info(), "verification": verification}
         if world == 1 and not a.no_cpu_baseline and not use_dist:
-            out["cpu_baseline"] = cpu_baseline(solver, a.tol, a.cpu_seconds)
+            # CPU assembly baseline: the oracle's own assembly of the same scene at 256^3 (rows per second)
+            asm_scene = None
+            if a.config in (None, 1, 2, 3, 4) and not getattr(a, "no_cpu_assembly", False):
+                asm_scene = scenes.fat_beam(256, 4, variable_viscosity=False, device="cpu")
+            out["cpu_baseline"] = cpu_baseline(solver, a.tol, a.cpu_seconds, asm_scene)
+            cb_asm = out["cpu_baseline"].get("assembly")
+            if cb_asm:
+                out["assembly_rows_per_s"] = n / (assemble_wall_ms * 1e-3)
+                out["speedup_assembly_vs_cpu_rows_per_s"] = out["assembly_rows_per_s"] / cb_asm["rows_per_s"]
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             out["speedup_vs_cpu_all_parallel"] = out["value"] / out["cpu_baseline"]["all_parallel"]["iter_per_s"]
         emit(out)

@@ -10,7 +10,12 @@ SURVEY.md 8(d) asks for two variants of the reference's CPU solve on the same CS
                    Lower|Upper> does when built with -fopenmp (reference CMakeLists.txt:27-32)
   all_parallel   : every vector operation parallel too (a generous baseline)
 
-usage: cpu_baseline.py <dir with row_ptr.npy col.npy val.npy rhs.npy x0.npy> <tol> <budget_seconds> <threads>
+It also times the oracle's own (OpenMP row-parallel) assembly, SURVEY 8(d) "CPU assembly baseline", on a SMALLER instance
+of the same scene (asm_*.npy in the same directory: liquid SDF + velocity of the fat beam at 256^3, 4 levels -- the 512^3
+pyramids are ~8 GB of host arrays and minutes of serial pre-pass, too much for a default bench run): pre-pass, then
+stencils + restriction + CSR, reported as rows per second.
+
+usage: cpu_baseline.py <dir with row_ptr.npy col.npy val.npy rhs.npy x0.npy [asm_meta.json asm_*.npy]> <tol> <budget_seconds> <threads>
 prints one JSON object.
 """
 from __future__ import annotations
@@ -90,7 +95,33 @@ def main():
             "iter_per_s": done / info.seconds, "iterations": done, "seconds": info.seconds,
             "spmv_share": info.spmv_seconds / max(info.seconds, 1e-12),
             "spmv_gbps": spmv_bytes / max(per_spmv, 1e-12) / 1e9, "spmv_threads": threads, "vector_threads": vt}
+    meta_path = os.path.join(d, "asm_meta.json")
+    if os.path.exists(meta_path):
+        out["assembly"] = time_assembly(d, json.load(open(meta_path)), threads)
     print(json.dumps(out))
+
+
+def time_assembly(d, meta, threads):
+    """the oracle's pre-pass + assembly of the scene dumped by bench.py (OMP_NUM_THREADS is already set for this process)"""
+    sys.path.insert(0, HERE)
+    import oracle as O
+    o = O.Oracle(*meta["res"], meta["dx"], meta["dt"], meta["levels"], True)
+    o.set_field(O.F_LIQUID, np.load(os.path.join(d, "asm_liquid.npy")))
+    o.set_field(O.F_VISCOSITY, None, float(meta["viscosity"]))
+    o.set_field(O.F_DENSITY, None, float(meta["density"]))
+    for a in range(3):
+        o.set_field(O.F_VELOCITY + a, np.load(os.path.join(d, f"asm_vel{a}.npy")))
+    t0 = time.perf_counter()
+    o.prepass()
+    t1 = time.perf_counter()
+    o.build_stencils()
+    o.build_initial_guess()
+    o.assemble()
+    t2 = time.perf_counter()
+    m = o.csr()
+    n, nnz = len(m.rhs), int(m.row_ptr[-1])
+    return {"workload": meta["name"], "rows": n, "nnz": nnz, "levels": int(o.levels), "threads": threads,
+            "prepass_seconds": t1 - t0, "assembly_seconds": t2 - t1, "rows_per_s": n / max(t2 - t1, 1e-9)}
 
 
 if __name__ == "__main__":
