@@ -28,6 +28,8 @@ static constexpr int kVecGrid = 2048;        // grid-stride vector kernels: 8 bl
 static constexpr int kStreamCap = 4096;      // LDS products per tile (32 KiB)
 static constexpr int kChunk = 32;            // iterations enqueued between host polls
 static constexpr int kTimedChunkEvery = 8; // hipGraph replay: 1 chunk in 8 is enqueued launch by launch with timing events
+static constexpr int kFuseAlphaMax = 4096;   // single-GPU loop: SpMV partial sums that k_update_r's workgroups fold themselves (<= 262 k rows;
+                                             // 5.9 k partials at 380 k rows: 27.1 -> 25.4 k it/s, so not beyond)
 static constexpr int kSampleEvery = 4;       // SpMV launches bracketed by HIP events: every 4th (events are not free)
 
 struct PcgScalars {
@@ -1129,14 +1131,37 @@ __global__ __launch_bounds__(kBlock) void k_inv_diag_coded(CsrView A, uint16_t *
 
 // r -= alpha t ; partials: r.r and r.(invd r).  (x += alpha p rides along with the p update below:
 // one vector pass less per iteration -- 10 n instead of 11 n doubles of traffic.)
-template <bool CODED>
+// FUSED (single-GPU loop, small systems): the alpha step -- fold of the SpMV's `nb` partial sums, alpha = r.z / p.Ap -- is done
+// here by every workgroup for itself, as k_update_xp does with the beta step; only worth it while the SpMV leaves few
+// partials (one per wave of 64 rows): the loop uses it up to kFuseAlphaMax of them.  The kernel's own partial sums then go
+// to a second array (`partial`), because other workgroups are still reading the SpMV's.
+template <bool CODED, bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, double *__restrict__ r, const double *__restrict__ t,
                                                      const double *__restrict__ invd, const uint16_t *__restrict__ dcode,
-                                                     const PcgScalars *sc, double *__restrict__ partial)
+                                                     PcgScalars *sc, double *__restrict__ partial,
+                                                     const double *__restrict__ spmv_partial = nullptr, int nb = 0, int parity = 0)
 {
-    if (sc->done) return;
+    if (sc->done) {
+        if (FUSED && blockIdx.x == 0 && threadIdx.x == 0 && sc->done == 2) sc->done = 1; // the pending x update has run (OP_ALPHA)
+        return;
+    }
     __shared__ double red[4];
-    const double alpha = sc->alpha;
+    double alpha;
+    if (FUSED) {
+        __shared__ double tot;
+        double pap = 0.;
+        for (int k = threadIdx.x; k < nb; k += kBlock) pap += spmv_partial[k];
+        pap = block_sum(pap, red);
+        if (threadIdx.x == 0) tot = pap;
+        __syncthreads();
+        pap = tot;
+        alpha = (parity ? sc->rho_alt : sc->rho) / pap;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { // what OP_ALPHA does
+            sc->red[0] = pap;
+            sc->pAp = pap;
+            sc->alpha = alpha;
+        }
+    } else alpha = sc->alpha;
     double rr = 0., rz = 0.;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const double ri = r[i] - alpha * t[i];
@@ -2021,12 +2046,19 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
         // single GPU: the beta step rides in k_update_xp (4 launches per iteration); r.z alternates between two slots by the
         // parity of the iteration -- every chunk starts at a multiple of kChunk (even), so c & 1 IS that parity
         const int parity = fuse_beta ? (c & 1) : 0;
-        AVS_TRY(reduce_stage(w, nb, 1, parity ? OP_ALPHA_ODD : OP_ALPHA, tol, 1, stream, dist));
-        if (coded) hipLaunchKernelGGL(k_update_r<true>, dim3(g), dim3(kBlock), 0, stream, n, r, t, w->invtab.p, w->dcode.p, sc, partial);
-        else hipLaunchKernelGGL(k_update_r<false>, dim3(g), dim3(kBlock), 0, stream, n, r, t, invd, nullptr, sc, partial);
+        const bool fuse_alpha = fuse_beta && nb <= kFuseAlphaMax; // few SpMV partials: every workgroup of k_update_r folds them itself
+        double *vpart = fuse_alpha ? partial + (w->npartial / 2) : partial; // (the SpMV's are still being read)
+        if (fuse_alpha) {
+            if (coded) hipLaunchKernelGGL((k_update_r<true, true>), dim3(g), dim3(kBlock), 0, stream, n, r, t, w->invtab.p, w->dcode.p, sc, vpart, partial, nb, parity);
+            else hipLaunchKernelGGL((k_update_r<false, true>), dim3(g), dim3(kBlock), 0, stream, n, r, t, invd, nullptr, sc, vpart, partial, nb, parity);
+        } else {
+            AVS_TRY(reduce_stage(w, nb, 1, parity ? OP_ALPHA_ODD : OP_ALPHA, tol, 1, stream, dist));
+            if (coded) hipLaunchKernelGGL((k_update_r<true, false>), dim3(g), dim3(kBlock), 0, stream, n, r, t, w->invtab.p, w->dcode.p, sc, partial, nullptr, 0, 0);
+            else hipLaunchKernelGGL((k_update_r<false, false>), dim3(g), dim3(kBlock), 0, stream, n, r, t, invd, nullptr, sc, partial, nullptr, 0, 0);
+        }
         if (fuse_beta) {
-            if (coded) hipLaunchKernelGGL((k_update_xp<true, true>), dim3(g), dim3(kBlock), 0, stream, n, x, p, r, w->invtab.p, w->dcode.p, sc, partial, g, parity);
-            else hipLaunchKernelGGL((k_update_xp<false, true>), dim3(g), dim3(kBlock), 0, stream, n, x, p, r, invd, nullptr, sc, partial, g, parity);
+            if (coded) hipLaunchKernelGGL((k_update_xp<true, true>), dim3(g), dim3(kBlock), 0, stream, n, x, p, r, w->invtab.p, w->dcode.p, sc, vpart, g, parity);
+            else hipLaunchKernelGGL((k_update_xp<false, true>), dim3(g), dim3(kBlock), 0, stream, n, x, p, r, invd, nullptr, sc, vpart, g, parity);
             return AVS_OK;
         }
         AVS_TRY(reduce_stage(w, g, 2, OP_BETA, tol, 1, stream, dist));
