@@ -275,6 +275,7 @@ static avs_status direct_prepare(avs_ctx *c, PcgDist *d)
     d->comm_block = p;
     d->comm_bytes = bytes;
     AVS_HIP(hipMemset(p, 0, bytes));
+    AVS_HIP(hipMemset((char *)p + offsetof(CommHeader, red), 0xFF, sizeof(CommHeader::red))); // partial-sum slots: armed (sentinel)
     DistBlob b;
     memset(&b, 0, sizeof(b));
     b.magic = kBlobMagic;
@@ -1381,6 +1382,7 @@ static avs_status direct_connect_loopback(avs_ctx *c, PcgDist *d)
     void *p = nullptr;
     AVS_HIP(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained));
     AVS_HIP(hipMemset(p, 0, bytes));
+    AVS_HIP(hipMemset((char *)p + offsetof(CommHeader, red), 0xFF, sizeof(CommHeader::red)));
     d->comm_block = p;
     d->comm_bytes = bytes;
     std::vector<uint8_t> blobs((size_t)d->world * AVS_DIST_BLOB_BYTES, 0);
@@ -1405,7 +1407,7 @@ static avs_status direct_connect_loopback(avs_ctx *c, PcgDist *d)
     CommHeader *mine = (CommHeader *)d->comm_block;
     for (int i = 0; i < h.npeers; ++i) h.peer_hflag_dst[i] = &mine->hflag[h.peer_rank[i]];
     for (int q = 0; q < d->world; ++q) {
-        h.all_red_dst[q] = &mine->red[0][d->rank][0];
+        h.all_red_dst[q] = &mine->red[0][q][0]; // as if rank q had written its sums into my block
         h.all_rflag_dst[q] = &mine->rflag[q];
     }
     // a peer that only sends to me (no entry from me to it) would never get its flag raised: give every receive a sender

@@ -273,8 +273,9 @@ constexpr int kMaxRanks = 32;
 
 struct CommHeader {                               // start of every comm block (device memory, written by peers)
     unsigned long long hflag[kMaxRanks];          // hflag[q]: epoch of the last halo rank q completed in my halo area
-    unsigned long long rflag[kMaxRanks];          // rflag[q]: epoch of rank q's latest partial sums
-    double red[2][kMaxRanks][4];                  // the partial sums, double-buffered by epoch parity
+    unsigned long long rflag[kMaxRanks];          // (unused since the partial-sum slots carry their own arrival: kept for the layout)
+    double red[2][kMaxRanks][4];                  // the partial sums, double-buffered by epoch parity; armed with an all-ones NaN,
+                                                  // a slot is "there" as soon as it holds anything else (re-armed by its reader)
 };
 
 struct DistDev {                                  // device-resident, read-only for the kernels of one plan

@@ -176,7 +176,7 @@ __device__ __forceinline__ void halo_wait(const HaloView &hv)
 }
 
 // Last workgroup of the halo-touching SpMV launch: fold the round's partial sums (fixed order), exchange them with every
-// rank through the comm blocks (each rank stores its 4 sums into every block, parity-buffered, then raises its flag),
+// rank through the comm blocks (each rank stores its 4 sums into every block, parity-buffered, sentinel-armed slots),
 // add the contributions in RANK order -- every rank computes bit-identical scalars, so all ranks take the same
 // convergence decision in the same iteration -- and apply the scalar step.  Replaces k_reduce + ncclAllReduce + k_scalar.
 template <int BLK>
@@ -237,20 +237,32 @@ __device__ void dist_finalize(const HaloView &hv, double acc[4])
     __syncthreads();
     const unsigned long long E = *hv.epoch + 1ull;
     const int par = (int)(E & 1ull);
-    if (tid < dd->world * 4) { // one lane per (rank, value): the exchanges travel in parallel, their return acknowledges them
+    if (tid < dd->world * 4) {
+        // One lane per (rank, value).  The value IS the message: every slot of red[parity] is armed with the sentinel (an
+        // all-ones NaN), a rank drops its 4 sums into its slots of every block with fire-and-forget write-through stores, and
+        // every rank watches the world x 4 slots of its OWN block until none holds the sentinel -- one one-way trip after the
+        // slowest rank, instead of exchange (round trip) + flag (one way) + read.  A consumed slot is re-armed at once; it is
+        // written again two rounds later, after its writer has seen this rank's contribution to the round in between.
         const int q = tid >> 2, k = tid & 3;
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(dd->all_red_dst[q] + (size_t)par * kMaxRanks * 4 + k);
-        const unsigned long long old = __hip_atomic_exchange(dst, (unsigned long long)__double_as_longlong(fin_sum[k]), __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_SYSTEM);
-        if (old == 0x7ff8dead7ff8deadull) fin_sum[0] = 0.; // never true: keeps the exchange's result (= its completion) alive
+        st_sys(dst, (unsigned long long)__double_as_longlong(fin_sum[k]));
+        unsigned long long *src = reinterpret_cast<unsigned long long *>(&dd->mine->red[par][q][k]);
+        unsigned long long v = ld_sys(src);
+        if (v == kSentinel) {
+            const long long t0 = wall_clock64();
+            while ((v = ld_sys(src)) == kSentinel) {
+                if (wall_clock64() - t0 > dd->timeout_ticks) {
+                    __hip_atomic_store(&hv.sc->fault, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&hv.sc->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v = 0ull;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        fin_all[tid] = __longlong_as_double((long long)v);
+        st_sys(src, kSentinel);
     }
-    __syncthreads();
-    if (tid < dd->world) {
-        st_sys(dd->all_rflag_dst[tid], E);
-        wait_flag(&dd->mine->rflag[tid], E, dd->timeout_ticks, hv.sc, 2);
-    }
-    __syncthreads();
-    if (tid < dd->world * 4) fin_all[tid] = ld_sys_f64(&dd->mine->red[par][tid >> 2][tid & 3]); // all contributions in parallel
     __syncthreads();
     if (tid == 0) {
         for (int k = 0; k < nred; ++k) {
