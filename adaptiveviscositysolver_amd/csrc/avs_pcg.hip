@@ -2103,7 +2103,7 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
         timed_chunk = !replay;
         if (replay) {
             const void *key[10] = {A.row_ptr, A.col, A.val, A.codes, A.packed, A.table, x, (const void *)(intptr_t)A.n,
-                                   (const void *)(intptr_t)(A.table_size * 64 + A.col_bits), (const void *)(intptr_t)(coded ? 1 : 0)};
+                                   (const void *)(intptr_t)(A.table_size * 64 + A.col_bits), (const void *)(intptr_t)((coded ? 1 : 0) | (fuse_beta ? 2 : 0))};
             if (w->graph && (memcmp(key, w->graph_key, sizeof(key)) != 0 || w->graph_tol != tol)) {
                 (void)hipGraphExecDestroy(w->graph);
                 w->graph = nullptr;

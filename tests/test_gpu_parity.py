@@ -302,6 +302,38 @@ def test_solve_is_deterministic(graph, dev, built_lib, monkeypatch):
     s.close()
 
 
+@pytest.mark.parametrize("n0", [64, 128])
+def test_fused_scalar_steps_match_separate_reductions(n0, dev, built_lib, monkeypatch):
+    """Single-GPU loop: the beta step folded into k_update_xp (and, for <= 4096 SpMV partials -- the 64^3 case --, the alpha
+    step folded into k_update_r) against the loop with a k_reduce launch per step.  Same algorithm, different summation
+    trees: same iteration count +-1 and the same solution to rounding; iteration caps that stop in an odd / even
+    iteration exercise the parity-slotted r.z; repeated and interleaved solves on one context must not leak state."""
+    sc = scenes.fat_beam(n0, 3, device=dev)
+    pyr = build_pyramid(sc)
+    s = gpu_solve_for(sc, pyr)
+    s.assemble()
+    ref = {}
+    for mode in ("0", "1", "0", "1"):
+        monkeypatch.setenv("AVS_PCG_FUSE_BETA", mode)
+        info = s.solve(1e-9, 5000)
+        x = s.solution()
+        assert info.converged == 1
+        if mode in ref:                                  # same mode again: bit for bit (fixed summation orders)
+            assert info.iterations == ref[mode][0] and np.array_equal(x, ref[mode][1])
+        ref[mode] = (info.iterations, x)
+    assert abs(ref["1"][0] - ref["0"][0]) <= 1
+    assert rel_l2(ref["1"][1], ref["0"][1]) < 1e-8
+    for cap in (1, 2, 31, 32, 33, 64, 65):               # stop by the cap: x after exactly `cap` iterations in both loops
+        xs = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("AVS_PCG_FUSE_BETA", mode)
+            info = s.solve(1e-12, cap)
+            assert info.iterations == cap and info.converged == 0
+            xs[mode] = s.solution()
+        assert rel_l2(xs["1"], xs["0"]) < 1e-10, cap
+    s.close()
+
+
 def test_graph_replay_equals_plain_launches(dev, built_lib, monkeypatch):
     """Replaying captured hipGraph chunks runs the same kernels on the same data: identical iterations and solution."""
     sc = scenes.fat_beam(64, 3, device=dev)
