@@ -50,12 +50,14 @@ static inline unsigned grid_for(size_t n, unsigned cap = 1u << 20)
 // ---------------------------------------------------------------------------------------------
 // P1: weights
 // ---------------------------------------------------------------------------------------------
-// One 512-thread workgroup = one 8x8x8 brick of sample indices, for ALL SEVEN weight fields at once (centre, 3 edge,
+// One 512-thread workgroup = one 32x4x4 brick of sample indices, for ALL SEVEN weight fields at once (centre, 3 edge,
 // 3 face lattices differ only in which axes are cell-centred).  The SDF cells the brick can touch (di = -2 .. +1 around
-// every sample => an 11^3 window, clamped at the border) are staged in LDS once; the sign shortcuts and the 27 trilinear
-// sub-samples of every field then read LDS only.
-static constexpr int kWB = 8;             // brick edge
-static constexpr int kWH = kWB + 3;       // staged window edge: offsets -2 .. kWB
+// every sample => a 35x7x7 window, clamped at the border) are staged in LDS once; the sign shortcuts and the 27 trilinear
+// sub-samples of every field then read LDS only.  The brick is long in x: a wave stores two full 128-B runs per field
+// (an 8^3 brick wrote 32-B pieces, and the kernel -- mostly bricks far from the surface, which only store -- ran at 1 TB/s).
+static constexpr int kWBX = 32, kWBY = 4, kWBZ = 4;                    // brick extents
+static constexpr int kWHX = kWBX + 3, kWHY = kWBY + 3, kWHZ = kWBZ + 3; // staged window: offsets -2 .. extent
+static constexpr int kWThreads = kWBX * kWBY * kWBZ;
 static constexpr int kWFields = 7;
 
 struct WeightFields {
@@ -67,17 +69,53 @@ struct WeightFields {
     int n;
 };
 
-__global__ __launch_bounds__(kWB *kWB *kWB) void k_sdf_weights(const float *__restrict__ sdf, Grid3 src, Grid3 bricks, WeightFields F)
+// Pass 1 (every brick): the brick-level form of the exact sign shortcut -- a window of one sign gives every sample of the
+// brick n^3 or 0.  Away from the surface that is almost every brick; they are finished here (seven coalesced stores per
+// thread, few registers, full occupancy).  Bricks whose window changes sign go on a list for k_sdf_weights, whose 150
+// registers allow ONE workgroup per CU: run over all bricks it spent most of its time waiting for the window loads of bricks
+// that needed no arithmetic (5.8 ms at 512^3, 45.6 ms at 1024^3).
+__global__ __launch_bounds__(kWThreads) void k_sdf_weights_far(const float *__restrict__ sdf, Grid3 src, Grid3 bricks, WeightFields F,
+                                                               int32_t *__restrict__ near_list /* [0]: count, then brick ids */)
 {
-    __shared__ float win[kWH * kWH * kWH];
+    const int n = F.n;
+    const int b = blockIdx.x;
+    const int o0[3] = {(b % bricks.r[0]) * kWBX, ((b / bricks.r[0]) % bricks.r[1]) * kWBY, (b / (bricks.r[0] * bricks.r[1])) * kWBZ};
+    int seen_neg = 0, seen_pos = 0;
+    for (int w = threadIdx.x; w < kWHX * kWHY * kWHZ; w += kWThreads) {
+        const int wx = w % kWHX, wy = (w / kWHX) % kWHY, wz = w / (kWHX * kWHY);
+        const float v = sdf[lin3(src, clampi(o0[0] - 2 + wx, 0, src.r[0] - 1), clampi(o0[1] - 2 + wy, 0, src.r[1] - 1),
+                                 clampi(o0[2] - 2 + wz, 0, src.r[2] - 1))];
+        if (v < 0.f) seen_neg = 1;
+        else seen_pos = 1;
+    }
+    const int any_neg = __syncthreads_or(seen_neg);
+    const int any_pos = __syncthreads_or(seen_pos);
+    if (any_pos && any_neg) {
+        if (threadIdx.x == 0) near_list[1 + atomicAdd(near_list, 1)] = b; // (the order of the list does not matter)
+        return;
+    }
+    const float value = (float)(any_neg ? n * n * n : 0) / (float)(n * n * n);
+    const int t = threadIdx.x;
+    const int p[3] = {o0[0] + t % kWBX, o0[1] + (t / kWBX) % kWBY, o0[2] + t / (kWBX * kWBY)};
+    for (int f = 0; f < kWFields; ++f) {
+        const Grid3 tgt = F.tgt[f];
+        if (p[0] < tgt.r[0] && p[1] < tgt.r[1] && p[2] < tgt.r[2]) F.out[f][lin3(tgt, p[0], p[1], p[2])] = value;
+    }
+}
+
+// Pass 2: the bricks near the surface (near_list), everything from LDS.
+__global__ __launch_bounds__(kWThreads) void k_sdf_weights(const float *__restrict__ sdf, Grid3 src, Grid3 bricks, WeightFields F,
+                                                           const int32_t *__restrict__ near_list)
+{
+    __shared__ float win[kWHX * kWHY * kWHZ];
     const int n = F.n;
     const float n3 = (float)(n * n * n);
-    const int b = blockIdx.x;
-    const int o0[3] = {(b % bricks.r[0]) * kWB, ((b / bricks.r[0]) % bricks.r[1]) * kWB, (b / (bricks.r[0] * bricks.r[1])) * kWB};
+    const int b = near_list[1 + blockIdx.x];
+    const int o0[3] = {(b % bricks.r[0]) * kWBX, ((b / bricks.r[0]) % bricks.r[1]) * kWBY, (b / (bricks.r[0] * bricks.r[1])) * kWBZ};
     // window cell (wx, wy, wz) holds sdf at clamp(o0 - 2 + w): clamping here reproduces the clamped reads below
     int seen_neg = 0, seen_pos = 0;
-    for (int w = threadIdx.x; w < kWH * kWH * kWH; w += kWB * kWB * kWB) {
-        const int wx = w % kWH, wy = (w / kWH) % kWH, wz = w / (kWH * kWH);
+    for (int w = threadIdx.x; w < kWHX * kWHY * kWHZ; w += kWThreads) {
+        const int wx = w % kWHX, wy = (w / kWHX) % kWHY, wz = w / (kWHX * kWHY);
         const float v = sdf[lin3(src, clampi(o0[0] - 2 + wx, 0, src.r[0] - 1), clampi(o0[1] - 2 + wy, 0, src.r[1] - 1),
                                  clampi(o0[2] - 2 + wz, 0, src.r[2] - 1))];
         win[w] = v;
@@ -89,12 +127,12 @@ __global__ __launch_bounds__(kWB *kWB *kWB) void k_sdf_weights(const float *__re
     const int any_neg = __syncthreads_or(seen_neg);
     const int any_pos = __syncthreads_or(seen_pos);
     const int t = threadIdx.x;
-    const int p[3] = {o0[0] + t % kWB, o0[1] + (t / kWB) % kWB, o0[2] + t / (kWB * kWB)};
-    // NB: unclamped source coordinates c in [o0-2, o0+kWB] map to the window cell that was filled with the clamped
+    const int p[3] = {o0[0] + t % kWBX, o0[1] + (t / kWBX) % kWBY, o0[2] + t / (kWBX * kWBY)};
+    // NB: unclamped source coordinates c in [o0-2, o0+extent] map to the window cell that was filled with the clamped
     // coordinate, so `at` returns exactly what the reference's clamped read returns.
     auto at = [&](int cx, int cy, int cz) {
-        const int ix = clampi(cx - (o0[0] - 2), 0, kWH - 1), iy = clampi(cy - (o0[1] - 2), 0, kWH - 1), iz = clampi(cz - (o0[2] - 2), 0, kWH - 1);
-        return win[ix + kWH * (iy + kWH * iz)];
+        const int ix = clampi(cx - (o0[0] - 2), 0, kWHX - 1), iy = clampi(cy - (o0[1] - 2), 0, kWHY - 1), iz = clampi(cz - (o0[2] - 2), 0, kWHZ - 1);
+        return win[ix + kWHX * (iy + kWHY * iz)];
     };
     for (int f = 0; f < kWFields; ++f) {
         const Grid3 tgt = F.tgt[f];
@@ -561,6 +599,7 @@ struct avs_prepass {
     bool have_solid = false;
     DevBuf<int8_t> mask, labels[AVS_MAX_LEVELS];
     DevBuf<int32_t> vidx[AVS_MAX_LEVELS][3], eidx[AVS_MAX_LEVELS][3], cidx[AVS_MAX_LEVELS], ridx[3];
+    DevBuf<int32_t> near_list; // k_sdf_weights_far: [0] = count, then the bricks whose SDF window changes sign
     int64_t counts[4] = {0, 0, 0, 0}; // velocity, edge, centre, regular
     double ms[4] = {0, 0, 0, 0};
     bool ready = false;
@@ -597,8 +636,17 @@ static avs_status run_weights(avs_prepass *p, WeightFields &F)
         for (int s = 0; s < F.n; ++s) sub_consts(F.n, c == 1, s, &F.di[c][s], &F.fr[c][s]);
     int sr[3];
     pp_res(p->desc, 2, 0, 0, sr);
-    const Grid3 bricks{{(sr[0] + 1 + kWB - 1) / kWB, (sr[1] + 1 + kWB - 1) / kWB, (sr[2] + 1 + kWB - 1) / kWB}};
-    hipLaunchKernelGGL(k_sdf_weights, dim3((unsigned)bricks.vol()), dim3(kWB * kWB * kWB), 0, p->stream, p->liquid.p, g3(sr), bricks, F);
+    const Grid3 bricks{{(sr[0] + 1 + kWBX - 1) / kWBX, (sr[1] + 1 + kWBY - 1) / kWBY, (sr[2] + 1 + kWBZ - 1) / kWBZ}};
+    const size_t nb = bricks.vol();
+    AVS_TRY(p->near_list.reserve(nb + 1));
+    AVS_HIP(hipMemsetAsync(p->near_list.p, 0, sizeof(int32_t), p->stream));
+    hipLaunchKernelGGL(k_sdf_weights_far, dim3((unsigned)nb), dim3(kWThreads), 0, p->stream, p->liquid.p, g3(sr), bricks, F, p->near_list.p);
+    int32_t n_near = 0;
+    AVS_HIP(hipMemcpyAsync(&n_near, p->near_list.p, sizeof(int32_t), hipMemcpyDeviceToHost, p->stream));
+    AVS_HIP(hipStreamSynchronize(p->stream));
+    if (n_near > 0)
+        hipLaunchKernelGGL(k_sdf_weights, dim3((unsigned)n_near), dim3(kWThreads), 0, p->stream, p->liquid.p, g3(sr), bricks, F,
+                           (const int32_t *)p->near_list.p);
     AVS_HIP(hipGetLastError());
     return AVS_OK;
 }
