@@ -243,10 +243,32 @@ __global__ __launch_bounds__(kBlock) void k_nodes_distribute(PyramidView P, Post
 __device__ double interp_sp_grid(const PyramidView &P, const PostView &W, const I3 &P2, int axis)
 {
     const int L = P.levels;
-    I3 cell{{P2[0] >> 1, P2[1] >> 1, P2[2] >> 1}}; // floor(indexPoint) on the level-0 node lattice
-    for (int level = 0; level < L; ++level) {
-        const I3 cr = cell_res(P, level);
-        if (P.labels[level][lin(cr, clamp3(cell, cr))] == AVS_ACTIVE) {
+    // The reference walks up from level 0 until it meets an ACTIVE cell: up to `levels` DEPENDENT reads (all of them for a
+    // face deep inside a coarse cell -- most faces that come here).  All candidate labels are requested at once instead and
+    // the lowest ACTIVE level is picked: same answer, one memory round trip.
+    int found = -1;
+    {
+        I3 c{{P2[0] >> 1, P2[1] >> 1, P2[2] >> 1}}; // floor(indexPoint) on the level-0 node lattice
+        int8_t lab[AVS_MAX_LEVELS];
+#pragma unroll
+        for (int level = 0; level < AVS_MAX_LEVELS; ++level) {
+            lab[level] = 0;
+            if (level < L) {
+                const I3 cr = cell_res(P, level);
+                lab[level] = P.labels[level][lin(cr, clamp3(c, cr))];
+                c = half3(c);
+            }
+        }
+#pragma unroll
+        for (int level = AVS_MAX_LEVELS - 1; level >= 0; --level)
+            if (level < L && lab[level] == AVS_ACTIVE) found = level;
+    }
+    if (found < 0) return 0.; // reference: assert(false)
+    I3 cell{{P2[0] >> 1, P2[1] >> 1, P2[2] >> 1}};
+    for (int l = 0; l < found; ++l) cell = half3(cell);
+    {
+        const int level = found;
+        {
             const double scale = (double)(1 << (level + 1)); // half fine cells per cell of this level
             double ifp[3];
             I3 face;
@@ -256,8 +278,9 @@ __device__ double interp_sp_grid(const PyramidView &P, const PostView &W, const 
                 face[a] = (int)floor(ifp[a]);
             }
             bool transition = false;
-            for (int fi = 0; fi < 8 && !transition; ++fi) // HDKcellToNode(face, fi), interp.cpp:683-698
-                transition = vidx_clamped(P, level, axis, I3{{face[0] + (fi & 1), face[1] + ((fi >> 1) & 1), face[2] + ((fi >> 2) & 1)}}) == AVS_UNASSIGNED;
+#pragma unroll
+            for (int fi = 0; fi < 8; ++fi) // HDKcellToNode(face, fi), interp.cpp:683-698 (all eight reads in flight: no early exit)
+                transition |= vidx_clamped(P, level, axis, I3{{face[0] + (fi & 1), face[1] + ((fi >> 1) & 1), face[2] + ((fi >> 2) & 1)}}) == AVS_UNASSIGNED;
             if (!transition) { // trilinear over the 8 faces, interp.cpp:700-728
                 double iw[3];
 #pragma unroll
@@ -321,9 +344,7 @@ __device__ double interp_sp_grid(const PyramidView &P, const PostView &W, const 
             }
             return (1. - ciw) * fiv[0] + ciw * fiv[1];
         }
-        cell = half3(cell);
     }
-    return 0.; // reference: assert(false)
 }
 
 // T7: cpp:2815-2894 -----------------------------------------------------------------------------
