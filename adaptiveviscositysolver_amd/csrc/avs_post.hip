@@ -87,32 +87,42 @@ __global__ __launch_bounds__(kBlock) void k_nodes_sample(PyramidView P, PostView
     const double weight = (double)(1 << (P.levels - l - 1));
     for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
         const I3 node = unlin(nr, o);
+        // the twelve faces around the node: all indices requested at once (the reference's loops stop at the first
+        // SOLIDBOUNDARY / OUTSIDE face, but "active and not inactive" does not depend on the order of the tests)
         bool active = false, inactive = false;
-        for (int fa = 0; !inactive && fa < 3; ++fa) {
+        int32_t vi[12];
+        size_t fo[12];
+#pragma unroll
+        for (int fa = 0; fa < 3; ++fa) {
             const I3 fr = face_res(P, l, fa);
             const int b1 = (fa + 1) % 3, b2 = (fa + 2) % 3;
+#pragma unroll
             for (int fi = 0; fi < 4; ++fi) {
                 const I3 f = node_to_face(node, fa, fi);
-                if (f[b1] < 0 || f[b2] < 0 || f[b1] >= fr[b1] || f[b2] >= fr[b2]) { inactive = true; continue; }
-                const int32_t vi = P.vidx[l][fa][lin(fr, f)];
-                if (vi >= 0) active = true;
-                else if (vi == AVS_SOLIDBOUNDARY || vi == AVS_OUTSIDE) { inactive = true; break; }
+                const bool oob = f[b1] < 0 || f[b2] < 0 || f[b1] >= fr[b1] || f[b2] >= fr[b2];
+                inactive |= oob;
+                fo[fa * 4 + fi] = lin(fr, clamp3(f, fr));
+                vi[fa * 4 + fi] = P.vidx[l][fa][fo[fa * 4 + fi]];
+                if (!oob) {
+                    active |= vi[fa * 4 + fi] >= 0;
+                    inactive |= vi[fa * 4 + fi] == AVS_SOLIDBOUNDARY || vi[fa * 4 + fi] == AVS_OUTSIDE;
+                }
             }
         }
         if (!(active && !inactive)) continue; // labels / values / weights / flags were zero-filled
         W.nlab[l][o] = 1;
         int32_t flag = 0;
+#pragma unroll
         for (int fa = 0; fa < 3; ++fa) {
-            const I3 fr = face_res(P, l, fa);
             double av = 0., aw = 0.;
-            for (int fi = 0; fi < 4; ++fi) {
-                const size_t fo = lin(fr, node_to_face(node, fa, fi)); // active nodes have all 12 faces in bounds
-                const int32_t vi = P.vidx[l][fa][fo];
-                if (vi >= 0) {
-                    av += weight * (double)W.vel[l][fa][fo];
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) { // active nodes have all 12 faces in bounds
+                const int32_t v = vi[fa * 4 + fi];
+                if (v >= 0) {
+                    av += weight * (double)W.vel[l][fa][fo[fa * 4 + fi]];
                     aw += weight;
                     flag += 1 << (fa * 4 + fi);
-                } else if (vi != AVS_UNASSIGNED) {
+                } else if (v != AVS_UNASSIGNED) {
                     aw += weight;
                     flag += 1 << (fa * 4 + fi);
                 }
@@ -277,10 +287,16 @@ __device__ double interp_sp_grid(const PyramidView &P, const PostView &W, const 
                 ifp[a] = (double)P2[a] / scale - (a == axis ? 0. : .5); // posToIndex on the face lattice
                 face[a] = (int)floor(ifp[a]);
             }
+            // HDKcellToNode(face, fi), interp.cpp:683-698: the eight faces around the sample.  Their indices (transition test) and
+            // their velocities (trilinear branch) are requested together, no early exit: one round trip instead of up to nine
             bool transition = false;
+            float fv[8];
 #pragma unroll
-            for (int fi = 0; fi < 8; ++fi) // HDKcellToNode(face, fi), interp.cpp:683-698 (all eight reads in flight: no early exit)
-                transition |= vidx_clamped(P, level, axis, I3{{face[0] + (fi & 1), face[1] + ((fi >> 1) & 1), face[2] + ((fi >> 2) & 1)}}) == AVS_UNASSIGNED;
+            for (int fi = 0; fi < 8; ++fi) {
+                const I3 nf{{face[0] + (fi & 1), face[1] + ((fi >> 1) & 1), face[2] + ((fi >> 2) & 1)}};
+                transition |= vidx_clamped(P, level, axis, nf) == AVS_UNASSIGNED;
+                fv[fi] = vel_clamped(P, W, level, axis, nf);
+            }
             if (!transition) { // trilinear over the 8 faces, interp.cpp:700-728
                 double iw[3];
 #pragma unroll
@@ -289,12 +305,13 @@ __device__ double interp_sp_grid(const PyramidView &P, const PostView &W, const 
                     iw[a] = iw[a] < 0. ? 0. : (iw[a] > 1. ? 1. : iw[a]);
                 }
                 double v = 0.;
+#pragma unroll
                 for (int fi = 0; fi < 8; ++fi) {
                     const I3 nf{{face[0] + (fi & 1), face[1] + ((fi >> 1) & 1), face[2] + ((fi >> 2) & 1)}};
                     double wt = 1.;
 #pragma unroll
                     for (int a = 0; a < 3; ++a) wt *= (nf[a] - face[a] == 0) ? (1. - iw[a]) : iw[a];
-                    v += wt * (double)vel_clamped(P, W, level, axis, nf);
+                    v += wt * (double)fv[fi];
                 }
                 return v;
             }
@@ -355,8 +372,8 @@ __global__ __launch_bounds__(kBlock) void k_apply_regular(PyramidView P, PostVie
     const size_t total = (size_t)fr[0] * fr[1] * fr[2];
     for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
         const int32_t ri = ridx[o];
+        const int32_t oi = P.vidx[0][axis][o]; // (requested with ridx: both lattices are the level-0 face lattice)
         if (ri >= 0) {
-            const int32_t oi = P.vidx[0][axis][o];
             if (oi >= 0) out[o] = (float)x[oi];
             else if (oi == AVS_SOLIDBOUNDARY) out[o] = sample_f32(P.solidvel[axis], fr, off_face(axis), pos2_face(0, axis, unlin(fr, o)));
             else if (oi == AVS_UNASSIGNED) out[o] = (float)interp_sp_grid(P, W, pos2_face(0, axis, unlin(fr, o)), axis);
