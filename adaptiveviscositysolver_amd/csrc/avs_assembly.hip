@@ -445,21 +445,48 @@ __device__ __forceinline__ void row_push(RowAcc &ra, int32_t c, double v)
     ++ra.n;
 }
 
+static constexpr int kStencilBatch = 8; // stencil entries requested at once (see apply_stencil)
+
 // applyToMatrix, cpp:2404-2457
 template <bool EMIT>
 __device__ void apply_stencil(RowAcc &ra, double coefficient, int32_t vi, int cnt, const int32_t *__restrict__ idx,
                               const double *__restrict__ coef, int64_t stride, int bcnt,
                               const double *__restrict__ bval)
 {
+    // The reference searches the stencil for the row's own entry (first match), then walks it again.  Done literally that is
+    // up to 2 cnt DEPENDENT loads per stencil (the search stops at the match, the walk stores between its loads), six
+    // stencils per row.  The first kStencilBatch entries -- nearly every stencil has no more -- are requested at once.
+    int32_t ji[kStencilBatch];
+    double cf[kStencilBatch];
+#pragma unroll
+    for (int k = 0; k < kStencilBatch; ++k) {
+        ji[k] = k < cnt ? idx[(size_t)k * stride] : -1;
+        cf[k] = (EMIT && k < cnt) ? coef[(size_t)k * stride] : 0.;
+    }
     bool found = false;
-    for (int i = 0; i < cnt; ++i)
+#pragma unroll
+    for (int k = 0; k < kStencilBatch; ++k)
+        if (!found && k < cnt && ji[k] == vi) {
+            coefficient *= cf[k];
+            found = true;
+        }
+    for (int i = kStencilBatch; !found && i < cnt; ++i)
         if (idx[(size_t)i * stride] == vi) {
             coefficient *= coef[(size_t)i * stride];
             found = true;
-            break;
         }
     if (!found) ra.bad = 1; // assert(foundSelf) cpp:2436
-    for (int i = 0; i < cnt; ++i) {
+#pragma unroll
+    for (int k = 0; k < kStencilBatch; ++k)
+        if (k < cnt) {
+            const int32_t j = ji[k];
+            if (EMIT) {
+                const double element = coefficient * cf[k];
+                if (j == vi) ra.diag += element;
+                else row_push<true>(ra, j, element);
+            } else if (j != vi) ++ra.n;
+        }
+    for (int i = kStencilBatch; i < cnt; ++i) {
         const int32_t j = idx[(size_t)i * stride];
         if (EMIT) {
             const double element = coefficient * coef[(size_t)i * stride];
