@@ -23,6 +23,9 @@ SCENES = {
     "sphere64": lambda dev: scenes.sphere(64, 4, device=dev),
     "sheet64": lambda dev: scenes.thin_sheet(64, 3, thickness_cells=12, device=dev),
     "beam_noncubic": lambda dev: scenes.fat_beam(64, 3, res=(64, 32, 32), device=dev),
+    # five levels really appear (level-4 cells in the core): 12^4-leaf restriction rows (several batches of 144-leaf units per
+    # lane group), level-4 rows in the row sweep, rows with > 64 raw triplets next to the coarsest cells
+    "beam256_L5": lambda dev: scenes.fat_beam(256, 5, device=dev),
 }
 
 
@@ -68,6 +71,8 @@ def test_assembly_bit_exact(name, dev, built_lib):
     rp, col, val, rhs = s.csr()
     A = o.csr()
     assert ai.n_velocity == A.n and ai.nnz == len(A.col) and ai.raw_triplets == o.raw_triplets
+    if name == "beam256_L5":
+        assert o.levels == 5 and int((o.dof_table(0)[:, 0] & 0xff).max()) == 4   # level-4 velocity DOFs exist
     assert np.array_equal(rp, A.row_ptr.astype(np.int32))
     assert np.array_equal(col, A.col)
     assert np.array_equal(val, A.val)
