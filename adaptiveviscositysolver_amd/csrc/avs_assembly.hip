@@ -332,14 +332,27 @@ __device__ __forceinline__ void fold_144(float wgt, const float (&leaf)[144], do
 // the four lanes fold one after the other, handing the running sum on -- the order of the additions is unchanged.  (The fold
 // is the serial part: with G lanes per row a wave spends G x the issue slots on it, so G stays small; 12 lanes: 0.90 ms.)
 __global__ __launch_bounds__(kBlock) void k_initial_guess(PyramidView P, const int32_t *__restrict__ vdof, int64_t n,
-                                                          double *__restrict__ x0, const int32_t *__restrict__ ids)
+                                                          double *__restrict__ x0, const int32_t *__restrict__ ids,
+                                                          int32_t *__restrict__ coarse_list /* [0]: count, then DOF ids */)
 {
     const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (slot >= n) return;
-    const int id = ids ? ids[slot] : (int)slot; // multi-GPU: only the DOFs this rank owns (x0 stays indexed by DOF)
-    const int4 rec = reinterpret_cast<const int4 *>(vdof)[id];
+    const bool valid = slot < n;
+    const int id = valid ? (ids ? ids[slot] : (int)slot) : 0; // multi-GPU: only the DOFs this rank owns (x0 stays indexed by DOF)
+    int4 rec = make_int4(0, 0, 0, 0);
+    if (valid) rec = reinterpret_cast<const int4 *>(vdof)[id];
     const int level = rec.x & 0xff, axis = rec.x >> 8;
-    if (level > 2) return; // k_initial_guess_coarse
+    { // rows of level >= 3 go on a list for k_initial_guess_coarse (one atomic per wave; the order of the list does not matter)
+        const bool coarse = valid && level > 2;
+        const unsigned long long cm = __ballot(coarse);
+        if (cm) {
+            const int lane = threadIdx.x & 63;
+            int base = 0;
+            if (lane == __ffsll((long long)cm) - 1) base = atomicAdd(coarse_list, __popcll(cm));
+            base = __shfl(base, __ffsll((long long)cm) - 1, 64);
+            if (coarse) coarse_list[1 + base + __popcll(cm & ((1ull << lane) - 1ull))] = id;
+        }
+    }
+    if (!valid || level > 2) return;
     const I3 face{{rec.y, rec.z, rec.w}};
     const I3 vr = face_res(P, 0, axis);
     const FieldView &V = P.vel[axis];
@@ -361,30 +374,25 @@ __global__ __launch_bounds__(kBlock) void k_initial_guess(PyramidView P, const i
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_initial_guess_coarse(PyramidView P, const int32_t *__restrict__ vdof, int64_t n,
-                                                                 double *__restrict__ x0, const int32_t *__restrict__ ids)
+static constexpr int kCoarseGrid = 256;  // persistent workgroups of k_initial_guess_coarse (256 VGPRs: one wave per SIMD = one workgroup per CU)
+
+__global__ __launch_bounds__(kBlock) void k_initial_guess_coarse(PyramidView P, const int32_t *__restrict__ vdof, double *__restrict__ x0,
+                                                                 const int32_t *__restrict__ coarse_list)
 {
-    const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const bool valid = slot < n;
-    const int id = valid ? (ids ? ids[slot] : (int)slot) : 0;
-    int4 rec = make_int4(0, 0, 0, 0);
-    if (valid) rec = reinterpret_cast<const int4 *>(vdof)[id];
-    const int level = rec.x & 0xff, axis = rec.x >> 8;
-    unsigned long long todo = __ballot(valid && level >= 3);
     constexpr int G = 4;                  // lanes per row: sixteen rows at a time
     const int s = lane / G, t = lane % G;
-    while (todo) {                        // wave-uniform
-        int src = -1;
-        for (int q = 0; q < 64 / G; ++q) {
-            const int w = todo ? __ffsll((long long)todo) - 1 : -1;
-            if (todo) todo &= todo - 1;
-            if (s == q) src = w;
-        }
-        const bool on = src >= 0;
-        const int from = on ? src : lane;
-        const int rlevel = __shfl(level, from, 64), raxis = __shfl(axis, from, 64), rid = __shfl(id, from, 64);
-        const I3 face{{__shfl(rec.y, from, 64), __shfl(rec.z, from, 64), __shfl(rec.w, from, 64)}};
+    const int count = coarse_list[0];
+    const int nwaves = gridDim.x * (kBlock / 64);
+    // persistent waves over groups of sixteen listed rows (the rows of one level sit in one id range, or -- multi-GPU, rows
+    // in brick order -- are scattered: either way every wave gets full groups)
+    for (int g0 = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * (64 / G); g0 < count; g0 += nwaves * (64 / G)) {
+        const bool on = g0 + s < count;
+        const int rid = on ? coarse_list[1 + g0 + s] : 0;
+        int4 rec = make_int4(0, 0, 0, 0);
+        if (on) rec = reinterpret_cast<const int4 *>(vdof)[rid];
+        const int rlevel = rec.x & 0xff, raxis = rec.x >> 8;
+        const I3 face{{rec.y, rec.z, rec.w}};
         const I3 vr = face_res(P, 0, raxis);
         const FieldView &V = P.vel[raxis];
         const int a1 = (raxis + 1) % 3, a2 = (raxis + 2) % 3;
@@ -1157,11 +1165,13 @@ avs_status build_initial_guess(avs_ctx *c)
     if (!c->tables_ready) AVS_TRY(build_dof_tables(c));
     AVS_TRY(c->x0.alloc((size_t)c->n_vel));
     if (c->n_vel) {
+        AVS_TRY(c->scratch.coarse_list.reserve((size_t)c->n_vel + 1));
+        AVS_HIP(hipMemsetAsync(c->scratch.coarse_list.p, 0, sizeof(int32_t), c->stream));
         hipLaunchKernelGGL(k_initial_guess, dim3(grid_for(c->n_vel)), dim3(kBlock), 0, c->stream, c->view(), c->vdof.p, c->n_vel, c->x0.p,
-                           (const int32_t *)nullptr);
+                           (const int32_t *)nullptr, c->scratch.coarse_list.p);
         if (c->desc.levels > 3)
-            hipLaunchKernelGGL(k_initial_guess_coarse, dim3(grid_for(c->n_vel)), dim3(kBlock), 0, c->stream, c->view(), c->vdof.p, c->n_vel, c->x0.p,
-                               (const int32_t *)nullptr);
+            hipLaunchKernelGGL(k_initial_guess_coarse, dim3(kCoarseGrid), dim3(kBlock), 0, c->stream, c->view(), c->vdof.p, c->x0.p,
+                               (const int32_t *)c->scratch.coarse_list.p);
     }
     AVS_HIP(hipGetLastError());
     c->guess_ready = true;
@@ -1176,9 +1186,12 @@ avs_status build_initial_guess_rows(avs_ctx *c, const int32_t *ids, int64_t m)
     AVS_TRY(c->x0.alloc((size_t)c->n_vel));
     AVS_HIP(hipMemsetAsync(c->x0.p, 0, (size_t)c->n_vel * sizeof(double), c->stream));
     if (m) {
-        hipLaunchKernelGGL(k_initial_guess, dim3(grid_for(m)), dim3(kBlock), 0, c->stream, c->view(), c->vdof.p, m, c->x0.p, ids);
+        AVS_TRY(c->scratch.coarse_list.reserve((size_t)m + 1));
+        AVS_HIP(hipMemsetAsync(c->scratch.coarse_list.p, 0, sizeof(int32_t), c->stream));
+        hipLaunchKernelGGL(k_initial_guess, dim3(grid_for(m)), dim3(kBlock), 0, c->stream, c->view(), c->vdof.p, m, c->x0.p, ids, c->scratch.coarse_list.p);
         if (c->desc.levels > 3)
-            hipLaunchKernelGGL(k_initial_guess_coarse, dim3(grid_for(m)), dim3(kBlock), 0, c->stream, c->view(), c->vdof.p, m, c->x0.p, ids);
+            hipLaunchKernelGGL(k_initial_guess_coarse, dim3(kCoarseGrid), dim3(kBlock), 0, c->stream, c->view(), c->vdof.p, c->x0.p,
+                               (const int32_t *)c->scratch.coarse_list.p);
     }
     AVS_HIP(hipGetLastError());
     c->guess_ready = false; // avs_get_initial_guess / avs_build_system must not see a mostly-zero vector
