@@ -542,8 +542,14 @@ __device__ __forceinline__ unsigned tile_flags(const int32_t *__restrict__ grid,
 }
 
 __global__ __launch_bounds__(kBlock) void k_tile_counts(const int32_t *__restrict__ grid, Grid3 g, int ntx, int nty,
-                                                        int32_t *__restrict__ tile_count)
+                                                        int32_t *__restrict__ tile_count, const uint8_t *__restrict__ occ)
 {
+    // a tile the classification never visited (occupancy flag clear) holds no DOF: not read at all -- on a thin sheet that is
+    // nine tiles in ten
+    if (occ && !occ[blockIdx.x]) {
+        if (threadIdx.x == 0) tile_count[blockIdx.x] = 0;
+        return;
+    }
     __shared__ int red[kBlock / 64];
     size_t first, zs;
     int cnt = __popc(tile_flags(grid, g, ntx, nty, &first, &zs));
@@ -557,6 +563,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_counts(const int32_t *__restric
 __global__ __launch_bounds__(kBlock) void k_tile_ids(int32_t *__restrict__ grid, Grid3 g, int ntx, int nty,
                                                      const int32_t *__restrict__ tile_off, const long long *__restrict__ base)
 {
+    if (tile_off[blockIdx.x + 1] == tile_off[blockIdx.x]) return; // no DOF in this tile: nothing to read, nothing to write
     __shared__ int cnt[kTile * (kBlock / 64)]; // flagged voxels of (step z, wave w), then their exclusive prefix
     size_t first, zs;
     const unsigned bits = tile_flags(grid, g, ntx, nty, &first, &zs);
@@ -845,24 +852,23 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     // tile-occupancy flags of the six lattices of the level being classified (one buffer each; the face lattices of level 0
     // are kept for the regular-grid classification below, which uses the same rule on the same lattices)
     const size_t occ_cap = (size_t)(d.nx / kTile + 2) * (size_t)(d.ny / kTile + 2) * (size_t)(d.nz / kTile + 2);
-    DevBuf<uint8_t> occ, occ0; // 6 x occ_cap: [kind][axis]; occ0: level 0
-    AVS_TRY(occ.alloc(6 * occ_cap));
-    AVS_TRY(occ0.alloc(6 * occ_cap));
+    DevBuf<uint8_t> occ_all; // [level][kind][axis][occ_cap]: kept until the numbering, which skips the tiles nobody visited
+    AVS_TRY(occ_all.alloc((size_t)capped * 6 * occ_cap));
     TileGrid tg0[3];
     for (int l = 0; l < capped; ++l) {
         int cr[3];
         pp_res(d, 2, l, 0, cr);
-        DevBuf<uint8_t> &ob = l == 0 ? occ0 : occ;
+        uint8_t *ob = occ_all.p + (size_t)l * 6 * occ_cap;
         TileSets T;
         for (int kind = 0; kind < 2; ++kind)
             for (int a = 0; a < 3; ++a) {
                 int gr[3];
                 pp_res(d, kind, l, a, gr);
                 T.tg[kind][a] = TileGrid{{(gr[0] + kTile - 1) / kTile, (gr[1] + kTile - 1) / kTile, (gr[2] + kTile - 1) / kTile}};
-                T.occ[kind][a] = ob.p + (size_t)(kind * 3 + a) * occ_cap;
+                T.occ[kind][a] = ob + (size_t)(kind * 3 + a) * occ_cap;
                 if (l == 0 && kind == 0) tg0[a] = T.tg[kind][a];
             }
-        AVS_HIP(hipMemsetAsync(ob.p, 0, 6 * occ_cap, st)); // (the stream orders the reuse of `occ` by the next level)
+        AVS_HIP(hipMemsetAsync(ob, 0, 6 * occ_cap, st));
         hipLaunchKernelGGL(k_mark_tiles_all, dim3(grid_for(g3(cr).vol())), dim3(kBlock), 0, st, p->labels[l].p, l == 0 ? p->liquid.p : nullptr, occ_sdf,
                            g3(cr), T);
         for (int a = 0; a < 3; ++a) {
@@ -907,7 +913,7 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         A.centerw = p->centerw.p;
         for (int b = 0; b < 3; ++b) A.edgew[b] = p->edgew[b].p;
         A.solid = solid ? p->solid.p : nullptr;
-        hipLaunchKernelGGL(k_classify_regular, dim3(grid_for(g3(gr).vol())), dim3(kBlock), 0, st, A, g3(gr), tg, (const uint8_t *)(occ0.p + (size_t)a * occ_cap), p->ridx[a].p);
+        hipLaunchKernelGGL(k_classify_regular, dim3(grid_for(g3(gr).vol())), dim3(kBlock), 0, st, A, g3(gr), tg, (const uint8_t *)(occ_all.p + (size_t)a * occ_cap), p->ridx[a].p);
         AVS_HIP(hipGetLastError());
     }
     AVS_HIP(hipStreamSynchronize(st)); // occ dies here
@@ -926,11 +932,11 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     AVS_TRY(scan_tmp.alloc(scan_tmp_elems((int64_t)max_tiles + 1)));
     AVS_TRY(base.alloc(4));
     AVS_HIP(hipMemsetAsync(base.p, 0, 4 * sizeof(long long), st));
-    auto number = [&](int32_t *grid, const int gr[3], int counter) -> avs_status {
+    auto number = [&](int32_t *grid, const int gr[3], int counter, const uint8_t *occ) -> avs_status {
         const Grid3 g = g3(gr);
         const int ntx = (gr[0] + kTile - 1) / kTile, nty = (gr[1] + kTile - 1) / kTile, ntz = (gr[2] + kTile - 1) / kTile;
         const int64_t nt = (int64_t)ntx * nty * ntz;
-        hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)nt), dim3(kBlock), 0, st, (const int32_t *)grid, g, ntx, nty, fl.p);
+        hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)nt), dim3(kBlock), 0, st, (const int32_t *)grid, g, ntx, nty, fl.p, occ);
         AVS_TRY(exclusive_scan_i32(fl.p, ids.p, nt, scan_tmp.p, scan_tmp.n, st));
         hipLaunchKernelGGL(k_tile_ids, dim3((unsigned)nt), dim3(kBlock), 0, st, grid, g, ntx, nty, (const int32_t *)ids.p,
                            (const long long *)(base.p + counter));
@@ -942,12 +948,13 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
             for (int a = 0; a < (kind == 2 ? 1 : 3); ++a) {
                 int gr[3];
                 pp_res(d, kind, l, a, gr);
-                AVS_TRY(number(kind == 0 ? p->vidx[l][a].p : (kind == 1 ? p->eidx[l][a].p : p->cidx[l].p), gr, kind));
+                const uint8_t *oc = kind == 2 ? nullptr : occ_all.p + ((size_t)l * 6 + (size_t)kind * 3 + a) * occ_cap; // centres: no tile rule
+                AVS_TRY(number(kind == 0 ? p->vidx[l][a].p : (kind == 1 ? p->eidx[l][a].p : p->cidx[l].p), gr, kind, oc));
             }
     for (int a = 0; a < 3; ++a) { // regular grid: one counter over the three axes, cpp:1486-1509
         int gr[3];
         pp_res(d, 0, 0, a, gr);
-        AVS_TRY(number(p->ridx[a].p, gr, 3));
+        AVS_TRY(number(p->ridx[a].p, gr, 3, occ_all.p + (size_t)a * occ_cap)); // classified with the level-0 face occupancy
     }
     AVS_HIP(hipGetLastError());
     long long hb[4] = {0, 0, 0, 0};
