@@ -22,6 +22,8 @@ namespace avs {
 
 static constexpr int kBlock = 256;
 static constexpr int kTile = 16;
+static_assert(kBlock == kTile * kTile, "tile kernels: one thread per (x, y) column of a 16^3 tile");
+static_assert(AVS_UNASSIGNED == -1, "index lattices are pre-filled with memset(0xFF)");
 static constexpr int kMaxSuper = 8;
 
 struct SubConsts { // per axis: integer cell offset and fp32 fraction of every sub-sample
@@ -374,13 +376,15 @@ __global__ __launch_bounds__(kBlock) void k_classify_velocity(ClassifyArgs A, Gr
     const int l = A.level, axis = A.axis;
     const Grid3 cg{{A.n[0] >> l, A.n[1] >> l, A.n[2] >> l}};
     const Grid3 c0{{A.n[0], A.n[1], A.n[2]}};
-    const size_t total = fg.vol();
-    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
-        int f[3];
-        f[0] = (int)(o % fg.r[0]);
-        const size_t q = o / fg.r[0];
-        f[1] = (int)(q % fg.r[1]);
-        f[2] = (int)(q / fg.r[1]);
+    // one workgroup per 16^3 tile of the lattice; the lattice was pre-filled with AVS_UNASSIGNED and a tile nobody marked
+    // keeps that value ("constant tiles are never visited", cpp:1197): it is neither read nor written here
+    if (!occ[blockIdx.x]) return;
+    const int tile_x = blockIdx.x % tg.tr[0], tile_y = (blockIdx.x / tg.tr[0]) % tg.tr[1], tile_z = blockIdx.x / (tg.tr[0] * tg.tr[1]);
+    const int vi_ = tile_x * kTile + (threadIdx.x & (kTile - 1)), vj_ = tile_y * kTile + (threadIdx.x >> 4);
+    if (vi_ >= fg.r[0] || vj_ >= fg.r[1]) return;
+    for (int vz_ = 0; vz_ < kTile && tile_z * kTile + vz_ < fg.r[2]; ++vz_) {
+        int f[3] = {vi_, vj_, tile_z * kTile + vz_};
+        const size_t o = lin3(fg, f[0], f[1], f[2]);
         int32_t v = AVS_UNASSIGNED;
         if (occ[tile_of(tg, f[0], f[1], f[2])]) { // constant tiles are never visited (cpp:1197)
             int b[3] = {f[0], f[1], f[2]};
@@ -426,13 +430,15 @@ __global__ __launch_bounds__(kBlock) void k_classify_regular(ClassifyArgs A, Gri
 {
     const int axis = A.axis;
     const Grid3 c0{{A.n[0], A.n[1], A.n[2]}};
-    const size_t total = fg.vol();
-    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
-        int f[3];
-        f[0] = (int)(o % fg.r[0]);
-        const size_t q = o / fg.r[0];
-        f[1] = (int)(q % fg.r[1]);
-        f[2] = (int)(q / fg.r[1]);
+    // one workgroup per 16^3 tile of the lattice; the lattice was pre-filled with AVS_UNASSIGNED and a tile nobody marked
+    // keeps that value ("constant tiles are never visited", cpp:1197): it is neither read nor written here
+    if (!occ[blockIdx.x]) return;
+    const int tile_x = blockIdx.x % tg.tr[0], tile_y = (blockIdx.x / tg.tr[0]) % tg.tr[1], tile_z = blockIdx.x / (tg.tr[0] * tg.tr[1]);
+    const int vi_ = tile_x * kTile + (threadIdx.x & (kTile - 1)), vj_ = tile_y * kTile + (threadIdx.x >> 4);
+    if (vi_ >= fg.r[0] || vj_ >= fg.r[1]) return;
+    for (int vz_ = 0; vz_ < kTile && tile_z * kTile + vz_ < fg.r[2]; ++vz_) {
+        int f[3] = {vi_, vj_, tile_z * kTile + vz_};
+        const size_t o = lin3(fg, f[0], f[1], f[2]);
         int32_t v = AVS_UNASSIGNED;
         int b[3] = {f[0], f[1], f[2]};
         --b[axis];
@@ -466,13 +472,15 @@ __global__ __launch_bounds__(kBlock) void k_classify_edges(ClassifyArgs A, Grid3
 {
     const int l = A.level, axis = A.axis;
     const Grid3 cg{{A.n[0] >> l, A.n[1] >> l, A.n[2] >> l}};
-    const size_t total = eg.vol();
-    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
-        int e[3];
-        e[0] = (int)(o % eg.r[0]);
-        const size_t q = o / eg.r[0];
-        e[1] = (int)(q % eg.r[1]);
-        e[2] = (int)(q / eg.r[1]);
+    // one workgroup per 16^3 tile of the lattice; the lattice was pre-filled with AVS_UNASSIGNED and a tile nobody marked
+    // keeps that value ("constant tiles are never visited", cpp:1197): it is neither read nor written here
+    if (!occ[blockIdx.x]) return;
+    const int tile_x = blockIdx.x % tg.tr[0], tile_y = (blockIdx.x / tg.tr[0]) % tg.tr[1], tile_z = blockIdx.x / (tg.tr[0] * tg.tr[1]);
+    const int vi_ = tile_x * kTile + (threadIdx.x & (kTile - 1)), vj_ = tile_y * kTile + (threadIdx.x >> 4);
+    if (vi_ >= eg.r[0] || vj_ >= eg.r[1]) return;
+    for (int vz_ = 0; vz_ < kTile && tile_z * kTile + vz_ < eg.r[2]; ++vz_) {
+        int e[3] = {vi_, vj_, tile_z * kTile + vz_};
+        const size_t o = lin3(eg, e[0], e[1], e[2]);
         int32_t v = AVS_UNASSIGNED;
         if (occ[tile_of(tg, e[0], e[1], e[2])]) {
             bool active = false;
@@ -889,8 +897,9 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
                 A.centerw = p->centerw.p;
                 for (int b = 0; b < 3; ++b) A.edgew[b] = p->edgew[b].p;
                 A.solid = solid ? p->solid.p : nullptr;
-                if (kind == 0) hipLaunchKernelGGL(k_classify_velocity, dim3(grid_for(g3(gr).vol())), dim3(kBlock), 0, st, A, g3(gr), tg, oc, buf.p);
-                else hipLaunchKernelGGL(k_classify_edges, dim3(grid_for(g3(gr).vol())), dim3(kBlock), 0, st, A, g3(gr), tg, oc, buf.p);
+                AVS_HIP(hipMemsetAsync(buf.p, 0xFF, g3(gr).vol() * sizeof(int32_t), st)); // AVS_UNASSIGNED everywhere; occupied tiles are classified
+                if (kind == 0) hipLaunchKernelGGL(k_classify_velocity, dim3((unsigned)tg.vol()), dim3(kBlock), 0, st, A, g3(gr), tg, oc, buf.p);
+                else hipLaunchKernelGGL(k_classify_edges, dim3((unsigned)tg.vol()), dim3(kBlock), 0, st, A, g3(gr), tg, oc, buf.p);
                 AVS_HIP(hipGetLastError());
             }
         }
@@ -913,7 +922,8 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         A.centerw = p->centerw.p;
         for (int b = 0; b < 3; ++b) A.edgew[b] = p->edgew[b].p;
         A.solid = solid ? p->solid.p : nullptr;
-        hipLaunchKernelGGL(k_classify_regular, dim3(grid_for(g3(gr).vol())), dim3(kBlock), 0, st, A, g3(gr), tg, (const uint8_t *)(occ_all.p + (size_t)a * occ_cap), p->ridx[a].p);
+        AVS_HIP(hipMemsetAsync(p->ridx[a].p, 0xFF, g3(gr).vol() * sizeof(int32_t), st));
+        hipLaunchKernelGGL(k_classify_regular, dim3((unsigned)tg.vol()), dim3(kBlock), 0, st, A, g3(gr), tg, (const uint8_t *)(occ_all.p + (size_t)a * occ_cap), p->ridx[a].p);
         AVS_HIP(hipGetLastError());
     }
     AVS_HIP(hipStreamSynchronize(st)); // occ dies here
