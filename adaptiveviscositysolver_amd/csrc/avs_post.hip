@@ -87,6 +87,20 @@ __global__ __launch_bounds__(kBlock) void k_nodes_sample(PyramidView P, PostView
     const double weight = (double)(1 << (P.levels - l - 1));
     for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
         const I3 node = unlin(nr, o);
+        { // A face DOF has an ACTIVE cell of this level on one side (cpp:1232-1319), and the twelve faces around a node separate
+          // the eight cells around it: no ACTIVE cell among them => no DOF face => the node stays inactive.  Eight 1-byte
+          // reads instead of twelve 4-byte ones for the bulk of the lattice (air, and the inside of coarser cells).
+            const I3 cr = cell_res(P, l);
+            bool any_active = false;
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci) {
+                const I3 c{{node[0] - 1 + (ci & 1), node[1] - 1 + ((ci >> 1) & 1), node[2] - 1 + ((ci >> 2) & 1)}};
+                const bool in = c[0] >= 0 && c[1] >= 0 && c[2] >= 0 && c[0] < cr[0] && c[1] < cr[1] && c[2] < cr[2];
+                const int8_t lb = P.labels[l][lin(cr, clamp3(c, cr))];
+                any_active |= in && lb == AVS_ACTIVE;
+            }
+            if (!any_active) continue; // labels / values / weights / flags were zero-filled
+        }
         // the twelve faces around the node: all indices requested at once (the reference's loops stop at the first
         // SOLIDBOUNDARY / OUTSIDE face, but "active and not inactive" does not depend on the order of the tests)
         bool active = false, inactive = false;
