@@ -467,7 +467,7 @@ avs_status avs_transfer_to_regular_grid(avs_ctx *c, float *out_x, float *out_y, 
         AVS_TRY(c->post_nlab[l].alloc(nn));
         AVS_TRY(c->post_nf[l].alloc(nn));
         AVS_HIP(hipMemsetAsync(c->post_nlab[l].p, 0, nn, st));
-        AVS_HIP(hipMemsetAsync(c->post_nf[l].p, 0, nn * sizeof(int32_t), st));
+        // (node flags and weights are only ever read for nodes that k_nodes_sample marked active, and it writes them: no fill)
         W.nlab[l] = c->post_nlab[l].p;
         W.nf[l] = c->post_nf[l].p;
         for (int a = 0; a < 3; ++a) {
@@ -479,7 +479,6 @@ avs_status avs_transfer_to_regular_grid(avs_ctx *c, float *out_x, float *out_y, 
             AVS_TRY(c->post_nw[l][a].alloc(nn));
             AVS_HIP(hipMemsetAsync(c->post_vel[l][a].p, 0, nf * sizeof(float), st));
             AVS_HIP(hipMemsetAsync(c->post_nval[l][a].p, 0, nn * sizeof(float), st));
-            AVS_HIP(hipMemsetAsync(c->post_nw[l][a].p, 0, nn * sizeof(float), st));
             W.vel[l][a] = c->post_vel[l][a].p;
             W.nval[l][a] = c->post_nval[l][a].p;
             W.nw[l][a] = c->post_nw[l][a].p;
