@@ -2150,11 +2150,29 @@ int orc_spmv_csr(int64_t n, const int64_t *row_ptr, const int32_t *col, const do
 static double dot_(int64_t n, const double *a, const double *b, int threads)
 {
     double s = 0.;
+#ifdef _OPENMP
     if (threads > 1) {
-#pragma omp parallel for schedule(static) num_threads(threads) reduction(+ : s)
-        for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
-    } else
-        for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
+        /* Deterministic for a given team size: every thread sums a fixed contiguous share, the shares are added in thread
+         * order.  (An OpenMP `reduction` combines the partial sums in arrival order: the iteration count of a 1271-iteration
+         * solve then wandered between 1271 and 1277 from run to run, and with it the parity tests that compare counts.) */
+        enum { MAXT = 1024 };
+        double part[MAXT];
+        int team = 1;
+        if (threads > MAXT) threads = MAXT;
+#pragma omp parallel num_threads(threads)
+        {
+            const int t = omp_get_thread_num(), T = omp_get_num_threads();
+            const int64_t i0 = n * t / T, i1 = n * (t + 1) / T;
+            double ps = 0.;
+            for (int64_t i = i0; i < i1; ++i) ps += a[i] * b[i];
+            part[t] = ps;
+            if (t == 0) team = T;
+        }
+        for (int t = 0; t < team; ++t) s += part[t];
+        return s;
+    }
+#endif
+    for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
     return s;
 }
 
