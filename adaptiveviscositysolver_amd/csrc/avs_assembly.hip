@@ -9,15 +9,15 @@
 //   K0  k_dof_table        index grids -> dof tables (+ max id validation)
 //   K1  k_edge_stencils    getEdgeStressFaces + edgeOctreeVolumes + weights   cpp:1717-1908, 2004-2160
 //   K2  k_center_stencils  getCenterStressFaces + weights                    cpp:1910-1963, 2162-2289
-//   K3  k_initial_guess    buildVelocityMappingPartial                       cpp:2291-2402
+//   K3  k_initial_guess (+ _coarse)  buildVelocityMappingPartial; rows of level >= 3 by 4 lanes each   cpp:2291-2402
 //   K4  k_rows<false>      dry run of the row sweep: raw triplets per row    cpp:2459-2777
 //   K5  exclusive scan     wave64 shuffle scan -> raw offsets / row pointers
-//   K6  k_rows<true>       row sweep, raw triplets in emission order                   cpp:2404-2457
-//   K6b k_sort_rows        per row (one half-wave, in registers): stable sort by column + left fold of
-//                          duplicates in emission order = setFromTriplets for one row  cpp:613-614
-//   K7  k_compact          rows -> final CSR, coalesced 16-lane copies
+//   K6  k_rows<true>       row sweep, raw triplets in emission order, wave-transposed     cpp:2404-2457
+//   K6b k_unique_rows      first occurrences of every row's columns -> unique counts -> row pointers
+//   K7  k_merge_rows       per row, in registers: rank of the first occurrences + left fold of the duplicates in
+//                          emission order = setFromTriplets for one row, straight into the final CSR   cpp:613-614
 //
-// Rows are independent (a gather): no atomics anywhere.  All arithmetic is done in the reference's
+// Rows are independent (a gather): no atomics on the data path (one per wave to list the coarse rows).  All arithmetic is done in the reference's
 // order with one rounding per operation (compile with -ffp-contract=off), so the CSR values, the
 // right-hand side and the initial guess are bit-identical to the CPU oracle.
 #include "avs_device_common.hpp"

@@ -1,18 +1,21 @@
 // avs_prepass.hip -- the steps of solveGasSubclass BEFORE the hot path, on the device
 // (SURVEY.md 8(f) "next #1 / #4"; reference: HDK_AdaptiveViscosity.cpp "cpp:", HDK_OctreeGrid.cpp "oct.cpp:").
 //
-//   P1 k_sdf_weights     integration weights (cpp:712-766; HDK computeSDFWeightsSampled is not in the
+//   P1 k_sdf_weights_far + k_sdf_weights   integration weights (cpp:712-766; HDK computeSDFWeightsSampled is not in the
 //                        reference tree: fraction of n^3 sub-samples with interpolated SDF < 0, defined in
-//                        oracle/avs_oracle.c and restated identically here, fp32, x then y then z)
+//                        oracle/avs_oracle.c and restated identically here, fp32, x then y then z); bricks whose SDF
+//                        window has one sign are finished by the first kernel, the surface bricks by the second
 //   P2 k_mask_labels     refinement mask + level-0 labels (cpp:815-867, oct.cpp:383-388)
 //   P3 k_oct_*           label pyramid, three passes per level (oct.cpp:93-189) + top level (oct.cpp:843-875)
-//   P4 k_mark_*/k_classify_*  tile occupancy + face / edge / centre classification (cpp:886-1443)
-//   P5 k_flags_tilemajor + scan + k_apply_ids   serial numbering in HDK 16^3 tile order (cpp:1566-1593,
-//                        1635-1660, 1688-1712) as an exclusive scan over the tile-major flag sequence
+//   P4 k_mark_tiles_all + k_classify_*  tile occupancy (six lattices of a level per launch) + face / edge / centre
+//                        classification (cpp:886-1443): lattices pre-filled with UNASSIGNED, occupied tiles classified
+//   P5 k_tile_counts + scan + k_tile_ids   serial numbering in HDK 16^3 tile order (cpp:1566-1593, 1635-1660,
+//                        1688-1712): per-tile counts, exclusive scan over the tiles, ranks inside a tile by wave ballots;
+//                        tiles the classification never visited are skipped
 //
 // Every per-voxel rule is a gather from the finer / same level: one thread per output voxel (or per
-// parent cell), no atomics, deterministic.  All integer outputs are bit-identical to the oracle and
-// to the tensor-op restatement in prepass.py (tests/test_gpu_prepass.py).
+// parent cell), deterministic (the only atomic appends surface bricks to a list whose order does not matter).  All integer
+// outputs are bit-identical to the oracle and to the tensor-op restatement tests/prepass_torch.py (tests/test_gpu_prepass.py).
 #include <cmath>
 #include <new>
 
