@@ -726,6 +726,16 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
                     constexpr int sh = kCwinOffBits + kCwinSlotBits;
                     q[u] = u4_t{q[u].x >> sh, q[u].y >> sh, q[u].z >> sh, q[u].w >> sh};
                 }
+                if ((CWIN || TLT > 0) && kk < ts) {
+                    // Head of the first pass: the aligned quad starts up to 3 entries BEFORE the tile's first non-zero.  Those
+                    // entries belong to the previous tile -- they are never summed, but their words are relative to THAT tile's
+                    // column windows / dictionary: decoded against this tile's they point anywhere (a gather up to 16 K entries
+                    // past the end of x: found as a GPU memory fault on a 3-rank distributed solve by tools/stress_parity.py).
+                    const int safe = (int)row0;
+                    if (kk + 0 < ts) { c[u].x = safe; q[u].x = 0u; }
+                    if (kk + 1 < ts) { c[u].y = safe; q[u].y = 0u; }
+                    if (kk + 2 < ts) { c[u].z = safe; q[u].z = 0u; }
+                }
                 xv[u][0] = gather(c[u].x);
                 xv[u][1] = gather(c[u].y);
                 xv[u][2] = gather(c[u].z);
@@ -748,7 +758,8 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
             }
             if (tid < te - te4) { // ragged end of the pass (at most 3 entries; entries below ts are never summed)
                 const int kk = te4 + tid;
-                prod[kk - base] = val(A.codes[kk]) * gather(A.col[kk]); // the unpacked arrays stay resident
+                if (kk >= ts) prod[kk - base] = val(A.codes[kk]) * gather(A.col[kk]); // the unpacked arrays stay resident (an entry
+                                                                                       // below ts is the previous tile's: see above)
             }
         };
         if (TLT > 0 && big) products(value_big);

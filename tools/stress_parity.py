@@ -67,6 +67,10 @@ def run(count, seed, quiet=False):
         sc = scenes.Scene(res=res, dx=dx, dt=float(rng.uniform(0.005, 0.05)), levels=levels, liquid=liquid, solid=solid, viscosity=visc,
                           density=float(rng.uniform(1, 2000)), velocity=scenes.smooth_velocity(res, dx, gravity_dt=0.1), solid_velocity=solid_velocity,
                           use_enhanced_gradients=bool(rng.random() < 0.7), name=f"stress{case}")
+        only = os.environ.get('STRESS_ONLY')
+        if only is not None and case != int(only):   # replay the random stream of a skipped case (assumes it was not a rejected one)
+            pw_ = int(rng.integers(2, 9)); rng.integers(0, pw_); rng.integers(-1, 3); rng.integers(2, 4); rng.integers(-1, 3)
+            continue
         if VERBOSE: print(case, 'scene', res, 'levels', levels, 'solid', solid is not None, 'varvisc', not isinstance(visc, float), 'enh', sc.use_enhanced_gradients, flush=True)
         o = oracle_for_scene(sc)
         o.prepass()
@@ -141,7 +145,9 @@ def run(count, seed, quiet=False):
             g2 = C.c_void_p()
             capi.check(lib.avs_local_group_create(pw, C.byref(g2)))
             s.dist_init_local(g2, pr)
+            if VERBOSE: print(case, 'planner', mode, pw, pr, pax, flush=True)
             s.dist_partition(pax)
+            if VERBOSE: print(case, 'planner', mode, 'done', flush=True)
             sz = s.plan_sizes
             ti, tb = s.overlap_tiles
             arrs = [np.empty(int(k), np.int32) for k in (sz.n_own, sz.n_own + 1, sz.nnz_local, sz.n_send, sz.n_peers, sz.n_peers, sz.n_peers, ti, tb)]
@@ -168,7 +174,11 @@ def run(count, seed, quiet=False):
             try:
                 ss[r].dist_init_local(grp, r)
                 ss[r].dist_assemble(int(rng_axis))
+                if VERBOSE:
+                    f_ = ss[r].matrix_format(); z_ = ss[r].plan_sizes
+                    print(case, 'rank', r, 'dist assembled: own', z_.n_own, 'halo', z_.n_halo, 'nnz', z_.nnz_local, 'bytes/nnz', f_.bytes_per_nonzero, 'table', f_.value_table_size, 'tile tables', f_.tile_local_tables, 'windows', f_.column_windows, flush=True)
                 di = ss[r].dist_solve(1e-10, 8000)
+                if VERBOSE: print(case, 'rank', r, 'dist solved', flush=True)
                 outs[r] = (di.iterations, di.converged, ss[r].dist_solution())
             except Exception as e:
                 errs.append((r, e))
