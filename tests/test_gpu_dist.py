@@ -180,7 +180,7 @@ def test_device_planner_equals_host_planner(world, cut_axis, scene, built_lib, m
     s.close()
 
 
-@pytest.mark.parametrize("world,cut_axis,scene", [(1, -1, "beam"), (2, -1, "beam"), (4, 0, "varvisc"), (3, 2, "sphere")])
+@pytest.mark.parametrize("world,cut_axis,scene", [(1, -1, "beam"), (2, -1, "beam"), (4, 0, "varvisc"), (3, 2, "sphere"), (3, 0, "varvisc128")])
 def test_distributed_assembly_matches_single_solve(world, cut_axis, scene, built_lib):
     """avs_dist_assemble: every rank assembles only its own rows (no global matrix) -- the partitioned solve must
     reproduce the single-rank solve, the local systems must add up to the global one, and the send / receive lists of
@@ -188,7 +188,10 @@ def test_distributed_assembly_matches_single_solve(world, cut_axis, scene, built
     dev = torch.device("cuda:0")
     sc = {"beam": lambda: scenes.fat_beam(64, 3, device=dev),
           "varvisc": lambda: scenes.fat_beam(64, 3, variable_viscosity=True, device=dev),
-          "sphere": lambda: scenes.sphere(64, 4, device=dev)}[scene]()
+          "sphere": lambda: scenes.sphere(64, 4, device=dev),
+          # tens of thousands of distinct values per rank: tile-local dictionaries + windowed columns on matrices with halo
+          # columns and the [interior | halo-reading] row order (the form whose head-of-pass decode once gathered out of range)
+          "varvisc128": lambda: scenes.fat_beam(128, 4, variable_viscosity=True, device=dev)}[scene]()
     pyr = build_pyramid(sc)
     ref = make_solver(sc, pyr)
     tol = 1e-10
@@ -214,6 +217,9 @@ def test_distributed_assembly_matches_single_solve(world, cut_axis, scene, built
             plan = _plan_arrays(s)
             info = s.dist_solve(tol, 5000)
             x = s.dist_solution()
+            if scene == "varvisc128":
+                fmt = s.matrix_format()
+                assert fmt.tile_local_tables == 1 and fmt.column_windows == 1 and fmt.bytes_per_nonzero == 4
             results[r] = (info, x, ai, plan)
         except Exception as e:  # pragma: no cover
             errors.append((r, e))
