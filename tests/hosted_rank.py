@@ -29,7 +29,8 @@ def main():
     dev = torch.device("cuda:0")
     sc = {"beam": lambda: scenes.fat_beam(64, 3, device=dev),
           "varvisc": lambda: scenes.fat_beam(64, 3, variable_viscosity=True, device=dev),
-          "beam128": lambda: scenes.fat_beam(128, 3, device=dev)}[scene]()
+          "beam128": lambda: scenes.fat_beam(128, 3, device=dev),
+          "varvisc128": lambda: scenes.fat_beam(128, 4, variable_viscosity=True, device=dev)}[scene]()
     pp = DevicePrepass(sc.res, sc.dx, sc.levels)
     pi = pp.run(sc.liquid, sc.solid)
     s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels)
@@ -58,7 +59,8 @@ def main():
     np.save(os.path.join(workdir, f"info_{rank}.npy"), np.array([runs[0][0], runs[0][1], runs[1][0], runs[1][1],
                                                                   s.plan_sizes.n_own, s.plan_sizes.n_halo,
                                                                   1 if ci["transport"] == "direct" else 0,
-                                                                  ci["rccl_calls_per_iteration"], ci["launches_per_iteration"]], np.float64))
+                                                                  ci["rccl_calls_per_iteration"], ci["launches_per_iteration"],
+                                                                  s.matrix_format().tile_local_tables, s.matrix_format().column_windows], np.float64))
     # keep the comm block alive until every rank has finished (a peer may still be reading its own copy of the flags)
     open(os.path.join(workdir, f"done_{rank}"), "w").write("ok")
     for q in range(world):

@@ -105,7 +105,7 @@ def test_rccl_world_size_one(built_lib):
     assert ci["launches_per_iteration"] == 2 and ci["graph_replay"]      # update (+ push), SpMV (+ finalizer block)
 
 
-@pytest.mark.parametrize("scene,world", [("beam", 2), ("varvisc", 2), ("beam128", 3), ("beam128", 8)])
+@pytest.mark.parametrize("scene,world", [("beam", 2), ("varvisc", 2), ("beam128", 3), ("beam128", 8), ("varvisc128", 3)])
 def test_processes_direct_transport(scene, world, tmp_path, built_lib):
     """One PROCESS per rank (both on cuda:0): comm blocks mapped through HIP IPC handles, halo entries stored straight into
     the neighbour's block, CG sums by flag-based all-gather -- no RCCL anywhere (hosted group, blobs through files)."""
@@ -115,7 +115,9 @@ def test_processes_direct_transport(scene, world, tmp_path, built_lib):
     dev = torch.device("cuda:0")
     sc = {"beam": lambda: scenes.fat_beam(64, 3, device=dev),
           "varvisc": lambda: scenes.fat_beam(64, 3, variable_viscosity=True, device=dev),
-          "beam128": lambda: scenes.fat_beam(128, 3, device=dev)}[scene]()
+          "beam128": lambda: scenes.fat_beam(128, 3, device=dev),
+          # tile-local dictionaries + windowed columns through the HALO instantiation of the SpMV (peer-written halo area)
+          "varvisc128": lambda: scenes.fat_beam(128, 4, variable_viscosity=True, device=dev)}[scene]()
     pyr = build_pyramid(sc)
     ref = make_solver(sc, pyr)
     tol = 1e-9
@@ -133,7 +135,9 @@ def test_processes_direct_transport(scene, world, tmp_path, built_lib):
     n_own = 0
     for r in range(world):
         x += np.load(tmp_path / f"x_{r}.npy")
-        it1, c1, it2, c2, own, halo, direct, rccl_calls, launches = np.load(tmp_path / f"info_{r}.npy")
+        it1, c1, it2, c2, own, halo, direct, rccl_calls, launches, tile_tables, windows = np.load(tmp_path / f"info_{r}.npy")
+        if scene == "varvisc128":
+            assert tile_tables == 1 and windows == 1
         assert c1 == 1 and c2 == 1 and it1 == it2 and abs(it1 - iref.iterations) <= 3
         assert direct == 1 and rccl_calls == 0 and launches <= 4 and halo > 0
         n_own += int(own)
