@@ -97,18 +97,22 @@ def test_transfer_full_size_properties(built_lib):
         assert out[a][sel].min() >= x.min() - 1e-3 and out[a][sel].max() <= x.max() + 1e-3
 
 
-def test_non_power_of_two_simulation_grid(built_lib):
+@pytest.mark.parametrize("n,fres,levels,center,half", [
+    (64, (48, 40, 24), 3, (24, 20, 12), (17, 13, 6.5)),
+    (64, (50, 33, 17), 3, (25, 16.5, 8.5), (18, 10, 3.4)),        # odd extents, a thin slab: tiles and bricks cut by the grid border
+    (128, (96, 70, 40), 4, (48, 35, 20), (40, 28, 13.5)),         # four levels on a padded lattice
+])
+def test_non_power_of_two_simulation_grid(n, fres, levels, center, half, built_lib):
     """A 48 x 40 x 24 simulation grid (what a real Houdini frame looks like): HDK_OctreeGrid::init stretches the octree grid
     to 64^3 (oct.cpp:10-24) and keeps every cell outside the simulation grid INACTIVE (oct.cpp:375-379).  The device pre-pass
     takes the SDF on the simulation grid, the solve context the scalar fields, the transfer returns the simulation grid's
     faces.  Reference: the oracle on the 64^3 lattice with analytic fields (nothing outside the 48 x 40 x 24 box may
     matter): pyramid, regular-grid classification, CSR, rhs bit-exact; transfer bit-exact from the same solution vector."""
-    n, fres = 64, (48, 40, 24)
     dx = 1.0 / n
-    liquid = scenes.box_sdf((n, n, n), dx, center=(24 * dx, 20 * dx, 12 * dx), half=(17 * dx, 13 * dx, 6.5 * dx))
+    liquid = scenes.box_sdf((n, n, n), dx, center=tuple(c * dx for c in center), half=tuple(h * dx for h in half))
     xs = (torch.arange(n, dtype=torch.float64) + 0.5) * dx
     visc = (150.0 * (1.0 + 5.0 * xs))[None, None, :].expand(n, n, n).to(torch.float32).contiguous()
-    sc = scenes.Scene(res=(n, n, n), dx=dx, dt=1.0 / 60.0, levels=3, liquid=liquid, viscosity=visc, density=900.0,
+    sc = scenes.Scene(res=(n, n, n), dx=dx, dt=1.0 / 60.0, levels=levels, liquid=liquid, viscosity=visc, density=900.0,
                       velocity=scenes.smooth_velocity((n, n, n), dx, gravity_dt=0.1), name="corner_box")
     o = oracle_for_scene(sc)
     o.prepass()
@@ -116,7 +120,7 @@ def test_non_power_of_two_simulation_grid(built_lib):
     o.hot_path()
     # device side: everything on the simulation grid
     crop = lambda t, add=(0, 0, 0): t[:fres[2] + add[2], :fres[1] + add[1], :fres[0] + add[0]].contiguous()
-    pp = DevicePrepass((n, n, n), dx, 3, field_res=fres)
+    pp = DevicePrepass((n, n, n), dx, levels, field_res=fres)
     info = pp.run(crop(liquid).cuda(), None)
     assert info.levels == o.levels and (info.n_velocity, info.n_edge, info.n_center) == (o.count(0), o.count(1), o.count(2))
     assert info.n_regular == o.regular_count
