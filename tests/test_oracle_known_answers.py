@@ -133,6 +133,11 @@ def test_pcg_matches_independent_scipy_cg():
     # parallel variant gives the same answer up to summation order
     xp, infop = o.solve(1e-12, 20000, threads=4)
     assert rel_l2(xp, x) < 1e-9
+    # ... and is deterministic for a given thread count: the dot products add per-thread shares in thread order (an OpenMP
+    # `reduction` combined them in arrival order, and the iteration count of a long solve wandered from run to run)
+    for _ in range(3):
+        xq, infoq = o.solve(1e-12, 20000, threads=4)
+        assert infoq.iterations == infop.iterations and np.array_equal(xq, xp)
 
 
 def test_pcg_zero_rhs_and_converged_guess():
