@@ -95,7 +95,8 @@ class AssemblyInfo(C.Structure):
 
 class DistInfo(C.Structure):
     _fields_ = [("world_size", C.c_int32), ("rccl_ranks", C.c_int32), ("transport", C.c_int32), ("graph_replay", C.c_int32),
-                ("launches_per_iteration", C.c_int32), ("collectives_per_iteration", C.c_int32)]
+                ("launches_per_iteration", C.c_int32), ("collectives_per_iteration", C.c_int32),
+                ("selftest_rounds", C.c_int32), ("paranoid", C.c_int32), ("selftest_bad_entries", C.c_int64)]
 
 
 class MatrixFormat(C.Structure):

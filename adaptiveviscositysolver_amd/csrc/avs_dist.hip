@@ -14,6 +14,7 @@
 // reduction logic and is what tests/test_gpu_dist.py checks against the single-rank solve.
 #include <rccl/rccl.h>
 
+#include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -87,6 +88,12 @@ struct PcgDist {
     int push_grid = 0, push_chunk = 0;
     DevBuf<unsigned long long> epoch;
     DevBuf<unsigned> tickets;
+    DevBuf<uint8_t> blob_send, blob_recv; // RCCL groups: staging of the blob all-gather ...
+    DevBuf<int> vote_word;                // ... and of the transport votes (allocated once, at avs_dist_init)
+    DevBuf<unsigned long long> psum; // paranoid mode: per-peer checksum accumulators of the push
+    DistDev dd_host{};               // what d->dd holds (the self-test toggles `paranoid` around its rounds)
+    long long selftest_bad = -1;     // transport self-test of this plan: -1 not run, else the all-gathered count of bad entries
+    int selftest_rounds = 0;
     std::vector<uint8_t> blob;
     bool direct_prepared = false, direct_ready = false;
     bool direct_pending = false; // a new plan exists: the (collective) transport set-up runs at the next avs_dist_solve
@@ -236,12 +243,34 @@ struct DistBlob {
     int32_t rank, pid, device;
     uint64_t raw_ptr, bytes;
     int64_t n_halo;
+    uint64_t nonce;                 // of the exporting PROCESS: pids alone collide across pid namespaces (containers on one node)
     int32_t recv_off_of[kMaxRanks]; // offset inside my halo area where rank q's entries land (-1: none)
     int32_t recv_cnt_of[kMaxRanks];
+    int32_t send_cnt_of[kMaxRanks]; // what I send to rank q: every rank can check every pair from the gathered blobs
     hipIpcMemHandle_t handle;
     int32_t have_handle;
 };
 static_assert(sizeof(DistBlob) <= AVS_DIST_BLOB_BYTES, "blob does not fit");
+
+// one random 64-bit number per process (not per context): "same process" = same nonce AND same pid
+static uint64_t process_nonce()
+{
+    static const uint64_t nonce = [] {
+        uint64_t v = 0;
+        if (FILE *f = fopen("/dev/urandom", "rb")) {
+            if (fread(&v, sizeof(v), 1, f) != 1) v = 0;
+            fclose(f);
+        }
+        if (!v) { // no urandom: address-space layout + clock + pid
+            timespec ts{};
+            clock_gettime(CLOCK_REALTIME, &ts);
+            v = (uint64_t)(uintptr_t)&v ^ ((uint64_t)ts.tv_nsec << 20) ^ ((uint64_t)ts.tv_sec << 44) ^ (uint64_t)getpid() * 0x9E3779B97F4A7C15ull;
+        }
+        return v | 1ull; // never 0: a zeroed blob is never "this process"
+    }();
+    return nonce;
+}
+static bool same_process(const DistBlob &a, const DistBlob &b) { return a.pid == b.pid && a.nonce == b.nonce && a.nonce != 0; }
 constexpr uint32_t kBlobMagic = 0x41565342u; // "AVSB"
 constexpr size_t kHeaderBytes = (sizeof(CommHeader) + 255) & ~(size_t)255;
 
@@ -281,16 +310,19 @@ static avs_status direct_prepare(avs_ctx *c, PcgDist *d)
     b.magic = kBlobMagic;
     b.rank = d->rank;
     b.pid = (int32_t)getpid();
+    b.nonce = process_nonce();
     b.device = c->desc.device;
     b.raw_ptr = (uint64_t)(uintptr_t)p;
     b.bytes = bytes;
     b.n_halo = d->n_halo;
-    for (int q = 0; q < kMaxRanks; ++q) { b.recv_off_of[q] = -1; b.recv_cnt_of[q] = 0; }
-    for (size_t i = 0; i < d->peers.size(); ++i)
+    for (int q = 0; q < kMaxRanks; ++q) { b.recv_off_of[q] = -1; b.recv_cnt_of[q] = 0; b.send_cnt_of[q] = 0; }
+    for (size_t i = 0; i < d->peers.size(); ++i) {
         if (d->recv_counts[i] > 0) {
             b.recv_off_of[d->peers[i]] = d->recv_offs[i];
             b.recv_cnt_of[d->peers[i]] = d->recv_counts[i];
         }
+        b.send_cnt_of[d->peers[i]] = d->send_counts[i];
+    }
     if (d->world > 1 && hipIpcGetMemHandle(&b.handle, p) == hipSuccess) b.have_handle = 1; // peers in this process need none
     else (void)hipGetLastError();
     d->blob.assign(AVS_DIST_BLOB_BYTES, 0);
@@ -298,8 +330,10 @@ static avs_status direct_prepare(avs_ctx *c, PcgDist *d)
     AVS_TRY(d->dd.alloc(1));
     AVS_TRY(d->epoch.alloc(1));
     AVS_TRY(d->tickets.alloc(2));
+    AVS_TRY(d->psum.alloc(kMaxRanks));
     AVS_HIP(hipMemset(d->epoch.p, 0, sizeof(unsigned long long)));
     AVS_HIP(hipMemset(d->tickets.p, 0, 2 * sizeof(unsigned)));
+    AVS_HIP(hipMemset(d->psum.p, 0, kMaxRanks * sizeof(unsigned long long)));
     d->direct_prepared = true;
     return AVS_OK;
 }
@@ -308,17 +342,18 @@ static avs_status direct_prepare(avs_ctx *c, PcgDist *d)
 // a mismatch fails here, with a status, instead of hanging in the first exchange -- whatever the transport
 static avs_status check_exchange_counts(PcgDist *d, const uint8_t *blobs)
 {
-    for (int q = 0; q < d->world; ++q) {
-        if (q == d->rank) continue;
-        DistBlob b;
-        memcpy(&b, blobs + (size_t)q * AVS_DIST_BLOB_BYTES, sizeof(b));
-        if (b.magic != kBlobMagic) continue; // that rank could not prepare a block: nothing to compare with
-        int mine = 0;
-        for (size_t i = 0; i < d->peers.size(); ++i)
-            if (d->peers[i] == q) mine = d->send_counts[i];
-        AVS_REQUIRE(mine == b.recv_cnt_of[d->rank], AVS_EINTERNAL, "rank %d sends %d halo entries to rank %d, which expects %d", d->rank, mine, q,
-                    b.recv_cnt_of[d->rank]);
-    }
+    // EVERY pair, from the gathered blobs only: all ranks see the same blobs, so all ranks return the same status (a rank-local
+    // verdict would leave the others waiting in the next collective)
+    for (int a = 0; a < d->world; ++a)
+        for (int q = 0; q < d->world; ++q) {
+            if (q == a) continue;
+            DistBlob ba, bq;
+            memcpy(&ba, blobs + (size_t)a * AVS_DIST_BLOB_BYTES, sizeof(ba));
+            memcpy(&bq, blobs + (size_t)q * AVS_DIST_BLOB_BYTES, sizeof(bq));
+            if (ba.magic != kBlobMagic || bq.magic != kBlobMagic) continue; // a rank without a block: nothing to compare with
+            AVS_REQUIRE(ba.send_cnt_of[q] == bq.recv_cnt_of[a], AVS_EINTERNAL, "rank %d sends %d halo entries to rank %d, which expects %d", a,
+                        ba.send_cnt_of[q], q, bq.recv_cnt_of[a]);
+        }
     return AVS_OK;
 }
 
@@ -333,11 +368,11 @@ static avs_status direct_connect(avs_ctx *c, PcgDist *d, const uint8_t *blobs)
         AVS_REQUIRE(all[(size_t)q].magic == kBlobMagic && all[(size_t)q].rank == q, AVS_EINVAL, "direct transport: blob %d is not rank %d's", q, q);
     }
     AVS_TRY(check_exchange_counts(d, blobs));
-    const int32_t my_pid = (int32_t)getpid();
+    const DistBlob &me = all[(size_t)d->rank];
     for (int q = 0; q < d->world; ++q) {
         if (q == d->rank) { d->peer_block[q] = d->comm_block; continue; }
         const DistBlob &b = all[(size_t)q];
-        if (b.pid == my_pid) { // same process (in-process group): the pointer itself, peer access when on another GPU
+        if (same_process(b, me) && me.nonce == process_nonce()) { // same process (in-process group): the pointer itself, peer access when on another GPU
             if (b.device != c->desc.device) {
                 const hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
@@ -374,17 +409,25 @@ static avs_status direct_connect(avs_ctx *c, PcgDist *d, const uint8_t *blobs)
         h.peer_rank[i] = q;
         h.send_off[i] = d->send_offs[(size_t)i];
         h.recv_cnt[i] = d->recv_counts[(size_t)i];
+        h.recv_off[i] = d->recv_offs[(size_t)i];
         const int off = all[(size_t)q].recv_off_of[d->rank];
         h.peer_halo_dst[i] = (double *)((char *)d->peer_block[q] + kHeaderBytes) + (off > 0 ? off : 0);
         h.peer_hflag_dst[i] = &((CommHeader *)d->peer_block[q])->hflag[d->rank];
+        h.peer_hsum_dst[i] = &((CommHeader *)d->peer_block[q])->hsum[d->rank];
     }
     h.send_off[h.npeers] = (int)d->n_send;
     for (int q = 0; q < d->world; ++q) {
         CommHeader *hq = (CommHeader *)d->peer_block[q];
         h.all_red_dst[q] = &hq->red[0][d->rank][0];
-        h.all_rflag_dst[q] = &hq->rflag[d->rank];
     }
     h.send_idx = d->send_idx.p;
+    h.psum = d->psum.p;
+    h.inject_stale_round = -1;
+    if (const char *e = getenv("AVS_DIST_PARANOID")) h.paranoid = atoi(e) != 0;
+    if (const char *e = getenv("AVS_DIST_INJECT_STALE")) { // test hook: proves the paranoid check sees a stale entry
+        h.inject_stale_round = atoll(e);
+        h.paranoid = 1;
+    }
     // segments of the send lists per workgroup of the fused update + push kernel (send lists are ascending local row ids)
     {
         sr_update_geometry((long long)d->n_own, &d->push_grid, &d->push_chunk);
@@ -429,8 +472,11 @@ static avs_status direct_connect(avs_ctx *c, PcgDist *d, const uint8_t *blobs)
     if (const char *e = getenv("AVS_DIST_TIMEOUT_MS")) ms = atoll(e) > 0 ? atoll(e) : ms;
     h.timeout_ticks = (long long)khz * ms;
     AVS_HIP(hipMemcpy(d->dd.p, &h, sizeof(h), hipMemcpyHostToDevice));
+    d->dd_host = h;
     d->direct_ready = true;
     d->transport = AVS_TRANSPORT_DIRECT;
+    d->selftest_bad = -1;
+    d->selftest_rounds = 0;
     return AVS_OK;
 }
 
@@ -451,6 +497,38 @@ bool dist_direct_args(PcgDist *d, DirectArgs *out)
     out->n_tiles_bnd = d->n_tiles_bnd;
     out->tile_flags = d->tile_flags.p;
     return true;
+}
+
+// Transport self-test (avs_pcg.hip: direct_selftest).  Runs with `paranoid` forced on, then restores the plan's setting.  Returns
+// AVS_OK when the rounds ran; *passed tells whether every entry of every round arrived intact and in time ON EVERY RANK (the
+// count is all-gathered through the comm blocks, so all ranks agree without another collective).  AVS_DIST_SELFTEST_ROUNDS=0 skips.
+static avs_status run_selftest(avs_ctx *c, PcgDist *d, bool *passed)
+{
+    *passed = true;
+    int rounds = 64;
+    if (const char *e = getenv("AVS_DIST_SELFTEST_ROUNDS")) rounds = atoi(e);
+    if (const char *e = getenv("AVS_DIST_LOOPBACK"))
+        if (atoi(e) != 0) rounds = 0; // a looped-back rank never fills its halo area
+    if (rounds <= 0 || !d->direct_ready) return AVS_OK;
+    DirectArgs da;
+    if (!dist_direct_args(d, &da)) return AVS_OK;
+    DistDev h = d->dd_host;
+    const int keep_paranoid = h.paranoid;
+    h.paranoid = 1;
+    AVS_HIP(hipMemcpyAsync(d->dd.p, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+    long long bad = 0;
+    int fault = 0;
+    const avs_status st = direct_selftest(da, rounds, c->stream, &bad, &fault);
+    h.paranoid = keep_paranoid;
+    AVS_HIP(hipMemcpyAsync(d->dd.p, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+    AVS_HIP(hipStreamSynchronize(c->stream));
+    AVS_TRY(st);
+    d->selftest_rounds = rounds;
+    d->selftest_bad = fault ? -2 : bad;
+    *passed = fault == 0 && bad == 0;
+    if (!*passed)
+        set_error("direct transport self-test failed on rank %d: %lld bad halo entries / checksums in %d rounds, fault %d", d->rank, bad, rounds, fault);
+    return AVS_OK;
 }
 
 // after a plan exists: choose the transport, exchange the blobs, connect -- all ranks end up with the SAME transport
@@ -484,9 +562,8 @@ static avs_status direct_setup(avs_ctx *c, PcgDist *d)
         }
         g->barrier();
     } else if (d->comm) {
-        DevBuf<uint8_t> send, recv;
-        AVS_TRY(send.alloc(AVS_DIST_BLOB_BYTES));
-        AVS_TRY(recv.alloc(all.size()));
+        DevBuf<uint8_t> &send = d->blob_send, &recv = d->blob_recv; // (allocated in avs_dist_init: no allocation between collectives)
+        AVS_REQUIRE(send.p && recv.n >= all.size(), AVS_EINTERNAL, "blob staging was not allocated at avs_dist_init");
         if (!ok) d->blob.assign(AVS_DIST_BLOB_BYTES, 0);
         AVS_HIP(hipMemcpyAsync(send.p, d->blob.data(), AVS_DIST_BLOB_BYTES, hipMemcpyHostToDevice, c->stream));
         AVS_NCCL(ncclAllGather(send.p, recv.p, AVS_DIST_BLOB_BYTES, ncclUint8, d->comm, c->stream));
@@ -495,61 +572,84 @@ static avs_status direct_setup(avs_ctx *c, PcgDist *d)
     } else {
         return AVS_OK;
     }
-    if (d->world > 1) AVS_TRY(check_exchange_counts(d, all.data()));
+    if (d->world > 1) AVS_TRY(check_exchange_counts(d, all.data())); // (decided from the gathered blobs: the same status on every rank)
     if (off) { // RCCL transport requested: the comm block is not needed
         direct_release(d);
         return AVS_OK;
     }
-    // Ranks of ONE process on ONE device (virtual ranks, a test set-up) share that device's few hardware queues: the
-    // waiting kernel of one rank can sit in the same queue in front of the kernel it waits for (measured:
-    // tools/probes/spin_probe.hip, only as many streams as hardware queues make progress).  Such groups keep the
-    // host-mediated transport unless AVS_DIST_TRANSPORT=direct insists.  Every rank sees the same blobs => same decision.
-    bool shared_device = false;
-    for (int a = 0; a < d->world && ok; ++a)
+    // Every decision below is taken from the GATHERED blobs (identical on all ranks), never from a rank-local result, so that no
+    // rank leaves while the others enter the vote: a blob without the magic = that rank could not prepare a block = nobody connects.
+    bool every = true, shared_device = false;
+    for (int a = 0; a < d->world; ++a) {
+        DistBlob ba;
+        memcpy(&ba, all.data() + (size_t)a * AVS_DIST_BLOB_BYTES, sizeof(ba));
+        if (ba.magic != kBlobMagic) { every = false; continue; }
+        // Ranks of ONE process on ONE device (virtual ranks, a test set-up) share that device's few hardware queues: the
+        // waiting kernel of one rank can sit in the same queue in front of the kernel it waits for (measured:
+        // tools/probes/spin_probe.hip, only as many streams as hardware queues make progress).  Such groups keep the
+        // host-mediated transport unless AVS_DIST_TRANSPORT=direct insists.
         for (int b2 = a + 1; b2 < d->world; ++b2) {
-            DistBlob ba, bb;
-            memcpy(&ba, all.data() + (size_t)a * AVS_DIST_BLOB_BYTES, sizeof(ba));
+            DistBlob bb;
             memcpy(&bb, all.data() + (size_t)b2 * AVS_DIST_BLOB_BYTES, sizeof(bb));
-            if (ba.magic == kBlobMagic && bb.magic == kBlobMagic && ba.pid == bb.pid && ba.device == bb.device) shared_device = true;
+            if (bb.magic == kBlobMagic && same_process(ba, bb) && ba.device == bb.device) shared_device = true;
         }
-    if (shared_device && !forced) {
+    }
+    if (!every || (shared_device && !forced)) {
         direct_release(d);
+        if (!every && forced) {
+            set_error("direct transport: a rank could not allocate / export its comm block");
+            return st != AVS_OK ? st : AVS_ERCCL;
+        }
         return AVS_OK;
     }
-    if (ok) {
-        st = direct_connect(c, d, all.data());
-        ok = st == AVS_OK ? 1 : 0;
-    }
-    // agreement: one rank that cannot connect sends everybody back to the RCCL transport
+    st = direct_connect(c, d, all.data());
+    ok = st == AVS_OK ? 1 : 0;
+    // agreement: one rank that cannot connect sends everybody back to the RCCL transport.  (The vote's device word is allocated
+    // before the collective is entered; an allocation failure there is reported as a "no" vote through a host-side 0.)
+    auto vote = [&](int mine, int *all_ok) -> avs_status {
+        *all_ok = mine;
+        if (d->world > 1 && d->group) {
+            avs_local_group *g = d->group;
+            {
+                std::lock_guard<std::mutex> lk(g->m);
+                if (d->rank == 0) g->direct_votes = 0;
+            }
+            g->barrier();
+            {
+                std::lock_guard<std::mutex> lk(g->m);
+                g->direct_votes += mine;
+            }
+            g->barrier();
+            {
+                std::lock_guard<std::mutex> lk(g->m);
+                *all_ok = g->direct_votes == d->world;
+            }
+            g->barrier();
+        } else if (d->world > 1 && d->comm) {
+            AVS_HIP(hipMemcpyAsync(d->vote_word.p, &mine, sizeof(int), hipMemcpyHostToDevice, c->stream));
+            AVS_NCCL(ncclAllReduce(d->vote_word.p, d->vote_word.p, 1, ncclInt32, ncclMin, d->comm, c->stream));
+            AVS_HIP(hipMemcpyAsync(all_ok, d->vote_word.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            AVS_HIP(hipStreamSynchronize(c->stream));
+        }
+        return AVS_OK;
+    };
     int all_ok = ok;
-    if (d->world > 1 && d->group) {
-        avs_local_group *g = d->group;
-        {
-            std::lock_guard<std::mutex> lk(g->m);
-            if (d->rank == 0) g->direct_votes = 0;
+    AVS_TRY(vote(ok, &all_ok));
+    if (all_ok) {
+        // every rank is connected: prove the links before a solve depends on them.  The rounds rendezvous through the comm blocks
+        // themselves; the bad-entry count is all-gathered there, and one more vote covers a rank whose rounds timed out.
+        bool passed = true;
+        const avs_status ts = run_selftest(c, d, &passed);
+        int pass_all = (ts == AVS_OK && passed) ? 1 : 0;
+        AVS_TRY(vote(pass_all, &pass_all));
+        if (!pass_all) {
+            all_ok = 0;
+            if (st == AVS_OK) st = AVS_ERCCL;
         }
-        g->barrier();
-        {
-            std::lock_guard<std::mutex> lk(g->m);
-            g->direct_votes += ok;
-        }
-        g->barrier();
-        {
-            std::lock_guard<std::mutex> lk(g->m);
-            all_ok = g->direct_votes == d->world;
-        }
-        g->barrier();
-    } else if (d->world > 1 && d->comm) {
-        DevBuf<int> v;
-        AVS_TRY(v.alloc(1));
-        AVS_HIP(hipMemcpyAsync(v.p, &ok, sizeof(int), hipMemcpyHostToDevice, c->stream));
-        AVS_NCCL(ncclAllReduce(v.p, v.p, 1, ncclInt32, ncclMin, d->comm, c->stream));
-        AVS_HIP(hipMemcpyAsync(&all_ok, v.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        AVS_HIP(hipStreamSynchronize(c->stream));
     }
     if (!all_ok) {
         if (forced) {
-            if (ok) set_error("direct transport: another rank could not connect");
+            if (ok && st == AVS_OK) set_error("direct transport: another rank could not connect");
             return st != AVS_OK ? st : AVS_ERCCL;
         }
         direct_release(d); // quietly: the RCCL / host-mediated transport takes over
@@ -1316,6 +1416,9 @@ avs_status avs_dist_init(avs_ctx *c, const uint8_t id[AVS_UNIQUE_ID_BYTES], int3
     AVS_TRY(new_dist(c, rank, world));
     ncclUniqueId u;
     memcpy(&u, id, sizeof(u));
+    AVS_TRY(c->dist->blob_send.alloc(AVS_DIST_BLOB_BYTES)); // staging of the transport set-up collectives: allocated here, so that no
+    AVS_TRY(c->dist->blob_recv.alloc((size_t)world * AVS_DIST_BLOB_BYTES)); // rank can fail an allocation BETWEEN two collectives
+    AVS_TRY(c->dist->vote_word.alloc(1));
     AVS_NCCL(ncclCommInitRank(&c->dist->comm, world, u, rank));
     // second communicator for the point-to-point traffic (same ranks); without it the exchange shares
     // `comm` and stays on the solver stream (no overlap)
@@ -1405,15 +1508,20 @@ static avs_status direct_connect_loopback(avs_ctx *c, PcgDist *d)
     DistDev h;
     AVS_HIP(hipMemcpy(&h, d->dd.p, sizeof(h), hipMemcpyDeviceToHost));
     CommHeader *mine = (CommHeader *)d->comm_block;
-    for (int i = 0; i < h.npeers; ++i) h.peer_hflag_dst[i] = &mine->hflag[h.peer_rank[i]];
+    for (int i = 0; i < h.npeers; ++i) {
+        h.peer_hflag_dst[i] = &mine->hflag[h.peer_rank[i]];
+        h.peer_hsum_dst[i] = &mine->hsum[h.peer_rank[i]];
+    }
+    h.paranoid = 0; // the halo area of a looped-back rank is never written: nothing to check
+    h.inject_stale_round = -1;
     for (int q = 0; q < d->world; ++q) {
         h.all_red_dst[q] = &mine->red[0][q][0]; // as if rank q had written its sums into my block
-        h.all_rflag_dst[q] = &mine->rflag[q];
     }
     // a peer that only sends to me (no entry from me to it) would never get its flag raised: give every receive a sender
     for (int i = 0; i < h.npeers; ++i)
         AVS_REQUIRE(h.recv_cnt[i] == 0 || h.send_off[i + 1] > h.send_off[i], AVS_EINTERNAL, "loopback: peer %d sends but does not receive", h.peer_rank[i]);
     AVS_HIP(hipMemcpy(d->dd.p, &h, sizeof(h), hipMemcpyHostToDevice));
+    d->dd_host = h;
     return AVS_OK;
 }
 
@@ -1424,7 +1532,16 @@ avs_status avs_dist_import_blobs(avs_ctx *c, const uint8_t *blobs)
     if (const char *e = getenv("AVS_DIST_LOOPBACK"))
         if (atoi(e) != 0) return direct_connect_loopback(c, c->dist);
     AVS_REQUIRE(blobs, AVS_EINVAL, "null argument");
-    return direct_connect(c, c->dist, blobs);
+    AVS_TRY(direct_connect(c, c->dist, blobs));
+    // hosted group: every rank calls this with the same blobs; the self-test's rounds rendezvous through the comm blocks.  There is
+    // no other transport to fall back to, so a failure is an error.
+    bool passed = true;
+    AVS_TRY(run_selftest(c, c->dist, &passed));
+    if (!passed) {
+        c->dist->direct_ready = false;
+        return AVS_ERCCL;
+    }
+    return AVS_OK;
 }
 
 avs_status avs_dist_partition(avs_ctx *c, int32_t cut_axis)
@@ -1664,6 +1781,9 @@ avs_status avs_dist_get_info(avs_ctx *c, avs_dist_info *info)
         info->rccl_ranks = cnt;
     }
     info->transport = d->transport;
+    info->selftest_rounds = d->selftest_rounds;
+    info->selftest_bad_entries = d->selftest_bad;
+    info->paranoid = d->direct_ready ? d->dd_host.paranoid : 0;
     if (d->direct_ready) {
         const char *e = getenv("AVS_PCG_GRAPH");
         info->graph_replay = !(e && atoi(e) == 0);

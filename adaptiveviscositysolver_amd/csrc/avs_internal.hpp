@@ -273,7 +273,8 @@ constexpr int kMaxRanks = 32;
 
 struct CommHeader {                               // start of every comm block (device memory, written by peers)
     unsigned long long hflag[kMaxRanks];          // hflag[q]: epoch of the last halo rank q completed in my halo area
-    unsigned long long rflag[kMaxRanks];          // (unused since the partial-sum slots carry their own arrival: kept for the layout)
+    unsigned long long hsum[kMaxRanks];           // paranoid mode (AVS_DIST_PARANOID=1, the transport self-test): checksum (sum of the bit
+                                                  // patterns mod 2^64) of the entries rank q stored in this round, written BEFORE hflag[q]
     double red[2][kMaxRanks][4];                  // the partial sums, double-buffered by epoch parity; armed with an all-ones NaN,
                                                   // a slot is "there" as soon as it holds anything else (re-armed by its reader)
 };
@@ -289,7 +290,16 @@ struct DistDev {                                  // device-resident, read-only 
     double *peer_halo_dst[kMaxRanks];             // where my entries for peer i start inside ITS halo area
     unsigned long long *peer_hflag_dst[kMaxRanks]; // &peer i's hflag[my rank]
     double *all_red_dst[kMaxRanks];               // &rank q's red[0][my rank][0] (q = 0 .. world-1, me included)
-    unsigned long long *all_rflag_dst[kMaxRanks]; // &rank q's rflag[my rank]
+    // paranoid mode: every pushing workgroup adds the bit patterns of what it stored for peer i to psum[i] (device-local
+    // accumulators) before it takes its ticket; the last one moves the totals into the peers' hsum[my rank], waits for the
+    // acknowledgement, then raises the flags.  The reader (dist_finalize, once per round, before it contributes its partial sums --
+    // i.e. before any peer can start the next round) re-adds its halo segments and compares: a stale or torn halo entry is a
+    // fault (code 4), not a silently wrong product.
+    int paranoid;
+    int recv_off[kMaxRanks];                      // where peer i's entries start inside my halo area
+    unsigned long long *peer_hsum_dst[kMaxRanks]; // &peer i's hsum[my rank]
+    unsigned long long *psum;                     // kMaxRanks accumulators (zero between rounds)
+    long long inject_stale_round;                 // test hook (AVS_DIST_INJECT_STALE=k): in round k the first entry for peer 0 is NOT stored
     const int32_t *send_idx;
     long long timeout_ticks;                      // wall_clock64() ticks a flag wait may take before it reports a fault
     // fused update + push (k_sr_update_push): workgroup b of push_grid owns rows [b push_chunk, (b+1) push_chunk); the entries
@@ -311,6 +321,8 @@ struct DirectArgs {                               // what pcg_solve_direct needs
     const uint8_t *tile_flags = nullptr; // per tile: 1 = reads halo columns
 };
 bool dist_direct_args(PcgDist *d, DirectArgs *out); // false: the direct transport is not connected
+// `rounds` pattern rounds over the connected blocks (avs_pcg.hip); *bad_entries = all-gathered count of wrong entries / checksums
+avs_status direct_selftest(const DirectArgs &da, int rounds, hipStream_t stream, long long *bad_entries, int *fault);
 
 // inputs already laid out on the PADDED octree lattice (what the device pre-pass produces): no crop / pad step (avs_api.hip, avs_post.hip)
 avs_status set_scalar_field_lattice(::avs_ctx *c, avs_field_kind kind, int32_t axis, const float *data, float constant, avs_memspace where,

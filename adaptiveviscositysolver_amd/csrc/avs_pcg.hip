@@ -63,6 +63,7 @@ struct HaloView {                        // by-value argument of the SpMV launch
     int ntiles = 0, ppt = 1, nfin = 1;   // workgroups ntiles .. ntiles + nfin - 1 of the launch are the finalizers
     int g = 0, nred_vec = 0, op = 0;
     double tol = 0.;
+    int selftest = 0;                    // the caller (k_direct_selftest) has run paranoid_check itself
 };
 constexpr unsigned long long kSentinel = 0xFFFFFFFFFFFFFFFFull; // an all-ones NaN: never a partial sum
 constexpr int kFinShare = 16384;         // stage slots one finalizer block watches and folds
@@ -71,8 +72,12 @@ constexpr int kFinShare = 16384;         // stage slots one finalizer block watc
 // XCD's L2 -- the vectors just written -- and measured 15 us per round):
 //   * everything a peer (or another XCD) must see is written with system- / agent-scope ATOMIC stores or exchanges: they
 //     write through to memory; everything read back is read with atomic loads, which bypass the caches;
-//   * "data before flag": the writer waits for its own stores to be acknowledged (s_waitcnt, what a workgroup-scope
-//     release fence compiles to) or uses exchanges, whose return value IS the acknowledgement, before the flag goes out.
+//   * "data before flag": the writer waits for its own stores to be acknowledged -- an explicit `s_waitcnt vmcnt(0)`
+//     (wait_own_stores; on gfx950 stores count in vmcnt and a write-through store is acknowledged by the memory side it was
+//     written through to: the peer's HBM over xGMI for sc0 sc1, this device's memory for sc1) -- or uses exchanges, whose
+//     return value IS the acknowledgement, before the ticket / flag goes out.  A workgroup-scope release fence is NOT
+//     enough: it lowers to `s_waitcnt lgkmcnt(0)` only (round-2 review, found in the shipped ISA).  tests/test_isa_ordering.py
+//     disassembles the library and checks that the wait sits between the last halo store and the barrier / ticket.
 __device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -82,7 +87,12 @@ __device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ double ld_sys_f64(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void wait_own_stores() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+__device__ __forceinline__ void wait_own_stores()
+{
+    // every VMEM operation this wave has issued (loads, stores, atomics) has completed: no cache write-back, no invalidate.
+    // The "memory" clobber keeps the compiler from moving the stores below it or the ticket / flag above it.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 // bounded wait: a missing peer must not hang the GPU (the host turns the fault into AVS_ERCCL)
 __device__ __forceinline__ bool wait_flag(const unsigned long long *f, unsigned long long want, long long timeout, PcgScalars *sc, int code)
 {
@@ -97,6 +107,19 @@ __device__ __forceinline__ bool wait_flag(const unsigned long long *f, unsigned 
         __builtin_amdgcn_s_sleep(4);
     }
     return true;
+}
+
+// paranoid mode / transport self-test: checksums are sums of the 64-bit patterns (mod 2^64: order-independent, exact)
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v; // lane 0
+}
+// what rank `from` stores as entry k of its segment in round E of the transport self-test (never the sentinel, never 0)
+__device__ __forceinline__ unsigned long long selftest_pattern(unsigned long long E, int from, int k)
+{
+    return (E << 40) ^ ((unsigned long long)(from + 1) << 32) ^ (unsigned long long)(unsigned)k ^ 0x4000000000000000ull;
 }
 
 struct PcgWork {
@@ -211,6 +234,54 @@ __device__ __forceinline__ void fold_vec_partials(const HaloView &hv, double acc
     }
 }
 
+// Paranoid mode (AVS_DIST_PARANOID=1 and the transport self-test): once per round, BEFORE this rank contributes its partial sums
+// (so before any peer can start the next round and overwrite the halo), re-add every halo segment and compare with the checksum
+// the sender left in hsum[] ahead of its flag.  A stale / torn / missing entry => fault 4 (AVS_ERCCL on the host).
+// pattern != 0: additionally every entry must BE the self-test pattern of this round (returns the number that are not).
+template <int BLK>
+__device__ unsigned long long paranoid_check(const HaloView &hv, bool pattern)
+{
+    __shared__ unsigned long long pc_red[BLK / 64];
+    __shared__ unsigned long long pc_bad;
+    const DistDev *dd = hv.dd;
+    const int tid = threadIdx.x;
+    const unsigned long long E = *hv.epoch + 1ull;
+    if (tid == 0) pc_bad = 0ull;
+    if (tid < dd->npeers && dd->recv_cnt[tid] > 0) wait_flag(&dd->mine->hflag[dd->peer_rank[tid]], E, dd->timeout_ticks, hv.sc, 1);
+    __syncthreads();
+    const unsigned long long *halo = reinterpret_cast<const unsigned long long *>(dd->my_halo);
+    for (int i = 0; i < dd->npeers; ++i) {
+        const int cnt = dd->recv_cnt[i], off = dd->recv_off[i], q = dd->peer_rank[i];
+        if (cnt <= 0) continue;
+        unsigned long long cs = 0ull, bad = 0ull;
+        for (int j = tid; j < cnt; j += BLK) {
+            const unsigned long long v = ld_sys(halo + off + j);
+            cs += v;
+            if (pattern && v != selftest_pattern(E, q, j)) ++bad;
+        }
+        cs = wave_sum_u64(cs);
+        bad = wave_sum_u64(bad);
+        __syncthreads();
+        if ((tid & 63) == 0) pc_red[tid >> 6] = cs;
+        if ((tid & 63) == 0 && bad) atomicAdd(&pc_bad, bad);
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long t = 0ull;
+#pragma unroll
+            for (int w = 0; w < BLK / 64; ++w) t += pc_red[w];
+            if (t != ld_sys(&dd->mine->hsum[q])) {
+                pc_bad += 1ull << 32; // checksum mismatches in the high half
+                if (!pattern) { // a solve stops here; the self-test only counts (every rank must still get every round's total)
+                    __hip_atomic_store(&hv.sc->fault, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&hv.sc->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    return pc_bad;
+}
+
 // acc[0 .. nred_vec) = this thread's share of the vector partials, acc[nred_vec] = its share of the SpMV's x.Ax
 template <int BLK>
 __device__ void dist_finalize(const HaloView &hv, double acc[4])
@@ -219,6 +290,7 @@ __device__ void dist_finalize(const HaloView &hv, double acc[4])
     __shared__ double fin_sum[4];
     __shared__ double fin_all[kMaxRanks * 4];
     const DistDev *dd = hv.dd;
+    if (dd->paranoid && !hv.selftest) (void)paranoid_check<BLK>(hv, false); // block-uniform
     const int tid = threadIdx.x;
     const int nred = hv.nred_vec + 1;
 #pragma unroll
@@ -1696,6 +1768,26 @@ void sr_update_geometry(long long n, int *grid, int *chunk)
     *grid = (int)((n + c - 1) / c > 0 ? (n + c - 1) / c : 1);
 }
 
+// One thread of every pushing workgroup, AFTER the workgroup's stores have been acknowledged (wait_own_stores + barrier): take a
+// ticket; the last one raises this rank's flag in the blocks of the peers it feeds.  Paranoid mode: the round's checksums first,
+// acknowledged, then the flags.
+__device__ __forceinline__ void push_raise_flags(const DistDev *dd, const unsigned long long *epoch, unsigned *ticket, unsigned nblocks)
+{
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t != nblocks - 1u) return;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int np = dd->npeers;
+    const unsigned long long E = *epoch + 1ull;
+    if (dd->paranoid) {
+        for (int i = 0; i < np; ++i)
+            if (dd->send_off[i + 1] > dd->send_off[i])
+                st_sys(dd->peer_hsum_dst[i], __hip_atomic_exchange(dd->psum + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        wait_own_stores();
+    }
+    for (int i = 0; i < np; ++i)
+        if (dd->send_off[i + 1] > dd->send_off[i]) st_sys(dd->peer_hflag_dst[i], E);
+}
+
 // k_sr_update + k_push in one launch: workgroup b owns a CONTIGUOUS range of rows, updates them, and then stores those of its
 // new u entries that a peer reads straight into that peer's halo area; the last pushing workgroup raises the flags.
 __global__ __launch_bounds__(kBlock) void k_sr_update_push(int64_t n, double *__restrict__ x, double *__restrict__ r, double *__restrict__ p,
@@ -1735,26 +1827,28 @@ __global__ __launch_bounds__(kBlock) void k_sr_update_push(int64_t n, double *__
         partial[gridDim.x + blockIdx.x] = rr;
     }
     const int np = dd->npeers, G = (int)gridDim.x, b = (int)blockIdx.x;
+    const int paranoid = dd->paranoid;
+    const bool inject = paranoid && dd->inject_stale_round == (long long)(*epoch + 1ull); // test hook: one entry is NOT stored
     bool any = false;
     for (int i = 0; i < np; ++i) {
         const int a = dd->push_seg[i * (G + 1) + b], e = dd->push_seg[i * (G + 1) + b + 1];
         double *dst = dd->peer_halo_dst[i] - dd->send_off[i];
-        for (int j = a + (int)threadIdx.x; j < e; j += kBlock)
-            __hip_atomic_store(dst + j, u[dd->send_idx[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        unsigned long long cs = 0ull;
+        for (int j = a + (int)threadIdx.x; j < e; j += kBlock) {
+            const double v = u[dd->send_idx[j]];
+            if (!(inject && j == 0)) __hip_atomic_store(dst + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            cs += (unsigned long long)__double_as_longlong(v);
+        }
+        if (paranoid && e > a) { // (block-uniform condition)
+            cs = wave_sum_u64(cs);
+            if ((threadIdx.x & 63) == 0 && cs) __hip_atomic_fetch_add(dd->psum + i, cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         any = any || e > a;
     }
     if (!any) return; // block-uniform
     wait_own_stores();
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == (unsigned)dd->n_send_blocks - 1u) {
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long E = *epoch + 1ull;
-            for (int i = 0; i < np; ++i)
-                if (dd->send_off[i + 1] > dd->send_off[i]) st_sys(dd->peer_hflag_dst[i], E);
-        }
-    }
+    if (threadIdx.x == 0) push_raise_flags(dd, epoch, ticket, (unsigned)dd->n_send_blocks);
 }
 
 __global__ __launch_bounds__(256) void k_push(const DistDev *__restrict__ dd, const double *__restrict__ v,
@@ -1765,27 +1859,90 @@ __global__ __launch_bounds__(256) void k_push(const DistDev *__restrict__ dd, co
     const int np = dd->npeers;
     const int n_send = dd->send_off[np];
     const int j = blockIdx.x * 256 + threadIdx.x;
+    const int paranoid = dd->paranoid;
+    const unsigned long long E = *epoch + 1ull;
+    int mine = -1;
+    unsigned long long bits = 0ull;
     if (j < n_send) {
         int i = 0;
         while (j >= dd->send_off[i + 1]) ++i;
+        mine = i;
+        // v == nullptr: the transport self-test's pattern of this round instead of vector entries
+        bits = v ? (unsigned long long)__double_as_longlong(v[dd->send_idx[j]]) : selftest_pattern(E, dd->rank, j - dd->send_off[i]);
         // a write-through store over xGMI / into the peer process's block
-        __hip_atomic_store(dd->peer_halo_dst[i] + (j - dd->send_off[i]), v[dd->send_idx[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!(paranoid && dd->inject_stale_round == (long long)E && j == 0)) // (test hook: one entry is NOT stored)
+            st_sys(reinterpret_cast<unsigned long long *>(dd->peer_halo_dst[i] + (j - dd->send_off[i])), bits);
+    }
+    if (paranoid) {
+        for (int i = 0; i < np; ++i) { // a wave's lanes may feed different peers: one pass per peer
+            if (dd->send_off[i + 1] <= (int)blockIdx.x * 256 || dd->send_off[i] >= (int)(blockIdx.x + 1) * 256) continue; // block-uniform
+            const unsigned long long cs = wave_sum_u64(mine == i ? bits : 0ull);
+            if ((threadIdx.x & 63) == 0 && cs) __hip_atomic_fetch_add(dd->psum + i, cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     wait_own_stores(); // acknowledged by the destination before this wave reaches the barrier
     __syncthreads();
+    if (threadIdx.x == 0) push_raise_flags(dd, epoch, ticket, gridDim.x); // every block's stores are out: raise my flag in the blocks of the peers I feed
+}
+
+// One round of the transport self-test (direct_selftest): a single workgroup waits for the peers' flags, checks the checksums and
+// that every halo entry IS this round's pattern (a stale entry holds the previous round's), then all-gathers the cumulative
+// count of bad entries through the same finalisation the solve uses (which is also the barrier between rounds).
+__global__ __launch_bounds__(256) void k_direct_selftest(HaloView hv, unsigned long long *bad_total)
+{
+    if (hv.sc->done) return; // a wait timed out in an earlier round: the peers find out through their own time limit
+    const unsigned long long bad = paranoid_check<256>(hv, true);
+    __shared__ double cum;
     if (threadIdx.x == 0) {
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == gridDim.x - 1) { // every block's stores are out: raise my flag in the blocks of the peers I feed
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long E = *epoch + 1ull;
-            for (int i = 0; i < np; ++i)
-                if (dd->send_off[i + 1] > dd->send_off[i]) st_sys(dd->peer_hflag_dst[i], E);
-        }
+        *bad_total += (bad & 0xFFFFFFFFull) + (bad >> 32);
+        cum = (double)*bad_total;
     }
+    __syncthreads();
+    double acc[4] = {0., 0., 0., 0.};
+    if (threadIdx.x == 0) acc[0] = cum;
+    dist_finalize<256>(hv, acc);
 }
 
 avs_status spmv_dot_tiles(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc, const int32_t *tiles,
                           int ntiles, hipStream_t stream);
+
+// Transport self-test, run once per plan right after the blocks are connected and before the direct transport is trusted with a
+// solve (round-2 review: "never run on more than one GPU"): `rounds` full-size halo rounds over the real links with a
+// round-dependent pattern, checksum + per-entry verification by the reader while the next flag is already being polled, and the
+// bad-entry count all-gathered through the solve's own finalisation.  Every rank gets the same total => the same decision.
+avs_status direct_selftest(const DirectArgs &da, int rounds, hipStream_t stream, long long *bad_entries, int *fault)
+{
+    DevBuf<PcgScalars> sc;
+    DevBuf<unsigned long long> bad;
+    AVS_TRY(sc.alloc(1));
+    AVS_TRY(bad.alloc(1));
+    AVS_HIP(hipMemsetAsync(sc.p, 0, sizeof(PcgScalars), stream));
+    AVS_HIP(hipMemsetAsync(bad.p, 0, sizeof(unsigned long long), stream));
+    const int push_blocks = da.n_send > 0 ? (da.n_send + 255) / 256 : 0;
+    HaloView hv;
+    hv.dd = da.dd;
+    hv.epoch = da.epoch;
+    hv.epoch_w = da.epoch;
+    hv.fin_ticket = da.fin_ticket;
+    hv.sc = sc.p;
+    hv.nfin = 1;
+    hv.nred_vec = 0;
+    hv.op = 0;
+    hv.selftest = 1;
+    for (int r = 0; r < rounds; ++r) {
+        if (push_blocks)
+            hipLaunchKernelGGL(k_push, dim3(push_blocks), dim3(256), 0, stream, da.dd, (const double *)nullptr, (const unsigned long long *)da.epoch,
+                               da.push_ticket, (const PcgScalars *)sc.p);
+        hipLaunchKernelGGL(k_direct_selftest, dim3(1), dim3(256), 0, stream, hv, bad.p);
+    }
+    AVS_HIP(hipGetLastError());
+    PcgScalars h;
+    AVS_HIP(hipMemcpyAsync(&h, sc.p, sizeof(h), hipMemcpyDeviceToHost, stream));
+    AVS_HIP(hipStreamSynchronize(stream));
+    *fault = h.fault;
+    *bad_entries = (long long)h.red[0]; // the LAST round's all-gathered cumulative count (all ranks hold the same number)
+    return AVS_OK;
+}
 
 static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b, double *x, double tol, int max_iters,
                                    hipStream_t stream, avs_solve_info *info, const DirectArgs &da)
@@ -1864,8 +2021,12 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
         AVS_HIP(hipMemcpyAsync(w->host_sc, sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, stream));
         AVS_HIP(hipStreamSynchronize(stream));
         if (w->host_sc->fault) {
-            set_error("direct transport: a peer's %s did not arrive within the time limit (rank stalled or dead?)",
-                      w->host_sc->fault == 1 ? "halo entries" : "partial sums");
+            if (w->host_sc->fault == 4)
+                set_error("direct transport (paranoid mode): a halo segment does not add up to the checksum its sender left ahead of the flag "
+                          "-- stale or torn halo entries (iteration ~%d)", w->host_sc->iter);
+            else
+                set_error("direct transport: a peer's %s did not arrive within the time limit (rank stalled or dead?)",
+                          w->host_sc->fault == 1 ? "halo entries" : "partial sums");
             return AVS_ERCCL;
         }
         if (info && last_chunk > 0 && timed_chunk) {

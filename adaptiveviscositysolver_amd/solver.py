@@ -195,7 +195,9 @@ class ViscositySolve:
         return {"world_size": int(di.world_size), "rccl_ranks": int(di.rccl_ranks),
                 "transport": {0: "rccl", 1: "direct"}.get(int(di.transport), str(di.transport)),
                 "graph_replay": bool(di.graph_replay), "launches_per_iteration": int(di.launches_per_iteration),
-                "rccl_calls_per_iteration": int(di.collectives_per_iteration)}
+                "rccl_calls_per_iteration": int(di.collectives_per_iteration),
+                "selftest_rounds": int(di.selftest_rounds), "selftest_bad_entries": int(di.selftest_bad_entries),
+                "paranoid": bool(di.paranoid)}
 
     def dist_solution(self):
         n = self.info().n_velocity

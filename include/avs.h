@@ -363,6 +363,11 @@ typedef struct {
     int32_t graph_replay;              /* 1 = full chunks of iterations are replayed from a captured hipGraph */
     int32_t launches_per_iteration;    /* kernel launches per CG iteration of the loop in use */
     int32_t collectives_per_iteration; /* RCCL calls per CG iteration */
+    int32_t selftest_rounds;           /* direct transport: pattern rounds run over the connected comm blocks before the first solve
+                                          (AVS_DIST_SELFTEST_ROUNDS, default 64; 0 = not run) */
+    int32_t paranoid;                  /* 1 = every round's halo segments are checked against the sender's checksum (AVS_DIST_PARANOID=1) */
+    int64_t selftest_bad_entries;      /* all-gathered count of wrong halo entries / checksums in those rounds (0 = passed, -1 = not run,
+                                          -2 = a wait timed out); a non-zero count retires the direct transport for the plan */
 } avs_dist_info;
 avs_status avs_dist_get_info(avs_ctx *ctx, avs_dist_info *info);
 /* gathers the full solution (global DOF order) on every rank */

@@ -48,11 +48,17 @@ def main():
         wait_for(os.path.join(workdir, f"blob_{q}.bin"))
         allb += open(os.path.join(workdir, f"blob_{q}.bin"), "rb").read()
     buf = (C.c_uint8 * len(allb)).from_buffer_copy(allb)
-    capi.check(s.lib.avs_dist_import_blobs(s.h, buf))
     runs = []
-    for _ in range(2):                                   # twice: the second solve replays the captured graph
-        info = s.dist_solve(tol, 5000)
-        runs.append((info.iterations, info.converged, info.error))
+    try:
+        capi.check(s.lib.avs_dist_import_blobs(s.h, buf))    # connects the comm blocks and runs the transport self-test
+        for _ in range(2):                                   # twice: the second solve replays the captured graph
+            info = s.dist_solve(tol, 5000)
+            runs.append((info.iterations, info.converged, info.error))
+    except capi.AvsError as e:                               # (the stale-halo tests expect exactly this)
+        open(os.path.join(workdir, f"err_{rank}.txt"), "w").write(f"{e.status}\n{e}")
+        open(os.path.join(workdir, f"done_{rank}"), "w").write("failed")
+        sys.stderr.write(str(e))
+        sys.exit(7)
     x = s.dist_solution()                                 # hosted group: owned entries, zeros elsewhere
     ci = s.dist_comm_info()
     np.save(os.path.join(workdir, f"x_{rank}.npy"), x)
@@ -60,7 +66,9 @@ def main():
                                                                   s.plan_sizes.n_own, s.plan_sizes.n_halo,
                                                                   1 if ci["transport"] == "direct" else 0,
                                                                   ci["rccl_calls_per_iteration"], ci["launches_per_iteration"],
-                                                                  s.matrix_format().tile_local_tables, s.matrix_format().column_windows], np.float64))
+                                                                  s.matrix_format().tile_local_tables, s.matrix_format().column_windows,
+                                                                  ci["selftest_rounds"], ci["selftest_bad_entries"], 1 if ci["paranoid"] else 0],
+                                                                 np.float64))
     # keep the comm block alive until every rank has finished (a peer may still be reading its own copy of the flags)
     open(os.path.join(workdir, f"done_{rank}"), "w").write("ok")
     for q in range(world):

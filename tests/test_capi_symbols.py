@@ -33,12 +33,12 @@ def test_struct_layouts_match_header(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "avs.h"\nint main(void){printf("%zu %zu %zu\\n", '
                    'sizeof(avs_desc), sizeof(avs_solve_info), sizeof(avs_assembly_info));'
-                   'printf("%zu\\n", sizeof(avs_matrix_format));return 0;}\n')
+                   'printf("%zu %zu\\n", sizeof(avs_matrix_format), sizeof(avs_dist_info));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     assert sizes == [ctypes.sizeof(capi.Desc), ctypes.sizeof(capi.SolveInfo), ctypes.sizeof(capi.AssemblyInfo),
-                     ctypes.sizeof(capi.MatrixFormat)]
+                     ctypes.sizeof(capi.MatrixFormat), ctypes.sizeof(capi.DistInfo)]
 
 
 def test_no_cpu_fallback_without_gpu(built_lib):

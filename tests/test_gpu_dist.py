@@ -135,7 +135,8 @@ def test_processes_direct_transport(scene, world, tmp_path, built_lib):
     n_own = 0
     for r in range(world):
         x += np.load(tmp_path / f"x_{r}.npy")
-        it1, c1, it2, c2, own, halo, direct, rccl_calls, launches, tile_tables, windows = np.load(tmp_path / f"info_{r}.npy")
+        it1, c1, it2, c2, own, halo, direct, rccl_calls, launches, tile_tables, windows, st_rounds, st_bad, paranoid = np.load(tmp_path / f"info_{r}.npy")
+        assert st_rounds == 64 and st_bad == 0 and paranoid == 0    # the transport self-test ran over the mapped blocks and passed
         if scene == "varvisc128":
             assert tile_tables == 1 and windows == 1
         assert c1 == 1 and c2 == 1 and it1 == it2 and abs(it1 - iref.iterations) <= 3
@@ -143,6 +144,55 @@ def test_processes_direct_transport(scene, world, tmp_path, built_lib):
         n_own += int(own)
     assert n_own == len(xref)
     assert rel_l2(x, xref) < 1e-7
+
+
+def _run_hosted(tmp_path, scene, world, tol, extra_env):
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", AVS_DIST_TIMEOUT_MS="30000", **extra_env)
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "hosted_rank.py"), str(tmp_path), str(r), str(world), scene, repr(tol)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=280) for p in procs]
+    return [(p.returncode, so, se) for p, (so, se) in zip(procs, outs)]
+
+
+def test_processes_paranoid_mode(tmp_path, built_lib):
+    """AVS_DIST_PARANOID=1: every round's halo segments are re-added by the reader and compared with the checksum the sender left
+    ahead of its flag (round-2 review: "make the guard able to see a stale halo").  Same iterations and solution as without."""
+    dev = torch.device("cuda:0")
+    sc = scenes.fat_beam(128, 3, device=dev)
+    ref = make_solver(sc, build_pyramid(sc))
+    tol = 1e-9
+    iref = ref.solve(tol, 5000)
+    xref = ref.solution()
+    ref.close()
+    res = _run_hosted(tmp_path, "beam128", 3, tol, {"AVS_DIST_PARANOID": "1"})
+    for rc, so, se in res:
+        assert rc == 0, se[-3000:]
+    x = np.zeros_like(xref)
+    for r in range(3):
+        x += np.load(tmp_path / f"x_{r}.npy")
+        info = np.load(tmp_path / f"info_{r}.npy")
+        assert info[1] == 1 and abs(info[0] - iref.iterations) <= 3
+        assert info[-3] == 64 and info[-2] == 0 and info[-1] == 1
+    assert rel_l2(x, xref) < 1e-7
+
+
+@pytest.mark.parametrize("stale_round,where", [(10, "self-test"), (200, "solve")])
+def test_stale_halo_entry_is_detected(stale_round, where, tmp_path, built_lib):
+    """Test hook AVS_DIST_INJECT_STALE=k: in round k every rank does NOT store the first entry it owes its first peer, so that peer
+    multiplies with the value of round k-1 -- exactly what a flag overtaking its data over xGMI would produce.  Rounds 1..64 are the
+    transport self-test (must fail the connect), later ones belong to the solve (must stop with AVS_ERCCL in paranoid mode)."""
+    res = _run_hosted(tmp_path, "beam128", 2, 1e-9, {"AVS_DIST_INJECT_STALE": str(stale_round), "AVS_DIST_TIMEOUT_MS": "4000"})
+    assert all(rc == 7 for rc, _, _ in res), [se[-500:] for _, _, se in res]
+    msgs = [open(tmp_path / f"err_{r}.txt").read() for r in range(2)]
+    assert all(m.split()[0] == str(capi.ERCCL) for m in msgs), msgs
+    if where == "self-test":
+        assert all("self-test failed" in m for m in msgs), msgs
+    else:
+        assert any("checksum" in m for m in msgs), msgs
 
 
 def _plan_arrays(s):

@@ -1,0 +1,48 @@
+"""The direct transport's "data before flag" must be in the INSTRUCTION STREAM of the shipped library (round-2 review, weak #3).
+
+`wait_own_stores()` used to be a workgroup-scope release fence, which gfx950 lowers to `s_waitcnt lgkmcnt(0)` only: the
+write-through halo stores (sc0 sc1) could still be in flight when the ticket / flag went out.  It is now an explicit
+`s_waitcnt vmcnt(0)`.  These tests disassemble libavs_hip.so (tools/isa_check.py; no GPU needed) and assert that every such
+store is followed by a vmcnt(0) wait before the barrier / ticket atomic, in k_push, k_sr_update_push, k_reduce_mb and the
+finalizer of every HALO SpMV instantiation.  The checker was verified to FAIL on the round-2 source (see profiles/r03_notes.md).
+"""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import isa_check  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not os.path.exists(isa_check.LIB) or not os.path.exists(isa_check.LLVM + "/llvm-objdump"),
+                                reason="needs the built library and llvm-objdump")
+
+
+def test_code_objects_are_gfx950_only():
+    imgs = isa_check.code_objects()
+    assert len(imgs) >= 5  # one per .hip translation unit with kernels
+
+
+def test_halo_stores_are_acknowledged_before_ticket_and_flag():
+    rows = isa_check.run_checks()
+    names = " ".join(k for k, _, _ in rows)
+    for must in ("avs::k_push(", "avs::k_sr_update_push(", "avs::k_reduce_mb(", "k_spmv_vi2<", "k_spmv_tile<"):
+        assert must in names, f"{must} not covered"
+    bad = [(k, m) for k, ok, m in rows if not ok]
+    assert not bad, bad
+
+
+def test_push_kernels_store_write_through_at_system_scope():
+    # the halo entries must leave with sc0 sc1 (system scope, write-through): a plain store could sit in this XCD's L2
+    for pat in (r"^avs::k_push\(", r"^avs::k_sr_update_push\("):
+        for k, ins in isa_check.kernels_matching(pat).items():
+            assert any(isa_check.is_remote_store(s) for s in ins), k
+
+
+def test_checker_is_sensitive():
+    # the same listing with the wait removed must be rejected
+    for k, ins in isa_check.kernels_matching(r"^avs::k_push\(").items():
+        i = max(j for j, s in enumerate(ins) if isa_check.is_remote_store(s) and any(t.startswith("s_barrier") for t in ins[j:]))
+        cut = [s for j, s in enumerate(ins) if not (j > i and isa_check.waits_vmcnt0(s))]
+        ok, _ = isa_check.check_store_wait_sync(cut, isa_check.is_remote_store, isa_check.SYNC)
+        assert not ok
