@@ -1790,9 +1790,14 @@ __device__ __forceinline__ void push_raise_flags(const DistDev *dd, const unsign
 
 // k_sr_update + k_push in one launch: workgroup b owns a CONTIGUOUS range of rows, updates them, and then stores those of its
 // new u entries that a peer reads straight into that peer's halo area; the last pushing workgroup raises the flags.
+// CODED (round 3): the diagonal's 2-B value code + the table of inverted values instead of the 8-B inverse (11.25 n instead of
+// 12 n doubles of vector traffic; the same doubles, so nothing changes numerically).  Rows are taken two at a time with 16-B
+// loads / stores (ranges start at multiples of the block size, so the pairs are aligned).
+template <bool CODED>
 __global__ __launch_bounds__(kBlock) void k_sr_update_push(int64_t n, double *__restrict__ x, double *__restrict__ r, double *__restrict__ p,
                                                            double *__restrict__ s, double *__restrict__ u, const double *__restrict__ w,
-                                                           const double *__restrict__ invd, const PcgScalars *sc, double *__restrict__ partial,
+                                                           const double *__restrict__ invd, const uint16_t *__restrict__ dcode,
+                                                           const PcgScalars *sc, double *__restrict__ partial,
                                                            const DistDev *__restrict__ dd, const unsigned long long *__restrict__ epoch,
                                                            unsigned *__restrict__ ticket)
 {
@@ -1807,7 +1812,38 @@ __global__ __launch_bounds__(kBlock) void k_sr_update_push(int64_t n, double *__
     const double alpha = sc->alpha, beta = sc->beta;
     __shared__ double red[4];
     double ru = 0., rr = 0.;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+    int64_t i = lo + 2 * (int64_t)threadIdx.x;
+    for (; i + 1 < hi; i += 2 * kBlock) { // (lo is a multiple of kBlock: i is even, the 16-B accesses are aligned)
+        const d2_t uv = *reinterpret_cast<const d2_t *>(u + i), pv = *reinterpret_cast<const d2_t *>(p + i);
+        const d2_t wv = *reinterpret_cast<const d2_t *>(w + i), sv = *reinterpret_cast<const d2_t *>(s + i);
+        const d2_t xv = *reinterpret_cast<const d2_t *>(x + i), rv = *reinterpret_cast<const d2_t *>(r + i);
+        double id0, id1;
+        if (CODED) {
+            const unsigned cc = *reinterpret_cast<const unsigned *>(dcode + i);
+            id0 = invd[cc & 0xffffu];
+            id1 = invd[cc >> 16];
+        } else {
+            const d2_t iv = *reinterpret_cast<const d2_t *>(invd + i);
+            id0 = iv.x;
+            id1 = iv.y;
+        }
+        d2_t pn, sn, xn, rn, un;
+        pn.x = uv.x + beta * pv.x;  pn.y = uv.y + beta * pv.y;
+        sn.x = wv.x + beta * sv.x;  sn.y = wv.y + beta * sv.y;
+        xn.x = xv.x + alpha * pn.x; xn.y = xv.y + alpha * pn.y;
+        rn.x = rv.x - alpha * sn.x; rn.y = rv.y - alpha * sn.y;
+        un.x = id0 * rn.x;          un.y = id1 * rn.y;
+        *reinterpret_cast<d2_t *>(p + i) = pn;
+        *reinterpret_cast<d2_t *>(s + i) = sn;
+        *reinterpret_cast<d2_t *>(x + i) = xn;
+        *reinterpret_cast<d2_t *>(r + i) = rn;
+        *reinterpret_cast<d2_t *>(u + i) = un;
+        ru += rn.x * un.x;
+        rr += rn.x * rn.x;
+        ru += rn.y * un.y;
+        rr += rn.y * rn.y;
+    }
+    if (i < hi) { // odd tail of the last range
         const double pi = u[i] + beta * p[i];
         const double si = w[i] + beta * s[i];
         p[i] = pi;
@@ -1815,7 +1851,7 @@ __global__ __launch_bounds__(kBlock) void k_sr_update_push(int64_t n, double *__
         x[i] += alpha * pi;
         const double ri = r[i] - alpha * si;
         r[i] = ri;
-        const double ui = invd[i] * ri;
+        const double ui = (CODED ? invd[dcode[i]] : invd[i]) * ri;
         u[i] = ui;
         ru += ri * ui;
         rr += ri * ri;
@@ -1969,6 +2005,14 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
     AVS_HIP(hipMemsetAsync(p, 0, (size_t)w->n_ext * sizeof(double), stream));
     AVS_HIP(hipMemsetAsync(sv, 0, (size_t)n * sizeof(double), stream));
     hipLaunchKernelGGL(k_inv_diag, dim3(rowgrid), dim3(kBlock), 0, stream, A, invd);
+    // one dictionary of few values: the loop's vector kernel reads a 2-B diagonal code (k_inv_diag_coded; never with tile-local tables)
+    const bool coded = A.codes && !A.tab_ptr && A.table_size <= kViLdsTable;
+    if (coded) {
+        if (!w->dcode.p) AVS_TRY(w->dcode.alloc((size_t)n + 2));
+        if (!w->invtab.p) AVS_TRY(w->invtab.alloc((size_t)kViLdsTable + 1));
+        const int cg = (int)(((n > A.table_size + 1 ? n : A.table_size + 1) + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(k_inv_diag_coded, dim3(cg), dim3(kBlock), 0, stream, A, w->dcode.p, w->invtab.p);
+    }
     AVS_HIP(hipEventRecord(w->ev0, stream));
 
     // one round: exchange `vec`, wv = A vec (+ partials of vec.wv), fold `nred_vec` vector partial arrays + that one, step `op`
@@ -2008,8 +2052,12 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
 
     auto enqueue_iteration = [&](int c, bool timed) -> avs_status {
         // update and push in one launch (3 launches per iteration)
-        hipLaunchKernelGGL(k_sr_update_push, dim3(g), dim3(kBlock), 0, stream, n, x, r, p, sv, u, wv, invd, (const PcgScalars *)sc, pvec, da.dd,
-                           (const unsigned long long *)da.epoch, da.push_ticket);
+        if (coded)
+            hipLaunchKernelGGL(k_sr_update_push<true>, dim3(g), dim3(kBlock), 0, stream, n, x, r, p, sv, u, wv, (const double *)w->invtab.p,
+                               (const uint16_t *)w->dcode.p, (const PcgScalars *)sc, pvec, da.dd, (const unsigned long long *)da.epoch, da.push_ticket);
+        else
+            hipLaunchKernelGGL(k_sr_update_push<false>, dim3(g), dim3(kBlock), 0, stream, n, x, r, p, sv, u, wv, (const double *)invd,
+                               (const uint16_t *)nullptr, (const PcgScalars *)sc, pvec, da.dd, (const unsigned long long *)da.epoch, da.push_ticket);
         return round(u, 2, (int)OP_SR_STEP, timed ? w->evA[c] : nullptr, timed ? w->evB[c] : nullptr, false);
     };
     bool use_graph = true;
@@ -2186,9 +2234,9 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
     AVS_HIP(hipMemsetAsync(sc, 0, sizeof(PcgScalars), stream));
     hipLaunchKernelGGL(k_inv_diag, dim3(rowgrid), dim3(kBlock), 0, stream, A, invd);
     // few distinct values: the two vector kernels of the loop read a 2-B diagonal code instead of the 8-B inverse
-    const bool coded = A.codes && A.table_size <= kViLdsTable;
+    const bool coded = A.codes && !A.tab_ptr && A.table_size <= kViLdsTable; // (tile-local codes are not indices into one table)
     if (coded) {
-        if (!w->dcode.p) AVS_TRY(w->dcode.alloc((size_t)n));
+        if (!w->dcode.p) AVS_TRY(w->dcode.alloc((size_t)n + 2));
         if (!w->invtab.p) AVS_TRY(w->invtab.alloc((size_t)kViLdsTable + 1));
         const int cg = (int)(((n > A.table_size + 1 ? n : A.table_size + 1) + kBlock - 1) / kBlock);
         hipLaunchKernelGGL(k_inv_diag_coded, dim3(cg), dim3(kBlock), 0, stream, A, w->dcode.p, w->invtab.p);

@@ -26,6 +26,9 @@ class Scene:
     solid_velocity: list | None = None                  # None = 0
     use_enhanced_gradients: bool = True
     name: str = ""
+    # Simulation grid when it is smaller than the power-of-two octree lattice `res` (HDK_OctreeGrid::init pads, oct.cpp:10-24).
+    # The tensors above then cover the whole octree lattice (what the oracle takes); crop_to_field() gives what Houdini holds.
+    field_res: tuple | None = None
 
 
 def _axes(res, device, dtype=torch.float32):
@@ -92,6 +95,43 @@ def constant_velocity(res, c, device="cpu"):
     return out
 
 
+def linear_field(res, dx, axis, c0, grad, device="cpu"):
+    """c0 + grad . P sampled on the cell-centre lattice (axis = None) or on the face lattice of `axis` (fp32).  Trilinear
+    interpolation reproduces a linear function exactly, so the value the solver samples at ANY position P must be c0 + grad . P
+    (up to the fp32 rounding of the stored samples) -- which is what tests/independent.py::check_sampled_fields uses to pin the
+    sample POSITIONS of density (cpp:2759-2766) and solid velocity (cpp:1896-1905, 1952-1960) without the oracle."""
+    nx, ny, nz = res
+    r = [nx, ny, nz]
+    if axis is not None:
+        r[axis] += 1
+    ax = []
+    for a in range(3):
+        i = torch.arange(r[a], device=device, dtype=torch.float64)
+        ax.append((i if a == axis else i + 0.5) * dx)
+    v = c0 + grad[0] * ax[0][None, None, :] + grad[1] * ax[1][None, :, None] + grad[2] * ax[2][:, None, None]
+    return v.to(torch.float32).contiguous()
+
+
+def with_sampled_fields(sc, rho0=800.0, rho_grad=(0.25, 1.0, -0.5), device=None):
+    """The same scene with a centre-lattice density TENSOR rho0 (1 + g . P) and a spatially varying solid velocity (a different
+    linear field per component): the branches of the reference that every constant-field scene skips (round-2 review, weak #2)."""
+    device = device if device is not None else sc.liquid.device
+    sc.density = linear_field(sc.res, sc.dx, None, rho0, tuple(rho0 * g for g in rho_grad), device)
+    grads = ((0.5, -1.0, 2.0), (-2.0, 0.5, 1.0), (1.0, 2.0, -0.5))
+    sc.solid_velocity = [linear_field(sc.res, sc.dx, a, 0.3 * (a + 1), grads[a], device) for a in range(3)]
+    sc.name += "_rho_usolid"
+    return sc
+
+
+def sphere_obstacle_sdf(res, dx, center, radius, device="cpu"):
+    """Solid ball (positive inside the solid, cpp:1157): curved SOLIDBOUNDARY surfaces with faces of all three axes."""
+    x, y, z = _axes(res, device)
+    X = ((x + 0.5) * dx - center[0])[None, None, :]
+    Y = ((y + 0.5) * dx - center[1])[None, :, None]
+    Z = ((z + 0.5) * dx - center[2])[:, None, None]
+    return (radius - torch.sqrt(X * X + Y * Y + Z * Z)).to(torch.float32).contiguous()
+
+
 def fat_beam(n, levels, *, variable_viscosity=False, wall=False, device="cpu", dt=1.0 / 60.0,
              viscosity=10000.0, density=1000.0, res=None):
     """The "fat beam" of SURVEY 8(d): half-extents (0.45, 0.225, 0.225) centred in the unit cube."""
@@ -131,6 +171,94 @@ def sphere(n, levels, radius=0.3, device="cpu", dt=1.0 / 60.0, viscosity=100.0):
     vel = smooth_velocity(res, dx, device=device)
     return Scene(res=res, dx=dx, dt=dt, levels=levels, liquid=liquid, viscosity=viscosity,
                  density=1000.0, velocity=vel, name=f"sphere_{n}_L{levels}")
+
+
+def sphere_with_obstacle(n, levels, device="cpu", viscosity=100.0):
+    """Liquid ball with a solid ball cut out of it: SOLIDBOUNDARY faces of all three axes on a curved surface."""
+    sc = sphere(n, levels, device=device, viscosity=viscosity)
+    sc.solid = sphere_obstacle_sdf(sc.res, sc.dx, (0.5, 0.62, 0.45), 0.17, device)
+    sc.name = f"sphere_obstacle_{n}_L{levels}"
+    return sc
+
+
+def _pow2_lattice(field_res):
+    return tuple(1 << max(0, (int(r) - 1).bit_length()) for r in field_res)
+
+
+def viscous_beam_scene(device="cpu", coarsen=1):
+    """Scene-equivalent of /root/reference/Scenes/viscousBeam.hip: FLIP object with particle separation 1/1024
+    and grid scale 2 => dx = 1/512; liquid box 0.51 x 0.1 x 0.1 centred at (0.253, 0.5, 0.5); density 1000, viscosity 10000,
+    60 fps => dt = 1/60; HDK_AdaptiveViscosity: 4 octree levels, tolerance 1e-3, 2500 iterations.  Two ground planes: y = 0 and one
+    rotated -90 degrees about z at x = 0.01 -- a wall the beam's end is clamped in (solid for x < 0.01).
+    The simulation grid is the liquid's bounding box + padding, 304 x 80 x 80 voxels -- NOT powers of two, like any real Houdini frame --
+    and the octree lattice HDK_OctreeGrid::init stretches it to is 512 x 128 x 128.  Velocity: at rest plus one gravity step with a
+    cantilever-like sag rate growing towards the free end (synthetic: the scene file holds no velocity field).
+    `coarsen` = 2, 4: the same geometry on a 2x / 4x coarser grid (CPU-sized plumbing cases)."""
+    dx = 1.0 / 512 * coarsen
+    fres = (304 // coarsen, 80 // coarsen, 80 // coarsen)
+    res = _pow2_lattice(fres)
+    origin = (-16 * dx / coarsen * coarsen, 0.5 - fres[1] // 2 * dx, 0.5 - fres[2] // 2 * dx)
+    dt = 1.0 / 60.0
+    center = tuple(c - o for c, o in zip((0.253, 0.5, 0.5), origin))
+    liquid = box_sdf(res, dx, center, (0.255, 0.05, 0.05), device)
+    wall = wall_sdf(res, dx, 0.01 - origin[0], device)
+    y = (torch.arange(res[1], device=device, dtype=torch.float32) + 0.5) * dx
+    ground = ((0.0 - origin[1]) - y)[None, :, None].expand(res[2], res[1], res[0])
+    solid = torch.maximum(wall, ground).contiguous()
+    vel = constant_velocity(res, (0.0, 0.0, 0.0), device)
+    x = (torch.arange(res[0], device=device, dtype=torch.float64) + 0.5) * dx + origin[0]
+    sag = -9.80665 * dt * (1.0 + 4.0 * (x.clamp(min=0.0) / 0.51) ** 2)
+    vel[1] = sag[None, None, :].expand(res[2], res[1] + 1, res[0]).to(torch.float32).contiguous()
+    return Scene(res=res, dx=dx, dt=dt, levels=4, liquid=liquid, solid=solid, viscosity=10000.0, density=1000.0, velocity=vel,
+                 name=f"viscous_beam_hip_{fres[0]}x{fres[1]}x{fres[2]}", field_res=fres)
+
+
+def viscous_buckling_scene(device="cpu", coarsen=1):
+    """Scene-equivalent of /root/reference/Scenes/viscousBuckling.hip: particle separation 0.0005, grid scale 2 =>
+    dx = 1e-3 -- NOT a power of two, and a fp32 quantity in the reference (getVoxelSize(), cpp:1733): it is handed over as
+    (double)(float)1e-3; source box 0.1 x 0.1 x 0.01 at (0, 0.25, 0) pouring onto the ground plane y = 0; density 1000, viscosity 200,
+    120 fps => dt = 1/120; 4 octree levels requested (the 10-voxel-thick sheet caps what appears).  Modelled as the sheet a few frames
+    in: a 0.1 x 0.3 x 0.01 curtain from the source down INTO the ground (solid boundary faces at its foot), falling at free-fall speed
+    with a lateral sway.  Simulation grid 132 x 330 x 40 voxels (octree lattice 256 x 512 x 64)."""
+    import numpy as np
+    dx = float(np.float32(1e-3)) * coarsen
+    fres = (132 // coarsen, 330 // coarsen, 40 // coarsen)
+    res = _pow2_lattice(fres)
+    origin = (-(fres[0] // 2) * dx, -12 * dx, -(fres[2] // 2) * dx)
+    dt = 1.0 / 120.0
+    lo, hi = (-0.05, -0.004, -0.005), (0.05, 0.3, 0.005)
+    center = tuple(0.5 * (a + b) - o for a, b, o in zip(lo, hi, origin))
+    half = tuple(0.5 * (b - a) for a, b in zip(lo, hi))
+    liquid = box_sdf(res, dx, center, half, device)
+    y = (torch.arange(res[1], device=device, dtype=torch.float32) + 0.5) * dx
+    solid = ((0.0 - origin[1]) - y)[None, :, None].expand(res[2], res[1], res[0]).contiguous()
+    vel = constant_velocity(res, (0.0, 0.0, 0.0), device)
+    yf = torch.arange(res[1] + 1, device=device, dtype=torch.float64) * dx + origin[1]
+    fall = -torch.sqrt(2.0 * 9.80665 * (0.3 - yf).clamp(min=0.0))
+    vel[1] = fall[None, :, None].expand(res[2], res[1] + 1, res[0]).to(torch.float32).contiguous()
+    yc = (torch.arange(res[1], device=device, dtype=torch.float64) + 0.5) * dx + origin[1]
+    sway = 0.05 * torch.sin(2.0 * math.pi * yc / 0.1)
+    vel[0] = sway[None, :, None].expand(res[2], res[1], res[0] + 1).to(torch.float32).contiguous()
+    return Scene(res=res, dx=dx, dt=dt, levels=4, liquid=liquid, solid=solid, viscosity=200.0, density=1000.0, velocity=vel,
+                 name=f"viscous_buckling_hip_{fres[0]}x{fres[1]}x{fres[2]}", field_res=fres)
+
+
+def crop_to_field(scene):
+    """What Houdini holds: every field on the SIMULATION grid (scene.field_res) instead of the padded octree lattice."""
+    import copy
+    if scene.field_res is None:
+        return scene
+    fx, fy, fz = scene.field_res
+
+    def crop(t, add=(0, 0, 0)):
+        return t[:fz + add[2], :fy + add[1], :fx + add[0]].contiguous() if isinstance(t, torch.Tensor) else t
+    out = copy.copy(scene)
+    out.liquid, out.solid = crop(scene.liquid), crop(scene.solid)
+    out.viscosity, out.density = crop(scene.viscosity), crop(scene.density)
+    out.velocity = [crop(scene.velocity[a], tuple(int(b == a) for b in range(3))) for a in range(3)]
+    if scene.solid_velocity is not None:
+        out.solid_velocity = [crop(scene.solid_velocity[a], tuple(int(b == a) for b in range(3))) for a in range(3)]
+    return out
 
 
 def to_device(scene, device):

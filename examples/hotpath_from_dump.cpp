@@ -1,5 +1,6 @@
 // hotpath_from_dump.cpp -- C++ driver of the hot path: reads a field dump (the exchange format a
-// Houdini user exports frames with; writer: adaptiveviscositysolver_amd/dump.py),
+// Houdini user exports frames with; writers: adaptiveviscositysolver_amd/dump.py and the HDK shim;
+// AVSDUMP1 = power-of-two simulation grid, AVSDUMP2 = any grid, scalar fields on the simulation grid's lattices),
 // runs assembly + PCG on the GPU through avs_host.hpp and writes the solution vector.
 //
 //   g++ -std=c++17 -Iinclude -Iadaptiveviscositysolver_amd/host examples/hotpath_from_dump.cpp
@@ -53,13 +54,15 @@ int main(int argc, char **argv)
         if (!f) throw std::runtime_error("cannot open dump");
         char magic[8];
         f.read(magic, 8);
-        if (std::memcmp(magic, "AVSDUMP1", 8) != 0) throw std::runtime_error("not an AVSDUMP1 file");
-        int n[3];
+        const bool v2 = std::memcmp(magic, "AVSDUMP2", 8) == 0; // + the simulation grid: scalar fields live on ITS lattices
+        if (!v2 && std::memcmp(magic, "AVSDUMP1", 8) != 0) throw std::runtime_error("not an AVSDUMP1 / AVSDUMP2 file");
+        int n[3], fn[3];
         n[0] = rd<int32_t>(f); n[1] = rd<int32_t>(f); n[2] = rd<int32_t>(f);
         const int levels = rd<int32_t>(f), enhanced = rd<int32_t>(f);
+        for (int a = 0; a < 3; ++a) fn[a] = v2 ? rd<int32_t>(f) : n[a];
         const double dx = rd<double>(f), dt = rd<double>(f);
         const int64_t nv = rd<int64_t>(f), ne = rd<int64_t>(f), nc = rd<int64_t>(f);
-        avs_host::AdaptiveViscosity solver(n[0], n[1], n[2], dx, dt, levels, enhanced != 0);
+        avs_host::AdaptiveViscosity solver(n[0], n[1], n[2], dx, dt, levels, enhanced != 0, 0, v2 ? fn : nullptr);
         int r[3];
         for (int l = 0; l < levels; ++l) {
             gridRes(n, 2, l, 0, r);
@@ -79,7 +82,7 @@ int main(int argc, char **argv)
                 const int isConst = rd<int32_t>(f);
                 if (isConst) solver.setField(s.kind, a, nullptr, rd<float>(f));
                 else {
-                    gridRes(n, s.kindRes, 0, a, r);
+                    gridRes(fn, s.kindRes, 0, a, r);
                     solver.setField(s.kind, a, rdv<float>(f, vol(r)).data());
                 }
             }

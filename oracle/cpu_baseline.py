@@ -82,19 +82,21 @@ def main():
 
     out = {"cpu_model": cpu_model(), "threads": threads, "n": n, "nnz": nnz, "variants": {}}
     share = budget / 2.0
+    WARM = 24   # dropped: thread start-up, first touch of the vectors, cold caches (round-2 review, weak #8: the 6 s samples that
+                # included them read 54 it/s where the same loop did 78 it/s over a whole solve)
     for name, vt in (("eigen_faithful", 1), ("all_parallel", threads)):
-        t0 = time.perf_counter()
-        probe = run(threads, vt, 3)
-        per_iter = max(probe.seconds / 3.0, 1e-6)
-        left = share - (time.perf_counter() - t0)
-        iters = int(max(3, min(2500, left / per_iter)))
+        run(threads, vt, 4)
+        probe = run(threads, vt, WARM)
+        per_iter = max(probe.seconds / max(probe.iterations, 1), 1e-6)
+        iters = int(max(3, min(2500, share / per_iter)))
         info = run(threads, vt, iters)
         done = max(info.iterations, 1)
         per_spmv = info.spmv_seconds / done
         out["variants"][name] = {
             "iter_per_s": done / info.seconds, "iterations": done, "seconds": info.seconds,
             "spmv_share": info.spmv_seconds / max(info.seconds, 1e-12),
-            "spmv_gbps": spmv_bytes / max(per_spmv, 1e-12) / 1e9, "spmv_threads": threads, "vector_threads": vt}
+            "spmv_gbps": spmv_bytes / max(per_spmv, 1e-12) / 1e9, "spmv_threads": threads, "vector_threads": vt,
+            "warmup_iterations_dropped": WARM + 4}
     meta_path = os.path.join(d, "asm_meta.json")
     if os.path.exists(meta_path):
         out["assembly"] = time_assembly(d, json.load(open(meta_path)), threads)

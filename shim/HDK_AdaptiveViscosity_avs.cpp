@@ -103,19 +103,20 @@ struct Handles {
 };
 
 // Optional frame export for the offline harness (adaptiveviscositysolver_amd/dump.py, examples/hotpath_from_dump.cpp):
-// "AVSDUMP1", nx ny nz levels enhanced (int32), dx dt (f64), n_vel n_edge n_center (int64); per level labels int8, vidx[3],
-// eidx[3], cidx int32; then centre weights, edge weights[3], face weights[3], viscosity, density, velocity[3], solid
-// velocity[3], each as int32 is_const + one float or the dense array.  Arrays live on the padded octree lattices, so the
-// dump is only written for power-of-two simulation grids (where both coincide).
-bool write_dump(const char *path, avs_prepass *pp, const avs_prepass_info &info, const int n[3], double dx, double dt, bool enhanced,
-                const Flat &face_w0, const Flat &face_w1, const Flat &face_w2, const Flat &visc, const Flat &dens, const Flat vel[3],
-                const Flat solidvel[3])
+// "AVSDUMP2", nx ny nz levels enhanced field_nx field_ny field_nz (int32), dx dt (f64), n_vel n_edge n_center (int64); per level
+// labels int8, vidx[3], eidx[3], cidx int32 on the padded OCTREE lattices; then centre weights, edge weights[3], face weights[3],
+// viscosity, density, velocity[3], solid velocity[3], each as int32 is_const + one float or the dense array on the SIMULATION grid's
+// lattices (field_n*: what avs_set_scalar_field takes) -- so any frame can be replayed, not only power-of-two grids (round 2's
+// AVSDUMP1 writer refused everything else, i.e. every real frame).
+bool write_dump(const char *path, avs_prepass *pp, const avs_prepass_info &info, const int n[3], const int sim[3], double dx, double dt,
+                bool enhanced, const Flat &face_w0, const Flat &face_w1, const Flat &face_w2, const Flat &visc, const Flat &dens,
+                const Flat vel[3], const Flat solidvel[3])
 {
     FILE *f = std::fopen(path, "wb");
     if (!f) return false;
     auto put = [&](const void *p, size_t bytes) { return std::fwrite(p, 1, bytes, f) == bytes; };
-    bool ok = put("AVSDUMP1", 8);
-    const int32_t head[5] = {n[0], n[1], n[2], info.levels, enhanced ? 1 : 0};
+    bool ok = put("AVSDUMP2", 8);
+    const int32_t head[8] = {n[0], n[1], n[2], info.levels, enhanced ? 1 : 0, sim[0], sim[1], sim[2]};
     const double scal[2] = {dx, dt};
     const int64_t counts[3] = {info.n_velocity, info.n_edge, info.n_center};
     ok = ok && put(head, sizeof(head)) && put(scal, sizeof(scal)) && put(counts, sizeof(counts));
@@ -149,12 +150,23 @@ bool write_dump(const char *path, avs_prepass *pp, const avs_prepass_info &info,
         const int32_t one = 1;
         return put(&one, 4) && put(&v.constant, 4);
     };
+    // the pre-pass keeps its weights on the octree lattice: crop to the simulation grid's centre / edge lattices
+    auto put_cropped = [&](const std::vector<float> &full, int kind, int axis) {
+        size_t ro[3] = {(size_t)n[0], (size_t)n[1], (size_t)n[2]}, rs[3] = {(size_t)sim[0], (size_t)sim[1], (size_t)sim[2]};
+        if (kind == 1)
+            for (int b = 0; b < 3; ++b) { ro[b] += (b != axis); rs[b] += (b != axis); }
+        std::vector<float> c(rs[0] * rs[1] * rs[2]);
+        for (size_t k = 0; k < rs[2]; ++k)
+            for (size_t j = 0; j < rs[1]; ++j)
+                std::memcpy(&c[(k * rs[1] + j) * rs[0]], &full[(k * ro[1] + j) * ro[0]], rs[0] * sizeof(float));
+        return put_dense(c);
+    };
     std::vector<float> w;
     w.resize(lattice(2, 0, 0));
-    ok = ok && avs_prepass_get_weights(pp, AVS_FIELD_CENTER_WEIGHTS, 0, w.data(), AVS_MEM_HOST) == AVS_OK && put_dense(w);
+    ok = ok && avs_prepass_get_weights(pp, AVS_FIELD_CENTER_WEIGHTS, 0, w.data(), AVS_MEM_HOST) == AVS_OK && put_cropped(w, 2, 0);
     for (int a = 0; a < 3 && ok; ++a) {
         w.resize(lattice(1, 0, a));
-        ok = avs_prepass_get_weights(pp, AVS_FIELD_EDGE_WEIGHTS, a, w.data(), AVS_MEM_HOST) == AVS_OK && put_dense(w);
+        ok = avs_prepass_get_weights(pp, AVS_FIELD_EDGE_WEIGHTS, a, w.data(), AVS_MEM_HOST) == AVS_OK && put_cropped(w, 1, a);
     }
     ok = ok && put_flat(face_w0) && put_flat(face_w1) && put_flat(face_w2) && put_flat(visc) && put_flat(dens);
     for (int a = 0; a < 3 && ok; ++a) ok = put_flat(vel[a]);
@@ -251,10 +263,9 @@ bool HDK_AdaptiveViscosity::solveGasSubclass(SIM_Engine &engine, SIM_Object *obj
     for (int a = 0; a < 3; ++a)
         if (!put(AVS_FIELD_FACE_WEIGHTS, a, fw[a]) || !put(AVS_FIELD_VELOCITY, a, vel[a]) || !put(AVS_FIELD_SOLID_VELOCITY, a, svel[a])) return false;
 
-    // optional: export the frame for the offline harness (power-of-two grids only, see write_dump)
+    // optional: export the frame for the offline harness (any grid: AVSDUMP2 carries the simulation grid, see write_dump)
     if (const char *dump = std::getenv("AVS_DUMP_PATH"))
-        if (sim[0] == oct[0] && sim[1] == oct[1] && sim[2] == oct[2])
-            (void)write_dump(dump, h.pp, pinfo, oct, dx, timestep, getUseEnhancedGradients(), fw[0], fw[1], fw[2], visc, dens, vel, svel);
+        (void)write_dump(dump, h.pp, pinfo, oct, sim, dx, timestep, getUseEnhancedGradients(), fw[0], fw[1], fw[2], visc, dens, vel, svel);
 
     // ---- the hot path: cpp:418-653 -----------------------------------------------------------------------------------------
     avs_assembly_info ainfo;

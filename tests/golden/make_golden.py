@@ -22,6 +22,8 @@ from util import oracle_for_scene  # noqa: E402
 CASES = {
     "sphere16_L3": lambda: scenes.sphere(16, 3, radius=0.36),
     "beam32_L2_wall_varvisc": lambda: scenes.fat_beam(32, 2, wall=True, variable_viscosity=True),
+    # round 3: density TENSOR (cpp:2759-2766) + spatially varying solid velocity (cpp:1896-1905, 1952-1960) around a solid ball
+    "sphere32_obstacle_rho_usolid": lambda: scenes.with_sampled_fields(scenes.sphere_with_obstacle(32, 3)),
 }
 
 
@@ -35,8 +37,10 @@ def scene_from_fixture(g):
                         liquid=torch.from_numpy(np.array(g["liquid"])),
                         solid=(None if g["solid"].size == 0 else torch.from_numpy(np.array(g["solid"]))),
                         viscosity=(float(visc) if visc.ndim == 0 else torch.from_numpy(np.array(visc))),
-                        density=float(g["density"]),
-                        velocity=[torch.from_numpy(np.array(g[f"velocity_{ax}"])) for ax in "xyz"])
+                        density=(float(g["density"]) if g["density"].ndim == 0 else torch.from_numpy(np.array(g["density"]))),
+                        velocity=[torch.from_numpy(np.array(g[f"velocity_{ax}"])) for ax in "xyz"],
+                        solid_velocity=([torch.from_numpy(np.array(g[f"solid_velocity_{ax}"])) for ax in "xyz"]
+                                        if "solid_velocity_x" in g.files else None))
 
 
 def build(name, fixture=None):
@@ -52,10 +56,13 @@ def build(name, fixture=None):
              liquid=sc.liquid.numpy(), velocity_x=sc.velocity[0].numpy(), velocity_y=sc.velocity[1].numpy(),
              velocity_z=sc.velocity[2].numpy(),
              viscosity=(np.float32(sc.viscosity) if isinstance(sc.viscosity, float) else sc.viscosity.numpy()),
-             density=np.float32(sc.density),
+             density=(np.float32(sc.density) if isinstance(sc.density, (int, float)) else sc.density.numpy()),
              solid=(np.zeros(0, np.float32) if sc.solid is None else sc.solid.numpy()),
              centerw=o.get_field(O.F_CENTERW), row_ptr=A.row_ptr.astype(np.int32), col=A.col, val=A.val, rhs=A.rhs,
              x0=o.initial_guess(), x=x, iterations=info.iterations)
+    if sc.solid_velocity is not None:
+        for a, ax in enumerate("xyz"):
+            d[f"solid_velocity_{ax}"] = sc.solid_velocity[a].numpy()
     for a in range(3):
         d[f"ridx{a}"] = o.regular_index(a)
         d[f"out{a}"] = out[a]
@@ -73,7 +80,7 @@ def build(name, fixture=None):
 
 
 if __name__ == "__main__":
-    for name in CASES:
+    for name in (sys.argv[1:] or CASES):
         d = build(name)
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **d)

@@ -117,3 +117,102 @@ def check_linear_shear(vel_table, edge_table, dx, edge, center, n_center, labels
             out["center_max"] = float(np.abs(du[complete]).max()) if complete.any() else 0.0
             out["center_n"] = int(complete.sum())
     return out
+
+
+def check_sampled_fields(dx, vel_table, edge_table, center_table, n_center, diag_rho1, diag_rho2, diag_lin, edge_unit, center_unit,
+                         edge_lin, center_lin, rho_c0, rho_grad, us_c0, us_grad):
+    """(iii) WHERE density and solid velocity are sampled (cpp:2759-2766, 1896-1905, 1952-1960) -- branches a constant field never
+    exercises -- pinned without the oracle.  Both fields are LINEAR functions of position stored on their own lattices; trilinear
+    interpolation reproduces a linear function exactly, so a sampled value reveals the sample POSITION.
+
+    Three assemblies of one scene: density 1 / density 2 / density rho(P) = rho_c0 + rho_grad . P, and solid velocity (1, 1, 1) /
+    u_c(P) = us_c0[c] + us_grad[c] . P.  Then
+      * V_i = diag(rho = 2) - diag(rho = 1) is the control volume, and (diag(rho(P)) - diag(rho = 1)) / V_i + 1 must be rho at the
+        centre of face i (face_positions: geometry only);
+      * the boundary terms of the unit run ARE the coefficients, so bval_lin / bval_unit is the sampled solid velocity: for an edge
+        stress of axis a at position E it must be u_a (the EDGE-axis component: the reference's quirk) at
+        E + sign/2 dx e_g for a gradient axis g != a; for the centre stress list of axis a at cell centre C it must be u_a at
+        C + sign/2 dx e_a."""
+    out = {}
+    pos, ax, lv = face_positions(vel_table, dx)
+    V = diag_rho2 - diag_rho1
+    has = V > 1e-9 * np.abs(V).max()
+    rho = 1.0 + (diag_lin - diag_rho1)[has] / V[has]
+    want = rho_c0 + pos[has] @ np.asarray(rho_grad, np.float64)
+    out["density_n"] = int(has.sum())
+    out["density_levels"] = sorted(set(int(v) for v in lv[has]))
+    out["density_max_rel"] = float(np.abs(rho / want - 1.0).max())
+    half = 0.5 * dx
+    # edge stresses (boundary terms exist at level 0 only: assert(level == 0), cpp:1903)
+    e_ax = (edge_table[:, 0] >> 8) & 0xff
+    E = edge_table[:, 1:4].astype(np.float64) * dx
+    E[np.arange(len(e_ax)), e_ax] += half
+    bad = n = 0
+    worst = 0.0
+    for k in range(edge_unit["bval"].shape[0]):
+        m = edge_unit["bcnt"] > k
+        if not m.any():
+            continue
+        assert np.array_equal(edge_unit["bcnt"], edge_lin["bcnt"])
+        cu, cl = edge_unit["bval"][k][m], edge_lin["bval"][k][m]
+        a = e_ax[m]
+        c0 = np.asarray(us_c0, np.float64)[a]
+        g = np.asarray(us_grad, np.float64)[a]                       # gradient of the sampled component u_a
+        d = (cl / cu - (c0 + (E[m] * g).sum(axis=1))) / (half * np.sign(cu))
+        cand = np.stack([g[np.arange(len(a)), (a + 1) % 3], g[np.arange(len(a)), (a + 2) % 3]], axis=1)
+        err = np.abs(cand - d[:, None]).min(axis=1)
+        bad += int((err > 2e-3).sum())
+        worst = max(worst, float(err.max()))
+        n += int(m.sum())
+    out.update(edge_boundary_n=n, edge_boundary_bad=bad, edge_boundary_worst=worst)
+    Cc = (center_table[:, 1:4].astype(np.float64) + 0.5) * dx
+    bad = n = 0
+    worst = 0.0
+    ns = len(center_unit["bcnt"])
+    cell = np.arange(ns) % n_center
+    list_axis = np.arange(ns) // n_center
+    for k in range(center_unit["bval"].shape[0]):
+        m = center_unit["bcnt"] > k
+        if not m.any():
+            continue
+        cu, cl = center_unit["bval"][k][m], center_lin["bval"][k][m]
+        a = list_axis[m]
+        c0 = np.asarray(us_c0, np.float64)[a]
+        g = np.asarray(us_grad, np.float64)[a]
+        d = (cl / cu - (c0 + (Cc[cell[m]] * g).sum(axis=1))) / (half * np.sign(cu))
+        err = np.abs(d - g[np.arange(len(a)), a])
+        bad += int((err > 2e-3).sum())
+        worst = max(worst, float(err.max()))
+        n += int(m.sum())
+    out.update(center_boundary_n=n, center_boundary_bad=bad, center_boundary_worst=worst)
+    return out
+
+
+RHO_LIN = (800.0, (200.0, 800.0, -400.0))
+US_C0 = (0.3, 0.6, 0.9)
+US_GRAD = ((0.5, -1.0, 2.0), (-2.0, 0.5, 1.0), (1.0, 2.0, -0.5))
+
+
+def sampled_field_runs(name, n, run):
+    """The three assemblies check_sampled_fields needs, through `run(scene) -> dict` (oracle on the CPU, HIP path on the GPU)."""
+    from adaptiveviscositysolver_amd import scenes
+
+    def mk():
+        if name == "sphere_obstacle":
+            return scenes.sphere_with_obstacle(n, 4 if n >= 64 else 3, viscosity=1.0)
+        return scenes.fat_beam(n, 3, wall=True, viscosity=1.0)
+    sc0 = mk()
+    one = scenes.constant_velocity(sc0.res, (1.0, 1.0, 1.0))
+    lin = [scenes.linear_field(sc0.res, sc0.dx, a, US_C0[a], US_GRAD[a]) for a in range(3)]
+    outs = []
+    for dens, us in ((1.0, one), (2.0, one), (scenes.linear_field(sc0.res, sc0.dx, None, RHO_LIN[0], RHO_LIN[1]), lin)):
+        sc = mk()
+        sc.density, sc.solid_velocity = dens, us
+        outs.append(run(sc))
+
+    def diag(o):
+        rp, col, val = o["csr"]
+        return sp.csr_matrix((val, col, rp.astype(np.int64)), shape=(len(rp) - 1, len(rp) - 1)).diagonal()
+    a, b, c = outs
+    return check_sampled_fields(sc0.dx, a["vel_table"], a["edge_table"], a["center_table"], a["n_center"], diag(a), diag(b), diag(c),
+                                a["edge"], a["center"], c["edge"], c["center"], RHO_LIN[0], RHO_LIN[1], US_C0, US_GRAD)

@@ -43,3 +43,28 @@ def test_cpp_host_reproduces_oracle(tmp_path, built_lib):
     xo, io = o.solve(1e-10, 5000)
     assert len(x) == len(xo) and rel_l2(x, xo) < 1e-5
     assert f"octree DOFS={len(xo)}" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_host_replays_a_non_power_of_two_frame(tmp_path, built_lib):
+    """AVSDUMP2: a frame on a 76 x 20 x 20 simulation grid (the coarsened viscousBeam.hip equivalent; octree lattice 128 x 32 x 32)
+    through the dump format and the C++ host -- round 2's writer refused every grid that is not a power of two."""
+    import torch
+    from adaptiveviscositysolver_amd import scenes
+    from adaptiveviscositysolver_amd.dump import write_dump
+    from util import build_pyramid, oracle_for_scene, rel_l2
+    sc = scenes.viscous_beam_scene(coarsen=4)
+    pyr = build_pyramid(scenes.to_device(sc, torch.device("cuda:0")))
+    dump = str(tmp_path / "frame.avsd")
+    write_dump(dump, sc, pyr)
+    assert open(dump, "rb").read(8) == b"AVSDUMP2"
+    exe = build_example(tmp_path)
+    out = str(tmp_path / "x.f64")
+    r = subprocess.run([exe, dump, out, "1e-10", "5000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    x = np.fromfile(out, dtype=np.float64)
+    o = oracle_for_scene(sc)           # the oracle's own pre-pass on the padded lattice
+    o.prepass()
+    o.hot_path()
+    xo, io = o.solve(1e-10, 5000)
+    assert len(x) == len(xo) and rel_l2(x, xo) < 1e-5

@@ -151,7 +151,8 @@ def _run_hosted(tmp_path, scene, world, tol, extra_env):
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", AVS_DIST_TIMEOUT_MS="30000", **extra_env)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", AVS_DIST_TIMEOUT_MS="30000")
+    env.update(extra_env)
     procs = [subprocess.Popen([sys.executable, os.path.join(here, "hosted_rank.py"), str(tmp_path), str(r), str(world), scene, repr(tol)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
     outs = [p.communicate(timeout=280) for p in procs]

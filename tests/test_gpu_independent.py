@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from adaptiveviscositysolver_amd import ViscositySolve, capi, scenes
-from independent import check_linear_shear, check_scatter_form
+from independent import check_linear_shear, check_scatter_form, sampled_field_runs
 from util import build_pyramid, feed
 
 pytestmark = pytest.mark.gpu
@@ -17,6 +17,8 @@ CASES = {
     "sheet64_L3": lambda: scenes.thin_sheet(64, 3, thickness_cells=12),
     "noncubic_L3": lambda: scenes.fat_beam(64, 3, res=(64, 32, 32)),
     "beam128_L3": lambda: scenes.fat_beam(128, 3),                      # BASELINE configs[1]
+    "beam64_L3_wall_rho_usolid": lambda: scenes.with_sampled_fields(scenes.fat_beam(64, 3, wall=True)),
+    "sphere64_obstacle_rho_usolid": lambda: scenes.with_sampled_fields(scenes.sphere_with_obstacle(64, 4)),
 }
 
 
@@ -55,3 +57,19 @@ def test_linear_shear_known_answer(name, enhanced, built_lib):
         assert r["edge_transition_max"] <= 1e-9 * a, r
     else:
         assert r["edge_transition_bad"] > 0
+
+
+@pytest.mark.parametrize("name", ["sphere_obstacle", "beam_wall"])
+def test_density_and_solid_velocity_are_sampled_where_the_reference_samples_them(name, built_lib):
+    """tests/independent.py (iii) against the HIP path: linear density / solid-velocity fields reveal the sample positions."""
+    def run(sc):
+        s, pyr = assembled(sc, True)
+        rp, col, val, _ = s.csr()
+        return dict(vel_table=s.dof_table(capi.INDEX_VELOCITY), edge_table=s.dof_table(capi.INDEX_EDGE),
+                    center_table=s.dof_table(capi.INDEX_CENTER), n_center=pyr.n_center, csr=(rp, col, val),
+                    edge=s.edge_stencils(), center=s.center_stencils())
+    r = sampled_field_runs(name, 64, run)
+    print(name, r)
+    assert r["density_n"] > 1000 and len(r["density_levels"]) >= 2 and r["density_max_rel"] < 1e-6
+    assert r["edge_boundary_n"] > 500 and r["edge_boundary_bad"] == 0
+    assert r["center_boundary_n"] > 500 and r["center_boundary_bad"] == 0

@@ -26,6 +26,10 @@ SCENES = {
     # five levels really appear (level-4 cells in the core): 12^4-leaf restriction rows (several batches of 144-leaf units per
     # lane group), level-4 rows in the row sweep, rows with > 64 raw triplets next to the coarsest cells
     "beam256_L5": lambda dev: scenes.fat_beam(256, 5, device=dev),
+    # centre-lattice density TENSOR (cpp:2759-2766) + spatially varying solid velocity (cpp:1896-1905, 1952-1960): branches no
+    # constant-field scene reaches (round-2 review, weak #2)
+    "beam64_wall_rho_usolid": lambda dev: scenes.with_sampled_fields(scenes.fat_beam(64, 3, wall=True, device=dev)),
+    "sphere64_obstacle_rho_usolid": lambda dev: scenes.with_sampled_fields(scenes.sphere_with_obstacle(64, 4, device=dev)),
 }
 
 
@@ -79,7 +83,7 @@ def test_assembly_bit_exact(name, dev, built_lib):
     assert np.array_equal(rhs, A.rhs)
 
 
-@pytest.mark.parametrize("name", ["beam32", "beam64_L3_wall", "beam64_varvisc", "sphere64"])
+@pytest.mark.parametrize("name", ["beam32", "beam64_L3_wall", "beam64_varvisc", "sphere64", "sphere64_obstacle_rho_usolid"])
 def test_solve_matches_oracle(name, dev, built_lib):
     sc = scenes.to_device(SCENES[name]("cpu"), dev)
     pyr = build_pyramid(sc)

@@ -112,14 +112,18 @@ def test_non_power_of_two_simulation_grid(n, fres, levels, center, half, built_l
     liquid = scenes.box_sdf((n, n, n), dx, center=tuple(c * dx for c in center), half=tuple(h * dx for h in half))
     xs = (torch.arange(n, dtype=torch.float64) + 0.5) * dx
     visc = (150.0 * (1.0 + 5.0 * xs))[None, None, :].expand(n, n, n).to(torch.float32).contiguous()
-    sc = scenes.Scene(res=(n, n, n), dx=dx, dt=1.0 / 60.0, levels=levels, liquid=liquid, viscosity=visc, density=900.0,
+    # density TENSOR on the simulation grid (cpp:2759-2766).  The library pads it to the octree lattice by border replication; the
+    # oracle gets the same thing built with numpy (crop, then edge-pad) -- NOT the analytic field continued outside
+    crop = lambda t, add=(0, 0, 0): t[:fres[2] + add[2], :fres[1] + add[1], :fres[0] + add[0]].contiguous()
+    dens = scenes.linear_field((n, n, n), dx, None, 700.0, (150.0, 400.0, -250.0))
+    dens_padded = torch.from_numpy(np.pad(crop(dens).numpy(), [(0, n - fres[2]), (0, n - fres[1]), (0, n - fres[0])], mode="edge"))
+    sc = scenes.Scene(res=(n, n, n), dx=dx, dt=1.0 / 60.0, levels=levels, liquid=liquid, viscosity=visc, density=dens_padded,
                       velocity=scenes.smooth_velocity((n, n, n), dx, gravity_dt=0.1), name="corner_box")
     o = oracle_for_scene(sc)
     o.prepass()
     o.build_regular_indices()
     o.hot_path()
     # device side: everything on the simulation grid
-    crop = lambda t, add=(0, 0, 0): t[:fres[2] + add[2], :fres[1] + add[1], :fres[0] + add[0]].contiguous()
     pp = DevicePrepass((n, n, n), dx, levels, field_res=fres)
     info = pp.run(crop(liquid).cuda(), None)
     assert info.levels == o.levels and (info.n_velocity, info.n_edge, info.n_center) == (o.count(0), o.count(1), o.count(2))
@@ -135,7 +139,7 @@ def test_non_power_of_two_simulation_grid(n, fres, levels, center, half, built_l
     s = ViscositySolve((n, n, n), dx, sc.dt, info.levels, device=0, field_res=fres)
     pp.apply(s)
     s.set_field(capi.FIELD_VISCOSITY, 0, crop(visc).cuda())
-    s.set_field(capi.FIELD_DENSITY, 0, None, 900.0)
+    s.set_field(capi.FIELD_DENSITY, 0, crop(dens).cuda())
     for a in range(3):
         add = tuple(1 if b == a else 0 for b in range(3))
         s.set_field(capi.FIELD_VELOCITY, a, crop(sc.velocity[a], add).cuda())

@@ -26,7 +26,7 @@ def test_code_objects_are_gfx950_only():
 def test_halo_stores_are_acknowledged_before_ticket_and_flag():
     rows = isa_check.run_checks()
     names = " ".join(k for k, _, _ in rows)
-    for must in ("avs::k_push(", "avs::k_sr_update_push(", "avs::k_reduce_mb(", "k_spmv_vi2<", "k_spmv_tile<"):
+    for must in ("avs::k_push(", "avs::k_sr_update_push<", "avs::k_reduce_mb(", "k_spmv_vi2<", "k_spmv_tile<"):
         assert must in names, f"{must} not covered"
     bad = [(k, m) for k, ok, m in rows if not ok]
     assert not bad, bad
@@ -34,7 +34,7 @@ def test_halo_stores_are_acknowledged_before_ticket_and_flag():
 
 def test_push_kernels_store_write_through_at_system_scope():
     # the halo entries must leave with sc0 sc1 (system scope, write-through): a plain store could sit in this XCD's L2
-    for pat in (r"^avs::k_push\(", r"^avs::k_sr_update_push\("):
+    for pat in (r"^avs::k_push\(", r"avs::k_sr_update_push<"):
         for k, ins in isa_check.kernels_matching(pat).items():
             assert any(isa_check.is_remote_store(s) for s in ins), k
 

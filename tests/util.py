@@ -65,7 +65,12 @@ class DevicePyramid:
     def __init__(self, sc, device=0):
         from adaptiveviscositysolver_amd import DevicePrepass, capi
         self._capi = capi
-        self.pp = DevicePrepass(sc.res, sc.dx, sc.levels, device=device)
+        # a scene on a non-power-of-two simulation grid: the pre-pass gets field_n* and the SDFs on THAT grid, as from Houdini
+        fres = getattr(sc, "field_res", None)
+        self.pp = DevicePrepass(sc.res, sc.dx, sc.levels, device=device, field_res=fres)
+        if fres is not None and tuple(sc.liquid.shape) == (sc.res[2], sc.res[1], sc.res[0]):
+            from adaptiveviscositysolver_amd import scenes as _scenes
+            sc = _scenes.crop_to_field(sc)
         info = self.pp.run(sc.liquid, sc.solid)
         self.info = info
         self.levels = int(info.levels)

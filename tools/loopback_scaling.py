@@ -23,7 +23,9 @@ ap.add_argument("--n", type=int, default=512)
 ap.add_argument("--levels", type=int, default=4)
 ap.add_argument("--worlds", default="1,2,4,8")
 ap.add_argument("--iters", type=int, default=320)
+ap.add_argument("--ranks", default="", help="comma-separated subset of ranks to run (profiling one rank under rocprofv3)")
 a = ap.parse_args()
+only = [int(r) for r in a.ranks.split(",")] if a.ranks else None
 dev = torch.device("cuda:0")
 sc = scenes.fat_beam(a.n, a.levels, device=dev)
 pp = DevicePrepass(sc.res, sc.dx, sc.levels)
@@ -32,6 +34,8 @@ out = {"n": a.n, "levels": int(pi.levels), "rows": int(pi.n_velocity), "iteratio
 for world in [int(w) for w in a.worlds.split(",")]:
     ranks = []
     for r in range(world):
+        if only is not None and r not in only:
+            continue
         s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels)
         pp.apply(s)
         s.set_scene_fields(sc)

@@ -60,18 +60,25 @@ def run(count, seed, quiet=False):
                             + (((z + 0.5) * dx - cs[2]) ** 2)[:, None, None])
             solid = (rs - ds).to(torch.float32).contiguous()
             solid_velocity = scenes.constant_velocity(res, tuple(rng.uniform(-1, 1, 3)))
+        if solid is not None and rng.random() < 0.6: # round 3: a spatially VARYING solid velocity (cpp:1896-1905, 1952-1960 sample it)
+            solid_velocity = [scenes.linear_field(res, dx, a, float(rng.uniform(-1, 1)), tuple(rng.uniform(-2, 2, 3))) for a in range(3)]
         visc = float(rng.uniform(1, 5000))
         if rng.random() < 0.4:
             g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
             visc = (50.0 + 500.0 * torch.rand((res[2], res[1], res[0]), generator=g)).to(torch.float32).contiguous()
+        dens = float(rng.uniform(1, 2000))
+        if rng.random() < 0.4: # round 3: a centre-lattice density TENSOR (cpp:2759-2766: density.getValue(point))
+            g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+            dens = (scenes.linear_field(res, dx, None, dens + 500.0, tuple(rng.uniform(-300, 300, 3)))
+                    + 100.0 * torch.rand((res[2], res[1], res[0]), generator=g)).to(torch.float32).contiguous()
         sc = scenes.Scene(res=res, dx=dx, dt=float(rng.uniform(0.005, 0.05)), levels=levels, liquid=liquid, solid=solid, viscosity=visc,
-                          density=float(rng.uniform(1, 2000)), velocity=scenes.smooth_velocity(res, dx, gravity_dt=0.1), solid_velocity=solid_velocity,
+                          density=dens, velocity=scenes.smooth_velocity(res, dx, gravity_dt=0.1), solid_velocity=solid_velocity,
                           use_enhanced_gradients=bool(rng.random() < 0.7), name=f"stress{case}")
         only = os.environ.get('STRESS_ONLY')
         if only is not None and case != int(only):   # replay the random stream of a skipped case (assumes it was not a rejected one)
             pw_ = int(rng.integers(2, 9)); rng.integers(0, pw_); rng.integers(-1, 3); rng.integers(2, 4); rng.integers(-1, 3)
             continue
-        if VERBOSE: print(case, 'scene', res, 'levels', levels, 'solid', solid is not None, 'varvisc', not isinstance(visc, float), 'enh', sc.use_enhanced_gradients, flush=True)
+        if VERBOSE: print(case, 'scene', res, 'levels', levels, 'solid', solid is not None, 'varvisc', not isinstance(visc, float), 'vardens', not isinstance(dens, float), 'enh', sc.use_enhanced_gradients, flush=True)
         o = oracle_for_scene(sc)
         o.prepass()
         if VERBOSE: print(case, 'oracle prepass done, levels', o.levels, flush=True)
