@@ -20,8 +20,13 @@ namespace avs {
 
 static constexpr int kBlock = 256;
 
+// INTERLEAVE (round 3): the key also carries the fine cell inside the brick (z, y, x), so that inside a brick the stable sort leaves
+// the DOFs CELL by cell -- u, v, w of one cell next to each other -- instead of all u faces, then all v, then all w.  A 512-row
+// SpMV tile is then a compact 8 x 8 x 2.7-cell slab with all three components: 8 of a row's 15 entries are faces of the OTHER two
+// components of the same / adjacent cells, which the axis-major order kept 512 and 1024 rows away -- outside the tile's LDS window
+// of x (its own 512 rows) -- and the cell-major order brings inside it.
 __global__ __launch_bounds__(kBlock) void k_brick_keys(const int32_t *__restrict__ vdof, int64_t n, int nx, int ny, int nz,
-                                                       int shift, uint32_t *__restrict__ keys, int32_t *__restrict__ ids)
+                                                       int shift, int interleave, uint32_t *__restrict__ keys, int32_t *__restrict__ ids)
 {
     const int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (d >= n) return;
@@ -33,7 +38,12 @@ __global__ __launch_bounds__(kBlock) void k_brick_keys(const int32_t *__restrict
     pz = pz < nz ? pz : nz - 1;
     const uint32_t bx = (uint32_t)(px >> shift), by = (uint32_t)(py >> shift), bz = (uint32_t)(pz >> shift);
     const uint32_t nbx = (uint32_t)((nx + (1 << shift) - 1) >> shift), nby = (uint32_t)((ny + (1 << shift) - 1) >> shift);
-    keys[d] = (bz * nby + by) * nbx + bx;
+    uint32_t key = (bz * nby + by) * nbx + bx;
+    if (interleave) {
+        const uint32_t m = (1u << shift) - 1u;
+        key = (key << (3 * shift)) | ((((uint32_t)pz & m) << (2 * shift)) | (((uint32_t)py & m) << shift) | ((uint32_t)px & m));
+    }
+    keys[d] = key;
     ids[d] = (int32_t)d;
 }
 
@@ -86,8 +96,15 @@ avs_status build_brick_permutation(avs_ctx *c, int brick_shift)
     AVS_TRY(c->perm.alloc((size_t)n));
     AVS_TRY(c->inv.alloc((size_t)n));
     if (n == 0) return AVS_OK;
+    // cell-major order inside the bricks while brick id + cell bits fit the 32-bit sort key (AVS_BRICK_INTERLEAVE=0: axis-major, round 2)
+    int interleave = 1;
+    if (const char *e = getenv("AVS_BRICK_INTERLEAVE")) interleave = atoi(e) != 0;
+    {
+        const uint64_t nb = (uint64_t)((c->desc.nx >> brick_shift) + 1) * ((c->desc.ny >> brick_shift) + 1) * ((c->desc.nz >> brick_shift) + 1);
+        if ((nb << (3 * brick_shift)) >= (1ull << 32)) interleave = 0;
+    }
     hipLaunchKernelGGL(k_brick_keys, dim3(grid_for(n)), dim3(kBlock), 0, st, c->vdof.p, n, c->desc.nx, c->desc.ny, c->desc.nz,
-                       brick_shift, keys_in.p, ids_in.p);
+                       brick_shift, interleave, keys_in.p, ids_in.p);
     size_t tmp_bytes = 0;
     AVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in.p, keys_out.p, ids_in.p, c->perm.p, (size_t)n, 0, 32, st));
     DevBuf<char> &tmp = c->scratch.sort_tmp;

@@ -195,9 +195,12 @@ def viscous_beam_scene(device="cpu", coarsen=1):
     cantilever-like sag rate growing towards the free end (synthetic: the scene file holds no velocity field).
     `coarsen` = 2, 4: the same geometry on a 2x / 4x coarser grid (CPU-sized plumbing cases)."""
     dx = 1.0 / 512 * coarsen
-    fres = (304 // coarsen, 80 // coarsen, 80 // coarsen)
+    # the liquid's extent in voxels + a padding that does NOT shrink with the coarsening (refinement band + graded coarse cells need
+    # their ~14 voxels whatever dx is), rounded up to whole level-3 cells: 304 x 80 x 80 at coarsen = 1
+    up8 = lambda v: 8 * int(math.ceil(v / 8.0))
+    fres = (up8(261.12 / coarsen + 42.88), up8(51.2 / coarsen + 28.8), up8(51.2 / coarsen + 28.8))
     res = _pow2_lattice(fres)
-    origin = (-16 * dx / coarsen * coarsen, 0.5 - fres[1] // 2 * dx, 0.5 - fres[2] // 2 * dx)
+    origin = (-16 * dx, 0.5 - fres[1] // 2 * dx, 0.5 - fres[2] // 2 * dx)
     dt = 1.0 / 60.0
     center = tuple(c - o for c, o in zip((0.253, 0.5, 0.5), origin))
     liquid = box_sdf(res, dx, center, (0.255, 0.05, 0.05), device)
@@ -222,9 +225,10 @@ def viscous_buckling_scene(device="cpu", coarsen=1):
     with a lateral sway.  Simulation grid 132 x 330 x 40 voxels (octree lattice 256 x 512 x 64)."""
     import numpy as np
     dx = float(np.float32(1e-3)) * coarsen
-    fres = (132 // coarsen, 330 // coarsen, 40 // coarsen)
+    # liquid extent in voxels + fixed padding (16 / 12 + 14 / 15 voxels): 132 x 330 x 40 at coarsen = 1
+    fres = (100 // coarsen + 32, 304 // coarsen + 26, 10 // coarsen + 30)
     res = _pow2_lattice(fres)
-    origin = (-(fres[0] // 2) * dx, -12 * dx, -(fres[2] // 2) * dx)
+    origin = (-(fres[0] / 2.0) * dx, -12 * dx, -(fres[2] / 2.0) * dx)
     dt = 1.0 / 120.0
     lo, hi = (-0.05, -0.004, -0.005), (0.05, 0.3, 0.005)
     center = tuple(0.5 * (a + b) - o for a, b, o in zip(lo, hi, origin))

@@ -47,7 +47,7 @@ def test_cpp_host_reproduces_oracle(tmp_path, built_lib):
 
 @pytest.mark.gpu
 def test_cpp_host_replays_a_non_power_of_two_frame(tmp_path, built_lib):
-    """AVSDUMP2: a frame on a 76 x 20 x 20 simulation grid (the coarsened viscousBeam.hip equivalent; octree lattice 128 x 32 x 32)
+    """AVSDUMP2: a frame on a 112 x 48 x 48 simulation grid (the coarsened viscousBeam.hip equivalent; octree lattice 128 x 64 x 64)
     through the dump format and the C++ host -- round 2's writer refused every grid that is not a power of two."""
     import torch
     from adaptiveviscositysolver_amd import scenes
