@@ -66,7 +66,7 @@ class Desc(C.Structure):
 class SolveInfo(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("error", C.c_double),
                 ("rhs_norm2", C.c_double), ("n", C.c_int64), ("nnz", C.c_int64),
-                ("solve_ms", C.c_double), ("spmv_ms", C.c_double)]
+                ("solve_ms", C.c_double), ("spmv_ms", C.c_double), ("resident", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PlanSizes(C.Structure):

@@ -92,6 +92,7 @@ struct PcgDist {
     DevBuf<int> vote_word;                // ... and of the transport votes (allocated once, at avs_dist_init)
     DevBuf<unsigned long long> psum; // paranoid mode: per-peer checksum accumulators of the push
     DistDev dd_host{};               // what d->dd holds (the self-test toggles `paranoid` around its rounds)
+    bool exclusive_device = true;    // no other rank of the group on this physical GPU
     long long selftest_bad = -1;     // transport self-test of this plan: -1 not run, else the all-gathered count of bad entries
     int selftest_rounds = 0;
     std::vector<uint8_t> blob;
@@ -249,6 +250,7 @@ struct DistBlob {
     int32_t send_cnt_of[kMaxRanks]; // what I send to rank q: every rank can check every pair from the gathered blobs
     hipIpcMemHandle_t handle;
     int32_t have_handle;
+    int32_t pci;                    // physical GPU: domain << 16 | bus << 8 | device (two ranks on one GPU cannot both run the CU-resident loop)
 };
 static_assert(sizeof(DistBlob) <= AVS_DIST_BLOB_BYTES, "blob does not fit");
 
@@ -312,6 +314,14 @@ static avs_status direct_prepare(avs_ctx *c, PcgDist *d)
     b.pid = (int32_t)getpid();
     b.nonce = process_nonce();
     b.device = c->desc.device;
+    {
+        int dom = 0, bus = 0, dv = 0;
+        (void)hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, c->desc.device);
+        (void)hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, c->desc.device);
+        (void)hipDeviceGetAttribute(&dv, hipDeviceAttributePciDeviceId, c->desc.device);
+        (void)hipGetLastError();
+        b.pci = (dom << 16) | ((bus & 0xff) << 8) | (dv & 0xff);
+    }
     b.raw_ptr = (uint64_t)(uintptr_t)p;
     b.bytes = bytes;
     b.n_halo = d->n_halo;
@@ -473,6 +483,9 @@ static avs_status direct_connect(avs_ctx *c, PcgDist *d, const uint8_t *blobs, b
     h.timeout_ticks = (long long)khz * ms;
     AVS_HIP(hipMemcpy(d->dd.p, &h, sizeof(h), hipMemcpyHostToDevice));
     d->dd_host = h;
+    d->exclusive_device = true;
+    for (int q = 0; q < d->world; ++q)
+        if (q != d->rank && all[(size_t)q].pci == me.pci && check_counts) d->exclusive_device = false; // (loop-back: the "peers" are this rank itself)
     d->direct_ready = true;
     d->transport = AVS_TRANSPORT_DIRECT;
     d->selftest_bad = -1;
@@ -496,6 +509,7 @@ bool dist_direct_args(PcgDist *d, DirectArgs *out)
     out->n_tiles_int = d->n_tiles_int;
     out->n_tiles_bnd = d->n_tiles_bnd;
     out->tile_flags = d->tile_flags.p;
+    out->exclusive_device = d->exclusive_device;
     return true;
 }
 

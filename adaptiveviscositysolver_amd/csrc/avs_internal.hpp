@@ -319,6 +319,7 @@ struct DirectArgs {                               // what pcg_solve_direct needs
     const int32_t *tiles_int = nullptr, *tiles_bnd = nullptr;
     int n_tiles_int = 0, n_tiles_bnd = 0;
     const uint8_t *tile_flags = nullptr; // per tile: 1 = reads halo columns
+    bool exclusive_device = false;       // no other rank of the group runs on this physical GPU (the CU-resident loop needs every CU)
 };
 bool dist_direct_args(PcgDist *d, DirectArgs *out); // false: the direct transport is not connected
 // `rounds` pattern rounds over the connected blocks (avs_pcg.hip); *bad_entries = all-gathered count of wrong entries / checksums

@@ -141,6 +141,8 @@ struct PcgWork {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t evA[kChunk] = {}, evB[kChunk] = {}; // per-launch SpMV timing inside the solve
     size_t npartial = 0;
+    struct ResidentPlan *resident = nullptr; // CU-resident loop (avs_pcg_resident.inl): lane plan of the current matrix
+    int resident_used = 0;                   // the last solve ran it
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1942,6 +1944,8 @@ __global__ __launch_bounds__(256) void k_direct_selftest(HaloView hv, unsigned l
 avs_status spmv_dot_tiles(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc, const int32_t *tiles,
                           int ntiles, hipStream_t stream);
 
+#include "avs_pcg_resident.inl"
+
 // Transport self-test, run once per plan right after the blocks are connected and before the direct transport is trusted with a
 // solve (round-2 review: "never run on more than one GPU"): `rounds` full-size halo rounds over the real links with a
 // round-dependent pattern, checksum + per-entry verification by the reader while the next flag is already being polled, and the
@@ -2050,6 +2054,17 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
     AVS_TRY(round(u, 3, (int)OP_SR_INIT, nullptr, nullptr));
     AVS_HIP(hipGetLastError());
 
+    // Systems that fit on the chip (<= ~1 M rows, packed single-dictionary form): the rest of the solve in ONE cooperative launch,
+    // matrix words in the register files, vector slices in LDS (avs_pcg_resident.inl).  Needs the GPU for itself.
+    w->resident_used = 0;
+    if (coded && (da.exclusive_device || getenv("AVS_CG_RESIDENT_CUS")) && resident_wanted(true)) {
+        if (!w->resident) w->resident = new (std::nothrow) ResidentPlan();
+        if (w->resident && resident_prepare(w->resident, A, w->n_ext, &da, stream)) {
+            AVS_TRY(resident_run(w->resident, A, x, r, p, sv, u, wv, w->dcode.p, w->invtab.p, sc, max_iters, &da, stream));
+            w->resident_used = 1;
+        }
+    }
+
     auto enqueue_iteration = [&](int c, bool timed) -> avs_status {
         // update and push in one launch (3 launches per iteration)
         if (coded)
@@ -2073,8 +2088,8 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
                 set_error("direct transport (paranoid mode): a halo segment does not add up to the checksum its sender left ahead of the flag "
                           "-- stale or torn halo entries (iteration ~%d)", w->host_sc->iter);
             else
-                set_error("direct transport: a peer's %s did not arrive within the time limit (rank stalled or dead?)",
-                          w->host_sc->fault == 1 ? "halo entries" : "partial sums");
+                set_error("direct transport: %s did not arrive within the time limit (rank stalled or dead?)",
+                          w->host_sc->fault == 1 ? "a peer's halo entries" : (w->host_sc->fault == 2 ? "a peer's partial sums" : "a workgroup's partial sums"));
             return AVS_ERCCL;
         }
         if (info && last_chunk > 0 && timed_chunk) {
@@ -2085,7 +2100,7 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
                 if (hipEventElapsedTime(&ems, w->evA[c2], w->evB[c2]) == hipSuccess) { spmv_ms_sum += ems; ++spmv_samples; }
             }
         }
-        if (w->host_sc->done || enqueued >= max_iters) break;
+        if (w->host_sc->done || enqueued >= max_iters || w->resident_used) break;
         const int chunk = (max_iters - enqueued) < kChunk ? (max_iters - enqueued) : kChunk;
         const bool replay = use_graph && (enqueued / kChunk) % kTimedChunkEvery != 0 && chunk == kChunk && !w->graph_broken;
         timed_chunk = !replay;
@@ -2142,6 +2157,7 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
         info->nnz = A.nnz;
         info->solve_ms = ms;
         info->spmv_ms = spmv_samples ? spmv_ms_sum / spmv_samples : 0.;
+        info->resident = w->resident_used;
     }
     return AVS_OK;
 }
@@ -2187,6 +2203,7 @@ int64_t pcg_rows(const PcgWork *w) { return w ? w->n : -1; }
 void pcg_destroy(PcgWork *w)
 {
     if (!w) return;
+    delete w->resident;
     if (w->graph) (void)hipGraphExecDestroy(w->graph);
     if (w->host_sc) (void)hipHostFree(w->host_sc);
     if (w->ev0) (void)hipEventDestroy(w->ev0);
@@ -2213,6 +2230,72 @@ static avs_status reduce_stage(PcgWork *w, int nb, int nred, int op, double tol,
     return AVS_OK;
 }
 
+// Single GPU, no partition: the single-reduction iteration on the chip when the system qualifies (*ran = false otherwise, nothing
+// touched).  Set-up (r = b - A x, u = M^-1 r, w = A u, the three sums) with the launch-per-phase kernels, the loop resident.
+static avs_status pcg_solve_resident_single(PcgWork *w, const CsrView &A, const double *b, double *x, double tol, int max_iters,
+                                            hipStream_t stream, avs_solve_info *info, bool *ran)
+{
+    *ran = false;
+    const int64_t n = A.n;
+    const bool coded = A.codes && !A.tab_ptr && A.table_size <= kViLdsTable;
+    if (!coded) return AVS_OK;
+    if (!w->resident) w->resident = new (std::nothrow) ResidentPlan();
+    if (!w->resident || !resident_prepare(w->resident, A, A.n, nullptr, stream)) return AVS_OK;
+    *ran = true;
+    const int g = (int)((n + kBlock - 1) / kBlock < kVecGrid ? ((n + kBlock - 1) / kBlock > 0 ? (n + kBlock - 1) / kBlock : 1) : kVecGrid);
+    const int rowgrid = (int)((n + kBlock - 1) / kBlock) > 0 ? (int)((n + kBlock - 1) / kBlock) : 1;
+    const int variant = spmv_default_variant(A);
+    AVS_TRY(w->s.alloc((size_t)n));
+    AVS_TRY(w->u.alloc((size_t)w->n_ext));
+    double *p = w->p.p, *r = w->r.p, *wv = w->t.p, *sv = w->s.p, *u = w->u.p, *invd = w->invd.p;
+    double *pvec = w->partial.p, *pspmv = w->partial.p + 4 * (size_t)kVecGrid;
+    PcgScalars *sc = w->sc.p;
+    AVS_HIP(hipMemsetAsync(sc, 0, 2 * sizeof(PcgScalars), stream));
+    AVS_HIP(hipMemsetAsync(p, 0, (size_t)w->n_ext * sizeof(double), stream));
+    AVS_HIP(hipMemsetAsync(sv, 0, (size_t)n * sizeof(double), stream));
+    hipLaunchKernelGGL(k_inv_diag, dim3(rowgrid), dim3(kBlock), 0, stream, A, invd);
+    if (!w->dcode.p) AVS_TRY(w->dcode.alloc((size_t)n + 2));
+    if (!w->invtab.p) AVS_TRY(w->invtab.alloc((size_t)kViLdsTable + 1));
+    const int cg = (int)(((n > A.table_size + 1 ? n : A.table_size + 1) + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_inv_diag_coded, dim3(cg), dim3(kBlock), 0, stream, A, w->dcode.p, w->invtab.p);
+    AVS_HIP(hipEventRecord(w->ev0, stream));
+    AVS_HIP(hipMemcpyAsync(u, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    AVS_TRY(spmv_dispatch<false>(A, u, wv, nullptr, nullptr, variant, stream, nullptr));
+    hipLaunchKernelGGL(k_sr_init, dim3(g), dim3(kBlock), 0, stream, n, b, wv, invd, r, u, pvec);
+    int nb = 0;
+    AVS_TRY(spmv_dispatch<true>(A, u, wv, pspmv, nullptr, variant, stream, &nb));
+    reduce_launch(w, pvec, g, 3, sc, (int)OP_NONE, tol, 0, 0, stream);
+    reduce_launch(w, pspmv, nb, 1, sc, (int)OP_NONE, tol, 0, 3, stream);
+    hipLaunchKernelGGL(k_scalar, dim3(1), dim3(64), 0, stream, sc, (int)OP_SR_INIT, tol);
+    AVS_HIP(hipGetLastError());
+    AVS_TRY(resident_run(w->resident, A, x, r, p, sv, u, wv, w->dcode.p, w->invtab.p, sc, max_iters, nullptr, stream));
+    w->resident_used = 1;
+    AVS_HIP(hipMemcpyAsync(w->host_sc, sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, stream));
+    AVS_HIP(hipStreamSynchronize(stream));
+    if (w->host_sc->fault) {
+        set_error("resident PCG: a workgroup did not reach a grid barrier within the time limit (fault %d)", w->host_sc->fault);
+        return AVS_EINTERNAL;
+    }
+    if (w->host_sc->done == 3) AVS_HIP(hipMemsetAsync(x, 0, (size_t)n * sizeof(double), stream)); // rhs == 0: x := 0
+    AVS_HIP(hipEventRecord(w->ev1, stream));
+    AVS_HIP(hipEventSynchronize(w->ev1));
+    float ms = 0.f;
+    AVS_HIP(hipEventElapsedTime(&ms, w->ev0, w->ev1));
+    if (info) {
+        const PcgScalars &h = *w->host_sc;
+        info->iterations = h.iter;
+        info->converged = (h.done != 0) ? 1 : 0;
+        info->rhs_norm2 = h.rhs_norm2;
+        info->error = (h.done == 3 || h.rhs_norm2 == 0.) ? 0. : sqrt(h.rr / h.rhs_norm2);
+        info->n = n;
+        info->nnz = A.nnz;
+        info->solve_ms = ms;
+        info->spmv_ms = 0.; // no separate SpMV launch to time
+        info->resident = 1;
+    }
+    return AVS_OK;
+}
+
 avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, double tol, int max_iters,
                      hipStream_t stream, avs_solve_info *info, PcgDist *dist)
 {
@@ -2224,6 +2307,11 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
     }
     if (dist && dist_wants_single_reduction(dist))
         return pcg_solve_single_reduction(w, A, b, x, tol, max_iters, stream, info, dist);
+    if (!dist && resident_wanted(false)) { // opt-in (AVS_CG_RESIDENT=1): small single-GPU systems on the chip
+        bool ran = false;
+        const avs_status rs = pcg_solve_resident_single(w, A, b, x, tol, max_iters, stream, info, &ran);
+        if (ran || rs != AVS_OK) return rs;
+    }
     const int vgrid = (int)((n + kBlock - 1) / kBlock < kVecGrid ? (n + kBlock - 1) / kBlock : kVecGrid);
     const int g = vgrid > 0 ? vgrid : 1;
     const int rowgrid = (int)((n + kBlock - 1) / kBlock) > 0 ? (int)((n + kBlock - 1) / kBlock) : 1;

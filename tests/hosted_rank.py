@@ -49,11 +49,13 @@ def main():
         allb += open(os.path.join(workdir, f"blob_{q}.bin"), "rb").read()
     buf = (C.c_uint8 * len(allb)).from_buffer_copy(allb)
     runs = []
+    resident = 0
     try:
         capi.check(s.lib.avs_dist_import_blobs(s.h, buf))    # connects the comm blocks and runs the transport self-test
         for _ in range(2):                                   # twice: the second solve replays the captured graph
             info = s.dist_solve(tol, 5000)
             runs.append((info.iterations, info.converged, info.error))
+            resident = int(info.resident)
     except capi.AvsError as e:                               # (the stale-halo tests expect exactly this)
         open(os.path.join(workdir, f"err_{rank}.txt"), "w").write(f"{e.status}\n{e}")
         open(os.path.join(workdir, f"done_{rank}"), "w").write("failed")
@@ -67,7 +69,7 @@ def main():
                                                                   1 if ci["transport"] == "direct" else 0,
                                                                   ci["rccl_calls_per_iteration"], ci["launches_per_iteration"],
                                                                   s.matrix_format().tile_local_tables, s.matrix_format().column_windows,
-                                                                  ci["selftest_rounds"], ci["selftest_bad_entries"], 1 if ci["paranoid"] else 0],
+                                                                  resident, ci["selftest_rounds"], ci["selftest_bad_entries"], 1 if ci["paranoid"] else 0],
                                                                  np.float64))
     # keep the comm block alive until every rank has finished (a peer may still be reading its own copy of the flags)
     open(os.path.join(workdir, f"done_{rank}"), "w").write("ok")

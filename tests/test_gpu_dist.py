@@ -135,7 +135,8 @@ def test_processes_direct_transport(scene, world, tmp_path, built_lib):
     n_own = 0
     for r in range(world):
         x += np.load(tmp_path / f"x_{r}.npy")
-        it1, c1, it2, c2, own, halo, direct, rccl_calls, launches, tile_tables, windows, st_rounds, st_bad, paranoid = np.load(tmp_path / f"info_{r}.npy")
+        it1, c1, it2, c2, own, halo, direct, rccl_calls, launches, tile_tables, windows, resident, st_rounds, st_bad, paranoid = np.load(tmp_path / f"info_{r}.npy")
+        assert resident == 0     # ranks that share one GPU keep the launch-per-phase loop (the resident loop needs every CU)
         assert st_rounds == 64 and st_bad == 0 and paranoid == 0    # the transport self-test ran over the mapped blocks and passed
         if scene == "varvisc128":
             assert tile_tables == 1 and windows == 1
@@ -177,7 +178,32 @@ def test_processes_paranoid_mode(tmp_path, built_lib):
         x += np.load(tmp_path / f"x_{r}.npy")
         info = np.load(tmp_path / f"info_{r}.npy")
         assert info[1] == 1 and abs(info[0] - iref.iterations) <= 3
-        assert info[-3] == 64 and info[-2] == 0 and info[-1] == 1
+        assert info[-3] == 64 and info[-2] == 0 and info[-1] == 1 and info[-4] == 0   # (paranoid mode keeps the launch-per-phase loop)
+    assert rel_l2(x, xref) < 1e-7
+
+
+@pytest.mark.parametrize("scene,world,cus", [("beam128", 2, 96), ("beam128", 3, 64)])
+def test_processes_resident_loop_across_ranks(scene, world, cus, tmp_path, built_lib):
+    """The CU-resident loop (avs_pcg_resident.inl) between REAL ranks: one process per rank on a share of one GPU's CUs
+    (AVS_CG_RESIDENT_CUS; on a multi-GPU node every rank has all CUs of its own GPU).  Pushes into the peer's halo area, halo flags
+    raised by the grid barrier's last arriver, rank sums all-gathered by workgroup 0 through the comm blocks -- against the
+    single-GPU solve."""
+    dev = torch.device("cuda:0")
+    sc = scenes.fat_beam(128, 3, device=dev)
+    ref = make_solver(sc, build_pyramid(sc))
+    tol = 1e-9
+    iref = ref.solve(tol, 5000)
+    xref = ref.solution()
+    ref.close()
+    res = _run_hosted(tmp_path, scene, world, tol, {"AVS_CG_RESIDENT_CUS": str(cus), "AVS_DIST_TIMEOUT_MS": "8000"})
+    for rc, so, se in res:
+        assert rc == 0, se[-3000:]
+    x = np.zeros_like(xref)
+    for r in range(world):
+        x += np.load(tmp_path / f"x_{r}.npy")
+        info = np.load(tmp_path / f"info_{r}.npy")
+        assert info[1] == 1 and info[3] == 1 and abs(info[0] - iref.iterations) <= 3 and info[0] == info[2]
+        assert info[-4] == 1, "the resident loop did not run"
     assert rel_l2(x, xref) < 1e-7
 
 

@@ -1,0 +1,122 @@
+"""CU-resident PCG (avs_pcg_resident.inl): one cooperative launch for all iterations, the packed matrix words in the register files,
+the vector slices in LDS.  It must agree with the oracle like the launch-per-phase loops do (same recurrences as the direct
+transport's single-reduction loop; only the order of additions inside the three dot products differs)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from adaptiveviscositysolver_amd import ViscositySolve, capi, scenes
+from util import build_pyramid, feed, oracle_from_pyramid, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "beam64_L3_wall": lambda: scenes.fat_beam(64, 3, wall=True),
+    "sphere64_L4": lambda: scenes.sphere(64, 4),
+    "beam128_L3": lambda: scenes.fat_beam(128, 3),                       # BASELINE configs[1]
+    "hip_buckling": lambda: scenes.viscous_buckling_scene(),            # 0.79 M rows: the vector slices + remote columns nearly fill the LDS
+    "obstacle_rho_usolid": lambda: scenes.with_sampled_fields(scenes.sphere_with_obstacle(64, 4)),
+    "viscous_beam_hip_coarse": lambda: scenes.viscous_beam_scene(coarsen=2),
+}
+
+
+@pytest.fixture
+def resident_env():
+    old = os.environ.get("AVS_CG_RESIDENT")
+    os.environ["AVS_CG_RESIDENT"] = "1"
+    yield
+    if old is None:
+        os.environ.pop("AVS_CG_RESIDENT", None)
+    else:
+        os.environ["AVS_CG_RESIDENT"] = old
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_resident_single_gpu_solve_matches_oracle(name, resident_env, built_lib):
+    sc = CASES[name]()
+    dsc = scenes.to_device(sc, torch.device("cuda:0"))
+    pyr = build_pyramid(dsc)
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0, field_res=sc.field_res)
+    feed(s, pyr)
+    s.set_scene_fields(scenes.crop_to_field(dsc))
+    s.assemble()
+    o = oracle_from_pyramid(sc, pyr)
+    o.hot_path()
+    for tol in (1e-10, 1e-3):
+        info = s.solve(tol, 5000)
+        assert info.resident == 1, "the resident loop did not run (system not eligible?)"
+        xo, io = o.solve(tol, 5000)
+        assert info.converged == 1 and info.error <= tol
+        assert abs(info.iterations - io.iterations) <= max(3, io.iterations // 100), (info.iterations, io.iterations)
+        if tol < 1e-6:
+            assert rel_l2(s.solution(), xo) < 1e-7
+    # the same context through the launch-per-phase loop: the two GPU loops agree even closer
+    x_res = s.solution()
+    os.environ["AVS_CG_RESIDENT"] = "0"
+    info2 = s.solve(1e-3, 5000)
+    assert info2.resident == 0
+    assert rel_l2(s.solution(), x_res) < 1e-2 * 1e-3 * 50   # both within tol of the same solution
+    s.close()
+
+
+def test_resident_refuses_what_does_not_fit(resident_env, built_lib):
+    """7.4 M rows do not fit the register files: the solve silently keeps the launch-per-phase loop."""
+    sc = scenes.fat_beam(256, 4, variable_viscosity=True, device=torch.device("cuda:0"))   # tile dictionaries: not the packed form
+    pyr = build_pyramid(sc)
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
+    feed(s, pyr)
+    s.set_scene_fields(sc)
+    s.assemble()
+    info = s.solve(1e-3, 2500)
+    assert info.resident == 0 and info.converged == 1
+    s.close()
+
+
+def test_resident_direct_transport_world_1(built_lib):
+    """The partitioned path (direct transport, one rank): resident by default, against the single-GPU solve of the same system."""
+    import ctypes as C
+    sc = scenes.fat_beam(128, 4, device=torch.device("cuda:0"))
+    pyr = build_pyramid(sc)
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
+    feed(s, pyr)
+    s.set_scene_fields(sc)
+    buf = (C.c_uint8 * capi.UNIQUE_ID_BYTES)()
+    capi.check(s.lib.avs_dist_get_unique_id(buf))
+    capi.check(s.lib.avs_dist_init(s.h, buf, 0, 1))
+    s.assemble()
+    ref = s.solve(1e-9, 5000)
+    xref = s.solution()
+    s.dist_assemble()
+    info = s.dist_solve(1e-9, 5000)
+    assert info.resident == 1 and info.converged == 1 and abs(info.iterations - ref.iterations) <= 3
+    assert rel_l2(s.dist_solution(), xref) < 1e-7
+    info = s.dist_solve(1e-9, 5000)          # again: the plan is re-used
+    assert info.resident == 1 and abs(info.iterations - ref.iterations) <= 3
+    s.close()
+
+
+def test_resident_long_row_path(resident_env, built_lib):
+    """Rows that do not fit a lane's registers keep their first words there and read the rest from memory.  No scene here has a row
+    of more than 75 merged entries, so the test lowers the quads a lane may use to 4 (20 words): every transition row takes the path."""
+    os.environ["AVS_CG_RESIDENT_MAX_QUADS"] = "4"
+    try:
+        sc = scenes.sphere(64, 4)
+        dsc = scenes.to_device(sc, torch.device("cuda:0"))
+        pyr = build_pyramid(dsc)
+        s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
+        feed(s, pyr)
+        s.set_scene_fields(dsc)
+        s.assemble()
+        rp = s.csr()[0]
+        assert int(np.diff(rp).max()) > 20
+        info = s.solve(1e-10, 5000)
+        assert info.resident == 1 and info.converged == 1
+        o = oracle_from_pyramid(sc, pyr)
+        o.hot_path()
+        xo, io = o.solve(1e-10, 5000)
+        assert abs(info.iterations - io.iterations) <= 3 and rel_l2(s.solution(), xo) < 1e-7
+        s.close()
+    finally:
+        os.environ.pop("AVS_CG_RESIDENT_MAX_QUADS", None)
