@@ -2307,7 +2307,7 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
     }
     if (dist && dist_wants_single_reduction(dist))
         return pcg_solve_single_reduction(w, A, b, x, tol, max_iters, stream, info, dist);
-    if (!dist && resident_wanted(false)) { // opt-in (AVS_CG_RESIDENT=1): small single-GPU systems on the chip
+    if (!dist && resident_wanted(false)) { // systems that fit on the chip (<= ~1 M rows, packed form): one cooperative launch
         bool ran = false;
         const avs_status rs = pcg_solve_resident_single(w, A, b, x, tol, max_iters, stream, info, &ran);
         if (ran || rs != AVS_OK) return rs;

@@ -199,9 +199,24 @@ def extra_workload(label, sc, local_rank, tol, max_iters):
     iters = sum(i.iterations for i in infos)
     rec = {"workload": label, "n_dofs": int(ai.n_velocity), "nnz": int(ai.nnz), "levels": int(pinfo.levels),
            "cg_iterations_per_step": iters // 2, "converged": int(all(i.converged for i in infos)),
+           "resident_loop": bool(infos[0].resident),   # CU-resident PCG (one cooperative launch; no separate SpMV launch to time)
            "value": iters / el, "unit": "iter/s", "ms_per_step": el / 2 * 1e3, "assembly_wall_ms": asm_ms,
            "prepass_ms": pinfo.weights_ms + pinfo.octree_ms + pinfo.classify_ms + pinfo.number_ms,
-           "roofline": spmv_rates(int(ai.n_velocity), int(ai.nnz), s.matrix_format(), sum(i.spmv_ms for i in infos) / 2)}
+           "roofline": (spmv_rates(int(ai.n_velocity), int(ai.nnz), s.matrix_format(), sum(i.spmv_ms for i in infos) / 2)
+                        if infos[0].spmv_ms > 0 else None)}
+    if infos[0].resident:   # the same workload through the launch-per-phase loop: what the resident loop is worth, and the SpMV roofline
+        os.environ["AVS_CG_RESIDENT"] = "0"
+        try:
+            s.solve(tol, max_iters)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            inf2 = [s.solve(tol, max_iters) for _ in range(2)]
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t0
+            rec["launch_per_phase"] = {"value": sum(i.iterations for i in inf2) / el2, "unit": "iter/s",
+                                       "roofline": spmv_rates(int(ai.n_velocity), int(ai.nnz), s.matrix_format(), sum(i.spmv_ms for i in inf2) / 2)}
+        finally:
+            os.environ.pop("AVS_CG_RESIDENT", None)
     s.close()
     torch.cuda.empty_cache()
     return rec

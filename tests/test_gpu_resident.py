@@ -1,5 +1,5 @@
-"""CU-resident PCG (avs_pcg_resident.inl): one cooperative launch for all iterations, the packed matrix words in the register files,
-the vector slices in LDS.  It must agree with the oracle like the launch-per-phase loops do (same recurrences as the direct
+"""CU-resident PCG (avs_pcg_resident.inl, the default for systems that fit the chip): one cooperative launch for all iterations, the
+packed matrix words in the register files, the vector slices in LDS.  It must agree with the oracle like the launch-per-phase loops do (same recurrences as the direct
 transport's single-reduction loop; only the order of additions inside the three dot products differs)."""
 import os
 
@@ -17,7 +17,7 @@ CASES = {
     "sphere64_L4": lambda: scenes.sphere(64, 4),
     "beam128_L3": lambda: scenes.fat_beam(128, 3),                       # BASELINE configs[1]
     "hip_buckling": lambda: scenes.viscous_buckling_scene(),            # 0.79 M rows: the vector slices + remote columns nearly fill the LDS
-    "obstacle_rho_usolid": lambda: scenes.with_sampled_fields(scenes.sphere_with_obstacle(64, 4)),
+    "sphere_obstacle": lambda: scenes.sphere_with_obstacle(64, 4),        # curved solid boundary: rhs carries the boundary terms
     "viscous_beam_hip_coarse": lambda: scenes.viscous_beam_scene(coarsen=2),
 }
 
@@ -61,9 +61,14 @@ def test_resident_single_gpu_solve_matches_oracle(name, resident_env, built_lib)
     s.close()
 
 
-def test_resident_refuses_what_does_not_fit(resident_env, built_lib):
-    """7.4 M rows do not fit the register files: the solve silently keeps the launch-per-phase loop."""
-    sc = scenes.fat_beam(256, 4, variable_viscosity=True, device=torch.device("cuda:0"))   # tile dictionaries: not the packed form
+@pytest.mark.parametrize("which", ["tile_dictionaries", "density_tensor", "too_many_rows"])
+def test_resident_refuses_what_does_not_fit(which, resident_env, built_lib):
+    """Systems that are not in the packed single-dictionary form (a viscosity / density field with thousands of distinct values) or
+    too large for the register files silently keep the launch-per-phase loop."""
+    dev = torch.device("cuda:0")
+    sc = {"tile_dictionaries": lambda: scenes.fat_beam(256, 4, variable_viscosity=True, device=dev),
+          "density_tensor": lambda: scenes.with_sampled_fields(scenes.sphere_with_obstacle(64, 4, device=dev)),
+          "too_many_rows": lambda: scenes.fat_beam(256, 5, device=dev)}[which]()
     pyr = build_pyramid(sc)
     s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
     feed(s, pyr)
