@@ -54,7 +54,8 @@ struct ResidentArgs {
     const uint16_t *dcode;                // diagonal's value code per row; invtab[code] = 1 / table[code]
     const double *invtab;
     // synchronisation (device memory, agent scope)
-    unsigned long long *bar_flags;        // G: barriers workgroup b has reached
+    unsigned *bar_count;                  // barrier after the update
+    unsigned long long *bar_epoch;        // completed update barriers
     double *slots;                        // G x 4 partial sums, sentinel-armed (the value is its own arrival flag)
     double *bcast;                        // kResGens x 4: (alpha, beta, rho, done), sentinel-armed ring
     PcgScalars *sc;
@@ -370,18 +371,18 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
         wait_own_stores(); // u (agent scope) and the peers' entries (system scope) acknowledged before this wave reaches the barrier
         if (timed) ts[1] = wall_clock64();
         if (a.wg_times && tid == 0 && it == 20) a.wg_times[4 * b + 1] = wall_clock64();
-        // ---- B: grid barrier, flag per workgroup (no atomic on the critical path: every workgroup publishes its arrival with one
-        // write-through store and polls all G flags, one per thread -- the counter version cost an atomic round trip + a flag round
-        // trip); workgroup 0, once it has seen everybody, raises this rank's halo flags in the peers' blocks (every workgroup's
-        // pushes were acknowledged before it published).  Then drop the stale lines of u from L1 / L2 ----
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(a.bar_flags + b, (unsigned long long)it + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid < G && !res_spin_u64(a.bar_flags + tid, (unsigned long long)it + 1ull, timeout)) sh_fail = 1;
+        // ---- B: grid barrier; its last arriver raises this rank's halo flags; then drop the stale lines of u from L1 / L2 ----
         __syncthreads();
         if (tid == 0) {
-            if (dd && b == 0)
-                for (int i = 0; i < dd->npeers; ++i)
-                    if (dd->send_off[i + 1] > dd->send_off[i]) st_sys(dd->peer_hflag_dst[i], E);
+            const unsigned t = __hip_atomic_fetch_add(a.bar_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == (unsigned)G - 1u) {
+                __hip_atomic_store(a.bar_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (dd)
+                    for (int i = 0; i < dd->npeers; ++i)
+                        if (dd->send_off[i + 1] > dd->send_off[i]) st_sys(dd->peer_hflag_dst[i], E);
+                wait_own_stores(); // the counter is back at 0 before anybody can be released into the next barrier
+                __hip_atomic_store(a.bar_epoch, (unsigned long long)it + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (!res_spin_u64(a.bar_epoch, (unsigned long long)it + 1ull, timeout)) sh_fail = 1;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // buffer_inv sc1: this CU's L1 and the XCD's L2 drop other writers' lines
         }
         if (dd && a.wg_halo[b] && tid >= 64 && tid < 64 + dd->npeers && dd->recv_cnt[tid - 64] > 0)
@@ -576,8 +577,9 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
 struct ResidentPlan {
     DevBuf<int32_t> lane_row0, wg_lane0, wg_row0, push_seg, rem_list, rem_count;
     DevBuf<uint32_t> lane_meta, rwords;
-    DevBuf<unsigned long long> bar_flags;
+    DevBuf<unsigned long long> bar_epoch;
     DevBuf<uint8_t> wg_halo;
+    DevBuf<unsigned> bar_count;
     DevBuf<double> slots, bcast;
     DevBuf<long long> timers;
     int G = 0, max_timed = 0, lc_bits = 0, ng = 0, max_quads = kResQuads;
@@ -823,7 +825,8 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
         }
     }
     bool up = pl->lane_row0.alloc((size_t)L) == AVS_OK && pl->lane_meta.alloc((size_t)L) == AVS_OK && pl->wg_lane0.alloc((size_t)G + 1) == AVS_OK &&
-              pl->push_seg.alloc(seg.size()) == AVS_OK && pl->wg_halo.alloc((size_t)G) == AVS_OK && pl->bar_flags.alloc((size_t)G) == AVS_OK && pl->slots.alloc((size_t)G * 4) == AVS_OK && pl->bcast.alloc(4 * kResGens) == AVS_OK;
+              pl->push_seg.alloc(seg.size()) == AVS_OK && pl->wg_halo.alloc((size_t)G) == AVS_OK && pl->bar_count.alloc(2) == AVS_OK &&
+              pl->bar_epoch.alloc(1) == AVS_OK && pl->slots.alloc((size_t)G * 4) == AVS_OK && pl->bcast.alloc(4 * kResGens) == AVS_OK;
     if (!up) return no("plan allocation failed");
     up = hipMemcpy(pl->lane_row0.p, lrow.data(), (size_t)L * 4, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(pl->lane_meta.p, lmeta.data(), (size_t)L * 4, hipMemcpyHostToDevice) == hipSuccess &&
@@ -874,7 +877,8 @@ static avs_status resident_run(ResidentPlan *pl, const CsrView &A, double *x, do
     a.x = x; a.r = r; a.p = p; a.s = s; a.u = u; a.w = wv;
     a.dcode = dcode;
     a.invtab = invtab;
-    a.bar_flags = pl->bar_flags.p;
+    a.bar_count = pl->bar_count.p;
+    a.bar_epoch = pl->bar_epoch.p;
     a.slots = pl->slots.p;
     a.bcast = pl->bcast.p;
     a.sc = sc;
@@ -903,7 +907,8 @@ static avs_status resident_run(ResidentPlan *pl, const CsrView &A, double *x, do
             a.max_timed = pl->max_timed;
             a.wg_times = pl->timers.p + (size_t)pl->max_timed * kResTimers;
         }
-    AVS_HIP(hipMemsetAsync(pl->bar_flags.p, 0, (size_t)pl->G * sizeof(unsigned long long), stream));
+    AVS_HIP(hipMemsetAsync(pl->bar_count.p, 0, 2 * sizeof(unsigned), stream));
+    AVS_HIP(hipMemsetAsync(pl->bar_epoch.p, 0, sizeof(unsigned long long), stream));
     AVS_HIP(hipMemsetAsync(pl->slots.p, 0xFF, (size_t)pl->G * 4 * sizeof(double), stream));   // armed: kSentinel in every slot
     AVS_HIP(hipMemsetAsync(pl->bcast.p, 0xFF, 4 * kResGens * sizeof(double), stream));
     void *args[] = {&a};
