@@ -211,7 +211,6 @@ __global__ __launch_bounds__(kResThreads) void k_resident_remap(const uint32_t *
 template <int NG>
 __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
 {
-    constexpr unsigned WM = (1u << kResWordBits) - 1u;
     extern __shared__ __attribute__((aligned(16))) double rlds[];
     // u: the workgroup's slice, then its remote-column cache (one index space: a word's local column addresses both)
     // (the split is per workgroup -- its own row and remote-column counts: workgroups of coarse regions have few rows and many remote
@@ -305,6 +304,19 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
     int done = a.sc->done, iter = a.sc->iter;
     double rho = a.sc->rho;
     const double threshold = a.sc->threshold;
+    // x, w (and s when it lives in global memory) of the lane's rows for the NEXT update: requested as soon as this iteration's
+    // sums are on their way, so that their latency hides behind the wait for the broadcast instead of opening the update phase
+    double xk[kResRowsMax], wk[kResRowsMax], sk[kResRowsMax];
+    auto prefetch = [&]() {
+#pragma unroll
+        for (int k = 0; k < kResRowsMax; ++k)
+            if (k < nrows) {
+                xk[k] = a.x[row0 + k];
+                wk[k] = a.w[row0 + k];
+                if (NG >= 1) sk[k] = a.s[row0 + k];
+            }
+    };
+    prefetch();
     int it = 0;
     for (; it < a.max_iters && !done; ++it) {
         const bool timed = a.timers && b == 0 && tid == 0 && it < a.max_timed;
@@ -315,13 +327,10 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
         // ---- A: vector update of the lane's rows (k_sr_update_push's arithmetic), u to global, boundary entries to the peers ----
         double ru = 0., rr = 0.;
         {
-            double xk[kResRowsMax], wk[kResRowsMax], sk[kResRowsMax], pk[kResRowsMax], rk2[kResRowsMax];
+            double pk[kResRowsMax], rk2[kResRowsMax];
 #pragma unroll
             for (int k = 0; k < kResRowsMax; ++k)
                 if (k < nrows) {
-                    xk[k] = a.x[row0 + k];
-                    wk[k] = a.w[row0 + k];
-                    if (NG >= 1) sk[k] = a.s[row0 + k];
                     if (NG >= 2) pk[k] = a.p[row0 + k];
                     if (NG >= 3) rk2[k] = a.r[row0 + k];
                 }
@@ -415,16 +424,17 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
                     // the words are loop-invariant: without this the compiler hoists every decode (code, column, LDS addresses) out of
                     // the iteration loop and spills hundreds of registers
                     asm volatile("" : "+v"(mm));
-                    const unsigned w0 = mm.x & WM;
-                    const unsigned w1 = __builtin_amdgcn_alignbit(mm.y, mm.x, 25) & WM;
-                    const unsigned w2 = __builtin_amdgcn_alignbit(mm.z, mm.y, 18) & WM;
-                    const unsigned w3 = __builtin_amdgcn_alignbit(mm.w, mm.z, 11) & WM;
-                    const unsigned w4 = (mm.w >> 4) & WM;
-                    const double v0 = tbl[w0 >> cbits], x0 = u_l[w0 & cmask];
-                    const double v1 = tbl[w1 >> cbits], x1 = u_l[w1 & cmask];
-                    const double v2 = tbl[w2 >> cbits], x2 = u_l[w2 & cmask];
-                    const double v3 = tbl[w3 >> cbits], x3 = u_l[w3 & cmask];
-                    const double v4 = tbl[w4 >> cbits], x4 = u_l[w4 & cmask];
+                    // five 25-bit words at bit offsets 0, 25, 50, 75, 100 of the quad: column = low lc_bits, code = the bits above (bit-field
+                    // extracts straight from the shifted dwords: no intermediate 25-bit mask)
+                    const unsigned t1 = __builtin_amdgcn_alignbit(mm.y, mm.x, 25);
+                    const unsigned t2 = __builtin_amdgcn_alignbit(mm.z, mm.y, 18);
+                    const unsigned t3 = __builtin_amdgcn_alignbit(mm.w, mm.z, 11);
+                    const unsigned kb = (unsigned)(kResWordBits - cbits);
+                    const double v0 = tbl[__builtin_amdgcn_ubfe(mm.x, (unsigned)cbits, kb)], x0 = u_l[mm.x & cmask];
+                    const double v1 = tbl[__builtin_amdgcn_ubfe(t1, (unsigned)cbits, kb)], x1 = u_l[t1 & cmask];
+                    const double v2 = tbl[__builtin_amdgcn_ubfe(t2, (unsigned)cbits, kb)], x2 = u_l[t2 & cmask];
+                    const double v3 = tbl[__builtin_amdgcn_ubfe(t3, (unsigned)cbits, kb)], x3 = u_l[t3 & cmask];
+                    const double v4 = tbl[__builtin_amdgcn_ubfe(mm.w, 4u + (unsigned)cbits, kb)], x4 = u_l[__builtin_amdgcn_ubfe(mm.w, 4u, (unsigned)cbits)];
                     acc += v0 * x0; // left to right inside the row: the oracle's order (padding words add +0)
                     acc += v1 * x1;
                     acc += v2 * x2;
@@ -458,6 +468,7 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
             __hip_atomic_store(a.slots + 4 * b + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(a.slots + 4 * b + 2, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        prefetch(); // (w was stored by this very lane above; x and s in the previous update)
         if (timed) ts[4] = wall_clock64();
         if (a.wg_times && tid == 0 && it == 20) { // every workgroup's own phase stamps of one iteration (imbalance diagnostics)
             a.wg_times[4 * b + 3] = wall_clock64();
