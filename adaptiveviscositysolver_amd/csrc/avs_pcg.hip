@@ -1744,6 +1744,7 @@ static avs_status pcg_solve_single_reduction(PcgWork *w, const CsrView &A, const
         info->nnz = A.nnz;
         info->solve_ms = ms;
         info->spmv_ms = spmv_samples ? spmv_ms_sum / spmv_samples : 0.;
+        info->resident = 0;
     }
     return AVS_OK;
 }
@@ -2060,8 +2061,9 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
     if (coded && (da.exclusive_device || getenv("AVS_CG_RESIDENT_CUS")) && resident_wanted(true)) {
         if (!w->resident) w->resident = new (std::nothrow) ResidentPlan();
         if (w->resident && resident_prepare(w->resident, A, w->n_ext, &da, stream)) {
-            AVS_TRY(resident_run(w->resident, A, x, r, p, sv, u, wv, w->dcode.p, w->invtab.p, sc, max_iters, &da, stream));
-            w->resident_used = 1;
+            bool launched = false;
+            AVS_TRY(resident_run(w->resident, A, x, r, p, sv, u, wv, w->dcode.p, w->invtab.p, sc, max_iters, &da, stream, &launched));
+            w->resident_used = launched ? 1 : 0; // (refused: the loop below takes over from the same state)
         }
     }
 
@@ -2241,7 +2243,6 @@ static avs_status pcg_solve_resident_single(PcgWork *w, const CsrView &A, const 
     if (!coded) return AVS_OK;
     if (!w->resident) w->resident = new (std::nothrow) ResidentPlan();
     if (!w->resident || !resident_prepare(w->resident, A, A.n, nullptr, stream)) return AVS_OK;
-    *ran = true;
     const int g = (int)((n + kBlock - 1) / kBlock < kVecGrid ? ((n + kBlock - 1) / kBlock > 0 ? (n + kBlock - 1) / kBlock : 1) : kVecGrid);
     const int rowgrid = (int)((n + kBlock - 1) / kBlock) > 0 ? (int)((n + kBlock - 1) / kBlock) : 1;
     const int variant = spmv_default_variant(A);
@@ -2268,12 +2269,17 @@ static avs_status pcg_solve_resident_single(PcgWork *w, const CsrView &A, const 
     reduce_launch(w, pspmv, nb, 1, sc, (int)OP_NONE, tol, 0, 3, stream);
     hipLaunchKernelGGL(k_scalar, dim3(1), dim3(64), 0, stream, sc, (int)OP_SR_INIT, tol);
     AVS_HIP(hipGetLastError());
-    AVS_TRY(resident_run(w->resident, A, x, r, p, sv, u, wv, w->dcode.p, w->invtab.p, sc, max_iters, nullptr, stream));
+    bool launched = false;
+    AVS_TRY(resident_run(w->resident, A, x, r, p, sv, u, wv, w->dcode.p, w->invtab.p, sc, max_iters, nullptr, stream, &launched));
+    if (!launched) return AVS_OK; // (x is untouched: the launch-per-phase loop starts over from it)
+    *ran = true;
     w->resident_used = 1;
     AVS_HIP(hipMemcpyAsync(w->host_sc, sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, stream));
     AVS_HIP(hipStreamSynchronize(stream));
     if (w->host_sc->fault) {
-        set_error("resident PCG: a workgroup did not reach a grid barrier within the time limit (fault %d)", w->host_sc->fault);
+        w->resident->ok = false; // not again on this context: the next solve takes the launch-per-phase loop
+        set_error("resident PCG: a workgroup did not reach a grid barrier within the time limit (fault %d); the context falls back to the "
+                  "launch-per-phase loop for its next solves", w->host_sc->fault);
         return AVS_EINTERNAL;
     }
     if (w->host_sc->done == 3) AVS_HIP(hipMemsetAsync(x, 0, (size_t)n * sizeof(double), stream)); // rhs == 0: x := 0
@@ -2459,6 +2465,7 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
         info->nnz = A.nnz;
         info->solve_ms = ms;
         info->spmv_ms = spmv_samples ? spmv_ms_sum / spmv_samples : 0.;
+        info->resident = 0;
     }
     return AVS_OK;
 }

@@ -865,10 +865,13 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
 }
 
 // Runs the rest of the solve (state in sc / the vectors, as the set-up rounds left it) in ONE cooperative launch.
+// *launched = false: the cooperative launch was refused (the grid is not co-resident on this device right now); nothing was
+// touched, the plan is retired and the caller carries on with the launch-per-phase loop.
 static avs_status resident_run(ResidentPlan *pl, const CsrView &A, double *x, double *r, double *p, double *s, double *u, double *wv,
                                const uint16_t *dcode, const double *invtab, PcgScalars *sc, int max_iters, const DirectArgs *da,
-                               hipStream_t stream)
+                               hipStream_t stream, bool *launched)
 {
+    *launched = false;
     ResidentArgs a{};
     a.row_ptr = A.row_ptr;
     a.table = A.table;
@@ -923,7 +926,15 @@ static avs_status resident_run(ResidentPlan *pl, const CsrView &A, double *x, do
     AVS_HIP(hipMemsetAsync(pl->slots.p, 0xFF, (size_t)pl->G * 4 * sizeof(double), stream));   // armed: kSentinel in every slot
     AVS_HIP(hipMemsetAsync(pl->bcast.p, 0xFF, 4 * kResGens * sizeof(double), stream));
     void *args[] = {&a};
-    AVS_HIP(hipLaunchCooperativeKernel(resident_kernel(pl->ng), dim3((unsigned)pl->G), dim3(kResThreads), args, (unsigned)pl->lds, stream));
+    const hipError_t le = hipLaunchCooperativeKernel(resident_kernel(pl->ng), dim3((unsigned)pl->G), dim3(kResThreads), args, (unsigned)pl->lds, stream);
+    if (le != hipSuccess) {
+        (void)hipGetLastError();
+        pl->ok = false;
+        pl->why = std::string("cooperative launch refused: ") + hipGetErrorString(le);
+        if (getenv("AVS_CG_RESIDENT_VERBOSE")) fprintf(stderr, "[avs resident] not used: %s\n", pl->why.c_str());
+        return AVS_OK;
+    }
+    *launched = true;
     if (a.timers) { // per-phase averages of workgroup 0 (tuning aid)
         std::vector<long long> t((size_t)pl->max_timed * kResTimers + (size_t)pl->G * 4);
         AVS_HIP(hipMemcpyAsync(t.data(), pl->timers.p, t.size() * sizeof(long long), hipMemcpyDeviceToHost, stream));
