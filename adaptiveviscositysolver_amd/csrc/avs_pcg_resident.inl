@@ -27,6 +27,11 @@ static constexpr int kResQuads = 15;     // 128-bit register quads of matrix wor
 static constexpr int kResQuadWords = 5;  // 25-bit words per quad; a row takes ceil(len / 5) consecutive quads of ONE lane
 static constexpr int kResRowsMax = 6;    // rows per lane
 static constexpr int kResWordBits = 25;  // value code | workgroup-local column
+#ifndef AVS_RES_PREFETCH
+#define AVS_RES_PREFETCH 0
+#endif
+static constexpr bool kResPrefetch = AVS_RES_PREFETCH != 0; // request w (and s) for the next update during the reduction: measured neutral
+                                                            // (update 10.3 -> 8.5 us, SpMV 12.1 -> 13.0 us: the live registers push matrix quads to scratch), off
 static constexpr int kResTimers = 8;   // phase time stamps per iteration (AVS_CG_RESIDENT_TIMERS=n)
 static constexpr int kResGens = 4;     // generations of the broadcast slots (a ring: re-armed two iterations ahead)
 
@@ -54,8 +59,10 @@ struct ResidentArgs {
     const uint16_t *dcode;                // diagonal's value code per row; invtab[code] = 1 / table[code]
     const double *invtab;
     // synchronisation (device memory, agent scope)
-    unsigned *bar_count;                  // barrier after the update
-    unsigned long long *bar_epoch;        // completed update barriers
+    unsigned *bar_count;                  // [0]: pushing workgroups that have stored their boundary entries (the last raises the halo flags)
+    unsigned long long *bar_flags;        // G: update phases workgroup g has completed (its u is in memory)
+    const unsigned *dep_mask;             // G x 32: the workgroups whose u entries workgroup b reads
+    int n_push_wgs;                       // workgroups with boundary entries to push
     double *slots;                        // G x 4 partial sums, sentinel-armed (the value is its own arrival flag)
     double *bcast;                        // kResGens x 4: (alpha, beta, rho, done), sentinel-armed ring
     PcgScalars *sc;
@@ -137,9 +144,11 @@ static constexpr int kRemapBlock = 16; // bitmap words per prefix block
 __global__ __launch_bounds__(kResThreads) void k_resident_remap(const uint32_t *__restrict__ packed, const int32_t *__restrict__ row_ptr, int col_bits,
                                                                 int lc_bits, const int32_t *__restrict__ wg_row0, int rem_cap, int n_ext,
                                                                 uint32_t *__restrict__ rwords, int32_t *__restrict__ rem_list,
-                                                                int32_t *__restrict__ rem_count, int *__restrict__ fail)
+                                                                int32_t *__restrict__ rem_count, int *__restrict__ fail, int n_own,
+                                                                unsigned *__restrict__ dep_mask)
 {
     extern __shared__ unsigned bm[]; // bitmap[nw], prefix[nb + 1]
+    __shared__ unsigned deps[32];    // bit g: a remote column of this workgroup belongs to workgroup g (G <= 1024)
     const int nw = (n_ext + 31) >> 5, nb = (nw + kRemapBlock - 1) / kRemapBlock;
     unsigned *prefix = bm + nb * kRemapBlock;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -147,6 +156,7 @@ __global__ __launch_bounds__(kResThreads) void k_resident_remap(const uint32_t *
     const int k0 = row_ptr[r0], k1 = row_ptr[r1];
     const unsigned cmask = (1u << col_bits) - 1u;
     for (int i = tid; i < nb * kRemapBlock; i += kResThreads) bm[i] = 0u;
+    if (tid < 32) deps[tid] = 0u;
     __syncthreads();
     for (int k = k0 + tid; k < k1; k += kResThreads) {
         const int col = (int)(packed[k] & cmask);
@@ -186,10 +196,22 @@ __global__ __launch_bounds__(kResThreads) void k_resident_remap(const uint32_t *
             int sl = slot_of(w << 5);
             while (bits) {
                 const int bit = __ffs((int)bits) - 1;
-                rem_list[(size_t)b * rem_cap + sl++] = (w << 5) + bit;
+                const int col = (w << 5) + bit;
+                rem_list[(size_t)b * rem_cap + sl++] = col;
+                if (col < n_own) { // the workgroup that owns (writes) this entry of u: binary search in the row boundaries
+                    int lo = 0, hi = (int)gridDim.x;
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (wg_row0[mid] <= col) lo = mid;
+                        else hi = mid;
+                    }
+                    atomicOr(&deps[lo >> 5], 1u << (lo & 31));
+                }
                 bits &= bits - 1u;
             }
         }
+    __syncthreads();
+    if (tid < 32) dep_mask[(size_t)b * 32 + tid] = deps[tid];
     const int wrows = r1 - r0;
     for (int k = k0 + tid; k < k1; k += kResThreads) {
         const uint32_t wd = packed[k];
@@ -298,6 +320,10 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
     const int cbits = a.lc_bits;
     const int nrem = a.rem_count[b];
     const int32_t *rem = a.rem_list + (size_t)b * a.rem_stride;
+    const bool mydep = tid < G && tid != b && ((a.dep_mask[(size_t)b * 32 + (tid >> 5)] >> (tid & 31)) & 1u) != 0u; // producer of this workgroup
+    bool pushes = false;
+    if (dd)
+        for (int i = 0; i < dd->npeers; ++i) pushes = pushes || a.push_seg[i * (G + 1) + b + 1] > a.push_seg[i * (G + 1) + b];
     const unsigned long long E0 = dd ? *a.epoch : 0ull; // every workgroup reads the same value: it is only written at the very end
     const double *halo = dd ? dd->my_halo : nullptr;
     double alpha = a.sc->alpha, beta = a.sc->beta;
@@ -306,17 +332,17 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
     const double threshold = a.sc->threshold;
     // x, w (and s when it lives in global memory) of the lane's rows for the NEXT update: requested as soon as this iteration's
     // sums are on their way, so that their latency hides behind the wait for the broadcast instead of opening the update phase
-    double xk[kResRowsMax], wk[kResRowsMax], sk[kResRowsMax];
+    // (x is not prefetched: nothing but its own store waits for it, and 12 more live registers push the matrix quads into scratch)
+    double wk[kResRowsMax], sk[kResRowsMax];
     auto prefetch = [&]() {
 #pragma unroll
         for (int k = 0; k < kResRowsMax; ++k)
             if (k < nrows) {
-                xk[k] = a.x[row0 + k];
                 wk[k] = a.w[row0 + k];
                 if (NG >= 1) sk[k] = a.s[row0 + k];
             }
     };
-    prefetch();
+    if (kResPrefetch) prefetch();
     int it = 0;
     for (; it < a.max_iters && !done; ++it) {
         const bool timed = a.timers && b == 0 && tid == 0 && it < a.max_timed;
@@ -326,11 +352,13 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
         const unsigned long long E = E0 + (unsigned long long)it + 1ull;
         // ---- A: vector update of the lane's rows (k_sr_update_push's arithmetic), u to global, boundary entries to the peers ----
         double ru = 0., rr = 0.;
+        if (!kResPrefetch) prefetch();
         {
-            double pk[kResRowsMax], rk2[kResRowsMax];
+            double xk[kResRowsMax], pk[kResRowsMax], rk2[kResRowsMax];
 #pragma unroll
             for (int k = 0; k < kResRowsMax; ++k)
                 if (k < nrows) {
+                    xk[k] = a.x[row0 + k];
                     if (NG >= 2) pk[k] = a.p[row0 + k];
                     if (NG >= 3) rk2[k] = a.r[row0 + k];
                 }
@@ -380,31 +408,48 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
         wait_own_stores(); // u (agent scope) and the peers' entries (system scope) acknowledged before this wave reaches the barrier
         if (timed) ts[1] = wall_clock64();
         if (a.wg_times && tid == 0 && it == 20) a.wg_times[4 * b + 1] = wall_clock64();
-        // ---- B: grid barrier; its last arriver raises this rank's halo flags; then drop the stale lines of u from L1 / L2 ----
+        // ---- B: no grid barrier here: a workgroup only needs the u entries of the workgroups it reads from (10-30 of 256: the
+        // neighbours in the brick order).  It publishes "my update k is in memory" (one write-through flag, after its stores were
+        // acknowledged) and polls the flags of its producers, one per thread.  The reduction at the end of the iteration is the
+        // grid-wide synchronisation that keeps iteration k + 1 from overwriting what iteration k still reads.  The workgroups that
+        // push boundary entries to other ranks take a ticket; the last one raises this rank's halo flags.  Then drop the stale lines
+        // of u from L1 / L2 ----
         __syncthreads();
         if (tid == 0) {
-            const unsigned t = __hip_atomic_fetch_add(a.bar_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t == (unsigned)G - 1u) {
-                __hip_atomic_store(a.bar_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (dd)
+            __hip_atomic_store(a.bar_flags + b, (unsigned long long)it + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (dd && pushes) { // (a monotone ticket, zeroed by the host before the launch: no reset to order)
+                const unsigned t = __hip_atomic_fetch_add(a.bar_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((t + 1u) % (unsigned)a.n_push_wgs == 0u)
                     for (int i = 0; i < dd->npeers; ++i)
                         if (dd->send_off[i + 1] > dd->send_off[i]) st_sys(dd->peer_hflag_dst[i], E);
-                wait_own_stores(); // the counter is back at 0 before anybody can be released into the next barrier
-                __hip_atomic_store(a.bar_epoch, (unsigned long long)it + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else if (!res_spin_u64(a.bar_epoch, (unsigned long long)it + 1ull, timeout)) sh_fail = 1;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // buffer_inv sc1: this CU's L1 and the XCD's L2 drop other writers' lines
+            }
         }
-        if (dd && a.wg_halo[b] && tid >= 64 && tid < 64 + dd->npeers && dd->recv_cnt[tid - 64] > 0)
-            if (!wait_flag(&dd->mine->hflag[dd->peer_rank[tid - 64]], E, timeout, a.sc, 1)) sh_fail = 1;
+        if (mydep && !res_spin_u64(a.bar_flags + tid, (unsigned long long)it + 1ull, timeout)) sh_fail = 1;
+        if (dd && a.wg_halo[b] && tid >= 960 && tid < 960 + dd->npeers && dd->recv_cnt[tid - 960] > 0)
+            if (!wait_flag(&dd->mine->hflag[dd->peer_rank[tid - 960]], E, timeout, a.sc, 1)) sh_fail = 1;
+        __syncthreads(); // every producer's u and the peers' halo entries are in memory
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // buffer_inv sc1: this CU's L1 and the XCD's L2 drop other writers' lines
         __syncthreads();
         if (sh_fail) break; // (block-uniform)
         if (timed) ts[2] = wall_clock64();
         // ---- C: w = A u for the lane's rows.  First the workgroup's remote columns -> LDS, ONE round trip for all of them (plain loads
         // of the global u: this CU's L1 / the XCD's L2 were invalidated behind the barrier; other ranks' entries: the halo area of the
         // comm block, fine-grained memory first touched after the flag); then every gather is an LDS read.
-        for (int k = tid; k < nrem; k += kResThreads) {
-            const int src = rem[k];
-            u_l[wrows + k] = (src < a.n) ? a.u[src] : halo[src - a.n];
+        for (int k0 = tid; k0 < nrem; k0 += 8 * kResThreads) { // eight loads in flight per lane: a halo-reading workgroup fills 8-10 k slots
+            double v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j * kResThreads;
+                if (k < nrem) {
+                    const int src = rem[k];
+                    v[j] = (src < a.n) ? a.u[src] : halo[src - a.n];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j * kResThreads;
+                if (k < nrem) u_l[wrows + k] = v[j];
+            }
         }
         __syncthreads();
         if (timed) ts[3] = wall_clock64();
@@ -468,7 +513,7 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
             __hip_atomic_store(a.slots + 4 * b + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(a.slots + 4 * b + 2, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        prefetch(); // (w was stored by this very lane above; x and s in the previous update)
+        if (kResPrefetch) prefetch(); // (w was stored by this very lane above; s in the previous update)
         if (timed) ts[4] = wall_clock64();
         if (a.wg_times && tid == 0 && it == 20) { // every workgroup's own phase stamps of one iteration (imbalance diagnostics)
             a.wg_times[4 * b + 3] = wall_clock64();
@@ -588,7 +633,9 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
 struct ResidentPlan {
     DevBuf<int32_t> lane_row0, wg_lane0, wg_row0, push_seg, rem_list, rem_count;
     DevBuf<uint32_t> lane_meta, rwords;
-    DevBuf<unsigned long long> bar_epoch;
+    DevBuf<unsigned long long> bar_flags;
+    DevBuf<unsigned> dep_mask;
+    int n_push_wgs = 0;
     DevBuf<uint8_t> wg_halo;
     DevBuf<unsigned> bar_count;
     DevBuf<double> slots, bcast;
@@ -703,7 +750,7 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
     if (remap_lds > 160 * 1024 - 4096) return no("too many local columns for the plan kernel's bitmap");
     DevBuf<int> fail;
     if (pl->wg_row0.alloc((size_t)G + 1) != AVS_OK || pl->rwords.alloc((size_t)A.nnz) != AVS_OK || pl->rem_count.alloc((size_t)G) != AVS_OK ||
-        pl->rem_list.alloc((size_t)G * cap) != AVS_OK || fail.alloc(1) != AVS_OK ||
+        pl->rem_list.alloc((size_t)G * cap) != AVS_OK || fail.alloc(1) != AVS_OK || pl->dep_mask.alloc((size_t)G * 32) != AVS_OK || G > 1024 ||
         hipFuncSetAttribute((const void *)k_resident_remap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)remap_lds) != hipSuccess) {
         (void)hipGetLastError();
         return no("plan allocation failed");
@@ -749,7 +796,8 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
             return no("plan upload failed");
         }
         hipLaunchKernelGGL(k_resident_remap, dim3((unsigned)G), dim3(kResThreads), remap_lds, stream, A.packed, A.row_ptr, A.col_bits, lc_bits,
-                           (const int32_t *)pl->wg_row0.p, cap, (int)n_ext, pl->rwords.p, pl->rem_list.p, pl->rem_count.p, fail.p);
+                           (const int32_t *)pl->wg_row0.p, cap, (int)n_ext, pl->rwords.p, pl->rem_list.p, pl->rem_count.p, fail.p, (int)n,
+                           pl->dep_mask.p);
         int f = 0;
         if (hipMemcpyAsync(&f, fail.p, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess ||
             hipMemcpyAsync(rc.data(), pl->rem_count.p, (size_t)G * sizeof(int32_t), hipMemcpyDeviceToHost, stream) != hipSuccess ||
@@ -823,6 +871,12 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
                 seg[(size_t)i * (G + 1) + b] = (int32_t)(itp - sidx.data());
             }
         }
+        pl->n_push_wgs = 0;
+        for (int b = 0; b < G; ++b) {
+            bool any = false;
+            for (int i = 0; i < np; ++i) any = any || seg[(size_t)i * (G + 1) + b + 1] > seg[(size_t)i * (G + 1) + b];
+            pl->n_push_wgs += any ? 1 : 0;
+        }
         // workgroups that read halo columns wait for the peers' flags: every workgroup overlapping a halo-reading 512-row tile of the plan
         std::vector<int32_t> tb((size_t)(da->n_tiles_bnd > 0 ? da->n_tiles_bnd : 1));
         if (da->n_tiles_bnd && hipMemcpy(tb.data(), da->tiles_bnd, (size_t)da->n_tiles_bnd * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) {
@@ -837,7 +891,7 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
     }
     bool up = pl->lane_row0.alloc((size_t)L) == AVS_OK && pl->lane_meta.alloc((size_t)L) == AVS_OK && pl->wg_lane0.alloc((size_t)G + 1) == AVS_OK &&
               pl->push_seg.alloc(seg.size()) == AVS_OK && pl->wg_halo.alloc((size_t)G) == AVS_OK && pl->bar_count.alloc(2) == AVS_OK &&
-              pl->bar_epoch.alloc(1) == AVS_OK && pl->slots.alloc((size_t)G * 4) == AVS_OK && pl->bcast.alloc(4 * kResGens) == AVS_OK;
+              pl->bar_flags.alloc((size_t)G) == AVS_OK && pl->slots.alloc((size_t)G * 4) == AVS_OK && pl->bcast.alloc(4 * kResGens) == AVS_OK;
     if (!up) return no("plan allocation failed");
     up = hipMemcpy(pl->lane_row0.p, lrow.data(), (size_t)L * 4, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(pl->lane_meta.p, lmeta.data(), (size_t)L * 4, hipMemcpyHostToDevice) == hipSuccess &&
@@ -892,7 +946,9 @@ static avs_status resident_run(ResidentPlan *pl, const CsrView &A, double *x, do
     a.dcode = dcode;
     a.invtab = invtab;
     a.bar_count = pl->bar_count.p;
-    a.bar_epoch = pl->bar_epoch.p;
+    a.bar_flags = pl->bar_flags.p;
+    a.dep_mask = pl->dep_mask.p;
+    a.n_push_wgs = pl->n_push_wgs > 0 ? pl->n_push_wgs : 1;
     a.slots = pl->slots.p;
     a.bcast = pl->bcast.p;
     a.sc = sc;
@@ -922,7 +978,7 @@ static avs_status resident_run(ResidentPlan *pl, const CsrView &A, double *x, do
             a.wg_times = pl->timers.p + (size_t)pl->max_timed * kResTimers;
         }
     AVS_HIP(hipMemsetAsync(pl->bar_count.p, 0, 2 * sizeof(unsigned), stream));
-    AVS_HIP(hipMemsetAsync(pl->bar_epoch.p, 0, sizeof(unsigned long long), stream));
+    AVS_HIP(hipMemsetAsync(pl->bar_flags.p, 0, (size_t)pl->G * sizeof(unsigned long long), stream));
     AVS_HIP(hipMemsetAsync(pl->slots.p, 0xFF, (size_t)pl->G * 4 * sizeof(double), stream));   // armed: kSentinel in every slot
     AVS_HIP(hipMemsetAsync(pl->bcast.p, 0xFF, 4 * kResGens * sizeof(double), stream));
     void *args[] = {&a};

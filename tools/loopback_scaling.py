@@ -40,17 +40,28 @@ for world in [int(w) for w in a.worlds.split(",")]:
         pp.apply(s)
         s.set_scene_fields(sc)
         capi.check(s.lib.avs_dist_init_hosted(s.h, r, world))
+        s.dist_assemble()                             # warm-up pass (first touch), then the timed one
+        torch.cuda.synchronize()
+        import time
+        t_as = time.perf_counter()
         s.dist_assemble()
+        torch.cuda.synchronize()
+        asm_ms = (time.perf_counter() - t_as) * 1e3
         capi.check(s.lib.avs_dist_import_blobs(s.h, None))
         s.dist_solve(1e-30, 64)                       # warm-up: graph capture, first touch
         info = s.dist_solve(1e-30, a.iters)           # never converges: exactly a.iters iterations
         sz = s.plan_sizes
         ranks.append({"rank": r, "n_own": int(sz.n_own), "n_halo": int(sz.n_halo), "n_send": int(sz.n_send), "n_peers": int(sz.n_peers),
                       "nnz_local": int(sz.nnz_local), "tiles": list(s.overlap_tiles), "us_per_iteration": info.solve_ms * 1e3 / max(info.iterations, 1),
-                      "spmv_us": info.spmv_ms * 1e3, "iterations": int(info.iterations)})
+                      "spmv_us": info.spmv_ms * 1e3, "iterations": int(info.iterations), "resident_loop": bool(info.resident),
+                      "dist_assemble_wall_ms": asm_ms})
         s.close()
     worst = max(x["us_per_iteration"] for x in ranks)
-    out["worlds"][world] = {"ranks": ranks, "max_us_per_iteration": worst, "projected_iter_per_s": 1e6 / worst}
+    # end to end for the headline solve (1271 iterations at tol 1e-3): replicated pre-pass + this rank's distributed assembly + iterations
+    pre_ms = pi.weights_ms + pi.octree_ms + pi.classify_ms + pi.number_ms
+    e2e = max(pre_ms + x["dist_assemble_wall_ms"] for x in ranks) + 1271 * worst * 1e-3
+    out["worlds"][world] = {"ranks": ranks, "max_us_per_iteration": worst, "projected_iter_per_s": 1e6 / worst,
+                            "prepass_ms_replicated": pre_ms, "projected_end_to_end_ms_1271_iterations": e2e}
 base = out["worlds"].get(1, {}).get("projected_iter_per_s")
 for w, v in out["worlds"].items():
     if base:
