@@ -78,6 +78,25 @@ struct ResidentArgs {
     long long *wg_times;                  // optional: G x 4 stamps of every workgroup in iteration 20 (start, update done, fill done, SpMV done)
 };
 
+// Loop-body reads of the kernel arguments go through these: one scalar load from the kernarg segment AT THE USE.  Left to itself the
+// compiler loads all ~40 fields of ResidentArgs at entry, keeps the ~25 the loop touches live across it, runs out of SGPRs and spills
+// them to VGPR lanes: 817 v_readlane restores in a 4,000-instruction iteration (20 % of the VALU issue slots of a VALU-bound loop).
+// (the struct is the kernel's only parameter: it sits at offset 0 of the kernarg segment)
+template <int OFF> __device__ __forceinline__ unsigned long long res_karg64()
+{
+    unsigned long long v;
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(OFF));
+    return v;
+}
+template <int OFF> __device__ __forceinline__ unsigned res_karg32()
+{
+    unsigned v;
+    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(OFF));
+    return v;
+}
+#define RES_P(f) (reinterpret_cast<decltype(ResidentArgs::f)>(res_karg64<(int)offsetof(ResidentArgs, f)>()))
+#define RES_I(f) ((int)res_karg32<(int)offsetof(ResidentArgs, f)>())
+
 __device__ __forceinline__ bool res_spin_u64(const unsigned long long *f, unsigned long long want, long long timeout)
 {
     if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
@@ -254,9 +273,9 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
     const int wrow0 = a.wg_row0[b], wrows = a.wg_row0[b + 1] - wrow0;
     const int lane = a.wg_lane0[b] + tid;
     const bool have = lane < a.wg_lane0[b + 1];
-    int row0 = 0, nrows = 0, tail = 0;
+    int row0_c = 0, nrows = 0, tail = 0;
     if (have) {
-        row0 = a.lane_row0[lane];
+        row0_c = a.lane_row0[lane];
         const uint32_t meta = a.lane_meta[lane];
         nrows = (int)(meta & 7u);
         tail = (int)(meta >> 10);
@@ -267,6 +286,7 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
     int nquads = 0;        // quads of the lane that hold words
     const unsigned padword = (unsigned)a.table_size << a.lc_bits; // code = table_size (the zero), column 0
     {
+        const int row0 = row0_c;
         int rcur = row0, off = 0; // row being laid out, words of it already placed
         int len = (have && nrows > 0) ? a.row_ptr[row0 + 1] - a.row_ptr[row0] : 0;
 #pragma unroll
@@ -303,7 +323,7 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
     unsigned dc[3] = {0u, 0u, 0u}; // diagonal codes of the lane's rows, two per register
 #pragma unroll
     for (int k = 0; k < kResRowsMax; ++k)
-        if (k < nrows) dc[k >> 1] |= (unsigned)a.dcode[row0 + k] << ((k & 1) * 16);
+        if (k < nrows) dc[k >> 1] |= (unsigned)a.dcode[row0_c + k] << ((k & 1) * 16);
     for (int i = tid; i < wrows; i += kResThreads) {
         u_l[i] = a.u[wrow0 + i];
         if (NG < 3) r_l[i] = a.r[wrow0 + i];
@@ -334,33 +354,42 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
     // sums are on their way, so that their latency hides behind the wait for the broadcast instead of opening the update phase
     // (x is not prefetched: nothing but its own store waits for it, and 12 more live registers push the matrix quads into scratch)
     double wk[kResRowsMax], sk[kResRowsMax];
-    auto prefetch = [&]() {
+    auto prefetch = [&](int row0) {
+        const double *const pw = RES_P(w), *const ps = NG >= 1 ? RES_P(s) : nullptr;
 #pragma unroll
         for (int k = 0; k < kResRowsMax; ++k)
             if (k < nrows) {
-                wk[k] = a.w[row0 + k];
-                if (NG >= 1) sk[k] = a.s[row0 + k];
+                wk[k] = pw[row0 + k];
+                if (NG >= 1) sk[k] = ps[row0 + k];
             }
     };
-    if (kResPrefetch) prefetch();
+    if (kResPrefetch) prefetch(row0_c);
+    const int max_iters = a.max_iters, max_timed = a.max_timed;
+    const bool timing = a.timers && b == 0 && tid == 0, stamps = a.wg_times && tid == 0;
     int it = 0;
-    for (; it < a.max_iters && !done; ++it) {
-        const bool timed = a.timers && b == 0 && tid == 0 && it < a.max_timed;
-        long long *ts = timed ? a.timers + (size_t)it * kResTimers : nullptr;
+    for (; it < max_iters && !done; ++it) {
+        const bool timed = timing && it < max_timed;
+        long long *ts = timed ? RES_P(timers) + (size_t)it * kResTimers : nullptr;
         if (timed) ts[0] = wall_clock64();
-        if (a.wg_times && tid == 0 && it == 20) a.wg_times[4 * b + 0] = wall_clock64();
+        if (stamps && it == 20) RES_P(wg_times)[4 * b + 0] = wall_clock64();
         const unsigned long long E = E0 + (unsigned long long)it + 1ull;
+        // (opaque per iteration: otherwise the 64-bit addresses of x, w, s for all six rows -- 36 registers -- are hoisted out of the
+        // loop and kept live through the SpMV walk, and the allocator parks the matrix quads in scratch instead)
+        int row0 = row0_c;
+        asm volatile("" : "+v"(row0));
         // ---- A: vector update of the lane's rows (k_sr_update_push's arithmetic), u to global, boundary entries to the peers ----
         double ru = 0., rr = 0.;
-        if (!kResPrefetch) prefetch();
+        if (!kResPrefetch) prefetch(row0);
         {
+            double *const gx = RES_P(x), *const gp = NG >= 2 ? RES_P(p) : nullptr, *const gr = NG >= 3 ? RES_P(r) : nullptr;
+            double *const gs = NG >= 1 ? RES_P(s) : nullptr;
             double xk[kResRowsMax], pk[kResRowsMax], rk2[kResRowsMax];
 #pragma unroll
             for (int k = 0; k < kResRowsMax; ++k)
                 if (k < nrows) {
-                    xk[k] = a.x[row0 + k];
-                    if (NG >= 2) pk[k] = a.p[row0 + k];
-                    if (NG >= 3) rk2[k] = a.r[row0 + k];
+                    xk[k] = gx[row0 + k];
+                    if (NG >= 2) pk[k] = gp[row0 + k];
+                    if (NG >= 3) rk2[k] = gr[row0 + k];
                 }
 #pragma unroll
             for (int k = 0; k < kResRowsMax; ++k)
@@ -368,13 +397,13 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
                     const int li = row0 + k - wrow0;
                     const double pi = u_l[li] + beta * (NG >= 2 ? pk[k] : p_l[li]);
                     const double si = wk[k] + beta * (NG >= 1 ? sk[k] : s_l[li]);
-                    if (NG >= 2) a.p[row0 + k] = pi;
+                    if (NG >= 2) gp[row0 + k] = pi;
                     else p_l[li] = pi;
-                    if (NG >= 1) a.s[row0 + k] = si;
+                    if (NG >= 1) gs[row0 + k] = si;
                     else s_l[li] = si;
-                    a.x[row0 + k] = xk[k] + alpha * pi;
+                    gx[row0 + k] = xk[k] + alpha * pi;
                     const double ri = (NG >= 3 ? rk2[k] : r_l[li]) - alpha * si;
-                    if (NG >= 3) a.r[row0 + k] = ri;
+                    if (NG >= 3) gr[row0 + k] = ri;
                     else r_l[li] = ri;
                     const double ui = itab[(dc[k >> 1] >> ((k & 1) * 16)) & 0xffffu] * ri;
                     u_l[li] = ui;
@@ -386,20 +415,22 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
         // u to global for the other workgroups: write-through (other XCDs read it), coalesced, 16 B per lane where the slice allows
         // (8-B sc1 stores cost 2.7x per byte, MI355X_MICROARCH.md)
         {
+            double *const gu = RES_P(u);
             const int head = (wrow0 & 1) && wrows > 0 ? 1 : 0; // 16-B alignment of the global address
-            if (tid == 0 && head) __hip_atomic_store(a.u + wrow0, u_l[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && head) __hip_atomic_store(gu + wrow0, u_l[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int pairs = (wrows - head) >> 1;
             for (int i = tid; i < pairs; i += kResThreads) {
                 d2_t v;
                 v.x = u_l[head + 2 * i];
                 v.y = u_l[head + 2 * i + 1];
-                res_store_wt16(a.u + wrow0 + head + 2 * i, v);
+                res_store_wt16(gu + wrow0 + head + 2 * i, v);
             }
-            if (tid == 0 && ((wrows - head) & 1)) __hip_atomic_store(a.u + wrow0 + wrows - 1, u_l[wrows - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && ((wrows - head) & 1)) __hip_atomic_store(gu + wrow0 + wrows - 1, u_l[wrows - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (dd && dd->npeers) {
+            const int32_t *const pseg = RES_P(push_seg);
             for (int i = 0; i < dd->npeers; ++i) {
-                const int sa = a.push_seg[i * (G + 1) + b], se = a.push_seg[i * (G + 1) + b + 1];
+                const int sa = pseg[i * (G + 1) + b], se = pseg[i * (G + 1) + b + 1];
                 double *dst = dd->peer_halo_dst[i] - dd->send_off[i];
                 for (int j = sa + tid; j < se; j += kResThreads)
                     __hip_atomic_store(dst + j, u_l[dd->send_idx[j] - wrow0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -407,7 +438,7 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
         }
         wait_own_stores(); // u (agent scope) and the peers' entries (system scope) acknowledged before this wave reaches the barrier
         if (timed) ts[1] = wall_clock64();
-        if (a.wg_times && tid == 0 && it == 20) a.wg_times[4 * b + 1] = wall_clock64();
+        if (stamps && it == 20) RES_P(wg_times)[4 * b + 1] = wall_clock64();
         // ---- B: no grid barrier here: a workgroup only needs the u entries of the workgroups it reads from (10-30 of 256: the
         // neighbours in the brick order).  It publishes "my update k is in memory" (one write-through flag, after its stores were
         // acknowledged) and polls the flags of its producers, one per thread.  The reduction at the end of the iteration is the
@@ -416,17 +447,17 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
         // of u from L1 / L2 ----
         __syncthreads();
         if (tid == 0) {
-            __hip_atomic_store(a.bar_flags + b, (unsigned long long)it + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(RES_P(bar_flags) + b, (unsigned long long)it + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (dd && pushes) { // (a monotone ticket, zeroed by the host before the launch: no reset to order)
-                const unsigned t = __hip_atomic_fetch_add(a.bar_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((t + 1u) % (unsigned)a.n_push_wgs == 0u)
+                const unsigned t = __hip_atomic_fetch_add(RES_P(bar_count), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((t + 1u) % (unsigned)RES_I(n_push_wgs) == 0u)
                     for (int i = 0; i < dd->npeers; ++i)
                         if (dd->send_off[i + 1] > dd->send_off[i]) st_sys(dd->peer_hflag_dst[i], E);
             }
         }
-        if (mydep && !res_spin_u64(a.bar_flags + tid, (unsigned long long)it + 1ull, timeout)) sh_fail = 1;
-        if (dd && a.wg_halo[b] && tid >= 960 && tid < 960 + dd->npeers && dd->recv_cnt[tid - 960] > 0)
-            if (!wait_flag(&dd->mine->hflag[dd->peer_rank[tid - 960]], E, timeout, a.sc, 1)) sh_fail = 1;
+        if (mydep && !res_spin_u64(RES_P(bar_flags) + tid, (unsigned long long)it + 1ull, timeout)) sh_fail = 1;
+        if (dd && RES_P(wg_halo)[b] && tid >= 960 && tid < 960 + dd->npeers && dd->recv_cnt[tid - 960] > 0)
+            if (!wait_flag(&dd->mine->hflag[dd->peer_rank[tid - 960]], E, timeout, RES_P(sc), 1)) sh_fail = 1;
         __syncthreads(); // every producer's u and the peers' halo entries are in memory
         if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // buffer_inv sc1: this CU's L1 and the XCD's L2 drop other writers' lines
         __syncthreads();
@@ -435,27 +466,30 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
         // ---- C: w = A u for the lane's rows.  First the workgroup's remote columns -> LDS, ONE round trip for all of them (plain loads
         // of the global u: this CU's L1 / the XCD's L2 were invalidated behind the barrier; other ranks' entries: the halo area of the
         // comm block, fine-grained memory first touched after the flag); then every gather is an LDS read.
-        for (int k0 = tid; k0 < nrem; k0 += 8 * kResThreads) { // eight loads in flight per lane: a halo-reading workgroup fills 8-10 k slots
-            double v[8];
+        const double *const fu = RES_P(u);
+        const int fn = RES_I(n);
+        for (int k0 = tid; k0 < nrem; k0 += 4 * kResThreads) { // four loads in flight per lane: a halo-reading workgroup fills 8-10 k slots
+            double v[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 4; ++j) {
                 const int k = k0 + j * kResThreads;
                 if (k < nrem) {
                     const int src = rem[k];
-                    v[j] = (src < a.n) ? a.u[src] : halo[src - a.n];
+                    v[j] = (src < fn) ? fu[src] : halo[src - fn];
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 4; ++j) {
                 const int k = k0 + j * kResThreads;
                 if (k < nrem) u_l[wrows + k] = v[j];
             }
         }
         __syncthreads();
         if (timed) ts[3] = wall_clock64();
-        if (a.wg_times && tid == 0 && it == 20) a.wg_times[4 * b + 2] = wall_clock64();
+        if (stamps && it == 20) RES_P(wg_times)[4 * b + 2] = wall_clock64();
         double wu = 0.;
         {
+            double *const gw = RES_P(w);
             double acc = 0.;
             int rk = 0; // row of the lane being summed
             unsigned em = endmask;
@@ -471,35 +505,46 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
                     asm volatile("" : "+v"(mm));
                     // five 25-bit words at bit offsets 0, 25, 50, 75, 100 of the quad: column = low lc_bits, code = the bits above (bit-field
                     // extracts straight from the shifted dwords: no intermediate 25-bit mask)
-                    const unsigned t1 = __builtin_amdgcn_alignbit(mm.y, mm.x, 25);
-                    const unsigned t2 = __builtin_amdgcn_alignbit(mm.z, mm.y, 18);
-                    const unsigned t3 = __builtin_amdgcn_alignbit(mm.w, mm.z, 11);
                     const unsigned kb = (unsigned)(kResWordBits - cbits);
-                    const double v0 = tbl[__builtin_amdgcn_ubfe(mm.x, (unsigned)cbits, kb)], x0 = u_l[mm.x & cmask];
-                    const double v1 = tbl[__builtin_amdgcn_ubfe(t1, (unsigned)cbits, kb)], x1 = u_l[t1 & cmask];
-                    const double v2 = tbl[__builtin_amdgcn_ubfe(t2, (unsigned)cbits, kb)], x2 = u_l[t2 & cmask];
-                    const double v3 = tbl[__builtin_amdgcn_ubfe(t3, (unsigned)cbits, kb)], x3 = u_l[t3 & cmask];
-                    const double v4 = tbl[__builtin_amdgcn_ubfe(mm.w, 4u + (unsigned)cbits, kb)], x4 = u_l[__builtin_amdgcn_ubfe(mm.w, 4u, (unsigned)cbits)];
-                    acc += v0 * x0; // left to right inside the row: the oracle's order (padding words add +0)
-                    acc += v1 * x1;
-                    acc += v2 * x2;
-                    acc += v3 * x3;
-                    acc += v4 * x4;
+                    { // words 0, 1 (three groups with scheduling barriers between them: ten reads in flight at once need 20 more
+                      // registers than the file has next to the 60 of the matrix, and the allocator then parks the MATRIX in scratch)
+                        const unsigned t1 = __builtin_amdgcn_alignbit(mm.y, mm.x, 25);
+                        const double v0 = tbl[__builtin_amdgcn_ubfe(mm.x, (unsigned)cbits, kb)], x0 = u_l[mm.x & cmask];
+                        const double v1 = tbl[__builtin_amdgcn_ubfe(t1, (unsigned)cbits, kb)], x1 = u_l[t1 & cmask];
+                        acc = __builtin_fma(v0, x0, acc); // left to right inside the row: the oracle's order (padding words add +0)
+                        acc = __builtin_fma(v1, x1, acc);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    { // words 2, 3
+                        const unsigned t2 = __builtin_amdgcn_alignbit(mm.z, mm.y, 18);
+                        const unsigned t3 = __builtin_amdgcn_alignbit(mm.w, mm.z, 11);
+                        const double v2 = tbl[__builtin_amdgcn_ubfe(t2, (unsigned)cbits, kb)], x2 = u_l[t2 & cmask];
+                        const double v3 = tbl[__builtin_amdgcn_ubfe(t3, (unsigned)cbits, kb)], x3 = u_l[t3 & cmask];
+                        acc = __builtin_fma(v2, x2, acc);
+                        acc = __builtin_fma(v3, x3, acc);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    { // word 4
+                        const double v4 = tbl[__builtin_amdgcn_ubfe(mm.w, 4u + (unsigned)cbits, kb)], x4 = u_l[__builtin_amdgcn_ubfe(mm.w, 4u, (unsigned)cbits)];
+                        acc = __builtin_fma(v4, x4, acc);
+                    }
                     if ((em >> q) & 1u) {
-                        a.w[row0 + rk] = acc;
+                        gw[row0 + rk] = acc;
                         wu += acc * u_l[row0 + rk - wrow0];
                         acc = 0.;
                         ++rk;
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0); // keep the scheduler from hoisting later quads' reads: their live ranges push the matrix to scratch
             }
             if (tail > 0) { // a row of more words than the registers hold (a coarse face ringed by fine ones; a handful per scene)
-                const int kt = a.row_ptr[row0] + a.max_quads * kResQuadWords;
+                const int kt = RES_P(row_ptr)[row0] + RES_I(max_quads) * kResQuadWords;
+                const uint32_t *const twords = RES_P(rwords);
                 for (int k = kt; k < kt + tail; ++k) {
-                    const uint32_t wd = a.rwords[k];
+                    const uint32_t wd = twords[k];
                     acc += tbl[wd >> cbits] * u_l[wd & cmask];
                 }
-                a.w[row0] = acc;
+                gw[row0] = acc;
                 wu += acc * u_l[row0 - wrow0];
             }
         }
@@ -509,26 +554,28 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
         double s0 = ru, s1 = rr, s2 = wu;
         res_block_fold3(s0, s1, s2, fold);
         if (tid == 0) {
-            __hip_atomic_store(a.slots + 4 * b + 0, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.slots + 4 * b + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.slots + 4 * b + 2, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double *const sl = RES_P(slots) + 4 * b;
+            __hip_atomic_store(sl + 0, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sl + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sl + 2, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (kResPrefetch) prefetch(); // (w was stored by this very lane above; s in the previous update)
+        if (kResPrefetch) prefetch(row0); // (w was stored by this very lane above; s in the previous update)
         if (timed) ts[4] = wall_clock64();
-        if (a.wg_times && tid == 0 && it == 20) { // every workgroup's own phase stamps of one iteration (imbalance diagnostics)
-            a.wg_times[4 * b + 3] = wall_clock64();
+        if (stamps && it == 20) { // every workgroup's own phase stamps of one iteration (imbalance diagnostics)
+            RES_P(wg_times)[4 * b + 3] = wall_clock64();
         }
         const int gen = it & (kResGens - 1);
         if (b == 0) {
             double v0 = 0., v1 = 0., v2 = 0.;
             if (tid < G) {
-                bool ok = res_take_slot(a.slots + 4 * tid + 0, timeout, &v0);
-                ok = res_take_slot(a.slots + 4 * tid + 1, timeout, &v1) && ok;
-                ok = res_take_slot(a.slots + 4 * tid + 2, timeout, &v2) && ok;
+                double *const sl = RES_P(slots) + 4 * tid;
+                bool ok = res_take_slot(sl + 0, timeout, &v0);
+                ok = res_take_slot(sl + 1, timeout, &v1) && ok;
+                ok = res_take_slot(sl + 2, timeout, &v2) && ok;
                 if (!ok) sh_fail = 1;
                 // re-arm (the next values come after the next grid barrier, which this thread reaches with its stores acknowledged)
                 for (int k = 0; k < 3; ++k)
-                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.slots + 4 * tid + k), kSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(sl + k), kSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             res_block_fold3(v0, v1, v2, fold);
             if (tid == 0) { bc[0] = v0; bc[1] = v1; bc[2] = v2; bc[3] = 0.; }
@@ -546,7 +593,7 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
                         const long long tw = wall_clock64();
                         while ((v = ld_sys(src)) == kSentinel) {
                             if (wall_clock64() - tw > timeout) {
-                                __hip_atomic_store(&a.sc->fault, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(&RES_P(sc)->fault, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 sh_fail = 1;
                                 v = 0ull;
                                 break;
@@ -581,26 +628,28 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
                     niter = iter + 1;
                 }
                 // the ring: re-arm the generation two iterations ahead, publish this one
-                double *ahead = a.bcast + 4 * ((it + 2) & (kResGens - 1)), *me = a.bcast + 4 * gen;
+                double *const ring = RES_P(bcast);
+                double *ahead = ring + 4 * ((it + 2) & (kResGens - 1)), *me = ring + 4 * gen;
                 for (int k = 0; k < 4; ++k)
                     __hip_atomic_store(reinterpret_cast<unsigned long long *>(ahead + k), kSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(me + 0, na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(me + 1, nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(me + 2, nrho, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(me + 3, (double)(nd * 1048576 + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // done | 1 (never the sentinel)
-                if (a.timers && it < a.max_timed) { // debug record (AVS_CG_RESIDENT_TIMERS): the sums this step was taken from
-                    a.timers[(size_t)it * kResTimers + 6] = __double_as_longlong(rr_all);
-                    a.timers[(size_t)it * kResTimers + 7] = __double_as_longlong(delta - (gamma / rho) * gamma / alpha);
+                if (timed) { // debug record (AVS_CG_RESIDENT_TIMERS): the sums this step was taken from
+                    ts[6] = __double_as_longlong(rr_all);
+                    ts[7] = __double_as_longlong(delta - (gamma / rho) * gamma / alpha);
                 }
                 // the host's copy of the state (always written by this one thread: plain stores)
-                a.sc->red[0] = gamma; a.sc->red[1] = rr_all; a.sc->red[2] = delta;
-                a.sc->rr = rr_all; a.sc->alpha = na; a.sc->beta = nb; a.sc->rho = nrho; a.sc->iter = niter; a.sc->done = nd;
-                if (sh_fail && !a.sc->fault) a.sc->fault = 3;
+                PcgScalars *const hs = RES_P(sc);
+                hs->red[0] = gamma; hs->red[1] = rr_all; hs->red[2] = delta;
+                hs->rr = rr_all; hs->alpha = na; hs->beta = nb; hs->rho = nrho; hs->iter = niter; hs->done = nd;
+                if (sh_fail && !hs->fault) hs->fault = 3;
             }
         }
         // everybody (the publisher included) picks the step up from the ring
         if (tid < 4)
-            if (!res_take_slot(a.bcast + 4 * gen + tid, timeout, &bc[4 + tid])) sh_fail = 1;
+            if (!res_take_slot(RES_P(bcast) + 4 * gen + tid, timeout, &bc[4 + tid])) sh_fail = 1;
         __syncthreads();
         if (sh_fail) break;
         const int nd = (int)bc[7] >> 20;
