@@ -27,10 +27,14 @@ static constexpr int kResQuads = 15;     // 128-bit register quads of matrix wor
 static constexpr int kResQuadWords = 5;  // 25-bit words per quad; a row takes ceil(len / 5) consecutive quads of ONE lane
 static constexpr int kResRowsMax = 6;    // rows per lane
 static constexpr int kResWordBits = 25;  // value code | workgroup-local column
-#ifndef AVS_RES_PREFETCH
-#define AVS_RES_PREFETCH 0
+#ifndef AVS_RES_UPD
+#define AVS_RES_UPD 4
 #endif
-static constexpr bool kResPrefetch = AVS_RES_PREFETCH != 0; // request w (and s) for the next update during the reduction: measured neutral
+#ifndef AVS_RES_FILL
+#define AVS_RES_FILL 4
+#endif
+static constexpr int kResFill = AVS_RES_FILL; // remote columns per thread in flight in the cache fill
+static constexpr int kResUpd = AVS_RES_UPD; // rows per thread in flight in the vector update
                                                             // (update 10.3 -> 8.5 us, SpMV 12.1 -> 13.0 us: the live registers push matrix quads to scratch), off
 static constexpr int kResTimers = 8;   // phase time stamps per iteration (AVS_CG_RESIDENT_TIMERS=n)
 static constexpr int kResGens = 4;     // generations of the broadcast slots (a ring: re-armed two iterations ahead)
@@ -75,6 +79,7 @@ struct ResidentArgs {
     const int32_t *push_seg;              // npeers x (G + 1): segments of send_idx per workgroup
     long long *timers;                    // optional: max_timed x kResTimers wall-clock stamps of workgroup 0
     int max_timed;
+    int coherent_fill;                    // 1: the remote columns are read with agent / system scope loads and L2 is NOT invalidated (see phase B)
     long long *wg_times;                  // optional: G x 4 stamps of every workgroup in iteration 20 (start, update done, fill done, SpMV done)
 };
 
@@ -112,6 +117,11 @@ __device__ __forceinline__ bool res_spin_u64(const unsigned long long *f, unsign
 __device__ __forceinline__ void res_store_wt16(double *p, d2_t v)
 {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+// the same at system scope (sc0 sc1): boundary entries into a peer's halo area
+__device__ __forceinline__ void res_store_sys16(double *p, d2_t v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
 }
 // a sentinel-armed slot: spin until it holds a value (false: timed out)
 __device__ __forceinline__ bool res_take_slot(const double *slot, long long timeout, double *out)
@@ -320,10 +330,6 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
         wave_nq = other > wave_nq ? other : wave_nq;
     }
     wave_nq = __builtin_amdgcn_readfirstlane(wave_nq);
-    unsigned dc[3] = {0u, 0u, 0u}; // diagonal codes of the lane's rows, two per register
-#pragma unroll
-    for (int k = 0; k < kResRowsMax; ++k)
-        if (k < nrows) dc[k >> 1] |= (unsigned)a.dcode[row0_c + k] << ((k & 1) * 16);
     for (int i = tid; i < wrows; i += kResThreads) {
         u_l[i] = a.u[wrow0 + i];
         if (NG < 3) r_l[i] = a.r[wrow0 + i];
@@ -350,21 +356,8 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
     int done = a.sc->done, iter = a.sc->iter;
     double rho = a.sc->rho;
     const double threshold = a.sc->threshold;
-    // x, w (and s when it lives in global memory) of the lane's rows for the NEXT update: requested as soon as this iteration's
-    // sums are on their way, so that their latency hides behind the wait for the broadcast instead of opening the update phase
-    // (x is not prefetched: nothing but its own store waits for it, and 12 more live registers push the matrix quads into scratch)
-    double wk[kResRowsMax], sk[kResRowsMax];
-    auto prefetch = [&](int row0) {
-        const double *const pw = RES_P(w), *const ps = NG >= 1 ? RES_P(s) : nullptr;
-#pragma unroll
-        for (int k = 0; k < kResRowsMax; ++k)
-            if (k < nrows) {
-                wk[k] = pw[row0 + k];
-                if (NG >= 1) sk[k] = ps[row0 + k];
-            }
-    };
-    if (kResPrefetch) prefetch(row0_c);
     const int max_iters = a.max_iters, max_timed = a.max_timed;
+    const bool coherent = a.coherent_fill != 0;
     const bool timing = a.timers && b == 0 && tid == 0, stamps = a.wg_times && tid == 0;
     int it = 0;
     for (; it < max_iters && !done; ++it) {
@@ -377,39 +370,52 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
         // loop and kept live through the SpMV walk, and the allocator parks the matrix quads in scratch instead)
         int row0 = row0_c;
         asm volatile("" : "+v"(row0));
-        // ---- A: vector update of the lane's rows (k_sr_update_push's arithmetic), u to global, boundary entries to the peers ----
+        // ---- A: vector update of the workgroup's rows (k_sr_update_push's arithmetic), u to global, boundary entries to the peers.
+        // Row i of the slice belongs to thread i mod 1024 HERE (not to the lane that sums it in the SpMV): the vectors in LDS do not
+        // care, and the ones in global memory (x, w, and the tiers) are read and written as whole 512-B runs per wave instead of
+        // 8 B every ~32 B (the lane-owned order cost the L1 four times the tag look-ups: the update was 11 us of a 40 us iteration) ----
         double ru = 0., rr = 0.;
-        if (!kResPrefetch) prefetch(row0);
         {
-            double *const gx = RES_P(x), *const gp = NG >= 2 ? RES_P(p) : nullptr, *const gr = NG >= 3 ? RES_P(r) : nullptr;
-            double *const gs = NG >= 1 ? RES_P(s) : nullptr;
-            double xk[kResRowsMax], pk[kResRowsMax], rk2[kResRowsMax];
+            double *const gx = RES_P(x) + wrow0, *const gp = NG >= 2 ? RES_P(p) + wrow0 : nullptr, *const gr = NG >= 3 ? RES_P(r) + wrow0 : nullptr;
+            double *const gs = NG >= 1 ? RES_P(s) + wrow0 : nullptr;
+            const double *const gw = RES_P(w) + wrow0;
+            const uint16_t *const gd = RES_P(dcode) + wrow0;
+            for (int i0 = tid; i0 < wrows; i0 += kResUpd * kResThreads) {
+                double xv[kResUpd], wv[kResUpd], sv[kResUpd], pv[kResUpd], rv[kResUpd];
+                unsigned dv[kResUpd];
 #pragma unroll
-            for (int k = 0; k < kResRowsMax; ++k)
-                if (k < nrows) {
-                    xk[k] = gx[row0 + k];
-                    if (NG >= 2) pk[k] = gp[row0 + k];
-                    if (NG >= 3) rk2[k] = gr[row0 + k];
+                for (int j = 0; j < kResUpd; ++j) {
+                    const int i = i0 + j * kResThreads;
+                    if (i < wrows) {
+                        xv[j] = gx[i];
+                        wv[j] = gw[i];
+                        dv[j] = gd[i];
+                        if (NG >= 1) sv[j] = gs[i];
+                        if (NG >= 2) pv[j] = gp[i];
+                        if (NG >= 3) rv[j] = gr[i];
+                    }
                 }
 #pragma unroll
-            for (int k = 0; k < kResRowsMax; ++k)
-                if (k < nrows) {
-                    const int li = row0 + k - wrow0;
-                    const double pi = u_l[li] + beta * (NG >= 2 ? pk[k] : p_l[li]);
-                    const double si = wk[k] + beta * (NG >= 1 ? sk[k] : s_l[li]);
-                    if (NG >= 2) gp[row0 + k] = pi;
-                    else p_l[li] = pi;
-                    if (NG >= 1) gs[row0 + k] = si;
-                    else s_l[li] = si;
-                    gx[row0 + k] = xk[k] + alpha * pi;
-                    const double ri = (NG >= 3 ? rk2[k] : r_l[li]) - alpha * si;
-                    if (NG >= 3) gr[row0 + k] = ri;
-                    else r_l[li] = ri;
-                    const double ui = itab[(dc[k >> 1] >> ((k & 1) * 16)) & 0xffffu] * ri;
-                    u_l[li] = ui;
-                    ru += ri * ui;
-                    rr += ri * ri;
+                for (int j = 0; j < kResUpd; ++j) {
+                    const int i = i0 + j * kResThreads;
+                    if (i < wrows) {
+                        const double pi = u_l[i] + beta * (NG >= 2 ? pv[j] : p_l[i]);
+                        const double si = wv[j] + beta * (NG >= 1 ? sv[j] : s_l[i]);
+                        if (NG >= 2) gp[i] = pi;
+                        else p_l[i] = pi;
+                        if (NG >= 1) gs[i] = si;
+                        else s_l[i] = si;
+                        gx[i] = xv[j] + alpha * pi;
+                        const double ri = (NG >= 3 ? rv[j] : r_l[i]) - alpha * si;
+                        if (NG >= 3) gr[i] = ri;
+                        else r_l[i] = ri;
+                        const double ui = itab[dv[j]] * ri;
+                        u_l[i] = ui;
+                        ru += ri * ui;
+                        rr += ri * ri;
+                    }
                 }
+            }
         }
         __syncthreads(); // the workgroup's u is complete in LDS
         // u to global for the other workgroups: write-through (other XCDs read it), coalesced, 16 B per lane where the slice allows
@@ -432,8 +438,20 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
             for (int i = 0; i < dd->npeers; ++i) {
                 const int sa = pseg[i * (G + 1) + b], se = pseg[i * (G + 1) + b + 1];
                 double *dst = dd->peer_halo_dst[i] - dd->send_off[i];
-                for (int j = sa + tid; j < se; j += kResThreads)
-                    __hip_atomic_store(dst + j, u_l[dd->send_idx[j] - wrow0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const int32_t *const sidx = dd->send_idx;
+                // consecutive entries of the peer's halo area: two per fabric write where the address allows (an 8-B write-through store
+                // costs 2.7x per byte, MI355X_MICROARCH.md); the flag that orders them is raised after wait_own_stores()
+                const int head = (sa < se && (reinterpret_cast<uintptr_t>(dst + sa) & 15u)) ? 1 : 0;
+                if (tid == 0 && head) __hip_atomic_store(dst + sa, u_l[sidx[sa] - wrow0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const int pairs = (se - sa - head) >> 1;
+                for (int q = tid; q < pairs; q += kResThreads) {
+                    const int j = sa + head + 2 * q;
+                    d2_t v;
+                    v.x = u_l[sidx[j] - wrow0];
+                    v.y = u_l[sidx[j + 1] - wrow0];
+                    res_store_sys16(dst + j, v);
+                }
+                if (tid == 0 && ((se - sa - head) & 1)) __hip_atomic_store(dst + se - 1, u_l[sidx[se - 1] - wrow0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
         wait_own_stores(); // u (agent scope) and the peers' entries (system scope) acknowledged before this wave reaches the barrier
@@ -459,8 +477,10 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
         if (dd && RES_P(wg_halo)[b] && tid >= 960 && tid < 960 + dd->npeers && dd->recv_cnt[tid - 960] > 0)
             if (!wait_flag(&dd->mine->hflag[dd->peer_rank[tid - 960]], E, timeout, RES_P(sc), 1)) sh_fail = 1;
         __syncthreads(); // every producer's u and the peers' halo entries are in memory
-        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // buffer_inv sc1: this CU's L1 and the XCD's L2 drop other writers' lines
-        __syncthreads();
+        if (!coherent) {
+            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // buffer_inv sc1: this CU's L1 and the XCD's L2 drop other writers' lines
+            __syncthreads();
+        }
         if (sh_fail) break; // (block-uniform)
         if (timed) ts[2] = wall_clock64();
         // ---- C: w = A u for the lane's rows.  First the workgroup's remote columns -> LDS, ONE round trip for all of them (plain loads
@@ -468,18 +488,20 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
         // comm block, fine-grained memory first touched after the flag); then every gather is an LDS read.
         const double *const fu = RES_P(u);
         const int fn = RES_I(n);
-        for (int k0 = tid; k0 < nrem; k0 += 4 * kResThreads) { // four loads in flight per lane: a halo-reading workgroup fills 8-10 k slots
-            double v[4];
+        for (int k0 = tid; k0 < nrem; k0 += kResFill * kResThreads) { // kResFill loads in flight per lane: a halo-reading workgroup fills 8-10 k slots
+            double v[kResFill];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < kResFill; ++j) {
                 const int k = k0 + j * kResThreads;
                 if (k < nrem) {
                     const int src = rem[k];
-                    v[j] = (src < fn) ? fu[src] : halo[src - fn];
+                    if (!coherent) v[j] = (src < fn) ? fu[src] : halo[src - fn];
+                    else if (src < fn) v[j] = __hip_atomic_load(fu + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else v[j] = __hip_atomic_load(halo + (src - fn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < kResFill; ++j) {
                 const int k = k0 + j * kResThreads;
                 if (k < nrem) u_l[wrows + k] = v[j];
             }
@@ -559,7 +581,6 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
             __hip_atomic_store(sl + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(sl + 2, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (kResPrefetch) prefetch(row0); // (w was stored by this very lane above; s in the previous update)
         if (timed) ts[4] = wall_clock64();
         if (stamps && it == 20) { // every workgroup's own phase stamps of one iteration (imbalance diagnostics)
             RES_P(wg_times)[4 * b + 3] = wall_clock64();
@@ -1017,6 +1038,7 @@ static avs_status resident_run(ResidentPlan *pl, const CsrView &A, double *x, do
     a.push_seg = pl->push_seg.p;
     a.timers = nullptr;
     a.max_timed = 0;
+    a.coherent_fill = getenv("AVS_CG_RESIDENT_COHERENT_FILL") ? atoi(getenv("AVS_CG_RESIDENT_COHERENT_FILL")) : 1;
     if (const char *e = getenv("AVS_CG_RESIDENT_TIMERS"))
         if (atoi(e) > 0) {
             pl->max_timed = atoi(e) > 4096 ? 4096 : atoi(e);

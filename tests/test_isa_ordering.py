@@ -26,7 +26,7 @@ def test_code_objects_are_gfx950_only():
 def test_halo_stores_are_acknowledged_before_ticket_and_flag():
     rows = isa_check.run_checks()
     names = " ".join(k for k, _, _ in rows)
-    for must in ("avs::k_push(", "avs::k_sr_update_push<", "avs::k_reduce_mb(", "k_spmv_vi2<", "k_spmv_tile<"):
+    for must in ("avs::k_push(", "avs::k_sr_update_push<", "avs::k_reduce_mb(", "k_spmv_vi2<", "k_spmv_tile<", "avs::k_cg_resident<"):
         assert must in names, f"{must} not covered"
     bad = [(k, m) for k, ok, m in rows if not ok]
     assert not bad, bad

@@ -87,6 +87,11 @@ def is_agent_store(ins: str) -> bool:
     return bool(re.match(r"^(flat|global)_store_dword", ins)) and " sc1" in ins
 
 
+def is_wide_wt_store(ins: str) -> bool:
+    """The resident loop's 16-B write-through stores: the workgroup's slice of u (sc1) and the boundary entries it pushes (sc0 sc1)."""
+    return bool(re.match(r"^global_store_dwordx4", ins)) and " sc1" in ins
+
+
 def waits_vmcnt0(ins: str) -> bool:
     return ins.startswith("s_waitcnt") and re.search(r"vmcnt\(0\)", ins) is not None
 
@@ -153,6 +158,8 @@ CHECKS = [
     ("k_push", r"^avs::k_push\(", is_remote_store, SYNC),
     ("k_sr_update_push", r"^(void )?avs::k_sr_update_push", is_remote_store, SYNC),
     ("k_reduce_mb", r"^avs::k_reduce_mb\(", is_agent_store, r"^(global|flat)_atomic_add\s"),
+    # CU-resident loop: u slice + pushed entries acknowledged before the barrier behind which the producer flag / the ticket is raised
+    ("k_cg_resident", r"^(void )?avs::k_cg_resident<", is_wide_wt_store, SYNC),
 ]
 
 if __name__ == "__main__":
