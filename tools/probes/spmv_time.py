@@ -1,9 +1,11 @@
+"""Default SpMV of the 512^3 beam, timed by avs_bench_spmv (which also checks y against the plain CSR kernel bit for bit)."""
 import sys, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from adaptiveviscositysolver_amd import DevicePrepass, ViscositySolve, scenes
 dev = torch.device("cuda:0")
-sc = scenes.fat_beam(512, 4, device=dev)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+sc = scenes.fat_beam(n, 4, device=dev)
 pp = DevicePrepass(sc.res, sc.dx, sc.levels); pi = pp.run(sc.liquid, sc.solid)
 s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels); pp.apply(s); s.set_scene_fields(sc); pp.close(); s.assemble()
 for r in range(3): print("default SpMV us:", s.bench_spmv(0, 200) * 1e3)
