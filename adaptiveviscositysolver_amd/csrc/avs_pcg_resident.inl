@@ -34,6 +34,14 @@ static constexpr int kResWordBits = 25;  // value code | workgroup-local column
 #define AVS_RES_FILL 4
 #endif
 static constexpr int kResFill = AVS_RES_FILL; // remote columns per thread in flight in the cache fill
+#ifndef AVS_RES_STREAM_DB
+#define AVS_RES_STREAM_DB 0
+#endif
+#ifndef AVS_RES_STREAM
+#define AVS_RES_STREAM 2
+#endif
+static constexpr int kResStream = AVS_RES_STREAM; // streamed quads per batch (AVS_RES_STREAM_DB: the next batch in flight while this one is multiplied --
+                                                  // measured on the 4-way partition: 2 / 4 per batch, with and without: 73.8-76.2 us, all within noise)
 static constexpr int kResUpd = AVS_RES_UPD; // rows per thread in flight in the vector update
                                                             // (update 10.3 -> 8.5 us, SpMV 12.1 -> 13.0 us: the live registers push matrix quads to scratch), off
 static constexpr int kResTimers = 8;   // phase time stamps per iteration (AVS_CG_RESIDENT_TIMERS=n)
@@ -48,11 +56,17 @@ struct ResidentArgs {
     int G;     // workgroups (= CUs used)
     // lane plan
     const int32_t *lane_row0;
-    const uint32_t *lane_meta;            // rows (3 bits) | words of a long row left in memory (bits 10..31)
+    const uint32_t *lane_meta;            // register rows (3 bits) | streamed rows (bits 3..9) | words of a long row left in memory (bits 10..31)
     const int32_t *wg_lane0, *wg_row0;    // G + 1 entries each
     // workgroup-local re-encoding of the words (k_resident_remap): code << lc_bits | local column; local column < rows of the
     // workgroup = one of its own rows (LDS slice of u), >= : slot of the workgroup's remote-column cache behind the slice
     const uint32_t *rwords;
+    // STREAMED rows (a slab larger than the register files: the 4-way partition): after its register rows a lane owns `m` more
+    // consecutive rows (lane_meta bits 3..9) whose quads stay in memory -- same 5 x 25-bit quads, a row = whole quads, bit 127 = the
+    // row's last quad -- laid out per wave lane-interleaved (quad j of lane l at swords[16 B x (wave_soff[wave] + 64 j + l)]: one
+    // 1-KiB run per wave load), padded to the wave's longest lane with quads of zero words
+    const uint32_t *swords;
+    const int32_t *wave_soff;             // G x 16 + 1, in quads
     int lc_bits;
     int max_quads;                        // quads a lane uses (kResQuads; tests lower it to send ordinary rows down the long-row path)
     const int32_t *rem_list;              // G x rem_stride: source of every remote slot (< n: global u, >= n: the halo area)
@@ -101,6 +115,11 @@ template <int OFF> __device__ __forceinline__ unsigned res_karg32()
 }
 #define RES_P(f) (reinterpret_cast<decltype(ResidentArgs::f)>(res_karg64<(int)offsetof(ResidentArgs, f)>()))
 #define RES_I(f) ((int)res_karg32<(int)offsetof(ResidentArgs, f)>())
+// The same pointer, typed as GLOBAL memory.  The value comes out of an asm statement, so the compiler only knows a generic pointer and
+// emits flat_load / flat_store -- which tick the LDS counter (lgkmcnt) as well as vmcnt: every LDS wait then also waits for the
+// outstanding global loads, and nothing can be kept in flight across LDS work (the streamed quads, the update's x / w / s loads).
+template <class T> using res_gptr = T __attribute__((address_space(1))) *;
+#define RES_G(f) (reinterpret_cast<res_gptr<std::remove_pointer_t<decltype(ResidentArgs::f)>>>(res_karg64<(int)offsetof(ResidentArgs, f)>()))
 
 __device__ __forceinline__ bool res_spin_u64(const unsigned long long *f, unsigned long long want, long long timeout)
 {
@@ -170,86 +189,134 @@ __device__ __forceinline__ void res_block_fold3(double &v0, double &v1, double &
 // the per-iteration fill of the cache reads ascending addresses (runs of neighbouring entries coalesce; a hash order cost 10 us
 // per iteration on the workgroups that read 8 k halo entries) and the numbering is deterministic.
 static constexpr int kRemapBlock = 16; // bitmap words per prefix block
+static constexpr int kRemapChunk = 1 << 20; // columns per bitmap pass (128 KiB of LDS + 8 KiB of block prefixes): larger slabs take several passes
 __global__ __launch_bounds__(kResThreads) void k_resident_remap(const uint32_t *__restrict__ packed, const int32_t *__restrict__ row_ptr, int col_bits,
                                                                 int lc_bits, const int32_t *__restrict__ wg_row0, int rem_cap, int n_ext,
                                                                 uint32_t *__restrict__ rwords, int32_t *__restrict__ rem_list,
                                                                 int32_t *__restrict__ rem_count, int *__restrict__ fail, int n_own,
-                                                                unsigned *__restrict__ dep_mask)
+                                                                unsigned *__restrict__ dep_mask, int chunk)
 {
-    extern __shared__ unsigned bm[]; // bitmap[nw], prefix[nb + 1]
+    extern __shared__ unsigned bm[]; // bitmap[nw], prefix[nb + 1] of ONE chunk of columns
     __shared__ unsigned deps[32];    // bit g: a remote column of this workgroup belongs to workgroup g (G <= 1024)
-    const int nw = (n_ext + 31) >> 5, nb = (nw + kRemapBlock - 1) / kRemapBlock;
-    unsigned *prefix = bm + nb * kRemapBlock;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int r0 = wg_row0[b], r1 = wg_row0[b + 1];
     const int k0 = row_ptr[r0], k1 = row_ptr[r1];
     const unsigned cmask = (1u << col_bits) - 1u;
-    for (int i = tid; i < nb * kRemapBlock; i += kResThreads) bm[i] = 0u;
+    const int wrows = r1 - r0;
     if (tid < 32) deps[tid] = 0u;
-    __syncthreads();
-    for (int k = k0 + tid; k < k1; k += kResThreads) {
-        const int col = (int)(packed[k] & cmask);
-        if ((col < r0 || col >= r1) && col < n_ext) atomicOr(&bm[col >> 5], 1u << (col & 31));
-    }
-    __syncthreads();
-    for (int i = tid; i < nb; i += kResThreads) {
-        unsigned c = 0u;
-#pragma unroll
-        for (int w = 0; w < kRemapBlock; ++w) c += (unsigned)__popc(bm[i * kRemapBlock + w]);
-        prefix[i + 1] = c;
-    }
-    __syncthreads();
-    if (tid == 0) { // exclusive scan over a few thousand block counts
-        unsigned run = 0u;
-        prefix[0] = 0u;
-        for (int i = 1; i <= nb; ++i) {
-            run += prefix[i];
-            prefix[i] = run;
+    int base = 0; // remote slots handed out by the chunks below this one (ascending columns overall)
+    for (int c0 = 0; c0 < n_ext; c0 += chunk) {
+        const int c1 = (c0 + chunk < n_ext) ? c0 + chunk : n_ext;
+        const int nw = (c1 - c0 + 31) >> 5, nb = (nw + kRemapBlock - 1) / kRemapBlock;
+        unsigned *prefix = bm + nb * kRemapBlock;
+        for (int i = tid; i < nb * kRemapBlock; i += kResThreads) bm[i] = 0u;
+        __syncthreads();
+        for (int k = k0 + tid; k < k1; k += kResThreads) {
+            const int col = (int)(packed[k] & cmask);
+            if ((col < r0 || col >= r1) && col >= c0 && col < c1) atomicOr(&bm[(col - c0) >> 5], 1u << ((col - c0) & 31));
         }
-        rem_count[b] = (int32_t)run;
-        if ((int)run > rem_cap) atomicExch(fail, 1);
-    }
-    __syncthreads();
-    const int total = (int)prefix[nb];
-    auto slot_of = [&](int col) {
-        const int w = col >> 5, blk = w / kRemapBlock;
-        unsigned sl = prefix[blk];
-        for (int j = blk * kRemapBlock; j < w; ++j) sl += (unsigned)__popc(bm[j]);
-        return (int)(sl + (unsigned)__popc(bm[w] & ((1u << (col & 31)) - 1u)));
-    };
-    // the list of sources, ascending: every set bit
-    if (total <= rem_cap)
-        for (int w = tid; w < nw; w += kResThreads) {
-            unsigned bits = bm[w];
-            if (!bits) continue;
-            int sl = slot_of(w << 5);
-            while (bits) {
-                const int bit = __ffs((int)bits) - 1;
-                const int col = (w << 5) + bit;
-                rem_list[(size_t)b * rem_cap + sl++] = col;
-                if (col < n_own) { // the workgroup that owns (writes) this entry of u: binary search in the row boundaries
-                    int lo = 0, hi = (int)gridDim.x;
-                    while (hi - lo > 1) {
-                        const int mid = (lo + hi) >> 1;
-                        if (wg_row0[mid] <= col) lo = mid;
-                        else hi = mid;
-                    }
-                    atomicOr(&deps[lo >> 5], 1u << (lo & 31));
-                }
-                bits &= bits - 1u;
+        __syncthreads();
+        for (int i = tid; i < nb; i += kResThreads) {
+            unsigned c = 0u;
+#pragma unroll
+            for (int w = 0; w < kRemapBlock; ++w) c += (unsigned)__popc(bm[i * kRemapBlock + w]);
+            prefix[i + 1] = c;
+        }
+        __syncthreads();
+        if (tid == 0) { // exclusive scan over a few thousand block counts
+            unsigned run = 0u;
+            prefix[0] = 0u;
+            for (int i = 1; i <= nb; ++i) {
+                run += prefix[i];
+                prefix[i] = run;
             }
         }
-    __syncthreads();
+        __syncthreads();
+        const int total = (int)prefix[nb];
+        auto slot_of = [&](int col) { // (col relative to c0)
+            const int w = col >> 5, blk = w / kRemapBlock;
+            unsigned sl = prefix[blk];
+            for (int j = blk * kRemapBlock; j < w; ++j) sl += (unsigned)__popc(bm[j]);
+            return (int)(sl + (unsigned)__popc(bm[w] & ((1u << (col & 31)) - 1u)));
+        };
+        // the list of sources, ascending: every set bit
+        if (base + total <= rem_cap)
+            for (int w = tid; w < nw; w += kResThreads) {
+                unsigned bits = bm[w];
+                if (!bits) continue;
+                int sl = base + slot_of(w << 5);
+                while (bits) {
+                    const int bit = __ffs((int)bits) - 1;
+                    const int col = c0 + (w << 5) + bit;
+                    rem_list[(size_t)b * rem_cap + sl++] = col;
+                    if (col < n_own) { // the workgroup that owns (writes) this entry of u: binary search in the row boundaries
+                        int lo = 0, hi = (int)gridDim.x;
+                        while (hi - lo > 1) {
+                            const int mid = (lo + hi) >> 1;
+                            if (wg_row0[mid] <= col) lo = mid;
+                            else hi = mid;
+                        }
+                        atomicOr(&deps[lo >> 5], 1u << (lo & 31));
+                    }
+                    bits &= bits - 1u;
+                }
+            }
+        for (int k = k0 + tid; k < k1; k += kResThreads) {
+            const uint32_t wd = packed[k];
+            const int col = (int)(wd & cmask);
+            if ((col < r0 || col >= r1) && col >= c0 && col < c1)
+                rwords[k] = ((wd >> col_bits) << lc_bits) | (uint32_t)(wrows + base + slot_of(col - c0));
+        }
+        base += total;
+        __syncthreads(); // the bitmap is cleared for the next chunk
+    }
+    if (tid == 0) {
+        rem_count[b] = (int32_t)base;
+        if (base > rem_cap) atomicExch(fail, 1);
+    }
     if (tid < 32) dep_mask[(size_t)b * 32 + tid] = deps[tid];
-    const int wrows = r1 - r0;
-    for (int k = k0 + tid; k < k1; k += kResThreads) {
+    for (int k = k0 + tid; k < k1; k += kResThreads) { // the workgroup's own rows (and anything past the local columns: never read)
         const uint32_t wd = packed[k];
         const int col = (int)(wd & cmask);
-        int lc;
-        if (col >= r0 && col < r1) lc = col - r0;
-        else lc = col < n_ext ? wrows + slot_of(col) : 0;
-        rwords[k] = ((wd >> col_bits) << lc_bits) | (uint32_t)lc;
+        if (col >= r0 && col < r1) rwords[k] = ((wd >> col_bits) << lc_bits) | (uint32_t)(col - r0);
+        else if (col >= n_ext) rwords[k] = (wd >> col_bits) << lc_bits;
     }
+}
+
+// Plan kernel for STREAMED rows: thread = lane; packs the re-encoded words of the lane's streamed rows into quads (five 25-bit words, a
+// row = whole quads, bit 127 of its last one set) in the wave's lane-interleaved stream (see ResidentArgs::swords), padded to the wave's
+// longest lane with quads of zero words.
+__global__ __launch_bounds__(kResThreads) void k_resident_stream_layout(const int32_t *__restrict__ row_ptr, const uint32_t *__restrict__ rwords,
+                                                                        const int32_t *__restrict__ lane_row0, const uint32_t *__restrict__ lane_meta,
+                                                                        const int32_t *__restrict__ wg_lane0, const int32_t *__restrict__ wave_soff,
+                                                                        uint32_t padword, u4_t *__restrict__ squads)
+{
+    const int b = blockIdx.x, tid = threadIdx.x, wv = b * (kResThreads / 64) + (tid >> 6);
+    const int off0 = wave_soff[wv], wcnt = (wave_soff[wv + 1] - off0) >> 6;
+    u4_t *dst = squads + off0 + (tid & 63);
+    const int lane = wg_lane0[b] + tid;
+    auto pack = [&](const unsigned long long *wv5, bool last) {
+        const unsigned long long lo = wv5[0] | (wv5[1] << 25) | (wv5[2] << 50);
+        unsigned long long hi = (wv5[2] >> 14) | (wv5[3] << 11) | (wv5[4] << 36);
+        if (last) hi |= 1ull << 63;
+        return u4_t{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+    };
+    int j = 0;
+    if (lane < wg_lane0[b + 1]) {
+        const uint32_t meta = lane_meta[lane];
+        const int m = (int)((meta >> 3) & 127u);
+        const int r = lane_row0[lane] + (int)(meta & 7u);
+        for (int rr = r; rr < r + m; ++rr) {
+            const int ks = row_ptr[rr], ke = row_ptr[rr + 1];
+            for (int k = ks; k < ke && j < wcnt; k += kResQuadWords, ++j) {
+                unsigned long long w5[kResQuadWords];
+                for (int t = 0; t < kResQuadWords; ++t) w5[t] = k + t < ke ? rwords[k + t] : padword;
+                dst[(size_t)64 * (size_t)j] = pack(w5, k + kResQuadWords >= ke);
+            }
+        }
+    }
+    const unsigned long long p5[kResQuadWords] = {padword, padword, padword, padword, padword};
+    for (; j < wcnt; ++j) dst[(size_t)64 * (size_t)j] = pack(p5, false);
 }
 
 // NG: how many of the row-local vectors (s, then p, then r) stay in global memory (owner-only accesses) instead of LDS -- what is
@@ -259,7 +326,7 @@ __global__ __launch_bounds__(kResThreads) void k_resident_remap(const uint32_t *
 // boundaries: the inner loop is decode, two LDS reads and one FMA per word, and one end-of-row test per quad.  (Measured on the
 // 8-way partition of the 512^3 system, tools/probes/rowlen_local.py: rows of 2 / 12 / 15 / 17 / 18 / 20 / 26 words make up 97 %;
 // quads + <= 6 rows per lane need 0.89-0.92 of the chip's 262,144 lanes; slots of 15 or 18 words would need 1.06.)
-template <int NG>
+template <int NG, bool STREAM>
 __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double rlds[];
@@ -358,6 +425,7 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
     const double threshold = a.sc->threshold;
     const int max_iters = a.max_iters, max_timed = a.max_timed;
     const bool coherent = a.coherent_fill != 0;
+    const int tsize = a.table_size;
     const bool timing = a.timers && b == 0 && tid == 0, stamps = a.wg_times && tid == 0;
     int it = 0;
     for (; it < max_iters && !done; ++it) {
@@ -376,10 +444,10 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
         // 8 B every ~32 B (the lane-owned order cost the L1 four times the tag look-ups: the update was 11 us of a 40 us iteration) ----
         double ru = 0., rr = 0.;
         {
-            double *const gx = RES_P(x) + wrow0, *const gp = NG >= 2 ? RES_P(p) + wrow0 : nullptr, *const gr = NG >= 3 ? RES_P(r) + wrow0 : nullptr;
-            double *const gs = NG >= 1 ? RES_P(s) + wrow0 : nullptr;
-            const double *const gw = RES_P(w) + wrow0;
-            const uint16_t *const gd = RES_P(dcode) + wrow0;
+            const res_gptr<double> gx = RES_G(x) + wrow0, gp = NG >= 2 ? RES_G(p) + wrow0 : nullptr, gr = NG >= 3 ? RES_G(r) + wrow0 : nullptr;
+            const res_gptr<double> gs = NG >= 1 ? RES_G(s) + wrow0 : nullptr;
+            const res_gptr<const double> gw = RES_G(w) + wrow0;
+            const res_gptr<const uint16_t> gd = RES_G(dcode) + wrow0;
             for (int i0 = tid; i0 < wrows; i0 += kResUpd * kResThreads) {
                 double xv[kResUpd], wv[kResUpd], sv[kResUpd], pv[kResUpd], rv[kResUpd];
                 unsigned dv[kResUpd];
@@ -486,7 +554,7 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
         // ---- C: w = A u for the lane's rows.  First the workgroup's remote columns -> LDS, ONE round trip for all of them (plain loads
         // of the global u: this CU's L1 / the XCD's L2 were invalidated behind the barrier; other ranks' entries: the halo area of the
         // comm block, fine-grained memory first touched after the flag); then every gather is an LDS read.
-        const double *const fu = RES_P(u);
+        const res_gptr<const double> fu = RES_G(u);
         const int fn = RES_I(n);
         for (int k0 = tid; k0 < nrem; k0 += kResFill * kResThreads) { // kResFill loads in flight per lane: a halo-reading workgroup fills 8-10 k slots
             double v[kResFill];
@@ -511,7 +579,7 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
         if (stamps && it == 20) RES_P(wg_times)[4 * b + 2] = wall_clock64();
         double wu = 0.;
         {
-            double *const gw = RES_P(w);
+            const res_gptr<double> gw = RES_G(w);
             double acc = 0.;
             int rk = 0; // row of the lane being summed
             unsigned em = endmask;
@@ -561,13 +629,66 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
             }
             if (tail > 0) { // a row of more words than the registers hold (a coarse face ringed by fine ones; a handful per scene)
                 const int kt = RES_P(row_ptr)[row0] + RES_I(max_quads) * kResQuadWords;
-                const uint32_t *const twords = RES_P(rwords);
+                const res_gptr<const uint32_t> twords = RES_G(rwords);
                 for (int k = kt; k < kt + tail; ++k) {
                     const uint32_t wd = twords[k];
                     acc += tbl[wd >> cbits] * u_l[wd & cmask];
                 }
                 gw[row0] = acc;
                 wu += acc * u_l[row0 - wrow0];
+            }
+            if (STREAM) { // the lane's streamed rows: the same quads, from memory -- one 1-KiB run per wave load
+                const int32_t *const so = RES_P(wave_soff) + b * (kResThreads / 64) + (tid >> 6);
+                const int off0 = __builtin_amdgcn_readfirstlane(so[0]);
+                const int wcnt = (__builtin_amdgcn_readfirstlane(so[1]) - off0) >> 6; // quads of the wave's longest lane
+                const res_gptr<const u4_t> sq = reinterpret_cast<res_gptr<const u4_t>>(RES_G(swords)) + off0 + (tid & 63);
+                const unsigned kb = (unsigned)(kResWordBits - cbits);
+                const unsigned pw = (unsigned)tsize << cbits; // a word that multiplies the dictionary's zero
+                const unsigned long long plo = (unsigned long long)pw | ((unsigned long long)pw << 25) | ((unsigned long long)pw << 50);
+                const unsigned long long phi = ((unsigned long long)pw >> 14) | ((unsigned long long)pw << 11) | ((unsigned long long)pw << 36);
+                const u4_t padq = u4_t{(unsigned)plo, (unsigned)(plo >> 32), (unsigned)phi, (unsigned)(phi >> 32)};
+                int row = row0 + nrows;
+                double sacc = 0.;
+#if AVS_RES_STREAM_DB
+                u4_t qn[kResStream]; // the batch in flight while the previous one is multiplied
+#pragma unroll
+                for (int i = 0; i < kResStream; ++i) qn[i] = (i < wcnt) ? sq[(size_t)64 * (size_t)i] : padq;
+#endif
+                for (int j0 = 0; j0 < wcnt; j0 += kResStream) {
+                    u4_t qv[kResStream];
+#if AVS_RES_STREAM_DB
+#pragma unroll
+                    for (int i = 0; i < kResStream; ++i) qv[i] = qn[i];
+#pragma unroll
+                    for (int i = 0; i < kResStream; ++i) qn[i] = (j0 + kResStream + i < wcnt) ? sq[(size_t)64 * (size_t)(j0 + kResStream + i)] : padq;
+#else
+#pragma unroll
+                    for (int i = 0; i < kResStream; ++i) qv[i] = (j0 + i < wcnt) ? sq[(size_t)64 * (size_t)(j0 + i)] : padq;
+#endif
+#pragma unroll
+                    for (int i = 0; i < kResStream; ++i) {
+                        const u4_t mm = qv[i];
+                        const unsigned t1 = __builtin_amdgcn_alignbit(mm.y, mm.x, 25);
+                        const unsigned t2 = __builtin_amdgcn_alignbit(mm.z, mm.y, 18);
+                        const unsigned t3 = __builtin_amdgcn_alignbit(mm.w, mm.z, 11);
+                        const double v0 = tbl[__builtin_amdgcn_ubfe(mm.x, (unsigned)cbits, kb)], x0 = u_l[mm.x & cmask];
+                        const double v1 = tbl[__builtin_amdgcn_ubfe(t1, (unsigned)cbits, kb)], x1 = u_l[t1 & cmask];
+                        const double v2 = tbl[__builtin_amdgcn_ubfe(t2, (unsigned)cbits, kb)], x2 = u_l[t2 & cmask];
+                        const double v3 = tbl[__builtin_amdgcn_ubfe(t3, (unsigned)cbits, kb)], x3 = u_l[t3 & cmask];
+                        const double v4 = tbl[__builtin_amdgcn_ubfe(mm.w, 4u + (unsigned)cbits, kb)], x4 = u_l[__builtin_amdgcn_ubfe(mm.w, 4u, (unsigned)cbits)];
+                        sacc = __builtin_fma(v0, x0, sacc);
+                        sacc = __builtin_fma(v1, x1, sacc);
+                        sacc = __builtin_fma(v2, x2, sacc);
+                        sacc = __builtin_fma(v3, x3, sacc);
+                        sacc = __builtin_fma(v4, x4, sacc);
+                        if (mm.w >> 31) { // (bit 127) the row's last quad
+                            gw[row] = sacc;
+                            wu += sacc * u_l[row - wrow0];
+                            sacc = 0.;
+                            ++row;
+                        }
+                    }
+                }
             }
         }
         // ---- D: one reduction of (r.u, |r|^2, w.u): every workgroup drops its three sums into sentinel-armed slots (fire and forget:
@@ -702,7 +823,9 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
 // ---------------------------------------------------------------------------------------------
 struct ResidentPlan {
     DevBuf<int32_t> lane_row0, wg_lane0, wg_row0, push_seg, rem_list, rem_count;
-    DevBuf<uint32_t> lane_meta, rwords;
+    DevBuf<uint32_t> lane_meta, rwords, swords;
+    DevBuf<int32_t> wave_soff;
+    bool streams = false;
     DevBuf<unsigned long long> bar_flags;
     DevBuf<unsigned> dep_mask;
     int n_push_wgs = 0;
@@ -726,13 +849,14 @@ static bool resident_wanted(bool distributed)
     return true; // default for every system that qualifies (plan: 1.5-2 ms per new matrix; AVS_CG_RESIDENT=0 keeps the launch-per-phase loops)
 }
 
-static const void *resident_kernel(int ng)
+static const void *resident_kernel(int ng, bool streams)
 {
+    // (streamed rows are a template parameter: their code costs the plain kernels 15 more spilled registers otherwise)
     switch (ng) {
-    case 0: return (const void *)k_cg_resident<0>;
-    case 1: return (const void *)k_cg_resident<1>;
-    case 2: return (const void *)k_cg_resident<2>;
-    default: return (const void *)k_cg_resident<3>;
+    case 0: return streams ? (const void *)k_cg_resident<0, true> : (const void *)k_cg_resident<0, false>;
+    case 1: return streams ? (const void *)k_cg_resident<1, true> : (const void *)k_cg_resident<1, false>;
+    case 2: return streams ? (const void *)k_cg_resident<2, true> : (const void *)k_cg_resident<2, false>;
+    default: return streams ? (const void *)k_cg_resident<3, true> : (const void *)k_cg_resident<3, false>;
     }
 }
 
@@ -781,43 +905,94 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
     std::vector<uint32_t> lmeta;
     lrow.reserve((size_t)n / 4 + 16);
     lmeta.reserve((size_t)n / 4 + 16);
-    for (int64_t i = 0; i < n;) {
-        const int Lr = rp[(size_t)i + 1] - rp[(size_t)i];
-        if (Lr <= 0) return no("empty row"); // (every row of this system carries its diagonal, cpp:2768)
-        if (Lr > W) {
-            if (Lr - W >= (1 << 22)) return no("row too long");
-            lrow.push_back((int32_t)i);
-            lmeta.push_back(1u | ((unsigned)(Lr - W) << 10));
-            ++i;
-            continue;
+    // T: streamed QUADS per lane.  0 while the slab fits the register files; otherwise every lane takes, after its register rows, rows
+    // worth about T quads (error diffusion keeps the average; equal quads per lane, not equal rows: a wave walks its longest lane's
+    // stream, and with rows of 3-6 quads an equal-rows split padded the streams by 64 %); at most 127 rows per lane
+    const char *lane_fail = nullptr;
+    auto quads_of = [&](int64_t row) { return (rp[(size_t)row + 1] - rp[(size_t)row] + kResQuadWords - 1) / kResQuadWords; };
+    auto form_lanes = [&](double T) {
+        lrow.clear();
+        lmeta.clear();
+        double debt = 0.;
+        for (int64_t i = 0; i < n;) {
+            const int Lr = rp[(size_t)i + 1] - rp[(size_t)i];
+            if (Lr <= 0) { lane_fail = "empty row"; return; } // (every row of this system carries its diagonal, cpp:2768)
+            if (Lr > W) {
+                if (Lr - W >= (1 << 22)) { lane_fail = "row too long"; return; }
+                lrow.push_back((int32_t)i);
+                lmeta.push_back(1u | ((unsigned)(Lr - W) << 10));
+                ++i;
+                continue;
+            }
+            int rows = 0, used = 0;
+            const int64_t first = i;
+            while (i < n && rows < kResRowsMax) {
+                const int Li = rp[(size_t)i + 1] - rp[(size_t)i];
+                if (Li <= 0 || Li > W) break;
+                const int k = (Li + kResQuadWords - 1) / kResQuadWords;
+                if (used + k > max_quads) break;
+                used += k;
+                ++rows;
+                ++i;
+            }
+            debt += T;
+            int m = 0;
+            while (i < n && m < 127) {
+                if (rp[(size_t)i + 1] - rp[(size_t)i] <= 0) { lane_fail = "empty row"; return; }
+                const int k = quads_of(i);
+                if ((double)k > debt + 0.5 * (double)k) break; // (take the row when at least half of it is owed)
+                debt -= (double)k;
+                ++m;
+                ++i;
+            }
+            lrow.push_back((int32_t)first);
+            lmeta.push_back((unsigned)rows | ((unsigned)m << 3));
         }
-        int rows = 0, used = 0;
-        const int64_t first = i;
-        while (i < n && rows < kResRowsMax) {
-            const int Li = rp[(size_t)i + 1] - rp[(size_t)i];
-            if (Li <= 0 || Li > W) break;
-            const int k = (Li + kResQuadWords - 1) / kResQuadWords;
-            if (used + k > max_quads) break;
-            used += k;
-            ++rows;
-            ++i;
+    };
+    form_lanes(0.);
+    if (lane_fail) return no(lane_fail);
+    double stream_T = 0.;
+    const int64_t lane_cap = (int64_t)G * kResThreads;
+    if ((int64_t)lrow.size() > lane_cap * 93 / 100) {
+        if (getenv("AVS_CG_RESIDENT_NO_STREAM")) return no("too many rows for the register files of this GPU");
+        int64_t q_total = 0;
+        for (int64_t i = 0; i < n; ++i) q_total += quads_of(i);
+        const double L0 = (double)lrow.size(), q_lane = (double)q_total / L0; // register quads an average lane holds
+        double Lt = 0.90 * (double)lane_cap;
+        for (int attempt = 0; attempt < 8; ++attempt, Lt *= 0.97) {
+            stream_T = ((double)q_total - Lt * q_lane) / Lt;
+            form_lanes(stream_T);
+            if (lane_fail) return no(lane_fail);
+            if ((int64_t)lrow.size() <= lane_cap * 93 / 100) break;
         }
-        lrow.push_back((int32_t)first);
-        lmeta.push_back((unsigned)rows);
+        if ((int64_t)lrow.size() > lane_cap * 95 / 100) return no("too many rows for the register files of this GPU, even with streamed rows");
     }
     const int64_t L = (int64_t)lrow.size();
     int64_t lpw = (L + G - 1) / G;
     if (lpw > kResThreads) return no("too many rows for the register files of this GPU");
+    // quads a lane streams per iteration (cost model, stream layout)
+    std::vector<int32_t> lane_sw((size_t)L, 0);
+    int64_t stream_words = 0;
+    for (int64_t l = 0; l < L; ++l) {
+        const int m = (int)((lmeta[(size_t)l] >> 3) & 127u);
+        if (m) {
+            const int64_t r = (int64_t)lrow[(size_t)l] + (int64_t)(lmeta[(size_t)l] & 7u);
+            for (int64_t q = r; q < r + m; ++q) lane_sw[(size_t)l] += (rp[(size_t)q + 1] - rp[(size_t)q] + kResQuadWords - 1) / kResQuadWords; // quads
+            stream_words += rp[(size_t)(r + m)] - rp[(size_t)r];
+        }
+    }
     std::vector<int32_t> wl((size_t)G + 1), wr((size_t)G + 1), rc((size_t)G);
     int max_rows = 0;
     int code_bits = 1;
     while ((1 << code_bits) < A.table_size + 1) ++code_bits; // + the zero the padding words address
     if (code_bits >= kResWordBits - 8) return no("dictionary needs too many bits");
     const size_t lds_max = 160 * 1024 - 4096 - 1024;
-    const int cap = 16384; // stride of the per-workgroup source lists (a workgroup with more remote columns does not qualify)
+    const int cap = stream_T > 0. ? 32768 : 16384; // stride of the per-workgroup source lists (a workgroup with more remote columns does not qualify)
     const int64_t n_ext = n_cols > n ? n_cols : n;
-    const size_t remap_lds = ((size_t)(((n_ext + 31) / 32 + kRemapBlock - 1) / kRemapBlock) * (kRemapBlock + 1) + 2) * sizeof(unsigned);
-    if (remap_lds > 160 * 1024 - 4096) return no("too many local columns for the plan kernel's bitmap");
+    int64_t chunk_cols = std::min<int64_t>(n_ext, kRemapChunk);
+    if (const char *e = getenv("AVS_CG_RESIDENT_REMAP_CHUNK")) // tests: several bitmap passes on a small system
+        if (atoll(e) >= 512) chunk_cols = std::min<int64_t>(chunk_cols, (atoll(e) + 511) / 512 * 512);
+    const size_t remap_lds = ((size_t)(((chunk_cols + 31) / 32 + kRemapBlock - 1) / kRemapBlock) * (kRemapBlock + 1) + 2) * sizeof(unsigned);
     DevBuf<int> fail;
     if (pl->wg_row0.alloc((size_t)G + 1) != AVS_OK || pl->rwords.alloc((size_t)A.nnz) != AVS_OK || pl->rem_count.alloc((size_t)G) != AVS_OK ||
         pl->rem_list.alloc((size_t)G * cap) != AVS_OK || fail.alloc(1) != AVS_OK || pl->dep_mask.alloc((size_t)G * 32) != AVS_OK || G > 1024 ||
@@ -825,8 +1000,11 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
         (void)hipGetLastError();
         return no("plan allocation failed");
     }
-    int max_ng = 1; // tiers 2, 3 measured no faster than the launch-per-phase loop (the vector traffic is back): off unless asked for
-    if (const char *e = getenv("AVS_CG_RESIDENT_MAX_GLOBAL")) max_ng = atoi(e);
+    // Tiers: the fewest row-local vectors in global memory that fit.  Tier 1 (s) is tried with re-balancing first; tiers 2 and 3 (p, r
+    // too) only when that fails -- larger slabs (streamed rows: the 2- and 4-way partitions) -- since their vector traffic is back in
+    // the update phase (coalesced since the second pass of round 3, which is what makes them worth it).
+    int max_ng_limit = 3;
+    if (const char *e = getenv("AVS_CG_RESIDENT_MAX_GLOBAL")) max_ng_limit = atoi(e);
     // Workgroup boundaries by estimated time, not by lanes: the SpMV phase costs per lane (every lane walks its quads), the vector
     // update per row (measured: ~12.7 ns per lane, ~3.6 ns per row of a workgroup) -- workgroups of fine regions have 2x the rows
     // of those in coarse regions at equal lanes.  Then the words are re-encoded (k_resident_remap) and the LDS footprints checked:
@@ -834,11 +1012,18 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
     // re-weighted and the split is redone -- a few rounds.
     std::vector<double> lane_w((size_t)L, 1.0), cum((size_t)L + 1, 0.);
     const double c_lane = 12.7, c_row = 3.6;
+    const double kStreamCost = getenv("AVS_CG_RESIDENT_STREAM_COST") ? atof(getenv("AVS_CG_RESIDENT_STREAM_COST")) : 1.5;
     int ng = -1, lc_bits = 0, max_cols = 0;
     size_t lds = 0;
     const char *last_reason = "the vector slices + remote columns of a workgroup do not fit the LDS";
-    for (int round = 0; round < 5 && ng < 0; ++round) {
-        for (int64_t l = 0; l < L; ++l) cum[(size_t)l + 1] = cum[(size_t)l] + lane_w[(size_t)l] * (c_lane + c_row * (double)(lmeta[(size_t)l] & 7u));
+    for (int max_ng = std::min(1, max_ng_limit); max_ng <= max_ng_limit && ng < 0; ++max_ng) {
+    if ((size_t)(4 - max_ng) * (size_t)(n / G) * sizeof(double) > lds_max) continue; // (even the average workgroup's slices would not fit)
+    std::fill(lane_w.begin(), lane_w.end(), 1.0);
+    bool give_up = false;
+    for (int round = 0; round < 5 && ng < 0 && !give_up; ++round) {
+        for (int64_t l = 0; l < L; ++l) // (a streamed quad costs what a register quad does plus its load; 15 quads = one lane's walk)
+            cum[(size_t)l + 1] = cum[(size_t)l] + lane_w[(size_t)l] * (c_lane * (1. + kStreamCost * (double)lane_sw[(size_t)l] / (double)kResQuads) +
+                                                                      c_row * (double)((lmeta[(size_t)l] & 7u) + ((lmeta[(size_t)l] >> 3) & 127u)));
         int64_t l0 = 0;
         wl[0] = 0;
         for (int b = 1; b <= G; ++b) {
@@ -851,7 +1036,7 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
             l0 = l1;
         }
         if (l0 != L || getenv("AVS_CG_RESIDENT_EQUAL_LANES")) {
-            if (round > 0) break; // (re-weighting pushed a workgroup past 1024 lanes: give up)
+            if (round > 0) { give_up = true; break; } // (re-weighting pushed a workgroup past 1024 lanes: give up)
             for (int b = 0; b <= G; ++b) wl[(size_t)b] = (int32_t)std::min<int64_t>((int64_t)b * lpw, L);
         }
         max_rows = 0;
@@ -867,7 +1052,7 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
         }
         hipLaunchKernelGGL(k_resident_remap, dim3((unsigned)G), dim3(kResThreads), remap_lds, stream, A.packed, A.row_ptr, A.col_bits, lc_bits,
                            (const int32_t *)pl->wg_row0.p, cap, (int)n_ext, pl->rwords.p, pl->rem_list.p, pl->rem_count.p, fail.p, (int)n,
-                           pl->dep_mask.p);
+                           pl->dep_mask.p, (int)chunk_cols);
         int f = 0;
         if (hipMemcpyAsync(&f, fail.p, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess ||
             hipMemcpyAsync(rc.data(), pl->rem_count.p, (size_t)G * sizeof(int32_t), hipMemcpyDeviceToHost, stream) != hipSuccess ||
@@ -875,7 +1060,7 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
             (void)hipGetLastError();
             return no("remap failed");
         }
-        if (f) { last_reason = "a workgroup reads more remote columns than its source list holds"; break; }
+        if (f) { last_reason = "a workgroup reads more remote columns than its source list holds"; give_up = true; break; }
         // LDS split: every workgroup holds its slice of u + its remote-column cache, and as many of r, p, s as still fit (tiers: NG =
         // 0 .. 3 of them in global memory instead).  Footprint of workgroup b: (4 - NG) rows_b + remote_b doubles; the largest decides.
         const size_t extra = (2 * ((size_t)A.table_size + 1) + 48 + 8) * sizeof(double);
@@ -901,6 +1086,7 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
             }
         }
     }
+    }
     if (verbose) {
         std::vector<int32_t> srt(rc);
         std::sort(srt.begin(), srt.end());
@@ -911,7 +1097,7 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
     if ((1 << lc_bits) < max_cols) return no("rows + remote columns exceed the word's column bits");
     lpw = 0;
     for (int b = 0; b < G; ++b) lpw = std::max<int64_t>(lpw, wl[(size_t)b + 1] - wl[(size_t)b]);
-    const void *kern = resident_kernel(ng);
+    const void *kern = resident_kernel(ng, stream_words > 0);
     if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) != hipSuccess) {
         (void)hipGetLastError();
         return no("LDS opt-in refused");
@@ -969,6 +1155,35 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
          hipMemcpy(pl->push_seg.p, seg.data(), seg.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(pl->wg_halo.p, whalo.data(), whalo.size(), hipMemcpyHostToDevice) == hipSuccess;
     if (!up) { (void)hipGetLastError(); return no("plan upload failed"); }
+    pl->streams = false;
+    if (stream_words > 0) { // the waves' lane-interleaved streams of the rows that do not fit the registers
+        const int wpg = kResThreads / 64;
+        std::vector<int32_t> soff((size_t)G * wpg + 1, 0);
+        int64_t run = 0;
+        for (int b = 0; b < G; ++b)
+            for (int w = 0; w < wpg; ++w) {
+                int mx = 0;
+                for (int64_t l = (int64_t)wl[(size_t)b] + 64 * w; l < std::min<int64_t>((int64_t)wl[(size_t)b] + 64 * (w + 1), wl[(size_t)b + 1]); ++l)
+                    mx = std::max(mx, lane_sw[(size_t)l]);
+                soff[(size_t)b * wpg + w] = (int32_t)run;
+                run += 64 * (int64_t)mx;
+            }
+        soff[(size_t)G * wpg] = (int32_t)run;
+        if (run >= (1ll << 29)) return no("streamed quads exceed 32-bit offsets");
+        if (pl->swords.alloc((size_t)run * 4) != AVS_OK || pl->wave_soff.alloc(soff.size()) != AVS_OK ||
+            hipMemcpy(pl->wave_soff.p, soff.data(), soff.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            return no("stream allocation failed");
+        }
+        hipLaunchKernelGGL(k_resident_stream_layout, dim3((unsigned)G), dim3(kResThreads), 0, stream, A.row_ptr, (const uint32_t *)pl->rwords.p,
+                           (const int32_t *)pl->lane_row0.p, (const uint32_t *)pl->lane_meta.p, (const int32_t *)pl->wg_lane0.p,
+                           (const int32_t *)pl->wave_soff.p, (uint32_t)A.table_size << lc_bits, reinterpret_cast<u4_t *>(pl->swords.p));
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { (void)hipGetLastError(); return no("stream layout failed"); }
+        pl->streams = true;
+        if (verbose)
+            fprintf(stderr, "[avs resident] streamed rows: %.1f %% of the words (%lld of %lld), %.1f MB per iteration incl. padding, %.1f streamed quads per lane\n",
+                    100. * (double)stream_words / (double)A.nnz, (long long)stream_words, (long long)A.nnz, (double)run * 16e-6, stream_T);
+    }
     if (verbose) {
         timespec t1{};
         clock_gettime(CLOCK_MONOTONIC, &t1);
@@ -1007,6 +1222,8 @@ static avs_status resident_run(ResidentPlan *pl, const CsrView &A, double *x, do
     a.wg_lane0 = pl->wg_lane0.p;
     a.wg_row0 = pl->wg_row0.p;
     a.rwords = pl->rwords.p;
+    a.swords = pl->streams ? pl->swords.p : nullptr;
+    a.wave_soff = pl->streams ? pl->wave_soff.p : nullptr;
     a.lc_bits = pl->lc_bits;
     a.max_quads = pl->max_quads;
     a.rem_list = pl->rem_list.p;
@@ -1053,7 +1270,7 @@ static avs_status resident_run(ResidentPlan *pl, const CsrView &A, double *x, do
     AVS_HIP(hipMemsetAsync(pl->slots.p, 0xFF, (size_t)pl->G * 4 * sizeof(double), stream));   // armed: kSentinel in every slot
     AVS_HIP(hipMemsetAsync(pl->bcast.p, 0xFF, 4 * kResGens * sizeof(double), stream));
     void *args[] = {&a};
-    const hipError_t le = hipLaunchCooperativeKernel(resident_kernel(pl->ng), dim3((unsigned)pl->G), dim3(kResThreads), args, (unsigned)pl->lds, stream);
+    const hipError_t le = hipLaunchCooperativeKernel(resident_kernel(pl->ng, pl->streams), dim3((unsigned)pl->G), dim3(kResThreads), args, (unsigned)pl->lds, stream);
     if (le != hipSuccess) {
         (void)hipGetLastError();
         pl->ok = false;

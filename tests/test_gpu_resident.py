@@ -66,6 +66,15 @@ def test_resident_refuses_what_does_not_fit(which, resident_env, built_lib):
     """Systems that are not in the packed single-dictionary form (a viscosity / density field with thousands of distinct values) or
     too large for the register files silently keep the launch-per-phase loop."""
     dev = torch.device("cuda:0")
+    if which == "too_many_rows":    # 1.27 M rows: more than the register files hold; with streamed rows switched off the loop must decline
+        os.environ["AVS_CG_RESIDENT_NO_STREAM"] = "1"
+    try:
+        _refuses(which, dev)
+    finally:
+        os.environ.pop("AVS_CG_RESIDENT_NO_STREAM", None)
+
+
+def _refuses(which, dev):
     sc = {"tile_dictionaries": lambda: scenes.fat_beam(256, 4, variable_viscosity=True, device=dev),
           "density_tensor": lambda: scenes.with_sampled_fields(scenes.sphere_with_obstacle(64, 4, device=dev)),
           "too_many_rows": lambda: scenes.fat_beam(256, 5, device=dev)}[which]()
@@ -125,3 +134,38 @@ def test_resident_long_row_path(resident_env, built_lib):
         s.close()
     finally:
         os.environ.pop("AVS_CG_RESIDENT_MAX_QUADS", None)
+
+
+@pytest.mark.parametrize("mode", ["forced_on_64_cus", "beam256_whole_chip"])
+def test_resident_streamed_rows(mode, resident_env, built_lib):
+    """A system larger than the register files: every lane keeps what fits and STREAMS the quads of its remaining rows from memory
+    (lane-interleaved per wave), the row-local vectors r, p, s move to global memory as the LDS requires.  forced_on_64_cus: the
+    128^3 beam on a quarter of the chip (34 % of the words streamed) with a 64 K-column bitmap chunk in the plan kernel (six passes);
+    beam256_whole_chip: 1.27 M rows on all CUs (27 % streamed).  Against the oracle like every other loop."""
+    env = {"AVS_CG_RESIDENT_CUS": "64", "AVS_CG_RESIDENT_REMAP_CHUNK": "65536"} if mode == "forced_on_64_cus" else {}
+    os.environ.update(env)
+    try:
+        sc = scenes.fat_beam(128, 3) if mode == "forced_on_64_cus" else scenes.fat_beam(256, 4)
+        dsc = scenes.to_device(sc, torch.device("cuda:0"))
+        pyr = build_pyramid(dsc)
+        s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
+        feed(s, pyr)
+        s.set_scene_fields(dsc)
+        s.assemble()
+        o = oracle_from_pyramid(sc, pyr)
+        o.hot_path()
+        for tol in (1e-10, 1e-3):
+            info = s.solve(tol, 5000)
+            assert info.resident == 1 and info.converged == 1 and info.error <= tol
+            xo, io = o.solve(tol, 5000)
+            assert abs(info.iterations - io.iterations) <= max(3, io.iterations // 100), (info.iterations, io.iterations)
+            if tol < 1e-6:
+                assert rel_l2(s.solution(), xo) < 1e-7
+        x_res = s.solution()
+        os.environ["AVS_CG_RESIDENT"] = "0"                # the same context through the launch-per-phase loop
+        info2 = s.solve(1e-3, 5000)
+        assert info2.resident == 0 and rel_l2(s.solution(), x_res) < 5e-4
+        s.close()
+    finally:
+        for k in env:
+            os.environ.pop(k, None)

@@ -9,7 +9,8 @@ dev = torch.device("cuda:0")
 CASES = {"beam64w": lambda: scenes.fat_beam(64, 3, wall=True, device=dev), "sphere64": lambda: scenes.sphere(64, 4, device=dev),
          "sphere32": lambda: scenes.sphere(32, 3, device=dev),
          "beam128": lambda: scenes.fat_beam(128, 3, device=dev), "beam128L4": lambda: scenes.fat_beam(128, 4, device=dev),
-         "beam256L5": lambda: scenes.fat_beam(256, 5, device=dev), "hipbeam": lambda: scenes.viscous_beam_scene(device=dev),
+         "beam256L5": lambda: scenes.fat_beam(256, 5, device=dev), "beam256L4": lambda: scenes.fat_beam(256, 4, device=dev),
+         "beam320L4": lambda: scenes.fat_beam(320, 4, device=dev), "beam384L4": lambda: scenes.fat_beam(384, 4, device=dev), "hipbeam": lambda: scenes.viscous_beam_scene(device=dev),
          "hipbuckling": lambda: scenes.viscous_buckling_scene(device=dev)}
 for name in (sys.argv[1:] or list(CASES)):
     sc = CASES[name]()
