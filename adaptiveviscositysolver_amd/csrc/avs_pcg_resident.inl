@@ -1020,7 +1020,7 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
     if ((size_t)(4 - max_ng) * (size_t)(n / G) * sizeof(double) > lds_max) continue; // (even the average workgroup's slices would not fit)
     std::fill(lane_w.begin(), lane_w.end(), 1.0);
     bool give_up = false;
-    for (int round = 0; round < 5 && ng < 0 && !give_up; ++round) {
+    for (int round = 0; round < (stream_T > 0. ? 9 : 5) && ng < 0 && !give_up; ++round) { // (large slabs: a lower tier is worth more rounds)
         for (int64_t l = 0; l < L; ++l) // (a streamed quad costs what a register quad does plus its load; 15 quads = one lane's walk)
             cum[(size_t)l + 1] = cum[(size_t)l] + lane_w[(size_t)l] * (c_lane * (1. + kStreamCost * (double)lane_sw[(size_t)l] / (double)kResQuads) +
                                                                       c_row * (double)((lmeta[(size_t)l] & 7u) + ((lmeta[(size_t)l] >> 3) & 127u)));
@@ -1079,6 +1079,12 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
         if (ng < 0) { // shrink the offenders (at the largest tier allowed) and split again
             const int t = max_ng < 3 ? (max_ng < 0 ? 0 : max_ng) : 3;
             const double limit = (double)(lds_max - extra) / sizeof(double);
+            { // ... unless the MEDIAN workgroup does not fit either: no re-split helps, go to the next tier
+                std::vector<double> fps((size_t)G);
+                for (int b = 0; b < G; ++b) fps[(size_t)b] = (double)(4 - t) * (double)(wr[(size_t)b + 1] - wr[(size_t)b]) + (double)rc[(size_t)b];
+                std::nth_element(fps.begin(), fps.begin() + G / 2, fps.end());
+                if (fps[(size_t)G / 2] > 0.98 * limit) { give_up = true; break; }
+            }
             for (int b = 0; b < G; ++b) {
                 const double fp = (double)(4 - t) * (double)(wr[(size_t)b + 1] - wr[(size_t)b]) + (double)rc[(size_t)b];
                 if (fp > 0.97 * limit)

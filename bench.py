@@ -564,6 +564,7 @@ def main():
             extras = []
             for label, make in (
                     ("config 3: fat_beam 256^3, 4 levels, mu(x)=200(1+9x)", lambda: scenes.fat_beam(256, 4, variable_viscosity=True, device=dev)),
+                    ("fat_beam 256^3, 4 levels, uniform viscosity (1.27 M rows: CU-resident loop with streamed rows)", lambda: scenes.fat_beam(256, 4, device=dev)),
                     ("fat_beam 512^3, 4 levels, mu(x)=200(1+9x)", lambda: scenes.fat_beam(512, 4, variable_viscosity=True, device=dev)),
                     ("config 5: thin_sheet 1024^3 (half-thickness 16 dx), 5 levels requested", lambda: scenes.thin_sheet(1024, 5, thickness_cells=32, device=dev)),
                     ("scene viscousBeam.hip equivalent (304x80x80 simulation grid)", lambda: scenes.viscous_beam_scene(device=dev)),

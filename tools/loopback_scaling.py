@@ -26,6 +26,29 @@ ap.add_argument("--iters", type=int, default=320)
 ap.add_argument("--ranks", default="", help="comma-separated subset of ranks to run (profiling one rank under rocprofv3)")
 a = ap.parse_args()
 only = [int(r) for r in a.ranks.split(",")] if a.ranks else None
+if "," in a.worlds:
+    # one PROCESS per world size (as a deployment has): dozens of contexts built and freed in one process leave the allocator in a
+    # state where the partitioned assembly of the later worlds shows 40-60 ms instead of 10
+    import subprocess
+    merged = None
+    for w in a.worlds.split(","):
+        cmd = [sys.executable, os.path.abspath(__file__), "--n", str(a.n), "--levels", str(a.levels), "--worlds", w, "--iters", str(a.iters)]
+        if a.ranks:
+            cmd += ["--ranks", a.ranks]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            sys.exit(r.returncode)
+        d = json.loads(r.stdout[r.stdout.index("{"):])
+        if merged is None:
+            merged = d
+        else:
+            merged["worlds"].update(d["worlds"])
+    base = merged["worlds"].get("1", {}).get("projected_iter_per_s")
+    for w, v in merged["worlds"].items():
+        if base:
+            v["projected_speedup_vs_world1_direct"] = v["projected_iter_per_s"] / base
+    print(json.dumps(merged, indent=1))
+    sys.exit(0)
 dev = torch.device("cuda:0")
 sc = scenes.fat_beam(a.n, a.levels, device=dev)
 pp = DevicePrepass(sc.res, sc.dx, sc.levels)
@@ -43,10 +66,12 @@ for world in [int(w) for w in a.worlds.split(",")]:
         s.dist_assemble()                             # warm-up pass (first touch), then the timed one
         torch.cuda.synchronize()
         import time
-        t_as = time.perf_counter()
-        s.dist_assemble()
-        torch.cuda.synchronize()
-        asm_ms = (time.perf_counter() - t_as) * 1e3
+        asm_ms = 1e30                                 # best of three: this process builds and frees dozens of contexts, and an
+        for _ in range(3):                            # assembly that lands behind a large free shows 45-60 ms instead of 10
+            t_as = time.perf_counter()
+            s.dist_assemble()
+            torch.cuda.synchronize()
+            asm_ms = min(asm_ms, (time.perf_counter() - t_as) * 1e3)
         capi.check(s.lib.avs_dist_import_blobs(s.h, None))
         s.dist_solve(1e-30, 64)                       # warm-up: graph capture, first touch
         info = s.dist_solve(1e-30, a.iters)           # never converges: exactly a.iters iterations
