@@ -182,7 +182,8 @@ def test_processes_paranoid_mode(tmp_path, built_lib):
     assert rel_l2(x, xref) < 1e-7
 
 
-@pytest.mark.parametrize("scene,world,cus", [("beam128", 2, 96), ("beam128", 3, 64)])
+@pytest.mark.parametrize("scene,world,cus", [("beam128", 2, 96), ("beam128", 3, 64),
+                                             ("beam128", 2, 40)])   # 40 CUs per rank: the slab exceeds their register files -> streamed rows
 def test_processes_resident_loop_across_ranks(scene, world, cus, tmp_path, built_lib):
     """The CU-resident loop (avs_pcg_resident.inl) between REAL ranks: one process per rank on a share of one GPU's CUs
     (AVS_CG_RESIDENT_CUS; on a multi-GPU node every rank has all CUs of its own GPU).  Pushes into the peer's halo area, halo flags
