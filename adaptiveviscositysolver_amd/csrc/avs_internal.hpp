@@ -196,6 +196,9 @@ struct CsrView {
     // windowed columns: packed[k] = code << 20 | slot << 14 | offset, column = cbase[64 * tile + slot] + offset -- the columns a
     // 512-row tile reads lie in a few 16384-wide windows of the brick-major numbering (col_bits is 0 in this form)
     const int32_t *cbase = nullptr;
+    // generation of the value index these pointers belong to (build_matrix_index): plans derived from the WORDS (the CU-resident loop's
+    // re-encoding) are keyed on it -- a re-assembly may rewrite the same buffers
+    uint64_t epoch = 0;
 };
 constexpr int kCwinOffBits = 14, kCwinSlotBits = 6, kCwinSlots = 1 << kCwinSlotBits, kCwinCodeBits = 32 - kCwinOffBits - kCwinSlotBits;
 
@@ -210,11 +213,13 @@ struct ValueIndex {
     int col_bits = 0;    // > 0 = packed words
     bool tile_tables = false;
     bool col_windows = false;
+    uint64_t epoch = 0;  // set by build_matrix_index: a new number for every matrix it indexes
     void clear() { table_size = 0; col_bits = 0; tile_tables = false; col_windows = false; }
     int bytes_per_nonzero() const { return table_size <= 0 ? 12 : ((col_bits > 0 || col_windows) ? 4 : 6); }
     void apply(CsrView &A) const
     {
         A.codes = nullptr; A.table = nullptr; A.table_size = 0; A.packed = nullptr; A.col_bits = 0; A.tab_ptr = nullptr; A.cbase = nullptr;
+        A.epoch = epoch;
         if (table_size <= 0) return;
         A.codes = codes.p; A.table = table.p; A.table_size = table_size;
         if (col_bits > 0) { A.packed = packed.p; A.col_bits = col_bits; }

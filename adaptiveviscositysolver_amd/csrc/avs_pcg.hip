@@ -2108,7 +2108,7 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
         timed_chunk = !replay;
         if (replay) {
             const void *key[10] = {A.row_ptr, A.col, A.codes, A.packed, A.table, x, b, (const void *)da.dd, (const void *)(intptr_t)A.n,
-                                   (const void *)(intptr_t)(((int64_t)A.table_size << 8) + A.col_bits + 1000003ll * ntiles)};
+                                   (const void *)(intptr_t)(((int64_t)A.table_size << 8) + A.col_bits + 1000003ll * ntiles + 1000000007ll * (int64_t)A.epoch)};
             (void)da.tiles_int;
             if (w->graph && (memcmp(key, w->graph_key, sizeof(key)) != 0 || w->graph_tol != tol)) {
                 (void)hipGraphExecDestroy(w->graph);
@@ -2417,7 +2417,7 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
         timed_chunk = !replay;
         if (replay) {
             const void *key[10] = {A.row_ptr, A.col, A.val, A.codes, A.packed, A.table, x, (const void *)(intptr_t)A.n,
-                                   (const void *)(intptr_t)(A.table_size * 64 + A.col_bits), (const void *)(intptr_t)((coded ? 1 : 0) | (fuse_beta ? 2 : 0))};
+                                   (const void *)(intptr_t)(A.table_size * 64 + A.col_bits), (const void *)(intptr_t)((coded ? 1 : 0) | (fuse_beta ? 2 : 0) | (int64_t)(A.epoch << 2))};
             if (w->graph && (memcmp(key, w->graph_key, sizeof(key)) != 0 || w->graph_tol != tol)) {
                 (void)hipGraphExecDestroy(w->graph);
                 w->graph = nullptr;

@@ -837,6 +837,7 @@ struct ResidentPlan {
     size_t lds = 0;
     const void *key[4] = {};
     int64_t key_n = -1;
+    uint64_t key_epoch = 0;
     bool ok = false, tried = false;
     std::string why;
 };
@@ -864,7 +865,8 @@ static const void *resident_kernel(int ng, bool streams)
 static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols, const DirectArgs *da, hipStream_t stream)
 {
     const void *key[4] = {A.row_ptr, A.packed, A.table, da ? (const void *)da->dd : nullptr};
-    if (pl->tried && memcmp(key, pl->key, sizeof(key)) == 0 && pl->key_n == A.n) return pl->ok;
+    if (pl->tried && memcmp(key, pl->key, sizeof(key)) == 0 && pl->key_n == A.n && pl->key_epoch == A.epoch) return pl->ok;
+    pl->key_epoch = A.epoch; // (a re-assembly with the same DOF count rewrites the same buffers: the words of the plan would be stale)
     pl->tried = true;
     pl->ok = false;
     memcpy(pl->key, key, sizeof(key));

@@ -8,6 +8,7 @@
 // of fine cells become contiguous, in reference-id order inside the brick (stable sort).  The in-row
 // entry order is NOT changed, so every row sum is still the reference's left-to-right sum
 // (bit-identical y); inputs and outputs of the C ABI stay in the reference's numbering.
+#include <atomic>
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
@@ -565,6 +566,8 @@ avs_status build_matrix_index(const int32_t *row_ptr, const int32_t *col, const 
                               ValueIndex &vi, hipStream_t st)
 {
     vi.clear();
+    static std::atomic<uint64_t> generation{0};
+    vi.epoch = ++generation;
     if (nnz == 0) return AVS_OK;
     if (const char *e = getenv("AVS_VALUE_INDEX"))
         if (atoi(e) == 0) return AVS_OK;

@@ -169,3 +169,30 @@ def test_resident_streamed_rows(mode, resident_env, built_lib):
     finally:
         for k in env:
             os.environ.pop(k, None)
+
+
+def test_resident_plan_follows_a_reassembly(resident_env, built_lib):
+    """The resident plan holds a re-encoding of the matrix WORDS.  A second assembly on the same context with the same DOF count
+    (next frame, other viscosity / density) rewrites the same device buffers: the plan must be rebuilt (it is keyed on the value
+    index's generation, not only on pointers).  The second system here has other values AND another dictionary order."""
+    sc = scenes.fat_beam(128, 3)
+    dsc = scenes.to_device(sc, torch.device("cuda:0"))
+    pyr = build_pyramid(dsc)
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
+    feed(s, pyr)
+    s.set_scene_fields(dsc)
+    s.assemble()
+    assert s.solve(1e-9, 5000).resident == 1
+    x1 = s.solution()
+    s.set_field(capi.FIELD_VISCOSITY, 0, None, 3.0)          # viscous term ~3000x smaller against the same mass term
+    s.set_field(capi.FIELD_DENSITY, 0, None, 1730.0)
+    s.assemble()
+    info = s.solve(1e-9, 5000)
+    assert info.resident == 1 and info.converged == 1
+    x2 = s.solution()
+    os.environ["AVS_CG_RESIDENT"] = "0"
+    ref = s.solve(1e-9, 5000)
+    assert ref.resident == 0 and abs(ref.iterations - info.iterations) <= 2
+    assert rel_l2(x2, s.solution()) < 1e-7
+    assert rel_l2(x2, x1) > 1e-6                              # (it is another system)
+    s.close()
