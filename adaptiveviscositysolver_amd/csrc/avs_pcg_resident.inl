@@ -891,6 +891,9 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
     int G = cus;
     if (const char *e = getenv("AVS_CG_RESIDENT_CUS")) // tests: two ranks on ONE GPU, each on a share of the CUs
         if (atoi(e) > 0 && atoi(e) < cus) G = atoi(e);
+    // Cheap refusals first (before the row pointers cross PCIe and the host walks them: 20-100 ms at 4-7 M rows, per new matrix):
+    // every workgroup keeps its slice of u in LDS next to its remote columns (never less than about half as much again)
+    if ((size_t)(n / G) * sizeof(double) > (size_t)(160 * 1024) * 65 / 100) return no("the workgroups' slices of u leave no room for their remote columns in the LDS");
     std::vector<int32_t> rp((size_t)n + 1);
     if (hipMemcpyAsync(rp.data(), A.row_ptr, rp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream) != hipSuccess ||
         hipStreamSynchronize(stream) != hipSuccess) {
