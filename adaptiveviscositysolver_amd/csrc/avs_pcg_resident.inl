@@ -1015,7 +1015,12 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
     // of those in coarse regions at equal lanes.  Then the words are re-encoded (k_resident_remap) and the LDS footprints checked:
     // a workgroup whose slices + remote columns do not fit (the ones that read the halo: up to 10 k remote columns) gets its lanes
     // re-weighted and the split is redone -- a few rounds.
-    std::vector<double> lane_w((size_t)L, 1.0), cum((size_t)L + 1, 0.);
+    std::vector<double> lane_w((size_t)L, 1.0), cum((size_t)L + 1, 0.), lane_extra((size_t)L, 0.);
+    // remote columns cost their workgroup a fill (the halo-reading workgroups fill 8-10 k and finished 5 us after the
+    // median one).  Known only after a first split: round 0 measures them, round 1 splits with them spread over the workgroup's lanes.
+    // Per slot, in the units of c_lane / c_row: 0 / 1.1 / 2 / 3 / 4.5 -> 8-way loop-back (ranks 0 / 3) 33.8 / 35.9, 32.6 / 35.0, 31.6 / 33.0,
+    // 30.0 / 32.1, 30.4 / 32.3 us per iteration.
+    const double c_rem = getenv("AVS_CG_RESIDENT_REMOTE_COST") ? atof(getenv("AVS_CG_RESIDENT_REMOTE_COST")) : 3.0;
     const double c_lane = 12.7, c_row = 3.6;
     const double kStreamCost = getenv("AVS_CG_RESIDENT_STREAM_COST") ? atof(getenv("AVS_CG_RESIDENT_STREAM_COST")) : 1.5;
     int ng = -1, lc_bits = 0, max_cols = 0;
@@ -1028,7 +1033,8 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
     for (int round = 0; round < (stream_T > 0. ? 9 : 5) && ng < 0 && !give_up; ++round) { // (large slabs: a lower tier is worth more rounds)
         for (int64_t l = 0; l < L; ++l) // (a streamed quad costs what a register quad does plus its load; 15 quads = one lane's walk)
             cum[(size_t)l + 1] = cum[(size_t)l] + lane_w[(size_t)l] * (c_lane * (1. + kStreamCost * (double)lane_sw[(size_t)l] / (double)kResQuads) +
-                                                                      c_row * (double)((lmeta[(size_t)l] & 7u) + ((lmeta[(size_t)l] >> 3) & 127u)));
+                                                                      c_row * (double)((lmeta[(size_t)l] & 7u) + ((lmeta[(size_t)l] >> 3) & 127u)) +
+                                                                      lane_extra[(size_t)l]);
         int64_t l0 = 0;
         wl[0] = 0;
         for (int b = 1; b <= G; ++b) {
@@ -1066,6 +1072,17 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
             return no("remap failed");
         }
         if (f) { last_reason = "a workgroup reads more remote columns than its source list holds"; give_up = true; break; }
+        if (round == 0 && c_rem > 0.) { // the remote columns are known now: one more split that counts them
+            bool any = false;
+            for (int b = 0; b < G; ++b) {
+                const int64_t lanes_b = wl[(size_t)b + 1] - wl[(size_t)b];
+                for (int64_t l = wl[(size_t)b]; l < wl[(size_t)b + 1]; ++l) {
+                    any = any || lane_extra[(size_t)l] == 0.;
+                    lane_extra[(size_t)l] = c_rem * (double)rc[(size_t)b] / (double)(lanes_b > 0 ? lanes_b : 1);
+                }
+            }
+            if (any) continue;
+        }
         // LDS split: every workgroup holds its slice of u + its remote-column cache, and as many of r, p, s as still fit (tiers: NG =
         // 0 .. 3 of them in global memory instead).  Footprint of workgroup b: (4 - NG) rows_b + remote_b doubles; the largest decides.
         const size_t extra = (2 * ((size_t)A.table_size + 1) + 48 + 8) * sizeof(double);
