@@ -1029,7 +1029,8 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
     for (int max_ng = std::min(1, max_ng_limit); max_ng <= max_ng_limit && ng < 0; ++max_ng) {
     if ((size_t)(4 - max_ng) * (size_t)(n / G) * sizeof(double) > lds_max) continue; // (even the average workgroup's slices would not fit)
     std::fill(lane_w.begin(), lane_w.end(), 1.0);
-    bool give_up = false;
+    std::fill(lane_extra.begin(), lane_extra.end(), 0.);
+    bool give_up = false, reweighted = false, extras_active = false, extras_off = false;
     for (int round = 0; round < (stream_T > 0. ? 9 : 5) && ng < 0 && !give_up; ++round) { // (large slabs: a lower tier is worth more rounds)
         for (int64_t l = 0; l < L; ++l) // (a streamed quad costs what a register quad does plus its load; 15 quads = one lane's walk)
             cum[(size_t)l + 1] = cum[(size_t)l] + lane_w[(size_t)l] * (c_lane * (1. + kStreamCost * (double)lane_sw[(size_t)l] / (double)kResQuads) +
@@ -1046,8 +1047,15 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
             wl[(size_t)b] = (int32_t)l1;
             l0 = l1;
         }
+        if (l0 != L && extras_active && !reweighted) { // the remote-column term alone pushed a workgroup past 1024 lanes: split without it
+            std::fill(lane_extra.begin(), lane_extra.end(), 0.);
+            extras_active = false;
+            extras_off = true;
+            --round;
+            continue;
+        }
         if (l0 != L || getenv("AVS_CG_RESIDENT_EQUAL_LANES")) {
-            if (round > 0) { give_up = true; break; } // (re-weighting pushed a workgroup past 1024 lanes: give up)
+            if (reweighted) { give_up = true; break; } // (re-weighting pushed a workgroup past 1024 lanes: give up)
             for (int b = 0; b <= G; ++b) wl[(size_t)b] = (int32_t)std::min<int64_t>((int64_t)b * lpw, L);
         }
         max_rows = 0;
@@ -1072,7 +1080,7 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
             return no("remap failed");
         }
         if (f) { last_reason = "a workgroup reads more remote columns than its source list holds"; give_up = true; break; }
-        if (round == 0 && c_rem > 0.) { // the remote columns are known now: one more split that counts them
+        if (round == 0 && c_rem > 0. && !extras_off) { // the remote columns are known now: one more split that counts them
             bool any = false;
             for (int b = 0; b < G; ++b) {
                 const int64_t lanes_b = wl[(size_t)b + 1] - wl[(size_t)b];
@@ -1081,7 +1089,7 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
                     lane_extra[(size_t)l] = c_rem * (double)rc[(size_t)b] / (double)(lanes_b > 0 ? lanes_b : 1);
                 }
             }
-            if (any) continue;
+            if (any) { extras_active = true; continue; }
         }
         // LDS split: every workgroup holds its slice of u + its remote-column cache, and as many of r, p, s as still fit (tiers: NG =
         // 0 .. 3 of them in global memory instead).  Footprint of workgroup b: (4 - NG) rows_b + remote_b doubles; the largest decides.
@@ -1109,8 +1117,10 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
             }
             for (int b = 0; b < G; ++b) {
                 const double fp = (double)(4 - t) * (double)(wr[(size_t)b + 1] - wr[(size_t)b]) + (double)rc[(size_t)b];
-                if (fp > 0.97 * limit)
+                if (fp > 0.97 * limit) {
+                    reweighted = true;
                     for (int64_t l = wl[(size_t)b]; l < wl[(size_t)b + 1]; ++l) lane_w[(size_t)l] *= 1.12 * fp / limit;
+                }
             }
         }
     }
