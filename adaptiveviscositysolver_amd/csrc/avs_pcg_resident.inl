@@ -874,6 +874,14 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
     const bool verbose = getenv("AVS_CG_RESIDENT_VERBOSE") != nullptr;
     timespec plan_t0{};
     clock_gettime(CLOCK_MONOTONIC, &plan_t0);
+    timespec stage_t = plan_t0;
+    auto stage = [&](const char *what) { // (verbose: where the plan's milliseconds go)
+        if (!verbose) return;
+        timespec t{};
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        fprintf(stderr, "[avs resident]   plan stage %-28s %.2f ms\n", what, (t.tv_sec - stage_t.tv_sec) * 1e3 + (t.tv_nsec - stage_t.tv_nsec) * 1e-6);
+        stage_t = t;
+    };
     auto no = [&](const char *why) {
         pl->why = why;
         if (verbose) fprintf(stderr, "[avs resident] not used: %s (n = %lld)\n", why, (long long)A.n);
@@ -954,15 +962,21 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
             lmeta.push_back((unsigned)rows | ((unsigned)m << 3));
         }
     };
-    form_lanes(0.);
-    if (lane_fail) return no(lane_fail);
-    double stream_T = 0.;
+    stage("row pointers to the host");
     const int64_t lane_cap = (int64_t)G * kResThreads;
-    if ((int64_t)lrow.size() > lane_cap * 93 / 100) {
+    int64_t q_total = 0;
+    for (int64_t i = 0; i < n; ++i) q_total += quads_of(i);
+    // (a slab whose quads exceed what the lanes could hold even at 14 of 15 quads each needs streamed rows for certain: the
+    // registers-only pass -- 2 ns per row on the host -- is skipped)
+    const bool surely_streams = (double)q_total > 14. * 0.93 * (double)lane_cap;
+    if (!surely_streams) form_lanes(0.);
+    if (lane_fail) return no(lane_fail);
+    stage("lanes (registers only)");
+    double stream_T = 0.;
+    if (surely_streams || (int64_t)lrow.size() > lane_cap * 93 / 100) {
         if (getenv("AVS_CG_RESIDENT_NO_STREAM")) return no("too many rows for the register files of this GPU");
-        int64_t q_total = 0;
-        for (int64_t i = 0; i < n; ++i) q_total += quads_of(i);
-        const double L0 = (double)lrow.size(), q_lane = (double)q_total / L0; // register quads an average lane holds
+        // register quads an average lane holds: measured when the registers-only pass ran, else 12.8 (4-way slab 12.9, 256^3 beam 12.7)
+        const double q_lane = surely_streams ? 12.8 : (double)q_total / (double)lrow.size();
         double Lt = 0.90 * (double)lane_cap;
         for (int attempt = 0; attempt < 8; ++attempt, Lt *= 0.97) {
             stream_T = ((double)q_total - Lt * q_lane) / Lt;
@@ -975,6 +989,7 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
     const int64_t L = (int64_t)lrow.size();
     int64_t lpw = (L + G - 1) / G;
     if (lpw > kResThreads) return no("too many rows for the register files of this GPU");
+    stage("lanes with streamed rows");
     // quads a lane streams per iteration (cost model, stream layout)
     std::vector<int32_t> lane_sw((size_t)L, 0);
     int64_t stream_words = 0;
@@ -1020,6 +1035,8 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
     // median one).  Known only after a first split: round 0 measures them, round 1 splits with them spread over the workgroup's lanes.
     // Per slot, in the units of c_lane / c_row: 0 / 1.1 / 2 / 3 / 4.5 -> 8-way loop-back (ranks 0 / 3) 33.8 / 35.9, 32.6 / 35.0, 31.6 / 33.0,
     // 30.0 / 32.1, 30.4 / 32.3 us per iteration.
+    std::vector<int32_t> rc_round0;
+    bool round0_done = false, reuse_round0 = false;
     const double c_rem = getenv("AVS_CG_RESIDENT_REMOTE_COST") ? atof(getenv("AVS_CG_RESIDENT_REMOTE_COST")) : 3.0;
     const double c_lane = 12.7, c_row = 3.6;
     const double kStreamCost = getenv("AVS_CG_RESIDENT_STREAM_COST") ? atof(getenv("AVS_CG_RESIDENT_STREAM_COST")) : 1.5;
@@ -1069,17 +1086,38 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
             (void)hipGetLastError();
             return no("plan upload failed");
         }
-        hipLaunchKernelGGL(k_resident_remap, dim3((unsigned)G), dim3(kResThreads), remap_lds, stream, A.packed, A.row_ptr, A.col_bits, lc_bits,
-                           (const int32_t *)pl->wg_row0.p, cap, (int)n_ext, pl->rwords.p, pl->rem_list.p, pl->rem_count.p, fail.p, (int)n,
-                           pl->dep_mask.p, (int)chunk_cols);
-        int f = 0;
-        if (hipMemcpyAsync(&f, fail.p, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess ||
-            hipMemcpyAsync(rc.data(), pl->rem_count.p, (size_t)G * sizeof(int32_t), hipMemcpyDeviceToHost, stream) != hipSuccess ||
-            hipStreamSynchronize(stream) != hipSuccess) {
-            (void)hipGetLastError();
-            return no("remap failed");
+        // re-encode the words for this split (the plan kernel) and fetch the remote-column counts
+        auto remap = [&]() -> int { // 0 ok, 1 a source list overflowed, -1 failure
+            hipLaunchKernelGGL(k_resident_remap, dim3((unsigned)G), dim3(kResThreads), remap_lds, stream, A.packed, A.row_ptr, A.col_bits, lc_bits,
+                               (const int32_t *)pl->wg_row0.p, cap, (int)n_ext, pl->rwords.p, pl->rem_list.p, pl->rem_count.p, fail.p, (int)n,
+                               pl->dep_mask.p, (int)chunk_cols);
+            int f = 0;
+            if (hipMemcpyAsync(&f, fail.p, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                hipMemcpyAsync(rc.data(), pl->rem_count.p, (size_t)G * sizeof(int32_t), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                hipStreamSynchronize(stream) != hipSuccess) {
+                (void)hipGetLastError();
+                return -1;
+            }
+            return f ? 1 : 0;
+        };
+        // (round 0 of a later tier is the split of the first tier's round 0: its counts are re-used, the words re-encoded only if it is accepted)
+        reuse_round0 = round == 0 && round0_done && !getenv("AVS_CG_RESIDENT_EQUAL_LANES");
+        if (reuse_round0) rc = rc_round0;
+        else {
+            const int rm = remap();
+            if (rm < 0) return no("remap failed");
+            if (rm > 0) { last_reason = "a workgroup reads more remote columns than its source list holds"; give_up = true; break; }
         }
-        if (f) { last_reason = "a workgroup reads more remote columns than its source list holds"; give_up = true; break; }
+        if (round == 0) {
+            if (!reuse_round0) { rc_round0 = rc; round0_done = true; }
+            // a tier whose TOTAL demand is close to the chip's LDS never fits (lanes, not LDS, bound the split; every further round is a
+            // re-encoding pass: 10 ms of plan time on a 1.3 M-row system): next tier
+            const int t = max_ng < 3 ? (max_ng < 0 ? 0 : max_ng) : 3;
+            const double limit0 = (double)(lds_max - (2 * ((size_t)A.table_size + 1) + 48 + 8) * sizeof(double)) / sizeof(double);
+            double demand = 0.;
+            for (int b = 0; b < G; ++b) demand += (double)(4 - t) * (double)(wr[(size_t)b + 1] - wr[(size_t)b]) + (double)rc[(size_t)b];
+            if (demand > 0.88 * limit0 * (double)G) { give_up = true; break; }
+        }
         if (round == 0 && c_rem > 0. && !extras_off) { // the remote columns are known now: one more split that counts them
             bool any = false;
             for (int b = 0; b < G; ++b) {
@@ -1106,6 +1144,10 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
             if (verbose) fprintf(stderr, "[avs resident] round %d, LDS tier %d: largest workgroup footprint %zu B (limit %zu)\n", round, t, need, lds_max);
             if (need <= lds_max) { ng = t; lds = need; }
         }
+        if (ng >= 0 && reuse_round0) { // accepted on re-used counts: the words still hold another split's encoding
+            const int rm = remap();
+            if (rm != 0) return no("remap failed");
+        }
         if (ng < 0) { // shrink the offenders (at the largest tier allowed) and split again
             const int t = max_ng < 3 ? (max_ng < 0 ? 0 : max_ng) : 3;
             const double limit = (double)(lds_max - extra) / sizeof(double);
@@ -1125,6 +1167,7 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
         }
     }
     }
+    stage("split + re-encoding rounds");
     if (verbose) {
         std::vector<int32_t> srt(rc);
         std::sort(srt.begin(), srt.end());
@@ -1193,6 +1236,7 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
          hipMemcpy(pl->push_seg.p, seg.data(), seg.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(pl->wg_halo.p, whalo.data(), whalo.size(), hipMemcpyHostToDevice) == hipSuccess;
     if (!up) { (void)hipGetLastError(); return no("plan upload failed"); }
+    stage("push segments, uploads");
     pl->streams = false;
     if (stream_words > 0) { // the waves' lane-interleaved streams of the rows that do not fit the registers
         const int wpg = kResThreads / 64;
