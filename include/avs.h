@@ -101,7 +101,8 @@ typedef struct {
     double solve_ms;    /* HIP-event time of the PCG loop */
     double spmv_ms;     /* mean HIP-event time of one SpMV launch during this solve (0 if not sampled) */
     int32_t resident;   /* 1 = the iterations ran in the CU-resident loop (one cooperative launch: matrix words in the register files,
-                           vector slices in LDS -- systems of up to ~1 M rows in the packed single-dictionary form, single-GPU solves and
+                           vector slices in LDS -- systems of up to ~1 M rows (~1.9 M with the rows that do not fit streamed from memory) in the packed
+                           single-dictionary form, single-GPU solves and
                            partitioned solves whose rank has its GPU for itself; AVS_CG_RESIDENT=0 keeps the launch-per-phase loops) */
     int32_t reserved;
 } avs_solve_info;
