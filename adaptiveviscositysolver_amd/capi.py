@@ -24,6 +24,7 @@ OK, EINVAL, ENOMEM, EHIP, ERCCL, EINTERNAL, ESTATE = range(7)
 STATUS_NAMES = {0: "AVS_OK", 1: "AVS_EINVAL", 2: "AVS_ENOMEM", 3: "AVS_EHIP", 4: "AVS_ERCCL",
                 5: "AVS_EINTERNAL", 6: "AVS_ESTATE"}
 MEM_HOST, MEM_DEVICE = 0, 1
+PRECISION_F64, PRECISION_F32 = 0, 1   # avs_desc.precision (SolveType of the reference, util.h:25-37)
 INACTIVE, ACTIVE, UP, DOWN = 0, 1, 2, 3
 UNASSIGNED, SOLIDBOUNDARY, OUTSIDE = -1, -2, -3
 INDEX_VELOCITY, INDEX_EDGE, INDEX_CENTER = 0, 1, 2
@@ -60,7 +61,7 @@ class Desc(C.Structure):
     _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("dx", C.c_double),
                 ("dt", C.c_double), ("levels", C.c_int32), ("use_enhanced_gradients", C.c_int32),
                 ("device", C.c_int32), ("stream", C.c_void_p),
-                ("field_nx", C.c_int32), ("field_ny", C.c_int32), ("field_nz", C.c_int32)]
+                ("field_nx", C.c_int32), ("field_ny", C.c_int32), ("field_nz", C.c_int32), ("precision", C.c_int32)]
 
 
 class SolveInfo(C.Structure):

@@ -88,6 +88,7 @@ avs::PyramidView avs_ctx::view() const
     P.n[1] = desc.ny;
     P.n[2] = desc.nz;
     P.enhanced = desc.use_enhanced_gradients;
+    P.f32 = desc.precision == AVS_PRECISION_F32;
     P.dx = desc.dx;
     P.dt = desc.dt;
     for (int l = 0; l < AVS_MAX_LEVELS; ++l) {
@@ -128,6 +129,7 @@ avs_status avs_create(const avs_desc *d, avs_ctx **out)
     AVS_REQUIRE(d->field_nx >= 0 && d->field_nx <= d->nx && d->field_ny >= 0 && d->field_ny <= d->ny && d->field_nz >= 0 &&
                     d->field_nz <= d->nz,
                 AVS_EINVAL, "field resolution %d %d %d must lie in [0, octree resolution]", d->field_nx, d->field_ny, d->field_nz);
+    AVS_REQUIRE(d->precision == AVS_PRECISION_F64 || d->precision == AVS_PRECISION_F32, AVS_EINVAL, "precision must be AVS_PRECISION_F64 or AVS_PRECISION_F32");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     AVS_REQUIRE(e == hipSuccess && ndev > 0, AVS_EHIP, "no HIP device available (%s)", hipGetErrorString(e));
@@ -437,6 +439,22 @@ static CsrView csr_of(avs_ctx *c)
     return A;
 }
 
+__global__ __launch_bounds__(256) void k_narrow_f32(double *__restrict__ x, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = (double)(float)x[i];
+}
+
+extern "C++" {
+namespace avs {
+void narrow_solution_if_f32(avs_ctx *c, double *x, int64_t n)
+{
+    if (c->desc.precision == AVS_PRECISION_F32 && n > 0) // viscositySolution is an Eigen::VectorXf there: what the transfer reads are float values
+        hipLaunchKernelGGL(k_narrow_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, x, n);
+}
+} // namespace avs
+} // extern "C++"
+
 avs_status avs_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_info *info)
 {
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
@@ -462,6 +480,7 @@ avs_status avs_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_info *
         AVS_HIP(hipMemcpyAsync(c->x.p, c->x0.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         AVS_TRY(pcg_solve(c->pcg, csr_of(c), c->rhs.p, c->x.p, tol, max_iters, c->stream, &local, nullptr));
     }
+    narrow_solution_if_f32(c, c->x.p, n);
     if (info) *info = local;
     c->solved = true;
     return AVS_OK;

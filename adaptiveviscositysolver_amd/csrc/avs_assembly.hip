@@ -64,6 +64,9 @@ __global__ __launch_bounds__(kBlock) void k_check_table(const int32_t *__restric
         if (table[4 * d] < 0) *err = 3;
 }
 
+// x as the fp32 build of the reference would hold it (a float value in a double)
+__device__ __forceinline__ double solve_type(double x, int f32) { return f32 ? (double)(float)x : x; }
+
 // ---------------------------------------------------------------------------------------------
 // K1: edge stress stencils
 // ---------------------------------------------------------------------------------------------
@@ -358,19 +361,19 @@ __global__ __launch_bounds__(kBlock) void k_initial_guess(PyramidView P, const i
     const FieldView &V = P.vel[axis];
     const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
     if (level == 0) {
-        x0[id] = 1.0 * (double)field_at(V, vr, face); // weight 1 (cpp:2347, 2373)
+        x0[id] = 1.0 * (double)field_at(V, vr, face); // weight 1 (cpp:2347, 2373) (an fp32 value: nothing to narrow)
     } else if (level == 1) {
         float leaf[12];
         double acc = 0.;
         gather_12(V, vr, face, axis, a1, a2, leaf);
         fold_12(1.f, leaf, acc);
-        x0[id] = acc;
+        x0[id] = solve_type(acc, P.f32); // initialGuess(octreeFaceIndex) = restrictedVelocity, cpp:2371
     } else {
         float leaf[144];
         double acc = 0.;
         gather_144(V, vr, face, axis, a1, a2, leaf);
         fold_144(1.f, leaf, acc);
-        x0[id] = acc;
+        x0[id] = solve_type(acc, P.f32); // initialGuess(octreeFaceIndex) = restrictedVelocity, cpp:2371
     }
 }
 
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(kBlock) void k_initial_guess_coarse(PyramidView P, 
                 carry = __shfl(mine, s * G + r, 64);
             }
         }
-        if (on && t == 0) x0[rid] = carry;
+        if (on && t == 0) x0[rid] = solve_type(carry, P.f32);
     }
 }
 
@@ -441,14 +444,16 @@ struct RowAcc {
     double *val;
     double diag, rhs;
     int bad;
+    int f32; // SolveType = fpreal32 (PyramidView::f32): triplets narrowed where Eigen::Triplet<SolveType> is built, rhs updated in float steps
 };
+
 
 template <bool EMIT>
 __device__ __forceinline__ void row_push(RowAcc &ra, int32_t c, double v)
 {
     if (EMIT) { // raw triplet, emission order (what the reference push_backs, cpp:2447); wave-transposed: entry k of the row
         ra.col[(size_t)ra.n * kRawStride] = c; // of lane l lives at base + 64 k + l, so the k-th push of a wave is ONE coalesced store
-        ra.val[(size_t)ra.n * kRawStride] = v;
+        ra.val[(size_t)ra.n * kRawStride] = solve_type(v, ra.f32); // Eigen::Triplet<SolveType>(row, col, element), cpp:2447 / 2768
     }
     ++ra.n;
 }
@@ -503,7 +508,7 @@ __device__ void apply_stencil(RowAcc &ra, double coefficient, int32_t vi, int cn
         } else if (j != vi) ++ra.n;
     }
     if (EMIT)
-        for (int i = 0; i < bcnt; ++i) ra.rhs -= coefficient * bval[(size_t)i * stride];
+        for (int i = 0; i < bcnt; ++i) ra.rhs = solve_type(ra.rhs - coefficient * bval[(size_t)i * stride], ra.f32); // rhs(row) -= ..., cpp:2456
 }
 
 template <bool EMIT>
@@ -558,7 +563,7 @@ __global__ __launch_bounds__(kBlock) void k_rows(PyramidView P, const int32_t *_
     const I3 face{{rec.y, rec.z, rec.w}};
     const I3 cr = cell_res(P, level);
     const I3 fr = face_res(P, level, axis);
-    RowAcc ra{0, nullptr, nullptr, 0., 0., 0};
+    RowAcc ra{0, nullptr, nullptr, 0., 0., 0, P.f32};
     if (EMIT) { // rawptr: first slot of the row's WAVE (64 consecutive rows) in the transposed raw arrays
         const size_t base = (size_t)rawptr[row >> 6] + (size_t)(row & 63);
         ra.col = raw_col + base;
@@ -647,7 +652,7 @@ __global__ __launch_bounds__(kBlock) void k_rows(PyramidView P, const int32_t *_
         if (P.dens.is_const) fw *= (double)P.dens.cval;
         else fw *= (double)sample_f32(P.dens, cell_res(P, 0), I3{{1, 1, 1}}, pos2_face(level, axis, face));
         row_push<true>(ra, vi, fw + ra.diag);
-        ra.rhs += fw * x0[vi]; // x0 is indexed by DOF
+        ra.rhs = solve_type(ra.rhs + fw * x0[vi], ra.f32); // x0 is indexed by DOF (cpp:2772; x0 already holds SolveType values)
         rhs[row] = ra.rhs;
     } else ++ra.n;
     if (EMIT) {
@@ -790,6 +795,13 @@ __global__ __launch_bounds__(kBlock) void k_unique_rows(int64_t n, const int32_t
 
 static constexpr int kMergeLds = 1088; // merged entries of one wave staged in LDS (64 rows x 17; interior rows have 15): 12.75 KiB per wave, 3 workgroups per CU
 
+// F32: the duplicates of SolveType = fpreal32 triplets are summed in float (Eigen::SparseMatrix<float>::setFromTriplets); the raw values
+// are float values already (row_push)
+template <bool F32> __device__ __forceinline__ double merge_add(double a, double b)
+{
+    return F32 ? (double)((float)a + (float)b) : a + b;
+}
+template <bool F32>
 __global__ __launch_bounds__(kBlock) void k_merge_rows(int64_t n, const int32_t *__restrict__ rawptr, const int32_t *__restrict__ raw_col,
                                                        const double *__restrict__ raw_val, const int32_t *__restrict__ row_count,
                                                        const int32_t *__restrict__ row_ptr, int32_t *__restrict__ col, double *__restrict__ val)
@@ -833,7 +845,7 @@ __global__ __launch_bounds__(kBlock) void k_merge_rows(int64_t n, const int32_t 
                 for (int j = 0; j < k; ++j) {
                     const bool eq = c[j] == c[k];
                     dup |= eq;
-                    v[j] = eq ? v[j] + v[k] : v[j];
+                    v[j] = eq ? merge_add<F32>(v[j], v[k]) : v[j];
                 }
                 if (k < R && !dup) m |= 1u << k;
             }
@@ -883,7 +895,7 @@ __global__ __launch_bounds__(kBlock) void k_merge_rows(int64_t n, const int32_t 
                     const int32_t cq = __builtin_amdgcn_readlane(cb, q);
                     const double vq = lane_bcast(vb, q);
                     if (cq >= 0 && cq < c_e) ++urank;                                   // first occurrences only
-                    if (first && b0 + q > e && (cq & kColMask) == c_e) sum = sum + vq; // left fold in emission order
+                    if (first && b0 + q > e && (cq & kColMask) == c_e) sum = merge_add<F32>(sum, vq); // left fold in emission order
                 }
             }
             if (first) {
@@ -910,7 +922,7 @@ __global__ __launch_bounds__(kBlock) void k_merge_rows(int64_t n, const int32_t 
             const int32_t cq = __builtin_amdgcn_readlane(c_e, q);
             const double vq = lane_bcast(v_e, q);
             if (((firsts >> q) & 1ull) && cq < c_e) ++urank;
-            if (first && q > lane && cq == c_e) sum = sum + vq; // left fold in emission order
+            if (first && q > lane && cq == c_e) sum = merge_add<F32>(sum, vq); // left fold in emission order
         }
         if (first) {
             ocw[dr - ooff + urank] = c_e;
@@ -1260,8 +1272,12 @@ avs_status assemble_rows(avs_ctx *c, const int32_t *ids, int64_t m, DevBuf<int32
     AVS_TRY(col.alloc((size_t)nnz));
     AVS_TRY(val.alloc((size_t)nnz));
     // K6b + K7: rank, fold, write the final CSR
-    if (n) hipLaunchKernelGGL(k_merge_rows, dim3(grid_for(n)), dim3(kBlock), 0, st, n, (const int32_t *)rawptr.p, (const int32_t *)raw_col.p,
-                              (const double *)raw_val.p, (const int32_t *)row_count.p, (const int32_t *)row_ptr.p, col.p, val.p);
+    if (n && c->desc.precision == AVS_PRECISION_F32)
+        hipLaunchKernelGGL(k_merge_rows<true>, dim3(grid_for(n)), dim3(kBlock), 0, st, n, (const int32_t *)rawptr.p, (const int32_t *)raw_col.p,
+                           (const double *)raw_val.p, (const int32_t *)row_count.p, (const int32_t *)row_ptr.p, col.p, val.p);
+    else if (n)
+        hipLaunchKernelGGL(k_merge_rows<false>, dim3(grid_for(n)), dim3(kBlock), 0, st, n, (const int32_t *)rawptr.p, (const int32_t *)raw_col.p,
+                           (const double *)raw_val.p, (const int32_t *)row_count.p, (const int32_t *)row_ptr.p, col.p, val.p);
     AVS_HIP(hipGetLastError());
     AVS_HIP(hipStreamSynchronize(st)); // the caller may read nnz-sized results right away; the raw buffers stay in the context
     return AVS_OK;

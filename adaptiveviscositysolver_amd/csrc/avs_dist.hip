@@ -1859,6 +1859,7 @@ avs_status avs_dist_get_solution(avs_ctx *c, double *x, int64_t n, avs_memspace 
     AVS_TRY(c->x.alloc((size_t)n));
     if (d->reordered) AVS_TRY(unpermute(c, full.p, c->x.p)); // back to the reference's DOF numbering
     else AVS_HIP(hipMemcpyAsync(c->x.p, full.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    narrow_solution_if_f32(c, c->x.p, n);
     c->solved = true;
     AVS_HIP(copy_out(x, c->x.p, (size_t)n * sizeof(double), where, st));
     AVS_HIP(hipStreamSynchronize(st));

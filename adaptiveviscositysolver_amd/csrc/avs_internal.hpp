@@ -135,6 +135,7 @@ struct PyramidView {
     int levels;
     int n[3];
     int enhanced;
+    int f32; // avs_desc::precision == AVS_PRECISION_F32: the narrowing points of SolveType = fpreal32
     double dx, dt;
     const int8_t *labels[AVS_MAX_LEVELS];
     const int32_t *vidx[AVS_MAX_LEVELS][3];
@@ -232,6 +233,9 @@ struct ValueIndex {
 // ones: smoothly varying viscosity), else one dictionary of <= 65536 values, else plain CSR
 avs_status build_matrix_index(const int32_t *row_ptr, const int32_t *col, const double *val, int64_t n, int64_t nnz, int64_t n_cols,
                               ValueIndex &vi, hipStream_t st);
+
+// avs_desc::precision == AVS_PRECISION_F32: the solution as the reference's Eigen::VectorXf holds it (avs_api.hip)
+void narrow_solution_if_f32(avs_ctx *c, double *x, int64_t n);
 
 // PCG work space + device scalars (see avs_pcg.hip)
 struct PcgWork;

@@ -23,14 +23,14 @@ class ViscositySolve:
         x = s.solution()                                  # viscositySolution, consumed by cpp:661-707
     """
 
-    def __init__(self, res, dx, dt, levels, use_enhanced_gradients=True, device=0, stream=None, field_res=None):
+    def __init__(self, res, dx, dt, levels, use_enhanced_gradients=True, device=0, stream=None, field_res=None, precision=capi.PRECISION_F64):
         """`res`: octree (power-of-two) level-0 resolution; `field_res`: resolution of the simulation grid the scalar
         fields live on when HDK_OctreeGrid::init had to pad it (oct.cpp:13-24); None = res."""
         self.lib = capi.load()
         self.res = tuple(int(r) for r in res)
         fr = tuple(int(r) for r in field_res) if field_res is not None else (0, 0, 0)
         d = capi.Desc(self.res[0], self.res[1], self.res[2], float(dx), float(dt), int(levels),
-                      int(bool(use_enhanced_gradients)), int(device), C.c_void_p(stream or 0), fr[0], fr[1], fr[2])
+                      int(bool(use_enhanced_gradients)), int(device), C.c_void_p(stream or 0), fr[0], fr[1], fr[2], int(precision))
         h = C.c_void_p()
         capi.check(self.lib.avs_create(C.byref(d), C.byref(h)))
         self.h = h

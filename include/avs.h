@@ -89,7 +89,15 @@ typedef struct {
      * density by border replication, everything else with 0).  The pre-pass takes the same field_n* in its own descriptor;
      * avs_set_regular_index_field / avs_transfer_to_regular_grid exchange arrays on the simulation grid's face lattices. */
     int32_t field_nx, field_ny, field_nz;
+    /* AVS_PRECISION_F64 (0, default): SolveType = fpreal64, the build the reference ships.  AVS_PRECISION_F32: the system the
+     * reference builds with USESINGLEPRECISION (util.h:25-37: SolveType = fpreal32): every triplet narrowed to float where
+     * Eigen::Triplet<SolveType> is constructed (cpp:2447, 2768), duplicates summed in float (setFromTriplets, cpp:613-614), the
+     * right-hand side updated in float steps (cpp:2456, 2772), the initial guess narrowed at its store (cpp:2371).  Matrix, rhs and
+     * x0 are then float VALUES in the same fp64 arrays (bit-exact against the oracle's f32 mode); the PCG iterates on that system in
+     * fp64 (at least as accurate as Eigen's float CG, same stopping rule) and the solution is narrowed to float (Eigen::VectorXf). */
+    int32_t precision;
 } avs_desc;
+enum { AVS_PRECISION_F64 = 0, AVS_PRECISION_F32 = 1 };
 
 typedef struct {
     int32_t iterations; /* solver.iterations() (cpp:629) */

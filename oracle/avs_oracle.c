@@ -41,6 +41,7 @@ struct orc_ctx {
     int n[3];
     double dx, dt;
     int desired_levels, levels, enhanced;
+    int f32; /* SolveType = fpreal32 (USESINGLEPRECISION, util.h:25-37): see orc_set_precision */
 
     fieldf liquid, solid, visc, dens, vel[3], solidvel[3], facew[3], centerw, edgew[3];
 
@@ -1345,7 +1346,7 @@ int orc_build_initial_guess(orc_ctx *c)
         /* depth-first recursion visits the leaves in the same order as the reference's FIFO
          * queue pops them (both are lexicographic in (child, offset) per level) */
         restrict_rec(c, axis, face, 1.f, level, vr, &acc);
-        c->x0[id] = acc;
+        c->x0[id] = c->f32 ? (double)(float)acc : acc; /* initialGuess(octreeFaceIndex) = restrictedVelocity (a VectorXf element), cpp:2371 */
     }
     return 0;
 }
@@ -1359,7 +1360,9 @@ typedef struct {
     double *val;
     double diag, rhs;
     int bad;
+    int f32; /* Eigen::Triplet<float> / VectorXf semantics */
 } rowacc;
+static inline double solve_type(double x, int f32) { return f32 ? (double)(float)x : x; }
 
 /* applyToMatrix, cpp:2404-2457 */
 static void apply_to_matrix(rowacc *ra, double coefficient, int32_t vi, int cnt, const int32_t *idx,
@@ -1380,12 +1383,12 @@ static void apply_to_matrix(rowacc *ra, double coefficient, int32_t vi, int cnt,
         else {
             if (ra->col) {
                 ra->col[ra->n] = idx[(size_t)i * stride];
-                ra->val[ra->n] = element;
+                ra->val[ra->n] = solve_type(element, ra->f32); /* Eigen::Triplet<SolveType>(row, col, element), cpp:2447 */
             }
             ra->n++;
         }
     }
-    for (int i = 0; i < bcnt; ++i) ra->rhs -= coefficient * bval[(size_t)i * bstride];
+    for (int i = 0; i < bcnt; ++i) ra->rhs = solve_type(ra->rhs - coefficient * bval[(size_t)i * bstride], ra->f32); /* cpp:2456 */
 }
 
 static inline void apply_edge(const orc_ctx *c, rowacc *ra, int32_t vi, int32_t eid)
@@ -1526,16 +1529,16 @@ static void assemble_row(const orc_ctx *c, int32_t vi, rowacc *ra)
     }
     if (ra->col) {
         ra->col[ra->n] = vi;
-        ra->val[ra->n] = fw + ra->diag; /* cpp:2768 */
+        ra->val[ra->n] = solve_type(fw + ra->diag, ra->f32); /* cpp:2768 */
     }
     ra->n++;
-    ra->rhs += fw * c->x0[vi]; /* cpp:2772 */
+    ra->rhs = solve_type(ra->rhs + fw * c->x0[vi], ra->f32); /* cpp:2772 */
 }
 
 /* Eigen::SparseMatrix::setFromTriplets (cpp:613-614; Eigen is not vendored -- any 3.3/3.4):
  * duplicates of one (row, col) are summed left to right in triplet order, then each column is
  * sorted by row.  A is stored column-major in Eigen; CSR of the same matrix is built here. */
-static int64_t compress_row(int64_t n, int32_t *col, double *val)
+static int64_t compress_row(int64_t n, int32_t *col, double *val, int f32)
 {
     /* stable insertion sort by column */
     for (int64_t i = 1; i < n; ++i) {
@@ -1552,7 +1555,7 @@ static int64_t compress_row(int64_t n, int32_t *col, double *val)
     }
     int64_t m = 0;
     for (int64_t i = 0; i < n; ++i) {
-        if (m > 0 && col[m - 1] == col[i]) val[m - 1] = val[m - 1] + val[i];
+        if (m > 0 && col[m - 1] == col[i]) val[m - 1] = f32 ? (double)((float)val[m - 1] + (float)val[i]) : val[m - 1] + val[i];
         else {
             col[m] = col[i];
             val[m] = val[i];
@@ -1576,7 +1579,7 @@ int orc_assemble(orc_ctx *c)
     int bad = 0;
 #pragma omp parallel for schedule(static) reduction(| : bad)
     for (int64_t i = 0; i < n; ++i) {
-        rowacc ra = {0, NULL, NULL, 0., 0., 0};
+        rowacc ra = {0, NULL, NULL, 0., 0., 0, c->f32};
         assemble_row(c, (int32_t)i, &ra);
         rawptr[i + 1] = ra.n;
         bad |= ra.bad;
@@ -1589,10 +1592,10 @@ int orc_assemble(orc_ctx *c)
     if (!rc || !rv) { free(rawptr); free(rc); free(rv); return 2; }
 #pragma omp parallel for schedule(static) reduction(| : bad)
     for (int64_t i = 0; i < n; ++i) {
-        rowacc ra = {0, rc + rawptr[i], rv + rawptr[i], 0., 0., 0};
+        rowacc ra = {0, rc + rawptr[i], rv + rawptr[i], 0., 0., 0, c->f32};
         assemble_row(c, (int32_t)i, &ra);
         c->rhs[i] = ra.rhs;
-        c->row_ptr[i + 1] = compress_row(ra.n, rc + rawptr[i], rv + rawptr[i]);
+        c->row_ptr[i + 1] = compress_row(ra.n, rc + rawptr[i], rv + rawptr[i], c->f32);
         bad |= ra.bad;
     }
     for (int64_t i = 0; i < n; ++i) c->row_ptr[i + 1] += c->row_ptr[i];
@@ -2325,9 +2328,96 @@ done:
     return 0;
 }
 
+/* Eigen::ConjugateGradient<SparseMatrix<float>, Lower|Upper> (USESINGLEPRECISION): the algorithm above with every scalar and vector a float
+ * (dots accumulate in float, left to right -- Eigen's vectorised reduction order is not reproduced; the GPU side is compared to the
+ * SOLUTION within a tolerance).  The system arrives as float values in double arrays. */
+static int orc_pcg_csr_f32(int64_t n, const int64_t *row_ptr, const int32_t *col, const double *val, const double *b, double *x,
+                           double tol_d, int max_iters, orc_pcg_info *info)
+{
+    const int64_t nnz = row_ptr[n];
+    float *v = (float *)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(float));
+    float *xf = (float *)malloc((size_t)(n > 0 ? n : 1) * 6 * sizeof(float));
+    if (!v || !xf) { free(v); free(xf); return 2; }
+    float *r = xf + n, *p = r + n, *z = p + n, *tmp = z + n, *invd = tmp + n;
+    for (int64_t k = 0; k < nnz; ++k) v[k] = (float)val[k];
+    for (int64_t i = 0; i < n; ++i) xf[i] = (float)x[i];
+    const float tol = (float)tol_d;
+    const double t0 = now_s();
+    for (int64_t i = 0; i < n; ++i) {
+        float d = 0.f;
+        int have = 0;
+        for (int64_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k)
+            if (col[k] == i) { d = v[k]; have = 1; }
+        invd[i] = (have && d != 0.f) ? 1.f / d : 1.f;
+    }
+#define SPMV_F(src, dst) for (int64_t i_ = 0; i_ < n; ++i_) { float s_ = 0.f; for (int64_t k_ = row_ptr[i_]; k_ < row_ptr[i_ + 1]; ++k_) s_ += v[k_] * (src)[col[k_]]; (dst)[i_] = s_; }
+#define DOT_F(a_, b_, out_) { float s_ = 0.f; for (int64_t i_ = 0; i_ < n; ++i_) s_ += (a_)[i_] * (b_)[i_]; out_ = s_; }
+    int iters = 0;
+    float err = 0.f, rhsNorm2, residualNorm2;
+    SPMV_F(xf, tmp);
+    for (int64_t i = 0; i < n; ++i) r[i] = (float)b[i] - tmp[i];
+    { float s_ = 0.f; for (int64_t i = 0; i < n; ++i) s_ += (float)b[i] * (float)b[i]; rhsNorm2 = s_; }
+    if (rhsNorm2 == 0.f) {
+        for (int64_t i = 0; i < n; ++i) xf[i] = 0.f;
+    } else {
+        float threshold = tol * tol * rhsNorm2;
+        if (threshold < 1.17549435e-38f) threshold = 1.17549435e-38f;
+        DOT_F(r, r, residualNorm2);
+        if (residualNorm2 >= threshold) {
+            for (int64_t i = 0; i < n; ++i) p[i] = invd[i] * r[i];
+            float absNew;
+            DOT_F(r, p, absNew);
+            int i = 0;
+            while (i < max_iters) {
+                SPMV_F(p, tmp);
+                float pq;
+                DOT_F(p, tmp, pq);
+                const float alpha = absNew / pq;
+                for (int64_t k = 0; k < n; ++k) xf[k] += alpha * p[k];
+                for (int64_t k = 0; k < n; ++k) r[k] -= alpha * tmp[k];
+                DOT_F(r, r, residualNorm2);
+                if (residualNorm2 < threshold) break;
+                for (int64_t k = 0; k < n; ++k) z[k] = invd[k] * r[k];
+                const float absOld = absNew;
+                DOT_F(r, z, absNew);
+                const float beta = absNew / absOld;
+                for (int64_t k = 0; k < n; ++k) p[k] = z[k] + beta * p[k];
+                i++;
+            }
+            iters = i;
+        }
+        err = sqrtf(residualNorm2 / rhsNorm2);
+    }
+#undef SPMV_F
+#undef DOT_F
+    for (int64_t i = 0; i < n; ++i) x[i] = (double)xf[i];
+    if (info) {
+        info->iterations = iters;
+        info->error = (double)err;
+        info->rhs_norm2 = (double)rhsNorm2;
+        info->seconds = now_s() - t0;
+        info->spmv_seconds = 0.;
+        info->threads = 1;
+    }
+    free(v); free(xf);
+    return 0;
+}
+
+/* 0 = SolveType fpreal64 (default), 1 = fpreal32: set before orc_build_initial_guess / orc_assemble */
+int orc_set_precision(orc_ctx *c, int f32)
+{
+    if (!c || (f32 != 0 && f32 != 1)) return 1;
+    c->f32 = f32;
+    return 0;
+}
+
 int orc_solve(orc_ctx *c, double tol, int max_iters, int threads, double *x_out, orc_pcg_info *info)
 {
     if (!c->row_ptr || !c->x0) return 3;
+    if (c->f32) {
+        memcpy(x_out, c->x0, (size_t)c->nvel * sizeof(double));
+        return orc_pcg_csr_f32(c->nvel, c->row_ptr, c->col, c->val, c->rhs, x_out, tol, max_iters, info);
+    }
     memcpy(x_out, c->x0, (size_t)c->nvel * sizeof(double)); /* solveWithGuess(rhs, guess) cpp:627 */
     return orc_pcg_csr(c->nvel, c->row_ptr, c->col, c->val, c->rhs, x_out, tol, max_iters, threads, info);
 }

@@ -117,6 +117,10 @@ int orc_pcg_csr_ex(int64_t n, const int64_t *row_ptr, const int32_t *col, const 
                    orc_pcg_info *info);
 int orc_spmv_csr(int64_t n, const int64_t *row_ptr, const int32_t *col, const double *val,
                  const double *x, double *y, int threads);
+/* SolveType of the reference (util.h:25-37): 0 = fpreal64 (default), 1 = fpreal32 (USESINGLEPRECISION): triplets narrowed to float where
+ * Eigen::Triplet<SolveType> is built, duplicates summed in float, rhs updated in float steps, initial guess narrowed at its store, the
+ * CG run with float scalars and vectors.  Call before orc_build_initial_guess / orc_assemble.  Outputs stay double arrays (float values). */
+int orc_set_precision(orc_ctx *c, int f32);
 int orc_solve(orc_ctx *c, double tol, int max_iters, int threads, double *x_out, orc_pcg_info *info);
 
 /* ---- post-solve transfer (cpp:655-707) ---------------------------------

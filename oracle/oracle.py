@@ -84,6 +84,8 @@ def lib():
         L.orc_pcg_csr.argtypes = [i64, vp, vp, vp, vp, vp, f64, i32, i32, C.POINTER(PcgInfo)]
         L.orc_spmv_csr.argtypes = [i64, vp, vp, vp, vp, vp, i32]
         L.orc_solve.argtypes = [vp, f64, i32, i32, vp, C.POINTER(PcgInfo)]
+        L.orc_set_precision.argtypes = [vp, i32]
+        L.orc_set_precision.restype = i32
         L.orc_build_regular_indices.argtypes = [vp, f64]
         L.orc_regular_count.restype = i64
         L.orc_regular_count.argtypes = [vp]
@@ -121,11 +123,14 @@ class Csr:
 class Oracle:
     """One viscosity step on the CPU: pre-pass -> stencils -> CSR -> Jacobi-PCG."""
 
-    def __init__(self, nx, ny, nz, dx, dt, levels=4, use_enhanced_gradients=True):
+    def __init__(self, nx, ny, nz, dx, dt, levels=4, use_enhanced_gradients=True, f32=False):
+        """f32: SolveType = fpreal32 (the reference built with USESINGLEPRECISION, util.h:25-37)."""
         self.L = lib()
         self.h = self.L.orc_create(nx, ny, nz, dx, dt, levels, int(bool(use_enhanced_gradients)))
         if not self.h:
             raise ValueError("oracle: bad descriptor (resolution must be powers of two)")
+        if f32:
+            _chk(self.L.orc_set_precision(self.h, 1), "set_precision")
         self.res = (nx, ny, nz)
         self.dx, self.dt = dx, dt
 

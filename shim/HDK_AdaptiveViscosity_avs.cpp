@@ -248,6 +248,9 @@ bool HDK_AdaptiveViscosity::solveGasSubclass(SIM_Engine &engine, SIM_Object *obj
     d.dt = timestep;                                   // cpp:130
     d.levels = pinfo.levels;
     d.use_enhanced_gradients = getUseEnhancedGradients() ? 1 : 0;
+#ifdef USESINGLEPRECISION // HDK_Utilities.h:25-37: SolveType = fpreal32
+    d.precision = AVS_PRECISION_F32;
+#endif
     d.device = 0;
     if (!check(avs_create(&d, &h.ctx))) return false;
     if (!check(avs_prepass_apply(h.pp, h.ctx))) return false;  // labels, index pyramids, counts, centre / edge weights, regular indices

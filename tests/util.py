@@ -17,10 +17,10 @@ def _np(t):
     return t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
 
 
-def oracle_for_scene(sc, enhanced=None):
-    """CPU oracle loaded with the fields of a scenes.Scene (host tensors)."""
+def oracle_for_scene(sc, enhanced=None, f32=False):
+    """CPU oracle loaded with the fields of a scenes.Scene (host tensors).  f32: SolveType = fpreal32 (USESINGLEPRECISION)."""
     o = O.Oracle(*sc.res, sc.dx, sc.dt, sc.levels,
-                 sc.use_enhanced_gradients if enhanced is None else enhanced)
+                 sc.use_enhanced_gradients if enhanced is None else enhanced, f32=f32)
     o.set_field(O.F_LIQUID, _np(sc.liquid))
     if sc.solid is not None:
         o.set_field(O.F_SOLID, _np(sc.solid))
