@@ -93,7 +93,7 @@ typedef struct {
      * reference builds with USESINGLEPRECISION (util.h:25-37: SolveType = fpreal32): every triplet narrowed to float where
      * Eigen::Triplet<SolveType> is constructed (cpp:2447, 2768), duplicates summed in float (setFromTriplets, cpp:613-614), the
      * right-hand side updated in float steps (cpp:2456, 2772), the initial guess narrowed at its store (cpp:2371).  Matrix, rhs and
-     * x0 are then float VALUES in the same fp64 arrays (bit-exact against the oracle's f32 mode); the PCG iterates on that system in
+     * x0 are then float VALUES in the same fp64 arrays; the PCG iterates on that system in
      * fp64 (at least as accurate as Eigen's float CG, same stopping rule) and the solution is narrowed to float (Eigen::VectorXf). */
     int32_t precision;
 } avs_desc;
