@@ -977,14 +977,14 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
         if (getenv("AVS_CG_RESIDENT_NO_STREAM")) return no("too many rows for the register files of this GPU");
         // register quads an average lane holds: measured when the registers-only pass ran, else 12.8 (4-way slab 12.9, 256^3 beam 12.7)
         const double q_lane = surely_streams ? 12.8 : (double)q_total / (double)lrow.size();
-        double Lt = 0.90 * (double)lane_cap;
+        double Lt = (getenv("AVS_CG_RESIDENT_LANE_FILL") ? atof(getenv("AVS_CG_RESIDENT_LANE_FILL")) : 0.90) * (double)lane_cap;
         for (int attempt = 0; attempt < 8; ++attempt, Lt *= 0.97) {
             stream_T = ((double)q_total - Lt * q_lane) / Lt;
             form_lanes(stream_T);
             if (lane_fail) return no(lane_fail);
-            if ((int64_t)lrow.size() <= lane_cap * 93 / 100) break;
+            if ((int64_t)lrow.size() <= lane_cap * 96 / 100) break;
         }
-        if ((int64_t)lrow.size() > lane_cap * 95 / 100) return no("too many rows for the register files of this GPU, even with streamed rows");
+        if ((int64_t)lrow.size() > lane_cap * 97 / 100) return no("too many rows for the register files of this GPU, even with streamed rows");
     }
     const int64_t L = (int64_t)lrow.size();
     int64_t lpw = (L + G - 1) / G;
