@@ -25,6 +25,8 @@ STATUS_NAMES = {0: "AVS_OK", 1: "AVS_EINVAL", 2: "AVS_ENOMEM", 3: "AVS_EHIP", 4:
                 5: "AVS_EINTERNAL", 6: "AVS_ESTATE"}
 MEM_HOST, MEM_DEVICE = 0, 1
 PRECISION_F64, PRECISION_F32 = 0, 1   # avs_desc.precision (SolveType of the reference, util.h:25-37)
+OPTION_PRECONDITIONER = 0             # avs_set_solver_option
+PRECONDITIONER_JACOBI, PRECONDITIONER_NONE = 0, 1
 INACTIVE, ACTIVE, UP, DOWN = 0, 1, 2, 3
 UNASSIGNED, SOLIDBOUNDARY, OUTSIDE = -1, -2, -3
 INDEX_VELOCITY, INDEX_EDGE, INDEX_CENTER = 0, 1, 2
@@ -35,7 +37,7 @@ INDEX_VELOCITY, INDEX_EDGE, INDEX_CENTER = 0, 1, 2
 EXPORTED_SYMBOLS = [
     "avs_last_error", "avs_version", "avs_create", "avs_destroy", "avs_set_labels",
     "avs_set_index_field", "avs_set_dof_counts", "avs_set_scalar_field", "avs_build_stencils",
-    "avs_build_initial_guess", "avs_build_system", "avs_assemble", "avs_solve",
+    "avs_build_initial_guess", "avs_build_system", "avs_assemble", "avs_solve", "avs_set_solver_option",
     "avs_get_assembly_info", "avs_get_matrix_format", "avs_get_solution", "avs_get_initial_guess", "avs_get_csr",
     "avs_get_edge_stencils", "avs_get_center_stencils", "avs_pcg_csr", "avs_spmv_csr",
     "avs_bench_spmv", "avs_spmv_sell", "avs_bench_stream", "avs_prepass_create", "avs_prepass_destroy", "avs_prepass_run",
@@ -134,6 +136,7 @@ def load():
     L.avs_build_system.argtypes = [vp]
     L.avs_assemble.argtypes = [vp, C.POINTER(AssemblyInfo)]
     L.avs_solve.argtypes = [vp, f64, i32, C.POINTER(SolveInfo)]
+    L.avs_set_solver_option.argtypes = [vp, i32, i32]
     L.avs_get_assembly_info.argtypes = [vp, C.POINTER(AssemblyInfo)]
     L.avs_get_matrix_format.argtypes = [vp, C.POINTER(MatrixFormat)]
     L.avs_get_solution.argtypes = [vp, vp, i64, i32]

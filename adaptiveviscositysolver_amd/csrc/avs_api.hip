@@ -436,6 +436,7 @@ static CsrView csr_of(avs_ctx *c)
     A.col = c->reordered ? c->p_col.p : c->col.p;
     A.val = c->reordered ? c->p_val.p : c->val.p;
     if (c->reordered) c->vi.apply(A);
+    A.no_precond = c->no_precond;
     return A;
 }
 
@@ -443,6 +444,15 @@ __global__ __launch_bounds__(256) void k_narrow_f32(double *__restrict__ x, int6
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) x[i] = (double)(float)x[i];
+}
+
+avs_status avs_set_solver_option(avs_ctx *c, avs_solver_option option, int32_t value)
+{
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(option == AVS_OPTION_PRECONDITIONER, AVS_EINVAL, "unknown solver option %d", (int)option);
+    AVS_REQUIRE(value == AVS_PRECONDITIONER_JACOBI || value == AVS_PRECONDITIONER_NONE, AVS_EINVAL, "preconditioner must be JACOBI or NONE");
+    c->no_precond = value == AVS_PRECONDITIONER_NONE;
+    return AVS_OK;
 }
 
 extern "C++" {

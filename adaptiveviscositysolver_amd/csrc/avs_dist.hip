@@ -1765,6 +1765,7 @@ avs_status avs_dist_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_i
     A.col = d->col.p;
     A.val = d->val.p;
     d->vi.apply(A);
+    A.no_precond = c->no_precond;
     avs_solve_info local{};
     const avs_status rc = pcg_solve(d->pcg, A, d->rhs.p, d->x.p, tol, max_iters, c->stream, &local, d);
     if (rc != AVS_OK) {

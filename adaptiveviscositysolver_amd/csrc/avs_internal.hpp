@@ -200,6 +200,7 @@ struct CsrView {
     // generation of the value index these pointers belong to (build_matrix_index): plans derived from the WORDS (the CU-resident loop's
     // re-encoding) are keyed on it -- a re-assembly may rewrite the same buffers
     uint64_t epoch = 0;
+    int no_precond = 0; // AVS_PRECONDITIONER_NONE: the inverse diagonal the loops multiply with is 1 everywhere
 };
 constexpr int kCwinOffBits = 14, kCwinSlotBits = 6, kCwinSlots = 1 << kCwinSlotBits, kCwinCodeBits = 32 - kCwinOffBits - kCwinSlotBits;
 
@@ -383,6 +384,7 @@ struct avs_ctx {
     };
     Field centerw, edgew[3], facew[3], visc, dens, vel[3], solidvel[3];
     int64_t n_vel = -1, n_edge = -1, n_center = -1;
+    int no_precond = 0; // avs_set_solver_option(AVS_OPTION_PRECONDITIONER, AVS_PRECONDITIONER_NONE)
 
     // dof tables: 4 x int32 per dof (level | axis << 8, i, j, k)
     avs::DevBuf<int32_t> vdof, edof, cdof;

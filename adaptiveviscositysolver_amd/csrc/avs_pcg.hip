@@ -1164,7 +1164,7 @@ __global__ __launch_bounds__(kBlock) void k_inv_diag(CsrView A, double *__restri
     double d = 0.;
     for (int k = A.row_ptr[i]; k < A.row_ptr[i + 1]; ++k)
         if (A.col[k] == (int32_t)i) d = A.val ? A.val[k] : A.table[(A.tab_ptr ? A.tab_ptr[i / kTileRows] : 0) + A.codes[k]];
-    invd[i] = (d != 0.) ? 1. / d : 1.;
+    invd[i] = (d != 0. && !A.no_precond) ? 1. / d : 1.; // (no_precond: plain CG, z = r)
 }
 
 // r = b - t ; partials: [0..g) b.b, [g..2g) r.r
@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(kBlock) void k_inv_diag_coded(CsrView A, uint16_t *
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i <= A.table_size) {
         const double d = i < A.table_size ? A.table[i] : 0.;
-        invtab[i] = (d != 0.) ? 1. / d : 1.;
+        invtab[i] = (d != 0. && !A.no_precond) ? 1. / d : 1.;
     }
     if (i >= A.n) return;
     unsigned code = (unsigned)A.table_size;

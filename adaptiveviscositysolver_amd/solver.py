@@ -118,6 +118,10 @@ class ViscositySolve:
             else:
                 put(capi.FIELD_SOLID_VELOCITY, a, scene.solid_velocity[a])
 
+    def set_solver_option(self, option, value):
+        """avs_set_solver_option: e.g. (capi.OPTION_PRECONDITIONER, capi.PRECONDITIONER_NONE) = plain CG (cpp:638-642)."""
+        capi.check(self.lib.avs_set_solver_option(self.h, int(option), int(value)))
+
     # ---- hot path -------------------------------------------------------------------------
     def build_stencils(self):
         capi.check(self.lib.avs_build_stencils(self.h))

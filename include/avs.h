@@ -164,6 +164,15 @@ avs_status avs_assemble(avs_ctx *ctx, avs_assembly_info *info /* may be NULL */)
  * ---------------------------------------------------------------------------------------- */
 avs_status avs_solve(avs_ctx *ctx, double tolerance, int32_t max_iterations, avs_solve_info *info);
 
+/* Solver options of the context (set any time before avs_solve / avs_dist_solve; the default is what the USEEIGEN build does).
+ * AVS_OPTION_PRECONDITIONER: AVS_PRECONDITIONER_JACOBI (0, default: Eigen's DiagonalPreconditioner, cpp:618) or
+ * AVS_PRECONDITIONER_NONE (1): plain CG, what the build WITHOUT USEEIGEN asks of HDK's UT_SparseMatrixRowT::solveConjugateGradient
+ * (cpp:638-642: the preconditioner argument is nullptr).  That routine is closed source: the recurrence is standard CG, the stopping
+ * rule used here stays Eigen's (|r|^2 < tol^2 |b|^2), and the result is only pinned to that extent. */
+typedef enum { AVS_OPTION_PRECONDITIONER = 0 } avs_solver_option;
+enum { AVS_PRECONDITIONER_JACOBI = 0, AVS_PRECONDITIONER_NONE = 1 };
+avs_status avs_set_solver_option(avs_ctx *ctx, avs_solver_option option, int32_t value);
+
 /* ------------------------------------------------------------------------------------------
  * Outputs.  avs_get_solution is what cpp:661-707 consumes (viscositySolution).
  * The others exist for parity tests.  Any pointer may be NULL to skip that array.

@@ -42,6 +42,7 @@ struct orc_ctx {
     double dx, dt;
     int desired_levels, levels, enhanced;
     int f32; /* SolveType = fpreal32 (USESINGLEPRECISION, util.h:25-37): see orc_set_precision */
+    int no_precond; /* plain CG (the build without USEEIGEN passes no preconditioner, cpp:638-642): see orc_set_preconditioner */
 
     fieldf liquid, solid, visc, dens, vel[3], solidvel[3], facew[3], centerw, edgew[3];
 
@@ -2197,6 +2198,7 @@ static void *numa_copy(const void *src, size_t bytes, int threads)
 static int orc_pcg_csr_impl(int64_t n, const int64_t *row_ptr, const int32_t *col, const double *val,
                             const double *b, double *x, double tol, int max_iters, int spmv_threads, int threads,
                             orc_pcg_info *info);
+static _Thread_local int orc_no_precond_tls = 0; /* set by orc_solve around its call (the public PCG entry points keep their signatures) */
 
 int orc_pcg_csr(int64_t n, const int64_t *row_ptr, const int32_t *col, const double *val,
                 const double *b, double *x, double tol, int max_iters, int threads,
@@ -2257,7 +2259,7 @@ static int orc_pcg_csr_impl(int64_t n, const int64_t *row_ptr, const int32_t *co
         int have = 0;
         for (int64_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k)
             if (col[k] == i) { d = val[k]; have = 1; }
-        invd[i] = (have && d != 0.) ? 1. / d : 1.;
+        invd[i] = (have && d != 0. && !orc_no_precond_tls) ? 1. / d : 1.;
     }
     double t0 = now_s(), tspmv = 0.;
     int iters = 0;
@@ -2348,7 +2350,7 @@ static int orc_pcg_csr_f32(int64_t n, const int64_t *row_ptr, const int32_t *col
         int have = 0;
         for (int64_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k)
             if (col[k] == i) { d = v[k]; have = 1; }
-        invd[i] = (have && d != 0.f) ? 1.f / d : 1.f;
+        invd[i] = (have && d != 0.f && !orc_no_precond_tls) ? 1.f / d : 1.f;
     }
 #define SPMV_F(src, dst) for (int64_t i_ = 0; i_ < n; ++i_) { float s_ = 0.f; for (int64_t k_ = row_ptr[i_]; k_ < row_ptr[i_ + 1]; ++k_) s_ += v[k_] * (src)[col[k_]]; (dst)[i_] = s_; }
 #define DOT_F(a_, b_, out_) { float s_ = 0.f; for (int64_t i_ = 0; i_ < n; ++i_) s_ += (a_)[i_] * (b_)[i_]; out_ = s_; }
@@ -2411,9 +2413,25 @@ int orc_set_precision(orc_ctx *c, int f32)
     return 0;
 }
 
+/* 0 = Jacobi (Eigen's DiagonalPreconditioner, default), 1 = none (plain CG) */
+int orc_set_preconditioner(orc_ctx *c, int none)
+{
+    if (!c || (none != 0 && none != 1)) return 1;
+    c->no_precond = none;
+    return 0;
+}
+
+static int orc_solve_inner(orc_ctx *c, double tol, int max_iters, int threads, double *x_out, orc_pcg_info *info);
 int orc_solve(orc_ctx *c, double tol, int max_iters, int threads, double *x_out, orc_pcg_info *info)
 {
     if (!c->row_ptr || !c->x0) return 3;
+    orc_no_precond_tls = c->no_precond;
+    const int rc = orc_solve_inner(c, tol, max_iters, c->no_precond ? 1 : threads, x_out, info); /* (the flag is thread-local: serial solve) */
+    orc_no_precond_tls = 0;
+    return rc;
+}
+static int orc_solve_inner(orc_ctx *c, double tol, int max_iters, int threads, double *x_out, orc_pcg_info *info)
+{
     if (c->f32) {
         memcpy(x_out, c->x0, (size_t)c->nvel * sizeof(double));
         return orc_pcg_csr_f32(c->nvel, c->row_ptr, c->col, c->val, c->rhs, x_out, tol, max_iters, info);

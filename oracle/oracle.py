@@ -86,6 +86,8 @@ def lib():
         L.orc_solve.argtypes = [vp, f64, i32, i32, vp, C.POINTER(PcgInfo)]
         L.orc_set_precision.argtypes = [vp, i32]
         L.orc_set_precision.restype = i32
+        L.orc_set_preconditioner.argtypes = [vp, i32]
+        L.orc_set_preconditioner.restype = i32
         L.orc_build_regular_indices.argtypes = [vp, f64]
         L.orc_regular_count.restype = i64
         L.orc_regular_count.argtypes = [vp]

@@ -279,6 +279,9 @@ bool HDK_AdaptiveViscosity::solveGasSubclass(SIM_Engine &engine, SIM_Object *obj
     }
     {
         UT_PerfMonAutoSolveEvent event(this, "Solve Linear System (GPU)");
+#ifndef USEEIGEN // the non-Eigen build passes no preconditioner to UT_SparseMatrixRowT::solveConjugateGradient (cpp:638-642)
+        if (!check(avs_set_solver_option(h.ctx, AVS_OPTION_PRECONDITIONER, AVS_PRECONDITIONER_NONE))) return false;
+#endif
         if (!check(avs_solve(h.ctx, getSolverTolerance(), getMaxIterations(), &sinfo))) return false; // non-convergence is not an error (cpp:645-652)
         UT_WorkBuffer extra;
         extra.sprintf("iterations=%d, error=%.6f, octree DOFS=%d, regular DOFs=%d", (int)sinfo.iterations, sinfo.error, (int)sinfo.n,

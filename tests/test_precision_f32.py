@@ -79,3 +79,53 @@ def test_gpu_f32_system_bit_exact_and_solve(name, built_lib):
     assert rel_l2(x, s64.solution()) < 1e-4
     s.close()
     s64.close()
+
+
+def test_oracle_plain_cg_option():
+    """No preconditioner (the build without USEEIGEN passes nullptr to HDK's solveConjugateGradient, cpp:638-642): same solution,
+    more iterations than Jacobi-PCG on a system whose diagonal varies (octree levels, wall)."""
+    sc = scenes.fat_beam(32, 3, wall=True)
+    o = _oracle(sc, False)
+    xj, ij = o.solve(1e-8, 5000)
+    o.L.orc_set_preconditioner(o.h, 1)
+    xn, inn = o.solve(1e-8, 5000)
+    assert inn.iterations > ij.iterations and rel_l2(xn, xj) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,resident", [("beam64_L3_wall", "1"), ("beam64_L3_wall", "0"), ("varvisc", "0")])
+def test_gpu_plain_cg_option(name, resident, built_lib):
+    import os
+    import torch
+    from adaptiveviscositysolver_amd import ViscositySolve, capi
+    from util import build_pyramid, feed, oracle_from_pyramid
+    sc = scenes.fat_beam(64, 3, wall=True) if name == "beam64_L3_wall" else scenes.fat_beam(32, 2, wall=True, variable_viscosity=True)
+    dsc = scenes.to_device(sc, torch.device("cuda:0"))
+    pyr = build_pyramid(dsc)
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
+    feed(s, pyr)
+    s.set_scene_fields(dsc)
+    s.assemble()
+    o = oracle_from_pyramid(sc, pyr)
+    o.hot_path()
+    old = os.environ.get("AVS_CG_RESIDENT")
+    os.environ["AVS_CG_RESIDENT"] = resident
+    try:
+        jac = s.solve(1e-9, 8000)
+        s.set_solver_option(capi.OPTION_PRECONDITIONER, capi.PRECONDITIONER_NONE)
+        info = s.solve(1e-9, 8000)
+        x = s.solution()
+        o.L.orc_set_preconditioner(o.h, 1)
+        xo, io = o.solve(1e-9, 8000)
+        assert info.converged == 1 and info.iterations > jac.iterations
+        assert abs(info.iterations - io.iterations) <= max(3, io.iterations // 50), (info.iterations, io.iterations)
+        assert rel_l2(x, xo) < 1e-7
+        s.set_solver_option(capi.OPTION_PRECONDITIONER, capi.PRECONDITIONER_JACOBI)     # and back
+        again = s.solve(1e-9, 8000)
+        assert abs(again.iterations - jac.iterations) <= 1
+    finally:
+        if old is None:
+            os.environ.pop("AVS_CG_RESIDENT", None)
+        else:
+            os.environ["AVS_CG_RESIDENT"] = old
+    s.close()
