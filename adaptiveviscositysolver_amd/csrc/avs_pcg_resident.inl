@@ -424,6 +424,8 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
     double rho = a.sc->rho;
     const double threshold = a.sc->threshold;
     const int max_iters = a.max_iters, max_timed = a.max_timed;
+    double alpha_pend = 0.;
+    bool x_pending = false;
     const bool coherent = a.coherent_fill != 0;
     const int tsize = a.table_size;
     const bool timing = a.timers && b == 0 && tid == 0, stamps = a.wg_times && tid == 0;
@@ -442,6 +444,9 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
         // Row i of the slice belongs to thread i mod 1024 HERE (not to the lane that sums it in the SpMV): the vectors in LDS do not
         // care, and the ones in global memory (x, w, and the tiers) are read and written as whole 512-B runs per wave instead of
         // 8 B every ~32 B (the lane-owned order cost the L1 four times the tag look-ups: the update was 11 us of a 40 us iteration) ----
+        // x is touched every SECOND iteration: the update that computes p_new still holds p_old, which is all the skipped
+        // x += alpha_prev p_old needs (16 of the 56-82 B per row of this phase, every other time)
+        const bool skip_x = (it & 1) == 0;
         double ru = 0., rr = 0.;
         {
             const res_gptr<double> gx = RES_G(x) + wrow0, gp = NG >= 2 ? RES_G(p) + wrow0 : nullptr, gr = NG >= 3 ? RES_G(r) + wrow0 : nullptr;
@@ -455,7 +460,7 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
                 for (int j = 0; j < kResUpd; ++j) {
                     const int i = i0 + j * kResThreads;
                     if (i < wrows) {
-                        xv[j] = gx[i];
+                        if (!skip_x) xv[j] = gx[i];
                         wv[j] = gw[i];
                         dv[j] = gd[i];
                         if (NG >= 1) sv[j] = gs[i];
@@ -467,13 +472,14 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
                 for (int j = 0; j < kResUpd; ++j) {
                     const int i = i0 + j * kResThreads;
                     if (i < wrows) {
-                        const double pi = u_l[i] + beta * (NG >= 2 ? pv[j] : p_l[i]);
+                        const double p_old = NG >= 2 ? pv[j] : p_l[i];
+                        const double pi = u_l[i] + beta * p_old;
                         const double si = wv[j] + beta * (NG >= 1 ? sv[j] : s_l[i]);
                         if (NG >= 2) gp[i] = pi;
                         else p_l[i] = pi;
                         if (NG >= 1) gs[i] = si;
                         else s_l[i] = si;
-                        gx[i] = xv[j] + alpha * pi;
+                        if (!skip_x) gx[i] = (xv[j] + alpha_pend * p_old) + alpha * pi; // = the two sequential updates, bit for bit
                         const double ri = (NG >= 3 ? rv[j] : r_l[i]) - alpha * si;
                         if (NG >= 3) gr[i] = ri;
                         else r_l[i] = ri;
@@ -485,6 +491,8 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
                 }
             }
         }
+        x_pending = skip_x;
+        if (skip_x) alpha_pend = alpha;
         __syncthreads(); // the workgroup's u is complete in LDS
         // u to global for the other workgroups: write-through (other XCDs read it), coalesced, 16 B per lane where the slice allows
         // (8-B sc1 stores cost 2.7x per byte, MI355X_MICROARCH.md)
@@ -806,6 +814,8 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
         __syncthreads(); // bc is rewritten next iteration
     }
     // ---- write the vectors back (a later solve / the host reads them), close the round counter -----------------------------------
+    if (x_pending) // the last update skipped x: x += alpha p with the p it left behind
+        for (int i = tid; i < wrows; i += kResThreads) a.x[wrow0 + i] += alpha_pend * (NG >= 2 ? a.p[wrow0 + i] : p_l[i]);
     for (int i = tid; i < wrows; i += kResThreads) {
         if (NG < 3) a.r[wrow0 + i] = r_l[i];
         if (NG < 2) a.p[wrow0 + i] = p_l[i];
