@@ -1794,7 +1794,7 @@ __device__ __forceinline__ void push_raise_flags(const DistDev *dd, const unsign
 // k_sr_update + k_push in one launch: workgroup b owns a CONTIGUOUS range of rows, updates them, and then stores those of its
 // new u entries that a peer reads straight into that peer's halo area; the last pushing workgroup raises the flags.
 // CODED (round 3): the diagonal's 2-B value code + the table of inverted values instead of the 8-B inverse (11.25 n instead of
-// 12 n doubles of vector traffic; the same doubles, so nothing changes numerically).  Rows are taken two at a time with 16-B
+// 12 n doubles of vector traffic; the same doubles, so nothing changes numerically); u is recomputed from r instead of read (10.25 n).  Rows are taken two at a time with 16-B
 // loads / stores (ranges start at multiples of the block size, so the pairs are aligned).
 template <bool CODED>
 __global__ __launch_bounds__(kBlock) void k_sr_update_push(int64_t n, double *__restrict__ x, double *__restrict__ r, double *__restrict__ p,
@@ -1817,7 +1817,7 @@ __global__ __launch_bounds__(kBlock) void k_sr_update_push(int64_t n, double *__
     double ru = 0., rr = 0.;
     int64_t i = lo + 2 * (int64_t)threadIdx.x;
     for (; i + 1 < hi; i += 2 * kBlock) { // (lo is a multiple of kBlock: i is even, the 16-B accesses are aligned)
-        const d2_t uv = *reinterpret_cast<const d2_t *>(u + i), pv = *reinterpret_cast<const d2_t *>(p + i);
+        const d2_t pv = *reinterpret_cast<const d2_t *>(p + i);
         const d2_t wv = *reinterpret_cast<const d2_t *>(w + i), sv = *reinterpret_cast<const d2_t *>(s + i);
         const d2_t xv = *reinterpret_cast<const d2_t *>(x + i), rv = *reinterpret_cast<const d2_t *>(r + i);
         double id0, id1;
@@ -1830,6 +1830,10 @@ __global__ __launch_bounds__(kBlock) void k_sr_update_push(int64_t n, double *__
             id0 = iv.x;
             id1 = iv.y;
         }
+        // u is not read: what memory holds is inv(d) * r of the r just loaded (this kernel, or the set-up round, wrote exactly that product)
+        d2_t uv;
+        uv.x = id0 * rv.x;
+        uv.y = id1 * rv.y;
         d2_t pn, sn, xn, rn, un;
         pn.x = uv.x + beta * pv.x;  pn.y = uv.y + beta * pv.y;
         sn.x = wv.x + beta * sv.x;  sn.y = wv.y + beta * sv.y;
@@ -1847,14 +1851,15 @@ __global__ __launch_bounds__(kBlock) void k_sr_update_push(int64_t n, double *__
         rr += rn.y * rn.y;
     }
     if (i < hi) { // odd tail of the last range
-        const double pi = u[i] + beta * p[i];
+        const double idi = CODED ? invd[dcode[i]] : invd[i];
+        const double pi = idi * r[i] + beta * p[i]; // (u[i] == inv(d) r[i], see above)
         const double si = w[i] + beta * s[i];
         p[i] = pi;
         s[i] = si;
         x[i] += alpha * pi;
         const double ri = r[i] - alpha * si;
         r[i] = ri;
-        const double ui = (CODED ? invd[dcode[i]] : invd[i]) * ri;
+        const double ui = idi * ri;
         u[i] = ui;
         ru += ri * ui;
         rr += ri * ri;
