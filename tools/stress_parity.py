@@ -14,6 +14,7 @@ import numpy as np
 import torch
 faulthandler.enable()
 VERBOSE = os.environ.get('STRESS_VERBOSE')
+F32 = bool(os.environ.get('STRESS_F32'))   # every case in the fp32 build's precision (avs_desc.precision, oracle f32 mode)
 
 from adaptiveviscositysolver_amd import DevicePrepass, ViscositySolve, capi, scenes
 from util import oracle_for_scene, rel_l2
@@ -79,7 +80,7 @@ def run(count, seed, quiet=False):
             pw_ = int(rng.integers(2, 9)); rng.integers(0, pw_); rng.integers(-1, 3); rng.integers(2, 4); rng.integers(-1, 3)
             continue
         if VERBOSE: print(case, 'scene', res, 'levels', levels, 'solid', solid is not None, 'varvisc', not isinstance(visc, float), 'vardens', not isinstance(dens, float), 'enh', sc.use_enhanced_gradients, flush=True)
-        o = oracle_for_scene(sc)
+        o = oracle_for_scene(sc, f32=F32)
         o.prepass()
         if VERBOSE: print(case, 'oracle prepass done, levels', o.levels, flush=True)
         if o.levels == 0:
@@ -93,7 +94,7 @@ def run(count, seed, quiet=False):
             dsc = scenes.to_device(sc, dev)
             pp = DevicePrepass(sc.res, sc.dx, sc.levels)
             pi = pp.run(dsc.liquid, dsc.solid)
-            s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, use_enhanced_gradients=sc.use_enhanced_gradients, device=0)
+            s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, use_enhanced_gradients=sc.use_enhanced_gradients, device=0, precision=int(F32))
             pp.apply(s)
             s.set_scene_fields(dsc)
             try:
@@ -113,7 +114,7 @@ def run(count, seed, quiet=False):
         why = []
         ok = pi.levels == o.levels and pi.n_velocity == oc.n
         if not ok: why.append('prepass counts')
-        s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, use_enhanced_gradients=sc.use_enhanced_gradients, device=0)
+        s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, use_enhanced_gradients=sc.use_enhanced_gradients, device=0, precision=int(F32))
         pp.apply(s)
         s.set_scene_fields(dsc)
         if VERBOSE: print(case, 'device prepass done', pi.levels, pi.n_velocity, flush=True)
@@ -123,10 +124,11 @@ def run(count, seed, quiet=False):
         t_ = np.array_equal(rp, oc.row_ptr) and np.array_equal(col, oc.col) and np.array_equal(val, oc.val) and np.array_equal(rhs, oc.rhs)
         if not t_: why.append('csr')
         ok = ok and t_
-        info = s.solve(1e-10, 8000)
-        xo, oi = o.solve(1e-10, 8000)
+        info = s.solve(1e-5 if F32 else 1e-10, 8000)
+        xo, oi = o.solve(1e-5 if F32 else 1e-10, 8000)   # (f32: Eigen's algorithm with float scalars and vectors; the device iterates in fp64)
         x = s.solution()
-        t_ = info.converged == 1 and abs(info.iterations - oi.iterations) <= max(3, oi.iterations // 8) and rel_l2(x, xo) < 1e-7
+        if F32: t_ = info.converged == 1 and rel_l2(x, xo) < 1e-3 and np.array_equal(x, x.astype(np.float32).astype(np.float64))
+        else: t_ = info.converged == 1 and abs(info.iterations - oi.iterations) <= max(3, oi.iterations // 8) and rel_l2(x, xo) < 1e-7
         if not t_: why.append(f'solve it {info.iterations} vs {oi.iterations} conv {info.converged} rel {rel_l2(x, xo):.2e}')
         ok = ok and t_
         if VERBOSE: print(case, 'solves done', flush=True)
@@ -171,7 +173,7 @@ def run(count, seed, quiet=False):
         capi.check(lib.avs_local_group_create(world, C.byref(grp)))
         ss = []
         for _ in range(world):
-            t = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, use_enhanced_gradients=sc.use_enhanced_gradients, device=0)
+            t = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, use_enhanced_gradients=sc.use_enhanced_gradients, device=0, precision=int(F32))
             pp.apply(t)
             t.set_scene_fields(dsc)
             ss.append(t)
@@ -184,7 +186,7 @@ def run(count, seed, quiet=False):
                 if VERBOSE:
                     f_ = ss[r].matrix_format(); z_ = ss[r].plan_sizes
                     print(case, 'rank', r, 'dist assembled: own', z_.n_own, 'halo', z_.n_halo, 'nnz', z_.nnz_local, 'bytes/nnz', f_.bytes_per_nonzero, 'table', f_.value_table_size, 'tile tables', f_.tile_local_tables, 'windows', f_.column_windows, flush=True)
-                di = ss[r].dist_solve(1e-10, 8000)
+                di = ss[r].dist_solve(1e-5 if F32 else 1e-10, 8000)
                 if VERBOSE: print(case, 'rank', r, 'dist solved', flush=True)
                 outs[r] = (di.iterations, di.converged, ss[r].dist_solution())
             except Exception as e:
@@ -194,7 +196,7 @@ def run(count, seed, quiet=False):
         th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
         [t.start() for t in th]
         [t.join(300) for t in th]
-        t_ = not errs and all(v is not None and v[1] == 1 and abs(v[0] - info.iterations) <= max(3, info.iterations // 12) and rel_l2(v[2], x) < 1e-7 for v in outs)
+        t_ = not errs and all(v is not None and v[1] == 1 and abs(v[0] - info.iterations) <= max(3, info.iterations // 12) and rel_l2(v[2], x) < (1e-4 if F32 else 1e-7) for v in outs)
         if not t_: why.append('dist ' + str([(v[0], v[1], rel_l2(v[2], x)) if v else None for v in outs]))
         ok = ok and t_
         for t in ss:
