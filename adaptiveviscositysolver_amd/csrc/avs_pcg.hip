@@ -724,6 +724,16 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
         }
     }
     auto gather = [&](int col) -> double {
+        if (WIN > 0 && !HALO) {
+            // Both reads are issued for every lane, from a clamped address, and the value is selected afterwards.  As two exec-masked
+            // branches writing ONE register the compiler put an `s_waitcnt lgkmcnt(0)` between the LDS read and the global load of every
+            // gather (write-after-write on the destination): the eight global gathers of a pass went out one LDS round trip apart.
+            const unsigned off = (unsigned)(col - w0);
+            const bool in = off < wlen;
+            const double a = xs[in ? off : 0u];
+            const double b = x[in ? w0 : col];
+            return in ? a : b;
+        }
         if (WIN > 0) {
             const unsigned off = (unsigned)(col - w0);
             if (off < wlen) return xs[off];

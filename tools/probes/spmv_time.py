@@ -9,3 +9,4 @@ sc = scenes.fat_beam(n, 4, device=dev)
 pp = DevicePrepass(sc.res, sc.dx, sc.levels); pi = pp.run(sc.liquid, sc.solid)
 s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels); pp.apply(s); s.set_scene_fields(sc); pp.close(); s.assemble()
 for r in range(3): print("default SpMV us:", s.bench_spmv(0, 200) * 1e3)
+for r in range(3): print("fused-dot SpMV us:", s.bench_spmv(100, 200) * 1e3)
