@@ -38,8 +38,7 @@ constexpr int kStampTiles = 24, kStampWgs = 1024;
 __device__ long long g_brick_stamps[kStampWgs * kStampTiles * 8];
 #define BRICK_STAMP(slot)                                                                                            \
     do {                                                                                                             \
-        if ((B.debug & 16) && tid == 0 && iter < kStampTiles && blockIdx.x < kStampWgs) {                             \
-            if ((slot) == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
+        if ((B.debug & 16) && threadIdx.x == 0 && iter < kStampTiles && blockIdx.x < kStampWgs) {                             \
             g_brick_stamps[((int)blockIdx.x * kStampTiles + iter) * 8 + (slot)] = wall_clock64();                    \
         }                                                                                                            \
     } while (0)
@@ -70,244 +69,212 @@ __device__ __forceinline__ double lds_f64(const double *base, unsigned byte_off)
     return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
-constexpr int kBrickRpt = kBrickMaxRows / kBrickBlk;                    // rows per thread
-constexpr int kBrickRu = 6;                                             // halo fill runs per quarter wave held in registers
-constexpr int kBrickPq = (kBrickPatWords / 4 + kBrickBlk - 1) / kBrickBlk; // pattern quads per thread
-constexpr int kBrickSu = kBrickPark / kBrickBlk;                        // words per thread of a G tile's first streamed pass
+constexpr int kBrickRu = kBrickMaxRuns / (kBrickBlk / 16);              // halo fill runs per quarter wave
 
-struct BrickHdr { int row0, nrows, npat, pat0, run0, nruns, pq0, npq, srow0, nsrows, sword0, nsw, rd0, nprow; };
-// what a tile's x / pattern loads need (requested one tile ahead, while the previous tile is multiplied)
-struct BrickAhead {
-    uint32_t rdsc[kBrickRu];
-    uint32_t pqo[kBrickPq];
-    uint32_t w0[kBrickSu];
-    uint32_t pinf;
-    int nbreg;
-};
+// A tile's descriptors are ONE contiguous block of 32-bit words (<= 8 KB), fetched with one 16-B load per thread and parked in LDS:
+//   [0] row0 [1] nrows [2] npat [3] nruns [4] npq (pattern quads) [5] nprow (pattern rows) [6] srow0 [7] nsrows [8] sword0 [9] nsw
+//   [16 .. 48) first rows of the 27 neighbour bricks
+//   [10] rd0 (first pattern-row descriptor of the tile in rdesc)
+//   runs[nruns] | pquads[npq] | pinfo[npat]
+// The per-row arrays (rdesc: descriptor + position of every pattern row in execution order; ownslot) stay in global memory.
+constexpr int kBlkHdr = 48;
 
-__device__ __forceinline__ BrickHdr brick_load_hdr(const BrickTile &T)
-{
-    BrickHdr h;
-    h.row0 = T.row0; h.nrows = T.nrows; h.npat = T.npat; h.pat0 = T.pat0; h.run0 = T.run0; h.nruns = T.nruns; h.pq0 = T.pq0; h.npq = T.npq;
-    h.srow0 = T.srow0; h.nsrows = T.nsrows; h.sword0 = T.sword0; h.nsw = T.nsw; h.rd0 = T.rd0; h.nprow = T.nprow;
-    return h;
-}
-
-__device__ __forceinline__ void brick_load_ahead(const BrickView &B, const BrickTile &T, const BrickHdr &h, int tid, BrickAhead &d)
-{
-    const bool emode = h.npat == 0;
-#pragma unroll
-    for (int u = 0; u < kBrickSu; ++u) {
-        const int e = tid + u * kBrickBlk;
-        d.w0[u] = 0u;
-        if (!emode && u * kBrickBlk < h.nsw) // block-uniform: a batch nobody needs is not requested (a load instruction costs the same
-                                             // address-unit time with one active lane as with 64)
-        d.w0[u] = B.swords[(int64_t)h.sword0 + ((!emode && e < h.nsw) ? e : 0)]; // (unconditional loads from a valid address: a conditional
-                                                                                   //  load is a branch + s_waitcnt vmcnt(0) per load)
-    }
-    d.nbreg = T.nb[tid & 31];                                           // first rows of the 27 neighbour bricks, one per lane
-    const int qw = tid >> 4;
-#pragma unroll
-    for (int u = 0; u < kBrickRu; ++u) {
-        const int q = u * (kBrickBlk / 16) + qw;
-        d.rdsc[u] = 0xffffffffu;
-        if (u * (kBrickBlk / 16) < h.nruns) {
-            const uint32_t r = B.runs[h.run0 + (q < h.nruns ? q : 0)];
-            d.rdsc[u] = (q < h.nruns) ? r : 0xffffffffu;
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < kBrickPq; ++u) {
-        const int q = tid + u * kBrickBlk;
-        d.pqo[u] = 0u;
-        if (u * kBrickBlk < h.npq) d.pqo[u] = B.pquads[h.pq0 + (q < h.npq ? q : 0)];
-    }
-    d.pinf = 0u;
-    if (h.npat > 0) d.pinf = B.pinfo[h.pat0 + (tid < h.npat ? tid : 0)];
-}
-
-template <bool DOT, int PERSIST>
-__global__ __launch_bounds__(kBrickBlk) void k_spmv_brick(BrickView B, const double *__restrict__ x, double *__restrict__ y,
+template <bool DOT>
+__global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_spmv_brick(BrickView B, const double *__restrict__ x, double *__restrict__ y,
                                                          double *__restrict__ partial, const int *__restrict__ done_flag)
 {
     if (DOT && done_flag && *done_flag) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *xs = smem;                                                  // kBrickSlotsPad
-    double *vals = smem + kBrickSlotsPad;                               // table_size + 1 (the last entry is 0.0: padding words), even
-    double *park = vals + ((B.table_size + 2) & ~1);                    // kBrickPark products of streamed rows
-    uint32_t *pw = reinterpret_cast<uint32_t *>(park + kBrickPark);     // kBrickPatWords + 8
-    uint32_t *pinfo = pw + kBrickPatWords + 8;                          // kBrickPatMax: local start | quads << 16 | simple << 31
+    double *park = smem + kBrickSlotsPad;                               // kBrickPark doubles, right behind the lattice: [0, kBrickXSlots) extra
+                                                                        // x slots (off-lattice columns), behind them first the tile's
+                                                                        // descriptor block, then the products of its streamed rows
+    double *vals = park + kBrickPark;                                   // table_size + 1 (the last entry is 0.0: padding words), even
+    uint32_t *pw = reinterpret_cast<uint32_t *>(vals + ((B.table_size + 2) & ~1)); // kBrickPatWords + 8
+    uint32_t *pinfo = pw + kBrickPatWords + 8;                          // kBrickPatMax: local start | quads << 16
+    const uint32_t *bw = reinterpret_cast<const uint32_t *>(park + kBrickXSlots);
     const int tid = threadIdx.x;
     const int lane = tid & 63, l16 = tid & 15, qw = tid >> 4;
     const unsigned cmask = (1u << B.col_bits) - 1u;
     const int cbits = B.col_bits;
     constexpr int QW = kBrickBlk / 16;
+    static_assert((kBrickPark - kBrickXSlots) * 2 <= kBrickBlk * 4, "one 16-B load per thread fetches a whole descriptor block");
 
     for (int i = tid; i <= B.table_size; i += kBrickBlk) vals[i] = (i < B.table_size) ? B.table[i] : 0.; // once per workgroup
 
     int tile = blockIdx.x;
     if (tile >= B.ntiles) return;
-    BrickHdr h = brick_load_hdr(B.tiles[tile]);
-    BrickAhead d;
-    brick_load_ahead(B, B.tiles[tile], h, tid, d);
+    const uint4 *blocks16 = reinterpret_cast<const uint4 *>(B.blocks);
+    uint2 tb = B.tile_blk[tile];                                         // first 16-B unit, units
+    uint4 blk = blocks16[(int64_t)tb.x + (tid < (int)tb.y ? tid : 0)];
+    int nsw_prev = 0;
 
     int iter = 0;
     for (;;) {
         BRICK_STAMP(0);
-        const bool emode = h.npat == 0;                 // no pattern rows: the products of the streamed rows may use the x lattice's LDS
-        double *prod = emode ? xs : park;
-        const int cap = emode ? kBrickSlotsPad : kBrickPark;
-        // ---- this tile's loads, one round trip: x of the halo runs (a run's neighbour-brick base comes from the lane that holds it), x of
-        //      the tile's own rows with their slots, the pattern quads, x of the first streamed pass, the row descriptors
+        if (nsw_prev > 0) __syncthreads();                               // the previous tile's streamed sums have read `park`
+        if (tid < (int)tb.y) reinterpret_cast<uint4 *>(park + kBrickXSlots)[tid] = blk;
+        __syncthreads();                                                 // every wave is done with the previous tile; the block is visible
+        const int row0 = __builtin_amdgcn_readfirstlane((int)bw[0]), nrows = __builtin_amdgcn_readfirstlane((int)bw[1]);
+        const int npat = __builtin_amdgcn_readfirstlane((int)bw[2]), nruns = __builtin_amdgcn_readfirstlane((int)bw[3]);
+        const int npq = __builtin_amdgcn_readfirstlane((int)bw[4]), nprow = __builtin_amdgcn_readfirstlane((int)bw[5]);
+        const int srow0 = __builtin_amdgcn_readfirstlane((int)bw[6]), nsrows = __builtin_amdgcn_readfirstlane((int)bw[7]);
+        const int sword0 = __builtin_amdgcn_readfirstlane((int)bw[8]), nsw = __builtin_amdgcn_readfirstlane((int)bw[9]);
+        const int rd0 = __builtin_amdgcn_readfirstlane((int)bw[10]);
+        const int o_runs = kBlkHdr, o_pq = o_runs + nruns, o_pi = o_pq + npq;
+        const bool emode = npat == 0;                 // no pattern rows: the products of the streamed rows may use the x lattice's LDS
+        double *prod = emode ? xs : park + kBrickXSlots;
+        const int cap = emode ? kBrickSlotsPad : kBrickPark - kBrickXSlots;
+        BRICK_STAMP(1);
+        // ---- this tile's loads, one round trip: x of the halo runs, x of the tile's own rows, the pattern quads
         double fv[kBrickRu];
+        uint32_t rdsc[kBrickRu];
 #pragma unroll
         for (int u = 0; u < kBrickRu; ++u) {
-            const uint32_t r = d.rdsc[u];
-            const int nbase = __builtin_amdgcn_ds_bpermute((int)(r >> 27) << 2, d.nbreg);
-            const int len = (int)(r & 15u) + 1;
-            const bool on = (r != 0xffffffffu) && l16 < len && !(B.debug & 1);
             fv[u] = 0.;
-            if (u * QW < h.nruns) fv[u] = x[on ? (int64_t)nbase + (int)((r >> 16) & 0x7ffu) + l16 : (int64_t)h.row0];
+            rdsc[u] = 0xffffffffu;
+            if (u * QW < nruns) {                      // block-uniform: a batch nobody needs is not requested
+                const int q = u * QW + qw;
+                const uint32_t r = bw[o_runs + (q < nruns ? q : 0)];
+                const int nbase = (int)bw[16 + (r >> 27)];
+                const bool on = q < nruns && l16 <= (int)(r & 15u) && !(B.debug & 1);
+                rdsc[u] = on ? r : 0xffffffffu;
+                fv[u] = x[on ? (int64_t)nbase + (int)((r >> 16) & 0x7ffu) + l16 : (int64_t)row0];
+            }
         }
-        double xo[kBrickRpt];
-        uint32_t os[kBrickRpt];
+        constexpr int RPT = kBrickMaxRows / kBrickBlk;
+        double xo[RPT];
+        uint32_t os[RPT];
 #pragma unroll
-        for (int k = 0; k < kBrickRpt; ++k) {
-            const int r = tid + k * kBrickBlk;
-            const bool on = !emode && r < h.nrows;
+        for (int k = 0; k < RPT; ++k) {
             xo[k] = 0.;
             os[k] = 0xffffu;
-            if (!emode && k * kBrickBlk < h.nrows) {
-                xo[k] = x[(int64_t)h.row0 + (on ? r : 0)];
-                const uint32_t o = B.ownslot[(int64_t)h.row0 + (on ? r : 0)];
-                os[k] = on ? o : 0xffffu;
+            if (!emode && k * kBrickBlk < nrows) {
+                const int r = tid + k * kBrickBlk;
+                xo[k] = x[(int64_t)row0 + (r < nrows ? r : 0)];
+                const uint32_t o = B.ownslot[(int64_t)row0 + (r < nrows ? r : 0)];
+                os[k] = r < nrows ? o : 0xffffu;
             }
         }
-        uint4 pqv[kBrickPq];
+        constexpr int PQ = (kBrickPatWords / 4 + kBrickBlk - 1) / kBrickBlk;
+        uint4 pqv[PQ];
 #pragma unroll
-        for (int u = 0; u < kBrickPq; ++u) {
-            const int q = tid + u * kBrickBlk;
+        for (int u = 0; u < PQ; ++u) {
             pqv[u] = uint4{0u, 0u, 0u, 0u};
-            if (u * kBrickBlk < h.npq) pqv[u] = *reinterpret_cast<const uint4 *>(B.pwords + (q < h.npq ? d.pqo[u] : 0u));
-        }
-        double xv0[kBrickSu];
-#pragma unroll
-        for (int u = 0; u < kBrickSu; ++u) {
-            const int e = tid + u * kBrickBlk;
-            xv0[u] = 0.;
-            if (!emode && u * kBrickBlk < h.nsw) xv0[u] = x[(e < h.nsw) ? (d.w0[u] & cmask) : (uint32_t)h.row0];
-        }
-        uint32_t rd[kBrickRpt], ro[kBrickRpt];
-#pragma unroll
-        for (int k = 0; k < kBrickRpt; ++k) {
-            const int i = tid + k * kBrickBlk;
-            rd[k] = 0u;
-            ro[k] = 0u;
-            if (k * kBrickBlk < h.nprow) {
-                rd[k] = B.rdesc[h.rd0 + (i < h.nprow ? i : 0)];
-                ro[k] = (uint32_t)B.rorder[h.rd0 + (i < h.nprow ? i : 0)];
+            if (u * kBrickBlk < npq) {
+                const int q = tid + u * kBrickBlk;
+                pqv[u] = *reinterpret_cast<const uint4 *>(B.pwords + bw[o_pq + (q < npq ? q : 0)]);
             }
         }
-        uint2 sd[kBrickRpt];
+        uint2 rdv[RPT]; // descriptor, position in the tile
 #pragma unroll
-        for (int k = 0; k < kBrickRpt; ++k) {
-            const int i = brick_srow_of_thread(tid, k);
-            sd[k] = uint2{0u, 0u};
-            if (k * kBrickBlk < h.nsrows) {
-                const uint2 t = B.sdesc[h.srow0 + (i < h.nsrows ? i : 0)];
-                sd[k] = (i < h.nsrows) ? t : uint2{0u, 0u};
+        for (int k = 0; k < RPT; ++k) {
+            rdv[k] = uint2{0u, 0u};
+            if (k * kBrickBlk < nprow) {
+                const int i = tid + k * kBrickBlk;
+                rdv[k] = B.rdesc[rd0 + (i < nprow ? i : 0)];
             }
         }
-        // the next tile's header: scalar loads, in flight while this tile's data arrives
+        const uint32_t pinf = bw[o_pi + (tid < npat ? tid : 0)];
+        // streamed rows (few tiles): descriptors, and for a G tile the first pass of words with their x
+        uint2 sd[kBrickMaxRows / kBrickBlk];
+#pragma unroll
+        for (int k = 0; k < kBrickMaxRows / kBrickBlk; ++k) sd[k] = uint2{0u, 0u};
+        uint32_t w0[2] = {0u, 0u};
+        double xv0[2] = {0., 0.};
+        if (nsrows > 0) {
+#pragma unroll
+            for (int k = 0; k < kBrickMaxRows / kBrickBlk; ++k) {
+                if (k * kBrickBlk >= nsrows) break;
+                const int i = brick_srow_of_thread(tid, k);
+                const uint2 t = B.sdesc[srow0 + (i < nsrows ? i : 0)];
+                sd[k] = (i < nsrows) ? t : uint2{0u, 0u};
+            }
+            if (!emode) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int e = tid + u * kBrickBlk;
+                    w0[u] = B.swords[(int64_t)sword0 + (e < nsw ? e : 0)];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) xv0[u] = x[w0[u] & cmask];
+            }
+        }
+        // the next tile's block address: a scalar load, in flight while this tile's data arrives
         const int tnext = tile + (int)gridDim.x;
-        const bool more = PERSIST != 0 && tnext < B.ntiles;
-        const BrickTile &Tn = B.tiles[more ? tnext : tile];
-        const BrickHdr hn = brick_load_hdr(Tn);
-        BRICK_STAMP(1);
+        const bool more = tnext < B.ntiles;
+        const uint2 tbn = B.tile_blk[more ? tnext : tile];
         // ---- LDS writes
-        if (tid < h.npat) pinfo[tid] = d.pinf;
+        if (tid < npat) pinfo[tid] = pinf;
 #pragma unroll
-        for (int u = 0; u < kBrickPq; ++u) {
+        for (int u = 0; u < PQ; ++u) {
             const int q = tid + u * kBrickBlk;
-            if (q < h.npq) reinterpret_cast<uint4 *>(pw)[q] = pqv[u];
+            if (q < npq) reinterpret_cast<uint4 *>(pw)[q] = pqv[u];
         }
 #pragma unroll
-        for (int u = 0; u < kBrickRu; ++u) {
-            const uint32_t r = d.rdsc[u];
-            const int len = (int)(r & 15u) + 1;
-            if (r != 0xffffffffu && l16 < len) xs[((r >> 4) & 0xfffu) + l16] = fv[u];
-        }
+        for (int u = 0; u < kBrickRu; ++u)
+            if (rdsc[u] != 0xffffffffu) xs[((rdsc[u] >> 4) & 0xfffu) + l16] = fv[u]; // (extra slots: xs runs on into `park`)
 #pragma unroll
-        for (int k = 0; k < kBrickRpt; ++k)
+        for (int k = 0; k < RPT; ++k)
             if (os[k] != 0xffffu) xs[os[k]] = xo[k];
-        // tiles with more halo runs than the registers hold (few): the rest in a plain loop
-        for (int q0 = kBrickRu * QW; q0 < h.nruns; q0 += QW) {
-            const int q = q0 + qw;
-            const uint32_t r = B.runs[h.run0 + (q < h.nruns ? q : 0)];
-            const int nbase = __builtin_amdgcn_ds_bpermute((int)(r >> 27) << 2, d.nbreg);
-            const int len = (int)(r & 15u) + 1;
-            const bool on = q < h.nruns && l16 < len;
-            const double xv1 = x[on ? (int64_t)nbase + (int)((r >> 16) & 0x7ffu) + l16 : (int64_t)h.row0];
-            if (on) xs[((r >> 4) & 0xfffu) + l16] = xv1;
-        }
-        const uint32_t w0a = d.w0[0], w0b = kBrickSu > 1 ? d.w0[kBrickSu - 1] : 0u;
         __syncthreads();
         BRICK_STAMP(2);
 
-        // ---- what the next tile's loads need travels while this tile is multiplied
-        if (PERSIST == 1) brick_load_ahead(B, Tn, hn, tid, d);
+        // ---- the next tile's block travels while this tile is multiplied (16 B per thread)
+        blk = blocks16[(int64_t)tbn.x + (tid < (int)tbn.y ? tid : 0)];
 
         double dot = 0.;
         if (!emode) {
-            // products of the first streamed pass
-            static_assert(kBrickSu == 2, "two words per thread in the first streamed pass");
-            if (tid < h.nsw) prod[tid] = vals[w0a >> cbits] * xv0[0];
-            if (tid + kBrickBlk < h.nsw) prod[tid + kBrickBlk] = vals[w0b >> cbits] * xv0[1];
+            // products of the first streamed pass (the block in `park` is dead now)
+            if (nsw > 0) {
+                if (tid < nsw && tid < cap) prod[tid] = vals[w0[0] >> cbits] * xv0[0];
+                if (tid + kBrickBlk < nsw && tid + kBrickBlk < cap) prod[tid + kBrickBlk] = vals[w0[1] >> cbits] * xv0[1];
+            }
             // pattern rows: one lane per row, everything from LDS
 #pragma unroll
-            for (int k = 0; k < kBrickRpt; ++k) {
-                if (k * kBrickBlk >= h.nprow) break; // block-uniform
-                const int i = tid + k * kBrickBlk;
-                if (i < h.nprow && !(B.debug & 2)) {
-                    const uint32_t rdv = rd[k];
-                    const unsigned pid = rdv >> 20;
-                    const int lr = (int)((rdv >> 18) & 3u), ax = (int)((rdv >> 16) & 3u);
-                    const int cx = (int)(rdv & 15u) - 1, cy = (int)((rdv >> 4) & 15u) - 1, cz = (int)((rdv >> 8) & 15u) - 1; // local level-lr cell
-                    unsigned b8[4]; // byte offsets of the row's base on the four lattices
+            for (int k = 0; k < RPT; ++k) {
+            if (k * kBrickBlk >= nprow) break;
+            if (tid + k * kBrickBlk < nprow && !(B.debug & 2)) {
+                const uint32_t rd = rdv[k].x, ro = rdv[k].y;
+                const unsigned pid = rd >> 20;
+                const int lr = (int)((rd >> 18) & 3u), ax = (int)((rd >> 16) & 3u);
+                const int cx = (int)(rd & 15u) - 1, cy = (int)((rd >> 4) & 15u) - 1, cz = (int)((rd >> 8) & 15u) - 1; // local level-lr cell
+                unsigned b8[4]; // byte offsets of the row's base on the four lattices
 #pragma unroll
-                    for (int lc = 0; lc < 4; ++lc) {
-                        const int up = lc > lr ? lc - lr : 0, dn2 = lr > lc ? lr - lc : 0;
-                        const int S = (8 >> lc) + 2;
-                        const int bx = ((cx >> up) << dn2) + 1, by = ((cy >> up) << dn2) + 1, bz = ((cz >> up) << dn2) + 1;
-                        b8[lc] = (unsigned)((kBrickLoff[lc] + ((bz * S + by) * S + bx) * 3) * 8);
-                    }
-                    const unsigned own8 = (lr == 0 ? b8[0] : lr == 1 ? b8[1] : lr == 2 ? b8[2] : b8[3]) + 8u * (unsigned)ax;
-                    const unsigned P01 = (b8[0] & 0xffffu) | (b8[1] << 16), P23 = (b8[2] & 0xffffu) | (b8[3] << 16);
-                    const unsigned pi = pinfo[pid];
-                    const uint4 *wq = reinterpret_cast<const uint4 *>(pw + (pi & 0xffffu));
-                    const int nq = (int)((pi >> 16) & 0x7fffu);
-                    // word: delta << 19 (signed 13) | 000 | lattice level << 14 | code << 3.  A pattern is padded to whole quads with
-                    // words that repeat its first entry's slot with the code of 0.0: +-0.0 added to a sum that is never -0.0.
-                    auto addr = [&](uint32_t w) -> unsigned {
-                        const unsigned sel = ((w >> 14) & 3u) * 0x0202u + 0x0c0c0100u;
-                        return (unsigned)((int)w >> 16) + __builtin_amdgcn_perm(P23, P01, sel); // + 16-bit field number `level` of P23:P01
-                    };
-                    double sum = 0.;
-                    // software pipeline: the words of quad q + 1 and the value / x reads of quad q are in flight while quad q - 1 is added
-                    // (reading the words one quad past the pattern is harmless: the LDS image ends with spare quads; they are never decoded)
+                for (int lc = 0; lc < 4; ++lc) {
+                    const int up = lc > lr ? lc - lr : 0, dn2 = lr > lc ? lr - lc : 0;
+                    const int S = (8 >> lc) + 2;
+                    const int bx = ((cx >> up) << dn2) + 1, by = ((cy >> up) << dn2) + 1, bz = ((cz >> up) << dn2) + 1;
+                    b8[lc] = (unsigned)((kBrickLoff[lc] + ((bz * S + by) * S + bx) * 3) * 8);
+                }
+                const unsigned own8 = (lr == 0 ? b8[0] : lr == 1 ? b8[1] : lr == 2 ? b8[2] : b8[3]) + 8u * (unsigned)ax;
+                const unsigned P01 = (b8[0] & 0xffffu) | (b8[1] << 16), P23 = (b8[2] & 0xffffu) | (b8[3] << 16);
+                const unsigned pi = pinfo[pid];
+                const uint4 *wq = reinterpret_cast<const uint4 *>(pw + (pi & 0xffffu));
+                const int nq = (int)((pi >> 16) & 0x7fffu);
+                // word: delta << 19 (signed 13) | 000 | lattice level << 14 | code << 3.  A pattern is padded to whole quads with
+                // words that repeat its first entry's slot with the code of 0.0: +-0.0 added to a sum that is never -0.0.
+                auto addr = [&](uint32_t w) -> unsigned {
+                    const unsigned sel = ((w >> 14) & 3u) * 0x0202u + 0x0c0c0100u;
+                    return (unsigned)((int)w >> 16) + __builtin_amdgcn_perm(P23, P01, sel); // + 16-bit field number `level` of P23:P01
+                };
+                double sum = 0.;
+                // software pipeline: the words of quad q + 1 and the value / x reads of quad q are in flight while quad q - 1 is added
+                // (reading the words one quad past the pattern is harmless: the LDS image ends with spare quads; they are never decoded)
+                auto walk = [&](auto adr) {
                     double v0, v1, v2, v3, x0, x1, x2, x3;
-                    uint4 w = wq[0];
+                    const uint4 w = wq[0];
                     uint4 wn = wq[1];
-                    v0 = lds_f64(vals, w.x & 0x3ff8u); x0 = lds_f64(xs, addr(w.x));
-                    v1 = lds_f64(vals, w.y & 0x3ff8u); x1 = lds_f64(xs, addr(w.y));
-                    v2 = lds_f64(vals, w.z & 0x3ff8u); x2 = lds_f64(xs, addr(w.z));
-                    v3 = lds_f64(vals, w.w & 0x3ff8u); x3 = lds_f64(xs, addr(w.w));
+                    v0 = lds_f64(vals, w.x & 0x3ff8u); x0 = lds_f64(xs, adr(w.x));
+                    v1 = lds_f64(vals, w.y & 0x3ff8u); x1 = lds_f64(xs, adr(w.y));
+                    v2 = lds_f64(vals, w.z & 0x3ff8u); x2 = lds_f64(xs, adr(w.z));
+                    v3 = lds_f64(vals, w.w & 0x3ff8u); x3 = lds_f64(xs, adr(w.w));
                     for (int q = 1; q < nq; ++q) {
                         const uint4 wnn = wq[q + 1];
-                        const double a0 = lds_f64(vals, wn.x & 0x3ff8u), c0 = lds_f64(xs, addr(wn.x));
-                        const double a1 = lds_f64(vals, wn.y & 0x3ff8u), c1 = lds_f64(xs, addr(wn.y));
-                        const double a2 = lds_f64(vals, wn.z & 0x3ff8u), c2 = lds_f64(xs, addr(wn.z));
-                        const double a3 = lds_f64(vals, wn.w & 0x3ff8u), c3 = lds_f64(xs, addr(wn.w));
+                        const double a0 = lds_f64(vals, wn.x & 0x3ff8u), c0 = lds_f64(xs, adr(wn.x));
+                        const double a1 = lds_f64(vals, wn.y & 0x3ff8u), c1 = lds_f64(xs, adr(wn.y));
+                        const double a2 = lds_f64(vals, wn.z & 0x3ff8u), c2 = lds_f64(xs, adr(wn.z));
+                        const double a3 = lds_f64(vals, wn.w & 0x3ff8u), c3 = lds_f64(xs, adr(wn.w));
                         sum += v0 * x0;
                         sum += v1 * x1;
                         sum += v2 * x2;
@@ -319,19 +286,26 @@ __global__ __launch_bounds__(kBrickBlk) void k_spmv_brick(BrickView B, const dou
                     sum += v1 * x1;
                     sum += v2 * x2;
                     sum += v3 * x3;
-                    y[(int64_t)h.row0 + (int)ro[k]] = sum;
-                    if (DOT) dot += sum * lds_f64(xs, own8);
+                };
+                if (pi >> 31) { // every column of the pattern on the level-0 lattice (rows are executed sorted by pattern: waves rarely mix)
+                    const unsigned b0 = b8[0];
+                    walk([&](uint32_t w) -> unsigned { return (unsigned)((int)w >> 16) + b0; });
+                } else {
+                    walk(addr);
                 }
+                y[(int64_t)row0 + (int)ro] = sum;
+                if (DOT) dot += sum * lds_f64(xs, own8);
+            }
             }
         }
         BRICK_STAMP(3);
         // streamed rows: passes of `cap` products parked in LDS, then every row adds its segment left to right
-        if (h.nsw > 0 && !(B.debug & 4)) {
-            double ssum[kBrickRpt];
+        if (nsw > 0 && !(B.debug & 4)) {
+            double ssum[kBrickMaxRows / kBrickBlk];
 #pragma unroll
-            for (int k = 0; k < kBrickRpt; ++k) ssum[k] = 0.;
-            for (int ts = 0; ts < h.nsw; ts += cap) {
-                const int te = (ts + cap < h.nsw) ? ts + cap : h.nsw;
+            for (int k = 0; k < kBrickMaxRows / kBrickBlk; ++k) ssum[k] = 0.;
+            for (int ts = 0; ts < nsw; ts += cap) {
+                const int te = (ts + cap < nsw) ? ts + cap : nsw;
                 if (emode || ts > 0) {
                     if (ts > 0) __syncthreads(); // the previous pass has been summed
                     for (int e0 = ts + tid; e0 < te; e0 += 4 * kBrickBlk) {
@@ -340,13 +314,10 @@ __global__ __launch_bounds__(kBrickBlk) void k_spmv_brick(BrickView B, const dou
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int e = e0 + u * kBrickBlk;
-                            w4[u] = B.swords[(int64_t)h.sword0 + (e < te ? e : ts)];
+                            w4[u] = B.swords[(int64_t)sword0 + (e < te ? e : ts)];
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int e = e0 + u * kBrickBlk;
-                            x4[u] = x[w4[u] & cmask];
-                        }
+                        for (int u = 0; u < 4; ++u) x4[u] = x[w4[u] & cmask];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int e = e0 + u * kBrickBlk;
@@ -356,21 +327,19 @@ __global__ __launch_bounds__(kBrickBlk) void k_spmv_brick(BrickView B, const dou
                 }
                 __syncthreads();
 #pragma unroll
-                for (int k = 0; k < kBrickRpt; ++k) {
+                for (int k = 0; k < kBrickMaxRows / kBrickBlk; ++k) {
                     const int len = (int)(sd[k].x >> 16), st = (int)sd[k].y;
                     const int a = st > ts ? st : ts, b = (st + len < te) ? st + len : te;
                     for (int j = a; j < b; ++j) ssum[k] += prod[j - ts];
                 }
             }
 #pragma unroll
-            for (int k = 0; k < kBrickRpt; ++k) {
-                const int len = (int)(sd[k].x >> 16);
-                if (len > 0) {
-                    const int64_t row = (int64_t)h.row0 + (int)(sd[k].x & 0xffffu);
+            for (int k = 0; k < kBrickMaxRows / kBrickBlk; ++k)
+                if ((sd[k].x >> 16) > 0) {
+                    const int64_t row = (int64_t)row0 + (int)(sd[k].x & 0xffffu);
                     y[row] = ssum[k];
                     if (DOT) dot += ssum[k] * x[row];
                 }
-            }
         }
         if (DOT) {
             const double dsum = brick_wave_sum_dpp(dot);
@@ -378,12 +347,10 @@ __global__ __launch_bounds__(kBrickBlk) void k_spmv_brick(BrickView B, const dou
         }
         BRICK_STAMP(4);
         if (!more) break;
-        __syncthreads(); // every wave is done with this tile's LDS
-        BRICK_STAMP(5);
         ++iter;
         tile = tnext;
-        h = hn;
-        if (PERSIST == 2) brick_load_ahead(B, B.tiles[tile], h, tid, d);
+        tb = tbn;
+        nsw_prev = (nsw > 0 && !(B.debug & 4)) ? 1 : 0;
     }
 }
 
@@ -401,7 +368,7 @@ static int brick_grid(const BrickView &B, size_t lds)
     if (dev < 0 || dev >= 64) dev = 0;
     if (!cached[dev]) {
         int per_cu = 0, cus = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_spmv_brick<true, 1>, kBrickBlk, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_spmv_brick<true>, kBrickBlk, lds);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (per_cu < 1) per_cu = 1;
         if (cus < 1) cus = 256;
@@ -418,32 +385,13 @@ avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, dou
     const size_t lds = brick_lds_bytes(B);
     static bool attr_set = false;
     if (lds > 48 * 1024 && !attr_set) {
-        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         attr_set = true;
     }
-    int persist = 1;
-    if (const char *e = getenv("AVS_BRICK_PERSIST")) persist = atoi(e);
-    if (persist == 2) {
-        int per_cu = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_spmv_brick<true, 2>, kBrickBlk, lds);
-        int grid = 256 * (per_cu > 0 ? per_cu : 1);
-        if (const char *e = getenv("AVS_BRICK_GRID")) grid = atoi(e);
-        if (grid > B.ntiles) grid = B.ntiles;
-        if (partial) hipLaunchKernelGGL((k_spmv_brick<true, 2>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
-        else hipLaunchKernelGGL((k_spmv_brick<false, 2>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
-    } else if (persist) {
-        const int grid = brick_grid(B, lds);
-        if (partial) hipLaunchKernelGGL((k_spmv_brick<true, 1>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
-        else hipLaunchKernelGGL((k_spmv_brick<false, 1>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
-    } else {
-        if (partial) hipLaunchKernelGGL((k_spmv_brick<true, 0>), dim3(B.ntiles), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
-        else hipLaunchKernelGGL((k_spmv_brick<false, 0>), dim3(B.ntiles), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
-    }
+    const int grid = brick_grid(B, lds);
+    if (partial) hipLaunchKernelGGL((k_spmv_brick<true>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
+    else hipLaunchKernelGGL((k_spmv_brick<false>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
     AVS_HIP(hipGetLastError());
     return AVS_OK;
 }
@@ -457,16 +405,12 @@ extern "C" avs_status avs_brick_spmv_probe(const avs_brick_arrays *a, const doub
 {
     AVS_REQUIRE(a && x && y && repeats > 0, AVS_EINVAL, "bad argument");
     AVS_REQUIRE(a->table_size > 0 && a->table_size < avs::kBrickTableMax, AVS_EINVAL, "value table size %d out of range", a->table_size);
-    static_assert(sizeof(avs::BrickTile) == 192, "tile header layout");
     avs::BrickView B;
     B.ntiles = a->ntiles;
-    B.tiles = reinterpret_cast<const avs::BrickTile *>(a->tiles);
-    B.rdesc = a->rdesc;
-    B.rorder = a->rorder;
+    B.tile_blk = reinterpret_cast<const uint2 *>(a->tile_blk);
+    B.blocks = a->blocks;
+    B.rdesc = reinterpret_cast<const uint2 *>(a->rdesc);
     B.ownslot = a->ownslot;
-    B.runs = a->runs;
-    B.pquads = a->pquads;
-    B.pinfo = a->pinfo;
     B.pwords = a->pwords;
     B.sdesc = reinterpret_cast<const uint2 *>(a->sdesc);
     B.swords = a->swords;
@@ -489,13 +433,13 @@ extern "C" avs_status avs_brick_spmv_probe(const avs_brick_arrays *a, const doub
         for (int w = 0; w < avs::kStampWgs; ++w)
             for (int i = 1; i + 1 < avs::kStampTiles; ++i) {
                 const long long *p = &hs[((size_t)w * avs::kStampTiles + i) * 8], *pn = p + 8;
-                if (!p[0] || !p[5] || !pn[0]) continue;
+                if (!p[0] || !p[4] || !pn[0]) continue;
                 acc[0] += (double)(p[1] - p[0]); acc[1] += (double)(p[2] - p[1]); acc[2] += (double)(p[3] - p[2]);
-                acc[3] += (double)(p[4] - p[3]); acc[4] += (double)(p[5] - p[4]); acc[5] += (double)(pn[0] - p[0]);
+                acc[3] += (double)(p[4] - p[3]); acc[4] += (double)(pn[0] - p[4]); acc[5] += (double)(pn[0] - p[0]);
                 ++cnt;
             }
         if (cnt)
-            fprintf(stderr, "brick phases (us, mean of %ld tiles): wait data %.2f | lds writes + barrier %.2f | pattern rows %.2f | streamed %.2f | barrier B %.2f | tile %.2f\n",
+            fprintf(stderr, "brick phases (us, mean of %ld tiles): block to LDS + barrier %.2f | issue loads, LDS writes, barrier %.2f | pattern rows %.2f | streamed + dot %.2f | loop %.2f | tile %.2f\n",
                     cnt, acc[0] / cnt / 100, acc[1] / cnt / 100, acc[2] / cnt / 100, acc[3] / cnt / 100, acc[4] / cnt / 100, acc[5] / cnt / 100);
     }
     return AVS_OK;

@@ -210,40 +210,29 @@ constexpr int kCwinOffBits = 14, kCwinSlotBits = 6, kCwinSlots = 1 << kCwinSlotB
 // ---------------------------------------------------------------------------------------------
 constexpr int kBrickLoff[5] = {0, 3000, 3648, 3840, 3921}; // slot offsets of the level-0..3 lattices: (8>>l)+2 cells per axis, 3 faces per cell
 constexpr int kBrickSlots = 3921, kBrickSlotsPad = 3936;
-constexpr int kBrickMaxRows = 1024;   // rows per tile (a full 8^3 brick of fine cells holds 1536 + its coarse faces: cut in two)
+constexpr int kBrickMaxRows = 1024;   // rows per tile, two per thread (a fuller brick is cut into two tiles with one lattice origin)
+constexpr int kBrickMaxRuns = 320;    // halo fill runs per tile
+constexpr int kBrickXSlots = 160;     // extra x slots per tile behind the lattice (slots 3936 .. 4095: off-lattice columns in the 27 neighbour bricks)
 constexpr int kBrickPatWords = 2560;  // pattern words staged in LDS per tile (10 KiB)
 constexpr int kBrickPark = 1024;      // products of streamed rows parked per pass in a G tile (8 KiB): 52.7 KiB per workgroup, three per CU
 constexpr int kBrickPatMax = 512;     // patterns per tile
 constexpr int kBrickPatLen = 64;      // longest row stored as a pattern
 constexpr int kBrickTableMax = 2048;  // value dictionary entries (LDS resident)
 constexpr int kBrickMinRows = 64;     // bricks with fewer rows are merged into E tiles
-constexpr int kBrickETileRows = 128;   // rows per E tile: its words fit one pass of the lattice's LDS (3936) unless the rows are long
-struct BrickTile {                     // 192 B per tile, read with scalar loads
-    int32_t row0, nrows;              // the tile's rows (brick-major ids)
-    int32_t npat, pat0;               // patterns staged in LDS: pinfo[pat0 ..)
-    int32_t run0, nruns;              // fill runs
-    int32_t pq0, npq;                 // pattern quads: pquads[pq0 ..) -> LDS quad 0 .. npq-1
-    int32_t srow0, nsrows;            // streamed rows
-    int32_t sword0, nsw;              // their words
-    int32_t rd0, nprow;               // pattern rows in execution order: rdesc / rorder [rd0 .. rd0 + nprow)
-    int32_t pad[2];
-    int32_t nb[32];                   // first row of the 27 bricks around the tile's brick, index (dz+1)*9 + (dy+1)*3 + (dx+1)
-};
+constexpr int kBrickETileRows = 256;   // rows per E tile: its words fit one pass of the lattice's LDS (3936) unless the rows are long
 struct BrickView {
     int ntiles = 0;
-    const BrickTile *tiles = nullptr;
-    const uint32_t *rdesc = nullptr;  // per pattern row, execution order: pattern id << 20 | level << 18 | axis << 16 | (cz+1) << 8 | (cy+1) << 4 | (cx+1)
-    const uint16_t *rorder = nullptr; // ... and its position in the tile (row = row0 + rorder)
+    const uint2 *tile_blk = nullptr;  // per tile: first 16-B unit of its descriptor block in `blocks`, units (<= 512)
+    const uint32_t *blocks = nullptr; // descriptor blocks (layout: avs_brick.hip), 16-B aligned
+    const uint2 *rdesc = nullptr;     // per pattern row, execution order: {pattern id << 20 | level << 18 | axis << 16 | (cz+1) << 8 | (cy+1) << 4 | (cx+1), position in the tile}
     const uint16_t *ownslot = nullptr; // per row: its own lattice slot in its tile (0xffff: none); the fill runs cover the halo only
-    const uint32_t *runs = nullptr;   // fill runs: neighbour brick << 27 | offset in it << 16 | first slot << 4 | len - 1
-    const uint32_t *pquads = nullptr; // per tile, per LDS quad: word offset of the quad in pwords
-    const uint32_t *pinfo = nullptr;  // per tile pattern: first word in the tile's LDS image | quads << 16 | (every column on the level-0 lattice) << 31
-    const uint32_t *pwords = nullptr; // pattern words: delta << 19 (signed 13 bits) | lattice level << 14 | value code << 3; a pattern is padded to quads with its first entry's slot and the code of 0.0 (= table_size)
+    const uint32_t *pwords = nullptr; // pattern words: delta << 19 (signed 13 bits) | lattice level << 14 | value code << 3; a pattern is
+                                      // padded to quads with its first entry's slot and the code of 0.0 (= table_size)
     const uint2 *sdesc = nullptr;     // streamed rows: local row | len << 16, first word relative to the tile's sword0
     const uint32_t *swords = nullptr; // code << col_bits | column, CSR order
     const double *table = nullptr;
     int table_size = 0, col_bits = 0;
-    int debug = 0; // measurement only: 1 no fill, 2 no pattern rows, 4 no streamed rows (wrong results)
+    int debug = 0; // measurement only: 1 no fill, 2 no pattern rows, 4 no streamed rows (wrong results), 16 phase stamps
 };
 size_t brick_lds_bytes(const BrickView &B);
 avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, double *partial, const int *done_flag, hipStream_t stream);

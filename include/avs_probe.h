@@ -11,18 +11,14 @@ extern "C" {
  * (tools/brick_build.py, the reference builder the device builder is tested against). */
 typedef struct {
     int32_t ntiles;
-    const int32_t *tiles;    /* 48 x int32 per tile: row0, nrows, npat, pat0, run0, nruns, pq0, npq, srow0, nsrows, sword0, nsw, rd0, nprow, 2 x pad,
-                                32 x first row of the neighbour bricks */
-    const uint32_t *rdesc;   /* per pattern row (execution order) */
-    const uint16_t *rorder;  /* its position in the tile */
-    const uint16_t *ownslot; /* per row: own lattice slot in its tile, 0xffff none */
-    const uint32_t *runs;    /* fill runs, 4 B each */
-    const uint32_t *pquads;  /* per tile and LDS quad: word offset in pwords */
-    const uint32_t *pinfo;   /* per tile pattern: local first word | len << 16 */
-    const uint32_t *pwords;  /* global pattern words */
-    const uint32_t *sdesc;   /* 2 x uint32 per streamed row: local row | len << 16, first word relative to the tile's */
-    const uint32_t *swords;  /* streamed words (code << col_bits | column), CSR order */
-    const double *table;     /* value dictionary */
+    const uint32_t *tile_blk; /* 2 x uint32 per tile: first 16-B unit of its descriptor block, units */
+    const uint32_t *blocks;   /* descriptor blocks (layout: csrc/avs_brick.hip) */
+    const uint32_t *rdesc;    /* 2 x uint32 per pattern row (execution order): descriptor, position in the tile */
+    const uint16_t *ownslot;  /* per row: own lattice slot in its tile, 0xffff none */
+    const uint32_t *pwords;   /* global pattern words */
+    const uint32_t *sdesc;    /* 2 x uint32 per streamed row: local row | len << 16, first word relative to the tile's */
+    const uint32_t *swords;   /* streamed words (code << col_bits | column), CSR order */
+    const double *table;      /* value dictionary */
     int32_t table_size, col_bits;
 } avs_brick_arrays;
 /* y = A x (+ per-wave partials of x.y when partial != NULL) with the brick kernel, `repeats` timed launches */

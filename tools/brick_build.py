@@ -10,6 +10,10 @@ import torch
 
 LOFF = [0, 3000, 3648, 3840, 3921]
 MAX_ROWS = 1024
+MAX_RUNS = 320
+BLOCK_WORDS = 1728
+XSLOT0 = 3936      # first extra slot (off-lattice columns inside the 27 neighbour bricks)
+XSLOTS = 160
 PAT_WORDS = 2560
 PAT_MAX = 512
 PAT_LEN = 64
@@ -115,6 +119,21 @@ def build(rp, col, code, geo, table_size, col_bits):
     lc = lv[col]
     cslot = lattice_slot(lc, ax[col], [I[k][col] for k in range(3)], ob)
     base = base_slot(lv[row_e], [I[k][row_e] for k in range(3)], ob, lc)
+    # off-lattice columns of G tiles that lie in one of the 27 neighbour bricks (a coarse face on the brick's boundary reads fine faces two
+    # cells away): up to XSLOTS extra slots per tile behind the lattice, addressed relative to the row's level-0 base
+    cbk = brick[col]
+    nbr = ((cbk % nbx - ob[0]).abs() <= 1) & (((cbk // nbx) % nby - ob[1]).abs() <= 1) & ((cbk // (nbx * nby) - ob[2]).abs() <= 1)
+    xcand = (cslot < 0) & nbr & tile_is_g[t_e]
+    xpair = torch.unique(t_e[xcand] * n + col[xcand])
+    xt = xpair // n
+    xrank = torch.arange(len(xpair), device=dev) - torch.searchsorted(xt, xt)
+    xs_slot = torch.full((nnz,), -1, dtype=torch.int64, device=dev)
+    pos = torch.searchsorted(xpair, t_e[xcand] * n + col[xcand])
+    xs_slot[xcand] = torch.where(xrank[pos] < XSLOTS, XSLOT0 + xrank[pos], torch.full_like(pos, -1))
+    is_x = xs_slot >= 0
+    cslot = torch.where(is_x, xs_slot, cslot)
+    lc_eff = torch.where(is_x, torch.zeros_like(lc), lc)
+    base = torch.where(is_x, base_slot(lv[row_e], [I[k][row_e] for k in range(3)], ob, torch.zeros_like(lc)), base)
     delta = cslot - base
     ent_ok = (cslot >= 0) & (delta >= -4096) & (delta < 4096) & (code < 2048)
     own = lattice_slot(lv, ax, I, [tbx[tile_of_row], tby[tile_of_row], tbz[tile_of_row]])
@@ -126,7 +145,7 @@ def build(rp, col, code, geo, table_size, col_bits):
     cell_ok = (cell[0] >= 0) & (cell[0] < 16) & (cell[1] >= 0) & (cell[1] < 16) & (cell[2] >= 0) & (cell[2] < 16)
     regular = tile_is_g[tile_of_row] & ~bad_rows & (lens <= PAT_LEN) & (lens > 0) & (own >= 0) & cell_ok & (lv < 4)
 
-    word = ((delta & 0x1fff) << 19) | (lc.clamp(max=3) << 14) | ((code & 0x7ff) << 3)
+    word = ((delta & 0x1fff) << 19) | (lc_eff.clamp(max=3) << 14) | ((code & 0x7ff) << 3)
     j_in_row = torch.arange(nnz, device=dev) - rp[:-1][row_e]
     M1, M2, M3 = -7046029254386353131, -4417276706812531889, 1609587929392839161
     h = (word * M1) ^ (word >> 15) * M2
@@ -141,7 +160,7 @@ def build(rp, col, code, geo, table_size, col_bits):
     rep = torch.full((npatg,), n, dtype=torch.int64, device=dev)
     rep.scatter_reduce_(0, ginv, reg_rows, reduce="amin")       # representative row of every pattern (the first)
     plen = lens[rep]
-    nz_tag = torch.zeros(n, dtype=torch.bool, device=dev); nz_tag[row_e[lc != 0]] = True
+    nz_tag = torch.zeros(n, dtype=torch.bool, device=dev); nz_tag[row_e[lc_eff != 0]] = True
     psimple = (~nz_tag[rep]).long()
     plen4 = (plen + 3) & ~3
     poff = torch.zeros(npatg + 1, dtype=torch.int64, device=dev); poff[1:] = torch.cumsum(plen4, 0)
@@ -262,7 +281,7 @@ def build(rp, col, code, geo, table_size, col_bits):
     if len(sdesc) == 0: sdesc = torch.zeros((1, 2), dtype=torch.int64, device=dev)
     total_words = int(sword0[-1])
 
-    # tile headers: 48 ints
+    # ---- one descriptor block per tile: header (48 words) | runs | pquads | pinfo | rdesc | rorder (u16) | ownslot (u16), padded to 16 B
     bfirst = torch.full((int(brick.max()) + 2,), 0, dtype=torch.int64, device=dev)   # first row of every brick id (0 for bricks without rows)
     bfirst[brick[bstart]] = bstart
     nb = torch.zeros((ntiles, 32), dtype=torch.int64, device=dev)
@@ -275,16 +294,37 @@ def build(rp, col, code, geo, table_size, col_bits):
                 idb = ((Z * nby + Y) * nbx + X).clamp(0, len(bfirst) - 1)
                 nb[:, (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)] = torch.where(ok, bfirst[idb], torch.zeros_like(idb))
     z = torch.zeros_like(pat0)
-    tiles = torch.cat([torch.stack([tile_row0, tile_rows, npat_tile, pat0, run0, nruns_tile, pq0, npq_tile, srow0, ns_tile, sword0[:-1], nsw_tile, rd0, nprow_tile, z, z], 1), nb], 1)
+    hdr = torch.cat([torch.stack([tile_row0, tile_rows, npat_tile, nruns_tile, npq_tile, nprow_tile, srow0, ns_tile, sword0[:-1], nsw_tile, rd0, z, z, z, z, z], 1), nb], 1)
+    words = 48 + nruns_tile + npq_tile + npat_tile
+    units = (words + 3) // 4
+    assert int(words.max()) <= BLOCK_WORDS, f"a tile's descriptor block has {int(words.max())} words"
+    assert int(nruns_tile.max()) <= MAX_RUNS, f"a tile with {int(nruns_tile.max())} halo runs"
+    unit0 = torch.cumsum(units, 0) - units
+    blocks = torch.zeros(int(units.sum()) * 4 + 2048, dtype=torch.int64, device=dev)
+    w0 = unit0 * 4
+    def put(per_tile_start, counts, values):
+        """values: concatenation over tiles (tile-major) of `counts[t]` words each -> blocks[w0[t] + per_tile_start[t] + i]"""
+        if len(values) == 0: return
+        tix = torch.repeat_interleave(torch.arange(ntiles, device=dev), counts)
+        i = torch.arange(len(values), device=dev) - (torch.cumsum(counts, 0) - counts)[tix]
+        blocks[w0[tix] + per_tile_start[tix] + i] = values
+    blocks[(w0[:, None] + torch.arange(48, device=dev)[None, :]).flatten()] = hdr.flatten()
+    o = torch.full_like(w0, 48)
+    put(o, nruns_tile, runs[: int(nruns_tile.sum())]); o = o + nruns_tile
+    put(o, npq_tile, pquads[: int(npq_tile.sum())]); o = o + npq_tile
+    put(o, npat_tile, pinfo[: int(npat_tile.sum())]); o = o + npat_tile
+    tile_blk = torch.stack([unit0, units], 1)
+
     stats = dict(rows=n, nnz=nnz, tiles=ntiles, g_tiles=int(tile_is_g.sum()), regular_rows=int(regular.sum()), regular_nnz=int(lens[regular].sum()),
                  global_patterns=npatg, pattern_words=int(poff[-1]), tile_patterns=int(len(up)), runs=int(len(rstart)), max_runs_per_tile=int(nruns_tile.max()), max_pattern_quads_per_tile=int(npq_tile.max()), streamed_rows=int(len(srows)),
                  streamed_words=total_words, hash_collision_rows=int(coll.sum()), dropped_rows=int(len(dropped)),
-                 bytes=dict(rdesc=6 * int(len(prow)), ownslot=2 * n, runs=4 * int(len(rstart)), pquads=4 * int(npq_tile.sum()), pinfo=4 * int(len(up)), swords=4 * total_words, sdesc=8 * int(len(srows)),
-                            tiles=192 * ntiles, pwords=4 * int(poff[-1])))
+                 bytes=dict(rdesc=8 * int(len(prow)), ownslot=2 * n,  swords=4 * total_words, sdesc=8 * int(len(srows)),
+                            blocks=16 * int(units.sum()), pwords=4 * int(poff[-1])))
     stats["bytes"]["total"] = sum(stats["bytes"].values())
     i32 = lambda t: t.to(torch.int32).contiguous()
-    out = dict(ntiles=ntiles, tiles=i32(tiles), rdesc=_u32(rdesc), rorder=rorder.to(torch.int16).contiguous(), ownslot=torch.where(ownslot >= 32768, ownslot - 65536, ownslot).to(torch.int16).contiguous(), runs=_u32(runs), pquads=_u32(pquads), pinfo=_u32(pinfo), pwords=_u32(pwords),
-               sdesc=_u32(sdesc), swords=_u32(swords), table_size=table_size, col_bits=col_bits, stats=stats)
+    out = dict(ntiles=ntiles, tile_blk=_u32(tile_blk), blocks=_u32(blocks), rdesc=_u32(torch.stack([rdesc, rorder], 1)),
+               ownslot=torch.where(ownslot >= 32768, ownslot - 65536, ownslot).to(torch.int16).contiguous(), pwords=_u32(pwords), sdesc=_u32(sdesc), swords=_u32(swords),
+               table_size=table_size, col_bits=col_bits, stats=stats)
     return out
 
 
@@ -298,33 +338,34 @@ def emulate(form, table, x):
     """y = A x with the arithmetic of k_spmv_brick (torch, any device): per row left-to-right, multiply then add"""
     dev = x.device
     u = lambda t: t.long() & 0xffffffff
-    T = form["tiles"].long()
     n = len(x)
     y = torch.zeros(n, dtype=torch.float64, device=dev)
-    rdesc = u(form["rdesc"]); runs = u(form["runs"]); pquads = u(form["pquads"]); pinfo = u(form["pinfo"]); pw = u(form["pwords"])
+    TB = u(form["tile_blk"]); BL = u(form["blocks"]); pw = u(form["pwords"])
     sdesc = u(form["sdesc"]); sw = u(form["swords"])
     cb = form["col_bits"]
     for t in range(form["ntiles"]):
-        row0, nrows, npat, pat0, run0, nruns, pq0, npq, sr0, nsr, sw0, nsw = [int(v) for v in T[t, :12]]
-        nbb = T[t, 16:48]
-        xs = torch.full((3936,), float("nan"), dtype=torch.float64, device=dev)
-        for q in range(run0, run0 + nruns):
-            d = int(runs[q])
-            c = int(nbb[d >> 27]) + ((d >> 16) & 0x7ff)
-            s, ln = (d >> 4) & 0xfff, (d & 15) + 1
-            xs[s:s + ln] = x[c:c + ln]
+        b0 = int(TB[t, 0]) * 4
+        bw = BL[b0: b0 + int(TB[t, 1]) * 4]
+        row0, nrows, npat, nruns, npq, nprow, sr0, nsr, sw0, nsw, rd0_ = [int(v) for v in bw[:11]]
+        o_runs = 48; o_pq = o_runs + nruns; o_pi = o_pq + npq
+        RD = u(form["rdesc"])
+        xs = torch.full((3936 + 160,), float("nan"), dtype=torch.float64, device=dev)
+        for q in range(nruns):
+            d = int(bw[o_runs + q])
+            c = int(bw[16 + (d >> 27)]) + ((d >> 16) & 0x7ff)
+            s_, ln = (d >> 4) & 0xfff, (d & 15) + 1
+            xs[s_:s_ + ln] = x[c:c + ln]
         if npat > 0:
             for r in range(nrows):
                 o = int(form["ownslot"][row0 + r]) & 0xffff
                 if o != 0xffff: xs[o] = x[row0 + r]
         lds = torch.zeros(max(4 * npq, 4), dtype=torch.int64, device=dev)
         for q in range(npq):
-            o = int(pquads[pq0 + q])
+            o = int(bw[o_pq + q])
             lds[4 * q:4 * q + 4] = pw[o:o + 4]
-        rd0_, nprow = int(T[t, 12]), int(T[t, 13])
         for i in range(nprow):
-            d = int(rdesc[rd0_ + i])
-            r = int(form["rorder"][rd0_ + i]) & 0xffff
+            d = int(RD[rd0_ + i, 0])
+            r = int(RD[rd0_ + i, 1])
             pid = d >> 20
             assert pid < npat
             lr, axis = (d >> 18) & 3, (d >> 16) & 3
@@ -335,23 +376,23 @@ def emulate(form, table, x):
                 S = (8 >> lc) + 2
                 b = [((v >> up) << dn) + 1 for v in c]
                 base.append(LOFF[lc] + ((b[2] * S + b[1]) * S + b[0]) * 3)
-            pi = int(pinfo[pat0 + pid])
+            pi = int(bw[o_pi + pid])
             off, ln = pi & 0xffff, 4 * ((pi >> 16) & 0x7fff)
-            s = torch.zeros((), dtype=torch.float64, device=dev)
+            s_ = torch.zeros((), dtype=torch.float64, device=dev)
             for j in range(ln):
                 w = int(lds[off + j])
                 dl = w >> 19
                 if dl >= 4096: dl -= 8192
-                if pi >> 31: assert (w >> 14) & 3 == 0
-                tv = table[(w >> 3) & 0x7ff] if ((w >> 3) & 0x7ff) < len(table) else torch.zeros((), dtype=torch.float64, device=dev)
-                s = s + tv * xs[base[(w >> 14) & 3] + dl]
-            y[row0 + r] = s
+                code = (w >> 3) & 0x7ff
+                tv = table[code] if code < len(table) else torch.zeros((), dtype=torch.float64, device=dev)
+                s_ = s_ + tv * xs[base[(w >> 14) & 3] + dl]
+            y[row0 + r] = s_
         for i in range(nsr):
             d, stw = int(sdesc[sr0 + i, 0]), int(sdesc[sr0 + i, 1])
             lrow, ln = d & 0xffff, d >> 16
-            s = torch.zeros((), dtype=torch.float64, device=dev)
+            s_ = torch.zeros((), dtype=torch.float64, device=dev)
             for j in range(ln):
                 w = int(sw[sw0 + stw + j])
-                s = s + table[w >> cb] * x[w & ((1 << cb) - 1)]
-            y[row0 + lrow] = s
+                s_ = s_ + table[w >> cb] * x[w & ((1 << cb) - 1)]
+            y[row0 + lrow] = s_
     return y

@@ -56,9 +56,9 @@ build_s = time.time() - t0
 st = form["stats"]
 
 class Arr(C.Structure):
-    _fields_ = [("ntiles", C.c_int32)] + [(k, C.c_void_p) for k in ("tiles", "rdesc", "rorder", "ownslot", "runs", "pquads", "pinfo", "pwords", "sdesc", "swords", "table")] + \
+    _fields_ = [("ntiles", C.c_int32)] + [(k, C.c_void_p) for k in ("tile_blk", "blocks", "rdesc", "ownslot", "pwords", "sdesc", "swords", "table")] + \
                [("table_size", C.c_int32), ("col_bits", C.c_int32)]
-arr = Arr(form["ntiles"], *[form[k].data_ptr() for k in ("tiles", "rdesc", "rorder", "ownslot", "runs", "pquads", "pinfo", "pwords", "sdesc", "swords")], table.data_ptr(),
+arr = Arr(form["ntiles"], *[form[k].data_ptr() for k in ("tile_blk", "blocks", "rdesc", "ownslot", "pwords", "sdesc", "swords")], table.data_ptr(),
           len(table), col_bits)
 L.avs_brick_spmv_probe.argtypes = [C.POINTER(Arr), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_double)]
 g = torch.Generator(device=dev); g.manual_seed(7)
