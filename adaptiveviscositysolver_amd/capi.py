@@ -105,7 +105,8 @@ class DistInfo(C.Structure):
 class MatrixFormat(C.Structure):
     _fields_ = [("reordered", C.c_int32), ("value_table_size", C.c_int32), ("column_bits", C.c_int32),
                 ("bytes_per_nonzero", C.c_int32), ("tile_local_tables", C.c_int32),
-                ("column_windows", C.c_int32)]
+                ("column_windows", C.c_int32), ("brick_tiles", C.c_int32), ("brick_patterns", C.c_int32),
+                ("brick_pattern_rows", C.c_int64), ("brick_bytes", C.c_int64)]
 
 
 _lib = None

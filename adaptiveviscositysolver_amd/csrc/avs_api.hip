@@ -412,6 +412,11 @@ avs_status avs_get_matrix_format(avs_ctx *c, avs_matrix_format *fmt)
     fmt->bytes_per_nonzero = vi ? c->vi.bytes_per_nonzero() : 12;
     fmt->tile_local_tables = vi && c->vi.tile_tables ? 1 : 0;
     fmt->column_windows = vi && c->vi.col_windows ? 1 : 0;
+    const bool bk = c->reordered && c->brick.ready;
+    fmt->brick_tiles = bk ? c->brick.ntiles : 0;
+    fmt->brick_patterns = bk ? c->brick.patterns : 0;
+    fmt->brick_pattern_rows = bk ? c->brick.regular_rows : 0;
+    fmt->brick_bytes = bk ? c->brick.stored_bytes(c->n_vel) : 0;
     return AVS_OK;
 }
 
@@ -437,6 +442,7 @@ static CsrView csr_of(avs_ctx *c)
     A.val = c->reordered ? c->p_val.p : c->val.p;
     if (c->reordered) c->vi.apply(A);
     A.no_precond = c->no_precond;
+    A.brick = (c->reordered && c->brick.ready) ? &c->brick_view : nullptr;
     return A;
 }
 
@@ -685,6 +691,7 @@ avs_status avs_bench_spmv(avs_ctx *c, int32_t variant, int32_t repeats, double *
     const double *xin = c->reordered ? c->p_x0.p : c->x0.p;
     const bool dot = variant >= 100; // 100 + id: the fused-dot form the solver launches
     if (dot) variant -= 100;
+    if (variant == 61) { A.brick = nullptr; variant = 0; } // the value-indexed stream kernel where the brick form would be used
     DevBuf<double> partial;
     if (dot) AVS_TRY(partial.alloc(spmv_partial_elems(n)));
     AVS_TRY(dot ? spmv_dot_launch(A, xin, y.p, partial.p, variant, c->stream) : spmv_launch(A, xin, y.p, variant, c->stream)); // warm-up

@@ -77,7 +77,7 @@ constexpr int kBrickRu = kBrickMaxRuns / (kBrickBlk / 16);              // halo 
 //   [10] rd0 (first pattern-row descriptor of the tile in rdesc)
 //   runs[nruns] | pquads[npq] | pinfo[npat]
 // The per-row arrays (rdesc: descriptor + position of every pattern row in execution order; ownslot) stay in global memory.
-constexpr int kBlkHdr = 48;
+constexpr int kBlkHdr = kBlkHdrWords;
 
 template <bool DOT>
 __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_spmv_brick(BrickView B, const double *__restrict__ x, double *__restrict__ y,

@@ -1,0 +1,784 @@
+// avs_brick_build.hip -- builds the brick-structured SpMV form (avs_brick.hip) of the brick-major system on the device.
+//
+// Input: the permuted CSR (p_row_ptr / p_col), its value codes and packed words (ValueIndex: one dictionary of < 2047 values, code and
+// column in one 32-bit word), the permutation and the dof table (which face a row is: level, axis, cell -- cpp:1566-1593).  Output: the
+// arrays behind BrickView.  Lossless by construction: a row is stored as a pattern only after its words have been compared, one by one,
+// with the words of the pattern it hashed to (K5); anything that does not fit a limit (lattice, extra slots, LDS budgets, runs) is kept
+// as packed words ("streamed" rows) -- tests/test_gpu_matrix_formats.py and avs_bench_spmv compare y with the plain CSR kernel bit for bit.
+//
+//   K1  geometry of every row (brick, level, axis, cell) + brick starts               [one host round trip: the tile table, O(bricks)]
+//   K3  per G tile: extra slots (off-lattice columns in the 27 neighbour bricks), per entry its slot and pattern word, per row a 64-bit
+//       hash of the word sequence
+//   K4  global pattern set: hash-table insert, pattern ids + storage, copy of the representative rows' words    [counts read back]
+//   K5  every row against its pattern, word for word (hash collisions become streamed rows)
+//   K6  per tile: patterns used (LDS budgets), execution order (sorted by length, pattern), row descriptors, halo fill runs, own slots,
+//       descriptor block
+//   K7  streamed rows: their packed words compacted tile after tile, headers patched
+#include <algorithm>
+#include <vector>
+
+#include "avs_internal.hpp"
+
+namespace avs {
+
+namespace {
+constexpr int kBlk = 256;
+constexpr int kTileBlk = 512;
+constexpr int kHashBitsPat = 21;                 // pattern hash table: 2 M slots
+constexpr int kMaxPatterns = 1 << 19;            // more distinct patterns: the scene is not regular, the form is not built
+constexpr int kBlockStride = 1728;               // words reserved per descriptor block (48 + 320 + 640 + 512 = 1520 at the limits)
+constexpr int kXsRows = kBrickXSlots;
+
+struct TileInfo {                                // built on the host from the brick starts
+    int32_t row0, nrows, is_g, obx, oby, obz, pad0, pad1;
+    int32_t nb[32];
+};
+
+__device__ __forceinline__ uint64_t geo_pack(uint32_t brick, int level, int axis, int i, int j, int k)
+{
+    return ((uint64_t)brick << 38) | ((uint64_t)(level & 7) << 35) | ((uint64_t)(axis & 3) << 33) | ((uint64_t)(i & 0x7ff) << 22) |
+           ((uint64_t)(j & 0x7ff) << 11) | (uint64_t)(k & 0x7ff);
+}
+struct Geo { int brick, level, axis, i, j, k; };
+__device__ __forceinline__ Geo geo_unpack(uint64_t g)
+{
+    Geo r;
+    r.brick = (int)(g >> 38); r.level = (int)((g >> 35) & 7); r.axis = (int)((g >> 33) & 3);
+    r.i = (int)((g >> 22) & 0x7ff); r.j = (int)((g >> 11) & 0x7ff); r.k = (int)(g & 0x7ff);
+    return r;
+}
+
+// K1: brick, level, axis, level-cell of every row of the brick-major system (the key of k_brick_keys, avs_reorder.hip)
+__global__ __launch_bounds__(kBlk) void k_bk_geo(const int32_t *__restrict__ vdof, const int32_t *__restrict__ perm, int64_t n, int nx, int ny,
+                                                int nz, uint64_t *__restrict__ geo)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlk + threadIdx.x;
+    if (r >= n) return;
+    const int4 rec = reinterpret_cast<const int4 *>(vdof)[perm[r]];
+    const int level = rec.x & 0xff, axis = (rec.x >> 8) & 0xff;
+    int px = rec.y << level, py = rec.z << level, pz = rec.w << level;
+    px = px < nx ? px : nx - 1;
+    py = py < ny ? py : ny - 1;
+    pz = pz < nz ? pz : nz - 1;
+    const uint32_t nbx = (uint32_t)((nx + 7) >> 3), nby = (uint32_t)((ny + 7) >> 3);
+    const uint32_t brick = ((uint32_t)(pz >> 3) * nby + (uint32_t)(py >> 3)) * nbx + (uint32_t)(px >> 3);
+    geo[r] = geo_pack(brick, level, axis, rec.y, rec.z, rec.w);
+}
+__global__ __launch_bounds__(kBlk) void k_bk_first(const uint64_t *__restrict__ geo, int64_t n, int32_t *__restrict__ first)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlk + threadIdx.x;
+    if (r >= n) return;
+    first[r] = (r == 0 || (geo[r] >> 38) != (geo[r - 1] >> 38)) ? 1 : 0;
+}
+__global__ __launch_bounds__(kBlk) void k_bk_brick_starts(const uint64_t *__restrict__ geo, const int32_t *__restrict__ first,
+                                                         const int32_t *__restrict__ bidx, int64_t n, int32_t *__restrict__ bstart,
+                                                         int32_t *__restrict__ bbrick)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlk + threadIdx.x;
+    if (r >= n || !first[r]) return;
+    bstart[bidx[r]] = (int32_t)r;
+    bbrick[bidx[r]] = (int32_t)(geo[r] >> 38);
+}
+
+// slot of a face on the lattices of a tile whose brick is (obx, oby, obz): -1 when it is not on them
+__device__ __forceinline__ int lattice_slot(const Geo &g, int obx, int oby, int obz)
+{
+    if (g.level > 3) return -1;
+    const int w = 8 >> g.level, S = w + 2;
+    const int rx = g.i - w * obx + 1, ry = g.j - w * oby + 1, rz = g.k - w * obz + 1;
+    if (rx < 0 || rx >= S || ry < 0 || ry >= S || rz < 0 || rz >= S) return -1;
+    return kBrickLoff[g.level] + ((rz * S + ry) * S + rx) * 3 + g.axis;
+}
+// base of a row (level lr, local level-lr cell c = cell - w_lr * origin) on the lattice of level lc (as k_spmv_brick computes it)
+__device__ __forceinline__ int base_slot(int lr, int cx, int cy, int cz, int lc)
+{
+    const int up = lc > lr ? lc - lr : 0, dn = lr > lc ? lr - lc : 0;
+    const int S = (8 >> lc) + 2;
+    const int bx = ((cx >> up) << dn) + 1, by = ((cy >> up) << dn) + 1, bz = ((cz >> up) << dn) + 1;
+    return kBrickLoff[lc] + ((bz * S + by) * S + bx) * 3;
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t h)
+{
+    h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 33;
+    return h;
+}
+
+// K3: one workgroup per tile.  Pass A collects the off-lattice columns that lie in the 27 neighbour bricks (extra slots, ascending column
+// order so that the fill finds runs); pass B gives every entry its slot + pattern word and every row its hash.
+__global__ __launch_bounds__(kTileBlk) void k_bk_rows(const TileInfo *__restrict__ tiles, const int32_t *__restrict__ row_ptr,
+                                                     const int32_t *__restrict__ col, const uint16_t *__restrict__ codes,
+                                                     const uint64_t *__restrict__ geo, int nbx, int nby, int zero_code,
+                                                     uint32_t *__restrict__ ewords, uint16_t *__restrict__ eslot, uint64_t *__restrict__ row_hash,
+                                                     uint32_t *__restrict__ rgeo, uint16_t *__restrict__ ownslot)
+{
+    __shared__ int xset[512];       // hash set of extra columns
+    __shared__ int xlist[512];      // ... compacted, then sorted
+    __shared__ int xcount;
+    const TileInfo &T = tiles[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int row0 = T.row0, nrows = T.nrows;
+    if (!T.is_g) {
+        for (int r = tid; r < nrows; r += kTileBlk) {
+            row_hash[row0 + r] = 0ull;
+            rgeo[row0 + r] = 0u;
+            ownslot[row0 + r] = 0xffffu;
+        }
+        return;
+    }
+    const int obx = T.obx, oby = T.oby, obz = T.obz;
+    xset[tid] = -1;
+    if (tid == 0) xcount = 0;
+    __syncthreads();
+    for (int r = tid; r < nrows; r += kTileBlk) {
+        const int rs = row_ptr[row0 + r], re = row_ptr[row0 + r + 1];
+        for (int k = rs; k < re; ++k) {
+            const int c = col[k];
+            const Geo g = geo_unpack(geo[c]);
+            if (lattice_slot(g, obx, oby, obz) >= 0) continue;
+            const int cbx = g.brick % nbx, cby = (g.brick / nbx) % nby, cbz = g.brick / (nbx * nby);
+            if (abs(cbx - obx) > 1 || abs(cby - oby) > 1 || abs(cbz - obz) > 1) continue;
+            unsigned h = ((unsigned)c * 2654435761u) >> 23; // 9 bits
+            for (int probe = 0; probe < 512; ++probe) {
+                const int old = atomicCAS(&xset[h], -1, c);
+                if (old == -1 || old == c) break;
+                h = (h + 1) & 511u;
+            }
+        }
+    }
+    __syncthreads();
+    if (xset[tid] >= 0) xlist[atomicAdd(&xcount, 1)] = xset[tid];
+    __syncthreads();
+    const int nxs = xcount; // (a full set means more than 512 candidates: the surplus never got in and stays off-lattice)
+    int mine = -1, rank = 0;
+    if (tid < nxs) {
+        mine = xlist[tid];
+        for (int i = 0; i < nxs; ++i) rank += xlist[i] < mine ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid < nxs) xlist[rank] = mine; // ascending
+    __syncthreads();
+    const int nxk = nxs < kXsRows ? nxs : kXsRows; // the smallest kXsRows columns get a slot
+    for (int r = tid; r < nrows; r += kTileBlk) {
+        const int row = row0 + r;
+        const Geo gr = geo_unpack(geo[row]);
+        const int rs = row_ptr[row], re = row_ptr[row + 1];
+        const int own = lattice_slot(gr, obx, oby, obz);
+        const int w = 8 >> (gr.level > 3 ? 3 : gr.level);
+        const int cx = gr.i - w * obx, cy = gr.j - w * oby, cz = gr.k - w * obz; // local cell, -1 .. w for a lattice row
+        bool ok = own >= 0 && re > rs && re - rs <= kBrickPatLen && cx >= -1 && cx < 15 && cy >= -1 && cy < 15 && cz >= -1 && cz < 15;
+        uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)(re - rs);
+        bool simple = true;
+        for (int k = rs; k < re; ++k) {
+            const int c = col[k];
+            const Geo g = geo_unpack(geo[c]);
+            int slot = lattice_slot(g, obx, oby, obz);
+            int tag = g.level > 3 ? 3 : g.level;
+            if (slot < 0) { // extra slot?
+                int lo = 0, hi = nxk;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (xlist[mid] < c) lo = mid + 1; else hi = mid;
+                }
+                if (lo < nxk && xlist[lo] == c) { slot = kBrickSlotsPad + lo; tag = 0; }
+            }
+            const unsigned code = codes[k];
+            uint32_t word = 0u;
+            if (slot >= 0 && gr.level <= 3) {
+                const int delta = slot - base_slot(gr.level, cx, cy, cz, tag);
+                if (delta < -4096 || delta > 4095 || code >= (unsigned)zero_code) ok = false;
+                word = ((uint32_t)(delta & 0x1fff) << 19) | ((uint32_t)tag << 14) | (code << 3);
+                if (tag) simple = false;
+            } else {
+                ok = false;
+            }
+            ewords[k] = word;
+            eslot[k] = slot >= 0 ? (uint16_t)slot : (uint16_t)0xffffu;
+            h = mix64(h ^ (uint64_t)word) + (uint64_t)(k - rs) * 0x9e3779b97f4a7c15ull;
+        }
+        if (h == 0ull) h = 1ull;
+        row_hash[row] = ok ? h : 0ull;
+        // descriptor without the pattern id: simple << 31 is dropped later (it lives in pinfo), level << 18 | axis << 16 | cell + 1
+        rgeo[row] = ok ? (((uint32_t)gr.level << 18) | ((uint32_t)gr.axis << 16) | ((uint32_t)(cz + 1) << 8) | ((uint32_t)(cy + 1) << 4) |
+                          (uint32_t)(cx + 1) | (simple ? 0x80000000u : 0u))
+                       : 0u;
+        ownslot[row] = own >= 0 ? (uint16_t)own : (uint16_t)0xffffu;
+    }
+}
+
+// K4a: insert the hashes; the winner of a slot leaves its row as the pattern's representative
+__global__ __launch_bounds__(kBlk) void k_bk_insert(const uint64_t *__restrict__ row_hash, int64_t n, unsigned long long *__restrict__ keys,
+                                                   int32_t *__restrict__ rep, int *__restrict__ overflow)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlk + threadIdx.x;
+    if (r >= n) return;
+    const uint64_t h = row_hash[r];
+    if (!h) return;
+    unsigned s = (unsigned)(h >> (64 - kHashBitsPat));
+    for (int probe = 0; probe < 64; ++probe) {
+        const unsigned long long cur = __hip_atomic_load(&keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == h) return;
+        if (cur == 0ull) {
+            const unsigned long long old = atomicCAS(&keys[s], 0ull, (unsigned long long)h);
+            if (old == 0ull) { rep[s] = (int32_t)r; return; }
+            if (old == h) return;
+        }
+        s = (s + 1) & ((1u << kHashBitsPat) - 1u);
+    }
+    atomicExch(overflow, 1); // (the row will not find its hash in K5 and becomes a streamed row)
+}
+// K4b: every occupied slot becomes a pattern: id, length, storage
+__global__ __launch_bounds__(kBlk) void k_bk_assign(const unsigned long long *__restrict__ keys, const int32_t *__restrict__ rep,
+                                                   const int32_t *__restrict__ row_ptr, int32_t *__restrict__ slot_id,
+                                                   int32_t *__restrict__ pat_rep, int32_t *__restrict__ pat_off, int *__restrict__ counters)
+{
+    const int s = blockIdx.x * kBlk + threadIdx.x;
+    if (s >= (1 << kHashBitsPat)) return;
+    slot_id[s] = -1;
+    if (!keys[s]) return;
+    const int id = atomicAdd(&counters[0], 1);
+    if (id >= kMaxPatterns) return;
+    const int r = rep[s];
+    const int len4 = (row_ptr[r + 1] - row_ptr[r] + 3) & ~3;
+    const int off = atomicAdd(&counters[1], len4);
+    slot_id[s] = id;
+    pat_rep[id] = r;
+    pat_off[id] = off;
+}
+// K4c: the representative rows' words become the pattern table (padded to quads: first entry's slot, code of 0.0)
+__global__ __launch_bounds__(kBlk) void k_bk_copy_patterns(int npat, const int32_t *__restrict__ pat_rep, const int32_t *__restrict__ pat_off,
+                                                          const int32_t *__restrict__ row_ptr, const uint32_t *__restrict__ ewords,
+                                                          int zero_code, uint32_t *__restrict__ pwords)
+{
+    const int sub = threadIdx.x & 15;
+    const int p = (blockIdx.x * kBlk + threadIdx.x) >> 4;
+    if (p >= npat) return;
+    const int r = pat_rep[p], rs = row_ptr[r], len = row_ptr[r + 1] - rs, off = pat_off[p];
+    const int len4 = (len + 3) & ~3;
+    const uint32_t pad = (ewords[rs] & ~(0x7ffu << 3)) | ((uint32_t)zero_code << 3);
+    for (int j = sub; j < len4; j += 16) pwords[off + j] = j < len ? ewords[rs + j] : pad;
+}
+// K5: a row keeps its pattern only if its words ARE the pattern's words
+__global__ __launch_bounds__(kBlk) void k_bk_verify(const uint64_t *__restrict__ row_hash, int64_t n, const unsigned long long *__restrict__ keys,
+                                                   const int32_t *__restrict__ slot_id, const int32_t *__restrict__ pat_off,
+                                                   const int32_t *__restrict__ pat_rep, const int32_t *__restrict__ row_ptr,
+                                                   const uint32_t *__restrict__ ewords, const uint32_t *__restrict__ pwords,
+                                                   int32_t *__restrict__ row_pid)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlk + threadIdx.x;
+    if (r >= n) return;
+    const uint64_t h = row_hash[r];
+    int pid = -1;
+    if (h) {
+        unsigned s = (unsigned)(h >> (64 - kHashBitsPat));
+        for (int probe = 0; probe < 64; ++probe) {
+            const unsigned long long cur = keys[s];
+            if (cur == h) { pid = slot_id[s]; break; }
+            if (cur == 0ull) break;
+            s = (s + 1) & ((1u << kHashBitsPat) - 1u);
+        }
+        if (pid >= 0) {
+            const int rs = row_ptr[r], len = row_ptr[r + 1] - rs;
+            const int q = pat_rep[pid];
+            if (row_ptr[q + 1] - row_ptr[q] != len) pid = -1;
+            else {
+                const int off = pat_off[pid];
+                for (int j = 0; j < len; ++j)
+                    if (ewords[rs + j] != pwords[off + j]) { pid = -1; break; }
+            }
+        }
+    }
+    row_pid[r] = pid;
+}
+
+// K6: one workgroup per tile writes everything the SpMV reads for it
+__global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict__ tiles, const int32_t *__restrict__ row_ptr,
+                                                     const int32_t *__restrict__ col, const uint16_t *__restrict__ eslot,
+                                                     const int32_t *__restrict__ row_pid, const uint32_t *__restrict__ rgeo,
+                                                     const int32_t *__restrict__ pat_off, const int32_t *__restrict__ pat_rep,
+                                                     const uint64_t *__restrict__ geo, int nbx, int nby, const uint8_t *__restrict__ force_e,
+                                                     uint32_t *__restrict__ blocks, uint2 *__restrict__ tile_blk, uint2 *__restrict__ rdesc,
+                                                     uint2 *__restrict__ sdesc, int32_t *__restrict__ slen, int32_t *__restrict__ tile_info_out,
+                                                     int *__restrict__ fallbacks)
+{
+    __shared__ int smap[4096];                 // slot -> column of the halo fill
+    __shared__ int pkey[1024], pidx[1024];     // distinct global pattern ids of the tile (hash set) -> list index
+    __shared__ int plist[1024], plen4[1024], pstart[1024]; // ... in list order: id, padded length, first word in the LDS image
+    __shared__ unsigned skey[1024];            // execution order sort
+    __shared__ int scan[kTileBlk];
+    __shared__ int counters[8];                // 0 patterns listed, 1 patterns kept, 2 pattern rows, 3 streamed rows, 4 streamed words, 5 runs
+    const int t = blockIdx.x;
+    const TileInfo &T = tiles[t];
+    const int tid = threadIdx.x;
+    const int row0 = T.row0, nrows = T.nrows;
+    uint32_t *blk = blocks + (int64_t)t * kBlockStride;
+    const bool gtile = T.is_g && !(force_e && force_e[t]);
+    for (int i = tid; i < 4096; i += kTileBlk) smap[i] = -1;
+    for (int i = tid; i < 1024; i += kTileBlk) { pkey[i] = -1; skey[i] = 0xffffffffu; }
+    if (tid < 8) counters[tid] = 0;
+    __syncthreads();
+    // ---- distinct patterns
+    int my_pid[2] = {-1, -1};
+    if (gtile)
+        for (int k = 0; k < 2; ++k) {
+            const int r = tid + k * kTileBlk;
+            if (r >= nrows) break;
+            const int pid = row_pid[row0 + r];
+            my_pid[k] = pid;
+            if (pid < 0) continue;
+            unsigned h = ((unsigned)pid * 2654435761u) >> 22; // 10 bits
+            for (;;) {
+                const int old = atomicCAS(&pkey[h], -1, pid);
+                if (old == -1) { const int li = atomicAdd(&counters[0], 1); pidx[h] = li; plist[li] = pid; break; }
+                if (old == pid) break;
+                h = (h + 1) & 1023u;
+            }
+        }
+    __syncthreads();
+    const int nlist = counters[0];
+    for (int i = tid; i < nlist; i += kTileBlk) {
+        const int q = pat_rep[plist[i]];
+        plen4[i] = (row_ptr[q + 1] - row_ptr[q] + 3) & ~3;
+    }
+    __syncthreads();
+    if (tid == 0) { // list order prefix (<= 1024 entries): which patterns fit the LDS image
+        int acc = 0, kept = 0;
+        for (int i = 0; i < nlist; ++i) {
+            if (kept < kBrickPatMax && acc + plen4[i] <= kBrickPatWords && i == kept) { pstart[i] = acc; acc += plen4[i]; ++kept; }
+            else pstart[i] = -1;
+        }
+        counters[1] = kept;
+        counters[6] = acc; // words
+    }
+    __syncthreads();
+    const int npat = counters[1], npq = counters[6] >> 2;
+    // ---- rows: pattern row (local index) or streamed
+    int my_li[2] = {-1, -1}, my_len[2] = {0, 0};
+    for (int k = 0; k < 2; ++k) {
+        const int r = tid + k * kTileBlk;
+        if (r >= nrows) break;
+        my_len[k] = row_ptr[row0 + r + 1] - row_ptr[row0 + r];
+        const int pid = my_pid[k];
+        if (pid >= 0) {
+            unsigned h = ((unsigned)pid * 2654435761u) >> 22;
+            while (pkey[h] != pid) h = (h + 1) & 1023u;
+            const int li = pidx[h];
+            if (pstart[li] >= 0) my_li[k] = li;
+        }
+        if (my_li[k] >= 0) {
+            atomicAdd(&counters[2], 1);
+            skey[r] = ((unsigned)my_len[k] << 20) | ((unsigned)my_li[k] << 10) | (unsigned)r; // len <= 64, li < 512, r < 1024
+        }
+    }
+    __syncthreads();
+    const int nprow = counters[2];
+    // ---- execution order: bitonic sort of 1024 keys (0xffffffff = not a pattern row, sorts last)
+    for (int size = 2; size <= 1024; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < 512; i += kTileBlk) {
+                const int lo = ((i / stride) * stride * 2) + (i % stride), hi = lo + stride;
+                const bool up = ((lo / size) & 1) == 0;
+                const unsigned a = skey[lo], b = skey[hi];
+                if ((a > b) == up) { skey[lo] = b; skey[hi] = a; }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < nprow; i += kTileBlk) {
+        const unsigned key = skey[i];
+        const int r = (int)(key & 1023u), li = (int)((key >> 10) & 1023u);
+        rdesc[row0 + i] = uint2{((uint32_t)li << 20) | (rgeo[row0 + r] & 0x000fffffu), (uint32_t)r};
+    }
+    // ---- streamed rows: descriptors in row order, words counted (their offsets follow from a scan over all rows: K7)
+    int sflag[2], slenv[2];
+    for (int k = 0; k < 2; ++k) {
+        const int r = tid + k * kTileBlk;
+        sflag[k] = (r < nrows && my_li[k] < 0) ? 1 : 0;
+        slenv[k] = sflag[k] ? my_len[k] : 0;
+        if (r < nrows) slen[row0 + r] = slenv[k];
+    }
+    // block scan of (count, words) over the rows in row order: rows tid (k = 0) come before rows tid + 512 (k = 1)
+    int base_cnt = 0, base_w = 0;
+    for (int k = 0; k < 2; ++k) {
+        scan[tid] = sflag[k];
+        __syncthreads();
+        for (int o = 1; o < kTileBlk; o <<= 1) {
+            const int v = tid >= o ? scan[tid - o] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        const int my_cnt = scan[tid] - sflag[k] + base_cnt, tot_cnt = scan[kTileBlk - 1];
+        __syncthreads();
+        scan[tid] = slenv[k];
+        __syncthreads();
+        for (int o = 1; o < kTileBlk; o <<= 1) {
+            const int v = tid >= o ? scan[tid - o] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        const int my_w = scan[tid] - slenv[k] + base_w, tot_w = scan[kTileBlk - 1];
+        __syncthreads();
+        if (sflag[k]) sdesc[row0 + my_cnt] = uint2{(uint32_t)(tid + k * kTileBlk) | ((uint32_t)my_len[k] << 16), (uint32_t)my_w};
+        base_cnt += tot_cnt;
+        base_w += tot_w;
+    }
+    const int nsrows = base_cnt, nsw = base_w;
+    // ---- halo fill: slot -> column of every entry of a pattern row that is not one of the tile's own rows
+    if (gtile)
+        for (int k = 0; k < 2; ++k) {
+            if (my_li[k] < 0) continue;
+            const int row = row0 + tid + k * kTileBlk;
+            for (int e = row_ptr[row]; e < row_ptr[row + 1]; ++e) {
+                const int c = col[e];
+                if (c >= row0 && c < row0 + nrows) continue;
+                smap[eslot[e]] = c; // (a slot has one column: every writer stores the same value)
+            }
+        }
+    __syncthreads();
+    // run starts: slot s filled and not the continuation of the run through s - 1 (consecutive columns of one brick, at most 16 long)
+    constexpr int SPT = 4096 / kTileBlk; // 8 consecutive slots per thread
+    int nstart = 0;
+    unsigned startmask = 0;
+    {
+        const int s0 = tid * SPT;
+        for (int u = 0; u < SPT; ++u) {
+            const int s = s0 + u, c = smap[s];
+            if (c < 0) continue;
+            bool st = true;
+            if (s > 0) {
+                const int cp = smap[s - 1];
+                if (cp >= 0 && cp + 1 == c && (geo[cp] >> 38) == (geo[c] >> 38)) st = false;
+            }
+            if (st) { startmask |= 1u << u; ++nstart; }
+        }
+    }
+    // natural runs are cut every 16 slots: position inside the natural run needs the last natural start at or before s
+    __shared__ int laststart[kTileBlk];
+    {
+        int last = -1;
+        for (int u = 0; u < SPT; ++u)
+            if (startmask & (1u << u)) last = tid * SPT + u;
+        laststart[tid] = last;
+        __syncthreads();
+        for (int o = 1; o < kTileBlk; o <<= 1) { // inclusive max scan
+            const int v = tid >= o ? laststart[tid - o] : -1;
+            __syncthreads();
+            if (v > laststart[tid]) laststart[tid] = v;
+            __syncthreads();
+        }
+    }
+    unsigned cutmask = 0;
+    int ncut = 0;
+    {
+        int last = tid > 0 ? laststart[tid - 1] : -1;
+        for (int u = 0; u < SPT; ++u) {
+            const int s = tid * SPT + u;
+            if (smap[s] < 0) continue;
+            if (startmask & (1u << u)) last = s;
+            if (((s - last) & 15) == 0) { cutmask |= 1u << u; ++ncut; }
+        }
+    }
+    scan[tid] = ncut;
+    __syncthreads();
+    for (int o = 1; o < kTileBlk; o <<= 1) {
+        const int v = tid >= o ? scan[tid - o] : 0;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    const int nruns = scan[kTileBlk - 1];
+    int my_run = scan[tid] - ncut;
+    const bool fits = nruns <= kBrickMaxRuns && kBlkHdrWords + nruns + npq + npat <= kBlockStride;
+    __syncthreads();
+    if (!fits) { // (block-uniform) a tile over a limit is redone as an E tile
+        if (tid == 0) atomicExch(fallbacks, 1);
+        if (tid == 0) tile_info_out[t] = -1;
+        return;
+    }
+    if (gtile) {
+        for (int u = 0; u < SPT; ++u) {
+            if (!(cutmask & (1u << u))) continue;
+            const int s = tid * SPT + u;
+            int len = 1;
+            while (len < 16 && s + len < 4096 && smap[s + len] >= 0 && smap[s + len] == smap[s] + len && (geo[smap[s + len]] >> 38) == (geo[smap[s]] >> 38)) ++len;
+            // (the loop above may run past the next cut of the SAME natural run only if that cut is 16 away: len < 16 stops it)
+            const int c = smap[s];
+            const int cb = (int)(geo[c] >> 38);
+            const int cbx = cb % nbx, cby = (cb / nbx) % nby, cbz = cb / (nbx * nby);
+            const int w = (cbz - T.obz + 1) * 9 + (cby - T.oby + 1) * 3 + (cbx - T.obx + 1);
+            blk[kBlkHdrWords + my_run] = ((uint32_t)w << 27) | ((uint32_t)(c - T.nb[w]) << 16) | ((uint32_t)s << 4) | (uint32_t)(len - 1);
+            ++my_run;
+        }
+        // pattern quads + pinfo in list order
+        for (int i = tid; i < npat; i += kTileBlk) {
+            const int id = plist[i];
+            const uint32_t simple = rgeo[pat_rep[id]] >> 31;
+            blk[kBlkHdrWords + nruns + npq + i] = (uint32_t)pstart[i] | ((uint32_t)(plen4[i] >> 2) << 16) | (simple << 31);
+            for (int q = 0; q < (plen4[i] >> 2); ++q) blk[kBlkHdrWords + nruns + (pstart[i] >> 2) + q] = (uint32_t)(pat_off[id] + 4 * q);
+        }
+    }
+    // header
+    if (tid < 16) {
+        int v = 0;
+        switch (tid) {
+        case 0: v = row0; break;
+        case 1: v = nrows; break;
+        case 2: v = gtile ? npat : 0; break;
+        case 3: v = gtile ? nruns : 0; break;
+        case 4: v = gtile ? npq : 0; break;
+        case 5: v = gtile ? nprow : 0; break;
+        case 6: v = row0; break;   // srow0: the tile's streamed-row descriptors start at its first row
+        case 7: v = nsrows; break;
+        case 8: v = 0; break;      // sword0: K7
+        case 9: v = nsw; break;
+        case 10: v = row0; break;  // rd0: the tile's pattern-row descriptors start at its first row
+        default: break;
+        }
+        blk[tid] = (uint32_t)v;
+    }
+    if (tid < 32) blk[16 + tid] = (uint32_t)T.nb[tid];
+    if (tid == 0) {
+        const int words = kBlkHdrWords + (gtile ? nruns + npq + npat : 0);
+        tile_blk[t] = uint2{(uint32_t)((int64_t)t * (kBlockStride / 4)), (uint32_t)((words + 3) >> 2)};
+        tile_info_out[t] = nprow;
+    }
+}
+
+// K7: streamed words tile after tile (sstart = exclusive scan of slen over the rows) + the headers' sword0
+__global__ __launch_bounds__(kBlk) void k_bk_copy_streamed(int64_t n, const int32_t *__restrict__ slen, const int32_t *__restrict__ sstart,
+                                                          const int32_t *__restrict__ row_ptr, const uint32_t *__restrict__ packed,
+                                                          uint32_t *__restrict__ swords)
+{
+    const int sub = threadIdx.x & 15;
+    const int64_t groups = ((int64_t)gridDim.x * kBlk) >> 4;
+    for (int64_t r = ((int64_t)blockIdx.x * kBlk + threadIdx.x) >> 4; r < n; r += groups) {
+        const int len = slen[r];
+        if (!len) continue;
+        const int src = row_ptr[r], dst = sstart[r];
+        for (int j = sub; j < len; j += 16) swords[dst + j] = packed[src + j];
+    }
+}
+__global__ __launch_bounds__(kBlk) void k_bk_patch(int ntiles, const TileInfo *__restrict__ tiles, const int32_t *__restrict__ sstart,
+                                                  uint32_t *__restrict__ blocks)
+{
+    const int t = blockIdx.x * kBlk + threadIdx.x;
+    if (t >= ntiles) return;
+    blocks[(int64_t)t * kBlockStride + 8] = (uint32_t)sstart[tiles[t].row0];
+}
+__global__ __launch_bounds__(kBlk) void k_bk_count_regular(int ntiles, const int32_t *__restrict__ tile_nprow, unsigned long long *__restrict__ total)
+{
+    const int t = blockIdx.x * kBlk + threadIdx.x;
+    if (t < ntiles && tile_nprow[t] > 0) atomicAdd(total, (unsigned long long)tile_nprow[t]);
+}
+} // namespace
+
+void BrickForm::clear()
+{
+    ready = false;
+    ntiles = 0;
+    regular_rows = 0;
+    patterns = 0;
+}
+
+int64_t BrickForm::stored_bytes(int64_t n) const
+{
+    // descriptor blocks (used words), row descriptors 8 B, own slots 2 B per row, streamed words + descriptors, pattern table, tile list
+    return 4 * block_words + 8 * regular_rows + 2 * n + 4 * streamed_words + 8 * streamed_rows + 4 * pattern_words + 8 * (int64_t)ntiles;
+}
+
+void BrickForm::view(BrickView &B, const ValueIndex &vi) const
+{
+    B = BrickView();
+    if (!ready) return;
+    B.ntiles = ntiles;
+    B.tile_blk = tile_blk.p;
+    B.blocks = blocks.p;
+    B.rdesc = rdesc.p;
+    B.ownslot = ownslot.p;
+    B.pwords = pwords.p;
+    B.sdesc = sdesc.p;
+    B.swords = swords.p;
+    B.table = vi.table.p;
+    B.table_size = vi.table_size;
+    B.col_bits = vi.col_bits;
+}
+
+// c->p_row_ptr / p_col / vi (codes, packed) / perm / vdof -> c->brick.  Leaves c->brick.ready = false (and AVS_OK) when the matrix does
+// not qualify or is not regular enough; an error status only for real failures.
+avs_status build_brick_form(avs_ctx *c)
+{
+    BrickForm &bf = c->brick;
+    bf.clear();
+    const int64_t n = c->n_vel, nnz = c->nnz;
+    const ValueIndex &vi = c->vi;
+    if (n <= 0 || !c->reordered || vi.col_bits <= 0 || vi.tile_tables || vi.col_windows) return AVS_OK;
+    if (vi.table_size <= 0 || vi.table_size + 1 >= kBrickTableMax) return AVS_OK; // (one code is reserved for 0.0)
+    if (c->brick_shift != 3 || c->desc.levels < 1) return AVS_OK;
+    if (c->desc.nx > 1024 || c->desc.ny > 1024 || c->desc.nz > 1024 || nnz >= (1ll << 31)) return AVS_OK;
+    hipStream_t st = c->stream;
+    const int nx = c->desc.nx, ny = c->desc.ny, nz = c->desc.nz;
+    const int nbx = (nx + 7) >> 3, nby = (ny + 7) >> 3, nbz = (nz + 7) >> 3;
+    BrickScratch &S = bf.scratch;
+    AVS_TRY(S.geo.reserve((size_t)n));
+    AVS_TRY(S.first.reserve((size_t)n + 1));
+    AVS_TRY(S.bidx.reserve((size_t)n + 1));
+    AVS_TRY(S.scan_tmp.reserve(scan_tmp_elems(n)));
+    const unsigned gn = (unsigned)((n + kBlk - 1) / kBlk);
+    hipLaunchKernelGGL(k_bk_geo, dim3(gn), dim3(kBlk), 0, st, c->vdof.p, c->perm.p, n, nx, ny, nz, S.geo.p);
+    hipLaunchKernelGGL(k_bk_first, dim3(gn), dim3(kBlk), 0, st, S.geo.p, n, S.first.p);
+    AVS_TRY(exclusive_scan_i32(S.first.p, S.bidx.p, n, S.scan_tmp.p, S.scan_tmp.n, st));
+    int32_t nbricks = 0;
+    AVS_HIP(hipMemcpyAsync(&nbricks, S.bidx.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipStreamSynchronize(st));
+    AVS_TRY(S.bstart.reserve((size_t)nbricks + 1));
+    AVS_TRY(S.bbrick.reserve((size_t)nbricks + 1));
+    hipLaunchKernelGGL(k_bk_brick_starts, dim3(gn), dim3(kBlk), 0, st, S.geo.p, S.first.p, S.bidx.p, n, S.bstart.p, S.bbrick.p);
+    std::vector<int32_t> hstart((size_t)nbricks + 1), hbrick((size_t)nbricks);
+    AVS_HIP(hipMemcpyAsync(hstart.data(), S.bstart.p, (size_t)nbricks * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipMemcpyAsync(hbrick.data(), S.bbrick.p, (size_t)nbricks * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipStreamSynchronize(st));
+    hstart[(size_t)nbricks] = (int32_t)n;
+    // ---- tiles (host, O(bricks)): a brick with >= kBrickMinRows rows is a G tile (cut every kBrickMaxRows rows), runs of smaller bricks
+    //      are cut into E tiles of kBrickETileRows rows
+    std::vector<TileInfo> tiles;
+    tiles.reserve((size_t)nbricks);
+    auto first_row_of = [&](int bx, int by, int bz) -> int32_t {
+        if (bx < 0 || bx >= nbx || by < 0 || by >= nby || bz < 0 || bz >= nbz) return 0;
+        const int32_t id = (bz * nby + by) * nbx + bx;
+        const auto it = std::lower_bound(hbrick.begin(), hbrick.end(), id);
+        return (it != hbrick.end() && *it == id) ? hstart[(size_t)(it - hbrick.begin())] : 0;
+    };
+    int64_t run_start = -1;
+    auto flush_run = [&](int64_t end) {
+        for (int64_t r0 = run_start; r0 < end; r0 += kBrickETileRows) {
+            TileInfo t{};
+            t.row0 = (int32_t)r0;
+            t.nrows = (int32_t)std::min<int64_t>(kBrickETileRows, end - r0);
+            tiles.push_back(t);
+        }
+        run_start = -1;
+    };
+    for (int32_t b = 0; b < nbricks; ++b) {
+        const int rows = hstart[(size_t)b + 1] - hstart[(size_t)b];
+        if (rows >= 2048) return AVS_OK; // (a run offset names at most 2047 rows of a brick)
+        if (rows >= kBrickMinRows) {
+            if (run_start >= 0) flush_run(hstart[(size_t)b]);
+            const int id = hbrick[(size_t)b];
+            const int bx = id % nbx, by = (id / nbx) % nby, bz = id / (nbx * nby);
+            for (int off = 0; off < rows; off += kBrickMaxRows) {
+                TileInfo t{};
+                t.row0 = hstart[(size_t)b] + off;
+                t.nrows = std::min(kBrickMaxRows, rows - off);
+                t.is_g = 1;
+                t.obx = bx; t.oby = by; t.obz = bz;
+                for (int dz = -1; dz <= 1; ++dz)
+                    for (int dy = -1; dy <= 1; ++dy)
+                        for (int dx = -1; dx <= 1; ++dx) t.nb[(dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)] = first_row_of(bx + dx, by + dy, bz + dz);
+                tiles.push_back(t);
+            }
+        } else if (run_start < 0) {
+            run_start = hstart[(size_t)b];
+        }
+    }
+    if (run_start >= 0) flush_run(n);
+    const int ntiles = (int)tiles.size();
+    if (ntiles == 0) return AVS_OK;
+    AVS_TRY(S.tiles.reserve((size_t)ntiles * sizeof(TileInfo)));
+    AVS_HIP(hipMemcpyAsync(S.tiles.p, tiles.data(), (size_t)ntiles * sizeof(TileInfo), hipMemcpyHostToDevice, st));
+    const TileInfo *dtiles = reinterpret_cast<const TileInfo *>(S.tiles.p);
+    // ---- K3
+    AVS_TRY(S.ewords.reserve((size_t)nnz));
+    AVS_TRY(S.eslot.reserve((size_t)nnz));
+    AVS_TRY(S.row_hash.reserve((size_t)n));
+    AVS_TRY(S.rgeo.reserve((size_t)n));
+    AVS_TRY(bf.ownslot.alloc((size_t)n + 8));
+    const int zero_code = vi.table_size;
+    hipLaunchKernelGGL(k_bk_rows, dim3(ntiles), dim3(kTileBlk), 0, st, dtiles, c->p_row_ptr.p, c->p_col.p, vi.codes.p, S.geo.p, nbx, nby, zero_code,
+                       S.ewords.p, S.eslot.p, S.row_hash.p, S.rgeo.p, bf.ownslot.p);
+    // ---- K4
+    const size_t hslots = (size_t)1 << kHashBitsPat;
+    AVS_TRY(S.keys.reserve(hslots));
+    AVS_TRY(S.rep.reserve(hslots));
+    AVS_TRY(S.slot_id.reserve(hslots));
+    AVS_TRY(S.pat_rep.reserve((size_t)kMaxPatterns));
+    AVS_TRY(S.pat_off.reserve((size_t)kMaxPatterns));
+    AVS_TRY(S.counters.reserve(16));
+    AVS_HIP(hipMemsetAsync(S.keys.p, 0, hslots * sizeof(unsigned long long), st));
+    AVS_HIP(hipMemsetAsync(S.counters.p, 0, 16 * sizeof(int), st));
+    hipLaunchKernelGGL(k_bk_insert, dim3(gn), dim3(kBlk), 0, st, S.row_hash.p, n, S.keys.p, S.rep.p, S.counters.p + 2);
+    hipLaunchKernelGGL(k_bk_assign, dim3((unsigned)(hslots / kBlk)), dim3(kBlk), 0, st, S.keys.p, S.rep.p, c->p_row_ptr.p, S.slot_id.p, S.pat_rep.p,
+                       S.pat_off.p, S.counters.p);
+    int hc[4] = {};
+    AVS_HIP(hipMemcpyAsync(hc, S.counters.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipStreamSynchronize(st));
+    const int npat = hc[0], nwords = hc[1];
+    if (npat <= 0 || npat > kMaxPatterns) return AVS_OK; // nothing regular / not a regular scene
+    AVS_TRY(bf.pwords.alloc((size_t)nwords + 16));
+    hipLaunchKernelGGL(k_bk_copy_patterns, dim3((unsigned)(((size_t)npat * 16 + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, npat, S.pat_rep.p, S.pat_off.p,
+                       c->p_row_ptr.p, S.ewords.p, zero_code, bf.pwords.p);
+    // ---- K5
+    AVS_TRY(S.row_pid.reserve((size_t)n));
+    hipLaunchKernelGGL(k_bk_verify, dim3(gn), dim3(kBlk), 0, st, S.row_hash.p, n, S.keys.p, S.slot_id.p, S.pat_off.p, S.pat_rep.p, c->p_row_ptr.p,
+                       S.ewords.p, bf.pwords.p, S.row_pid.p);
+    // ---- K6 (+ a second round for the tiles that exceeded a limit: they become E tiles)
+    AVS_TRY(bf.blocks.alloc((size_t)ntiles * kBlockStride + 64));
+    AVS_TRY(bf.tile_blk.alloc((size_t)ntiles + 1));
+    AVS_TRY(bf.rdesc.alloc((size_t)n + 8));
+    AVS_TRY(bf.sdesc.alloc((size_t)n + 8));
+    AVS_TRY(S.slen.reserve((size_t)n + 1));
+    AVS_TRY(S.sstart.reserve((size_t)n + 1));
+    AVS_TRY(S.tile_nprow.reserve((size_t)ntiles));
+    AVS_TRY(S.force_e.reserve((size_t)ntiles));
+    AVS_HIP(hipMemsetAsync(S.force_e.p, 0, (size_t)ntiles, st));
+    for (int round = 0; round < 2; ++round) {
+        AVS_HIP(hipMemsetAsync(S.counters.p + 4, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_bk_tile, dim3(ntiles), dim3(kTileBlk), 0, st, dtiles, c->p_row_ptr.p, c->p_col.p, S.eslot.p, S.row_pid.p, S.rgeo.p,
+                           S.pat_off.p, S.pat_rep.p, S.geo.p, nbx, nby, S.force_e.p, bf.blocks.p, bf.tile_blk.p, bf.rdesc.p, bf.sdesc.p, S.slen.p,
+                           S.tile_nprow.p, S.counters.p + 4);
+        int fb = 0;
+        AVS_HIP(hipMemcpyAsync(&fb, S.counters.p + 4, sizeof(int), hipMemcpyDeviceToHost, st));
+        AVS_HIP(hipStreamSynchronize(st));
+        if (!fb) break;
+        AVS_REQUIRE(round == 0, AVS_EINTERNAL, "brick form: a tile exceeds its limits as an E tile");
+        std::vector<int32_t> hn((size_t)ntiles);
+        std::vector<uint8_t> hf((size_t)ntiles, 0);
+        AVS_HIP(hipMemcpy(hn.data(), S.tile_nprow.p, (size_t)ntiles * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int t = 0; t < ntiles; ++t) hf[(size_t)t] = hn[(size_t)t] < 0 ? 1 : 0;
+        AVS_HIP(hipMemcpy(S.force_e.p, hf.data(), (size_t)ntiles, hipMemcpyHostToDevice));
+    }
+    // ---- K7
+    AVS_TRY(exclusive_scan_i32(S.slen.p, S.sstart.p, n, S.scan_tmp.p, S.scan_tmp.n, st));
+    AVS_TRY(S.total.reserve(1));
+    AVS_HIP(hipMemsetAsync(S.total.p, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_bk_count_regular, dim3((unsigned)((ntiles + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, ntiles, S.tile_nprow.p, S.total.p);
+    int32_t total_sw = 0;
+    unsigned long long regular = 0;
+    AVS_HIP(hipMemcpyAsync(&total_sw, S.sstart.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipMemcpyAsync(&regular, S.total.p, sizeof(regular), hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipStreamSynchronize(st));
+    AVS_TRY(bf.swords.alloc((size_t)total_sw + 16));
+    hipLaunchKernelGGL(k_bk_copy_streamed, dim3(4096), dim3(kBlk), 0, st, n, S.slen.p, S.sstart.p, c->p_row_ptr.p, vi.packed.p, bf.swords.p);
+    hipLaunchKernelGGL(k_bk_patch, dim3((unsigned)((ntiles + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, ntiles, dtiles, S.sstart.p, bf.blocks.p);
+    AVS_HIP(hipGetLastError());
+    bf.ntiles = ntiles;
+    bf.regular_rows = (int64_t)regular;
+    bf.patterns = npat;
+    bf.streamed_words = total_sw;
+    bf.pattern_words = nwords;
+    bf.streamed_rows = n - (int64_t)regular;
+    {
+        std::vector<uint2> hb((size_t)ntiles);
+        AVS_HIP(hipMemcpy(hb.data(), bf.tile_blk.p, (size_t)ntiles * sizeof(uint2), hipMemcpyDeviceToHost));
+        int64_t w = 0;
+        for (const uint2 &b : hb) w += 4 * (int64_t)b.y;
+        bf.block_words = w;
+    }
+    // worth it only where most rows are patterns (a curved surface with ~10^4 distinct values gives every row its own)
+    double min_frac = 0.6;
+    if (const char *e = getenv("AVS_BRICK_MIN_REGULAR")) min_frac = atof(e);
+    bf.ready = (double)regular >= min_frac * (double)n;
+    return AVS_OK;
+}
+
+} // namespace avs

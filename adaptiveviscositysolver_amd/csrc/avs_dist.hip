@@ -1299,6 +1299,7 @@ static avs_status dist_assemble_device(avs_ctx *c, PcgDist *d, int cut_axis, int
 // storage form of the rank's local rows (avs_get_matrix_format when no global matrix exists)
 bool dist_matrix_format(avs_ctx *c, avs_matrix_format *fmt)
 {
+    if (fmt) { fmt->brick_tiles = 0; fmt->brick_patterns = 0; fmt->brick_pattern_rows = 0; fmt->brick_bytes = 0; }
     PcgDist *d = c->dist;
     if (!d || !d->partitioned) return false;
     fmt->reordered = d->reordered ? 1 : 0;

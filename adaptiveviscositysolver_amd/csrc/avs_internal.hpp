@@ -202,12 +202,14 @@ struct CsrView {
     // re-encoding) are keyed on it -- a re-assembly may rewrite the same buffers
     uint64_t epoch = 0;
     int no_precond = 0; // AVS_PRECONDITIONER_NONE: the inverse diagonal the loops multiply with is 1 everywhere
+    const struct BrickView *brick = nullptr; // host pointer: the brick-structured form of this matrix (single-GPU launch-per-phase loop)
 };
 constexpr int kCwinOffBits = 14, kCwinSlotBits = 6, kCwinSlots = 1 << kCwinSlotBits, kCwinCodeBits = 32 - kCwinOffBits - kCwinSlotBits;
 
 // ---------------------------------------------------------------------------------------------
 // brick-structured form (avs_brick.hip): tile-local lattice slots + global row patterns + streamed rows
 // ---------------------------------------------------------------------------------------------
+constexpr int kBlkHdrWords = 48;         // header of a tile's descriptor block (avs_brick.hip)
 constexpr int kBrickLoff[5] = {0, 3000, 3648, 3840, 3921}; // slot offsets of the level-0..3 lattices: (8>>l)+2 cells per axis, 3 faces per cell
 constexpr int kBrickSlots = 3921, kBrickSlotsPad = 3936;
 constexpr int kBrickMaxRows = 1024;   // rows per tile, two per thread (a fuller brick is cut into two tiles with one lattice origin)
@@ -219,6 +221,7 @@ constexpr int kBrickPatMax = 512;     // patterns per tile
 constexpr int kBrickPatLen = 64;      // longest row stored as a pattern
 constexpr int kBrickTableMax = 2048;  // value dictionary entries (LDS resident)
 constexpr int kBrickMinRows = 64;     // bricks with fewer rows are merged into E tiles
+constexpr int64_t kBrickMinSystemRows = 2000000; // smaller systems run the CU-resident loop (or are launch-bound): the form is not built
 constexpr int kBrickETileRows = 256;   // rows per E tile: its words fit one pass of the lattice's LDS (3936) unless the rows are long
 struct BrickView {
     int ntiles = 0;
@@ -233,6 +236,30 @@ struct BrickView {
     const double *table = nullptr;
     int table_size = 0, col_bits = 0;
     int debug = 0; // measurement only: 1 no fill, 2 no pattern rows, 4 no streamed rows (wrong results), 16 phase stamps
+};
+// the form's arrays, owned by the context next to the CSR / value index of the solve matrix (avs_brick_build.hip)
+struct BrickScratch { // build-time buffers, kept across frames
+    DevBuf<uint64_t> geo, row_hash;
+    DevBuf<int32_t> first, bidx, scan_tmp, bstart, bbrick, rep, slot_id, pat_rep, pat_off, row_pid, slen, sstart, tile_nprow;
+    DevBuf<uint32_t> ewords, rgeo;
+    DevBuf<uint16_t> eslot;
+    DevBuf<unsigned long long> keys, total;
+    DevBuf<int> counters;
+    DevBuf<char> tiles;
+    DevBuf<uint8_t> force_e;
+};
+struct ValueIndex;
+struct BrickForm {
+    DevBuf<uint2> tile_blk, rdesc, sdesc;
+    DevBuf<uint32_t> blocks, pwords, swords;
+    DevBuf<uint16_t> ownslot;
+    BrickScratch scratch;
+    int ntiles = 0, patterns = 0;
+    int64_t regular_rows = 0, streamed_words = 0, block_words = 0, pattern_words = 0, streamed_rows = 0;
+    bool ready = false;
+    void clear();
+    void view(BrickView &B, const ValueIndex &vi) const;
+    int64_t stored_bytes(int64_t n) const; // what one SpMV launch reads of the matrix
 };
 size_t brick_lds_bytes(const BrickView &B);
 avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, double *partial, const int *done_flag, hipStream_t stream);
@@ -388,6 +415,7 @@ avs_status dist_halo_begin(PcgDist *d, double *p_ext, hipStream_t main_stream);
 avs_status dist_halo_end(PcgDist *d, hipStream_t main_stream);
 int spmv_tile_rows();
 avs_status build_reordered_system(struct ::avs_ctx *c, int brick_shift);
+avs_status build_brick_form(struct ::avs_ctx *c); // avs_brick_build.hip
 avs_status unpermute(struct ::avs_ctx *c, const double *xp, double *x);
 // builds the value dictionary of `val` (nnz entries); *table_size = 0 when there are more than 65536 distinct values
 avs_status build_value_index(const double *val, int64_t nnz, DevBuf<uint16_t> &codes, DevBuf<double> &table, int *table_size, hipStream_t st);
@@ -449,6 +477,8 @@ struct avs_ctx {
     avs::DevBuf<double> p_val, p_rhs, p_x0, p_x;
     // value dictionary of the solve matrix (avs_reorder.hip): at most 65536 distinct doubles
     avs::ValueIndex vi;
+    avs::BrickForm brick;   // brick-structured form of the solve matrix (large single-dictionary systems)
+    avs::BrickView brick_view;
     bool reordered = false;
     int brick_shift = 3; // 8^3 fine cells per brick; < 0 disables the renumbering
     avs_assembly_info ainfo{};

@@ -1000,6 +1000,10 @@ static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, do
                                 const PcgScalars *sc, int variant, hipStream_t stream, int *nblocks)
 {
     if (A.n <= 0) { if (nblocks) *nblocks = 0; return AVS_OK; }
+    if (A.brick && A.brick->ntiles > 0 && (variant == 0 || variant == spmv_default_variant(A))) { // brick-structured form (avs_brick.hip)
+        if (nblocks) *nblocks = A.brick->ntiles * 8;
+        return spmv_brick_launch(*A.brick, x, y, DOT ? partial : nullptr, (DOT && sc) ? &sc->done : nullptr, stream);
+    }
     if (A.codes && (variant == 0 || variant == spmv_default_variant(A))) { // value-indexed matrix: 6 or 4 B per non-zero
         const int nt = (int)((A.n + kTileRows - 1) / kTileRows);
         if (nblocks) *nblocks = nt * (kTileRows / 64);
@@ -2333,6 +2337,14 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
         const avs_status rs = pcg_solve_resident_single(w, A, b, x, tol, max_iters, stream, info, &ran);
         if (ran || rs != AVS_OK) return rs;
     }
+    if (A.brick && A.brick->ntiles > 0) { // one partial per wave of every tile: tiles may be smaller than 512 rows
+        const size_t need = 2 * ((size_t)A.brick->ntiles * 8 + 16) + 4 * (size_t)kVecGrid + 16;
+        if (need > w->npartial) {
+            AVS_TRY(w->partial.alloc(need));
+            w->npartial = need;
+            if (w->graph) { (void)hipGraphExecDestroy(w->graph); w->graph = nullptr; }
+        }
+    }
     const int vgrid = (int)((n + kBlock - 1) / kBlock < kVecGrid ? (n + kBlock - 1) / kBlock : kVecGrid);
     const int g = vgrid > 0 ? vgrid : 1;
     const int rowgrid = (int)((n + kBlock - 1) / kBlock) > 0 ? (int)((n + kBlock - 1) / kBlock) : 1;
@@ -2432,7 +2444,7 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
         timed_chunk = !replay;
         if (replay) {
             const void *key[10] = {A.row_ptr, A.col, A.val, A.codes, A.packed, A.table, x, (const void *)(intptr_t)A.n,
-                                   (const void *)(intptr_t)(A.table_size * 64 + A.col_bits), (const void *)(intptr_t)((coded ? 1 : 0) | (fuse_beta ? 2 : 0) | (int64_t)(A.epoch << 2))};
+                                   (const void *)(intptr_t)(A.table_size * 64 + A.col_bits), (const void *)(intptr_t)((coded ? 1 : 0) | (fuse_beta ? 2 : 0) | (A.brick ? 4 : 0) | (int64_t)(A.epoch << 3))};
             if (w->graph && (memcmp(key, w->graph_key, sizeof(key)) != 0 || w->graph_tol != tol)) {
                 (void)hipGraphExecDestroy(w->graph);
                 w->graph = nullptr;

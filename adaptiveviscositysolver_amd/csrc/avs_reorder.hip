@@ -142,6 +142,12 @@ avs_status build_reordered_system(avs_ctx *c, int brick_shift)
     AVS_HIP(hipGetLastError());
     AVS_TRY(build_matrix_index(c->p_row_ptr.p, c->p_col.p, c->p_val.p, n, nnz, n, c->vi, st));
     c->reordered = true;
+    // systems too large for the CU-resident loop: the brick-structured form of the matrix (avs_brick.hip); AVS_BRICK=0 / 1 never / always
+    c->brick.clear();
+    int want = n >= kBrickMinSystemRows ? 1 : 0;
+    if (const char *e = getenv("AVS_BRICK")) want = atoi(e);
+    if (want) AVS_TRY(build_brick_form(c));
+    c->brick.view(c->brick_view, c->vi);
     return AVS_OK;
 }
 

@@ -192,6 +192,11 @@ typedef struct avs_matrix_format {
     int32_t bytes_per_nonzero;  /* 12, 6 or 4 */
     int32_t tile_local_tables;  /* 1 = one dictionary per 512-row SpMV tile (value_table_size = total entries, 8 B each, streamed once) */
     int32_t column_windows;     /* 1 = 4-B words code | window slot | offset: a tile's columns lie in <= 64 windows of 2^14 ids (+ 256 B per tile) */
+    int32_t brick_tiles;        /* > 0 = the single-GPU loop multiplies with the brick-structured form (csrc/avs_brick.hip): rows of one 8^3
+                                 * brick of fine cells stored as geometric row patterns (one 8-B descriptor per row), the rest as 4-B words */
+    int32_t brick_patterns;     /* distinct row patterns of the whole matrix */
+    int64_t brick_pattern_rows; /* rows stored as patterns */
+    int64_t brick_bytes;        /* bytes the brick kernel streams per launch for the matrix (descriptors, runs, pattern lists, words) */
 } avs_matrix_format;
 avs_status avs_get_matrix_format(avs_ctx *ctx, avs_matrix_format *fmt);
 avs_status avs_get_solution(avs_ctx *ctx, double *x, int64_t n, avs_memspace where);
