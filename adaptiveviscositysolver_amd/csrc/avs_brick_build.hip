@@ -15,6 +15,7 @@
 //       descriptor block
 //   K7  streamed rows: their packed words compacted tile after tile, headers patched
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "avs_internal.hpp"
@@ -80,6 +81,89 @@ __global__ __launch_bounds__(kBlk) void k_bk_brick_starts(const uint64_t *__rest
     bbrick[bidx[r]] = (int32_t)(geo[r] >> 38);
 }
 
+// ---- tiles, from the brick starts (all O(bricks)): a brick with >= kBrickMinRows rows is a G tile (cut every kBrickMaxRows rows), the rows
+//      of a run of smaller bricks are cut into E tiles of kBrickETileRows rows
+__global__ __launch_bounds__(kBlk) void k_bk_run_first(const int32_t *__restrict__ bstart, int nbricks, int32_t *__restrict__ run_first)
+{
+    const int b = blockIdx.x * kBlk + threadIdx.x;
+    if (b >= nbricks) return;
+    const bool big = bstart[b + 1] - bstart[b] >= kBrickMinRows;
+    const bool prev_big = b == 0 || bstart[b] - bstart[b - 1] >= kBrickMinRows;
+    run_first[b] = (!big && prev_big) ? 1 : 0;
+}
+__global__ __launch_bounds__(kBlk) void k_bk_run_starts(const int32_t *__restrict__ bstart, const int32_t *__restrict__ run_first,
+                                                       const int32_t *__restrict__ run_id, int nbricks, int32_t *__restrict__ run_start)
+{
+    const int b = blockIdx.x * kBlk + threadIdx.x;
+    if (b < nbricks && run_first[b]) run_start[run_id[b]] = bstart[b];
+}
+// tiles a brick starts: a big brick ceil(rows / kBrickMaxRows); a small one the multiples of kBrickETileRows (counted from its run's
+// first row) that fall inside it
+__device__ __forceinline__ int tiles_of_brick(const int32_t *bstart, const int32_t *run_first, const int32_t *run_id, const int32_t *run_start, int b,
+                                              int *first_off)
+{
+    const int r0 = bstart[b], rows = bstart[b + 1] - r0;
+    if (rows >= kBrickMinRows) { *first_off = 0; return (rows + kBrickMaxRows - 1) / kBrickMaxRows; }
+    const int rid = run_id[b] + (run_first[b] ? 0 : -1); // exclusive scan: the run this brick belongs to
+    const int off = r0 - run_start[rid];
+    const int k0 = (off + kBrickETileRows - 1) / kBrickETileRows, k1 = (off + rows + kBrickETileRows - 1) / kBrickETileRows;
+    *first_off = k0 * kBrickETileRows - off;
+    return k1 - k0;
+}
+__global__ __launch_bounds__(kBlk) void k_bk_tile_counts(const int32_t *__restrict__ bstart, const int32_t *__restrict__ run_first,
+                                                        const int32_t *__restrict__ run_id, const int32_t *__restrict__ run_start, int nbricks,
+                                                        int32_t *__restrict__ tcount, int *__restrict__ too_big)
+{
+    const int b = blockIdx.x * kBlk + threadIdx.x;
+    if (b >= nbricks) return;
+    if (bstart[b + 1] - bstart[b] >= 2048) atomicExch(too_big, 1); // (a run offset names at most 2047 rows of a brick)
+    int fo;
+    tcount[b] = tiles_of_brick(bstart, run_first, run_id, run_start, b, &fo);
+}
+__global__ __launch_bounds__(kBlk) void k_bk_tile_rows(const int32_t *__restrict__ bstart, const int32_t *__restrict__ bbrick,
+                                                      const int32_t *__restrict__ run_first, const int32_t *__restrict__ run_id,
+                                                      const int32_t *__restrict__ run_start, const int32_t *__restrict__ tile0, int nbricks, int nbx,
+                                                      int nby, TileInfo *__restrict__ tiles)
+{
+    const int b = blockIdx.x * kBlk + threadIdx.x;
+    if (b >= nbricks) return;
+    int fo;
+    const int cnt = tiles_of_brick(bstart, run_first, run_id, run_start, b, &fo);
+    const int r0 = bstart[b], rows = bstart[b + 1] - r0;
+    const bool big = rows >= kBrickMinRows;
+    const int id = bbrick[b];
+    for (int i = 0; i < cnt; ++i) {
+        TileInfo &T = tiles[tile0[b] + i];
+        T.row0 = r0 + (big ? i * kBrickMaxRows : fo + i * kBrickETileRows);
+        T.is_g = big ? 1 : 0;
+        T.obx = id % nbx; T.oby = (id / nbx) % nby; T.obz = id / (nbx * nby);
+    }
+}
+// rows of a tile = up to the next tile's first row; first rows of the 27 bricks around a G tile's brick (binary search in the brick list)
+__global__ __launch_bounds__(kBlk) void k_bk_tile_finish(int ntiles, int64_t n, const int32_t *__restrict__ bstart, const int32_t *__restrict__ bbrick,
+                                                        int nbricks, int nbx, int nby, int nbz, TileInfo *__restrict__ tiles)
+{
+    const int sub = threadIdx.x & 31;
+    const int t = (blockIdx.x * kBlk + threadIdx.x) >> 5;
+    if (t >= ntiles) return;
+    TileInfo &T = tiles[t];
+    if (sub == 0) T.nrows = (t + 1 < ntiles ? tiles[t + 1].row0 : (int32_t)n) - T.row0;
+    int v = 0;
+    if (T.is_g && sub < 27) {
+        const int bx = T.obx + sub % 3 - 1, by = T.oby + (sub / 3) % 3 - 1, bz = T.obz + sub / 9 - 1;
+        if (bx >= 0 && bx < nbx && by >= 0 && by < nby && bz >= 0 && bz < nbz) {
+            const int id = (bz * nby + by) * nbx + bx;
+            int lo = 0, hi = nbricks;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (bbrick[mid] < id) lo = mid + 1; else hi = mid;
+            }
+            if (lo < nbricks && bbrick[lo] == id) v = bstart[lo];
+        }
+    }
+    T.nb[sub] = v;
+}
+
 // slot of a face on the lattices of a tile whose brick is (obx, oby, obz): -1 when it is not on them
 __device__ __forceinline__ int lattice_slot(const Geo &g, int obx, int oby, int obz)
 {
@@ -104,17 +188,38 @@ __device__ __forceinline__ uint64_t mix64(uint64_t h)
     return h;
 }
 
-// K3: one workgroup per tile.  Pass A collects the off-lattice columns that lie in the 27 neighbour bricks (extra slots, ascending column
-// order so that the fill finds runs); pass B gives every entry its slot + pattern word and every row its hash.
+// global pattern set (K4a): insert a row's hash; the winner of a slot leaves the row as the pattern's representative
+__device__ __forceinline__ void pattern_insert(uint64_t h, int row, unsigned long long *__restrict__ keys, int32_t *__restrict__ rep, int *overflow)
+{
+    unsigned s = (unsigned)(h >> (64 - kHashBitsPat));
+    for (int probe = 0; probe < 64; ++probe) {
+        const unsigned long long cur = __hip_atomic_load(&keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == h) return;
+        if (cur == 0ull) {
+            const unsigned long long old = atomicCAS(&keys[s], 0ull, (unsigned long long)h);
+            if (old == 0ull) { rep[s] = (int32_t)row; return; }
+            if (old == h) return;
+        }
+        s = (s + 1) & ((1u << kHashBitsPat) - 1u);
+    }
+    atomicExch(overflow, 1); // (the row will not find its hash in K5 and becomes a streamed row)
+}
+
+// K3: one workgroup per tile, 16 lanes per row.  Pass A gives every entry its lattice slot and collects the off-lattice columns that lie in
+// the 27 neighbour bricks (extra slots, ascending column order so that the fill finds runs); pass B forms the pattern words and every
+// row's hash (a sum of position-keyed word hashes: the lanes of a row add their shares), and the tile's DISTINCT hashes go into the
+// global pattern set (a few dozen inserts per tile instead of one per row).
 __global__ __launch_bounds__(kTileBlk) void k_bk_rows(const TileInfo *__restrict__ tiles, const int32_t *__restrict__ row_ptr,
                                                      const int32_t *__restrict__ col, const uint16_t *__restrict__ codes,
                                                      const uint64_t *__restrict__ geo, int nbx, int nby, int zero_code,
                                                      uint32_t *__restrict__ ewords, uint16_t *__restrict__ eslot, uint64_t *__restrict__ row_hash,
-                                                     uint32_t *__restrict__ rgeo, uint16_t *__restrict__ ownslot)
+                                                     uint32_t *__restrict__ rgeo, uint16_t *__restrict__ ownslot,
+                                                     unsigned long long *__restrict__ keys, int32_t *__restrict__ rep, int *__restrict__ overflow)
 {
     __shared__ int xset[512];       // hash set of extra columns
     __shared__ int xlist[512];      // ... compacted, then sorted
     __shared__ int xcount;
+    __shared__ unsigned long long hset[2048]; // the tile's distinct row hashes
     const TileInfo &T = tiles[blockIdx.x];
     const int tid = threadIdx.x;
     const int row0 = T.row0, nrows = T.nrows;
@@ -127,23 +232,32 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_rows(const TileInfo *__restrict
         return;
     }
     const int obx = T.obx, oby = T.oby, obz = T.obz;
+    const int sub = tid & 15, grp = tid >> 4;
+    constexpr int GRPS = kTileBlk / 16;
     xset[tid] = -1;
+    for (int i = tid; i < 2048; i += kTileBlk) hset[i] = 0ull;
     if (tid == 0) xcount = 0;
     __syncthreads();
-    for (int r = tid; r < nrows; r += kTileBlk) {
+    for (int r = grp; r < nrows; r += GRPS) {
         const int rs = row_ptr[row0 + r], re = row_ptr[row0 + r + 1];
-        for (int k = rs; k < re; ++k) {
+        for (int k = rs + sub; k < re; k += 16) {
             const int c = col[k];
             const Geo g = geo_unpack(geo[c]);
-            if (lattice_slot(g, obx, oby, obz) >= 0) continue;
-            const int cbx = g.brick % nbx, cby = (g.brick / nbx) % nby, cbz = g.brick / (nbx * nby);
-            if (abs(cbx - obx) > 1 || abs(cby - oby) > 1 || abs(cbz - obz) > 1) continue;
-            unsigned h = ((unsigned)c * 2654435761u) >> 23; // 9 bits
-            for (int probe = 0; probe < 512; ++probe) {
-                const int old = atomicCAS(&xset[h], -1, c);
-                if (old == -1 || old == c) break;
-                h = (h + 1) & 511u;
+            int slot = lattice_slot(g, obx, oby, obz);
+            if (slot < 0) {
+                slot = 0xffff;
+                const int cbx = g.brick % nbx, cby = (g.brick / nbx) % nby, cbz = g.brick / (nbx * nby);
+                if (abs(cbx - obx) <= 1 && abs(cby - oby) <= 1 && abs(cbz - obz) <= 1) {
+                    slot = 0xfffe; // candidate for an extra slot
+                    unsigned h = ((unsigned)c * 2654435761u) >> 23; // 9 bits
+                    for (int probe = 0; probe < 512; ++probe) {
+                        const int old = atomicCAS(&xset[h], -1, c);
+                        if (old == -1 || old == c) break;
+                        h = (h + 1) & 511u;
+                    }
+                }
             }
+            eslot[k] = (uint16_t)slot;
         }
     }
     __syncthreads();
@@ -159,33 +273,35 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_rows(const TileInfo *__restrict
     if (tid < nxs) xlist[rank] = mine; // ascending
     __syncthreads();
     const int nxk = nxs < kXsRows ? nxs : kXsRows; // the smallest kXsRows columns get a slot
-    for (int r = tid; r < nrows; r += kTileBlk) {
+    for (int r = grp; r < nrows; r += GRPS) {
         const int row = row0 + r;
         const Geo gr = geo_unpack(geo[row]);
         const int rs = row_ptr[row], re = row_ptr[row + 1];
         const int own = lattice_slot(gr, obx, oby, obz);
-        const int w = 8 >> (gr.level > 3 ? 3 : gr.level);
+        const int lr = gr.level > 3 ? 3 : gr.level;
+        const int w = 8 >> lr;
         const int cx = gr.i - w * obx, cy = gr.j - w * oby, cz = gr.k - w * obz; // local cell, -1 .. w for a lattice row
         bool ok = own >= 0 && re > rs && re - rs <= kBrickPatLen && cx >= -1 && cx < 15 && cy >= -1 && cy < 15 && cz >= -1 && cz < 15;
-        uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)(re - rs);
+        uint64_t h = 0ull;
         bool simple = true;
-        for (int k = rs; k < re; ++k) {
-            const int c = col[k];
-            const Geo g = geo_unpack(geo[c]);
-            int slot = lattice_slot(g, obx, oby, obz);
-            int tag = g.level > 3 ? 3 : g.level;
-            if (slot < 0) { // extra slot?
+        for (int k = rs + sub; k < re; k += 16) {
+            int slot = eslot[k];
+            int tag = slot < kBrickLoff[1] ? 0 : slot < kBrickLoff[2] ? 1 : slot < kBrickLoff[3] ? 2 : 3;
+            if (slot == 0xfffe) { // extra slot?
+                const int c = col[k];
                 int lo = 0, hi = nxk;
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
                     if (xlist[mid] < c) lo = mid + 1; else hi = mid;
                 }
-                if (lo < nxk && xlist[lo] == c) { slot = kBrickSlotsPad + lo; tag = 0; }
+                slot = (lo < nxk && xlist[lo] == c) ? kBrickSlotsPad + lo : 0xffff;
+                tag = 0;
+                eslot[k] = (uint16_t)slot;
             }
             const unsigned code = codes[k];
             uint32_t word = 0u;
-            if (slot >= 0 && gr.level <= 3) {
-                const int delta = slot - base_slot(gr.level, cx, cy, cz, tag);
+            if (slot != 0xffff && gr.level <= 3) {
+                const int delta = slot - base_slot(lr, cx, cy, cz, tag);
                 if (delta < -4096 || delta > 4095 || code >= (unsigned)zero_code) ok = false;
                 word = ((uint32_t)(delta & 0x1fff) << 19) | ((uint32_t)tag << 14) | (code << 3);
                 if (tag) simple = false;
@@ -193,40 +309,39 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_rows(const TileInfo *__restrict
                 ok = false;
             }
             ewords[k] = word;
-            eslot[k] = slot >= 0 ? (uint16_t)slot : (uint16_t)0xffffu;
-            h = mix64(h ^ (uint64_t)word) + (uint64_t)(k - rs) * 0x9e3779b97f4a7c15ull;
+            h += mix64(((uint64_t)word << 8) ^ (uint64_t)(k - rs) ^ 0x9e3779b97f4a7c15ull);
         }
+        // the 16 lanes of the row: sum of the hashes, AND of the flags
+        int okf = ok ? 1 : 0, sf = simple ? 1 : 0;
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) {
+            h += __shfl_xor(h, m, 16);
+            okf &= __shfl_xor(okf, m, 16);
+            sf &= __shfl_xor(sf, m, 16);
+        }
+        h = mix64(h ^ (uint64_t)(re - rs));
         if (h == 0ull) h = 1ull;
-        row_hash[row] = ok ? h : 0ull;
-        // descriptor without the pattern id: simple << 31 is dropped later (it lives in pinfo), level << 18 | axis << 16 | cell + 1
-        rgeo[row] = ok ? (((uint32_t)gr.level << 18) | ((uint32_t)gr.axis << 16) | ((uint32_t)(cz + 1) << 8) | ((uint32_t)(cy + 1) << 4) |
-                          (uint32_t)(cx + 1) | (simple ? 0x80000000u : 0u))
-                       : 0u;
-        ownslot[row] = own >= 0 ? (uint16_t)own : (uint16_t)0xffffu;
+        if (sub == 0) {
+            row_hash[row] = okf ? h : 0ull;
+            rgeo[row] = okf ? (((uint32_t)gr.level << 18) | ((uint32_t)gr.axis << 16) | ((uint32_t)(cz + 1) << 8) | ((uint32_t)(cy + 1) << 4) |
+                               (uint32_t)(cx + 1) | (sf ? 0x80000000u : 0u))
+                            : 0u;
+            ownslot[row] = own >= 0 ? (uint16_t)own : (uint16_t)0xffffu;
+            if (okf) { // first sighting of the hash in this tile: into the global set
+                unsigned s2 = (unsigned)(h >> 53); // 11 bits
+                bool fresh = false;
+                for (int probe = 0; probe < 2048; ++probe) {
+                    const unsigned long long old = atomicCAS(&hset[s2], 0ull, (unsigned long long)h);
+                    if (old == 0ull) { fresh = true; break; }
+                    if (old == h) break;
+                    s2 = (s2 + 1) & 2047u;
+                }
+                if (fresh) pattern_insert(h, row, keys, rep, overflow);
+            }
+        }
     }
 }
 
-// K4a: insert the hashes; the winner of a slot leaves its row as the pattern's representative
-__global__ __launch_bounds__(kBlk) void k_bk_insert(const uint64_t *__restrict__ row_hash, int64_t n, unsigned long long *__restrict__ keys,
-                                                   int32_t *__restrict__ rep, int *__restrict__ overflow)
-{
-    const int64_t r = (int64_t)blockIdx.x * kBlk + threadIdx.x;
-    if (r >= n) return;
-    const uint64_t h = row_hash[r];
-    if (!h) return;
-    unsigned s = (unsigned)(h >> (64 - kHashBitsPat));
-    for (int probe = 0; probe < 64; ++probe) {
-        const unsigned long long cur = __hip_atomic_load(&keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == h) return;
-        if (cur == 0ull) {
-            const unsigned long long old = atomicCAS(&keys[s], 0ull, (unsigned long long)h);
-            if (old == 0ull) { rep[s] = (int32_t)r; return; }
-            if (old == h) return;
-        }
-        s = (s + 1) & ((1u << kHashBitsPat) - 1u);
-    }
-    atomicExch(overflow, 1); // (the row will not find its hash in K5 and becomes a streamed row)
-}
 // K4b: every occupied slot becomes a pattern: id, length, storage
 __global__ __launch_bounds__(kBlk) void k_bk_assign(const unsigned long long *__restrict__ keys, const int32_t *__restrict__ rep,
                                                    const int32_t *__restrict__ row_ptr, int32_t *__restrict__ slot_id,
@@ -617,10 +732,21 @@ avs_status build_brick_form(avs_ctx *c)
     if (c->brick_shift != 3 || c->desc.levels < 1) return AVS_OK;
     if (c->desc.nx > 1024 || c->desc.ny > 1024 || c->desc.nz > 1024 || nnz >= (1ll << 31)) return AVS_OK;
     hipStream_t st = c->stream;
+    const bool timing = getenv("AVS_BRICK_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(st);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "brick build: %-28s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     const int nx = c->desc.nx, ny = c->desc.ny, nz = c->desc.nz;
     const int nbx = (nx + 7) >> 3, nby = (ny + 7) >> 3, nbz = (nz + 7) >> 3;
     BrickScratch &S = bf.scratch;
     AVS_TRY(S.geo.reserve((size_t)n));
+    AVS_TRY(S.counters.reserve(16));
+    AVS_HIP(hipMemsetAsync(S.counters.p, 0, 16 * sizeof(int), st));
     AVS_TRY(S.first.reserve((size_t)n + 1));
     AVS_TRY(S.bidx.reserve((size_t)n + 1));
     AVS_TRY(S.scan_tmp.reserve(scan_tmp_elems(n)));
@@ -631,62 +757,37 @@ avs_status build_brick_form(avs_ctx *c)
     int32_t nbricks = 0;
     AVS_HIP(hipMemcpyAsync(&nbricks, S.bidx.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     AVS_HIP(hipStreamSynchronize(st));
-    AVS_TRY(S.bstart.reserve((size_t)nbricks + 1));
-    AVS_TRY(S.bbrick.reserve((size_t)nbricks + 1));
+    AVS_TRY(S.bstart.reserve((size_t)nbricks + 2));
+    AVS_TRY(S.bbrick.reserve((size_t)nbricks + 2));
+    AVS_TRY(S.run_first.reserve((size_t)nbricks + 2));
+    AVS_TRY(S.run_id.reserve((size_t)nbricks + 2));
+    AVS_TRY(S.run_start.reserve((size_t)nbricks + 2));
+    AVS_TRY(S.tcount.reserve((size_t)nbricks + 2));
+    AVS_TRY(S.tile0.reserve((size_t)nbricks + 2));
     hipLaunchKernelGGL(k_bk_brick_starts, dim3(gn), dim3(kBlk), 0, st, S.geo.p, S.first.p, S.bidx.p, n, S.bstart.p, S.bbrick.p);
-    std::vector<int32_t> hstart((size_t)nbricks + 1), hbrick((size_t)nbricks);
-    AVS_HIP(hipMemcpyAsync(hstart.data(), S.bstart.p, (size_t)nbricks * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    AVS_HIP(hipMemcpyAsync(hbrick.data(), S.bbrick.p, (size_t)nbricks * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    AVS_HIP(hipStreamSynchronize(st));
-    hstart[(size_t)nbricks] = (int32_t)n;
-    // ---- tiles (host, O(bricks)): a brick with >= kBrickMinRows rows is a G tile (cut every kBrickMaxRows rows), runs of smaller bricks
-    //      are cut into E tiles of kBrickETileRows rows
-    std::vector<TileInfo> tiles;
-    tiles.reserve((size_t)nbricks);
-    auto first_row_of = [&](int bx, int by, int bz) -> int32_t {
-        if (bx < 0 || bx >= nbx || by < 0 || by >= nby || bz < 0 || bz >= nbz) return 0;
-        const int32_t id = (bz * nby + by) * nbx + bx;
-        const auto it = std::lower_bound(hbrick.begin(), hbrick.end(), id);
-        return (it != hbrick.end() && *it == id) ? hstart[(size_t)(it - hbrick.begin())] : 0;
-    };
-    int64_t run_start = -1;
-    auto flush_run = [&](int64_t end) {
-        for (int64_t r0 = run_start; r0 < end; r0 += kBrickETileRows) {
-            TileInfo t{};
-            t.row0 = (int32_t)r0;
-            t.nrows = (int32_t)std::min<int64_t>(kBrickETileRows, end - r0);
-            tiles.push_back(t);
-        }
-        run_start = -1;
-    };
-    for (int32_t b = 0; b < nbricks; ++b) {
-        const int rows = hstart[(size_t)b + 1] - hstart[(size_t)b];
-        if (rows >= 2048) return AVS_OK; // (a run offset names at most 2047 rows of a brick)
-        if (rows >= kBrickMinRows) {
-            if (run_start >= 0) flush_run(hstart[(size_t)b]);
-            const int id = hbrick[(size_t)b];
-            const int bx = id % nbx, by = (id / nbx) % nby, bz = id / (nbx * nby);
-            for (int off = 0; off < rows; off += kBrickMaxRows) {
-                TileInfo t{};
-                t.row0 = hstart[(size_t)b] + off;
-                t.nrows = std::min(kBrickMaxRows, rows - off);
-                t.is_g = 1;
-                t.obx = bx; t.oby = by; t.obz = bz;
-                for (int dz = -1; dz <= 1; ++dz)
-                    for (int dy = -1; dy <= 1; ++dy)
-                        for (int dx = -1; dx <= 1; ++dx) t.nb[(dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)] = first_row_of(bx + dx, by + dy, bz + dz);
-                tiles.push_back(t);
-            }
-        } else if (run_start < 0) {
-            run_start = hstart[(size_t)b];
-        }
+    {
+        const int32_t n32 = (int32_t)n;
+        AVS_HIP(hipMemcpyAsync(S.bstart.p + nbricks, &n32, sizeof(int32_t), hipMemcpyHostToDevice, st)); // (pageable source: copied at the call)
     }
-    if (run_start >= 0) flush_run(n);
-    const int ntiles = (int)tiles.size();
-    if (ntiles == 0) return AVS_OK;
+    const unsigned gb = (unsigned)((nbricks + kBlk - 1) / kBlk);
+    hipLaunchKernelGGL(k_bk_run_first, dim3(gb), dim3(kBlk), 0, st, S.bstart.p, nbricks, S.run_first.p);
+    AVS_TRY(exclusive_scan_i32(S.run_first.p, S.run_id.p, nbricks, S.scan_tmp.p, S.scan_tmp.n, st));
+    hipLaunchKernelGGL(k_bk_run_starts, dim3(gb), dim3(kBlk), 0, st, S.bstart.p, S.run_first.p, S.run_id.p, nbricks, S.run_start.p);
+    hipLaunchKernelGGL(k_bk_tile_counts, dim3(gb), dim3(kBlk), 0, st, S.bstart.p, S.run_first.p, S.run_id.p, S.run_start.p, nbricks, S.tcount.p, S.counters.p + 3);
+    AVS_TRY(exclusive_scan_i32(S.tcount.p, S.tile0.p, nbricks, S.scan_tmp.p, S.scan_tmp.n, st));
+    int32_t ntiles = 0;
+    AVS_HIP(hipMemcpyAsync(&ntiles, S.tile0.p + nbricks, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipStreamSynchronize(st));
+    lap("geometry + brick starts");
+    if (ntiles <= 0) return AVS_OK;
     AVS_TRY(S.tiles.reserve((size_t)ntiles * sizeof(TileInfo)));
-    AVS_HIP(hipMemcpyAsync(S.tiles.p, tiles.data(), (size_t)ntiles * sizeof(TileInfo), hipMemcpyHostToDevice, st));
+    TileInfo *wtiles = reinterpret_cast<TileInfo *>(S.tiles.p);
+    hipLaunchKernelGGL(k_bk_tile_rows, dim3(gb), dim3(kBlk), 0, st, S.bstart.p, S.bbrick.p, S.run_first.p, S.run_id.p, S.run_start.p, S.tile0.p, nbricks,
+                       nbx, nby, wtiles);
+    hipLaunchKernelGGL(k_bk_tile_finish, dim3((unsigned)(((size_t)ntiles * 32 + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, ntiles, n, S.bstart.p, S.bbrick.p,
+                       nbricks, nbx, nby, nbz, wtiles);
     const TileInfo *dtiles = reinterpret_cast<const TileInfo *>(S.tiles.p);
+    lap("tiles");
     // ---- K3
     AVS_TRY(S.ewords.reserve((size_t)nnz));
     AVS_TRY(S.eslot.reserve((size_t)nnz));
@@ -694,8 +795,6 @@ avs_status build_brick_form(avs_ctx *c)
     AVS_TRY(S.rgeo.reserve((size_t)n));
     AVS_TRY(bf.ownslot.alloc((size_t)n + 8));
     const int zero_code = vi.table_size;
-    hipLaunchKernelGGL(k_bk_rows, dim3(ntiles), dim3(kTileBlk), 0, st, dtiles, c->p_row_ptr.p, c->p_col.p, vi.codes.p, S.geo.p, nbx, nby, zero_code,
-                       S.ewords.p, S.eslot.p, S.row_hash.p, S.rgeo.p, bf.ownslot.p);
     // ---- K4
     const size_t hslots = (size_t)1 << kHashBitsPat;
     AVS_TRY(S.keys.reserve(hslots));
@@ -703,17 +802,18 @@ avs_status build_brick_form(avs_ctx *c)
     AVS_TRY(S.slot_id.reserve(hslots));
     AVS_TRY(S.pat_rep.reserve((size_t)kMaxPatterns));
     AVS_TRY(S.pat_off.reserve((size_t)kMaxPatterns));
-    AVS_TRY(S.counters.reserve(16));
     AVS_HIP(hipMemsetAsync(S.keys.p, 0, hslots * sizeof(unsigned long long), st));
-    AVS_HIP(hipMemsetAsync(S.counters.p, 0, 16 * sizeof(int), st));
-    hipLaunchKernelGGL(k_bk_insert, dim3(gn), dim3(kBlk), 0, st, S.row_hash.p, n, S.keys.p, S.rep.p, S.counters.p + 2);
+    hipLaunchKernelGGL(k_bk_rows, dim3(ntiles), dim3(kTileBlk), 0, st, dtiles, c->p_row_ptr.p, c->p_col.p, vi.codes.p, S.geo.p, nbx, nby, zero_code,
+                       S.ewords.p, S.eslot.p, S.row_hash.p, S.rgeo.p, bf.ownslot.p, S.keys.p, S.rep.p, S.counters.p + 2);
+    lap("K3 rows + pattern insert");
     hipLaunchKernelGGL(k_bk_assign, dim3((unsigned)(hslots / kBlk)), dim3(kBlk), 0, st, S.keys.p, S.rep.p, c->p_row_ptr.p, S.slot_id.p, S.pat_rep.p,
                        S.pat_off.p, S.counters.p);
     int hc[4] = {};
     AVS_HIP(hipMemcpyAsync(hc, S.counters.p, sizeof(hc), hipMemcpyDeviceToHost, st));
     AVS_HIP(hipStreamSynchronize(st));
     const int npat = hc[0], nwords = hc[1];
-    if (npat <= 0 || npat > kMaxPatterns) return AVS_OK; // nothing regular / not a regular scene
+    lap("K4 assign");
+    if (npat <= 0 || npat > kMaxPatterns || hc[3]) return AVS_OK; // nothing regular / not a regular scene
     AVS_TRY(bf.pwords.alloc((size_t)nwords + 16));
     hipLaunchKernelGGL(k_bk_copy_patterns, dim3((unsigned)(((size_t)npat * 16 + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, npat, S.pat_rep.p, S.pat_off.p,
                        c->p_row_ptr.p, S.ewords.p, zero_code, bf.pwords.p);
@@ -721,6 +821,7 @@ avs_status build_brick_form(avs_ctx *c)
     AVS_TRY(S.row_pid.reserve((size_t)n));
     hipLaunchKernelGGL(k_bk_verify, dim3(gn), dim3(kBlk), 0, st, S.row_hash.p, n, S.keys.p, S.slot_id.p, S.pat_off.p, S.pat_rep.p, c->p_row_ptr.p,
                        S.ewords.p, bf.pwords.p, S.row_pid.p);
+    lap("K4c copy + K5 verify");
     // ---- K6 (+ a second round for the tiles that exceeded a limit: they become E tiles)
     AVS_TRY(bf.blocks.alloc((size_t)ntiles * kBlockStride + 64));
     AVS_TRY(bf.tile_blk.alloc((size_t)ntiles + 1));
@@ -747,6 +848,7 @@ avs_status build_brick_form(avs_ctx *c)
         for (int t = 0; t < ntiles; ++t) hf[(size_t)t] = hn[(size_t)t] < 0 ? 1 : 0;
         AVS_HIP(hipMemcpy(S.force_e.p, hf.data(), (size_t)ntiles, hipMemcpyHostToDevice));
     }
+    lap("K6 tiles");
     // ---- K7
     AVS_TRY(exclusive_scan_i32(S.slen.p, S.sstart.p, n, S.scan_tmp.p, S.scan_tmp.n, st));
     AVS_TRY(S.total.reserve(1));
@@ -761,6 +863,7 @@ avs_status build_brick_form(avs_ctx *c)
     hipLaunchKernelGGL(k_bk_copy_streamed, dim3(4096), dim3(kBlk), 0, st, n, S.slen.p, S.sstart.p, c->p_row_ptr.p, vi.packed.p, bf.swords.p);
     hipLaunchKernelGGL(k_bk_patch, dim3((unsigned)((ntiles + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, ntiles, dtiles, S.sstart.p, bf.blocks.p);
     AVS_HIP(hipGetLastError());
+    lap("K7 streamed");
     bf.ntiles = ntiles;
     bf.regular_rows = (int64_t)regular;
     bf.patterns = npat;

@@ -240,7 +240,7 @@ struct BrickView {
 // the form's arrays, owned by the context next to the CSR / value index of the solve matrix (avs_brick_build.hip)
 struct BrickScratch { // build-time buffers, kept across frames
     DevBuf<uint64_t> geo, row_hash;
-    DevBuf<int32_t> first, bidx, scan_tmp, bstart, bbrick, rep, slot_id, pat_rep, pat_off, row_pid, slen, sstart, tile_nprow;
+    DevBuf<int32_t> first, bidx, scan_tmp, bstart, bbrick, run_first, run_id, run_start, tcount, tile0, rep, slot_id, pat_rep, pat_off, row_pid, slen, sstart, tile_nprow;
     DevBuf<uint32_t> ewords, rgeo;
     DevBuf<uint16_t> eslot;
     DevBuf<unsigned long long> keys, total;
