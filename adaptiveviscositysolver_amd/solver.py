@@ -232,6 +232,10 @@ class ViscositySolve:
         bpn, tab = int(fmt.bytes_per_nonzero), int(fmt.value_table_size)
         ltab = "LTAB" if 0 < tab <= 2048 else "GTAB"
         cw = int(fmt.column_windows)
+        if int(getattr(fmt, "brick_tiles", 0)):
+            return (f"k_spmv_brick<DOT> (brick-structured form: {int(fmt.brick_tiles)} tiles, {int(fmt.brick_pattern_rows)} rows as "
+                    f"{int(fmt.brick_patterns)} geometric row patterns (8 B per row), x of a brick + halo in LDS, the other rows as 4-B words; "
+                    f"{tab}-entry dictionary; brick-major system)")
         if int(fmt.tile_local_tables):
             form = ("4 B/nnz: tile-local value code | window slot | offset in one word" if cw else
                     "6 B/nnz: 2-B tile-local value codes + int32 column")

@@ -164,6 +164,8 @@ def spmv_rates(n, nnz, fmt, mean_spmv_ms):
         stored += 8 * int(fmt.value_table_size) + 4 * ((n + 511) // 512 + 1)
     if int(fmt.column_windows):      # + 64 window bases per tile
         stored += 256 * ((n + 511) // 512)
+    if int(getattr(fmt, "brick_tiles", 0)):   # brick-structured form: what the kernel reads of the matrix + x and y
+        stored = int(fmt.brick_bytes) + 16 * n
     t = mean_spmv_ms * 1e-3
     return {"algorithmic_bytes_per_launch": bytes_spmv, "stored_bytes_per_launch": stored, "mean_launch_us": mean_spmv_ms * 1e3,
             "frac": (bytes_spmv / t / 1e9 / HBM_PEAK_GBPS) if t > 0 else None,
@@ -491,6 +493,9 @@ def main():
             stored_bytes += 8 * int(fmt.value_table_size) + 4 * ((n + 511) // 512 + 1)
         if stored_bytes and int(fmt.column_windows):      # + 64 window bases per tile
             stored_bytes += 256 * ((n + 511) // 512)
+        brick = int(getattr(fmt, "brick_tiles", 0)) > 0 and not use_dist
+        if brick:                                         # brick-structured form: descriptors + pattern lists + words, x and y
+            stored_bytes = float(int(fmt.brick_bytes) + 16 * n)
         stored_rate = stored_bytes / (mean_spmv_ms * 1e-3) / 1e9 if stored_bytes and mean_spmv_ms > 0 else None
         kernel = solver.spmv_kernel_name() if hasattr(solver, "spmv_kernel_name") else f"{bpn} B/nnz"
         traffic, traffic_source = None, None
@@ -500,7 +505,7 @@ def main():
                 recs = json.load(open(prof))
                 for rec in (recs if isinstance(recs, list) else [recs]):
                     if (traffic is None and "superseded_by" not in rec and rec.get("n") == n and rec.get("nnz") == nnz and
-                            rec.get("bytes_per_nonzero", 12) == bpn and bool(rec.get("tile_local_tables", False)) == bool(fmt.tile_local_tables)):
+                            bool(rec.get("brick", False)) == brick and rec.get("bytes_per_nonzero", 12) == bpn and bool(rec.get("tile_local_tables", False)) == bool(fmt.tile_local_tables)):
                         traffic = rec.get("hbm_bytes_per_launch")
                         traffic_source = ("profiles/spmv_traffic.json <- " + str(rec.get("source", "?")) +
                                           " (PMC passes of an EARLIER run of this workload, not of this process)")
@@ -527,12 +532,15 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": local_bytes, "mean_launch_us": mean_spmv_ms * 1e3,
                          "frac_of_achievable_6290": achieved / 6290.0,
-                         "stored_bytes_per_nonzero": bpn, "stored_bytes_per_launch": stored_bytes,
+                         "stored_bytes_per_nonzero": (stored_bytes - 16 * n) / nnz if brick else bpn, "stored_bytes_per_launch": stored_bytes,
+                         "brick_form": ({"tiles": int(fmt.brick_tiles), "patterns": int(fmt.brick_patterns), "pattern_rows": int(fmt.brick_pattern_rows),
+                                         "matrix_bytes": int(fmt.brick_bytes)} if brick else None),
                          "stored_rate_gbps": stored_rate,
                          "stored_frac": (stored_rate / HBM_PEAK_GBPS) if stored_rate else None,
                          "value_table_size": int(fmt.value_table_size), "tile_local_tables": bool(fmt.tile_local_tables), "column_windows": bool(fmt.column_windows),
-                         "note": "achieved/frac follow SURVEY 8(d) (12 B per non-zero); the matrix is streamed in a lossless "
-                                 f"{bpn}-B form, so frac is an effective rate and may exceed 1 -- stored_* is the physical stream"},
+                         "note": "achieved/frac follow SURVEY 8(d) (12 B per non-zero); the matrix is read in a lossless "
+                                 + ("brick-structured form (one 8-B descriptor per pattern row)" if brick else f"{bpn}-B form") +
+                                 ", so frac is an effective rate and may exceed 1 -- stored_* is the physical stream"},
             "solve_event_iter_per_s": iters_total / (sum(solve_ms) * 1e-3),
             "assembly_ms": {"stencils": ai.stencil_ms, "initial_guess": ai.guess_ms, "system": ai.system_ms,
                             "wall": assemble_wall_ms},
