@@ -160,6 +160,27 @@ class ViscositySolve:
         buf = (C.c_uint8 * capi.UNIQUE_ID_BYTES).from_buffer_copy(raw)
         capi.check(self.lib.avs_dist_init(self.h, buf, rank, world))
 
+    def dist_init_hosted(self, rank, world):
+        """Hosted group (no RCCL communicator): the host program moves the comm-block blobs; here torch.distributed (any backend)
+        all-gathers them after every distributed assembly / partition (`_hosted_connect`)."""
+        capi.check(self.lib.avs_dist_init_hosted(self.h, rank, world))
+        self._hosted = (rank, world)
+
+    def _hosted_connect(self):
+        import torch
+        import torch.distributed as dist
+        rank, world = self._hosted
+        blob = (C.c_uint8 * capi.DIST_BLOB_BYTES)()
+        capi.check(self.lib.avs_dist_export_blob(self.h, blob))
+        mine = torch.tensor(list(bytes(blob)), dtype=torch.uint8)
+        if dist.get_backend() == "nccl":
+            mine = mine.to(torch.device("cuda", torch.cuda.current_device()))
+        allb = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allb, mine)
+        raw = b"".join(bytes(t.cpu().tolist()) for t in allb)
+        buf = (C.c_uint8 * len(raw)).from_buffer_copy(raw)
+        capi.check(self.lib.avs_dist_import_blobs(self.h, buf))   # maps the peers' blocks and runs the transport self-test
+
     def dist_init_local(self, group, rank):
         capi.check(self.lib.avs_dist_init_local(self.h, group, rank))
 
@@ -185,6 +206,8 @@ class ViscositySolve:
         ti, tb = C.c_int32(), C.c_int32()
         capi.check(self.lib.avs_dist_get_overlap_tiles(self.h, C.byref(ti), C.byref(tb)))
         self.overlap_tiles = (ti.value, tb.value)
+        if getattr(self, "_hosted", None) and self._hosted[1] > 1:
+            self._hosted_connect()
         return info
 
     def dist_solve(self, tol=1e-3, max_iters=2500):

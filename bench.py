@@ -50,7 +50,7 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=4, choices=(3, 4, 5), help="BASELINE.json workload (see the docstring)")
-    ap.add_argument("--n", type=int, default=0, help="base grid resolution (0 = the config's)")
+    ap.add_argument("--n", "--base-n", dest="n", type=int, default=0, help="base grid resolution (0 = the config's)")
     ap.add_argument("--levels", type=int, default=0)
     ap.add_argument("--variable-viscosity", action="store_true", help="fat beam with mu(x) = 200 (1 + 9x)")
     ap.add_argument("--scene", choices=("beam", "buckling"), default=None,
@@ -62,6 +62,13 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=22.0, help="timed budget of the cpu_baseline leg (both variants together: >= 10 s steady state each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the partitioned path even with one rank")
+    ap.add_argument("--one-device", action="store_true",
+                    help="rehearsal of the --gpus N path on ONE GPU: every rank uses cuda:0, torch.distributed runs on gloo, the library's "
+                         "group is a hosted one (comm blocks mapped through HIP IPC, blobs all-gathered by this script); the same "
+                         "verification, timing and JSON code as the real multi-GPU run")
+    ap.add_argument("--verify-tol", type=float, default=1e-8,
+                    help="tolerance of the verification solves of the multi-GPU path (the rehearsal on one device loosens it: its ranks "
+                         "time-slice one GPU and every flag wait costs a context switch)")
     ap.add_argument("--launch-check", action="store_true",
                     help="only start the ranks, form the process group, all-reduce once and print a JSON line")
     return ap.parse_args(argv)
@@ -78,6 +85,8 @@ def free_port():
 
 def launcher_command(gpus, argv, port=None):
     """the torch.distributed.run command that starts `gpus` ranks of this script on this node"""
+    # torch.distributed.run's argparse resolves abbreviations even behind the script name: "--n" is "ambiguous" there
+    argv = ["--base-n" if v == "--n" else ("--base-n=" + v[4:] if v.startswith("--n=") else v) for v in argv]
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
             "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()),
             os.path.abspath(__file__)] + list(argv)
@@ -280,12 +289,18 @@ def main():
             emit({"launch_check": bool(ok), "n_gpus": world, "backend": backend})
         raise SystemExit(0 if ok else 1)
 
+    if a.one_device:
+        local_rank = 0                      # every rank on cuda:0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if a.one_device else dev    # where the tensors of this script's own collectives live
     if world > 1 or under_launcher:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from adaptiveviscositysolver_amd import DevicePrepass, ViscositySolve, scenes
 
@@ -321,7 +336,11 @@ def main():
     partition_ms = 0.0
     dist_info = None
     if use_dist:
-        if world > 1 or under_launcher:
+        if a.one_device and (world > 1 or under_launcher):
+            # hosted group: no RCCL communicator (RCCL refuses two ranks on one device); after every distributed assembly the ranks
+            # exchange their 512-byte comm-block blobs and map each other's blocks (HIP IPC) -- solver.dist_assemble does it
+            solver.dist_init_hosted(rank, world)
+        elif world > 1 or under_launcher:
             solver.dist_init(rank, world)      # RCCL id made on rank 0, broadcast with torch.distributed
         else:
             import ctypes as C
@@ -331,17 +350,27 @@ def main():
             capi.check(solver.lib.avs_dist_init(solver.h, buf, 0, 1))
         # reference for the check below: the single-GPU path on this rank's own GPU (every rank holds the whole pyramid),
         # solved to 1e-8 -- tight enough that ONE stale halo entry in one round shows in the field (round-2 review, weak #3)
-        verify_tol = 1e-8
+        verify_tol = a.verify_tol
         solver.assemble()
         ref = solver.solve(verify_tol, 4 * a.max_iters)
         x_ref = torch.empty(ref.n, dtype=torch.float64, device=dev)
         from adaptiveviscositysolver_amd import capi as _capi
         _capi.check(solver.lib.avs_get_solution(solver.h, x_ref.data_ptr(), ref.n, _capi.MEM_DEVICE))
 
+        def dist_solution():
+            """the whole velocity vector on this rank (a hosted group returns the owned entries only: the ranks' vectors are added)"""
+            x = torch.empty(ref.n, dtype=torch.float64, device=dev)
+            _capi.check(solver.lib.avs_dist_get_solution(solver.h, x.data_ptr(), ref.n, _capi.MEM_DEVICE))
+            if a.one_device and world > 1:
+                xc = x.cpu()
+                torch.distributed.all_reduce(xc)
+                x = xc.to(dev)
+            return x
+
         def agree(flag):
             if world == 1:
                 return bool(flag)
-            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=cdev)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
             return bool(t.item())
 
@@ -359,11 +388,10 @@ def main():
                 solver.dist_assemble()
                 for _ in range(3):
                     info = solver.dist_solve(verify_tol, 4 * a.max_iters)
-                    x = torch.empty(ref.n, dtype=torch.float64, device=dev)
-                    _capi.check(solver.lib.avs_dist_get_solution(solver.h, x.data_ptr(), ref.n, _capi.MEM_DEVICE))
+                    x = dist_solution()
                     rel = float(torch.linalg.norm(x - x_ref) / torch.linalg.norm(x_ref))
                     rec["solves"].append({"iterations": int(info.iterations), "converged": int(info.converged), "rel_l2_vs_single_gpu": rel})
-                    ok = ok and bool(info.converged) and abs(info.iterations - ref.iterations) <= max(3, 0.01 * ref.iterations) and rel < 1e-6
+                    ok = ok and bool(info.converged) and abs(info.iterations - ref.iterations) <= max(3, 0.01 * ref.iterations) and rel < max(1e-6, 100 * verify_tol)
                 ci = solver.dist_comm_info()
                 rec.update(transport=ci["transport"], reference_iterations=int(ref.iterations), paranoid=ci["paranoid"],
                            selftest_rounds=ci["selftest_rounds"], selftest_bad_entries=ci["selftest_bad_entries"])
@@ -383,12 +411,11 @@ def main():
                         solver.dist_assemble()
                         for _ in range(2):
                             info = solver.dist_solve(verify_tol, 4 * a.max_iters)
-                            x = torch.empty(ref.n, dtype=torch.float64, device=dev)
-                            _capi.check(solver.lib.avs_dist_get_solution(solver.h, x.data_ptr(), ref.n, _capi.MEM_DEVICE))
+                            x = dist_solution()
                             rel = float(torch.linalg.norm(x - x_ref) / torch.linalg.norm(x_ref))
                             rec.setdefault(tag, []).append({"iterations": int(info.iterations), "converged": int(info.converged),
                                                             "rel_l2_vs_single_gpu": rel, "resident_loop": bool(info.resident)})
-                            good = good and bool(info.converged) and abs(info.iterations - ref.iterations) <= max(3, 0.01 * ref.iterations) and rel < 1e-6
+                            good = good and bool(info.converged) and abs(info.iterations - ref.iterations) <= max(3, 0.01 * ref.iterations) and rel < max(1e-6, 100 * verify_tol)
                     except Exception as e:
                         rec[tag + "_error"] = str(e)[:300]
                         good = False
@@ -402,9 +429,15 @@ def main():
 
         # direct transport (peer-mapped comm blocks) first; the RCCL send/recv + all-reduce loop is the fallback
         verification = [try_transport(os.environ.get("AVS_DIST_TRANSPORT", ""))]
-        if not verification[-1]["ok"] and verification[-1].get("transport") != "rccl":
+        if not verification[-1]["ok"] and verification[-1].get("transport") != "rccl" and not a.one_device:
             verification.append(try_transport("rccl"))
         if not verification[-1]["ok"]:
+            try:
+                ci = solver.dist_comm_info()
+            except Exception as e:
+                ci = {"error": str(e)[:200]}
+            sys.stderr.write(json.dumps({"rank": rank, "world": world, "one_device": bool(a.one_device), "comm": ci,
+                                         "verification": verification}) + "\n")
             if rank == 0:
                 emit({"metric": "cg_iterations_per_sec", "value": 0.0, "unit": "iter/s", "n_gpus": world, "error":
                       "no multi-GPU transport reproduced the single-GPU solve", "verification": verification})
@@ -448,7 +481,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -473,7 +506,7 @@ def main():
         mine = [int(sz.n_own), int(sz.n_halo), int(sz.nnz_local), int(sz.n_send), int(sz.n_peers)]
         per_rank = [mine]
         if world > 1:
-            tn = torch.tensor(mine, dtype=torch.int64, device=dev)
+            tn = torch.tensor(mine, dtype=torch.int64, device=cdev)
             allr = [torch.zeros_like(tn) for _ in range(world)]
             torch.distributed.all_gather(allr, tn)
             per_rank = [[int(v) for v in r.tolist()] for r in allr]
