@@ -553,7 +553,6 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
     __syncthreads();
     // run starts: slot s filled and not the continuation of the run through s - 1 (consecutive columns of one brick, at most 16 long)
     constexpr int SPT = 4096 / kTileBlk; // 8 consecutive slots per thread
-    int nstart = 0;
     unsigned startmask = 0;
     {
         const int s0 = tid * SPT;
@@ -565,7 +564,7 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
                 const int cp = smap[s - 1];
                 if (cp >= 0 && cp + 1 == c && (geo[cp] >> 38) == (geo[c] >> 38)) st = false;
             }
-            if (st) { startmask |= 1u << u; ++nstart; }
+            if (st) startmask |= 1u << u;
         }
     }
     // natural runs are cut every 16 slots: position inside the natural run needs the last natural start at or before s

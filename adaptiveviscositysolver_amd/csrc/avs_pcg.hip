@@ -127,6 +127,8 @@ struct PcgWork {
     DevBuf<double> r, p, t, invd, partial;
     DevBuf<uint16_t> dcode;  // value-indexed matrix: code of every row's diagonal entry ...
     DevBuf<double> invtab;   // ... into the table of inverted values (2 B instead of 8 B per row and vector pass)
+    DevBuf<double> x_save;   // the initial guess while the CU-resident loop runs (restored if it faults)
+    int resident_faults = 0; // CU-resident launches of this workspace that ended in a timed-out wait
     DevBuf<double> s, u; // single-reduction variant (multi-GPU): s = A p recurrence, u = M^-1 r with halo tail
     DevBuf<PcgScalars> sc;
     DevBuf<double> stage2;         // direct transport: per-workgroup SpMV sums of the halo-touching launch
@@ -2105,6 +2107,7 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
         AVS_HIP(hipMemcpyAsync(w->host_sc, sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, stream));
         AVS_HIP(hipStreamSynchronize(stream));
         if (w->host_sc->fault) {
+            if (w->resident_used && w->resident) w->resident->ok = false; // the next distributed solve takes the launch-per-phase loop
             if (w->host_sc->fault == 4)
                 set_error("direct transport (paranoid mode): a halo segment does not add up to the checksum its sender left ahead of the flag "
                           "-- stale or torn halo entries (iteration ~%d)", w->host_sc->iter);
@@ -2288,19 +2291,23 @@ static avs_status pcg_solve_resident_single(PcgWork *w, const CsrView &A, const 
     reduce_launch(w, pspmv, nb, 1, sc, (int)OP_NONE, tol, 0, 3, stream);
     hipLaunchKernelGGL(k_scalar, dim3(1), dim3(64), 0, stream, sc, (int)OP_SR_INIT, tol);
     AVS_HIP(hipGetLastError());
+    // the initial guess is kept: if a bounded wait inside the cooperative launch times out (the grid was not co-resident in time: a GPU
+    // shared with a viewport or OpenCL work) the solve is redone from it by the launch-per-phase loop IN THIS CALL
+    AVS_TRY(w->x_save.alloc((size_t)n));
+    AVS_HIP(hipMemcpyAsync(w->x_save.p, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
     bool launched = false;
     AVS_TRY(resident_run(w->resident, A, x, r, p, sv, u, wv, w->dcode.p, w->invtab.p, sc, max_iters, nullptr, stream, &launched));
     if (!launched) return AVS_OK; // (x is untouched: the launch-per-phase loop starts over from it)
-    *ran = true;
-    w->resident_used = 1;
     AVS_HIP(hipMemcpyAsync(w->host_sc, sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, stream));
     AVS_HIP(hipStreamSynchronize(stream));
-    if (w->host_sc->fault) {
-        w->resident->ok = false; // not again on this context: the next solve takes the launch-per-phase loop
-        set_error("resident PCG: a workgroup did not reach a grid barrier within the time limit (fault %d); the context falls back to the "
-                  "launch-per-phase loop for its next solves", w->host_sc->fault);
-        return AVS_EINTERNAL;
+    if (w->host_sc->fault || getenv("AVS_CG_RESIDENT_FAKE_FAULT")) { // (the variable is the test hook of exactly this path)
+        w->resident->ok = false; // not again on this context
+        w->resident_faults++;
+        AVS_HIP(hipMemcpyAsync(x, w->x_save.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        return AVS_OK;           // *ran stays false: pcg_solve carries on with the launch-per-phase loop
     }
+    *ran = true;
+    w->resident_used = 1;
     if (w->host_sc->done == 3) AVS_HIP(hipMemsetAsync(x, 0, (size_t)n * sizeof(double), stream)); // rhs == 0: x := 0
     AVS_HIP(hipEventRecord(w->ev1, stream));
     AVS_HIP(hipEventSynchronize(w->ev1));

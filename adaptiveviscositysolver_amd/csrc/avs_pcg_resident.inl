@@ -609,8 +609,9 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
                         const unsigned t1 = __builtin_amdgcn_alignbit(mm.y, mm.x, 25);
                         const double v0 = tbl[__builtin_amdgcn_ubfe(mm.x, (unsigned)cbits, kb)], x0 = u_l[mm.x & cmask];
                         const double v1 = tbl[__builtin_amdgcn_ubfe(t1, (unsigned)cbits, kb)], x1 = u_l[t1 & cmask];
-                        acc = __builtin_fma(v0, x0, acc); // left to right inside the row: the oracle's order (padding words add +0)
-                        acc = __builtin_fma(v1, x1, acc);
+                        acc += v0 * x0; // left to right inside the row, multiply then add (no FMA): the oracle's order and rounding, the same
+                                        // row sums as the launch-per-phase kernels bit for bit (padding words add +0)
+                        acc += v1 * x1;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     { // words 2, 3
@@ -618,13 +619,13 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
                         const unsigned t3 = __builtin_amdgcn_alignbit(mm.w, mm.z, 11);
                         const double v2 = tbl[__builtin_amdgcn_ubfe(t2, (unsigned)cbits, kb)], x2 = u_l[t2 & cmask];
                         const double v3 = tbl[__builtin_amdgcn_ubfe(t3, (unsigned)cbits, kb)], x3 = u_l[t3 & cmask];
-                        acc = __builtin_fma(v2, x2, acc);
-                        acc = __builtin_fma(v3, x3, acc);
+                        acc += v2 * x2;
+                        acc += v3 * x3;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     { // word 4
                         const double v4 = tbl[__builtin_amdgcn_ubfe(mm.w, 4u + (unsigned)cbits, kb)], x4 = u_l[__builtin_amdgcn_ubfe(mm.w, 4u, (unsigned)cbits)];
-                        acc = __builtin_fma(v4, x4, acc);
+                        acc += v4 * x4;
                     }
                     if ((em >> q) & 1u) {
                         gw[row0 + rk] = acc;
@@ -684,11 +685,11 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
                         const double v2 = tbl[__builtin_amdgcn_ubfe(t2, (unsigned)cbits, kb)], x2 = u_l[t2 & cmask];
                         const double v3 = tbl[__builtin_amdgcn_ubfe(t3, (unsigned)cbits, kb)], x3 = u_l[t3 & cmask];
                         const double v4 = tbl[__builtin_amdgcn_ubfe(mm.w, 4u + (unsigned)cbits, kb)], x4 = u_l[__builtin_amdgcn_ubfe(mm.w, 4u, (unsigned)cbits)];
-                        sacc = __builtin_fma(v0, x0, sacc);
-                        sacc = __builtin_fma(v1, x1, sacc);
-                        sacc = __builtin_fma(v2, x2, sacc);
-                        sacc = __builtin_fma(v3, x3, sacc);
-                        sacc = __builtin_fma(v4, x4, sacc);
+                        sacc += v0 * x0;
+                        sacc += v1 * x1;
+                        sacc += v2 * x2;
+                        sacc += v3 * x3;
+                        sacc += v4 * x4;
                         if (mm.w >> 31) { // (bit 127) the row's last quad
                             gw[row] = sacc;
                             wu += sacc * u_l[row - wrow0];
@@ -723,9 +724,12 @@ __global__ __launch_bounds__(kResThreads) void k_cg_resident(ResidentArgs a)
                 ok = res_take_slot(sl + 1, timeout, &v1) && ok;
                 ok = res_take_slot(sl + 2, timeout, &v2) && ok;
                 if (!ok) sh_fail = 1;
-                // re-arm (the next values come after the next grid barrier, which this thread reaches with its stores acknowledged)
+                // re-arm, and wait for the sentinel stores to be acknowledged: the broadcast below releases the workgroups into the next
+                // iteration, whose partial sums land in these very slots -- a sentinel still in flight then would overwrite one (a
+                // workgroup barrier does not wait for vmcnt)
                 for (int k = 0; k < 3; ++k)
                     __hip_atomic_store(reinterpret_cast<unsigned long long *>(sl + k), kSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                wait_own_stores();
             }
             res_block_fold3(v0, v1, v2, fold);
             if (tid == 0) { bc[0] = v0; bc[1] = v1; bc[2] = v2; bc[3] = 0.; }
@@ -1338,7 +1342,9 @@ static avs_status resident_run(ResidentPlan *pl, const CsrView &A, double *x, do
         (void)hipGetLastError();
         khz = 100000;
     }
-    long long ms = 20000;
+    // a wait between workgroups of ONE device ends in microseconds unless the cooperative grid is not co-resident in time (a shared
+    // GPU): 2 s, then the solve is redone by the launch-per-phase loop in the same call; waits on peers keep the transport's 20 s
+    long long ms = da ? 20000 : 2000;
     if (const char *e = getenv("AVS_DIST_TIMEOUT_MS")) ms = atoll(e) > 0 ? atoll(e) : ms;
     a.timeout_ticks = (long long)khz * ms;
     a.dd = da ? da->dd : nullptr;

@@ -196,3 +196,29 @@ def test_resident_plan_follows_a_reassembly(resident_env, built_lib):
     assert rel_l2(x2, s.solution()) < 1e-7
     assert rel_l2(x2, x1) > 1e-6                              # (it is another system)
     s.close()
+
+
+def test_resident_fault_is_redone_by_the_launch_per_phase_loop(resident_env, monkeypatch, built_lib):
+    """A bounded wait inside the cooperative launch that times out (a GPU shared with a viewport: the grid not co-resident in time) must
+    not cost the frame: the same avs_solve call restores the initial guess and solves with the launch-per-phase loop, and the context stays
+    on that loop.  AVS_CG_RESIDENT_FAKE_FAULT makes the host treat the launch as faulted (advisor, round 3)."""
+    sc = scenes.fat_beam(64, 3)
+    dsc = scenes.to_device(sc, torch.device("cuda:0"))
+    pyr = build_pyramid(dsc)
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
+    feed(s, pyr)
+    s.set_scene_fields(dsc)
+    s.assemble()
+    good = s.solve(1e-8, 5000)
+    assert good.resident == 1 and good.converged == 1
+    x_good = np.array(s.solution(), copy=True)
+    monkeypatch.setenv("AVS_CG_RESIDENT_FAKE_FAULT", "1")
+    s.assemble()                       # a new plan, the resident loop is tried again ...
+    info = s.solve(1e-8, 5000)         # ... "faults", and the call still returns the solution
+    assert info.converged == 1 and info.resident == 0
+    assert abs(info.iterations - good.iterations) <= max(3, good.iterations // 100)
+    assert rel_l2(s.solution(), x_good) < 1e-7
+    monkeypatch.delenv("AVS_CG_RESIDENT_FAKE_FAULT")
+    again = s.solve(1e-8, 5000)        # the plan was retired: the context stays on the launch-per-phase loop
+    assert again.converged == 1 and again.resident == 0
+    s.close()
