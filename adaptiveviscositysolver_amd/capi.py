@@ -13,6 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AVS_LIB_PATH", os.path.join(_HERE, "libavs_hip.so"))
+PROBE_LIB_PATH = os.environ.get("AVS_PROBE_LIB_PATH", os.path.join(_HERE, "libavs_probe.so"))
 
 MAX_LEVELS = 8
 EDGE_STENCIL_CAP, CENTER_STENCIL_CAP = 32, 8
@@ -25,7 +26,10 @@ STATUS_NAMES = {0: "AVS_OK", 1: "AVS_EINVAL", 2: "AVS_ENOMEM", 3: "AVS_EHIP", 4:
                 5: "AVS_EINTERNAL", 6: "AVS_ESTATE"}
 MEM_HOST, MEM_DEVICE = 0, 1
 PRECISION_F64, PRECISION_F32 = 0, 1   # avs_desc.precision (SolveType of the reference, util.h:25-37)
-OPTION_PRECONDITIONER = 0             # avs_set_solver_option
+(OPTION_PRECONDITIONER, OPTION_RESIDENT_LOOP, OPTION_TRANSPORT, OPTION_PARANOID, OPTION_GRAPH_REPLAY, OPTION_BRICK_FORM,
+ OPTION_FUSED_SCALAR_STEPS, OPTION_RELOAD_ENVIRONMENT) = range(8)  # avs_set_solver_option
+USE_TRANSPORT_AUTO, USE_TRANSPORT_RCCL, USE_TRANSPORT_DIRECT = 0, 1, 2
+BRICK_AUTO, BRICK_NEVER, BRICK_ALWAYS = -1, 0, 1
 PRECONDITIONER_JACOBI, PRECONDITIONER_NONE = 0, 1
 INACTIVE, ACTIVE, UP, DOWN = 0, 1, 2, 3
 UNASSIGNED, SOLIDBOUNDARY, OUTSIDE = -1, -2, -3
@@ -39,8 +43,8 @@ EXPORTED_SYMBOLS = [
     "avs_set_index_field", "avs_set_dof_counts", "avs_set_scalar_field", "avs_build_stencils",
     "avs_build_initial_guess", "avs_build_system", "avs_assemble", "avs_solve", "avs_set_solver_option",
     "avs_get_assembly_info", "avs_get_matrix_format", "avs_get_solution", "avs_get_initial_guess", "avs_get_csr",
-    "avs_get_edge_stencils", "avs_get_center_stencils", "avs_pcg_csr", "avs_spmv_csr",
-    "avs_bench_spmv", "avs_spmv_sell", "avs_bench_stream", "avs_prepass_create", "avs_prepass_destroy", "avs_prepass_run",
+    "avs_get_edge_stencils", "avs_get_center_stencils", "avs_pcg_csr",
+    "avs_prepass_create", "avs_prepass_destroy", "avs_prepass_run",
     "avs_prepass_get_info", "avs_prepass_get_labels", "avs_prepass_get_mask", "avs_prepass_get_index",
     "avs_prepass_get_weights", "avs_prepass_get_regular_index", "avs_prepass_apply", "avs_set_regular_index_field",
     "avs_transfer_to_regular_grid", "avs_get_node_grid", "avs_get_dof_table", "avs_plan_owners", "avs_plan_create", "avs_plan_get_sizes",
@@ -49,6 +53,8 @@ EXPORTED_SYMBOLS = [
     "avs_spmv_tile_rows", "avs_dist_assemble", "avs_dist_get_plan_sizes", "avs_dist_get_overlap_tiles", "avs_dist_get_plan_arrays", "avs_dist_solve", "avs_dist_get_solution",
     "avs_dist_get_info", "avs_dist_init_hosted", "avs_dist_export_blob", "avs_dist_import_blobs",
 ]
+# include/avs_probe.h: exported by libavs_probe.so only (the -DAVS_PROBES build of the same sources)
+PROBE_SYMBOLS = ["avs_spmv_csr", "avs_bench_spmv", "avs_spmv_sell", "avs_bench_stream", "avs_brick_spmv_probe"]
 _VOID_RETURN = ("avs_last_error", "avs_version", "avs_destroy", "avs_plan_destroy", "avs_local_group_destroy",
                 "avs_prepass_destroy")
 
@@ -110,18 +116,27 @@ class MatrixFormat(C.Structure):
 
 
 _lib = None
+_probe_lib = None
 
 
-def load():
-    """Load libavs_hip.so; raises if it has not been built (python __graft_entry__.py build)."""
-    global _lib
-    if _lib is not None:
+def load_probe():
+    """libavs_probe.so: the product sources built with -DAVS_PROBES (+ the entries of include/avs_probe.h).  Tools and tests only."""
+    return load(probe=True)
+
+
+def load(probe=False):
+    """Load libavs_hip.so (or the probe build); raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib, _probe_lib
+    if probe and _probe_lib is not None:
+        return _probe_lib
+    if not probe and _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = PROBE_LIB_PATH if probe else LIB_PATH
+    if not os.path.exists(path):
         raise FileNotFoundError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, i32, i64, f64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_float
     L.avs_last_error.restype = C.c_char_p
     L.avs_version.restype = C.c_char_p
@@ -146,10 +161,11 @@ def load():
     L.avs_get_edge_stencils.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32]
     L.avs_get_center_stencils.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32]
     L.avs_pcg_csr.argtypes = [i64, vp, vp, vp, vp, vp, f64, i32, i32, i32, vp, C.POINTER(SolveInfo)]
-    L.avs_spmv_csr.argtypes = [i64, vp, vp, vp, vp, vp, i32, i32, vp]
-    L.avs_bench_spmv.argtypes = [vp, i32, i32, C.POINTER(f64)]
-    L.avs_spmv_sell.argtypes = [i64, vp, vp, vp, vp, vp, i32, vp, C.POINTER(f64)]
-    L.avs_bench_stream.argtypes = [i32, i64, i32, i32, C.POINTER(f64)]
+    if probe:
+        L.avs_spmv_csr.argtypes = [i64, vp, vp, vp, vp, vp, i32, i32, vp]
+        L.avs_bench_spmv.argtypes = [vp, i32, i32, C.POINTER(f64)]
+        L.avs_spmv_sell.argtypes = [i64, vp, vp, vp, vp, vp, i32, vp, C.POINTER(f64)]
+        L.avs_bench_stream.argtypes = [i32, i64, i32, i32, C.POINTER(f64)]
     L.avs_prepass_create.argtypes = [C.POINTER(PrepassDesc), C.POINTER(vp)]
     L.avs_prepass_destroy.argtypes = [vp]
     L.avs_prepass_destroy.restype = None
@@ -190,17 +206,21 @@ def load():
     L.avs_dist_init_hosted.argtypes = [vp, i32, i32]
     L.avs_dist_export_blob.argtypes = [vp, vp]
     L.avs_dist_import_blobs.argtypes = [vp, vp]
-    for name in EXPORTED_SYMBOLS:
+    for name in EXPORTED_SYMBOLS + (PROBE_SYMBOLS if probe else []):
         fn = getattr(L, name)
         if name not in _VOID_RETURN:
             fn.restype = C.c_int
-    _lib = L
+    if probe:
+        _probe_lib = L
+    else:
+        _lib = L
     return L
 
 
 def check(status):
     if status != OK:
-        raise AvsError(status, load().avs_last_error().decode("utf-8", "replace"))
+        msgs = [m for m in (l.avs_last_error().decode("utf-8", "replace") for l in (_lib, _probe_lib) if l is not None) if m]
+        raise AvsError(status, " | ".join(dict.fromkeys(msgs)) or "(no message)")
 
 
 def ptr_of(buf):

@@ -80,6 +80,59 @@ static size_t vol3(const int r[3]) { return (size_t)r[0] * (size_t)r[1] * (size_
 
 using namespace avs;
 
+namespace avs {
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+static double env_dbl(const char *name, double dflt) { const char *e = getenv(name); return e ? atof(e) : dflt; }
+// the only reader of the environment (besides AVS_ROCTX, a process-wide tracing switch, and the probe build's test hooks)
+Options options_from_env()
+{
+    Options o;
+    o.resident = env_int("AVS_CG_RESIDENT", 1) != 0;
+    if (const char *e = getenv("AVS_DIST_TRANSPORT")) o.transport = strcmp(e, "rccl") == 0 ? 1 : (strcmp(e, "direct") == 0 ? 2 : 0);
+    o.paranoid = env_int("AVS_DIST_PARANOID", 0) != 0;
+    o.graph = env_int("AVS_PCG_GRAPH", 1) != 0;
+    if (const char *e = getenv("AVS_BRICK")) o.brick = atoi(e) != 0;
+    o.brick_interleave = env_int("AVS_BRICK_INTERLEAVE", 1) != 0;
+    o.brick_shift = env_int("AVS_BRICK_SHIFT", 3);
+    o.value_index = env_int("AVS_VALUE_INDEX", 1) != 0;
+    o.value_pack = env_int("AVS_VALUE_PACK", 1) != 0;
+    o.tile_tables = env_int("AVS_TILE_TABLES", 1) != 0;
+    o.column_windows = env_int("AVS_COLUMN_WINDOWS", 1) != 0;
+    o.brick_min_regular = env_dbl("AVS_BRICK_MIN_REGULAR", 0.6);
+    o.brick_timing = getenv("AVS_BRICK_TIMING") != nullptr;
+    o.fuse_beta = env_int("AVS_PCG_FUSE_BETA", 1) != 0;
+    o.resident_cus = env_int("AVS_CG_RESIDENT_CUS", 0);
+    o.resident_equal_lanes = getenv("AVS_CG_RESIDENT_EQUAL_LANES") != nullptr;
+    o.resident_max_global = env_int("AVS_CG_RESIDENT_MAX_GLOBAL", 3);
+    o.resident_max_quads = env_int("AVS_CG_RESIDENT_MAX_QUADS", 0);
+    o.resident_no_stream = getenv("AVS_CG_RESIDENT_NO_STREAM") != nullptr;
+    if (const char *e = getenv("AVS_CG_RESIDENT_REMAP_CHUNK")) o.resident_remap_chunk = atoll(e);
+    o.resident_lane_fill = env_dbl("AVS_CG_RESIDENT_LANE_FILL", 0.90);
+    o.resident_remote_cost = env_dbl("AVS_CG_RESIDENT_REMOTE_COST", 3.0);
+    o.resident_stream_cost = env_dbl("AVS_CG_RESIDENT_STREAM_COST", 1.5);
+    o.resident_coherent_fill = env_int("AVS_CG_RESIDENT_COHERENT_FILL", 1);
+    o.resident_timers = env_int("AVS_CG_RESIDENT_TIMERS", 0);
+    o.resident_verbose = env_int("AVS_CG_RESIDENT_VERBOSE", 0);
+    if (const char *e = getenv("AVS_DIST_CG")) o.dist_standard_cg = strcmp(e, "standard") == 0;
+    o.dist_overlap = env_int("AVS_DIST_OVERLAP", 1) != 0;
+    o.dist_loopback = env_int("AVS_DIST_LOOPBACK", 0) != 0;
+    if (const char *e = getenv("AVS_DIST_PLAN")) o.dist_host_plan = strcmp(e, "host") == 0;
+    o.dist_selftest_rounds = env_int("AVS_DIST_SELFTEST_ROUNDS", 64);
+    o.dist_split_rows = env_int("AVS_DIST_SPLIT_ROWS", 1) != 0;
+    if (const char *e = getenv("AVS_DIST_TIMEOUT_MS")) o.dist_timeout_ms = atoll(e) > 0 ? atoll(e) : 0;
+    return o;
+}
+static thread_local const Options *tl_opt = nullptr;
+const Options &cur_opt()
+{
+    if (tl_opt) return *tl_opt;
+    static thread_local Options fallback = options_from_env(); // an entry point without a context (avs_pcg_csr, measurement entries)
+    return fallback;
+}
+OptScope::OptScope(const ::avs_ctx *c) : prev(tl_opt) { if (c) tl_opt = &c->opt; }
+OptScope::~OptScope() { tl_opt = prev; }
+} // namespace avs
+
 avs::PyramidView avs_ctx::view() const
 {
     PyramidView P{};
@@ -138,6 +191,7 @@ avs_status avs_create(const avs_desc *d, avs_ctx **out)
     avs_ctx *c = new (std::nothrow) avs_ctx();
     AVS_REQUIRE(c, AVS_ENOMEM, "out of host memory");
     c->desc = *d;
+    c->opt = options_from_env(); // the environment is read here, once per context
     if (c->desc.field_nx == 0) c->desc.field_nx = d->nx;
     if (c->desc.field_ny == 0) c->desc.field_ny = d->ny;
     if (c->desc.field_nz == 0) c->desc.field_nz = d->nz;
@@ -177,6 +231,7 @@ static void invalidate(avs_ctx *c, bool tables)
 
 avs_status avs_set_labels(avs_ctx *c, int32_t level, const int8_t *labels, avs_memspace where)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c && labels, AVS_EINVAL, "null argument");
     AVS_REQUIRE(level >= 0 && level < c->desc.levels, AVS_EINVAL, "level %d out of range", level);
     AVS_HIP(hipSetDevice(c->desc.device));
@@ -193,6 +248,7 @@ avs_status avs_set_labels(avs_ctx *c, int32_t level, const int8_t *labels, avs_m
 avs_status avs_set_index_field(avs_ctx *c, avs_index_kind kind, int32_t level, int32_t axis, const int32_t *idx,
                                avs_memspace where)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c && idx, AVS_EINVAL, "null argument");
     AVS_REQUIRE(level >= 0 && level < c->desc.levels, AVS_EINVAL, "level %d out of range", level);
     AVS_REQUIRE(kind == AVS_INDEX_CENTER || (axis >= 0 && axis < 3), AVS_EINVAL, "axis %d out of range", axis);
@@ -216,6 +272,7 @@ avs_status avs_set_index_field(avs_ctx *c, avs_index_kind kind, int32_t level, i
 
 avs_status avs_set_dof_counts(avs_ctx *c, int64_t nv, int64_t ne, int64_t nc)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_REQUIRE(nv >= 0 && ne >= 0 && nc >= 0 && nv < INT32_MAX && ne < INT32_MAX && nc < INT32_MAX / 3, AVS_EINVAL,
                 "DOF counts out of range");
@@ -288,6 +345,7 @@ extern "C" {
 avs_status avs_set_scalar_field(avs_ctx *c, avs_field_kind kind, int32_t axis, const float *data, float constant,
                                 avs_memspace where)
 {
+    avs::OptScope opt_scope_(c);
     return avs::set_scalar_field_lattice(c, kind, axis, data, constant, where, false);
 }
 
@@ -347,18 +405,21 @@ extern "C" {
 
 avs_status avs_build_stencils(avs_ctx *c)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_HIP(hipSetDevice(c->desc.device));
     return build_stencils(c);
 }
 avs_status avs_build_initial_guess(avs_ctx *c)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_HIP(hipSetDevice(c->desc.device));
     return build_initial_guess(c);
 }
 avs_status avs_build_system(avs_ctx *c)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_HIP(hipSetDevice(c->desc.device));
     return build_system(c);
@@ -366,6 +427,7 @@ avs_status avs_build_system(avs_ctx *c)
 
 avs_status avs_assemble(avs_ctx *c, avs_assembly_info *info)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_HIP(hipSetDevice(c->desc.device));
     Timer t(c->stream);
@@ -385,7 +447,7 @@ avs_status avs_assemble(avs_ctx *c, avs_assembly_info *info)
         c->ainfo.system_ms = t.stop();
         t.start();
         c->reordered = false;
-        if (const char *e = getenv("AVS_BRICK_SHIFT")) c->brick_shift = atoi(e);
+        c->brick_shift = c->opt.brick_shift;
         if (c->brick_shift >= 0) AVS_TRY(build_reordered_system(c, c->brick_shift));
         c->ainfo.csr_ms = t.stop();
     }
@@ -402,6 +464,7 @@ int32_t avs_spmv_tile_rows(void) { return spmv_tile_rows(); }
 
 avs_status avs_get_matrix_format(avs_ctx *c, avs_matrix_format *fmt)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c && fmt, AVS_EINVAL, "null argument");
     if (!c->system_ready && dist_matrix_format(c, fmt)) return AVS_OK; // avs_dist_assemble: the rank's own rows
     AVS_REQUIRE(c->system_ready, AVS_ESTATE, "no system: call avs_assemble first");
@@ -422,6 +485,7 @@ avs_status avs_get_matrix_format(avs_ctx *c, avs_matrix_format *fmt)
 
 avs_status avs_get_assembly_info(avs_ctx *c, avs_assembly_info *info)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c && info, AVS_EINVAL, "null argument");
     c->ainfo.n_velocity = c->n_vel;
     c->ainfo.n_edge = c->n_edge;
@@ -454,11 +518,29 @@ __global__ __launch_bounds__(256) void k_narrow_f32(double *__restrict__ x, int6
 
 avs_status avs_set_solver_option(avs_ctx *c, avs_solver_option option, int32_t value)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
-    AVS_REQUIRE(option == AVS_OPTION_PRECONDITIONER, AVS_EINVAL, "unknown solver option %d", (int)option);
-    AVS_REQUIRE(value == AVS_PRECONDITIONER_JACOBI || value == AVS_PRECONDITIONER_NONE, AVS_EINVAL, "preconditioner must be JACOBI or NONE");
-    c->no_precond = value == AVS_PRECONDITIONER_NONE;
-    return AVS_OK;
+    switch (option) {
+    case AVS_OPTION_PRECONDITIONER:
+        AVS_REQUIRE(value == AVS_PRECONDITIONER_JACOBI || value == AVS_PRECONDITIONER_NONE, AVS_EINVAL, "preconditioner must be JACOBI or NONE");
+        c->no_precond = value == AVS_PRECONDITIONER_NONE;
+        return AVS_OK;
+    case AVS_OPTION_RESIDENT_LOOP: c->opt.resident = value != 0; return AVS_OK;
+    case AVS_OPTION_TRANSPORT:
+        AVS_REQUIRE(value >= AVS_USE_TRANSPORT_AUTO && value <= AVS_USE_TRANSPORT_DIRECT, AVS_EINVAL, "transport must be AUTO, RCCL or DIRECT");
+        c->opt.transport = value;
+        return AVS_OK;
+    case AVS_OPTION_PARANOID: c->opt.paranoid = value != 0; return AVS_OK;
+    case AVS_OPTION_GRAPH_REPLAY: c->opt.graph = value != 0; return AVS_OK;
+    case AVS_OPTION_BRICK_FORM:
+        AVS_REQUIRE(value >= AVS_BRICK_AUTO && value <= AVS_BRICK_ALWAYS, AVS_EINVAL, "brick form must be AUTO, NEVER or ALWAYS");
+        c->opt.brick = value;
+        return AVS_OK;
+    case AVS_OPTION_FUSED_SCALAR_STEPS: c->opt.fuse_beta = value != 0; return AVS_OK;
+    case AVS_OPTION_RELOAD_ENVIRONMENT: c->opt = options_from_env(); return AVS_OK;
+    }
+    set_error("unknown solver option %d", (int)option);
+    return AVS_EINVAL;
 }
 
 extern "C++" {
@@ -473,6 +555,7 @@ void narrow_solution_if_f32(avs_ctx *c, double *x, int64_t n)
 
 avs_status avs_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_info *info)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->system_ready, AVS_ESTATE, "avs_assemble must succeed before avs_solve");
     AVS_REQUIRE(tol >= 0. && max_iters >= 0, AVS_EINVAL, "tolerance / max_iterations out of range");
@@ -514,6 +597,7 @@ static avs_status get_vec(avs_ctx *c, const double *src, int64_t have, double *d
 
 avs_status avs_get_solution(avs_ctx *c, double *x, int64_t n, avs_memspace where)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->solved, AVS_ESTATE, "no solution: call avs_solve first");
     return get_vec(c, c->x.p, c->n_vel, x, n, where);
@@ -521,6 +605,7 @@ avs_status avs_get_solution(avs_ctx *c, double *x, int64_t n, avs_memspace where
 
 avs_status avs_get_initial_guess(avs_ctx *c, double *x0, int64_t n, avs_memspace where)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->guess_ready, AVS_ESTATE, "no initial guess: call avs_build_initial_guess / avs_assemble first");
     return get_vec(c, c->x0.p, c->n_vel, x0, n, where);
@@ -528,6 +613,7 @@ avs_status avs_get_initial_guess(avs_ctx *c, double *x0, int64_t n, avs_memspace
 
 avs_status avs_get_csr(avs_ctx *c, int32_t *row_ptr, int32_t *col, double *val, double *rhs, avs_memspace where)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->system_ready, AVS_ESTATE, "no system: call avs_assemble first");
     AVS_HIP(hipSetDevice(c->desc.device));
@@ -565,11 +651,13 @@ static avs_status get_stencils(avs_ctx *c, bool edge, int32_t *cnt, int32_t *idx
 avs_status avs_get_edge_stencils(avs_ctx *c, int32_t *cnt, int32_t *idx, double *coef, int32_t *bcnt, double *bval,
                                  double *weight, avs_memspace where)
 {
+    avs::OptScope opt_scope_(c);
     return get_stencils(c, true, cnt, idx, coef, bcnt, bval, weight, where);
 }
 avs_status avs_get_center_stencils(avs_ctx *c, int32_t *cnt, int32_t *idx, double *coef, int32_t *bcnt, double *bval,
                                    double *weight, avs_memspace where)
 {
+    avs::OptScope opt_scope_(c);
     return get_stencils(c, false, cnt, idx, coef, bcnt, bval, weight, where);
 }
 
@@ -654,6 +742,7 @@ avs_status avs_pcg_csr(int64_t n, const int32_t *row_ptr, const int32_t *col, co
     return rc;
 }
 
+#ifdef AVS_PROBES // measurement / test entries (include/avs_probe.h): compiled into libavs_probe.so only
 avs_status avs_spmv_csr(int64_t n, const int32_t *row_ptr, const int32_t *col, const double *val, const double *x,
                         double *y, int32_t variant, int32_t repeats, void *stream)
 {
@@ -679,6 +768,7 @@ __global__ void k_count_bit_diff(int64_t n, const double *__restrict__ a, const 
 
 avs_status avs_bench_spmv(avs_ctx *c, int32_t variant, int32_t repeats, double *ms_per_launch)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c && ms_per_launch, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->system_ready, AVS_ESTATE, "no system: call avs_assemble first");
     AVS_REQUIRE(repeats > 0, AVS_EINVAL, "repeats must be positive");
@@ -745,5 +835,6 @@ avs_status avs_bench_stream(int32_t mode, int64_t bytes, int32_t repeats, int32_
     *gbps = (mode == 2 ? 2.0 : 1.0) * (double)n * 8.0 / (ms * 1e-3) / 1e9;
     return AVS_OK;
 }
+#endif // AVS_PROBES
 
 } // extern "C"

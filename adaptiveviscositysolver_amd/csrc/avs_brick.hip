@@ -33,15 +33,22 @@ namespace avs {
 
 constexpr int kBrickBlk = 512;
 
+#ifdef AVS_PROBES
 // measurement only (AVS_BRICK_DEBUG & 16): wall_clock64 stamps of workgroup phases, 8 per tile, first kStampTiles tiles of every workgroup
 constexpr int kStampTiles = 24, kStampWgs = 1024;
 __device__ long long g_brick_stamps[kStampWgs * kStampTiles * 8];
+#define BRICK_DBG(bit) (B.debug & (bit))
 #define BRICK_STAMP(slot)                                                                                            \
     do {                                                                                                             \
-        if ((B.debug & 16) && threadIdx.x == 0 && iter < kStampTiles && blockIdx.x < kStampWgs) {                             \
+        if (BRICK_DBG(16) && threadIdx.x == 0 && iter < kStampTiles && blockIdx.x < kStampWgs) {                             \
             g_brick_stamps[((int)blockIdx.x * kStampTiles + iter) * 8 + (slot)] = wall_clock64();                    \
         }                                                                                                            \
     } while (0)
+
+#else
+#define BRICK_DBG(bit) 0
+#define BRICK_STAMP(slot) do { } while (0)
+#endif
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double brick_dpp_add(double v)
@@ -110,6 +117,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
     int nsw_prev = 0;
 
     int iter = 0;
+    (void)iter;
     for (;;) {
         BRICK_STAMP(0);
         if (nsw_prev > 0) __syncthreads();                               // the previous tile's streamed sums have read `park`
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                 const int q = u * QW + qw;
                 const uint32_t r = bw[o_runs + (q < nruns ? q : 0)];
                 const int nbase = (int)bw[16 + (r >> 27)];
-                const bool on = q < nruns && l16 <= (int)(r & 15u) && !(B.debug & 1);
+                const bool on = q < nruns && l16 <= (int)(r & 15u) && !BRICK_DBG(1);
                 rdsc[u] = on ? r : 0xffffffffu;
                 fv[u] = x[on ? (int64_t)nbase + (int)((r >> 16) & 0x7ffu) + l16 : (int64_t)row0];
             }
@@ -234,7 +242,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
             if (k * kBrickBlk >= nprow) break;
-            if (tid + k * kBrickBlk < nprow && !(B.debug & 2)) {
+            if (tid + k * kBrickBlk < nprow && !BRICK_DBG(2)) {
                 const uint32_t rd = rdv[k].x, ro = rdv[k].y;
                 const unsigned pid = rd >> 20;
                 const int lr = (int)((rd >> 18) & 3u), ax = (int)((rd >> 16) & 3u);
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         }
         BRICK_STAMP(3);
         // streamed rows: passes of `cap` products parked in LDS, then every row adds its segment left to right
-        if (nsw > 0 && !(B.debug & 4)) {
+        if (nsw > 0 && !BRICK_DBG(4)) {
             double ssum[kBrickMaxRows / kBrickBlk];
 #pragma unroll
             for (int k = 0; k < kBrickMaxRows / kBrickBlk; ++k) ssum[k] = 0.;
@@ -350,7 +358,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         ++iter;
         tile = tnext;
         tb = tbn;
-        nsw_prev = (nsw > 0 && !(B.debug & 4)) ? 1 : 0;
+        nsw_prev = (nsw > 0 && !BRICK_DBG(4)) ? 1 : 0;
     }
 }
 
@@ -375,7 +383,9 @@ static int brick_grid(const BrickView &B, size_t lds)
         cached[dev] = per_cu * cus;
     }
     int g = cached[dev];
+#ifdef AVS_PROBES
     if (const char *e = getenv("AVS_BRICK_GRID")) g = atoi(e) > 0 ? atoi(e) : g;
+#endif
     return g < B.ntiles ? g : B.ntiles;
 }
 
@@ -398,6 +408,7 @@ avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, dou
 
 } // namespace avs
 
+#ifdef AVS_PROBES
 // Measurement / test entry: SpMV on a brick form whose arrays the caller built (tools/brick_build.py: the torch reference builder the
 // device builder is tested against).  Device pointers.
 extern "C" avs_status avs_brick_spmv_probe(const avs_brick_arrays *a, const double *x, double *y, double *partial, int32_t repeats,
@@ -444,3 +455,4 @@ extern "C" avs_status avs_brick_spmv_probe(const avs_brick_arrays *a, const doub
     }
     return AVS_OK;
 }
+#endif // AVS_PROBES

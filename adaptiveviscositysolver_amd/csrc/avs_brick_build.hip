@@ -731,7 +731,7 @@ avs_status build_brick_form(avs_ctx *c)
     if (c->brick_shift != 3 || c->desc.levels < 1) return AVS_OK;
     if (c->desc.nx > 1024 || c->desc.ny > 1024 || c->desc.nz > 1024 || nnz >= (1ll << 31)) return AVS_OK;
     hipStream_t st = c->stream;
-    const bool timing = getenv("AVS_BRICK_TIMING") != nullptr;
+    const bool timing = c->opt.brick_timing != 0;
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;
@@ -877,8 +877,7 @@ avs_status build_brick_form(avs_ctx *c)
         bf.block_words = w;
     }
     // worth it only where most rows are patterns (a curved surface with ~10^4 distinct values gives every row its own)
-    double min_frac = 0.6;
-    if (const char *e = getenv("AVS_BRICK_MIN_REGULAR")) min_frac = atof(e);
+    const double min_frac = c->opt.brick_min_regular;
     bf.ready = (double)regular >= min_frac * (double)n;
     return AVS_OK;
 }

@@ -180,8 +180,7 @@ avs_status dist_halo_exchange(PcgDist *d, double *p_ext, hipStream_t stream)
 bool dist_tile_lists(PcgDist *d, const int32_t **t_int, int *n_int, const int32_t **t_bnd, int *n_bnd)
 {
     if (!d || d->world <= 1 || d->no_overlap || !d->comm_stream || d->n_tiles_int + d->n_tiles_bnd == 0) return false;
-    const char *e = getenv("AVS_DIST_OVERLAP");
-    if (e && atoi(e) == 0) return false;
+    if (!cur_opt().dist_overlap) return false;
     *t_int = d->tiles_int.p; *n_int = d->n_tiles_int;
     *t_bnd = d->tiles_bnd.p; *n_bnd = d->n_tiles_bnd;
     return true;
@@ -230,8 +229,7 @@ avs_status dist_allreduce(PcgDist *d, double *dev, int count, hipStream_t stream
 bool dist_wants_single_reduction(PcgDist *d)
 {
     if (!d || d->world <= 1) return false;
-    const char *e = getenv("AVS_DIST_CG");
-    return !(e && strcmp(e, "standard") == 0);
+    return !cur_opt().dist_standard_cg;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -433,11 +431,13 @@ static avs_status direct_connect(avs_ctx *c, PcgDist *d, const uint8_t *blobs, b
     h.send_idx = d->send_idx.p;
     h.psum = d->psum.p;
     h.inject_stale_round = -1;
-    if (const char *e = getenv("AVS_DIST_PARANOID")) h.paranoid = atoi(e) != 0;
+    h.paranoid = cur_opt().paranoid != 0;
+#ifdef AVS_PROBES
     if (const char *e = getenv("AVS_DIST_INJECT_STALE")) { // test hook: proves the paranoid check sees a stale entry
         h.inject_stale_round = atoll(e);
         h.paranoid = 1;
     }
+#endif
     // segments of the send lists per workgroup of the fused update + push kernel (send lists are ascending local row ids)
     {
         sr_update_geometry((long long)d->n_own, &d->push_grid, &d->push_chunk);
@@ -479,7 +479,7 @@ static avs_status direct_connect(avs_ctx *c, PcgDist *d, const uint8_t *blobs, b
         khz = 100000; // 100 MHz constant clock
     }
     long long ms = 20000;
-    if (const char *e = getenv("AVS_DIST_TIMEOUT_MS")) ms = atoll(e) > 0 ? atoll(e) : ms;
+    if (cur_opt().dist_timeout_ms > 0) ms = cur_opt().dist_timeout_ms;
     h.timeout_ticks = (long long)khz * ms;
     AVS_HIP(hipMemcpy(d->dd.p, &h, sizeof(h), hipMemcpyHostToDevice));
     d->dd_host = h;
@@ -519,10 +519,8 @@ bool dist_direct_args(PcgDist *d, DirectArgs *out)
 static avs_status run_selftest(avs_ctx *c, PcgDist *d, bool *passed)
 {
     *passed = true;
-    int rounds = 64;
-    if (const char *e = getenv("AVS_DIST_SELFTEST_ROUNDS")) rounds = atoi(e);
-    if (const char *e = getenv("AVS_DIST_LOOPBACK"))
-        if (atoi(e) != 0) rounds = 0; // a looped-back rank never fills its halo area
+    int rounds = cur_opt().dist_selftest_rounds;
+    if (cur_opt().dist_loopback) rounds = 0; // a looped-back rank never fills its halo area
     if (rounds <= 0 || !d->direct_ready) return AVS_OK;
     DirectArgs da;
     if (!dist_direct_args(d, &da)) return AVS_OK;
@@ -548,9 +546,8 @@ static avs_status run_selftest(avs_ctx *c, PcgDist *d, bool *passed)
 // after a plan exists: choose the transport, exchange the blobs, connect -- all ranks end up with the SAME transport
 static avs_status direct_setup(avs_ctx *c, PcgDist *d)
 {
-    const char *env = getenv("AVS_DIST_TRANSPORT");
-    const bool forced = env && strcmp(env, "direct") == 0;
-    const bool off = env && strcmp(env, "rccl") == 0;
+    const bool forced = cur_opt().transport == 2;
+    const bool off = cur_opt().transport == 1;
     direct_release(d);
     if (d->hosted) { // the host program finishes the set-up (avs_dist_export_blob / avs_dist_import_blobs)
         AVS_REQUIRE(!off, AVS_EINVAL, "a hosted group has no RCCL communicator: AVS_DIST_TRANSPORT=rccl is impossible");
@@ -1177,7 +1174,7 @@ static avs_status dist_assemble_device(avs_ctx *c, PcgDist *d, int cut_axis, int
     if (n_own) hipLaunchKernelGGL(k_da_mark, dim3(8192), dim3(256), 0, st, n_own, d->row_ptr.p, d->col.p, c->inv.p, owner.p, rank, is_halo.p,
                                   needed_by.p);
     bool split = world > 1;
-    if (const char *e = getenv("AVS_DIST_SPLIT_ROWS")) split = split && atoi(e) != 0;
+    split = split && cur_opt().dist_split_rows != 0;
     if (split && n_own) { // [interior | halo-reading] local row order (see k_da_new_index)
         DevBuf<int32_t> new_of, len_new, rp2, col2, own2, ids2;
         DevBuf<double> val2, rhs2;
@@ -1390,6 +1387,7 @@ extern "C" {
 
 avs_status avs_get_dof_table(avs_ctx *c, avs_index_kind kind, int32_t *table, avs_memspace where)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c && table, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->tables_ready, AVS_ESTATE, "dof tables not built: call avs_assemble first");
     AVS_HIP(hipSetDevice(c->desc.device));
@@ -1426,6 +1424,7 @@ static avs_status new_dist(avs_ctx *c, int rank, int world)
 
 avs_status avs_dist_init(avs_ctx *c, const uint8_t id[AVS_UNIQUE_ID_BYTES], int32_t rank, int32_t world)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c && id, AVS_EINVAL, "null argument");
     AVS_HIP(hipSetDevice(c->desc.device));
     AVS_TRY(new_dist(c, rank, world));
@@ -1460,6 +1459,7 @@ void avs_local_group_destroy(avs_local_group *g) { delete g; }
 
 avs_status avs_dist_init_local(avs_ctx *c, avs_local_group *g, int32_t rank)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c && g, AVS_EINVAL, "null argument");
     AVS_TRY(new_dist(c, rank, g->world));
     c->dist->group = g;
@@ -1470,6 +1470,7 @@ avs_status avs_dist_init_local(avs_ctx *c, avs_local_group *g, int32_t rank)
 
 avs_status avs_dist_init_hosted(avs_ctx *c, int32_t rank, int32_t world)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_TRY(new_dist(c, rank, world));
     c->dist->hosted = true;
@@ -1478,6 +1479,7 @@ avs_status avs_dist_init_hosted(avs_ctx *c, int32_t rank, int32_t world)
 
 avs_status avs_dist_export_blob(avs_ctx *c, uint8_t blob[AVS_DIST_BLOB_BYTES])
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c && blob, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->dist && c->dist->direct_prepared, AVS_ESTATE, "no comm block: call avs_dist_assemble / avs_dist_partition first");
     memcpy(blob, c->dist->blob.data(), AVS_DIST_BLOB_BYTES);
@@ -1542,10 +1544,10 @@ static avs_status direct_connect_loopback(avs_ctx *c, PcgDist *d)
 
 avs_status avs_dist_import_blobs(avs_ctx *c, const uint8_t *blobs)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->dist, AVS_ESTATE, "call avs_dist_init_hosted first");
-    if (const char *e = getenv("AVS_DIST_LOOPBACK"))
-        if (atoi(e) != 0) return direct_connect_loopback(c, c->dist);
+    if (cur_opt().dist_loopback) return direct_connect_loopback(c, c->dist);
     AVS_REQUIRE(blobs, AVS_EINVAL, "null argument");
     AVS_TRY(direct_connect(c, c->dist, blobs));
     // hosted group: every rank calls this with the same blobs; the self-test's rounds rendezvous through the comm blocks.  There is
@@ -1561,6 +1563,7 @@ avs_status avs_dist_import_blobs(avs_ctx *c, const uint8_t *blobs)
 
 avs_status avs_dist_partition(avs_ctx *c, int32_t cut_axis)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->dist, AVS_ESTATE, "call avs_dist_init / avs_dist_init_local first");
     AVS_REQUIRE(c->system_ready, AVS_ESTATE, "avs_assemble must succeed before avs_dist_partition");
@@ -1580,8 +1583,7 @@ avs_status avs_dist_partition(avs_ctx *c, int32_t cut_axis)
     // so every rank's local rows keep the brick locality; results are mapped back in avs_dist_get_solution
     const bool ro = c->reordered;
     const double *g_rhs = ro ? c->p_rhs.p : c->rhs.p, *g_x0 = ro ? c->p_x0.p : c->x0.p;
-    const char *mode = getenv("AVS_DIST_PLAN");
-    const bool host_plan = mode && strcmp(mode, "host") == 0;
+    const bool host_plan = cur_opt().dist_host_plan != 0;
     d->vi.clear();
     if (host_plan) AVS_TRY(plan_on_host(c, d, cut_axis, extent, ro));
     else AVS_TRY(plan_on_device(c, d, cut_axis, extent, ro));
@@ -1633,6 +1635,7 @@ avs_status avs_dist_partition(avs_ctx *c, int32_t cut_axis)
 
 avs_status avs_dist_assemble(avs_ctx *c, int32_t cut_axis, avs_assembly_info *info)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->dist, AVS_ESTATE, "call avs_dist_init / avs_dist_init_local first");
     AVS_HIP(hipSetDevice(c->desc.device));
@@ -1699,6 +1702,7 @@ avs_status avs_dist_assemble(avs_ctx *c, int32_t cut_axis, avs_assembly_info *in
 
 avs_status avs_dist_get_plan_sizes(avs_ctx *c, avs_plan_sizes *s)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c && s, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->dist && c->dist->partitioned, AVS_ESTATE, "call avs_dist_partition first");
     s->n_own = c->dist->n_own;
@@ -1713,6 +1717,7 @@ avs_status avs_dist_get_plan_arrays(avs_ctx *c, int32_t *own_global, int32_t *ro
                                     int32_t *peers, int32_t *send_counts, int32_t *recv_counts, int32_t *tiles_interior,
                                     int32_t *tiles_boundary)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->dist && c->dist->partitioned, AVS_ESTATE, "call avs_dist_partition first");
     PcgDist *d = c->dist;
@@ -1738,6 +1743,7 @@ avs_status avs_dist_get_plan_arrays(avs_ctx *c, int32_t *own_global, int32_t *ro
 
 avs_status avs_dist_get_overlap_tiles(avs_ctx *c, int32_t *interior, int32_t *boundary)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c && interior && boundary, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->dist && c->dist->partitioned, AVS_ESTATE, "call avs_dist_partition first");
     *interior = c->dist->n_tiles_int;
@@ -1747,6 +1753,7 @@ avs_status avs_dist_get_overlap_tiles(avs_ctx *c, int32_t *interior, int32_t *bo
 
 avs_status avs_dist_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_info *info)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->dist && c->dist->partitioned, AVS_ESTATE, "call avs_dist_partition first");
     AVS_REQUIRE(tol >= 0. && max_iters >= 0, AVS_EINVAL, "tolerance / max_iterations out of range");
@@ -1786,6 +1793,7 @@ avs_status avs_dist_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_i
 
 avs_status avs_dist_get_info(avs_ctx *c, avs_dist_info *info)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c && info, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->dist, AVS_ESTATE, "call avs_dist_init / avs_dist_init_local first");
     PcgDist *d = c->dist;
@@ -1801,8 +1809,7 @@ avs_status avs_dist_get_info(avs_ctx *c, avs_dist_info *info)
     info->selftest_bad_entries = d->selftest_bad;
     info->paranoid = d->direct_ready ? d->dd_host.paranoid : 0;
     if (d->direct_ready) {
-        const char *e = getenv("AVS_PCG_GRAPH");
-        info->graph_replay = !(e && atoi(e) == 0);
+        info->graph_replay = c->opt.graph != 0;
         info->launches_per_iteration = 2; // update (+ push), SpMV over all tiles (+ all-gather + scalar step in its finalizer block)
         info->collectives_per_iteration = 0;
         return AVS_OK;
@@ -1816,6 +1823,7 @@ avs_status avs_dist_get_info(avs_ctx *c, avs_dist_info *info)
 
 avs_status avs_dist_get_solution(avs_ctx *c, double *x, int64_t n, avs_memspace where)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c && x, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->dist && c->dist->solved, AVS_ESTATE, "no solution: call avs_dist_solve first");
     PcgDist *d = c->dist;

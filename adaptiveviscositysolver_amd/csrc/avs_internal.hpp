@@ -73,6 +73,43 @@ struct PhaseScope { // consecutive phases of one function: next() closes the pre
 };
 
 // ---------------------------------------------------------------------------------------------
+// Options: every switch of the library.  The defaults come from the environment ONCE, when a context is created (options_from_env is
+// the only function that calls getenv); the switches a host may legitimately set are then reachable through avs_set_solver_option.
+// Code deep inside a solve reads the options of the context whose entry point is running on this thread (cur_opt()).
+// ---------------------------------------------------------------------------------------------
+struct Options {
+    // user-facing (avs_set_solver_option)
+    int resident = 1;            // AVS_CG_RESIDENT: the CU-resident PCG loop where a system qualifies
+    int transport = 0;           // AVS_DIST_TRANSPORT: 0 auto (direct after its self-test, else RCCL), 1 rccl, 2 direct
+    int paranoid = 0;            // AVS_DIST_PARANOID: per-round halo checksums
+    int graph = 1;               // AVS_PCG_GRAPH: hipGraph replay of iteration chunks
+    int brick = -1;              // AVS_BRICK: brick-structured SpMV form: -1 auto (systems >= kBrickMinSystemRows), 0 never, 1 always
+    // storage forms of the solve matrix
+    int brick_interleave = 1, brick_shift = 3, value_index = 1, value_pack = 1, tile_tables = 1, column_windows = 1;
+    double brick_min_regular = 0.6;
+    int brick_timing = 0;
+    // single-GPU loop
+    int fuse_beta = 1;
+    // CU-resident loop: tuning and test switches
+    int resident_cus = 0, resident_equal_lanes = 0, resident_max_global = 3, resident_max_quads = 0, resident_no_stream = 0;
+    long long resident_remap_chunk = 0;
+    double resident_lane_fill = 0.90, resident_remote_cost = 3.0, resident_stream_cost = 1.5;
+    int resident_coherent_fill = 1, resident_timers = 0, resident_verbose = 0;
+    // multi-GPU
+    int dist_standard_cg = 0, dist_overlap = 1, dist_loopback = 0, dist_host_plan = 0, dist_selftest_rounds = 64, dist_split_rows = 1;
+    long long dist_timeout_ms = 0; // 0: the defaults (20 s between ranks, 2 s inside one device)
+};
+Options options_from_env();
+const Options &cur_opt();
+struct OptScope { // RAII: the options of `c` are the current ones on this thread while an entry point of the C ABI runs
+    explicit OptScope(const struct ::avs_ctx *c);
+    ~OptScope();
+    OptScope(const OptScope &) = delete;
+    OptScope &operator=(const OptScope &) = delete;
+    const Options *prev;
+};
+
+// ---------------------------------------------------------------------------------------------
 // device buffer with explicit lifetime (hipMalloc/hipFree), sized in elements
 // ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -444,6 +481,7 @@ struct avs_ctx {
         bool is_const = true;
     };
     Field centerw, edgew[3], facew[3], visc, dens, vel[3], solidvel[3];
+    avs::Options opt;   // switches: environment defaults taken at avs_create, avs_set_solver_option afterwards
     int64_t n_vel = -1, n_edge = -1, n_center = -1;
     int no_precond = 0; // avs_set_solver_option(AVS_OPTION_PRECONDITIONER, AVS_PRECONDITIONER_NONE)
 

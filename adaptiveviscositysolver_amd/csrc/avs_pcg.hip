@@ -927,6 +927,7 @@ static avs_status spmv_vi2_launch(const CsrView &A, const double *x, double *y, 
     return spmv_vi2_launch_t<BLK, CAP, DOT, false, false, WIN>(A, x, y, partial, sc, tiles, ntiles, lds, stream);
 }
 
+#ifdef AVS_PROBES
 // ---------------------------------------------------------------------------------------------
 // stream ceilings of this chip for the access widths the SpMV uses (measurement helpers)
 // ---------------------------------------------------------------------------------------------
@@ -993,6 +994,8 @@ __global__ __launch_bounds__(256) void k_spmv_sell(int64_t nslices, const int64_
     y[s * 64 + lane] = sum;
 }
 
+#endif // AVS_PROBES
+
 static inline int stream_grid(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
 
 int spmv_default_variant(const CsrView &) { return 24; } // 512 rows/WG, 32 KiB LDS, 16-B vector + non-temporal stream (profiles/r01_spmv_variants.md)
@@ -1011,6 +1014,7 @@ static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, do
         if (nblocks) *nblocks = nt * (kTileRows / 64);
         return spmv_vi2_launch<kTileRows, kTileCap, DOT, kTileWin>(A, x, y, partial, sc, nullptr, nt, stream);
     }
+#ifdef AVS_PROBES // geometry sweeps of the value-indexed kernels (profiles/r01_spmv_variants.md, r02_varvisc.md)
     if (A.tab_ptr && variant >= 51 && variant <= 54) { // geometry sweep of the tile-table kernel (profiles/r02_varvisc.md)
         const int nt = (int)((A.n + kTileRows - 1) / kTileRows);
         if (nblocks) *nblocks = nt * (kTileRows / 64);
@@ -1047,9 +1051,16 @@ static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, do
         }
 #undef AVS_VI2_CASE
     }
+#endif
     if (variant == 0) variant = spmv_default_variant(A);
     int g;
     switch (variant) { // the plain kernels below read A.val / A.col only
+#define AVS_TILE_CASE(ID, BLK, CAP, VEC, XCD, CHUNK, NT)                                                                  \
+    case ID:                                                                                                   \
+        g = (int)((A.n + BLK - 1) / BLK);                                                                      \
+        hipLaunchKernelGGL((k_spmv_tile<BLK, CAP, DOT, VEC, XCD, NT>), dim3(g), dim3(BLK), 0, stream, A, x, y, partial, sc, CHUNK); \
+        break;
+#ifdef AVS_PROBES // the round-1 kernel sweep (14 = the plain reference kernel avs_bench_spmv compares against)
     case 1:
         g = stream_grid(A.n);
         hipLaunchKernelGGL((k_spmv_stream<DOT>), dim3(g), dim3(kBlock), 0, stream, A, x, y, partial, sc);
@@ -1065,11 +1076,6 @@ static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, do
     case 4:
         g = kVecGrid * 4;
         hipLaunchKernelGGL((k_spmv_vec<16, DOT>), dim3(g), dim3(kBlock), 0, stream, A, x, y, partial, sc);
-        break;
-#define AVS_TILE_CASE(ID, BLK, CAP, VEC, XCD, CHUNK, NT)                                                                  \
-    case ID:                                                                                                   \
-        g = (int)((A.n + BLK - 1) / BLK);                                                                      \
-        hipLaunchKernelGGL((k_spmv_tile<BLK, CAP, DOT, VEC, XCD, NT>), dim3(g), dim3(BLK), 0, stream, A, x, y, partial, sc, CHUNK); \
         break;
         AVS_TILE_CASE(5, 256, 4096, false, true, 0, false)
         AVS_TILE_CASE(6, 256, 4096, true, false, 0, false)
@@ -1090,6 +1096,7 @@ static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, do
         AVS_TILE_CASE(21, 256, 2048, true, true, 8, true)
         AVS_TILE_CASE(22, 128, 1024, true, false, 0, true)
         AVS_TILE_CASE(23, 128, 2048, true, false, 0, true)
+#endif
         AVS_TILE_CASE(24, 512, 4096, true, false, 0, true)
 #undef AVS_TILE_CASE
     default:
@@ -2079,7 +2086,7 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
     // Systems that fit on the chip (<= ~1 M rows, packed single-dictionary form): the rest of the solve in ONE cooperative launch,
     // matrix words in the register files, vector slices in LDS (avs_pcg_resident.inl).  Needs the GPU for itself.
     w->resident_used = 0;
-    if (coded && (da.exclusive_device || getenv("AVS_CG_RESIDENT_CUS")) && resident_wanted(true)) {
+    if (coded && (da.exclusive_device || cur_opt().resident_cus > 0) && resident_wanted(true)) {
         if (!w->resident) w->resident = new (std::nothrow) ResidentPlan();
         if (w->resident && resident_prepare(w->resident, A, w->n_ext, &da, stream)) {
             bool launched = false;
@@ -2098,8 +2105,7 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
                                (const uint16_t *)nullptr, (const PcgScalars *)sc, pvec, da.dd, (const unsigned long long *)da.epoch, da.push_ticket);
         return round(u, 2, (int)OP_SR_STEP, timed ? w->evA[c] : nullptr, timed ? w->evB[c] : nullptr, false);
     };
-    bool use_graph = true;
-    if (const char *e = getenv("AVS_PCG_GRAPH")) use_graph = atoi(e) != 0;
+    bool use_graph = cur_opt().graph != 0;
     int enqueued = 0, last_chunk = 0, spmv_samples = 0;
     double spmv_ms_sum = 0.;
     bool timed_chunk = true;
@@ -2300,7 +2306,11 @@ static avs_status pcg_solve_resident_single(PcgWork *w, const CsrView &A, const 
     if (!launched) return AVS_OK; // (x is untouched: the launch-per-phase loop starts over from it)
     AVS_HIP(hipMemcpyAsync(w->host_sc, sc, sizeof(PcgScalars), hipMemcpyDeviceToHost, stream));
     AVS_HIP(hipStreamSynchronize(stream));
-    if (w->host_sc->fault || getenv("AVS_CG_RESIDENT_FAKE_FAULT")) { // (the variable is the test hook of exactly this path)
+    bool faulted = w->host_sc->fault != 0;
+#ifdef AVS_PROBES
+    if (getenv("AVS_CG_RESIDENT_FAKE_FAULT")) faulted = true; // test hook of exactly this path (probe build only)
+#endif
+    if (faulted) {
         w->resident->ok = false; // not again on this context
         w->resident_faults++;
         AVS_HIP(hipMemcpyAsync(x, w->x_save.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
@@ -2393,9 +2403,9 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
     bool finished = false;
     bool timed_chunk = true;
     bool use_graph = !dist;
-    if (const char *e = getenv("AVS_PCG_GRAPH")) use_graph = use_graph && atoi(e) != 0;
+    use_graph = use_graph && cur_opt().graph != 0;
     bool fuse_beta = !dist; // multi-GPU (RCCL transport): the sums are all-reduced between the two vector kernels
-    if (const char *e = getenv("AVS_PCG_FUSE_BETA")) fuse_beta = fuse_beta && atoi(e) != 0;
+    fuse_beta = fuse_beta && cur_opt().fuse_beta != 0;
     static_assert(kChunk % 2 == 0, "the parity of an iteration is taken from its position in the chunk");
     auto enqueue_iteration = [&](int c, bool timed) -> avs_status {
         int nb = 0;
@@ -2504,6 +2514,7 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
     return AVS_OK;
 }
 
+#ifdef AVS_PROBES
 avs_status spmv_sell_launch(int64_t nslices, const int64_t *slice_ptr, const int32_t *col, const double *val, const double *x, double *y,
                             hipStream_t stream)
 {
@@ -2513,8 +2524,11 @@ avs_status spmv_sell_launch(int64_t nslices, const int64_t *slice_ptr, const int
     return AVS_OK;
 }
 
+#endif
+
 } // namespace avs
 
+#ifdef AVS_PROBES
 extern "C" avs_status avs_spmv_sell(int64_t nslices, const int64_t *slice_ptr, const int32_t *col, const double *val, const double *x,
                                     double *y, int32_t repeats, void *stream, double *ms_per_launch)
 {
@@ -2528,3 +2542,4 @@ extern "C" avs_status avs_spmv_sell(int64_t nslices, const int64_t *slice_ptr, c
     if (ms_per_launch) *ms_per_launch = ms;
     return AVS_OK;
 }
+#endif // AVS_PROBES

@@ -859,9 +859,7 @@ struct ResidentPlan {
 static bool resident_wanted(bool distributed)
 {
     (void)distributed;
-    const char *e = getenv("AVS_CG_RESIDENT");
-    if (e) return atoi(e) != 0;
-    return true; // default for every system that qualifies (plan: 1.5-2 ms per new matrix; AVS_CG_RESIDENT=0 keeps the launch-per-phase loops)
+    return cur_opt().resident != 0; // default for every system that qualifies (plan: 1.5-2 ms per new matrix; AVS_CG_RESIDENT=0 keeps the launch-per-phase loops)
 }
 
 static const void *resident_kernel(int ng, bool streams)
@@ -885,7 +883,7 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
     pl->ok = false;
     memcpy(pl->key, key, sizeof(key));
     pl->key_n = A.n;
-    const bool verbose = getenv("AVS_CG_RESIDENT_VERBOSE") != nullptr;
+    const bool verbose = cur_opt().resident_verbose > 0;
     timespec plan_t0{};
     clock_gettime(CLOCK_MONOTONIC, &plan_t0);
     timespec stage_t = plan_t0;
@@ -911,8 +909,7 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
     }
     const int64_t n = A.n;
     int G = cus;
-    if (const char *e = getenv("AVS_CG_RESIDENT_CUS")) // tests: two ranks on ONE GPU, each on a share of the CUs
-        if (atoi(e) > 0 && atoi(e) < cus) G = atoi(e);
+    if (cur_opt().resident_cus > 0 && cur_opt().resident_cus < cus) G = cur_opt().resident_cus; // tests: two ranks on ONE GPU, each on a share of the CUs
     // Cheap refusals first (before the row pointers cross PCIe and the host walks them: 20-100 ms at 4-7 M rows, per new matrix):
     // every workgroup keeps its slice of u in LDS next to its remote columns (never less than about half as much again)
     if ((size_t)(n / G) * sizeof(double) > (size_t)(160 * 1024) * 65 / 100) return no("the workgroups' slices of u leave no room for their remote columns in the LDS");
@@ -925,8 +922,7 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
     // ---- lanes: consecutive rows, each in ceil(len / 5) of the lane's 15 quads, at most 6 rows; a row of more than 75 words sits
     // alone, the rest of it is read from memory ----
     int max_quads = kResQuads;
-    if (const char *e = getenv("AVS_CG_RESIDENT_MAX_QUADS")) // tests: rows of more than 5 x this many words take the long-row path
-        if (atoi(e) >= 1 && atoi(e) <= kResQuads) max_quads = atoi(e);
+    if (cur_opt().resident_max_quads >= 1 && cur_opt().resident_max_quads <= kResQuads) max_quads = cur_opt().resident_max_quads; // tests: long-row path
     const int W = max_quads * kResQuadWords;
     std::vector<int32_t> lrow;
     std::vector<uint32_t> lmeta;
@@ -988,10 +984,10 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
     stage("lanes (registers only)");
     double stream_T = 0.;
     if (surely_streams || (int64_t)lrow.size() > lane_cap * 93 / 100) {
-        if (getenv("AVS_CG_RESIDENT_NO_STREAM")) return no("too many rows for the register files of this GPU");
+        if (cur_opt().resident_no_stream) return no("too many rows for the register files of this GPU");
         // register quads an average lane holds: measured when the registers-only pass ran, else 12.8 (4-way slab 12.9, 256^3 beam 12.7)
         const double q_lane = surely_streams ? 12.8 : (double)q_total / (double)lrow.size();
-        double Lt = (getenv("AVS_CG_RESIDENT_LANE_FILL") ? atof(getenv("AVS_CG_RESIDENT_LANE_FILL")) : 0.90) * (double)lane_cap;
+        double Lt = cur_opt().resident_lane_fill * (double)lane_cap;
         for (int attempt = 0; attempt < 8; ++attempt, Lt *= 0.97) {
             stream_T = ((double)q_total - Lt * q_lane) / Lt;
             form_lanes(stream_T);
@@ -1024,8 +1020,8 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
     const int cap = stream_T > 0. ? 32768 : 16384; // stride of the per-workgroup source lists (a workgroup with more remote columns does not qualify)
     const int64_t n_ext = n_cols > n ? n_cols : n;
     int64_t chunk_cols = std::min<int64_t>(n_ext, kRemapChunk);
-    if (const char *e = getenv("AVS_CG_RESIDENT_REMAP_CHUNK")) // tests: several bitmap passes on a small system
-        if (atoll(e) >= 512) chunk_cols = std::min<int64_t>(chunk_cols, (atoll(e) + 511) / 512 * 512);
+    if (cur_opt().resident_remap_chunk >= 512) // tests: several bitmap passes on a small system
+        chunk_cols = std::min<int64_t>(chunk_cols, (cur_opt().resident_remap_chunk + 511) / 512 * 512);
     const size_t remap_lds = ((size_t)(((chunk_cols + 31) / 32 + kRemapBlock - 1) / kRemapBlock) * (kRemapBlock + 1) + 2) * sizeof(unsigned);
     DevBuf<int> fail;
     if (pl->wg_row0.alloc((size_t)G + 1) != AVS_OK || pl->rwords.alloc((size_t)A.nnz) != AVS_OK || pl->rem_count.alloc((size_t)G) != AVS_OK ||
@@ -1038,7 +1034,7 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
     // too) only when that fails -- larger slabs (streamed rows: the 2- and 4-way partitions) -- since their vector traffic is back in
     // the update phase (coalesced since the second pass of round 3, which is what makes them worth it).
     int max_ng_limit = 3;
-    if (const char *e = getenv("AVS_CG_RESIDENT_MAX_GLOBAL")) max_ng_limit = atoi(e);
+    max_ng_limit = cur_opt().resident_max_global;
     // Workgroup boundaries by estimated time, not by lanes: the SpMV phase costs per lane (every lane walks its quads), the vector
     // update per row (measured: ~12.7 ns per lane, ~3.6 ns per row of a workgroup) -- workgroups of fine regions have 2x the rows
     // of those in coarse regions at equal lanes.  Then the words are re-encoded (k_resident_remap) and the LDS footprints checked:
@@ -1051,9 +1047,9 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
     // 30.0 / 32.1, 30.4 / 32.3 us per iteration.
     std::vector<int32_t> rc_round0;
     bool round0_done = false, reuse_round0 = false;
-    const double c_rem = getenv("AVS_CG_RESIDENT_REMOTE_COST") ? atof(getenv("AVS_CG_RESIDENT_REMOTE_COST")) : 3.0;
+    const double c_rem = cur_opt().resident_remote_cost;
     const double c_lane = 12.7, c_row = 3.6;
-    const double kStreamCost = getenv("AVS_CG_RESIDENT_STREAM_COST") ? atof(getenv("AVS_CG_RESIDENT_STREAM_COST")) : 1.5;
+    const double kStreamCost = cur_opt().resident_stream_cost;
     int ng = -1, lc_bits = 0, max_cols = 0;
     size_t lds = 0;
     const char *last_reason = "the vector slices + remote columns of a workgroup do not fit the LDS";
@@ -1085,7 +1081,7 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
             --round;
             continue;
         }
-        if (l0 != L || getenv("AVS_CG_RESIDENT_EQUAL_LANES")) {
+        if (l0 != L || cur_opt().resident_equal_lanes) {
             if (reweighted) { give_up = true; break; } // (re-weighting pushed a workgroup past 1024 lanes: give up)
             for (int b = 0; b <= G; ++b) wl[(size_t)b] = (int32_t)std::min<int64_t>((int64_t)b * lpw, L);
         }
@@ -1115,7 +1111,7 @@ static bool resident_prepare(ResidentPlan *pl, const CsrView &A, int64_t n_cols,
             return f ? 1 : 0;
         };
         // (round 0 of a later tier is the split of the first tier's round 0: its counts are re-used, the words re-encoded only if it is accepted)
-        reuse_round0 = round == 0 && round0_done && !getenv("AVS_CG_RESIDENT_EQUAL_LANES");
+        reuse_round0 = round == 0 && round0_done && !cur_opt().resident_equal_lanes;
         if (reuse_round0) rc = rc_round0;
         else {
             const int rm = remap();
@@ -1345,7 +1341,7 @@ static avs_status resident_run(ResidentPlan *pl, const CsrView &A, double *x, do
     // a wait between workgroups of ONE device ends in microseconds unless the cooperative grid is not co-resident in time (a shared
     // GPU): 2 s, then the solve is redone by the launch-per-phase loop in the same call; waits on peers keep the transport's 20 s
     long long ms = da ? 20000 : 2000;
-    if (const char *e = getenv("AVS_DIST_TIMEOUT_MS")) ms = atoll(e) > 0 ? atoll(e) : ms;
+    if (cur_opt().dist_timeout_ms > 0) ms = cur_opt().dist_timeout_ms;
     a.timeout_ticks = (long long)khz * ms;
     a.dd = da ? da->dd : nullptr;
     a.epoch = da ? da->epoch : nullptr;
@@ -1353,10 +1349,9 @@ static avs_status resident_run(ResidentPlan *pl, const CsrView &A, double *x, do
     a.push_seg = pl->push_seg.p;
     a.timers = nullptr;
     a.max_timed = 0;
-    a.coherent_fill = getenv("AVS_CG_RESIDENT_COHERENT_FILL") ? atoi(getenv("AVS_CG_RESIDENT_COHERENT_FILL")) : 1;
-    if (const char *e = getenv("AVS_CG_RESIDENT_TIMERS"))
-        if (atoi(e) > 0) {
-            pl->max_timed = atoi(e) > 4096 ? 4096 : atoi(e);
+    a.coherent_fill = cur_opt().resident_coherent_fill;
+    if (cur_opt().resident_timers > 0) {
+            pl->max_timed = cur_opt().resident_timers > 4096 ? 4096 : cur_opt().resident_timers;
             AVS_TRY(pl->timers.alloc((size_t)pl->max_timed * kResTimers + (size_t)pl->G * 4));
             AVS_HIP(hipMemsetAsync(pl->timers.p, 0, ((size_t)pl->max_timed * kResTimers + (size_t)pl->G * 4) * sizeof(long long), stream));
             a.timers = pl->timers.p;
@@ -1373,7 +1368,7 @@ static avs_status resident_run(ResidentPlan *pl, const CsrView &A, double *x, do
         (void)hipGetLastError();
         pl->ok = false;
         pl->why = std::string("cooperative launch refused: ") + hipGetErrorString(le);
-        if (getenv("AVS_CG_RESIDENT_VERBOSE")) fprintf(stderr, "[avs resident] not used: %s\n", pl->why.c_str());
+        if (cur_opt().resident_verbose > 0) fprintf(stderr, "[avs resident] not used: %s\n", pl->why.c_str());
         return AVS_OK;
     }
     *launched = true;
@@ -1395,7 +1390,7 @@ static avs_status resident_run(ResidentPlan *pl, const CsrView &A, double *x, do
                     sp.push_back((double)(wt[4 * b + 3] - wt[4 * b + 2]) * 1e3 / khz);
                     tot.push_back((double)(wt[4 * b + 3] - first) * 1e3 / khz);
                 }
-            if (!tot.empty() && getenv("AVS_CG_RESIDENT_VERBOSE")) {
+            if (!tot.empty() && cur_opt().resident_verbose > 0) {
                 std::vector<int32_t> wl2((size_t)pl->G + 1), wr2((size_t)pl->G + 1), rc2((size_t)pl->G);
                 (void)hipMemcpy(wl2.data(), pl->wg_lane0.p, wl2.size() * 4, hipMemcpyDeviceToHost);
                 (void)hipMemcpy(wr2.data(), pl->wg_row0.p, wr2.size() * 4, hipMemcpyDeviceToHost);
@@ -1429,7 +1424,7 @@ static avs_status resident_run(ResidentPlan *pl, const CsrView &A, double *x, do
             for (int k = 0; k < 5; ++k) sum[k] += (double)(q[k + 1] - q[k]);
             ++cnt;
         }
-        if (getenv("AVS_CG_RESIDENT_VERBOSE") && atoi(getenv("AVS_CG_RESIDENT_VERBOSE")) >= 2)
+        if (cur_opt().resident_verbose >= 2)
             for (int i = 0; i < pl->max_timed && i < 80; ++i) {
                 const long long *q = t.data() + (size_t)i * kResTimers;
                 double rr, den;

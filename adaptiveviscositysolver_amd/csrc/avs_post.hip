@@ -412,6 +412,7 @@ extern "C" {
 // regularVelocityIndices[axis], cpp:303-329: >= 0 regular DOF, AVS_SOLIDBOUNDARY, else untouched
 avs_status avs_set_regular_index_field(avs_ctx *c, int32_t axis, const int32_t *idx, avs_memspace where)
 {
+    avs::OptScope opt_scope_(c);
     return avs::set_regular_index_lattice(c, axis, idx, where, false);
 }
 
@@ -450,6 +451,7 @@ extern "C" {
 
 avs_status avs_transfer_to_regular_grid(avs_ctx *c, float *out_x, float *out_y, float *out_z, avs_memspace where)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c && out_x && out_y && out_z, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->solved, AVS_ESTATE, "no solution: call avs_solve first");
     AVS_REQUIRE(c->have_ridx[0] && c->have_ridx[1] && c->have_ridx[2], AVS_ESTATE, "regular-grid index fields missing (avs_set_regular_index_field)");
@@ -535,6 +537,7 @@ avs_status avs_transfer_to_regular_grid(avs_ctx *c, float *out_x, float *out_y, 
 // node grids after all passes (parity tests): labels int8, values fp32, (n+1)^3 per level
 avs_status avs_get_node_grid(avs_ctx *c, int32_t level, int8_t *labels, float *vx, float *vy, float *vz, avs_memspace where)
 {
+    avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->post_ready && level >= 0 && level < c->desc.levels, AVS_ESTATE, "call avs_transfer_to_regular_grid first");
     AVS_HIP(hipSetDevice(c->desc.device));

@@ -98,8 +98,7 @@ avs_status build_brick_permutation(avs_ctx *c, int brick_shift)
     AVS_TRY(c->inv.alloc((size_t)n));
     if (n == 0) return AVS_OK;
     // cell-major order inside the bricks while brick id + cell bits fit the 32-bit sort key (AVS_BRICK_INTERLEAVE=0: axis-major, round 2)
-    int interleave = 1;
-    if (const char *e = getenv("AVS_BRICK_INTERLEAVE")) interleave = atoi(e) != 0;
+    int interleave = cur_opt().brick_interleave;
     {
         const uint64_t nb = (uint64_t)((c->desc.nx >> brick_shift) + 1) * ((c->desc.ny >> brick_shift) + 1) * ((c->desc.nz >> brick_shift) + 1);
         if ((nb << (3 * brick_shift)) >= (1ull << 32)) interleave = 0;
@@ -145,7 +144,7 @@ avs_status build_reordered_system(avs_ctx *c, int brick_shift)
     // systems too large for the CU-resident loop: the brick-structured form of the matrix (avs_brick.hip); AVS_BRICK=0 / 1 never / always
     c->brick.clear();
     int want = n >= kBrickMinSystemRows ? 1 : 0;
-    if (const char *e = getenv("AVS_BRICK")) want = atoi(e);
+    if (c->opt.brick >= 0) want = c->opt.brick;
     if (want) AVS_TRY(build_brick_form(c));
     c->brick.view(c->brick_view, c->vi);
     return AVS_OK;
@@ -263,8 +262,7 @@ avs_status build_value_index(const double *val, int64_t nnz, DevBuf<uint16_t> &c
 {
     *table_size = 0;
     if (nnz == 0) return AVS_OK;
-    if (const char *e = getenv("AVS_VALUE_INDEX"))
-        if (atoi(e) == 0) return AVS_OK;
+    if (!cur_opt().value_index) return AVS_OK;
     DevBuf<unsigned long long> slots, keys;
     DevBuf<uint16_t> slot_code;
     DevBuf<int> counters;
@@ -316,8 +314,7 @@ avs_status build_packed_index(const uint16_t *codes, const int32_t *col, int64_t
 {
     *col_bits = 0;
     if (nnz == 0 || table_size <= 0) return AVS_OK;
-    if (const char *e = getenv("AVS_VALUE_PACK"))
-        if (atoi(e) == 0) return AVS_OK;
+    if (!cur_opt().value_pack) return AVS_OK;
     const int cb = bits_for(n_cols), vb = bits_for(table_size);
     if (cb + vb > 32) return AVS_OK;
     AVS_TRY(packed.alloc((size_t)nnz));
@@ -440,8 +437,7 @@ static avs_status build_tile_tables(const int32_t *row_ptr, const double *val, i
 {
     *ok = false;
     if (n == 0 || nnz == 0) return AVS_OK;
-    if (const char *e = getenv("AVS_TILE_TABLES"))
-        if (atoi(e) == 0) return AVS_OK;
+    if (!cur_opt().tile_tables) return AVS_OK;
     const int64_t ntiles = (n + kTltRows - 1) / kTltRows;
     DevBuf<int32_t> tab_len, scan_tmp;
     DevBuf<int> overflow;
@@ -547,8 +543,7 @@ static avs_status build_column_windows(const int32_t *row_ptr, const int32_t *co
 {
     vi.col_windows = false;
     if (n == 0 || nnz == 0 || vi.table_size <= 0) return AVS_OK;
-    if (const char *e = getenv("AVS_COLUMN_WINDOWS"))
-        if (atoi(e) == 0) return AVS_OK;
+    if (!cur_opt().column_windows) return AVS_OK;
     const int64_t ntiles = (n + kTltRows - 1) / kTltRows;
     DevBuf<int> overflow;
     AVS_TRY(overflow.alloc(1));
@@ -575,8 +570,7 @@ avs_status build_matrix_index(const int32_t *row_ptr, const int32_t *col, const 
     static std::atomic<uint64_t> generation{0};
     vi.epoch = ++generation;
     if (nnz == 0) return AVS_OK;
-    if (const char *e = getenv("AVS_VALUE_INDEX"))
-        if (atoi(e) == 0) return AVS_OK;
+    if (!cur_opt().value_index) return AVS_OK;
     int global_size = 0;
     AVS_TRY(build_value_index(val, nnz, vi.codes, vi.table, &global_size, st));
     if (global_size > 0 && global_size <= 2048) { // LDS-resident dictionary (+ packed words when the bits allow)

@@ -23,10 +23,12 @@ class ViscositySolve:
         x = s.solution()                                  # viscositySolution, consumed by cpp:661-707
     """
 
-    def __init__(self, res, dx, dt, levels, use_enhanced_gradients=True, device=0, stream=None, field_res=None, precision=capi.PRECISION_F64):
+    def __init__(self, res, dx, dt, levels, use_enhanced_gradients=True, device=0, stream=None, field_res=None, precision=capi.PRECISION_F64,
+                 probe=False):
         """`res`: octree (power-of-two) level-0 resolution; `field_res`: resolution of the simulation grid the scalar
-        fields live on when HDK_OctreeGrid::init had to pad it (oct.cpp:13-24); None = res."""
-        self.lib = capi.load()
+        fields live on when HDK_OctreeGrid::init had to pad it (oct.cpp:13-24); None = res.  probe=True: the context lives in
+        libavs_probe.so (the same sources + the measurement entries of include/avs_probe.h: bench_spmv ...) -- tools and tests only."""
+        self.lib = capi.load(probe=probe)
         self.res = tuple(int(r) for r in res)
         fr = tuple(int(r) for r in field_res) if field_res is not None else (0, 0, 0)
         d = capi.Desc(self.res[0], self.res[1], self.res[2], float(dx), float(dt), int(levels),
@@ -240,6 +242,9 @@ class ViscositySolve:
         return t
 
     def bench_spmv(self, variant=0, repeats=100):
+        """mean time of one launch of the solver's SpMV (ms); checks y against the plain CSR kernel bit for bit.  Probe library only."""
+        if not hasattr(self.lib, "avs_bench_spmv") or self.lib is not capi.load(probe=True):
+            raise RuntimeError("bench_spmv is a measurement entry of libavs_probe.so: create the solver with probe=True")
         ms = C.c_double()
         capi.check(self.lib.avs_bench_spmv(self.h, variant, repeats, C.byref(ms)))
         return ms.value

@@ -218,7 +218,8 @@ def extra_workload(label, sc, local_rank, tol, max_iters):
            "roofline": (spmv_rates(int(ai.n_velocity), int(ai.nnz), s.matrix_format(), sum(i.spmv_ms for i in infos) / 2)
                         if infos[0].spmv_ms > 0 else None)}
     if infos[0].resident:   # the same workload through the launch-per-phase loop: what the resident loop is worth, and the SpMV roofline
-        os.environ["AVS_CG_RESIDENT"] = "0"
+        from adaptiveviscositysolver_amd import capi as _c
+        s.set_solver_option(_c.OPTION_RESIDENT_LOOP, 0)
         try:
             s.solve(tol, max_iters)
             torch.cuda.synchronize()
@@ -229,7 +230,7 @@ def extra_workload(label, sc, local_rank, tol, max_iters):
             rec["launch_per_phase"] = {"value": sum(i.iterations for i in inf2) / el2, "unit": "iter/s",
                                        "roofline": spmv_rates(int(ai.n_velocity), int(ai.nnz), s.matrix_format(), sum(i.spmv_ms for i in inf2) / 2)}
         finally:
-            os.environ.pop("AVS_CG_RESIDENT", None)
+            s.set_solver_option(_c.OPTION_RESIDENT_LOOP, 1)
     s.close()
     torch.cuda.empty_cache()
     return rec
@@ -379,9 +380,9 @@ def main():
             segments are re-added by the reader and compared with the sender's checksum: a stale entry is a fault, not a slightly
             different field), each checked against the single-GPU solve of the same system: converged, iteration count within 1 %,
             velocity field to 1e-6 relative L2.  All ranks reach the same verdict."""
-            if name:
-                os.environ["AVS_DIST_TRANSPORT"] = name
-            os.environ["AVS_DIST_PARANOID"] = "1"
+            solver.set_solver_option(_capi.OPTION_TRANSPORT, {"": _capi.USE_TRANSPORT_AUTO, "rccl": _capi.USE_TRANSPORT_RCCL,
+                                                              "direct": _capi.USE_TRANSPORT_DIRECT}[name])
+            solver.set_solver_option(_capi.OPTION_PARANOID, 1)
             rec = {"requested": name or "auto", "tol": verify_tol, "solves": []}
             ok = True
             try:
@@ -399,7 +400,7 @@ def main():
                 rec["error"] = str(e)[:300]
                 ok = False
             finally:
-                os.environ.pop("AVS_DIST_PARANOID", None)
+                solver.set_solver_option(_capi.OPTION_PARANOID, 0)
             ok = agree(ok)
             if ok:
                 # The loop that will be TIMED is not the paranoid one (paranoid mode keeps the launch-per-phase loop; without it a rank
@@ -421,7 +422,7 @@ def main():
                         good = False
                     return agree(good)
                 if not timed_mode_ok("timed_mode"):
-                    os.environ["AVS_CG_RESIDENT"] = "0"
+                    solver.set_solver_option(_capi.OPTION_RESIDENT_LOOP, 0)
                     rec["resident_disabled"] = True
                     ok = timed_mode_ok("timed_mode_launch_per_phase")
             rec["ok"] = ok

@@ -169,7 +169,18 @@ avs_status avs_solve(avs_ctx *ctx, double tolerance, int32_t max_iterations, avs
  * AVS_PRECONDITIONER_NONE (1): plain CG, what the build WITHOUT USEEIGEN asks of HDK's UT_SparseMatrixRowT::solveConjugateGradient
  * (cpp:638-642: the preconditioner argument is nullptr).  That routine is closed source: the recurrence is standard CG, the stopping
  * rule used here stays Eigen's (|r|^2 < tol^2 |b|^2), and the result is only pinned to that extent. */
-typedef enum { AVS_OPTION_PRECONDITIONER = 0 } avs_solver_option;
+typedef enum {
+    AVS_OPTION_PRECONDITIONER = 0,
+    AVS_OPTION_RESIDENT_LOOP = 1, /* 1 (default): the CU-resident PCG loop where a system fits the chip; 0: always the launch-per-phase loops */
+    AVS_OPTION_TRANSPORT = 2,     /* multi-GPU: AVS_USE_TRANSPORT_AUTO (direct after its connect-time self-test, else RCCL), _RCCL, _DIRECT */
+    AVS_OPTION_PARANOID = 3,      /* multi-GPU: 1 = every round's halo segments are re-added by the reader and compared with the sender's checksum */
+    AVS_OPTION_GRAPH_REPLAY = 4,  /* 1 (default): chunks of iterations replay a captured hipGraph */
+    AVS_OPTION_BRICK_FORM = 5,    /* brick-structured SpMV form: AVS_BRICK_AUTO (systems of >= 2 M rows), _NEVER, _ALWAYS; takes effect at the next avs_assemble */
+    AVS_OPTION_FUSED_SCALAR_STEPS = 6, /* 1 (default): the CG scalar steps ride in the vector kernels; 0: one reduction launch per step */
+    AVS_OPTION_RELOAD_ENVIRONMENT = 7  /* any value: take the AVS_* environment variables again (they are read once, at avs_create; tools and tests) */
+} avs_solver_option;
+enum { AVS_USE_TRANSPORT_AUTO = 0, AVS_USE_TRANSPORT_RCCL = 1, AVS_USE_TRANSPORT_DIRECT = 2 };
+enum { AVS_BRICK_AUTO = -1, AVS_BRICK_NEVER = 0, AVS_BRICK_ALWAYS = 1 };
 enum { AVS_PRECONDITIONER_JACOBI = 0, AVS_PRECONDITIONER_NONE = 1 };
 avs_status avs_set_solver_option(avs_ctx *ctx, avs_solver_option option, int32_t value);
 
@@ -233,18 +244,7 @@ avs_status avs_pcg_csr(int64_t n, const int32_t *row_ptr, const int32_t *col, co
                        const double *b, double *x_inout, double tolerance, int32_t max_iterations,
                        avs_memspace where, int32_t device, void *stream, avs_solve_info *info);
 
-/* One SpMV y = A x on device-resident CSR (measurement entry: the graded kernel).
- * `variant` selects the kernel (0 = library default).  Enqueues `repeats` launches. */
-avs_status avs_spmv_csr(int64_t n, const int32_t *row_ptr, const int32_t *col, const double *val,
-                        const double *x, double *y, int32_t variant, int32_t repeats, void *stream);
-/* Measurement entry for the SELL-C-sigma experiment (C = 64: one wavefront per slice; BASELINE configs[4]): slice s holds 64
- * consecutive rows column-major, entry j of lane l at slice_ptr[s] + 64 j + l, padded with (col 0, val 0.0); device pointers.
- * y comes out in the slice (sigma-sorted) row order.  tools/sell_experiment.py builds the layout. */
-avs_status avs_spmv_sell(int64_t nslices, const int64_t *slice_ptr, const int32_t *col, const double *val, const double *x,
-                         double *y, int32_t repeats, void *stream, double *ms_per_launch);
-/* SpMV on the system owned by ctx (after avs_assemble), same kernel the solver uses;
- * returns the mean HIP-event time per launch in *ms_per_launch. */
-avs_status avs_bench_spmv(avs_ctx *ctx, int32_t variant, int32_t repeats, double *ms_per_launch);
+/* (measurement / test entries -- single SpMV launches, kernel sweeps, stream probes -- live in include/avs_probe.h and libavs_probe.so) */
 
 /* ------------------------------------------------------------------------------------------
  * Pre-pass on the device (SURVEY 8(f) "next #1/#4"): what solveGasSubclass computes BEFORE the hot
@@ -289,9 +289,6 @@ avs_status avs_prepass_get_weights(avs_prepass *pp, avs_field_kind kind /* CENTE
  * levels == info.levels on the same device (device-to-device copies) */
 avs_status avs_prepass_apply(avs_prepass *pp, avs_ctx *ctx);
 
-/* Measured stream ceilings of the device for the access pattern of the SpMV's matrix stream
- * (mode 0: read-only 16 B/lane, 1: read-only non-temporal, 2: copy); GB/s of bytes moved. */
-avs_status avs_bench_stream(int32_t mode, int64_t bytes, int32_t repeats, int32_t device, double *gbps);
 
 /* dof -> lattice location tables built by the library from the index pyramids:
  * 4 x int32 per DOF = (level | axis << 8, i, j, k).  kind selects velocity / edge / centre. */

@@ -1,11 +1,30 @@
-/* avs_probe.h -- measurement and test entries of libavs_hip.so that are NOT part of the plugin seam (include/avs.h).
- * tools/, tests/ and bench.py's probes bind these; a Houdini host never does. */
+/* avs_probe.h -- measurement and test entries that are NOT part of the plugin seam (include/avs.h).  They are compiled (-DAVS_PROBES) into
+ * libavs_probe.so only -- a superset build of libavs_hip.so from the same sources that also carries the SpMV kernel sweeps, the SELL and
+ * stream probes and the fault-injection hooks (AVS_DIST_INJECT_STALE, AVS_CG_RESIDENT_FAKE_FAULT).  tools/ and the tests that need them
+ * load that library; the product library exports none of this. */
 #ifndef AVS_PROBE_H
 #define AVS_PROBE_H
 #include "avs.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* One SpMV y = A x on device-resident CSR (measurement entry: the graded kernel).
+ * `variant` selects the kernel (0 = library default).  Enqueues `repeats` launches. */
+avs_status avs_spmv_csr(int64_t n, const int32_t *row_ptr, const int32_t *col, const double *val,
+                        const double *x, double *y, int32_t variant, int32_t repeats, void *stream);
+/* Measurement entry for the SELL-C-sigma experiment (C = 64: one wavefront per slice; BASELINE configs[4]): slice s holds 64
+ * consecutive rows column-major, entry j of lane l at slice_ptr[s] + 64 j + l, padded with (col 0, val 0.0); device pointers.
+ * y comes out in the slice (sigma-sorted) row order.  tools/sell_experiment.py builds the layout. */
+avs_status avs_spmv_sell(int64_t nslices, const int64_t *slice_ptr, const int32_t *col, const double *val, const double *x,
+                         double *y, int32_t repeats, void *stream, double *ms_per_launch);
+/* SpMV on the system owned by ctx (after avs_assemble), same kernel the solver uses;
+ * returns the mean HIP-event time per launch in *ms_per_launch. */
+avs_status avs_bench_spmv(avs_ctx *ctx, int32_t variant, int32_t repeats, double *ms_per_launch);
+
+/* Measured stream ceilings of the device for the access pattern of the SpMV's matrix stream
+ * (mode 0: read-only 16 B/lane, 1: read-only non-temporal, 2: copy); GB/s of bytes moved. */
+avs_status avs_bench_stream(int32_t mode, int64_t bytes, int32_t repeats, int32_t device, double *gbps);
 
 /* The brick-structured SpMV form (csrc/avs_brick.hip) as plain device arrays, for a form built OUTSIDE the library
  * (tools/brick_build.py, the reference builder the device builder is tested against). */

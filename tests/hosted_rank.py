@@ -33,7 +33,8 @@ def main():
           "varvisc128": lambda: scenes.fat_beam(128, 4, variable_viscosity=True, device=dev)}[scene]()
     pp = DevicePrepass(sc.res, sc.dx, sc.levels)
     pi = pp.run(sc.liquid, sc.solid)
-    s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels)
+    # the stale-entry injection hook exists in the probe build only
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, probe=bool(os.environ.get("AVS_DIST_INJECT_STALE")))
     pp.apply(s)
     s.set_scene_fields(sc)
     capi.check(s.lib.avs_dist_init_hosted(s.h, rank, world))

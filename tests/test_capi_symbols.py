@@ -20,6 +20,27 @@ def test_header_and_binding_agree():
     assert header_functions() == sorted(capi.EXPORTED_SYMBOLS)
 
 
+def probe_header_functions():
+    src = open(os.path.join(ROOT, "include", "avs_probe.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(avs_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_probe_entries_live_in_the_probe_library_only(built_lib):
+    """include/avs_probe.h (single SpMV launches, kernel sweeps, SELL / stream probes, the brick-form probe) is exported by libavs_probe.so --
+    the -DAVS_PROBES build of the same sources -- and by nothing a plugin links (round-3 review: measurement code shipped in the product)."""
+    assert probe_header_functions() == sorted(capi.PROBE_SYMBOLS)
+    product, probe = ctypes.CDLL(capi.LIB_PATH), ctypes.CDLL(capi.PROBE_LIB_PATH)
+    for name in capi.PROBE_SYMBOLS:
+        assert not hasattr(product, name), f"{name} is exported by the product library"
+        assert hasattr(probe, name), name
+    for name in header_functions():     # the probe build is a superset
+        assert hasattr(probe, name), name
+    import subprocess
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH], text=True)
+    assert "probe" not in syms and "sell" not in syms.lower() and "stream_probe" not in syms
+
+
 def test_library_exports_every_symbol(built_lib):
     raw = ctypes.CDLL(capi.LIB_PATH)
     for name in header_functions():

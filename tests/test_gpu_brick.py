@@ -17,12 +17,12 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 pytestmark = pytest.mark.gpu
 
 
-def _solver(sc, monkeypatch, brick):
+def _solver(sc, monkeypatch, brick, probe=True):
     monkeypatch.setenv("AVS_BRICK", "1" if brick else "0")
     monkeypatch.setenv("AVS_CG_RESIDENT", "0")   # the brick form serves the launch-per-phase loop
     pyr = build_pyramid(sc)
     dsc = scenes.to_device(sc, torch.device("cuda:0"))
-    s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0, probe=probe)   # probe build: avs_bench_spmv / avs_brick_spmv_probe
     feed(s, pyr)
     s.set_scene_fields(dsc)
     return s
@@ -58,7 +58,7 @@ def test_brick_form_is_lossless(name, monkeypatch, built_lib):
 def test_solve_through_the_brick_form(name, monkeypatch, built_lib):
     out = {}
     for brick in (False, True):
-        s = _solver(SCENES[name](), monkeypatch, brick)
+        s = _solver(SCENES[name](), monkeypatch, brick, probe=False)   # the PRODUCT library
         s.assemble()
         assert (s.matrix_format().brick_tiles > 0) == brick
         info = s.solve(tol=1e-9, max_iters=4000)

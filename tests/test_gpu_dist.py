@@ -249,6 +249,7 @@ def test_device_planner_equals_host_planner(world, cut_axis, scene, built_lib, m
         plans = []
         for mode in ("device", "host"):
             monkeypatch.setenv("AVS_DIST_PLAN", mode)
+            s.set_solver_option(capi.OPTION_RELOAD_ENVIRONMENT, 1)   # (the environment is read at avs_create)
             grp = C.c_void_p()
             capi.check(lib.avs_local_group_create(world, C.byref(grp)))
             s.dist_init_local(grp, r)          # planning needs no peer: each rank plans from the replicated system

@@ -59,7 +59,7 @@ def test_full_size_properties(name, built_lib):
     g = torch.Generator(device=dev).manual_seed(11)
     x = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
     y = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
-    ax, ay = spmv(s.lib, rp, col, val, x, 24), spmv(s.lib, rp, col, val, y, 3)
+    ax, ay = spmv(capi.load_probe(), rp, col, val, x, 24), spmv(capi.load_probe(), rp, col, val, y, 3)
     lhs, rhs_ = float(y @ ax), float(x @ ay)
     assert abs(lhs - rhs_) <= 1e-10 * max(abs(lhs), abs(rhs_), 1.0)
     assert float(x @ ax) > 0
@@ -69,7 +69,7 @@ def test_full_size_properties(name, built_lib):
     assert info.converged == 1
     xs = torch.empty(n, dtype=torch.float64, device=dev)
     capi.check(s.lib.avs_get_solution(s.h, xs.data_ptr(), n, capi.MEM_DEVICE))
-    r = rhs - spmv(s.lib, rp, col, val, xs, 3)
+    r = rhs - spmv(capi.load_probe(), rp, col, val, xs, 3)
     rel = float(torch.linalg.norm(r) / torch.linalg.norm(rhs))
     assert rel <= 1.05 * tol and abs(rel - info.error) <= 0.05 * tol
     # idempotence: seam A started from the solution needs no iteration
@@ -262,7 +262,7 @@ def test_config5_thin_sheet_1024_properties(built_lib):
     pp = DevicePrepass(sc.res, sc.dx, sc.levels)
     pi = pp.run(sc.liquid, sc.solid)
     assert pi.levels >= 3                                    # h >= 16 dx so that at least 3 levels appear
-    s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, device=0)
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, device=0, probe=True)   # (bench_spmv below: a probe-library entry)
     pp.apply(s)
     s.set_scene_fields(sc)
     pp.close()
@@ -280,7 +280,7 @@ def test_config5_thin_sheet_1024_properties(built_lib):
     g = torch.Generator(device=dev).manual_seed(5)
     x = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
     y = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
-    ax, ay = spmv(s.lib, rp, col, val, x, 24), spmv(s.lib, rp, col, val, y, 3)
+    ax, ay = spmv(capi.load_probe(), rp, col, val, x, 24), spmv(capi.load_probe(), rp, col, val, y, 3)
     lhs, rhs_ = float(y @ ax), float(x @ ay)
     assert abs(lhs - rhs_) <= 1e-10 * max(abs(lhs), abs(rhs_), 1.0) and float(x @ ax) > 0
     del x, y, ax, ay
@@ -292,7 +292,7 @@ def test_config5_thin_sheet_1024_properties(built_lib):
     assert info6.converged == 1
     xs = torch.empty(n, dtype=torch.float64, device=dev)
     capi.check(s.lib.avs_get_solution(s.h, xs.data_ptr(), n, capi.MEM_DEVICE))
-    r = rhs - spmv(s.lib, rp, col, val, xs, 3)
+    r = rhs - spmv(capi.load_probe(), rp, col, val, xs, 3)
     rel = float(torch.linalg.norm(r) / torch.linalg.norm(rhs))
     assert rel <= 1.05 * tol and abs(rel - info6.error) <= 0.05 * tol
     fmt = s.matrix_format()

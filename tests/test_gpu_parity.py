@@ -145,7 +145,7 @@ def test_spmv_variants(variant, dev, built_lib):
     rng = np.random.default_rng(7)
     x = rng.standard_normal(n)
     want = O.spmv_csr(rp.astype(np.int64), col, val, x)
-    lib = capi.load()
+    lib = capi.load_probe()      # avs_spmv_csr: a measurement entry (include/avs_probe.h)
     t = lambda a: torch.from_numpy(a).to(dev)
     d_rp, d_col, d_val, d_x = t(rp), t(col), t(val), t(x)
     d_y = torch.zeros(n, dtype=torch.float64, device=dev)
@@ -323,7 +323,7 @@ def test_fused_scalar_steps_match_separate_reductions(n0, dev, built_lib, monkey
     s.assemble()
     ref = {}
     for mode in ("0", "1", "0", "1"):
-        monkeypatch.setenv("AVS_PCG_FUSE_BETA", mode)
+        s.set_solver_option(capi.OPTION_FUSED_SCALAR_STEPS, int(mode))
         info = s.solve(1e-9, 5000)
         x = s.solution()
         assert info.converged == 1
@@ -335,7 +335,7 @@ def test_fused_scalar_steps_match_separate_reductions(n0, dev, built_lib, monkey
     for cap in (1, 2, 31, 32, 33, 64, 65):               # stop by the cap: x after exactly `cap` iterations in both loops
         xs = {}
         for mode in ("1", "0"):
-            monkeypatch.setenv("AVS_PCG_FUSE_BETA", mode)
+            s.set_solver_option(capi.OPTION_FUSED_SCALAR_STEPS, int(mode))
             info = s.solve(1e-12, cap)
             assert info.iterations == cap and info.converged == 0
             xs[mode] = s.solution()
@@ -351,7 +351,7 @@ def test_graph_replay_equals_plain_launches(dev, built_lib, monkeypatch):
     s.assemble()
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("AVS_PCG_GRAPH", mode)
+        s.set_solver_option(capi.OPTION_GRAPH_REPLAY, int(mode))
         info = s.solve(1e-9, 5000)
         out[mode] = (info.iterations, s.solution())
     assert out["1"][0] == out["0"][0] and out["1"][0] > 64      # several chunks: the graph really was replayed

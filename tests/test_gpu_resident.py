@@ -54,7 +54,7 @@ def test_resident_single_gpu_solve_matches_oracle(name, resident_env, built_lib)
             assert rel_l2(s.solution(), xo) < 1e-7
     # the same context through the launch-per-phase loop: the two GPU loops agree even closer
     x_res = s.solution()
-    os.environ["AVS_CG_RESIDENT"] = "0"
+    s.set_solver_option(capi.OPTION_RESIDENT_LOOP, 0)
     info2 = s.solve(1e-3, 5000)
     assert info2.resident == 0
     assert rel_l2(s.solution(), x_res) < 1e-2 * 1e-3 * 50   # both within tol of the same solution
@@ -162,7 +162,7 @@ def test_resident_streamed_rows(mode, resident_env, built_lib):
             if tol < 1e-6:
                 assert rel_l2(s.solution(), xo) < 1e-7
         x_res = s.solution()
-        os.environ["AVS_CG_RESIDENT"] = "0"                # the same context through the launch-per-phase loop
+        s.set_solver_option(capi.OPTION_RESIDENT_LOOP, 0)   # the same context through the launch-per-phase loop
         info2 = s.solve(1e-3, 5000)
         assert info2.resident == 0 and rel_l2(s.solution(), x_res) < 5e-4
         s.close()
@@ -190,7 +190,7 @@ def test_resident_plan_follows_a_reassembly(resident_env, built_lib):
     info = s.solve(1e-9, 5000)
     assert info.resident == 1 and info.converged == 1
     x2 = s.solution()
-    os.environ["AVS_CG_RESIDENT"] = "0"
+    s.set_solver_option(capi.OPTION_RESIDENT_LOOP, 0)
     ref = s.solve(1e-9, 5000)
     assert ref.resident == 0 and abs(ref.iterations - info.iterations) <= 2
     assert rel_l2(x2, s.solution()) < 1e-7
@@ -205,7 +205,7 @@ def test_resident_fault_is_redone_by_the_launch_per_phase_loop(resident_env, mon
     sc = scenes.fat_beam(64, 3)
     dsc = scenes.to_device(sc, torch.device("cuda:0"))
     pyr = build_pyramid(dsc)
-    s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0, probe=True)   # (the hook exists in the probe build only)
     feed(s, pyr)
     s.set_scene_fields(dsc)
     s.assemble()

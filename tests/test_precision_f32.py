@@ -110,6 +110,7 @@ def test_gpu_plain_cg_option(name, resident, built_lib):
     o.hot_path()
     old = os.environ.get("AVS_CG_RESIDENT")
     os.environ["AVS_CG_RESIDENT"] = resident
+    s.set_solver_option(capi.OPTION_RESIDENT_LOOP, int(resident))
     try:
         jac = s.solve(1e-9, 8000)
         s.set_solver_option(capi.OPTION_PRECONDITIONER, capi.PRECONDITIONER_NONE)

@@ -28,7 +28,7 @@ fres = getattr(sc, "field_res", None)
 pp = DevicePrepass(sc.res, sc.dx, sc.levels, field_res=fres)
 if fres is not None: sc = scenes.crop_to_field(sc)
 pi = pp.run(sc.liquid, sc.solid)
-s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, field_res=fres)
+s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, field_res=fres, probe=True)
 pp.apply(s); s.set_scene_fields(sc); pp.close()
 res = sc.res
 del sc; torch.cuda.empty_cache()

@@ -35,7 +35,7 @@ if a.torch_prepass:
     torch.cuda.synchronize(); t2 = time.time()
     print(f"scene {t1-t0:.2f}s tensor prepass {t2-t1:.2f}s levels {pyr.levels} nv {pyr.n_velocity} ne {pyr.n_edge} nc {pyr.n_center} "
           f"peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
-    s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0)
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0, probe=True)
     s.set_pyramid(pyr)
     del pyr
 else:
@@ -44,7 +44,7 @@ else:
     torch.cuda.synchronize(); t2 = time.time()
     print(f"scene {t1-t0:.2f}s device prepass {t2-t1:.2f}s (weights {pi.weights_ms:.1f} octree {pi.octree_ms:.1f} classify {pi.classify_ms:.1f} "
           f"numbering {pi.number_ms:.1f} ms) levels {pi.levels} nv {pi.n_velocity} ne {pi.n_edge} nc {pi.n_center}", flush=True)
-    s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, device=0)
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, device=0, probe=True)
     pp.apply(s)
     pp.close()
 s.set_scene_fields(sc)

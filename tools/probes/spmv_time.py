@@ -7,6 +7,6 @@ dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 sc = scenes.fat_beam(n, 4, device=dev)
 pp = DevicePrepass(sc.res, sc.dx, sc.levels); pi = pp.run(sc.liquid, sc.solid)
-s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels); pp.apply(s); s.set_scene_fields(sc); pp.close(); s.assemble()
+s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, probe=True); pp.apply(s); s.set_scene_fields(sc); pp.close(); s.assemble()
 for r in range(3): print("default SpMV us:", s.bench_spmv(0, 200) * 1e3)
 for r in range(3): print("fused-dot SpMV us:", s.bench_spmv(100, 200) * 1e3)

@@ -26,7 +26,7 @@ for name in (sys.argv[1:] or list(CASES)):
     for tol in (1e-3, 1e-10):
         out = {}
         for res in ("0", "1"):
-            os.environ["AVS_CG_RESIDENT"] = res
+            s.set_solver_option(capi.OPTION_RESIDENT_LOOP, int(res))
             s.solve(tol, 5000)
             info = s.solve(tol, 5000)
             out[res] = (info.iterations, info.converged, info.error, info.solve_ms, info.resident, s.solution())

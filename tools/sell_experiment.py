@@ -26,7 +26,7 @@ dev = torch.device("cuda:0")
 sc = scenes.thin_sheet(a.n, a.levels, thickness_cells=32, device=dev) if a.scene == "sheet" else scenes.fat_beam(a.n, a.levels, device=dev)
 pp = DevicePrepass(sc.res, sc.dx, sc.levels)
 pi = pp.run(sc.liquid, sc.solid)
-s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels)
+s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, probe=True)
 pp.apply(s)
 s.set_scene_fields(sc)
 pp.close()

@@ -1,7 +1,7 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from adaptiveviscositysolver_amd import capi
-L = capi.load()
+L = capi.load_probe()
 for mode, name in ((0, "read-only 16B/lane"), (1, "read-only non-temporal"), (2, "copy (read+write)")):
     for gb in (1.5, 4.0):
         g = C.c_double()

@@ -94,7 +94,7 @@ def run(count, seed, quiet=False):
             dsc = scenes.to_device(sc, dev)
             pp = DevicePrepass(sc.res, sc.dx, sc.levels)
             pi = pp.run(dsc.liquid, dsc.solid)
-            s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, use_enhanced_gradients=sc.use_enhanced_gradients, device=0, precision=int(F32))
+            s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, use_enhanced_gradients=sc.use_enhanced_gradients, device=0, precision=int(F32), probe=True)
             pp.apply(s)
             s.set_scene_fields(dsc)
             try:
@@ -114,7 +114,7 @@ def run(count, seed, quiet=False):
         why = []
         ok = pi.levels == o.levels and pi.n_velocity == oc.n
         if not ok: why.append('prepass counts')
-        s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, use_enhanced_gradients=sc.use_enhanced_gradients, device=0, precision=int(F32))
+        s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, use_enhanced_gradients=sc.use_enhanced_gradients, device=0, precision=int(F32), probe=True)
         pp.apply(s)
         s.set_scene_fields(dsc)
         if VERBOSE: print(case, 'device prepass done', pi.levels, pi.n_velocity, flush=True)
@@ -151,6 +151,7 @@ def run(count, seed, quiet=False):
         plans = []
         for mode in ("device", "host"):
             os.environ["AVS_DIST_PLAN"] = mode
+            s.set_solver_option(capi.OPTION_RELOAD_ENVIRONMENT, 1)   # (the environment is read at avs_create)
             g2 = C.c_void_p()
             capi.check(lib.avs_local_group_create(pw, C.byref(g2)))
             s.dist_init_local(g2, pr)
@@ -173,7 +174,7 @@ def run(count, seed, quiet=False):
         capi.check(lib.avs_local_group_create(world, C.byref(grp)))
         ss = []
         for _ in range(world):
-            t = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, use_enhanced_gradients=sc.use_enhanced_gradients, device=0, precision=int(F32))
+            t = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, use_enhanced_gradients=sc.use_enhanced_gradients, device=0, precision=int(F32), probe=True)
             pp.apply(t)
             t.set_scene_fields(dsc)
             ss.append(t)
