@@ -151,6 +151,26 @@ def fat_beam(n, levels, *, variable_viscosity=False, wall=False, device="cpu", d
                  density=density, velocity=vel, name=f"fat_beam_{n}_L{levels}")
 
 
+def tank(n, levels, fill=0.55, wall_cells=2.3, device="cpu", dt=1.0 / 60.0, viscosity=500.0):
+    """An open tank: the liquid fills the domain up to `fill` of its height and touches the domain border on five sides; the collision SDF is
+    the tank itself, `wall_cells` cells thick inside the border (floor + four walls) -- the normal state of a Houdini tank scene: faces on the
+    grid border, ghost faces towards the solid (cpp:1757-1762, 1201-1320)."""
+    res = (n, n, n)
+    dx = 1.0 / n
+    # liquid: the box [-1, 2] x [-1, fill] x [-1, 2] (far beyond the border in x, z and below)
+    liquid = box_sdf(res, dx, (0.5, 0.5 * (fill - 1.0), 0.5), (1.5, 0.5 * (fill + 1.0), 1.5), device)   # negative inside the liquid
+    x, y, z = _axes(res, device)
+    d = wall_cells * dx
+    cx, cy, cz = (x + 0.5) * dx, (y + 0.5) * dx, (z + 0.5) * dx
+    sx = torch.maximum(d - cx, cx - (1.0 - d))[None, None, :]
+    sz = torch.maximum(d - cz, cz - (1.0 - d))[:, None, None]
+    sy = (d - cy)[None, :, None]                          # floor only: the tank is open at the top
+    solid = torch.maximum(torch.maximum(sx, sz), sy).expand(n, n, n).to(torch.float32).contiguous()   # positive inside the solid
+    vel = smooth_velocity(res, dx, gravity_dt=9.80665 * dt, device=device)
+    return Scene(res=res, dx=dx, dt=dt, levels=levels, liquid=liquid.contiguous(), solid=solid, viscosity=viscosity,
+                 density=1000.0, velocity=vel, name=f"tank_{n}_L{levels}")
+
+
 def thin_sheet(n, levels, thickness_cells=16, device="cpu", dt=1.0 / 120.0, viscosity=200.0):
     res = (n, n, n)
     dx = 1.0 / n

@@ -332,6 +332,22 @@ def pcg_csr(row_ptr, col, val, b, x0, tol=1e-3, max_iters=2500, threads=1):
     return x, info
 
 
+def pcg_csr_ex(row_ptr, col, val, b, x0, tol=1e-3, max_iters=2500, spmv_threads=1, vec_threads=1):
+    """Same loop with separate thread counts: (T, 1) = row-parallel SpMV, SERIAL dot products and AXPYs -- the order of additions in every
+    dot product is then independent of the thread count (what Eigen's ConjugateGradient does under OpenMP: only the product is threaded)."""
+    L = lib()
+    L.orc_pcg_csr_ex.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int,
+                                 C.POINTER(PcgInfo)]
+    rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    cl = np.ascontiguousarray(col, dtype=np.int32)
+    vl = np.ascontiguousarray(val, dtype=np.float64)
+    bb = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.array(x0, dtype=np.float64, copy=True)
+    info = PcgInfo()
+    _chk(L.orc_pcg_csr_ex(len(bb), _p(rp), _p(cl), _p(vl), _p(bb), _p(x), tol, max_iters, spmv_threads, vec_threads, C.byref(info)), "pcg_csr_ex")
+    return x, info
+
+
 def spmv_csr(row_ptr, col, val, x, threads=1):
     L = lib()
     rp = np.ascontiguousarray(row_ptr, dtype=np.int64)

@@ -19,6 +19,7 @@ CASES = {
     "beam128_L3": lambda: scenes.fat_beam(128, 3),                      # BASELINE configs[1]
     "beam64_L3_wall_rho_usolid": lambda: scenes.with_sampled_fields(scenes.fat_beam(64, 3, wall=True)),
     "sphere64_obstacle_rho_usolid": lambda: scenes.with_sampled_fields(scenes.sphere_with_obstacle(64, 4)),
+    "tank64_L3_usolid": lambda: scenes.with_sampled_fields(scenes.tank(64, 3)),   # liquid on the domain border, walls as collision SDF
 }
 
 

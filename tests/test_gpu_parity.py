@@ -30,6 +30,10 @@ SCENES = {
     # constant-field scene reaches (round-2 review, weak #2)
     "beam64_wall_rho_usolid": lambda dev: scenes.with_sampled_fields(scenes.fat_beam(64, 3, wall=True, device=dev)),
     "sphere64_obstacle_rho_usolid": lambda dev: scenes.with_sampled_fields(scenes.sphere_with_obstacle(64, 4, device=dev)),
+    # an open TANK: liquid on the domain border on five sides, the collision SDF on the walls and the floor (round-3 review, item 9b):
+    # border faces, ghost faces towards the solid (cpp:1757-1762, 1201-1320), on a power-of-two grid (no padding convention involved)
+    "tank64_L3": lambda dev: scenes.tank(64, 3, device=dev),
+    "tank128_L4_usolid": lambda dev: scenes.with_sampled_fields(scenes.tank(128, 4, device=dev)),
 }
 
 

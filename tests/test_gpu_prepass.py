@@ -18,6 +18,7 @@ CASES = {
     "noncubic": lambda dev: scenes.fat_beam(64, 3, res=(64, 32, 32), device=dev),
     "sheet64": lambda dev: scenes.thin_sheet(64, 3, thickness_cells=12, device=dev),
     "levels_capped": lambda dev: scenes.fat_beam(16, 6, device=dev),
+    "tank64_L3": lambda dev: scenes.tank(64, 3, device=dev),     # liquid on the domain border, collision SDF on the walls
 }
 
 

@@ -20,6 +20,10 @@ CASES = {
     # boundary terms carry u_solid(pos) (cpp:1896-1905, 1952-1960) -- the scatter form must still hold
     "beam32_L3_wall_rho_usolid": lambda: scenes.with_sampled_fields(scenes.fat_beam(32, 3, wall=True)),
     "sphere32_obstacle_rho_usolid": lambda: scenes.with_sampled_fields(scenes.sphere_with_obstacle(32, 3)),
+    # an open TANK: liquid on the domain border on five sides, the collision SDF on the walls and the floor (round-3 review, item 9b):
+    # border faces, ghost faces towards the solid (cpp:1757-1762, 1201-1320), on a power-of-two grid (no padding convention involved)
+    "tank32_L2": lambda: scenes.tank(32, 2),
+    "tank64_L3_usolid": lambda: scenes.with_sampled_fields(scenes.tank(64, 3)),
 }
 
 
