@@ -41,7 +41,7 @@ public:
     // nx, ny, nz: padded octree resolution; fieldRes: the simulation grid the scalar fields live on (oct.cpp:13-24),
     // nullptr = the same
     AdaptiveViscosity(int nx, int ny, int nz, double dx, double dt, int octreeLevels, bool useEnhancedGradients = true,
-                      int device = 0, const int *fieldRes = nullptr)
+                      int device = 0, const int *fieldRes = nullptr, int solveType = AVS_PRECISION_F64)
     {
         avs_desc d{};
         d.nx = nx; d.ny = ny; d.nz = nz;
@@ -51,6 +51,7 @@ public:
         d.use_enhanced_gradients = useEnhancedGradients ? 1 : 0;
         d.device = device;
         d.stream = nullptr;
+        d.precision = solveType; // SolveType of the reference build (util.h:25-37): fpreal64, or fpreal32 under USESINGLEPRECISION
         check(avs_create(&d, &myCtx), "avs_create");
         myLevels = octreeLevels;
     }
@@ -72,6 +73,10 @@ public:
     {
         check(avs_set_scalar_field(myCtx, kind, axis, data, constant, AVS_MEM_HOST), "field");
     }
+
+    // solver switches (avs_set_solver_option): e.g. (AVS_OPTION_PRECONDITIONER, AVS_PRECONDITIONER_NONE) = the build without USEEIGEN
+    // (cpp:633-642); (AVS_OPTION_RESIDENT_LOOP, 0) on a GPU shared with a viewport; (AVS_OPTION_BRICK_FORM, AVS_BRICK_NEVER)
+    void setSolverOption(avs_solver_option option, int value) { check(avs_set_solver_option(myCtx, option, value), "avs_set_solver_option"); }
 
     // ---- hot path ---------------------------------------------------------------------------------
     void buildStressStencils() { check(avs_build_stencils(myCtx), "buildStressStencils"); }

@@ -183,6 +183,30 @@ def spmv_rates(n, nnz, fmt, mean_spmv_ms):
                                         if int(fmt.value_table_size) else "") + (", windowed columns" if int(fmt.column_windows) else "")}
 
 
+def resident_roofline(n, nnz, iterations, solve_ms):
+    """The CU-resident loop has no separate SpMV launch: one cooperative launch runs the whole solve with the matrix words in the
+    register files.  `achieved` is the SURVEY 8(d) figure of ONE iteration's product (12 B per non-zero + row pointers + x + y)
+    over the time of a whole iteration -- an effective rate, the matrix never crosses the HBM pins -- and the counter fractions of
+    the same workload (an EARLIER run: profiles/r04_resident_pmc.json) say what bounds it: waves wait ~0.83 of their cycles
+    (flags, reduction slots, the remote-column fill), the SIMDs issue VALU 0.17-0.19 of the time, HBM moves <= 0.1 of its peak."""
+    alg = 12 * nnz + 4 * (n + 1) + 16 * n
+    t = solve_ms * 1e-3 / max(1, iterations)
+    rec = {"bound": "hbm", "kernel": "k_cg_resident (whole PCG iteration; no separate SpMV launch)", "achieved": alg / t / 1e9 if t > 0 else 0.0,
+           "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (alg / t / 1e9 / HBM_PEAK_GBPS) if t > 0 else 0.0, "traffic": None,
+           "algorithmic_bytes_per_iteration": alg, "us_per_iteration": t * 1e6,
+           "note": "effective rate of a whole iteration (12 B per non-zero by SURVEY 8(d)); the loop is latency-bound, not bandwidth- or issue-bound"}
+    prof = os.path.join(ROOT, "profiles", "r04_resident_pmc.json")
+    try:
+        for w in json.load(open(prof))["workloads"]:
+            if w["n"] == n and w["nnz"] == nnz:
+                rec["traffic"] = w["hbm_bytes_per_iteration_upper"]
+                rec["pmc"] = {k: w[k] for k in ("valu_issue_frac", "wait_frac", "lds_bank_conflict_frac_of_lds_active", "per_wave_per_iteration")}
+                rec["pmc_source"] = "profiles/r04_resident_pmc.json (rocprofv3 --pmc passes of an EARLIER 96-iteration run of this workload, not of this process)"
+    except Exception:
+        pass
+    return rec
+
+
 def extra_workload(label, sc, local_rank, tol, max_iters):
     """One secondary workload through the same product path: pre-pass, assembly (second pass timed), one warm-up solve and two timed
     solves; the numbers the judge otherwise only sees in builder-run lines (round-2 review, weak #5)."""
@@ -216,7 +240,8 @@ def extra_workload(label, sc, local_rank, tol, max_iters):
            "value": iters / el, "unit": "iter/s", "ms_per_step": el / 2 * 1e3, "first_solve_ms": first_solve_ms, "assembly_wall_ms": asm_ms,
            "prepass_ms": pinfo.weights_ms + pinfo.octree_ms + pinfo.classify_ms + pinfo.number_ms,
            "roofline": (spmv_rates(int(ai.n_velocity), int(ai.nnz), s.matrix_format(), sum(i.spmv_ms for i in infos) / 2)
-                        if infos[0].spmv_ms > 0 else None)}
+                        if infos[0].spmv_ms > 0 else
+                        resident_roofline(int(ai.n_velocity), int(ai.nnz), iters // 2, el / 2 * 1e3) if infos[0].resident else None)}
     if infos[0].resident:   # the same workload through the launch-per-phase loop: what the resident loop is worth, and the SpMV roofline
         from adaptiveviscositysolver_amd import capi as _c
         s.set_solver_option(_c.OPTION_RESIDENT_LOOP, 0)
@@ -584,6 +609,8 @@ def main():
             "transfer_to_regular_grid_ms": transfer_ms,
             "end_to_end_ms": (sum(prepass_ms.values()) + assemble_wall_ms + elapsed / a.steps * 1e3 + transfer_ms) if transfer_ms else None,
         }
+        if mean_spmv_ms <= 0 and bool(info.resident) and not use_dist:   # CU-resident loop: no SpMV launch was timed
+            out["roofline"] = resident_roofline(n, nnz, iters_total // a.steps, elapsed / a.steps * 1e3)
         if use_dist:
             out["dist"] = {"per_rank": [dict(zip(("n_own", "n_halo", "nnz_local", "n_send", "n_peers"), r)) for r in per_rank],
                            **solver.dist_comm_info(), "resident_loop": bool(info.resident), "verification": verification}
