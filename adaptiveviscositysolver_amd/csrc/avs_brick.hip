@@ -71,9 +71,18 @@ __device__ __forceinline__ double brick_wave_sum_dpp(double v) // lane 63 holds 
 // i-th streamed row of a tile -> thread: consecutive rows go to different waves (a handful of rows per tile: every wave gets a few lanes)
 __device__ __forceinline__ int brick_srow_of_thread(int tid, int k) { return k * kBrickBlk + ((tid & 63) << 3) + (tid >> 6); }
 
-__device__ __forceinline__ double lds_f64(const double *base, unsigned byte_off)
+// The kernel has no static LDS: the dynamic segment starts at LDS address 0, and a read from a BYTE ADDRESS spares the "+ base" the
+// compiler otherwise leaves in the instruction stream per access (v_add_u32 v, 0, v: one of six VALU instructions per matrix entry).
+typedef const double __attribute__((address_space(3))) *brick_lds_cdp;
+__device__ __forceinline__ double lds_abs_f64(unsigned byte_addr) { return *(brick_lds_cdp)(uintptr_t)byte_addr; }
+constexpr unsigned kBrickValsByte = (unsigned)((kBrickSlotsPad + kBrickPark) * sizeof(double)); // `vals` behind the lattice and `park`
+
+// element `idx` of an array whose base is workgroup-uniform: a 32-bit byte offset in a VGPR + the base in SGPRs (global_load ... saddr)
+// instead of 64-bit address arithmetic per lane
+template <class T>
+__device__ __forceinline__ T ld_u32(const T *base, unsigned idx)
 {
-    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off);
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (size_t)(unsigned)(idx * (unsigned)sizeof(T)));
 }
 
 constexpr int kBrickRu = kBrickMaxRuns / (kBrickBlk / 16);              // halo fill runs per quarter wave
@@ -99,6 +108,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
     double *vals = park + kBrickPark;                                   // table_size + 1 (the last entry is 0.0: padding words), even
     uint32_t *pw = reinterpret_cast<uint32_t *>(vals + ((B.table_size + 2) & ~1)); // kBrickPatWords + 8
     uint32_t *pinfo = pw + kBrickPatWords + 8;                          // kBrickPatMax: local start | quads << 16
+    uint2 *rbt = reinterpret_cast<uint2 *>(pinfo + kBrickPatMax);       // kBrickRowBase entries: a row's bases on the four lattices, per axis
     const uint32_t *bw = reinterpret_cast<const uint32_t *>(park + kBrickXSlots);
     const int tid = threadIdx.x;
     const int lane = tid & 63, l16 = tid & 15, qw = tid >> 4;
@@ -108,9 +118,34 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
     static_assert((kBrickPark - kBrickXSlots) * 2 <= kBrickBlk * 4, "one 16-B load per thread fetches a whole descriptor block");
 
     for (int i = tid; i <= B.table_size; i += kBrickBlk) vals[i] = (i < B.table_size) ? B.table[i] : 0.; // once per workgroup
+    // A row of level lr at local cell (cx, cy, cz) has the byte offset 8 (kBrickLoff[lc] + 3 ((bz S + by) S + bx)) on lattice lc, with
+    // b = ((c >> up) << down) + 1 per axis: the sum of one term per axis.  Table entry (axis d, lr, c + 1) = the four lattices' terms as
+    // 16-bit fields {lattice 0 | lattice 1 << 16, lattice 2 | lattice 3 << 16} (the sums stay below 2^15: no carries between the fields);
+    // the x entries carry the lattice offsets.  Three 8-B LDS reads and four adds per row instead of ~60 VALU instructions.
+    if (tid < kBrickRowBase) {
+        const int d = tid / 40, lr = (tid / 10) & 3, cc = tid % 10 - 1;
+        unsigned f[4];
+#pragma unroll
+        for (int lc = 0; lc < 4; ++lc) {
+            const int up = lc > lr ? lc - lr : 0, dn2 = lr > lc ? lr - lc : 0;
+            const int S = (8 >> lc) + 2;
+            const int b = ((cc >> up) << dn2) + 1;
+            f[lc] = (unsigned)(24 * b * (d == 0 ? 1 : d == 1 ? S : S * S) + (d == 0 ? 8 * kBrickLoff[lc] : 0));
+        }
+        rbt[tid] = uint2{f[0] | (f[1] << 16), f[2] | (f[3] << 16)};
+    }
 
-    int tile = blockIdx.x;
-    if (tile >= B.ntiles) return;
+    // Tile -> workgroup.  Workgroup b runs on XCD b mod 8 (round-robin dispatch); consecutive tiles are neighbouring bricks and read
+    // each other's rows as halo.  Every XCD therefore walks ONE contiguous eighth of the tiles, its workgroups side by side: a halo
+    // value is fetched by one L2 (tile = b + k gridDim: by up to eight).
+    int tile = blockIdx.x, tstep = (int)gridDim.x, tend = B.ntiles;
+    if ((gridDim.x & 7u) == 0u && B.ntiles >= (int)gridDim.x && !BRICK_DBG(32)) {
+        const int c = (int)(blockIdx.x & 7u);
+        tstep = (int)(gridDim.x >> 3);
+        tile = (int)(((int64_t)B.ntiles * c) >> 3) + (int)(blockIdx.x >> 3);
+        tend = (int)(((int64_t)B.ntiles * (c + 1)) >> 3);
+    }
+    if (tile >= tend) return;                                            // (cannot happen: the grid is at most ntiles workgroups)
     const uint4 *blocks16 = reinterpret_cast<const uint4 *>(B.blocks);
     uint2 tb = B.tile_blk[tile];                                         // first 16-B unit, units
     uint4 blk = blocks16[(int64_t)tb.x + (tid < (int)tb.y ? tid : 0)];
@@ -118,6 +153,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
 
     int iter = 0;
     (void)iter;
+    double dot = 0.;                                                     // x.y of this lane's rows, all tiles of the workgroup
     for (;;) {
         BRICK_STAMP(0);
         if (nsw_prev > 0) __syncthreads();                               // the previous tile's streamed sums have read `park`
@@ -147,7 +183,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                 const int nbase = (int)bw[16 + (r >> 27)];
                 const bool on = q < nruns && l16 <= (int)(r & 15u) && !BRICK_DBG(1);
                 rdsc[u] = on ? r : 0xffffffffu;
-                fv[u] = x[on ? (int64_t)nbase + (int)((r >> 16) & 0x7ffu) + l16 : (int64_t)row0];
+                fv[u] = ld_u32(x, (unsigned)(on ? nbase + (int)((r >> 16) & 0x7ffu) + l16 : row0));
             }
         }
         constexpr int RPT = kBrickMaxRows / kBrickBlk;
@@ -159,8 +195,8 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
             os[k] = 0xffffu;
             if (!emode && k * kBrickBlk < nrows) {
                 const int r = tid + k * kBrickBlk;
-                xo[k] = x[(int64_t)row0 + (r < nrows ? r : 0)];
-                const uint32_t o = B.ownslot[(int64_t)row0 + (r < nrows ? r : 0)];
+                xo[k] = ld_u32(x + row0, (unsigned)(r < nrows ? r : 0));
+                const uint32_t o = ld_u32(B.ownslot + row0, (unsigned)(r < nrows ? r : 0));
                 os[k] = r < nrows ? o : 0xffffu;
             }
         }
@@ -177,10 +213,11 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         uint2 rdv[RPT]; // descriptor, position in the tile
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            rdv[k] = uint2{0u, 0u};
+            rdv[k] = uint2{0u, 0xffffffffu};
             if (k * kBrickBlk < nprow) {
                 const int i = tid + k * kBrickBlk;
-                rdv[k] = B.rdesc[rd0 + (i < nprow ? i : 0)];
+                rdv[k] = ld_u32(B.rdesc + rd0, (unsigned)(i < nprow ? i : 0));
+                rdv[k].y = i < nprow ? rdv[k].y : 0xffffffffu;
             }
         }
         const uint32_t pinf = bw[o_pi + (tid < npat ? tid : 0)];
@@ -209,8 +246,8 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
             }
         }
         // the next tile's block address: a scalar load, in flight while this tile's data arrives
-        const int tnext = tile + (int)gridDim.x;
-        const bool more = tnext < B.ntiles;
+        const int tnext = tile + tstep;
+        const bool more = tnext < tend;
         const uint2 tbn = B.tile_blk[more ? tnext : tile];
         // ---- LDS writes
         if (tid < npat) pinfo[tid] = pinf;
@@ -231,7 +268,6 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         // ---- the next tile's block travels while this tile is multiplied (16 B per thread)
         blk = blocks16[(int64_t)tbn.x + (tid < (int)tbn.y ? tid : 0)];
 
-        double dot = 0.;
         if (!emode) {
             // products of the first streamed pass (the block in `park` is dead now)
             if (nsw > 0) {
@@ -242,21 +278,14 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
             if (k * kBrickBlk >= nprow) break;
-            if (tid + k * kBrickBlk < nprow && !BRICK_DBG(2)) {
+            if (rdv[k].y != 0xffffffffu && !BRICK_DBG(2)) {
                 const uint32_t rd = rdv[k].x, ro = rdv[k].y;
                 const unsigned pid = rd >> 20;
                 const int lr = (int)((rd >> 18) & 3u), ax = (int)((rd >> 16) & 3u);
-                const int cx = (int)(rd & 15u) - 1, cy = (int)((rd >> 4) & 15u) - 1, cz = (int)((rd >> 8) & 15u) - 1; // local level-lr cell
-                unsigned b8[4]; // byte offsets of the row's base on the four lattices
-#pragma unroll
-                for (int lc = 0; lc < 4; ++lc) {
-                    const int up = lc > lr ? lc - lr : 0, dn2 = lr > lc ? lr - lc : 0;
-                    const int S = (8 >> lc) + 2;
-                    const int bx = ((cx >> up) << dn2) + 1, by = ((cy >> up) << dn2) + 1, bz = ((cz >> up) << dn2) + 1;
-                    b8[lc] = (unsigned)((kBrickLoff[lc] + ((bz * S + by) * S + bx) * 3) * 8);
-                }
-                const unsigned own8 = (lr == 0 ? b8[0] : lr == 1 ? b8[1] : lr == 2 ? b8[2] : b8[3]) + 8u * (unsigned)ax;
-                const unsigned P01 = (b8[0] & 0xffffu) | (b8[1] << 16), P23 = (b8[2] & 0xffffu) | (b8[3] << 16);
+                const uint2 *rb = rbt + lr * 10;
+                const uint2 tx = rb[rd & 15u], ty = rb[40 + ((rd >> 4) & 15u)], tz = rb[80 + ((rd >> 8) & 15u)];
+                const unsigned P01 = tx.x + ty.x + tz.x, P23 = tx.y + ty.y + tz.y; // byte offsets of the row's base on the four lattices
+                const unsigned own8 = __builtin_amdgcn_perm(P23, P01, (unsigned)lr * 0x0202u + 0x0c0c0100u) + 8u * (unsigned)ax;
                 const unsigned pi = pinfo[pid];
                 const uint4 *wq = reinterpret_cast<const uint4 *>(pw + (pi & 0xffffu));
                 const int nq = (int)((pi >> 16) & 0x7fffu);
@@ -273,16 +302,16 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                     double v0, v1, v2, v3, x0, x1, x2, x3;
                     const uint4 w = wq[0];
                     uint4 wn = wq[1];
-                    v0 = lds_f64(vals, w.x & 0x3ff8u); x0 = lds_f64(xs, adr(w.x));
-                    v1 = lds_f64(vals, w.y & 0x3ff8u); x1 = lds_f64(xs, adr(w.y));
-                    v2 = lds_f64(vals, w.z & 0x3ff8u); x2 = lds_f64(xs, adr(w.z));
-                    v3 = lds_f64(vals, w.w & 0x3ff8u); x3 = lds_f64(xs, adr(w.w));
+                    v0 = lds_abs_f64(kBrickValsByte + (w.x & 0x3ff8u)); x0 = lds_abs_f64(adr(w.x));
+                    v1 = lds_abs_f64(kBrickValsByte + (w.y & 0x3ff8u)); x1 = lds_abs_f64(adr(w.y));
+                    v2 = lds_abs_f64(kBrickValsByte + (w.z & 0x3ff8u)); x2 = lds_abs_f64(adr(w.z));
+                    v3 = lds_abs_f64(kBrickValsByte + (w.w & 0x3ff8u)); x3 = lds_abs_f64(adr(w.w));
                     for (int q = 1; q < nq; ++q) {
                         const uint4 wnn = wq[q + 1];
-                        const double a0 = lds_f64(vals, wn.x & 0x3ff8u), c0 = lds_f64(xs, adr(wn.x));
-                        const double a1 = lds_f64(vals, wn.y & 0x3ff8u), c1 = lds_f64(xs, adr(wn.y));
-                        const double a2 = lds_f64(vals, wn.z & 0x3ff8u), c2 = lds_f64(xs, adr(wn.z));
-                        const double a3 = lds_f64(vals, wn.w & 0x3ff8u), c3 = lds_f64(xs, adr(wn.w));
+                        const double a0 = lds_abs_f64(kBrickValsByte + (wn.x & 0x3ff8u)), c0 = lds_abs_f64(adr(wn.x));
+                        const double a1 = lds_abs_f64(kBrickValsByte + (wn.y & 0x3ff8u)), c1 = lds_abs_f64(adr(wn.y));
+                        const double a2 = lds_abs_f64(kBrickValsByte + (wn.z & 0x3ff8u)), c2 = lds_abs_f64(adr(wn.z));
+                        const double a3 = lds_abs_f64(kBrickValsByte + (wn.w & 0x3ff8u)), c3 = lds_abs_f64(adr(wn.w));
                         sum += v0 * x0;
                         sum += v1 * x1;
                         sum += v2 * x2;
@@ -296,13 +325,13 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                     sum += v3 * x3;
                 };
                 if (pi >> 31) { // every column of the pattern on the level-0 lattice (rows are executed sorted by pattern: waves rarely mix)
-                    const unsigned b0 = b8[0];
+                    const unsigned b0 = P01 & 0xffffu;
                     walk([&](uint32_t w) -> unsigned { return (unsigned)((int)w >> 16) + b0; });
                 } else {
                     walk(addr);
                 }
-                y[(int64_t)row0 + (int)ro] = sum;
-                if (DOT) dot += sum * lds_f64(xs, own8);
+                *reinterpret_cast<double *>(reinterpret_cast<char *>(y + row0) + (size_t)(unsigned)(ro << 3)) = sum;
+                if (DOT) dot += sum * lds_abs_f64(own8);
             }
             }
         }
@@ -349,10 +378,6 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                     if (DOT) dot += ssum[k] * x[row];
                 }
         }
-        if (DOT) {
-            const double dsum = brick_wave_sum_dpp(dot);
-            if (lane == 63) partial[(int64_t)tile * (kBrickBlk / 64) + (tid >> 6)] = dsum;
-        }
         BRICK_STAMP(4);
         if (!more) break;
         ++iter;
@@ -360,11 +385,15 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         tb = tbn;
         nsw_prev = (nsw > 0 && !BRICK_DBG(4)) ? 1 : 0;
     }
+    if (DOT) { // one partial per wave of every WORKGROUP (fixed order: the tile walk is static)
+        const double dsum = brick_wave_sum_dpp(dot);
+        if (lane == 63) partial[(int)blockIdx.x * (kBrickBlk / 64) + (tid >> 6)] = dsum;
+    }
 }
 
 size_t brick_lds_bytes(const BrickView &B)
 {
-    return (size_t)(kBrickSlotsPad + ((B.table_size + 2) & ~1) + kBrickPark) * sizeof(double) + (size_t)(kBrickPatWords + 8 + kBrickPatMax) * sizeof(uint32_t);
+    return (size_t)(kBrickSlotsPad + ((B.table_size + 2) & ~1) + kBrickPark) * sizeof(double) + (size_t)(kBrickPatWords + 8 + kBrickPatMax + 2 * kBrickRowBase) * sizeof(uint32_t);
 }
 
 // persistent grid: as many workgroups as the device keeps resident (queried once per process and device)
@@ -389,6 +418,34 @@ static int brick_grid(const BrickView &B, size_t lds)
     return g < B.ntiles ? g : B.ntiles;
 }
 
+#ifdef AVS_PROBES
+// phase times of the last launch with AVS_BRICK_DEBUG & 16, in 10-ns ticks: mean over workgroups and tiles
+static void brick_print_stamps()
+{
+    std::vector<long long> hs((size_t)kStampWgs * kStampTiles * 8);
+    if (hipMemcpyFromSymbol(hs.data(), HIP_SYMBOL(g_brick_stamps), hs.size() * sizeof(long long)) != hipSuccess) return;
+    double acc[6] = {};
+    long cnt = 0;
+    for (int w = 0; w < kStampWgs; ++w)
+        for (int i = 1; i + 1 < kStampTiles; ++i) {
+            const long long *p = &hs[((size_t)w * kStampTiles + i) * 8], *pn = p + 8;
+            if (!p[0] || !p[4] || !pn[0]) continue;
+            acc[0] += (double)(p[1] - p[0]); acc[1] += (double)(p[2] - p[1]); acc[2] += (double)(p[3] - p[2]);
+            acc[3] += (double)(p[4] - p[3]); acc[4] += (double)(pn[0] - p[4]); acc[5] += (double)(pn[0] - p[0]);
+            ++cnt;
+        }
+    if (cnt)
+        fprintf(stderr, "brick phases (us, mean of %ld tiles): block to LDS + barrier %.2f | issue loads, LDS writes, barrier %.2f | pattern rows %.2f | streamed + dot %.2f | loop %.2f | tile %.2f\n",
+                cnt, acc[0] / cnt / 100, acc[1] / cnt / 100, acc[2] / cnt / 100, acc[3] / cnt / 100, acc[4] / cnt / 100, acc[5] / cnt / 100);
+}
+#endif
+
+// partial sums of x.y the fused-dot launch writes: one per wave of every workgroup of the persistent grid
+int brick_partial_count(const BrickView &B)
+{
+    return B.ntiles > 0 ? brick_grid(B, brick_lds_bytes(B)) * (kBrickBlk / 64) : 0;
+}
+
 avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, double *partial, const int *done_flag, hipStream_t stream)
 {
     if (B.ntiles <= 0) return AVS_OK;
@@ -400,10 +457,24 @@ avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, dou
         attr_set = true;
     }
     const int grid = brick_grid(B, lds);
+#ifdef AVS_PROBES
+    static const int dbg = getenv("AVS_BRICK_DEBUG") ? atoi(getenv("AVS_BRICK_DEBUG")) : 0; // phase switches / stamps (measurement builds only)
+    BrickView Bd = B;
+    Bd.debug |= dbg;
+    if (partial) hipLaunchKernelGGL((k_spmv_brick<true>), dim3(grid), dim3(kBrickBlk), lds, stream, Bd, x, y, partial, done_flag);
+    else hipLaunchKernelGGL((k_spmv_brick<false>), dim3(grid), dim3(kBrickBlk), lds, stream, Bd, x, y, partial, done_flag);
+    AVS_HIP(hipGetLastError());
+    if (Bd.debug & 64) { // print the phase stamps of THIS launch (synchronises: not for timing loops)
+        AVS_HIP(hipStreamSynchronize(stream));
+        brick_print_stamps();
+    }
+    return AVS_OK;
+#else
     if (partial) hipLaunchKernelGGL((k_spmv_brick<true>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
     else hipLaunchKernelGGL((k_spmv_brick<false>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
     AVS_HIP(hipGetLastError());
     return AVS_OK;
+#endif
 }
 
 } // namespace avs
@@ -436,23 +507,7 @@ extern "C" avs_status avs_brick_spmv_probe(const avs_brick_arrays *a, const doub
     for (int i = 0; i < repeats; ++i) AVS_TRY(avs::spmv_brick_launch(B, x, y, partial, nullptr, st));
     const double ms = t.stop() / repeats;
     if (ms_per_launch) *ms_per_launch = ms;
-    if (B.debug & 16) { // phase times of the last launch, in 10-ns ticks: mean over workgroups and tiles
-        std::vector<long long> hs((size_t)avs::kStampWgs * avs::kStampTiles * 8);
-        AVS_HIP(hipMemcpyFromSymbol(hs.data(), HIP_SYMBOL(avs::g_brick_stamps), hs.size() * sizeof(long long)));
-        double acc[6] = {};
-        long cnt = 0;
-        for (int w = 0; w < avs::kStampWgs; ++w)
-            for (int i = 1; i + 1 < avs::kStampTiles; ++i) {
-                const long long *p = &hs[((size_t)w * avs::kStampTiles + i) * 8], *pn = p + 8;
-                if (!p[0] || !p[4] || !pn[0]) continue;
-                acc[0] += (double)(p[1] - p[0]); acc[1] += (double)(p[2] - p[1]); acc[2] += (double)(p[3] - p[2]);
-                acc[3] += (double)(p[4] - p[3]); acc[4] += (double)(pn[0] - p[4]); acc[5] += (double)(pn[0] - p[0]);
-                ++cnt;
-            }
-        if (cnt)
-            fprintf(stderr, "brick phases (us, mean of %ld tiles): block to LDS + barrier %.2f | issue loads, LDS writes, barrier %.2f | pattern rows %.2f | streamed + dot %.2f | loop %.2f | tile %.2f\n",
-                    cnt, acc[0] / cnt / 100, acc[1] / cnt / 100, acc[2] / cnt / 100, acc[3] / cnt / 100, acc[4] / cnt / 100, acc[5] / cnt / 100);
-    }
+    if (B.debug & 16) avs::brick_print_stamps();
     return AVS_OK;
 }
 #endif // AVS_PROBES

@@ -254,7 +254,8 @@ constexpr int kBrickMaxRuns = 320;    // halo fill runs per tile
 constexpr int kBrickXSlots = 160;     // extra x slots per tile behind the lattice (slots 3936 .. 4095: off-lattice columns in the 27 neighbour bricks)
 constexpr int kBrickPatWords = 2560;  // pattern words staged in LDS per tile (10 KiB)
 constexpr int kBrickPark = 1024;      // products of streamed rows parked per pass in a G tile (8 KiB): 52.7 KiB per workgroup, three per CU
-constexpr int kBrickPatMax = 512;     // patterns per tile
+constexpr int kBrickPatMax = 384;     // patterns per tile
+constexpr int kBrickRowBase = 120;    // LDS table of row bases: 3 axes x 4 levels x 10 coordinates
 constexpr int kBrickPatLen = 64;      // longest row stored as a pattern
 constexpr int kBrickTableMax = 2048;  // value dictionary entries (LDS resident)
 constexpr int kBrickMinRows = 64;     // bricks with fewer rows are merged into E tiles
@@ -300,6 +301,7 @@ struct BrickForm {
 };
 size_t brick_lds_bytes(const BrickView &B);
 avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, double *partial, const int *done_flag, hipStream_t stream);
+int brick_partial_count(const BrickView &B);   // partial sums the fused-dot launch writes (one per wave of every persistent workgroup)
 
 // the lossless storage forms of one matrix's values (avs_reorder.hip), owned next to the CSR arrays
 struct ValueIndex {

@@ -1006,7 +1006,7 @@ static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, do
 {
     if (A.n <= 0) { if (nblocks) *nblocks = 0; return AVS_OK; }
     if (A.brick && A.brick->ntiles > 0 && (variant == 0 || variant == spmv_default_variant(A))) { // brick-structured form (avs_brick.hip)
-        if (nblocks) *nblocks = A.brick->ntiles * 8;
+        if (nblocks) *nblocks = brick_partial_count(*A.brick);
         return spmv_brick_launch(*A.brick, x, y, DOT ? partial : nullptr, (DOT && sc) ? &sc->done : nullptr, stream);
     }
     if (A.codes && (variant == 0 || variant == spmv_default_variant(A))) { // value-indexed matrix: 6 or 4 B per non-zero

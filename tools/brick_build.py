@@ -15,7 +15,7 @@ BLOCK_WORDS = 1728
 XSLOT0 = 3936      # first extra slot (off-lattice columns inside the 27 neighbour bricks)
 XSLOTS = 160
 PAT_WORDS = 2560
-PAT_MAX = 512
+PAT_MAX = 384
 PAT_LEN = 64
 MIN_ROWS = 64
 ETILE_ROWS = 256

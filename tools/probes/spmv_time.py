@@ -8,5 +8,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 sc = scenes.fat_beam(n, 4, device=dev)
 pp = DevicePrepass(sc.res, sc.dx, sc.levels); pi = pp.run(sc.liquid, sc.solid)
 s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, probe=True); pp.apply(s); s.set_scene_fields(sc); pp.close(); s.assemble()
-for r in range(3): print("default SpMV us:", s.bench_spmv(0, 200) * 1e3)
-for r in range(3): print("fused-dot SpMV us:", s.bench_spmv(100, 200) * 1e3)
+reps = int(os.environ.get("SPMV_REPEATS", "200"))
+for r in range(3): print("default SpMV us:", s.bench_spmv(0, reps) * 1e3)
+for r in range(3): print("fused-dot SpMV us:", s.bench_spmv(100, reps) * 1e3)
+for r in range(2): print("stream kernel (variant 61) fused-dot us:", s.bench_spmv(61, reps) * 1e3)
+print(s.matrix_format().brick_tiles, "tiles")
