@@ -535,9 +535,10 @@ avs_status avs_set_solver_option(avs_ctx *c, avs_solver_option option, int32_t v
     case AVS_OPTION_BRICK_FORM:
         AVS_REQUIRE(value >= AVS_BRICK_AUTO && value <= AVS_BRICK_ALWAYS, AVS_EINVAL, "brick form must be AUTO, NEVER or ALWAYS");
         c->opt.brick = value;
+        c->brick_verdict_rows = 0; // AUTO measures again at the next assembly
         return AVS_OK;
     case AVS_OPTION_FUSED_SCALAR_STEPS: c->opt.fuse_beta = value != 0; return AVS_OK;
-    case AVS_OPTION_RELOAD_ENVIRONMENT: c->opt = options_from_env(); return AVS_OK;
+    case AVS_OPTION_RELOAD_ENVIRONMENT: c->opt = options_from_env(); c->brick_verdict_rows = 0; return AVS_OK;
     }
     set_error("unknown solver option %d", (int)option);
     return AVS_EINVAL;

@@ -112,7 +112,8 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
     const uint32_t *bw = reinterpret_cast<const uint32_t *>(park + kBrickXSlots);
     const int tid = threadIdx.x;
     const int lane = tid & 63, l16 = tid & 15, qw = tid >> 4;
-    const unsigned cmask = (1u << B.col_bits) - 1u;
+    const bool wide = B.col_bits == 0;                                   // 64-bit streamed words: column | code << 32
+    const unsigned cmask = wide ? 0xffffffffu : (1u << B.col_bits) - 1u;
     const int cbits = B.col_bits;
     constexpr int QW = kBrickBlk / 16;
     static_assert((kBrickPark - kBrickXSlots) * 2 <= kBrickBlk * 4, "one 16-B load per thread fetches a whole descriptor block");
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                 const uint2 t = B.sdesc[srow0 + (i < nsrows ? i : 0)];
                 sd[k] = (i < nsrows) ? t : uint2{0u, 0u};
             }
-            if (!emode) {
+            if (!emode && !wide) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int e = tid + u * kBrickBlk;
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
 
         if (!emode) {
             // products of the first streamed pass (the block in `park` is dead now)
-            if (nsw > 0) {
+            if (nsw > 0 && !wide) {
                 if (tid < nsw && tid < cap) prod[tid] = vals[w0[0] >> cbits] * xv0[0];
                 if (tid + kBrickBlk < nsw && tid + kBrickBlk < cap) prod[tid + kBrickBlk] = vals[w0[1] >> cbits] * xv0[1];
             }
@@ -343,22 +344,31 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
             for (int k = 0; k < kBrickMaxRows / kBrickBlk; ++k) ssum[k] = 0.;
             for (int ts = 0; ts < nsw; ts += cap) {
                 const int te = (ts + cap < nsw) ? ts + cap : nsw;
-                if (emode || ts > 0) {
+                if (emode || wide || ts > 0) {
                     if (ts > 0) __syncthreads(); // the previous pass has been summed
                     for (int e0 = ts + tid; e0 < te; e0 += 4 * kBrickBlk) {
-                        uint32_t w4[4];
+                        uint32_t w4[4], c4[4];
                         double x4[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int e = e0 + u * kBrickBlk;
-                            w4[u] = B.swords[(int64_t)sword0 + (e < te ? e : ts)];
+                            const int64_t at = (int64_t)sword0 + (e < te ? e : ts);
+                            if (wide) {
+                                const uint2 w = reinterpret_cast<const uint2 *>(B.swords)[at];
+                                w4[u] = w.x;
+                                c4[u] = w.y;
+                            } else {
+                                const uint32_t w = B.swords[at];
+                                w4[u] = w & cmask;
+                                c4[u] = w >> cbits;
+                            }
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) x4[u] = x[w4[u] & cmask];
+                        for (int u = 0; u < 4; ++u) x4[u] = x[w4[u]];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int e = e0 + u * kBrickBlk;
-                            if (e < te) prod[e - ts] = vals[w4[u] >> cbits] * x4[u];
+                            if (e < te) prod[e - ts] = vals[c4[u]] * x4[u];
                         }
                     }
                 }

@@ -659,9 +659,13 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
     }
 }
 
-// K7: streamed words tile after tile (sstart = exclusive scan of slen over the rows) + the headers' sword0
+// K7: streamed words tile after tile (sstart = exclusive scan of slen over the rows) + the headers' sword0.  A word is the packed
+// stream's (code << col_bits | column) when code and column share 32 bits, else 64 bits: column | code << 32 (WIDE: matrices of more
+// than 2^(32 - bits(table)) columns -- the 1024^3 thin sheet -- and the unpacked 6-B form).
+template <bool WIDE>
 __global__ __launch_bounds__(kBlk) void k_bk_copy_streamed(int64_t n, const int32_t *__restrict__ slen, const int32_t *__restrict__ sstart,
                                                           const int32_t *__restrict__ row_ptr, const uint32_t *__restrict__ packed,
+                                                          const uint16_t *__restrict__ codes, const int32_t *__restrict__ col,
                                                           uint32_t *__restrict__ swords)
 {
     const int sub = threadIdx.x & 15;
@@ -670,7 +674,10 @@ __global__ __launch_bounds__(kBlk) void k_bk_copy_streamed(int64_t n, const int3
         const int len = slen[r];
         if (!len) continue;
         const int src = row_ptr[r], dst = sstart[r];
-        for (int j = sub; j < len; j += 16) swords[dst + j] = packed[src + j];
+        for (int j = sub; j < len; j += 16) {
+            if (WIDE) reinterpret_cast<uint2 *>(swords)[dst + j] = uint2{(uint32_t)col[src + j], (uint32_t)codes[src + j]};
+            else swords[dst + j] = packed[src + j];
+        }
     }
 }
 __global__ __launch_bounds__(kBlk) void k_bk_patch(int ntiles, const TileInfo *__restrict__ tiles, const int32_t *__restrict__ sstart,
@@ -698,7 +705,7 @@ void BrickForm::clear()
 int64_t BrickForm::stored_bytes(int64_t n) const
 {
     // descriptor blocks (used words), row descriptors 8 B, own slots 2 B per row, streamed words + descriptors, pattern table, tile list
-    return 4 * block_words + 8 * regular_rows + 2 * n + 4 * streamed_words + 8 * streamed_rows + 4 * pattern_words + 8 * (int64_t)ntiles;
+    return 4 * block_words + 8 * regular_rows + 2 * n + (wide ? 8 : 4) * streamed_words + 8 * streamed_rows + 4 * pattern_words + 8 * (int64_t)ntiles;
 }
 
 void BrickForm::view(BrickView &B, const ValueIndex &vi) const
@@ -715,7 +722,7 @@ void BrickForm::view(BrickView &B, const ValueIndex &vi) const
     B.swords = swords.p;
     B.table = vi.table.p;
     B.table_size = vi.table_size;
-    B.col_bits = vi.col_bits;
+    B.col_bits = wide ? 0 : vi.col_bits;   // 0: 64-bit streamed words
 }
 
 // c->p_row_ptr / p_col / vi (codes, packed) / perm / vdof -> c->brick.  Leaves c->brick.ready = false (and AVS_OK) when the matrix does
@@ -726,7 +733,8 @@ avs_status build_brick_form(avs_ctx *c)
     bf.clear();
     const int64_t n = c->n_vel, nnz = c->nnz;
     const ValueIndex &vi = c->vi;
-    if (n <= 0 || !c->reordered || vi.col_bits <= 0 || vi.tile_tables || vi.col_windows) return AVS_OK;
+    if (n <= 0 || !c->reordered || vi.tile_tables || !vi.codes.p) return AVS_OK; // one dictionary; packed, windowed or 6-B columns
+    const bool wide = vi.col_bits <= 0 || vi.col_windows; // no (code << col_bits | column) stream to copy the streamed rows from
     if (vi.table_size <= 0 || vi.table_size + 1 >= kBrickTableMax) return AVS_OK; // (one code is reserved for 0.0)
     if (c->brick_shift != 3 || c->desc.levels < 1) return AVS_OK;
     if (c->desc.nx > 1024 || c->desc.ny > 1024 || c->desc.nz > 1024 || nnz >= (1ll << 31)) return AVS_OK;
@@ -858,8 +866,14 @@ avs_status build_brick_form(avs_ctx *c)
     AVS_HIP(hipMemcpyAsync(&total_sw, S.sstart.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     AVS_HIP(hipMemcpyAsync(&regular, S.total.p, sizeof(regular), hipMemcpyDeviceToHost, st));
     AVS_HIP(hipStreamSynchronize(st));
-    AVS_TRY(bf.swords.alloc((size_t)total_sw + 16));
-    hipLaunchKernelGGL(k_bk_copy_streamed, dim3(4096), dim3(kBlk), 0, st, n, S.slen.p, S.sstart.p, c->p_row_ptr.p, vi.packed.p, bf.swords.p);
+    bf.wide = wide;
+    AVS_TRY(bf.swords.alloc(((size_t)total_sw + 16) * (wide ? 2 : 1)));
+    if (wide)
+        hipLaunchKernelGGL(k_bk_copy_streamed<true>, dim3(4096), dim3(kBlk), 0, st, n, S.slen.p, S.sstart.p, c->p_row_ptr.p, (const uint32_t *)nullptr,
+                           vi.codes.p, c->p_col.p, bf.swords.p);
+    else
+        hipLaunchKernelGGL(k_bk_copy_streamed<false>, dim3(4096), dim3(kBlk), 0, st, n, S.slen.p, S.sstart.p, c->p_row_ptr.p, vi.packed.p,
+                           (const uint16_t *)nullptr, (const int32_t *)nullptr, bf.swords.p);
     hipLaunchKernelGGL(k_bk_patch, dim3((unsigned)((ntiles + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, ntiles, dtiles, S.sstart.p, bf.blocks.p);
     AVS_HIP(hipGetLastError());
     lap("K7 streamed");

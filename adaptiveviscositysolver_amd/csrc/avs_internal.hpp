@@ -270,7 +270,7 @@ struct BrickView {
     const uint32_t *pwords = nullptr; // pattern words: delta << 19 (signed 13 bits) | lattice level << 14 | value code << 3; a pattern is
                                       // padded to quads with its first entry's slot and the code of 0.0 (= table_size)
     const uint2 *sdesc = nullptr;     // streamed rows: local row | len << 16, first word relative to the tile's sword0
-    const uint32_t *swords = nullptr; // code << col_bits | column, CSR order
+    const uint32_t *swords = nullptr; // code << col_bits | column, CSR order; col_bits == 0: 64-bit words column | code << 32
     const double *table = nullptr;
     int table_size = 0, col_bits = 0;
     int debug = 0; // measurement only: 1 no fill, 2 no pattern rows, 4 no streamed rows (wrong results), 16 phase stamps
@@ -295,6 +295,7 @@ struct BrickForm {
     int ntiles = 0, patterns = 0;
     int64_t regular_rows = 0, streamed_words = 0, block_words = 0, pattern_words = 0, streamed_rows = 0;
     bool ready = false;
+    bool wide = false;    // streamed words are 64 bits (column | code << 32)
     void clear();
     void view(BrickView &B, const ValueIndex &vi) const;
     int64_t stored_bytes(int64_t n) const; // what one SpMV launch reads of the matrix
@@ -519,6 +520,11 @@ struct avs_ctx {
     avs::ValueIndex vi;
     avs::BrickForm brick;   // brick-structured form of the solve matrix (large single-dictionary systems)
     avs::BrickView brick_view;
+    // AVS_BRICK_AUTO: brick form or word stream, whichever multiplied faster when a matrix of (about) this size was first seen
+    int brick_verdict = 0;
+    int64_t brick_verdict_rows = 0;
+    double brick_tune_ms[2] = {0., 0.};   // stream, brick (ms per launch at the measurement)
+    avs::DevBuf<double> brick_tune_y;
     bool reordered = false;
     int brick_shift = 3; // 8^3 fine cells per brick; < 0 disables the renumbering
     avs_assembly_info ainfo{};

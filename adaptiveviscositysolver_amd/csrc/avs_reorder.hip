@@ -145,8 +145,44 @@ avs_status build_reordered_system(avs_ctx *c, int brick_shift)
     c->brick.clear();
     int want = n >= kBrickMinSystemRows ? 1 : 0;
     if (c->opt.brick >= 0) want = c->opt.brick;
+    // AUTO: the form is kept only where it is FASTER than the word stream on this matrix.  That is measured (a fat volume with ~490 rows
+    // per shell brick: 0.7x the stream's time; a thin sheet with ~340: 1.2x), once per context and matrix size: a simulation's next
+    // frames reuse the verdict (and do not build a form that lost) until the row count has moved by more than 10 %.
+    const bool autosel = c->opt.brick < 0 && want;
+    const bool cached = autosel && c->brick_verdict_rows > 0 && std::llabs(n - c->brick_verdict_rows) * 10 <= c->brick_verdict_rows;
+    if (cached && !c->brick_verdict) want = 0;
     if (want) AVS_TRY(build_brick_form(c));
     c->brick.view(c->brick_view, c->vi);
+    if (autosel && c->brick.ready && !cached) {
+        AVS_TRY(c->brick_tune_y.reserve((size_t)n));
+        CsrView A;
+        A.n = n;
+        A.nnz = nnz;
+        A.row_ptr = c->p_row_ptr.p;
+        A.col = c->p_col.p;
+        A.val = c->p_val.p;
+        c->vi.apply(A);
+        double ms[2] = {0., 0.};
+        for (int form = 0; form < 2; ++form) {
+            auto launch = [&]() -> avs_status {
+                return form ? spmv_brick_launch(c->brick_view, c->p_x0.p, c->brick_tune_y.p, nullptr, nullptr, st)
+                            : spmv_launch(A, c->p_x0.p, c->brick_tune_y.p, 0, st);
+            };
+            AVS_TRY(launch()); // (first touch, kernel load)
+            Timer t(st);
+            t.start();
+            for (int r = 0; r < 3; ++r) AVS_TRY(launch());
+            ms[form] = t.stop() / 3;
+        }
+        c->brick_verdict = ms[1] < 0.92 * ms[0] ? 1 : 0;
+        c->brick_verdict_rows = n;
+        c->brick_tune_ms[0] = ms[0];
+        c->brick_tune_ms[1] = ms[1];
+    }
+    if (autosel && c->brick.ready && !c->brick_verdict) { // the word stream is the faster form for this matrix
+        c->brick.clear();
+        c->brick.view(c->brick_view, c->vi);
+    }
     return AVS_OK;
 }
 

@@ -54,6 +54,26 @@ def test_brick_form_is_lossless(name, monkeypatch, built_lib):
     s.close()
 
 
+@pytest.mark.parametrize("env", [{"AVS_VALUE_PACK": "0"},                                   # -> windowed columns, the 1024^3 sheet's form
+                                 {"AVS_VALUE_PACK": "0", "AVS_COLUMN_WINDOWS": "0"}])      # -> 6-B form (2-B code + int32 column)
+@pytest.mark.parametrize("name", ["beam128_L4", "sheet128_L4"])
+def test_brick_form_with_wide_streamed_words(name, env, monkeypatch, built_lib):
+    """matrices whose code and column do not share 32 bits (the 1024^3 thin sheet: 25 + 8 bits) keep their streamed rows as 64-bit words
+    (column | code << 32); forced here on small systems by switching the packed form off"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    s = _solver(SCENES[name](), monkeypatch, True)
+    ai = s.assemble()
+    fmt = s.matrix_format()
+    assert fmt.column_bits == 0, "the packed form was not switched off"
+    assert fmt.brick_tiles > 0 and fmt.brick_pattern_rows >= 0.6 * ai.n_velocity
+    s.bench_spmv(0, 3)
+    s.bench_spmv(100, 3)
+    info = s.solve(tol=1e-9, max_iters=4000)
+    assert info.converged
+    s.close()
+
+
 @pytest.mark.parametrize("name", ["beam128_L4", "beam64_L3_wall", "sheet128_L4"])
 def test_solve_through_the_brick_form(name, monkeypatch, built_lib):
     out = {}
@@ -110,3 +130,32 @@ def test_reference_builder_and_device_builder_agree(monkeypatch, built_lib):
     torch.cuda.synchronize()
     assert int((y.view(torch.int64) != yref.view(torch.int64)).sum()) == 0
     s.close()
+
+
+def test_auto_mode_keeps_the_faster_form(monkeypatch, built_lib):
+    """AVS_BRICK_AUTO (the default) measures both forms at the first assembly of a matrix size and keeps the faster: the brick form on
+    the fat 512^3 beam (~490 rows per shell brick: 0.7x the word stream's time), the word stream on a thin sheet (~340 rows per brick:
+    1.2x) -- and a sheet's later assemblies do not build the form again"""
+    from adaptiveviscositysolver_amd import DevicePrepass
+    monkeypatch.delenv("AVS_BRICK", raising=False)
+    dev = torch.device("cuda:0")
+    for make, brick in ((lambda: scenes.fat_beam(512, 4, device=dev), True), (lambda: scenes.thin_sheet(512, 4, thickness_cells=32, device=dev), False)):
+        sc = make()
+        pp = DevicePrepass(sc.res, sc.dx, sc.levels)
+        pi = pp.run(sc.liquid, sc.solid)
+        s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, device=0, probe=True)
+        pp.apply(s); s.set_scene_fields(sc); pp.close()
+        del sc
+        torch.cuda.empty_cache()
+        for _ in range(2):
+            ai = s.assemble()
+            fmt = s.matrix_format()
+            assert ai.n_velocity >= 2_000_000
+            assert (fmt.brick_tiles > 0) == brick, (fmt.brick_tiles, brick)
+        s.bench_spmv(100, 2)   # bit-identical to plain CSR either way
+        s.set_solver_option(capi.OPTION_BRICK_FORM, capi.BRICK_ALWAYS)
+        s.assemble()
+        assert s.matrix_format().brick_tiles > 0
+        s.bench_spmv(100, 2)
+        s.close()
+        torch.cuda.empty_cache()

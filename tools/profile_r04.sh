@@ -7,14 +7,17 @@ cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && O=$R/gpurun_out/r04prof &
 TAG=${1:-r04}
 stats() { name=$1; shift; timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$name -o $TAG -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra "$@" > $O/stats_$name.log 2>&1; echo "stats $name rc=$?"; rm -f $O/stats_$name/*/*kernel_trace.csv $O/stats_$name/*kernel_trace.csv; }
 stats uniform
+if [ "${2:-all}" = "all" ]; then
 stats beam --scene beam
 stats buckling --scene buckling
+fi
 pmc() { name=$1; re=$2; shift; shift; timeout 400 rocprofv3 --kernel-include-regex "$re" --pmc "$@" --output-format csv -d $O/pmc_$name -o p -- python $R/bench.py --steps 1 --warmup 0 --max-iters 96 --no-cpu-baseline --no-extra $EXTRA > $O/pmc_$name.log 2>&1; echo "pmc $name rc=$?"; }
 EXTRA=""
 pmc fetch "spmv|k_update_r" FETCH_SIZE
 pmc write "spmv|k_update_r" WRITE_SIZE
 pmc sq_a "spmv_brick" SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS
 pmc sq_b "spmv_brick" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS
+if [ "${2:-all}" = "all" ]; then
 EXTRA="--scene buckling"
 pmc res_a "cg_resident" SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS
 pmc res_b "cg_resident" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS
@@ -25,6 +28,7 @@ pmc resb_a "cg_resident" SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
 pmc resb_b "cg_resident" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS
 pmc resb_fetch "cg_resident" FETCH_SIZE
 pmc resb_write "cg_resident" WRITE_SIZE
+fi
 cd $R && python - <<'PY'
 import csv, collections, glob, json, os
 out = {}
