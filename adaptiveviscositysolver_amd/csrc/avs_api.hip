@@ -786,10 +786,26 @@ avs_status avs_bench_spmv(avs_ctx *c, int32_t variant, int32_t repeats, double *
     DevBuf<double> partial;
     if (dot) AVS_TRY(partial.alloc(spmv_partial_elems(n)));
     AVS_TRY(dot ? spmv_dot_launch(A, xin, y.p, partial.p, variant, c->stream) : spmv_launch(A, xin, y.p, variant, c->stream)); // warm-up
-    t.start();
-    for (int i = 0; i < repeats; ++i)
-        AVS_TRY(dot ? spmv_dot_launch(A, xin, y.p, partial.p, variant, c->stream) : spmv_launch(A, xin, y.p, variant, c->stream));
-    *ms_per_launch = t.stop() / repeats;
+    const char *thrash = getenv("AVS_BENCH_THRASH_MB"); // > 0: that many MB are overwritten between the launches (a COLD launch, as
+                                                         // inside the PCG loop, whose vector kernels move ~0.6 GB between two products)
+    if (thrash && atoi(thrash) > 0) {
+        DevBuf<char> junk;
+        const size_t jb = (size_t)atoi(thrash) << 20;
+        AVS_TRY(junk.alloc(jb));
+        double acc = 0.;
+        for (int i = 0; i < repeats; ++i) {
+            AVS_HIP(hipMemsetAsync(junk.p, i & 0xff, jb, c->stream));
+            t.start();
+            AVS_TRY(dot ? spmv_dot_launch(A, xin, y.p, partial.p, variant, c->stream) : spmv_launch(A, xin, y.p, variant, c->stream));
+            acc += t.stop();
+        }
+        *ms_per_launch = acc / repeats;
+    } else {
+        t.start();
+        for (int i = 0; i < repeats; ++i)
+            AVS_TRY(dot ? spmv_dot_launch(A, xin, y.p, partial.p, variant, c->stream) : spmv_launch(A, xin, y.p, variant, c->stream));
+        *ms_per_launch = t.stop() / repeats;
+    }
     // every variant must reproduce the plain 12-B CSR kernel bit for bit (same products, same left-to-right row sums)
     if (n > 0) {
         DevBuf<double> yref;

@@ -145,6 +145,12 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         tstep = (int)(gridDim.x >> 3);
         tile = (int)(((int64_t)B.ntiles * c) >> 3) + (int)(blockIdx.x >> 3);
         tend = (int)(((int64_t)B.ntiles * (c + 1)) >> 3);
+        if (BRICK_DBG(128)) { // experiment: every workgroup walks CONSECUTIVE tiles (its own contiguous share of the XCD's range)
+            const int t0 = (int)(((int64_t)B.ntiles * c) >> 3), cnt = tend - t0, s = (int)(blockIdx.x >> 3);
+            tile = t0 + (int)(((int64_t)cnt * s) / tstep);
+            tend = t0 + (int)(((int64_t)cnt * (s + 1)) / tstep);
+            tstep = 1;
+        }
     }
     if (tile >= tend) return;                                            // (cannot happen: the grid is at most ntiles workgroups)
     const uint4 *blocks16 = reinterpret_cast<const uint4 *>(B.blocks);
