@@ -451,6 +451,35 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
         }
     __syncthreads();
     const int nlist = counters[0];
+    // The list order above is the order of arrival (atomics): make it CANONICAL -- patterns ordered by the first row of the tile that uses
+    // them -- so that which patterns are kept, the local pattern numbers, the execution order of the rows and with it the lane that sums
+    // a row's share of p.Ap are the same in every build of the same matrix (y never depended on it; the solver's iteration counts did).
+    for (int i = tid; i < nlist; i += kTileBlk) pstart[i] = 0x7fffffff;
+    __syncthreads();
+    if (gtile)
+        for (int k = 0; k < 2; ++k) {
+            const int pid = my_pid[k];
+            if (pid < 0) continue;
+            unsigned h = ((unsigned)pid * 2654435761u) >> 22;
+            while (pkey[h] != pid) h = (h + 1) & 1023u;
+            atomicMin(&pstart[pidx[h]], tid + k * kTileBlk);
+        }
+    __syncthreads();
+    for (int i = tid; i < nlist; i += kTileBlk) {
+        const int m = pstart[i];
+        int rk = 0;
+        for (int j = 0; j < nlist; ++j) rk += pstart[j] < m ? 1 : 0;
+        plen4[i] = rk;                                   // canonical index of list entry i
+        skey[rk] = (unsigned)plist[i];
+    }
+    __syncthreads();
+    for (int h = tid; h < 1024; h += kTileBlk)
+        if (pkey[h] != -1) pidx[h] = plen4[pidx[h]];
+    __syncthreads();
+    for (int i = tid; i < nlist; i += kTileBlk) plist[i] = (int)skey[i];
+    __syncthreads();
+    for (int i = tid; i < nlist; i += kTileBlk) skey[i] = 0xffffffffu;
+    __syncthreads();
     for (int i = tid; i < nlist; i += kTileBlk) {
         const int q = pat_rep[plist[i]];
         plen4[i] = (row_ptr[q + 1] - row_ptr[q] + 3) & ~3;

@@ -1283,11 +1283,13 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, double *__restri
         }
     } else alpha = sc->alpha;
     double rr = 0., rz = 0.;
+    // t = A p is read for the last time here and r is next read one kernel later: the streams that nobody reads again before they
+    // are overwritten are loaded / stored NON-TEMPORALLY, so that they do not push the matrix out of the caches between two products
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const double ri = r[i] - alpha * t[i];
+        const double ri = r[i] - alpha * __builtin_nontemporal_load(t + i);
         r[i] = ri;
         rr += ri * ri;
-        rz += ri * ((CODED ? invd[dcode[i]] : invd[i]) * ri);
+        rz += ri * ((CODED ? invd[__builtin_nontemporal_load(dcode + i)] : invd[i]) * ri);
     }
     rr = block_sum(rr, red);
     rz = block_sum(rz, red);
@@ -1351,8 +1353,8 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, double *__restr
     }
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const double pi = p[i];
-        x[i] += alpha * pi;
-        p[i] = (CODED ? invd[dcode[i]] : invd[i]) * r[i] + beta * pi;
+        __builtin_nontemporal_store(__builtin_nontemporal_load(x + i) + alpha * pi, x + i); // (x is touched once per iteration)
+        p[i] = (CODED ? invd[__builtin_nontemporal_load(dcode + i)] : invd[i]) * __builtin_nontemporal_load(r + i) + beta * pi;
     }
 }
 

@@ -159,3 +159,19 @@ def test_auto_mode_keeps_the_faster_form(monkeypatch, built_lib):
         s.bench_spmv(100, 2)
         s.close()
         torch.cuda.empty_cache()
+
+
+def test_brick_form_is_reproducible(monkeypatch, built_lib):
+    """the builder assigns global pattern numbers with atomics; everything the arithmetic order depends on (a tile's local pattern numbers,
+    the execution order of its rows, hence which lane adds a row's share of p.Ap) is canonical: two builds of the same matrix give the same
+    iteration count and the same solution bit for bit"""
+    got = []
+    for _ in range(3):
+        s = _solver(SCENES["beam128_L4"](), monkeypatch, True, probe=False)
+        s.assemble()
+        assert s.matrix_format().brick_tiles > 0
+        info = s.solve(tol=1e-9, max_iters=4000)
+        got.append((info.iterations, np.asarray(s.solution()).tobytes()))
+        s.close()
+    assert got[0][0] == got[1][0] == got[2][0]
+    assert got[0][1] == got[1][1] == got[2][1]
