@@ -239,6 +239,7 @@ struct CsrView {
     // re-encoding) are keyed on it -- a re-assembly may rewrite the same buffers
     uint64_t epoch = 0;
     int no_precond = 0; // AVS_PRECONDITIONER_NONE: the inverse diagonal the loops multiply with is 1 everywhere
+    bool keep_cached = false; // the matrix words are small enough to stay in the Infinity Cache between two products: plain loads
     const struct BrickView *brick = nullptr; // host pointer: the brick-structured form of this matrix (single-GPU launch-per-phase loop)
 };
 constexpr int kCwinOffBits = 14, kCwinSlotBits = 6, kCwinSlots = 1 << kCwinSlotBits, kCwinCodeBits = 32 - kCwinOffBits - kCwinSlotBits;
@@ -305,6 +306,7 @@ avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, dou
 int brick_partial_count(const BrickView &B);   // partial sums the fused-dot launch writes (one per wave of every persistent workgroup)
 
 // the lossless storage forms of one matrix's values (avs_reorder.hip), owned next to the CSR arrays
+constexpr int64_t kKeepCachedBytes = 200ll << 20; // what may stay in the 256 MB Infinity Cache across a PCG iteration
 struct ValueIndex {
     DevBuf<uint16_t> codes;
     DevBuf<double> table;
@@ -327,6 +329,7 @@ struct ValueIndex {
         if (col_bits > 0) { A.packed = packed.p; A.col_bits = col_bits; }
         if (tile_tables) A.tab_ptr = tab_ptr.p;
         if (col_windows) { A.packed = packed.p; A.cbase = cbase.p; A.col_bits = 0; }
+        A.keep_cached = (int64_t)bytes_per_nonzero() * A.nnz + 40 * A.n <= kKeepCachedBytes; // words + the five vectors of an iteration
     }
 };
 // picks the most compact lossless form that fits: one dictionary of <= 2048 values (LDS-resident; packed 4-B words when the

@@ -491,6 +491,14 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(CsrView A, const double 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef int i2_t __attribute__((ext_vector_type(2)));
 
+// matrix words of the value-indexed kernels: non-temporal when the matrix is larger than the caches can hold between two products (the
+// read-once stream must not evict x from L2), plain when it may stay in the 256 MB Infinity Cache from one iteration to the next
+template <typename T>
+__device__ __forceinline__ T stream_load_rt(const T *p, bool keep)
+{
+    if (keep) return *p;
+    return __builtin_nontemporal_load(p);
+}
 template <bool NT, typename T>
 __device__ __forceinline__ T stream_load(const T *p)
 {
@@ -756,11 +764,11 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
             cn[u] = i4_t{0, 0, 0, 0};
             if (kk < te4) {
                 if (WORDS) {
-                    qn[u] = stream_load<true>(reinterpret_cast<const u4_t *>(A.packed + kk));
+                    qn[u] = stream_load_rt(reinterpret_cast<const u4_t *>(A.packed + kk), A.keep_cached);
                 } else {
-                    const us4_t h = stream_load<true>(reinterpret_cast<const us4_t *>(A.codes + kk));
+                    const us4_t h = stream_load_rt(reinterpret_cast<const us4_t *>(A.codes + kk), A.keep_cached);
                     qn[u] = u4_t{h.x, h.y, h.z, h.w};
-                    cn[u] = stream_load<true>(reinterpret_cast<const i4_t *>(A.col + kk));
+                    cn[u] = stream_load_rt(reinterpret_cast<const i4_t *>(A.col + kk), A.keep_cached);
                 }
             }
         }
@@ -1259,7 +1267,7 @@ template <bool CODED, bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, double *__restrict__ r, const double *__restrict__ t,
                                                      const double *__restrict__ invd, const uint16_t *__restrict__ dcode,
                                                      PcgScalars *sc, double *__restrict__ partial,
-                                                     const double *__restrict__ spmv_partial = nullptr, int nb = 0, int parity = 0)
+                                                     const double *__restrict__ spmv_partial = nullptr, int nb = 0, int parity = 0, int keep = 0)
 {
     if (sc->done) {
         if (FUSED && blockIdx.x == 0 && threadIdx.x == 0 && sc->done == 2) sc->done = 1; // the pending x update has run (OP_ALPHA)
@@ -1285,11 +1293,12 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, double *__restri
     double rr = 0., rz = 0.;
     // t = A p is read for the last time here and r is next read one kernel later: the streams that nobody reads again before they
     // are overwritten are loaded / stored NON-TEMPORALLY, so that they do not push the matrix out of the caches between two products
+    // (`keep`: matrix and vectors together fit the Infinity Cache -- then everything is left to it)
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const double ri = r[i] - alpha * __builtin_nontemporal_load(t + i);
+        const double ri = r[i] - alpha * stream_load_rt(t + i, keep != 0);
         r[i] = ri;
         rr += ri * ri;
-        rz += ri * ((CODED ? invd[__builtin_nontemporal_load(dcode + i)] : invd[i]) * ri);
+        rz += ri * ((CODED ? invd[stream_load_rt(dcode + i, keep != 0)] : invd[i]) * ri);
     }
     rr = block_sum(rr, red);
     rz = block_sum(rz, red);
@@ -1311,7 +1320,7 @@ template <bool CODED, bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, double *__restrict__ x, double *__restrict__ p,
                                                       const double *__restrict__ r, const double *__restrict__ invd,
                                                       const uint16_t *__restrict__ dcode, PcgScalars *sc,
-                                                      const double *__restrict__ partial = nullptr, int g = 0, int parity = 0)
+                                                      const double *__restrict__ partial = nullptr, int g = 0, int parity = 0, int keep = 0)
 {
     int done = sc->done;
     if (done == 1 || done == 3) return;
@@ -1353,8 +1362,10 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, double *__restr
     }
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const double pi = p[i];
-        __builtin_nontemporal_store(__builtin_nontemporal_load(x + i) + alpha * pi, x + i); // (x is touched once per iteration)
-        p[i] = (CODED ? invd[__builtin_nontemporal_load(dcode + i)] : invd[i]) * __builtin_nontemporal_load(r + i) + beta * pi;
+        const double xi = stream_load_rt(x + i, keep != 0) + alpha * pi; // (x is touched once per iteration)
+        if (keep) x[i] = xi;
+        else __builtin_nontemporal_store(xi, x + i);
+        p[i] = (CODED ? invd[stream_load_rt(dcode + i, keep != 0)] : invd[i]) * stream_load_rt(r + i, keep != 0) + beta * pi;
     }
 }
 
@@ -2409,6 +2420,7 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
     bool fuse_beta = !dist; // multi-GPU (RCCL transport): the sums are all-reduced between the two vector kernels
     fuse_beta = fuse_beta && cur_opt().fuse_beta != 0;
     static_assert(kChunk % 2 == 0, "the parity of an iteration is taken from its position in the chunk");
+    const int keep = A.keep_cached ? 1 : 0; // matrix + vectors fit the Infinity Cache: no non-temporal hints in the vector kernels
     auto enqueue_iteration = [&](int c, bool timed) -> avs_status {
         int nb = 0;
         if (dist) AVS_TRY(dist_halo_exchange(dist, p, stream));
@@ -2421,21 +2433,21 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
         const bool fuse_alpha = fuse_beta && nb <= kFuseAlphaMax; // few SpMV partials: every workgroup of k_update_r folds them itself
         double *vpart = fuse_alpha ? partial + (w->npartial / 2) : partial; // (the SpMV's are still being read)
         if (fuse_alpha) {
-            if (coded) hipLaunchKernelGGL((k_update_r<true, true>), dim3(g), dim3(kBlock), 0, stream, n, r, t, w->invtab.p, w->dcode.p, sc, vpart, partial, nb, parity);
-            else hipLaunchKernelGGL((k_update_r<false, true>), dim3(g), dim3(kBlock), 0, stream, n, r, t, invd, nullptr, sc, vpart, partial, nb, parity);
+            if (coded) hipLaunchKernelGGL((k_update_r<true, true>), dim3(g), dim3(kBlock), 0, stream, n, r, t, w->invtab.p, w->dcode.p, sc, vpart, partial, nb, parity, keep);
+            else hipLaunchKernelGGL((k_update_r<false, true>), dim3(g), dim3(kBlock), 0, stream, n, r, t, invd, nullptr, sc, vpart, partial, nb, parity, keep);
         } else {
             AVS_TRY(reduce_stage(w, nb, 1, parity ? OP_ALPHA_ODD : OP_ALPHA, tol, 1, stream, dist));
-            if (coded) hipLaunchKernelGGL((k_update_r<true, false>), dim3(g), dim3(kBlock), 0, stream, n, r, t, w->invtab.p, w->dcode.p, sc, partial, nullptr, 0, 0);
-            else hipLaunchKernelGGL((k_update_r<false, false>), dim3(g), dim3(kBlock), 0, stream, n, r, t, invd, nullptr, sc, partial, nullptr, 0, 0);
+            if (coded) hipLaunchKernelGGL((k_update_r<true, false>), dim3(g), dim3(kBlock), 0, stream, n, r, t, w->invtab.p, w->dcode.p, sc, partial, nullptr, 0, 0, keep);
+            else hipLaunchKernelGGL((k_update_r<false, false>), dim3(g), dim3(kBlock), 0, stream, n, r, t, invd, nullptr, sc, partial, nullptr, 0, 0, keep);
         }
         if (fuse_beta) {
-            if (coded) hipLaunchKernelGGL((k_update_xp<true, true>), dim3(g), dim3(kBlock), 0, stream, n, x, p, r, w->invtab.p, w->dcode.p, sc, vpart, g, parity);
-            else hipLaunchKernelGGL((k_update_xp<false, true>), dim3(g), dim3(kBlock), 0, stream, n, x, p, r, invd, nullptr, sc, vpart, g, parity);
+            if (coded) hipLaunchKernelGGL((k_update_xp<true, true>), dim3(g), dim3(kBlock), 0, stream, n, x, p, r, w->invtab.p, w->dcode.p, sc, vpart, g, parity, keep);
+            else hipLaunchKernelGGL((k_update_xp<false, true>), dim3(g), dim3(kBlock), 0, stream, n, x, p, r, invd, nullptr, sc, vpart, g, parity, keep);
             return AVS_OK;
         }
         AVS_TRY(reduce_stage(w, g, 2, OP_BETA, tol, 1, stream, dist));
-        if (coded) hipLaunchKernelGGL((k_update_xp<true, false>), dim3(g), dim3(kBlock), 0, stream, n, x, p, r, w->invtab.p, w->dcode.p, sc, nullptr, 0, 0);
-        else hipLaunchKernelGGL((k_update_xp<false, false>), dim3(g), dim3(kBlock), 0, stream, n, x, p, r, invd, nullptr, sc, nullptr, 0, 0);
+        if (coded) hipLaunchKernelGGL((k_update_xp<true, false>), dim3(g), dim3(kBlock), 0, stream, n, x, p, r, w->invtab.p, w->dcode.p, sc, nullptr, 0, 0, keep);
+        else hipLaunchKernelGGL((k_update_xp<false, false>), dim3(g), dim3(kBlock), 0, stream, n, x, p, r, invd, nullptr, sc, nullptr, 0, 0, keep);
         return AVS_OK;
     };
     while (!finished) {
