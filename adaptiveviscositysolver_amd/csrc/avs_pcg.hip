@@ -493,12 +493,20 @@ typedef int i2_t __attribute__((ext_vector_type(2)));
 
 // matrix words of the value-indexed kernels: non-temporal when the matrix is larger than the caches can hold between two products (the
 // read-once stream must not evict x from L2), plain when it may stay in the 256 MB Infinity Cache from one iteration to the next
-template <typename T>
-__device__ __forceinline__ T stream_load_rt(const T *p, bool keep)
+template <bool KEEP, typename T>
+__device__ __forceinline__ T stream_load_k(const T *p)
 {
-    if (keep) return *p;
+    if (KEEP) return *p;
     return __builtin_nontemporal_load(p);
 }
+template <bool KEEP, typename T>
+__device__ __forceinline__ void stream_store_k(T v, T *p)
+{
+    if (KEEP) *p = v;
+    else __builtin_nontemporal_store(v, p);
+}
+// (the choice is a TEMPLATE parameter: with a run-time flag the optimiser merges the plain and the hinted load of one address into one
+// plain load and the hint is gone)
 template <bool NT, typename T>
 __device__ __forceinline__ T stream_load(const T *p)
 {
@@ -674,7 +682,7 @@ typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 // TLT > 0: tile-local dictionaries (CsrView::tab_ptr): the tile's own table is staged in LDS (its first TLT entries; a tile with
 // more distinct values takes a separate path that reads the rest through L1), codes are tile-local.
 // CWIN: windowed columns (CsrView::cbase): one 32-bit word per non-zero = code << 20 | window slot << 14 | offset.
-template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, int WIN = 0, int TLT = 0, bool HALO = false, bool CWIN = false>
+template <int BLK, int CAP, bool DOT, bool LTAB, bool PACK, int WIN = 0, int TLT = 0, bool HALO = false, bool CWIN = false, bool KEEPW = false>
 __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__restrict__ x, double *__restrict__ y,
                                                   double *__restrict__ partial, const PcgScalars *sc,
                                                   const int32_t *__restrict__ tiles, HaloView hv = HaloView())
@@ -764,11 +772,11 @@ __global__ __launch_bounds__(BLK) void k_spmv_vi2(CsrView A, const double *__res
             cn[u] = i4_t{0, 0, 0, 0};
             if (kk < te4) {
                 if (WORDS) {
-                    qn[u] = stream_load_rt(reinterpret_cast<const u4_t *>(A.packed + kk), A.keep_cached);
+                    qn[u] = stream_load_k<KEEPW>(reinterpret_cast<const u4_t *>(A.packed + kk));
                 } else {
-                    const us4_t h = stream_load_rt(reinterpret_cast<const us4_t *>(A.codes + kk), A.keep_cached);
+                    const us4_t h = stream_load_k<KEEPW>(reinterpret_cast<const us4_t *>(A.codes + kk));
                     qn[u] = u4_t{h.x, h.y, h.z, h.w};
-                    cn[u] = stream_load_rt(reinterpret_cast<const i4_t *>(A.col + kk), A.keep_cached);
+                    cn[u] = stream_load_k<KEEPW>(reinterpret_cast<const i4_t *>(A.col + kk));
                 }
             }
         }
@@ -890,6 +898,15 @@ static avs_status spmv_vi2_launch_t(const CsrView &A, const double *x, double *y
 {
     // > 48 KiB of dynamic LDS (value table of ~1.5 k+ entries) needs the opt-in; it is a per-device function attribute, so it
     // is set on every such launch (cheap, rare path) rather than cached in a process-wide flag
+    if (A.keep_cached && !HALO) { // the words may stay in the Infinity Cache between two products: plain loads
+        if (lds > 48 * 1024)
+            AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, WIN, TLT, HALO, CWIN, !HALO>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+        hipLaunchKernelGGL((k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, WIN, TLT, HALO, CWIN, !HALO>), dim3(ntiles), dim3(BLK), lds, stream, A, x, y,
+                           partial, sc, tiles, hv);
+        AVS_HIP(hipGetLastError());
+        return AVS_OK;
+    }
     if (lds > 48 * 1024)
         AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_vi2<BLK, CAP, DOT, LTAB, PACK, WIN, TLT, HALO, CWIN>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
@@ -1263,11 +1280,11 @@ __global__ __launch_bounds__(kBlock) void k_inv_diag_coded(CsrView A, uint16_t *
 // here by every workgroup for itself, as k_update_xp does with the beta step; only worth it while the SpMV leaves few
 // partials (one per wave of 64 rows): the loop uses it up to kFuseAlphaMax of them.  The kernel's own partial sums then go
 // to a second array (`partial`), because other workgroups are still reading the SpMV's.
-template <bool CODED, bool FUSED>
+template <bool CODED, bool FUSED, bool KEEP>
 __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, double *__restrict__ r, const double *__restrict__ t,
                                                      const double *__restrict__ invd, const uint16_t *__restrict__ dcode,
                                                      PcgScalars *sc, double *__restrict__ partial,
-                                                     const double *__restrict__ spmv_partial = nullptr, int nb = 0, int parity = 0, int keep = 0)
+                                                     const double *__restrict__ spmv_partial = nullptr, int nb = 0, int parity = 0)
 {
     if (sc->done) {
         if (FUSED && blockIdx.x == 0 && threadIdx.x == 0 && sc->done == 2) sc->done = 1; // the pending x update has run (OP_ALPHA)
@@ -1295,10 +1312,10 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, double *__restri
     // are overwritten are loaded / stored NON-TEMPORALLY, so that they do not push the matrix out of the caches between two products
     // (`keep`: matrix and vectors together fit the Infinity Cache -- then everything is left to it)
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const double ri = r[i] - alpha * stream_load_rt(t + i, keep != 0);
+        const double ri = r[i] - alpha * stream_load_k<KEEP>(t + i);
         r[i] = ri;
         rr += ri * ri;
-        rz += ri * ((CODED ? invd[stream_load_rt(dcode + i, keep != 0)] : invd[i]) * ri);
+        rz += ri * ((CODED ? invd[stream_load_k<KEEP>(dcode + i)] : invd[i]) * ri);
     }
     rr = block_sum(rr, red);
     rz = block_sum(rz, red);
@@ -1316,11 +1333,11 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, double *__restri
 // bits everywhere), instead of in a k_reduce launch of its own between the two vector kernels (4.9 us + a launch gap per
 // iteration).  Workgroup 0 publishes the scalars; the old r.z is read from the slot of this iteration's parity and the new
 // one written to the other slot, so a workgroup that starts late still reads what the early ones read.
-template <bool CODED, bool FUSED>
+template <bool CODED, bool FUSED, bool KEEP>
 __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, double *__restrict__ x, double *__restrict__ p,
                                                       const double *__restrict__ r, const double *__restrict__ invd,
                                                       const uint16_t *__restrict__ dcode, PcgScalars *sc,
-                                                      const double *__restrict__ partial = nullptr, int g = 0, int parity = 0, int keep = 0)
+                                                      const double *__restrict__ partial = nullptr, int g = 0, int parity = 0)
 {
     int done = sc->done;
     if (done == 1 || done == 3) return;
@@ -1362,10 +1379,8 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, double *__restr
     }
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const double pi = p[i];
-        const double xi = stream_load_rt(x + i, keep != 0) + alpha * pi; // (x is touched once per iteration)
-        if (keep) x[i] = xi;
-        else __builtin_nontemporal_store(xi, x + i);
-        p[i] = (CODED ? invd[stream_load_rt(dcode + i, keep != 0)] : invd[i]) * stream_load_rt(r + i, keep != 0) + beta * pi;
+        stream_store_k<KEEP>(stream_load_k<KEEP>(x + i) + alpha * pi, x + i); // (x is touched once per iteration)
+        p[i] = (CODED ? invd[stream_load_k<KEEP>(dcode + i)] : invd[i]) * stream_load_k<KEEP>(r + i) + beta * pi;
     }
 }
 
@@ -1652,14 +1667,15 @@ __global__ __launch_bounds__(kBlock) void k_sr_update(int64_t n, double *__restr
     __shared__ double red[4];
     double ru = 0., rr = 0.;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const double pi = u[i] + beta * p[i];
-        const double si = w[i] + beta * s[i];
-        p[i] = pi;
-        s[i] = si;
-        x[i] += alpha * pi;
-        const double ri = r[i] - alpha * si;
-        r[i] = ri;
-        const double ui = invd[i] * ri;
+        // (p, s, x, r belong to this kernel, w is read for the last time: non-temporal -- u and the matrix keep the caches)
+        const double pi = u[i] + beta * __builtin_nontemporal_load(p + i);
+        const double si = __builtin_nontemporal_load(w + i) + beta * __builtin_nontemporal_load(s + i);
+        __builtin_nontemporal_store(pi, p + i);
+        __builtin_nontemporal_store(si, s + i);
+        __builtin_nontemporal_store(__builtin_nontemporal_load(x + i) + alpha * pi, x + i);
+        const double ri = __builtin_nontemporal_load(r + i) - alpha * si;
+        __builtin_nontemporal_store(ri, r + i);
+        const double ui = __builtin_nontemporal_load(invd + i) * ri;
         u[i] = ui;
         ru += ri * ui;
         rr += ri * ri;
@@ -1853,12 +1869,14 @@ __global__ __launch_bounds__(kBlock) void k_sr_update_push(int64_t n, double *__
     double ru = 0., rr = 0.;
     int64_t i = lo + 2 * (int64_t)threadIdx.x;
     for (; i + 1 < hi; i += 2 * kBlock) { // (lo is a multiple of kBlock: i is even, the 16-B accesses are aligned)
-        const d2_t pv = *reinterpret_cast<const d2_t *>(p + i);
-        const d2_t wv = *reinterpret_cast<const d2_t *>(w + i), sv = *reinterpret_cast<const d2_t *>(s + i);
-        const d2_t xv = *reinterpret_cast<const d2_t *>(x + i), rv = *reinterpret_cast<const d2_t *>(r + i);
+        // p, s, x, r are touched by this kernel only, w = A u is read for the last time: non-temporal, so that u (the next product's
+        // input) and as much of the matrix as fits stay cached
+        const d2_t pv = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(p + i));
+        const d2_t wv = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(w + i)), sv = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(s + i));
+        const d2_t xv = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(x + i)), rv = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(r + i));
         double id0, id1;
         if (CODED) {
-            const unsigned cc = *reinterpret_cast<const unsigned *>(dcode + i);
+            const unsigned cc = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(dcode + i));
             id0 = invd[cc & 0xffffu];
             id1 = invd[cc >> 16];
         } else {
@@ -1876,10 +1894,10 @@ __global__ __launch_bounds__(kBlock) void k_sr_update_push(int64_t n, double *__
         xn.x = xv.x + alpha * pn.x; xn.y = xv.y + alpha * pn.y;
         rn.x = rv.x - alpha * sn.x; rn.y = rv.y - alpha * sn.y;
         un.x = id0 * rn.x;          un.y = id1 * rn.y;
-        *reinterpret_cast<d2_t *>(p + i) = pn;
-        *reinterpret_cast<d2_t *>(s + i) = sn;
-        *reinterpret_cast<d2_t *>(x + i) = xn;
-        *reinterpret_cast<d2_t *>(r + i) = rn;
+        __builtin_nontemporal_store(pn, reinterpret_cast<d2_t *>(p + i));
+        __builtin_nontemporal_store(sn, reinterpret_cast<d2_t *>(s + i));
+        __builtin_nontemporal_store(xn, reinterpret_cast<d2_t *>(x + i));
+        __builtin_nontemporal_store(rn, reinterpret_cast<d2_t *>(r + i));
         *reinterpret_cast<d2_t *>(u + i) = un;
         ru += rn.x * un.x;
         rr += rn.x * rn.x;
@@ -2351,6 +2369,12 @@ static avs_status pcg_solve_resident_single(PcgWork *w, const CsrView &A, const 
     return AVS_OK;
 }
 
+// (KEEP is a template parameter of the vector kernels: see stream_load_k)
+#define AVS_VEC_LAUNCH(KERNEL, C, F, ...)                                                                             \
+    do {                                                                                                              \
+        if (keep) hipLaunchKernelGGL((KERNEL<C, F, true>), dim3(g), dim3(kBlock), 0, stream, __VA_ARGS__);            \
+        else hipLaunchKernelGGL((KERNEL<C, F, false>), dim3(g), dim3(kBlock), 0, stream, __VA_ARGS__);                \
+    } while (0)
 avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, double tol, int max_iters,
                      hipStream_t stream, avs_solve_info *info, PcgDist *dist)
 {
@@ -2433,21 +2457,21 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
         const bool fuse_alpha = fuse_beta && nb <= kFuseAlphaMax; // few SpMV partials: every workgroup of k_update_r folds them itself
         double *vpart = fuse_alpha ? partial + (w->npartial / 2) : partial; // (the SpMV's are still being read)
         if (fuse_alpha) {
-            if (coded) hipLaunchKernelGGL((k_update_r<true, true>), dim3(g), dim3(kBlock), 0, stream, n, r, t, w->invtab.p, w->dcode.p, sc, vpart, partial, nb, parity, keep);
-            else hipLaunchKernelGGL((k_update_r<false, true>), dim3(g), dim3(kBlock), 0, stream, n, r, t, invd, nullptr, sc, vpart, partial, nb, parity, keep);
+            if (coded) AVS_VEC_LAUNCH(k_update_r, true, true, n, r, t, w->invtab.p, w->dcode.p, sc, vpart, partial, nb, parity);
+            else AVS_VEC_LAUNCH(k_update_r, false, true, n, r, t, invd, nullptr, sc, vpart, partial, nb, parity);
         } else {
             AVS_TRY(reduce_stage(w, nb, 1, parity ? OP_ALPHA_ODD : OP_ALPHA, tol, 1, stream, dist));
-            if (coded) hipLaunchKernelGGL((k_update_r<true, false>), dim3(g), dim3(kBlock), 0, stream, n, r, t, w->invtab.p, w->dcode.p, sc, partial, nullptr, 0, 0, keep);
-            else hipLaunchKernelGGL((k_update_r<false, false>), dim3(g), dim3(kBlock), 0, stream, n, r, t, invd, nullptr, sc, partial, nullptr, 0, 0, keep);
+            if (coded) AVS_VEC_LAUNCH(k_update_r, true, false, n, r, t, w->invtab.p, w->dcode.p, sc, partial, nullptr, 0, 0);
+            else AVS_VEC_LAUNCH(k_update_r, false, false, n, r, t, invd, nullptr, sc, partial, nullptr, 0, 0);
         }
         if (fuse_beta) {
-            if (coded) hipLaunchKernelGGL((k_update_xp<true, true>), dim3(g), dim3(kBlock), 0, stream, n, x, p, r, w->invtab.p, w->dcode.p, sc, vpart, g, parity, keep);
-            else hipLaunchKernelGGL((k_update_xp<false, true>), dim3(g), dim3(kBlock), 0, stream, n, x, p, r, invd, nullptr, sc, vpart, g, parity, keep);
+            if (coded) AVS_VEC_LAUNCH(k_update_xp, true, true, n, x, p, r, w->invtab.p, w->dcode.p, sc, vpart, g, parity);
+            else AVS_VEC_LAUNCH(k_update_xp, false, true, n, x, p, r, invd, nullptr, sc, vpart, g, parity);
             return AVS_OK;
         }
         AVS_TRY(reduce_stage(w, g, 2, OP_BETA, tol, 1, stream, dist));
-        if (coded) hipLaunchKernelGGL((k_update_xp<true, false>), dim3(g), dim3(kBlock), 0, stream, n, x, p, r, w->invtab.p, w->dcode.p, sc, nullptr, 0, 0, keep);
-        else hipLaunchKernelGGL((k_update_xp<false, false>), dim3(g), dim3(kBlock), 0, stream, n, x, p, r, invd, nullptr, sc, nullptr, 0, 0, keep);
+        if (coded) AVS_VEC_LAUNCH(k_update_xp, true, false, n, x, p, r, w->invtab.p, w->dcode.p, sc, nullptr, 0, 0);
+        else AVS_VEC_LAUNCH(k_update_xp, false, false, n, x, p, r, invd, nullptr, sc, nullptr, 0, 0);
         return AVS_OK;
     };
     while (!finished) {

@@ -46,3 +46,23 @@ def test_checker_is_sensitive():
         cut = [s for j, s in enumerate(ins) if not (j > i and isa_check.waits_vmcnt0(s))]
         ok, _ = isa_check.check_store_wait_sync(cut, isa_check.is_remote_store, isa_check.SYNC)
         assert not ok
+
+
+def test_nontemporal_hints_are_in_the_instruction_stream():
+    """Round 4: the PCG's vector kernels read / write the streams nobody touches again before they are overwritten with the `nt` bit, so that
+    the matrix stays cached between two products (headline +8 %).  The choice is a TEMPLATE parameter: with a run-time flag the optimiser
+    merged the plain and the hinted load of one address into one plain load and the hint silently disappeared -- this test is what notices."""
+    def nt_ops(pattern):
+        found = isa_check.kernels_matching(pattern)
+        assert found, pattern
+        return {k: [i for i in ins if i.startswith("global_") and i.split()[-1] == "nt"] for k, ins in found.items()}
+    for k, ops in nt_ops(r"avs::k_update_xp<true, true, false>").items():
+        assert sum(o.startswith("global_load") for o in ops) >= 3 and any(o.startswith("global_store") for o in ops), (k, ops)
+    for k, ops in nt_ops(r"avs::k_update_r<true, false, false>").items():
+        assert sum(o.startswith("global_load") for o in ops) >= 2, (k, ops)
+    for k, ops in {**nt_ops(r"avs::k_update_xp<true, true, true>"), **nt_ops(r"avs::k_update_r<true, false, true>")}.items():
+        assert not ops, (k, ops)   # matrix + vectors fit the Infinity Cache: everything is left to it
+    for k, ops in nt_ops(r"avs::k_spmv_vi2<512, 4096, true, true, true, 512, 0, false, false, false>").items():
+        assert sum(o.startswith("global_load") for o in ops) >= 2, (k, ops)
+    for k, ops in nt_ops(r"avs::k_sr_update_push<true>").items():
+        assert sum(o.startswith("global_load") for o in ops) >= 5, (k, ops)
