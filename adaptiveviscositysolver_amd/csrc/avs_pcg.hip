@@ -1667,15 +1667,14 @@ __global__ __launch_bounds__(kBlock) void k_sr_update(int64_t n, double *__restr
     __shared__ double red[4];
     double ru = 0., rr = 0.;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        // (p, s, x, r belong to this kernel, w is read for the last time: non-temporal -- u and the matrix keep the caches)
-        const double pi = u[i] + beta * __builtin_nontemporal_load(p + i);
-        const double si = __builtin_nontemporal_load(w + i) + beta * __builtin_nontemporal_load(s + i);
-        __builtin_nontemporal_store(pi, p + i);
-        __builtin_nontemporal_store(si, s + i);
-        __builtin_nontemporal_store(__builtin_nontemporal_load(x + i) + alpha * pi, x + i);
-        const double ri = __builtin_nontemporal_load(r + i) - alpha * si;
-        __builtin_nontemporal_store(ri, r + i);
-        const double ui = __builtin_nontemporal_load(invd + i) * ri;
+        const double pi = u[i] + beta * p[i];
+        const double si = w[i] + beta * s[i];
+        p[i] = pi;
+        s[i] = si;
+        x[i] += alpha * pi;
+        const double ri = r[i] - alpha * si;
+        r[i] = ri;
+        const double ui = invd[i] * ri;
         u[i] = ui;
         ru += ri * ui;
         rr += ri * ri;
@@ -1869,14 +1868,12 @@ __global__ __launch_bounds__(kBlock) void k_sr_update_push(int64_t n, double *__
     double ru = 0., rr = 0.;
     int64_t i = lo + 2 * (int64_t)threadIdx.x;
     for (; i + 1 < hi; i += 2 * kBlock) { // (lo is a multiple of kBlock: i is even, the 16-B accesses are aligned)
-        // p, s, x, r are touched by this kernel only, w = A u is read for the last time: non-temporal, so that u (the next product's
-        // input) and as much of the matrix as fits stay cached
-        const d2_t pv = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(p + i));
-        const d2_t wv = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(w + i)), sv = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(s + i));
-        const d2_t xv = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(x + i)), rv = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(r + i));
+        const d2_t pv = *reinterpret_cast<const d2_t *>(p + i);
+        const d2_t wv = *reinterpret_cast<const d2_t *>(w + i), sv = *reinterpret_cast<const d2_t *>(s + i);
+        const d2_t xv = *reinterpret_cast<const d2_t *>(x + i), rv = *reinterpret_cast<const d2_t *>(r + i);
         double id0, id1;
         if (CODED) {
-            const unsigned cc = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(dcode + i));
+            const unsigned cc = *reinterpret_cast<const unsigned *>(dcode + i);
             id0 = invd[cc & 0xffffu];
             id1 = invd[cc >> 16];
         } else {
@@ -1894,10 +1891,10 @@ __global__ __launch_bounds__(kBlock) void k_sr_update_push(int64_t n, double *__
         xn.x = xv.x + alpha * pn.x; xn.y = xv.y + alpha * pn.y;
         rn.x = rv.x - alpha * sn.x; rn.y = rv.y - alpha * sn.y;
         un.x = id0 * rn.x;          un.y = id1 * rn.y;
-        __builtin_nontemporal_store(pn, reinterpret_cast<d2_t *>(p + i));
-        __builtin_nontemporal_store(sn, reinterpret_cast<d2_t *>(s + i));
-        __builtin_nontemporal_store(xn, reinterpret_cast<d2_t *>(x + i));
-        __builtin_nontemporal_store(rn, reinterpret_cast<d2_t *>(r + i));
+        *reinterpret_cast<d2_t *>(p + i) = pn;
+        *reinterpret_cast<d2_t *>(s + i) = sn;
+        *reinterpret_cast<d2_t *>(x + i) = xn;
+        *reinterpret_cast<d2_t *>(r + i) = rn;
         *reinterpret_cast<d2_t *>(u + i) = un;
         ru += rn.x * un.x;
         rr += rn.x * rn.x;

@@ -64,5 +64,3 @@ def test_nontemporal_hints_are_in_the_instruction_stream():
         assert not ops, (k, ops)   # matrix + vectors fit the Infinity Cache: everything is left to it
     for k, ops in nt_ops(r"avs::k_spmv_vi2<512, 4096, true, true, true, 512, 0, false, false, false>").items():
         assert sum(o.startswith("global_load") for o in ops) >= 2, (k, ops)
-    for k, ops in nt_ops(r"avs::k_sr_update_push<true>").items():
-        assert sum(o.startswith("global_load") for o in ops) >= 5, (k, ops)
