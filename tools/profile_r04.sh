@@ -11,7 +11,8 @@ if [ "${2:-all}" = "all" ]; then
 stats beam --scene beam
 stats buckling --scene buckling
 fi
-pmc() { name=$1; re=$2; shift; shift; timeout 400 rocprofv3 --kernel-include-regex "$re" --pmc "$@" --output-format csv -d $O/pmc_$name -o p -- python $R/bench.py --steps 1 --warmup 0 --max-iters 96 --no-cpu-baseline --no-extra $EXTRA > $O/pmc_$name.log 2>&1; echo "pmc $name rc=$?"; }
+# (AVS_BRICK=1: under counter collection every dispatch carries milliseconds of overhead, which the auto mode's timing of the two forms would measure)
+pmc() { name=$1; re=$2; shift; shift; AVS_BRICK=1 timeout 400 rocprofv3 --kernel-include-regex "$re" --pmc "$@" --output-format csv -d $O/pmc_$name -o p -- python $R/bench.py --steps 1 --warmup 0 --max-iters 96 --no-cpu-baseline --no-extra $EXTRA > $O/pmc_$name.log 2>&1; echo "pmc $name rc=$?"; }
 EXTRA=""
 pmc fetch "spmv|k_update_r" FETCH_SIZE
 pmc write "spmv|k_update_r" WRITE_SIZE
