@@ -175,6 +175,11 @@ avs_status build_reordered_system(avs_ctx *c, int brick_shift)
             ms[form] = t.stop() / 3;
         }
         c->brick_verdict = ms[1] < 0.92 * ms[0] ? 1 : 0;
+        // A profiler that adds milliseconds to every dispatch (counter collection) makes the two timings equal: when the word stream
+        // appears to run below 0.5 TB/s the measurement is not one, and the verdict comes from what the measurements of undisturbed runs
+        // correlate with -- how full the tiles are (profiles/r04_brick_spmv.md, section 7: >= 480 rows per tile wins, <= 360 loses).
+        const double stream_bytes = 4. * (double)nnz + 20. * (double)n;
+        if (ms[0] * 1e-3 > stream_bytes / 0.5e12) c->brick_verdict = (double)n / (double)c->brick.ntiles >= 420. ? 1 : 0;
         c->brick_verdict_rows = n;
         c->brick_tune_ms[0] = ms[0];
         c->brick_tune_ms[1] = ms[1];
