@@ -1311,11 +1311,36 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, double *__restri
     // t = A p is read for the last time here and r is next read one kernel later: the streams that nobody reads again before they
     // are overwritten are loaded / stored NON-TEMPORALLY, so that they do not push the matrix out of the caches between two products
     // (`keep`: matrix and vectors together fit the Infinity Cache -- then everything is left to it)
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const double ri = r[i] - alpha * stream_load_k<KEEP>(t + i);
+    const int64_t n2 = n >> 1; // two rows per thread (16-B accesses), partial sums in the order (even row, odd row)
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n2; j += (int64_t)gridDim.x * kBlock) {
+        const int64_t i = 2 * j;
+        const d2_t rv = *reinterpret_cast<const d2_t *>(r + i);
+        const d2_t tv = stream_load_k<KEEP>(reinterpret_cast<const d2_t *>(t + i));
+        double id0, id1;
+        if (CODED) {
+            const unsigned cc = stream_load_k<KEEP>(reinterpret_cast<const unsigned *>(dcode + i));
+            id0 = invd[cc & 0xffffu];
+            id1 = invd[cc >> 16];
+        } else {
+            const d2_t iv = *reinterpret_cast<const d2_t *>(invd + i);
+            id0 = iv.x;
+            id1 = iv.y;
+        }
+        d2_t rn;
+        rn.x = rv.x - alpha * tv.x;
+        rn.y = rv.y - alpha * tv.y;
+        *reinterpret_cast<d2_t *>(r + i) = rn;
+        rr += rn.x * rn.x;
+        rz += rn.x * (id0 * rn.x);
+        rr += rn.y * rn.y;
+        rz += rn.y * (id1 * rn.y);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        const double ri = r[i] - alpha * t[i];
         r[i] = ri;
         rr += ri * ri;
-        rz += ri * ((CODED ? invd[stream_load_k<KEEP>(dcode + i)] : invd[i]) * ri);
+        rz += ri * ((CODED ? invd[dcode[i]] : invd[i]) * ri);
     }
     rr = block_sum(rr, red);
     rz = block_sum(rz, red);
@@ -1377,10 +1402,34 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, double *__restr
             x[i] += alpha * p[i];
         return;
     }
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    // two rows per thread: 16-B loads / stores (the arrays are 16-B aligned; the odd last row goes alone)
+    const int64_t n2 = n >> 1;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n2; j += (int64_t)gridDim.x * kBlock) {
+        const int64_t i = 2 * j;
+        const d2_t pv = *reinterpret_cast<const d2_t *>(p + i);
+        const d2_t xv = stream_load_k<KEEP>(reinterpret_cast<const d2_t *>(x + i));
+        const d2_t rv = stream_load_k<KEEP>(reinterpret_cast<const d2_t *>(r + i));
+        double id0, id1;
+        if (CODED) {
+            const unsigned cc = stream_load_k<KEEP>(reinterpret_cast<const unsigned *>(dcode + i));
+            id0 = invd[cc & 0xffffu];
+            id1 = invd[cc >> 16];
+        } else {
+            const d2_t iv = *reinterpret_cast<const d2_t *>(invd + i);
+            id0 = iv.x;
+            id1 = iv.y;
+        }
+        d2_t xn, pn;
+        xn.x = xv.x + alpha * pv.x;       xn.y = xv.y + alpha * pv.y;
+        pn.x = id0 * rv.x + beta * pv.x;  pn.y = id1 * rv.y + beta * pv.y;
+        stream_store_k<KEEP>(xn, reinterpret_cast<d2_t *>(x + i)); // (x is touched once per iteration)
+        *reinterpret_cast<d2_t *>(p + i) = pn;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
         const double pi = p[i];
-        stream_store_k<KEEP>(stream_load_k<KEEP>(x + i) + alpha * pi, x + i); // (x is touched once per iteration)
-        p[i] = (CODED ? invd[stream_load_k<KEEP>(dcode + i)] : invd[i]) * stream_load_k<KEEP>(r + i) + beta * pi;
+        x[i] += alpha * pi;
+        p[i] = (CODED ? invd[dcode[i]] : invd[i]) * r[i] + beta * pi;
     }
 }
 
