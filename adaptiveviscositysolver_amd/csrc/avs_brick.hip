@@ -401,9 +401,18 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         tb = tbn;
         nsw_prev = (nsw > 0 && !BRICK_DBG(4)) ? 1 : 0;
     }
-    if (DOT) { // one partial per wave of every WORKGROUP (fixed order: the tile walk is static)
+    if (DOT) { // ONE partial per workgroup (fixed order: the tile walk is static, the waves' sums are added in wave order): few enough
+               // for the vector kernel that follows to fold them itself instead of a reduction launch in between
         const double dsum = brick_wave_sum_dpp(dot);
-        if (lane == 63) partial[(int)blockIdx.x * (kBrickBlk / 64) + (tid >> 6)] = dsum;
+        __syncthreads();                                                 // (the last tile's streamed sums may still be reading `park`)
+        if (lane == 63) park[tid >> 6] = dsum;
+        __syncthreads();
+        if (tid == 0) {
+            double s = park[0];
+#pragma unroll
+            for (int k = 1; k < kBrickBlk / 64; ++k) s += park[k];
+            partial[blockIdx.x] = s;
+        }
     }
 }
 
@@ -456,10 +465,10 @@ static void brick_print_stamps()
 }
 #endif
 
-// partial sums of x.y the fused-dot launch writes: one per wave of every workgroup of the persistent grid
+// partial sums of x.y the fused-dot launch writes: one per workgroup of the persistent grid
 int brick_partial_count(const BrickView &B)
 {
-    return B.ntiles > 0 ? brick_grid(B, brick_lds_bytes(B)) * (kBrickBlk / 64) : 0;
+    return B.ntiles > 0 ? brick_grid(B, brick_lds_bytes(B)) : 0;
 }
 
 avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, double *partial, const int *done_flag, hipStream_t stream)

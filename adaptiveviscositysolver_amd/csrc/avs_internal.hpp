@@ -303,7 +303,7 @@ struct BrickForm {
 };
 size_t brick_lds_bytes(const BrickView &B);
 avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, double *partial, const int *done_flag, hipStream_t stream);
-int brick_partial_count(const BrickView &B);   // partial sums the fused-dot launch writes (one per wave of every persistent workgroup)
+int brick_partial_count(const BrickView &B);   // partial sums the fused-dot launch writes (one per persistent workgroup)
 
 // the lossless storage forms of one matrix's values (avs_reorder.hip), owned next to the CSR arrays
 constexpr int64_t kKeepCachedBytes = 200ll << 20; // what may stay in the 256 MB Infinity Cache across a PCG iteration
