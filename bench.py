@@ -214,7 +214,8 @@ def extra_workload(label, sc, local_rank, tol, max_iters):
     from adaptiveviscositysolver_amd import DevicePrepass, ViscositySolve, scenes
     fsc = scenes.crop_to_field(sc)
     pp = DevicePrepass(sc.res, sc.dx, sc.levels, device=local_rank, field_res=sc.field_res)
-    pinfo = pp.run(fsc.liquid, fsc.solid)
+    pp.run(fsc.liquid, fsc.solid)            # first pass: allocations and first touch of the pyramids (seconds at 1024^3)
+    pinfo = pp.run(fsc.liquid, fsc.solid)    # the timed pass: what every later frame pays
     s = ViscositySolve(sc.res, sc.dx, sc.dt, pinfo.levels, device=local_rank, field_res=sc.field_res)
     pp.apply(s)
     s.set_scene_fields(fsc)
@@ -242,6 +243,18 @@ def extra_workload(label, sc, local_rank, tol, max_iters):
            "roofline": (spmv_rates(int(ai.n_velocity), int(ai.nnz), s.matrix_format(), sum(i.spmv_ms for i in infos) / 2)
                         if infos[0].spmv_ms > 0 else
                         resident_roofline(int(ai.n_velocity), int(ai.nnz), iters // 2, el / 2 * 1e3) if infos[0].resident else None)}
+    try:   # post-solve transfer to the regular MAC grid (cpp:655-707), second call timed
+        from adaptiveviscositysolver_amd import capi as _cc
+        outs = [torch.empty_like(v) for v in fsc.velocity]
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _cc.check(s.lib.avs_transfer_to_regular_grid(s.h, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), _cc.MEM_DEVICE))
+            torch.cuda.synchronize()
+            rec["transfer_to_regular_grid_ms"] = (time.perf_counter() - t0) * 1e3
+        del outs
+    except Exception as e:
+        rec["transfer_error"] = str(e)[:200]
     if infos[0].resident:   # the same workload through the launch-per-phase loop: what the resident loop is worth, and the SpMV roofline
         from adaptiveviscositysolver_amd import capi as _c
         s.set_solver_option(_c.OPTION_RESIDENT_LOOP, 0)
