@@ -510,6 +510,7 @@ struct avs_ctx {
     // post-solve transfer (avs_post.hip): regular-grid classification + interpolator work fields
     avs::DevBuf<int32_t> ridx[3];
     bool have_ridx[3] = {};
+    avs::DevBuf<uint8_t> ridx_tiles[3]; // per 64 x 8 x 8 tile of the face lattice: any face the transfer writes (avs_post.hip)
     avs::DevBuf<float> post_vel[AVS_MAX_LEVELS][3], post_nval[AVS_MAX_LEVELS][3], post_nw[AVS_MAX_LEVELS][3];
     avs::DevBuf<int32_t> post_nf[AVS_MAX_LEVELS];
     avs::DevBuf<int8_t> post_nlab[AVS_MAX_LEVELS];
