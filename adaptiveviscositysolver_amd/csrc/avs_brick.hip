@@ -137,19 +137,31 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
     }
 
     // Tile -> workgroup.  Workgroup b runs on XCD b mod 8 (round-robin dispatch); consecutive tiles are neighbouring bricks and read
-    // each other's rows as halo.  Every XCD therefore walks ONE contiguous eighth of the tiles, its workgroups side by side: a halo
-    // value is fetched by one L2 (tile = b + k gridDim: by up to eight).
-    int tile = blockIdx.x, tstep = (int)gridDim.x, tend = B.ntiles;
+    // each other's rows as halo, so what an XCD works on at any time is one contiguous run of gridDim / 8 tiles, its workgroups side by
+    // side (a halo value is fetched by one L2; tile = b + k gridDim: by up to eight).  Two walks, chosen per matrix (BrickView::walk,
+    // measured at the first assembly of a matrix size, avs_reorder.hip):
+    //   0  one contiguous EIGHTH of the tiles per XCD -- best where tiles cost the same everywhere (512^3 beam: 2 % over walk 1 in the loop);
+    //   1  chunks of gridDim / 8 tiles dealt to the XCDs in turn -- every XCD sees the same mix of tiles.  A thin sheet's eighths are its z
+    //      layers (full surface bricks here, coarse interior there) and the kernel waits for the slowest XCD: 133 (walk 0) against 94 us.
+    int tile = blockIdx.x, tstep = (int)gridDim.x, tend = B.ntiles, mrun = 0, mjump = 0, mk = 0;
     if ((gridDim.x & 7u) == 0u && B.ntiles >= (int)gridDim.x && !BRICK_DBG(32)) {
-        const int c = (int)(blockIdx.x & 7u);
-        tstep = (int)(gridDim.x >> 3);
-        tile = (int)(((int64_t)B.ntiles * c) >> 3) + (int)(blockIdx.x >> 3);
-        tend = (int)(((int64_t)B.ntiles * (c + 1)) >> 3);
-        if (BRICK_DBG(128)) { // experiment: every workgroup walks CONSECUTIVE tiles (its own contiguous share of the XCD's range)
-            const int t0 = (int)(((int64_t)B.ntiles * c) >> 3), cnt = tend - t0, s = (int)(blockIdx.x >> 3);
-            tile = t0 + (int)(((int64_t)cnt * s) / tstep);
-            tend = t0 + (int)(((int64_t)cnt * (s + 1)) / tstep);
-            tstep = 1;
+        const int c = (int)(blockIdx.x & 7u), gx = (int)(gridDim.x >> 3);
+        tile = c * gx + (int)(blockIdx.x >> 3);
+        if (B.walk == 0 && !BRICK_DBG(2048)) { // one contiguous eighth of the tiles per XCD (chosen per matrix by measurement: see below)
+            tstep = gx;
+            tile = (int)(((int64_t)B.ntiles * c) >> 3) + (int)(blockIdx.x >> 3);
+            tend = (int)(((int64_t)B.ntiles * (c + 1)) >> 3);
+        }
+        if (BRICK_DBG(512) || BRICK_DBG(1024)) { // measurement: chunks of m * gx tiles per XCD (m walks of its workgroups), m = 4 / 16
+            mrun = BRICK_DBG(512) ? 4 : 16;
+            tile = c * mrun * gx + (int)(blockIdx.x >> 3);
+            tstep = gx;
+            mjump = 7 * mrun * gx;
+        }
+        if (BRICK_DBG(256)) { // measurement: one contiguous eighth of the tiles per XCD
+            tstep = gx;
+            tile = (int)(((int64_t)B.ntiles * c) >> 3) + (int)(blockIdx.x >> 3);
+            tend = (int)(((int64_t)B.ntiles * (c + 1)) >> 3);
         }
     }
     if (tile >= tend) return;                                            // (cannot happen: the grid is at most ntiles workgroups)
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
             }
         }
         // the next tile's block address: a scalar load, in flight while this tile's data arrives
-        const int tnext = tile + tstep;
+        const int tnext = tile + tstep + ((mrun && mk + 1 == mrun) ? mjump : 0);
         const bool more = tnext < tend;
         const uint2 tbn = B.tile_blk[more ? tnext : tile];
         // ---- LDS writes
@@ -398,6 +410,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         if (!more) break;
         ++iter;
         tile = tnext;
+        mk = (mrun && mk + 1 == mrun) ? 0 : mk + 1;
         tb = tbn;
         nsw_prev = (nsw > 0 && !BRICK_DBG(4)) ? 1 : 0;
     }

@@ -271,6 +271,7 @@ struct BrickView {
     const uint32_t *pwords = nullptr; // pattern words: delta << 19 (signed 13 bits) | lattice level << 14 | value code << 3; a pattern is
                                       // padded to quads with its first entry's slot and the code of 0.0 (= table_size)
     const uint2 *sdesc = nullptr;     // streamed rows: local row | len << 16, first word relative to the tile's sword0
+    int walk = 1;                     // tile -> workgroup: 0 one contiguous eighth of the tiles per XCD, 1 chunks dealt to the XCDs in turn (avs_brick.hip)
     const uint32_t *swords = nullptr; // code << col_bits | column, CSR order; col_bits == 0: 64-bit words column | code << 32
     const double *table = nullptr;
     int table_size = 0, col_bits = 0;
@@ -525,7 +526,7 @@ struct avs_ctx {
     avs::BrickForm brick;   // brick-structured form of the solve matrix (large single-dictionary systems)
     avs::BrickView brick_view;
     // AVS_BRICK_AUTO: brick form or word stream, whichever multiplied faster when a matrix of (about) this size was first seen
-    int brick_verdict = 0;
+    int brick_verdict = 0, brick_walk = 1;
     int64_t brick_verdict_rows = 0;
     double brick_tune_ms[2] = {0., 0.};   // stream, brick (ms per launch at the measurement)
     avs::DevBuf<double> brick_tune_y;

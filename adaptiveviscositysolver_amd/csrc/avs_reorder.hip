@@ -145,15 +145,16 @@ avs_status build_reordered_system(avs_ctx *c, int brick_shift)
     c->brick.clear();
     int want = n >= kBrickMinSystemRows ? 1 : 0;
     if (c->opt.brick >= 0) want = c->opt.brick;
-    // AUTO: the form is kept only where it is FASTER than the word stream on this matrix.  That is measured (a fat volume with ~490 rows
-    // per shell brick: 0.7x the stream's time; a thin sheet with ~340: 1.2x), once per context and matrix size: a simulation's next
-    // frames reuse the verdict (and do not build a form that lost) until the row count has moved by more than 10 %.
+    // AUTO: the form is kept only where it is FASTER than the word stream on this matrix, and its tile walk (BrickView::walk) is the faster
+    // of the two.  That is measured -- three launches each -- once per context and matrix size (a fat volume with ~490 rows per shell
+    // brick: 0.7x the stream's time, contiguous eighths; a thin sheet with ~340: 0.87x with interleaved chunks, 1.2x without); a
+    // simulation's next frames reuse the verdict (and do not build a form that lost) until the row count has moved by more than 10 %.
     const bool autosel = c->opt.brick < 0 && want;
-    const bool cached = autosel && c->brick_verdict_rows > 0 && std::llabs(n - c->brick_verdict_rows) * 10 <= c->brick_verdict_rows;
-    if (cached && !c->brick_verdict) want = 0;
+    const bool cached = c->brick_verdict_rows > 0 && std::llabs(n - c->brick_verdict_rows) * 10 <= c->brick_verdict_rows;
+    if (autosel && cached && !c->brick_verdict) want = 0;
     if (want) AVS_TRY(build_brick_form(c));
     c->brick.view(c->brick_view, c->vi);
-    if (autosel && c->brick.ready && !cached) {
+    if (want && c->brick.ready && !cached) { // (forced form: the walk is still measured)
         AVS_TRY(c->brick_tune_y.reserve((size_t)n));
         CsrView A;
         A.n = n;
@@ -162,10 +163,12 @@ avs_status build_reordered_system(avs_ctx *c, int brick_shift)
         A.col = c->p_col.p;
         A.val = c->p_val.p;
         c->vi.apply(A);
-        double ms[2] = {0., 0.};
-        for (int form = 0; form < 2; ++form) {
+        double ms[3] = {0., 0., 0.}; // word stream, brick form walk 0, walk 1
+        for (int form = autosel ? 0 : 1; form < 3; ++form) {
+            BrickView V = c->brick_view;
+            V.walk = form - 1;
             auto launch = [&]() -> avs_status {
-                return form ? spmv_brick_launch(c->brick_view, c->p_x0.p, c->brick_tune_y.p, nullptr, nullptr, st)
+                return form ? spmv_brick_launch(V, c->p_x0.p, c->brick_tune_y.p, nullptr, nullptr, st)
                             : spmv_launch(A, c->p_x0.p, c->brick_tune_y.p, 0, st);
             };
             AVS_TRY(launch()); // (first touch, kernel load)
@@ -174,20 +177,27 @@ avs_status build_reordered_system(avs_ctx *c, int brick_shift)
             for (int r = 0; r < 3; ++r) AVS_TRY(launch());
             ms[form] = t.stop() / 3;
         }
-        c->brick_verdict = ms[1] < 0.92 * ms[0] ? 1 : 0;
-        // A profiler that adds milliseconds to every dispatch (counter collection) makes the two timings equal: when the word stream
+        c->brick_walk = ms[2] < 0.97 * ms[1] ? 1 : 0; // (the contiguous eighths win the loop by more than they win a stand-alone launch)
+        const double best = c->brick_walk ? ms[2] : ms[1];
+        c->brick_verdict = autosel ? (best < 0.92 * ms[0] ? 1 : 0) : 1;
+        // A profiler that adds milliseconds to every dispatch (counter collection) makes the timings equal: when the word stream
         // appears to run below 0.5 TB/s the measurement is not one, and the verdict comes from what the measurements of undisturbed runs
-        // correlate with -- how full the tiles are (profiles/r04_brick_spmv.md, section 7: >= 480 rows per tile wins, <= 360 loses).
+        // correlate with -- how full the tiles are (profiles/r04_brick_spmv.md, section 7).
         const double stream_bytes = 4. * (double)nnz + 20. * (double)n;
-        if (ms[0] * 1e-3 > stream_bytes / 0.5e12) c->brick_verdict = (double)n / (double)c->brick.ntiles >= 420. ? 1 : 0;
+        if (autosel && ms[0] * 1e-3 > stream_bytes / 0.5e12) {
+            const double fill = (double)n / (double)c->brick.ntiles;
+            c->brick_verdict = fill >= 330. ? 1 : 0;
+            c->brick_walk = fill >= 420. ? 0 : 1;
+        }
         c->brick_verdict_rows = n;
         c->brick_tune_ms[0] = ms[0];
-        c->brick_tune_ms[1] = ms[1];
+        c->brick_tune_ms[1] = best;
     }
     if (autosel && c->brick.ready && !c->brick_verdict) { // the word stream is the faster form for this matrix
         c->brick.clear();
         c->brick.view(c->brick_view, c->vi);
     }
+    c->brick_view.walk = c->brick_walk;
     return AVS_OK;
 }
 

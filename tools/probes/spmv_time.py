@@ -5,7 +5,9 @@ import torch
 from adaptiveviscositysolver_amd import DevicePrepass, ViscositySolve, scenes
 dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-sc = scenes.fat_beam(n, 4, device=dev)
+kind = os.environ.get("SPMV_SCENE", "beam")   # beam | sheet (thickness SPMV_SHEET_CELLS, default 32) | tank
+sc = (scenes.thin_sheet(n, 4 if n <= 512 else 5, thickness_cells=int(os.environ.get("SPMV_SHEET_CELLS", "32")), device=dev) if kind == "sheet"
+      else scenes.tank(n, 4, device=dev) if kind == "tank" else scenes.fat_beam(n, 4, device=dev))
 pp = DevicePrepass(sc.res, sc.dx, sc.levels); pi = pp.run(sc.liquid, sc.solid)
 s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, probe=True); pp.apply(s); s.set_scene_fields(sc); pp.close(); s.assemble()
 reps = int(os.environ.get("SPMV_REPEATS", "200"))
