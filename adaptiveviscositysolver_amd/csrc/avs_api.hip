@@ -129,7 +129,14 @@ const Options &cur_opt()
     static thread_local Options fallback = options_from_env(); // an entry point without a context (avs_pcg_csr, measurement entries)
     return fallback;
 }
-OptScope::OptScope(const ::avs_ctx *c) : prev(tl_opt) { if (c) tl_opt = &c->opt; }
+OptScope::OptScope(const ::avs_ctx *c) : prev(tl_opt)
+{
+    if (c) tl_opt = &c->opt;
+    // hipGetLastError() is per THREAD, not per library: the host application (or torch in the tests: pointer-attribute probes of host
+    // memory leave "invalid argument" behind) may have left an error that is none of ours.  Every outermost entry of the C ABI starts clean,
+    // so that the checks behind our own launches report our own launches.
+    if (!prev) (void)hipGetLastError();
+}
 OptScope::~OptScope() { tl_opt = prev; }
 } // namespace avs
 

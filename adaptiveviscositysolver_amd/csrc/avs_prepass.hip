@@ -739,6 +739,7 @@ void avs_prepass_destroy(avs_prepass *p)
 
 avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *solid, avs_memspace where)
 {
+    (void)hipGetLastError(); // (a stale error of the host application's own HIP calls on this thread is not ours: see OptScope)
     AVS_REQUIRE(p && liquid, AVS_EINVAL, "null argument");
     AVS_HIP(hipSetDevice(p->desc.device));
     hipStream_t st = p->stream;
@@ -1064,6 +1065,7 @@ avs_status avs_prepass_get_weights(avs_prepass *p, avs_field_kind kind, int32_t 
 
 avs_status avs_prepass_apply(avs_prepass *p, avs_ctx *ctx)
 {
+    (void)hipGetLastError(); // (a stale error of the host application's own HIP calls on this thread is not ours: see OptScope)
     AVS_REQUIRE(p && ctx, AVS_EINVAL, "null argument");
     AVS_REQUIRE(p->ready && p->levels >= 1, AVS_ESTATE, "pre-pass has no levels (no liquid in the refinement band)");
     AVS_REQUIRE(ctx->desc.levels == p->levels && ctx->desc.nx == p->desc.nx && ctx->desc.ny == p->desc.ny && ctx->desc.nz == p->desc.nz &&
