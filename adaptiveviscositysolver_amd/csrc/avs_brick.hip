@@ -189,6 +189,10 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         double *prod = emode ? xs : park + kBrickXSlots;
         const int cap = emode ? kBrickSlotsPad : kBrickPark - kBrickXSlots;
         BRICK_STAMP(1);
+#ifdef AVS_PROBES
+        if (BRICK_DBG(16) && threadIdx.x == 0 && iter < kStampTiles && blockIdx.x < kStampWgs) // tile kind: 1 E tile, 2 G tile with streamed rows, 0 G tile
+            g_brick_stamps[((int)blockIdx.x * kStampTiles + iter) * 8 + 5] = emode ? 1 : (nsw > 0 ? 2 : 0);
+#endif
         // ---- this tile's loads, one round trip: x of the halo runs, x of the tile's own rows, the pattern quads
         double fv[kBrickRu];
         uint32_t rdsc[kBrickRu];
@@ -364,11 +368,12 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                 const int te = (ts + cap < nsw) ? ts + cap : nsw;
                 if (emode || wide || ts > 0) {
                     if (ts > 0) __syncthreads(); // the previous pass has been summed
-                    for (int e0 = ts + tid; e0 < te; e0 += 4 * kBrickBlk) {
-                        uint32_t w4[4], c4[4];
-                        double x4[4];
+                    constexpr int SU = 4; // (8 entries per thread -- a whole pass of an E tile in one round of loads -- was measured SLOWER: 7.1 -> 7.7 us per E tile)
+                    for (int e0 = ts + tid; e0 < te; e0 += SU * kBrickBlk) {
+                        uint32_t w4[SU], c4[SU];
+                        double x4[SU];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < SU; ++u) {
                             const int e = e0 + u * kBrickBlk;
                             const int64_t at = (int64_t)sword0 + (e < te ? e : ts);
                             if (wide) {
@@ -382,9 +387,9 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                             }
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) x4[u] = x[w4[u]];
+                        for (int u = 0; u < SU; ++u) x4[u] = x[w4[u]];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < SU; ++u) {
                             const int e = e0 + u * kBrickBlk;
                             if (e < te) prod[e - ts] = vals[c4[u]] * x4[u];
                         }
@@ -462,19 +467,22 @@ static void brick_print_stamps()
 {
     std::vector<long long> hs((size_t)kStampWgs * kStampTiles * 8);
     if (hipMemcpyFromSymbol(hs.data(), HIP_SYMBOL(g_brick_stamps), hs.size() * sizeof(long long)) != hipSuccess) return;
-    double acc[6] = {};
-    long cnt = 0;
-    for (int w = 0; w < kStampWgs; ++w)
-        for (int i = 1; i + 1 < kStampTiles; ++i) {
-            const long long *p = &hs[((size_t)w * kStampTiles + i) * 8], *pn = p + 8;
-            if (!p[0] || !p[4] || !pn[0]) continue;
-            acc[0] += (double)(p[1] - p[0]); acc[1] += (double)(p[2] - p[1]); acc[2] += (double)(p[3] - p[2]);
-            acc[3] += (double)(p[4] - p[3]); acc[4] += (double)(pn[0] - p[4]); acc[5] += (double)(pn[0] - p[0]);
-            ++cnt;
-        }
-    if (cnt)
-        fprintf(stderr, "brick phases (us, mean of %ld tiles): block to LDS + barrier %.2f | issue loads, LDS writes, barrier %.2f | pattern rows %.2f | streamed + dot %.2f | loop %.2f | tile %.2f\n",
-                cnt, acc[0] / cnt / 100, acc[1] / cnt / 100, acc[2] / cnt / 100, acc[3] / cnt / 100, acc[4] / cnt / 100, acc[5] / cnt / 100);
+    static const char *kind[3] = {"G tiles", "E tiles", "G tiles with streamed rows"};
+    for (int ty = 0; ty < 3; ++ty) {
+        double acc[6] = {};
+        long cnt = 0;
+        for (int w = 0; w < kStampWgs; ++w)
+            for (int i = 1; i + 1 < kStampTiles; ++i) {
+                const long long *p = &hs[((size_t)w * kStampTiles + i) * 8], *pn = p + 8;
+                if (!p[0] || !p[4] || !pn[0] || p[5] != ty) continue;
+                acc[0] += (double)(p[1] - p[0]); acc[1] += (double)(p[2] - p[1]); acc[2] += (double)(p[3] - p[2]);
+                acc[3] += (double)(p[4] - p[3]); acc[4] += (double)(pn[0] - p[4]); acc[5] += (double)(pn[0] - p[0]);
+                ++cnt;
+            }
+        if (cnt)
+            fprintf(stderr, "brick phases (us, mean of %ld %s): block to LDS + barrier %.2f | issue loads, LDS writes, barrier %.2f | pattern rows %.2f | streamed + dot %.2f | loop %.2f | tile %.2f\n",
+                    cnt, kind[ty], acc[0] / cnt / 100, acc[1] / cnt / 100, acc[2] / cnt / 100, acc[3] / cnt / 100, acc[4] / cnt / 100, acc[5] / cnt / 100);
+    }
 }
 #endif
 
