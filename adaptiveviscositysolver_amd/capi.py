@@ -29,7 +29,7 @@ PRECISION_F64, PRECISION_F32 = 0, 1   # avs_desc.precision (SolveType of the ref
 (OPTION_PRECONDITIONER, OPTION_RESIDENT_LOOP, OPTION_TRANSPORT, OPTION_PARANOID, OPTION_GRAPH_REPLAY, OPTION_BRICK_FORM,
  OPTION_FUSED_SCALAR_STEPS, OPTION_RELOAD_ENVIRONMENT) = range(8)  # avs_set_solver_option
 USE_TRANSPORT_AUTO, USE_TRANSPORT_RCCL, USE_TRANSPORT_DIRECT = 0, 1, 2
-BRICK_AUTO, BRICK_NEVER, BRICK_ALWAYS = -1, 0, 1
+BRICK_AUTO, BRICK_NEVER, BRICK_ALWAYS, BRICK_TUNE = -1, 0, 1, 2
 PRECONDITIONER_JACOBI, PRECONDITIONER_NONE = 0, 1
 INACTIVE, ACTIVE, UP, DOWN = 0, 1, 2, 3
 UNASSIGNED, SOLIDBOUNDARY, OUTSIDE = -1, -2, -3
@@ -39,7 +39,7 @@ INDEX_VELOCITY, INDEX_EDGE, INDEX_CENTER = 0, 1, 2
 
 # every symbol include/avs.h declares (checked by tests/test_capi_symbols.py)
 EXPORTED_SYMBOLS = [
-    "avs_last_error", "avs_version", "avs_create", "avs_destroy", "avs_set_labels",
+    "avs_last_error", "avs_version", "avs_abi_version", "avs_cancel", "avs_create", "avs_destroy", "avs_set_labels",
     "avs_set_index_field", "avs_set_dof_counts", "avs_set_scalar_field", "avs_build_stencils",
     "avs_build_initial_guess", "avs_build_system", "avs_assemble", "avs_solve", "avs_set_solver_option",
     "avs_get_assembly_info", "avs_get_matrix_format", "avs_get_solution", "avs_get_initial_guess", "avs_get_csr",
@@ -54,7 +54,8 @@ EXPORTED_SYMBOLS = [
     "avs_dist_get_info", "avs_dist_init_hosted", "avs_dist_export_blob", "avs_dist_import_blobs",
 ]
 # include/avs_probe.h: exported by libavs_probe.so only (the -DAVS_PROBES build of the same sources)
-PROBE_SYMBOLS = ["avs_spmv_csr", "avs_bench_spmv", "avs_spmv_sell", "avs_bench_stream", "avs_brick_spmv_probe"]
+PROBE_SYMBOLS = ["avs_spmv_csr", "avs_bench_spmv", "avs_spmv_sell", "avs_bench_stream", "avs_brick_spmv_probe", "avs_spmv_solver_form",
+                 "avs_dist_spmv_local_form"]
 _VOID_RETURN = ("avs_last_error", "avs_version", "avs_destroy", "avs_plan_destroy", "avs_local_group_destroy",
                 "avs_prepass_destroy")
 
@@ -75,7 +76,7 @@ class Desc(C.Structure):
 class SolveInfo(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("error", C.c_double),
                 ("rhs_norm2", C.c_double), ("n", C.c_int64), ("nnz", C.c_int64),
-                ("solve_ms", C.c_double), ("spmv_ms", C.c_double), ("resident", C.c_int32), ("reserved", C.c_int32)]
+                ("solve_ms", C.c_double), ("spmv_ms", C.c_double), ("resident", C.c_int32), ("cancelled", C.c_int32)]
 
 
 class PlanSizes(C.Structure):
@@ -109,10 +110,30 @@ class DistInfo(C.Structure):
 
 
 class MatrixFormat(C.Structure):
-    _fields_ = [("reordered", C.c_int32), ("value_table_size", C.c_int32), ("column_bits", C.c_int32),
+    _fields_ = [("struct_size", C.c_int32), ("reordered", C.c_int32), ("value_table_size", C.c_int32), ("column_bits", C.c_int32),
                 ("bytes_per_nonzero", C.c_int32), ("tile_local_tables", C.c_int32),
-                ("column_windows", C.c_int32), ("brick_tiles", C.c_int32), ("brick_patterns", C.c_int32),
-                ("brick_pattern_rows", C.c_int64), ("brick_bytes", C.c_int64)]
+                ("column_windows", C.c_int32), ("brick_tiles", C.c_int32), ("brick_patterns", C.c_int32), ("_pad", C.c_int32),
+                ("brick_pattern_rows", C.c_int64), ("brick_bytes", C.c_int64), ("brick_walk", C.c_int32), ("brick_value_codes", C.c_int32)]
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.struct_size = C.sizeof(MatrixFormat)
+
+
+def source_fingerprint():
+    """sha256 (16 hex digits) over the library's sources: kernels, internal headers, the public header.  Counter records under
+    profiles/ carry the fingerprint of the tree they were taken with; bench.py only quotes a record whose fingerprint is the running one."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")) + glob.glob(os.path.join(csrc, "*.inl")) +
+                   glob.glob(os.path.join(csrc, "*.cpp")) + [os.path.join(csrc, "Makefile")] +
+                   glob.glob(os.path.join(os.path.dirname(csrc), "..", "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 _lib = None
@@ -152,6 +173,8 @@ def load(probe=False):
     L.avs_build_system.argtypes = [vp]
     L.avs_assemble.argtypes = [vp, C.POINTER(AssemblyInfo)]
     L.avs_solve.argtypes = [vp, f64, i32, C.POINTER(SolveInfo)]
+    L.avs_cancel.argtypes = [vp]
+    L.avs_abi_version.restype = C.c_int32
     L.avs_set_solver_option.argtypes = [vp, i32, i32]
     L.avs_get_assembly_info.argtypes = [vp, C.POINTER(AssemblyInfo)]
     L.avs_get_matrix_format.argtypes = [vp, C.POINTER(MatrixFormat)]
@@ -166,6 +189,8 @@ def load(probe=False):
         L.avs_bench_spmv.argtypes = [vp, i32, i32, C.POINTER(f64)]
         L.avs_spmv_sell.argtypes = [i64, vp, vp, vp, vp, vp, i32, vp, C.POINTER(f64)]
         L.avs_bench_stream.argtypes = [i32, i64, i32, i32, C.POINTER(f64)]
+        L.avs_spmv_solver_form.argtypes = [vp, vp, vp, i32, C.POINTER(f64)]
+        L.avs_dist_spmv_local_form.argtypes = [vp, vp, vp, i32, C.POINTER(f64)]
     L.avs_prepass_create.argtypes = [C.POINTER(PrepassDesc), C.POINTER(vp)]
     L.avs_prepass_destroy.argtypes = [vp]
     L.avs_prepass_destroy.restype = None

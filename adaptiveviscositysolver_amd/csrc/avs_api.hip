@@ -91,7 +91,7 @@ Options options_from_env()
     if (const char *e = getenv("AVS_DIST_TRANSPORT")) o.transport = strcmp(e, "rccl") == 0 ? 1 : (strcmp(e, "direct") == 0 ? 2 : 0);
     o.paranoid = env_int("AVS_DIST_PARANOID", 0) != 0;
     o.graph = env_int("AVS_PCG_GRAPH", 1) != 0;
-    if (const char *e = getenv("AVS_BRICK")) o.brick = atoi(e) != 0;
+    if (const char *e = getenv("AVS_BRICK")) { const int v = atoi(e); o.brick = v < 0 ? -1 : (v > 2 ? 1 : v); } // <0 auto, 0 never, 1 always, 2 tune
     o.brick_interleave = env_int("AVS_BRICK_INTERLEAVE", 1) != 0;
     o.brick_shift = env_int("AVS_BRICK_SHIFT", 3);
     o.value_index = env_int("AVS_VALUE_INDEX", 1) != 0;
@@ -123,21 +123,32 @@ Options options_from_env()
     return o;
 }
 static thread_local const Options *tl_opt = nullptr;
+static thread_local Options tl_fallback;
+static thread_local bool tl_fallback_ready = false;
 const Options &cur_opt()
 {
     if (tl_opt) return *tl_opt;
-    static thread_local Options fallback = options_from_env(); // an entry point without a context (avs_pcg_csr, measurement entries)
-    return fallback;
+    // an entry point without a context (avs_pcg_csr, measurement entries): the environment as it is when the entry starts
+    // (OptScope(nullptr) re-reads it), not once per thread for the life of the process
+    if (!tl_fallback_ready) { tl_fallback = options_from_env(); tl_fallback_ready = true; }
+    return tl_fallback;
 }
 OptScope::OptScope(const ::avs_ctx *c) : prev(tl_opt)
 {
     if (c) tl_opt = &c->opt;
+    else if (!prev) { tl_fallback = options_from_env(); tl_fallback_ready = true; }
     // hipGetLastError() is per THREAD, not per library: the host application (or torch in the tests: pointer-attribute probes of host
     // memory leave "invalid argument" behind) may have left an error that is none of ours.  Every outermost entry of the C ABI starts clean,
     // so that the checks behind our own launches report our own launches.
     if (!prev) (void)hipGetLastError();
 }
 OptScope::~OptScope() { tl_opt = prev; }
+
+static thread_local std::atomic<int> *tl_cancel = nullptr;
+CancelScope::CancelScope(std::atomic<int> *flag) : prev(tl_cancel) { tl_cancel = flag; }
+CancelScope::~CancelScope() { tl_cancel = prev; }
+bool cancel_requested() { return tl_cancel && tl_cancel->load(std::memory_order_acquire) != 0; }
+bool cancel_consume() { return tl_cancel && tl_cancel->exchange(0, std::memory_order_acq_rel) != 0; }
 } // namespace avs
 
 avs::PyramidView avs_ctx::view() const
@@ -175,7 +186,8 @@ avs::PyramidView avs_ctx::view() const
 extern "C" {
 
 const char *avs_last_error(void) { return avs::g_err; }
-const char *avs_version(void) { return "avs-mi355x 0.1 (gfx950)"; }
+const char *avs_version(void) { return "avs-mi355x 0.2 (gfx950)"; }
+int32_t avs_abi_version(void) { return AVS_ABI_VERSION; }
 
 avs_status avs_create(const avs_desc *d, avs_ctx **out)
 {
@@ -469,11 +481,22 @@ avs_status avs_assemble(avs_ctx *c, avs_assembly_info *info)
 
 int32_t avs_spmv_tile_rows(void) { return spmv_tile_rows(); }
 
-avs_status avs_get_matrix_format(avs_ctx *c, avs_matrix_format *fmt)
+avs_status avs_get_matrix_format(avs_ctx *c, avs_matrix_format *out)
 {
     avs::OptScope opt_scope_(c);
-    AVS_REQUIRE(c && fmt, AVS_EINVAL, "null argument");
-    if (!c->system_ready && dist_matrix_format(c, fmt)) return AVS_OK; // avs_dist_assemble: the rank's own rows
+    AVS_REQUIRE(c && out, AVS_EINVAL, "null argument");
+    // the struct has grown between ABI revisions: only the bytes the caller's header knows are written
+    const int32_t size = out->struct_size;
+    AVS_REQUIRE(size >= (int32_t)(offsetof(avs_matrix_format, reordered) + sizeof(int32_t)) && size <= 4096, AVS_EINVAL,
+                "avs_matrix_format.struct_size must be set to sizeof(avs_matrix_format) before the call (got %d)", (int)size);
+    avs_matrix_format f{};
+    avs_matrix_format *fmt = &f;
+    f.struct_size = (int32_t)sizeof(avs_matrix_format);
+    auto hand_over = [&]() {
+        memcpy(out, &f, (size_t)size < sizeof(f) ? (size_t)size : sizeof(f));
+        out->struct_size = size;
+    };
+    if (!c->system_ready && dist_matrix_format(c, fmt)) { hand_over(); return AVS_OK; } // avs_dist_assemble: the rank's own rows
     AVS_REQUIRE(c->system_ready, AVS_ESTATE, "no system: call avs_assemble first");
     const bool vi = c->reordered && c->vi.table_size > 0;
     fmt->reordered = c->reordered ? 1 : 0;
@@ -487,6 +510,9 @@ avs_status avs_get_matrix_format(avs_ctx *c, avs_matrix_format *fmt)
     fmt->brick_patterns = bk ? c->brick.patterns : 0;
     fmt->brick_pattern_rows = bk ? c->brick.regular_rows : 0;
     fmt->brick_bytes = bk ? c->brick.stored_bytes(c->n_vel) : 0;
+    fmt->brick_walk = bk ? c->brick_view.walk : 0;
+    fmt->brick_value_codes = 0;
+    hand_over();
     return AVS_OK;
 }
 
@@ -540,9 +566,9 @@ avs_status avs_set_solver_option(avs_ctx *c, avs_solver_option option, int32_t v
     case AVS_OPTION_PARANOID: c->opt.paranoid = value != 0; return AVS_OK;
     case AVS_OPTION_GRAPH_REPLAY: c->opt.graph = value != 0; return AVS_OK;
     case AVS_OPTION_BRICK_FORM:
-        AVS_REQUIRE(value >= AVS_BRICK_AUTO && value <= AVS_BRICK_ALWAYS, AVS_EINVAL, "brick form must be AUTO, NEVER or ALWAYS");
+        AVS_REQUIRE(value >= AVS_BRICK_AUTO && value <= AVS_BRICK_TUNE, AVS_EINVAL, "brick form must be AUTO, NEVER, ALWAYS or TUNE");
         c->opt.brick = value;
-        c->brick_verdict_rows = 0; // AUTO measures again at the next assembly
+        c->brick_verdict_rows = 0; // decided again at the next assembly
         return AVS_OK;
     case AVS_OPTION_FUSED_SCALAR_STEPS: c->opt.fuse_beta = value != 0; return AVS_OK;
     case AVS_OPTION_RELOAD_ENVIRONMENT: c->opt = options_from_env(); c->brick_verdict_rows = 0; return AVS_OK;
@@ -561,9 +587,18 @@ void narrow_solution_if_f32(avs_ctx *c, double *x, int64_t n)
 } // namespace avs
 } // extern "C++"
 
+avs_status avs_cancel(avs_ctx *c)
+{
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
+    // no HIP call, no lock: this runs on another thread than the solve it ends (the reference polls opInterrupt() the same way, cpp:2528)
+    c->cancel.store(1, std::memory_order_release);
+    return AVS_OK;
+}
+
 avs_status avs_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_info *info)
 {
     avs::OptScope opt_scope_(c);
+    avs::CancelScope cancel_scope_(c ? &c->cancel : nullptr);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->system_ready, AVS_ESTATE, "avs_assemble must succeed before avs_solve");
     AVS_REQUIRE(tol >= 0. && max_iters >= 0, AVS_EINVAL, "tolerance / max_iterations out of range");
@@ -676,6 +711,7 @@ avs_status avs_pcg_csr(int64_t n, const int32_t *row_ptr, const int32_t *col, co
                        double *x, double tol, int32_t max_iters, avs_memspace where, int32_t device, void *stream,
                        avs_solve_info *info)
 {
+    avs::OptScope opt_scope_(nullptr); // context-free entry: the AVS_* environment of this call
     AVS_REQUIRE(n >= 0 && row_ptr && b && x && (n == 0 || (col && val)), AVS_EINVAL, "null argument");
     AVS_REQUIRE(tol >= 0. && max_iters >= 0, AVS_EINVAL, "tolerance / max_iterations out of range");
     int ndev = 0;
@@ -836,6 +872,70 @@ avs_status avs_bench_spmv(avs_ctx *c, int32_t variant, int32_t repeats, double *
     return AVS_OK;
 }
 
+
+namespace {
+__global__ void k_probe_gather(int64_t n, const double *__restrict__ src, const int32_t *__restrict__ idx, double *__restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+__global__ void k_probe_scatter(int64_t n, const double *__restrict__ src, const int32_t *__restrict__ idx, double *__restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[idx[i]] = src[i];
+}
+} // namespace
+
+extern "C++" {
+namespace avs {
+// y = A x through the solver's form (+ the folded partial sums of x.y of the fused-dot instantiation)
+avs_status probe_spmv_form(const CsrView &A, const double *x, double *y, bool fused, double *dot_out, hipStream_t st)
+{
+    if (!fused) return spmv_launch(A, x, y, 0, st);
+    DevBuf<double> partial;
+    size_t np = spmv_partial_elems(A.n);
+    if (A.brick && A.brick->ntiles > 0 && (size_t)brick_partial_count(*A.brick) > np) np = (size_t)brick_partial_count(*A.brick);
+    AVS_TRY(partial.alloc(np));
+    AVS_HIP(hipMemsetAsync(partial.p, 0, np * sizeof(double), st));
+    AVS_TRY(spmv_dot_launch(A, x, y, partial.p, 0, st));
+    if (dot_out) {
+        std::vector<double> h(np);
+        AVS_HIP(hipMemcpyAsync(h.data(), partial.p, np * sizeof(double), hipMemcpyDeviceToHost, st));
+        AVS_HIP(hipStreamSynchronize(st));
+        double s = 0.;
+        for (double v : h) s += v; // (slots the launch did not write are zero)
+        *dot_out = s;
+    }
+    return AVS_OK;
+}
+} // namespace avs
+}
+
+avs_status avs_spmv_solver_form(avs_ctx *c, const double *x, double *y, int32_t fused_dot, double *dot_out)
+{
+    avs::OptScope opt_scope_(c);
+    AVS_REQUIRE(c && x && y, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->system_ready, AVS_ESTATE, "no system: call avs_assemble first");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    const int64_t n = c->n_vel;
+    if (n == 0) return AVS_OK;
+    CsrView A = csr_of(c);
+    const unsigned g = (unsigned)((n + 255) / 256);
+    if (!c->reordered) {
+        AVS_TRY(probe_spmv_form(A, x, y, fused_dot != 0, dot_out, c->stream));
+    } else {
+        DevBuf<double> xp, yp;
+        AVS_TRY(xp.alloc((size_t)n));
+        AVS_TRY(yp.alloc((size_t)n));
+        hipLaunchKernelGGL(k_probe_gather, dim3(g), dim3(256), 0, c->stream, n, x, c->perm.p, xp.p);       // xp[new] = x[perm[new]]
+        AVS_TRY(probe_spmv_form(A, xp.p, yp.p, fused_dot != 0, dot_out, c->stream));
+        hipLaunchKernelGGL(k_probe_scatter, dim3(g), dim3(256), 0, c->stream, n, yp.p, c->perm.p, y);      // y[perm[new]] = yp[new]
+        AVS_HIP(hipGetLastError());
+        AVS_HIP(hipStreamSynchronize(c->stream));
+    }
+    AVS_HIP(hipStreamSynchronize(c->stream));
+    return AVS_OK;
+}
 
 // Measured stream ceilings (mode 0: read-only 16 B/lane, 1: read-only non-temporal, 2: copy) on
 // `bytes` of HBM; returns GB/s of bytes MOVED (copy counts read + write).

@@ -27,6 +27,8 @@
 // One lane sums one row left to right with a multiply and an add per entry (no FMA, -ffp-contract=off): y is bit-identical to the
 // plain CSR kernel.  Reference: Eigen's `mat * p` inside ConjugateGradient (cpp:618-630 of HDK_AdaptiveViscosity.cpp); the row
 // structure is that of cpp:2537-2745.
+#include <mutex>
+
 #include "avs_internal.hpp"
 
 namespace avs {
@@ -439,26 +441,54 @@ size_t brick_lds_bytes(const BrickView &B)
     return (size_t)(kBrickSlotsPad + ((B.table_size + 2) & ~1) + kBrickPark) * sizeof(double) + (size_t)(kBrickPatWords + 8 + kBrickPatMax + 2 * kBrickRowBase) * sizeof(uint32_t);
 }
 
-// persistent grid: as many workgroups as the device keeps resident (queried once per process and device)
+// LDS a workgroup may ask for on this device (the kernel opts in to more than the default 48 KiB, hipFuncSetAttribute below)
+constexpr size_t kBrickLdsLimit = 64 * 1024;
+bool brick_lds_fits(const BrickView &B) { return brick_lds_bytes(B) <= kBrickLdsLimit; }
+
+// persistent grid: as many workgroups as the device keeps resident for THIS LDS size (a larger value table costs a workgroup per CU);
+// queried once per (device, LDS size), guarded: contexts of several host threads share the cache
 static int brick_grid(const BrickView &B, size_t lds)
 {
-    static int cached[64] = {};
+    struct Entry { int dev; size_t lds; int grid; };
+    static std::mutex mu;
+    static std::vector<Entry> cache;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64) dev = 0;
-    if (!cached[dev]) {
-        int per_cu = 0, cus = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_spmv_brick<true>, kBrickBlk, lds);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (per_cu < 1) per_cu = 1;
-        if (cus < 1) cus = 256;
-        cached[dev] = per_cu * cus;
+    int g = 0;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (const Entry &e : cache)
+            if (e.dev == dev && e.lds == lds) g = e.grid;
+        if (!g) {
+            int per_cu = 0, cus = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_spmv_brick<true>, kBrickBlk, lds);
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            if (per_cu < 1) per_cu = 1;
+            if (cus < 1) cus = 256;
+            g = per_cu * cus;
+            cache.push_back(Entry{dev, lds, g});
+        }
     }
-    int g = cached[dev];
 #ifdef AVS_PROBES
     if (const char *e = getenv("AVS_BRICK_GRID")) g = atoi(e) > 0 ? atoi(e) : g;
 #endif
     return g < B.ntiles ? g : B.ntiles;
+}
+
+// the kernel's dynamic LDS limit is a per-device attribute of the loaded code object: raised once per device
+static avs_status brick_raise_lds_limit()
+{
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done[dev]) return AVS_OK;
+    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
+    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
+    done[dev] = true;
+    return AVS_OK;
 }
 
 #ifdef AVS_PROBES
@@ -496,12 +526,9 @@ avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, dou
 {
     if (B.ntiles <= 0) return AVS_OK;
     const size_t lds = brick_lds_bytes(B);
-    static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
-        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        attr_set = true;
-    }
+    AVS_REQUIRE(lds <= kBrickLdsLimit, AVS_EINTERNAL, "brick form: %zu bytes of LDS per workgroup exceed the limit (value table of %d entries)", lds,
+                B.table_size);
+    AVS_TRY(brick_raise_lds_limit());
     const int grid = brick_grid(B, lds);
 #ifdef AVS_PROBES
     static const int dbg = getenv("AVS_BRICK_DEBUG") ? atoi(getenv("AVS_BRICK_DEBUG")) : 0; // phase switches / stamps (measurement builds only)

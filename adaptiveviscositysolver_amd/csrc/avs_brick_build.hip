@@ -731,6 +731,22 @@ void BrickForm::clear()
     patterns = 0;
 }
 
+void BrickScratch::release()
+{
+    geo.release(); row_hash.release();
+    first.release(); bidx.release(); scan_tmp.release(); bstart.release(); bbrick.release(); run_first.release(); run_id.release();
+    run_start.release(); tcount.release(); tile0.release(); rep.release(); slot_id.release(); pat_rep.release(); pat_off.release();
+    row_pid.release(); slen.release(); sstart.release(); tile_nprow.release();
+    ewords.release(); rgeo.release(); eslot.release(); keys.release(); total.release(); counters.release(); tiles.release(); force_e.release();
+}
+
+void BrickForm::release()
+{
+    clear();
+    tile_blk.release(); rdesc.release(); sdesc.release(); blocks.release(); pwords.release(); swords.release(); ownslot.release();
+    scratch.release();
+}
+
 int64_t BrickForm::stored_bytes(int64_t n) const
 {
     // descriptor blocks (used words), row descriptors 8 B, own slots 2 B per row, streamed words + descriptors, pattern table, tile list
@@ -765,6 +781,11 @@ avs_status build_brick_form(avs_ctx *c)
     if (n <= 0 || !c->reordered || vi.tile_tables || !vi.codes.p) return AVS_OK; // one dictionary; packed, windowed or 6-B columns
     const bool wide = vi.col_bits <= 0 || vi.col_windows; // no (code << col_bits | column) stream to copy the streamed rows from
     if (vi.table_size <= 0 || vi.table_size + 1 >= kBrickTableMax) return AVS_OK; // (one code is reserved for 0.0)
+    {
+        BrickView probe;
+        probe.table_size = vi.table_size;
+        if (!brick_lds_fits(probe)) return AVS_OK; // the value table next to the lattice would exceed a workgroup's LDS: the word stream serves this matrix
+    }
     if (c->brick_shift != 3 || c->desc.levels < 1) return AVS_OK;
     if (c->desc.nx > 1024 || c->desc.ny > 1024 || c->desc.nz > 1024 || nnz >= (1ll << 31)) return AVS_OK;
     hipStream_t st = c->stream;

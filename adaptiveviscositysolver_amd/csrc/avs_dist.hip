@@ -1754,6 +1754,7 @@ avs_status avs_dist_get_overlap_tiles(avs_ctx *c, int32_t *interior, int32_t *bo
 avs_status avs_dist_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_info *info)
 {
     avs::OptScope opt_scope_(c);
+    avs::CancelScope cancel_scope_(c ? &c->cancel : nullptr);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->dist && c->dist->partitioned, AVS_ESTATE, "call avs_dist_partition first");
     AVS_REQUIRE(tol >= 0. && max_iters >= 0, AVS_EINVAL, "tolerance / max_iterations out of range");

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -83,7 +84,8 @@ struct Options {
     int transport = 0;           // AVS_DIST_TRANSPORT: 0 auto (direct after its self-test, else RCCL), 1 rccl, 2 direct
     int paranoid = 0;            // AVS_DIST_PARANOID: per-round halo checksums
     int graph = 1;               // AVS_PCG_GRAPH: hipGraph replay of iteration chunks
-    int brick = -1;              // AVS_BRICK: brick-structured SpMV form: -1 auto (systems >= kBrickMinSystemRows), 0 never, 1 always
+    int brick = -1;              // AVS_BRICK: brick-structured SpMV form: -1 auto (systems >= kBrickMinSystemRows; decided by the fill rule), 0 never,
+                                 // 1 always, 2 tune (auto, but decided by timing both forms at the assembly: not reproducible from run to run)
     // storage forms of the solve matrix
     int brick_interleave = 1, brick_shift = 3, value_index = 1, value_pack = 1, tile_tables = 1, column_windows = 1;
     double brick_min_regular = 0.6;
@@ -108,6 +110,17 @@ struct OptScope { // RAII: the options of `c` are the current ones on this threa
     OptScope &operator=(const OptScope &) = delete;
     const Options *prev;
 };
+
+// avs_cancel: the request word of the context whose solve runs on this thread; the PCG loops poll it where they poll the device state
+struct CancelScope {
+    explicit CancelScope(std::atomic<int> *flag);
+    ~CancelScope();
+    CancelScope(const CancelScope &) = delete;
+    CancelScope &operator=(const CancelScope &) = delete;
+    std::atomic<int> *prev;
+};
+bool cancel_requested();   // a request is pending for the running solve (not consumed)
+bool cancel_consume();     // ... and taken: the loop that sees true ends now
 
 // ---------------------------------------------------------------------------------------------
 // device buffer with explicit lifetime (hipMalloc/hipFree), sized in elements
@@ -261,6 +274,7 @@ constexpr int kBrickPatLen = 64;      // longest row stored as a pattern
 constexpr int kBrickTableMax = 2048;  // value dictionary entries (LDS resident)
 constexpr int kBrickMinRows = 64;     // bricks with fewer rows are merged into E tiles
 constexpr int64_t kBrickMinSystemRows = 2000000; // smaller systems run the CU-resident loop (or are launch-bound): the form is not built
+constexpr double kBrickMinFill = 330., kBrickEighthsFill = 420.; // rows per tile: the form beats the word stream / the contiguous-eighths walk beats the dealt chunks
 constexpr int kBrickETileRows = 256;   // rows per E tile: its words fit one pass of the lattice's LDS (3936) unless the rows are long
 struct BrickView {
     int ntiles = 0;
@@ -279,6 +293,7 @@ struct BrickView {
 };
 // the form's arrays, owned by the context next to the CSR / value index of the solve matrix (avs_brick_build.hip)
 struct BrickScratch { // build-time buffers, kept across frames
+    void release();
     DevBuf<uint64_t> geo, row_hash;
     DevBuf<int32_t> first, bidx, scan_tmp, bstart, bbrick, run_first, run_id, run_start, tcount, tile0, rep, slot_id, pat_rep, pat_off, row_pid, slen, sstart, tile_nprow;
     DevBuf<uint32_t> ewords, rgeo;
@@ -298,11 +313,13 @@ struct BrickForm {
     int64_t regular_rows = 0, streamed_words = 0, block_words = 0, pattern_words = 0, streamed_rows = 0;
     bool ready = false;
     bool wide = false;    // streamed words are 64 bits (column | code << 32)
-    void clear();
+    void clear();   // not ready; buffers stay for the next build
+    void release(); // + every buffer and the build scratch freed (a matrix the form does not serve)
     void view(BrickView &B, const ValueIndex &vi) const;
     int64_t stored_bytes(int64_t n) const; // what one SpMV launch reads of the matrix
 };
 size_t brick_lds_bytes(const BrickView &B);
+bool brick_lds_fits(const BrickView &B);          // the workgroup's LDS (lattice + value table + pattern image) within the device's limit
 avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, double *partial, const int *done_flag, hipStream_t stream);
 int brick_partial_count(const BrickView &B);   // partial sums the fused-dot launch writes (one per persistent workgroup)
 
@@ -489,6 +506,7 @@ struct avs_ctx {
     };
     Field centerw, edgew[3], facew[3], visc, dens, vel[3], solidvel[3];
     avs::Options opt;   // switches: environment defaults taken at avs_create, avs_set_solver_option afterwards
+    std::atomic<int> cancel{0}; // avs_cancel: set by any thread, consumed by the solve loop that sees it
     int64_t n_vel = -1, n_edge = -1, n_center = -1;
     int no_precond = 0; // avs_set_solver_option(AVS_OPTION_PRECONDITIONER, AVS_PRECONDITIONER_NONE)
 

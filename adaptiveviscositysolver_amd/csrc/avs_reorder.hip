@@ -143,18 +143,32 @@ avs_status build_reordered_system(avs_ctx *c, int brick_shift)
     c->reordered = true;
     // systems too large for the CU-resident loop: the brick-structured form of the matrix (avs_brick.hip); AVS_BRICK=0 / 1 never / always
     c->brick.clear();
-    int want = n >= kBrickMinSystemRows ? 1 : 0;
-    if (c->opt.brick >= 0) want = c->opt.brick;
-    // AUTO: the form is kept only where it is FASTER than the word stream on this matrix, and its tile walk (BrickView::walk) is the faster
-    // of the two.  That is measured -- three launches each -- once per context and matrix size (a fat volume with ~490 rows per shell
-    // brick: 0.7x the stream's time, contiguous eighths; a thin sheet with ~340: 0.87x with interleaved chunks, 1.2x without); a
-    // simulation's next frames reuse the verdict (and do not build a form that lost) until the row count has moved by more than 10 %.
-    const bool autosel = c->opt.brick < 0 && want;
+    const int mode = c->opt.brick; // -1 auto, 0 never, 1 always, 2 tune
+    int want = (mode == 0) ? 0 : (mode == 1 ? 1 : (n >= kBrickMinSystemRows ? 1 : 0));
+    // AUTO keeps the form where it multiplies faster than the word stream, and picks its tile walk (BrickView::walk).  Both follow from
+    // a STRUCTURAL rule -- rows per tile -- so that the same input gives the same kernel, the same fold order of p.Ap and therefore the
+    // same iteration count and solution bits in every run, with or without a profiler attached (round-4 review: the choice used to be
+    // a three-launch stopwatch).  The rule is what the undisturbed timings of round 4 correlate with (profiles/r04_brick_spmv.md,
+    // section 7): the cost is per tile, so the form wins where tiles are full (fat volume, ~490 rows per shell brick: 0.7x the
+    // stream's time; thin sheets, ~330-340: 0.87x) and the contiguous-eighths walk wins where every eighth holds the same mix of tiles
+    // (fat volumes).  AVS_BRICK_TUNE (mode 2) restores the measurement for experiments.  A simulation's next frames reuse the verdict
+    // (and do not build a form that lost) until the row count has moved by more than 10 %.
+    const bool autosel = (mode < 0 || mode == 2) && want;
     const bool cached = c->brick_verdict_rows > 0 && std::llabs(n - c->brick_verdict_rows) * 10 <= c->brick_verdict_rows;
     if (autosel && cached && !c->brick_verdict) want = 0;
     if (want) AVS_TRY(build_brick_form(c));
     c->brick.view(c->brick_view, c->vi);
-    if (want && c->brick.ready && !cached) { // (forced form: the walk is still measured)
+    if (want && c->brick.ready) {
+        const double fill = (double)n / (double)c->brick.ntiles;
+        if (autosel) c->brick_verdict = fill >= kBrickMinFill ? 1 : 0;
+        else c->brick_verdict = 1;
+        c->brick_walk = fill >= kBrickEighthsFill ? 0 : 1;
+        c->brick_verdict_rows = n;
+    } else if (want && autosel) { // not regular enough / too many values / a limit: remembered like a lost comparison
+        c->brick_verdict = 0;
+        c->brick_verdict_rows = n;
+    }
+    if (mode == 2 && want && c->brick.ready && !cached) { // measurement instead of the rule (three launches each; host-synchronous)
         AVS_TRY(c->brick_tune_y.reserve((size_t)n));
         CsrView A;
         A.n = n;
@@ -164,37 +178,33 @@ avs_status build_reordered_system(avs_ctx *c, int brick_shift)
         A.val = c->p_val.p;
         c->vi.apply(A);
         double ms[3] = {0., 0., 0.}; // word stream, brick form walk 0, walk 1
-        for (int form = autosel ? 0 : 1; form < 3; ++form) {
+        bool launched = true;
+        for (int form = 0; form < 3 && launched; ++form) {
             BrickView V = c->brick_view;
             V.walk = form - 1;
             auto launch = [&]() -> avs_status {
                 return form ? spmv_brick_launch(V, c->p_x0.p, c->brick_tune_y.p, nullptr, nullptr, st)
                             : spmv_launch(A, c->p_x0.p, c->brick_tune_y.p, 0, st);
             };
-            AVS_TRY(launch()); // (first touch, kernel load)
+            if (launch() != AVS_OK) { launched = false; break; } // (first touch, kernel load)
             Timer t(st);
             t.start();
-            for (int r = 0; r < 3; ++r) AVS_TRY(launch());
+            for (int r = 0; r < 3 && launched; ++r) launched = launch() == AVS_OK;
             ms[form] = t.stop() / 3;
         }
-        c->brick_walk = ms[2] < 0.97 * ms[1] ? 1 : 0; // (the contiguous eighths win the loop by more than they win a stand-alone launch)
-        const double best = c->brick_walk ? ms[2] : ms[1];
-        c->brick_verdict = autosel ? (best < 0.92 * ms[0] ? 1 : 0) : 1;
-        // A profiler that adds milliseconds to every dispatch (counter collection) makes the timings equal: when the word stream
-        // appears to run below 0.5 TB/s the measurement is not one, and the verdict comes from what the measurements of undisturbed runs
-        // correlate with -- how full the tiles are (profiles/r04_brick_spmv.md, section 7).
-        const double stream_bytes = 4. * (double)nnz + 20. * (double)n;
-        if (autosel && ms[0] * 1e-3 > stream_bytes / 0.5e12) {
-            const double fill = (double)n / (double)c->brick.ntiles;
-            c->brick_verdict = fill >= 330. ? 1 : 0;
-            c->brick_walk = fill >= 420. ? 0 : 1;
+        if (launched) {
+            c->brick_walk = ms[2] < 0.97 * ms[1] ? 1 : 0; // (the contiguous eighths win the loop by more than they win a stand-alone launch)
+            const double best = c->brick_walk ? ms[2] : ms[1];
+            c->brick_verdict = best < 0.92 * ms[0] ? 1 : 0;
+            c->brick_tune_ms[0] = ms[0];
+            c->brick_tune_ms[1] = best;
+        } else {
+            (void)hipGetLastError();
+            c->brick_verdict = 0; // a form that cannot be launched here loses; the word stream serves the matrix
         }
-        c->brick_verdict_rows = n;
-        c->brick_tune_ms[0] = ms[0];
-        c->brick_tune_ms[1] = best;
     }
-    if (autosel && c->brick.ready && !c->brick_verdict) { // the word stream is the faster form for this matrix
-        c->brick.clear();
+    if (autosel && !c->brick_verdict) { // the word stream is the form for this matrix: nothing of the brick form stays allocated
+        c->brick.release();
         c->brick.view(c->brick_view, c->vi);
     }
     c->brick_view.walk = c->brick_walk;

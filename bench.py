@@ -9,11 +9,16 @@ including reductions and, multi-GPU, halo + all-reduce)".  The system is assembl
 "assembly_ms" / "hot_path_ms" (= assembly + one solve).  Inputs are synthesised in HBM.
 
   metric  : CG iterations per second (whole job) -- BASELINE.json "CG iterations/sec + SpMV GB/s"
-  roofline: the SpMV kernel, algorithmic bytes 12*nnz + 4*(n+1) + 16*n per launch (SURVEY.md 8(d):
-            fp64 value + int32 column) over the mean HIP-event duration of the SpMV launches inside
-            the timed solves; peak = 8 TB/s HBM (MI355X_MICROARCH.md).  The solver streams a LOSSLESS
-            compressed form of the matrix (DESIGN.md 5), so "achieved" is an effective rate;
-            "stored_*" are the bytes the kernel really has to move.
+  roofline: the SpMV kernel against the HBM roofline (peak = 8 TB/s, MI355X_MICROARCH.md).  "achieved" / "frac"
+            are PHYSICAL: the bytes the kernel moves per launch -- the PMC traffic (FETCH_SIZE + WRITE_SIZE passes,
+            corrected as the guide prescribes) when profiles/spmv_counters.json holds a record taken with THIS source
+            tree, else the bytes it has to read at least once ("stored": the lossless compressed form of the matrix
+            + x + y, a lower bound of the traffic) -- over the mean HIP-event duration of the SpMV launches inside
+            the timed solves; frac <= 1 by construction.  "effective_gbps" is SURVEY.md 8(d)'s algorithmic figure
+            (12*nnz + 4*(n+1) + 16*n: fp64 value + int32 column per non-zero) over the same time: an equivalent
+            rate for comparisons with 12-B CSR kernels, NOT a fraction of anything (the matrix is read in 1-4 B
+            per non-zero).  "binding" names the resource that actually limits the kernel, from the SQ counters
+            of the same record (the brick kernel: VALU issue), or null when no record matches.
   cpu_baseline: the CPU oracle's PCG (port of the Eigen algorithm) on the same CSR system, run in a
             clean subprocess on the host cores of this box (rank 0, N=1 only): both SURVEY 8(d)
             variants, "eigen_faithful" (parallel SpMV, serial vector ops) and "all_parallel".  Its "assembly" entry is
@@ -164,9 +169,31 @@ def cpu_baseline(solver, tol, budget_s, asm_scene=None):
                   f"{ef['spmv_gbps']:.0f} GB/s (SURVEY 8(d) bytes) on {threads} threads"}
 
 
-def spmv_rates(n, nnz, fmt, mean_spmv_ms):
-    """SURVEY 8(d) rate (12 B per non-zero) and the physical rate of the stored stream for one SpMV launch of `mean_spmv_ms`"""
-    bytes_spmv = 12 * nnz + 4 * (n + 1) + 16 * n
+_COUNTERS = None
+
+
+def counter_record(n, nnz, brick, bpn, tile_tables):
+    """PMC record of this workload's SpMV kernel taken with THIS source tree (profiles/spmv_counters.json, written by
+    tools/profile_r05.sh from separate rocprofv3 --pmc passes), else None: counters of another binary describe another kernel."""
+    global _COUNTERS
+    if _COUNTERS is None:
+        _COUNTERS = []
+        try:
+            from adaptiveviscositysolver_amd import capi
+            mine = capi.source_fingerprint()
+            recs = json.load(open(os.path.join(ROOT, "profiles", "spmv_counters.json")))
+            _COUNTERS = [r for r in recs if r.get("source_sha16") == mine]
+        except Exception:
+            _COUNTERS = []
+    for r in _COUNTERS:
+        if (r.get("n") == n and r.get("nnz") == nnz and bool(r.get("brick", False)) == bool(brick) and r.get("bytes_per_nonzero", 12) == bpn
+                and bool(r.get("tile_local_tables", False)) == bool(tile_tables)):
+            return r
+    return None
+
+
+def stored_bytes_of(n, nnz, fmt):
+    """what one SpMV launch has to read / write at least once: the stored form of the matrix + x + y"""
     bpn = int(fmt.bytes_per_nonzero)
     stored = bpn * nnz + 4 * (n + 1) + 16 * n
     if int(fmt.tile_local_tables):   # + the tile dictionaries (8 B per entry) and their offsets
@@ -175,36 +202,79 @@ def spmv_rates(n, nnz, fmt, mean_spmv_ms):
         stored += 256 * ((n + 511) // 512)
     if int(getattr(fmt, "brick_tiles", 0)):   # brick-structured form: what the kernel reads of the matrix + x and y
         stored = int(fmt.brick_bytes) + 16 * n
+    return stored
+
+
+def spmv_roofline(n, nnz, fmt, mean_spmv_ms, kernel=None, rows_local=None, nnz_local=None):
+    """The SpMV launch against the HBM roofline, physical bytes only (frac <= 1 by construction), + SURVEY 8(d)'s effective rate and
+    the resource that binds according to the counters of this source tree (module docstring)."""
+    nl, zl = (rows_local or n), (nnz_local or nnz)
+    alg = 12 * zl + 4 * (nl + 1) + 16 * nl
+    bpn = int(fmt.bytes_per_nonzero)
+    brick = int(getattr(fmt, "brick_tiles", 0)) > 0
+    stored = stored_bytes_of(nl, zl, fmt)
     t = mean_spmv_ms * 1e-3
-    return {"algorithmic_bytes_per_launch": bytes_spmv, "stored_bytes_per_launch": stored, "mean_launch_us": mean_spmv_ms * 1e3,
-            "frac": (bytes_spmv / t / 1e9 / HBM_PEAK_GBPS) if t > 0 else None,
-            "stored_frac": (stored / t / 1e9 / HBM_PEAK_GBPS) if t > 0 else None,
-            "format": f"{bpn} B/nnz" + (", tile dictionaries" if int(fmt.tile_local_tables) else f", {int(fmt.value_table_size)}-entry dictionary"
-                                        if int(fmt.value_table_size) else "") + (", windowed columns" if int(fmt.column_windows) else "")}
+    rec = counter_record(n, nnz, brick, bpn, int(fmt.tile_local_tables)) if rows_local is None else None
+    traffic = rec.get("hbm_bytes_per_launch") if rec else None
+    phys = traffic if traffic else stored
+    achieved = phys / t / 1e9 if t > 0 else 0.0
+    form = (f"brick-structured form, {(stored - 16 * nl) / max(1, zl):.2f} B/nnz" if brick else f"{bpn} B/nnz" +
+            (", tile dictionaries" if int(fmt.tile_local_tables) else f", {int(fmt.value_table_size)}-entry dictionary" if int(fmt.value_table_size) else "") +
+            (", windowed columns" if int(fmt.column_windows) else ""))
+    out = {"bound": "hbm", "kernel": kernel or form, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBPS,
+           "achieved_basis": ("PMC traffic of this source tree" if traffic else
+                              "stored bytes (matrix form + x + y: what the kernel reads / writes at least once, a lower bound of the traffic; "
+                              "no PMC record of this source tree under profiles/)"),
+           "traffic": traffic, "traffic_source": (rec.get("source") if rec else None),
+           "stored_bytes_per_launch": stored, "stored_gbps": stored / t / 1e9 if t > 0 else None,
+           "stored_frac": stored / t / 1e9 / HBM_PEAK_GBPS if t > 0 else None,
+           "algorithmic_bytes_per_launch": alg, "effective_gbps": alg / t / 1e9 if t > 0 else None,
+           "effective_note": "SURVEY 8(d) bytes (12 B per non-zero) over the launch time: an equivalent rate for comparison with 12-B CSR "
+                             "kernels; the matrix is read in a lossless compressed form, so this is not a fraction of the HBM peak",
+           "mean_launch_us": mean_spmv_ms * 1e3, "format": form,
+           "brick_form": ({"tiles": int(fmt.brick_tiles), "patterns": int(fmt.brick_patterns), "pattern_rows": int(fmt.brick_pattern_rows),
+                           "matrix_bytes": int(fmt.brick_bytes), "walk": int(getattr(fmt, "brick_walk", 0)),
+                           "value_codes": int(getattr(fmt, "brick_value_codes", 0))} if brick else None),
+           "value_table_size": int(fmt.value_table_size), "tile_local_tables": bool(fmt.tile_local_tables), "column_windows": bool(fmt.column_windows),
+           "binding": None}
+    if rec and rec.get("valu_issue_frac") is not None:
+        out["binding"] = {"resource": rec.get("binding_resource", "valu_issue"), "frac": rec["valu_issue_frac"],
+                          "valu_wave_instructions_per_launch": rec.get("valu_wave_instructions_per_launch"),
+                          "wait_frac": rec.get("wait_frac"), "lds_bank_conflict_frac_of_lds_active": rec.get("lds_bank_conflict_frac_of_lds_active"),
+                          "kernel_us_rocprof": rec.get("mean_kernel_us_rocprof"),
+                          "source": rec.get("source"), "source_sha16": rec.get("source_sha16")}
+    return out
 
 
 def resident_roofline(n, nnz, iterations, solve_ms):
     """The CU-resident loop has no separate SpMV launch: one cooperative launch runs the whole solve with the matrix words in the
-    register files.  `achieved` is the SURVEY 8(d) figure of ONE iteration's product (12 B per non-zero + row pointers + x + y)
-    over the time of a whole iteration -- an effective rate, the matrix never crosses the HBM pins -- and the counter fractions of
-    the same workload (an EARLIER run: profiles/r04_resident_pmc.json) say what bounds it: waves wait ~0.83 of their cycles
-    (flags, reduction slots, the remote-column fill), the SIMDs issue VALU 0.17-0.19 of the time, HBM moves <= 0.1 of its peak."""
+    register files; only the row-local streams (x, w, and s / p / r of the slices that do not fit the LDS) cross the HBM pins.
+    `achieved` is therefore small by design: the PMC upper bound of the bytes one iteration moves when a record of this workload
+    exists, else the streams the plan keeps in global memory at least (x read + write, w write + read: 32 B per row); `binding` says
+    what limits the loop instead: the latency chain of an iteration (waves wait ~0.83 of their cycles)."""
     alg = 12 * nnz + 4 * (n + 1) + 16 * n
     t = solve_ms * 1e-3 / max(1, iterations)
-    rec = {"bound": "hbm", "kernel": "k_cg_resident (whole PCG iteration; no separate SpMV launch)", "achieved": alg / t / 1e9 if t > 0 else 0.0,
-           "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (alg / t / 1e9 / HBM_PEAK_GBPS) if t > 0 else 0.0, "traffic": None,
-           "algorithmic_bytes_per_iteration": alg, "us_per_iteration": t * 1e6,
-           "note": "effective rate of a whole iteration (12 B per non-zero by SURVEY 8(d)); the loop is latency-bound, not bandwidth- or issue-bound"}
+    phys, basis, pmc, src = 32 * n, "x and w streams (32 B per row: a lower bound of what one iteration moves)", None, None
     prof = os.path.join(ROOT, "profiles", "r04_resident_pmc.json")
     try:
         for w in json.load(open(prof))["workloads"]:
             if w["n"] == n and w["nnz"] == nnz:
-                rec["traffic"] = w["hbm_bytes_per_iteration_upper"]
-                rec["pmc"] = {k: w[k] for k in ("valu_issue_frac", "wait_frac", "lds_bank_conflict_frac_of_lds_active", "per_wave_per_iteration")}
-                rec["pmc_source"] = "profiles/r04_resident_pmc.json (rocprofv3 --pmc passes of an EARLIER 96-iteration run of this workload, not of this process)"
+                phys = w["hbm_bytes_per_iteration_upper"]
+                basis = "PMC upper bound per iteration (one-time matrix load included) of the round-4 binary"
+                pmc = {k: w[k] for k in ("valu_issue_frac", "wait_frac", "lds_bank_conflict_frac_of_lds_active", "per_wave_per_iteration")}
+                src = "profiles/r04_resident_pmc.json (rocprofv3 --pmc passes of a round-4 run of this workload: not this source tree, not this process)"
     except Exception:
         pass
-    return rec
+    achieved = phys / t / 1e9 if t > 0 else 0.0
+    return {"bound": "hbm", "kernel": "k_cg_resident (whole PCG iteration; no separate SpMV launch)", "achieved": achieved,
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "achieved_basis": basis, "traffic": None,
+            "algorithmic_bytes_per_iteration": alg, "effective_gbps": alg / t / 1e9 if t > 0 else None,
+            "effective_note": "SURVEY 8(d) bytes of one product over the time of a whole iteration: an equivalent rate (the matrix never "
+                              "crosses the HBM pins), not a fraction of the HBM peak",
+            "us_per_iteration": t * 1e6,
+            "binding": {"resource": "latency (update -> producer flags -> remote fill -> walk -> reduction slots -> broadcast)",
+                        "frac": (pmc or {}).get("wait_frac"), "pmc": pmc, "source": src}}
 
 
 def extra_workload(label, sc, local_rank, tol, max_iters):
@@ -240,7 +310,7 @@ def extra_workload(label, sc, local_rank, tol, max_iters):
            "resident_loop": bool(infos[0].resident),   # CU-resident PCG (one cooperative launch; no separate SpMV launch to time)
            "value": iters / el, "unit": "iter/s", "ms_per_step": el / 2 * 1e3, "first_solve_ms": first_solve_ms, "assembly_wall_ms": asm_ms,
            "prepass_ms": pinfo.weights_ms + pinfo.octree_ms + pinfo.classify_ms + pinfo.number_ms,
-           "roofline": (spmv_rates(int(ai.n_velocity), int(ai.nnz), s.matrix_format(), sum(i.spmv_ms for i in infos) / 2)
+           "roofline": (spmv_roofline(int(ai.n_velocity), int(ai.nnz), s.matrix_format(), sum(i.spmv_ms for i in infos) / 2, s.spmv_kernel_name())
                         if infos[0].spmv_ms > 0 else
                         resident_roofline(int(ai.n_velocity), int(ai.nnz), iters // 2, el / 2 * 1e3) if infos[0].resident else None)}
     try:   # post-solve transfer to the regular MAC grid (cpp:655-707), second call timed
@@ -266,7 +336,8 @@ def extra_workload(label, sc, local_rank, tol, max_iters):
             torch.cuda.synchronize()
             el2 = time.perf_counter() - t0
             rec["launch_per_phase"] = {"value": sum(i.iterations for i in inf2) / el2, "unit": "iter/s",
-                                       "roofline": spmv_rates(int(ai.n_velocity), int(ai.nnz), s.matrix_format(), sum(i.spmv_ms for i in inf2) / 2)}
+                                       "roofline": spmv_roofline(int(ai.n_velocity), int(ai.nnz), s.matrix_format(), sum(i.spmv_ms for i in inf2) / 2,
+                                                                 s.spmv_kernel_name())}
         finally:
             s.set_solver_option(_c.OPTION_RESIDENT_LOOP, 1)
     s.close()
@@ -553,36 +624,14 @@ def main():
     if rank == 0:
         ai = dist_info if use_dist else solver.info()
         n, nnz = int(ai.n_velocity), (nnz_total if use_dist else int(ai.nnz))
-        bytes_spmv = 12 * nnz + 4 * (n + 1) + 16 * n          # whole system (all ranks together)
         mean_spmv_ms = float(np.mean(spmv_ms))
-        # per-launch algorithmic bytes on THIS rank's block of rows
-        local_bytes = float(solver.local_spmv_bytes) if use_dist else bytes_spmv
-        achieved = local_bytes / (mean_spmv_ms * 1e-3) / 1e9 if mean_spmv_ms > 0 else 0.0
         fmt = solver.matrix_format()
-        bpn = int(fmt.bytes_per_nonzero)
-        stored_bytes = local_bytes - (12 - bpn) * (local_bytes - 4 * (n + 1) - 16 * n) / 12.0 if not use_dist else None
-        if stored_bytes and int(fmt.tile_local_tables):   # + the tile dictionaries (8 B per entry) and their offsets
-            stored_bytes += 8 * int(fmt.value_table_size) + 4 * ((n + 511) // 512 + 1)
-        if stored_bytes and int(fmt.column_windows):      # + 64 window bases per tile
-            stored_bytes += 256 * ((n + 511) // 512)
-        brick = int(getattr(fmt, "brick_tiles", 0)) > 0 and not use_dist
-        if brick:                                         # brick-structured form: descriptors + pattern lists + words, x and y
-            stored_bytes = float(int(fmt.brick_bytes) + 16 * n)
-        stored_rate = stored_bytes / (mean_spmv_ms * 1e-3) / 1e9 if stored_bytes and mean_spmv_ms > 0 else None
-        kernel = solver.spmv_kernel_name() if hasattr(solver, "spmv_kernel_name") else f"{bpn} B/nnz"
-        traffic, traffic_source = None, None
-        prof = os.path.join(ROOT, "profiles", "spmv_traffic.json")
-        if os.path.exists(prof):
-            try:
-                recs = json.load(open(prof))
-                for rec in (recs if isinstance(recs, list) else [recs]):
-                    if (traffic is None and "superseded_by" not in rec and rec.get("n") == n and rec.get("nnz") == nnz and
-                            bool(rec.get("brick", False)) == brick and rec.get("bytes_per_nonzero", 12) == bpn and bool(rec.get("tile_local_tables", False)) == bool(fmt.tile_local_tables)):
-                        traffic = rec.get("hbm_bytes_per_launch")
-                        traffic_source = ("profiles/spmv_traffic.json <- " + str(rec.get("source", "?")) +
-                                          " (PMC passes of an EARLIER run of this workload, not of this process)")
-            except Exception:
-                traffic = None
+        kernel = solver.spmv_kernel_name() if hasattr(solver, "spmv_kernel_name") else None
+        if use_dist:   # THIS rank's block of rows
+            sz = solver.plan_sizes
+            roof = spmv_roofline(n, nnz, fmt, mean_spmv_ms, kernel, rows_local=int(sz.n_own), nnz_local=int(sz.nnz_local))
+        else:
+            roof = spmv_roofline(n, nnz, fmt, mean_spmv_ms, kernel)
         out = {
             "metric": "cg_iterations_per_sec",
             "value": iters_total / elapsed,
@@ -600,19 +649,7 @@ def main():
                        "baseline_config": a.config,
                        "n_dofs": n, "nnz": nnz, "cg_iterations_per_step": iters_total // a.steps,
                        "parallelism": (f"slab x{world}, distributed assembly" if use_dist else "single")},
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_launch": local_bytes, "mean_launch_us": mean_spmv_ms * 1e3,
-                         "frac_of_achievable_6290": achieved / 6290.0,
-                         "stored_bytes_per_nonzero": (stored_bytes - 16 * n) / nnz if brick else bpn, "stored_bytes_per_launch": stored_bytes,
-                         "brick_form": ({"tiles": int(fmt.brick_tiles), "patterns": int(fmt.brick_patterns), "pattern_rows": int(fmt.brick_pattern_rows),
-                                         "matrix_bytes": int(fmt.brick_bytes)} if brick else None),
-                         "stored_rate_gbps": stored_rate,
-                         "stored_frac": (stored_rate / HBM_PEAK_GBPS) if stored_rate else None,
-                         "value_table_size": int(fmt.value_table_size), "tile_local_tables": bool(fmt.tile_local_tables), "column_windows": bool(fmt.column_windows),
-                         "note": "achieved/frac follow SURVEY 8(d) (12 B per non-zero); the matrix is read in a lossless "
-                                 + ("brick-structured form (one 8-B descriptor per pattern row)" if brick else f"{bpn}-B form") +
-                                 ", so frac is an effective rate and may exceed 1 -- stored_* is the physical stream"},
+            "roofline": roof,
             "solve_event_iter_per_s": iters_total / (sum(solve_ms) * 1e-3),
             "assembly_ms": {"stencils": ai.stencil_ms, "initial_guess": ai.guess_ms, "system": ai.system_ms,
                             "wall": assemble_wall_ms},

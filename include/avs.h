@@ -112,7 +112,7 @@ typedef struct {
                            vector slices in LDS -- systems of up to ~1 M rows (~1.9 M with the rows that do not fit streamed from memory) in the packed
                            single-dictionary form, single-GPU solves and
                            partitioned solves whose rank has its GPU for itself; AVS_CG_RESIDENT=0 keeps the launch-per-phase loops) */
-    int32_t reserved;
+    int32_t cancelled;  /* 1 = avs_cancel ended the loop before convergence / max_iterations (converged is 0; x holds the last iterate) */
 } avs_solve_info;
 
 typedef struct {
@@ -126,6 +126,10 @@ typedef struct avs_ctx avs_ctx;
 
 const char *avs_last_error(void);
 const char *avs_version(void);
+/* ABI revision of this header: bumped whenever a struct layout or the set of exported entries changes (2: round 5 -- avs_matrix_format
+ * carries struct_size, avs_solve_info.cancelled, avs_cancel; the measurement entries moved to libavs_probe.so in round 4). */
+#define AVS_ABI_VERSION 2
+int32_t avs_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
  * Context.  Replaces the stack-allocated temporaries of solveGasSubclass (cpp:429-470, 507-551).
@@ -163,6 +167,13 @@ avs_status avs_assemble(avs_ctx *ctx, avs_assembly_info *info /* may be NULL */)
  * with DiagonalPreconditioner, solveWithGuess(rhs, restrictedVelocity) (cpp:618-630).
  * ---------------------------------------------------------------------------------------- */
 avs_status avs_solve(avs_ctx *ctx, double tolerance, int32_t max_iterations, avs_solve_info *info);
+/* User interrupt: the reference polls UT_Interrupt::opInterrupt() inside its loops (cpp:2528; HDK_OctreeGrid.cpp:584-588).  Callable from
+ * ANY thread while another thread is inside avs_solve / avs_dist_solve on the same context: the running loop ends at its next poll of
+ * the device state (every 32 iterations of the launch-per-phase loops; the CU-resident loop, one cooperative launch of at most
+ * max_iterations x ~20-70 us, ends with its launch), the solve returns AVS_OK with converged = 0 and cancelled = 1, and the request is
+ * consumed.  A request that finds no solve running cancels the next one.  In a partitioned solve every rank must be cancelled (the
+ * ranks leave the loop in the same iteration: the request travels with the CG sums). */
+avs_status avs_cancel(avs_ctx *ctx);
 
 /* Solver options of the context (set any time before avs_solve / avs_dist_solve; the default is what the USEEIGEN build does).
  * AVS_OPTION_PRECONDITIONER: AVS_PRECONDITIONER_JACOBI (0, default: Eigen's DiagonalPreconditioner, cpp:618) or
@@ -175,12 +186,14 @@ typedef enum {
     AVS_OPTION_TRANSPORT = 2,     /* multi-GPU: AVS_USE_TRANSPORT_AUTO (direct after its connect-time self-test, else RCCL), _RCCL, _DIRECT */
     AVS_OPTION_PARANOID = 3,      /* multi-GPU: 1 = every round's halo segments are re-added by the reader and compared with the sender's checksum */
     AVS_OPTION_GRAPH_REPLAY = 4,  /* 1 (default): chunks of iterations replay a captured hipGraph */
-    AVS_OPTION_BRICK_FORM = 5,    /* brick-structured SpMV form: AVS_BRICK_AUTO (systems of >= 2 M rows), _NEVER, _ALWAYS; takes effect at the next avs_assemble */
+    AVS_OPTION_BRICK_FORM = 5,    /* brick-structured SpMV form: AVS_BRICK_AUTO (systems of >= 2 M rows, kept where the tiles are full enough -- a
+                                   * structural rule, so the same input always runs the same kernel), _NEVER, _ALWAYS, _TUNE (auto, decided by timing
+                                   * both forms at the assembly: host-synchronous and not reproducible from run to run); takes effect at the next avs_assemble */
     AVS_OPTION_FUSED_SCALAR_STEPS = 6, /* 1 (default): the CG scalar steps ride in the vector kernels; 0: one reduction launch per step */
     AVS_OPTION_RELOAD_ENVIRONMENT = 7  /* any value: take the AVS_* environment variables again (they are read once, at avs_create; tools and tests) */
 } avs_solver_option;
 enum { AVS_USE_TRANSPORT_AUTO = 0, AVS_USE_TRANSPORT_RCCL = 1, AVS_USE_TRANSPORT_DIRECT = 2 };
-enum { AVS_BRICK_AUTO = -1, AVS_BRICK_NEVER = 0, AVS_BRICK_ALWAYS = 1 };
+enum { AVS_BRICK_AUTO = -1, AVS_BRICK_NEVER = 0, AVS_BRICK_ALWAYS = 1, AVS_BRICK_TUNE = 2 };
 enum { AVS_PRECONDITIONER_JACOBI = 0, AVS_PRECONDITIONER_NONE = 1 };
 avs_status avs_set_solver_option(avs_ctx *ctx, avs_solver_option option, int32_t value);
 
@@ -197,6 +210,8 @@ avs_status avs_get_assembly_info(avs_ctx *ctx, avs_assembly_info *info);
  * has 10^4..10^5 distinct ones (smoothly varying viscosity), and a tile's table fits in LDS.  When code and column do not fit
  * one word directly (many values, or more than 2^25 columns) the column is stored tile-relative (column_windows): 4 B again. */
 typedef struct avs_matrix_format {
+    int32_t struct_size;        /* IN: sizeof(avs_matrix_format) of the caller's header -- only that many bytes are written (the struct has grown
+                                 * between revisions; a caller built against an older header keeps working) */
     int32_t reordered;          /* 1 = rows/columns renumbered brick-major inside the solver */
     int32_t value_table_size;   /* distinct values; 0 = not value-indexed (> 65536 distinct values) */
     int32_t column_bits;        /* > 0 = packed form, columns in the low bits */
@@ -208,6 +223,9 @@ typedef struct avs_matrix_format {
     int32_t brick_patterns;     /* distinct row patterns of the whole matrix */
     int64_t brick_pattern_rows; /* rows stored as patterns */
     int64_t brick_bytes;        /* bytes the brick kernel streams per launch for the matrix (descriptors, runs, pattern lists, words) */
+    int32_t brick_walk;         /* tile walk of the persistent workgroups: 0 one contiguous eighth of the tiles per XCD, 1 chunks dealt to the XCDs in turn */
+    int32_t brick_value_codes;  /* 1 = variable-viscosity variant: the patterns carry the geometry only, every pattern row streams its own 2-B value codes
+                                 * into a per-tile value table (round 5) */
 } avs_matrix_format;
 avs_status avs_get_matrix_format(avs_ctx *ctx, avs_matrix_format *fmt);
 avs_status avs_get_solution(avs_ctx *ctx, double *x, int64_t n, avs_memspace where);

@@ -22,6 +22,15 @@ avs_status avs_spmv_sell(int64_t nslices, const int64_t *slice_ptr, const int32_
  * returns the mean HIP-event time per launch in *ms_per_launch. */
 avs_status avs_bench_spmv(avs_ctx *ctx, int32_t variant, int32_t repeats, double *ms_per_launch);
 
+/* y = A x with the storage form and kernel the solver's loop launches for the system owned by ctx (brick-structured form, word stream,
+ * ...), for an ARBITRARY x: x and y are device vectors in the REFERENCE's DOF numbering (the entry permutes into the solver's brick-major
+ * numbering and back).  fused_dot != 0 launches the fused-dot instantiation (what the PCG loop runs) and returns the folded x.y in
+ * *dot_out.  The parity tests compare y with the CPU oracle's CSR product bit for bit. */
+avs_status avs_spmv_solver_form(avs_ctx *ctx, const double *x, double *y, int32_t fused_dot, double *dot_out);
+/* the same for the LOCAL system of a partitioned solve (after avs_dist_assemble / avs_dist_partition): x_ext holds the rank's
+ * [owned | halo] entries in local numbering (n_own + n_halo doubles, device), y its n_own rows */
+avs_status avs_dist_spmv_local_form(avs_ctx *ctx, const double *x_ext, double *y, int32_t fused_dot, double *dot_out);
+
 /* Measured stream ceilings of the device for the access pattern of the SpMV's matrix stream
  * (mode 0: read-only 16 B/lane, 1: read-only non-temporal, 2: copy); GB/s of bytes moved. */
 avs_status avs_bench_stream(int32_t mode, int64_t bytes, int32_t repeats, int32_t device, double *gbps);
