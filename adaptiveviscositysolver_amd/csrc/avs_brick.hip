@@ -25,11 +25,17 @@
 // 53 KB of LDS: 68 us of a 170 us kernel with the arithmetic switched off).  Inside the walk the next tile's header (scalar) and ALL its
 // descriptors are requested before the current tile is multiplied, so a tile waits for one global round trip (x and pattern words).
 // One lane sums one row left to right with a multiply and an add per entry (no FMA, -ffp-contract=off): y is bit-identical to the
-// plain CSR kernel.  Reference: Eigen's `mat * p` inside ConjugateGradient (cpp:618-630 of HDK_AdaptiveViscosity.cpp); the row
+// plain CSR kernel.
+// Round 5 -- partitioned systems: a fill run names its column as (one of <= 32 windows of 2^11 columns in the tile header, offset), so
+// the local system of a rank ([owned | halo] columns) is just another matrix; with the halo in the tail of the vector (RCCL transport)
+// the kernel is unchanged.  HALO instantiation (direct transport): halo columns live in the rank's comm block, written by the peers --
+// a tile flagged in its header first waits for the peers' epoch flags, reads halo columns with system-scope loads, and every
+// persistent workgroup drops its x.y partial into a stage slot for the finalizer kernel that follows (k_halo_finalize, avs_pcg.hip).  Reference: Eigen's `mat * p` inside ConjugateGradient (cpp:618-630 of HDK_AdaptiveViscosity.cpp); the row
 // structure is that of cpp:2537-2745.
 #include <mutex>
 
 #include "avs_internal.hpp"
+#include "avs_halo.hpp"
 
 namespace avs {
 
@@ -97,11 +103,13 @@ constexpr int kBrickRu = kBrickMaxRuns / (kBrickBlk / 16);              // halo 
 // The per-row arrays (rdesc: descriptor + position of every pattern row in execution order; ownslot) stay in global memory.
 constexpr int kBlkHdr = kBlkHdrWords;
 
-template <bool DOT>
+template <bool DOT, bool HALO>
 __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_spmv_brick(BrickView B, const double *__restrict__ x, double *__restrict__ y,
-                                                         double *__restrict__ partial, const int *__restrict__ done_flag)
+                                                         double *__restrict__ partial, const int *__restrict__ done_flag, HaloView hv)
 {
     if (DOT && done_flag && *done_flag) return;
+    const double *__restrict__ hx = HALO ? hv.dd->my_halo : nullptr;   // the comm block's halo area: column c >= n_own lives at hx[c - n_own]
+    const unsigned n_own = HALO ? (unsigned)hv.dd->n_own : 0u;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *xs = smem;                                                  // kBrickSlotsPad
     double *park = smem + kBrickSlotsPad;                               // kBrickPark doubles, right behind the lattice: [0, kBrickXSlots) extra
@@ -186,6 +194,13 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         const int srow0 = __builtin_amdgcn_readfirstlane((int)bw[6]), nsrows = __builtin_amdgcn_readfirstlane((int)bw[7]);
         const int sword0 = __builtin_amdgcn_readfirstlane((int)bw[8]), nsw = __builtin_amdgcn_readfirstlane((int)bw[9]);
         const int rd0 = __builtin_amdgcn_readfirstlane((int)bw[10]);
+        const bool hb = HALO && __builtin_amdgcn_readfirstlane((int)bw[11]) != 0; // this tile's rows read halo columns
+        if (HALO && hb) halo_wait(hv);                 // (block-uniform) the peers' entries of this round have landed; only the first such tile really waits
+        // a column of the vector the rows multiply with: own entries from x, halo entries from the comm block (bypassing the caches)
+        auto xg = [&](unsigned c) -> double {
+            if (HALO && hb && c >= n_own) return ld_sys_f64(hx + (c - n_own));
+            return ld_u32(x, c);
+        };
         const int o_runs = kBlkHdr, o_pq = o_runs + nruns, o_pi = o_pq + npq;
         const bool emode = npat == 0;                 // no pattern rows: the products of the streamed rows may use the x lattice's LDS
         double *prod = emode ? xs : park + kBrickXSlots;
@@ -208,7 +223,8 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                 const int nbase = (int)bw[16 + (r >> 27)];
                 const bool on = q < nruns && l16 <= (int)(r & 15u) && !BRICK_DBG(1);
                 rdsc[u] = on ? r : 0xffffffffu;
-                fv[u] = ld_u32(x, (unsigned)(on ? nbase + (int)((r >> 16) & 0x7ffu) + l16 : row0));
+                const unsigned cidx = (unsigned)(on ? nbase + (int)((r >> 16) & 0x7ffu) + l16 : row0);
+                fv[u] = (HALO && hb) ? xg(cidx) : ld_u32(x, cidx);
             }
         }
         constexpr int RPT = kBrickMaxRows / kBrickBlk;
@@ -267,7 +283,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                     w0[u] = B.swords[(int64_t)sword0 + (e < nsw ? e : 0)];
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) xv0[u] = x[w0[u] & cmask];
+                for (int u = 0; u < 2; ++u) xv0[u] = xg(w0[u] & cmask);
             }
         }
         // the next tile's block address: a scalar load, in flight while this tile's data arrives
@@ -389,7 +405,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                             }
                         }
 #pragma unroll
-                        for (int u = 0; u < SU; ++u) x4[u] = x[w4[u]];
+                        for (int u = 0; u < SU; ++u) x4[u] = xg(w4[u]);
 #pragma unroll
                         for (int u = 0; u < SU; ++u) {
                             const int e = e0 + u * kBrickBlk;
@@ -431,7 +447,9 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
             double s = park[0];
 #pragma unroll
             for (int k = 1; k < kBrickBlk / 64; ++k) s += park[k];
-            partial[blockIdx.x] = s;
+            if (!HALO) partial[blockIdx.x] = s;
+            else // direct transport: write-through, fire and forget -- the finalizer kernel that follows folds the slots (halo_finalizer)
+                __hip_atomic_store(hv.stage + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -461,7 +479,7 @@ static int brick_grid(const BrickView &B, size_t lds)
             if (e.dev == dev && e.lds == lds) g = e.grid;
         if (!g) {
             int per_cu = 0, cus = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_spmv_brick<true>, kBrickBlk, lds);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_spmv_brick<true, false>, kBrickBlk, lds);
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             if (per_cu < 1) per_cu = 1;
             if (cus < 1) cus = 256;
@@ -485,8 +503,9 @@ static avs_status brick_raise_lds_limit()
     if (dev < 0 || dev >= 64) dev = 0;
     std::lock_guard<std::mutex> lk(mu);
     if (done[dev]) return AVS_OK;
-    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
-    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
+    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
+    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
+    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
     done[dev] = true;
     return AVS_OK;
 }
@@ -534,8 +553,8 @@ avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, dou
     static const int dbg = getenv("AVS_BRICK_DEBUG") ? atoi(getenv("AVS_BRICK_DEBUG")) : 0; // phase switches / stamps (measurement builds only)
     BrickView Bd = B;
     Bd.debug |= dbg;
-    if (partial) hipLaunchKernelGGL((k_spmv_brick<true>), dim3(grid), dim3(kBrickBlk), lds, stream, Bd, x, y, partial, done_flag);
-    else hipLaunchKernelGGL((k_spmv_brick<false>), dim3(grid), dim3(kBrickBlk), lds, stream, Bd, x, y, partial, done_flag);
+    if (partial) hipLaunchKernelGGL((k_spmv_brick<true, false>), dim3(grid), dim3(kBrickBlk), lds, stream, Bd, x, y, partial, done_flag, HaloView());
+    else hipLaunchKernelGGL((k_spmv_brick<false, false>), dim3(grid), dim3(kBrickBlk), lds, stream, Bd, x, y, partial, done_flag, HaloView());
     AVS_HIP(hipGetLastError());
     if (Bd.debug & 64) { // print the phase stamps of THIS launch (synchronises: not for timing loops)
         AVS_HIP(hipStreamSynchronize(stream));
@@ -543,11 +562,27 @@ avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, dou
     }
     return AVS_OK;
 #else
-    if (partial) hipLaunchKernelGGL((k_spmv_brick<true>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
-    else hipLaunchKernelGGL((k_spmv_brick<false>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
+    if (partial) hipLaunchKernelGGL((k_spmv_brick<true, false>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag, HaloView());
+    else hipLaunchKernelGGL((k_spmv_brick<false, false>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag, HaloView());
     AVS_HIP(hipGetLastError());
     return AVS_OK;
 #endif
+}
+
+// the SpMV launch of the direct transport on the brick form: the persistent grid over all tiles (the tiles flagged in their header
+// wait for the peers' flags and read halo columns from the comm block); workgroup b drops its x.y partial into hv.stage[b] --
+// hv.ntiles == brick_partial_count(B) slots, folded by the finalizer kernel the caller launches behind this one
+avs_status spmv_brick_halo_launch(const BrickView &B, const double *x, double *y, const int *done_flag, const HaloView &hv, hipStream_t stream)
+{
+    if (B.ntiles <= 0) return AVS_OK;
+    const size_t lds = brick_lds_bytes(B);
+    AVS_REQUIRE(lds <= kBrickLdsLimit, AVS_EINTERNAL, "brick form: %zu bytes of LDS per workgroup exceed the limit", lds);
+    AVS_TRY(brick_raise_lds_limit());
+    const int grid = brick_grid(B, lds);
+    AVS_REQUIRE(grid == hv.ntiles, AVS_EINTERNAL, "brick form: %d stage slots for a grid of %d workgroups", hv.ntiles, grid);
+    hipLaunchKernelGGL((k_spmv_brick<true, true>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, (double *)nullptr, done_flag, hv);
+    AVS_HIP(hipGetLastError());
+    return AVS_OK;
 }
 
 } // namespace avs

@@ -1,8 +1,12 @@
 // avs_brick_build.hip -- builds the brick-structured SpMV form (avs_brick.hip) of the brick-major system on the device.
 //
-// Input: the permuted CSR (p_row_ptr / p_col), its value codes and packed words (ValueIndex: one dictionary of < 2047 values, code and
-// column in one 32-bit word), the permutation and the dof table (which face a row is: level, axis, cell -- cpp:1566-1593).  Output: the
-// arrays behind BrickView.  Lossless by construction: a row is stored as a pattern only after its words have been compared, one by one,
+// Input (BrickSource): a CSR in the solver's numbering -- the permuted global system (p_row_ptr / p_col) or, round 5, the LOCAL system of
+// a partitioned solve, whose columns [n_rows, n_cols) are halo entries -- its value codes and packed words (ValueIndex: one dictionary of
+// < 2047 values, code and column in one 32-bit word), and for every column the reference DOF behind it + the dof table (which face a
+// column is: level, axis, cell -- cpp:1566-1593).  Output: the arrays behind BrickView.  A fill run names its column as (window of 2^11
+// consecutive columns, offset); a tile's <= 32 windows are in its header -- own-row windows first, then halo windows (aligned relative
+// to n_rows, so no window straddles the two ranges) -- which makes the form independent of how the rows of a brick are laid out: the
+// [interior | halo-reading] split order of a rank's rows simply gives a brick two runs of rows, i.e. two sets of tiles.  Lossless by construction: a row is stored as a pattern only after its words have been compared, one by one,
 // with the words of the pattern it hashed to (K5); anything that does not fit a limit (lattice, extra slots, LDS budgets, runs) is kept
 // as packed words ("streamed" rows) -- tests/test_gpu_matrix_formats.py and avs_bench_spmv compare y with the plain CSR kernel bit for bit.
 //
@@ -30,10 +34,12 @@ constexpr int kMaxPatterns = 1 << 19;            // more distinct patterns: the 
 constexpr int kBlockStride = 1728;               // words reserved per descriptor block (48 + 320 + 640 + 512 = 1520 at the limits)
 constexpr int kXsRows = kBrickXSlots;
 
-struct TileInfo {                                // built on the host from the brick starts
+struct TileInfo {                                // built on the device from the brick starts
     int32_t row0, nrows, is_g, obx, oby, obz, pad0, pad1;
-    int32_t nb[32];
 };
+// window key of a column: own rows and halo entries are numbered apart, so that no window of 2^kBrickWinBits columns holds both
+__device__ __forceinline__ int win_key(int c, int n_rows) { return c < n_rows ? (c >> kBrickWinBits) : (((c - n_rows) >> kBrickWinBits) | (1 << 24)); }
+__device__ __forceinline__ int win_base(int key, int n_rows) { return (key & (1 << 24)) ? n_rows + ((key & 0xffffff) << kBrickWinBits) : (key << kBrickWinBits); }
 
 __device__ __forceinline__ uint64_t geo_pack(uint32_t brick, int level, int axis, int i, int j, int k)
 {
@@ -50,12 +56,12 @@ __device__ __forceinline__ Geo geo_unpack(uint64_t g)
 }
 
 // K1: brick, level, axis, level-cell of every row of the brick-major system (the key of k_brick_keys, avs_reorder.hip)
-__global__ __launch_bounds__(kBlk) void k_bk_geo(const int32_t *__restrict__ vdof, const int32_t *__restrict__ perm, int64_t n, int nx, int ny,
+__global__ __launch_bounds__(kBlk) void k_bk_geo(const int32_t *__restrict__ vdof, const int32_t *__restrict__ ref_id, int64_t n, int nx, int ny,
                                                 int nz, uint64_t *__restrict__ geo)
 {
     const int64_t r = (int64_t)blockIdx.x * kBlk + threadIdx.x;
     if (r >= n) return;
-    const int4 rec = reinterpret_cast<const int4 *>(vdof)[perm[r]];
+    const int4 rec = reinterpret_cast<const int4 *>(vdof)[ref_id[r]];
     const int level = rec.x & 0xff, axis = (rec.x >> 8) & 0xff;
     int px = rec.y << level, py = rec.z << level, pz = rec.w << level;
     px = px < nx ? px : nx - 1;
@@ -139,29 +145,12 @@ __global__ __launch_bounds__(kBlk) void k_bk_tile_rows(const int32_t *__restrict
         T.obx = id % nbx; T.oby = (id / nbx) % nby; T.obz = id / (nbx * nby);
     }
 }
-// rows of a tile = up to the next tile's first row; first rows of the 27 bricks around a G tile's brick (binary search in the brick list)
-__global__ __launch_bounds__(kBlk) void k_bk_tile_finish(int ntiles, int64_t n, const int32_t *__restrict__ bstart, const int32_t *__restrict__ bbrick,
-                                                        int nbricks, int nbx, int nby, int nbz, TileInfo *__restrict__ tiles)
+// rows of a tile = up to the next tile's first row
+__global__ __launch_bounds__(kBlk) void k_bk_tile_finish(int ntiles, int64_t n, TileInfo *__restrict__ tiles)
 {
-    const int sub = threadIdx.x & 31;
-    const int t = (blockIdx.x * kBlk + threadIdx.x) >> 5;
+    const int t = blockIdx.x * kBlk + threadIdx.x;
     if (t >= ntiles) return;
-    TileInfo &T = tiles[t];
-    if (sub == 0) T.nrows = (t + 1 < ntiles ? tiles[t + 1].row0 : (int32_t)n) - T.row0;
-    int v = 0;
-    if (T.is_g && sub < 27) {
-        const int bx = T.obx + sub % 3 - 1, by = T.oby + (sub / 3) % 3 - 1, bz = T.obz + sub / 9 - 1;
-        if (bx >= 0 && bx < nbx && by >= 0 && by < nby && bz >= 0 && bz < nbz) {
-            const int id = (bz * nby + by) * nbx + bx;
-            int lo = 0, hi = nbricks;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (bbrick[mid] < id) lo = mid + 1; else hi = mid;
-            }
-            if (lo < nbricks && bbrick[lo] == id) v = bstart[lo];
-        }
-    }
-    T.nb[sub] = v;
+    tiles[t].nrows = (t + 1 < ntiles ? tiles[t + 1].row0 : (int32_t)n) - tiles[t].row0;
 }
 
 // slot of a face on the lattices of a tile whose brick is (obx, oby, obz): -1 when it is not on them
@@ -411,10 +400,10 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
                                                      const int32_t *__restrict__ col, const uint16_t *__restrict__ eslot,
                                                      const int32_t *__restrict__ row_pid, const uint32_t *__restrict__ rgeo,
                                                      const int32_t *__restrict__ pat_off, const int32_t *__restrict__ pat_rep,
-                                                     const uint64_t *__restrict__ geo, int nbx, int nby, const uint8_t *__restrict__ force_e,
+                                                     int n_rows, int has_halo, const uint8_t *__restrict__ force_e,
                                                      uint32_t *__restrict__ blocks, uint2 *__restrict__ tile_blk, uint2 *__restrict__ rdesc,
                                                      uint2 *__restrict__ sdesc, int32_t *__restrict__ slen, int32_t *__restrict__ tile_info_out,
-                                                     int *__restrict__ fallbacks)
+                                                     uint8_t *__restrict__ tile_bnd_out, int *__restrict__ fallbacks)
 {
     __shared__ int smap[4096];                 // slot -> column of the halo fill
     __shared__ int pkey[1024], pidx[1024];     // distinct global pattern ids of the tile (hash set) -> list index
@@ -431,7 +420,11 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
     for (int i = tid; i < 4096; i += kTileBlk) smap[i] = -1;
     for (int i = tid; i < 1024; i += kTileBlk) { pkey[i] = -1; skey[i] = 0xffffffffu; }
     if (tid < 8) counters[tid] = 0;
-    __syncthreads();
+    int bnd = 0; // partitioned systems: does any row of the tile read a halo column?
+    if (has_halo)
+        for (int r = tid; r < nrows; r += kTileBlk)
+            for (int e = row_ptr[row0 + r]; e < row_ptr[row0 + r + 1]; ++e) bnd |= col[e] >= n_rows ? 1 : 0;
+    bnd = __syncthreads_or(bnd);
     // ---- distinct patterns
     int my_pid[2] = {-1, -1};
     if (gtile)
@@ -580,7 +573,35 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
             }
         }
     __syncthreads();
-    // run starts: slot s filled and not the continuation of the run through s - 1 (consecutive columns of one brick, at most 16 long)
+    // the windows of 2^kBrickWinBits consecutive columns the fill reads: hash set in pkey (free since the rows were classified), then
+    // ascending in pidx -- own-row windows first, halo windows (key bit 24) behind them
+    for (int i = tid; i < 64; i += kTileBlk) pkey[i] = -1;
+    __syncthreads();
+    for (int u = 0; u < 4096 / kTileBlk; ++u) {
+        const int c = smap[tid * (4096 / kTileBlk) + u];
+        if (c < 0) continue;
+        const int wk = win_key(c, n_rows);
+        if (u > 0 && smap[tid * (4096 / kTileBlk) + u - 1] >= 0 && win_key(smap[tid * (4096 / kTileBlk) + u - 1], n_rows) == wk) continue; // (already in)
+        unsigned h = ((unsigned)wk * 2654435761u) >> 26;
+        bool in = false;
+        for (int probe = 0; probe < 64 && !in; ++probe) {
+            const int old = atomicCAS(&pkey[h], -1, wk);
+            in = old == -1 || old == wk;
+            h = (h + 1) & 63u;
+        }
+        if (!in) atomicExch(&counters[7], 1000); // more than 64 windows
+    }
+    __syncthreads();
+    if (tid < 64 && pkey[tid] != -1) {
+        const int v = pkey[tid];
+        int rk = 0;
+        for (int j = 0; j < 64; ++j) rk += (pkey[j] != -1 && pkey[j] < v) ? 1 : 0;
+        pidx[rk] = v;
+        atomicAdd(&counters[7], 1);
+    }
+    __syncthreads();
+    const int nwin = counters[7];
+    // run starts: slot s filled and not the continuation of the run through s - 1 (consecutive columns of one window, at most 16 long)
     constexpr int SPT = 4096 / kTileBlk; // 8 consecutive slots per thread
     unsigned startmask = 0;
     {
@@ -591,7 +612,7 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
             bool st = true;
             if (s > 0) {
                 const int cp = smap[s - 1];
-                if (cp >= 0 && cp + 1 == c && (geo[cp] >> 38) == (geo[c] >> 38)) st = false;
+                if (cp >= 0 && cp + 1 == c && win_key(cp, n_rows) == win_key(c, n_rows)) st = false;
             }
             if (st) startmask |= 1u << u;
         }
@@ -632,7 +653,7 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
     }
     const int nruns = scan[kTileBlk - 1];
     int my_run = scan[tid] - ncut;
-    const bool fits = nruns <= kBrickMaxRuns && kBlkHdrWords + nruns + npq + npat <= kBlockStride;
+    const bool fits = nruns <= kBrickMaxRuns && kBlkHdrWords + nruns + npq + npat <= kBlockStride && nwin <= 32;
     __syncthreads();
     if (!fits) { // (block-uniform) a tile over a limit is redone as an E tile
         if (tid == 0) atomicExch(fallbacks, 1);
@@ -644,13 +665,13 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
             if (!(cutmask & (1u << u))) continue;
             const int s = tid * SPT + u;
             int len = 1;
-            while (len < 16 && s + len < 4096 && smap[s + len] >= 0 && smap[s + len] == smap[s] + len && (geo[smap[s + len]] >> 38) == (geo[smap[s]] >> 38)) ++len;
-            // (the loop above may run past the next cut of the SAME natural run only if that cut is 16 away: len < 16 stops it)
             const int c = smap[s];
-            const int cb = (int)(geo[c] >> 38);
-            const int cbx = cb % nbx, cby = (cb / nbx) % nby, cbz = cb / (nbx * nby);
-            const int w = (cbz - T.obz + 1) * 9 + (cby - T.oby + 1) * 3 + (cbx - T.obx + 1);
-            blk[kBlkHdrWords + my_run] = ((uint32_t)w << 27) | ((uint32_t)(c - T.nb[w]) << 16) | ((uint32_t)s << 4) | (uint32_t)(len - 1);
+            const int wk = win_key(c, n_rows);
+            while (len < 16 && s + len < 4096 && smap[s + len] >= 0 && smap[s + len] == c + len && win_key(c + len, n_rows) == wk) ++len;
+            // (the loop above may run past the next cut of the SAME natural run only if that cut is 16 away: len < 16 stops it)
+            int w = 0;
+            while (pidx[w] != wk) ++w;
+            blk[kBlkHdrWords + my_run] = ((uint32_t)w << 27) | ((uint32_t)(c - win_base(wk, n_rows)) << 16) | ((uint32_t)s << 4) | (uint32_t)(len - 1);
             ++my_run;
         }
         // pattern quads + pinfo in list order
@@ -676,12 +697,14 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
         case 8: v = 0; break;      // sword0: K7
         case 9: v = nsw; break;
         case 10: v = row0; break;  // rd0: the tile's pattern-row descriptors start at its first row
+        case 11: v = bnd; break;   // the tile's rows read halo columns (partitioned solve, direct transport: wait for the peers' flags)
         default: break;
         }
         blk[tid] = (uint32_t)v;
     }
-    if (tid < 32) blk[16 + tid] = (uint32_t)T.nb[tid];
+    if (tid < 32) blk[16 + tid] = (gtile && tid < nwin) ? (uint32_t)win_base(pidx[tid], n_rows) : 0u; // first columns of the fill windows
     if (tid == 0) {
+        tile_bnd_out[t] = (uint8_t)bnd;
         const int words = kBlkHdrWords + (gtile ? nruns + npq + npat : 0);
         tile_blk[t] = uint2{(uint32_t)((int64_t)t * (kBlockStride / 4)), (uint32_t)((words + 3) >> 2)};
         tile_info_out[t] = nprow;
@@ -743,7 +766,7 @@ void BrickScratch::release()
 void BrickForm::release()
 {
     clear();
-    tile_blk.release(); rdesc.release(); sdesc.release(); blocks.release(); pwords.release(); swords.release(); ownslot.release();
+    tile_blk.release(); rdesc.release(); sdesc.release(); blocks.release(); pwords.release(); swords.release(); ownslot.release(); tile_flags.release();
     scratch.release();
 }
 
@@ -768,17 +791,18 @@ void BrickForm::view(BrickView &B, const ValueIndex &vi) const
     B.table = vi.table.p;
     B.table_size = vi.table_size;
     B.col_bits = wide ? 0 : vi.col_bits;   // 0: 64-bit streamed words
+    B.n_rows = (int)n_rows;
 }
 
-// c->p_row_ptr / p_col / vi (codes, packed) / perm / vdof -> c->brick.  Leaves c->brick.ready = false (and AVS_OK) when the matrix does
-// not qualify or is not regular enough; an error status only for real failures.
-avs_status build_brick_form(avs_ctx *c)
+// BrickSource -> bf.  Leaves bf.ready = false (and AVS_OK) when the matrix does not qualify or is not regular enough; an error status
+// only for real failures.
+avs_status build_brick_form(BrickForm &bf, const BrickSource &src, const Options &opt, hipStream_t st)
 {
-    BrickForm &bf = c->brick;
     bf.clear();
-    const int64_t n = c->n_vel, nnz = c->nnz;
-    const ValueIndex &vi = c->vi;
-    if (n <= 0 || !c->reordered || vi.tile_tables || !vi.codes.p) return AVS_OK; // one dictionary; packed, windowed or 6-B columns
+    const int64_t n = src.n_rows, nnz = src.nnz, n_cols = src.n_cols;
+    if (n <= 0 || !src.vi || !src.row_ptr || !src.col || !src.ref_id || !src.vdof) return AVS_OK;
+    const ValueIndex &vi = *src.vi;
+    if (vi.tile_tables || !vi.codes.p) return AVS_OK; // one dictionary; packed, windowed or 6-B columns
     const bool wide = vi.col_bits <= 0 || vi.col_windows; // no (code << col_bits | column) stream to copy the streamed rows from
     if (vi.table_size <= 0 || vi.table_size + 1 >= kBrickTableMax) return AVS_OK; // (one code is reserved for 0.0)
     {
@@ -786,10 +810,9 @@ avs_status build_brick_form(avs_ctx *c)
         probe.table_size = vi.table_size;
         if (!brick_lds_fits(probe)) return AVS_OK; // the value table next to the lattice would exceed a workgroup's LDS: the word stream serves this matrix
     }
-    if (c->brick_shift != 3 || c->desc.levels < 1) return AVS_OK;
-    if (c->desc.nx > 1024 || c->desc.ny > 1024 || c->desc.nz > 1024 || nnz >= (1ll << 31)) return AVS_OK;
-    hipStream_t st = c->stream;
-    const bool timing = c->opt.brick_timing != 0;
+    if (src.brick_shift != 3 || src.levels < 1) return AVS_OK;
+    if (src.nx > 1024 || src.ny > 1024 || src.nz > 1024 || nnz >= (1ll << 31) || n_cols >= (1ll << 31) - (1 << kBrickWinBits)) return AVS_OK;
+    const bool timing = opt.brick_timing != 0;
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;
@@ -798,17 +821,17 @@ avs_status build_brick_form(avs_ctx *c)
         fprintf(stderr, "brick build: %-28s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
         t_prev = now;
     };
-    const int nx = c->desc.nx, ny = c->desc.ny, nz = c->desc.nz;
-    const int nbx = (nx + 7) >> 3, nby = (ny + 7) >> 3, nbz = (nz + 7) >> 3;
+    const int nx = src.nx, ny = src.ny, nz = src.nz;
+    const int nbx = (nx + 7) >> 3, nby = (ny + 7) >> 3;
     BrickScratch &S = bf.scratch;
-    AVS_TRY(S.geo.reserve((size_t)n));
+    AVS_TRY(S.geo.reserve((size_t)n_cols));
     AVS_TRY(S.counters.reserve(16));
     AVS_HIP(hipMemsetAsync(S.counters.p, 0, 16 * sizeof(int), st));
     AVS_TRY(S.first.reserve((size_t)n + 1));
     AVS_TRY(S.bidx.reserve((size_t)n + 1));
     AVS_TRY(S.scan_tmp.reserve(scan_tmp_elems(n)));
     const unsigned gn = (unsigned)((n + kBlk - 1) / kBlk);
-    hipLaunchKernelGGL(k_bk_geo, dim3(gn), dim3(kBlk), 0, st, c->vdof.p, c->perm.p, n, nx, ny, nz, S.geo.p);
+    hipLaunchKernelGGL(k_bk_geo, dim3((unsigned)((n_cols + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, src.vdof, src.ref_id, n_cols, nx, ny, nz, S.geo.p);
     hipLaunchKernelGGL(k_bk_first, dim3(gn), dim3(kBlk), 0, st, S.geo.p, n, S.first.p);
     AVS_TRY(exclusive_scan_i32(S.first.p, S.bidx.p, n, S.scan_tmp.p, S.scan_tmp.n, st));
     int32_t nbricks = 0;
@@ -841,8 +864,7 @@ avs_status build_brick_form(avs_ctx *c)
     TileInfo *wtiles = reinterpret_cast<TileInfo *>(S.tiles.p);
     hipLaunchKernelGGL(k_bk_tile_rows, dim3(gb), dim3(kBlk), 0, st, S.bstart.p, S.bbrick.p, S.run_first.p, S.run_id.p, S.run_start.p, S.tile0.p, nbricks,
                        nbx, nby, wtiles);
-    hipLaunchKernelGGL(k_bk_tile_finish, dim3((unsigned)(((size_t)ntiles * 32 + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, ntiles, n, S.bstart.p, S.bbrick.p,
-                       nbricks, nbx, nby, nbz, wtiles);
+    hipLaunchKernelGGL(k_bk_tile_finish, dim3((unsigned)((ntiles + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, ntiles, n, wtiles);
     const TileInfo *dtiles = reinterpret_cast<const TileInfo *>(S.tiles.p);
     lap("tiles");
     // ---- K3
@@ -860,10 +882,10 @@ avs_status build_brick_form(avs_ctx *c)
     AVS_TRY(S.pat_rep.reserve((size_t)kMaxPatterns));
     AVS_TRY(S.pat_off.reserve((size_t)kMaxPatterns));
     AVS_HIP(hipMemsetAsync(S.keys.p, 0, hslots * sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(k_bk_rows, dim3(ntiles), dim3(kTileBlk), 0, st, dtiles, c->p_row_ptr.p, c->p_col.p, vi.codes.p, S.geo.p, nbx, nby, zero_code,
+    hipLaunchKernelGGL(k_bk_rows, dim3(ntiles), dim3(kTileBlk), 0, st, dtiles, src.row_ptr, src.col, vi.codes.p, S.geo.p, nbx, nby, zero_code,
                        S.ewords.p, S.eslot.p, S.row_hash.p, S.rgeo.p, bf.ownslot.p, S.keys.p, S.rep.p, S.counters.p + 2);
     lap("K3 rows + pattern insert");
-    hipLaunchKernelGGL(k_bk_assign, dim3((unsigned)(hslots / kBlk)), dim3(kBlk), 0, st, S.keys.p, S.rep.p, c->p_row_ptr.p, S.slot_id.p, S.pat_rep.p,
+    hipLaunchKernelGGL(k_bk_assign, dim3((unsigned)(hslots / kBlk)), dim3(kBlk), 0, st, S.keys.p, S.rep.p, src.row_ptr, S.slot_id.p, S.pat_rep.p,
                        S.pat_off.p, S.counters.p);
     int hc[4] = {};
     AVS_HIP(hipMemcpyAsync(hc, S.counters.p, sizeof(hc), hipMemcpyDeviceToHost, st));
@@ -873,10 +895,10 @@ avs_status build_brick_form(avs_ctx *c)
     if (npat <= 0 || npat > kMaxPatterns || hc[3]) return AVS_OK; // nothing regular / not a regular scene
     AVS_TRY(bf.pwords.alloc((size_t)nwords + 16));
     hipLaunchKernelGGL(k_bk_copy_patterns, dim3((unsigned)(((size_t)npat * 16 + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, npat, S.pat_rep.p, S.pat_off.p,
-                       c->p_row_ptr.p, S.ewords.p, zero_code, bf.pwords.p);
+                       src.row_ptr, S.ewords.p, zero_code, bf.pwords.p);
     // ---- K5
     AVS_TRY(S.row_pid.reserve((size_t)n));
-    hipLaunchKernelGGL(k_bk_verify, dim3(gn), dim3(kBlk), 0, st, S.row_hash.p, n, S.keys.p, S.slot_id.p, S.pat_off.p, S.pat_rep.p, c->p_row_ptr.p,
+    hipLaunchKernelGGL(k_bk_verify, dim3(gn), dim3(kBlk), 0, st, S.row_hash.p, n, S.keys.p, S.slot_id.p, S.pat_off.p, S.pat_rep.p, src.row_ptr,
                        S.ewords.p, bf.pwords.p, S.row_pid.p);
     lap("K4c copy + K5 verify");
     // ---- K6 (+ a second round for the tiles that exceeded a limit: they become E tiles)
@@ -888,12 +910,13 @@ avs_status build_brick_form(avs_ctx *c)
     AVS_TRY(S.sstart.reserve((size_t)n + 1));
     AVS_TRY(S.tile_nprow.reserve((size_t)ntiles));
     AVS_TRY(S.force_e.reserve((size_t)ntiles));
+    AVS_TRY(bf.tile_flags.alloc((size_t)ntiles + 1));
     AVS_HIP(hipMemsetAsync(S.force_e.p, 0, (size_t)ntiles, st));
     for (int round = 0; round < 2; ++round) {
         AVS_HIP(hipMemsetAsync(S.counters.p + 4, 0, sizeof(int), st));
-        hipLaunchKernelGGL(k_bk_tile, dim3(ntiles), dim3(kTileBlk), 0, st, dtiles, c->p_row_ptr.p, c->p_col.p, S.eslot.p, S.row_pid.p, S.rgeo.p,
-                           S.pat_off.p, S.pat_rep.p, S.geo.p, nbx, nby, S.force_e.p, bf.blocks.p, bf.tile_blk.p, bf.rdesc.p, bf.sdesc.p, S.slen.p,
-                           S.tile_nprow.p, S.counters.p + 4);
+        hipLaunchKernelGGL(k_bk_tile, dim3(ntiles), dim3(kTileBlk), 0, st, dtiles, src.row_ptr, src.col, S.eslot.p, S.row_pid.p, S.rgeo.p,
+                           S.pat_off.p, S.pat_rep.p, (int)n, n_cols > n ? 1 : 0, S.force_e.p, bf.blocks.p, bf.tile_blk.p, bf.rdesc.p, bf.sdesc.p, S.slen.p,
+                           S.tile_nprow.p, bf.tile_flags.p, S.counters.p + 4);
         int fb = 0;
         AVS_HIP(hipMemcpyAsync(&fb, S.counters.p + 4, sizeof(int), hipMemcpyDeviceToHost, st));
         AVS_HIP(hipStreamSynchronize(st));
@@ -919,10 +942,10 @@ avs_status build_brick_form(avs_ctx *c)
     bf.wide = wide;
     AVS_TRY(bf.swords.alloc(((size_t)total_sw + 16) * (wide ? 2 : 1)));
     if (wide)
-        hipLaunchKernelGGL(k_bk_copy_streamed<true>, dim3(4096), dim3(kBlk), 0, st, n, S.slen.p, S.sstart.p, c->p_row_ptr.p, (const uint32_t *)nullptr,
-                           vi.codes.p, c->p_col.p, bf.swords.p);
+        hipLaunchKernelGGL(k_bk_copy_streamed<true>, dim3(4096), dim3(kBlk), 0, st, n, S.slen.p, S.sstart.p, src.row_ptr, (const uint32_t *)nullptr,
+                           vi.codes.p, src.col, bf.swords.p);
     else
-        hipLaunchKernelGGL(k_bk_copy_streamed<false>, dim3(4096), dim3(kBlk), 0, st, n, S.slen.p, S.sstart.p, c->p_row_ptr.p, vi.packed.p,
+        hipLaunchKernelGGL(k_bk_copy_streamed<false>, dim3(4096), dim3(kBlk), 0, st, n, S.slen.p, S.sstart.p, src.row_ptr, vi.packed.p,
                            (const uint16_t *)nullptr, (const int32_t *)nullptr, bf.swords.p);
     hipLaunchKernelGGL(k_bk_patch, dim3((unsigned)((ntiles + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, ntiles, dtiles, S.sstart.p, bf.blocks.p);
     AVS_HIP(hipGetLastError());
@@ -933,17 +956,53 @@ avs_status build_brick_form(avs_ctx *c)
     bf.streamed_words = total_sw;
     bf.pattern_words = nwords;
     bf.streamed_rows = n - (int64_t)regular;
+    bf.n_rows = n;
+    bf.halo_tiles = 0;
     {
         std::vector<uint2> hb((size_t)ntiles);
         AVS_HIP(hipMemcpy(hb.data(), bf.tile_blk.p, (size_t)ntiles * sizeof(uint2), hipMemcpyDeviceToHost));
         int64_t w = 0;
         for (const uint2 &b : hb) w += 4 * (int64_t)b.y;
         bf.block_words = w;
+        if (n_cols > n) {
+            // partitioned system: the tiles whose rows read halo columns go to the END of the walk order (a stable partition of the
+            // tile list -- a tile is named by its descriptor block alone), so that a persistent workgroup multiplies all its other
+            // tiles while the peers' entries travel and meets a flag wait, if at all, last
+            std::vector<uint8_t> hf((size_t)ntiles), hf2((size_t)ntiles);
+            AVS_HIP(hipMemcpy(hf.data(), bf.tile_flags.p, (size_t)ntiles, hipMemcpyDeviceToHost));
+            std::vector<uint2> hb2;
+            hb2.reserve((size_t)ntiles);
+            for (int pass = 0; pass < 2; ++pass)
+                for (int t = 0; t < ntiles; ++t)
+                    if ((hf[(size_t)t] != 0) == (pass == 1)) { hf2[hb2.size()] = hf[(size_t)t]; hb2.push_back(hb[(size_t)t]); }
+            for (uint8_t f : hf) bf.halo_tiles += f ? 1 : 0;
+            AVS_HIP(hipMemcpy(bf.tile_blk.p, hb2.data(), (size_t)ntiles * sizeof(uint2), hipMemcpyHostToDevice));
+            AVS_HIP(hipMemcpy(bf.tile_flags.p, hf2.data(), (size_t)ntiles, hipMemcpyHostToDevice));
+        }
     }
     // worth it only where most rows are patterns (a curved surface with ~10^4 distinct values gives every row its own)
-    const double min_frac = c->opt.brick_min_regular;
+    const double min_frac = opt.brick_min_regular;
     bf.ready = (double)regular >= min_frac * (double)n;
     return AVS_OK;
+}
+
+// the single-GPU system of a context: c->p_row_ptr / p_col / vi (codes, packed) / perm / vdof -> c->brick
+avs_status build_brick_form(avs_ctx *c)
+{
+    c->brick.clear();
+    if (!c->reordered) return AVS_OK;
+    BrickSource src;
+    src.n_rows = src.n_cols = c->n_vel;
+    src.nnz = c->nnz;
+    src.row_ptr = c->p_row_ptr.p;
+    src.col = c->p_col.p;
+    src.vi = &c->vi;
+    src.vdof = c->vdof.p;
+    src.ref_id = c->perm.p;
+    src.nx = c->desc.nx; src.ny = c->desc.ny; src.nz = c->desc.nz;
+    src.levels = c->desc.levels;
+    src.brick_shift = c->brick_shift;
+    return build_brick_form(c->brick, src, c->opt, c->stream);
 }
 
 } // namespace avs

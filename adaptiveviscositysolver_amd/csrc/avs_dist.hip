@@ -72,6 +72,9 @@ struct PcgDist {
     DevBuf<int32_t> row_ptr, col;
     DevBuf<double> val, rhs, x0, x;
     ValueIndex vi;            // lossless storage form of the LOCAL rows (own dictionaries: the rank's rows hold a subset of the values)
+    BrickForm brick;          // brick-structured form of the local rows (round 5; slabs of >= kBrickMinSystemRows rows), avs_brick_build.hip
+    BrickView brick_view;
+    DevBuf<int32_t> local_ref; // reference DOF id behind every local column [owned | halo] (what the brick builder reads the geometry from)
     PcgWork *pcg = nullptr;
     bool partitioned = false, solved = false, reordered = false;
 
@@ -1062,6 +1065,16 @@ __global__ __launch_bounds__(256) void k_da_localize(int64_t n_own, const int32_
     }
 }
 
+// reference DOF id of every halo column: global brick-major id g with a local id >= n_own -> perm[g]
+__global__ __launch_bounds__(256) void k_da_halo_ref(int64_t n, const int32_t *__restrict__ g2l, const int32_t *__restrict__ perm, int64_t n_own,
+                                                     int32_t *__restrict__ local_ref)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n) return;
+    const int32_t l = g2l[g];
+    if (l >= n_own) local_ref[l] = perm[g];
+}
+
 __global__ __launch_bounds__(256) void k_da_flag_send(int64_t n_own, const uint32_t *__restrict__ needed_by, int q, int32_t *__restrict__ f)
 {
     const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1111,6 +1124,46 @@ __global__ __launch_bounds__(256) void k_da_g2l_own(int64_t n_own, const int32_t
 {
     const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (l < n_own) g2l[own_global[l]] = (int32_t)l;
+}
+
+// the brick-structured form for a rank's local rows: same rule as the single-GPU system (avs_reorder.hip)
+static bool dist_brick_wanted(const avs_ctx *c, int64_t n_own)
+{
+    const int mode = c->opt.brick;
+    if (c->brick_shift != 3) return false;
+    return mode == 1 || (mode != 0 && n_own >= kBrickMinSystemRows);
+}
+static avs_status dist_build_brick(avs_ctx *c, PcgDist *d)
+{
+    d->brick.clear();
+    d->brick.view(d->brick_view, d->vi);
+    if (!dist_brick_wanted(c, d->n_own) || !d->local_ref.p || d->local_ref.n < (size_t)(d->n_own + d->n_halo)) return AVS_OK;
+    BrickSource src;
+    src.n_rows = d->n_own;
+    src.n_cols = d->n_own + d->n_halo;
+    src.nnz = d->nnz_local;
+    src.row_ptr = d->row_ptr.p;
+    src.col = d->col.p;
+    src.vi = &d->vi;
+    src.vdof = c->vdof.p;
+    src.ref_id = d->local_ref.p;
+    src.nx = c->desc.nx; src.ny = c->desc.ny; src.nz = c->desc.nz;
+    src.levels = c->desc.levels;
+    src.brick_shift = c->brick_shift;
+    AVS_TRY(build_brick_form(d->brick, src, c->opt, c->stream));
+    if (d->brick.ready) {
+        const double fill = (double)d->n_own / (double)d->brick.ntiles;
+        if (c->opt.brick != 1 && fill < kBrickMinFill) d->brick.release(); // (auto: the word stream serves part-filled tiles better)
+        else {
+            d->brick.view(d->brick_view, d->vi);
+            d->brick_view.walk = fill >= kBrickEighthsFill ? 0 : 1;
+            return AVS_OK;
+        }
+    } else if (c->opt.brick != 1) {
+        d->brick.release();
+    }
+    d->brick.view(d->brick_view, d->vi);
+    return AVS_OK;
 }
 
 static avs_status dist_assemble_device(avs_ctx *c, PcgDist *d, int cut_axis, int extent)
@@ -1175,6 +1228,10 @@ static avs_status dist_assemble_device(avs_ctx *c, PcgDist *d, int cut_axis, int
                                   needed_by.p);
     bool split = world > 1;
     split = split && cur_opt().dist_split_rows != 0;
+    // A slab the brick-structured form will serve keeps the plain ascending (brick-major) row order: its tiles are whole bricks, and the
+    // ones that read halo columns are moved to the end of the WALK order instead (build_brick_form), which keeps them full.  With the
+    // [interior | halo-reading] split every brick next to a cut would fall into two part-filled tiles.
+    if (dist_brick_wanted(c, n_own)) split = false;
     if (split && n_own) { // [interior | halo-reading] local row order (see k_da_new_index)
         DevBuf<int32_t> new_of, len_new, rp2, col2, own2, ids2;
         DevBuf<double> val2, rhs2;
@@ -1278,6 +1335,10 @@ static avs_status dist_assemble_device(avs_ctx *c, PcgDist *d, int cut_axis, int
         hipLaunchKernelGGL(k_plan_scatter, dim3(grid256(ntiles)), dim3(256), 0, st, ntiles, tile_int.p, tile_pos.p, (const int32_t *)nullptr,
                            d->tiles_int.p, (int32_t *)nullptr, 0);
 
+    // reference ids behind the local columns (owned: the assembled rows' DOFs; halo: through the brick-major permutation)
+    AVS_TRY(d->local_ref.alloc((size_t)(n_own + n_halo)));
+    if (n_own) AVS_HIP(hipMemcpyAsync(d->local_ref.p, ids.p, (size_t)n_own * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    if (n_halo) hipLaunchKernelGGL(k_da_halo_ref, dim3(grid256(n)), dim3(256), 0, st, n, (const int32_t *)g2l.p, (const int32_t *)c->perm.p, n_own, d->local_ref.p);
     // warm start of the owned DOFs
     AVS_TRY(d->x0.alloc((size_t)n_own));
     AVS_TRY(d->x.alloc((size_t)n_own));
@@ -1305,6 +1366,13 @@ bool dist_matrix_format(avs_ctx *c, avs_matrix_format *fmt)
     fmt->bytes_per_nonzero = d->vi.bytes_per_nonzero();
     fmt->tile_local_tables = d->vi.tile_tables ? 1 : 0;
     fmt->column_windows = d->vi.col_windows ? 1 : 0;
+    if (d->brick.ready) {
+        fmt->brick_tiles = d->brick.ntiles;
+        fmt->brick_patterns = d->brick.patterns;
+        fmt->brick_pattern_rows = d->brick.regular_rows;
+        fmt->brick_bytes = d->brick.stored_bytes(d->n_own);
+        fmt->brick_walk = d->brick_view.walk;
+    }
     return true;
 }
 
@@ -1585,6 +1653,9 @@ avs_status avs_dist_partition(avs_ctx *c, int32_t cut_axis)
     const double *g_rhs = ro ? c->p_rhs.p : c->rhs.p, *g_x0 = ro ? c->p_x0.p : c->x0.p;
     const bool host_plan = cur_opt().dist_host_plan != 0;
     d->vi.clear();
+    d->brick.clear();   // (the brick-structured form is built for distributed assemblies only: avs_dist_assemble)
+    d->brick.view(d->brick_view, d->vi);
+    d->local_ref.release();
     if (host_plan) AVS_TRY(plan_on_host(c, d, cut_axis, extent, ro));
     else AVS_TRY(plan_on_device(c, d, cut_axis, extent, ro));
     avs_plan_sizes sz{};
@@ -1676,6 +1747,7 @@ avs_status avs_dist_assemble(avs_ctx *c, int32_t cut_axis, avs_assembly_info *in
     }
     if (d->nnz_local) // the rank's own dictionaries: its rows only hold a subset of the global values
         AVS_TRY(build_matrix_index(d->row_ptr.p, d->col.p, d->val.p, d->n_own, d->nnz_local, d->n_own + d->n_halo, d->vi, st));
+    AVS_TRY(dist_build_brick(c, d)); // slabs of >= 2 M rows: the brick-structured form of the local rows
     if (!d->comm_stream) {
         AVS_HIP(hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking));
         AVS_HIP(hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming));
@@ -1775,6 +1847,7 @@ avs_status avs_dist_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_i
     A.val = d->val.p;
     d->vi.apply(A);
     A.no_precond = c->no_precond;
+    A.brick = d->brick.ready ? &d->brick_view : nullptr;
     avs_solve_info local{};
     const avs_status rc = pcg_solve(d->pcg, A, d->rhs.p, d->x.p, tol, max_iters, c->stream, &local, d);
     if (rc != AVS_OK) {
@@ -1791,6 +1864,31 @@ avs_status avs_dist_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_i
     d->solved = true;
     return AVS_OK;
 }
+
+#ifdef AVS_PROBES
+// measurement / test entry (include/avs_probe.h): the rank's local rows times a caller-supplied [owned | halo] vector, through the
+// storage form and kernel the partitioned loops launch (halo in the tail of the vector: the RCCL transport's layout)
+avs_status avs_dist_spmv_local_form(avs_ctx *c, const double *x_ext, double *y, int32_t fused_dot, double *dot_out)
+{
+    avs::OptScope opt_scope_(c);
+    AVS_REQUIRE(c && x_ext && y, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->dist && c->dist->partitioned, AVS_ESTATE, "call avs_dist_assemble / avs_dist_partition first");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    PcgDist *d = c->dist;
+    CsrView A;
+    A.n = d->n_own;
+    A.nnz = d->nnz_local;
+    A.row_ptr = d->row_ptr.p;
+    A.col = d->col.p;
+    A.val = d->val.p;
+    d->vi.apply(A);
+    A.brick = d->brick.ready ? &d->brick_view : nullptr;
+    if (A.n == 0) return AVS_OK;
+    AVS_TRY(probe_spmv_form(A, x_ext, y, fused_dot != 0, dot_out, c->stream));
+    AVS_HIP(hipStreamSynchronize(c->stream));
+    return AVS_OK;
+}
+#endif
 
 avs_status avs_dist_get_info(avs_ctx *c, avs_dist_info *info)
 {

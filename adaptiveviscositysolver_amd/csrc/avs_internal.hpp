@@ -260,7 +260,10 @@ constexpr int kCwinOffBits = 14, kCwinSlotBits = 6, kCwinSlots = 1 << kCwinSlotB
 // ---------------------------------------------------------------------------------------------
 // brick-structured form (avs_brick.hip): tile-local lattice slots + global row patterns + streamed rows
 // ---------------------------------------------------------------------------------------------
+struct ValueIndex;
+struct BrickForm;
 constexpr int kBlkHdrWords = 48;         // header of a tile's descriptor block (avs_brick.hip)
+constexpr int kBrickWinBits = 11;        // a fill run names its column as (window of 2^11 columns, offset): <= 32 windows per tile
 constexpr int kBrickLoff[5] = {0, 3000, 3648, 3840, 3921}; // slot offsets of the level-0..3 lattices: (8>>l)+2 cells per axis, 3 faces per cell
 constexpr int kBrickSlots = 3921, kBrickSlotsPad = 3936;
 constexpr int kBrickMaxRows = 1024;   // rows per tile, two per thread (a fuller brick is cut into two tiles with one lattice origin)
@@ -290,6 +293,7 @@ struct BrickView {
     const double *table = nullptr;
     int table_size = 0, col_bits = 0;
     int debug = 0; // measurement only: 1 no fill, 2 no pattern rows, 4 no streamed rows (wrong results), 16 phase stamps
+    int n_rows = 0; // partitioned systems: columns >= n_rows are halo entries ([owned | halo] local numbering)
 };
 // the form's arrays, owned by the context next to the CSR / value index of the solve matrix (avs_brick_build.hip)
 struct BrickScratch { // build-time buffers, kept across frames
@@ -303,13 +307,14 @@ struct BrickScratch { // build-time buffers, kept across frames
     DevBuf<char> tiles;
     DevBuf<uint8_t> force_e;
 };
-struct ValueIndex;
 struct BrickForm {
     DevBuf<uint2> tile_blk, rdesc, sdesc;
     DevBuf<uint32_t> blocks, pwords, swords;
     DevBuf<uint16_t> ownslot;
+    DevBuf<uint8_t> tile_flags;       // per tile (walk order): 1 = its rows read halo columns (partitioned systems)
     BrickScratch scratch;
-    int ntiles = 0, patterns = 0;
+    int ntiles = 0, patterns = 0, halo_tiles = 0;
+    int64_t n_rows = 0;               // rows of the system the form was built for (columns >= n_rows: halo)
     int64_t regular_rows = 0, streamed_words = 0, block_words = 0, pattern_words = 0, streamed_rows = 0;
     bool ready = false;
     bool wide = false;    // streamed words are 64 bits (column | code << 32)
@@ -318,6 +323,17 @@ struct BrickForm {
     void view(BrickView &B, const ValueIndex &vi) const;
     int64_t stored_bytes(int64_t n) const; // what one SpMV launch reads of the matrix
 };
+// what the form is built from: a CSR in the solver's numbering whose rows may read columns beyond the rows (the halo of a partitioned
+// system: columns [n_rows, n_cols) in the rank's local numbering), its value index, and the face behind every column
+struct BrickSource {
+    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    const int32_t *row_ptr = nullptr, *col = nullptr;
+    const ValueIndex *vi = nullptr;
+    const int32_t *vdof = nullptr;    // dof table, reference numbering (level | axis << 8, i, j, k)
+    const int32_t *ref_id = nullptr;  // n_cols: reference DOF id of every column (single GPU: the brick-major permutation)
+    int nx = 0, ny = 0, nz = 0, levels = 0, brick_shift = 3;
+};
+avs_status build_brick_form(BrickForm &bf, const BrickSource &src, const Options &opt, hipStream_t st); // avs_brick_build.hip
 size_t brick_lds_bytes(const BrickView &B);
 bool brick_lds_fits(const BrickView &B);          // the workgroup's LDS (lattice + value table + pattern image) within the device's limit
 avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, double *partial, const int *done_flag, hipStream_t stream);
@@ -477,6 +493,10 @@ avs_status dist_halo_end(PcgDist *d, hipStream_t main_stream);
 int spmv_tile_rows();
 avs_status build_reordered_system(struct ::avs_ctx *c, int brick_shift);
 avs_status build_brick_form(struct ::avs_ctx *c); // avs_brick_build.hip
+#ifdef AVS_PROBES
+// y = A x through the form the loops launch (+ the folded partial sums of x.y of the fused-dot instantiation); avs_api.hip
+avs_status probe_spmv_form(const CsrView &A, const double *x, double *y, bool fused, double *dot_out, hipStream_t st);
+#endif
 avs_status unpermute(struct ::avs_ctx *c, const double *xp, double *x);
 // builds the value dictionary of `val` (nnz entries); *table_size = 0 when there are more than 65536 distinct values
 avs_status build_value_index(const double *val, int64_t nnz, DevBuf<uint16_t> &codes, DevBuf<double> &table, int *table_size, hipStream_t st);

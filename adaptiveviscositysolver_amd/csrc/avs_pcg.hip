@@ -1403,7 +1403,7 @@ static avs_status pcg_solve_single_reduction(PcgWork *w, const CsrView &A, const
             const PcgScalars *now = sc + cur;
             const int32_t *t_int = nullptr, *t_bnd = nullptr;
             int n_int = 0, n_bnd = 0;
-            if (variant == 24 && dist_tile_lists(dist, &t_int, &n_int, &t_bnd, &n_bnd)) {
+            if (variant == 24 && !(A.brick && A.brick->ntiles > 0) && dist_tile_lists(dist, &t_int, &n_int, &t_bnd, &n_bnd)) {
                 // overlap: the exchange runs on the communication stream while the tiles that touch no halo
                 // column are multiplied; the halo-touching tiles follow once the halo has landed
                 AVS_TRY(dist_halo_begin(dist, u, stream));
@@ -1503,7 +1503,10 @@ __device__ __forceinline__ void push_raise_flags(const DistDev *dd, const unsign
 // CODED (round 3): the diagonal's 2-B value code + the table of inverted values instead of the 8-B inverse (11.25 n instead of
 // 12 n doubles of vector traffic; the same doubles, so nothing changes numerically); u is recomputed from r instead of read (10.25 n).  Rows are taken two at a time with 16-B
 // loads / stores (ranges start at multiples of the block size, so the pairs are aligned).
-template <bool CODED>
+// KEEP == false (round 5: the brick-structured form is small enough to stay in the Infinity Cache between two products -- but only
+// if the ~0.5 GB this kernel moves do not push it out): p, s, x, r -- read and written once per iteration, by this kernel only -- are
+// loaded and stored non-temporally; u (the next product's input) and w (the product's output, read here) stay cacheable.
+template <bool CODED, bool KEEP = true>
 __global__ __launch_bounds__(kBlock) void k_sr_update_push(int64_t n, double *__restrict__ x, double *__restrict__ r, double *__restrict__ p,
                                                            double *__restrict__ s, double *__restrict__ u, const double *__restrict__ w,
                                                            const double *__restrict__ invd, const uint16_t *__restrict__ dcode,
@@ -1524,12 +1527,12 @@ __global__ __launch_bounds__(kBlock) void k_sr_update_push(int64_t n, double *__
     double ru = 0., rr = 0.;
     int64_t i = lo + 2 * (int64_t)threadIdx.x;
     for (; i + 1 < hi; i += 2 * kBlock) { // (lo is a multiple of kBlock: i is even, the 16-B accesses are aligned)
-        const d2_t pv = *reinterpret_cast<const d2_t *>(p + i);
-        const d2_t wv = *reinterpret_cast<const d2_t *>(w + i), sv = *reinterpret_cast<const d2_t *>(s + i);
-        const d2_t xv = *reinterpret_cast<const d2_t *>(x + i), rv = *reinterpret_cast<const d2_t *>(r + i);
+        const d2_t pv = stream_load_k<KEEP>(reinterpret_cast<const d2_t *>(p + i));
+        const d2_t wv = *reinterpret_cast<const d2_t *>(w + i), sv = stream_load_k<KEEP>(reinterpret_cast<const d2_t *>(s + i));
+        const d2_t xv = stream_load_k<KEEP>(reinterpret_cast<const d2_t *>(x + i)), rv = stream_load_k<KEEP>(reinterpret_cast<const d2_t *>(r + i));
         double id0, id1;
         if (CODED) {
-            const unsigned cc = *reinterpret_cast<const unsigned *>(dcode + i);
+            const unsigned cc = stream_load_k<KEEP>(reinterpret_cast<const unsigned *>(dcode + i));
             id0 = invd[cc & 0xffffu];
             id1 = invd[cc >> 16];
         } else {
@@ -1547,10 +1550,10 @@ __global__ __launch_bounds__(kBlock) void k_sr_update_push(int64_t n, double *__
         xn.x = xv.x + alpha * pn.x; xn.y = xv.y + alpha * pn.y;
         rn.x = rv.x - alpha * sn.x; rn.y = rv.y - alpha * sn.y;
         un.x = id0 * rn.x;          un.y = id1 * rn.y;
-        *reinterpret_cast<d2_t *>(p + i) = pn;
-        *reinterpret_cast<d2_t *>(s + i) = sn;
-        *reinterpret_cast<d2_t *>(x + i) = xn;
-        *reinterpret_cast<d2_t *>(r + i) = rn;
+        stream_store_k<KEEP>(pn, reinterpret_cast<d2_t *>(p + i));
+        stream_store_k<KEEP>(sn, reinterpret_cast<d2_t *>(s + i));
+        stream_store_k<KEEP>(xn, reinterpret_cast<d2_t *>(x + i));
+        stream_store_k<KEEP>(rn, reinterpret_cast<d2_t *>(r + i));
         *reinterpret_cast<d2_t *>(u + i) = un;
         ru += rn.x * un.x;
         rr += rn.x * rn.x;
@@ -1657,6 +1660,15 @@ __global__ __launch_bounds__(256) void k_direct_selftest(HaloView hv, unsigned l
 avs_status spmv_dot_tiles(const CsrView &A, const double *x, double *y, double *partial, const PcgScalars *sc, const int32_t *tiles,
                           int ntiles, hipStream_t stream);
 
+// The finalizer of the direct transport as a launch of its own, behind the brick-structured form's SpMV (whose persistent workgroups
+// keep three per CU with the LDS they have: the finalizer's staging would cost the third): folds the round's stage slots and the
+// vector kernel's partials, all-gathers the sums with the other ranks and applies the scalar step (halo_finalizer, avs_halo.hpp).
+__global__ __launch_bounds__(512) void k_halo_finalize(HaloView hv)
+{
+    if (hv.sc->done) return;
+    halo_finalizer<512>(hv, (int)blockIdx.x);
+}
+
 #include "avs_pcg_resident.inl"
 
 // Transport self-test, run once per plan right after the blocks are connected and before the direct transport is trusted with a
@@ -1710,8 +1722,9 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
     double *p = w->p.p, *r = w->r.p, *wv = w->t.p, *sv = w->s.p, *u = w->u.p, *invd = w->invd.p;
     double *pvec = w->partial.p;                         // up to 3 * g vector-kernel partials
     PcgScalars *sc = w->sc.p;
-    const int ntiles = da.n_tiles_int + da.n_tiles_bnd;  // == ceil(n / kTileRows)
-    const int ppt = A.codes ? kTileRows / 64 : 1;        // value-indexed kernel: one partial per wave
+    const bool brick = A.brick && A.brick->ntiles > 0;   // brick-structured form of the local rows: one partial per persistent workgroup
+    const int ntiles = brick ? brick_partial_count(*A.brick) : da.n_tiles_int + da.n_tiles_bnd;  // (word stream: == ceil(n / kTileRows))
+    const int ppt = brick ? 1 : (A.codes ? kTileRows / 64 : 1); // value-indexed kernel: one partial per wave
     const int slots = ntiles * ppt;
     const int nfin = slots > 0 ? (slots + kFinShare - 1) / kFinShare : 1;
     AVS_TRY(w->stage2.alloc((size_t)(slots > 0 ? slots : 1) + (size_t)nfin));
@@ -1759,7 +1772,12 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
         hv.op = op;
         hv.tol = tol;
         hv.cancel = w->cancel_dev.p;
-        AVS_TRY(spmv_dot_tiles_halo(A, vec, wv, nullptr, sc, nullptr, ntiles + nfin, hv, stream));
+        if (brick) { // the persistent grid, then the finalizer as a small launch of its own
+            AVS_TRY(spmv_brick_halo_launch(*A.brick, vec, wv, &sc->done, hv, stream));
+            hipLaunchKernelGGL(k_halo_finalize, dim3(nfin), dim3(512), 0, stream, hv);
+        } else {
+            AVS_TRY(spmv_dot_tiles_halo(A, vec, wv, nullptr, sc, nullptr, ntiles + nfin, hv, stream));
+        }
         if (eb) AVS_HIP(hipEventRecord(eb, stream));
         return AVS_OK;
     };
@@ -1784,11 +1802,14 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
 
     auto enqueue_iteration = [&](int c, bool timed) -> avs_status {
         // update and push in one launch (3 launches per iteration)
-        if (coded)
-            hipLaunchKernelGGL(k_sr_update_push<true>, dim3(g), dim3(kBlock), 0, stream, n, x, r, p, sv, u, wv, (const double *)w->invtab.p,
+        if (coded && brick) // (the brick form serves single-dictionary matrices: coded)
+            hipLaunchKernelGGL((k_sr_update_push<true, false>), dim3(g), dim3(kBlock), 0, stream, n, x, r, p, sv, u, wv, (const double *)w->invtab.p,
+                               (const uint16_t *)w->dcode.p, (const PcgScalars *)sc, pvec, da.dd, (const unsigned long long *)da.epoch, da.push_ticket);
+        else if (coded)
+            hipLaunchKernelGGL((k_sr_update_push<true, true>), dim3(g), dim3(kBlock), 0, stream, n, x, r, p, sv, u, wv, (const double *)w->invtab.p,
                                (const uint16_t *)w->dcode.p, (const PcgScalars *)sc, pvec, da.dd, (const unsigned long long *)da.epoch, da.push_ticket);
         else
-            hipLaunchKernelGGL(k_sr_update_push<false>, dim3(g), dim3(kBlock), 0, stream, n, x, r, p, sv, u, wv, (const double *)invd,
+            hipLaunchKernelGGL((k_sr_update_push<false, true>), dim3(g), dim3(kBlock), 0, stream, n, x, r, p, sv, u, wv, (const double *)invd,
                                (const uint16_t *)nullptr, (const PcgScalars *)sc, pvec, da.dd, (const unsigned long long *)da.epoch, da.push_ticket);
         return round(u, 2, (int)OP_SR_STEP, timed ? w->evA[c] : nullptr, timed ? w->evB[c] : nullptr, false);
     };
@@ -1828,7 +1849,7 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
         timed_chunk = !replay;
         if (replay) {
             const void *key[10] = {A.row_ptr, A.col, A.codes, A.packed, A.table, x, b, (const void *)da.dd, (const void *)(intptr_t)A.n,
-                                   (const void *)(intptr_t)(((int64_t)A.table_size << 8) + A.col_bits + 1000003ll * ntiles + 1000000007ll * (int64_t)A.epoch)};
+                                   (const void *)(intptr_t)(((int64_t)A.table_size << 8) + A.col_bits + 1000003ll * ntiles + 1000000007ll * (int64_t)A.epoch + (brick ? 7 : 0))};
             (void)da.tiles_int;
             if (w->graph && (memcmp(key, w->graph_key, sizeof(key)) != 0 || w->graph_tol != tol)) {
                 (void)hipGraphExecDestroy(w->graph);

@@ -30,6 +30,8 @@ def main():
     sc = {"beam": lambda: scenes.fat_beam(64, 3, device=dev),
           "varvisc": lambda: scenes.fat_beam(64, 3, variable_viscosity=True, device=dev),
           "beam128": lambda: scenes.fat_beam(128, 3, device=dev),
+          "beam128_brick": lambda: scenes.fat_beam(128, 3, device=dev),        # (AVS_BRICK=1 in the environment: the brick-structured form)
+          "beam128L4_brick": lambda: scenes.fat_beam(128, 4, device=dev),
           "varvisc128": lambda: scenes.fat_beam(128, 4, variable_viscosity=True, device=dev)}[scene]()
     pp = DevicePrepass(sc.res, sc.dx, sc.levels)
     pi = pp.run(sc.liquid, sc.solid)
@@ -72,6 +74,7 @@ def main():
                                                                   s.matrix_format().tile_local_tables, s.matrix_format().column_windows,
                                                                   resident, ci["selftest_rounds"], ci["selftest_bad_entries"], 1 if ci["paranoid"] else 0],
                                                                  np.float64))
+    np.save(os.path.join(workdir, f"fmt_{rank}.npy"), np.array([s.matrix_format().brick_tiles, s.matrix_format().brick_pattern_rows], np.float64))
     # keep the comm block alive until every rank has finished (a peer may still be reading its own copy of the flags)
     open(os.path.join(workdir, f"done_{rank}"), "w").write("ok")
     for q in range(world):

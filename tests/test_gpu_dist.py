@@ -105,7 +105,8 @@ def test_rccl_world_size_one(built_lib):
     assert ci["launches_per_iteration"] == 2 and ci["graph_replay"]      # update (+ push), SpMV (+ finalizer block)
 
 
-@pytest.mark.parametrize("scene,world", [("beam", 2), ("varvisc", 2), ("beam128", 3), ("beam128", 8), ("varvisc128", 3)])
+@pytest.mark.parametrize("scene,world", [("beam", 2), ("varvisc", 2), ("beam128", 3), ("beam128", 8), ("varvisc128", 3),
+                                         ("beam128_brick", 3), ("beam128L4_brick", 2)])   # round 5: the brick-structured form, HALO instantiation
 def test_processes_direct_transport(scene, world, tmp_path, built_lib):
     """One PROCESS per rank (both on cuda:0): comm blocks mapped through HIP IPC handles, halo entries stored straight into
     the neighbour's block, CG sums by flag-based all-gather -- no RCCL anywhere (hosted group, blobs through files)."""
@@ -116,6 +117,8 @@ def test_processes_direct_transport(scene, world, tmp_path, built_lib):
     sc = {"beam": lambda: scenes.fat_beam(64, 3, device=dev),
           "varvisc": lambda: scenes.fat_beam(64, 3, variable_viscosity=True, device=dev),
           "beam128": lambda: scenes.fat_beam(128, 3, device=dev),
+          "beam128_brick": lambda: scenes.fat_beam(128, 3, device=dev),
+          "beam128L4_brick": lambda: scenes.fat_beam(128, 4, device=dev),
           # tile-local dictionaries + windowed columns through the HALO instantiation of the SpMV (peer-written halo area)
           "varvisc128": lambda: scenes.fat_beam(128, 4, variable_viscosity=True, device=dev)}[scene]()
     pyr = build_pyramid(sc)
@@ -126,6 +129,8 @@ def test_processes_direct_transport(scene, world, tmp_path, built_lib):
     ref.close()
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", AVS_DIST_TIMEOUT_MS="30000")
+    if scene.endswith("_brick"):
+        env["AVS_BRICK"] = "1"   # (slabs this small would not get the form by the size rule)
     procs = [subprocess.Popen([sys.executable, os.path.join(here, "hosted_rank.py"), str(tmp_path), str(r), str(world), scene, repr(tol)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
     outs = [p.communicate(timeout=280) for p in procs]
@@ -135,6 +140,8 @@ def test_processes_direct_transport(scene, world, tmp_path, built_lib):
     n_own = 0
     for r in range(world):
         x += np.load(tmp_path / f"x_{r}.npy")
+        brick_tiles, brick_rows = np.load(tmp_path / f"fmt_{r}.npy")
+        assert (brick_tiles > 0) == scene.endswith("_brick"), (scene, r, brick_tiles)
         it1, c1, it2, c2, own, halo, direct, rccl_calls, launches, tile_tables, windows, resident, st_rounds, st_bad, paranoid = np.load(tmp_path / f"info_{r}.npy")
         assert resident == 0     # ranks that share one GPU keep the launch-per-phase loop (the resident loop needs every CU)
         assert st_rounds == 64 and st_bad == 0 and paranoid == 0    # the transport self-test ran over the mapped blocks and passed
@@ -263,15 +270,20 @@ def test_device_planner_equals_host_planner(world, cut_axis, scene, built_lib, m
     s.close()
 
 
-@pytest.mark.parametrize("world,cut_axis,scene", [(1, -1, "beam"), (2, -1, "beam"), (4, 0, "varvisc"), (3, 2, "sphere"), (3, 0, "varvisc128")])
-def test_distributed_assembly_matches_single_solve(world, cut_axis, scene, built_lib):
+@pytest.mark.parametrize("world,cut_axis,scene", [(1, -1, "beam"), (2, -1, "beam"), (4, 0, "varvisc"), (3, 2, "sphere"), (3, 0, "varvisc128"),
+                                                  (1, -1, "beam128_brick"), (3, 0, "beam128_brick"), (2, 2, "beam128L4_brick")])
+def test_distributed_assembly_matches_single_solve(world, cut_axis, scene, built_lib, monkeypatch):
     """avs_dist_assemble: every rank assembles only its own rows (no global matrix) -- the partitioned solve must
     reproduce the single-rank solve, the local systems must add up to the global one, and the send / receive lists of
     neighbouring ranks must agree (they are derived independently on each side from the symmetric pattern)."""
     dev = torch.device("cuda:0")
+    if scene.endswith("_brick"):   # round 5: the brick-structured form of the rank's local rows ([owned | halo] columns, halo in the vector's tail)
+        monkeypatch.setenv("AVS_BRICK", "1")
     sc = {"beam": lambda: scenes.fat_beam(64, 3, device=dev),
           "varvisc": lambda: scenes.fat_beam(64, 3, variable_viscosity=True, device=dev),
           "sphere": lambda: scenes.sphere(64, 4, device=dev),
+          "beam128_brick": lambda: scenes.fat_beam(128, 3, device=dev),
+          "beam128L4_brick": lambda: scenes.fat_beam(128, 4, device=dev),
           # tens of thousands of distinct values per rank: tile-local dictionaries + windowed columns on matrices with halo
           # columns and the [interior | halo-reading] row order (the form whose head-of-pass decode once gathered out of range)
           "varvisc128": lambda: scenes.fat_beam(128, 4, variable_viscosity=True, device=dev)}[scene]()
@@ -303,6 +315,9 @@ def test_distributed_assembly_matches_single_solve(world, cut_axis, scene, built
             if scene == "varvisc128":
                 fmt = s.matrix_format()
                 assert fmt.tile_local_tables == 1 and fmt.column_windows == 1 and fmt.bytes_per_nonzero == 4
+            if scene.endswith("_brick"):
+                fmt = s.matrix_format()
+                assert fmt.brick_tiles > 0 and fmt.brick_pattern_rows > 0.6 * plan["sizes"][0], (r, fmt.brick_tiles, fmt.brick_pattern_rows)
             results[r] = (info, x, ai, plan)
         except Exception as e:  # pragma: no cover
             errors.append((r, e))
@@ -390,3 +405,45 @@ def test_loopback_measurement_mode(built_lib, monkeypatch):
         ti, tb = s.overlap_tiles
         assert 0 < tb < ti            # [interior | halo-reading] row order: few halo-reading tiles
         s.close()
+
+
+@pytest.mark.parametrize("world,rank,scene", [(2, 0, "beam128"), (3, 1, "beam128"), (2, 1, "sheet128")])
+def test_local_brick_form_product(world, rank, scene, built_lib, monkeypatch):
+    """the brick-structured form of ONE rank's local rows against the word stream of the same rows: a random [owned | halo] vector through
+    both (plain and fused-dot instantiations) must give the same y bit for bit (the word stream is the form the other tests pin against
+    the oracle).  Both plans use the plain ascending row order (AVS_DIST_SPLIT_ROWS=0), so the local numberings are the same."""
+    dev = torch.device("cuda:0")
+    sc = scenes.fat_beam(128, 4, device=dev) if scene == "beam128" else scenes.thin_sheet(128, 4, thickness_cells=12, device=dev)
+    pyr = build_pyramid(sc)
+    monkeypatch.setenv("AVS_DIST_SPLIT_ROWS", "0")
+    rng = np.random.default_rng(5)
+    ys, dots, owns, xs = {}, {}, {}, None
+    for brick in (1, 0):
+        monkeypatch.setenv("AVS_BRICK", str(brick))
+        s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0, probe=True)
+        feed(s, pyr)
+        s.set_scene_fields(sc)
+        capi.check(s.lib.avs_dist_init_hosted(s.h, rank, world))   # planning and assembly need no peer
+        s.dist_assemble(0)
+        sz = s.plan_sizes
+        fmt = s.matrix_format()
+        assert (fmt.brick_tiles > 0) == bool(brick) and sz.n_halo > 0
+        n_ext = int(sz.n_own + sz.n_halo)
+        if xs is None:
+            xs = [torch.from_numpy(rng.standard_normal(n_ext) * 10.0 ** rng.integers(-2, 3, n_ext)).to(dev) for _ in range(2)]
+        owns[brick] = _plan_arrays(s)["own"].copy()
+        for t, x in enumerate(xs):
+            assert len(x) == n_ext
+            for fused in (0, 1):
+                y = torch.full((int(sz.n_own),), float("nan"), dtype=torch.float64, device=dev)
+                dot = C.c_double()
+                capi.check(s.lib.avs_dist_spmv_local_form(s.h, x.data_ptr(), y.data_ptr(), fused, C.byref(dot)))
+                ys[(brick, t, fused)] = y.cpu().numpy()
+                dots[(brick, t, fused)] = dot.value
+        s.close()
+    assert np.array_equal(owns[0], owns[1])
+    for t in range(2):
+        for fused in (0, 1):
+            yb, yw = ys[(1, t, fused)], ys[(0, t, fused)]
+            assert np.array_equal(yb.view(np.int64), yw.view(np.int64)), (t, fused, int((yb != yw).sum()))
+        assert abs(dots[(1, t, 1)] - dots[(0, t, 1)]) <= 1e-9 * max(1.0, abs(dots[(0, t, 1)]))

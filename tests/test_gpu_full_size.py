@@ -183,6 +183,9 @@ def test_headline_512_against_the_oracle(built_lib):
     feed(s, pyr)
     s.set_scene_fields(sc)
     ai = s.assemble()
+    fmt0 = s.matrix_format()
+    # the comparison below must cover the kernel the headline runs: the brick-structured form, chosen by the (deterministic) default mode
+    assert fmt0.brick_tiles > 0 and fmt0.brick_pattern_rows > 0.9 * ai.n_velocity and fmt0.brick_walk == 0, (fmt0.brick_tiles, fmt0.brick_walk)
     sys_path = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     import sys
     sys.path.insert(0, sys_path)
