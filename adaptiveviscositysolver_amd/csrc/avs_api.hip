@@ -100,6 +100,11 @@ Options options_from_env()
     o.column_windows = env_int("AVS_COLUMN_WINDOWS", 1) != 0;
     o.brick_min_regular = env_dbl("AVS_BRICK_MIN_REGULAR", 0.6);
     o.brick_timing = getenv("AVS_BRICK_TIMING") != nullptr;
+    o.brick_plan = env_int("AVS_BRICK_PLAN", 1) != 0;
+    if (const char *e = getenv("AVS_BRICK_COST")) {
+        BrickCost &k = o.brick_cost;
+        (void)sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &k.tile, &k.row, &k.run, &k.word, &k.etile, &k.quad);
+    }
     o.fuse_beta = env_int("AVS_PCG_FUSE_BETA", 1) != 0;
     o.resident_cus = env_int("AVS_CG_RESIDENT_CUS", 0);
     o.resident_equal_lanes = getenv("AVS_CG_RESIDENT_EQUAL_LANES") != nullptr;

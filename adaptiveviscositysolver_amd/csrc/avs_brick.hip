@@ -28,14 +28,15 @@
 // plain CSR kernel.
 // Round 5 -- partitioned systems: a fill run names its column as (one of <= 32 windows of 2^11 columns in the tile header, offset), so
 // the local system of a rank ([owned | halo] columns) is just another matrix; with the halo in the tail of the vector (RCCL transport)
-// the kernel is unchanged.  HALO instantiation (direct transport): halo columns live in the rank's comm block, written by the peers --
-// a tile flagged in its header first waits for the peers' epoch flags, reads halo columns with system-scope loads, and every
-// persistent workgroup drops its x.y partial into a stage slot for the finalizer kernel that follows (k_halo_finalize, avs_pcg.hip).  Reference: Eigen's `mat * p` inside ConjugateGradient (cpp:618-630 of HDK_AdaptiveViscosity.cpp); the row
+// the kernel is unchanged.  Direct transport: the halo lives in the rank's comm block, written by the peers; a small launch in front of
+// this kernel (k_halo_gather, avs_pcg.hip) waits for the peers' flags and copies it behind the owned entries of the vector, and the
+// persistent workgroups' x.y partials go to the stage slots the finalizer launch behind it folds (k_halo_finalize).  (A HALO
+// instantiation of this kernel -- flag wait per flagged tile, comm-block loads in the fill -- was built first: 4-23 spilled registers
+// and 139-167 us against 118 for the plain kernel; the two small launches cost ~5 us.)  Reference: Eigen's `mat * p` inside ConjugateGradient (cpp:618-630 of HDK_AdaptiveViscosity.cpp); the row
 // structure is that of cpp:2537-2745.
 #include <mutex>
 
 #include "avs_internal.hpp"
-#include "avs_halo.hpp"
 
 namespace avs {
 
@@ -43,7 +44,7 @@ constexpr int kBrickBlk = 512;
 
 #ifdef AVS_PROBES
 // measurement only (AVS_BRICK_DEBUG & 16): wall_clock64 stamps of workgroup phases, 8 per tile, first kStampTiles tiles of every workgroup
-constexpr int kStampTiles = 24, kStampWgs = 1024;
+constexpr int kStampTiles = 40, kStampWgs = 1024;
 __device__ long long g_brick_stamps[kStampWgs * kStampTiles * 8];
 #define BRICK_DBG(bit) (B.debug & (bit))
 #define BRICK_STAMP(slot)                                                                                            \
@@ -93,23 +94,21 @@ __device__ __forceinline__ T ld_u32(const T *base, unsigned idx)
     return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (size_t)(unsigned)(idx * (unsigned)sizeof(T)));
 }
 
-constexpr int kBrickRu = kBrickMaxRuns / (kBrickBlk / 16);              // halo fill runs per quarter wave
 
 // A tile's descriptors are ONE contiguous block of 32-bit words (<= 8 KB), fetched with one 16-B load per thread and parked in LDS:
 //   [0] row0 [1] nrows [2] npat [3] nruns [4] npq (pattern quads) [5] nprow (pattern rows) [6] srow0 [7] nsrows [8] sword0 [9] nsw
 //   [16 .. 48) first rows of the 27 neighbour bricks
 //   [10] rd0 (first pattern-row descriptor of the tile in rdesc)
-//   runs[nruns] | pquads[npq] | pinfo[npat]
+//   runs[nruns] (8 B each: absolute first column | slot << 4 | length - 1) | pquads[npq] | pinfo[npat]
+//   [11] the tile's rows read halo columns (partitioned systems)
 // The per-row arrays (rdesc: descriptor + position of every pattern row in execution order; ownslot) stay in global memory.
 constexpr int kBlkHdr = kBlkHdrWords;
 
-template <bool DOT, bool HALO>
+template <bool DOT>
 __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_spmv_brick(BrickView B, const double *__restrict__ x, double *__restrict__ y,
-                                                         double *__restrict__ partial, const int *__restrict__ done_flag, HaloView hv)
+                                                         double *__restrict__ partial, const int *__restrict__ done_flag)
 {
     if (DOT && done_flag && *done_flag) return;
-    const double *__restrict__ hx = HALO ? hv.dd->my_halo : nullptr;   // the comm block's halo area: column c >= n_own lives at hx[c - n_own]
-    const unsigned n_own = HALO ? (unsigned)hv.dd->n_own : 0u;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *xs = smem;                                                  // kBrickSlotsPad
     double *park = smem + kBrickSlotsPad;                               // kBrickPark doubles, right behind the lattice: [0, kBrickXSlots) extra
@@ -153,35 +152,42 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
     //   0  one contiguous EIGHTH of the tiles per XCD -- best where tiles cost the same everywhere (512^3 beam: 2 % over walk 1 in the loop);
     //   1  chunks of gridDim / 8 tiles dealt to the XCDs in turn -- every XCD sees the same mix of tiles.  A thin sheet's eighths are its z
     //      layers (full surface bricks here, coarse interior there) and the kernel waits for the slowest XCD: 133 (walk 0) against 94 us.
-    int tile = blockIdx.x, tstep = (int)gridDim.x, tend = B.ntiles, mrun = 0, mjump = 0, mk = 0;
-    if ((gridDim.x & 7u) == 0u && B.ntiles >= (int)gridDim.x && !BRICK_DBG(32)) {
-        const int c = (int)(blockIdx.x & 7u), gx = (int)(gridDim.x >> 3);
-        tile = c * gx + (int)(blockIdx.x >> 3);
-        if (B.walk == 0 && !BRICK_DBG(2048)) { // one contiguous eighth of the tiles per XCD (chosen per matrix by measurement: see below)
-            tstep = gx;
-            tile = (int)(((int64_t)B.ntiles * c) >> 3) + (int)(blockIdx.x >> 3);
-            tend = (int)(((int64_t)B.ntiles * (c + 1)) >> 3);
+    //   2  (round 5) a PLANNED walk: every workgroup's tile sequence is laid out by the host from a cost model of the tiles (BrickForm::plan_walk:
+    //      cost-equal contiguous ranges per XCD, then the tiles of a range dealt, in order, to whichever of the XCD's workgroups has
+    //      the least work so far) -- the static walks end 15-20 % after their average workgroup (E tiles cost two G tiles, G tiles
+    //      differ by their rows); deterministic: the plan is a function of the matrix and the grid.
+    const uint2 *seq;                                                    // this workgroup's tiles: seq[0], seq[step], ... (cnt of them)
+    int step, cnt;
+    if (B.wlist && (int)gridDim.x == B.wgrid && !BRICK_DBG(32)) {
+        const int w0 = B.wptr[blockIdx.x];
+        seq = B.wlist + w0;
+        step = 1;
+        cnt = B.wptr[blockIdx.x + 1] - w0;
+    } else {
+        int tile = blockIdx.x, tstep = (int)gridDim.x, tend = B.ntiles;
+        if ((gridDim.x & 7u) == 0u && B.ntiles >= (int)gridDim.x && !BRICK_DBG(32)) {
+            const int c = (int)(blockIdx.x & 7u), gx = (int)(gridDim.x >> 3);
+            tile = c * gx + (int)(blockIdx.x >> 3);
+            if (B.walk == 0) { // one contiguous eighth of the tiles per XCD
+                tstep = gx;
+                tile = (int)(((int64_t)B.ntiles * c) >> 3) + (int)(blockIdx.x >> 3);
+                tend = (int)(((int64_t)B.ntiles * (c + 1)) >> 3);
+            }
         }
-        if (BRICK_DBG(512) || BRICK_DBG(1024)) { // measurement: chunks of m * gx tiles per XCD (m walks of its workgroups), m = 4 / 16
-            mrun = BRICK_DBG(512) ? 4 : 16;
-            tile = c * mrun * gx + (int)(blockIdx.x >> 3);
-            tstep = gx;
-            mjump = 7 * mrun * gx;
-        }
-        if (BRICK_DBG(256)) { // measurement: one contiguous eighth of the tiles per XCD
-            tstep = gx;
-            tile = (int)(((int64_t)B.ntiles * c) >> 3) + (int)(blockIdx.x >> 3);
-            tend = (int)(((int64_t)B.ntiles * (c + 1)) >> 3);
-        }
+        seq = B.tile_blk + tile;
+        step = tstep;
+        cnt = tile < tend ? (tend - tile + tstep - 1) / tstep : 0;
     }
-    if (tile >= tend) return;                                            // (cannot happen: the grid is at most ntiles workgroups)
+    if (cnt <= 0) {                                                      // (a workgroup without tiles: only when the grid exceeds what the plan could fill)
+        if (DOT && tid == 0) partial[blockIdx.x] = 0.;
+        return;
+    }
     const uint4 *blocks16 = reinterpret_cast<const uint4 *>(B.blocks);
-    uint2 tb = B.tile_blk[tile];                                         // first 16-B unit, units
+    uint2 tb = seq[0];                                                   // first 16-B unit, units
     uint4 blk = blocks16[(int64_t)tb.x + (tid < (int)tb.y ? tid : 0)];
     int nsw_prev = 0;
 
     int iter = 0;
-    (void)iter;
     double dot = 0.;                                                     // x.y of this lane's rows, all tiles of the workgroup
     for (;;) {
         BRICK_STAMP(0);
@@ -194,40 +200,65 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         const int srow0 = __builtin_amdgcn_readfirstlane((int)bw[6]), nsrows = __builtin_amdgcn_readfirstlane((int)bw[7]);
         const int sword0 = __builtin_amdgcn_readfirstlane((int)bw[8]), nsw = __builtin_amdgcn_readfirstlane((int)bw[9]);
         const int rd0 = __builtin_amdgcn_readfirstlane((int)bw[10]);
-        const bool hb = HALO && __builtin_amdgcn_readfirstlane((int)bw[11]) != 0; // this tile's rows read halo columns
-        if (HALO && hb) halo_wait(hv);                 // (block-uniform) the peers' entries of this round have landed; only the first such tile really waits
-        // a column of the vector the rows multiply with: own entries from x, halo entries from the comm block (bypassing the caches)
-        auto xg = [&](unsigned c) -> double {
-            if (HALO && hb && c >= n_own) return ld_sys_f64(hx + (c - n_own));
-            return ld_u32(x, c);
-        };
-        const int o_runs = kBlkHdr, o_pq = o_runs + nruns, o_pi = o_pq + npq;
+        const int o_runs = kBlkHdr, o_pq = o_runs + 2 * nruns, o_pi = o_pq + npq; // (runs are 8 B)
         const bool emode = npat == 0;                 // no pattern rows: the products of the streamed rows may use the x lattice's LDS
         double *prod = emode ? xs : park + kBrickXSlots;
         const int cap = emode ? kBrickSlotsPad : kBrickPark - kBrickXSlots;
         BRICK_STAMP(1);
 #ifdef AVS_PROBES
         if (BRICK_DBG(16) && threadIdx.x == 0 && iter < kStampTiles && blockIdx.x < kStampWgs) // tile kind: 1 E tile, 2 G tile with streamed rows, 0 G tile
-            g_brick_stamps[((int)blockIdx.x * kStampTiles + iter) * 8 + 5] = emode ? 1 : (nsw > 0 ? 2 : 0);
+        {
+            long long *sp = &g_brick_stamps[((int)blockIdx.x * kStampTiles + iter) * 8];
+            sp[5] = emode ? 1 : (nsw > 0 ? 2 : 0);
+            sp[6] = (long long)nprow | ((long long)nruns << 16) | ((long long)npq << 32) | ((long long)nrows << 48);   // what a cost model can see
+            sp[7] = (long long)nsw | ((long long)nsrows << 32);
+        }
 #endif
-        // ---- this tile's loads, one round trip: x of the halo runs, x of the tile's own rows, the pattern quads
-        double fv[kBrickRu];
-        uint32_t rdsc[kBrickRu];
+        // ---- this tile's loads, ONE round trip: x of the halo runs, x of the tile's own rows, the pattern quads, the row descriptors.
+        // Round 5: (i) a fill run is 8 B -- absolute first column | slot << 4 | length - 1 -- so a batch costs ONE LDS read (it was two
+        // dependent ones: run word, then the base of its neighbour brick); (ii) every LDS read the loads depend on (run words, pattern
+        // quad offsets) is issued before the first global load -- one wait instead of one or two per batch; (iii) nothing is SELECTED
+        // right behind a load (`valid ? loaded : default` made the compiler wait for that load on the spot: the round-4 binary stalled
+        // for the own-slot load, the row descriptors and the streamed descriptors one after the other, three serialised round trips);
+        // validity is a predicate recomputed where the value is used.
+        constexpr int RPT = kBrickMaxRows / kBrickBlk;
+        constexpr int PQ = (kBrickPatWords / 4 + kBrickBlk - 1) / kBrickBlk;
+        constexpr int kRuFast = 6;                     // fill batches held in registers (192 runs: nearly every tile); the rest, rare, go run by run
+        const uint2 *runs2 = reinterpret_cast<const uint2 *>(bw + o_runs);
+        double fv[kRuFast];
+        uint32_t rdsc[kRuFast];
+        uint32_t pqo[PQ];
 #pragma unroll
-        for (int u = 0; u < kBrickRu; ++u) {
-            fv[u] = 0.;
-            rdsc[u] = 0xffffffffu;
-            if (u * QW < nruns) {                      // block-uniform: a batch nobody needs is not requested
-                const int q = u * QW + qw;
-                const uint32_t r = bw[o_runs + (q < nruns ? q : 0)];
-                const int nbase = (int)bw[16 + (r >> 27)];
-                const bool on = q < nruns && l16 <= (int)(r & 15u) && !BRICK_DBG(1);
-                rdsc[u] = on ? r : 0xffffffffu;
-                const unsigned cidx = (unsigned)(on ? nbase + (int)((r >> 16) & 0x7ffu) + l16 : row0);
-                fv[u] = (HALO && hb) ? xg(cidx) : ld_u32(x, cidx);
+        for (int u = 0; u < PQ; ++u) {
+            pqo[u] = 0u;
+            if (u * kBrickBlk < npq) {
+                const int q = tid + u * kBrickBlk;
+                pqo[u] = bw[o_pq + (q < npq ? q : 0)];
             }
         }
-        constexpr int RPT = kBrickMaxRows / kBrickBlk;
+        const uint32_t pinf = bw[o_pi + (tid < npat ? tid : 0)];
+        {
+            uint2 rw[kRuFast];
+#pragma unroll
+            for (int u = 0; u < kRuFast; ++u) {
+                rw[u] = uint2{0u, 0u};
+                if (u * QW < nruns) {                  // block-uniform: a batch nobody needs is not requested
+                    const int q = u * QW + qw;
+                    rw[u] = runs2[q < nruns ? q : 0];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kRuFast; ++u) {
+                fv[u] = 0.;
+                rdsc[u] = 0xffffffffu;
+                if (u * QW < nruns) {
+                    const int q = u * QW + qw;
+                    const bool on = q < nruns && l16 <= (int)(rw[u].y & 15u) && !BRICK_DBG(1);
+                    rdsc[u] = on ? rw[u].y : 0xffffffffu;
+                    fv[u] = ld_u32(x, on ? rw[u].x + (unsigned)l16 : (unsigned)row0);
+                }
+            }
+        }
         double xo[RPT];
         uint32_t os[RPT];
 #pragma unroll
@@ -237,32 +268,25 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
             if (!emode && k * kBrickBlk < nrows) {
                 const int r = tid + k * kBrickBlk;
                 xo[k] = ld_u32(x + row0, (unsigned)(r < nrows ? r : 0));
-                const uint32_t o = ld_u32(B.ownslot + row0, (unsigned)(r < nrows ? r : 0));
-                os[k] = r < nrows ? o : 0xffffu;
+                os[k] = ld_u32(B.ownslot + row0, (unsigned)(r < nrows ? r : 0));   // (a clamped lane re-reads row 0's slot: it is not written, see below)
             }
         }
-        constexpr int PQ = (kBrickPatWords / 4 + kBrickBlk - 1) / kBrickBlk;
         uint4 pqv[PQ];
 #pragma unroll
         for (int u = 0; u < PQ; ++u) {
             pqv[u] = uint4{0u, 0u, 0u, 0u};
-            if (u * kBrickBlk < npq) {
-                const int q = tid + u * kBrickBlk;
-                pqv[u] = *reinterpret_cast<const uint4 *>(B.pwords + bw[o_pq + (q < npq ? q : 0)]);
-            }
+            if (u * kBrickBlk < npq) pqv[u] = *reinterpret_cast<const uint4 *>(B.pwords + pqo[u]);
         }
-        uint2 rdv[RPT]; // descriptor, position in the tile
+        uint2 rdv[RPT]; // descriptor, position in the tile (valid for tid + k * kBrickBlk < nprow)
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            rdv[k] = uint2{0u, 0xffffffffu};
+            rdv[k] = uint2{0u, 0u};
             if (k * kBrickBlk < nprow) {
                 const int i = tid + k * kBrickBlk;
                 rdv[k] = ld_u32(B.rdesc + rd0, (unsigned)(i < nprow ? i : 0));
-                rdv[k].y = i < nprow ? rdv[k].y : 0xffffffffu;
             }
         }
-        const uint32_t pinf = bw[o_pi + (tid < npat ? tid : 0)];
-        // streamed rows (few tiles): descriptors, and for a G tile the first pass of words with their x
+        // streamed rows (few tiles): descriptors (valid for brick_srow_of_thread(tid, k) < nsrows), and for a G tile the first pass of words with their x
         uint2 sd[kBrickMaxRows / kBrickBlk];
 #pragma unroll
         for (int k = 0; k < kBrickMaxRows / kBrickBlk; ++k) sd[k] = uint2{0u, 0u};
@@ -273,8 +297,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
             for (int k = 0; k < kBrickMaxRows / kBrickBlk; ++k) {
                 if (k * kBrickBlk >= nsrows) break;
                 const int i = brick_srow_of_thread(tid, k);
-                const uint2 t = B.sdesc[srow0 + (i < nsrows ? i : 0)];
-                sd[k] = (i < nsrows) ? t : uint2{0u, 0u};
+                sd[k] = B.sdesc[srow0 + (i < nsrows ? i : 0)];
             }
             if (!emode && !wide) {
 #pragma unroll
@@ -283,13 +306,12 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                     w0[u] = B.swords[(int64_t)sword0 + (e < nsw ? e : 0)];
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) xv0[u] = xg(w0[u] & cmask);
+                for (int u = 0; u < 2; ++u) xv0[u] = x[w0[u] & cmask];
             }
         }
         // the next tile's block address: a scalar load, in flight while this tile's data arrives
-        const int tnext = tile + tstep + ((mrun && mk + 1 == mrun) ? mjump : 0);
-        const bool more = tnext < tend;
-        const uint2 tbn = B.tile_blk[more ? tnext : tile];
+        const bool more = iter + 1 < cnt;
+        const uint2 tbn = seq[(int64_t)(more ? iter + 1 : iter) * step];
         // ---- LDS writes
         if (tid < npat) pinfo[tid] = pinf;
 #pragma unroll
@@ -298,11 +320,18 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
             if (q < npq) reinterpret_cast<uint4 *>(pw)[q] = pqv[u];
         }
 #pragma unroll
-        for (int u = 0; u < kBrickRu; ++u)
+        for (int u = 0; u < kRuFast; ++u)
             if (rdsc[u] != 0xffffffffu) xs[((rdsc[u] >> 4) & 0xfffu) + l16] = fv[u]; // (extra slots: xs runs on into `park`)
+        if (nruns > kRuFast * QW && !BRICK_DBG(1)) {   // (block-uniform, rare) the runs beyond the register batches: straight into LDS
+#pragma unroll 1
+            for (int q = kRuFast * QW + qw; q < nruns; q += QW) {
+                const uint2 r = runs2[q];
+                if (l16 <= (int)(r.y & 15u)) xs[((r.y >> 4) & 0xfffu) + l16] = ld_u32(x, r.x + (unsigned)l16);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < RPT; ++k)
-            if (os[k] != 0xffffu) xs[os[k]] = xo[k];
+            if (!emode && tid + k * kBrickBlk < nrows && os[k] != 0xffffu) xs[os[k]] = xo[k];
         __syncthreads();
         BRICK_STAMP(2);
 
@@ -319,7 +348,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
             if (k * kBrickBlk >= nprow) break;
-            if (rdv[k].y != 0xffffffffu && !BRICK_DBG(2)) {
+            if (tid + k * kBrickBlk < nprow && !BRICK_DBG(2)) {
                 const uint32_t rd = rdv[k].x, ro = rdv[k].y;
                 const unsigned pid = rd >> 20;
                 const int lr = (int)((rd >> 18) & 3u), ax = (int)((rd >> 16) & 3u);
@@ -405,7 +434,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                             }
                         }
 #pragma unroll
-                        for (int u = 0; u < SU; ++u) x4[u] = xg(w4[u]);
+                        for (int u = 0; u < SU; ++u) x4[u] = x[w4[u]];
 #pragma unroll
                         for (int u = 0; u < SU; ++u) {
                             const int e = e0 + u * kBrickBlk;
@@ -416,14 +445,14 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                 __syncthreads();
 #pragma unroll
                 for (int k = 0; k < kBrickMaxRows / kBrickBlk; ++k) {
-                    const int len = (int)(sd[k].x >> 16), st = (int)sd[k].y;
+                    const int len = brick_srow_of_thread(tid, k) < nsrows ? (int)(sd[k].x >> 16) : 0, st = (int)sd[k].y;
                     const int a = st > ts ? st : ts, b = (st + len < te) ? st + len : te;
                     for (int j = a; j < b; ++j) ssum[k] += prod[j - ts];
                 }
             }
 #pragma unroll
             for (int k = 0; k < kBrickMaxRows / kBrickBlk; ++k)
-                if ((sd[k].x >> 16) > 0) {
+                if (brick_srow_of_thread(tid, k) < nsrows && (sd[k].x >> 16) > 0) {
                     const int64_t row = (int64_t)row0 + (int)(sd[k].x & 0xffffu);
                     y[row] = ssum[k];
                     if (DOT) dot += ssum[k] * x[row];
@@ -432,8 +461,6 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         BRICK_STAMP(4);
         if (!more) break;
         ++iter;
-        tile = tnext;
-        mk = (mrun && mk + 1 == mrun) ? 0 : mk + 1;
         tb = tbn;
         nsw_prev = (nsw > 0 && !BRICK_DBG(4)) ? 1 : 0;
     }
@@ -447,9 +474,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
             double s = park[0];
 #pragma unroll
             for (int k = 1; k < kBrickBlk / 64; ++k) s += park[k];
-            if (!HALO) partial[blockIdx.x] = s;
-            else // direct transport: write-through, fire and forget -- the finalizer kernel that follows folds the slots (halo_finalizer)
-                __hip_atomic_store(hv.stage + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            partial[blockIdx.x] = s;
         }
     }
 }
@@ -479,7 +504,7 @@ static int brick_grid(const BrickView &B, size_t lds)
             if (e.dev == dev && e.lds == lds) g = e.grid;
         if (!g) {
             int per_cu = 0, cus = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_spmv_brick<true, false>, kBrickBlk, lds);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_spmv_brick<true>, kBrickBlk, lds);
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             if (per_cu < 1) per_cu = 1;
             if (cus < 1) cus = 256;
@@ -503,9 +528,8 @@ static avs_status brick_raise_lds_limit()
     if (dev < 0 || dev >= 64) dev = 0;
     std::lock_guard<std::mutex> lk(mu);
     if (done[dev]) return AVS_OK;
-    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
-    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
-    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
+    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
+    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
     done[dev] = true;
     return AVS_OK;
 }
@@ -516,6 +540,14 @@ static void brick_print_stamps()
 {
     std::vector<long long> hs((size_t)kStampWgs * kStampTiles * 8);
     if (hipMemcpyFromSymbol(hs.data(), HIP_SYMBOL(g_brick_stamps), hs.size() * sizeof(long long)) != hipSuccess) return;
+    if (const char *path = getenv("AVS_BRICK_STAMP_FILE")) { // raw stamps [workgroup][tile of its walk][8] for tools/probes/brick_cost_fit.py
+        if (FILE *f = fopen(path, "wb")) {
+            const int hdr[4] = {kStampWgs, kStampTiles, 8, 0};
+            fwrite(hdr, sizeof(hdr), 1, f);
+            fwrite(hs.data(), sizeof(long long), hs.size(), f);
+            fclose(f);
+        }
+    }
     static const char *kind[3] = {"G tiles", "E tiles", "G tiles with streamed rows"};
     for (int ty = 0; ty < 3; ++ty) {
         double acc[6] = {};
@@ -553,8 +585,8 @@ avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, dou
     static const int dbg = getenv("AVS_BRICK_DEBUG") ? atoi(getenv("AVS_BRICK_DEBUG")) : 0; // phase switches / stamps (measurement builds only)
     BrickView Bd = B;
     Bd.debug |= dbg;
-    if (partial) hipLaunchKernelGGL((k_spmv_brick<true, false>), dim3(grid), dim3(kBrickBlk), lds, stream, Bd, x, y, partial, done_flag, HaloView());
-    else hipLaunchKernelGGL((k_spmv_brick<false, false>), dim3(grid), dim3(kBrickBlk), lds, stream, Bd, x, y, partial, done_flag, HaloView());
+    if (partial) hipLaunchKernelGGL((k_spmv_brick<true>), dim3(grid), dim3(kBrickBlk), lds, stream, Bd, x, y, partial, done_flag);
+    else hipLaunchKernelGGL((k_spmv_brick<false>), dim3(grid), dim3(kBrickBlk), lds, stream, Bd, x, y, partial, done_flag);
     AVS_HIP(hipGetLastError());
     if (Bd.debug & 64) { // print the phase stamps of THIS launch (synchronises: not for timing loops)
         AVS_HIP(hipStreamSynchronize(stream));
@@ -562,27 +594,11 @@ avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, dou
     }
     return AVS_OK;
 #else
-    if (partial) hipLaunchKernelGGL((k_spmv_brick<true, false>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag, HaloView());
-    else hipLaunchKernelGGL((k_spmv_brick<false, false>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag, HaloView());
+    if (partial) hipLaunchKernelGGL((k_spmv_brick<true>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
+    else hipLaunchKernelGGL((k_spmv_brick<false>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
     AVS_HIP(hipGetLastError());
     return AVS_OK;
 #endif
-}
-
-// the SpMV launch of the direct transport on the brick form: the persistent grid over all tiles (the tiles flagged in their header
-// wait for the peers' flags and read halo columns from the comm block); workgroup b drops its x.y partial into hv.stage[b] --
-// hv.ntiles == brick_partial_count(B) slots, folded by the finalizer kernel the caller launches behind this one
-avs_status spmv_brick_halo_launch(const BrickView &B, const double *x, double *y, const int *done_flag, const HaloView &hv, hipStream_t stream)
-{
-    if (B.ntiles <= 0) return AVS_OK;
-    const size_t lds = brick_lds_bytes(B);
-    AVS_REQUIRE(lds <= kBrickLdsLimit, AVS_EINTERNAL, "brick form: %zu bytes of LDS per workgroup exceed the limit", lds);
-    AVS_TRY(brick_raise_lds_limit());
-    const int grid = brick_grid(B, lds);
-    AVS_REQUIRE(grid == hv.ntiles, AVS_EINTERNAL, "brick form: %d stage slots for a grid of %d workgroups", hv.ntiles, grid);
-    hipLaunchKernelGGL((k_spmv_brick<true, true>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, (double *)nullptr, done_flag, hv);
-    AVS_HIP(hipGetLastError());
-    return AVS_OK;
 }
 
 } // namespace avs

@@ -3,10 +3,9 @@
 // Input (BrickSource): a CSR in the solver's numbering -- the permuted global system (p_row_ptr / p_col) or, round 5, the LOCAL system of
 // a partitioned solve, whose columns [n_rows, n_cols) are halo entries -- its value codes and packed words (ValueIndex: one dictionary of
 // < 2047 values, code and column in one 32-bit word), and for every column the reference DOF behind it + the dof table (which face a
-// column is: level, axis, cell -- cpp:1566-1593).  Output: the arrays behind BrickView.  A fill run names its column as (window of 2^11
-// consecutive columns, offset); a tile's <= 32 windows are in its header -- own-row windows first, then halo windows (aligned relative
-// to n_rows, so no window straddles the two ranges) -- which makes the form independent of how the rows of a brick are laid out: the
-// [interior | halo-reading] split order of a rank's rows simply gives a brick two runs of rows, i.e. two sets of tiles.  Lossless by construction: a row is stored as a pattern only after its words have been compared, one by one,
+// column is: level, axis, cell -- cpp:1566-1593).  Output: the arrays behind BrickView.  A fill run names its first column absolutely
+// (8 B per run), which makes the form independent of how the rows of a brick are laid out: the [interior | halo-reading] split order
+// of a rank's rows simply gives a brick two runs of rows, i.e. two sets of tiles, and halo columns are just columns >= n_rows.  Lossless by construction: a row is stored as a pattern only after its words have been compared, one by one,
 // with the words of the pattern it hashed to (K5); anything that does not fit a limit (lattice, extra slots, LDS budgets, runs) is kept
 // as packed words ("streamed" rows) -- tests/test_gpu_matrix_formats.py and avs_bench_spmv compare y with the plain CSR kernel bit for bit.
 //
@@ -31,16 +30,12 @@ constexpr int kBlk = 256;
 constexpr int kTileBlk = 512;
 constexpr int kHashBitsPat = 21;                 // pattern hash table: 2 M slots
 constexpr int kMaxPatterns = 1 << 19;            // more distinct patterns: the scene is not regular, the form is not built
-constexpr int kBlockStride = 1728;               // words reserved per descriptor block (48 + 320 + 640 + 512 = 1520 at the limits)
+constexpr int kBlockStride = 1728;               // words reserved per descriptor block (48 + 2 x 320 + 640 + 384 = 1712 at the limits)
 constexpr int kXsRows = kBrickXSlots;
 
 struct TileInfo {                                // built on the device from the brick starts
     int32_t row0, nrows, is_g, obx, oby, obz, pad0, pad1;
 };
-// window key of a column: own rows and halo entries are numbered apart, so that no window of 2^kBrickWinBits columns holds both
-__device__ __forceinline__ int win_key(int c, int n_rows) { return c < n_rows ? (c >> kBrickWinBits) : (((c - n_rows) >> kBrickWinBits) | (1 << 24)); }
-__device__ __forceinline__ int win_base(int key, int n_rows) { return (key & (1 << 24)) ? n_rows + ((key & 0xffffff) << kBrickWinBits) : (key << kBrickWinBits); }
-
 __device__ __forceinline__ uint64_t geo_pack(uint32_t brick, int level, int axis, int i, int j, int k)
 {
     return ((uint64_t)brick << 38) | ((uint64_t)(level & 7) << 35) | ((uint64_t)(axis & 3) << 33) | ((uint64_t)(i & 0x7ff) << 22) |
@@ -573,35 +568,7 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
             }
         }
     __syncthreads();
-    // the windows of 2^kBrickWinBits consecutive columns the fill reads: hash set in pkey (free since the rows were classified), then
-    // ascending in pidx -- own-row windows first, halo windows (key bit 24) behind them
-    for (int i = tid; i < 64; i += kTileBlk) pkey[i] = -1;
-    __syncthreads();
-    for (int u = 0; u < 4096 / kTileBlk; ++u) {
-        const int c = smap[tid * (4096 / kTileBlk) + u];
-        if (c < 0) continue;
-        const int wk = win_key(c, n_rows);
-        if (u > 0 && smap[tid * (4096 / kTileBlk) + u - 1] >= 0 && win_key(smap[tid * (4096 / kTileBlk) + u - 1], n_rows) == wk) continue; // (already in)
-        unsigned h = ((unsigned)wk * 2654435761u) >> 26;
-        bool in = false;
-        for (int probe = 0; probe < 64 && !in; ++probe) {
-            const int old = atomicCAS(&pkey[h], -1, wk);
-            in = old == -1 || old == wk;
-            h = (h + 1) & 63u;
-        }
-        if (!in) atomicExch(&counters[7], 1000); // more than 64 windows
-    }
-    __syncthreads();
-    if (tid < 64 && pkey[tid] != -1) {
-        const int v = pkey[tid];
-        int rk = 0;
-        for (int j = 0; j < 64; ++j) rk += (pkey[j] != -1 && pkey[j] < v) ? 1 : 0;
-        pidx[rk] = v;
-        atomicAdd(&counters[7], 1);
-    }
-    __syncthreads();
-    const int nwin = counters[7];
-    // run starts: slot s filled and not the continuation of the run through s - 1 (consecutive columns of one window, at most 16 long)
+    // run starts: slot s filled and not the continuation of the run through s - 1 (consecutive slots with consecutive columns, at most 16 long)
     constexpr int SPT = 4096 / kTileBlk; // 8 consecutive slots per thread
     unsigned startmask = 0;
     {
@@ -612,7 +579,7 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
             bool st = true;
             if (s > 0) {
                 const int cp = smap[s - 1];
-                if (cp >= 0 && cp + 1 == c && win_key(cp, n_rows) == win_key(c, n_rows)) st = false;
+                if (cp >= 0 && cp + 1 == c) st = false;
             }
             if (st) startmask |= 1u << u;
         }
@@ -653,7 +620,7 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
     }
     const int nruns = scan[kTileBlk - 1];
     int my_run = scan[tid] - ncut;
-    const bool fits = nruns <= kBrickMaxRuns && kBlkHdrWords + nruns + npq + npat <= kBlockStride && nwin <= 32;
+    const bool fits = nruns <= kBrickMaxRuns && kBlkHdrWords + 2 * nruns + npq + npat <= kBlockStride;
     __syncthreads();
     if (!fits) { // (block-uniform) a tile over a limit is redone as an E tile
         if (tid == 0) atomicExch(fallbacks, 1);
@@ -666,20 +633,20 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
             const int s = tid * SPT + u;
             int len = 1;
             const int c = smap[s];
-            const int wk = win_key(c, n_rows);
-            while (len < 16 && s + len < 4096 && smap[s + len] >= 0 && smap[s + len] == c + len && win_key(c + len, n_rows) == wk) ++len;
+            while (len < 16 && s + len < 4096 && smap[s + len] == c + len) ++len;
             // (the loop above may run past the next cut of the SAME natural run only if that cut is 16 away: len < 16 stops it)
-            int w = 0;
-            while (pidx[w] != wk) ++w;
-            blk[kBlkHdrWords + my_run] = ((uint32_t)w << 27) | ((uint32_t)(c - win_base(wk, n_rows)) << 16) | ((uint32_t)s << 4) | (uint32_t)(len - 1);
+            // a run is 8 B: the absolute first column | slot << 4 | length - 1 (round 5; it was 4 B naming a neighbour brick and an offset,
+            // which cost the kernel a second, dependent LDS read per batch; halo columns of a partitioned system are just columns >= n_rows)
+            blk[kBlkHdrWords + 2 * my_run] = (uint32_t)c;
+            blk[kBlkHdrWords + 2 * my_run + 1] = ((uint32_t)s << 4) | (uint32_t)(len - 1);
             ++my_run;
         }
         // pattern quads + pinfo in list order
         for (int i = tid; i < npat; i += kTileBlk) {
             const int id = plist[i];
             const uint32_t simple = rgeo[pat_rep[id]] >> 31;
-            blk[kBlkHdrWords + nruns + npq + i] = (uint32_t)pstart[i] | ((uint32_t)(plen4[i] >> 2) << 16) | (simple << 31);
-            for (int q = 0; q < (plen4[i] >> 2); ++q) blk[kBlkHdrWords + nruns + (pstart[i] >> 2) + q] = (uint32_t)(pat_off[id] + 4 * q);
+            blk[kBlkHdrWords + 2 * nruns + npq + i] = (uint32_t)pstart[i] | ((uint32_t)(plen4[i] >> 2) << 16) | (simple << 31);
+            for (int q = 0; q < (plen4[i] >> 2); ++q) blk[kBlkHdrWords + 2 * nruns + (pstart[i] >> 2) + q] = (uint32_t)(pat_off[id] + 4 * q);
         }
     }
     // header
@@ -702,10 +669,10 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
         }
         blk[tid] = (uint32_t)v;
     }
-    if (tid < 32) blk[16 + tid] = (gtile && tid < nwin) ? (uint32_t)win_base(pidx[tid], n_rows) : 0u; // first columns of the fill windows
+    if (tid < 32) blk[16 + tid] = 0u; // (words 16 .. 47: free since the runs carry absolute columns)
     if (tid == 0) {
         tile_bnd_out[t] = (uint8_t)bnd;
-        const int words = kBlkHdrWords + (gtile ? nruns + npq + npat : 0);
+        const int words = kBlkHdrWords + (gtile ? 2 * nruns + npq + npat : 0);
         tile_blk[t] = uint2{(uint32_t)((int64_t)t * (kBlockStride / 4)), (uint32_t)((words + 3) >> 2)};
         tile_info_out[t] = nprow;
     }
@@ -739,6 +706,16 @@ __global__ __launch_bounds__(kBlk) void k_bk_patch(int ntiles, const TileInfo *_
     if (t >= ntiles) return;
     blocks[(int64_t)t * kBlockStride + 8] = (uint32_t)sstart[tiles[t].row0];
 }
+// what the cost model of the planned walk reads of a tile: the counts in its block header
+__global__ __launch_bounds__(kBlk) void k_bk_tile_features(int ntiles, const uint2 *__restrict__ tile_blk, const uint32_t *__restrict__ blocks,
+                                                          int4 *__restrict__ feat)
+{
+    const int t = blockIdx.x * kBlk + threadIdx.x;
+    if (t >= ntiles) return;
+    const uint32_t *bw = blocks + (int64_t)tile_blk[t].x * 4;
+    feat[2 * t] = int4{(int)bw[1], (int)bw[3], (int)bw[5], (int)bw[9]};      // rows, fill runs, pattern rows, streamed words
+    feat[2 * t + 1] = int4{(int)bw[2], (int)bw[4], (int)bw[7], 0};            // patterns, pattern quads, streamed rows
+}
 __global__ __launch_bounds__(kBlk) void k_bk_count_regular(int ntiles, const int32_t *__restrict__ tile_nprow, unsigned long long *__restrict__ total)
 {
     const int t = blockIdx.x * kBlk + threadIdx.x;
@@ -752,6 +729,7 @@ void BrickForm::clear()
     ntiles = 0;
     regular_rows = 0;
     patterns = 0;
+    wgrid = 0;
 }
 
 void BrickScratch::release()
@@ -766,8 +744,86 @@ void BrickScratch::release()
 void BrickForm::release()
 {
     clear();
-    tile_blk.release(); rdesc.release(); sdesc.release(); blocks.release(); pwords.release(); swords.release(); ownslot.release(); tile_flags.release();
+    tile_blk.release(); rdesc.release(); sdesc.release(); blocks.release(); pwords.release(); swords.release(); ownslot.release(); tile_flags.release(); wlist.release(); wptr.release();
     scratch.release();
+}
+
+// The persistent grid's tile walk, planned: the static strided walks end with their slowest workgroup 15-20 % after the average one
+// (profiles/r04_notes.md: E tiles cost two G tiles, G tiles differ by their rows; a dynamic queue was slower).  Here every workgroup's
+// sequence is fixed in advance by list scheduling on ESTIMATED tile costs: the tiles of an XCD, in their order (neighbouring bricks stay
+// neighbours in time: a halo value is fetched by one L2), each go to the workgroup of that XCD that has the least work so far.
+// Deterministic (a function of the form and the grid), so the fold order of p.Ap and with it the iteration count are reproducible.
+avs_status BrickForm::plan_walk(int grid, int xcd_mode, const BrickCost &cm, hipStream_t st)
+{
+    wgrid = 0;
+    plan_makespan = plan_mean = 0.;
+    if (!ready || ntiles <= 0 || grid <= 0 || (grid & 7) != 0 || ntiles < grid) return AVS_OK;
+    DevBuf<int4> dfeat;
+    AVS_TRY(dfeat.alloc((size_t)ntiles * 2));
+    hipLaunchKernelGGL(k_bk_tile_features, dim3((unsigned)((ntiles + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, ntiles, (const uint2 *)tile_blk.p,
+                       (const uint32_t *)blocks.p, dfeat.p);
+    std::vector<int4> feat((size_t)ntiles * 2);
+    std::vector<uint2> tb((size_t)ntiles);
+    AVS_HIP(hipMemcpyAsync(feat.data(), dfeat.p, feat.size() * sizeof(int4), hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipMemcpyAsync(tb.data(), tile_blk.p, tb.size() * sizeof(uint2), hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipStreamSynchronize(st));
+    std::vector<double> cost((size_t)ntiles);
+    double total = 0.;
+    for (int t = 0; t < ntiles; ++t) {
+        const int4 a = feat[2 * (size_t)t], b = feat[2 * (size_t)t + 1];
+        const bool etile = b.x == 0; // no patterns: packed words only
+        const double c = cm.tile + cm.row * a.z + cm.run * a.y + cm.word * a.w + cm.quad * b.y + (etile ? cm.etile : 0.);
+        cost[(size_t)t] = c;
+        total += c;
+    }
+    // tiles of every XCD, in walk order
+    const int gx = grid >> 3;
+    std::vector<std::vector<int>> xt(8);
+    if (xcd_mode == 0) { // contiguous ranges of equal COST
+        double acc = 0.;
+        int c = 0;
+        for (int t = 0; t < ntiles; ++t) {
+            while (c < 7 && acc >= total * (c + 1) / 8.) ++c;
+            xt[(size_t)c].push_back(t);
+            acc += cost[(size_t)t];
+        }
+    } else {             // chunks of gx tiles dealt to the XCDs in turn
+        for (int t = 0; t < ntiles; ++t) xt[(size_t)((t / gx) & 7)].push_back(t);
+    }
+    std::vector<std::vector<int>> seq((size_t)grid);
+    std::vector<double> load((size_t)grid, 0.);
+    for (int c = 0; c < 8; ++c) {
+        // a binary heap over the XCD's workgroups keyed by (work so far, workgroup): ties go to the lower workgroup -- deterministic
+        std::vector<std::pair<double, int>> heap;
+        for (int j = 0; j < gx; ++j) heap.emplace_back(0., c + 8 * j);
+        auto cmp = [](const std::pair<double, int> &a, const std::pair<double, int> &b) { return a > b; };
+        std::make_heap(heap.begin(), heap.end(), cmp);
+        for (int t : xt[(size_t)c]) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            auto &w = heap.back();
+            seq[(size_t)w.second].push_back(t);
+            w.first += cost[(size_t)t];
+            load[(size_t)w.second] = w.first;
+            std::push_heap(heap.begin(), heap.end(), cmp);
+        }
+    }
+    std::vector<int32_t> hptr((size_t)grid + 1, 0);
+    std::vector<uint2> hlist;
+    hlist.reserve((size_t)ntiles);
+    for (int b = 0; b < grid; ++b) {
+        if (seq[(size_t)b].empty()) return AVS_OK; // (an XCD with fewer tiles than workgroups: the strided walk serves such a matrix)
+        for (int t : seq[(size_t)b]) hlist.push_back(tb[(size_t)t]);
+        hptr[(size_t)b + 1] = (int32_t)hlist.size();
+        plan_makespan = std::max(plan_makespan, load[(size_t)b]);
+    }
+    plan_mean = total / grid;
+    AVS_TRY(wlist.alloc(hlist.size() + 1));
+    AVS_TRY(wptr.alloc(hptr.size()));
+    AVS_HIP(hipMemcpyAsync(wlist.p, hlist.data(), hlist.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
+    AVS_HIP(hipMemcpyAsync(wptr.p, hptr.data(), hptr.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    AVS_HIP(hipStreamSynchronize(st)); // (the host vectors die here)
+    wgrid = grid;
+    return AVS_OK;
 }
 
 int64_t BrickForm::stored_bytes(int64_t n) const
@@ -792,6 +848,7 @@ void BrickForm::view(BrickView &B, const ValueIndex &vi) const
     B.table_size = vi.table_size;
     B.col_bits = wide ? 0 : vi.col_bits;   // 0: 64-bit streamed words
     B.n_rows = (int)n_rows;
+    if (wgrid > 0) { B.wlist = wlist.p; B.wptr = wptr.p; B.wgrid = wgrid; }
 }
 
 // BrickSource -> bf.  Leaves bf.ready = false (and AVS_OK) when the matrix does not qualify or is not regular enough; an error status
@@ -811,7 +868,7 @@ avs_status build_brick_form(BrickForm &bf, const BrickSource &src, const Options
         if (!brick_lds_fits(probe)) return AVS_OK; // the value table next to the lattice would exceed a workgroup's LDS: the word stream serves this matrix
     }
     if (src.brick_shift != 3 || src.levels < 1) return AVS_OK;
-    if (src.nx > 1024 || src.ny > 1024 || src.nz > 1024 || nnz >= (1ll << 31) || n_cols >= (1ll << 31) - (1 << kBrickWinBits)) return AVS_OK;
+    if (src.nx > 1024 || src.ny > 1024 || src.nz > 1024 || nnz >= (1ll << 31) || n_cols >= (1ll << 31) - 64) return AVS_OK;
     const bool timing = opt.brick_timing != 0;
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {

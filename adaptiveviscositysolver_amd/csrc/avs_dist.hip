@@ -1157,6 +1157,12 @@ static avs_status dist_build_brick(avs_ctx *c, PcgDist *d)
         else {
             d->brick.view(d->brick_view, d->vi);
             d->brick_view.walk = fill >= kBrickEighthsFill ? 0 : 1;
+            if (c->opt.brick_plan) {
+                const int walk = d->brick_view.walk;
+                AVS_TRY(d->brick.plan_walk(brick_partial_count(d->brick_view), walk, c->opt.brick_cost, c->stream));
+                d->brick.view(d->brick_view, d->vi);
+                d->brick_view.walk = walk;
+            }
             return AVS_OK;
         }
     } else if (c->opt.brick != 1) {

@@ -427,7 +427,4 @@ __device__ void halo_finalizer(const HaloView &hv, int f)
 }
 
 
-// avs_brick.hip: the brick-structured form's SpMV launch of the direct transport
-avs_status spmv_brick_halo_launch(const BrickView &B, const double *x, double *y, const int *done_flag, const HaloView &hv, hipStream_t stream);
-
 } // namespace avs

@@ -78,6 +78,11 @@ struct PhaseScope { // consecutive phases of one function: next() closes the pre
 // the only function that calls getenv); the switches a host may legitimately set are then reachable through avs_set_solver_option.
 // Code deep inside a solve reads the options of the context whose entry point is running on this thread (cur_opt()).
 // ---------------------------------------------------------------------------------------------
+// what a tile costs the persistent kernel, in microseconds, as far as the descriptors show it: fitted to the per-tile phase stamps of the
+// probe build (tools/probes/brick_cost_fit.py; profiles/r05_notes.md)
+struct BrickCost {
+    double tile = 2.31, row = 0.0017, run = 0.0055, word = 0.0020, etile = 1.9, quad = 0.0028; // (fit of 50 k tiles: 512^3 beam, sheet, tank)
+};
 struct Options {
     // user-facing (avs_set_solver_option)
     int resident = 1;            // AVS_CG_RESIDENT: the CU-resident PCG loop where a system qualifies
@@ -90,6 +95,8 @@ struct Options {
     int brick_interleave = 1, brick_shift = 3, value_index = 1, value_pack = 1, tile_tables = 1, column_windows = 1;
     double brick_min_regular = 0.6;
     int brick_timing = 0;
+    int brick_plan = 1;          // AVS_BRICK_PLAN: cost-balanced planned walk of the brick kernel (0: the static strided walks)
+    BrickCost brick_cost;        // AVS_BRICK_COST=tile,row,run,word,etile,quad
     // single-GPU loop
     int fuse_beta = 1;
     // CU-resident loop: tuning and test switches
@@ -263,7 +270,6 @@ constexpr int kCwinOffBits = 14, kCwinSlotBits = 6, kCwinSlots = 1 << kCwinSlotB
 struct ValueIndex;
 struct BrickForm;
 constexpr int kBlkHdrWords = 48;         // header of a tile's descriptor block (avs_brick.hip)
-constexpr int kBrickWinBits = 11;        // a fill run names its column as (window of 2^11 columns, offset): <= 32 windows per tile
 constexpr int kBrickLoff[5] = {0, 3000, 3648, 3840, 3921}; // slot offsets of the level-0..3 lattices: (8>>l)+2 cells per axis, 3 faces per cell
 constexpr int kBrickSlots = 3921, kBrickSlotsPad = 3936;
 constexpr int kBrickMaxRows = 1024;   // rows per tile, two per thread (a fuller brick is cut into two tiles with one lattice origin)
@@ -294,6 +300,10 @@ struct BrickView {
     int table_size = 0, col_bits = 0;
     int debug = 0; // measurement only: 1 no fill, 2 no pattern rows, 4 no streamed rows (wrong results), 16 phase stamps
     int n_rows = 0; // partitioned systems: columns >= n_rows are halo entries ([owned | halo] local numbering)
+    // planned walk (BrickForm::plan_walk): workgroup b of a grid of wgrid workgroups takes the tiles wlist[wptr[b] .. wptr[b + 1]) (tile_blk entries)
+    const uint2 *wlist = nullptr;
+    const int32_t *wptr = nullptr;
+    int wgrid = 0;
 };
 // the form's arrays, owned by the context next to the CSR / value index of the solve matrix (avs_brick_build.hip)
 struct BrickScratch { // build-time buffers, kept across frames
@@ -312,6 +322,10 @@ struct BrickForm {
     DevBuf<uint32_t> blocks, pwords, swords;
     DevBuf<uint16_t> ownslot;
     DevBuf<uint8_t> tile_flags;       // per tile (walk order): 1 = its rows read halo columns (partitioned systems)
+    DevBuf<uint2> wlist;              // planned walk: the workgroups' tile sequences, one after the other
+    DevBuf<int32_t> wptr;
+    int wgrid = 0;                    // the grid the plan was laid out for (0: no plan)
+    double plan_makespan = 0., plan_mean = 0.; // the model's estimate for the slowest / the average workgroup (microseconds)
     BrickScratch scratch;
     int ntiles = 0, patterns = 0, halo_tiles = 0;
     int64_t n_rows = 0;               // rows of the system the form was built for (columns >= n_rows: halo)
@@ -321,6 +335,9 @@ struct BrickForm {
     void clear();   // not ready; buffers stay for the next build
     void release(); // + every buffer and the build scratch freed (a matrix the form does not serve)
     void view(BrickView &B, const ValueIndex &vi) const;
+    // lays the tiles out over a persistent grid of `grid` workgroups (a multiple of 8: workgroup b runs on XCD b mod 8) from the cost
+    // model; xcd_mode 0: one contiguous, cost-equal range of tiles per XCD, 1: chunks dealt to the XCDs in turn
+    avs_status plan_walk(int grid, int xcd_mode, const BrickCost &cost, hipStream_t st);
     int64_t stored_bytes(int64_t n) const; // what one SpMV launch reads of the matrix
 };
 // what the form is built from: a CSR in the solver's numbering whose rows may read columns beyond the rows (the halo of a partitioned

@@ -1668,6 +1668,19 @@ __global__ __launch_bounds__(512) void k_halo_finalize(HaloView hv)
     if (hv.sc->done) return;
     halo_finalizer<512>(hv, (int)blockIdx.x);
 }
+// ... and in FRONT of it: wait for the peers' entries of this round (their epoch flags), then copy the comm block's halo area behind the
+// owned entries of the vector the product reads (system-scope loads: the entries were written by other GPUs), so that the brick kernel
+// itself is the plain one -- [owned | halo] is one array, as with the RCCL transport.
+__global__ __launch_bounds__(256) void k_halo_gather(HaloView hv, double *__restrict__ vec)
+{
+    if (hv.sc->done) return;
+    halo_wait(hv);
+    const DistDev *dd = hv.dd;
+    int n_halo = 0;
+    for (int i = 0; i < dd->npeers; ++i) n_halo += dd->recv_cnt[i];
+    const long long n_own = dd->n_own;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n_halo; j += gridDim.x * 256) vec[n_own + j] = ld_sys_f64(dd->my_halo + j);
+}
 
 #include "avs_pcg_resident.inl"
 
@@ -1730,6 +1743,7 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
     AVS_TRY(w->stage2.alloc((size_t)(slots > 0 ? slots : 1) + (size_t)nfin));
     AVS_HIP(hipMemsetAsync(w->stage2.p, 0xFF, (size_t)(slots > 0 ? slots : 1) * sizeof(double), stream)); // arm: kSentinel in every slot
     const int push_blocks = da.n_send > 0 ? (da.n_send + 255) / 256 : 0;
+    const int n_halo_cols = (int)(w->n_ext - n);
 
     AVS_TRY(w->cancel_dev.alloc(1));
     AVS_HIP(hipMemsetAsync(w->cancel_dev.p, 0, sizeof(int), stream));
@@ -1772,8 +1786,12 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
         hv.op = op;
         hv.tol = tol;
         hv.cancel = w->cancel_dev.p;
-        if (brick) { // the persistent grid, then the finalizer as a small launch of its own
-            AVS_TRY(spmv_brick_halo_launch(*A.brick, vec, wv, &sc->done, hv, stream));
+        if (brick) { // halo into the vector's tail, the plain persistent grid (partials into the stage slots), the finalizer: three launches
+            if (da.npeers > 0) {
+                const int hg = n_halo_cols > 0 ? (n_halo_cols + 255) / 256 : 1;
+                hipLaunchKernelGGL(k_halo_gather, dim3(hg < 64 ? hg : 64), dim3(256), 0, stream, hv, const_cast<double *>(vec));
+            }
+            AVS_TRY(spmv_brick_launch(*A.brick, vec, wv, w->stage2.p, &sc->done, stream));
             hipLaunchKernelGGL(k_halo_finalize, dim3(nfin), dim3(512), 0, stream, hv);
         } else {
             AVS_TRY(spmv_dot_tiles_halo(A, vec, wv, nullptr, sc, nullptr, ntiles + nfin, hv, stream));

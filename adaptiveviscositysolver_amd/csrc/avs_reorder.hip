@@ -207,6 +207,10 @@ avs_status build_reordered_system(avs_ctx *c, int brick_shift)
         c->brick.release();
         c->brick.view(c->brick_view, c->vi);
     }
+    if (c->brick.ready && c->opt.brick_plan) { // the persistent grid's walk, laid out from the tiles' estimated costs (BrickForm::plan_walk)
+        AVS_TRY(c->brick.plan_walk(brick_partial_count(c->brick_view), c->brick_walk, c->opt.brick_cost, st));
+        c->brick.view(c->brick_view, c->vi);
+    }
     c->brick_view.walk = c->brick_walk;
     return AVS_OK;
 }

@@ -252,14 +252,15 @@ def build(rp, col, code, geo, table_size, col_bits):
     off3 = c3 - bstart[brick_of_row[c3]]
     assert len(off3) == 0 or int(off3.max()) < 2048
     brk = torch.ones(len(trip), dtype=torch.bool, device=dev)
-    brk[1:] = (t3[1:] != t3[:-1]) | (s3[1:] != s3[:-1] + 1) | (c3[1:] != c3[:-1] + 1) | (win[1:] != win[:-1])
+    brk[1:] = (t3[1:] != t3[:-1]) | (s3[1:] != s3[:-1] + 1) | (c3[1:] != c3[:-1] + 1)
     rstart = torch.nonzero(brk).flatten()
     rid = torch.cumsum(brk.long(), 0) - 1
     pos = torch.arange(len(trip), device=dev) - rstart[rid]
     brk = brk | (pos % 16 == 0)
     rstart = torch.nonzero(brk).flatten()
     rlen = torch.diff(torch.cat([rstart, torch.tensor([len(trip)], device=dev)]))
-    runs = (win[rstart] << 27) | (off3[rstart] << 16) | (s3[rstart] << 4) | (rlen - 1)
+    # a run is 8 B (round 5): the absolute first column | slot << 4 | length - 1
+    runs = torch.stack([c3[rstart], (s3[rstart] << 4) | (rlen - 1)], 1).flatten()
     nruns_tile = torch.bincount(t3[rstart], minlength=ntiles)
     run0 = torch.cumsum(nruns_tile, 0) - nruns_tile
     if len(runs) == 0: runs = torch.zeros(4, dtype=torch.int64, device=dev)
@@ -295,7 +296,7 @@ def build(rp, col, code, geo, table_size, col_bits):
                 nb[:, (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)] = torch.where(ok, bfirst[idb], torch.zeros_like(idb))
     z = torch.zeros_like(pat0)
     hdr = torch.cat([torch.stack([tile_row0, tile_rows, npat_tile, nruns_tile, npq_tile, nprow_tile, srow0, ns_tile, sword0[:-1], nsw_tile, rd0, z, z, z, z, z], 1), nb], 1)
-    words = 48 + nruns_tile + npq_tile + npat_tile
+    words = 48 + 2 * nruns_tile + npq_tile + npat_tile
     units = (words + 3) // 4
     assert int(words.max()) <= BLOCK_WORDS, f"a tile's descriptor block has {int(words.max())} words"
     assert int(nruns_tile.max()) <= MAX_RUNS, f"a tile with {int(nruns_tile.max())} halo runs"
@@ -310,7 +311,7 @@ def build(rp, col, code, geo, table_size, col_bits):
         blocks[w0[tix] + per_tile_start[tix] + i] = values
     blocks[(w0[:, None] + torch.arange(48, device=dev)[None, :]).flatten()] = hdr.flatten()
     o = torch.full_like(w0, 48)
-    put(o, nruns_tile, runs[: int(nruns_tile.sum())]); o = o + nruns_tile
+    put(o, 2 * nruns_tile, runs[: 2 * int(nruns_tile.sum())]); o = o + 2 * nruns_tile
     put(o, npq_tile, pquads[: int(npq_tile.sum())]); o = o + npq_tile
     put(o, npat_tile, pinfo[: int(npat_tile.sum())]); o = o + npat_tile
     tile_blk = torch.stack([unit0, units], 1)
@@ -347,12 +348,11 @@ def emulate(form, table, x):
         b0 = int(TB[t, 0]) * 4
         bw = BL[b0: b0 + int(TB[t, 1]) * 4]
         row0, nrows, npat, nruns, npq, nprow, sr0, nsr, sw0, nsw, rd0_ = [int(v) for v in bw[:11]]
-        o_runs = 48; o_pq = o_runs + nruns; o_pi = o_pq + npq
+        o_runs = 48; o_pq = o_runs + 2 * nruns; o_pi = o_pq + npq
         RD = u(form["rdesc"])
         xs = torch.full((3936 + 160,), float("nan"), dtype=torch.float64, device=dev)
         for q in range(nruns):
-            d = int(bw[o_runs + q])
-            c = int(bw[16 + (d >> 27)]) + ((d >> 16) & 0x7ff)
+            c, d = int(bw[o_runs + 2 * q]), int(bw[o_runs + 2 * q + 1])
             s_, ln = (d >> 4) & 0xfff, (d & 15) + 1
             xs[s_:s_ + ln] = x[c:c + ln]
         if npat > 0:
