@@ -101,6 +101,7 @@ Options options_from_env()
     o.brick_min_regular = env_dbl("AVS_BRICK_MIN_REGULAR", 0.6);
     o.brick_timing = getenv("AVS_BRICK_TIMING") != nullptr;
     o.brick_plan = env_int("AVS_BRICK_PLAN", 1) != 0;
+    o.brick_value_codes = env_int("AVS_BRICK_VALUE_CODES", 1) != 0;
     if (const char *e = getenv("AVS_BRICK_COST")) {
         BrickCost &k = o.brick_cost;
         (void)sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &k.tile, &k.row, &k.run, &k.word, &k.etile, &k.quad);
@@ -516,7 +517,7 @@ avs_status avs_get_matrix_format(avs_ctx *c, avs_matrix_format *out)
     fmt->brick_pattern_rows = bk ? c->brick.regular_rows : 0;
     fmt->brick_bytes = bk ? c->brick.stored_bytes(c->n_vel) : 0;
     fmt->brick_walk = bk ? c->brick_view.walk : 0;
-    fmt->brick_value_codes = 0;
+    fmt->brick_value_codes = bk && c->brick.vc ? 1 : 0;
     hand_over();
     return AVS_OK;
 }

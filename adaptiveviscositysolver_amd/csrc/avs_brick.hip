@@ -104,7 +104,7 @@ __device__ __forceinline__ T ld_u32(const T *base, unsigned idx)
 // The per-row arrays (rdesc: descriptor + position of every pattern row in execution order; ownslot) stay in global memory.
 constexpr int kBlkHdr = kBlkHdrWords;
 
-template <bool DOT>
+template <bool DOT, bool VC = false>
 __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_spmv_brick(BrickView B, const double *__restrict__ x, double *__restrict__ y,
                                                          double *__restrict__ partial, const int *__restrict__ done_flag)
 {
@@ -115,19 +115,20 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                                                                         // x slots (off-lattice columns), behind them first the tile's
                                                                         // descriptor block, then the products of its streamed rows
     double *vals = park + kBrickPark;                                   // table_size + 1 (the last entry is 0.0: padding words), even
-    uint32_t *pw = reinterpret_cast<uint32_t *>(vals + ((B.table_size + 2) & ~1)); // kBrickPatWords + 8
-    uint32_t *pinfo = pw + kBrickPatWords + 8;                          // kBrickPatMax: local start | quads << 16
+    uint32_t *pw = reinterpret_cast<uint32_t *>(vals + ((B.table_size + 2) & ~1)); // kBrickPatWords (VC: kBrickPatWordsVc) + 8
+    uint32_t *pinfo = pw + (VC ? kBrickPatWordsVc : kBrickPatWords) + 8; // kBrickPatMax: local start | quads << 16
     uint2 *rbt = reinterpret_cast<uint2 *>(pinfo + kBrickPatMax);       // kBrickRowBase entries: a row's bases on the four lattices, per axis
     const uint32_t *bw = reinterpret_cast<const uint32_t *>(park + kBrickXSlots);
     const int tid = threadIdx.x;
     const int lane = tid & 63, l16 = tid & 15, qw = tid >> 4;
-    const bool wide = B.col_bits == 0;                                   // 64-bit streamed words: column | code << 32
+    const bool wide = VC || B.col_bits == 0;                             // 64-bit streamed words: column | code << 32 (VC: 96 bits, column | value)
     const unsigned cmask = wide ? 0xffffffffu : (1u << B.col_bits) - 1u;
     const int cbits = B.col_bits;
     constexpr int QW = kBrickBlk / 16;
     static_assert((kBrickPark - kBrickXSlots) * 2 <= kBrickBlk * 4, "one 16-B load per thread fetches a whole descriptor block");
 
-    for (int i = tid; i <= B.table_size; i += kBrickBlk) vals[i] = (i < B.table_size) ? B.table[i] : 0.; // once per workgroup
+    if (!VC)
+        for (int i = tid; i <= B.table_size; i += kBrickBlk) vals[i] = (i < B.table_size) ? B.table[i] : 0.; // once per workgroup (VC: a table per tile)
     // A row of level lr at local cell (cx, cy, cz) has the byte offset 8 (kBrickLoff[lc] + 3 ((bz S + by) S + bx)) on lattice lc, with
     // b = ((c >> up) << down) + 1 per axis: the sum of one term per axis.  Table entry (axis d, lr, c + 1) = the four lattices' terms as
     // 16-bit fields {lattice 0 | lattice 1 << 16, lattice 2 | lattice 3 << 16} (the sums stay below 2^15: no carries between the fields);
@@ -200,6 +201,10 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         const int srow0 = __builtin_amdgcn_readfirstlane((int)bw[6]), nsrows = __builtin_amdgcn_readfirstlane((int)bw[7]);
         const int sword0 = __builtin_amdgcn_readfirstlane((int)bw[8]), nsw = __builtin_amdgcn_readfirstlane((int)bw[9]);
         const int rd0 = __builtin_amdgcn_readfirstlane((int)bw[10]);
+        // VC (variable viscosity: the patterns carry the geometry only): the tile's value codes start at vcodes[cw0] (one 8-B quad of four
+        // 16-bit byte offsets into the tile's value table per row quad, wave-interleaved in execution order), its ntv values at ttab[tt0]
+        const int cw0 = VC ? __builtin_amdgcn_readfirstlane((int)bw[12]) : 0, tt0 = VC ? __builtin_amdgcn_readfirstlane((int)bw[13]) : 0;
+        const int ntv = VC ? __builtin_amdgcn_readfirstlane((int)bw[14]) : 0;
         const int o_runs = kBlkHdr, o_pq = o_runs + 2 * nruns, o_pi = o_pq + npq; // (runs are 8 B)
         const bool emode = npat == 0;                 // no pattern rows: the products of the streamed rows may use the x lattice's LDS
         double *prod = emode ? xs : park + kBrickXSlots;
@@ -277,6 +282,12 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
             pqv[u] = uint4{0u, 0u, 0u, 0u};
             if (u * kBrickBlk < npq) pqv[u] = *reinterpret_cast<const uint4 *>(B.pwords + pqo[u]);
         }
+        double tval = 0.;
+        if (VC && ntv > 0) tval = ld_u32(B.ttab + tt0, (unsigned)(tid < ntv ? tid : 0));   // the tile's value table (<= kBrickTileVals entries)
+        int cbo[RPT];                                  // VC: first quad of this wave's blocks of the code stream (read NOW: the streamed rows'
+                                                       // products overwrite the block image while slower waves still walk their rows)
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) cbo[k] = VC ? __builtin_amdgcn_readfirstlane((int)bw[16 + k * (kBrickBlk / 64) + (tid >> 6)]) : 0;
         uint2 rdv[RPT]; // descriptor, position in the tile (valid for tid + k * kBrickBlk < nprow)
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
@@ -313,6 +324,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         const bool more = iter + 1 < cnt;
         const uint2 tbn = seq[(int64_t)(more ? iter + 1 : iter) * step];
         // ---- LDS writes
+        if (VC && tid <= ntv) vals[tid] = tid < ntv ? tval : 0.;          // (entry ntv = 0.0: the code of the padding words)
         if (tid < npat) pinfo[tid] = pinf;
 #pragma unroll
         for (int u = 0; u < PQ; ++u) {
@@ -394,11 +406,47 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                     sum += v2 * x2;
                     sum += v3 * x3;
                 };
+                // VC: the value of an entry comes from the row's own code stream -- quad q of this lane at cp[64 q] (the wave's rows are
+                // interleaved, so a wave load is one 512-B run) -- instead of from the pattern word; same pipeline, same order of additions
+                auto walk_vc = [&](auto adr) {
+                    const uint2 *cp = B.vcodes + (int64_t)cw0 + cbo[k] + lane;
+                    double v0, v1, v2, v3, x0, x1, x2, x3;
+                    const uint4 w = wq[0];
+                    uint4 wn = wq[1];
+                    uint2 c = cp[0];
+                    uint2 cn = cp[nq > 1 ? 64 : 0];
+                    v0 = lds_abs_f64(kBrickValsByte + (c.x & 0xffffu)); x0 = lds_abs_f64(adr(w.x));
+                    v1 = lds_abs_f64(kBrickValsByte + (c.x >> 16)); x1 = lds_abs_f64(adr(w.y));
+                    v2 = lds_abs_f64(kBrickValsByte + (c.y & 0xffffu)); x2 = lds_abs_f64(adr(w.z));
+                    v3 = lds_abs_f64(kBrickValsByte + (c.y >> 16)); x3 = lds_abs_f64(adr(w.w));
+                    for (int q = 1; q < nq; ++q) {
+                        const uint4 wnn = wq[q + 1];
+                        const uint2 cnn = cp[(q + 1 < nq ? q + 1 : q) * 64];
+                        const double a0 = lds_abs_f64(kBrickValsByte + (cn.x & 0xffffu)), c0 = lds_abs_f64(adr(wn.x));
+                        const double a1 = lds_abs_f64(kBrickValsByte + (cn.x >> 16)), c1 = lds_abs_f64(adr(wn.y));
+                        const double a2 = lds_abs_f64(kBrickValsByte + (cn.y & 0xffffu)), c2 = lds_abs_f64(adr(wn.z));
+                        const double a3 = lds_abs_f64(kBrickValsByte + (cn.y >> 16)), c3 = lds_abs_f64(adr(wn.w));
+                        sum += v0 * x0;
+                        sum += v1 * x1;
+                        sum += v2 * x2;
+                        sum += v3 * x3;
+                        v0 = a0; x0 = c0; v1 = a1; x1 = c1; v2 = a2; x2 = c2; v3 = a3; x3 = c3;
+                        wn = wnn;
+                        cn = cnn;
+                    }
+                    sum += v0 * x0;
+                    sum += v1 * x1;
+                    sum += v2 * x2;
+                    sum += v3 * x3;
+                };
+                // (a queue of four code quads per lane, the first four loaded with the tile's other loads, was measured: 20 spilled registers, 288 us)
                 if (pi >> 31) { // every column of the pattern on the level-0 lattice (rows are executed sorted by pattern: waves rarely mix)
                     const unsigned b0 = P01 & 0xffffu;
-                    walk([&](uint32_t w) -> unsigned { return (unsigned)((int)w >> 16) + b0; });
+                    if (VC) walk_vc([&](uint32_t w) -> unsigned { return (unsigned)((int)w >> 16) + b0; });
+                    else walk([&](uint32_t w) -> unsigned { return (unsigned)((int)w >> 16) + b0; });
                 } else {
-                    walk(addr);
+                    if (VC) walk_vc(addr);
+                    else walk(addr);
                 }
                 *reinterpret_cast<double *>(reinterpret_cast<char *>(y + row0) + (size_t)(unsigned)(ro << 3)) = sum;
                 if (DOT) dot += sum * lds_abs_f64(own8);
@@ -418,12 +466,18 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                     constexpr int SU = 4; // (8 entries per thread -- a whole pass of an E tile in one round of loads -- was measured SLOWER: 7.1 -> 7.7 us per E tile)
                     for (int e0 = ts + tid; e0 < te; e0 += SU * kBrickBlk) {
                         uint32_t w4[SU], c4[SU];
-                        double x4[SU];
+                        double x4[SU], v4[SU];
 #pragma unroll
                         for (int u = 0; u < SU; ++u) {
                             const int e = e0 + u * kBrickBlk;
                             const int64_t at = (int64_t)sword0 + (e < te ? e : ts);
-                            if (wide) {
+                            v4[u] = 0.;
+                            if (VC) { // 12 B per entry: column, value
+                                const uint32_t *w = B.swords + 3 * at;
+                                w4[u] = w[0];
+                                c4[u] = 0u;
+                                v4[u] = __hiloint2double((int)w[2], (int)w[1]);
+                            } else if (wide) {
                                 const uint2 w = reinterpret_cast<const uint2 *>(B.swords)[at];
                                 w4[u] = w.x;
                                 c4[u] = w.y;
@@ -438,7 +492,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
 #pragma unroll
                         for (int u = 0; u < SU; ++u) {
                             const int e = e0 + u * kBrickBlk;
-                            if (e < te) prod[e - ts] = vals[c4[u]] * x4[u];
+                            if (e < te) prod[e - ts] = (VC ? v4[u] : vals[c4[u]]) * x4[u];
                         }
                     }
                 }
@@ -481,7 +535,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
 
 size_t brick_lds_bytes(const BrickView &B)
 {
-    return (size_t)(kBrickSlotsPad + ((B.table_size + 2) & ~1) + kBrickPark) * sizeof(double) + (size_t)(kBrickPatWords + 8 + kBrickPatMax + 2 * kBrickRowBase) * sizeof(uint32_t);
+    return (size_t)(kBrickSlotsPad + ((B.table_size + 2) & ~1) + kBrickPark) * sizeof(double) + (size_t)((B.vc ? kBrickPatWordsVc : kBrickPatWords) + 8 + kBrickPatMax + 2 * kBrickRowBase) * sizeof(uint32_t);
 }
 
 // LDS a workgroup may ask for on this device (the kernel opts in to more than the default 48 KiB, hipFuncSetAttribute below)
@@ -492,7 +546,7 @@ bool brick_lds_fits(const BrickView &B) { return brick_lds_bytes(B) <= kBrickLds
 // queried once per (device, LDS size), guarded: contexts of several host threads share the cache
 static int brick_grid(const BrickView &B, size_t lds)
 {
-    struct Entry { int dev; size_t lds; int grid; };
+    struct Entry { int dev; size_t lds; int vc; int grid; };
     static std::mutex mu;
     static std::vector<Entry> cache;
     int dev = 0;
@@ -501,15 +555,16 @@ static int brick_grid(const BrickView &B, size_t lds)
     {
         std::lock_guard<std::mutex> lk(mu);
         for (const Entry &e : cache)
-            if (e.dev == dev && e.lds == lds) g = e.grid;
+            if (e.dev == dev && e.lds == lds && e.vc == B.vc) g = e.grid;
         if (!g) {
             int per_cu = 0, cus = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_spmv_brick<true>, kBrickBlk, lds);
+            if (B.vc) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_spmv_brick<true, true>, kBrickBlk, lds);
+            else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_spmv_brick<true, false>, kBrickBlk, lds);
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             if (per_cu < 1) per_cu = 1;
             if (cus < 1) cus = 256;
             g = per_cu * cus;
-            cache.push_back(Entry{dev, lds, g});
+            cache.push_back(Entry{dev, lds, B.vc, g});
         }
     }
 #ifdef AVS_PROBES
@@ -528,8 +583,10 @@ static avs_status brick_raise_lds_limit()
     if (dev < 0 || dev >= 64) dev = 0;
     std::lock_guard<std::mutex> lk(mu);
     if (done[dev]) return AVS_OK;
-    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
-    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
+    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
+    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
+    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
+    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
     done[dev] = true;
     return AVS_OK;
 }
@@ -585,8 +642,11 @@ avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, dou
     static const int dbg = getenv("AVS_BRICK_DEBUG") ? atoi(getenv("AVS_BRICK_DEBUG")) : 0; // phase switches / stamps (measurement builds only)
     BrickView Bd = B;
     Bd.debug |= dbg;
-    if (partial) hipLaunchKernelGGL((k_spmv_brick<true>), dim3(grid), dim3(kBrickBlk), lds, stream, Bd, x, y, partial, done_flag);
-    else hipLaunchKernelGGL((k_spmv_brick<false>), dim3(grid), dim3(kBrickBlk), lds, stream, Bd, x, y, partial, done_flag);
+    if (Bd.vc) {
+        if (partial) hipLaunchKernelGGL((k_spmv_brick<true, true>), dim3(grid), dim3(kBrickBlk), lds, stream, Bd, x, y, partial, done_flag);
+        else hipLaunchKernelGGL((k_spmv_brick<false, true>), dim3(grid), dim3(kBrickBlk), lds, stream, Bd, x, y, partial, done_flag);
+    } else if (partial) hipLaunchKernelGGL((k_spmv_brick<true, false>), dim3(grid), dim3(kBrickBlk), lds, stream, Bd, x, y, partial, done_flag);
+    else hipLaunchKernelGGL((k_spmv_brick<false, false>), dim3(grid), dim3(kBrickBlk), lds, stream, Bd, x, y, partial, done_flag);
     AVS_HIP(hipGetLastError());
     if (Bd.debug & 64) { // print the phase stamps of THIS launch (synchronises: not for timing loops)
         AVS_HIP(hipStreamSynchronize(stream));
@@ -594,8 +654,11 @@ avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, dou
     }
     return AVS_OK;
 #else
-    if (partial) hipLaunchKernelGGL((k_spmv_brick<true>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
-    else hipLaunchKernelGGL((k_spmv_brick<false>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
+    if (B.vc) {
+        if (partial) hipLaunchKernelGGL((k_spmv_brick<true, true>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
+        else hipLaunchKernelGGL((k_spmv_brick<false, true>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
+    } else if (partial) hipLaunchKernelGGL((k_spmv_brick<true, false>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
+    else hipLaunchKernelGGL((k_spmv_brick<false, false>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
     AVS_HIP(hipGetLastError());
     return AVS_OK;
 #endif

@@ -282,11 +282,11 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_rows(const TileInfo *__restrict
                 tag = 0;
                 eslot[k] = (uint16_t)slot;
             }
-            const unsigned code = codes[k];
+            const unsigned code = codes ? codes[k] : 0u;   // (value-code variant: the patterns carry the geometry only)
             uint32_t word = 0u;
             if (slot != 0xffff && gr.level <= 3) {
                 const int delta = slot - base_slot(lr, cx, cy, cz, tag);
-                if (delta < -4096 || delta > 4095 || code >= (unsigned)zero_code) ok = false;
+                if (delta < -4096 || delta > 4095 || (codes && code >= (unsigned)zero_code)) ok = false;
                 word = ((uint32_t)(delta & 0x1fff) << 19) | ((uint32_t)tag << 14) | (code << 3);
                 if (tag) simple = false;
             } else {
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
                                                      const int32_t *__restrict__ col, const uint16_t *__restrict__ eslot,
                                                      const int32_t *__restrict__ row_pid, const uint32_t *__restrict__ rgeo,
                                                      const int32_t *__restrict__ pat_off, const int32_t *__restrict__ pat_rep,
-                                                     int n_rows, int has_halo, const uint8_t *__restrict__ force_e,
+                                                     int n_rows, int has_halo, int pat_words_cap, int vc, const uint8_t *__restrict__ force_e,
                                                      uint32_t *__restrict__ blocks, uint2 *__restrict__ tile_blk, uint2 *__restrict__ rdesc,
                                                      uint2 *__restrict__ sdesc, int32_t *__restrict__ slen, int32_t *__restrict__ tile_info_out,
                                                      uint8_t *__restrict__ tile_bnd_out, int *__restrict__ fallbacks)
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
     if (tid == 0) { // list order prefix (<= 1024 entries): which patterns fit the LDS image
         int acc = 0, kept = 0;
         for (int i = 0; i < nlist; ++i) {
-            if (kept < kBrickPatMax && acc + plen4[i] <= kBrickPatWords && i == kept) { pstart[i] = acc; acc += plen4[i]; ++kept; }
+            if (kept < kBrickPatMax && acc + plen4[i] <= pat_words_cap && i == kept) { pstart[i] = acc; acc += plen4[i]; ++kept; }
             else pstart[i] = -1;
         }
         counters[1] = kept;
@@ -520,6 +520,14 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
         const int r = (int)(key & 1023u), li = (int)((key >> 10) & 1023u);
         rdesc[row0 + i] = uint2{((uint32_t)li << 20) | (rgeo[row0 + r] & 0x000fffffu), (uint32_t)r};
     }
+    // value-code variant: the code stream of the tile is laid out wave by wave of the execution order -- the wave of rows
+    // [512 k + 64 w, + 64) owns a block of (quads of its longest row, the last one: the order is ascending in length) x 64 lanes x 8 B
+    __shared__ int cblock[16];
+    if (vc && tid < 16) {
+        const int lo = (tid >> 3) * kTileBlk + (tid & 7) * 64, hi = lo + 64 < nprow ? lo + 64 : nprow;
+        cblock[tid] = hi > lo ? (int)(((skey[hi - 1] >> 20) + 3u) >> 2) * 64 : 0;
+    }
+    __syncthreads();
     // ---- streamed rows: descriptors in row order, words counted (their offsets follow from a scan over all rows: K7)
     int sflag[2], slenv[2];
     for (int k = 0; k < 2; ++k) {
@@ -665,11 +673,19 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
         case 9: v = nsw; break;
         case 10: v = row0; break;  // rd0: the tile's pattern-row descriptors start at its first row
         case 11: v = bnd; break;   // the tile's rows read halo columns (partitioned solve, direct transport: wait for the peers' flags)
-        default: break;
+        case 12:                   // value-code variant: size of the tile's code stream in 8-B quads (K7 turns it into its start)
+            if (vc && gtile) for (int i = 0; i < 16; ++i) v += cblock[i];
+            break;
+        case 13: v = t * kBrickTileStride; break; // ... the tile's value table in ttab
+        default: break;            // (14: the table's size, written by k_bk_tile_codes)
         }
         blk[tid] = (uint32_t)v;
     }
-    if (tid < 32) blk[16 + tid] = 0u; // (words 16 .. 47: free since the runs carry absolute columns)
+    if (tid < 32) { // words 16 .. 31: first quad of every wave's block of the code stream, relative to the tile's start (value-code variant)
+        int off = 0;
+        if (vc && gtile && tid < 16) for (int i = 0; i < tid; ++i) off += cblock[i];
+        blk[16 + tid] = (uint32_t)off;
+    }
     if (tid == 0) {
         tile_bnd_out[t] = (uint8_t)bnd;
         const int words = kBlkHdrWords + (gtile ? 2 * nruns + npq + npat : 0);
@@ -706,6 +722,144 @@ __global__ __launch_bounds__(kBlk) void k_bk_patch(int ntiles, const TileInfo *_
     if (t >= ntiles) return;
     blocks[(int64_t)t * kBlockStride + 8] = (uint32_t)sstart[tiles[t].row0];
 }
+// ---- value-code variant (variable viscosity) -------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned vhash(unsigned long long k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33;
+    return (unsigned)k & 1023u;
+}
+constexpr unsigned long long kNoValue = 0xFFFFFFFFFFFFFFFFull; // (a NaN pattern: never a matrix value)
+// inserts `key` into the 1024-slot set; false when the set is full
+__device__ __forceinline__ bool vset_insert(unsigned long long *set, unsigned long long key)
+{
+    unsigned h = vhash(key);
+    for (int probe = 0; probe < 1024; ++probe) {
+        const unsigned long long old = atomicCAS(&set[h], kNoValue, key);
+        if (old == kNoValue || old == key) return true;
+        h = (h + 1) & 1023u;
+    }
+    return false;
+}
+// a G tile whose rows hold more distinct values than a tile's LDS table takes becomes an E tile (counted over ALL its rows: the pattern
+// rows are not known yet)
+__global__ __launch_bounds__(kTileBlk) void k_bk_tile_valcount(const TileInfo *__restrict__ tiles, const int32_t *__restrict__ row_ptr,
+                                                              const double *__restrict__ val, uint8_t *__restrict__ force_e)
+{
+    __shared__ unsigned long long set[1024];
+    __shared__ int count, full;
+    const TileInfo &T = tiles[blockIdx.x];
+    if (!T.is_g) return;
+    const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
+    for (int i = tid; i < 1024; i += kTileBlk) set[i] = kNoValue;
+    if (tid == 0) { count = 0; full = 0; }
+    __syncthreads();
+    for (int r = grp; r < T.nrows; r += kTileBlk / 16)
+        for (int k = row_ptr[T.row0 + r] + sub; k < row_ptr[T.row0 + r + 1]; k += 16)
+            if (!vset_insert(set, (unsigned long long)__double_as_longlong(val[k]))) full = 1;
+    __syncthreads();
+    int c = 0;
+    for (int i = tid; i < 1024; i += kTileBlk) c += set[i] != kNoValue ? 1 : 0;
+    atomicAdd(&count, c);
+    __syncthreads();
+    if (tid == 0 && (full || count > kBrickTileVals)) force_e[blockIdx.x] = 1;
+}
+// per G tile, after K6: the value table of its pattern rows (ttab, entry ntv = nothing: the kernel puts 0.0 there) and the rows' codes
+// (byte offsets into the table) at their places in the code stream
+__global__ __launch_bounds__(kTileBlk) void k_bk_tile_codes(int ntiles, const uint2 *__restrict__ tile_blk, uint32_t *__restrict__ blocks,
+                                                           const int32_t *__restrict__ row_ptr, const double *__restrict__ val,
+                                                           const uint2 *__restrict__ rdesc, double *__restrict__ ttab, uint16_t *__restrict__ vcodes,
+                                                           int *__restrict__ overflow)
+{
+    __shared__ unsigned long long set[1024];
+    __shared__ int code_of[1024];
+    __shared__ int scan[kTileBlk];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    uint32_t *bw = blocks + (int64_t)tile_blk[t].x * 4;
+    const int row0 = (int)bw[0], npat = (int)bw[2], nprow = (int)bw[5], rd0 = (int)bw[10];
+    const int64_t cw0 = (int64_t)bw[12];
+    if (npat == 0 || nprow == 0) { if (tid == 0) bw[14] = 0u; return; }
+    for (int i = tid; i < 1024; i += kTileBlk) set[i] = kNoValue;
+    __syncthreads();
+    for (int i = tid; i < nprow; i += kTileBlk) {
+        const int r = row0 + (int)rdesc[rd0 + i].y;
+        for (int k = row_ptr[r]; k < row_ptr[r + 1]; ++k)
+            if (!vset_insert(set, (unsigned long long)__double_as_longlong(val[k]))) atomicExch(overflow, 1);
+    }
+    __syncthreads();
+    // slot -> code: exclusive count of the occupied slots before it (two slots per thread)
+    const int o0 = set[2 * tid] != kNoValue ? 1 : 0, o1 = set[2 * tid + 1] != kNoValue ? 1 : 0;
+    scan[tid] = o0 + o1;
+    __syncthreads();
+    for (int o = 1; o < kTileBlk; o <<= 1) {
+        const int v = tid >= o ? scan[tid - o] : 0;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    const int before = scan[tid] - o0 - o1, ntv = scan[kTileBlk - 1];
+    code_of[2 * tid] = before;
+    code_of[2 * tid + 1] = before + o0;
+    double *tab = ttab + (int64_t)t * kBrickTileStride;
+    if (ntv <= kBrickTileVals) {
+        if (o0) tab[before] = __longlong_as_double((long long)set[2 * tid]);
+        if (o1) tab[before + o0] = __longlong_as_double((long long)set[2 * tid + 1]);
+    } else if (tid == 0) {
+        atomicExch(overflow, 1); // (cannot happen: k_bk_tile_valcount counted a superset)
+    }
+    if (tid == 0) {
+        bw[14] = (uint32_t)ntv;
+        atomicAdd(overflow + 1, ntv);                        // (total table entries: what the form stores)
+    }
+    __syncthreads();
+    const unsigned pad = (unsigned)(ntv * 8);                // the table's 0.0 entry
+    for (int i = tid; i < nprow; i += kTileBlk) {
+        const int r = row0 + (int)rdesc[rd0 + i].y;
+        const int rs = row_ptr[r], len = row_ptr[r + 1] - rs;
+        const int kw = (i / kTileBlk) * (kTileBlk / 64) + ((i % kTileBlk) >> 6), lane = i & 63;
+        uint16_t *dst = vcodes + 4 * (cw0 + (int64_t)bw[16 + kw] + lane);   // quad q of this row at + 4 * 64 q
+        const int nq = (len + 3) >> 2;
+        for (int j = 0; j < 4 * nq; ++j) {
+            unsigned code = pad;
+            if (j < len) {
+                const unsigned long long key = (unsigned long long)__double_as_longlong(val[rs + j]);
+                unsigned h = vhash(key);
+                while (set[h] != key) h = (h + 1) & 1023u;
+                code = (unsigned)code_of[h] * 8u;
+            }
+            dst[(int64_t)(j >> 2) * 256 + (j & 3)] = (uint16_t)code;
+        }
+    }
+}
+// streamed rows of the value-code variant: 12 B per entry, column | value
+__global__ __launch_bounds__(kBlk) void k_bk_copy_streamed_vc(int64_t n, const int32_t *__restrict__ slen, const int32_t *__restrict__ sstart,
+                                                             const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+                                                             const double *__restrict__ val, uint32_t *__restrict__ swords)
+{
+    const int sub = threadIdx.x & 15;
+    const int64_t groups = ((int64_t)gridDim.x * kBlk) >> 4;
+    for (int64_t r = ((int64_t)blockIdx.x * kBlk + threadIdx.x) >> 4; r < n; r += groups) {
+        const int len = slen[r];
+        if (!len) continue;
+        const int src = row_ptr[r], dst = sstart[r];
+        for (int j = sub; j < len; j += 16) {
+            const long long v = __double_as_longlong(val[src + j]);
+            swords[3 * (int64_t)(dst + j)] = (uint32_t)col[src + j];
+            swords[3 * (int64_t)(dst + j) + 1] = (uint32_t)(v & 0xffffffffll);
+            swords[3 * (int64_t)(dst + j) + 2] = (uint32_t)((unsigned long long)v >> 32);
+        }
+    }
+}
+__global__ __launch_bounds__(kBlk) void k_bk_code_sizes(int ntiles, const uint32_t *__restrict__ blocks, int32_t *__restrict__ csize)
+{
+    const int t = blockIdx.x * kBlk + threadIdx.x;
+    if (t < ntiles) csize[t] = (int32_t)blocks[(int64_t)t * kBlockStride + 12];
+}
+__global__ __launch_bounds__(kBlk) void k_bk_patch_codes(int ntiles, const int32_t *__restrict__ cstart, uint32_t *__restrict__ blocks)
+{
+    const int t = blockIdx.x * kBlk + threadIdx.x;
+    if (t < ntiles) blocks[(int64_t)t * kBlockStride + 12] = (uint32_t)cstart[t];
+}
+
 // what the cost model of the planned walk reads of a tile: the counts in its block header
 __global__ __launch_bounds__(kBlk) void k_bk_tile_features(int ntiles, const uint2 *__restrict__ tile_blk, const uint32_t *__restrict__ blocks,
                                                           int4 *__restrict__ feat)
@@ -730,6 +884,7 @@ void BrickForm::clear()
     regular_rows = 0;
     patterns = 0;
     wgrid = 0;
+    vc = false;
 }
 
 void BrickScratch::release()
@@ -744,7 +899,7 @@ void BrickScratch::release()
 void BrickForm::release()
 {
     clear();
-    tile_blk.release(); rdesc.release(); sdesc.release(); blocks.release(); pwords.release(); swords.release(); ownslot.release(); tile_flags.release(); wlist.release(); wptr.release();
+    tile_blk.release(); rdesc.release(); sdesc.release(); blocks.release(); pwords.release(); swords.release(); ownslot.release(); tile_flags.release(); wlist.release(); wptr.release(); vcodes.release(); ttab.release();
     scratch.release();
 }
 
@@ -829,7 +984,8 @@ avs_status BrickForm::plan_walk(int grid, int xcd_mode, const BrickCost &cm, hip
 int64_t BrickForm::stored_bytes(int64_t n) const
 {
     // descriptor blocks (used words), row descriptors 8 B, own slots 2 B per row, streamed words + descriptors, pattern table, tile list
-    return 4 * block_words + 8 * regular_rows + 2 * n + (wide ? 8 : 4) * streamed_words + 8 * streamed_rows + 4 * pattern_words + 8 * (int64_t)ntiles;
+    return 4 * block_words + 8 * regular_rows + 2 * n + (vc ? 12 : (wide ? 8 : 4)) * streamed_words + 8 * streamed_rows + 4 * pattern_words + 8 * (int64_t)ntiles +
+           (vc ? 8 * code_quads + 8 * table_values : 0);
 }
 
 void BrickForm::view(BrickView &B, const ValueIndex &vi) const
@@ -847,6 +1003,7 @@ void BrickForm::view(BrickView &B, const ValueIndex &vi) const
     B.table = vi.table.p;
     B.table_size = vi.table_size;
     B.col_bits = wide ? 0 : vi.col_bits;   // 0: 64-bit streamed words
+    if (vc) { B.vc = 1; B.vcodes = vcodes.p; B.ttab = ttab.p; B.table = nullptr; B.table_size = kBrickTileVals; }
     B.n_rows = (int)n_rows;
     if (wgrid > 0) { B.wlist = wlist.p; B.wptr = wptr.p; B.wgrid = wgrid; }
 }
@@ -859,14 +1016,18 @@ avs_status build_brick_form(BrickForm &bf, const BrickSource &src, const Options
     const int64_t n = src.n_rows, nnz = src.nnz, n_cols = src.n_cols;
     if (n <= 0 || !src.vi || !src.row_ptr || !src.col || !src.ref_id || !src.vdof) return AVS_OK;
     const ValueIndex &vi = *src.vi;
-    if (vi.tile_tables || !vi.codes.p) return AVS_OK; // one dictionary; packed, windowed or 6-B columns
-    const bool wide = vi.col_bits <= 0 || vi.col_windows; // no (code << col_bits | column) stream to copy the streamed rows from
-    if (vi.table_size <= 0 || vi.table_size + 1 >= kBrickTableMax) return AVS_OK; // (one code is reserved for 0.0)
-    {
+    // One dictionary of few values (uniform viscosity): the patterns carry value codes into it.  Anything else -- tile-local dictionaries,
+    // thousands of values, no dictionary at all: spatially varying viscosity, cpp:2148-2150 -- takes the VALUE-CODE variant (round 5): the
+    // patterns carry the geometry only, every tile gets its own table of <= kBrickTileVals values in LDS and every pattern row a stream of
+    // 2-B codes into it.
+    bool vc = vi.tile_tables || !vi.codes.p || vi.table_size <= 0 || vi.table_size + 1 >= kBrickTableMax;
+    if (!vc) {
         BrickView probe;
         probe.table_size = vi.table_size;
-        if (!brick_lds_fits(probe)) return AVS_OK; // the value table next to the lattice would exceed a workgroup's LDS: the word stream serves this matrix
+        if (!brick_lds_fits(probe)) vc = true; // the one table next to the lattice would exceed a workgroup's LDS
     }
+    if (vc && (!src.val || !opt.brick_value_codes)) return AVS_OK;
+    const bool wide = vc || vi.col_bits <= 0 || vi.col_windows; // no (code << col_bits | column) stream to copy the streamed rows from
     if (src.brick_shift != 3 || src.levels < 1) return AVS_OK;
     if (src.nx > 1024 || src.ny > 1024 || src.nz > 1024 || nnz >= (1ll << 31) || n_cols >= (1ll << 31) - 64) return AVS_OK;
     const bool timing = opt.brick_timing != 0;
@@ -930,7 +1091,7 @@ avs_status build_brick_form(BrickForm &bf, const BrickSource &src, const Options
     AVS_TRY(S.row_hash.reserve((size_t)n));
     AVS_TRY(S.rgeo.reserve((size_t)n));
     AVS_TRY(bf.ownslot.alloc((size_t)n + 8));
-    const int zero_code = vi.table_size;
+    const int zero_code = vc ? 0 : vi.table_size;
     // ---- K4
     const size_t hslots = (size_t)1 << kHashBitsPat;
     AVS_TRY(S.keys.reserve(hslots));
@@ -939,7 +1100,7 @@ avs_status build_brick_form(BrickForm &bf, const BrickSource &src, const Options
     AVS_TRY(S.pat_rep.reserve((size_t)kMaxPatterns));
     AVS_TRY(S.pat_off.reserve((size_t)kMaxPatterns));
     AVS_HIP(hipMemsetAsync(S.keys.p, 0, hslots * sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(k_bk_rows, dim3(ntiles), dim3(kTileBlk), 0, st, dtiles, src.row_ptr, src.col, vi.codes.p, S.geo.p, nbx, nby, zero_code,
+    hipLaunchKernelGGL(k_bk_rows, dim3(ntiles), dim3(kTileBlk), 0, st, dtiles, src.row_ptr, src.col, vc ? (const uint16_t *)nullptr : (const uint16_t *)vi.codes.p, S.geo.p, nbx, nby, zero_code,
                        S.ewords.p, S.eslot.p, S.row_hash.p, S.rgeo.p, bf.ownslot.p, S.keys.p, S.rep.p, S.counters.p + 2);
     lap("K3 rows + pattern insert");
     hipLaunchKernelGGL(k_bk_assign, dim3((unsigned)(hslots / kBlk)), dim3(kBlk), 0, st, S.keys.p, S.rep.p, src.row_ptr, S.slot_id.p, S.pat_rep.p,
@@ -969,10 +1130,11 @@ avs_status build_brick_form(BrickForm &bf, const BrickSource &src, const Options
     AVS_TRY(S.force_e.reserve((size_t)ntiles));
     AVS_TRY(bf.tile_flags.alloc((size_t)ntiles + 1));
     AVS_HIP(hipMemsetAsync(S.force_e.p, 0, (size_t)ntiles, st));
+    if (vc) hipLaunchKernelGGL(k_bk_tile_valcount, dim3(ntiles), dim3(kTileBlk), 0, st, dtiles, src.row_ptr, src.val, S.force_e.p);
     for (int round = 0; round < 2; ++round) {
         AVS_HIP(hipMemsetAsync(S.counters.p + 4, 0, sizeof(int), st));
         hipLaunchKernelGGL(k_bk_tile, dim3(ntiles), dim3(kTileBlk), 0, st, dtiles, src.row_ptr, src.col, S.eslot.p, S.row_pid.p, S.rgeo.p,
-                           S.pat_off.p, S.pat_rep.p, (int)n, n_cols > n ? 1 : 0, S.force_e.p, bf.blocks.p, bf.tile_blk.p, bf.rdesc.p, bf.sdesc.p, S.slen.p,
+                           S.pat_off.p, S.pat_rep.p, (int)n, n_cols > n ? 1 : 0, vc ? kBrickPatWordsVc : kBrickPatWords, vc ? 1 : 0, S.force_e.p, bf.blocks.p, bf.tile_blk.p, bf.rdesc.p, bf.sdesc.p, S.slen.p,
                            S.tile_nprow.p, bf.tile_flags.p, S.counters.p + 4);
         int fb = 0;
         AVS_HIP(hipMemcpyAsync(&fb, S.counters.p + 4, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -982,7 +1144,9 @@ avs_status build_brick_form(BrickForm &bf, const BrickSource &src, const Options
         std::vector<int32_t> hn((size_t)ntiles);
         std::vector<uint8_t> hf((size_t)ntiles, 0);
         AVS_HIP(hipMemcpy(hn.data(), S.tile_nprow.p, (size_t)ntiles * sizeof(int32_t), hipMemcpyDeviceToHost));
-        for (int t = 0; t < ntiles; ++t) hf[(size_t)t] = hn[(size_t)t] < 0 ? 1 : 0;
+        std::vector<uint8_t> he((size_t)ntiles, 0);
+        AVS_HIP(hipMemcpy(he.data(), S.force_e.p, (size_t)ntiles, hipMemcpyDeviceToHost)); // (tiles already forced: too many values for a tile's table)
+        for (int t = 0; t < ntiles; ++t) hf[(size_t)t] = (hn[(size_t)t] < 0 || he[(size_t)t]) ? 1 : 0;
         AVS_HIP(hipMemcpy(S.force_e.p, hf.data(), (size_t)ntiles, hipMemcpyHostToDevice));
     }
     lap("K6 tiles");
@@ -997,8 +1161,36 @@ avs_status build_brick_form(BrickForm &bf, const BrickSource &src, const Options
     AVS_HIP(hipMemcpyAsync(&regular, S.total.p, sizeof(regular), hipMemcpyDeviceToHost, st));
     AVS_HIP(hipStreamSynchronize(st));
     bf.wide = wide;
-    AVS_TRY(bf.swords.alloc(((size_t)total_sw + 16) * (wide ? 2 : 1)));
-    if (wide)
+    bf.vc = vc;
+    bf.code_quads = 0;
+    bf.table_values = 0;
+    AVS_TRY(bf.swords.alloc(((size_t)total_sw + 16) * (vc ? 3 : (wide ? 2 : 1))));
+    if (vc) {
+        hipLaunchKernelGGL(k_bk_copy_streamed_vc, dim3(4096), dim3(kBlk), 0, st, n, S.slen.p, S.sstart.p, src.row_ptr, src.col, src.val, bf.swords.p);
+        // the code stream: per-tile sizes (header word 12) -> starts, then tables and codes tile by tile
+        AVS_TRY(S.tcount.reserve((size_t)ntiles + 2));
+        AVS_TRY(S.tile0.reserve((size_t)ntiles + 2));
+        const unsigned gt = (unsigned)((ntiles + kBlk - 1) / kBlk);
+        hipLaunchKernelGGL(k_bk_code_sizes, dim3(gt), dim3(kBlk), 0, st, ntiles, (const uint32_t *)bf.blocks.p, S.tcount.p);
+        AVS_TRY(exclusive_scan_i32(S.tcount.p, S.tile0.p, ntiles, S.scan_tmp.p, S.scan_tmp.n, st));
+        int32_t total_q = 0;
+        AVS_HIP(hipMemcpyAsync(&total_q, S.tile0.p + ntiles, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        AVS_HIP(hipStreamSynchronize(st));
+        AVS_REQUIRE(total_q >= 0, AVS_EINTERNAL, "brick form: code stream offsets overflow");
+        bf.code_quads = total_q;
+        AVS_TRY(bf.vcodes.alloc((size_t)total_q + 4096));
+        AVS_TRY(bf.ttab.alloc((size_t)ntiles * kBrickTileStride + 8));
+        AVS_HIP(hipMemsetAsync(bf.vcodes.p, 0, ((size_t)total_q + 4096) * sizeof(uint2), st));
+        hipLaunchKernelGGL(k_bk_patch_codes, dim3(gt), dim3(kBlk), 0, st, ntiles, (const int32_t *)S.tile0.p, bf.blocks.p);
+        AVS_HIP(hipMemsetAsync(S.counters.p + 5, 0, 2 * sizeof(int), st));
+        hipLaunchKernelGGL(k_bk_tile_codes, dim3(ntiles), dim3(kTileBlk), 0, st, ntiles, (const uint2 *)bf.tile_blk.p, bf.blocks.p, src.row_ptr, src.val,
+                           (const uint2 *)bf.rdesc.p, bf.ttab.p, reinterpret_cast<uint16_t *>(bf.vcodes.p), S.counters.p + 5);
+        int ovf[2] = {0, 0};
+        AVS_HIP(hipMemcpyAsync(ovf, S.counters.p + 5, sizeof(ovf), hipMemcpyDeviceToHost, st));
+        AVS_HIP(hipStreamSynchronize(st));
+        AVS_REQUIRE(!ovf[0], AVS_EINTERNAL, "brick form: a tile's value table overflowed");
+        bf.table_values = ovf[1];
+    } else if (wide)
         hipLaunchKernelGGL(k_bk_copy_streamed<true>, dim3(4096), dim3(kBlk), 0, st, n, S.slen.p, S.sstart.p, src.row_ptr, (const uint32_t *)nullptr,
                            vi.codes.p, src.col, bf.swords.p);
     else
@@ -1054,6 +1246,7 @@ avs_status build_brick_form(avs_ctx *c)
     src.row_ptr = c->p_row_ptr.p;
     src.col = c->p_col.p;
     src.vi = &c->vi;
+    src.val = c->p_val.p;
     src.vdof = c->vdof.p;
     src.ref_id = c->perm.p;
     src.nx = c->desc.nx; src.ny = c->desc.ny; src.nz = c->desc.nz;

@@ -1145,6 +1145,7 @@ static avs_status dist_build_brick(avs_ctx *c, PcgDist *d)
     src.row_ptr = d->row_ptr.p;
     src.col = d->col.p;
     src.vi = &d->vi;
+    src.val = d->val.p;
     src.vdof = c->vdof.p;
     src.ref_id = d->local_ref.p;
     src.nx = c->desc.nx; src.ny = c->desc.ny; src.nz = c->desc.nz;
@@ -1378,6 +1379,7 @@ bool dist_matrix_format(avs_ctx *c, avs_matrix_format *fmt)
         fmt->brick_pattern_rows = d->brick.regular_rows;
         fmt->brick_bytes = d->brick.stored_bytes(d->n_own);
         fmt->brick_walk = d->brick_view.walk;
+        fmt->brick_value_codes = d->brick.vc ? 1 : 0;
     }
     return true;
 }

@@ -95,6 +95,7 @@ struct Options {
     int brick_interleave = 1, brick_shift = 3, value_index = 1, value_pack = 1, tile_tables = 1, column_windows = 1;
     double brick_min_regular = 0.6;
     int brick_timing = 0;
+    int brick_value_codes = 1;   // AVS_BRICK_VALUE_CODES: the value-code variant of the brick form for matrices without one small dictionary (variable viscosity)
     int brick_plan = 1;          // AVS_BRICK_PLAN: cost-balanced planned walk of the brick kernel (0: the static strided walks)
     BrickCost brick_cost;        // AVS_BRICK_COST=tile,row,run,word,etile,quad
     // single-GPU loop
@@ -276,6 +277,9 @@ constexpr int kBrickMaxRows = 1024;   // rows per tile, two per thread (a fuller
 constexpr int kBrickMaxRuns = 320;    // halo fill runs per tile
 constexpr int kBrickXSlots = 160;     // extra x slots per tile behind the lattice (slots 3936 .. 4095: off-lattice columns in the 27 neighbour bricks)
 constexpr int kBrickPatWords = 2560;  // pattern words staged in LDS per tile (10 KiB)
+constexpr int kBrickPatWordsVc = 1536; // ... in the value-code variant (geometry-only patterns: fewer per tile), which needs the LDS for the tile's value table
+constexpr int kBrickTileStride = 448;  // doubles reserved per tile in BrickForm::ttab
+constexpr int kBrickTileVals = 446;   // value-code variant: distinct values of a tile's pattern rows (one LDS entry each + the 0.0 of the padding words)
 constexpr int kBrickPark = 1024;      // products of streamed rows parked per pass in a G tile (8 KiB): 52.7 KiB per workgroup, three per CU
 constexpr int kBrickPatMax = 384;     // patterns per tile
 constexpr int kBrickRowBase = 120;    // LDS table of row bases: 3 axes x 4 levels x 10 coordinates
@@ -304,6 +308,11 @@ struct BrickView {
     const uint2 *wlist = nullptr;
     const int32_t *wptr = nullptr;
     int wgrid = 0;
+    // value-code variant (variable viscosity, round 5): the patterns carry the geometry only; every pattern row streams 2-B codes into its
+    // tile's value table (table_size is then the LDS capacity of a tile's table)
+    int vc = 0;
+    const uint2 *vcodes = nullptr;   // per row quad four 16-bit byte offsets into the tile's table, wave-interleaved in execution order
+    const double *ttab = nullptr;    // the tiles' value tables, one after the other
 };
 // the form's arrays, owned by the context next to the CSR / value index of the solve matrix (avs_brick_build.hip)
 struct BrickScratch { // build-time buffers, kept across frames
@@ -322,6 +331,10 @@ struct BrickForm {
     DevBuf<uint32_t> blocks, pwords, swords;
     DevBuf<uint16_t> ownslot;
     DevBuf<uint8_t> tile_flags;       // per tile (walk order): 1 = its rows read halo columns (partitioned systems)
+    DevBuf<uint2> vcodes;             // value-code variant: the pattern rows' value codes (BrickView::vcodes)
+    DevBuf<double> ttab;              // ... and the tiles' value tables, kBrickTileStride doubles apart
+    bool vc = false;
+    int64_t code_quads = 0, table_values = 0;
     DevBuf<uint2> wlist;              // planned walk: the workgroups' tile sequences, one after the other
     DevBuf<int32_t> wptr;
     int wgrid = 0;                    // the grid the plan was laid out for (0: no plan)
@@ -346,6 +359,7 @@ struct BrickSource {
     int64_t n_rows = 0, n_cols = 0, nnz = 0;
     const int32_t *row_ptr = nullptr, *col = nullptr;
     const ValueIndex *vi = nullptr;
+    const double *val = nullptr;      // the values (CSR order): read by the value-code variant, whose tiles build their own tables
     const int32_t *vdof = nullptr;    // dof table, reference numbering (level | axis << 8, i, j, k)
     const int32_t *ref_id = nullptr;  // n_cols: reference DOF id of every column (single GPU: the brick-major permutation)
     int nx = 0, ny = 0, nz = 0, levels = 0, brick_shift = 3;

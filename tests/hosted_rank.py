@@ -32,6 +32,7 @@ def main():
           "beam128": lambda: scenes.fat_beam(128, 3, device=dev),
           "beam128_brick": lambda: scenes.fat_beam(128, 3, device=dev),        # (AVS_BRICK=1 in the environment: the brick-structured form)
           "beam128L4_brick": lambda: scenes.fat_beam(128, 4, device=dev),
+          "varvisc128_brick": lambda: scenes.fat_beam(128, 4, variable_viscosity=True, device=dev),
           "varvisc128": lambda: scenes.fat_beam(128, 4, variable_viscosity=True, device=dev)}[scene]()
     pp = DevicePrepass(sc.res, sc.dx, sc.levels)
     pi = pp.run(sc.liquid, sc.solid)

@@ -36,7 +36,12 @@ SCENES = {
     "sphere64_L3": lambda: scenes.sphere(64, 3),
     "beam64_L2": lambda: scenes.fat_beam(64, 2),
     "beam256_L5": lambda: scenes.fat_beam(256, 5),
+    # round 5 -- the value-code variant (variable viscosity, cpp:2148-2150: tens of thousands of distinct values; a sphere: thousands):
+    # geometry-only patterns + a 2-B code per entry into the tile's own value table
+    "beam128_L4_varvisc": lambda: scenes.fat_beam(128, 4, variable_viscosity=True),
+    "beam64_L3_varvisc_wall": lambda: scenes.fat_beam(64, 3, variable_viscosity=True, wall=True),
 }
+VALUE_CODE_SCENES = ("beam128_L4_varvisc", "beam64_L3_varvisc_wall", "sphere64_L3")
 
 
 @pytest.mark.parametrize("name", list(SCENES))
@@ -47,14 +52,18 @@ def test_brick_form_is_lossless(name, monkeypatch, built_lib):
     if name.startswith("beam") or name.startswith("sheet"):
         assert fmt.brick_tiles > 0, "the form was not built for a flat-faced scene"
         assert fmt.brick_pattern_rows >= 0.6 * ai.n_velocity
-        assert fmt.brick_bytes < 4 * ai.nnz
+        assert fmt.brick_bytes < (6 if name in VALUE_CODE_SCENES else 4) * ai.nnz   # (value codes: 2 B per entry + a table per tile)
+    if name in VALUE_CODE_SCENES and (fmt.brick_tiles > 0 or "sphere" not in name):   # (a curved surface may not be regular enough for the form)
+        assert fmt.brick_tiles > 0 and fmt.brick_value_codes == 1, (name, fmt.brick_tiles, fmt.brick_value_codes, fmt.value_table_size)
+    elif fmt.brick_tiles > 0:
+        assert fmt.brick_value_codes == 0
     # plain and fused-dot launches: avs_bench_spmv compares y with the plain CSR kernel bit for bit and fails on any difference
     s.bench_spmv(0, 3)
     s.bench_spmv(100, 3)
     s.close()
 
 
-@pytest.mark.parametrize("name", ["beam128_L4", "sheet128_L4", "beam64_L3_wall", "tank128_L4"])
+@pytest.mark.parametrize("name", ["beam128_L4", "sheet128_L4", "beam64_L3_wall", "tank128_L4", "beam128_L4_varvisc", "sphere64_L3"])
 def test_brick_product_against_the_oracle(name, monkeypatch, built_lib):
     """k_spmv_brick itself against the CPU oracle (round-4 review: the new hot kernel was compared with the plain CSR HIP kernel only):
     a random x in the reference's DOF numbering through the solver's form -- permutation, brick kernel (plain and fused-dot
@@ -64,7 +73,9 @@ def test_brick_product_against_the_oracle(name, monkeypatch, built_lib):
     s = _solver(sc, monkeypatch, True)
     ai = s.assemble()
     fmt = s.matrix_format()
-    assert fmt.brick_tiles > 0 and fmt.brick_pattern_rows >= 0.6 * ai.n_velocity, "the brick form did not run"
+    if "sphere" in name and fmt.brick_tiles == 0:
+        pytest.skip("the curved surface is not regular enough for the form")
+    assert fmt.brick_tiles > 0 and fmt.brick_pattern_rows >= 0.5 * ai.n_velocity, "the brick form did not run"
     pyr = build_pyramid(sc)
     o = oracle_from_pyramid(sc, pyr)
     o.hot_path()
@@ -109,7 +120,7 @@ def test_brick_form_with_wide_streamed_words(name, env, monkeypatch, built_lib):
     s.close()
 
 
-@pytest.mark.parametrize("name", ["beam128_L4", "beam64_L3_wall", "sheet128_L4"])
+@pytest.mark.parametrize("name", ["beam128_L4", "beam64_L3_wall", "sheet128_L4", "beam128_L4_varvisc"])
 def test_solve_through_the_brick_form(name, monkeypatch, built_lib):
     out = {}
     for brick in (False, True):

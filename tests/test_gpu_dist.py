@@ -106,7 +106,7 @@ def test_rccl_world_size_one(built_lib):
 
 
 @pytest.mark.parametrize("scene,world", [("beam", 2), ("varvisc", 2), ("beam128", 3), ("beam128", 8), ("varvisc128", 3),
-                                         ("beam128_brick", 3), ("beam128L4_brick", 2)])   # round 5: the brick-structured form, HALO instantiation
+                                         ("beam128_brick", 3), ("beam128L4_brick", 2), ("varvisc128_brick", 2)])   # round 5: the brick-structured form (+ its value-code variant)
 def test_processes_direct_transport(scene, world, tmp_path, built_lib):
     """One PROCESS per rank (both on cuda:0): comm blocks mapped through HIP IPC handles, halo entries stored straight into
     the neighbour's block, CG sums by flag-based all-gather -- no RCCL anywhere (hosted group, blobs through files)."""
@@ -119,6 +119,7 @@ def test_processes_direct_transport(scene, world, tmp_path, built_lib):
           "beam128": lambda: scenes.fat_beam(128, 3, device=dev),
           "beam128_brick": lambda: scenes.fat_beam(128, 3, device=dev),
           "beam128L4_brick": lambda: scenes.fat_beam(128, 4, device=dev),
+          "varvisc128_brick": lambda: scenes.fat_beam(128, 4, variable_viscosity=True, device=dev),
           # tile-local dictionaries + windowed columns through the HALO instantiation of the SpMV (peer-written halo area)
           "varvisc128": lambda: scenes.fat_beam(128, 4, variable_viscosity=True, device=dev)}[scene]()
     pyr = build_pyramid(sc)
@@ -271,7 +272,7 @@ def test_device_planner_equals_host_planner(world, cut_axis, scene, built_lib, m
 
 
 @pytest.mark.parametrize("world,cut_axis,scene", [(1, -1, "beam"), (2, -1, "beam"), (4, 0, "varvisc"), (3, 2, "sphere"), (3, 0, "varvisc128"),
-                                                  (1, -1, "beam128_brick"), (3, 0, "beam128_brick"), (2, 2, "beam128L4_brick")])
+                                                  (1, -1, "beam128_brick"), (3, 0, "beam128_brick"), (2, 2, "beam128L4_brick"), (2, 0, "varvisc128_brick")])
 def test_distributed_assembly_matches_single_solve(world, cut_axis, scene, built_lib, monkeypatch):
     """avs_dist_assemble: every rank assembles only its own rows (no global matrix) -- the partitioned solve must
     reproduce the single-rank solve, the local systems must add up to the global one, and the send / receive lists of
@@ -284,6 +285,7 @@ def test_distributed_assembly_matches_single_solve(world, cut_axis, scene, built
           "sphere": lambda: scenes.sphere(64, 4, device=dev),
           "beam128_brick": lambda: scenes.fat_beam(128, 3, device=dev),
           "beam128L4_brick": lambda: scenes.fat_beam(128, 4, device=dev),
+          "varvisc128_brick": lambda: scenes.fat_beam(128, 4, variable_viscosity=True, device=dev),
           # tens of thousands of distinct values per rank: tile-local dictionaries + windowed columns on matrices with halo
           # columns and the [interior | halo-reading] row order (the form whose head-of-pass decode once gathered out of range)
           "varvisc128": lambda: scenes.fat_beam(128, 4, variable_viscosity=True, device=dev)}[scene]()
@@ -318,6 +320,7 @@ def test_distributed_assembly_matches_single_solve(world, cut_axis, scene, built
             if scene.endswith("_brick"):
                 fmt = s.matrix_format()
                 assert fmt.brick_tiles > 0 and fmt.brick_pattern_rows > 0.6 * plan["sizes"][0], (r, fmt.brick_tiles, fmt.brick_pattern_rows)
+                assert fmt.brick_value_codes == (1 if scene.startswith("varvisc") else 0)
             results[r] = (info, x, ai, plan)
         except Exception as e:  # pragma: no cover
             errors.append((r, e))
