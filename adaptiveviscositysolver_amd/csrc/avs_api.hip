@@ -125,6 +125,7 @@ Options options_from_env()
     if (const char *e = getenv("AVS_DIST_PLAN")) o.dist_host_plan = strcmp(e, "host") == 0;
     o.dist_selftest_rounds = env_int("AVS_DIST_SELFTEST_ROUNDS", 64);
     o.dist_split_rows = env_int("AVS_DIST_SPLIT_ROWS", 1) != 0;
+    o.dist_plane_shift = env_int("AVS_DIST_PLANE_SHIFT", -1);
     if (const char *e = getenv("AVS_DIST_TIMEOUT_MS")) o.dist_timeout_ms = atoll(e) > 0 ? atoll(e) : 0;
     return o;
 }

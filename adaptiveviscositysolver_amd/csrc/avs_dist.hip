@@ -1179,7 +1179,14 @@ static avs_status dist_assemble_device(avs_ctx *c, PcgDist *d, int cut_axis, int
     const int64_t n = c->n_vel;
     const int rank = d->rank, world = d->world;
     AVS_REQUIRE(world <= 32, AVS_EINVAL, "at most 32 ranks");
-    const int shift = c->desc.levels - 1;
+    // Cut planes: the slabs are cut between planes of 2^shift fine cells.  The replicated planner (avs_dist_partition, avs_partition.cpp)
+    // keeps 2^(levels-1) -- no top-level cell straddles a cut; here, where every rank assembles its own rows, nothing needs that (a DOF
+    // belongs to the plane of its own position, whatever it reads is a halo column), and planes of at most 4 cells halve the granularity
+    // of the balance at 4 levels: on the 8-way partition of the 512^3 beam a rank's share moved in steps of 12.5 % (868 k .. 994 k rows,
+    // 30.5 .. 34.3 us per iteration in the loop-back measurement -- the slowest rank sets the pace).  AVS_DIST_PLANE_SHIFT overrides.
+    int shift = c->desc.levels - 1;
+    if (cur_opt().dist_plane_shift >= 0) shift = cur_opt().dist_plane_shift < shift ? cur_opt().dist_plane_shift : shift;
+    else if (shift > 2) shift = 2;
     const int nplanes = (extent + (1 << shift) - 1) >> shift;
     AVS_REQUIRE(nplanes <= 65535, AVS_EINVAL, "too many cut planes");
 

@@ -106,7 +106,7 @@ struct Options {
     double resident_lane_fill = 0.90, resident_remote_cost = 3.0, resident_stream_cost = 1.5;
     int resident_coherent_fill = 1, resident_timers = 0, resident_verbose = 0;
     // multi-GPU
-    int dist_standard_cg = 0, dist_overlap = 1, dist_loopback = 0, dist_host_plan = 0, dist_selftest_rounds = 64, dist_split_rows = 1;
+    int dist_standard_cg = 0, dist_overlap = 1, dist_loopback = 0, dist_host_plan = 0, dist_selftest_rounds = 64, dist_split_rows = 1, dist_plane_shift = -1;
     long long dist_timeout_ms = 0; // 0: the defaults (20 s between ranks, 2 s inside one device)
 };
 Options options_from_env();
