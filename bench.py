@@ -305,10 +305,22 @@ def extra_workload(label, sc, local_rank, tol, max_iters):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     iters = sum(i.iterations for i in infos)
+    # what a one-solve-per-frame caller pays (the reference: solveGasSubclass assembles a NEW matrix every substep, cpp:126): a re-assembly in
+    # the warmed-up context -- new value index, new brick form / resident lane plan, graph re-capture -- then ONE solve
+    s.assemble()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    inm = s.solve(tol, max_iters)
+    torch.cuda.synchronize()
+    new_matrix_solve_ms = (time.perf_counter() - t0) * 1e3
     rec = {"workload": label, "n_dofs": int(ai.n_velocity), "nnz": int(ai.nnz), "levels": int(pinfo.levels),
            "cg_iterations_per_step": iters // 2, "converged": int(all(i.converged for i in infos)),
            "resident_loop": bool(infos[0].resident),   # CU-resident PCG (one cooperative launch; no separate SpMV launch to time)
-           "value": iters / el, "unit": "iter/s", "ms_per_step": el / 2 * 1e3, "first_solve_ms": first_solve_ms, "assembly_wall_ms": asm_ms,
+           "value": iters / el, "unit": "iter/s", "ms_per_step": el / 2 * 1e3, "first_solve_ms": first_solve_ms, "new_matrix_solve_ms": new_matrix_solve_ms,
+           "new_matrix_note": "first_solve_ms = the first solve of a fresh context (allocations, code-object load, plan, graph capture); "
+                              "new_matrix_solve_ms = one solve right after a re-assembly in the warmed-up context (per-frame cost: plan / form / "
+                              "capture for the new matrix included); ms_per_step = steady state on an unchanged matrix",
+           "new_matrix_iterations": int(inm.iterations), "assembly_wall_ms": asm_ms,
            "prepass_ms": pinfo.weights_ms + pinfo.octree_ms + pinfo.classify_ms + pinfo.number_ms,
            "roofline": (spmv_roofline(int(ai.n_velocity), int(ai.nnz), s.matrix_format(), sum(i.spmv_ms for i in infos) / 2, s.spmv_kernel_name())
                         if infos[0].spmv_ms > 0 else
