@@ -39,16 +39,16 @@ def get(passname, kernel_sub, counter):
     return None
 us = None
 for r in csv.DictReader(open(f'gpurun_out/r05prof/{tag}_kernel_stats.csv')):
-    if 'k_spmv_brick<true>' in r['Name']:
+    if 'k_spmv_brick<true' in r['Name']:
         us = float(r['AverageNs']) / 1e3
         calls = int(r['Calls'])
 line = json.loads(open(f'gpurun_out/r05prof/{tag}_bench_line_under_rocprof.json').read().strip().splitlines()[-1])
 n, nnz = line['config']['n_dofs'], line['config']['nnz']
-fetch, write = get('pmc_fetch', 'spmv_brick<true>', 'FETCH_SIZE'), get('pmc_write', 'spmv_brick<true>', 'WRITE_SIZE')
+fetch, write = get('pmc_fetch', 'spmv_brick<true', 'FETCH_SIZE'), get('pmc_write', 'spmv_brick<true', 'WRITE_SIZE')
 cal_f, cal_w = get('pmc_fetch', 'k_update_r', 'FETCH_SIZE'), get('pmc_write', 'k_update_r', 'WRITE_SIZE')
-valu, waves = get('pmc_sq_b', 'spmv_brick<true>', 'SQ_INSTS_VALU'), get('pmc_sq_b', 'spmv_brick<true>', 'SQ_WAVES')
-wait, wcyc = get('pmc_sq_a', 'spmv_brick<true>', 'SQ_WAIT_ANY'), get('pmc_sq_a', 'spmv_brick<true>', 'SQ_WAVE_CYCLES')
-ldsc, ldsa = get('pmc_sq_a', 'spmv_brick<true>', 'SQ_LDS_BANK_CONFLICT'), get('pmc_sq_a', 'spmv_brick<true>', 'SQ_LDS_IDX_ACTIVE')
+valu, waves = get('pmc_sq_b', 'spmv_brick<true', 'SQ_INSTS_VALU'), get('pmc_sq_b', 'spmv_brick<true', 'SQ_WAVES')
+wait, wcyc = get('pmc_sq_a', 'spmv_brick<true', 'SQ_WAIT_ANY'), get('pmc_sq_a', 'spmv_brick<true', 'SQ_WAVE_CYCLES')
+ldsc, ldsa = get('pmc_sq_a', 'spmv_brick<true', 'SQ_LDS_BANK_CONFLICT'), get('pmc_sq_a', 'spmv_brick<true', 'SQ_LDS_IDX_ACTIVE')
 rec = {"kernel": "k_spmv_brick<DOT=true> inside the PCG loop, " + line['roofline']['kernel'][:200],
        "n": n, "nnz": nnz, "brick": True, "bytes_per_nonzero": 4, "tile_local_tables": False,
        "source_sha16": capi.source_fingerprint(),
