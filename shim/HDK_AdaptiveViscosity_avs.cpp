@@ -18,6 +18,7 @@
 #include <SIM/SIM_ScalarField.h>
 #include <SIM/SIM_VectorField.h>
 #include <UT/UT_DSOVersion.h>
+#include <UT/UT_Interrupt.h>
 #include <UT/UT_ParallelUtil.h>
 #include <UT/UT_PerfMonAutoEvent.h>
 #include <UT/UT_VoxelArray.h>
@@ -25,6 +26,9 @@
 
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "avs.h"
@@ -282,7 +286,21 @@ bool HDK_AdaptiveViscosity::solveGasSubclass(SIM_Engine &engine, SIM_Object *obj
 #ifndef USEEIGEN // the non-Eigen build passes no preconditioner to UT_SparseMatrixRowT::solveConjugateGradient (cpp:638-642)
         if (!check(avs_set_solver_option(h.ctx, AVS_OPTION_PRECONDITIONER, AVS_PRECONDITIONER_NONE))) return false;
 #endif
-        if (!check(avs_solve(h.ctx, getSolverTolerance(), getMaxIterations(), &sinfo))) return false; // non-convergence is not an error (cpp:645-652)
+        // The reference polls UT_Interrupt::opInterrupt() inside its loops (cpp:2528; HDK_OctreeGrid.cpp:584-588).  The solve runs on the
+        // device; a watcher thread polls the interrupt server while this thread is inside avs_solve and forwards a user break as avs_cancel
+        // (any thread may call it): the loop ends at its next poll of the device state, sinfo.cancelled == 1.
+        UT_Interrupt *boss = UTgetInterrupt();
+        std::atomic<bool> solving{true};
+        std::thread watcher([&] {
+            while (solving.load(std::memory_order_acquire)) {
+                if (boss->opInterrupt()) { (void)avs_cancel(h.ctx); break; }
+                std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            }
+        });
+        const bool solved = check(avs_solve(h.ctx, getSolverTolerance(), getMaxIterations(), &sinfo)); // non-convergence is not an error (cpp:645-652)
+        solving.store(false, std::memory_order_release);
+        watcher.join();
+        if (!solved || sinfo.cancelled) return false;
         UT_WorkBuffer extra;
         extra.sprintf("iterations=%d, error=%.6f, octree DOFS=%d, regular DOFs=%d", (int)sinfo.iterations, sinfo.error, (int)sinfo.n,
                       (int)pinfo.n_regular);
