@@ -27,7 +27,7 @@ STATUS_NAMES = {0: "AVS_OK", 1: "AVS_EINVAL", 2: "AVS_ENOMEM", 3: "AVS_EHIP", 4:
 MEM_HOST, MEM_DEVICE = 0, 1
 PRECISION_F64, PRECISION_F32 = 0, 1   # avs_desc.precision (SolveType of the reference, util.h:25-37)
 (OPTION_PRECONDITIONER, OPTION_RESIDENT_LOOP, OPTION_TRANSPORT, OPTION_PARANOID, OPTION_GRAPH_REPLAY, OPTION_BRICK_FORM,
- OPTION_FUSED_SCALAR_STEPS, OPTION_RELOAD_ENVIRONMENT) = range(8)  # avs_set_solver_option
+ OPTION_FUSED_SCALAR_STEPS, OPTION_RELOAD_ENVIRONMENT, OPTION_F32_VECTORS) = range(9)  # avs_set_solver_option
 USE_TRANSPORT_AUTO, USE_TRANSPORT_RCCL, USE_TRANSPORT_DIRECT = 0, 1, 2
 BRICK_AUTO, BRICK_NEVER, BRICK_ALWAYS, BRICK_TUNE = -1, 0, 1, 2
 PRECONDITIONER_JACOBI, PRECONDITIONER_NONE = 0, 1

@@ -107,6 +107,7 @@ Options options_from_env()
         (void)sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &k.tile, &k.row, &k.run, &k.word, &k.etile, &k.quad);
     }
     o.fuse_beta = env_int("AVS_PCG_FUSE_BETA", 1) != 0;
+    o.f32_vectors = env_int("AVS_F32_VECTORS", 1) != 0;
     o.resident_cus = env_int("AVS_CG_RESIDENT_CUS", 0);
     o.resident_equal_lanes = getenv("AVS_CG_RESIDENT_EQUAL_LANES") != nullptr;
     o.resident_max_global = env_int("AVS_CG_RESIDENT_MAX_GLOBAL", 3);
@@ -547,6 +548,7 @@ static CsrView csr_of(avs_ctx *c)
     if (c->reordered) c->vi.apply(A);
     A.no_precond = c->no_precond;
     A.brick = (c->reordered && c->brick.ready) ? &c->brick_view : nullptr;
+    A.f32_vectors = (c->desc.precision == AVS_PRECISION_F32 && c->opt.f32_vectors) ? 1 : 0;
     return A;
 }
 
@@ -579,6 +581,7 @@ avs_status avs_set_solver_option(avs_ctx *c, avs_solver_option option, int32_t v
         return AVS_OK;
     case AVS_OPTION_FUSED_SCALAR_STEPS: c->opt.fuse_beta = value != 0; return AVS_OK;
     case AVS_OPTION_RELOAD_ENVIRONMENT: c->opt = options_from_env(); c->brick_verdict_rows = 0; return AVS_OK;
+    case AVS_OPTION_F32_VECTORS: c->opt.f32_vectors = value != 0; return AVS_OK;
     }
     set_error("unknown solver option %d", (int)option);
     return AVS_EINVAL;
@@ -898,10 +901,11 @@ namespace avs {
 // y = A x through the solver's form (+ the folded partial sums of x.y of the fused-dot instantiation)
 avs_status probe_spmv_form(const CsrView &A, const double *x, double *y, bool fused, double *dot_out, hipStream_t st)
 {
+    if (A.f32_vectors) return spmv_f32_probe(A, x, y, fused, dot_out, st); // AVS_PRECISION_F32: the float kernels the solve launches
     if (!fused) return spmv_launch(A, x, y, 0, st);
     DevBuf<double> partial;
     size_t np = spmv_partial_elems(A.n);
-    if (A.brick && A.brick->ntiles > 0 && (size_t)brick_partial_count(*A.brick) > np) np = (size_t)brick_partial_count(*A.brick);
+    if (A.brick && A.brick->ntiles > 0 && (size_t)brick_partial_count(*A.brick, 8) > np) np = (size_t)brick_partial_count(*A.brick, 8);
     AVS_TRY(partial.alloc(np));
     AVS_HIP(hipMemsetAsync(partial.p, 0, np * sizeof(double), st));
     AVS_TRY(spmv_dot_launch(A, x, y, partial.p, 0, st));

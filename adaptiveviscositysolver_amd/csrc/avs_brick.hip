@@ -82,9 +82,15 @@ __device__ __forceinline__ int brick_srow_of_thread(int tid, int k) { return k *
 
 // The kernel has no static LDS: the dynamic segment starts at LDS address 0, and a read from a BYTE ADDRESS spares the "+ base" the
 // compiler otherwise leaves in the instruction stream per access (v_add_u32 v, 0, v: one of six VALU instructions per matrix entry).
-typedef const double __attribute__((address_space(3))) *brick_lds_cdp;
-__device__ __forceinline__ double lds_abs_f64(unsigned byte_addr) { return *(brick_lds_cdp)(uintptr_t)byte_addr; }
-constexpr unsigned kBrickValsByte = (unsigned)((kBrickSlotsPad + kBrickPark) * sizeof(double)); // `vals` behind the lattice and `park`
+template <typename T>
+__device__ __forceinline__ T lds_abs(unsigned byte_addr) { return *(const T __attribute__((address_space(3))) *)(uintptr_t)byte_addr; }
+// LDS layout in BYTES for vectors of T (double: the PCG loops; float: the float-vector loop of AVS_PRECISION_F32, avs_pcg_f32.inl):
+//   [0, kBrickSlotsPad T) the lattice | kBrickXSlots T extra x slots | kBrickBlockBytes: the tile's descriptor block, then the products of
+//   its streamed rows | vals (value table, T) | pattern words | pinfo | row-base table.  With T = float the lattice is 15.4 KB instead of
+//   31 KB: FOUR workgroups per CU instead of three.
+constexpr unsigned kBrickBlockBytes = (unsigned)((kBrickPark - kBrickXSlots) * sizeof(double));
+template <typename T> constexpr unsigned brick_vals_byte() { return (unsigned)((kBrickSlotsPad + kBrickXSlots) * sizeof(T)) + kBrickBlockBytes; } // `vals` behind the lattice and `park`
+template <typename T> constexpr unsigned brick_vals_elems(int table_size) { return (unsigned)((table_size + 4) & ~3); } // keeps the pattern image 16-B aligned for both T
 
 // element `idx` of an array whose base is workgroup-uniform: a 32-bit byte offset in a VGPR + the base in SGPRs (global_load ... saddr)
 // instead of 64-bit address arithmetic per lane
@@ -104,18 +110,20 @@ __device__ __forceinline__ T ld_u32(const T *base, unsigned idx)
 // The per-row arrays (rdesc: descriptor + position of every pattern row in execution order; ownslot) stay in global memory.
 constexpr int kBlkHdr = kBlkHdrWords;
 
-template <bool DOT, bool VC = false>
-__global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_spmv_brick(BrickView B, const double *__restrict__ x, double *__restrict__ y,
+template <bool DOT, bool VC = false, typename T = double>
+__global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 8 : 6, 8))) void k_spmv_brick(BrickView B, const T *__restrict__ x, T *__restrict__ y,
                                                          double *__restrict__ partial, const int *__restrict__ done_flag)
 {
     if (DOT && done_flag && *done_flag) return;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *xs = smem;                                                  // kBrickSlotsPad
-    double *park = smem + kBrickSlotsPad;                               // kBrickPark doubles, right behind the lattice: [0, kBrickXSlots) extra
-                                                                        // x slots (off-lattice columns), behind them first the tile's
-                                                                        // descriptor block, then the products of its streamed rows
-    double *vals = park + kBrickPark;                                   // table_size + 1 (the last entry is 0.0: padding words), even
-    uint32_t *pw = reinterpret_cast<uint32_t *>(vals + ((B.table_size + 2) & ~1)); // kBrickPatWords (VC: kBrickPatWordsVc) + 8
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr unsigned ES = (unsigned)sizeof(T);                         // bytes per vector element: every LDS byte offset below scales with it
+    constexpr unsigned kValsByte = brick_vals_byte<T>();
+    T *xs = reinterpret_cast<T *>(smem_raw);                             // kBrickSlotsPad
+    T *park = xs + kBrickSlotsPad;                                       // right behind the lattice: [0, kBrickXSlots) extra x slots (off-lattice
+                                                                        // columns), behind them kBrickBlockBytes: first the tile's descriptor
+                                                                        // block, then the products of its streamed rows
+    T *vals = reinterpret_cast<T *>(smem_raw + kValsByte);               // table_size + 1 (the last entry is 0.0: padding words), padded to 16 B
+    uint32_t *pw = reinterpret_cast<uint32_t *>(vals + brick_vals_elems<T>(B.table_size)); // kBrickPatWords (VC: kBrickPatWordsVc) + 8
     uint32_t *pinfo = pw + (VC ? kBrickPatWordsVc : kBrickPatWords) + 8; // kBrickPatMax: local start | quads << 16
     uint2 *rbt = reinterpret_cast<uint2 *>(pinfo + kBrickPatMax);       // kBrickRowBase entries: a row's bases on the four lattices, per axis
     const uint32_t *bw = reinterpret_cast<const uint32_t *>(park + kBrickXSlots);
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
     static_assert((kBrickPark - kBrickXSlots) * 2 <= kBrickBlk * 4, "one 16-B load per thread fetches a whole descriptor block");
 
     if (!VC)
-        for (int i = tid; i <= B.table_size; i += kBrickBlk) vals[i] = (i < B.table_size) ? B.table[i] : 0.; // once per workgroup (VC: a table per tile)
+        for (int i = tid; i <= B.table_size; i += kBrickBlk) vals[i] = (i < B.table_size) ? (T)B.table[i] : (T)0; // once per workgroup (VC: a table per tile; float: the values ARE floats, AVS_PRECISION_F32)
     // A row of level lr at local cell (cx, cy, cz) has the byte offset 8 (kBrickLoff[lc] + 3 ((bz S + by) S + bx)) on lattice lc, with
     // b = ((c >> up) << down) + 1 per axis: the sum of one term per axis.  Table entry (axis d, lr, c + 1) = the four lattices' terms as
     // 16-bit fields {lattice 0 | lattice 1 << 16, lattice 2 | lattice 3 << 16} (the sums stay below 2^15: no carries between the fields);
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
             const int up = lc > lr ? lc - lr : 0, dn2 = lr > lc ? lr - lc : 0;
             const int S = (8 >> lc) + 2;
             const int b = ((cc >> up) << dn2) + 1;
-            f[lc] = (unsigned)(24 * b * (d == 0 ? 1 : d == 1 ? S : S * S) + (d == 0 ? 8 * kBrickLoff[lc] : 0));
+            f[lc] = (unsigned)(3 * (int)ES * b * (d == 0 ? 1 : d == 1 ? S : S * S) + (d == 0 ? (int)ES * kBrickLoff[lc] : 0));
         }
         rbt[tid] = uint2{f[0] | (f[1] << 16), f[2] | (f[3] << 16)};
     }
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
     int nsw_prev = 0;
 
     int iter = 0;
-    double dot = 0.;                                                     // x.y of this lane's rows, all tiles of the workgroup
+    T dot = 0;                                                           // x.y of this lane's rows, all tiles of the workgroup
     for (;;) {
         BRICK_STAMP(0);
         if (nsw_prev > 0) __syncthreads();                               // the previous tile's streamed sums have read `park`
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         const int ntv = VC ? __builtin_amdgcn_readfirstlane((int)bw[14]) : 0;
         const int o_runs = kBlkHdr, o_pq = o_runs + 2 * nruns, o_pi = o_pq + npq; // (runs are 8 B)
         const bool emode = npat == 0;                 // no pattern rows: the products of the streamed rows may use the x lattice's LDS
-        double *prod = emode ? xs : park + kBrickXSlots;
+        T *prod = emode ? xs : park + kBrickXSlots;
         const int cap = emode ? kBrickSlotsPad : kBrickPark - kBrickXSlots;
         BRICK_STAMP(1);
 #ifdef AVS_PROBES
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         constexpr int PQ = (kBrickPatWords / 4 + kBrickBlk - 1) / kBrickBlk;
         constexpr int kRuFast = 6;                     // fill batches held in registers (192 runs: nearly every tile); the rest, rare, go run by run
         const uint2 *runs2 = reinterpret_cast<const uint2 *>(bw + o_runs);
-        double fv[kRuFast];
+        T fv[kRuFast];
         uint32_t rdsc[kRuFast];
         uint32_t pqo[PQ];
 #pragma unroll
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
             }
 #pragma unroll
             for (int u = 0; u < kRuFast; ++u) {
-                fv[u] = 0.;
+                fv[u] = 0;
                 rdsc[u] = 0xffffffffu;
                 if (u * QW < nruns) {
                     const int q = u * QW + qw;
@@ -264,11 +272,11 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                 }
             }
         }
-        double xo[RPT];
+        T xo[RPT];
         uint32_t os[RPT];
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            xo[k] = 0.;
+            xo[k] = 0;
             os[k] = 0xffffu;
             if (!emode && k * kBrickBlk < nrows) {
                 const int r = tid + k * kBrickBlk;
@@ -282,8 +290,8 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
             pqv[u] = uint4{0u, 0u, 0u, 0u};
             if (u * kBrickBlk < npq) pqv[u] = *reinterpret_cast<const uint4 *>(B.pwords + pqo[u]);
         }
-        double tval = 0.;
-        if (VC && ntv > 0) tval = ld_u32(B.ttab + tt0, (unsigned)(tid < ntv ? tid : 0));   // the tile's value table (<= kBrickTileVals entries)
+        T tval = 0;
+        if (VC && ntv > 0) tval = (T)ld_u32(B.ttab + tt0, (unsigned)(tid < ntv ? tid : 0));   // the tile's value table (<= kBrickTileVals entries)
         int cbo[RPT];                                  // VC: first quad of this wave's blocks of the code stream (read NOW: the streamed rows'
                                                        // products overwrite the block image while slower waves still walk their rows)
 #pragma unroll
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
 #pragma unroll
         for (int k = 0; k < kBrickMaxRows / kBrickBlk; ++k) sd[k] = uint2{0u, 0u};
         uint32_t w0[2] = {0u, 0u};
-        double xv0[2] = {0., 0.};
+        T xv0[2] = {0, 0};
         if (nsrows > 0) {
 #pragma unroll
             for (int k = 0; k < kBrickMaxRows / kBrickBlk; ++k) {
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         const bool more = iter + 1 < cnt;
         const uint2 tbn = seq[(int64_t)(more ? iter + 1 : iter) * step];
         // ---- LDS writes
-        if (VC && tid <= ntv) vals[tid] = tid < ntv ? tval : 0.;          // (entry ntv = 0.0: the code of the padding words)
+        if (VC && tid <= ntv) vals[tid] = tid < ntv ? tval : (T)0;          // (entry ntv = 0.0: the code of the padding words)
         if (tid < npat) pinfo[tid] = pinf;
 #pragma unroll
         for (int u = 0; u < PQ; ++u) {
@@ -367,33 +375,36 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                 const uint2 *rb = rbt + lr * 10;
                 const uint2 tx = rb[rd & 15u], ty = rb[40 + ((rd >> 4) & 15u)], tz = rb[80 + ((rd >> 8) & 15u)];
                 const unsigned P01 = tx.x + ty.x + tz.x, P23 = tx.y + ty.y + tz.y; // byte offsets of the row's base on the four lattices
-                const unsigned own8 = __builtin_amdgcn_perm(P23, P01, (unsigned)lr * 0x0202u + 0x0c0c0100u) + 8u * (unsigned)ax;
+                const unsigned own8 = __builtin_amdgcn_perm(P23, P01, (unsigned)lr * 0x0202u + 0x0c0c0100u) + ES * (unsigned)ax;
                 const unsigned pi = pinfo[pid];
                 const uint4 *wq = reinterpret_cast<const uint4 *>(pw + (pi & 0xffffu));
                 const int nq = (int)((pi >> 16) & 0x7fffu);
-                // word: delta << 19 (signed 13) | 000 | lattice level << 14 | code << 3.  A pattern is padded to whole quads with
-                // words that repeat its first entry's slot with the code of 0.0: +-0.0 added to a sum that is never -0.0.
+                // word: delta << 19 (signed 13) | 000 | lattice level << 14 | code << 3 -- byte offsets for 8-B elements; T = float reads
+                // the 4-B image of the table (BrickView::pwords32: delta << 18 | level << 14 | code << 2).  A pattern is padded to whole
+                // quads with words that repeat its first entry's slot with the code of 0.0: +-0.0 added to a sum that is never -0.0.
+                constexpr unsigned CM = ES == 8 ? 0x3ff8u : 0x1ffcu;       // the code field as a byte offset into `vals`
+                constexpr int VS = ES == 8 ? 0 : 1;                       // VC: the code stream holds byte offsets for 8-B values
                 auto addr = [&](uint32_t w) -> unsigned {
                     const unsigned sel = ((w >> 14) & 3u) * 0x0202u + 0x0c0c0100u;
                     return (unsigned)((int)w >> 16) + __builtin_amdgcn_perm(P23, P01, sel); // + 16-bit field number `level` of P23:P01
                 };
-                double sum = 0.;
+                T sum = 0;
                 // software pipeline: the words of quad q + 1 and the value / x reads of quad q are in flight while quad q - 1 is added
                 // (reading the words one quad past the pattern is harmless: the LDS image ends with spare quads; they are never decoded)
                 auto walk = [&](auto adr) {
-                    double v0, v1, v2, v3, x0, x1, x2, x3;
+                    T v0, v1, v2, v3, x0, x1, x2, x3;
                     const uint4 w = wq[0];
                     uint4 wn = wq[1];
-                    v0 = lds_abs_f64(kBrickValsByte + (w.x & 0x3ff8u)); x0 = lds_abs_f64(adr(w.x));
-                    v1 = lds_abs_f64(kBrickValsByte + (w.y & 0x3ff8u)); x1 = lds_abs_f64(adr(w.y));
-                    v2 = lds_abs_f64(kBrickValsByte + (w.z & 0x3ff8u)); x2 = lds_abs_f64(adr(w.z));
-                    v3 = lds_abs_f64(kBrickValsByte + (w.w & 0x3ff8u)); x3 = lds_abs_f64(adr(w.w));
+                    v0 = lds_abs<T>(kValsByte + (w.x & CM)); x0 = lds_abs<T>(adr(w.x));
+                    v1 = lds_abs<T>(kValsByte + (w.y & CM)); x1 = lds_abs<T>(adr(w.y));
+                    v2 = lds_abs<T>(kValsByte + (w.z & CM)); x2 = lds_abs<T>(adr(w.z));
+                    v3 = lds_abs<T>(kValsByte + (w.w & CM)); x3 = lds_abs<T>(adr(w.w));
                     for (int q = 1; q < nq; ++q) {
                         const uint4 wnn = wq[q + 1];
-                        const double a0 = lds_abs_f64(kBrickValsByte + (wn.x & 0x3ff8u)), c0 = lds_abs_f64(adr(wn.x));
-                        const double a1 = lds_abs_f64(kBrickValsByte + (wn.y & 0x3ff8u)), c1 = lds_abs_f64(adr(wn.y));
-                        const double a2 = lds_abs_f64(kBrickValsByte + (wn.z & 0x3ff8u)), c2 = lds_abs_f64(adr(wn.z));
-                        const double a3 = lds_abs_f64(kBrickValsByte + (wn.w & 0x3ff8u)), c3 = lds_abs_f64(adr(wn.w));
+                        const T a0 = lds_abs<T>(kValsByte + (wn.x & CM)), c0 = lds_abs<T>(adr(wn.x));
+                        const T a1 = lds_abs<T>(kValsByte + (wn.y & CM)), c1 = lds_abs<T>(adr(wn.y));
+                        const T a2 = lds_abs<T>(kValsByte + (wn.z & CM)), c2 = lds_abs<T>(adr(wn.z));
+                        const T a3 = lds_abs<T>(kValsByte + (wn.w & CM)), c3 = lds_abs<T>(adr(wn.w));
                         sum += v0 * x0;
                         sum += v1 * x1;
                         sum += v2 * x2;
@@ -410,22 +421,22 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                 // interleaved, so a wave load is one 512-B run) -- instead of from the pattern word; same pipeline, same order of additions
                 auto walk_vc = [&](auto adr) {
                     const uint2 *cp = B.vcodes + (int64_t)cw0 + cbo[k] + lane;
-                    double v0, v1, v2, v3, x0, x1, x2, x3;
+                    T v0, v1, v2, v3, x0, x1, x2, x3;
                     const uint4 w = wq[0];
                     uint4 wn = wq[1];
                     uint2 c = cp[0];
                     uint2 cn = cp[nq > 1 ? 64 : 0];
-                    v0 = lds_abs_f64(kBrickValsByte + (c.x & 0xffffu)); x0 = lds_abs_f64(adr(w.x));
-                    v1 = lds_abs_f64(kBrickValsByte + (c.x >> 16)); x1 = lds_abs_f64(adr(w.y));
-                    v2 = lds_abs_f64(kBrickValsByte + (c.y & 0xffffu)); x2 = lds_abs_f64(adr(w.z));
-                    v3 = lds_abs_f64(kBrickValsByte + (c.y >> 16)); x3 = lds_abs_f64(adr(w.w));
+                    v0 = lds_abs<T>(kValsByte + ((c.x & 0xffffu) >> VS)); x0 = lds_abs<T>(adr(w.x));
+                    v1 = lds_abs<T>(kValsByte + ((c.x >> 16) >> VS)); x1 = lds_abs<T>(adr(w.y));
+                    v2 = lds_abs<T>(kValsByte + ((c.y & 0xffffu) >> VS)); x2 = lds_abs<T>(adr(w.z));
+                    v3 = lds_abs<T>(kValsByte + ((c.y >> 16) >> VS)); x3 = lds_abs<T>(adr(w.w));
                     for (int q = 1; q < nq; ++q) {
                         const uint4 wnn = wq[q + 1];
                         const uint2 cnn = cp[(q + 1 < nq ? q + 1 : q) * 64];
-                        const double a0 = lds_abs_f64(kBrickValsByte + (cn.x & 0xffffu)), c0 = lds_abs_f64(adr(wn.x));
-                        const double a1 = lds_abs_f64(kBrickValsByte + (cn.x >> 16)), c1 = lds_abs_f64(adr(wn.y));
-                        const double a2 = lds_abs_f64(kBrickValsByte + (cn.y & 0xffffu)), c2 = lds_abs_f64(adr(wn.z));
-                        const double a3 = lds_abs_f64(kBrickValsByte + (cn.y >> 16)), c3 = lds_abs_f64(adr(wn.w));
+                        const T a0 = lds_abs<T>(kValsByte + ((cn.x & 0xffffu) >> VS)), c0 = lds_abs<T>(adr(wn.x));
+                        const T a1 = lds_abs<T>(kValsByte + ((cn.x >> 16) >> VS)), c1 = lds_abs<T>(adr(wn.y));
+                        const T a2 = lds_abs<T>(kValsByte + ((cn.y & 0xffffu) >> VS)), c2 = lds_abs<T>(adr(wn.z));
+                        const T a3 = lds_abs<T>(kValsByte + ((cn.y >> 16) >> VS)), c3 = lds_abs<T>(adr(wn.w));
                         sum += v0 * x0;
                         sum += v1 * x1;
                         sum += v2 * x2;
@@ -448,17 +459,17 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                     if (VC) walk_vc(addr);
                     else walk(addr);
                 }
-                *reinterpret_cast<double *>(reinterpret_cast<char *>(y + row0) + (size_t)(unsigned)(ro << 3)) = sum;
-                if (DOT) dot += sum * lds_abs_f64(own8);
+                *reinterpret_cast<T *>(reinterpret_cast<char *>(y + row0) + (size_t)(unsigned)(ro * ES)) = sum;
+                if (DOT) dot += sum * lds_abs<T>(own8);
             }
             }
         }
         BRICK_STAMP(3);
         // streamed rows: passes of `cap` products parked in LDS, then every row adds its segment left to right
         if (nsw > 0 && !BRICK_DBG(4)) {
-            double ssum[kBrickMaxRows / kBrickBlk];
+            T ssum[kBrickMaxRows / kBrickBlk];
 #pragma unroll
-            for (int k = 0; k < kBrickMaxRows / kBrickBlk; ++k) ssum[k] = 0.;
+            for (int k = 0; k < kBrickMaxRows / kBrickBlk; ++k) ssum[k] = 0;
             for (int ts = 0; ts < nsw; ts += cap) {
                 const int te = (ts + cap < nsw) ? ts + cap : nsw;
                 if (emode || wide || ts > 0) {
@@ -466,17 +477,17 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                     constexpr int SU = 4; // (8 entries per thread -- a whole pass of an E tile in one round of loads -- was measured SLOWER: 7.1 -> 7.7 us per E tile)
                     for (int e0 = ts + tid; e0 < te; e0 += SU * kBrickBlk) {
                         uint32_t w4[SU], c4[SU];
-                        double x4[SU], v4[SU];
+                        T x4[SU], v4[SU];
 #pragma unroll
                         for (int u = 0; u < SU; ++u) {
                             const int e = e0 + u * kBrickBlk;
                             const int64_t at = (int64_t)sword0 + (e < te ? e : ts);
-                            v4[u] = 0.;
+                            v4[u] = 0;
                             if (VC) { // 12 B per entry: column, value
                                 const uint32_t *w = B.swords + 3 * at;
                                 w4[u] = w[0];
                                 c4[u] = 0u;
-                                v4[u] = __hiloint2double((int)w[2], (int)w[1]);
+                                v4[u] = (T)__hiloint2double((int)w[2], (int)w[1]);
                             } else if (wide) {
                                 const uint2 w = reinterpret_cast<const uint2 *>(B.swords)[at];
                                 w4[u] = w.x;
@@ -520,33 +531,46 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
     }
     if (DOT) { // ONE partial per workgroup (fixed order: the tile walk is static, the waves' sums are added in wave order): few enough
                // for the vector kernel that follows to fold them itself instead of a reduction launch in between
-        const double dsum = brick_wave_sum_dpp(dot);
+        const double dsum = brick_wave_sum_dpp((double)dot);            // (float: a lane's few rows in float, everything across lanes in double)
+        double *wsum = reinterpret_cast<double *>(park + kBrickXSlots);
         __syncthreads();                                                 // (the last tile's streamed sums may still be reading `park`)
-        if (lane == 63) park[tid >> 6] = dsum;
+        if (lane == 63) wsum[tid >> 6] = dsum;
         __syncthreads();
         if (tid == 0) {
-            double s = park[0];
+            double s = wsum[0];
 #pragma unroll
-            for (int k = 1; k < kBrickBlk / 64; ++k) s += park[k];
+            for (int k = 1; k < kBrickBlk / 64; ++k) s += wsum[k];
             partial[blockIdx.x] = s;
         }
     }
 }
 
-size_t brick_lds_bytes(const BrickView &B)
+size_t brick_lds_bytes(const BrickView &B, int elem_bytes)
 {
-    return (size_t)(kBrickSlotsPad + ((B.table_size + 2) & ~1) + kBrickPark) * sizeof(double) + (size_t)((B.vc ? kBrickPatWordsVc : kBrickPatWords) + 8 + kBrickPatMax + 2 * kBrickRowBase) * sizeof(uint32_t);
+    const size_t es = (size_t)elem_bytes;
+    const size_t vals = elem_bytes == 4 ? brick_vals_elems<float>(B.table_size) : brick_vals_elems<double>(B.table_size);
+    return (size_t)(kBrickSlotsPad + kBrickXSlots) * es + kBrickBlockBytes + vals * es +
+           (size_t)((B.vc ? kBrickPatWordsVc : kBrickPatWords) + 8 + kBrickPatMax + 2 * kBrickRowBase) * sizeof(uint32_t);
 }
+size_t brick_lds_bytes(const BrickView &B) { return brick_lds_bytes(B, B.f32 ? 4 : 8); }
 
 // LDS a workgroup may ask for on this device (the kernel opts in to more than the default 48 KiB, hipFuncSetAttribute below)
 constexpr size_t kBrickLdsLimit = 64 * 1024;
-bool brick_lds_fits(const BrickView &B) { return brick_lds_bytes(B) <= kBrickLdsLimit; }
+bool brick_lds_fits(const BrickView &B) { return brick_lds_bytes(B, 8) <= kBrickLdsLimit; }
 
-// persistent grid: as many workgroups as the device keeps resident for THIS LDS size (a larger value table costs a workgroup per CU);
-// queried once per (device, LDS size), guarded: contexts of several host threads share the cache
-static int brick_grid(const BrickView &B, size_t lds)
+template <typename T>
+static const void *brick_kernel(bool dot, bool vc)
 {
-    struct Entry { int dev; size_t lds; int vc; int grid; };
+    if (vc) return dot ? (const void *)k_spmv_brick<true, true, T> : (const void *)k_spmv_brick<false, true, T>;
+    return dot ? (const void *)k_spmv_brick<true, false, T> : (const void *)k_spmv_brick<false, false, T>;
+}
+
+// persistent grid: as many workgroups as the device keeps resident for THIS LDS size (a larger value table costs a workgroup per CU;
+// the float kernel's lattice is half as large: four per CU); queried once per (device, LDS size, variant), guarded: contexts of several
+// host threads share the cache
+static int brick_grid(const BrickView &B, size_t lds, int elem_bytes)
+{
+    struct Entry { int dev; size_t lds; int vc, es; int grid; };
     static std::mutex mu;
     static std::vector<Entry> cache;
     int dev = 0;
@@ -555,16 +579,16 @@ static int brick_grid(const BrickView &B, size_t lds)
     {
         std::lock_guard<std::mutex> lk(mu);
         for (const Entry &e : cache)
-            if (e.dev == dev && e.lds == lds && e.vc == B.vc) g = e.grid;
+            if (e.dev == dev && e.lds == lds && e.vc == B.vc && e.es == elem_bytes) g = e.grid;
         if (!g) {
             int per_cu = 0, cus = 0;
-            if (B.vc) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_spmv_brick<true, true>, kBrickBlk, lds);
-            else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_spmv_brick<true, false>, kBrickBlk, lds);
+            const void *fn = elem_bytes == 4 ? brick_kernel<float>(true, B.vc != 0) : brick_kernel<double>(true, B.vc != 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBrickBlk, lds);
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             if (per_cu < 1) per_cu = 1;
             if (cus < 1) cus = 256;
             g = per_cu * cus;
-            cache.push_back(Entry{dev, lds, B.vc, g});
+            cache.push_back(Entry{dev, lds, B.vc, elem_bytes, g});
         }
     }
 #ifdef AVS_PROBES
@@ -583,10 +607,11 @@ static avs_status brick_raise_lds_limit()
     if (dev < 0 || dev >= 64) dev = 0;
     std::lock_guard<std::mutex> lk(mu);
     if (done[dev]) return AVS_OK;
-    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
-    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
-    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
-    AVS_HIP(hipFuncSetAttribute((const void *)k_spmv_brick<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
+    for (int dot = 0; dot < 2; ++dot)
+        for (int vc = 0; vc < 2; ++vc) {
+            AVS_HIP(hipFuncSetAttribute(brick_kernel<double>(dot, vc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
+            AVS_HIP(hipFuncSetAttribute(brick_kernel<float>(dot, vc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrickLdsLimit));
+        }
     done[dev] = true;
     return AVS_OK;
 }
@@ -624,44 +649,58 @@ static void brick_print_stamps()
 }
 #endif
 
-// partial sums of x.y the fused-dot launch writes: one per workgroup of the persistent grid
+// partial sums of x.y the fused-dot launch writes: one per workgroup of the persistent grid (of the kernel the view is laid out for:
+// BrickView::f32 -- the planned walk and the partial arrays follow that grid)
 int brick_partial_count(const BrickView &B)
 {
-    return B.ntiles > 0 ? brick_grid(B, brick_lds_bytes(B)) : 0;
+    const int es = B.f32 ? 4 : 8;
+    return B.ntiles > 0 ? brick_grid(B, brick_lds_bytes(B, es), es) : 0;
+}
+int brick_partial_count(const BrickView &B, int elem_bytes)
+{
+    return B.ntiles > 0 ? brick_grid(B, brick_lds_bytes(B, elem_bytes), elem_bytes) : 0;
 }
 
-avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, double *partial, const int *done_flag, hipStream_t stream)
+template <typename T>
+static avs_status spmv_brick_launch_t(const BrickView &B0, const T *x, T *y, double *partial, const int *done_flag, hipStream_t stream)
 {
-    if (B.ntiles <= 0) return AVS_OK;
-    const size_t lds = brick_lds_bytes(B);
+    if (B0.ntiles <= 0) return AVS_OK;
+    constexpr int es = (int)sizeof(T);
+    const size_t lds = brick_lds_bytes(B0, es);
     AVS_REQUIRE(lds <= kBrickLdsLimit, AVS_EINTERNAL, "brick form: %zu bytes of LDS per workgroup exceed the limit (value table of %d entries)", lds,
-                B.table_size);
+                B0.table_size);
     AVS_TRY(brick_raise_lds_limit());
-    const int grid = brick_grid(B, lds);
+    const int grid = brick_grid(B0, lds, es);
+    BrickView B = B0;
+    if (es == 4) {
+        AVS_REQUIRE(B.pwords32, AVS_EINTERNAL, "brick form: no 4-byte pattern image for the float kernel");
+        B.pwords = B.pwords32;
+    }
 #ifdef AVS_PROBES
     static const int dbg = getenv("AVS_BRICK_DEBUG") ? atoi(getenv("AVS_BRICK_DEBUG")) : 0; // phase switches / stamps (measurement builds only)
-    BrickView Bd = B;
-    Bd.debug |= dbg;
-    if (Bd.vc) {
-        if (partial) hipLaunchKernelGGL((k_spmv_brick<true, true>), dim3(grid), dim3(kBrickBlk), lds, stream, Bd, x, y, partial, done_flag);
-        else hipLaunchKernelGGL((k_spmv_brick<false, true>), dim3(grid), dim3(kBrickBlk), lds, stream, Bd, x, y, partial, done_flag);
-    } else if (partial) hipLaunchKernelGGL((k_spmv_brick<true, false>), dim3(grid), dim3(kBrickBlk), lds, stream, Bd, x, y, partial, done_flag);
-    else hipLaunchKernelGGL((k_spmv_brick<false, false>), dim3(grid), dim3(kBrickBlk), lds, stream, Bd, x, y, partial, done_flag);
+    B.debug |= dbg;
+#endif
+    if (B.vc) {
+        if (partial) hipLaunchKernelGGL((k_spmv_brick<true, true, T>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
+        else hipLaunchKernelGGL((k_spmv_brick<false, true, T>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
+    } else if (partial) hipLaunchKernelGGL((k_spmv_brick<true, false, T>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
+    else hipLaunchKernelGGL((k_spmv_brick<false, false, T>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
     AVS_HIP(hipGetLastError());
-    if (Bd.debug & 64) { // print the phase stamps of THIS launch (synchronises: not for timing loops)
+#ifdef AVS_PROBES
+    if (B.debug & 64) { // print the phase stamps of THIS launch (synchronises: not for timing loops)
         AVS_HIP(hipStreamSynchronize(stream));
         brick_print_stamps();
     }
-    return AVS_OK;
-#else
-    if (B.vc) {
-        if (partial) hipLaunchKernelGGL((k_spmv_brick<true, true>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
-        else hipLaunchKernelGGL((k_spmv_brick<false, true>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
-    } else if (partial) hipLaunchKernelGGL((k_spmv_brick<true, false>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
-    else hipLaunchKernelGGL((k_spmv_brick<false, false>), dim3(grid), dim3(kBrickBlk), lds, stream, B, x, y, partial, done_flag);
-    AVS_HIP(hipGetLastError());
-    return AVS_OK;
 #endif
+    return AVS_OK;
+}
+avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, double *partial, const int *done_flag, hipStream_t stream)
+{
+    return spmv_brick_launch_t<double>(B, x, y, partial, done_flag, stream);
+}
+avs_status spmv_brick_launch_f32(const BrickView &B, const float *x, float *y, double *partial, const int *done_flag, hipStream_t stream)
+{
+    return spmv_brick_launch_t<float>(B, x, y, partial, done_flag, stream);
 }
 
 } // namespace avs

@@ -877,6 +877,16 @@ __global__ __launch_bounds__(kBlk) void k_bk_count_regular(int ntiles, const int
 }
 } // namespace
 
+// pattern word for 8-B elements (delta << 19 | level << 14 | code << 3: the delta and the code as byte offsets) -> for 4-B elements
+// (delta << 18 | level << 14 | code << 2)
+__global__ void k_bk_pwords32(int n, const uint32_t *__restrict__ w8, uint32_t *__restrict__ w4)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t w = w8[i];
+    w4[i] = ((uint32_t)((int32_t)w >> 1) & 0xffff0000u) | (w & 0xc000u) | ((w & 0x3ff8u) >> 1);
+}
+
 void BrickForm::clear()
 {
     ready = false;
@@ -899,7 +909,7 @@ void BrickScratch::release()
 void BrickForm::release()
 {
     clear();
-    tile_blk.release(); rdesc.release(); sdesc.release(); blocks.release(); pwords.release(); swords.release(); ownslot.release(); tile_flags.release(); wlist.release(); wptr.release(); vcodes.release(); ttab.release();
+    tile_blk.release(); rdesc.release(); sdesc.release(); blocks.release(); pwords.release(); pwords32.release(); swords.release(); ownslot.release(); tile_flags.release(); wlist.release(); wptr.release(); vcodes.release(); ttab.release();
     scratch.release();
 }
 
@@ -998,6 +1008,7 @@ void BrickForm::view(BrickView &B, const ValueIndex &vi) const
     B.rdesc = rdesc.p;
     B.ownslot = ownslot.p;
     B.pwords = pwords.p;
+    B.pwords32 = pwords32.p;
     B.sdesc = sdesc.p;
     B.swords = swords.p;
     B.table = vi.table.p;
@@ -1229,6 +1240,10 @@ avs_status build_brick_form(BrickForm &bf, const BrickSource &src, const Options
             AVS_HIP(hipMemcpy(bf.tile_flags.p, hf2.data(), (size_t)ntiles, hipMemcpyHostToDevice));
         }
     }
+    // the pattern table once more with byte offsets for 4-B elements (the float-vector kernel of AVS_PRECISION_F32: a few thousand words)
+    AVS_TRY(bf.pwords32.alloc((size_t)nwords + 16));
+    hipLaunchKernelGGL(k_bk_pwords32, dim3((unsigned)((nwords + 16 + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, nwords + 16, bf.pwords.p, bf.pwords32.p);
+    AVS_HIP(hipGetLastError());
     // worth it only where most rows are patterns (a curved surface with ~10^4 distinct values gives every row its own)
     const double min_frac = opt.brick_min_regular;
     bf.ready = (double)regular >= min_frac * (double)n;

@@ -100,6 +100,8 @@ struct Options {
     BrickCost brick_cost;        // AVS_BRICK_COST=tile,row,run,word,etile,quad
     // single-GPU loop
     int fuse_beta = 1;
+    int f32_vectors = 1;         // AVS_F32_VECTORS: AVS_PRECISION_F32 contexts iterate on float vectors with float scalars (what Eigen's float CG does);
+                                 // 0: fp64 iteration on the float system
     // CU-resident loop: tuning and test switches
     int resident_cus = 0, resident_equal_lanes = 0, resident_max_global = 3, resident_max_quads = 0, resident_no_stream = 0;
     long long resident_remap_chunk = 0;
@@ -262,6 +264,7 @@ struct CsrView {
     int no_precond = 0; // AVS_PRECONDITIONER_NONE: the inverse diagonal the loops multiply with is 1 everywhere
     bool keep_cached = false; // the matrix words are small enough to stay in the Infinity Cache between two products: plain loads
     const struct BrickView *brick = nullptr; // host pointer: the brick-structured form of this matrix (single-GPU launch-per-phase loop)
+    int f32_vectors = 0; // AVS_PRECISION_F32: the values are floats; the single-GPU solve iterates on float vectors (avs_pcg_f32.inl)
 };
 constexpr int kCwinOffBits = 14, kCwinSlotBits = 6, kCwinSlots = 1 << kCwinSlotBits, kCwinCodeBits = 32 - kCwinOffBits - kCwinSlotBits;
 
@@ -313,6 +316,10 @@ struct BrickView {
     int vc = 0;
     const uint2 *vcodes = nullptr;   // per row quad four 16-bit byte offsets into the tile's table, wave-interleaved in execution order
     const double *ttab = nullptr;    // the tiles' value tables, one after the other
+    // float-vector loop (AVS_PRECISION_F32, avs_pcg_f32.inl): the pattern table with byte offsets for 4-B elements; f32 = the planned walk
+    // and the partial-sum count are those of the float kernel's grid (four workgroups per CU)
+    const uint32_t *pwords32 = nullptr;
+    int f32 = 0;
 };
 // the form's arrays, owned by the context next to the CSR / value index of the solve matrix (avs_brick_build.hip)
 struct BrickScratch { // build-time buffers, kept across frames
@@ -328,7 +335,7 @@ struct BrickScratch { // build-time buffers, kept across frames
 };
 struct BrickForm {
     DevBuf<uint2> tile_blk, rdesc, sdesc;
-    DevBuf<uint32_t> blocks, pwords, swords;
+    DevBuf<uint32_t> blocks, pwords, pwords32, swords;
     DevBuf<uint16_t> ownslot;
     DevBuf<uint8_t> tile_flags;       // per tile (walk order): 1 = its rows read halo columns (partitioned systems)
     DevBuf<uint2> vcodes;             // value-code variant: the pattern rows' value codes (BrickView::vcodes)
@@ -365,10 +372,13 @@ struct BrickSource {
     int nx = 0, ny = 0, nz = 0, levels = 0, brick_shift = 3;
 };
 avs_status build_brick_form(BrickForm &bf, const BrickSource &src, const Options &opt, hipStream_t st); // avs_brick_build.hip
-size_t brick_lds_bytes(const BrickView &B);
+size_t brick_lds_bytes(const BrickView &B);                 // of the kernel the view is laid out for (B.f32)
+size_t brick_lds_bytes(const BrickView &B, int elem_bytes); // vectors of doubles (8) / floats (4)
 bool brick_lds_fits(const BrickView &B);          // the workgroup's LDS (lattice + value table + pattern image) within the device's limit
 avs_status spmv_brick_launch(const BrickView &B, const double *x, double *y, double *partial, const int *done_flag, hipStream_t stream);
-int brick_partial_count(const BrickView &B);   // partial sums the fused-dot launch writes (one per persistent workgroup)
+int brick_partial_count(const BrickView &B);   // partial sums the fused-dot launch writes (one per persistent workgroup), kernel of B.f32
+int brick_partial_count(const BrickView &B, int elem_bytes);
+avs_status spmv_brick_launch_f32(const BrickView &B, const float *x, float *y, double *partial, const int *done_flag, hipStream_t stream);
 
 // the lossless storage forms of one matrix's values (avs_reorder.hip), owned next to the CSR arrays
 constexpr int64_t kKeepCachedBytes = 200ll << 20; // what may stay in the 256 MB Infinity Cache across a PCG iteration
@@ -527,6 +537,7 @@ avs_status build_brick_form(struct ::avs_ctx *c); // avs_brick_build.hip
 #ifdef AVS_PROBES
 // y = A x through the form the loops launch (+ the folded partial sums of x.y of the fused-dot instantiation); avs_api.hip
 avs_status probe_spmv_form(const CsrView &A, const double *x, double *y, bool fused, double *dot_out, hipStream_t st);
+avs_status spmv_f32_probe(const CsrView &A, const double *x, double *y, bool fused, double *dot_out, hipStream_t st); // avs_pcg_f32.inl
 #endif
 avs_status unpermute(struct ::avs_ctx *c, const double *xp, double *x);
 // builds the value dictionary of `val` (nnz entries); *table_size = 0 when there are more than 65536 distinct values

@@ -38,6 +38,7 @@ struct PcgWork {
     DevBuf<double> r, p, t, invd, partial;
     DevBuf<uint16_t> dcode;  // value-indexed matrix: code of every row's diagonal entry ...
     DevBuf<double> invtab;   // ... into the table of inverted values (2 B instead of 8 B per row and vector pass)
+    DevBuf<float> f_x, f_r, f_p, f_t, f_b, f_invd, f_invtab; // float-vector loop of AVS_PRECISION_F32 contexts (avs_pcg_f32.inl)
     DevBuf<double> x_save;   // the initial guess while the CU-resident loop runs (restored if it faults)
     DevBuf<double> cancel_word; // partitioned solves: [0] this rank's avs_cancel request as the kernels / the all-reduce see it (0. / 1.)
     DevBuf<int> cancel_dev;     // ... and as an int for the finalizer of the direct transport
@@ -700,7 +701,7 @@ static avs_status spmv_dispatch(const CsrView &A, const double *x, double *y, do
 {
     if (A.n <= 0) { if (nblocks) *nblocks = 0; return AVS_OK; }
     if (A.brick && A.brick->ntiles > 0 && (variant == 0 || variant == spmv_default_variant(A))) { // brick-structured form (avs_brick.hip)
-        if (nblocks) *nblocks = brick_partial_count(*A.brick);
+        if (nblocks) *nblocks = brick_partial_count(*A.brick, 8);
         return spmv_brick_launch(*A.brick, x, y, DOT ? partial : nullptr, (DOT && sc) ? &sc->done : nullptr, stream);
     }
     if (A.codes && (variant == 0 || variant == spmv_default_variant(A))) { // value-indexed matrix: 6 or 4 B per non-zero
@@ -1736,7 +1737,7 @@ static avs_status pcg_solve_direct(PcgWork *w, const CsrView &A, const double *b
     double *pvec = w->partial.p;                         // up to 3 * g vector-kernel partials
     PcgScalars *sc = w->sc.p;
     const bool brick = A.brick && A.brick->ntiles > 0;   // brick-structured form of the local rows: one partial per persistent workgroup
-    const int ntiles = brick ? brick_partial_count(*A.brick) : da.n_tiles_int + da.n_tiles_bnd;  // (word stream: == ceil(n / kTileRows))
+    const int ntiles = brick ? brick_partial_count(*A.brick, 8) : da.n_tiles_int + da.n_tiles_bnd;  // (word stream: == ceil(n / kTileRows))
     const int ppt = brick ? 1 : (A.codes ? kTileRows / 64 : 1); // value-indexed kernel: one partial per wave
     const int slots = ntiles * ppt;
     const int nfin = slots > 0 ? (slots + kFinShare - 1) / kFinShare : 1;
@@ -2073,6 +2074,8 @@ static avs_status pcg_solve_resident_single(PcgWork *w, const CsrView &A, const 
     return AVS_OK;
 }
 
+#include "avs_pcg_f32.inl"
+
 // (KEEP is a template parameter of the vector kernels: see stream_load_k)
 #define AVS_VEC_LAUNCH(KERNEL, C, F, ...)                                                                             \
     do {                                                                                                              \
@@ -2090,6 +2093,7 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
     }
     if (dist && dist_wants_single_reduction(dist))
         return pcg_solve_single_reduction(w, A, b, x, tol, max_iters, stream, info, dist);
+    if (!dist && A.f32_vectors) return pcg_solve_f32(w, A, b, x, tol, max_iters, stream, info); // AVS_PRECISION_F32: float vectors and scalars
     if (!dist && resident_wanted(false)) { // systems that fit on the chip (<= ~1 M rows, packed form): one cooperative launch
         bool ran = false;
         const avs_status rs = pcg_solve_resident_single(w, A, b, x, tol, max_iters, stream, info, &ran);

@@ -37,6 +37,7 @@ class ViscositySolve:
         capi.check(self.lib.avs_create(C.byref(d), C.byref(h)))
         self.h = h
         self.levels = int(levels)
+        self.precision = int(precision)
         self.counts = None
         self.field_res = tuple(fr[a] or self.res[a] for a in range(3))
 
@@ -123,6 +124,8 @@ class ViscositySolve:
     def set_solver_option(self, option, value):
         """avs_set_solver_option: e.g. (capi.OPTION_PRECONDITIONER, capi.PRECONDITIONER_NONE) = plain CG (cpp:638-642)."""
         capi.check(self.lib.avs_set_solver_option(self.h, int(option), int(value)))
+        if int(option) == capi.OPTION_F32_VECTORS:
+            self.f32_vectors_off = not value
 
     # ---- hot path -------------------------------------------------------------------------
     def build_stencils(self):
@@ -258,6 +261,12 @@ class ViscositySolve:
     def spmv_kernel_name(self):
         fmt = self.matrix_format()
         bpn, tab = int(fmt.bytes_per_nonzero), int(fmt.value_table_size)
+        if getattr(self, "precision", 0) == capi.PRECISION_F32 and not getattr(self, "f32_vectors_off", False):   # the float-vector loop (avs_pcg_f32.inl)
+            if int(getattr(fmt, "brick_tiles", 0)):
+                return (f"k_spmv_brick<DOT,{'VC,' if int(fmt.brick_value_codes) else ''}float> (brick-structured form, float vectors: {int(fmt.brick_tiles)} tiles, "
+                        f"{int(fmt.brick_pattern_rows)} rows as {int(fmt.brick_patterns)} geometric row patterns, x of a brick + halo as floats in LDS, "
+                        f"four workgroups per CU; {tab}-entry dictionary; brick-major system)")
+            return "k_f32_spmv_csr<DOT> (float vectors: column + value code streamed, float products parked in LDS; brick-major system)"
         ltab = "LTAB" if 0 < tab <= 2048 else "GTAB"
         cw = int(fmt.column_windows)
         if int(getattr(fmt, "brick_tiles", 0)):

@@ -62,6 +62,8 @@ def parse(argv=None):
                     help="scene-equivalent workload instead of --config: the reference's Scenes/viscousBeam.hip / viscousBuckling.hip "
                          "parameters on their non-power-of-two simulation grids (SURVEY.md section 6)")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_workloads (one timed solve each of the secondary workloads)")
+    ap.add_argument("--precision", choices=("f64", "f32"), default="f64",
+                    help="f32: the system and the iteration of the reference built with USESINGLEPRECISION (AVS_PRECISION_F32: float vectors)")
     ap.add_argument("--tol", type=float, default=1e-3)
     ap.add_argument("--max-iters", type=int, default=2500)
     ap.add_argument("--cpu-seconds", type=float, default=22.0, help="timed budget of the cpu_baseline leg (both variants together: >= 10 s steady state each)")
@@ -277,7 +279,7 @@ def resident_roofline(n, nnz, iterations, solve_ms):
                         "frac": (pmc or {}).get("wait_frac"), "pmc": pmc, "source": src}}
 
 
-def extra_workload(label, sc, local_rank, tol, max_iters):
+def extra_workload(label, sc, local_rank, tol, max_iters, precision=0):
     """One secondary workload through the same product path: pre-pass, assembly (second pass timed), one warm-up solve and two timed
     solves; the numbers the judge otherwise only sees in builder-run lines (round-2 review, weak #5)."""
     import torch
@@ -286,7 +288,7 @@ def extra_workload(label, sc, local_rank, tol, max_iters):
     pp = DevicePrepass(sc.res, sc.dx, sc.levels, device=local_rank, field_res=sc.field_res)
     pp.run(fsc.liquid, fsc.solid)            # first pass: allocations and first touch of the pyramids (seconds at 1024^3)
     pinfo = pp.run(fsc.liquid, fsc.solid)    # the timed pass: what every later frame pays
-    s = ViscositySolve(sc.res, sc.dx, sc.dt, pinfo.levels, device=local_rank, field_res=sc.field_res)
+    s = ViscositySolve(sc.res, sc.dx, sc.dt, pinfo.levels, device=local_rank, field_res=sc.field_res, precision=precision)
     pp.apply(s)
     s.set_scene_fields(fsc)
     pp.close()
@@ -313,7 +315,7 @@ def extra_workload(label, sc, local_rank, tol, max_iters):
     inm = s.solve(tol, max_iters)
     torch.cuda.synchronize()
     new_matrix_solve_ms = (time.perf_counter() - t0) * 1e3
-    rec = {"workload": label, "n_dofs": int(ai.n_velocity), "nnz": int(ai.nnz), "levels": int(pinfo.levels),
+    rec = {"workload": label, "dtype": "f32" if precision else "f64", "n_dofs": int(ai.n_velocity), "nnz": int(ai.nnz), "levels": int(pinfo.levels),
            "cg_iterations_per_step": iters // 2, "converged": int(all(i.converged for i in infos)),
            "resident_loop": bool(infos[0].resident),   # CU-resident PCG (one cooperative launch; no separate SpMV launch to time)
            "value": iters / el, "unit": "iter/s", "ms_per_step": el / 2 * 1e3, "first_solve_ms": first_solve_ms, "new_matrix_solve_ms": new_matrix_solve_ms,
@@ -447,7 +449,9 @@ def main():
     pp.run(fsc.liquid, fsc.solid)          # first pass: code-object load + first-touch of the big buffers
     pinfo = pp.run(fsc.liquid, fsc.solid)  # reported times are the second (steady-state) pass
     levels = pinfo.levels
-    solver = ViscositySolve(sc.res, sc.dx, sc.dt, levels, device=local_rank, field_res=sc.field_res)
+    from adaptiveviscositysolver_amd import capi as _capi
+    precision = _capi.PRECISION_F32 if a.precision == "f32" else _capi.PRECISION_F64
+    solver = ViscositySolve(sc.res, sc.dx, sc.dt, levels, device=local_rank, field_res=sc.field_res, precision=precision)
     pp.apply(solver)
     solver.set_scene_fields(fsc)
     prepass_ms = {"weights": pinfo.weights_ms, "octree": pinfo.octree_ms, "classify": pinfo.classify_ms,
@@ -655,7 +659,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": a.precision,
             "data": "synthetic",
             "config": {"workload": f"{wl}, {levels}-level octree, Jacobi-PCG solve to tol {a.tol:g} (warm start)",
                        "baseline_config": a.config,
@@ -676,7 +680,7 @@ def main():
         if use_dist:
             out["dist"] = {"per_rank": [dict(zip(("n_own", "n_halo", "nnz_local", "n_send", "n_peers"), r)) for r in per_rank],
                            **solver.dist_comm_info(), "resident_loop": bool(info.resident), "verification": verification}
-        if world == 1 and not a.no_cpu_baseline and not use_dist:
+        if world == 1 and not a.no_cpu_baseline and not use_dist and a.precision == "f64":
             # CPU assembly baseline: the oracle's own assembly of the same scene at 256^3 (rows per second)
             asm_scene = None
             if a.config in (None, 1, 2, 3, 4) and not getattr(a, "no_cpu_assembly", False):
@@ -688,7 +692,7 @@ def main():
                 out["speedup_assembly_vs_cpu_rows_per_s"] = out["assembly_rows_per_s"] / cb_asm["rows_per_s"]
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             out["speedup_vs_cpu_all_parallel"] = out["value"] / out["cpu_baseline"]["all_parallel"]["iter_per_s"]
-        if world == 1 and not use_dist and not a.no_extra and a.config == 4 and not a.scene and not a.variable_viscosity and not a.n:
+        if world == 1 and not use_dist and not a.no_extra and a.config == 4 and not a.scene and not a.variable_viscosity and not a.n and a.precision == "f64":
             # the secondary workloads, observed by whoever runs the headline: BASELINE configs[2], its field at 512^3, configs[4],
             # and the two scene-equivalents -- one timed pair of solves each, headline fields untouched
             solver.close()
@@ -706,6 +710,16 @@ def main():
                 try:
                     extras.append(extra_workload(label, make(), local_rank, a.tol, a.max_iters))
                 except Exception as e:   # never lose the headline line to a secondary workload
+                    extras.append({"workload": label, "error": str(e)[:300]})
+                torch.cuda.empty_cache()
+            # the headline workload as the reference built with USESINGLEPRECISION runs it (util.h:25-37): float system, float vectors and scalars
+            for label, make in (("fat_beam 512^3, 4 levels, uniform viscosity, SolveType = fpreal32 (AVS_PRECISION_F32: float-vector loop, k_spmv_brick<float>)",
+                                 lambda: scenes.fat_beam(512, 4, device=dev)),
+                                ("config 2 as SolveType = fpreal32: fat_beam 128^3, 3 levels (float-vector loop, streaming float SpMV)",
+                                 lambda: scenes.fat_beam(128, 3, device=dev))):
+                try:
+                    extras.append(extra_workload(label, make(), local_rank, a.tol, a.max_iters, precision=1))
+                except Exception as e:
                     extras.append({"workload": label, "error": str(e)[:300]})
                 torch.cuda.empty_cache()
             out["extra_workloads"] = extras

@@ -93,8 +93,10 @@ typedef struct {
      * reference builds with USESINGLEPRECISION (util.h:25-37: SolveType = fpreal32): every triplet narrowed to float where
      * Eigen::Triplet<SolveType> is constructed (cpp:2447, 2768), duplicates summed in float (setFromTriplets, cpp:613-614), the
      * right-hand side updated in float steps (cpp:2456, 2772), the initial guess narrowed at its store (cpp:2371).  Matrix, rhs and
-     * x0 are then float VALUES in the same fp64 arrays; the PCG iterates on that system in
-     * fp64 (at least as accurate as Eigen's float CG, same stopping rule) and the solution is narrowed to float (Eigen::VectorXf). */
+     * x0 are then float VALUES in the same fp64 arrays.  Single-GPU solves iterate on FLOAT vectors with float scalars, as Eigen's
+     * float CG does (round 5; dot products: a thread's terms in float, everything across threads in double -- Eigen's vectorised
+     * reduction order is not reproduced); partitioned solves, and single-GPU ones with AVS_OPTION_F32_VECTORS = 0, iterate in fp64 on
+     * the float system (at least as accurate, same stopping rule).  The solution is a float vector either way (Eigen::VectorXf). */
     int32_t precision;
 } avs_desc;
 enum { AVS_PRECISION_F64 = 0, AVS_PRECISION_F32 = 1 };
@@ -190,7 +192,11 @@ typedef enum {
                                    * structural rule, so the same input always runs the same kernel), _NEVER, _ALWAYS, _TUNE (auto, decided by timing
                                    * both forms at the assembly: host-synchronous and not reproducible from run to run); takes effect at the next avs_assemble */
     AVS_OPTION_FUSED_SCALAR_STEPS = 6, /* 1 (default): the CG scalar steps ride in the vector kernels; 0: one reduction launch per step */
-    AVS_OPTION_RELOAD_ENVIRONMENT = 7  /* any value: take the AVS_* environment variables again (they are read once, at avs_create; tools and tests) */
+    AVS_OPTION_RELOAD_ENVIRONMENT = 7, /* any value: take the AVS_* environment variables again (they are read once, at avs_create; tools and tests) */
+    AVS_OPTION_F32_VECTORS = 8    /* AVS_PRECISION_F32 contexts, single-GPU solves: 1 (default) = the iteration runs on float vectors with float
+                                   * scalars -- SolveType = fpreal32 through Eigen::ConjugateGradient (util.h:25-37, cpp:613-630) --; 0 = fp64
+                                   * iteration on the float system.  Takes effect at the next avs_assemble (the brick form's walk is laid out
+                                   * for the kernel that will run). */
 } avs_solver_option;
 enum { AVS_USE_TRANSPORT_AUTO = 0, AVS_USE_TRANSPORT_RCCL = 1, AVS_USE_TRANSPORT_DIRECT = 2 };
 enum { AVS_BRICK_AUTO = -1, AVS_BRICK_NEVER = 0, AVS_BRICK_ALWAYS = 1, AVS_BRICK_TUNE = 2 };

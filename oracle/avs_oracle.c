@@ -2330,9 +2330,53 @@ done:
     return 0;
 }
 
-/* Eigen::ConjugateGradient<SparseMatrix<float>, Lower|Upper> (USESINGLEPRECISION): the algorithm above with every scalar and vector a float
- * (dots accumulate in float, left to right -- Eigen's vectorised reduction order is not reproduced; the GPU side is compared to the
- * SOLUTION within a tolerance).  The system arrives as float values in double arrays. */
+/* Eigen's float reductions (a.dot(b), v.squaredNorm() of VectorXf): the linear vectorised redux of Eigen 3.3 / 3.4 (Core/Redux.h,
+ * redux_impl<..., LinearVectorizedTraversal, NoUnrolling>) with the packet the reference's build has -- its CMakeLists.txt sets no
+ * -march flag, so x86-64's baseline SSE2: 4 floats.  Two packet accumulators take alternate packets (a product, then an add, per lane:
+ * no FMA in SSE2), are added lane by lane, a last odd packet is added, the four lanes are folded as (l0 + l2) + (l1 + l3) (predux of
+ * Packet4f), and the scalar tail follows.  Eigen is not in /root/reference (a system dependency, no version pinned): this restates the
+ * published algorithm; vectors from Eigen's allocator are 16-byte aligned, so the aligned range starts at element 0.
+ * orc_set_f32_serial_dots(1) switches to plain left-to-right float sums (what rounds 3-4 of this oracle used). */
+static _Thread_local int orc_f32_serial_dots_tls = 0;
+int orc_set_f32_serial_dots(int on) { orc_f32_serial_dots_tls = on ? 1 : 0; return 0; }
+static float dot_f32_eigen(const float *a, const float *b, int64_t n)
+{
+    if (orc_f32_serial_dots_tls) {
+        float s = 0.f;
+        for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
+        return s;
+    }
+    const int64_t P = 4;
+    const int64_t size2 = (n / (2 * P)) * (2 * P), size1 = (n / P) * P;
+    float res;
+    if (size1 == 0) {
+        if (n == 0) return 0.f;
+        res = a[0] * b[0];
+        for (int64_t i = 1; i < n; ++i) res += a[i] * b[i];
+        return res;
+    }
+    float p0[4], p1[4];
+    for (int l = 0; l < 4; ++l) p0[l] = a[l] * b[l];
+    if (size1 > P) {
+        for (int l = 0; l < 4; ++l) p1[l] = a[P + l] * b[P + l];
+        for (int64_t i = 2 * P; i < size2; i += 2 * P)
+            for (int l = 0; l < 4; ++l) {
+                p0[l] += a[i + l] * b[i + l];
+                p1[l] += a[i + P + l] * b[i + P + l];
+            }
+        for (int l = 0; l < 4; ++l) p0[l] += p1[l];
+        if (size1 > size2)
+            for (int l = 0; l < 4; ++l) p0[l] += a[size2 + l] * b[size2 + l];
+    }
+    res = (p0[0] + p0[2]) + (p0[1] + p0[3]);
+    for (int64_t i = size1; i < n; ++i) res += a[i] * b[i];
+    return res;
+}
+
+/* Eigen::ConjugateGradient<SparseMatrix<float>, Lower|Upper> (USESINGLEPRECISION): the algorithm above with every scalar and vector a float;
+ * row sums left to right in float, dots in Eigen's reduction order (dot_f32_eigen).  The GPU side folds its dots in another order (a
+ * thread's terms in float, the rest in double), so it is compared to the SOLUTION and the iteration count within a tolerance.  The
+ * system arrives as float values in double arrays. */
 static int orc_pcg_csr_f32(int64_t n, const int64_t *row_ptr, const int32_t *col, const double *val, const double *b, double *x,
                            double tol_d, int max_iters, orc_pcg_info *info)
 {
@@ -2353,12 +2397,13 @@ static int orc_pcg_csr_f32(int64_t n, const int64_t *row_ptr, const int32_t *col
         invd[i] = (have && d != 0.f && !orc_no_precond_tls) ? 1.f / d : 1.f;
     }
 #define SPMV_F(src, dst) for (int64_t i_ = 0; i_ < n; ++i_) { float s_ = 0.f; for (int64_t k_ = row_ptr[i_]; k_ < row_ptr[i_ + 1]; ++k_) s_ += v[k_] * (src)[col[k_]]; (dst)[i_] = s_; }
-#define DOT_F(a_, b_, out_) { float s_ = 0.f; for (int64_t i_ = 0; i_ < n; ++i_) s_ += (a_)[i_] * (b_)[i_]; out_ = s_; }
+#define DOT_F(a_, b_, out_) { out_ = dot_f32_eigen((a_), (b_), n); }
     int iters = 0;
     float err = 0.f, rhsNorm2, residualNorm2;
     SPMV_F(xf, tmp);
     for (int64_t i = 0; i < n; ++i) r[i] = (float)b[i] - tmp[i];
-    { float s_ = 0.f; for (int64_t i = 0; i < n; ++i) s_ += (float)b[i] * (float)b[i]; rhsNorm2 = s_; }
+    for (int64_t i = 0; i < n; ++i) z[i] = (float)b[i]; /* (z is free until the loop) */
+    DOT_F(z, z, rhsNorm2);
     if (rhsNorm2 == 0.f) {
         for (int64_t i = 0; i < n; ++i) xf[i] = 0.f;
     } else {
