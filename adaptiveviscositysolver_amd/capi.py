@@ -47,7 +47,7 @@ EXPORTED_SYMBOLS = [
     "avs_prepass_create", "avs_prepass_destroy", "avs_prepass_run",
     "avs_prepass_get_info", "avs_prepass_get_labels", "avs_prepass_get_mask", "avs_prepass_get_index",
     "avs_prepass_get_weights", "avs_prepass_get_regular_index", "avs_prepass_apply", "avs_set_regular_index_field",
-    "avs_transfer_to_regular_grid", "avs_get_node_grid", "avs_get_dof_table", "avs_plan_owners", "avs_plan_create", "avs_plan_get_sizes",
+    "avs_transfer_to_regular_grid", "avs_transfer_to_regular_grid_in_place", "avs_get_node_grid", "avs_get_dof_table", "avs_plan_owners", "avs_plan_create", "avs_plan_get_sizes",
     "avs_plan_get_arrays", "avs_plan_destroy", "avs_dist_get_unique_id", "avs_dist_init",
     "avs_local_group_create", "avs_local_group_destroy", "avs_dist_init_local", "avs_dist_partition",
     "avs_spmv_tile_rows", "avs_dist_assemble", "avs_dist_get_plan_sizes", "avs_dist_get_overlap_tiles", "avs_dist_get_plan_arrays", "avs_dist_solve", "avs_dist_get_solution",
@@ -204,6 +204,7 @@ def load(probe=False):
     L.avs_prepass_get_regular_index.argtypes = [vp, i32, vp, i32]
     L.avs_set_regular_index_field.argtypes = [vp, i32, vp, i32]
     L.avs_transfer_to_regular_grid.argtypes = [vp, vp, vp, vp, i32]
+    L.avs_transfer_to_regular_grid_in_place.argtypes = [vp, vp, vp, vp]
     L.avs_get_node_grid.argtypes = [vp, i32, vp, vp, vp, vp, i32]
     L.avs_get_dof_table.argtypes = [vp, i32, vp, i32]
     L.avs_plan_owners.argtypes = [i64, vp, vp, i32, i32, i32, i32, vp]

@@ -108,6 +108,7 @@ Options options_from_env()
     }
     o.fuse_beta = env_int("AVS_PCG_FUSE_BETA", 1) != 0;
     o.f32_vectors = env_int("AVS_F32_VECTORS", 1) != 0;
+    o.prepass_temporal = env_int("AVS_PREPASS_TEMPORAL", 1) != 0;
     o.resident_cus = env_int("AVS_CG_RESIDENT_CUS", 0);
     o.resident_equal_lanes = getenv("AVS_CG_RESIDENT_EQUAL_LANES") != nullptr;
     o.resident_max_global = env_int("AVS_CG_RESIDENT_MAX_GLOBAL", 3);
@@ -281,7 +282,7 @@ avs_status avs_set_index_field(avs_ctx *c, avs_index_kind kind, int32_t level, i
     AVS_REQUIRE(kind == AVS_INDEX_CENTER || (axis >= 0 && axis < 3), AVS_EINVAL, "axis %d out of range", axis);
     AVS_HIP(hipSetDevice(c->desc.device));
     int r[3];
-    DevBuf<int32_t> *buf;
+    LatBuf<int32_t> *buf;
     bool *have;
     switch (kind) {
     case AVS_INDEX_VELOCITY: grid_res(c->desc, 0, level, axis, r); buf = &c->vidx[level][axis]; have = &c->have_vidx[level][axis]; break;
@@ -425,6 +426,64 @@ avs_status avs::set_scalar_field_lattice(avs_ctx *c, avs_field_kind kind, int32_
         f->is_const = false;
     }
     invalidate(c, false);
+    return AVS_OK;
+}
+
+uint64_t avs::next_buffer_id()
+{
+    static std::atomic<uint64_t> counter{0};
+    return ++counter;
+}
+
+// avs_prepass_apply: the context takes references on the pre-pass's lattices (labels, index pyramids, weights on the padded octree
+// lattices, regular-grid indices) -- what the avs_set_* entries do by copying, without the copies
+avs_status avs::adopt_prepass_lattices(avs_ctx *c, const PrepassLoan &loan)
+{
+    AVS_REQUIRE(c && loan.levels == c->desc.levels, AVS_EINVAL, "loan does not match the context");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    int r[3];
+    auto fits = [&](size_t have, int kind, int level, int axis) {
+        grid_res(c->desc, kind, level, axis, r);
+        return have == vol3(r);
+    };
+    for (int l = 0; l < loan.levels; ++l) {
+        AVS_REQUIRE(loan.labels[l] && loan.cidx[l] && fits(loan.labels[l]->n, 2, l, 0) && fits(loan.cidx[l]->n, 2, l, 0), AVS_EINVAL,
+                    "lent cell lattices of level %d do not match the context", l);
+        for (int a = 0; a < 3; ++a)
+            AVS_REQUIRE(loan.vidx[l][a] && loan.eidx[l][a] && fits(loan.vidx[l][a]->n, 0, l, a) && fits(loan.eidx[l][a]->n, 1, l, a), AVS_EINVAL,
+                        "lent index lattices of level %d axis %d do not match the context", l, a);
+    }
+    AVS_REQUIRE(loan.centerw && fits(loan.centerw->n, 2, 0, 0), AVS_EINVAL, "lent centre weights do not match the context");
+    for (int a = 0; a < 3; ++a)
+        AVS_REQUIRE(loan.edgew[a] && loan.facew[a] && fits(loan.edgew[a]->n, 1, 0, a) && fits(loan.facew[a]->n, 0, 0, a), AVS_EINVAL,
+                    "lent weight lattices of axis %d do not match the context", a);
+    AVS_REQUIRE(loan.counts[0] >= 0 && loan.counts[1] >= 0 && loan.counts[2] >= 0 && loan.counts[0] < INT32_MAX && loan.counts[1] < INT32_MAX &&
+                    loan.counts[2] < INT32_MAX / 3, AVS_EINVAL, "DOF counts out of range");
+    for (int l = 0; l < loan.levels; ++l) {
+        c->labels[l].adopt(loan.labels[l]);
+        c->have_labels[l] = true;
+        c->cidx[l].adopt(loan.cidx[l]);
+        c->have_cidx[l] = true;
+        for (int a = 0; a < 3; ++a) {
+            c->vidx[l][a].adopt(loan.vidx[l][a]);
+            c->eidx[l][a].adopt(loan.eidx[l][a]);
+            c->have_vidx[l][a] = c->have_eidx[l][a] = true;
+        }
+    }
+    auto field = [](avs_ctx::Field &f, const std::shared_ptr<DevBuf<float>> &h) {
+        f.buf.adopt(h);
+        f.is_const = false;
+    };
+    field(c->centerw, loan.centerw);
+    for (int a = 0; a < 3; ++a) {
+        field(c->edgew[a], loan.edgew[a]);
+        field(c->facew[a], loan.facew[a]);
+    }
+    c->n_vel = loan.counts[0];
+    c->n_edge = loan.counts[1];
+    c->n_center = loan.counts[2];
+    invalidate(c, true);
+    for (int a = 0; a < 3; ++a) AVS_TRY(adopt_regular_index_lattice(c, a, loan.ridx[a]));
     return AVS_OK;
 }
 

@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -100,6 +101,7 @@ struct Options {
     BrickCost brick_cost;        // AVS_BRICK_COST=tile,row,run,word,etile,quad
     // single-GPU loop
     int fuse_beta = 1;
+    int prepass_temporal = 1;    // AVS_PREPASS_TEMPORAL: the device pre-pass skips what its allocations already hold from their last filling (0: every run fills everything)
     int f32_vectors = 1;         // AVS_F32_VECTORS: AVS_PRECISION_F32 contexts iterate on float vectors with float scalars (what Eigen's float CG does);
                                  // 0: fp64 iteration on the float system
     // CU-resident loop: tuning and test switches
@@ -168,6 +170,89 @@ struct DevBuf {
         }
         n = count;
         return AVS_OK;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Lattices that change hands without a copy (round 5).  The device pre-pass (avs_prepass.hip) OWNS the label / index / weight lattices it
+// computes; avs_prepass_apply LENDS them to a solver context (a reference on the allocation) instead of copying ~12 full-size lattices
+// per level set and frame (78 GB at 1024^3: as long as the pre-pass itself).  A lent lattice is never written again while somebody else
+// holds it: the pre-pass keeps TWO allocations per lattice and writes the one nobody else references (frame k fills set A while the
+// context still reads set B of frame k-1; apply swaps the context over and B is free for frame k+1) -- the memory of today's copy, none
+// of its traffic.  Every allocation carries a unique id: what the pre-pass remembers about a lattice's contents from the last time it
+// filled it (tile occupancy, far-brick constants: avs_prepass.hip "temporal reuse") is keyed on that id.
+// ---------------------------------------------------------------------------------------------
+uint64_t next_buffer_id();
+template <typename T>
+struct SharedBuf { // producer side
+    std::shared_ptr<DevBuf<T>> h[2];
+    uint64_t ids[2] = {0, 0};
+    int cur = 0;
+    T *p = nullptr;   // the allocation being filled / last filled
+    size_t n = 0;
+    uint64_t id = 0;  // ... and its identity (changes whenever p names other memory or fresh memory)
+    // an allocation of `count` elements that nobody else references: the current one if it is exclusive, else the other slot, else new
+    avs_status alloc(size_t count)
+    {
+        int pick = -1;
+        for (int k = 0; k < 2 && pick < 0; ++k) {
+            const int s = (cur + k) & 1;
+            if (h[s] && h[s].use_count() == 1 && h[s]->n == count && h[s]->p) pick = s;
+        }
+        if (pick < 0) {
+            for (int k = 0; k < 2 && pick < 0; ++k) {
+                const int s = (cur + k) & 1;
+                if (!h[s] || h[s].use_count() == 1) pick = s; // empty, or exclusive with another size
+            }
+            if (pick < 0) pick = cur ^ 1;                    // both lent out: drop our reference to the older loan
+            h[pick] = std::make_shared<DevBuf<T>>();
+            const avs_status st = h[pick]->alloc(count);
+            if (st != AVS_OK) { h[pick].reset(); p = nullptr; n = 0; id = 0; return st; }
+            ids[pick] = next_buffer_id();
+        }
+        cur = pick;
+        p = h[cur]->p;
+        n = h[cur]->n;
+        id = ids[cur];
+        return AVS_OK;
+    }
+    void release()
+    {
+        h[0].reset();
+        h[1].reset();
+        p = nullptr;
+        n = 0;
+        id = 0;
+    }
+    std::shared_ptr<DevBuf<T>> handle() const { return h[cur]; }
+};
+template <typename T>
+struct LatBuf { // consumer side: owns its memory (alloc) or holds a reference on a lent allocation (adopt)
+    DevBuf<T> own;
+    std::shared_ptr<DevBuf<T>> lent;
+    T *p = nullptr;
+    size_t n = 0;
+    avs_status alloc(size_t count)
+    {
+        lent.reset();
+        const avs_status st = own.alloc(count);
+        p = own.p;
+        n = own.n;
+        return st;
+    }
+    void adopt(std::shared_ptr<DevBuf<T>> hnd)
+    {
+        own.release();
+        lent = std::move(hnd);
+        p = lent ? lent->p : nullptr;
+        n = lent ? lent->n : 0;
+    }
+    void release()
+    {
+        own.release();
+        lent.reset();
+        p = nullptr;
+        n = 0;
     }
 };
 
@@ -413,6 +498,17 @@ struct ValueIndex {
 avs_status build_matrix_index(const int32_t *row_ptr, const int32_t *col, const double *val, int64_t n, int64_t nnz, int64_t n_cols,
                               ValueIndex &vi, hipStream_t st);
 
+// what avs_prepass_apply hands to a context: references on the pre-pass's own allocations (no copy; see SharedBuf)
+struct PrepassLoan {
+    int levels = 0;
+    std::shared_ptr<DevBuf<int8_t>> labels[AVS_MAX_LEVELS];
+    std::shared_ptr<DevBuf<int32_t>> vidx[AVS_MAX_LEVELS][3], eidx[AVS_MAX_LEVELS][3], cidx[AVS_MAX_LEVELS], ridx[3];
+    std::shared_ptr<DevBuf<float>> centerw, edgew[3], facew[3];
+    int64_t counts[3] = {0, 0, 0};
+};
+avs_status adopt_prepass_lattices(avs_ctx *c, const PrepassLoan &loan);                                     // avs_api.hip
+avs_status adopt_regular_index_lattice(avs_ctx *c, int32_t axis, std::shared_ptr<DevBuf<int32_t>> handle);  // avs_post.hip
+
 // avs_desc::precision == AVS_PRECISION_F32: the solution as the reference's Eigen::VectorXf holds it (avs_api.hip)
 void narrow_solution_if_f32(avs_ctx *c, double *x, int64_t n);
 
@@ -557,12 +653,12 @@ struct avs_ctx {
     bool own_stream = false;
 
     // inputs
-    avs::DevBuf<int8_t> labels[AVS_MAX_LEVELS];
-    avs::DevBuf<int32_t> vidx[AVS_MAX_LEVELS][3], eidx[AVS_MAX_LEVELS][3], cidx[AVS_MAX_LEVELS];
+    avs::LatBuf<int8_t> labels[AVS_MAX_LEVELS];   // (LatBuf: set by copy through the avs_set_* entries, or lent by avs_prepass_apply)
+    avs::LatBuf<int32_t> vidx[AVS_MAX_LEVELS][3], eidx[AVS_MAX_LEVELS][3], cidx[AVS_MAX_LEVELS];
     bool have_labels[AVS_MAX_LEVELS] = {};
     bool have_vidx[AVS_MAX_LEVELS][3] = {}, have_eidx[AVS_MAX_LEVELS][3] = {}, have_cidx[AVS_MAX_LEVELS] = {};
     struct Field {
-        avs::DevBuf<float> buf;
+        avs::LatBuf<float> buf;
         float cval = 0.f;
         bool is_const = true;
     };
@@ -589,7 +685,7 @@ struct avs_ctx {
     bool guess_partial = false; // x0 holds the restriction of SOME rows only (avs_dist_assemble): never handed out
 
     // post-solve transfer (avs_post.hip): regular-grid classification + interpolator work fields
-    avs::DevBuf<int32_t> ridx[3];
+    avs::LatBuf<int32_t> ridx[3];
     bool have_ridx[3] = {};
     avs::DevBuf<uint8_t> ridx_tiles[3]; // per 64 x 8 x 8 tile of the face lattice: any face the transfer writes (avs_post.hip)
     avs::DevBuf<float> post_vel[AVS_MAX_LEVELS][3], post_nval[AVS_MAX_LEVELS][3], post_nw[AVS_MAX_LEVELS][3];
@@ -597,6 +693,11 @@ struct avs_ctx {
     avs::DevBuf<int8_t> post_nlab[AVS_MAX_LEVELS];
     avs::DevBuf<float> post_out[3]; // staging of the regular-grid output (host destination or padded octree grid), kept across calls
     bool post_ready = false;
+    // temporal reuse (round 5): what the transfer's staging grids hold since the last transfer -- post_vel[l][a] all zero again (the scattered
+    // entries are zeroed at the end of a transfer), node labels / values non-zero only where post_nlab is: the next transfer clears those
+    // nodes instead of zero-filling ~27 B per node of every level.  The pointers name the allocations the claim was made for.
+    const void *post_vel_zero[AVS_MAX_LEVELS][3] = {};
+    const void *post_nodes_sparse[AVS_MAX_LEVELS] = {};
 
     // brick-major copy of the system used by the solve (avs_reorder.hip); perm: new -> old
     avs::DevBuf<int32_t> perm, inv, p_row_ptr, p_col;

@@ -484,6 +484,7 @@ static avs_status pcg_solve_f32(PcgWork *w, const CsrView &A, const double *b, d
 #undef AVS_F32_LAUNCH_R
 #undef AVS_F32_LAUNCH_XP
 
+#ifdef AVS_PROBES
 // probe / test entry: y = A x through the float forms (x holds float values; y is widened), + the folded partial sums of the fused dot
 avs_status spmv_f32_probe(const CsrView &A, const double *x, double *y, bool fused, double *dot_out, hipStream_t st)
 {
@@ -516,3 +517,4 @@ avs_status spmv_f32_probe(const CsrView &A, const double *x, double *y, bool fus
     AVS_HIP(hipStreamSynchronize(st));
     return AVS_OK;
 }
+#endif // AVS_PROBES

@@ -79,6 +79,27 @@ __global__ __launch_bounds__(kBlock) void k_scatter_velocity(PyramidView P, Post
     W.vel[level][axis][lin(face_res(P, level, axis), I3{{rec.y, rec.z, rec.w}})] = (float)x[id]; // cpp:2808
 }
 
+// end of a transfer: the per-level face fields are all zero again (next transfer: no 4-B-per-face fill of every level)
+__global__ __launch_bounds__(kBlock) void k_unscatter_velocity(PyramidView P, PostView W, const int32_t *__restrict__ vdof, int64_t n)
+{
+    const int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (id >= n) return;
+    const int4 rec = reinterpret_cast<const int4 *>(vdof)[id];
+    const int level = rec.x & 0xff, axis = rec.x >> 8;
+    W.vel[level][axis][lin(face_res(P, level, axis), I3{{rec.y, rec.z, rec.w}})] = 0.f;
+}
+// start of a transfer on node grids the previous transfer left behind: values are non-zero only where the label is (k_nodes_sample
+// writes both for the nodes it activates, the later passes touch labelled nodes only) -- one 1-byte read per node instead of 13 B of fills
+__global__ __launch_bounds__(kBlock) void k_nodes_clear(PostView W, int l, size_t total)
+{
+    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+        if (W.nlab[l][o] == 0) continue;
+        W.nlab[l][o] = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) W.nval[l][a][o] = 0.f;
+    }
+}
+
 // T2: interp.cpp:118-188 + 190-286 ------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_nodes_sample(PyramidView P, PostView W, int l)
 {
@@ -416,7 +437,7 @@ __global__ __launch_bounds__(kBlock) void k_ridx_tile_flags(const int32_t *__res
 
 __global__ __launch_bounds__(kBlock) void k_apply_regular_tiled(PyramidView P, PostView W, int axis, const int32_t *__restrict__ ridx,
                                                                 const uint8_t *__restrict__ flags, RTileGrid tg, const double *__restrict__ x,
-                                                                const float *__restrict__ vel_in, float vel_const, float *__restrict__ out)
+                                                                const float *__restrict__ vel_in, float vel_const, float *__restrict__ out, int in_place)
 {
     const I3 fr = face_res(P, 0, axis);
     const int t = blockIdx.x;
@@ -425,7 +446,7 @@ __global__ __launch_bounds__(kBlock) void k_apply_regular_tiled(PyramidView P, P
     const int xx = tx * kRtX + lx;
     if (xx >= fr[0]) return;
     const bool occupied = flags[t] != 0;
-    const bool same = vel_in == out; // (in-place update of the caller's field: untouched faces need no store)
+    const bool same = in_place != 0; // in-place update of the caller's field (what the reference does to `vel`): untouched faces need no store
     for (int k = 0; k < kRtZ; ++k)
         for (int j = ly; j < kRtY; j += kBlock / 64) {
             const int y = ty * kRtY + j, z = tz * kRtZ + k;
@@ -436,6 +457,7 @@ __global__ __launch_bounds__(kBlock) void k_apply_regular_tiled(PyramidView P, P
                 continue;
             }
             const int32_t ri = ridx[o];
+            if (same && !(ri >= 0 || ri == AVS_SOLIDBOUNDARY)) continue; // (the caller's array already holds the input velocity)
             const int32_t oi = P.vidx[0][axis][o]; // (requested with ridx: both lattices are the level-0 face lattice)
             float v = vel_in ? vel_in[o] : vel_const;
             if (ri >= 0) {
@@ -513,9 +535,37 @@ avs_status avs::set_regular_index_lattice(avs_ctx *c, int32_t axis, const int32_
     return AVS_OK;
 }
 
+// the pre-pass's regular-grid index lattice, by reference (avs_prepass_apply): only the tile flags are computed (one read)
+avs_status avs::adopt_regular_index_lattice(avs_ctx *c, int32_t axis, std::shared_ptr<DevBuf<int32_t>> handle)
+{
+    AVS_REQUIRE(c && handle && handle->p && axis >= 0 && axis < 3, AVS_EINVAL, "bad argument");
+    int r[3] = {c->desc.nx, c->desc.ny, c->desc.nz};
+    r[axis] += 1;
+    const size_t n = (size_t)r[0] * r[1] * r[2];
+    AVS_REQUIRE(handle->n == n, AVS_EINVAL, "lent regular-grid index lattice of axis %d does not match the context", axis);
+    c->ridx[axis].adopt(std::move(handle));
+    const RTileGrid tg = rtile_grid(r);
+    const I3 fr3{{r[0], r[1], r[2]}};
+    AVS_TRY(c->ridx_tiles[axis].alloc(tg.vol()));
+    hipLaunchKernelGGL(k_ridx_tile_flags<false>, dim3((unsigned)tg.vol()), dim3(kBlock), 0, c->stream, (const int32_t *)c->ridx[axis].p,
+                       (int32_t *)nullptr, fr3, tg, c->ridx_tiles[axis].p);
+    AVS_HIP(hipGetLastError());
+    c->have_ridx[axis] = true;
+    return AVS_OK;
+}
+
 extern "C" {
 
+static avs_status transfer_impl(avs_ctx *c, float *out_x, float *out_y, float *out_z, avs_memspace where, bool in_place);
 avs_status avs_transfer_to_regular_grid(avs_ctx *c, float *out_x, float *out_y, float *out_z, avs_memspace where)
+{
+    return transfer_impl(c, out_x, out_y, out_z, where, false);
+}
+avs_status avs_transfer_to_regular_grid_in_place(avs_ctx *c, float *vel_x, float *vel_y, float *vel_z)
+{
+    return transfer_impl(c, vel_x, vel_y, vel_z, AVS_MEM_DEVICE, true);
+}
+static avs_status transfer_impl(avs_ctx *c, float *out_x, float *out_y, float *out_z, avs_memspace where, bool in_place)
 {
     avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c && out_x && out_y && out_z, AVS_EINVAL, "null argument");
@@ -530,11 +580,12 @@ avs_status avs_transfer_to_regular_grid(avs_ctx *c, float *out_x, float *out_y, 
     PostView W{};
     W.levels = L;
     // allocate + zero the per-level fields (makeConstant(0) / INACTIVENODE, interp.h:65-81, cpp:688)
+    const bool temporal = c->opt.prepass_temporal != 0;
     for (int l = 0; l < L; ++l) {
         const size_t nn = (size_t)((c->desc.nx >> l) + 1) * ((c->desc.ny >> l) + 1) * ((c->desc.nz >> l) + 1);
+        if (c->post_nlab[l].n != nn) c->post_nodes_sparse[l] = nullptr; // (a new allocation may get the old address)
         AVS_TRY(c->post_nlab[l].alloc(nn));
         AVS_TRY(c->post_nf[l].alloc(nn));
-        AVS_HIP(hipMemsetAsync(c->post_nlab[l].p, 0, nn, st));
         // (node flags and weights are only ever read for nodes that k_nodes_sample marked active, and it writes them: no fill)
         W.nlab[l] = c->post_nlab[l].p;
         W.nf[l] = c->post_nf[l].p;
@@ -542,14 +593,24 @@ avs_status avs_transfer_to_regular_grid(avs_ctx *c, float *out_x, float *out_y, 
             int fr[3] = {c->desc.nx >> l, c->desc.ny >> l, c->desc.nz >> l};
             fr[a] += 1;
             const size_t nf = (size_t)fr[0] * fr[1] * fr[2];
+            if (c->post_vel[l][a].n != nf) c->post_vel_zero[l][a] = nullptr;
+            if (c->post_nval[l][a].n != nn) c->post_nodes_sparse[l] = nullptr;
             AVS_TRY(c->post_vel[l][a].alloc(nf));
             AVS_TRY(c->post_nval[l][a].alloc(nn));
             AVS_TRY(c->post_nw[l][a].alloc(nn));
-            AVS_HIP(hipMemsetAsync(c->post_vel[l][a].p, 0, nf * sizeof(float), st));
-            AVS_HIP(hipMemsetAsync(c->post_nval[l][a].p, 0, nn * sizeof(float), st));
+            if (!(temporal && c->post_vel_zero[l][a] == c->post_vel[l][a].p)) AVS_HIP(hipMemsetAsync(c->post_vel[l][a].p, 0, nf * sizeof(float), st));
+            c->post_vel_zero[l][a] = nullptr; // (claimed again once this transfer has zeroed what it scatters)
             W.vel[l][a] = c->post_vel[l][a].p;
             W.nval[l][a] = c->post_nval[l][a].p;
             W.nw[l][a] = c->post_nw[l][a].p;
+        }
+        // node labels and values: the grids of the previous transfer are cleared where it labelled nodes; anything else is zero-filled
+        const bool sparse = temporal && c->post_nodes_sparse[l] == c->post_nlab[l].p;
+        c->post_nodes_sparse[l] = nullptr;
+        if (sparse) hipLaunchKernelGGL(k_nodes_clear, dim3(grid_for(nn)), dim3(kBlock), 0, st, W, l, nn);
+        else {
+            AVS_HIP(hipMemsetAsync(c->post_nlab[l].p, 0, nn, st));
+            for (int a = 0; a < 3; ++a) AVS_HIP(hipMemsetAsync(c->post_nval[l][a].p, 0, nn * sizeof(float), st));
         }
     }
     const int64_t n = c->n_vel;
@@ -571,6 +632,7 @@ avs_status avs_transfer_to_regular_grid(avs_ctx *c, float *out_x, float *out_y, 
         const size_t nf = (size_t)fr[0] * fr[1] * fr[2], ns = (size_t)sr[0] * sr[1] * sr[2];
         // a device destination on an unpadded grid is written in place; otherwise through a staging grid kept in the context
         float *work = outs[a];
+        const bool inpl = in_place && !padded && !c->vel[a].is_const; // (a padded grid goes through the staging grid: every face is written)
         if (where == AVS_MEM_HOST || padded) {
             AVS_TRY(c->post_out[a].alloc(nf));
             work = c->post_out[a].p;
@@ -580,7 +642,7 @@ avs_status avs_transfer_to_regular_grid(avs_ctx *c, float *out_x, float *out_y, 
         const RTileGrid tg = rtile_grid(fr);
         hipLaunchKernelGGL(k_apply_regular_tiled, dim3((unsigned)tg.vol()), dim3(kBlock), 0, st, P, W, a, (const int32_t *)c->ridx[a].p,
                            (const uint8_t *)c->ridx_tiles[a].p, tg, (const double *)c->x.p,
-                           c->vel[a].is_const ? (const float *)nullptr : (const float *)c->vel[a].buf.p, (float)c->vel[a].cval, work);
+                           c->vel[a].is_const ? (const float *)nullptr : (const float *)c->vel[a].buf.p, (float)c->vel[a].cval, work, inpl ? 1 : 0);
         AVS_HIP(hipGetLastError());
         if (padded) { // hand back the simulation grid's faces only
             if (where == AVS_MEM_DEVICE) AVS_TRY(crop_lattice_f32(work, fr[0], fr[1], fr[2], outs[a], sr[0], sr[1], sr[2], st));
@@ -593,7 +655,13 @@ avs_status avs_transfer_to_regular_grid(avs_ctx *c, float *out_x, float *out_y, 
             }
         } else if (where == AVS_MEM_HOST) AVS_HIP(copy_out(outs[a], work, nf * sizeof(float), where, st));
     }
+    if (n) hipLaunchKernelGGL(k_unscatter_velocity, dim3(grid_for((size_t)n)), dim3(kBlock), 0, st, P, W, c->vdof.p, n);
+    AVS_HIP(hipGetLastError());
     AVS_HIP(hipStreamSynchronize(st));
+    for (int l = 0; l < L; ++l) { // what the staging grids hold now (see post_vel_zero / post_nodes_sparse)
+        c->post_nodes_sparse[l] = c->post_nlab[l].p;
+        for (int a = 0; a < 3; ++a) c->post_vel_zero[l][a] = c->post_vel[l][a].p;
+    }
     c->post_ready = true;
     return AVS_OK;
 }

@@ -335,6 +335,14 @@ class ViscositySolve:
                                                          outs[2].ctypes.data, capi.MEM_HOST))
         return outs
 
+    def transfer_to_regular_grid_in_place(self, velocity):
+        """In-place form (what the reference does to `vel`, cpp:655-707): `velocity` = three DEVICE tensors that hold the field given to
+        set_scalar_field(FIELD_VELOCITY); only the faces the transfer changes are written."""
+        ptrs = [capi.ptr_of(v) for v in velocity]
+        if any(w != capi.MEM_DEVICE for _, w in ptrs):
+            raise ValueError("the in-place transfer updates device arrays")
+        capi.check(self.lib.avs_transfer_to_regular_grid_in_place(self.h, ptrs[0][0], ptrs[1][0], ptrs[2][0]))
+
     def node_grid(self, level):
         nx, ny, nz = (r >> level for r in self.res)
         shp = (nz + 1, ny + 1, nx + 1)

@@ -289,7 +289,11 @@ def extra_workload(label, sc, local_rank, tol, max_iters, precision=0):
     pp.run(fsc.liquid, fsc.solid)            # first pass: allocations and first touch of the pyramids (seconds at 1024^3)
     pinfo = pp.run(fsc.liquid, fsc.solid)    # the timed pass: what every later frame pays
     s = ViscositySolve(sc.res, sc.dx, sc.dt, pinfo.levels, device=local_rank, field_res=sc.field_res, precision=precision)
-    pp.apply(s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pp.apply(s)     # hands the pyramids to the context (round 5: by reference, no copy; the tile flags of the regular-grid indices are computed here)
+    torch.cuda.synchronize()
+    apply_ms = (time.perf_counter() - t0) * 1e3
     s.set_scene_fields(fsc)
     pp.close()
     s.assemble()
@@ -324,6 +328,8 @@ def extra_workload(label, sc, local_rank, tol, max_iters, precision=0):
                               "capture for the new matrix included); ms_per_step = steady state on an unchanged matrix",
            "new_matrix_iterations": int(inm.iterations), "assembly_wall_ms": asm_ms,
            "prepass_ms": pinfo.weights_ms + pinfo.octree_ms + pinfo.classify_ms + pinfo.number_ms,
+           "prepass_phases_ms": {"weights": pinfo.weights_ms, "octree": pinfo.octree_ms, "classify": pinfo.classify_ms, "numbering": pinfo.number_ms},
+           "prepass_apply_ms": apply_ms,
            "roofline": (spmv_roofline(int(ai.n_velocity), int(ai.nnz), s.matrix_format(), sum(i.spmv_ms for i in infos) / 2, s.spmv_kernel_name())
                         if infos[0].spmv_ms > 0 else
                         resident_roofline(int(ai.n_velocity), int(ai.nnz), iters // 2, el / 2 * 1e3) if infos[0].resident else None)}
@@ -337,6 +343,17 @@ def extra_workload(label, sc, local_rank, tol, max_iters, precision=0):
             torch.cuda.synchronize()
             rec["transfer_to_regular_grid_ms"] = (time.perf_counter() - t0) * 1e3
         del outs
+        if sc.field_res is None or tuple(sc.field_res) == tuple(sc.res):
+            vel = [v.clone() for v in fsc.velocity]     # the in-place form: the caller's own field is updated (what the reference does to `vel`)
+            for _ in range(2):
+                for v, src in zip(vel, fsc.velocity):
+                    v.copy_(src)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _cc.check(s.lib.avs_transfer_to_regular_grid_in_place(s.h, vel[0].data_ptr(), vel[1].data_ptr(), vel[2].data_ptr()))
+                torch.cuda.synchronize()
+                rec["transfer_in_place_ms"] = (time.perf_counter() - t0) * 1e3
+            del vel
     except Exception as e:
         rec["transfer_error"] = str(e)[:200]
     if infos[0].resident:   # the same workload through the launch-per-phase loop: what the resident loop is worth, and the SpMV roofline
@@ -452,7 +469,11 @@ def main():
     from adaptiveviscositysolver_amd import capi as _capi
     precision = _capi.PRECISION_F32 if a.precision == "f32" else _capi.PRECISION_F64
     solver = ViscositySolve(sc.res, sc.dx, sc.dt, levels, device=local_rank, field_res=sc.field_res, precision=precision)
-    pp.apply(solver)
+    torch.cuda.synchronize()
+    t_ap = time.perf_counter()
+    pp.apply(solver)   # by reference (round 5): no lattice is copied
+    torch.cuda.synchronize()
+    prepass_apply_ms = (time.perf_counter() - t_ap) * 1e3
     solver.set_scene_fields(fsc)
     prepass_ms = {"weights": pinfo.weights_ms, "octree": pinfo.octree_ms, "classify": pinfo.classify_ms,
                   "numbering": pinfo.number_ms}
@@ -612,6 +633,7 @@ def main():
         elapsed = float(t.item())
 
     transfer_ms = None
+    transfer_in_place_ms = None
     if not use_dist:
         # post-solve transfer to the regular MAC grid (cpp:655-707), outputs stay in HBM
         outs = [torch.empty_like(v) for v in fsc.velocity]
@@ -624,6 +646,18 @@ def main():
                                                            capi.MEM_DEVICE))
         torch.cuda.synchronize()
         transfer_ms = (time.perf_counter() - t_tr) * 1e3
+        del outs
+        if sc.field_res is None or tuple(sc.field_res) == tuple(sc.res):   # in-place form: the caller's own field is updated (cpp:655-707)
+            vel = [v.clone() for v in fsc.velocity]
+            for _ in range(2):
+                for v, src in zip(vel, fsc.velocity):
+                    v.copy_(src)
+                torch.cuda.synchronize()
+                t_tr = time.perf_counter()
+                capi.check(solver.lib.avs_transfer_to_regular_grid_in_place(solver.h, vel[0].data_ptr(), vel[1].data_ptr(), vel[2].data_ptr()))
+                torch.cuda.synchronize()
+                transfer_in_place_ms = (time.perf_counter() - t_tr) * 1e3
+            del vel
     nnz_total = None
     per_rank = None
     if use_dist:
@@ -670,10 +704,12 @@ def main():
             "assembly_ms": {"stencils": ai.stencil_ms, "initial_guess": ai.guess_ms, "system": ai.system_ms,
                             "wall": assemble_wall_ms},
             "prepass_ms": prepass_ms,
+            "prepass_apply_ms": prepass_apply_ms,
             "partition_ms": partition_ms,
             "hot_path_ms": assemble_wall_ms + partition_ms + elapsed / a.steps * 1e3,
             "transfer_to_regular_grid_ms": transfer_ms,
-            "end_to_end_ms": (sum(prepass_ms.values()) + assemble_wall_ms + elapsed / a.steps * 1e3 + transfer_ms) if transfer_ms else None,
+            "transfer_in_place_ms": transfer_in_place_ms,
+            "end_to_end_ms": (sum(prepass_ms.values()) + prepass_apply_ms + assemble_wall_ms + elapsed / a.steps * 1e3 + transfer_ms) if transfer_ms else None,
         }
         if mean_spmv_ms <= 0 and bool(info.resident) and not use_dist:   # CU-resident loop: no SpMV launch was timed
             out["roofline"] = resident_roofline(n, nnz, iters_total // a.steps, elapsed / a.steps * 1e3)

@@ -257,6 +257,12 @@ avs_status avs_get_center_stencils(avs_ctx *ctx, int32_t *cnt, int32_t *idx, dou
 avs_status avs_set_regular_index_field(avs_ctx *ctx, int32_t axis, const int32_t *indices, avs_memspace where);
 /* out_*: face lattices of the simulation grid (field_n*); faces that are not regular DOFs keep the input velocity */
 avs_status avs_transfer_to_regular_grid(avs_ctx *ctx, float *out_x, float *out_y, float *out_z, avs_memspace where);
+/* The same transfer as an IN-PLACE update, which is what the reference does to `vel` (cpp:655-707: only the faces named by
+ * regularVelocityIndices are assigned).  vel_x/y/z: DEVICE arrays on the simulation grid's face lattices that already hold the velocity
+ * field given to avs_set_scalar_field(AVS_FIELD_VELOCITY): only the faces the transfer changes are written -- on a sparse scene nine
+ * tiles in ten are neither read nor written.  (Simulation grids that HDK_OctreeGrid::init had to pad are written face by face as by
+ * avs_transfer_to_regular_grid.) */
+avs_status avs_transfer_to_regular_grid_in_place(avs_ctx *ctx, float *vel_x, float *vel_y, float *vel_z);
 /* interpolator node grids after all passes, (n+1)^3 per level: labels (0 inactive, 1 active), values fp32 */
 avs_status avs_get_node_grid(avs_ctx *ctx, int32_t level, int8_t *labels, float *vx, float *vy, float *vz, avs_memspace where);
 

@@ -168,3 +168,49 @@ def test_non_power_of_two_simulation_grid(n, fres, levels, center, half, built_l
         assert np.array_equal(outs[a].cpu().numpy(), out[a])
     s.close()
     pp.close()
+
+
+def test_transfer_staging_grids_are_reused_sparsely(built_lib):
+    """Round 5: the transfer no longer zero-fills its staging grids every call -- the scattered face values are zeroed at the end of a
+    transfer, node labels / values are cleared where the previous transfer labelled nodes (avs_post.hip).  One context through a sequence
+    of DIFFERENT frames (a new pyramid of the same level count lent by the pre-pass each time, two transfers per frame) must give what the
+    oracle gives for every frame: node grids and output bit for bit."""
+    dev = torch.device("cuda:0")
+    frames = [lambda d: scenes.fat_beam(64, 3, device=d), lambda d: scenes.sphere(64, 3, device=d),
+              lambda d: scenes.fat_beam(64, 3, wall=True, device=d), lambda d: scenes.tank(64, 3, device=d), lambda d: scenes.fat_beam(64, 3, device=d)]
+    pp = DevicePrepass((64, 64, 64), frames[0]("cpu").dx, 3)
+    s = None
+    for k, make in enumerate(frames):
+        sc = scenes.to_device(make("cpu"), dev)
+        info = pp.run(sc.liquid, sc.solid)
+        if s is None:
+            levels0 = info.levels
+        assert info.levels == levels0, (k, info.levels)     # (one context: the frames share a level count)
+        if s is None:
+            s = ViscositySolve(sc.res, sc.dx, sc.dt, info.levels, device=0)
+        pp.apply(s)
+        s.set_scene_fields(sc)
+        s.assemble()
+        s.solve(1e-10, 5000)
+        x = s.solution()
+        o = oracle_for_scene(make("cpu"))
+        o.prepass()
+        o.build_regular_indices()
+        want = o.transfer_to_regular_grid(x)
+        for rep in range(2):
+            out = s.transfer_to_regular_grid()
+            for l in range(o.levels):
+                lab_g, v_g = s.node_grid(l)
+                lab_o, v_o = o.node_grid(l)
+                assert np.array_equal(lab_g, lab_o), (k, rep, l)
+                for a in range(3):
+                    assert np.array_equal(v_g[a], v_o[a]), (k, rep, l, a)
+            for a in range(3):
+                assert np.array_equal(out[a], want[a]), (k, rep, a)
+        # the in-place form (the caller's device arrays hold the input velocity; only changed faces are written)
+        vel = [v.clone() for v in sc.velocity]
+        s.transfer_to_regular_grid_in_place(vel)
+        for a in range(3):
+            assert np.array_equal(vel[a].cpu().numpy(), want[a]), (k, "in place", a)
+    s.close()
+    pp.close()

@@ -85,3 +85,71 @@ def test_no_liquid_gives_zero_levels(built_lib):
     pp = DevicePrepass((16, 16, 16), 1 / 16, 3)
     info = pp.run(liquid)
     assert info.levels == 0 and info.n_velocity == 0
+
+
+def _snapshot(pp, levels):
+    out = {"cw": pp.weights(capi.FIELD_CENTER_WEIGHTS).copy(), "mask": pp.mask().copy()}
+    for a in range(3):
+        out[f"ew{a}"] = pp.weights(capi.FIELD_EDGE_WEIGHTS, a).copy()
+        out[f"fw{a}"] = pp.weights(capi.FIELD_FACE_WEIGHTS, a).copy()
+        out[f"r{a}"] = pp.regular_index(a).copy()
+    for l in range(levels):
+        out[f"lab{l}"] = pp.labels(l).copy()
+        out[f"c{l}"] = pp.index(capi.INDEX_CENTER, l).copy()
+        for a in range(3):
+            out[f"v{l}{a}"] = pp.index(capi.INDEX_VELOCITY, l, a).copy()
+            out[f"e{l}{a}"] = pp.index(capi.INDEX_EDGE, l, a).copy()
+    return out
+
+
+def _same(a, b):
+    assert a.keys() == b.keys()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_temporal_reuse_and_lending_are_invisible(built_lib):
+    """Round 5: a pre-pass object that runs frame after frame (i) skips what its allocations already hold from their last filling (far
+    weight bricks with an unchanged constant, index tiles outside the last occupancy: avs_prepass.hip "temporal reuse") and (ii) LENDS its
+    lattices to the solver context instead of copying them, filling its other set of allocations in the next frame.  Neither may be
+    visible: a sequence of DIFFERENT scenes through ONE object -- with applies in between, so that the allocations alternate -- must give
+    what a fresh object gives for each scene, bit for bit, and a context must keep the system of the frame it was applied in while the
+    pre-pass moves on."""
+    dev = torch.device("cuda:0")
+    frames = [scenes.fat_beam(64, 3), scenes.thin_sheet(64, 3, thickness_cells=12), scenes.sphere(64, 3), scenes.fat_beam(64, 3, wall=True),
+              scenes.tank(64, 3), scenes.fat_beam(64, 3), scenes.fat_beam(64, 3)]
+    pp = DevicePrepass((64, 64, 64), frames[0].dx, 3)
+    held = []          # (context, the CSR it must keep giving)
+    for k, sc_h in enumerate(frames):
+        sc = scenes.to_device(sc_h, dev)
+        info = pp.run(sc.liquid, sc.solid)
+        fresh = DevicePrepass(sc.res, sc.dx, 3)
+        finfo = fresh.run(sc.liquid, sc.solid)
+        assert (info.levels, info.n_velocity, info.n_edge, info.n_center) == (finfo.levels, finfo.n_velocity, finfo.n_edge, finfo.n_center), k
+        _same(_snapshot(pp, info.levels), _snapshot(fresh, finfo.levels))
+        fresh.close()
+        if k != 2:     # (frame 2 is not applied: the next run then refills the SAME allocations)
+            s = ViscositySolve(sc.res, sc.dx, sc.dt, info.levels, device=0)
+            pp.apply(s)
+            s.set_scene_fields(sc)
+            s.assemble()
+            held.append((s, sc, [x.copy() for x in s.csr()]))
+        # every context applied so far still assembles ITS frame (the pre-pass has not written into what it lent)
+        for s, ssc, want in held[-3:]:
+            s.assemble()
+            for got, w in zip(s.csr(), want):
+                assert np.array_equal(got, w), k
+    # the oracle for the last frame, through the lent lattices
+    o = oracle_for_scene(frames[-1])
+    o.prepass()
+    o.hot_path()
+    A = o.csr()
+    rp, col, val, rhs = held[-1][2]
+    assert np.array_equal(rp, A.row_ptr.astype(np.int32)) and np.array_equal(col, A.col) and np.array_equal(val, A.val) and np.array_equal(rhs, A.rhs)
+    pp.close()          # the contexts keep what they were lent
+    s, ssc, want = held[-1]
+    s.assemble()
+    info = s.solve(1e-8, 3000)
+    assert info.converged == 1
+    for s, _, _ in held:
+        s.close()
