@@ -483,7 +483,7 @@ avs_status avs::adopt_prepass_lattices(avs_ctx *c, const PrepassLoan &loan)
     c->n_edge = loan.counts[1];
     c->n_center = loan.counts[2];
     invalidate(c, true);
-    for (int a = 0; a < 3; ++a) AVS_TRY(adopt_regular_index_lattice(c, a, loan.ridx[a]));
+    for (int a = 0; a < 3; ++a) AVS_TRY(adopt_regular_index_lattice(c, a, loan.ridx[a], loan.ridx_occ[a], loan.ridx_occ_tiles[a]));
     return AVS_OK;
 }
 

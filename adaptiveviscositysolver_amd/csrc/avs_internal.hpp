@@ -505,9 +505,13 @@ struct PrepassLoan {
     std::shared_ptr<DevBuf<int32_t>> vidx[AVS_MAX_LEVELS][3], eidx[AVS_MAX_LEVELS][3], cidx[AVS_MAX_LEVELS], ridx[3];
     std::shared_ptr<DevBuf<float>> centerw, edgew[3], facew[3];
     int64_t counts[3] = {0, 0, 0};
+    // the 16^3-tile occupancy every regular-grid index lattice was classified with (device pointers valid during the call; null: unknown)
+    const uint8_t *ridx_occ[3] = {nullptr, nullptr, nullptr};
+    int ridx_occ_tiles[3][3] = {};
 };
 avs_status adopt_prepass_lattices(avs_ctx *c, const PrepassLoan &loan);                                     // avs_api.hip
-avs_status adopt_regular_index_lattice(avs_ctx *c, int32_t axis, std::shared_ptr<DevBuf<int32_t>> handle);  // avs_post.hip
+avs_status adopt_regular_index_lattice(avs_ctx *c, int32_t axis, std::shared_ptr<DevBuf<int32_t>> handle, const uint8_t *occ16,
+                                       const int occ16_tiles[3]);                                          // avs_post.hip
 
 // avs_desc::precision == AVS_PRECISION_F32: the solution as the reference's Eigen::VectorXf holds it (avs_api.hip)
 void narrow_solution_if_f32(avs_ctx *c, double *x, int64_t n);

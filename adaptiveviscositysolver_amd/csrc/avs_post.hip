@@ -412,12 +412,27 @@ struct RTileGrid {
 static inline RTileGrid rtile_grid(const int fr[3]) { return RTileGrid{{(fr[0] + kRtX - 1) / kRtX, (fr[1] + kRtY - 1) / kRtY, (fr[2] + kRtZ - 1) / kRtZ}}; }
 
 // flags[tile] = 1 when the tile holds a face the transfer writes; COPY: dst = src on the way (the lattice is being stored anyway)
+// occ16 (optional; avs_prepass_apply): the 16^3-tile occupancy the lattice was classified with -- outside those tiles it is AVS_UNASSIGNED,
+// so a 64 x 8 x 8 tile whose four 16^3 tiles are unoccupied is flagged 0 without being read (occ16_t: tiles per axis of that grid)
 template <bool COPY>
 __global__ __launch_bounds__(kBlock) void k_ridx_tile_flags(const int32_t *__restrict__ src, int32_t *__restrict__ dst, I3 fr, RTileGrid tg,
-                                                            uint8_t *__restrict__ flags)
+                                                            uint8_t *__restrict__ flags, const uint8_t *__restrict__ occ16 = nullptr, I3 occ16_t = I3{{0, 0, 0}})
 {
     const int t = blockIdx.x;
     const int tx = t % tg.t[0], ty = (t / tg.t[0]) % tg.t[1], tz = t / (tg.t[0] * tg.t[1]);
+    if (!COPY && occ16) {
+        static_assert(kRtX % 16 == 0 && 16 % kRtY == 0 && 16 % kRtZ == 0, "a regular tile lies inside one row of 16^3 tiles");
+        const int oy = ty * kRtY / 16, oz = tz * kRtZ / 16;
+        bool any16 = false;
+        for (int u = 0; u < kRtX / 16; ++u) {
+            const int ox = tx * (kRtX / 16) + u;
+            if (ox < occ16_t[0] && oy < occ16_t[1] && oz < occ16_t[2]) any16 |= occ16[ox + (size_t)occ16_t[0] * (oy + (size_t)occ16_t[1] * oz)] != 0;
+        }
+        if (!any16) {
+            if (threadIdx.x == 0) flags[t] = 0;
+            return;
+        }
+    }
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
     const int x = tx * kRtX + lx;
     int any = 0;
@@ -536,7 +551,7 @@ avs_status avs::set_regular_index_lattice(avs_ctx *c, int32_t axis, const int32_
 }
 
 // the pre-pass's regular-grid index lattice, by reference (avs_prepass_apply): only the tile flags are computed (one read)
-avs_status avs::adopt_regular_index_lattice(avs_ctx *c, int32_t axis, std::shared_ptr<DevBuf<int32_t>> handle)
+avs_status avs::adopt_regular_index_lattice(avs_ctx *c, int32_t axis, std::shared_ptr<DevBuf<int32_t>> handle, const uint8_t *occ16, const int occ16_tiles[3])
 {
     AVS_REQUIRE(c && handle && handle->p && axis >= 0 && axis < 3, AVS_EINVAL, "bad argument");
     int r[3] = {c->desc.nx, c->desc.ny, c->desc.nz};
@@ -548,7 +563,8 @@ avs_status avs::adopt_regular_index_lattice(avs_ctx *c, int32_t axis, std::share
     const I3 fr3{{r[0], r[1], r[2]}};
     AVS_TRY(c->ridx_tiles[axis].alloc(tg.vol()));
     hipLaunchKernelGGL(k_ridx_tile_flags<false>, dim3((unsigned)tg.vol()), dim3(kBlock), 0, c->stream, (const int32_t *)c->ridx[axis].p,
-                       (int32_t *)nullptr, fr3, tg, c->ridx_tiles[axis].p);
+                       (int32_t *)nullptr, fr3, tg, c->ridx_tiles[axis].p, occ16,
+                       occ16 ? I3{{occ16_tiles[0], occ16_tiles[1], occ16_tiles[2]}} : I3{{0, 0, 0}});
     AVS_HIP(hipGetLastError());
     c->have_ridx[axis] = true;
     return AVS_OK;

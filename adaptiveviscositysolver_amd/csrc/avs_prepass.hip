@@ -1256,6 +1256,14 @@ avs_status avs_prepass_apply(avs_prepass *p, avs_ctx *ctx)
         loan.ridx[a] = p->ridx[a].handle();
     }
     for (int k = 0; k < 3; ++k) loan.counts[k] = p->counts[k];
+    for (int a = 0; a < 3; ++a) // the occupancy each regular-grid lattice was classified with: the context flags its transfer tiles without reading the rest
+        for (int k = 0; k < 2; ++k)
+            if (p->temporal && p->rstate[a][k].id != 0 && p->rstate[a][k].id == p->ridx[a].id) {
+                int gr[3];
+                pp_res(p->desc, 0, 0, a, gr);
+                loan.ridx_occ[a] = p->rstate[a][k].occ.p;
+                for (int b = 0; b < 3; ++b) loan.ridx_occ_tiles[a][b] = (gr[b] + kTile - 1) / kTile;
+            }
     AVS_TRY(avs::adopt_prepass_lattices(ctx, loan));
     AVS_HIP(hipStreamSynchronize(ctx->stream));
     return AVS_OK;

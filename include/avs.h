@@ -316,7 +316,13 @@ avs_status avs_prepass_get_regular_index(avs_prepass *pp, int32_t axis, int32_t 
 avs_status avs_prepass_get_weights(avs_prepass *pp, avs_field_kind kind /* CENTER / EDGE / FACE weights */, int32_t axis, float *out,
                                    avs_memspace where);
 /* hands labels, index pyramids, DOF counts, regular-grid indices and the three weight fields to a solve context created with
- * levels == info.levels on the same device (device-to-device copies) */
+ * levels == info.levels on the same device.  BY REFERENCE (round 5; it used to copy ~12 full-size lattices per level set: 78 GB at
+ * 1024^3): the context holds the pre-pass's allocations; the pre-pass keeps two per lattice and its next avs_prepass_run fills the set no
+ * context references, so what a context was given stays as it is until its next avs_prepass_apply, and avs_prepass_destroy may be called
+ * while contexts still use what they were lent.  An avs_set_* call on the context replaces a lent lattice by the context's own copy.
+ * Frame after frame on one avs_prepass object the run also skips what its allocations already hold from their last filling (weight
+ * bricks far from the surface whose constant has not changed, index tiles outside the last occupancy): outputs identical to a fresh
+ * object's, bit for bit; AVS_PREPASS_TEMPORAL=0 in the environment at avs_prepass_create switches it off. */
 avs_status avs_prepass_apply(avs_prepass *pp, avs_ctx *ctx);
 
 
