@@ -483,6 +483,13 @@ avs_status avs::adopt_prepass_lattices(avs_ctx *c, const PrepassLoan &loan)
     c->n_edge = loan.counts[1];
     c->n_center = loan.counts[2];
     invalidate(c, true);
+    if (loan.dof[0] && loan.dof[1] && loan.dof[2] && loan.dof[0]->n >= (size_t)c->n_vel * 4 && loan.dof[1]->n >= (size_t)c->n_edge * 4 &&
+        loan.dof[2]->n >= (size_t)c->n_center * 4) { // the numbering pass wrote the dof tables: no sweep over the index lattices (build_dof_tables)
+        c->vdof.adopt(loan.dof[0]);
+        c->edof.adopt(loan.dof[1]);
+        c->cdof.adopt(loan.dof[2]);
+        c->tables_ready = true;
+    }
     for (int a = 0; a < 3; ++a) AVS_TRY(adopt_regular_index_lattice(c, a, loan.ridx[a], loan.ridx_occ[a], loan.ridx_occ_tiles[a]));
     return AVS_OK;
 }

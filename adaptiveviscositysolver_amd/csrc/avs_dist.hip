@@ -1474,7 +1474,7 @@ avs_status avs_get_dof_table(avs_ctx *c, avs_index_kind kind, int32_t *table, av
     AVS_REQUIRE(c && table, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->tables_ready, AVS_ESTATE, "dof tables not built: call avs_assemble first");
     AVS_HIP(hipSetDevice(c->desc.device));
-    const DevBuf<int32_t> &t = kind == AVS_INDEX_VELOCITY ? c->vdof : (kind == AVS_INDEX_EDGE ? c->edof : c->cdof);
+    const LatBuf<int32_t> &t = kind == AVS_INDEX_VELOCITY ? c->vdof : (kind == AVS_INDEX_EDGE ? c->edof : c->cdof);
     const int64_t n = kind == AVS_INDEX_VELOCITY ? c->n_vel : (kind == AVS_INDEX_EDGE ? c->n_edge : c->n_center);
     AVS_HIP(copy_out(table, t.p, (size_t)n * 4 * sizeof(int32_t), where, c->stream));
     AVS_HIP(hipStreamSynchronize(c->stream));

@@ -505,6 +505,8 @@ struct PrepassLoan {
     std::shared_ptr<DevBuf<int32_t>> vidx[AVS_MAX_LEVELS][3], eidx[AVS_MAX_LEVELS][3], cidx[AVS_MAX_LEVELS], ridx[3];
     std::shared_ptr<DevBuf<float>> centerw, edgew[3], facew[3];
     int64_t counts[3] = {0, 0, 0};
+    // dof tables (4 x int32 per dof: level | axis << 8, i, j, k) written by the numbering pass itself; null: the context builds them from the lattices
+    std::shared_ptr<DevBuf<int32_t>> dof[3];
     // the 16^3-tile occupancy every regular-grid index lattice was classified with (device pointers valid during the call; null: unknown)
     const uint8_t *ridx_occ[3] = {nullptr, nullptr, nullptr};
     int ridx_occ_tiles[3][3] = {};
@@ -673,7 +675,7 @@ struct avs_ctx {
     int no_precond = 0; // avs_set_solver_option(AVS_OPTION_PRECONDITIONER, AVS_PRECONDITIONER_NONE)
 
     // dof tables: 4 x int32 per dof (level | axis << 8, i, j, k)
-    avs::DevBuf<int32_t> vdof, edof, cdof;
+    avs::LatBuf<int32_t> vdof, edof, cdof; // (built from the index lattices, or lent by the pre-pass, which writes them while it numbers the DOFs)
     bool tables_ready = false;
 
     // stencils

@@ -661,8 +661,12 @@ __global__ __launch_bounds__(kBlock) void k_tile_counts(const int32_t *__restric
     if (threadIdx.x == 0) tile_count[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// `table` (optional): the dof table of this kind -- record (level | axis << 8, i, j, k) of every id handed out, what the solver context
+// otherwise rebuilds with a sweep over every index lattice (k_dof_table: 5 ms per frame at 1024^3); ids beyond `cap` are not recorded
+// (the table was sized from the previous frame's count: the caller then discards it)
 __global__ __launch_bounds__(kBlock) void k_tile_ids(int32_t *__restrict__ grid, Grid3 g, int ntx, int nty,
-                                                     const int32_t *__restrict__ tile_off, const long long *__restrict__ base)
+                                                     const int32_t *__restrict__ tile_off, const long long *__restrict__ base,
+                                                     int32_t *__restrict__ table = nullptr, long long cap = 0, int tag = 0)
 {
     if (tile_off[blockIdx.x + 1] == tile_off[blockIdx.x]) return; // no DOF in this tile: nothing to read, nothing to write
     __shared__ int cnt[kTile * (kBlock / 64)]; // flagged voxels of (step z, wave w), then their exclusive prefix
@@ -690,9 +694,15 @@ __global__ __launch_bounds__(kBlock) void k_tile_ids(int32_t *__restrict__ grid,
     __syncthreads();
     if (!bits) return;
     const int32_t id0 = (int32_t)*base + tile_off[blockIdx.x];
+    const int ti = (blockIdx.x % ntx) * kTile + (threadIdx.x & (kTile - 1)), tj = ((blockIdx.x / ntx) % nty) * kTile + (threadIdx.x >> 4);
+    const int tk = (blockIdx.x / (ntx * nty)) * kTile;
 #pragma unroll
     for (int z = 0; z < kTile; ++z)
-        if ((bits >> z) & 1u) grid[first + (size_t)z * zs] = id0 + cnt[z * (kBlock / 64) + wave] + __popcll(below[z]);
+        if ((bits >> z) & 1u) {
+            const int32_t id = id0 + cnt[z * (kBlock / 64) + wave] + __popcll(below[z]);
+            grid[first + (size_t)z * zs] = id;
+            if (table && id < cap) reinterpret_cast<int4 *>(table)[id] = make_int4(tag, ti, tj, tk + z);
+        }
 }
 
 __global__ void k_bump_base(long long *base, const int32_t *total)
@@ -729,6 +739,10 @@ struct avs_prepass {
     TileState vstate[AVS_MAX_LEVELS][3][2], estate[AVS_MAX_LEVELS][3][2], rstate[3][2];
     struct BrickState { uint64_t ids[7] = {}; DevBuf<uint8_t> st; };     // weight lattices: k_sdf_weights_far's per-brick record
     BrickState wstate[2];
+    SharedBuf<int32_t> dof[3];                 // dof tables written by the numbering pass (velocity, edge, centre), lent with the lattices
+    long long dof_cap[3] = {0, 0, 0};          // ... sized from the previous run's counts (0: none this run)
+    bool dof_valid[3] = {false, false, false}; // ... and complete (the count did not outgrow the capacity)
+    int64_t prev_counts[3] = {0, 0, 0};
     bool temporal = true; // AVS_PREPASS_TEMPORAL=0: every run fills everything (measurement / tests)
     int64_t counts[4] = {0, 0, 0, 0}; // velocity, edge, centre, regular
     double ms[4] = {0, 0, 0, 0};
@@ -905,6 +919,7 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     const size_t n0 = g3(r0).vol();
     const double extrapolation = d.dx * d.extrapolation_scale; // cpp:243
     p->ready = false;
+    for (int k = 0; k < 3; ++k) p->dof_valid[k] = false;
     EvTimer t(st);
 
     // the SDFs arrive on the simulation grid; outside it they are read with clamped coordinates (border replication)
@@ -1107,14 +1122,20 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     AVS_TRY(scan_tmp.alloc(scan_tmp_elems((int64_t)max_tiles + 1)));
     AVS_TRY(base.alloc(4));
     AVS_HIP(hipMemsetAsync(base.p, 0, 4 * sizeof(long long), st));
-    auto number = [&](int32_t *grid, const int gr[3], int counter, const uint8_t *occ) -> avs_status {
+    for (int k = 0; k < 3; ++k) { // dof tables: room for the previous frame's count + 25 % (a first run has no estimate: the context builds them)
+        p->dof_valid[k] = false;
+        p->dof_cap[k] = (p->temporal && p->prev_counts[k] > 0) ? p->prev_counts[k] + p->prev_counts[k] / 4 + 4096 : 0;
+        if (p->dof_cap[k] > 0) AVS_TRY(p->dof[k].alloc((size_t)p->dof_cap[k] * 4));
+    }
+    auto number = [&](int32_t *grid, const int gr[3], int counter, const uint8_t *occ, int tag) -> avs_status {
         const Grid3 g = g3(gr);
         const int ntx = (gr[0] + kTile - 1) / kTile, nty = (gr[1] + kTile - 1) / kTile, ntz = (gr[2] + kTile - 1) / kTile;
         const int64_t nt = (int64_t)ntx * nty * ntz;
         hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)nt), dim3(kBlock), 0, st, (const int32_t *)grid, g, ntx, nty, fl.p, occ);
         AVS_TRY(exclusive_scan_i32(fl.p, ids.p, nt, scan_tmp.p, scan_tmp.n, st));
+        const bool tab = counter < 3 && p->dof_cap[counter] > 0;
         hipLaunchKernelGGL(k_tile_ids, dim3((unsigned)nt), dim3(kBlock), 0, st, grid, g, ntx, nty, (const int32_t *)ids.p,
-                           (const long long *)(base.p + counter));
+                           (const long long *)(base.p + counter), tab ? p->dof[counter].p : (int32_t *)nullptr, tab ? p->dof_cap[counter] : 0ll, tag);
         hipLaunchKernelGGL(k_bump_base, dim3(1), dim3(64), 0, st, base.p + counter, (const int32_t *)(ids.p + nt));
         return AVS_OK;
     };
@@ -1124,18 +1145,22 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
                 int gr[3];
                 pp_res(d, kind, l, a, gr);
                 const uint8_t *oc = kind == 2 ? nullptr : occ_all.p + ((size_t)l * 6 + (size_t)kind * 3 + a) * occ_cap; // centres: no tile rule
-                AVS_TRY(number(kind == 0 ? p->vidx[l][a].p : (kind == 1 ? p->eidx[l][a].p : p->cidx[l].p), gr, kind, oc));
+                AVS_TRY(number(kind == 0 ? p->vidx[l][a].p : (kind == 1 ? p->eidx[l][a].p : p->cidx[l].p), gr, kind, oc, l | (a << 8)));
             }
     for (int a = 0; a < 3; ++a) { // regular grid: one counter over the three axes, cpp:1486-1509
         int gr[3];
         pp_res(d, 0, 0, a, gr);
-        AVS_TRY(number(p->ridx[a].p, gr, 3, occ_all.p + (size_t)a * occ_cap)); // classified with the level-0 face occupancy
+        AVS_TRY(number(p->ridx[a].p, gr, 3, occ_all.p + (size_t)a * occ_cap, 0)); // classified with the level-0 face occupancy
     }
     AVS_HIP(hipGetLastError());
     long long hb[4] = {0, 0, 0, 0};
     AVS_HIP(hipMemcpyAsync(hb, base.p, sizeof(hb), hipMemcpyDeviceToHost, st));
     AVS_HIP(hipStreamSynchronize(st));
     for (int k = 0; k < 4; ++k) p->counts[k] = hb[k];
+    for (int k = 0; k < 3; ++k) {
+        p->dof_valid[k] = p->dof_cap[k] > 0 && hb[k] <= p->dof_cap[k];
+        p->prev_counts[k] = hb[k];
+    }
     p->ms[3] = t.stop();
     p->ready = true;
     return AVS_OK;
@@ -1256,6 +1281,8 @@ avs_status avs_prepass_apply(avs_prepass *p, avs_ctx *ctx)
         loan.ridx[a] = p->ridx[a].handle();
     }
     for (int k = 0; k < 3; ++k) loan.counts[k] = p->counts[k];
+    if (p->dof_valid[0] && p->dof_valid[1] && p->dof_valid[2])
+        for (int k = 0; k < 3; ++k) loan.dof[k] = p->dof[k].handle();
     for (int a = 0; a < 3; ++a) // the occupancy each regular-grid lattice was classified with: the context flags its transfer tiles without reading the rest
         for (int k = 0; k < 2; ++k)
             if (p->temporal && p->rstate[a][k].id != 0 && p->rstate[a][k].id == p->ridx[a].id) {
