@@ -704,6 +704,11 @@ struct avs_ctx {
     // nodes instead of zero-filling ~27 B per node of every level.  The pointers name the allocations the claim was made for.
     const void *post_vel_zero[AVS_MAX_LEVELS][3] = {};
     const void *post_nodes_sparse[AVS_MAX_LEVELS] = {};
+    // the nodes the last transfer labelled, per level (k_nodes_sample_dofs): walked by the node passes and by the next transfer's clear
+    avs::DevBuf<uint32_t> post_list[AVS_MAX_LEVELS];
+    avs::DevBuf<unsigned> post_list_count;
+    unsigned post_list_n[AVS_MAX_LEVELS] = {};
+    bool post_lists_valid = false;
 
     // brick-major copy of the system used by the solve (avs_reorder.hip); perm: new -> old
     avs::DevBuf<int32_t> perm, inv, p_row_ptr, p_col;

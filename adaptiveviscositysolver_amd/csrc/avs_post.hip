@@ -90,9 +90,11 @@ __global__ __launch_bounds__(kBlock) void k_unscatter_velocity(PyramidView P, Po
 }
 // start of a transfer on node grids the previous transfer left behind: values are non-zero only where the label is (k_nodes_sample
 // writes both for the nodes it activates, the later passes touch labelled nodes only) -- one 1-byte read per node instead of 13 B of fills
-__global__ __launch_bounds__(kBlock) void k_nodes_clear(PostView W, int l, size_t total)
+// (`list` != null: the nodes the previous transfer labelled, k_nodes_sample_dofs; else a sweep over the level's nodes)
+__global__ __launch_bounds__(kBlock) void k_nodes_clear(PostView W, int l, size_t total, const uint32_t *__restrict__ list = nullptr)
 {
-    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+    for (size_t it = (size_t)blockIdx.x * kBlock + threadIdx.x; it < total; it += (size_t)gridDim.x * kBlock) {
+        const size_t o = list ? (size_t)list[it] : it;
         if (W.nlab[l][o] == 0) continue;
         W.nlab[l][o] = 0;
 #pragma unroll
@@ -101,6 +103,60 @@ __global__ __launch_bounds__(kBlock) void k_nodes_clear(PostView W, int l, size_
 }
 
 // T2: interp.cpp:118-188 + 190-286 ------------------------------------------------------------
+// One node: the twelve faces around it, all indices requested at once (the reference's loops stop at the first SOLIDBOUNDARY / OUTSIDE
+// face, but "active and not inactive" does not depend on the order of the tests).  `my_slot` >= 0 (k_nodes_sample_dofs): the caller came
+// from the DOF face in slot fa * 4 + fi and goes on only when that is the FIRST DOF face of the node -- so that exactly one of the up to
+// twelve threads that reach a node labels it.  Returns true when the node was labelled (active).
+__device__ __forceinline__ bool sample_node(const PyramidView &P, const PostView &W, int l, const I3 &node, size_t o, double weight, int my_slot)
+{
+    bool active = false, inactive = false;
+    int32_t vi[12];
+    size_t fo[12];
+    int first = -1;
+#pragma unroll
+    for (int fa = 0; fa < 3; ++fa) {
+        const I3 fr = face_res(P, l, fa);
+        const int b1 = (fa + 1) % 3, b2 = (fa + 2) % 3;
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) {
+            const I3 f = node_to_face(node, fa, fi);
+            const bool oob = f[b1] < 0 || f[b2] < 0 || f[b1] >= fr[b1] || f[b2] >= fr[b2];
+            inactive |= oob;
+            fo[fa * 4 + fi] = lin(fr, clamp3(f, fr));
+            vi[fa * 4 + fi] = P.vidx[l][fa][fo[fa * 4 + fi]];
+            if (!oob) {
+                if (vi[fa * 4 + fi] >= 0 && first < 0) first = fa * 4 + fi;
+                active |= vi[fa * 4 + fi] >= 0;
+                inactive |= vi[fa * 4 + fi] == AVS_SOLIDBOUNDARY || vi[fa * 4 + fi] == AVS_OUTSIDE;
+            }
+        }
+    }
+    if (my_slot >= 0 && first != my_slot) return false; // another thread's node
+    if (!(active && !inactive)) return false; // labels / values / weights / flags were zero-filled
+    W.nlab[l][o] = 1;
+    int32_t flag = 0;
+#pragma unroll
+    for (int fa = 0; fa < 3; ++fa) {
+        double av = 0., aw = 0.;
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) { // active nodes have all 12 faces in bounds
+            const int32_t v = vi[fa * 4 + fi];
+            if (v >= 0) {
+                av += weight * (double)W.vel[l][fa][fo[fa * 4 + fi]];
+                aw += weight;
+                flag += 1 << (fa * 4 + fi);
+            } else if (v != AVS_UNASSIGNED) {
+                aw += weight;
+                flag += 1 << (fa * 4 + fi);
+            }
+        }
+        W.nval[l][fa][o] = (float)av;
+        W.nw[l][fa][o] = (float)aw;
+    }
+    W.nf[l][o] = flag;
+    return true;
+}
+
 __global__ __launch_bounds__(kBlock) void k_nodes_sample(PyramidView P, PostView W, int l)
 {
     const I3 nr = node_res(P, l);
@@ -122,59 +178,63 @@ __global__ __launch_bounds__(kBlock) void k_nodes_sample(PyramidView P, PostView
             }
             if (!any_active) continue; // labels / values / weights / flags were zero-filled
         }
-        // the twelve faces around the node: all indices requested at once (the reference's loops stop at the first
-        // SOLIDBOUNDARY / OUTSIDE face, but "active and not inactive" does not depend on the order of the tests)
-        bool active = false, inactive = false;
-        int32_t vi[12];
-        size_t fo[12];
-#pragma unroll
-        for (int fa = 0; fa < 3; ++fa) {
-            const I3 fr = face_res(P, l, fa);
-            const int b1 = (fa + 1) % 3, b2 = (fa + 2) % 3;
-#pragma unroll
-            for (int fi = 0; fi < 4; ++fi) {
-                const I3 f = node_to_face(node, fa, fi);
-                const bool oob = f[b1] < 0 || f[b2] < 0 || f[b1] >= fr[b1] || f[b2] >= fr[b2];
-                inactive |= oob;
-                fo[fa * 4 + fi] = lin(fr, clamp3(f, fr));
-                vi[fa * 4 + fi] = P.vidx[l][fa][fo[fa * 4 + fi]];
-                if (!oob) {
-                    active |= vi[fa * 4 + fi] >= 0;
-                    inactive |= vi[fa * 4 + fi] == AVS_SOLIDBOUNDARY || vi[fa * 4 + fi] == AVS_OUTSIDE;
-                }
-            }
+        (void)sample_node(P, W, l, node, o, weight, -1);
+    }
+}
+
+// The same pass driven by the velocity DOFs (round 5): a node can only be active when one of its twelve faces is a DOF, i.e. when it is a
+// corner of a DOF face of its level -- so one thread per (DOF, corner) reaches every candidate, instead of one thread per node of every
+// level (1.07 G nodes at level 0 of a 1024^3 grid for a sheet with 18 M DOFs).  Of the threads that reach a node the one that came from
+// its first DOF face labels it, and appends it to the level's list: the later passes (bubble, finish, normalise, distribute, and the
+// next transfer's clear) then walk the lists instead of sweeping the node lattices.  Same arithmetic per node, nodes are independent:
+// same node grids, bit for bit.  cap: list capacity per level (an overflowing level keeps count > cap: the caller falls back to sweeps).
+struct NodeLists {
+    uint32_t *list[AVS_MAX_LEVELS];
+    unsigned *count; // [levels]
+    unsigned cap[AVS_MAX_LEVELS];
+};
+__global__ __launch_bounds__(kBlock) void k_nodes_sample_dofs(PyramidView P, PostView W, const int32_t *__restrict__ vdof, int64_t n, NodeLists NL)
+{
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    bool won = false;
+    int l = 0;
+    size_t o = 0;
+    if (t < 4 * n) {
+        const int4 rec = reinterpret_cast<const int4 *>(vdof)[t >> 2];
+        const int c = (int)(t & 3);
+        const int fa = rec.x >> 8;
+        l = rec.x & 0xff;
+        const int b1 = (fa + 1) % 3, b2 = (fa + 2) % 3;
+        I3 node{{rec.y, rec.z, rec.w}};
+        node[b1] += c & 1;
+        node[b2] += c >> 1;
+        o = lin(node_res(P, l), node);
+        const double weight = (double)(1 << (P.levels - l - 1));
+        won = sample_node(P, W, l, node, o, weight, fa * 4 + (3 - c)); // (node_to_face: slot fi of the node is the face at corner 3 - fi)
+    }
+    // one atomic per wave and level (a counter hit by every labelled node serialises: 18 M same-address atomics took 65 ms)
+    const int lane = threadIdx.x & 63;
+    for (int q = 0; q < P.levels; ++q) {
+        const unsigned long long m = __ballot(won && l == q);
+        if (m == 0ull) continue;
+        unsigned base = 0u;
+        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(NL.count + q, (unsigned)__popcll(m));
+        base = __shfl(base, __ffsll((long long)m) - 1, 64);
+        if (won && l == q) {
+            const unsigned at = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            if (at < NL.cap[q]) NL.list[q][at] = (uint32_t)o;
         }
-        if (!(active && !inactive)) continue; // labels / values / weights / flags were zero-filled
-        W.nlab[l][o] = 1;
-        int32_t flag = 0;
-#pragma unroll
-        for (int fa = 0; fa < 3; ++fa) {
-            double av = 0., aw = 0.;
-#pragma unroll
-            for (int fi = 0; fi < 4; ++fi) { // active nodes have all 12 faces in bounds
-                const int32_t v = vi[fa * 4 + fi];
-                if (v >= 0) {
-                    av += weight * (double)W.vel[l][fa][fo[fa * 4 + fi]];
-                    aw += weight;
-                    flag += 1 << (fa * 4 + fi);
-                } else if (v != AVS_UNASSIGNED) {
-                    aw += weight;
-                    flag += 1 << (fa * 4 + fi);
-                }
-            }
-            W.nval[l][fa][o] = (float)av;
-            W.nw[l][fa][o] = (float)aw;
-        }
-        W.nf[l][o] = flag;
     }
 }
 
 // T3: interp.cpp:288-355; one thread per node of level l+1 (its co-located child is node 2*p) ------
-__global__ __launch_bounds__(kBlock) void k_nodes_bubble(PyramidView P, PostView W, int l)
+// (`list` / `count`: the labelled nodes of level l + 1 instead of a sweep -- here and in the passes below)
+__global__ __launch_bounds__(kBlock) void k_nodes_bubble(PyramidView P, PostView W, int l, const uint32_t *__restrict__ list = nullptr, size_t count = 0)
 {
     const I3 nr = node_res(P, l), pr = node_res(P, l + 1);
-    const size_t total = (size_t)pr[0] * pr[1] * pr[2];
-    for (size_t po = (size_t)blockIdx.x * kBlock + threadIdx.x; po < total; po += (size_t)gridDim.x * kBlock) {
+    const size_t total = list ? count : (size_t)pr[0] * pr[1] * pr[2];
+    for (size_t it = (size_t)blockIdx.x * kBlock + threadIdx.x; it < total; it += (size_t)gridDim.x * kBlock) {
+        const size_t po = list ? (size_t)list[it] : it;
         if (W.nlab[l + 1][po] != 1) continue;
         const I3 par = unlin(pr, po);
         const I3 node{{2 * par[0], 2 * par[1], 2 * par[2]}};
@@ -190,13 +250,14 @@ __global__ __launch_bounds__(kBlock) void k_nodes_bubble(PyramidView P, PostView
 }
 
 // T4: interp.cpp:357-567 ------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_nodes_finish(PyramidView P, PostView W, int l)
+__global__ __launch_bounds__(kBlock) void k_nodes_finish(PyramidView P, PostView W, int l, const uint32_t *__restrict__ list = nullptr, size_t count = 0)
 {
     const I3 nr = node_res(P, l);
-    const size_t total = (size_t)nr[0] * nr[1] * nr[2];
+    const size_t total = list ? count : (size_t)nr[0] * nr[1] * nr[2];
     const int L = P.levels;
     const double weight = (double)(1 << (L - l - 1));
-    for (size_t no = (size_t)blockIdx.x * kBlock + threadIdx.x; no < total; no += (size_t)gridDim.x * kBlock) {
+    for (size_t it = (size_t)blockIdx.x * kBlock + threadIdx.x; it < total; it += (size_t)gridDim.x * kBlock) {
+        const size_t no = list ? (size_t)list[it] : it;
         if (W.nlab[l][no] != 1) continue;
         int32_t flag = W.nf[l][no];
         if (flag == 0xFFF) continue;
@@ -261,22 +322,24 @@ __global__ __launch_bounds__(kBlock) void k_nodes_finish(PyramidView P, PostView
 }
 
 // T5: interp.cpp:569-613 ------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_nodes_normalize(PyramidView P, PostView W, int l)
+__global__ __launch_bounds__(kBlock) void k_nodes_normalize(PyramidView P, PostView W, int l, const uint32_t *__restrict__ list = nullptr, size_t count = 0)
 {
     const I3 nr = node_res(P, l);
-    const size_t total = (size_t)nr[0] * nr[1] * nr[2];
-    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+    const size_t total = list ? count : (size_t)nr[0] * nr[1] * nr[2];
+    for (size_t it = (size_t)blockIdx.x * kBlock + threadIdx.x; it < total; it += (size_t)gridDim.x * kBlock) {
+        const size_t o = list ? (size_t)list[it] : it;
         if (W.nlab[l][o] != 1) continue;
         for (int a = 0; a < 3; ++a) W.nval[l][a][o] = (float)((double)W.nval[l][a][o] / (double)W.nw[l][a][o]);
     }
 }
 
 // T6: interp.cpp:615-658 ------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_nodes_distribute(PyramidView P, PostView W, int l)
+__global__ __launch_bounds__(kBlock) void k_nodes_distribute(PyramidView P, PostView W, int l, const uint32_t *__restrict__ list = nullptr, size_t count = 0)
 {
     const I3 nr = node_res(P, l), pr = node_res(P, l + 1);
-    const size_t total = (size_t)nr[0] * nr[1] * nr[2];
-    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+    const size_t total = list ? count : (size_t)nr[0] * nr[1] * nr[2];
+    for (size_t it = (size_t)blockIdx.x * kBlock + threadIdx.x; it < total; it += (size_t)gridDim.x * kBlock) {
+        const size_t o = list ? (size_t)list[it] : it;
         if (W.nlab[l][o] != 2) continue;
         const size_t po = lin(pr, half3(unlin(nr, o)));
         for (int a = 0; a < 3; ++a) W.nval[l][a][o] = W.nval[l + 1][a][po];
@@ -623,7 +686,9 @@ static avs_status transfer_impl(avs_ctx *c, float *out_x, float *out_y, float *o
         // node labels and values: the grids of the previous transfer are cleared where it labelled nodes; anything else is zero-filled
         const bool sparse = temporal && c->post_nodes_sparse[l] == c->post_nlab[l].p;
         c->post_nodes_sparse[l] = nullptr;
-        if (sparse) hipLaunchKernelGGL(k_nodes_clear, dim3(grid_for(nn)), dim3(kBlock), 0, st, W, l, nn);
+        if (sparse && c->post_lists_valid && c->post_list[l].p) // ... by the list of the nodes it labelled
+            hipLaunchKernelGGL(k_nodes_clear, dim3(grid_for(c->post_list_n[l])), dim3(kBlock), 0, st, W, l, (size_t)c->post_list_n[l], (const uint32_t *)c->post_list[l].p);
+        else if (sparse) hipLaunchKernelGGL(k_nodes_clear, dim3(grid_for(nn)), dim3(kBlock), 0, st, W, l, nn);
         else {
             AVS_HIP(hipMemsetAsync(c->post_nlab[l].p, 0, nn, st));
             for (int a = 0; a < 3; ++a) AVS_HIP(hipMemsetAsync(c->post_nval[l][a].p, 0, nn * sizeof(float), st));
@@ -632,11 +697,41 @@ static avs_status transfer_impl(avs_ctx *c, float *out_x, float *out_y, float *o
     const int64_t n = c->n_vel;
     if (n) hipLaunchKernelGGL(k_scatter_velocity, dim3(grid_for((size_t)n)), dim3(kBlock), 0, st, P, W, c->vdof.p, n, c->x.p);
     auto nodes = [&](int l) { return (size_t)((c->desc.nx >> l) + 1) * ((c->desc.ny >> l) + 1) * ((c->desc.nz >> l) + 1); };
-    for (int l = 0; l < L; ++l) hipLaunchKernelGGL(k_nodes_sample, dim3(grid_for(nodes(l))), dim3(kBlock), 0, st, P, W, l);
-    for (int l = 0; l < L - 1; ++l) hipLaunchKernelGGL(k_nodes_bubble, dim3(grid_for(nodes(l + 1))), dim3(kBlock), 0, st, P, W, l);
-    for (int l = 0; l < L - 1; ++l) hipLaunchKernelGGL(k_nodes_finish, dim3(grid_for(nodes(l))), dim3(kBlock), 0, st, P, W, l);
-    for (int l = 0; l < L; ++l) hipLaunchKernelGGL(k_nodes_normalize, dim3(grid_for(nodes(l))), dim3(kBlock), 0, st, P, W, l);
-    for (int l = L - 2; l >= 0; --l) hipLaunchKernelGGL(k_nodes_distribute, dim3(grid_for(nodes(l))), dim3(kBlock), 0, st, P, W, l);
+    // T2: driven by the velocity DOFs, with a list of the labelled nodes per level (k_nodes_sample_dofs); the sweeps over the node
+    // lattices remain for a context without DOFs, node lattices beyond 2^32 entries, a list that overflows, or AVS_PREPASS_TEMPORAL=0
+    bool lists = temporal && n > 0 && nodes(0) < (1ull << 32);
+    c->post_lists_valid = false;
+    unsigned hcount[AVS_MAX_LEVELS] = {};
+    if (lists) {
+        NodeLists NL{};
+        AVS_TRY(c->post_list_count.alloc(AVS_MAX_LEVELS));
+        AVS_HIP(hipMemsetAsync(c->post_list_count.p, 0, AVS_MAX_LEVELS * sizeof(unsigned), st));
+        NL.count = c->post_list_count.p;
+        for (int l = 0; l < L; ++l) {
+            const size_t cap = nodes(l) < (size_t)(2 * n + 1024) ? nodes(l) : (size_t)(2 * n + 1024); // (an active node is a corner of a DOF face)
+            AVS_TRY(c->post_list[l].reserve(cap));
+            NL.list[l] = c->post_list[l].p;
+            NL.cap[l] = (unsigned)(c->post_list[l].n < (1ull << 32) - 1 ? c->post_list[l].n : (1ull << 32) - 1);
+        }
+        hipLaunchKernelGGL(k_nodes_sample_dofs, dim3(grid_for((size_t)(4 * n), 1u << 30)), dim3(kBlock), 0, st, P, W, c->vdof.p, n, NL);
+        AVS_HIP(hipMemcpyAsync(hcount, c->post_list_count.p, sizeof(hcount), hipMemcpyDeviceToHost, st));
+        AVS_HIP(hipStreamSynchronize(st));
+        for (int l = 0; l < L; ++l) lists = lists && hcount[l] <= NL.cap[l];
+    } else {
+        for (int l = 0; l < L; ++l) hipLaunchKernelGGL(k_nodes_sample, dim3(grid_for(nodes(l))), dim3(kBlock), 0, st, P, W, l);
+    }
+    if (lists) {
+        auto lp = [&](int l) { return (const uint32_t *)c->post_list[l].p; };
+        for (int l = 0; l < L - 1; ++l) hipLaunchKernelGGL(k_nodes_bubble, dim3(grid_for(hcount[l + 1])), dim3(kBlock), 0, st, P, W, l, lp(l + 1), (size_t)hcount[l + 1]);
+        for (int l = 0; l < L - 1; ++l) hipLaunchKernelGGL(k_nodes_finish, dim3(grid_for(hcount[l])), dim3(kBlock), 0, st, P, W, l, lp(l), (size_t)hcount[l]);
+        for (int l = 0; l < L; ++l) hipLaunchKernelGGL(k_nodes_normalize, dim3(grid_for(hcount[l])), dim3(kBlock), 0, st, P, W, l, lp(l), (size_t)hcount[l]);
+        for (int l = L - 2; l >= 0; --l) hipLaunchKernelGGL(k_nodes_distribute, dim3(grid_for(hcount[l])), dim3(kBlock), 0, st, P, W, l, lp(l), (size_t)hcount[l]);
+    } else {
+        for (int l = 0; l < L - 1; ++l) hipLaunchKernelGGL(k_nodes_bubble, dim3(grid_for(nodes(l + 1))), dim3(kBlock), 0, st, P, W, l, (const uint32_t *)nullptr, (size_t)0);
+        for (int l = 0; l < L - 1; ++l) hipLaunchKernelGGL(k_nodes_finish, dim3(grid_for(nodes(l))), dim3(kBlock), 0, st, P, W, l, (const uint32_t *)nullptr, (size_t)0);
+        for (int l = 0; l < L; ++l) hipLaunchKernelGGL(k_nodes_normalize, dim3(grid_for(nodes(l))), dim3(kBlock), 0, st, P, W, l, (const uint32_t *)nullptr, (size_t)0);
+        for (int l = L - 2; l >= 0; --l) hipLaunchKernelGGL(k_nodes_distribute, dim3(grid_for(nodes(l))), dim3(kBlock), 0, st, P, W, l, (const uint32_t *)nullptr, (size_t)0);
+    }
     AVS_HIP(hipGetLastError());
     float *outs[3] = {out_x, out_y, out_z};
     const bool padded = c->desc.field_nx != c->desc.nx || c->desc.field_ny != c->desc.ny || c->desc.field_nz != c->desc.nz;
@@ -674,7 +769,9 @@ static avs_status transfer_impl(avs_ctx *c, float *out_x, float *out_y, float *o
     if (n) hipLaunchKernelGGL(k_unscatter_velocity, dim3(grid_for((size_t)n)), dim3(kBlock), 0, st, P, W, c->vdof.p, n);
     AVS_HIP(hipGetLastError());
     AVS_HIP(hipStreamSynchronize(st));
+    c->post_lists_valid = lists; // (the lists name every node whose label / values are non-zero now)
     for (int l = 0; l < L; ++l) { // what the staging grids hold now (see post_vel_zero / post_nodes_sparse)
+        c->post_list_n[l] = hcount[l];
         c->post_nodes_sparse[l] = c->post_nlab[l].p;
         for (int a = 0; a < 3; ++a) c->post_vel_zero[l][a] = c->post_vel[l][a].p;
     }
