@@ -174,7 +174,7 @@ def cpu_baseline(solver, tol, budget_s, asm_scene=None):
 _COUNTERS = None
 
 
-def counter_record(n, nnz, brick, bpn, tile_tables):
+def counter_record(n, nnz, brick, bpn, tile_tables, f32=False):
     """PMC record of this workload's SpMV kernel taken with THIS source tree (profiles/spmv_counters.json, written by
     tools/profile_r05.sh from separate rocprofv3 --pmc passes), else None: counters of another binary describe another kernel."""
     global _COUNTERS
@@ -189,7 +189,7 @@ def counter_record(n, nnz, brick, bpn, tile_tables):
             _COUNTERS = []
     for r in _COUNTERS:
         if (r.get("n") == n and r.get("nnz") == nnz and bool(r.get("brick", False)) == bool(brick) and r.get("bytes_per_nonzero", 12) == bpn
-                and bool(r.get("tile_local_tables", False)) == bool(tile_tables)):
+                and bool(r.get("tile_local_tables", False)) == bool(tile_tables) and bool(r.get("f32", False)) == bool(f32)):
             return r
     return None
 
@@ -214,9 +214,10 @@ def spmv_roofline(n, nnz, fmt, mean_spmv_ms, kernel=None, rows_local=None, nnz_l
     alg = 12 * zl + 4 * (nl + 1) + 16 * nl
     bpn = int(fmt.bytes_per_nonzero)
     brick = int(getattr(fmt, "brick_tiles", 0)) > 0
-    stored = stored_bytes_of(nl, zl, fmt)
+    f32 = bool(kernel) and "float" in kernel          # the float-vector loop's kernels (AVS_PRECISION_F32): x and y are 4-B elements
+    stored = stored_bytes_of(nl, zl, fmt) - (8 * nl if f32 else 0)
     t = mean_spmv_ms * 1e-3
-    rec = counter_record(n, nnz, brick, bpn, int(fmt.tile_local_tables)) if rows_local is None else None
+    rec = counter_record(n, nnz, brick, bpn, int(fmt.tile_local_tables), f32) if rows_local is None else None
     traffic = rec.get("hbm_bytes_per_launch") if rec else None
     phys = traffic if traffic else stored
     achieved = phys / t / 1e9 if t > 0 else 0.0
