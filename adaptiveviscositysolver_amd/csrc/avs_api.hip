@@ -107,7 +107,7 @@ Options options_from_env()
         (void)sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &k.tile, &k.row, &k.run, &k.word, &k.etile, &k.quad);
     }
     o.fuse_beta = env_int("AVS_PCG_FUSE_BETA", 1) != 0;
-    o.f32_vectors = env_int("AVS_F32_VECTORS", 1) != 0;
+    { const int v = env_int("AVS_F32_VECTORS", -1); o.f32_vectors = v < 0 ? -1 : (v > 0 ? 1 : 0); }
     o.prepass_temporal = env_int("AVS_PREPASS_TEMPORAL", 1) != 0;
     o.resident_cus = env_int("AVS_CG_RESIDENT_CUS", 0);
     o.resident_equal_lanes = getenv("AVS_CG_RESIDENT_EQUAL_LANES") != nullptr;
@@ -614,7 +614,7 @@ static CsrView csr_of(avs_ctx *c)
     if (c->reordered) c->vi.apply(A);
     A.no_precond = c->no_precond;
     A.brick = (c->reordered && c->brick.ready) ? &c->brick_view : nullptr;
-    A.f32_vectors = (c->desc.precision == AVS_PRECISION_F32 && c->opt.f32_vectors) ? 1 : 0;
+    A.f32_vectors = c->desc.precision == AVS_PRECISION_F32 ? c->opt.f32_vectors : 0;
     return A;
 }
 
@@ -647,7 +647,7 @@ avs_status avs_set_solver_option(avs_ctx *c, avs_solver_option option, int32_t v
         return AVS_OK;
     case AVS_OPTION_FUSED_SCALAR_STEPS: c->opt.fuse_beta = value != 0; return AVS_OK;
     case AVS_OPTION_RELOAD_ENVIRONMENT: c->opt = options_from_env(); c->brick_verdict_rows = 0; return AVS_OK;
-    case AVS_OPTION_F32_VECTORS: c->opt.f32_vectors = value != 0; return AVS_OK;
+    case AVS_OPTION_F32_VECTORS: c->opt.f32_vectors = value < 0 ? -1 : (value > 0 ? 1 : 0); return AVS_OK;
     }
     set_error("unknown solver option %d", (int)option);
     return AVS_EINVAL;

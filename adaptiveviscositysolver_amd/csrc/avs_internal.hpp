@@ -102,8 +102,10 @@ struct Options {
     // single-GPU loop
     int fuse_beta = 1;
     int prepass_temporal = 1;    // AVS_PREPASS_TEMPORAL: the device pre-pass skips what its allocations already hold from their last filling (0: every run fills everything)
-    int f32_vectors = 1;         // AVS_F32_VECTORS: AVS_PRECISION_F32 contexts iterate on float vectors with float scalars (what Eigen's float CG does);
-                                 // 0: fp64 iteration on the float system
+    int f32_vectors = -1;        // AVS_F32_VECTORS: AVS_PRECISION_F32 contexts iterate on float vectors with float scalars (what Eigen's float CG does):
+                                 // 1 always, 0 never (fp64 iteration on the float system), -1 auto: where the system is too large for the
+                                 // CU-resident loop (there the vectors' bandwidth is what an iteration costs; a system that fits the chip is
+                                 // solved faster by the resident fp64 loop: 128^3 beam 54 k against 29 k it/s)
     // CU-resident loop: tuning and test switches
     int resident_cus = 0, resident_equal_lanes = 0, resident_max_global = 3, resident_max_quads = 0, resident_no_stream = 0;
     long long resident_remap_chunk = 0;
@@ -349,7 +351,8 @@ struct CsrView {
     int no_precond = 0; // AVS_PRECONDITIONER_NONE: the inverse diagonal the loops multiply with is 1 everywhere
     bool keep_cached = false; // the matrix words are small enough to stay in the Infinity Cache between two products: plain loads
     const struct BrickView *brick = nullptr; // host pointer: the brick-structured form of this matrix (single-GPU launch-per-phase loop)
-    int f32_vectors = 0; // AVS_PRECISION_F32: the values are floats; the single-GPU solve iterates on float vectors (avs_pcg_f32.inl)
+    int f32_vectors = 0; // AVS_PRECISION_F32: the values are floats; the single-GPU solve iterates on float vectors (avs_pcg_f32.inl): 1 always,
+                         // -1 where the CU-resident loop does not take the system, 0 never
 };
 constexpr int kCwinOffBits = 14, kCwinSlotBits = 6, kCwinSlots = 1 << kCwinSlotBits, kCwinCodeBits = 32 - kCwinOffBits - kCwinSlotBits;
 

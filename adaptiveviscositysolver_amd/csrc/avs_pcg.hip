@@ -2093,12 +2093,13 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
     }
     if (dist && dist_wants_single_reduction(dist))
         return pcg_solve_single_reduction(w, A, b, x, tol, max_iters, stream, info, dist);
-    if (!dist && A.f32_vectors) return pcg_solve_f32(w, A, b, x, tol, max_iters, stream, info); // AVS_PRECISION_F32: float vectors and scalars
+    if (!dist && A.f32_vectors > 0) return pcg_solve_f32(w, A, b, x, tol, max_iters, stream, info); // AVS_PRECISION_F32: float vectors and scalars
     if (!dist && resident_wanted(false)) { // systems that fit on the chip (<= ~1 M rows, packed form): one cooperative launch
         bool ran = false;
         const avs_status rs = pcg_solve_resident_single(w, A, b, x, tol, max_iters, stream, info, &ran);
         if (ran || rs != AVS_OK) return rs;
     }
+    if (!dist && A.f32_vectors < 0) return pcg_solve_f32(w, A, b, x, tol, max_iters, stream, info); // (auto: the resident loop did not take it)
     if (A.brick && A.brick->ntiles > 0) { // one partial per wave of every tile: tiles may be smaller than 512 rows
         const size_t need = 2 * ((size_t)A.brick->ntiles * 8 + 16) + 4 * (size_t)kVecGrid + 16;
         if (need > w->npartial) {

@@ -125,7 +125,7 @@ class ViscositySolve:
         """avs_set_solver_option: e.g. (capi.OPTION_PRECONDITIONER, capi.PRECONDITIONER_NONE) = plain CG (cpp:638-642)."""
         capi.check(self.lib.avs_set_solver_option(self.h, int(option), int(value)))
         if int(option) == capi.OPTION_F32_VECTORS:
-            self.f32_vectors_off = not value
+            self.f32_vectors_off = int(value) == 0
 
     # ---- hot path -------------------------------------------------------------------------
     def build_stencils(self):

@@ -751,9 +751,7 @@ def main():
                 torch.cuda.empty_cache()
             # the headline workload as the reference built with USESINGLEPRECISION runs it (util.h:25-37): float system, float vectors and scalars
             for label, make in (("fat_beam 512^3, 4 levels, uniform viscosity, SolveType = fpreal32 (AVS_PRECISION_F32: float-vector loop, k_spmv_brick<float>)",
-                                 lambda: scenes.fat_beam(512, 4, device=dev)),
-                                ("config 2 as SolveType = fpreal32: fat_beam 128^3, 3 levels (float-vector loop, streaming float SpMV)",
-                                 lambda: scenes.fat_beam(128, 3, device=dev))):
+                                 lambda: scenes.fat_beam(512, 4, device=dev)),):
                 try:
                     extras.append(extra_workload(label, make(), local_rank, a.tol, a.max_iters, precision=1))
                 except Exception as e:

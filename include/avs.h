@@ -93,10 +93,11 @@ typedef struct {
      * reference builds with USESINGLEPRECISION (util.h:25-37: SolveType = fpreal32): every triplet narrowed to float where
      * Eigen::Triplet<SolveType> is constructed (cpp:2447, 2768), duplicates summed in float (setFromTriplets, cpp:613-614), the
      * right-hand side updated in float steps (cpp:2456, 2772), the initial guess narrowed at its store (cpp:2371).  Matrix, rhs and
-     * x0 are then float VALUES in the same fp64 arrays.  Single-GPU solves iterate on FLOAT vectors with float scalars, as Eigen's
+     * x0 are then float VALUES in the same fp64 arrays.  Single-GPU solves can iterate on FLOAT vectors with float scalars, as Eigen's
      * float CG does (round 5; dot products: a thread's terms in float, everything across threads in double -- Eigen's vectorised
-     * reduction order is not reproduced); partitioned solves, and single-GPU ones with AVS_OPTION_F32_VECTORS = 0, iterate in fp64 on
-     * the float system (at least as accurate, same stopping rule).  The solution is a float vector either way (Eigen::VectorXf). */
+     * reduction order is not reproduced): AVS_OPTION_F32_VECTORS = 1 always, -1 (default) for systems the CU-resident loop does not
+     * take; partitioned solves and the other cases iterate in fp64 on the float system (at least as accurate, same stopping rule).
+     * The solution is a float vector either way (Eigen::VectorXf). */
     int32_t precision;
 } avs_desc;
 enum { AVS_PRECISION_F64 = 0, AVS_PRECISION_F32 = 1 };
@@ -193,10 +194,12 @@ typedef enum {
                                    * both forms at the assembly: host-synchronous and not reproducible from run to run); takes effect at the next avs_assemble */
     AVS_OPTION_FUSED_SCALAR_STEPS = 6, /* 1 (default): the CG scalar steps ride in the vector kernels; 0: one reduction launch per step */
     AVS_OPTION_RELOAD_ENVIRONMENT = 7, /* any value: take the AVS_* environment variables again (they are read once, at avs_create; tools and tests) */
-    AVS_OPTION_F32_VECTORS = 8    /* AVS_PRECISION_F32 contexts, single-GPU solves: 1 (default) = the iteration runs on float vectors with float
-                                   * scalars -- SolveType = fpreal32 through Eigen::ConjugateGradient (util.h:25-37, cpp:613-630) --; 0 = fp64
-                                   * iteration on the float system.  Takes effect at the next avs_assemble (the brick form's walk is laid out
-                                   * for the kernel that will run). */
+    AVS_OPTION_F32_VECTORS = 8    /* AVS_PRECISION_F32 contexts, single-GPU solves: 1 = the iteration runs on float vectors with float scalars --
+                                   * SolveType = fpreal32 through Eigen::ConjugateGradient (util.h:25-37, cpp:613-630) --; 0 = fp64 iteration on
+                                   * the float system; -1 (default) = float vectors where the system is too large for the CU-resident loop
+                                   * (the bandwidth of the vectors is what an iteration costs there), the resident fp64 loop where it fits the
+                                   * chip (faster).  Takes effect at the next avs_assemble (the brick form's walk is laid out for the kernel
+                                   * that will run). */
 } avs_solver_option;
 enum { AVS_USE_TRANSPORT_AUTO = 0, AVS_USE_TRANSPORT_RCCL = 1, AVS_USE_TRANSPORT_DIRECT = 2 };
 enum { AVS_BRICK_AUTO = -1, AVS_BRICK_NEVER = 0, AVS_BRICK_ALWAYS = 1, AVS_BRICK_TUNE = 2 };

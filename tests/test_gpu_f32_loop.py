@@ -35,6 +35,7 @@ def _solver(sc, monkeypatch, brick, probe=True):
     s = ViscositySolve(sc.res, sc.dx, sc.dt, pyr.levels, device=0, probe=probe, precision=capi.PRECISION_F32)
     feed(s, pyr)
     s.set_scene_fields(dsc)
+    s.set_solver_option(capi.OPTION_F32_VECTORS, 1)     # always (the default, -1, leaves systems that fit the chip to the CU-resident fp64 loop)
     return s, pyr
 
 
@@ -122,6 +123,23 @@ def test_f32_loop_against_the_oracle_float_cg(name, monkeypatch, built_lib):
     assert i64.converged == 1
     assert e_gpu < max(1.5 * e_orc, 5e-5), (e_gpu, e_orc)        # as close to the float system's solution as Eigen-in-float gets
     assert d < 5e-5 + 2 * e_orc, (d, e_gpu, e_orc)
+    s.close()
+
+
+def test_f32_auto_mode_prefers_the_resident_loop_for_small_systems(monkeypatch, built_lib):
+    """AVS_OPTION_F32_VECTORS = -1 (default): a float system that fits the chip runs the CU-resident fp64 loop (faster there); one that does
+    not runs the float-vector loop"""
+    sc = scenes.fat_beam(64, 3)
+    s, pyr = _solver(sc, monkeypatch, False, probe=False)
+    s.set_solver_option(capi.OPTION_F32_VECTORS, -1)
+    s.assemble()
+    info = s.solve(1e-5, 5000)
+    assert info.converged == 1 and info.resident == 1
+    x = s.solution()
+    assert np.array_equal(x, x.astype(np.float32).astype(np.float64))
+    s.set_solver_option(capi.OPTION_RESIDENT_LOOP, 0)      # no resident loop: auto falls to the float-vector loop
+    i2 = s.solve(1e-5, 5000)
+    assert i2.converged == 1 and i2.resident == 0 and rel_l2(s.solution(), x) < 5e-5
     s.close()
 
 
