@@ -109,6 +109,7 @@ Options options_from_env()
     o.fuse_beta = env_int("AVS_PCG_FUSE_BETA", 1) != 0;
     { const int v = env_int("AVS_F32_VECTORS", -1); o.f32_vectors = v < 0 ? -1 : (v > 0 ? 1 : 0); }
     o.prepass_temporal = env_int("AVS_PREPASS_TEMPORAL", 1) != 0;
+    { const int v = env_int("AVS_POST_DOF_SAMPLE", -1); o.post_dof_sample = v < 0 ? -1 : (v > 0 ? 1 : 0); }
     o.resident_cus = env_int("AVS_CG_RESIDENT_CUS", 0);
     o.resident_equal_lanes = getenv("AVS_CG_RESIDENT_EQUAL_LANES") != nullptr;
     o.resident_max_global = env_int("AVS_CG_RESIDENT_MAX_GLOBAL", 3);

@@ -101,6 +101,8 @@ struct Options {
     BrickCost brick_cost;        // AVS_BRICK_COST=tile,row,run,word,etile,quad
     // single-GPU loop
     int fuse_beta = 1;
+    int post_dof_sample = -1;    // AVS_POST_DOF_SAMPLE: the transfer samples its nodes from the velocity DOFs (1) / by a sweep over the node lattices (0);
+                                 // -1: from the DOFs when the level-0 node lattice has more than 32 x as many nodes as there are DOFs
     int prepass_temporal = 1;    // AVS_PREPASS_TEMPORAL: the device pre-pass skips what its allocations already hold from their last filling (0: every run fills everything)
     int f32_vectors = -1;        // AVS_F32_VECTORS: AVS_PRECISION_F32 contexts iterate on float vectors with float scalars (what Eigen's float CG does):
                                  // 1 always, 0 never (fp64 iteration on the float system), -1 auto: where the system is too large for the

@@ -103,6 +103,25 @@ __global__ __launch_bounds__(kBlock) void k_nodes_clear(PostView W, int l, size_
 }
 
 // T2: interp.cpp:118-188 + 190-286 ------------------------------------------------------------
+// Per-level lists of the nodes T2 labels: the later passes (bubble, finish, normalise, distribute, and the next transfer's clear) walk
+// them instead of sweeping the node lattices.  cap: list capacity per level (an overflowing level keeps count > cap: the caller falls
+// back to sweeps).  One atomic per wave (a counter hit by every labelled node serialises: 18 M same-address atomics took 65 ms).
+struct NodeLists {
+    uint32_t *list[AVS_MAX_LEVELS];
+    unsigned *count; // [levels]
+    unsigned cap[AVS_MAX_LEVELS];
+};
+__device__ __forceinline__ void node_list_append(const NodeLists &NL, int l, size_t o) // called by the lanes that labelled a node of level l (l: wave-uniform)
+{
+    const unsigned long long m = __ballot(1);
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    unsigned base = 0u;
+    if (lane == leader) base = atomicAdd(NL.count + l, (unsigned)__popcll(m));
+    base = __shfl(base, leader, 64);
+    const unsigned at = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    if (at < NL.cap[l]) NL.list[l][at] = (uint32_t)o;
+}
+
 // One node: the twelve faces around it, all indices requested at once (the reference's loops stop at the first SOLIDBOUNDARY / OUTSIDE
 // face, but "active and not inactive" does not depend on the order of the tests).  `my_slot` >= 0 (k_nodes_sample_dofs): the caller came
 // from the DOF face in slot fa * 4 + fi and goes on only when that is the FIRST DOF face of the node -- so that exactly one of the up to
@@ -157,7 +176,8 @@ __device__ __forceinline__ bool sample_node(const PyramidView &P, const PostView
     return true;
 }
 
-__global__ __launch_bounds__(kBlock) void k_nodes_sample(PyramidView P, PostView W, int l)
+// (`NL.count` != null: the labelled nodes are listed)
+__global__ __launch_bounds__(kBlock) void k_nodes_sample(PyramidView P, PostView W, int l, NodeLists NL)
 {
     const I3 nr = node_res(P, l);
     const size_t total = (size_t)nr[0] * nr[1] * nr[2];
@@ -178,21 +198,17 @@ __global__ __launch_bounds__(kBlock) void k_nodes_sample(PyramidView P, PostView
             }
             if (!any_active) continue; // labels / values / weights / flags were zero-filled
         }
-        (void)sample_node(P, W, l, node, o, weight, -1);
+        if (sample_node(P, W, l, node, o, weight, -1) && NL.count) node_list_append(NL, l, o);
     }
 }
 
-// The same pass driven by the velocity DOFs (round 5): a node can only be active when one of its twelve faces is a DOF, i.e. when it is a
-// corner of a DOF face of its level -- so one thread per (DOF, corner) reaches every candidate, instead of one thread per node of every
-// level (1.07 G nodes at level 0 of a 1024^3 grid for a sheet with 18 M DOFs).  Of the threads that reach a node the one that came from
-// its first DOF face labels it, and appends it to the level's list: the later passes (bubble, finish, normalise, distribute, and the
-// next transfer's clear) then walk the lists instead of sweeping the node lattices.  Same arithmetic per node, nodes are independent:
-// same node grids, bit for bit.  cap: list capacity per level (an overflowing level keeps count > cap: the caller falls back to sweeps).
-struct NodeLists {
-    uint32_t *list[AVS_MAX_LEVELS];
-    unsigned *count; // [levels]
-    unsigned cap[AVS_MAX_LEVELS];
-};
+// The same pass driven by the velocity DOFs (round 5), for VERY sparse scenes: a node can only be active when one of its twelve faces is
+// a DOF, i.e. when it is a corner of a DOF face of its level -- so one thread per (DOF, corner) reaches every candidate, instead of one
+// thread per node of every level.  Of the threads that reach a node the one that came from its first DOF face labels it (no atomics on
+// the data path).  Same arithmetic per node, nodes are independent: same node grids, bit for bit.  A visit costs twelve index gathers, a
+// node the sweep rejects eight 1-byte label reads: measured, the two are equal at 18 nodes per DOF (512^3 beam: transfer 7.6 ms either
+// way) and the DOF-driven pass wins at 58 (1024^3 sheet with 18 M DOFs: 21.4 against 22.9 ms, 12.0 against 13.5 in place): it is
+// taken from 32 nodes per DOF on (AVS_POST_DOF_SAMPLE=0 / 1 forces either).
 __global__ __launch_bounds__(kBlock) void k_nodes_sample_dofs(PyramidView P, PostView W, const int32_t *__restrict__ vdof, int64_t n, NodeLists NL)
 {
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -212,19 +228,8 @@ __global__ __launch_bounds__(kBlock) void k_nodes_sample_dofs(PyramidView P, Pos
         const double weight = (double)(1 << (P.levels - l - 1));
         won = sample_node(P, W, l, node, o, weight, fa * 4 + (3 - c)); // (node_to_face: slot fi of the node is the face at corner 3 - fi)
     }
-    // one atomic per wave and level (a counter hit by every labelled node serialises: 18 M same-address atomics took 65 ms)
-    const int lane = threadIdx.x & 63;
-    for (int q = 0; q < P.levels; ++q) {
-        const unsigned long long m = __ballot(won && l == q);
-        if (m == 0ull) continue;
-        unsigned base = 0u;
-        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(NL.count + q, (unsigned)__popcll(m));
-        base = __shfl(base, __ffsll((long long)m) - 1, 64);
-        if (won && l == q) {
-            const unsigned at = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-            if (at < NL.cap[q]) NL.list[q][at] = (uint32_t)o;
-        }
-    }
+    for (int q = 0; q < P.levels; ++q) // (a wave's lanes may belong to different levels: one round per level present)
+        if (won && l == q) node_list_append(NL, q, o);
 }
 
 // T3: interp.cpp:288-355; one thread per node of level l+1 (its co-located child is node 2*p) ------
@@ -697,8 +702,8 @@ static avs_status transfer_impl(avs_ctx *c, float *out_x, float *out_y, float *o
     const int64_t n = c->n_vel;
     if (n) hipLaunchKernelGGL(k_scatter_velocity, dim3(grid_for((size_t)n)), dim3(kBlock), 0, st, P, W, c->vdof.p, n, c->x.p);
     auto nodes = [&](int l) { return (size_t)((c->desc.nx >> l) + 1) * ((c->desc.ny >> l) + 1) * ((c->desc.nz >> l) + 1); };
-    // T2: driven by the velocity DOFs, with a list of the labelled nodes per level (k_nodes_sample_dofs); the sweeps over the node
-    // lattices remain for a context without DOFs, node lattices beyond 2^32 entries, a list that overflows, or AVS_PREPASS_TEMPORAL=0
+    // T2 lists the nodes it labels, per level, and the later passes walk the lists; sweeps over the node lattices remain for a context
+    // without DOFs, node lattices beyond 2^32 entries, a list that overflows, or AVS_PREPASS_TEMPORAL=0
     bool lists = temporal && n > 0 && nodes(0) < (1ull << 32);
     c->post_lists_valid = false;
     unsigned hcount[AVS_MAX_LEVELS] = {};
@@ -713,12 +718,16 @@ static avs_status transfer_impl(avs_ctx *c, float *out_x, float *out_y, float *o
             NL.list[l] = c->post_list[l].p;
             NL.cap[l] = (unsigned)(c->post_list[l].n < (1ull << 32) - 1 ? c->post_list[l].n : (1ull << 32) - 1);
         }
-        hipLaunchKernelGGL(k_nodes_sample_dofs, dim3(grid_for((size_t)(4 * n), 1u << 30)), dim3(kBlock), 0, st, P, W, c->vdof.p, n, NL);
+        const int ds = c->opt.post_dof_sample;
+        if (ds > 0 || (ds < 0 && nodes(0) >= (size_t)32 * (size_t)n)) // sparse: from the DOFs
+            hipLaunchKernelGGL(k_nodes_sample_dofs, dim3(grid_for((size_t)(4 * n), 1u << 30)), dim3(kBlock), 0, st, P, W, c->vdof.p, n, NL);
+        else
+            for (int l = 0; l < L; ++l) hipLaunchKernelGGL(k_nodes_sample, dim3(grid_for(nodes(l))), dim3(kBlock), 0, st, P, W, l, NL);
         AVS_HIP(hipMemcpyAsync(hcount, c->post_list_count.p, sizeof(hcount), hipMemcpyDeviceToHost, st));
         AVS_HIP(hipStreamSynchronize(st));
         for (int l = 0; l < L; ++l) lists = lists && hcount[l] <= NL.cap[l];
     } else {
-        for (int l = 0; l < L; ++l) hipLaunchKernelGGL(k_nodes_sample, dim3(grid_for(nodes(l))), dim3(kBlock), 0, st, P, W, l);
+        for (int l = 0; l < L; ++l) hipLaunchKernelGGL(k_nodes_sample, dim3(grid_for(nodes(l))), dim3(kBlock), 0, st, P, W, l, NodeLists{});
     }
     if (lists) {
         auto lp = [&](int l) { return (const uint32_t *)c->post_list[l].p; };

@@ -170,14 +170,17 @@ def test_non_power_of_two_simulation_grid(n, fres, levels, center, half, built_l
     pp.close()
 
 
-def test_transfer_staging_grids_are_reused_sparsely(built_lib):
-    """Round 5: the transfer no longer zero-fills its staging grids every call -- the scattered face values are zeroed at the end of a
+@pytest.mark.parametrize("dof_sample", ["0", "1"])
+def test_transfer_staging_grids_are_reused_sparsely(dof_sample, monkeypatch, built_lib):
+    """(dof_sample: the node sampling as a sweep that lists the nodes it labels / driven by the velocity DOFs, AVS_POST_DOF_SAMPLE)
+    Round 5: the transfer no longer zero-fills its staging grids every call -- the scattered face values are zeroed at the end of a
     transfer, node labels / values are cleared where the previous transfer labelled nodes (avs_post.hip).  One context through a sequence
     of DIFFERENT frames (a new pyramid of the same level count lent by the pre-pass each time, two transfers per frame) must give what the
     oracle gives for every frame: node grids and output bit for bit."""
     dev = torch.device("cuda:0")
     frames = [lambda d: scenes.fat_beam(64, 3, device=d), lambda d: scenes.sphere(64, 3, device=d),
               lambda d: scenes.fat_beam(64, 3, wall=True, device=d), lambda d: scenes.tank(64, 3, device=d), lambda d: scenes.fat_beam(64, 3, device=d)]
+    monkeypatch.setenv("AVS_POST_DOF_SAMPLE", dof_sample)
     pp = DevicePrepass((64, 64, 64), frames[0]("cpu").dx, 3)
     s = None
     for k, make in enumerate(frames):
