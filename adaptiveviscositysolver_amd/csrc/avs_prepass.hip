@@ -595,12 +595,28 @@ __global__ __launch_bounds__(kBlock) void k_classify_edges(ClassifyArgs A, Grid3
     }
 }
 
-// classifyCenterStressesPartial, cpp:1407-1443
-__global__ __launch_bounds__(kBlock) void k_classify_centers(const int8_t *__restrict__ lab, const float *__restrict__ centerw, int level,
-                                                             size_t n, int32_t *__restrict__ out)
+// classifyCenterStressesPartial, cpp:1407-1443.  Round 5: the centre lattice by tiles, like the others.  A centre DOF needs an ACTIVE cell, and k_mark_tiles_all flags, for every ACTIVE
+// cell c, the tile of edge c of the axis-0 edge lattice -- whose tile COORDINATES are the cell's (c / 16 per axis; only the tile grid's
+// extents differ): the cell tiles with that flag are a superset of the tiles with a centre DOF, every other tile is AVS_UNASSIGNED
+// throughout (reset sparsely like the index lattices, not read by the numbering).
+__global__ __launch_bounds__(kBlock) void k_center_tiles(const uint8_t *__restrict__ occ_edge0, TileGrid te, TileGrid tc, uint8_t *__restrict__ occ_c)
 {
-    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < n; o += (size_t)gridDim.x * kBlock)
+    const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= tc.vol()) return;
+    const int tx = (int)(t % tc.tr[0]), ty = (int)((t / tc.tr[0]) % tc.tr[1]), tz = (int)(t / ((size_t)tc.tr[0] * tc.tr[1]));
+    occ_c[t] = occ_edge0[(size_t)tx + (size_t)te.tr[0] * ((size_t)ty + (size_t)te.tr[1] * (size_t)tz)];
+}
+__global__ __launch_bounds__(kBlock) void k_classify_centers_tiled(const int8_t *__restrict__ lab, const float *__restrict__ centerw, int level, Grid3 cg,
+                                                                   TileGrid tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out)
+{
+    if (!occ[blockIdx.x]) return;
+    const int tile_x = blockIdx.x % tg.tr[0], tile_y = (blockIdx.x / tg.tr[0]) % tg.tr[1], tile_z = blockIdx.x / (tg.tr[0] * tg.tr[1]);
+    const int i = tile_x * kTile + (threadIdx.x & (kTile - 1)), j = tile_y * kTile + (threadIdx.x >> 4);
+    if (i >= cg.r[0] || j >= cg.r[1]) return;
+    for (int z = 0; z < kTile && tile_z * kTile + z < cg.r[2]; ++z) {
+        const size_t o = lin3(cg, i, j, tile_z * kTile + z);
         out[o] = (lab[o] == AVS_ACTIVE && (level != 0 || centerw[o] > 0.f)) ? 0 : AVS_UNASSIGNED;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -736,7 +752,7 @@ struct avs_prepass {
     DevBuf<int32_t> work_list;   // k_brick_triage: [0] = count, then the bricks k_sdf_weights_far has to look at
     // temporal reuse: what an ALLOCATION (SharedBuf::id) holds since it was last filled
     struct TileState { uint64_t id = 0; DevBuf<uint8_t> occ; };          // index lattice: the tiles its classification visited
-    TileState vstate[AVS_MAX_LEVELS][3][2], estate[AVS_MAX_LEVELS][3][2], rstate[3][2];
+    TileState vstate[AVS_MAX_LEVELS][3][2], estate[AVS_MAX_LEVELS][3][2], rstate[3][2], cstate[AVS_MAX_LEVELS][2];
     struct BrickState { uint64_t ids[7] = {}; DevBuf<uint8_t> st; };     // weight lattices: k_sdf_weights_far's per-brick record
     BrickState wstate[2];
     SharedBuf<int32_t> dof[3];                 // dof tables written by the numbering pass (velocity, edge, centre), lent with the lattices
@@ -1036,12 +1052,12 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     // are kept for the regular-grid classification below, which uses the same rule on the same lattices)
     const size_t occ_cap = (size_t)(d.nx / kTile + 2) * (size_t)(d.ny / kTile + 2) * (size_t)(d.nz / kTile + 2);
     DevBuf<uint8_t> occ_all; // [level][kind][axis][occ_cap]: kept until the numbering, which skips the tiles nobody visited
-    AVS_TRY(occ_all.alloc((size_t)capped * 6 * occ_cap));
+    AVS_TRY(occ_all.alloc((size_t)capped * 7 * occ_cap));
     TileGrid tg0[3];
     for (int l = 0; l < capped; ++l) {
         int cr[3];
         pp_res(d, 2, l, 0, cr);
-        uint8_t *ob = occ_all.p + (size_t)l * 6 * occ_cap;
+        uint8_t *ob = occ_all.p + (size_t)l * 7 * occ_cap; // six lattices + the cell tiles (slot 6)
         TileSets T;
         for (int kind = 0; kind < 2; ++kind)
             for (int a = 0; a < 3; ++a) {
@@ -1051,7 +1067,7 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
                 T.occ[kind][a] = ob + (size_t)(kind * 3 + a) * occ_cap;
                 if (l == 0 && kind == 0) tg0[a] = T.tg[kind][a];
             }
-        AVS_HIP(hipMemsetAsync(ob, 0, 6 * occ_cap, st));
+        AVS_HIP(hipMemsetAsync(ob, 0, 7 * occ_cap, st));
         hipLaunchKernelGGL(k_mark_tiles_all, dim3(grid_for(g3(cr).vol())), dim3(kBlock), 0, st, p->labels[l].p, l == 0 ? p->liquid.p : nullptr, occ_sdf,
                            g3(cr), T);
         for (int a = 0; a < 3; ++a) {
@@ -1083,7 +1099,17 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         }
         AVS_TRY(p->cidx[l].alloc(g3(cr).vol()));
         if (g3(cr).vol() > max_vol) max_vol = g3(cr).vol();
-        hipLaunchKernelGGL(k_classify_centers, dim3(grid_for(g3(cr).vol())), dim3(kBlock), 0, st, p->labels[l].p, p->centerw.p, l, g3(cr).vol(), p->cidx[l].p);
+        {
+            const TileGrid tc{{(cr[0] + kTile - 1) / kTile, (cr[1] + kTile - 1) / kTile, (cr[2] + kTile - 1) / kTile}};
+            uint8_t *occ_c = ob + 6 * occ_cap;
+            hipLaunchKernelGGL(k_center_tiles, dim3(grid_for(tc.vol())), dim3(kBlock), 0, st, (const uint8_t *)T.occ[1][0], T.tg[1][0], tc, occ_c);
+            avs_prepass::TileState *ts = nullptr;
+            AVS_TRY(unassign_lattice(p, p->cidx[l], g3(cr), tc, occ_cap, p->cstate[l], &ts));
+            hipLaunchKernelGGL(k_classify_centers_tiled, dim3((unsigned)tc.vol()), dim3(kBlock), 0, st, p->labels[l].p, p->centerw.p, l, g3(cr), tc,
+                               (const uint8_t *)occ_c, p->cidx[l].p);
+            AVS_HIP(hipGetLastError());
+            AVS_TRY(remember_tiles(p, ts, p->cidx[l].id, occ_c, occ_cap));
+        }
     }
     for (int a = 0; a < 3; ++a) { // regular-grid faces, cpp:1457-1481
         int gr[3], cr[3];
@@ -1144,7 +1170,7 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
             for (int a = 0; a < (kind == 2 ? 1 : 3); ++a) {
                 int gr[3];
                 pp_res(d, kind, l, a, gr);
-                const uint8_t *oc = kind == 2 ? nullptr : occ_all.p + ((size_t)l * 6 + (size_t)kind * 3 + a) * occ_cap; // centres: no tile rule
+                const uint8_t *oc = occ_all.p + ((size_t)l * 7 + (kind == 2 ? 6 : (size_t)kind * 3 + a)) * occ_cap; // (centres: the cell tiles with an ACTIVE cell, k_center_tiles)
                 AVS_TRY(number(kind == 0 ? p->vidx[l][a].p : (kind == 1 ? p->eidx[l][a].p : p->cidx[l].p), gr, kind, oc, l | (a << 8)));
             }
     for (int a = 0; a < 3; ++a) { // regular grid: one counter over the three axes, cpp:1486-1509
