@@ -1,5 +1,6 @@
+# Kernel stats of one frame loop of the 1024^3 thin sheet (BASELINE configs[4]): two pre-pass runs, apply, two assemblies, 2 solves, 4 transfers (rocprofv3 --kernel-trace --stats)
 cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && O=$R/gpurun_out/c5prof && mkdir -p $O
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o c5 -- python $R/bench.py --config 5 --no-cpu-baseline --no-extra --steps 1 --warmup 0 > $O/stats.log 2>&1; echo "rc=$?"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o c5 -- python $R/bench.py --config 5 --no-cpu-baseline --no-extra --steps 1 --warmup 1 > $O/stats.log 2>&1; echo "rc=$?"
 f=$(ls $O/stats/*/c5_kernel_stats.csv $O/stats/c5_kernel_stats.csv 2>/dev/null | head -1); cp "$f" $O/c5_kernel_stats.csv
 rm -rf $O/stats
 python - <<'PY'
