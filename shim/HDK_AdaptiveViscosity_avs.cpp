@@ -28,6 +28,9 @@
 #include <cstring>
 #include <atomic>
 #include <chrono>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -95,16 +98,29 @@ int next_pow2(int v)
     return p;
 }
 
-// RAII for the two library handles
+// The two library handles, KEPT from substep to substep (round 5): avs_prepass_apply lends the pre-pass's lattices to the context
+// instead of copying them, and an avs_prepass object that lives across frames skips what its allocations already hold from the
+// previous frame (weight bricks far from the surface, index tiles outside the last occupancy) -- both only pay off when the objects
+// survive the call.  One set per solver node (keyed by the node's address; released when the geometry of the grids changes, and by
+// clearCache() when the plugin unloads).  A fresh pair per call, as before, is still correct: only slower.
 struct Handles {
     avs_prepass *pp = nullptr;
     avs_ctx *ctx = nullptr;
-    ~Handles()
-    {
-        if (ctx) avs_destroy(ctx);
-        if (pp) avs_prepass_destroy(pp);
-    }
+    int oct[3] = {0, 0, 0}, sim[3] = {0, 0, 0}, want_levels = 0, ctx_levels = 0, n_super = 0, enhanced = -1;
+    double dx = 0., extrapolation = 0., dt = 0.;
+    void releaseCtx() { if (ctx) avs_destroy(ctx); ctx = nullptr; ctx_levels = 0; }
+    void release() { releaseCtx(); if (pp) avs_prepass_destroy(pp); pp = nullptr; }
+    ~Handles() { release(); }
 };
+static std::mutex theHandlesLock;
+static std::map<const void *, std::unique_ptr<Handles>> theHandles;
+static Handles &handlesOf(const void *node)
+{
+    std::lock_guard<std::mutex> lk(theHandlesLock);
+    std::unique_ptr<Handles> &h = theHandles[node];
+    if (!h) h.reset(new Handles());
+    return *h;
+}
 
 // Optional frame export for the offline harness (adaptiveviscositysolver_amd/dump.py, examples/hotpath_from_dump.cpp):
 // "AVSDUMP2", nx ny nz levels enhanced field_nx field_ny field_nz (int32), dx dt (f64), n_vel n_edge n_center (int64); per level
@@ -208,7 +224,7 @@ bool HDK_AdaptiveViscosity::solveGasSubclass(SIM_Engine &engine, SIM_Object *obj
     const int oct[3] = {next_pow2(sim[0]), next_pow2(sim[1]), next_pow2(sim[2])}; // HDK_OctreeGrid::init, oct.cpp:10-24
     const double dx = liquid.getVoxelSize().maxComponent();                        // cpp:242
 
-    Handles h;
+    Handles &h = handlesOf(this);
     auto check = [&](avs_status s) {
         if (s == AVS_OK) return true;
         UT_WorkBuffer msg;
@@ -230,7 +246,15 @@ bool HDK_AdaptiveViscosity::solveGasSubclass(SIM_Engine &engine, SIM_Object *obj
         pd.n_super = getNumberSuperSamples();
         pd.extrapolation_scale = getExtrapolation();
         pd.device = 0;
-        if (!check(avs_prepass_create(&pd, &h.pp))) return false;
+        const bool same_grid = h.pp && h.oct[0] == oct[0] && h.oct[1] == oct[1] && h.oct[2] == oct[2] && h.sim[0] == sim[0] && h.sim[1] == sim[1] &&
+                               h.sim[2] == sim[2] && h.dx == dx && h.want_levels == pd.desired_levels && h.n_super == pd.n_super &&
+                               h.extrapolation == pd.extrapolation_scale;
+        if (!same_grid) { // a new grid (first substep, resized simulation box, changed parameters): new objects
+            h.release();
+            if (!check(avs_prepass_create(&pd, &h.pp))) return false;
+            for (int a = 0; a < 3; ++a) { h.oct[a] = oct[a]; h.sim[a] = sim[a]; }
+            h.dx = dx; h.want_levels = pd.desired_levels; h.n_super = pd.n_super; h.extrapolation = pd.extrapolation_scale;
+        }
         const Flat liquid_sdf = flatten(liquid), solid_sdf = flatten(*collision->getField());
         std::vector<float> liquid_dense, solid_dense; // the pre-pass wants dense SDFs
         auto dense = [&](const Flat &f, std::vector<float> &store) -> const float * {
@@ -256,7 +280,14 @@ bool HDK_AdaptiveViscosity::solveGasSubclass(SIM_Engine &engine, SIM_Object *obj
     d.precision = AVS_PRECISION_F32;
 #endif
     d.device = 0;
-    if (!check(avs_create(&d, &h.ctx))) return false;
+    // a context is created for one octree depth and one timestep (avs_desc): another depth this frame, or another substep length, re-creates it
+    if (h.ctx && (h.ctx_levels != pinfo.levels || h.enhanced != d.use_enhanced_gradients || h.dt != d.dt)) h.releaseCtx();
+    if (!h.ctx) {
+        if (!check(avs_create(&d, &h.ctx))) return false;
+        h.ctx_levels = pinfo.levels;
+        h.enhanced = d.use_enhanced_gradients;
+        h.dt = d.dt;
+    }
     if (!check(avs_prepass_apply(h.pp, h.ctx))) return false;  // labels, index pyramids, counts, centre / edge weights, regular indices
     const Flat visc = flatten(*viscosity->getField()), dens = flatten(*density->getField());
     Flat fw[3], vel[3], svel[3];
