@@ -17,6 +17,7 @@
 // parent cell), deterministic (the only atomic appends surface bricks to a list whose order does not matter).  All integer
 // outputs are bit-identical to the oracle and to the tensor-op restatement tests/prepass_torch.py (tests/test_gpu_prepass.py).
 #include <cmath>
+#include <climits>
 #include <new>
 
 #include "avs_device_common.hpp"
@@ -639,9 +640,9 @@ __device__ __forceinline__ size_t tilemajor_pos(const Grid3 &g, int i, int j, in
 // scan over the tiles -> k_tile_ids: the grid is read twice and written where flagged (12 B per voxel instead of the
 // 28 B of flag array + full-lattice scan + apply).
 __device__ __forceinline__ unsigned tile_flags(const int32_t *__restrict__ grid, const Grid3 &g, int ntx, int nty, size_t *first,
-                                               size_t *zstride)
+                                               size_t *zstride, int tile)
 {
-    const int tile = blockIdx.x, t = threadIdx.x;
+    const int t = threadIdx.x;
     const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
     const int i = tx * kTile + (t & (kTile - 1)), j = ty * kTile + (t >> 4);
     *zstride = (size_t)g.r[0] * g.r[1];
@@ -658,18 +659,50 @@ __device__ __forceinline__ unsigned tile_flags(const int32_t *__restrict__ grid,
     return bits;
 }
 
-__global__ __launch_bounds__(kBlock) void k_tile_counts(const int32_t *__restrict__ grid, Grid3 g, int ntx, int nty,
-                                                        int32_t *__restrict__ tile_count, const uint8_t *__restrict__ occ)
+// Round 5: ALL lattices of one kind in one launch (they used to be numbered one after the other: counts, a three-kernel scan, ids and a
+// base update per lattice -- 370 launches per frame, more time in launch gaps than in the kernels for every grid below 512^3).  The
+// tiles of the lattices are concatenated in numbering order (level-major, then axis), so ONE exclusive scan over the concatenated counts
+// gives every tile the id of its first DOF: the same ids as the sequential numbering, bit for bit.
+constexpr int kNumLattices = 3 * AVS_MAX_LEVELS;
+struct NumLattice {
+    int32_t *grid;
+    const uint8_t *occ; // tile occupancy the lattice was classified with (null: every tile is read)
+    Grid3 g;
+    int ntx, nty, tile0, tag; // tiles per row / column, first tile in the concatenated space, dof-table tag (level | axis << 8)
+};
+struct NumBatch {
+    NumLattice lat[kNumLattices];
+    int count, total_tiles;
+};
+// (the batch lives in device memory: a by-value kernel argument indexed with a run-time index is copied to scratch by every thread;
+// the lattices' first tiles come by value, compared in an unrolled loop on scalar registers: most workgroups belong to tiles without a
+// DOF and must find that out with ONE load -- a search through device memory made the 3 M mostly empty tiles of a 1024^3 batch slower
+// than the 12 separate launches had been)
+struct NumStarts {
+    int tile0[kNumLattices]; // unused entries: INT_MAX
+};
+__device__ __forceinline__ NumLattice batch_lattice(const NumStarts &S, const NumBatch *__restrict__ B, int tile)
 {
+    int li = 0;
+#pragma unroll
+    for (int k = 1; k < kNumLattices; ++k)
+        if (tile >= S.tile0[k]) li = k;
+    return B->lat[li];
+}
+
+__global__ __launch_bounds__(kBlock) void k_tile_counts(NumStarts S, const NumBatch *__restrict__ B, int32_t *__restrict__ tile_count)
+{
+    const NumLattice Lt = batch_lattice(S, B, (int)blockIdx.x);
+    const int tile = (int)blockIdx.x - Lt.tile0;
     // a tile the classification never visited (occupancy flag clear) holds no DOF: not read at all -- on a thin sheet that is
     // nine tiles in ten
-    if (occ && !occ[blockIdx.x]) {
+    if (Lt.occ && !Lt.occ[tile]) {
         if (threadIdx.x == 0) tile_count[blockIdx.x] = 0;
         return;
     }
     __shared__ int red[kBlock / 64];
     size_t first, zs;
-    int cnt = __popc(tile_flags(grid, g, ntx, nty, &first, &zs));
+    int cnt = __popc(tile_flags(Lt.grid, Lt.g, Lt.ntx, Lt.nty, &first, &zs, tile));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
@@ -679,15 +712,17 @@ __global__ __launch_bounds__(kBlock) void k_tile_counts(const int32_t *__restric
 
 // `table` (optional): the dof table of this kind -- record (level | axis << 8, i, j, k) of every id handed out, what the solver context
 // otherwise rebuilds with a sweep over every index lattice (k_dof_table: 5 ms per frame at 1024^3); ids beyond `cap` are not recorded
-// (the table was sized from the previous frame's count: the caller then discards it)
-__global__ __launch_bounds__(kBlock) void k_tile_ids(int32_t *__restrict__ grid, Grid3 g, int ntx, int nty,
-                                                     const int32_t *__restrict__ tile_off, const long long *__restrict__ base,
-                                                     int32_t *__restrict__ table = nullptr, long long cap = 0, int tag = 0)
+// (the table was sized from the previous frame's count: the caller then discards it).  total: where the kind's DOF count goes.
+__global__ __launch_bounds__(kBlock) void k_tile_ids(NumStarts S, const NumBatch *__restrict__ B, const int32_t *__restrict__ tile_off,
+                                                     int32_t *__restrict__ table, long long cap, long long *__restrict__ total, int total_tiles)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *total = (long long)tile_off[total_tiles];
     if (tile_off[blockIdx.x + 1] == tile_off[blockIdx.x]) return; // no DOF in this tile: nothing to read, nothing to write
+    const NumLattice Lt = batch_lattice(S, B, (int)blockIdx.x);
+    const int tile = (int)blockIdx.x - Lt.tile0;
     __shared__ int cnt[kTile * (kBlock / 64)]; // flagged voxels of (step z, wave w), then their exclusive prefix
     size_t first, zs;
-    const unsigned bits = tile_flags(grid, g, ntx, nty, &first, &zs);
+    const unsigned bits = tile_flags(Lt.grid, Lt.g, Lt.ntx, Lt.nty, &first, &zs, tile);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long below[kTile]; // ballot of step z restricted to the lanes below this one
 #pragma unroll
@@ -709,21 +744,16 @@ __global__ __launch_bounds__(kBlock) void k_tile_ids(int32_t *__restrict__ grid,
     }
     __syncthreads();
     if (!bits) return;
-    const int32_t id0 = (int32_t)*base + tile_off[blockIdx.x];
-    const int ti = (blockIdx.x % ntx) * kTile + (threadIdx.x & (kTile - 1)), tj = ((blockIdx.x / ntx) % nty) * kTile + (threadIdx.x >> 4);
-    const int tk = (blockIdx.x / (ntx * nty)) * kTile;
+    const int32_t id0 = tile_off[blockIdx.x];
+    const int ti = (tile % Lt.ntx) * kTile + (threadIdx.x & (kTile - 1)), tj = ((tile / Lt.ntx) % Lt.nty) * kTile + (threadIdx.x >> 4);
+    const int tk = (tile / (Lt.ntx * Lt.nty)) * kTile;
 #pragma unroll
     for (int z = 0; z < kTile; ++z)
         if ((bits >> z) & 1u) {
             const int32_t id = id0 + cnt[z * (kBlock / 64) + wave] + __popcll(below[z]);
-            grid[first + (size_t)z * zs] = id;
-            if (table && id < cap) reinterpret_cast<int4 *>(table)[id] = make_int4(tag, ti, tj, tk + z);
+            Lt.grid[first + (size_t)z * zs] = id;
+            if (table && id < cap) reinterpret_cast<int4 *>(table)[id] = make_int4(Lt.tag, ti, tj, tk + z);
         }
-}
-
-__global__ void k_bump_base(long long *base, const int32_t *total)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) *base += *total;
 }
 
 } // namespace avs
@@ -749,6 +779,9 @@ struct avs_prepass {
     SharedBuf<int32_t> vidx[AVS_MAX_LEVELS][3], eidx[AVS_MAX_LEVELS][3], cidx[AVS_MAX_LEVELS], ridx[3];
     DevBuf<int32_t> near_list; // k_sdf_weights_far: [0] = count, then the bricks whose SDF window changes sign
     DevBuf<uint8_t> brick_signs; // k_sdf_sign_blocks: the signs inside every 32x4x4 brick of cells
+    DevBuf<int32_t> num_counts, num_offsets, num_scan_tmp; // numbering: DOFs per tile of the concatenated lattices of one kind, their exclusive scan
+    DevBuf<long long> num_totals;                          // ... and the four DOF counts
+    DevBuf<struct avs::NumBatch> num_batches;              // ... the lattice lists of the four batches
     DevBuf<int32_t> work_list;   // k_brick_triage: [0] = count, then the bricks k_sdf_weights_far has to look at
     // temporal reuse: what an ALLOCATION (SharedBuf::id) holds since it was last filled
     struct TileState { uint64_t id = 0; DevBuf<uint8_t> occ; };          // index lattice: the tiles its classification visited
@@ -1138,14 +1171,9 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
 
     // ---- P5 numbering ----------------------------------------------------------------------
     t.start();
-    DevBuf<int32_t> fl, ids, scan_tmp;
-    DevBuf<long long> base;
-    // per-tile counters only: every lattice has at most (n/16 + 1)^3 tiles
-    const size_t max_tiles = (size_t)(d.nx / kTile + 2) * (size_t)(d.ny / kTile + 2) * (size_t)(d.nz / kTile + 2);
+    DevBuf<int32_t> &fl = p->num_counts, &ids = p->num_offsets, &scan_tmp = p->num_scan_tmp; // (scratch kept across frames)
+    DevBuf<long long> &base = p->num_totals;
     (void)max_vol;
-    AVS_TRY(fl.alloc(max_tiles + 1));
-    AVS_TRY(ids.alloc(max_tiles + 1));
-    AVS_TRY(scan_tmp.alloc(scan_tmp_elems((int64_t)max_tiles + 1)));
     AVS_TRY(base.alloc(4));
     AVS_HIP(hipMemsetAsync(base.p, 0, 4 * sizeof(long long), st));
     for (int k = 0; k < 3; ++k) { // dof tables: room for the previous frame's count + 25 % (a first run has no estimate: the context builds them)
@@ -1153,30 +1181,54 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         p->dof_cap[k] = (p->temporal && p->prev_counts[k] > 0) ? p->prev_counts[k] + p->prev_counts[k] / 4 + 4096 : 0;
         if (p->dof_cap[k] > 0) AVS_TRY(p->dof[k].alloc((size_t)p->dof_cap[k] * 4));
     }
-    auto number = [&](int32_t *grid, const int gr[3], int counter, const uint8_t *occ, int tag) -> avs_status {
-        const Grid3 g = g3(gr);
-        const int ntx = (gr[0] + kTile - 1) / kTile, nty = (gr[1] + kTile - 1) / kTile, ntz = (gr[2] + kTile - 1) / kTile;
-        const int64_t nt = (int64_t)ntx * nty * ntz;
-        hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)nt), dim3(kBlock), 0, st, (const int32_t *)grid, g, ntx, nty, fl.p, occ);
-        AVS_TRY(exclusive_scan_i32(fl.p, ids.p, nt, scan_tmp.p, scan_tmp.n, st));
-        const bool tab = counter < 3 && p->dof_cap[counter] > 0;
-        hipLaunchKernelGGL(k_tile_ids, dim3((unsigned)nt), dim3(kBlock), 0, st, grid, g, ntx, nty, (const int32_t *)ids.p,
-                           (const long long *)(base.p + counter), tab ? p->dof[counter].p : (int32_t *)nullptr, tab ? p->dof_cap[counter] : 0ll, tag);
-        hipLaunchKernelGGL(k_bump_base, dim3(1), dim3(64), 0, st, base.p + counter, (const int32_t *)(ids.p + nt));
-        return AVS_OK;
-    };
-    for (int kind = 0; kind < 3; ++kind)
-        for (int l = 0; l < capped; ++l)
-            for (int a = 0; a < (kind == 2 ? 1 : 3); ++a) {
+    // one batch per counter: velocity faces, edges, centres (each over all levels, in numbering order), regular-grid faces (cpp:1486-1509:
+    // one counter over the three axes)
+    NumBatch host_batches[4] = {}; // (alive until the synchronisation behind the last batch: they are the sources of asynchronous copies)
+    for (int counter = 0; counter < 4; ++counter) {
+        NumBatch &B = host_batches[counter];
+        int64_t tiles = 0;
+        auto add = [&](int32_t *grid, const int gr[3], const uint8_t *occ, int tag) {
+            NumLattice &Lt = B.lat[B.count++];
+            Lt.grid = grid;
+            Lt.occ = occ;
+            Lt.g = g3(gr);
+            Lt.ntx = (gr[0] + kTile - 1) / kTile;
+            Lt.nty = (gr[1] + kTile - 1) / kTile;
+            Lt.tile0 = (int)tiles;
+            Lt.tag = tag;
+            tiles += (int64_t)Lt.ntx * Lt.nty * ((gr[2] + kTile - 1) / kTile);
+        };
+        if (counter < 3) {
+            const int kind = counter;
+            for (int l = 0; l < capped; ++l)
+                for (int a = 0; a < (kind == 2 ? 1 : 3); ++a) {
+                    int gr[3];
+                    pp_res(d, kind, l, a, gr);
+                    const uint8_t *oc = occ_all.p + ((size_t)l * 7 + (kind == 2 ? 6 : (size_t)kind * 3 + a)) * occ_cap; // (centres: the cell tiles with an ACTIVE cell, k_center_tiles)
+                    add(kind == 0 ? p->vidx[l][a].p : (kind == 1 ? p->eidx[l][a].p : p->cidx[l].p), gr, oc, l | (a << 8));
+                }
+        } else {
+            for (int a = 0; a < 3; ++a) {
                 int gr[3];
-                pp_res(d, kind, l, a, gr);
-                const uint8_t *oc = occ_all.p + ((size_t)l * 7 + (kind == 2 ? 6 : (size_t)kind * 3 + a)) * occ_cap; // (centres: the cell tiles with an ACTIVE cell, k_center_tiles)
-                AVS_TRY(number(kind == 0 ? p->vidx[l][a].p : (kind == 1 ? p->eidx[l][a].p : p->cidx[l].p), gr, kind, oc, l | (a << 8)));
+                pp_res(d, 0, 0, a, gr);
+                add(p->ridx[a].p, gr, occ_all.p + (size_t)a * occ_cap, 0); // classified with the level-0 face occupancy
             }
-    for (int a = 0; a < 3; ++a) { // regular grid: one counter over the three axes, cpp:1486-1509
-        int gr[3];
-        pp_res(d, 0, 0, a, gr);
-        AVS_TRY(number(p->ridx[a].p, gr, 3, occ_all.p + (size_t)a * occ_cap, 0)); // classified with the level-0 face occupancy
+        }
+        AVS_REQUIRE(tiles < (1ll << 31) - 1, AVS_EINVAL, "too many tiles");
+        B.total_tiles = (int)tiles;
+        AVS_TRY(fl.reserve((size_t)tiles + 1));
+        AVS_TRY(ids.reserve((size_t)tiles + 1));
+        AVS_TRY(scan_tmp.reserve(scan_tmp_elems(tiles + 1)));
+        AVS_TRY(p->num_batches.alloc(4));
+        AVS_HIP(hipMemcpyAsync(p->num_batches.p + counter, &B, sizeof(NumBatch), hipMemcpyHostToDevice, st)); // (pageable source: staged before the call returns)
+        const NumBatch *Bd = p->num_batches.p + counter;
+        NumStarts S;
+        for (int k = 0; k < kNumLattices; ++k) S.tile0[k] = k < B.count ? B.lat[k].tile0 : INT_MAX;
+        hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)tiles), dim3(kBlock), 0, st, S, Bd, fl.p);
+        AVS_TRY(exclusive_scan_i32(fl.p, ids.p, tiles, scan_tmp.p, scan_tmp.n, st));
+        const bool tab = counter < 3 && p->dof_cap[counter] > 0;
+        hipLaunchKernelGGL(k_tile_ids, dim3((unsigned)tiles), dim3(kBlock), 0, st, S, Bd, (const int32_t *)ids.p, tab ? p->dof[counter].p : (int32_t *)nullptr,
+                           tab ? p->dof_cap[counter] : 0ll, base.p + counter, (int)tiles);
     }
     AVS_HIP(hipGetLastError());
     long long hb[4] = {0, 0, 0, 0};
