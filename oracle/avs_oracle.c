@@ -2373,6 +2373,9 @@ static float dot_f32_eigen(const float *a, const float *b, int64_t n)
     return res;
 }
 
+/* (exported for tests/test_oracle_known_answers.py: the reduction order against a numpy restatement of Redux.h) */
+float orc_dot_f32(const float *a, const float *b, int64_t n) { return dot_f32_eigen(a, b, n); }
+
 /* Eigen::ConjugateGradient<SparseMatrix<float>, Lower|Upper> (USESINGLEPRECISION): the algorithm above with every scalar and vector a float;
  * row sums left to right in float, dots in Eigen's reduction order (dot_f32_eigen).  The GPU side folds its dots in another order (a
  * thread's terms in float, the rest in double), so it is compared to the SOLUTION and the iteration count within a tolerance.  The

@@ -121,6 +121,7 @@ int orc_spmv_csr(int64_t n, const int64_t *row_ptr, const int32_t *col, const do
  * Eigen::Triplet<SolveType> is built, duplicates summed in float, rhs updated in float steps, initial guess narrowed at its store, the
  * CG run with float scalars and vectors.  Call before orc_build_initial_guess / orc_assemble.  Outputs stay double arrays (float values). */
 int orc_set_precision(orc_ctx *c, int f32);
+float orc_dot_f32(const float *a, const float *b, int64_t n); /* a.dot(b) of two VectorXf in the order of Eigen's SSE2 linear vectorised redux */
 int orc_set_f32_serial_dots(int on); /* float CG: 1 = left-to-right float dots instead of Eigen's SSE2 redux order (thread-local) */
 /* 0 = Jacobi (default), 1 = plain CG: the build without USEEIGEN hands HDK's solveConjugateGradient no preconditioner (cpp:638-642) */
 int orc_set_preconditioner(orc_ctx *c, int none);

@@ -313,3 +313,53 @@ def test_state_the_reference_asserts_on_is_rejected_not_crashed():
     o.prepass()
     with pytest.raises(RuntimeError):
         o.build_stencils()
+
+
+def _eigen_redux_f32(a, b):
+    """Eigen 3.3 / 3.4, Core/Redux.h, redux_impl<..., LinearVectorizedTraversal, NoUnrolling> for a.cwiseProduct(b).sum() of two VectorXf
+    with 4-float packets (SSE2: the reference's CMakeLists.txt sets no -march): two packet accumulators on alternate packets, added lane
+    by lane, a last odd packet, predux as (l0 + l2) + (l1 + l3), then the scalar tail.  Every operation rounds to float."""
+    f = np.float32
+    n = len(a)
+    prod = (a.astype(f) * b.astype(f)).astype(f)
+    size1, size2 = (n // 4) * 4, (n // 8) * 8
+    if size1 == 0:
+        res = f(0) if n == 0 else prod[0]
+        for i in range(1, n):
+            res = f(res + prod[i])
+        return res
+    p0 = prod[0:4].copy()
+    if size1 > 4:
+        p1 = prod[4:8].copy()
+        for i in range(8, size2, 8):
+            p0 = (p0 + prod[i:i + 4]).astype(f)
+            p1 = (p1 + prod[i + 4:i + 8]).astype(f)
+        p0 = (p0 + p1).astype(f)
+        if size1 > size2:
+            p0 = (p0 + prod[size2:size2 + 4]).astype(f)
+    res = f(f(p0[0] + p0[2]) + f(p0[1] + p0[3]))
+    for i in range(size1, n):
+        res = f(res + prod[i])
+    return res
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 7, 8, 9, 12, 13, 16, 31, 1000, 4099])
+def test_float_cg_dots_follow_eigens_redux_order(n):
+    """The oracle's float CG (SolveType = fpreal32) folds its dot products as Eigen's own float reduction does (oracle/avs_oracle.c,
+    dot_f32_eigen): bit for bit against a numpy restatement of Redux.h, and different from the left-to-right sum on long vectors."""
+    import ctypes as C
+    from oracle.oracle import lib
+    L = lib()
+    L.orc_dot_f32.restype = C.c_float
+    L.orc_dot_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    rng = np.random.default_rng(n + 1)
+    a = (rng.standard_normal(n) * 10.0 ** rng.integers(-2, 3, n)).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    got = np.float32(L.orc_dot_f32(a.ctypes.data, b.ctypes.data, n))
+    want = _eigen_redux_f32(a, b)
+    assert got.view(np.int32) == np.float32(want).view(np.int32), (n, got, want)
+    if n >= 1000:
+        serial = np.float32(0)
+        for v in (a * b).astype(np.float32):
+            serial = np.float32(serial + v)
+        assert abs(float(got) - float(np.dot(a.astype(np.float64), b.astype(np.float64)))) <= abs(float(serial) - float(np.dot(a.astype(np.float64), b.astype(np.float64)))) + 1e-3
