@@ -156,3 +156,57 @@ def test_f32_loop_tight_tolerance_terminates(monkeypatch, built_lib):
     s.solve(1e-10, 2500)
     assert rel_l2(x, s.solution()) < 2e-4
     s.close()
+
+
+def test_f32_loop_plain_cg_option(monkeypatch, built_lib):
+    """the float loop without a preconditioner (the build without USEEIGEN, cpp:638-642, in float): the inverse diagonal it multiplies with is
+    1.f; iteration count and solution against the oracle's float CG in the same mode"""
+    sc = scenes.fat_beam(64, 3, wall=True)
+    s, pyr = _solver(sc, monkeypatch, False, probe=False)
+    s.assemble()
+    jac = s.solve(1e-5, 8000)
+    s.set_solver_option(capi.OPTION_PRECONDITIONER, capi.PRECONDITIONER_NONE)
+    info = s.solve(1e-5, 8000)
+    x = s.solution()
+    o = _oracle_f32(sc, pyr)
+    o.L.orc_set_preconditioner(o.h, 1)
+    xo, io = o.solve(1e-5, 8000)
+    assert info.converged == 1 and info.resident == 0 and info.iterations > jac.iterations
+    assert abs(info.iterations - io.iterations) <= max(3, io.iterations // 25), (info.iterations, io.iterations)
+    assert rel_l2(x, xo) < 2e-4
+    s.close()
+
+
+def test_f32_loop_graph_replay_changes_nothing(monkeypatch, built_lib):
+    """chunks replayed from the captured hipGraph or enqueued launch by launch: same iteration count, same solution bits"""
+    sc = scenes.fat_beam(128, 4)
+    s, pyr = _solver(sc, monkeypatch, True, probe=False)
+    s.assemble()
+    a = s.solve(1e-5, 5000)
+    xa = s.solution()
+    s.set_solver_option(capi.OPTION_GRAPH_REPLAY, 0)
+    b = s.solve(1e-5, 5000)
+    assert a.iterations == b.iterations > 64 and np.array_equal(xa, s.solution())
+    s.close()
+
+
+def test_f32_loop_can_be_cancelled(monkeypatch, built_lib):
+    """avs_cancel (the reference's opInterrupt, cpp:2528) ends the float loop at its next poll like the fp64 loops"""
+    import threading
+    sc = scenes.fat_beam(128, 4)
+    s, pyr = _solver(sc, monkeypatch, True, probe=False)
+    s.assemble()
+    capi.check(s.lib.avs_cancel(s.h))
+    info = s.solve(1e-8, 5000)                      # a pending request cancels the next solve before its first iteration
+    assert info.cancelled == 1 and info.converged == 0 and info.iterations == 0
+    N = 1000
+    full = s.solve(1e-30, N)
+    assert full.iterations == N and not full.converged and not full.cancelled
+    canceller = threading.Timer(0.3 * full.solve_ms * 1e-3, lambda: capi.check(s.lib.avs_cancel(s.h)))
+    canceller.start()
+    info = s.solve(1e-30, N)
+    canceller.join()
+    assert info.cancelled == 1 and info.converged == 0 and 0 < info.iterations < N
+    again = s.solve(1e-5, 5000)
+    assert again.converged == 1 and again.cancelled == 0
+    s.close()
