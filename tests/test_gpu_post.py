@@ -166,6 +166,13 @@ def test_non_power_of_two_simulation_grid(n, fres, levels, center, half, built_l
     capi.check(s.lib.avs_transfer_to_regular_grid(s.h, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), capi.MEM_DEVICE))
     for a in range(3):
         assert np.array_equal(outs[a].cpu().numpy(), out[a])
+    # the in-place form on a padded grid (it goes through the staging grids: every face of the simulation grid is written) and twice in a
+    # row (the staging grids are reused sparsely)
+    for rep in range(2):
+        vel = [crop(sc.velocity[a], tuple(1 if b == a else 0 for b in range(3))).cuda() for a in range(3)]
+        s.transfer_to_regular_grid_in_place(vel)
+        for a in range(3):
+            assert np.array_equal(vel[a].cpu().numpy(), out[a]), (rep, a)
     s.close()
     pp.close()
 
