@@ -199,7 +199,7 @@ def test_f32_loop_can_be_cancelled(monkeypatch, built_lib):
     capi.check(s.lib.avs_cancel(s.h))
     info = s.solve(1e-8, 5000)                      # a pending request cancels the next solve before its first iteration
     assert info.cancelled == 1 and info.converged == 0 and info.iterations == 0
-    N = 1800                                        # (below the ~2,300 iterations after which the recurrence residual underflows to zero)
+    N = 1000                                        # (in float the recurrence residual reaches FLT_MIN -- "converged" -- well before the fp64 loops' ~2,300 iterations)
     full = s.solve(1e-30, N)
     assert full.iterations == N and not full.converged and not full.cancelled
     canceller = threading.Timer(0.3 * full.solve_ms * 1e-3, lambda: capi.check(s.lib.avs_cancel(s.h)))
