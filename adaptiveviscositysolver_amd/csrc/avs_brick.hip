@@ -87,7 +87,10 @@ __device__ __forceinline__ T lds_abs(unsigned byte_addr) { return *(const T __at
 // LDS layout in BYTES for vectors of T (double: the PCG loops; float: the float-vector loop of AVS_PRECISION_F32, avs_pcg_f32.inl):
 //   [0, kBrickSlotsPad T) the lattice | kBrickXSlots T extra x slots | kBrickBlockBytes: the tile's descriptor block, then the products of
 //   its streamed rows | vals (value table, T) | pattern words | pinfo | row-base table.  With T = float the lattice is 15.4 KB instead of
-//   31 KB: FOUR workgroups per CU instead of three.
+//   31 KB: the LDS would hold FOUR workgroups per CU instead of three -- but only at 64 registers per lane, where the fused-dot
+//   instantiation spills 13 of them (113 MB of scratch traffic per launch at 512^3): measured equal on the 512^3 beam (99 against 100.5 us),
+//   8 % slower on the 1024^3 sheet (317 against 288 us).  The kernel keeps the 80-register budget of the double instantiation: three
+//   workgroups per CU, no spills.
 constexpr unsigned kBrickBlockBytes = (unsigned)((kBrickPark - kBrickXSlots) * sizeof(double));
 template <typename T> constexpr unsigned brick_vals_byte() { return (unsigned)((kBrickSlotsPad + kBrickXSlots) * sizeof(T)) + kBrickBlockBytes; } // `vals` behind the lattice and `park`
 template <typename T> constexpr unsigned brick_vals_elems(int table_size) { return (unsigned)((table_size + 4) & ~3); } // keeps the pattern image 16-B aligned for both T
@@ -111,7 +114,7 @@ __device__ __forceinline__ T ld_u32(const T *base, unsigned idx)
 constexpr int kBlkHdr = kBlkHdrWords;
 
 template <bool DOT, bool VC = false, typename T = double>
-__global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 8 : 6, 8))) void k_spmv_brick(BrickView B, const T *__restrict__ x, T *__restrict__ y,
+__global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_spmv_brick(BrickView B, const T *__restrict__ x, T *__restrict__ y,
                                                          double *__restrict__ partial, const int *__restrict__ done_flag)
 {
     if (DOT && done_flag && *done_flag) return;

@@ -407,7 +407,7 @@ struct BrickView {
     const uint2 *vcodes = nullptr;   // per row quad four 16-bit byte offsets into the tile's table, wave-interleaved in execution order
     const double *ttab = nullptr;    // the tiles' value tables, one after the other
     // float-vector loop (AVS_PRECISION_F32, avs_pcg_f32.inl): the pattern table with byte offsets for 4-B elements; f32 = the planned walk
-    // and the partial-sum count are those of the float kernel's grid (four workgroups per CU)
+    // and the partial-sum count are those of the float kernel's grid
     const uint32_t *pwords32 = nullptr;
     int f32 = 0;
 };

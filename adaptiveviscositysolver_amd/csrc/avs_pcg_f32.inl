@@ -14,7 +14,7 @@
 //     reproduced -- neither is it by the oracle, whose float dots run left to right --, so iteration counts agree with the oracle's
 //     to a few per cent and the solution to the accuracy float CG reaches, not bit for bit.
 // The SpMV is the brick kernel instantiated for float vectors where the matrix has the form (k_spmv_brick<DOT, VC, float>: the lattice
-// in LDS is half as large, FOUR workgroups per CU), else a plain streaming kernel over the CSR arrays (value index or 8-B values).
+// in LDS is half as large), else a plain streaming kernel over the CSR arrays (value index or 8-B values).
 // Same control flow as the fp64 launch-per-phase loop (pcg_solve): three launches per iteration with the scalar steps fused into the
 // vector kernels, chunks of kChunk iterations replayed from a captured hipGraph, avs_cancel polled between chunks.
 

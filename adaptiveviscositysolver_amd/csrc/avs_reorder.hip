@@ -207,7 +207,7 @@ avs_status build_reordered_system(avs_ctx *c, int brick_shift)
         c->brick.release();
         c->brick.view(c->brick_view, c->vi);
     }
-    // AVS_PRECISION_F32 with float vectors: the loop launches the float kernel (four workgroups per CU): the walk is laid out for ITS grid
+    // AVS_PRECISION_F32 with float vectors: the loop launches the float kernel: the walk is laid out for ITS grid
     const int view_f32 = (c->desc.precision == AVS_PRECISION_F32 && c->opt.f32_vectors != 0) ? 1 : 0;
     c->brick_view.f32 = view_f32;
     if (c->brick.ready && c->opt.brick_plan) { // the persistent grid's walk, laid out from the tiles' estimated costs (BrickForm::plan_walk)

@@ -264,8 +264,7 @@ class ViscositySolve:
         if getattr(self, "precision", 0) == capi.PRECISION_F32 and not getattr(self, "f32_vectors_off", False):   # the float-vector loop (avs_pcg_f32.inl)
             if int(getattr(fmt, "brick_tiles", 0)):
                 return (f"k_spmv_brick<DOT,{'VC,' if int(fmt.brick_value_codes) else ''}float> (brick-structured form, float vectors: {int(fmt.brick_tiles)} tiles, "
-                        f"{int(fmt.brick_pattern_rows)} rows as {int(fmt.brick_patterns)} geometric row patterns, x of a brick + halo as floats in LDS, "
-                        f"four workgroups per CU; {tab}-entry dictionary; brick-major system)")
+                        f"{int(fmt.brick_pattern_rows)} rows as {int(fmt.brick_patterns)} geometric row patterns, x of a brick + halo as floats in LDS; {tab}-entry dictionary; brick-major system)")
             return "k_f32_spmv_csr<DOT> (float vectors: column + value code streamed, float products parked in LDS; brick-major system)"
         ltab = "LTAB" if 0 < tab <= 2048 else "GTAB"
         cw = int(fmt.column_windows)
