@@ -117,6 +117,12 @@ public:
     {
         check(avs_transfer_to_regular_grid(myCtx, u, v, w, AVS_MEM_HOST), "applyVelocitiesToRegularGrid");
     }
+    // the same as an in-place update of a DEVICE-resident velocity field (what the reference does to `vel`, cpp:655-707): the arrays already
+    // hold what was given as AVS_FIELD_VELOCITY; only the faces the transfer changes are written
+    void applyVelocitiesToRegularGridInPlace(float *d_u, float *d_v, float *d_w)
+    {
+        check(avs_transfer_to_regular_grid_in_place(myCtx, d_u, d_v, d_w), "applyVelocitiesToRegularGridInPlace");
+    }
     int octreeLevels() const { return myLevels; }
     avs_ctx *handle() const { return myCtx; }
 
