@@ -233,8 +233,6 @@ def spmv_roofline(n, nnz, fmt, mean_spmv_ms, kernel=None, rows_local=None, nnz_l
            "stored_bytes_per_launch": stored, "stored_gbps": stored / t / 1e9 if t > 0 else None,
            "stored_frac": stored / t / 1e9 / HBM_PEAK_GBPS if t > 0 else None,
            "algorithmic_bytes_per_launch": alg, "effective_gbps": alg / t / 1e9 if t > 0 else None,
-           "effective_note": "SURVEY 8(d) bytes (12 B per non-zero) over the launch time: an equivalent rate for comparison with 12-B CSR "
-                             "kernels; the matrix is read in a lossless compressed form, so this is not a fraction of the HBM peak",
            "mean_launch_us": mean_spmv_ms * 1e3, "format": form,
            "brick_form": ({"tiles": int(fmt.brick_tiles), "patterns": int(fmt.brick_patterns), "pattern_rows": int(fmt.brick_pattern_rows),
                            "matrix_bytes": int(fmt.brick_bytes), "walk": int(getattr(fmt, "brick_walk", 0)),
@@ -273,8 +271,6 @@ def resident_roofline(n, nnz, iterations, solve_ms):
     return {"bound": "hbm", "kernel": "k_cg_resident (whole PCG iteration; no separate SpMV launch)", "achieved": achieved,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "achieved_basis": basis, "traffic": None,
             "algorithmic_bytes_per_iteration": alg, "effective_gbps": alg / t / 1e9 if t > 0 else None,
-            "effective_note": "SURVEY 8(d) bytes of one product over the time of a whole iteration: an equivalent rate (the matrix never "
-                              "crosses the HBM pins), not a fraction of the HBM peak",
             "us_per_iteration": t * 1e6,
             "binding": {"resource": "latency (update -> producer flags -> remote fill -> walk -> reduction slots -> broadcast)",
                         "frac": (pmc or {}).get("wait_frac"), "pmc": pmc, "source": src}}
@@ -324,9 +320,6 @@ def extra_workload(label, sc, local_rank, tol, max_iters, precision=0):
            "cg_iterations_per_step": iters // 2, "converged": int(all(i.converged for i in infos)),
            "resident_loop": bool(infos[0].resident),   # CU-resident PCG (one cooperative launch; no separate SpMV launch to time)
            "value": iters / el, "unit": "iter/s", "ms_per_step": el / 2 * 1e3, "first_solve_ms": first_solve_ms, "new_matrix_solve_ms": new_matrix_solve_ms,
-           "new_matrix_note": "first_solve_ms = the first solve of a fresh context (allocations, code-object load, plan, graph capture); "
-                              "new_matrix_solve_ms = one solve right after a re-assembly in the warmed-up context (per-frame cost: plan / form / "
-                              "capture for the new matrix included); ms_per_step = steady state on an unchanged matrix",
            "new_matrix_iterations": int(inm.iterations), "assembly_wall_ms": asm_ms,
            "prepass_ms": pinfo.weights_ms + pinfo.octree_ms + pinfo.classify_ms + pinfo.number_ms,
            "prepass_phases_ms": {"weights": pinfo.weights_ms, "octree": pinfo.octree_ms, "classify": pinfo.classify_ms, "numbering": pinfo.number_ms},
@@ -378,11 +371,126 @@ def extra_workload(label, sc, local_rank, tol, max_iters, precision=0):
 
 
 _JSON_FD = None
+HEADLINE_LIMIT = 4096     # bytes: the driver keeps an 8 KB stdout tail; the round-5 line was 28 KB and could not be parsed
+FULL_RECORD = os.path.join(ROOT, "bench_extra.json")
+
+NOTES = {   # every explanation ONCE, in the full record only (the headline line carries numbers)
+    "roofline": "achieved/frac are PHYSICAL: PMC traffic (when profiles/spmv_counters.json holds a record of THIS source tree) else the stored "
+                "bytes (matrix form + x + y), over the mean HIP-event duration of the SpMV launches inside the timed solves; frac <= 1",
+    "effective_gbps": "SURVEY 8(d) bytes (12 B per non-zero + 4 (n+1) + 16 n) over the launch time: an equivalent rate for comparison with 12-B "
+                      "CSR kernels; the matrix is read in a lossless compressed form, so this is not a fraction of the HBM peak",
+    "new_matrix": "first_solve_ms = the first solve of a fresh context (allocations, code-object load, plan, graph capture); new_matrix_solve_ms "
+                  "= one solve right after a re-assembly in the warmed-up context (per-frame cost); ms_per_step = steady state, unchanged matrix",
+    "cpu_baseline": "oracle PCG (port of Eigen's loop) in a clean subprocess on this box's host cores; eigen_faithful = OpenMP row-parallel "
+                    "SpMV with serial dots/AXPYs (what Eigen::ConjugateGradient does), all_parallel = every loop parallel; 24 warm-up "
+                    "iterations dropped before each timed sample",
+    "resident": "k_cg_resident runs the whole PCG in one cooperative launch with the matrix in the register files: no separate SpMV launch",
+}
 
 
-def emit(obj):
-    """the ONE JSON line on the real stdout (libraries -- RCCL prints its version banner -- write to fd 1, which points to stderr)"""
-    line = (json.dumps(obj) + "\n").encode()
+def _clip(v, n=80):
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 1] + "~"
+
+
+def _num(v, sig=6):
+    """finite float rounded to `sig` significant digits (keeps the line short); non-finite -> None (strict JSON)"""
+    if isinstance(v, bool) or v is None or isinstance(v, int):
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float(f"{v:.{sig}g}")
+    return v
+
+
+def _pick(d, keys, clip=80):
+    return {k: _num(_clip(d.get(k), clip)) for k in keys if d is not None and k in d}
+
+
+def _sanitize(o):
+    """strict JSON: no NaN / Infinity anywhere"""
+    if isinstance(o, dict):
+        return {str(k): _sanitize(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_sanitize(v) for v in o]
+    if isinstance(o, float):
+        return None if (o != o or o in (float("inf"), float("-inf"))) else o
+    return o
+
+
+def headline_of(full, extra_path=None):
+    """the driver's record: the contract keys + roofline + cpu_baseline, <= HEADLINE_LIMIT bytes, strict JSON.  Everything else (per-phase
+    times, per-workload roofline blocks, notes) lives in the full record next to this script."""
+    h = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                     "dtype", "data", "error"), 120)
+    cfg = full.get("config") or {}
+    h["config"] = _pick(cfg, ("workload", "baseline_config", "n_dofs", "nnz", "cg_iterations_per_step", "parallelism"), 140)
+    r = full.get("roofline")
+    if r:
+        hr = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                       "stored_bytes_per_launch", "mean_launch_us", "effective_gbps", "us_per_iteration", "source_sha16"))
+        if r.get("binding"):
+            hr["binding"] = _pick(r["binding"], ("resource", "frac"), 60)
+        h["roofline"] = hr
+    c = full.get("cpu_baseline")
+    if c:
+        hc = _pick(c, ("value", "unit", "cores", "threads", "cpu_model", "kind"), 60)
+        hc["variant"] = "eigen_faithful: parallel SpMV, serial dots/AXPYs (Eigen's CG)"
+        hc["all_parallel_iter_per_s"] = _num((c.get("all_parallel") or {}).get("iter_per_s"))
+        hc["sample"] = _clip(c.get("sample"), 150)
+        h["cpu_baseline"] = hc
+    for k in ("speedup_vs_cpu_baseline", "speedup_vs_cpu_all_parallel", "hot_path_ms", "end_to_end_ms", "solve_event_iter_per_s"):
+        if full.get(k) is not None:
+            h[k] = _num(full[k])
+    if full.get("assembly_ms"):
+        h["assembly_wall_ms"] = _num(full["assembly_ms"].get("wall"))
+    if full.get("dist"):
+        d = full["dist"]
+        h["dist"] = _pick(d, ("transport", "resident_loop", "selftest_bad_entries"), 40)
+        h["dist"]["verified"] = bool(d.get("verification") and d["verification"][-1].get("ok"))
+    ex = []
+    for e in full.get("extra_workloads") or []:
+        rr = e.get("roofline") or {}
+        ex.append({"w": _clip(e.get("workload", ""), 56), "dtype": e.get("dtype"), "value": _num(e.get("value"), 5),
+                   "ms": _num(e.get("ms_per_step"), 4), "frac": _num(rr.get("frac"), 3),
+                   **({"error": _clip(e["error"], 60)} if e.get("error") else {})})
+    if ex:
+        h["extra"] = ex
+    if extra_path:
+        h["full_record"] = extra_path
+    h = _sanitize(h)
+    # never lose the headline to a long string: shed the optional parts until the line fits
+    for drop in ("extra", "dist", "full_record"):
+        if len(json.dumps(h, allow_nan=False)) + 1 < HEADLINE_LIMIT:
+            break
+        h.pop(drop, None)
+    return h
+
+
+def write_full_record(full):
+    """the whole record (extras, notes, per-phase times) as a file next to the script and, for gpurun, under gpurun_out/"""
+    full = _sanitize(dict(full, notes=NOTES))
+    paths = []
+    for p in (FULL_RECORD, os.path.join(ROOT, "gpurun_out", "bench_extra.json")):
+        try:
+            os.makedirs(os.path.dirname(p), exist_ok=True)
+            with open(p, "w") as f:
+                json.dump(full, f, indent=1, allow_nan=False)
+            paths.append(p)
+        except OSError:
+            pass
+    return os.path.relpath(paths[0], ROOT) if paths else None
+
+
+def emit(obj, headline=True):
+    """the ONE JSON line on the real stdout (libraries -- RCCL prints its version banner -- write to fd 1, which points to stderr).
+    With headline=True the full record goes to a file and the line is its <= 4 KB digest."""
+    if headline:
+        obj = headline_of(obj, write_full_record(obj))
+    text = json.dumps(obj, allow_nan=False)
+    if headline and len(text) + 1 >= HEADLINE_LIMIT:
+        raise RuntimeError(f"bench headline is {len(text)} bytes (limit {HEADLINE_LIMIT})")
+    line = (text + "\n").encode()
     if _JSON_FD is None:
         sys.stdout.write(line.decode())
         sys.stdout.flush()
@@ -428,7 +536,7 @@ def main():
         else:
             ok = True
         if rank == 0:
-            emit({"launch_check": bool(ok), "n_gpus": world, "backend": backend})
+            emit({"launch_check": bool(ok), "n_gpus": world, "backend": backend}, headline=False)
         raise SystemExit(0 if ok else 1)
 
     if a.one_device:
@@ -737,20 +845,20 @@ def main():
             torch.cuda.empty_cache()
             extras = []
             for label, make in (
-                    ("config 2: fat_beam 128^3, 3 levels, uniform viscosity (BASELINE configs[1]; CU-resident loop)", lambda: scenes.fat_beam(128, 3, device=dev)),
+                    ("config 2: fat_beam 128^3, 3 levels, uniform (BASELINE configs[1]; CU-resident loop)", lambda: scenes.fat_beam(128, 3, device=dev)),
                     ("config 3: fat_beam 256^3, 4 levels, mu(x)=200(1+9x)", lambda: scenes.fat_beam(256, 4, variable_viscosity=True, device=dev)),
-                    ("fat_beam 256^3, 4 levels, uniform viscosity (1.27 M rows: CU-resident loop with streamed rows)", lambda: scenes.fat_beam(256, 4, device=dev)),
+                    ("fat_beam 256^3, 4 levels, uniform (1.27 M rows: CU-resident loop, streamed rows)", lambda: scenes.fat_beam(256, 4, device=dev)),
                     ("fat_beam 512^3, 4 levels, mu(x)=200(1+9x)", lambda: scenes.fat_beam(512, 4, variable_viscosity=True, device=dev)),
-                    ("config 5: thin_sheet 1024^3 (half-thickness 16 dx), 5 levels requested", lambda: scenes.thin_sheet(1024, 5, thickness_cells=32, device=dev)),
-                    ("scene viscousBeam.hip equivalent (304x80x80 simulation grid)", lambda: scenes.viscous_beam_scene(device=dev)),
-                    ("scene viscousBuckling.hip equivalent (132x330x40 simulation grid, dx=(double)(float)1e-3)", lambda: scenes.viscous_buckling_scene(device=dev))):
+                    ("config 5: thin_sheet 1024^3, 5 levels (half-thickness 16 dx)", lambda: scenes.thin_sheet(1024, 5, thickness_cells=32, device=dev)),
+                    ("scene viscousBeam.hip equivalent (304x80x80 grid)", lambda: scenes.viscous_beam_scene(device=dev)),
+                    ("scene viscousBuckling.hip equivalent (132x330x40 grid, dx=(double)(float)1e-3)", lambda: scenes.viscous_buckling_scene(device=dev))):
                 try:
                     extras.append(extra_workload(label, make(), local_rank, a.tol, a.max_iters))
                 except Exception as e:   # never lose the headline line to a secondary workload
                     extras.append({"workload": label, "error": str(e)[:300]})
                 torch.cuda.empty_cache()
             # the headline workload as the reference built with USESINGLEPRECISION runs it (util.h:25-37): float system, float vectors and scalars
-            for label, make in (("fat_beam 512^3, 4 levels, uniform viscosity, SolveType = fpreal32 (AVS_PRECISION_F32: float-vector loop, k_spmv_brick<float>)",
+            for label, make in (("fat_beam 512^3 uniform, SolveType=fpreal32 (AVS_PRECISION_F32: float-vector loop, k_spmv_brick<float>)",
                                  lambda: scenes.fat_beam(512, 4, device=dev)),):
                 try:
                     extras.append(extra_workload(label, make(), local_rank, a.tol, a.max_iters, precision=1))
