@@ -39,7 +39,7 @@ INDEX_VELOCITY, INDEX_EDGE, INDEX_CENTER = 0, 1, 2
 
 # every symbol include/avs.h declares (checked by tests/test_capi_symbols.py)
 EXPORTED_SYMBOLS = [
-    "avs_last_error", "avs_version", "avs_abi_version", "avs_cancel", "avs_create", "avs_destroy", "avs_set_labels",
+    "avs_last_error", "avs_version", "avs_abi_version", "avs_cancel", "avs_cancel_clear", "avs_create", "avs_destroy", "avs_set_labels",
     "avs_set_index_field", "avs_set_dof_counts", "avs_set_scalar_field", "avs_build_stencils",
     "avs_build_initial_guess", "avs_build_system", "avs_assemble", "avs_solve", "avs_set_solver_option",
     "avs_get_assembly_info", "avs_get_matrix_format", "avs_get_solution", "avs_get_initial_guess", "avs_get_csr",
@@ -174,6 +174,7 @@ def load(probe=False):
     L.avs_assemble.argtypes = [vp, C.POINTER(AssemblyInfo)]
     L.avs_solve.argtypes = [vp, f64, i32, C.POINTER(SolveInfo)]
     L.avs_cancel.argtypes = [vp]
+    L.avs_cancel_clear.argtypes = [vp]
     L.avs_abi_version.restype = C.c_int32
     L.avs_set_solver_option.argtypes = [vp, i32, i32]
     L.avs_get_assembly_info.argtypes = [vp, C.POINTER(AssemblyInfo)]

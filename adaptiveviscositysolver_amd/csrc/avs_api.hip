@@ -672,6 +672,13 @@ avs_status avs_cancel(avs_ctx *c)
     return AVS_OK;
 }
 
+avs_status avs_cancel_clear(avs_ctx *c)
+{
+    AVS_REQUIRE(c, AVS_EINVAL, "null argument");
+    c->cancel.store(0, std::memory_order_release); // a request that arrived after the solve it was meant for must not end the next one
+    return AVS_OK;
+}
+
 avs_status avs_solve(avs_ctx *c, double tol, int32_t max_iters, avs_solve_info *info)
 {
     avs::OptScope opt_scope_(c);

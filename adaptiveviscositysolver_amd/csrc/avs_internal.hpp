@@ -725,6 +725,7 @@ struct avs_ctx {
     // AVS_BRICK_AUTO: brick form or word stream, whichever multiplied faster when a matrix of (about) this size was first seen
     int brick_verdict = 0, brick_walk = 1;
     int64_t brick_verdict_rows = 0;
+    int brick_verdict_reuse = 0;    // frames a cached "no" of the fill rule has been reused (re-examined every 16th)
     double brick_tune_ms[2] = {0., 0.};   // stream, brick (ms per launch at the measurement)
     avs::DevBuf<double> brick_tune_y;
     bool reordered = false;

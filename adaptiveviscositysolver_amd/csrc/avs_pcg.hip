@@ -2071,6 +2071,13 @@ static avs_status pcg_solve_resident_single(PcgWork *w, const CsrView &A, const 
         info->resident = 1;
         info->cancelled = 0;
     }
+    // avs_cancel during the cooperative launch: the launch cannot be interrupted, but the request ends HERE -- consumed, and reported when the
+    // loop stopped at max_iterations without converging (a converged solve is a converged solve; the request is consumed either way, so that
+    // it cannot hit the next solve on this context)
+    if (cancel_consume() && info && w->host_sc->done == 0) {
+        info->cancelled = 1;
+        info->converged = 0;
+    }
     return AVS_OK;
 }
 

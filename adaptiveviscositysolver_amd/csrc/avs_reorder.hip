@@ -155,10 +155,14 @@ avs_status build_reordered_system(avs_ctx *c, int brick_shift)
     // (and do not build a form that lost) until the row count has moved by more than 10 %.
     const bool autosel = (mode < 0 || mode == 2) && want;
     const bool cached = c->brick_verdict_rows > 0 && std::llabs(n - c->brick_verdict_rows) * 10 <= c->brick_verdict_rows;
-    if (autosel && cached && !c->brick_verdict) want = 0;
+    // (a cached "no" is re-examined every 16th frame: the rule depends on the rows per TILE, which can cross the threshold while the row
+    //  count stays within 10 % -- round-5 advisor finding)
+    if (autosel && cached && !c->brick_verdict && (++c->brick_verdict_reuse & 15) != 0) want = 0;
     if (want) AVS_TRY(build_brick_form(c));
     c->brick.view(c->brick_view, c->vi);
-    if (want && c->brick.ready) {
+    if (want && c->brick.ready && mode == 2 && cached) {
+        // AVS_BRICK_TUNE: the MEASURED verdict and walk of the first frame stand until the row count moves (the rule does not overwrite them)
+    } else if (want && c->brick.ready) {
         const double fill = (double)n / (double)c->brick.ntiles;
         if (autosel) c->brick_verdict = fill >= kBrickMinFill ? 1 : 0;
         else c->brick_verdict = 1;

@@ -6,6 +6,7 @@ for device memory and streams only.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -126,6 +127,7 @@ class ViscositySolve:
         capi.check(self.lib.avs_set_solver_option(self.h, int(option), int(value)))
         if int(option) == capi.OPTION_F32_VECTORS:
             self.f32_vectors_off = int(value) == 0
+            self.f32_vectors_set = int(value) >= 0     # an explicit option overrides AVS_F32_VECTORS in the environment
 
     # ---- hot path -------------------------------------------------------------------------
     def build_stencils(self):
@@ -258,10 +260,21 @@ class ViscositySolve:
         capi.check(self.lib.avs_get_matrix_format(self.h, C.byref(fmt)))
         return fmt
 
-    def spmv_kernel_name(self):
+    def runs_float_vectors(self, info=None):
+        """True when a solve of this context iterates on float vectors (avs_pcg_f32.inl): AVS_PRECISION_F32, not switched off by
+        AVS_OPTION_F32_VECTORS / AVS_F32_VECTORS=0, and -- given the avs_solve_info of a solve that ran -- not taken by the CU-resident
+        loop (which iterates in fp64 on the float system).  Derived from what ran, not from the precision alone."""
+        if getattr(self, "precision", 0) != capi.PRECISION_F32 or getattr(self, "f32_vectors_off", False):
+            return False
+        env = os.environ.get("AVS_F32_VECTORS")
+        if env is not None and env.strip() not in ("", "-1") and int(env) == 0 and not getattr(self, "f32_vectors_set", False):
+            return False
+        return not (info is not None and int(getattr(info, "resident", 0)))
+
+    def spmv_kernel_name(self, info=None):
         fmt = self.matrix_format()
         bpn, tab = int(fmt.bytes_per_nonzero), int(fmt.value_table_size)
-        if getattr(self, "precision", 0) == capi.PRECISION_F32 and not getattr(self, "f32_vectors_off", False):   # the float-vector loop (avs_pcg_f32.inl)
+        if self.runs_float_vectors(info):   # the float-vector loop (avs_pcg_f32.inl)
             if int(getattr(fmt, "brick_tiles", 0)):
                 return (f"k_spmv_brick<DOT,{'VC,' if int(fmt.brick_value_codes) else ''}float> (brick-structured form, float vectors: {int(fmt.brick_tiles)} tiles, "
                         f"{int(fmt.brick_pattern_rows)} rows as {int(fmt.brick_patterns)} geometric row patterns, x of a brick + halo as floats in LDS; {tab}-entry dictionary; brick-major system)")

@@ -324,7 +324,7 @@ def extra_workload(label, sc, local_rank, tol, max_iters, precision=0):
            "prepass_ms": pinfo.weights_ms + pinfo.octree_ms + pinfo.classify_ms + pinfo.number_ms,
            "prepass_phases_ms": {"weights": pinfo.weights_ms, "octree": pinfo.octree_ms, "classify": pinfo.classify_ms, "numbering": pinfo.number_ms},
            "prepass_apply_ms": apply_ms,
-           "roofline": (spmv_roofline(int(ai.n_velocity), int(ai.nnz), s.matrix_format(), sum(i.spmv_ms for i in infos) / 2, s.spmv_kernel_name())
+           "roofline": (spmv_roofline(int(ai.n_velocity), int(ai.nnz), s.matrix_format(), sum(i.spmv_ms for i in infos) / 2, s.spmv_kernel_name(infos[0]))
                         if infos[0].spmv_ms > 0 else
                         resident_roofline(int(ai.n_velocity), int(ai.nnz), iters // 2, el / 2 * 1e3) if infos[0].resident else None)}
     try:   # post-solve transfer to the regular MAC grid (cpp:655-707), second call timed
@@ -362,7 +362,7 @@ def extra_workload(label, sc, local_rank, tol, max_iters, precision=0):
             el2 = time.perf_counter() - t0
             rec["launch_per_phase"] = {"value": sum(i.iterations for i in inf2) / el2, "unit": "iter/s",
                                        "roofline": spmv_roofline(int(ai.n_velocity), int(ai.nnz), s.matrix_format(), sum(i.spmv_ms for i in inf2) / 2,
-                                                                 s.spmv_kernel_name())}
+                                                                 s.spmv_kernel_name(inf2[0]))}
         finally:
             s.set_solver_option(_c.OPTION_RESIDENT_LOOP, 1)
     s.close()
@@ -785,7 +785,7 @@ def main():
         n, nnz = int(ai.n_velocity), (nnz_total if use_dist else int(ai.nnz))
         mean_spmv_ms = float(np.mean(spmv_ms))
         fmt = solver.matrix_format()
-        kernel = solver.spmv_kernel_name() if hasattr(solver, "spmv_kernel_name") else None
+        kernel = solver.spmv_kernel_name(info)
         if use_dist:   # THIS rank's block of rows
             sz = solver.plan_sizes
             roof = spmv_roofline(n, nnz, fmt, mean_spmv_ms, kernel, rows_local=int(sz.n_own), nnz_local=int(sz.nnz_local))

@@ -173,10 +173,15 @@ avs_status avs_solve(avs_ctx *ctx, double tolerance, int32_t max_iterations, avs
 /* User interrupt: the reference polls UT_Interrupt::opInterrupt() inside its loops (cpp:2528; HDK_OctreeGrid.cpp:584-588).  Callable from
  * ANY thread while another thread is inside avs_solve / avs_dist_solve on the same context: the running loop ends at its next poll of
  * the device state (every 32 iterations of the launch-per-phase loops; the CU-resident loop, one cooperative launch of at most
- * max_iterations x ~20-70 us, ends with its launch), the solve returns AVS_OK with converged = 0 and cancelled = 1, and the request is
- * consumed.  A request that finds no solve running cancels the next one.  In a partitioned solve every rank must be cancelled (the
- * ranks leave the loop in the same iteration: the request travels with the CG sums). */
+ * max_iterations x ~20-70 us, cannot be interrupted: it runs to its end, and the request is consumed when it returns -- reported as
+ * cancelled = 1, converged = 0 if the launch stopped at max_iterations without converging, otherwise the solve is simply done), the solve
+ * returns AVS_OK with converged = 0 and cancelled = 1, and the request is consumed.  A request that is already pending when avs_solve
+ * starts skips the CU-resident loop: the launch-per-phase loop consumes it at its first poll (0 iterations, cancelled = 1).  A request
+ * that finds no solve running cancels the NEXT one -- a host whose watcher thread may call avs_cancel right after the solve returned
+ * calls avs_cancel_clear once the watcher has been joined (shim/HDK_AdaptiveViscosity_avs.cpp does).  In a partitioned solve every rank
+ * must be cancelled (the ranks leave the loop in the same iteration: the request travels with the CG sums). */
 avs_status avs_cancel(avs_ctx *ctx);
+avs_status avs_cancel_clear(avs_ctx *ctx);   /* drop a pending request (no solve may be running on the context) */
 
 /* Solver options of the context (set any time before avs_solve / avs_dist_solve; the default is what the USEEIGEN build does).
  * AVS_OPTION_PRECONDITIONER: AVS_PRECONDITIONER_JACOBI (0, default: Eigen's DiagonalPreconditioner, cpp:618) or

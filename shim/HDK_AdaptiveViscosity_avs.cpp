@@ -40,7 +40,10 @@
 void initializeSIM(void *) { IMPLEMENT_DATAFACTORY(HDK_AdaptiveViscosity); }
 
 HDK_AdaptiveViscosity::HDK_AdaptiveViscosity(const SIM_DataFactory *factory) : BaseClass(factory) {}
-HDK_AdaptiveViscosity::~HDK_AdaptiveViscosity() {}
+static void releaseHandlesOf(const void *node);
+// a deleted solver node gives back its pre-pass and context (device lattices, PCG workspace: tens of GB at 1024^3) -- and a new node
+// that happens to be allocated at the same address never inherits them
+HDK_AdaptiveViscosity::~HDK_AdaptiveViscosity() { releaseHandlesOf(this); }
 
 namespace {
 
@@ -101,8 +104,8 @@ int next_pow2(int v)
 // The two library handles, KEPT from substep to substep (round 5): avs_prepass_apply lends the pre-pass's lattices to the context
 // instead of copying them, and an avs_prepass object that lives across frames skips what its allocations already hold from the
 // previous frame (weight bricks far from the surface, index tiles outside the last occupancy) -- both only pay off when the objects
-// survive the call.  One set per solver node (keyed by the node's address; released when the geometry of the grids changes, and by
-// clearCache() when the plugin unloads).  A fresh pair per call, as before, is still correct: only slower.
+// survive the call.  One set per solver node (keyed by the node's address; released when the geometry of the grids changes, on any
+// error return, and by the node's destructor).  A fresh pair per call, as before, is still correct: only slower.
 struct Handles {
     avs_prepass *pp = nullptr;
     avs_ctx *ctx = nullptr;
@@ -112,15 +115,29 @@ struct Handles {
     void release() { releaseCtx(); if (pp) avs_prepass_destroy(pp); pp = nullptr; }
     ~Handles() { release(); }
 };
+// The map lives behind an intentionally leaked pointer: a static object would be destroyed at exit / dlclose, i.e. possibly AFTER the HIP
+// runtime has been torn down, and avs_destroy / hipFree from there can crash or hang the shutdown.  Nodes release their own entry
+// (destructor above); what a host never deletes is reclaimed with the process.
 static std::mutex theHandlesLock;
-static std::map<const void *, std::unique_ptr<Handles>> theHandles;
+static std::map<const void *, std::unique_ptr<Handles>> &handlesMap()
+{
+    static auto *m = new std::map<const void *, std::unique_ptr<Handles>>();
+    return *m;
+}
 static Handles &handlesOf(const void *node)
 {
     std::lock_guard<std::mutex> lk(theHandlesLock);
-    std::unique_ptr<Handles> &h = theHandles[node];
+    std::unique_ptr<Handles> &h = handlesMap()[node];
     if (!h) h.reset(new Handles());
     return *h;
 }
+} // namespace
+static void releaseHandlesOf(const void *node)
+{
+    std::lock_guard<std::mutex> lk(theHandlesLock);
+    handlesMap().erase(node); // ~Handles: avs_destroy + avs_prepass_destroy
+}
+namespace {
 
 // Optional frame export for the offline harness (adaptiveviscositysolver_amd/dump.py, examples/hotpath_from_dump.cpp):
 // "AVSDUMP2", nx ny nz levels enhanced field_nx field_ny field_nz (int32), dx dt (f64), n_vel n_edge n_center (int64); per level
@@ -230,6 +247,7 @@ bool HDK_AdaptiveViscosity::solveGasSubclass(SIM_Engine &engine, SIM_Object *obj
         UT_WorkBuffer msg;
         msg.sprintf("avs: %s", avs_last_error());
         addError(obj, SIM_MESSAGE, msg.buffer(), UT_ERROR_WARNING);
+        h.release(); // never leave a half-configured pre-pass / context for the next substep: it starts from fresh objects
         return false;
     };
 
@@ -331,6 +349,8 @@ bool HDK_AdaptiveViscosity::solveGasSubclass(SIM_Engine &engine, SIM_Object *obj
         const bool solved = check(avs_solve(h.ctx, getSolverTolerance(), getMaxIterations(), &sinfo)); // non-convergence is not an error (cpp:645-652)
         solving.store(false, std::memory_order_release);
         watcher.join();
+        // the watcher may have called avs_cancel just after the loop ended: a stale request must not end the NEXT substep's solve
+        if (h.ctx) (void)avs_cancel_clear(h.ctx);
         if (!solved || sinfo.cancelled) return false;
         UT_WorkBuffer extra;
         extra.sprintf("iterations=%d, error=%.6f, octree DOFS=%d, regular DOFs=%d", (int)sinfo.iterations, sinfo.error, (int)sinfo.n,

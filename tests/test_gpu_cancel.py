@@ -79,3 +79,30 @@ def test_cancel_a_partitioned_solve(monkeypatch, built_lib):
     again = s.dist_solve(1e-8, 20000)
     assert again.converged == 1 and again.cancelled == 0
     s.close()
+
+
+def test_cancel_during_a_resident_solve_is_consumed(monkeypatch, built_lib):
+    """round-5 advisor finding: the CU-resident loop (one cooperative launch) cannot be interrupted, but a request that arrives DURING
+    the launch must end with it -- reported when the launch stopped at max_iterations unconverged, consumed either way -- and never
+    hit the next solve on the context (the shim keeps its context across substeps)."""
+    s = _solver(monkeypatch, resident=True)
+    N = 1500
+    full = s.solve(1e-30, N)
+    assert full.resident == 1 and full.iterations == N and not full.cancelled
+    canceller = threading.Timer(0.3 * full.solve_ms * 1e-3, lambda: capi.check(s.lib.avs_cancel(s.h)))
+    canceller.start()
+    info = s.solve(1e-30, N)
+    canceller.join()
+    assert info.resident == 1 and info.iterations == N       # the launch ran to its end ...
+    assert info.cancelled == 1 and info.converged == 0       # ... and reports the request it consumed
+    again = s.solve(1e-8, 20000)                             # consumed: the next solve is not cancelled
+    assert again.converged == 1 and again.cancelled == 0 and again.iterations > 0
+    # a request that arrives after a converged resident solve started is consumed with it, too
+    canceller = threading.Timer(0.0, lambda: capi.check(s.lib.avs_cancel(s.h)))
+    info = s.solve(1e-8, 20000)
+    canceller.start()
+    canceller.join()
+    capi.check(s.lib.avs_cancel_clear(s.h))                  # what the shim does after joining its watcher thread
+    again = s.solve(1e-8, 20000)
+    assert again.converged == 1 and again.cancelled == 0 and again.iterations > 0
+    s.close()
