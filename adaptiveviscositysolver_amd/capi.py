@@ -27,7 +27,7 @@ STATUS_NAMES = {0: "AVS_OK", 1: "AVS_EINVAL", 2: "AVS_ENOMEM", 3: "AVS_EHIP", 4:
 MEM_HOST, MEM_DEVICE = 0, 1
 PRECISION_F64, PRECISION_F32 = 0, 1   # avs_desc.precision (SolveType of the reference, util.h:25-37)
 (OPTION_PRECONDITIONER, OPTION_RESIDENT_LOOP, OPTION_TRANSPORT, OPTION_PARANOID, OPTION_GRAPH_REPLAY, OPTION_BRICK_FORM,
- OPTION_FUSED_SCALAR_STEPS, OPTION_RELOAD_ENVIRONMENT, OPTION_F32_VECTORS) = range(9)  # avs_set_solver_option
+ OPTION_FUSED_SCALAR_STEPS, OPTION_RELOAD_ENVIRONMENT, OPTION_F32_VECTORS, OPTION_FUSED_VECTOR_UPDATE) = range(10)  # avs_set_solver_option
 USE_TRANSPORT_AUTO, USE_TRANSPORT_RCCL, USE_TRANSPORT_DIRECT = 0, 1, 2
 BRICK_AUTO, BRICK_NEVER, BRICK_ALWAYS, BRICK_TUNE = -1, 0, 1, 2
 PRECONDITIONER_JACOBI, PRECONDITIONER_NONE = 0, 1
@@ -55,7 +55,7 @@ EXPORTED_SYMBOLS = [
 ]
 # include/avs_probe.h: exported by libavs_probe.so only (the -DAVS_PROBES build of the same sources)
 PROBE_SYMBOLS = ["avs_spmv_csr", "avs_bench_spmv", "avs_spmv_sell", "avs_bench_stream", "avs_brick_spmv_probe", "avs_spmv_solver_form",
-                 "avs_dist_spmv_local_form"]
+                 "avs_dist_spmv_local_form", "avs_brick_wave_stats"]
 _VOID_RETURN = ("avs_last_error", "avs_version", "avs_destroy", "avs_plan_destroy", "avs_local_group_destroy",
                 "avs_prepass_destroy")
 
@@ -113,7 +113,8 @@ class MatrixFormat(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("reordered", C.c_int32), ("value_table_size", C.c_int32), ("column_bits", C.c_int32),
                 ("bytes_per_nonzero", C.c_int32), ("tile_local_tables", C.c_int32),
                 ("column_windows", C.c_int32), ("brick_tiles", C.c_int32), ("brick_patterns", C.c_int32), ("_pad", C.c_int32),
-                ("brick_pattern_rows", C.c_int64), ("brick_bytes", C.c_int64), ("brick_walk", C.c_int32), ("brick_value_codes", C.c_int32)]
+                ("brick_pattern_rows", C.c_int64), ("brick_bytes", C.c_int64), ("brick_walk", C.c_int32), ("brick_value_codes", C.c_int32),
+                ("fused_vector_update", C.c_int32), ("fused_vector_faults", C.c_int32)]
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
@@ -192,6 +193,7 @@ def load(probe=False):
         L.avs_bench_stream.argtypes = [i32, i64, i32, i32, C.POINTER(f64)]
         L.avs_spmv_solver_form.argtypes = [vp, vp, vp, i32, C.POINTER(f64)]
         L.avs_dist_spmv_local_form.argtypes = [vp, vp, vp, i32, C.POINTER(f64)]
+        L.avs_brick_wave_stats.argtypes = [vp, C.POINTER(f64)]
     L.avs_prepass_create.argtypes = [C.POINTER(PrepassDesc), C.POINTER(vp)]
     L.avs_prepass_destroy.argtypes = [vp]
     L.avs_prepass_destroy.restype = None

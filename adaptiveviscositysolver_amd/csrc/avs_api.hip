@@ -107,6 +107,8 @@ Options options_from_env()
         (void)sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &k.tile, &k.row, &k.run, &k.word, &k.etile, &k.quad);
     }
     o.fuse_beta = env_int("AVS_PCG_FUSE_BETA", 1) != 0;
+    { const int v = env_int("AVS_PCG_FUSE_VECTORS", 0); o.fuse_vectors = v < 0 ? -1 : (v > 0 ? 1 : 0); }
+    o.fused_timeout_ms = env_int("AVS_PCG_FUSED_TIMEOUT_MS", 2000);
     { const int v = env_int("AVS_F32_VECTORS", -1); o.f32_vectors = v < 0 ? -1 : (v > 0 ? 1 : 0); }
     o.prepass_temporal = env_int("AVS_PREPASS_TEMPORAL", 1) != 0;
     { const int v = env_int("AVS_POST_DOF_SAMPLE", -1); o.post_dof_sample = v < 0 ? -1 : (v > 0 ? 1 : 0); }
@@ -587,6 +589,7 @@ avs_status avs_get_matrix_format(avs_ctx *c, avs_matrix_format *out)
     fmt->brick_bytes = bk ? c->brick.stored_bytes(c->n_vel) : 0;
     fmt->brick_walk = bk ? c->brick_view.walk : 0;
     fmt->brick_value_codes = bk && c->brick.vc ? 1 : 0;
+    pcg_fused_state(c->pcg, &fmt->fused_vector_update, &fmt->fused_vector_faults);
     hand_over();
     return AVS_OK;
 }
@@ -649,6 +652,7 @@ avs_status avs_set_solver_option(avs_ctx *c, avs_solver_option option, int32_t v
     case AVS_OPTION_FUSED_SCALAR_STEPS: c->opt.fuse_beta = value != 0; return AVS_OK;
     case AVS_OPTION_RELOAD_ENVIRONMENT: c->opt = options_from_env(); c->brick_verdict_rows = 0; return AVS_OK;
     case AVS_OPTION_F32_VECTORS: c->opt.f32_vectors = value < 0 ? -1 : (value > 0 ? 1 : 0); return AVS_OK;
+    case AVS_OPTION_FUSED_VECTOR_UPDATE: c->opt.fuse_vectors = value < 0 ? -1 : (value > 0 ? 1 : 0); return AVS_OK;
     }
     set_error("unknown solver option %d", (int)option);
     return AVS_EINVAL;
@@ -994,6 +998,62 @@ avs_status probe_spmv_form(const CsrView &A, const double *x, double *y, bool fu
     return AVS_OK;
 }
 } // namespace avs
+}
+
+// Measurement: how evenly the pattern rows of a tile load the eight waves of its workgroup.  Lane i of the execution order walks row i
+// (rows sorted by pattern length): a wave's time is its LONGEST row, the tile's walk the slowest wave.  Host-side pass over the form.
+avs_status avs_brick_wave_stats(avs_ctx *c, double *out6)
+{
+    AVS_REQUIRE(c && c->system_ready, AVS_ESTATE, "no system");
+    const avs::BrickView &B = c->brick_view;
+    AVS_REQUIRE(B.ntiles > 0, AVS_ESTATE, "no brick form");
+    AVS_HIP(hipSetDevice(c->desc.device));
+    std::vector<uint2> tb((size_t)B.ntiles);
+    AVS_HIP(hipMemcpy(tb.data(), B.tile_blk, tb.size() * sizeof(uint2), hipMemcpyDeviceToHost));
+    size_t units = 0;
+    for (const uint2 &t : tb) units = std::max(units, (size_t)t.x + t.y);
+    std::vector<uint32_t> blocks(units * 4);
+    AVS_HIP(hipMemcpy(blocks.data(), B.blocks, blocks.size() * 4, hipMemcpyDeviceToHost));
+    size_t nrd = 0;
+    for (const uint2 &t : tb) { const uint32_t *bw = &blocks[(size_t)t.x * 4]; nrd = std::max(nrd, (size_t)bw[10] + bw[5]); }
+    std::vector<uint2> rdesc(nrd);
+    AVS_HIP(hipMemcpy(rdesc.data(), B.rdesc, nrd * sizeof(uint2), hipMemcpyDeviceToHost));
+    double sum_all = 0., sum_max = 0., sum_mean = 0., sum_lanes = 0., sum_rows = 0., sum_quads = 0.;
+    long gt = 0;
+    std::vector<long> hist(40, 0);
+    for (const uint2 &t : tb) {
+        const uint32_t *bw = &blocks[(size_t)t.x * 4];
+        const int npat = (int)bw[2], nruns = (int)bw[3], npq = (int)bw[4], nprow = (int)bw[5], rd0 = (int)bw[10];
+        if (npat == 0 || nprow == 0) continue;
+        const uint32_t *pinfo = bw + avs::kBlkHdrWords + 2 * nruns + npq;
+        int wmax[8] = {};   // quads a wave walks: sum over its (<= 2) row chunks of the chunk's longest row
+        for (int k = 0; k * 512 < nprow; ++k)
+            for (int w = 0; w < 8; ++w) {
+                int m = 0;
+                for (int l = 0; l < 64; ++l) {
+                    const int i = k * 512 + w * 64 + l;
+                    if (i >= nprow) break;
+                    const int nq = (int)((pinfo[rdesc[(size_t)rd0 + i].x >> 20] >> 16) & 0x7fffu);
+                    m = std::max(m, nq);
+                    sum_quads += nq;
+                }
+                wmax[w] += m;
+            }
+        int mx = 0, tot = 0;
+        for (int w = 0; w < 8; ++w) { mx = std::max(mx, wmax[w]); tot += wmax[w]; }
+        sum_max += mx;
+        sum_mean += tot / 8.;
+        sum_rows += nprow;
+        ++gt;
+        hist[std::min(39, mx)]++;
+    }
+    fprintf(stderr, "brick wave stats: %ld G tiles, rows per tile %.1f, quads per row %.2f, per tile: slowest wave %.2f quads, mean wave %.2f quads (ratio %.2f)\n",
+            gt, sum_rows / gt, sum_quads / sum_rows, sum_max / gt, sum_mean / gt, sum_max / sum_mean);
+    fprintf(stderr, "  slowest-wave quads histogram:");
+    for (int i = 0; i < 40; ++i) if (hist[i]) fprintf(stderr, " %d:%ld", i, hist[i]);
+    fprintf(stderr, "\n");
+    if (out6) { out6[0] = (double)gt; out6[1] = sum_rows / gt; out6[2] = sum_quads / sum_rows; out6[3] = sum_max / gt; out6[4] = sum_mean / gt; out6[5] = sum_all + sum_lanes; }
+    return AVS_OK;
 }
 
 avs_status avs_spmv_solver_form(avs_ctx *c, const double *x, double *y, int32_t fused_dot, double *dot_out)

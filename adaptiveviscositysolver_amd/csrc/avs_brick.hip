@@ -221,6 +221,14 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         T *prod = emode ? xs : park + kBrickXSlots;
         const int cap = emode ? kBrickSlotsPad : kBrickPark - kBrickXSlots;
         BRICK_STAMP(1);
+        // Round 6: a CU runs three workgroups on the same SIMDs and the kernel is bound by instruction ISSUE (38 M VALU wave-instructions per
+        // launch at 512^3, 80 % of them outside the row walk).  A wave in this phase -- descriptors, the tile's ONE round trip of loads, LDS
+        // writes, with the whole workgroup waiting at the barrier behind it -- goes ahead of the other workgroups' row walks (s_setprio 2
+        // until the barrier), and so do, in the walk, the two waves with the tile's LONGEST rows (the execution order is sorted by pattern
+        // length: the slowest wave walks 8.9 quads per tile against a mean of 4.3 on the 512^3 beam, 5.5 against 2.7 on the 1024^3 sheet,
+        // and the next tile cannot start before it is done).  Measured (profiles/r06_notes.md): 512^3 beam 111.5 -> 104.2 us stand-alone,
+        // 1024^3 sheet 324 -> 305 us.
+        if (!BRICK_DBG(512)) __builtin_amdgcn_s_setprio(2);
 #ifdef AVS_PROBES
         if (BRICK_DBG(16) && threadIdx.x == 0 && iter < kStampTiles && blockIdx.x < kStampWgs) // tile kind: 1 E tile, 2 G tile with streamed rows, 0 G tile
         {
@@ -358,6 +366,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         __syncthreads();
         BRICK_STAMP(2);
 
+        __builtin_amdgcn_s_setprio(0);
         // ---- the next tile's block travels while this tile is multiplied (16 B per thread)
         blk = blocks16[(int64_t)tbn.x + (tid < (int)tbn.y ? tid : 0)];
 
@@ -382,6 +391,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                 const unsigned pi = pinfo[pid];
                 const uint4 *wq = reinterpret_cast<const uint4 *>(pw + (pi & 0xffffu));
                 const int nq = (int)((pi >> 16) & 0x7fffu);
+                if (!BRICK_DBG(2048) && k * kBrickBlk + (tid | 63) + 97 > nprow) __builtin_amdgcn_s_setprio(1); // the last two 64-row chunks of the execution order (three when the last holds < 32 rows)
                 // word: delta << 19 (signed 13) | 000 | lattice level << 14 | code << 3 -- byte offsets for 8-B elements; T = float reads
                 // the 4-B image of the table (BrickView::pwords32: delta << 18 | level << 14 | code << 2).  A pattern is padded to whole
                 // quads with words that repeat its first entry's slot with the code of 0.0: +-0.0 added to a sum that is never -0.0.
@@ -463,6 +473,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                     else walk(addr);
                 }
                 *reinterpret_cast<T *>(reinterpret_cast<char *>(y + row0) + (size_t)(unsigned)(ro * ES)) = sum;
+                __builtin_amdgcn_s_setprio(0);
                 if (DOT) dot += sum * lds_abs<T>(own8);
             }
             }
@@ -680,7 +691,7 @@ static avs_status spmv_brick_launch_t(const BrickView &B0, const T *x, T *y, dou
         B.pwords = B.pwords32;
     }
 #ifdef AVS_PROBES
-    static const int dbg = getenv("AVS_BRICK_DEBUG") ? atoi(getenv("AVS_BRICK_DEBUG")) : 0; // phase switches / stamps (measurement builds only)
+    const int dbg = getenv("AVS_BRICK_DEBUG") ? atoi(getenv("AVS_BRICK_DEBUG")) : 0; // phase switches / stamps (measurement builds only; read per launch: a probe script flips it)
     B.debug |= dbg;
 #endif
     if (B.vc) {

@@ -101,6 +101,9 @@ struct Options {
     BrickCost brick_cost;        // AVS_BRICK_COST=tile,row,run,word,etile,quad
     // single-GPU loop
     int fuse_beta = 1;
+    int fuse_vectors = 0;        // AVS_PCG_FUSE_VECTORS: the two vector kernels of the single-GPU loop as one launch with a grid barrier (k_update_fused,
+                                 // avs_pcg.hip): 0 never, 1 wherever the system qualifies, -1 only systems larger than the Infinity Cache
+    int fused_timeout_ms = 2000; // AVS_PCG_FUSED_TIMEOUT_MS: bound of that barrier's wait
     int post_dof_sample = -1;    // AVS_POST_DOF_SAMPLE: the transfer samples its nodes from the velocity DOFs (1) / by a sweep over the node lattices (0);
                                  // -1: from the DOFs when the level-0 node lattice has more than 32 x as many nodes as there are DOFs
     int prepass_temporal = 1;    // AVS_PREPASS_TEMPORAL: the device pre-pass skips what its allocations already hold from their last filling (0: every run fills everything)
@@ -380,6 +383,7 @@ constexpr int kBrickPatLen = 64;      // longest row stored as a pattern
 constexpr int kBrickTableMax = 2048;  // value dictionary entries (LDS resident)
 constexpr int kBrickMinRows = 64;     // bricks with fewer rows are merged into E tiles
 constexpr int64_t kBrickMinSystemRows = 2000000; // smaller systems run the CU-resident loop (or are launch-bound): the form is not built
+constexpr int64_t kBrickMinSystemRowsVc = 1000000; // ... matrices the resident loop cannot take (tile-local value tables): the form from here on
 constexpr double kBrickMinFill = 330., kBrickEighthsFill = 420.; // rows per tile: the form beats the word stream / the contiguous-eighths walk beats the dealt chunks
 constexpr int kBrickETileRows = 256;   // rows per E tile: its words fit one pass of the lattice's LDS (3936) unless the rows are long
 struct BrickView {
@@ -395,7 +399,8 @@ struct BrickView {
     const uint32_t *swords = nullptr; // code << col_bits | column, CSR order; col_bits == 0: 64-bit words column | code << 32
     const double *table = nullptr;
     int table_size = 0, col_bits = 0;
-    int debug = 0; // measurement only: 1 no fill, 2 no pattern rows, 4 no streamed rows (wrong results), 16 phase stamps
+    int debug = 0; // measurement only: 1 no fill, 2 no pattern rows, 4 no streamed rows (wrong results), 16 phase stamps, 512 / 2048 without the
+                   // load phase's / the longest rows' s_setprio
     int n_rows = 0; // partitioned systems: columns >= n_rows are halo entries ([owned | halo] local numbering)
     // planned walk (BrickForm::plan_walk): workgroup b of a grid of wgrid workgroups takes the tiles wlist[wptr[b] .. wptr[b + 1]) (tile_blk entries)
     const uint2 *wlist = nullptr;
@@ -529,6 +534,7 @@ struct PcgWork;
 avs_status pcg_create(PcgWork **w, int64_t n, int64_t n_ext, hipStream_t stream);
 void pcg_destroy(PcgWork *w);
 int64_t pcg_rows(const PcgWork *w); // rows the workspace was sized for (-1: none)
+void pcg_fused_state(const PcgWork *w, int *used, int *faults); // k_update_fused: the last solve ran it / launches whose barrier timed out
 
 // Jacobi-PCG in Eigen's operation order; x holds the initial guess, returns the solution.
 // Optional halo hook (multi-GPU) is wired by avs_dist.hip through PcgDist.

@@ -43,6 +43,9 @@ struct PcgWork {
     DevBuf<double> cancel_word; // partitioned solves: [0] this rank's avs_cancel request as the kernels / the all-reduce see it (0. / 1.)
     DevBuf<int> cancel_dev;     // ... and as an int for the finalizer of the direct transport
     int resident_faults = 0; // CU-resident launches of this workspace that ended in a timed-out wait
+    DevBuf<unsigned long long> fused_bar; // k_update_fused: the grid barrier's ticket counter (monotonic)
+    bool fused_off = false;  // ... a launch of it timed out at its barrier on this workspace: the two-launch form from then on
+    int fused_faults = 0, fused_used = 0;
     DevBuf<double> s, u; // single-reduction variant (multi-GPU): s = A p recurrence, u = M^-1 r with halo tail
     DevBuf<PcgScalars> sc;
     DevBuf<double> stage2;         // direct transport: per-workgroup SpMV sums of the halo-touching launch
@@ -1104,6 +1107,238 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, double *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// Round 6 (review r05 #3): k_update_r and k_update_xp as ONE launch for HBM-sized systems -- r -= alpha t with its two sums, a GRID
+// BARRIER, then x += alpha p ; p = invd r + beta p with the new r (and the diagonal codes) still in REGISTERS: 7.25 n instead of
+// 8.5 n doubles of traffic per iteration and one launch boundary less.  kFusedGrid workgroups of 1024 threads, one per CU (128 registers
+// per lane: 16 rows of r per lane x 2); every sum is formed in exactly the order of the two kernels it replaces -- thread T of
+// workgroup B plays the threads (T & 255) of the 256-thread workgroups 4 B + (T >> 8) and 1024 + 4 B + (T >> 8) of the
+// kVecGrid-workgroup launches (same rows, same order, the same wave / four-wave folds, the same partial-sum arrays, the same 256-lane
+// folds of them) -- so the iteration, its scalars and the solution are bit-identical with the option on or off.
+// The barrier: the partial sums leave with write-through stores (agent scope), one monotonic 64-bit counter (never reset: a launch's
+// target is the next multiple of the grid above its own ticket), relaxed polls with s_sleep, bounded by wall_clock64 -- a grid that is
+// not co-resident in time (the GPU shared with other work) sets sc->fault instead of hanging.  No L2 write-back fence anywhere: what
+// crosses the barrier is read with agent-scope loads.  Plain launch (a graph node like any other); needs every CU free, which holds behind the persistent SpMV.
+// ---------------------------------------------------------------------------------------------
+static constexpr size_t kFusedLds = (size_t)8 * 1024 * 16; // the second emulated workgroup's new r: kFusedPairs x kFusedBlock pairs of doubles
+static constexpr unsigned kFusedStride = (unsigned)kVecGrid * kBlock * 16u; // bytes between two pairs of an emulated thread
+static constexpr int kFusedBlock = 1024, kFusedPairs = 8, kFusedBatch = 4; // (loads in flight per lane: kFusedBatch pairs of rows of each stream)
+// (kFusedPairs pairs of rows per emulated thread: n <= 2 * kFusedPairs * kVecGrid * kBlock rows)
+// element at a 32-bit BYTE offset from a uniform base (global_load ... saddr: no 64-bit address per lane and stream kept in registers)
+template <class T> __device__ __forceinline__ T *at_off(T *base, unsigned byte_off)
+{
+    return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + (size_t)byte_off);
+}
+template <class T> __device__ __forceinline__ const T *at_off(const T *base, unsigned byte_off)
+{
+    return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (size_t)byte_off);
+}
+__device__ __forceinline__ double quarter_sum(double v, double *lds4, int t) // block_sum of the 256-thread workgroup this quarter plays (valid where t == 0)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((t & 63) == 0) lds4[t >> 6] = v;
+    __syncthreads();
+    double s = 0.;
+    if (t == 0) s = ((lds4[0] + lds4[1]) + lds4[2]) + lds4[3];
+    return s;
+}
+template <bool CODED, bool KEEP>
+__global__ __launch_bounds__(kFusedBlock) void k_update_fused(int64_t n, double *__restrict__ x, double *__restrict__ p, double *__restrict__ r,
+                                                              const double *__restrict__ t, const double *__restrict__ invd,
+                                                              const uint16_t *__restrict__ dcode, PcgScalars *sc, double *__restrict__ vpart,
+                                                              const double *__restrict__ spmv_partial, int nb, int parity,
+                                                              unsigned long long *__restrict__ bar, long long timeout_ticks)
+{
+    {
+        const int d = sc->done;
+        if (d) {
+            if (blockIdx.x == 0 && threadIdx.x == 0 && d == 2) sc->done = 1; // the pending x update has run
+            return;
+        }
+    }
+    __shared__ double red[4][4];
+    __shared__ double bc[4];
+    __shared__ int sh_fail;
+    const int T = threadIdx.x, tq = T & 255, q = T >> 8;
+    constexpr int g = kVecGrid;
+    // ---- alpha: the fold of the SpMV's partial sums as every workgroup of k_update_r<FUSED> does it
+    double pap = 0.;
+    if (q == 0)
+        for (int k = tq; k < nb; k += kBlock) pap += spmv_partial[k];
+    pap = quarter_sum(pap, red[q], tq);
+    if (T == 0) { bc[0] = pap; sh_fail = 0; }
+    __syncthreads();
+    pap = bc[0];
+    const double rho_old = parity ? sc->rho_alt : sc->rho;
+    const double alpha = rho_old / pap;
+    // ---- phase 1: r -= alpha t   (loads of a lane beyond the last pair are clamped to pair 0 and their results dropped: no branches
+    //      around the loads, one predicate per store and per sum)
+ const int64_t n2 = n >> 1;
+    const unsigned lim = (unsigned)n2 * 16u;               // byte offset behind the last pair
+    d2_t rn[kFusedPairs];                                  // the new r of the first emulated workgroup's rows: registers ...
+    extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
+    d2_t *rl = reinterpret_cast<d2_t *>(fused_lds);        // ... of the second one's: LDS, rl[m * kFusedBlock + T] (128 KiB)
+    double rr[2] = {0., 0.}, rz[2] = {0., 0.};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int b = (int)blockIdx.x * 4 + q + (g / 2) * h;
+        const unsigned o0 = ((unsigned)b * kBlock + (unsigned)tq) * 16u; // byte offset of this lane's first pair (n < 2^28 rows: checked by the host)
+#pragma unroll
+        for (int m0 = 0; m0 < kFusedPairs; m0 += kFusedBatch) {
+            d2_t rv[kFusedBatch], tv[kFusedBatch], idv[kFusedBatch];
+            unsigned cc[kFusedBatch];
+#pragma unroll
+            for (int u = 0; u < kFusedBatch; ++u) {
+                const unsigned oj = o0 + (unsigned)(m0 + u) * kFusedStride;
+                const unsigned o = oj < lim ? oj : 0u;
+                rv[u] = *reinterpret_cast<const d2_t *>(at_off(r, o));
+                tv[u] = stream_load_k<KEEP>(reinterpret_cast<const d2_t *>(at_off(t, o)));
+                if (CODED) cc[u] = *reinterpret_cast<const unsigned *>(at_off(dcode, o >> 2)); // (read again in phase 2: 0.25 n)
+                else idv[u] = *reinterpret_cast<const d2_t *>(at_off(invd, o));
+            }
+#pragma unroll
+            for (int u = 0; u < kFusedBatch; ++u) {
+                const int m = m0 + u;
+                const unsigned oj = o0 + (unsigned)m * kFusedStride;
+                double id0, id1;
+                if (CODED) { id0 = invd[cc[u] & 0xffffu]; id1 = invd[cc[u] >> 16]; }
+                else { id0 = idv[u].x; id1 = idv[u].y; }
+                d2_t v;
+                v.x = rv[u].x - alpha * tv[u].x;
+                v.y = rv[u].y - alpha * tv[u].y;
+                if (h == 0) rn[m] = v;
+                else rl[m * kFusedBlock + T] = v;
+                if (oj < lim) {
+                    *reinterpret_cast<d2_t *>(at_off(r, oj)) = v;
+                    rr[h] += v.x * v.x;
+                    rz[h] += v.x * (id0 * v.x);
+                    rr[h] += v.y * v.y;
+                    rz[h] += v.y * (id1 * v.y);
+                }
+            }
+            asm volatile("" ::: "memory"); // (the next batch's loads stay behind this batch: registers)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    double r_last = 0.;
+    if ((n & 1) && blockIdx.x == 0 && T == 0) { // (the odd last row: thread 0 of workgroup 0 of k_update_r)
+        const int64_t i = n - 1;
+        r_last = r[i] - alpha * t[i];
+        r[i] = r_last;
+        rr[0] += r_last * r_last;
+        rz[0] += r_last * ((CODED ? invd[dcode[i]] : invd[i]) * r_last);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const double srr = quarter_sum(rr[h], red[q], tq);
+        const double srz = quarter_sum(rz[h], red[q], tq);
+        if (tq == 0) { // write-through: the other workgroups read these behind the barrier
+            const int b = (int)blockIdx.x * 4 + q + (g / 2) * h;
+            __hip_atomic_store(vpart + b, srr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(vpart + g + b, srz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // ---- grid barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the partial sums are acknowledged before the ticket is drawn
+    __syncthreads();
+    if (T == 0) {
+        const unsigned long long ticket = __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long target = (ticket / gridDim.x + 1ull) * gridDim.x;
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > timeout_ticks) { sh_fail = 1; break; }
+        }
+    }
+    __syncthreads();
+    if (sh_fail) { // not every workgroup arrived in time: the solve is void (the host reads sc->fault and redoes it with the two launches)
+        if (T == 0) {
+            __hip_atomic_store(&sc->fault, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sc->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    // ---- beta: the fold of the 2 g partial sums as every workgroup of k_update_xp<FUSED> does it
+    double frr = 0., frz = 0.;
+    if (q == 0)
+        for (int i = tq; i < g; i += kBlock) {
+            frr += __hip_atomic_load(vpart + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            frz += __hip_atomic_load(vpart + g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    frr = quarter_sum(frr, red[q], tq);
+    frz = quarter_sum(frz, red[q], tq);
+    if (T == 0) { bc[1] = frr; bc[2] = frz; }
+    __syncthreads();
+    frr = bc[1];
+    frz = bc[2];
+    int done = 0;
+    double beta = 0.;
+    if (frr < sc->threshold) done = 2; // Eigen: break before i++ (x += alpha p still runs)
+    else beta = frz / rho_old;
+    if (blockIdx.x == 0 && T == 0) { // what OP_ALPHA and OP_BETA do
+        sc->pAp = pap;
+        sc->alpha = alpha;
+        sc->red[0] = frr;
+        sc->red[1] = frz;
+        sc->rr = frr;
+        if (done == 2) sc->done = 2;
+        else {
+            if (parity) sc->rho = frz;
+            else sc->rho_alt = frz;
+            sc->beta = beta;
+            sc->iter += 1;
+        }
+    }
+    // ---- phase 2: x += alpha p ; p = invd r + beta p
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int b = (int)blockIdx.x * 4 + q + (g / 2) * h;
+        unsigned o0 = ((unsigned)b * kBlock + (unsigned)tq) * 16u;
+        asm volatile("" : "+v"(o0)); // (opaque: the addresses are formed again here instead of being carried, spilled, across the barrier from phase 1)
+#pragma unroll
+        for (int m0 = 0; m0 < kFusedPairs; m0 += kFusedBatch) {
+            d2_t pv[kFusedBatch], xv[kFusedBatch], idv[kFusedBatch]; // (the diagonal codes / the inverse diagonal are read again, r stays in registers)
+            unsigned cc[kFusedBatch];
+#pragma unroll
+            for (int u = 0; u < kFusedBatch; ++u) {
+                const unsigned oj = o0 + (unsigned)(m0 + u) * kFusedStride;
+                const unsigned o = oj < lim ? oj : 0u;
+                pv[u] = *reinterpret_cast<const d2_t *>(at_off(p, o));
+                xv[u] = stream_load_k<KEEP>(reinterpret_cast<const d2_t *>(at_off(x, o)));
+                if (CODED) cc[u] = stream_load_k<KEEP>(reinterpret_cast<const unsigned *>(at_off(dcode, o >> 2)));
+                else idv[u] = *reinterpret_cast<const d2_t *>(at_off(invd, o));
+            }
+#pragma unroll
+            for (int u = 0; u < kFusedBatch; ++u) {
+                const int m = m0 + u;
+                const unsigned oj = o0 + (unsigned)m * kFusedStride;
+                double id0, id1;
+                if (CODED) { id0 = invd[cc[u] & 0xffffu]; id1 = invd[cc[u] >> 16]; }
+                else { id0 = idv[u].x; id1 = idv[u].y; }
+                d2_t xn, pn;
+                const d2_t rv = h == 0 ? rn[m] : rl[m * kFusedBlock + T];
+                xn.x = xv[u].x + alpha * pv[u].x;
+                xn.y = xv[u].y + alpha * pv[u].y;
+                pn.x = id0 * rv.x + beta * pv[u].x;
+                pn.y = id1 * rv.y + beta * pv[u].y;
+                if (oj < lim) {
+                    stream_store_k<KEEP>(xn, reinterpret_cast<d2_t *>(at_off(x, oj)));
+                    if (done != 2) *reinterpret_cast<d2_t *>(at_off(p, oj)) = pn;
+                }
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && T == 0) {
+        const int64_t i = n - 1;
+        const double pi = p[i];
+        x[i] += alpha * pi;
+        if (done != 2) p[i] = (CODED ? invd[dcode[i]] : invd[i]) * r_last + beta * pi;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // scalar stages.  One 256-thread block sums `nb` partials of `nred` interleaved arrays in a fixed
 // order (deterministic), then (optionally) applies the scalar update.
 // ---------------------------------------------------------------------------------------------
@@ -1963,6 +2198,11 @@ avs_status pcg_create(PcgWork **out, int64_t n, int64_t n_ext, hipStream_t)
 }
 
 int64_t pcg_rows(const PcgWork *w) { return w ? w->n : -1; }
+void pcg_fused_state(const PcgWork *w, int *used, int *faults)
+{
+    if (used) *used = w ? w->fused_used : 0;
+    if (faults) *faults = w ? w->fused_faults : 0;
+}
 
 void pcg_destroy(PcgWork *w)
 {
@@ -2161,6 +2401,36 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
     fuse_beta = fuse_beta && cur_opt().fuse_beta != 0;
     static_assert(kChunk % 2 == 0, "the parity of an iteration is taken from its position in the chunk");
     const int keep = A.keep_cached ? 1 : 0; // matrix + vectors fit the Infinity Cache: no non-temporal hints in the vector kernels
+    // one fused launch for the two vector kernels (k_update_fused): HBM-sized single-GPU systems whose rows fit its registers, a device
+    // with one CU per workgroup of its grid; the initial guess is kept so that a timed-out barrier costs a redo, not a wrong answer
+    bool fuse_vec = false;
+    if (!dist && fuse_beta && cur_opt().fuse_vectors != 0 && !w->fused_off && g == kVecGrid &&
+        n <= (int64_t)2 * kFusedPairs * kVecGrid * kBlock && n < ((int64_t)1 << 28) && (cur_opt().fuse_vectors > 0 || !keep)) {
+        int dev = 0, cus = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        fuse_vec = cus >= kVecGrid / 8;
+    }
+    if (fuse_vec) {
+        static std::atomic<unsigned long long> raised{0}; // the kernel's dynamic LDS limit: once per device
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && !((raised.load() >> dev) & 1ull)) {
+            AVS_HIP(hipFuncSetAttribute((const void *)k_update_fused<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds));
+            AVS_HIP(hipFuncSetAttribute((const void *)k_update_fused<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds));
+            AVS_HIP(hipFuncSetAttribute((const void *)k_update_fused<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds));
+            AVS_HIP(hipFuncSetAttribute((const void *)k_update_fused<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds));
+            raised.fetch_or(1ull << dev);
+        }
+        if (!w->fused_bar.p) {
+            AVS_TRY(w->fused_bar.alloc(2));
+            AVS_HIP(hipMemsetAsync(w->fused_bar.p, 0, 2 * sizeof(unsigned long long), stream));
+        }
+        AVS_TRY(w->x_save.alloc((size_t)n));
+        AVS_HIP(hipMemcpyAsync(w->x_save.p, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    }
+    w->fused_used = fuse_vec ? 1 : 0;
+    const long long fused_timeout = (long long)cur_opt().fused_timeout_ms * 100000ll; // wall_clock64: 100 MHz
     auto enqueue_iteration = [&](int c, bool timed) -> avs_status {
         int nb = 0;
         if (dist) AVS_TRY(dist_halo_exchange(dist, p, stream));
@@ -2172,6 +2442,19 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
         const int parity = fuse_beta ? (c & 1) : 0;
         const bool fuse_alpha = fuse_beta && nb <= kFuseAlphaMax; // few SpMV partials: every workgroup of k_update_r folds them itself
         double *vpart = fuse_alpha ? partial + (w->npartial / 2) : partial; // (the SpMV's are still being read)
+        if (fuse_vec && fuse_alpha) {
+            const int fg = kVecGrid / 8;
+#define AVS_FUSED_LAUNCH(C, K, ...) hipLaunchKernelGGL((k_update_fused<C, K>), dim3(fg), dim3(kFusedBlock), kFusedLds, stream, __VA_ARGS__)
+            if (coded) {
+                if (keep) AVS_FUSED_LAUNCH(true, true, n, x, p, r, t, w->invtab.p, w->dcode.p, sc, vpart, partial, nb, parity, w->fused_bar.p, fused_timeout);
+                else AVS_FUSED_LAUNCH(true, false, n, x, p, r, t, w->invtab.p, w->dcode.p, sc, vpart, partial, nb, parity, w->fused_bar.p, fused_timeout);
+            } else {
+                if (keep) AVS_FUSED_LAUNCH(false, true, n, x, p, r, t, invd, nullptr, sc, vpart, partial, nb, parity, w->fused_bar.p, fused_timeout);
+                else AVS_FUSED_LAUNCH(false, false, n, x, p, r, t, invd, nullptr, sc, vpart, partial, nb, parity, w->fused_bar.p, fused_timeout);
+            }
+#undef AVS_FUSED_LAUNCH
+            return AVS_OK;
+        }
         if (fuse_alpha) {
             if (coded) AVS_VEC_LAUNCH(k_update_r, true, true, n, r, t, w->invtab.p, w->dcode.p, sc, vpart, partial, nb, parity);
             else AVS_VEC_LAUNCH(k_update_r, false, true, n, r, t, invd, nullptr, sc, vpart, partial, nb, parity);
@@ -2216,7 +2499,7 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
         timed_chunk = !replay;
         if (replay) {
             const void *key[10] = {A.row_ptr, A.col, A.val, A.codes, A.packed, A.table, x, (const void *)(intptr_t)A.n,
-                                   (const void *)(intptr_t)(A.table_size * 64 + A.col_bits), (const void *)(intptr_t)((coded ? 1 : 0) | (fuse_beta ? 2 : 0) | (A.brick ? 4 : 0) | (int64_t)(A.epoch << 3))};
+                                   (const void *)(intptr_t)(A.table_size * 64 + A.col_bits), (const void *)(intptr_t)((coded ? 1 : 0) | (fuse_beta ? 2 : 0) | (A.brick ? 4 : 0) | (int64_t)(A.epoch << 4) | (fuse_vec ? 8 : 0))};
             if (w->graph && (memcmp(key, w->graph_key, sizeof(key)) != 0 || w->graph_tol != tol)) {
                 (void)hipGraphExecDestroy(w->graph);
                 w->graph = nullptr;
@@ -2249,6 +2532,16 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
         AVS_HIP(hipGetLastError());
         enqueued += chunk;
         last_chunk = chunk;
+    }
+#ifdef AVS_PROBES
+    if (fuse_vec && getenv("AVS_PCG_FUSED_FAKE_FAULT")) w->host_sc->fault = 4; // test hook of exactly the path below (probe build only)
+#endif
+    if (fuse_vec && w->host_sc->fault == 4) { // the fused launch's grid barrier timed out (GPU shared with other work): the solve again, from
+        w->fused_off = true;                    // the initial guess, with the two vector launches -- on this workspace from now on
+        w->fused_faults++;
+        if (w->graph) { (void)hipGraphExecDestroy(w->graph); w->graph = nullptr; }
+        AVS_HIP(hipMemcpyAsync(x, w->x_save.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        return pcg_solve(w, A, b, x, tol, max_iters, stream, info, dist);
     }
     AVS_HIP(hipEventRecord(w->ev1, stream));
     AVS_HIP(hipEventSynchronize(w->ev1));

@@ -144,7 +144,11 @@ avs_status build_reordered_system(avs_ctx *c, int brick_shift)
     // systems too large for the CU-resident loop: the brick-structured form of the matrix (avs_brick.hip); AVS_BRICK=0 / 1 never / always
     c->brick.clear();
     const int mode = c->opt.brick; // -1 auto, 0 never, 1 always, 2 tune
-    int want = (mode == 0) ? 0 : (mode == 1 ? 1 : (n >= kBrickMinSystemRows ? 1 : 0));
+    // (matrices without one small dictionary -- variable viscosity: tile-local tables or > kViLdsTable values -- never run the CU-resident loop:
+    //  the form serves them from kBrickMinSystemRowsVc rows on.  BASELINE configs[2], 256^3 mu(x), 1.27 M rows: 14.5 k -> 15.7 k it/s, round 6)
+    const bool resident_kind = c->vi.table_size > 0 && !c->vi.tile_tables && c->vi.table_size <= kBrickTableMax; // (= kViLdsTable of avs_pcg.hip: what the resident loop stages)
+    const int64_t min_rows = resident_kind ? kBrickMinSystemRows : kBrickMinSystemRowsVc;
+    int want = (mode == 0) ? 0 : (mode == 1 ? 1 : (n >= min_rows ? 1 : 0));
     // AUTO keeps the form where it multiplies faster than the word stream, and picks its tile walk (BrickView::walk).  Both follow from
     // a STRUCTURAL rule -- rows per tile -- so that the same input gives the same kernel, the same fold order of p.Ap and therefore the
     // same iteration count and solution bits in every run, with or without a profiler attached (round-4 review: the choice used to be

@@ -199,12 +199,18 @@ typedef enum {
                                    * both forms at the assembly: host-synchronous and not reproducible from run to run); takes effect at the next avs_assemble */
     AVS_OPTION_FUSED_SCALAR_STEPS = 6, /* 1 (default): the CG scalar steps ride in the vector kernels; 0: one reduction launch per step */
     AVS_OPTION_RELOAD_ENVIRONMENT = 7, /* any value: take the AVS_* environment variables again (they are read once, at avs_create; tools and tests) */
-    AVS_OPTION_F32_VECTORS = 8    /* AVS_PRECISION_F32 contexts, single-GPU solves: 1 = the iteration runs on float vectors with float scalars --
+    AVS_OPTION_F32_VECTORS = 8,   /* AVS_PRECISION_F32 contexts, single-GPU solves: 1 = the iteration runs on float vectors with float scalars --
                                    * SolveType = fpreal32 through Eigen::ConjugateGradient (util.h:25-37, cpp:613-630) --; 0 = fp64 iteration on
                                    * the float system; -1 (default) = float vectors where the system is too large for the CU-resident loop
                                    * (the bandwidth of the vectors is what an iteration costs there), the resident fp64 loop where it fits the
                                    * chip (faster).  Takes effect at the next avs_assemble (the brick form's walk is laid out for the kernel
                                    * that will run). */
+    AVS_OPTION_FUSED_VECTOR_UPDATE = 9  /* single-GPU launch-per-phase loop: r -= alpha t and x += alpha p ; p = z + beta p as ONE launch with a grid barrier
+                                   * in between -- the new r stays in registers / LDS, 7.25 n instead of 8.5 n doubles per iteration; same sums in the
+                                   * same order: iteration counts and solution bits do not depend on it.  0 never, 1 wherever a system qualifies
+                                   * (>= 524,288 and <= 8,388,608 rows, a device with >= 256 CUs), -1 only systems larger than the Infinity Cache.
+                                   * A barrier that is not passed within AVS_PCG_FUSED_TIMEOUT_MS (2000; the GPU shared with other work) redoes
+                                   * the solve with the two launches.  Environment: AVS_PCG_FUSE_VECTORS. */
 } avs_solver_option;
 enum { AVS_USE_TRANSPORT_AUTO = 0, AVS_USE_TRANSPORT_RCCL = 1, AVS_USE_TRANSPORT_DIRECT = 2 };
 enum { AVS_BRICK_AUTO = -1, AVS_BRICK_NEVER = 0, AVS_BRICK_ALWAYS = 1, AVS_BRICK_TUNE = 2 };
@@ -240,6 +246,8 @@ typedef struct avs_matrix_format {
     int32_t brick_walk;         /* tile walk of the persistent workgroups: 0 one contiguous eighth of the tiles per XCD, 1 chunks dealt to the XCDs in turn */
     int32_t brick_value_codes;  /* 1 = variable-viscosity variant: the patterns carry the geometry only, every pattern row streams its own 2-B value codes
                                  * into a per-tile value table (round 5) */
+    int32_t fused_vector_update; /* 1 = the last avs_solve ran the two vector kernels of an iteration as one launch (AVS_OPTION_FUSED_VECTOR_UPDATE, round 6) */
+    int32_t fused_vector_faults; /* launches of it on this context whose grid barrier timed out (the solve was redone with the two launches) */
 } avs_matrix_format;
 avs_status avs_get_matrix_format(avs_ctx *ctx, avs_matrix_format *fmt);
 avs_status avs_get_solution(avs_ctx *ctx, double *x, int64_t n, avs_memspace where);

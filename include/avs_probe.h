@@ -31,6 +31,10 @@ avs_status avs_spmv_solver_form(avs_ctx *ctx, const double *x, double *y, int32_
  * [owned | halo] entries in local numbering (n_own + n_halo doubles, device), y its n_own rows */
 avs_status avs_dist_spmv_local_form(avs_ctx *ctx, const double *x_ext, double *y, int32_t fused_dot, double *dot_out);
 
+/* Measurement: load balance of the brick kernel's row walk -- per G tile the quads of the slowest of the eight waves against the mean wave
+ * (printed to stderr; out6 = {tiles, rows per tile, quads per row, slowest-wave quads, mean-wave quads, 0}) */
+avs_status avs_brick_wave_stats(avs_ctx *ctx, double *out6);
+
 /* Measured stream ceilings of the device for the access pattern of the SpMV's matrix stream
  * (mode 0: read-only 16 B/lane, 1: read-only non-temporal, 2: copy); GB/s of bytes moved. */
 avs_status avs_bench_stream(int32_t mode, int64_t bytes, int32_t repeats, int32_t device, double *gbps);
