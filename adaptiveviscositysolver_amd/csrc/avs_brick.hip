@@ -41,6 +41,18 @@
 namespace avs {
 
 constexpr int kBrickBlk = 512;
+#ifndef AVS_BRICK_TAIL
+#define AVS_BRICK_TAIL 2      // chunks of the execution order that count as a tile's tail
+#endif
+#ifndef AVS_BRICK_TAIL_PRIO
+#define AVS_BRICK_TAIL_PRIO 1
+#endif
+#ifndef AVS_BRICK_LOAD_PRIO
+#define AVS_BRICK_LOAD_PRIO 2
+#endif
+#ifndef AVS_BRICK_PRIO
+#define AVS_BRICK_PRIO 3 // s_setprio placements (see the load phase below): 0 none, 1 load phase, 2 + waves 6 and 7 in the walk, 3 + the waves of the tile's last two chunks
+#endif
 
 #ifdef AVS_PROBES
 // measurement only (AVS_BRICK_DEBUG & 16): wall_clock64 stamps of workgroup phases, 8 per tile, first kStampTiles tiles of every workgroup
@@ -132,6 +144,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
     const uint32_t *bw = reinterpret_cast<const uint32_t *>(park + kBrickXSlots);
     const int tid = threadIdx.x;
     const int lane = tid & 63, l16 = tid & 15, qw = tid >> 4;
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);          // (scalar)
     const bool wide = VC || B.col_bits == 0;                             // 64-bit streamed words: column | code << 32 (VC: 96 bits, column | value)
     const unsigned cmask = wide ? 0xffffffffu : (1u << B.col_bits) - 1u;
     const int cbits = B.col_bits;
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         // length: the slowest wave walks 8.9 quads per tile against a mean of 4.3 on the 512^3 beam, 5.5 against 2.7 on the 1024^3 sheet,
         // and the next tile cannot start before it is done).  Measured (profiles/r06_notes.md): 512^3 beam 111.5 -> 104.2 us stand-alone,
         // 1024^3 sheet 324 -> 305 us.
-        if (!BRICK_DBG(512)) __builtin_amdgcn_s_setprio(2);
+        if (AVS_BRICK_PRIO >= 1) __builtin_amdgcn_s_setprio(AVS_BRICK_LOAD_PRIO);
 #ifdef AVS_PROBES
         if (BRICK_DBG(16) && threadIdx.x == 0 && iter < kStampTiles && blockIdx.x < kStampWgs) // tile kind: 1 E tile, 2 G tile with streamed rows, 0 G tile
         {
@@ -313,7 +326,15 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
             rdv[k] = uint2{0u, 0u};
             if (k * kBrickBlk < nprow) {
                 const int i = tid + k * kBrickBlk;
+#ifdef AVS_EXP_MNT
+                {
+                    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+                    const u2v v = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(reinterpret_cast<const char *>(B.rdesc + rd0) + (size_t)((unsigned)(i < nprow ? i : 0) * 8u)));
+                    rdv[k] = uint2{v.x, v.y};
+                }
+#else
                 rdv[k] = ld_u32(B.rdesc + rd0, (unsigned)(i < nprow ? i : 0));
+#endif
             }
         }
         // streamed rows (few tiles): descriptors (valid for brick_srow_of_thread(tid, k) < nsrows), and for a G tile the first pass of words with their x
@@ -366,7 +387,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         __syncthreads();
         BRICK_STAMP(2);
 
-        __builtin_amdgcn_s_setprio(0);
+        if (AVS_BRICK_PRIO >= 1) __builtin_amdgcn_s_setprio(0);
         // ---- the next tile's block travels while this tile is multiplied (16 B per thread)
         blk = blocks16[(int64_t)tbn.x + (tid < (int)tbn.y ? tid : 0)];
 
@@ -391,7 +412,9 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                 const unsigned pi = pinfo[pid];
                 const uint4 *wq = reinterpret_cast<const uint4 *>(pw + (pi & 0xffffu));
                 const int nq = (int)((pi >> 16) & 0x7fffu);
-                if (!BRICK_DBG(2048) && k * kBrickBlk + (tid | 63) + 97 > nprow) __builtin_amdgcn_s_setprio(1); // the last two 64-row chunks of the execution order (three when the last holds < 32 rows)
+                // (the wave's chunk of the execution order is one of the tile's last two: a scalar test -- as a per-lane test on the row index it
+                //  cost two more spilled registers and made the kernel 4 % SLOWER than no priority at all)
+                if (AVS_BRICK_PRIO == 2 ? wave_id >= 6 : (AVS_BRICK_PRIO >= 3 && k * (kBrickBlk / 64) + wave_id + AVS_BRICK_TAIL >= ((nprow + 63) >> 6))) __builtin_amdgcn_s_setprio(AVS_BRICK_TAIL_PRIO);
                 // word: delta << 19 (signed 13) | 000 | lattice level << 14 | code << 3 -- byte offsets for 8-B elements; T = float reads
                 // the 4-B image of the table (BrickView::pwords32: delta << 18 | level << 14 | code << 2).  A pattern is padded to whole
                 // quads with words that repeat its first entry's slot with the code of 0.0: +-0.0 added to a sum that is never -0.0.
@@ -472,8 +495,12 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                     if (VC) walk_vc(addr);
                     else walk(addr);
                 }
+#ifdef AVS_EXP_YNT
+                __builtin_nontemporal_store(sum, reinterpret_cast<T *>(reinterpret_cast<char *>(y + row0) + (size_t)(unsigned)(ro * ES)));
+#else
                 *reinterpret_cast<T *>(reinterpret_cast<char *>(y + row0) + (size_t)(unsigned)(ro * ES)) = sum;
-                __builtin_amdgcn_s_setprio(0);
+#endif
+                if (AVS_BRICK_PRIO >= 2) __builtin_amdgcn_s_setprio(0);
                 if (DOT) dot += sum * lds_abs<T>(own8);
             }
             }
@@ -481,6 +508,9 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         BRICK_STAMP(3);
         // streamed rows: passes of `cap` products parked in LDS, then every row adds its segment left to right
         if (nsw > 0 && !BRICK_DBG(4)) {
+#ifdef AVS_EXP_SPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
             T ssum[kBrickMaxRows / kBrickBlk];
 #pragma unroll
             for (int k = 0; k < kBrickMaxRows / kBrickBlk; ++k) ssum[k] = 0;
@@ -537,6 +567,9 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                     if (DOT) dot += ssum[k] * x[row];
                 }
         }
+#ifdef AVS_EXP_SPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         BRICK_STAMP(4);
         if (!more) break;
         ++iter;

@@ -987,7 +987,11 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, double *__restri
     const int64_t n2 = n >> 1; // two rows per thread (16-B accesses), partial sums in the order (even row, odd row)
     for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n2; j += (int64_t)gridDim.x * kBlock) {
         const int64_t i = 2 * j;
+#ifndef AVS_EXP_NO_RNT
+        const d2_t rv = stream_load_k<KEEP>(reinterpret_cast<const d2_t *>(r + i));
+#else
         const d2_t rv = *reinterpret_cast<const d2_t *>(r + i);
+#endif
         const d2_t tv = stream_load_k<KEEP>(reinterpret_cast<const d2_t *>(t + i));
         double id0, id1;
         if (CODED) {
@@ -1002,7 +1006,11 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, double *__restri
         d2_t rn;
         rn.x = rv.x - alpha * tv.x;
         rn.y = rv.y - alpha * tv.y;
+#ifndef AVS_EXP_NO_RNT
+        stream_store_k<KEEP>(rn, reinterpret_cast<d2_t *>(r + i));
+#else
         *reinterpret_cast<d2_t *>(r + i) = rn;
+#endif
         rr += rn.x * rn.x;
         rz += rn.x * (id0 * rn.x);
         rr += rn.y * rn.y;
@@ -1119,6 +1127,7 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, double *__restr
 // not co-resident in time (the GPU shared with other work) sets sc->fault instead of hanging.  No L2 write-back fence anywhere: what
 // crosses the barrier is read with agent-scope loads.  Plain launch (a graph node like any other); needs every CU free, which holds behind the persistent SpMV.
 // ---------------------------------------------------------------------------------------------
+static constexpr size_t kFusedTabBytes = (size_t)(2048 + 1) * sizeof(double) + 8; // CODED: the inverted dictionary (kViLdsTable + 1 entries)
 static constexpr size_t kFusedLds = (size_t)8 * 1024 * 16; // the second emulated workgroup's new r: kFusedPairs x kFusedBlock pairs of doubles
 static constexpr unsigned kFusedStride = (unsigned)kVecGrid * kBlock * 16u; // bytes between two pairs of an emulated thread
 static constexpr int kFusedBlock = 1024, kFusedPairs = 8, kFusedBatch = 4; // (loads in flight per lane: kFusedBatch pairs of rows of each stream)
@@ -1147,7 +1156,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_update_fused(int64_t n, double 
                                                               const double *__restrict__ t, const double *__restrict__ invd,
                                                               const uint16_t *__restrict__ dcode, PcgScalars *sc, double *__restrict__ vpart,
                                                               const double *__restrict__ spmv_partial, int nb, int parity,
-                                                              unsigned long long *__restrict__ bar, long long timeout_ticks)
+                                                              unsigned long long *__restrict__ bar, long long timeout_ticks, int tab_n)
 {
     {
         const int d = sc->done;
@@ -1161,7 +1170,12 @@ __global__ __launch_bounds__(kFusedBlock) void k_update_fused(int64_t n, double 
     __shared__ int sh_fail;
     const int T = threadIdx.x, tq = T & 255, q = T >> 8;
     constexpr int g = kVecGrid;
-    // ---- alpha: the fold of the SpMV's partial sums as every workgroup of k_update_r<FUSED> does it
+    if (CODED) { // the inverted dictionary into LDS (a look-up per row and phase: from L1 it was a second, dependent round trip per batch)
+        extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds0[];
+        double *tw = reinterpret_cast<double *>(fused_lds0 + kFusedLds);
+        for (int i = T; i < tab_n; i += kFusedBlock) tw[i] = invd[i];
+    }
+    // ---- alpha: the fold of the SpMV's partial sums as every workgroup of k_update_r<FUSED> does it (the barriers in it publish the table)
     double pap = 0.;
     if (q == 0)
         for (int k = tq; k < nb; k += kBlock) pap += spmv_partial[k];
@@ -1178,6 +1192,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_update_fused(int64_t n, double 
     d2_t rn[kFusedPairs];                                  // the new r of the first emulated workgroup's rows: registers ...
     extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
     d2_t *rl = reinterpret_cast<d2_t *>(fused_lds);        // ... of the second one's: LDS, rl[m * kFusedBlock + T] (128 KiB)
+    const double *tab = reinterpret_cast<const double *>(fused_lds + kFusedLds); // CODED: the inverted dictionary (tab_n entries), staged below
     double rr[2] = {0., 0.}, rz[2] = {0., 0.};
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -1201,7 +1216,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_update_fused(int64_t n, double 
                 const int m = m0 + u;
                 const unsigned oj = o0 + (unsigned)m * kFusedStride;
                 double id0, id1;
-                if (CODED) { id0 = invd[cc[u] & 0xffffu]; id1 = invd[cc[u] >> 16]; }
+                if (CODED) { id0 = tab[cc[u] & 0xffffu]; id1 = tab[cc[u] >> 16]; }
                 else { id0 = idv[u].x; id1 = idv[u].y; }
                 d2_t v;
                 v.x = rv[u].x - alpha * tv[u].x;
@@ -1313,7 +1328,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_update_fused(int64_t n, double 
                 const int m = m0 + u;
                 const unsigned oj = o0 + (unsigned)m * kFusedStride;
                 double id0, id1;
-                if (CODED) { id0 = invd[cc[u] & 0xffffu]; id1 = invd[cc[u] >> 16]; }
+                if (CODED) { id0 = tab[cc[u] & 0xffffu]; id1 = tab[cc[u] >> 16]; }
                 else { id0 = idv[u].x; id1 = idv[u].y; }
                 d2_t xn, pn;
                 const d2_t rv = h == 0 ? rn[m] : rl[m * kFusedBlock + T];
@@ -2416,10 +2431,10 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (dev >= 0 && dev < 64 && !((raised.load() >> dev) & 1ull)) {
-            AVS_HIP(hipFuncSetAttribute((const void *)k_update_fused<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds));
-            AVS_HIP(hipFuncSetAttribute((const void *)k_update_fused<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds));
-            AVS_HIP(hipFuncSetAttribute((const void *)k_update_fused<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds));
-            AVS_HIP(hipFuncSetAttribute((const void *)k_update_fused<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds));
+            AVS_HIP(hipFuncSetAttribute((const void *)k_update_fused<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kFusedLds + kFusedTabBytes)));
+            AVS_HIP(hipFuncSetAttribute((const void *)k_update_fused<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kFusedLds + kFusedTabBytes)));
+            AVS_HIP(hipFuncSetAttribute((const void *)k_update_fused<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kFusedLds + kFusedTabBytes)));
+            AVS_HIP(hipFuncSetAttribute((const void *)k_update_fused<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kFusedLds + kFusedTabBytes)));
             raised.fetch_or(1ull << dev);
         }
         if (!w->fused_bar.p) {
@@ -2444,7 +2459,7 @@ avs_status pcg_solve(PcgWork *w, const CsrView &A, const double *b, double *x, d
         double *vpart = fuse_alpha ? partial + (w->npartial / 2) : partial; // (the SpMV's are still being read)
         if (fuse_vec && fuse_alpha) {
             const int fg = kVecGrid / 8;
-#define AVS_FUSED_LAUNCH(C, K, ...) hipLaunchKernelGGL((k_update_fused<C, K>), dim3(fg), dim3(kFusedBlock), kFusedLds, stream, __VA_ARGS__)
+#define AVS_FUSED_LAUNCH(C, K, ...) hipLaunchKernelGGL((k_update_fused<C, K>), dim3(fg), dim3(kFusedBlock), kFusedLds + (C ? kFusedTabBytes : 0), stream, __VA_ARGS__, A.table_size + 1)
             if (coded) {
                 if (keep) AVS_FUSED_LAUNCH(true, true, n, x, p, r, t, w->invtab.p, w->dcode.p, sc, vpart, partial, nb, parity, w->fused_bar.p, fused_timeout);
                 else AVS_FUSED_LAUNCH(true, false, n, x, p, r, t, w->invtab.p, w->dcode.p, sc, vpart, partial, nb, parity, w->fused_bar.p, fused_timeout);

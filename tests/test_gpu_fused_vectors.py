@@ -25,7 +25,7 @@ def _solver(sc, probe=False):
 CASES = {
     "beam256_L4_uniform": lambda dev: scenes.fat_beam(256, 4, device=dev),                            # 1.27 M rows, one small dictionary: coded diagonal
     "beam256_L4_mu_of_x": lambda dev: scenes.fat_beam(256, 4, variable_viscosity=True, device=dev),   # tile-local tables: 8-B inverse diagonal
-    "sphere192_L4": lambda dev: scenes.sphere(192, 4, device=dev),
+    "sphere256_L4": lambda dev: scenes.sphere(256, 4, device=dev),
 }
 
 

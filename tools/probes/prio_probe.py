@@ -20,9 +20,10 @@ def run(tag, dbg=0, cold=False, reps=200):
     else: os.environ.pop("AVS_BENCH_THRASH_MB", None)
     ts = [s.bench_spmv(100, reps if not cold else 60) * 1e3 for _ in range(3)]
     print(f"{tag:52s} {'cold' if cold else 'warm'}  us: " + " ".join(f"{t:7.1f}" for t in ts), flush=True)
-for cold in (False, True):
-    run("default (both priorities)", 0, cold)
-    run("no load-phase priority (512)", 512, cold)
-    run("no long-row priority (2048)", 2048, cold)
-    run("no priorities (512+2048)", 512 + 2048, cold)
-    run("default again", 0, cold)
+for rep in range(3):
+    for cold in (False, True):
+        run("default (both priorities)", 0, cold, 150)
+        run("no load-phase priority (512)", 512, cold, 150)
+        run("no long-row priority (2048)", 2048, cold, 150)
+        run("no priorities (512+2048)", 512 + 2048, cold, 150)
+        run("long-row rule: waves 6, 7 (8192)", 8192, cold, 150)
