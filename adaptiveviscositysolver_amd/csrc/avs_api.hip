@@ -1019,6 +1019,25 @@ avs_status avs_brick_wave_stats(avs_ctx *c, double *out6)
     std::vector<uint2> rdesc(nrd);
     AVS_HIP(hipMemcpy(rdesc.data(), B.rdesc, nrd * sizeof(uint2), hipMemcpyDeviceToHost));
     double sum_all = 0., sum_max = 0., sum_mean = 0., sum_lanes = 0., sum_rows = 0., sum_quads = 0.;
+    long run_hist[17] = {}, runs_total = 0, groups4 = 0, groups8 = 0, tiles_all = 0;
+    double sum_nrows = 0.;
+    for (const uint2 &t : tb) { // fill runs of every tile: lengths, and how many 4- / 8-lane groups would cover them
+        const uint32_t *bw = &blocks[(size_t)t.x * 4];
+        const int nruns = (int)bw[3];
+        ++tiles_all;
+        sum_nrows += bw[1];
+        for (int q = 0; q < nruns; ++q) {
+            const int len = (int)(bw[avs::kBlkHdrWords + 2 * q + 1] & 15u) + 1;
+            run_hist[len]++;
+            ++runs_total;
+            groups4 += (len + 3) / 4;
+            groups8 += (len + 7) / 8;
+        }
+    }
+    fprintf(stderr, "brick fill runs: %ld tiles, %.1f rows per tile, %.1f runs per tile (16-lane groups), %.1f 8-lane groups, %.1f 4-lane groups per tile; lengths:", tiles_all,
+            sum_nrows / tiles_all, (double)runs_total / tiles_all, (double)groups8 / tiles_all, (double)groups4 / tiles_all);
+    for (int l = 1; l <= 16; ++l) fprintf(stderr, " %d:%.1f%%", l, 100. * run_hist[l] / (double)(runs_total ? runs_total : 1));
+    fprintf(stderr, "\n");
     long gt = 0;
     std::vector<long> hist(40, 0);
     for (const uint2 &t : tb) {

@@ -143,12 +143,13 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
     uint2 *rbt = reinterpret_cast<uint2 *>(pinfo + kBrickPatMax);       // kBrickRowBase entries: a row's bases on the four lattices, per axis
     const uint32_t *bw = reinterpret_cast<const uint32_t *>(park + kBrickXSlots);
     const int tid = threadIdx.x;
-    const int lane = tid & 63, l16 = tid & 15, qw = tid >> 4;
+    constexpr int RL = kBrickRunLen;                                    // lanes per fill run
+    const int lane = tid & 63, l16 = tid & (RL - 1), qw = tid / RL;
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);          // (scalar)
     const bool wide = VC || B.col_bits == 0;                             // 64-bit streamed words: column | code << 32 (VC: 96 bits, column | value)
     const unsigned cmask = wide ? 0xffffffffu : (1u << B.col_bits) - 1u;
     const int cbits = B.col_bits;
-    constexpr int QW = kBrickBlk / 16;
+    constexpr int QW = kBrickBlk / RL;
     static_assert((kBrickPark - kBrickXSlots) * 2 <= kBrickBlk * 4, "one 16-B load per thread fetches a whole descriptor block");
 
     if (!VC)
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         // validity is a predicate recomputed where the value is used.
         constexpr int RPT = kBrickMaxRows / kBrickBlk;
         constexpr int PQ = (kBrickPatWords / 4 + kBrickBlk - 1) / kBrickBlk;
-        constexpr int kRuFast = 6;                     // fill batches held in registers (192 runs: nearly every tile); the rest, rare, go run by run
+        constexpr int kRuFast = RL == 16 ? 6 : (RL == 8 ? 4 : 3); // fill batches held in registers (192 / 256 / 384 runs: nearly every tile); the rest, rare, go run by run
         const uint2 *runs2 = reinterpret_cast<const uint2 *>(bw + o_runs);
         T fv[kRuFast];
         uint32_t rdsc[kRuFast];
@@ -414,7 +415,15 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
                 const int nq = (int)((pi >> 16) & 0x7fffu);
                 // (the wave's chunk of the execution order is one of the tile's last two: a scalar test -- as a per-lane test on the row index it
                 //  cost two more spilled registers and made the kernel 4 % SLOWER than no priority at all)
+#ifdef AVS_BRICK_GRADED
+                {
+                    const int back = ((nprow + 63) >> 6) - (k * (kBrickBlk / 64) + wave_id); // 1 = the last chunk
+                    if (back <= 2) __builtin_amdgcn_s_setprio(2);
+                    else if (back <= 4) __builtin_amdgcn_s_setprio(1);
+                }
+#else
                 if (AVS_BRICK_PRIO == 2 ? wave_id >= 6 : (AVS_BRICK_PRIO >= 3 && k * (kBrickBlk / 64) + wave_id + AVS_BRICK_TAIL >= ((nprow + 63) >> 6))) __builtin_amdgcn_s_setprio(AVS_BRICK_TAIL_PRIO);
+#endif
                 // word: delta << 19 (signed 13) | 000 | lattice level << 14 | code << 3 -- byte offsets for 8-B elements; T = float reads
                 // the 4-B image of the table (BrickView::pwords32: delta << 18 | level << 14 | code << 2).  A pattern is padded to whole
                 // quads with words that repeat its first entry's slot with the code of 0.0: +-0.0 added to a sum that is never -0.0.

@@ -615,7 +615,7 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
             const int s = tid * SPT + u;
             if (smap[s] < 0) continue;
             if (startmask & (1u << u)) last = s;
-            if (((s - last) & 15) == 0) { cutmask |= 1u << u; ++ncut; }
+            if (((s - last) & (kBrickRunLen - 1)) == 0) { cutmask |= 1u << u; ++ncut; }
         }
     }
     scan[tid] = ncut;
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(kTileBlk) void k_bk_tile(const TileInfo *__restrict
             const int s = tid * SPT + u;
             int len = 1;
             const int c = smap[s];
-            while (len < 16 && s + len < 4096 && smap[s + len] == c + len) ++len;
+            while (len < kBrickRunLen && s + len < 4096 && smap[s + len] == c + len) ++len;
             // (the loop above may run past the next cut of the SAME natural run only if that cut is 16 away: len < 16 stops it)
             // a run is 8 B: the absolute first column | slot << 4 | length - 1 (round 5; it was 4 B naming a neighbour brick and an offset,
             // which cost the kernel a second, dependent LDS read per batch; halo columns of a partitioned system are just columns >= n_rows)

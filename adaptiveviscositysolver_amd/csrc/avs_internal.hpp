@@ -370,7 +370,11 @@ constexpr int kBlkHdrWords = 48;         // header of a tile's descriptor block 
 constexpr int kBrickLoff[5] = {0, 3000, 3648, 3840, 3921}; // slot offsets of the level-0..3 lattices: (8>>l)+2 cells per axis, 3 faces per cell
 constexpr int kBrickSlots = 3921, kBrickSlotsPad = 3936;
 constexpr int kBrickMaxRows = 1024;   // rows per tile, two per thread (a fuller brick is cut into two tiles with one lattice origin)
-constexpr int kBrickMaxRuns = 320;    // halo fill runs per tile
+#ifndef AVS_BRICK_RUNLEN
+#define AVS_BRICK_RUNLEN 16
+#endif
+constexpr int kBrickRunLen = AVS_BRICK_RUNLEN; // entries per halo fill run = lanes that fill it (16, 8 or 4: avs_brick.hip)
+constexpr int kBrickMaxRuns = kBrickRunLen == 16 ? 320 : 512;    // halo fill runs per tile (and the descriptor block must fit kBlockStride words)
 constexpr int kBrickXSlots = 160;     // extra x slots per tile behind the lattice (slots 3936 .. 4095: off-lattice columns in the 27 neighbour bricks)
 constexpr int kBrickPatWords = 2560;  // pattern words staged in LDS per tile (10 KiB)
 constexpr int kBrickPatWordsVc = 1536; // ... in the value-code variant (geometry-only patterns: fewer per tile), which needs the LDS for the tile's value table

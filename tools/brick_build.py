@@ -14,6 +14,7 @@ MAX_RUNS = 320
 BLOCK_WORDS = 1728
 XSLOT0 = 3936      # first extra slot (off-lattice columns inside the 27 neighbour bricks)
 XSLOTS = 160
+RUNLEN = 16   # entries per halo fill run (kBrickRunLen of the library build under test)
 PAT_WORDS = 2560
 PAT_MAX = 384
 PAT_LEN = 64
@@ -256,7 +257,7 @@ def build(rp, col, code, geo, table_size, col_bits):
     rstart = torch.nonzero(brk).flatten()
     rid = torch.cumsum(brk.long(), 0) - 1
     pos = torch.arange(len(trip), device=dev) - rstart[rid]
-    brk = brk | (pos % 16 == 0)
+    brk = brk | (pos % RUNLEN == 0)
     rstart = torch.nonzero(brk).flatten()
     rlen = torch.diff(torch.cat([rstart, torch.tensor([len(trip)], device=dev)]))
     # a run is 8 B (round 5): the absolute first column | slot << 4 | length - 1
