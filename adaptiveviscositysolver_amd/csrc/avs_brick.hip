@@ -42,7 +42,7 @@ namespace avs {
 
 constexpr int kBrickBlk = 512;
 #ifndef AVS_BRICK_TAIL
-#define AVS_BRICK_TAIL 2      // chunks of the execution order that count as a tile's tail
+#define AVS_BRICK_TAIL 4      // chunks of the execution order that count as a tile's tail (in-loop A/B with four-lane fill runs: 2 -> 94.0 us, 4 -> 91.9 us)
 #endif
 #ifndef AVS_BRICK_TAIL_PRIO
 #define AVS_BRICK_TAIL_PRIO 1
@@ -261,7 +261,10 @@ __global__ __launch_bounds__(kBrickBlk) __attribute__((amdgpu_waves_per_eu(6, 8)
         // validity is a predicate recomputed where the value is used.
         constexpr int RPT = kBrickMaxRows / kBrickBlk;
         constexpr int PQ = (kBrickPatWords / 4 + kBrickBlk - 1) / kBrickBlk;
-        constexpr int kRuFast = RL == 16 ? 6 : (RL == 8 ? 4 : 3); // fill batches held in registers (192 / 256 / 384 runs: nearly every tile); the rest, rare, go run by run
+#ifndef AVS_BRICK_RUFAST
+#define AVS_BRICK_RUFAST (RL == 16 ? 6 : (RL == 8 ? 4 : (RL == 4 ? 3 : 2)))
+#endif
+        constexpr int kRuFast = AVS_BRICK_RUFAST; // fill batches held in registers (192 / 256 / 384 / 512 runs: nearly every tile); the rest, rare, go run by run
         const uint2 *runs2 = reinterpret_cast<const uint2 *>(bw + o_runs);
         T fv[kRuFast];
         uint32_t rdsc[kRuFast];

@@ -371,9 +371,12 @@ constexpr int kBrickLoff[5] = {0, 3000, 3648, 3840, 3921}; // slot offsets of th
 constexpr int kBrickSlots = 3921, kBrickSlotsPad = 3936;
 constexpr int kBrickMaxRows = 1024;   // rows per tile, two per thread (a fuller brick is cut into two tiles with one lattice origin)
 #ifndef AVS_BRICK_RUNLEN
-#define AVS_BRICK_RUNLEN 16
+#define AVS_BRICK_RUNLEN 4
 #endif
-constexpr int kBrickRunLen = AVS_BRICK_RUNLEN; // entries per halo fill run = lanes that fill it (16, 8 or 4: avs_brick.hip)
+// entries per halo fill run = lanes that fill it (16, 8, 4 or 2).  Rounds 4-5 used 16: but 85 % of the natural runs are 1-3 entries long (512^3
+// beam: 136 runs per tile, lengths 1: 53 %, 2: 10 %, 3: 22 %, 8: 5 %, 16: 5 %), so five batches of 32 sixteen-lane groups did the work of two
+// batches of 128 four-lane groups (175 per tile).  In-loop A/B (profiles/r06_notes.md): SpMV 104.0 -> 95.2 us, headline + 5.4 %.
+constexpr int kBrickRunLen = AVS_BRICK_RUNLEN;
 constexpr int kBrickMaxRuns = kBrickRunLen == 16 ? 320 : 512;    // halo fill runs per tile (and the descriptor block must fit kBlockStride words)
 constexpr int kBrickXSlots = 160;     // extra x slots per tile behind the lattice (slots 3936 .. 4095: off-lattice columns in the 27 neighbour bricks)
 constexpr int kBrickPatWords = 2560;  // pattern words staged in LDS per tile (10 KiB)

@@ -176,7 +176,7 @@ _COUNTERS = None
 
 def counter_record(n, nnz, brick, bpn, tile_tables, f32=False):
     """PMC record of this workload's SpMV kernel taken with THIS source tree (profiles/spmv_counters.json, written by
-    tools/profile_r05.sh from separate rocprofv3 --pmc passes), else None: counters of another binary describe another kernel."""
+    tools/profile_r06.sh from separate rocprofv3 --pmc passes), else None: counters of another binary describe another kernel."""
     global _COUNTERS
     if _COUNTERS is None:
         _COUNTERS = []
@@ -257,14 +257,17 @@ def resident_roofline(n, nnz, iterations, solve_ms):
     alg = 12 * nnz + 4 * (n + 1) + 16 * n
     t = solve_ms * 1e-3 / max(1, iterations)
     phys, basis, pmc, src = 32 * n, "x and w streams (32 B per row: a lower bound of what one iteration moves)", None, None
-    prof = os.path.join(ROOT, "profiles", "r04_resident_pmc.json")
+    prof = os.path.join(ROOT, "profiles", "resident_counters.json")   # written by tools/profile_r06_resident.sh, keyed by the source fingerprint
     try:
+        from adaptiveviscositysolver_amd import capi
+        mine = capi.source_fingerprint()
         for w in json.load(open(prof))["workloads"]:
-            if w["n"] == n and w["nnz"] == nnz:
-                phys = w["hbm_bytes_per_iteration_upper"]
-                basis = "PMC upper bound per iteration (one-time matrix load included) of the round-4 binary"
-                pmc = {k: w[k] for k in ("valu_issue_frac", "wait_frac", "lds_bank_conflict_frac_of_lds_active", "per_wave_per_iteration")}
-                src = "profiles/r04_resident_pmc.json (rocprofv3 --pmc passes of a round-4 run of this workload: not this source tree, not this process)"
+            if w["n"] == n and w["nnz"] == nnz and w.get("source_sha16") == mine:   # counters of another tree describe another kernel: not quoted
+                if w.get("hbm_bytes_per_iteration_upper"):
+                    phys = w["hbm_bytes_per_iteration_upper"]
+                    basis = "PMC upper bound per iteration (one-time matrix load included) of this source tree"
+                pmc = {k: w.get(k) for k in ("valu_issue_frac", "wait_frac", "lds_bank_conflict_frac_of_lds_active", "per_wave_per_iteration")}
+                src = w.get("source")
     except Exception:
         pass
     achieved = phys / t / 1e9 if t > 0 else 0.0

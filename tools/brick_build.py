@@ -10,11 +10,11 @@ import torch
 
 LOFF = [0, 3000, 3648, 3840, 3921]
 MAX_ROWS = 1024
-MAX_RUNS = 320
+MAX_RUNS = 512
 BLOCK_WORDS = 1728
 XSLOT0 = 3936      # first extra slot (off-lattice columns inside the 27 neighbour bricks)
 XSLOTS = 160
-RUNLEN = 16   # entries per halo fill run (kBrickRunLen of the library build under test)
+RUNLEN = 4   # entries per halo fill run (kBrickRunLen of the library build under test)
 PAT_WORDS = 2560
 PAT_MAX = 384
 PAT_LEN = 64
