@@ -1245,7 +1245,10 @@ avs_status build_brick_form(BrickForm &bf, const BrickSource &src, const Options
     hipLaunchKernelGGL(k_bk_pwords32, dim3((unsigned)((nwords + 16 + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, nwords + 16, bf.pwords.p, bf.pwords32.p);
     AVS_HIP(hipGetLastError());
     // worth it only where most rows are patterns (a curved surface with ~10^4 distinct values gives every row its own)
-    const double min_frac = opt.brick_min_regular;
+    // (value-code variant, round 6: a streamed row costs it 12 B per entry and a tile's table is small -- on a curved surface, 72 % pattern rows
+    //  and 10^5 patterns, it LOST to the word stream, 3,138 against 4,869 it/s on the 512^3 sphere, which the round-5 rule let through;
+    //  smoothly varying viscosity has 98 %: AUTO asks the variant for kBrickMinRegularVc)
+    const double min_frac = (bf.vc && opt.brick != 1) ? std::max(opt.brick_min_regular, kBrickMinRegularVc) : opt.brick_min_regular;
     bf.ready = (double)regular >= min_frac * (double)n;
     return AVS_OK;
 }

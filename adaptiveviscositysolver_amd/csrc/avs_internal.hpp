@@ -82,7 +82,7 @@ struct PhaseScope { // consecutive phases of one function: next() closes the pre
 // what a tile costs the persistent kernel, in microseconds, as far as the descriptors show it: fitted to the per-tile phase stamps of the
 // probe build (tools/probes/brick_cost_fit.py; profiles/r05_notes.md)
 struct BrickCost {
-    double tile = 2.31, row = 0.0017, run = 0.0055, word = 0.0020, etile = 1.9, quad = 0.0028; // (fit of 50 k tiles: 512^3 beam, sheet, tank)
+    double tile = 2.69, row = 0.0015, run = 0.0001, word = 0.0019, etile = 2.96, quad = 0.0027; // (round 6, four-lane fill runs: fit of 67 k tiles -- 512^3 beam, 512^3 tank, 1024^3 sheet; residual 13 % of a tile)
 };
 struct Options {
     // user-facing (avs_set_solver_option)
@@ -391,7 +391,10 @@ constexpr int kBrickTableMax = 2048;  // value dictionary entries (LDS resident)
 constexpr int kBrickMinRows = 64;     // bricks with fewer rows are merged into E tiles
 constexpr int64_t kBrickMinSystemRows = 2000000; // smaller systems run the CU-resident loop (or are launch-bound): the form is not built
 constexpr int64_t kBrickMinSystemRowsVc = 1000000; // ... matrices the resident loop cannot take (tile-local value tables): the form from here on
-constexpr double kBrickMinFill = 330., kBrickEighthsFill = 420.; // rows per tile: the form beats the word stream / the contiguous-eighths walk beats the dealt chunks
+// rows per tile: the form beats the word stream / the contiguous-eighths walk beats the dealt chunks.  Round 6 (four-lane fill runs, priorities): the
+// form wins by 23-57 % at every fill measured, 311 .. 622 rows per tile (tools/probes/fill_rule.py, profiles/r06_notes.md): 330 -> 300
+constexpr double kBrickMinFill = 300., kBrickEighthsFill = 420.;
+constexpr double kBrickMinRegularVc = 0.9; // value-code variant: pattern rows / rows below which AUTO keeps the word stream
 constexpr int kBrickETileRows = 256;   // rows per E tile: its words fit one pass of the lattice's LDS (3936) unless the rows are long
 struct BrickView {
     int ntiles = 0;

@@ -210,6 +210,36 @@ def test_auto_mode_is_a_structural_rule(monkeypatch, built_lib):
         torch.cuda.empty_cache()
 
 
+def test_auto_mode_and_the_value_code_variant(monkeypatch, built_lib):
+    """Round 6: matrices without one small dictionary get the value-code variant from 1 M rows on (BASELINE configs[2]: 256^3 mu(x), 1.27 M
+    rows, 98 % pattern rows) -- but only where nearly every row is a pattern row: a curved surface (512^3 sphere: 72 % pattern rows, 10^5
+    patterns) multiplies faster from the word stream (4,869 against 3,138 it/s) and AUTO must leave it there; ALWAYS still builds the form."""
+    from adaptiveviscositysolver_amd import DevicePrepass
+    monkeypatch.delenv("AVS_BRICK", raising=False)
+    dev = torch.device("cuda:0")
+    for make, want in ((lambda: scenes.fat_beam(256, 4, variable_viscosity=True, device=dev), True), (lambda: scenes.sphere(512, 4, device=dev), False)):
+        sc = make()
+        pp = DevicePrepass(sc.res, sc.dx, sc.levels)
+        pi = pp.run(sc.liquid, sc.solid)
+        s = ViscositySolve(sc.res, sc.dx, sc.dt, pi.levels, device=0, probe=True)
+        pp.apply(s); s.set_scene_fields(sc); pp.close()
+        del sc
+        torch.cuda.empty_cache()
+        ai = s.assemble()
+        fmt = s.matrix_format()
+        assert ai.n_velocity >= 1_000_000 and fmt.tile_local_tables == 1
+        assert (fmt.brick_tiles > 0) == want, (fmt.brick_tiles, fmt.brick_pattern_rows / ai.n_velocity)
+        if want:
+            assert fmt.brick_value_codes == 1 and fmt.brick_pattern_rows >= 0.9 * ai.n_velocity
+        s.bench_spmv(100, 2)   # bit-identical to plain CSR
+        s.set_solver_option(capi.OPTION_BRICK_FORM, capi.BRICK_ALWAYS)
+        s.assemble()
+        assert s.matrix_format().brick_tiles > 0 and s.matrix_format().brick_value_codes == 1
+        s.bench_spmv(100, 2)
+        s.close()
+        torch.cuda.empty_cache()
+
+
 def test_default_mode_is_reproducible_across_contexts(monkeypatch, built_lib):
     """the headline workload in the DEFAULT mode, six fresh contexts: the same iteration count and the same solution bits every time
     (the format choice no longer depends on a measurement; the persistent grid and the tile walk are fixed by the device and the matrix)"""
