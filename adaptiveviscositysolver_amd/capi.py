@@ -52,7 +52,10 @@ EXPORTED_SYMBOLS = [
     "avs_local_group_create", "avs_local_group_destroy", "avs_dist_init_local", "avs_dist_partition",
     "avs_spmv_tile_rows", "avs_dist_assemble", "avs_dist_get_plan_sizes", "avs_dist_get_overlap_tiles", "avs_dist_get_plan_arrays", "avs_dist_solve", "avs_dist_get_solution",
     "avs_dist_get_info", "avs_dist_init_hosted", "avs_dist_export_blob", "avs_dist_import_blobs",
+    "avs_prepass_set_slab", "avs_prepass_get_window", "avs_dist_bind_prepass", "avs_dist_get_cuts",
 ]
+# avs_allreduce_i32_fn: avs_status (*)(int32_t *device_data, int64_t count, void *stream, void *user)
+ALLREDUCE_I32_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
 # include/avs_probe.h: exported by libavs_probe.so only (the -DAVS_PROBES build of the same sources)
 PROBE_SYMBOLS = ["avs_spmv_csr", "avs_bench_spmv", "avs_spmv_sell", "avs_bench_stream", "avs_brick_spmv_probe", "avs_spmv_solver_form",
                  "avs_dist_spmv_local_form", "avs_brick_wave_stats"]
@@ -235,6 +238,10 @@ def load(probe=False):
     L.avs_dist_init_hosted.argtypes = [vp, i32, i32]
     L.avs_dist_export_blob.argtypes = [vp, vp]
     L.avs_dist_import_blobs.argtypes = [vp, vp]
+    L.avs_prepass_set_slab.argtypes = [vp, i32, vp, i32, i32, ALLREDUCE_I32_FN, vp]
+    L.avs_prepass_get_window.argtypes = [vp, vp, vp, vp]
+    L.avs_dist_bind_prepass.argtypes = [vp, vp, i32, vp]
+    L.avs_dist_get_cuts.argtypes = [vp, i32, C.POINTER(i32), vp]
     for name in EXPORTED_SYMBOLS + (PROBE_SYMBOLS if probe else []):
         fn = getattr(L, name)
         if name not in _VOID_RETURN:

@@ -486,6 +486,14 @@ avs_status avs::adopt_prepass_lattices(avs_ctx *c, const PrepassLoan &loan)
     c->n_edge = loan.counts[1];
     c->n_center = loan.counts[2];
     invalidate(c, true);
+    c->slab = loan.slab;
+    for (int k = 0; k < 3; ++k) {
+        c->wlist[k].adopt(loan.slab.on ? loan.wlist[k] : nullptr);
+        c->n_window[k] = loan.slab.on ? loan.n_window[k] : 0;
+    }
+    if (loan.slab.on)
+        AVS_REQUIRE(loan.dof[0] && loan.dof[1] && loan.dof[2] && loan.wlist[0] && loan.wlist[1] && loan.wlist[2], AVS_EINTERNAL,
+                    "slab-local pre-pass without dof tables / window lists");
     if (loan.dof[0] && loan.dof[1] && loan.dof[2] && loan.dof[0]->n >= (size_t)c->n_vel * 4 && loan.dof[1]->n >= (size_t)c->n_edge * 4 &&
         loan.dof[2]->n >= (size_t)c->n_center * 4) { // the numbering pass wrote the dof tables: no sweep over the index lattices (build_dof_tables)
         c->vdof.adopt(loan.dof[0]);
@@ -511,6 +519,7 @@ avs_status avs_build_initial_guess(avs_ctx *c)
     avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_HIP(hipSetDevice(c->desc.device));
+    AVS_REQUIRE(!c->slab.on, AVS_ESTATE, "the context holds a slab-local pre-pass (this rank's window only): only avs_dist_assemble works on it");
     return build_initial_guess(c);
 }
 avs_status avs_build_system(avs_ctx *c)
@@ -518,6 +527,7 @@ avs_status avs_build_system(avs_ctx *c)
     avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_HIP(hipSetDevice(c->desc.device));
+    AVS_REQUIRE(!c->slab.on, AVS_ESTATE, "the context holds a slab-local pre-pass (this rank's window only): only avs_dist_assemble works on it");
     return build_system(c);
 }
 
@@ -526,6 +536,7 @@ avs_status avs_assemble(avs_ctx *c, avs_assembly_info *info)
     avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c, AVS_EINVAL, "null argument");
     AVS_HIP(hipSetDevice(c->desc.device));
+    AVS_REQUIRE(!c->slab.on, AVS_ESTATE, "the context holds a slab-local pre-pass (this rank's window only): only avs_dist_assemble works on it");
     Timer t(c->stream);
     t.start();
     AVS_TRY(build_stencils(c)); // includes the dof tables; scopes "Build Edge / Cell Stress Stencils" inside

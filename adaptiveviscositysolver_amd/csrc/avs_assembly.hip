@@ -86,14 +86,29 @@ struct StencilWriter {
     }
 };
 
+// Slab-local assembly (round 6): a rank builds the stencils of the stresses near its slab only.  `list` names the stresses inside the
+// rank's window (null: all, in order); of those, the ones whose position along the cut axis lies within [lo[level], hi[level]) of their
+// level's lattice get a stencil, the others keep cnt = 0, which the row sweep reports (a row never finds itself in an empty stencil).
+struct StencilCore {
+    const int32_t *list;
+    int64_t m;   // entries of list
+    int axis;    // cut axis
+    int lo[AVS_MAX_LEVELS], hi[AVS_MAX_LEVELS];
+};
+
 __global__ __launch_bounds__(kBlock) void k_edge_stencils(PyramidView P, const int32_t *__restrict__ edof,
-                                                          StencilView S, int *err)
+                                                          StencilView S, int *err, StencilCore core)
 {
-    const int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (id >= S.count) return;
+    const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= (core.list ? core.m : S.count)) return;
+    const int64_t id = core.list ? core.list[slot] : slot;
     const int4 rec = reinterpret_cast<const int4 *>(edof)[id];
     const int level = rec.x & 0xff, axis = rec.x >> 8;
     const I3 edge{{rec.y, rec.z, rec.w}};
+    if (core.list) {
+        const int c = core.axis == 0 ? rec.y : (core.axis == 1 ? rec.z : rec.w);
+        if (c < core.lo[level] || c >= core.hi[level]) return;
+    }
     const double dx = P.dx * (double)(1 << level); // cpp:1733
     const double vdx0 = (double)(1 << level);      // cpp:2014 (fine-voxel units)
 
@@ -216,14 +231,19 @@ __global__ __launch_bounds__(kBlock) void k_edge_stencils(PyramidView P, const i
 // K2: centre stress stencils (3 lists per active cell) + weight
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_center_stencils(PyramidView P, const int32_t *__restrict__ cdof,
-                                                            StencilView S, int *err)
+                                                            StencilView S, int *err, StencilCore core)
 {
     const int64_t nc = S.count / 3;
-    const int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (id >= nc) return;
+    const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= (core.list ? core.m : nc)) return;
+    const int64_t id = core.list ? core.list[slot] : slot;
     const int4 rec = reinterpret_cast<const int4 *>(cdof)[id];
     const int level = rec.x & 0xff;
     const I3 cell{{rec.y, rec.z, rec.w}};
+    if (core.list) {
+        const int c = core.axis == 0 ? rec.y : (core.axis == 1 ? rec.z : rec.w);
+        if (c < core.lo[level] || c >= core.hi[level]) return;
+    }
     const double dx = P.dx * (double)(1 << level); // cpp:1923
     int bad = 0;
 #pragma unroll
@@ -1131,13 +1151,28 @@ avs_status build_stencils(avs_ctx *c)
     AVS_TRY(err.alloc(1));
     AVS_HIP(hipMemsetAsync(err.p, 0, sizeof(int), st));
     PyramidView P = c->view();
-    if (c->n_edge) {
-        Scope sc("Build Edge Stress Stencils"); // cpp:441
-        hipLaunchKernelGGL(k_edge_stencils, dim3(grid_for(c->n_edge)), dim3(kBlock), 0, st, P, c->edof.p, edge_view(c), err.p);
+    StencilCore ce{}, cc{};
+    int64_t me = c->n_edge, mc = c->n_center;
+    if (c->slab.on) { // the stresses near this rank's slab only; everybody else's count stays 0
+        AVS_REQUIRE(c->wlist[1].p && c->wlist[2].p, AVS_ESTATE, "slab-local context without window lists");
+        AVS_HIP(hipMemsetAsync(c->e_cnt.p, 0, ne * sizeof(int32_t), st));
+        AVS_HIP(hipMemsetAsync(c->c_cnt.p, 0, n3 * sizeof(int32_t), st));
+        ce.list = c->wlist[1].p; ce.m = me = c->n_window[1];
+        cc.list = c->wlist[2].p; cc.m = mc = c->n_window[2];
+        ce.axis = cc.axis = c->slab.axis;
+        for (int l = 0; l < c->desc.levels; ++l) {
+            const int s_lo = c->slab.cuts[c->slab.rank] >> l, s_hi = (c->slab.cuts[c->slab.rank + 1] + (1 << l) - 1) >> l;
+            ce.lo[l] = cc.lo[l] = s_lo - kSlabStencilMargin;
+            ce.hi[l] = cc.hi[l] = s_hi + kSlabStencilMargin + 1; // (+ 1: the edge lattice's extra entry)
+        }
     }
-    if (c->n_center) {
+    if (me) {
+        Scope sc("Build Edge Stress Stencils"); // cpp:441
+        hipLaunchKernelGGL(k_edge_stencils, dim3(grid_for(me)), dim3(kBlock), 0, st, P, c->edof.p, edge_view(c), err.p, ce);
+    }
+    if (mc) {
         Scope sc("Build Cell Stress Stencils"); // cpp:473
-        hipLaunchKernelGGL(k_center_stencils, dim3(grid_for(c->n_center)), dim3(kBlock), 0, st, P, c->cdof.p, center_view(c), err.p);
+        hipLaunchKernelGGL(k_center_stencils, dim3(grid_for(mc)), dim3(kBlock), 0, st, P, c->cdof.p, center_view(c), err.p, cc);
     }
     AVS_HIP(hipGetLastError());
     int e = 0;

@@ -13,6 +13,7 @@
 // copies and a host-side rendezvous.  Slow, but it executes the identical partition / halo /
 // reduction logic and is what tests/test_gpu_dist.py checks against the single-rank solve.
 #include <rccl/rccl.h>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <time.h>
 #include <unistd.h>
@@ -34,6 +35,7 @@ struct avs_local_group {
     long generation = 0;
     std::vector<avs::PcgDist *> members;
     std::vector<double> red; // world x 4 staging for all-reduce
+    std::vector<int32_t> red_i32; // dist_allreduce_i32
     std::vector<uint8_t> blobs; // world x AVS_DIST_BLOB_BYTES: comm-block descriptors of the direct transport
     int direct_votes = 0;       // members whose direct_connect succeeded (agreement: all or none)
     bool failed = false;
@@ -77,6 +79,10 @@ struct PcgDist {
     DevBuf<int32_t> local_ref; // reference DOF id behind every local column [owned | halo] (what the brick builder reads the geometry from)
     PcgWork *pcg = nullptr;
     bool partitioned = false, solved = false, reordered = false;
+    // slab cuts along cut_axis (fine cells, world + 1 entries): the ones this assembly used, and the ones its per-plane weights suggest
+    // for the next frame (slab-local assembly: the pre-pass needs the cuts BEFORE anything is counted)
+    std::vector<int32_t> cuts, next_cuts;
+    int cut_axis = 0;
 
     // direct transport (peer-mapped comm blocks), see avs_internal.hpp
     int transport = AVS_TRANSPORT_RCCL;
@@ -225,6 +231,33 @@ avs_status dist_allreduce(PcgDist *d, double *dev, int count, hipStream_t stream
     g->barrier();
     AVS_HIP(hipMemcpyAsync(dev, s, (size_t)count * sizeof(double), hipMemcpyHostToDevice, stream));
     AVS_HIP(hipStreamSynchronize(stream));
+    return AVS_OK;
+}
+
+// in-place sum of `count` int32 over all ranks (slab-local pre-pass: per-tile DOF counts; slab-local assembly: per-plane weights)
+avs_status dist_allreduce_i32(PcgDist *d, int32_t *dev, int64_t count, hipStream_t stream)
+{
+    if (d->world == 1 || count <= 0) return AVS_OK;
+    if (d->comm) {
+        AVS_NCCL(ncclAllReduce(dev, dev, (size_t)count, ncclInt32, ncclSum, d->comm, stream));
+        return AVS_OK;
+    }
+    avs_local_group *g = d->group;
+    AVS_REQUIRE(g, AVS_ESTATE, "no RCCL communicator and no in-process group: a hosted group sums through the caller's callback");
+    std::vector<int32_t> mine((size_t)count);
+    AVS_HIP(hipMemcpyAsync(mine.data(), dev, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    AVS_HIP(hipStreamSynchronize(stream));
+    g->barrier();
+    if (d->rank == 0) g->red_i32.assign((size_t)count, 0);
+    g->barrier();
+    for (int r = 0; r < g->world; ++r) { // rank after rank: integer sums do not depend on the order, the vector is shared
+        if (r == d->rank)
+            for (int64_t i = 0; i < count; ++i) g->red_i32[(size_t)i] += mine[(size_t)i];
+        g->barrier();
+    }
+    AVS_HIP(hipMemcpyAsync(dev, g->red_i32.data(), (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    AVS_HIP(hipStreamSynchronize(stream));
+    g->barrier(); // nobody clears the vector before everybody has copied it
     return AVS_OK;
 }
 
@@ -765,10 +798,12 @@ __global__ __launch_bounds__(256) void k_plan_mark(int64_t n, const int32_t *__r
 }
 
 __global__ __launch_bounds__(256) void k_plan_flag_halo(int64_t n, const uint8_t *__restrict__ is_halo, const uint8_t *__restrict__ owner,
-                                                        int q, int32_t *__restrict__ f)
+                                                        int q, int32_t *__restrict__ f, const int32_t *__restrict__ dom = nullptr)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) f[i] = is_halo[i] && owner[i] == q;
+    if (i >= n) return;
+    const int64_t id = dom ? dom[i] : i;
+    f[i] = is_halo[id] && owner[id] == q;
 }
 
 __global__ __launch_bounds__(256) void k_plan_flag_send(int64_t n, const uint8_t *__restrict__ owner, int rank,
@@ -781,12 +816,14 @@ __global__ __launch_bounds__(256) void k_plan_flag_send(int64_t n, const uint8_t
 // flagged i -> out[pos[i]] = (map ? map[i] : i); g2l[i] = base + pos[i] when g2l is given
 __global__ __launch_bounds__(256) void k_plan_scatter(int64_t n, const int32_t *__restrict__ f, const int32_t *__restrict__ pos,
                                                       const int32_t *__restrict__ map, int32_t *__restrict__ out,
-                                                      int32_t *__restrict__ g2l, int32_t base)
+                                                      int32_t *__restrict__ g2l, int32_t base, const int32_t *__restrict__ dom = nullptr)
 {
+    // dom (slab-local assembly): entry i stands for the id dom[i] (the window's DOFs in brick-major order) instead of for i itself
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n || !f[i]) return;
-    out[pos[i]] = map ? map[i] : (int32_t)i;
-    if (g2l) g2l[i] = base + pos[i];
+    const int32_t id = dom ? dom[i] : (int32_t)i;
+    out[pos[i]] = map ? map[i] : id;
+    if (g2l) g2l[id] = base + pos[i];
 }
 
 __global__ __launch_bounds__(256) void k_plan_local_len(int64_t n_own, const int32_t *__restrict__ own_global,
@@ -1025,18 +1062,21 @@ __global__ __launch_bounds__(256) void k_da_planes(int64_t n, const int32_t *__r
 // whose DOFs it reads (= the ranks that read this row's DOF)
 __global__ __launch_bounds__(256) void k_da_mark(int64_t n_own, const int32_t *__restrict__ row_ptr, int32_t *__restrict__ col,
                                                  const int32_t *__restrict__ inv, const uint8_t *__restrict__ owner, int rank,
-                                                 uint8_t *__restrict__ is_halo, uint32_t *__restrict__ needed_by)
+                                                 uint8_t *__restrict__ is_halo, uint32_t *__restrict__ needed_by, int *__restrict__ err = nullptr)
 {
+    // inv == null (slab-local assembly): ids stay the reference's; a column without an owner lies outside the rank's window (err)
     const int sub = threadIdx.x & 15;
     const int64_t group = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
     const int64_t ngroups = ((int64_t)gridDim.x * 256) >> 4;
     for (int64_t l = group; l < n_own; l += ngroups) {
         uint32_t bits = 0u;
         for (int k = row_ptr[l] + sub; k < row_ptr[l + 1]; k += 16) {
-            const int32_t cb = inv[col[k]];
+            const int32_t cb = inv ? inv[col[k]] : col[k];
             col[k] = cb;
             const int q = owner[cb];
-            if (q != rank) {
+            if (q == 0xFF) {
+                if (err) *err = 1;
+            } else if (q != rank) {
                 is_halo[cb] = 1; // same value from every writer
                 bits |= 1u << q;
             }
@@ -1067,12 +1107,13 @@ __global__ __launch_bounds__(256) void k_da_localize(int64_t n_own, const int32_
 
 // reference DOF id of every halo column: global brick-major id g with a local id >= n_own -> perm[g]
 __global__ __launch_bounds__(256) void k_da_halo_ref(int64_t n, const int32_t *__restrict__ g2l, const int32_t *__restrict__ perm, int64_t n_own,
-                                                     int32_t *__restrict__ local_ref)
+                                                     int32_t *__restrict__ local_ref, const int32_t *__restrict__ dom = nullptr)
 {
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= n) return;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t g = dom ? dom[i] : (int32_t)i;
     const int32_t l = g2l[g];
-    if (l >= n_own) local_ref[l] = perm[g];
+    if (l >= n_own) local_ref[l] = perm ? perm[g] : g;
 }
 
 __global__ __launch_bounds__(256) void k_da_flag_send(int64_t n_own, const uint32_t *__restrict__ needed_by, int q, int32_t *__restrict__ f)
@@ -1173,73 +1214,36 @@ static avs_status dist_build_brick(avs_ctx *c, PcgDist *d)
     return AVS_OK;
 }
 
-static avs_status dist_assemble_device(avs_ctx *c, PcgDist *d, int cut_axis, int extent)
+// Everything behind the choice of the owned rows, shared by the replicated-index assembly above and the slab-local one below: the rank's
+// rows, halo numbering, send lists, local column ids, tile lists.  Ids live in an id space of `n_ids` entries (brick-major ids / the
+// reference's ids); `dom` (null: 0 .. n_dom) lists, in brick-major order, the ids a halo column can have; owner / is_halo / g2l are
+// indexed by id.  inv (reference id -> id, null: identity), perm (id -> reference id, null: identity).
+static avs_status dist_assemble_tail(avs_ctx *c, PcgDist *d, DevBuf<int32_t> &ids, int64_t n_own, int64_t n_ids, const int32_t *dom, int64_t n_dom,
+                                     const int32_t *inv, const int32_t *perm, DevBuf<uint8_t> &owner, DevBuf<uint8_t> &is_halo, DevBuf<int32_t> &g2l,
+                                     DevBuf<int32_t> &flag, DevBuf<int32_t> &pos, DevBuf<int32_t> &scan_tmp)
 {
     hipStream_t st = c->stream;
-    const int64_t n = c->n_vel;
     const int rank = d->rank, world = d->world;
-    AVS_REQUIRE(world <= 32, AVS_EINVAL, "at most 32 ranks");
-    // Cut planes: the slabs are cut between planes of 2^shift fine cells.  The replicated planner (avs_dist_partition, avs_partition.cpp)
-    // keeps 2^(levels-1) -- no top-level cell straddles a cut; here, where every rank assembles its own rows, nothing needs that (a DOF
-    // belongs to the plane of its own position, whatever it reads is a halo column), and planes of at most 4 cells halve the granularity
-    // of the balance at 4 levels: on the 8-way partition of the 512^3 beam a rank's share moved in steps of 12.5 % (868 k .. 994 k rows,
-    // 30.5 .. 34.3 us per iteration in the loop-back measurement -- the slowest rank sets the pace).  AVS_DIST_PLANE_SHIFT overrides.
-    int shift = c->desc.levels - 1;
-    if (cur_opt().dist_plane_shift >= 0) shift = cur_opt().dist_plane_shift < shift ? cur_opt().dist_plane_shift : shift;
-    else if (shift > 2) shift = 2;
-    const int nplanes = (extent + (1 << shift) - 1) >> shift;
-    AVS_REQUIRE(nplanes <= 65535, AVS_EINVAL, "too many cut planes");
-
-    // global, index-only: raw triplet count per row (weights) and the brick-major permutation
-    DevBuf<int32_t> raw_count;
-    AVS_TRY(count_raw_rows(c, raw_count));
-    AVS_TRY(build_brick_permutation(c, c->brick_shift));
-
-    DevBuf<uint16_t> plane;
-    DevBuf<unsigned long long> weight;
-    DevBuf<int32_t> plane_owner, flag, pos, g2l, scan_tmp, halo_tmp, ids;
-    DevBuf<uint8_t> owner, is_halo;
+    const int64_t n = n_dom;
+    DevBuf<int32_t> halo_tmp;
     DevBuf<uint32_t> needed_by;
-    AVS_TRY(plane.alloc((size_t)n));
-    AVS_TRY(weight.alloc((size_t)nplanes));
-    AVS_TRY(plane_owner.alloc((size_t)nplanes));
-    AVS_TRY(flag.alloc((size_t)n + 1));
-    AVS_TRY(pos.alloc((size_t)n + 1));
-    AVS_TRY(g2l.alloc((size_t)n));
-    AVS_TRY(scan_tmp.alloc(scan_tmp_elems(n + 1)));
-    AVS_TRY(owner.alloc((size_t)n));
-    AVS_TRY(is_halo.alloc((size_t)n));
-    AVS_HIP(hipMemsetAsync(weight.p, 0, (size_t)nplanes * sizeof(unsigned long long), st));
-    AVS_HIP(hipMemsetAsync(is_halo.p, 0, (size_t)n, st));
-    AVS_HIP(hipMemsetAsync(g2l.p, 0xFF, (size_t)n * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_da_planes, dim3(2048), dim3(256), 0, st, n, c->vdof.p, c->perm.p, raw_count.p, cut_axis, extent, shift, nplanes,
-                       plane.p, weight.p);
-    std::vector<unsigned long long> h_w((size_t)nplanes);
-    AVS_HIP(hipMemcpyAsync(h_w.data(), weight.p, h_w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    AVS_HIP(hipStreamSynchronize(st));
-    std::vector<int64_t> h_w64(h_w.begin(), h_w.end());
-    std::vector<int> h_po((size_t)nplanes);
-    plane_owners_from_weights(h_w64.data(), nplanes, world, h_po.data());
-    AVS_HIP(hipMemcpyAsync(plane_owner.p, h_po.data(), h_po.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_plan_owner, dim3(grid256(n)), dim3(256), 0, st, n, plane.p, plane_owner.p, rank, owner.p, flag.p);
-
-    // owned rows (ascending brick-major id) and the DOFs behind them
-    int64_t n_own = 0;
-    AVS_TRY(scan_flags(flag.p, pos.p, n, scan_tmp, &n_own, st));
-    AVS_TRY(d->own_global.alloc((size_t)n_own));
-    AVS_TRY(ids.alloc((size_t)n_own));
-    hipLaunchKernelGGL(k_plan_scatter, dim3(grid256(n)), dim3(256), 0, st, n, flag.p, pos.p, (const int32_t *)nullptr, d->own_global.p,
-                       g2l.p, 0);
-    if (n_own) hipLaunchKernelGGL(k_gather_i<int32_t>, dim3(grid256(n_own)), dim3(256), 0, st, c->perm.p, d->own_global.p, ids.p, n_own);
-
+    DevBuf<int> mark_err;
+    AVS_TRY(mark_err.alloc(1));
+    AVS_HIP(hipMemsetAsync(mark_err.p, 0, sizeof(int), st));
     // restriction (warm start, also the mass term of the right-hand side) and rows of this rank only;
     // columns still in the reference numbering
     AVS_TRY(build_initial_guess_rows(c, ids.p, n_own));
     int64_t nnz_local = 0;
     AVS_TRY(assemble_rows(c, ids.p, n_own, d->row_ptr, d->col, d->val, d->rhs, &nnz_local, nullptr));
     AVS_TRY(needed_by.alloc((size_t)n_own));
-    if (n_own) hipLaunchKernelGGL(k_da_mark, dim3(8192), dim3(256), 0, st, n_own, d->row_ptr.p, d->col.p, c->inv.p, owner.p, rank, is_halo.p,
-                                  needed_by.p);
+    if (n_own) hipLaunchKernelGGL(k_da_mark, dim3(8192), dim3(256), 0, st, n_own, d->row_ptr.p, d->col.p, inv, owner.p, rank, is_halo.p,
+                                  needed_by.p, mark_err.p);
+    {
+        int e = 0;
+        AVS_HIP(hipMemcpyAsync(&e, mark_err.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        AVS_HIP(hipStreamSynchronize(st));
+        AVS_REQUIRE(e == 0, AVS_EINTERNAL, "slab-local assembly: a row reads a column outside the rank's window (index margin too small)");
+    }
     bool split = world > 1;
     split = split && cur_opt().dist_split_rows != 0;
     // A slab the brick-structured form will serve keeps the plain ascending (brick-major) row order: its tiles are whole bricks, and the
@@ -1287,15 +1291,15 @@ static avs_status dist_assemble_device(avs_ctx *c, PcgDist *d, int cut_axis, int
 
     // halo numbering (grouped by owner, ascending) and send lists (ascending owned rows that read a DOF of q)
     std::vector<int64_t> recv_cnt((size_t)world, 0), send_cnt((size_t)world, 0);
-    AVS_TRY(halo_tmp.alloc((size_t)n));
+    AVS_TRY(halo_tmp.alloc((size_t)(n > 0 ? n : 1)));
     int64_t n_halo = 0, n_send = 0;
     for (int q = 0; q < world; ++q) {
         if (q == rank) continue;
-        hipLaunchKernelGGL(k_plan_flag_halo, dim3(grid256(n)), dim3(256), 0, st, n, is_halo.p, owner.p, q, flag.p);
+        hipLaunchKernelGGL(k_plan_flag_halo, dim3(grid256(n)), dim3(256), 0, st, n, is_halo.p, owner.p, q, flag.p, dom);
         AVS_TRY(scan_flags(flag.p, pos.p, n, scan_tmp, &recv_cnt[(size_t)q], st));
         if (recv_cnt[(size_t)q])
             hipLaunchKernelGGL(k_plan_scatter, dim3(grid256(n)), dim3(256), 0, st, n, flag.p, pos.p, (const int32_t *)nullptr,
-                               halo_tmp.p, g2l.p, (int32_t)(n_own + n_halo));
+                               halo_tmp.p, g2l.p, (int32_t)(n_own + n_halo), dom);
         n_halo += recv_cnt[(size_t)q];
     }
     for (int q = 0; q < world; ++q) {
@@ -1352,7 +1356,7 @@ static avs_status dist_assemble_device(avs_ctx *c, PcgDist *d, int cut_axis, int
     // reference ids behind the local columns (owned: the assembled rows' DOFs; halo: through the brick-major permutation)
     AVS_TRY(d->local_ref.alloc((size_t)(n_own + n_halo)));
     if (n_own) AVS_HIP(hipMemcpyAsync(d->local_ref.p, ids.p, (size_t)n_own * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-    if (n_halo) hipLaunchKernelGGL(k_da_halo_ref, dim3(grid256(n)), dim3(256), 0, st, n, (const int32_t *)g2l.p, (const int32_t *)c->perm.p, n_own, d->local_ref.p);
+    if (n_halo) hipLaunchKernelGGL(k_da_halo_ref, dim3(grid256(n)), dim3(256), 0, st, n, (const int32_t *)g2l.p, perm, n_own, d->local_ref.p, dom);
     // warm start of the owned DOFs
     AVS_TRY(d->x0.alloc((size_t)n_own));
     AVS_TRY(d->x.alloc((size_t)n_own));
@@ -1366,6 +1370,238 @@ static avs_status dist_assemble_device(avs_ctx *c, PcgDist *d, int cut_axis, int
     d->n_send = n_send;
     d->nnz_local = nnz_local;
     return AVS_OK;
+}
+
+
+// cuts[r] = first fine cell of rank r's slab (cuts[world] = extent) from the planes' owners (non-decreasing)
+static void cuts_from_plane_owners(const std::vector<int> &po, int world, int shift, int extent, std::vector<int32_t> &cuts)
+{
+    cuts.assign((size_t)world + 1, extent);
+    cuts[0] = 0;
+    for (int r = 1; r < world; ++r) {
+        int p = 0;
+        while (p < (int)po.size() && po[(size_t)p] < r) ++p;
+        const long long c = (long long)p << shift;
+        cuts[(size_t)r] = (int32_t)(c < extent ? c : extent);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Slab-local assembly (round 6; SURVEY 8(e): "each GPU assembles the rows it owns from its slab of the pyramids plus a halo").
+// The context holds what a slab-local pre-pass lent it (avs_prepass_set_slab): lattices and dof tables valid inside the rank's window,
+// GLOBAL reference ids, the ids of the window's DOFs.  Nothing here is sized or swept by the global DOF count except three
+// lookup arrays indexed by reference id (owner, halo flag, local id: 6 B per DOF, filled by memset) -- the sweeps run over the window's
+// DOFs (brick-major: the stable sort of their brick keys, the same relative order as the global permutation's), the rows are the
+// reference's rows bit for bit, and the local order, halo order and send lists equal the replicated-index assembly's for the same cuts.
+// ---------------------------------------------------------------------------------------------
+struct CutTable {
+    int world;
+    int cuts[kMaxRanks + 1];
+};
+__global__ __launch_bounds__(256) void k_win_keys(const int32_t *__restrict__ vdof, const int32_t *__restrict__ wl, int64_t m, int nx, int ny, int nz,
+                                                  int shift, int interleave, uint32_t *__restrict__ keys)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const int4 rec = reinterpret_cast<const int4 *>(vdof)[wl[i]]; // (the key of avs_reorder.hip's k_brick_keys)
+    const int level = rec.x & 0xff;
+    int px = rec.y << level, py = rec.z << level, pz = rec.w << level;
+    px = px < nx ? px : nx - 1;
+    py = py < ny ? py : ny - 1;
+    pz = pz < nz ? pz : nz - 1;
+    const uint32_t bx = (uint32_t)(px >> shift), by = (uint32_t)(py >> shift), bz = (uint32_t)(pz >> shift);
+    const uint32_t nbx = (uint32_t)((nx + (1 << shift) - 1) >> shift), nby = (uint32_t)((ny + (1 << shift) - 1) >> shift);
+    uint32_t key = (bz * nby + by) * nbx + bx;
+    if (interleave) {
+        const uint32_t mk = (1u << shift) - 1u;
+        key = (key << (3 * shift)) | ((((uint32_t)pz & mk) << (2 * shift)) | (((uint32_t)py & mk) << shift) | ((uint32_t)px & mk));
+    }
+    keys[i] = key;
+}
+// owner of every DOF of the window (by the position of its face along the cut axis), own flags
+__global__ __launch_bounds__(256) void k_win_owner(int64_t m, const int32_t *__restrict__ vdof, const int32_t *__restrict__ dom, int axis, int extent,
+                                                   CutTable T, int rank, uint8_t *__restrict__ owner_ref, int32_t *__restrict__ own_flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const int32_t id = dom[i];
+    const int32_t *t = vdof + 4 * (int64_t)id;
+    const int level = t[0] & 0xff;
+    long long pos = (long long)t[1 + axis] << level;
+    if (pos >= extent) pos = extent - 1;
+    int r = 0;
+    while (r + 1 < T.world && pos >= T.cuts[r + 1]) ++r;
+    owner_ref[id] = (uint8_t)r;
+    own_flag[i] = r == rank;
+}
+// per-plane weights of the rank's rows (non-zeros + 2, as the host planner), in units of 16 so that the sum over
+// a plane of a 2048^2 cross-section fits the int32 the ranks exchange
+__global__ __launch_bounds__(256) void k_win_plane_weights(int64_t n_own, const int32_t *__restrict__ ids, const int32_t *__restrict__ vdof,
+                                                           const int32_t *__restrict__ row_ptr, int axis, int extent, int shift,
+                                                           unsigned long long *__restrict__ weight)
+{
+    const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= n_own) return;
+    atomicAdd(&weight[plane_of_dof(vdof, ids[l], axis, extent, shift)], (unsigned long long)(row_ptr[l + 1] - row_ptr[l]) + 2ull);
+}
+__global__ __launch_bounds__(256) void k_win_weights_pack(int n, const unsigned long long *__restrict__ w, int32_t *__restrict__ out)
+{
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i < n) out[i] = (int32_t)((w[i] + 15ull) >> 4);
+}
+
+avs_status dist_allreduce_i32(PcgDist *d, int32_t *dev, int64_t count, hipStream_t stream); // below
+
+static avs_status dist_assemble_window(avs_ctx *c, PcgDist *d)
+{
+    hipStream_t st = c->stream;
+    const SlabWindow &W = c->slab;
+    const int rank = d->rank, world = d->world;
+    AVS_REQUIRE(W.world == world && W.rank == rank, AVS_ESTATE, "the slab of the pre-pass (rank %d of %d) is not this context's rank (%d of %d)", W.rank,
+                W.world, rank, world);
+    AVS_REQUIRE(c->tables_ready && c->wlist[0].p, AVS_ESTATE, "slab-local context without dof tables / window lists");
+    const int64_t n = c->n_vel, n_w = c->n_window[0];
+    const int axis = W.axis;
+    const int extent = axis == 0 ? c->desc.nx : (axis == 1 ? c->desc.ny : c->desc.nz);
+    d->cuts.assign(W.cuts, W.cuts + world + 1);
+    d->cut_axis = axis;
+
+    // the window's velocity DOFs in brick-major order
+    DevBuf<uint32_t> keys_in, keys_out;
+    DevBuf<int32_t> dom, flag, pos, g2l, scan_tmp, ids;
+    DevBuf<uint8_t> owner, is_halo;
+    DevBuf<char> sort_tmp;
+    AVS_TRY(keys_in.alloc((size_t)(n_w > 0 ? n_w : 1)));
+    AVS_TRY(keys_out.alloc((size_t)(n_w > 0 ? n_w : 1)));
+    AVS_TRY(dom.alloc((size_t)(n_w > 0 ? n_w : 1)));
+    AVS_TRY(flag.alloc((size_t)n_w + 1));
+    AVS_TRY(pos.alloc((size_t)n_w + 1));
+    AVS_TRY(scan_tmp.alloc(scan_tmp_elems(n_w + 1)));
+    AVS_TRY(g2l.alloc((size_t)(n > 0 ? n : 1)));
+    AVS_TRY(owner.alloc((size_t)(n > 0 ? n : 1)));
+    AVS_TRY(is_halo.alloc((size_t)(n > 0 ? n : 1)));
+    AVS_HIP(hipMemsetAsync(g2l.p, 0xFF, (size_t)n * sizeof(int32_t), st));
+    AVS_HIP(hipMemsetAsync(owner.p, 0xFF, (size_t)n, st));
+    AVS_HIP(hipMemsetAsync(is_halo.p, 0, (size_t)n, st));
+    int interleave = cur_opt().brick_interleave;
+    {
+        const int bs = c->brick_shift;
+        const uint64_t nb = (uint64_t)((c->desc.nx >> bs) + 1) * ((c->desc.ny >> bs) + 1) * ((c->desc.nz >> bs) + 1);
+        if ((nb << (3 * bs)) >= (1ull << 32)) interleave = 0;
+    }
+    if (n_w) {
+        hipLaunchKernelGGL(k_win_keys, dim3(grid256(n_w)), dim3(256), 0, st, c->vdof.p, c->wlist[0].p, n_w, c->desc.nx, c->desc.ny, c->desc.nz,
+                           c->brick_shift, interleave, keys_in.p);
+        size_t tmp_bytes = 0;
+        AVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in.p, keys_out.p, c->wlist[0].p, dom.p, (size_t)n_w, 0, 32, st));
+        AVS_TRY(sort_tmp.alloc(tmp_bytes > 0 ? tmp_bytes : 1));
+        AVS_HIP(rocprim::radix_sort_pairs(sort_tmp.p, tmp_bytes, keys_in.p, keys_out.p, c->wlist[0].p, dom.p, (size_t)n_w, 0, 32, st)); // stable
+        CutTable T{};
+        T.world = world;
+        for (int r = 0; r <= world; ++r) T.cuts[r] = W.cuts[r];
+        hipLaunchKernelGGL(k_win_owner, dim3(grid256(n_w)), dim3(256), 0, st, n_w, c->vdof.p, dom.p, axis, extent, T, rank, owner.p, flag.p);
+    }
+    int64_t n_own = 0;
+    AVS_TRY(scan_flags(flag.p, pos.p, n_w, scan_tmp, &n_own, st));
+    AVS_TRY(ids.alloc((size_t)(n_own > 0 ? n_own : 1)));
+    AVS_TRY(d->own_global.alloc((size_t)n_own));
+    if (n_own) {
+        hipLaunchKernelGGL(k_plan_scatter, dim3(grid256(n_w)), dim3(256), 0, st, n_w, flag.p, pos.p, (const int32_t *)nullptr, ids.p, g2l.p, 0, dom.p);
+        AVS_HIP(hipMemcpyAsync(d->own_global.p, ids.p, (size_t)n_own * sizeof(int32_t), hipMemcpyDeviceToDevice, st)); // (reference ids: avs_dist_get_solution scatters by them)
+    }
+    AVS_TRY(dist_assemble_tail(c, d, ids, n_own, n, dom.p, n_w, nullptr, nullptr, owner, is_halo, g2l, flag, pos, scan_tmp));
+
+    // the cuts this frame's weights suggest for the next one: per-plane weights of the own rows, summed over the ranks
+    d->next_cuts = d->cuts;
+    if (!d->hosted) {
+        int shift = c->desc.levels - 1;
+        if (cur_opt().dist_plane_shift >= 0) shift = cur_opt().dist_plane_shift < shift ? cur_opt().dist_plane_shift : shift;
+        else if (shift > 2) shift = 2;
+        const int nplanes = (extent + (1 << shift) - 1) >> shift;
+        DevBuf<unsigned long long> weight;
+        DevBuf<int32_t> w32;
+        AVS_TRY(weight.alloc((size_t)nplanes));
+        AVS_TRY(w32.alloc((size_t)nplanes));
+        AVS_HIP(hipMemsetAsync(weight.p, 0, (size_t)nplanes * sizeof(unsigned long long), st));
+        if (n_own)
+            hipLaunchKernelGGL(k_win_plane_weights, dim3(grid256(n_own)), dim3(256), 0, st, n_own, (const int32_t *)d->local_ref.p, c->vdof.p,
+                               (const int32_t *)d->row_ptr.p, axis, extent, shift, weight.p);
+        hipLaunchKernelGGL(k_win_weights_pack, dim3(grid256(nplanes)), dim3(256), 0, st, nplanes, weight.p, w32.p);
+        AVS_TRY(dist_allreduce_i32(d, w32.p, nplanes, st));
+        std::vector<int32_t> hw((size_t)nplanes);
+        AVS_HIP(hipMemcpyAsync(hw.data(), w32.p, hw.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        AVS_HIP(hipStreamSynchronize(st));
+        std::vector<int64_t> w64(hw.begin(), hw.end());
+        std::vector<int> po((size_t)nplanes);
+        plane_owners_from_weights(w64.data(), nplanes, world, po.data());
+        cuts_from_plane_owners(po, world, shift, extent, d->next_cuts);
+    }
+    return AVS_OK;
+}
+
+static avs_status dist_assemble_device(avs_ctx *c, PcgDist *d, int cut_axis, int extent)
+{
+    hipStream_t st = c->stream;
+    const int64_t n = c->n_vel;
+    const int rank = d->rank, world = d->world;
+    AVS_REQUIRE(world <= 32, AVS_EINVAL, "at most 32 ranks");
+    // Cut planes: the slabs are cut between planes of 2^shift fine cells.  The replicated planner (avs_dist_partition, avs_partition.cpp)
+    // keeps 2^(levels-1) -- no top-level cell straddles a cut; here, where every rank assembles its own rows, nothing needs that (a DOF
+    // belongs to the plane of its own position, whatever it reads is a halo column), and planes of at most 4 cells halve the granularity
+    // of the balance at 4 levels: on the 8-way partition of the 512^3 beam a rank's share moved in steps of 12.5 % (868 k .. 994 k rows,
+    // 30.5 .. 34.3 us per iteration in the loop-back measurement -- the slowest rank sets the pace).  AVS_DIST_PLANE_SHIFT overrides.
+    int shift = c->desc.levels - 1;
+    if (cur_opt().dist_plane_shift >= 0) shift = cur_opt().dist_plane_shift < shift ? cur_opt().dist_plane_shift : shift;
+    else if (shift > 2) shift = 2;
+    const int nplanes = (extent + (1 << shift) - 1) >> shift;
+    AVS_REQUIRE(nplanes <= 65535, AVS_EINVAL, "too many cut planes");
+
+    // global, index-only: raw triplet count per row (weights) and the brick-major permutation
+    DevBuf<int32_t> raw_count;
+    AVS_TRY(count_raw_rows(c, raw_count));
+    AVS_TRY(build_brick_permutation(c, c->brick_shift));
+
+    DevBuf<uint16_t> plane;
+    DevBuf<unsigned long long> weight;
+    DevBuf<int32_t> plane_owner, flag, pos, g2l, scan_tmp, halo_tmp, ids;
+    DevBuf<uint8_t> owner, is_halo;
+    DevBuf<uint32_t> needed_by;
+    AVS_TRY(plane.alloc((size_t)n));
+    AVS_TRY(weight.alloc((size_t)nplanes));
+    AVS_TRY(plane_owner.alloc((size_t)nplanes));
+    AVS_TRY(flag.alloc((size_t)n + 1));
+    AVS_TRY(pos.alloc((size_t)n + 1));
+    AVS_TRY(g2l.alloc((size_t)n));
+    AVS_TRY(scan_tmp.alloc(scan_tmp_elems(n + 1)));
+    AVS_TRY(owner.alloc((size_t)n));
+    AVS_TRY(is_halo.alloc((size_t)n));
+    AVS_HIP(hipMemsetAsync(weight.p, 0, (size_t)nplanes * sizeof(unsigned long long), st));
+    AVS_HIP(hipMemsetAsync(is_halo.p, 0, (size_t)n, st));
+    AVS_HIP(hipMemsetAsync(g2l.p, 0xFF, (size_t)n * sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_da_planes, dim3(2048), dim3(256), 0, st, n, c->vdof.p, c->perm.p, raw_count.p, cut_axis, extent, shift, nplanes,
+                       plane.p, weight.p);
+    std::vector<unsigned long long> h_w((size_t)nplanes);
+    AVS_HIP(hipMemcpyAsync(h_w.data(), weight.p, h_w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    AVS_HIP(hipStreamSynchronize(st));
+    std::vector<int64_t> h_w64(h_w.begin(), h_w.end());
+    std::vector<int> h_po((size_t)nplanes);
+    plane_owners_from_weights(h_w64.data(), nplanes, world, h_po.data());
+    cuts_from_plane_owners(h_po, world, shift, extent, d->cuts);
+    d->next_cuts = d->cuts;
+    d->cut_axis = cut_axis;
+    AVS_HIP(hipMemcpyAsync(plane_owner.p, h_po.data(), h_po.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_plan_owner, dim3(grid256(n)), dim3(256), 0, st, n, plane.p, plane_owner.p, rank, owner.p, flag.p);
+
+    // owned rows (ascending brick-major id) and the DOFs behind them
+    int64_t n_own = 0;
+    AVS_TRY(scan_flags(flag.p, pos.p, n, scan_tmp, &n_own, st));
+    AVS_TRY(d->own_global.alloc((size_t)n_own));
+    AVS_TRY(ids.alloc((size_t)n_own));
+    hipLaunchKernelGGL(k_plan_scatter, dim3(grid256(n)), dim3(256), 0, st, n, flag.p, pos.p, (const int32_t *)nullptr, d->own_global.p,
+                       g2l.p, 0);
+    if (n_own) hipLaunchKernelGGL(k_gather_i<int32_t>, dim3(grid256(n_own)), dim3(256), 0, st, c->perm.p, d->own_global.p, ids.p, n_own);
+
+    return dist_assemble_tail(c, d, ids, n_own, n, nullptr, n, c->inv.p, c->perm.p, owner, is_halo, g2l, flag, pos, scan_tmp);
 }
 
 // storage form of the rank's local rows (avs_get_matrix_format when no global matrix exists)
@@ -1651,6 +1887,7 @@ avs_status avs_dist_partition(avs_ctx *c, int32_t cut_axis)
     AVS_REQUIRE(c->dist, AVS_ESTATE, "call avs_dist_init / avs_dist_init_local first");
     AVS_REQUIRE(c->system_ready, AVS_ESTATE, "avs_assemble must succeed before avs_dist_partition");
     AVS_HIP(hipSetDevice(c->desc.device));
+    AVS_REQUIRE(!c->slab.on, AVS_ESTATE, "the context holds a slab-local pre-pass (this rank's window only): only avs_dist_assemble works on it");
     PcgDist *d = c->dist;
     hipStream_t st = c->stream;
     const int64_t n = c->n_vel;
@@ -1727,6 +1964,10 @@ avs_status avs_dist_assemble(avs_ctx *c, int32_t cut_axis, avs_assembly_info *in
     AVS_HIP(hipSetDevice(c->desc.device));
     PcgDist *d = c->dist;
     hipStream_t st = c->stream;
+    if (c->slab.on) {
+        AVS_REQUIRE(cut_axis < 0 || cut_axis == c->slab.axis, AVS_EINVAL, "the context's lattices were cut along axis %d by the slab-local pre-pass", c->slab.axis);
+        cut_axis = c->slab.axis;
+    }
     if (cut_axis < 0) { // longest axis
         cut_axis = 0;
         if (c->desc.ny > c->desc.nx) cut_axis = 1;
@@ -1737,7 +1978,7 @@ avs_status avs_dist_assemble(avs_ctx *c, int32_t cut_axis, avs_assembly_info *in
     Timer t(st);
     avs_assembly_info ai{};
     t.start();
-    AVS_TRY(build_stencils(c)); // dof tables + stencils: index-only and cheap, every rank builds all of them
+    AVS_TRY(build_stencils(c)); // dof tables + stencils: index-only; every rank builds all of them -- or, on a slab-local context, the ones around its slab
     ai.stencil_ms = t.stop();
     Scope scope("Build Octree Linear System"); // cpp:554: here only this rank's rows
     ai.guess_ms = 0.; // the restriction of the owned DOFs is part of system_ms here
@@ -1745,7 +1986,8 @@ avs_status avs_dist_assemble(avs_ctx *c, int32_t cut_axis, avs_assembly_info *in
     c->system_ready = false; // no global matrix in this mode
     c->reordered = false;
     d->vi.clear();
-    AVS_TRY(dist_assemble_device(c, d, cut_axis, extent));
+    if (c->slab.on) AVS_TRY(dist_assemble_window(c, d));
+    else AVS_TRY(dist_assemble_device(c, d, cut_axis, extent));
     ai.system_ms = t.stop();
     t.start();
     d->n_global = c->n_vel;
@@ -1776,7 +2018,7 @@ avs_status avs_dist_assemble(avs_ctx *c, int32_t cut_axis, avs_assembly_info *in
     if (d->hosted) AVS_TRY(direct_setup(c, d));
     ai.csr_ms = t.stop();
     d->partitioned = true;
-    d->reordered = true; // own_global holds brick-major ids: avs_dist_get_solution maps back through c->inv
+    d->reordered = !c->slab.on; // own_global holds brick-major ids: avs_dist_get_solution maps back through c->inv (slab-local: reference ids)
     d->solved = false;
     ai.n_velocity = c->n_vel;
     ai.n_edge = c->n_edge;
@@ -1784,6 +2026,38 @@ avs_status avs_dist_assemble(avs_ctx *c, int32_t cut_axis, avs_assembly_info *in
     ai.nnz = d->nnz_local;
     ai.raw_triplets = 0;
     if (info) *info = ai;
+    return AVS_OK;
+}
+
+static avs_status prepass_allreduce_cb(int32_t *dev, int64_t count, void *stream, void *user)
+{
+    return dist_allreduce_i32(static_cast<PcgDist *>(user), dev, count, reinterpret_cast<hipStream_t>(stream));
+}
+
+avs_status avs_dist_bind_prepass(avs_ctx *c, avs_prepass *pp, int32_t cut_axis, const int32_t *cuts)
+{
+    avs::OptScope opt_scope_(c);
+    AVS_REQUIRE(c && pp, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->dist, AVS_ESTATE, "call avs_dist_init / avs_dist_init_local first");
+    PcgDist *d = c->dist;
+    if (d->world <= 1 || !cuts) return avs_prepass_set_slab(pp, 0, nullptr, 1, 0, nullptr, nullptr);
+    AVS_REQUIRE(d->comm || d->group, AVS_ESTATE, "a hosted group sums through the caller's own callback: avs_prepass_set_slab");
+    if (cut_axis < 0) {
+        cut_axis = 0;
+        if (c->desc.ny > c->desc.nx) cut_axis = 1;
+        if (c->desc.nz > (cut_axis == 0 ? c->desc.nx : c->desc.ny)) cut_axis = 2;
+    }
+    return avs_prepass_set_slab(pp, cut_axis, cuts, d->world, d->rank, prepass_allreduce_cb, d);
+}
+
+avs_status avs_dist_get_cuts(avs_ctx *c, int32_t which, int32_t *cut_axis, int32_t *cuts)
+{
+    avs::OptScope opt_scope_(c);
+    AVS_REQUIRE(c && cuts, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->dist && c->dist->partitioned && c->dist->cuts.size() == (size_t)c->dist->world + 1, AVS_ESTATE, "call avs_dist_assemble first");
+    const std::vector<int32_t> &v = which ? c->dist->next_cuts : c->dist->cuts;
+    for (size_t i = 0; i < v.size(); ++i) cuts[i] = v[i];
+    if (cut_axis) *cut_axis = c->dist->cut_axis;
     return AVS_OK;
 }
 

@@ -518,8 +518,24 @@ struct ValueIndex {
 avs_status build_matrix_index(const int32_t *row_ptr, const int32_t *col, const double *val, int64_t n, int64_t nnz, int64_t n_cols,
                               ValueIndex &vi, hipStream_t st);
 
+// Slab-local pre-pass (round 6, SURVEY 8(e) "assembles the rows it owns from its slab of the pyramids plus a halo"): what a rank's
+// lattices hold.  Along the cut axis the lattices of level l are valid for the entries [win_lo[l], win_hi[l]) (level-l cells; win_hi ==
+// the level's cell count means "to the end of every lattice", face and edge lattices' extra entry included); ids are the GLOBAL ones.
+constexpr int kSlabIndexMargin = 12;  // level-l cells around the rank's slab whose index lattices are classified (then rounded out to 16-entry tiles)
+constexpr int kSlabStencilMargin = 4; // level-l cells around the slab whose edge / centre stresses get a stencil (a stencil reads the lattices <= 2 cells of the coarser level further)
+struct SlabWindow {
+    bool on = false;
+    int axis = 0, world = 1, rank = 0;
+    int cuts[33] = {};  // fine cells along `axis`: rank r owns the faces at positions [cuts[r], cuts[r + 1])
+    int win_lo[AVS_MAX_LEVELS] = {}, win_hi[AVS_MAX_LEVELS] = {};
+};
+
 // what avs_prepass_apply hands to a context: references on the pre-pass's own allocations (no copy; see SharedBuf)
 struct PrepassLoan {
+    SlabWindow slab;
+    // slab-local pre-pass: the ids (ascending) of the velocity / edge / centre DOFs inside the window
+    std::shared_ptr<DevBuf<int32_t>> wlist[3];
+    int64_t n_window[3] = {0, 0, 0};
     int levels = 0;
     std::shared_ptr<DevBuf<int8_t>> labels[AVS_MAX_LEVELS];
     std::shared_ptr<DevBuf<int32_t>> vidx[AVS_MAX_LEVELS][3], eidx[AVS_MAX_LEVELS][3], cidx[AVS_MAX_LEVELS], ridx[3];
@@ -698,6 +714,11 @@ struct avs_ctx {
     // dof tables: 4 x int32 per dof (level | axis << 8, i, j, k)
     avs::LatBuf<int32_t> vdof, edof, cdof; // (built from the index lattices, or lent by the pre-pass, which writes them while it numbers the DOFs)
     bool tables_ready = false;
+    // slab-local pre-pass (avs_prepass_set_slab + avs_prepass_apply): the lattices and dof tables hold this rank's window only; the ids
+    // of the DOFs inside it (velocity, edge, centre; ascending).  Only avs_dist_assemble works on such a context.
+    avs::SlabWindow slab;
+    avs::LatBuf<int32_t> wlist[3];
+    int64_t n_window[3] = {0, 0, 0};
 
     // stencils
     avs::DevBuf<int32_t> e_cnt, e_idx, e_bcnt, c_cnt, c_idx, c_bcnt;

@@ -654,6 +654,7 @@ static avs_status transfer_impl(avs_ctx *c, float *out_x, float *out_y, float *o
     avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c && out_x && out_y && out_z, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->solved, AVS_ESTATE, "no solution: call avs_solve first");
+    AVS_REQUIRE(!c->slab.on, AVS_ESTATE, "the context holds a slab-local pre-pass (this rank's window only): the transfer needs the whole pyramid");
     AVS_REQUIRE(c->have_ridx[0] && c->have_ridx[1] && c->have_ridx[2], AVS_ESTATE, "regular-grid index fields missing (avs_set_regular_index_field)");
     AVS_REQUIRE(c->tables_ready, AVS_ESTATE, "dof tables missing");
     AVS_HIP(hipSetDevice(c->desc.device));

@@ -46,6 +46,20 @@ __device__ __forceinline__ size_t lin3(const Grid3 &g, int i, int j, int k)
     return (size_t)i + (size_t)g.r[0] * ((size_t)j + (size_t)g.r[1] * (size_t)k);
 }
 
+// Sub-box of a lattice (round 6, slab-local pre-pass): the dense kernels sweep `box` instead of the whole lattice -- a rank of a
+// partitioned solve fills its window only.  The full lattice as a box gives the old sweep, index for index.
+struct Box3 {
+    int lo[3], n[3];
+    __host__ __device__ size_t vol() const { return (n[0] > 0 && n[1] > 0 && n[2] > 0) ? (size_t)n[0] * n[1] * n[2] : 0; }
+};
+__device__ __forceinline__ void box_coords(const Box3 &b, size_t t, int &i, int &j, int &k)
+{
+    i = b.lo[0] + (int)(t % b.n[0]);
+    const size_t q = t / b.n[0];
+    j = b.lo[1] + (int)(q % b.n[1]);
+    k = b.lo[2] + (int)(q / b.n[1]);
+}
+
 static inline unsigned grid_for(size_t n, unsigned cap = 1u << 20)
 {
     size_t b = (n + kBlock - 1) / kBlock;
@@ -86,12 +100,15 @@ struct WeightFields {
 // it scan the window itself (the exact test, as before) -- it used to read the window of EVERY brick, 3.35x the lattice.
 // One WAVE per brick (eight cells per lane, a ballot instead of a block barrier), each workgroup walking many bricks: a workgroup per
 // brick is 2.2 M workgroups at 1024^3, and dispatching them -- ~3.4 ns each -- took as long as the old pass itself.
-__global__ __launch_bounds__(kBlock) void k_sdf_sign_blocks(const float *__restrict__ sdf, Grid3 src, Grid3 bricks, uint8_t *__restrict__ signs)
+__global__ __launch_bounds__(kBlock) void k_sdf_sign_blocks(const float *__restrict__ sdf, Grid3 src, Grid3 bricks, Box3 box, uint8_t *__restrict__ signs)
 {
-    const size_t nb = bricks.vol();
+    const size_t nb = box.vol();
     const int lane = threadIdx.x & 63;
-    for (size_t b = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); b < nb; b += (size_t)gridDim.x * (kBlock / 64)) {
-        const int o0[3] = {(int)(b % bricks.r[0]) * kWBX, (int)((b / bricks.r[0]) % bricks.r[1]) * kWBY, (int)(b / ((size_t)bricks.r[0] * bricks.r[1])) * kWBZ};
+    for (size_t t = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); t < nb; t += (size_t)gridDim.x * (kBlock / 64)) {
+        int bc[3];
+        box_coords(box, t, bc[0], bc[1], bc[2]);
+        const size_t b = (size_t)bc[0] + (size_t)bricks.r[0] * ((size_t)bc[1] + (size_t)bricks.r[1] * (size_t)bc[2]);
+        const int o0[3] = {bc[0] * kWBX, bc[1] * kWBY, bc[2] * kWBZ};
         int neg = 0, pos = 0;
 #pragma unroll
         for (int u = 0; u < kWThreads / 64; ++u) { // lanes 0..31: a 128-B row of x, lanes 32..63 the next y
@@ -111,12 +128,14 @@ __global__ __launch_bounds__(kBlock) void k_sdf_sign_blocks(const float *__restr
 // Pass 1, one THREAD per brick: where the 27 bricks around it agree on a sign and the lattices already hold that constant for it
 // (`state`, temporal reuse below) there is nothing to do -- in a running simulation that is nearly every brick; the others go on the work
 // list of k_sdf_weights_far.
-__global__ __launch_bounds__(kBlock) void k_brick_triage(Grid3 bricks, const uint8_t *__restrict__ signs, const uint8_t *__restrict__ state,
+__global__ __launch_bounds__(kBlock) void k_brick_triage(Grid3 bricks, Box3 box, const uint8_t *__restrict__ signs, const uint8_t *__restrict__ state,
                                                          int32_t *__restrict__ work_list /* [0]: count, then brick ids */)
 {
-    const size_t nb = bricks.vol();
-    for (size_t b = (size_t)blockIdx.x * kBlock + threadIdx.x; b < nb; b += (size_t)gridDim.x * kBlock) {
-        const int bc[3] = {(int)(b % bricks.r[0]), (int)((b / bricks.r[0]) % bricks.r[1]), (int)(b / ((size_t)bricks.r[0] * bricks.r[1]))};
+    const size_t nb = box.vol();
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < nb; t += (size_t)gridDim.x * kBlock) {
+        int bc[3];
+        box_coords(box, t, bc[0], bc[1], bc[2]);
+        const size_t b = (size_t)bc[0] + (size_t)bricks.r[0] * ((size_t)bc[1] + (size_t)bricks.r[1] * (size_t)bc[2]);
         unsigned sg = 0u;
         for (int dz = -1; dz <= 1; ++dz)
             for (int dy = -1; dy <= 1; ++dy)
@@ -277,14 +296,17 @@ __global__ __launch_bounds__(kWThreads) void k_sdf_weights(const float *__restri
 // P2: mask + base labels
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_mask_labels(const float *__restrict__ liquid, const float *__restrict__ solid,
-                                                        size_t n, double dx, double extrapolation, int8_t *__restrict__ mask,
+                                                        Box3 box, double dx, double extrapolation, int8_t *__restrict__ mask,
                                                         int8_t *__restrict__ labels, Grid3 g, Grid3 sim)
 {
     const double inner = dx * 2., outer = 3. * dx; // cpp:259-262 (fine bandwidth getter mismatch => 2)
-    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < n; o += (size_t)gridDim.x * kBlock) {
+    const size_t n = box.vol();
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < n; t += (size_t)gridDim.x * kBlock) {
+        int ci, cj, ck;
+        box_coords(box, t, ci, cj, ck);
+        const size_t o = lin3(g, ci, cj, ck);
         const double sdf = (double)liquid[o];
         int m;
-        const int ci = (int)(o % g.r[0]), cj = (int)((o / g.r[0]) % g.r[1]), ck = (int)(o / ((size_t)g.r[0] * g.r[1]));
         if (ci >= sim.r[0] || cj >= sim.r[1] || ck >= sim.r[2]) m = 1; // outside the simulation grid: stays INACTIVE (oct.cpp:375-379)
         else if (sdf > 0 && sdf < outer) m = 0;
         else if (sdf <= 0.) {
@@ -302,21 +324,14 @@ __global__ __launch_bounds__(kBlock) void k_mask_labels(const float *__restrict_
 // ---------------------------------------------------------------------------------------------
 // P3: octree passes, one thread per PARENT cell (reads / writes only its own 8 children and itself)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void parent_coords(size_t o, const Grid3 &pg, int &i, int &j, int &k)
-{
-    i = (int)(o % pg.r[0]);
-    const size_t q = o / pg.r[0];
-    j = (int)(q % pg.r[1]);
-    k = (int)(q / pg.r[1]);
-}
-
 // pass 1 (oct.cpp:395-565): UP with an ACTIVE sibling -> ACTIVE; a parent with an ACTIVE child -> DOWN
-__global__ __launch_bounds__(kBlock) void k_oct_pass1(int8_t *__restrict__ lab, Grid3 g, int8_t *__restrict__ par, Grid3 pg)
+__global__ __launch_bounds__(kBlock) void k_oct_pass1(int8_t *__restrict__ lab, Grid3 g, int8_t *__restrict__ par, Grid3 pg, Box3 box)
 {
-    const size_t total = pg.vol();
-    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+    const size_t total = box.vol();
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock) {
         int i, j, k;
-        parent_coords(o, pg, i, j, k);
+        box_coords(box, t, i, j, k);
+        const size_t o = lin3(pg, i, j, k);
         bool any = false;
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci)
@@ -333,12 +348,13 @@ __global__ __launch_bounds__(kBlock) void k_oct_pass1(int8_t *__restrict__ lab, 
 
 // pass 2 (oct.cpp:657-754): DOWN children -> parent DOWN (list applied first, oct.cpp:145), then face
 // grading: an UP child with an ACTIVE face neighbour -> parent ACTIVE (oct.cpp:162)
-__global__ __launch_bounds__(kBlock) void k_oct_pass2(const int8_t *__restrict__ lab, Grid3 g, int8_t *__restrict__ par, Grid3 pg)
+__global__ __launch_bounds__(kBlock) void k_oct_pass2(const int8_t *__restrict__ lab, Grid3 g, int8_t *__restrict__ par, Grid3 pg, Box3 box)
 {
-    const size_t total = pg.vol();
-    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+    const size_t total = box.vol();
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock) {
         int i, j, k;
-        parent_coords(o, pg, i, j, k);
+        box_coords(box, t, i, j, k);
+        const size_t o = lin3(pg, i, j, k);
         bool down = false, grade = false;
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci) {
@@ -363,13 +379,14 @@ __global__ __launch_bounds__(kBlock) void k_oct_pass2(const int8_t *__restrict__
 }
 
 // pass 3 (oct.cpp:757-840): an UP child under a still INACTIVE parent -> parent UP
-__global__ __launch_bounds__(kBlock) void k_oct_pass3(const int8_t *__restrict__ lab, Grid3 g, int8_t *__restrict__ par, Grid3 pg)
+__global__ __launch_bounds__(kBlock) void k_oct_pass3(const int8_t *__restrict__ lab, Grid3 g, int8_t *__restrict__ par, Grid3 pg, Box3 box)
 {
-    const size_t total = pg.vol();
-    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
-        if (par[o] != AVS_INACTIVE) continue;
+    const size_t total = box.vol();
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock) {
         int i, j, k;
-        parent_coords(o, pg, i, j, k);
+        box_coords(box, t, i, j, k);
+        const size_t o = lin3(pg, i, j, k);
+        if (par[o] != AVS_INACTIVE) continue;
         bool up = false;
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci)
@@ -378,16 +395,26 @@ __global__ __launch_bounds__(kBlock) void k_oct_pass3(const int8_t *__restrict__
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_oct_top(int8_t *__restrict__ lab, size_t n)
+__global__ __launch_bounds__(kBlock) void k_oct_top(int8_t *__restrict__ lab, Grid3 g, Box3 box)
 {
-    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < n; o += (size_t)gridDim.x * kBlock)
+    const size_t n = box.vol();
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < n; t += (size_t)gridDim.x * kBlock) {
+        int i, j, k;
+        box_coords(box, t, i, j, k);
+        const size_t o = lin3(g, i, j, k);
         if (lab[o] == AVS_UP) lab[o] = AVS_ACTIVE;
+    }
 }
 
-__global__ __launch_bounds__(kBlock) void k_any_active(const int8_t *__restrict__ lab, size_t n, int *__restrict__ flag)
+__global__ __launch_bounds__(kBlock) void k_any_active(const int8_t *__restrict__ lab, Grid3 g, Box3 box, int *__restrict__ flag)
 {
     bool any = false;
-    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < n; o += (size_t)gridDim.x * kBlock) any |= lab[o] == AVS_ACTIVE;
+    const size_t n = box.vol();
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < n; t += (size_t)gridDim.x * kBlock) {
+        int i, j, k;
+        box_coords(box, t, i, j, k);
+        any |= lab[lin3(g, i, j, k)] == AVS_ACTIVE;
+    }
     if (__ballot(any) && (threadIdx.x & 63) == 0) *flag = 1; // benign race: every writer stores 1
 }
 
@@ -396,13 +423,39 @@ __global__ __launch_bounds__(kBlock) void k_any_active(const int8_t *__restrict_
 // ---------------------------------------------------------------------------------------------
 struct TileGrid {
     int tr[3];
+    // the tiles a launch covers (round 6, slab-local pre-pass: the tiles of the rank's window; full grid: bn == tr, lo == 0)
+    int lo[3], bn[3];
     __host__ __device__ size_t vol() const { return (size_t)tr[0] * tr[1] * tr[2]; }
+    __host__ __device__ size_t launch() const { return (bn[0] > 0 && bn[1] > 0 && bn[2] > 0) ? (size_t)bn[0] * bn[1] * bn[2] : 0; }
 };
+static TileGrid tile_grid(const int gr[3])
+{
+    TileGrid t;
+    for (int a = 0; a < 3; ++a) {
+        t.tr[a] = (gr[a] + kTile - 1) / kTile;
+        t.lo[a] = 0;
+        t.bn[a] = t.tr[a];
+    }
+    return t;
+}
+// workgroup b of a tile kernel -> linear tile id on the full tile grid
+__device__ __forceinline__ unsigned launch_tile(const TileGrid &t, unsigned b)
+{
+    const int x = t.lo[0] + (int)(b % (unsigned)t.bn[0]), y = t.lo[1] + (int)((b / (unsigned)t.bn[0]) % (unsigned)t.bn[1]),
+              z = t.lo[2] + (int)(b / ((unsigned)t.bn[0] * (unsigned)t.bn[1]));
+    return (unsigned)x + (unsigned)t.tr[0] * ((unsigned)y + (unsigned)t.tr[1] * (unsigned)z);
+}
 __device__ __forceinline__ size_t tile_of(const TileGrid &t, int i, int j, int k)
 {
     return (size_t)(i / kTile) + (size_t)t.tr[0] * ((size_t)(j / kTile) + (size_t)t.tr[1] * (size_t)(k / kTile));
 }
 
+// (slab-local pre-pass: a tile outside the launch box of its grid belongs to another rank's window and is never marked)
+__device__ __forceinline__ bool in_launch(const TileGrid &t, int i, int j, int k)
+{
+    const int x = i / kTile - t.lo[0], y = j / kTile - t.lo[1], z = k / kTile - t.lo[2];
+    return x >= 0 && x < t.bn[0] && y >= 0 && y < t.bn[1] && z >= 0 && z < t.bn[2];
+}
 // Tile occupancy.  Kind 0: faces (both directions along `axis`) of hit cells, cpp:887-1000; kind 1: the 4 `axis` edges of
 // ACTIVE cells, cpp:1003-1057.  All six occupancy grids of one level (3 face lattices, 3 edge lattices) come from ONE read of
 // the cell lattice: one launch per lattice re-read the level-0 SDF / labels nine times (2.5 ms of the 7.7 ms classification
@@ -412,32 +465,30 @@ struct TileSets {
     uint8_t *occ[2][3];
 };
 __global__ __launch_bounds__(kBlock) void k_mark_tiles_all(const int8_t *__restrict__ lab, const float *__restrict__ liquid, double occ_sdf,
-                                                           Grid3 cg, TileSets T)
+                                                           Grid3 cg, Box3 box, TileSets T)
 {
-    const size_t total = cg.vol();
-    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+    const size_t total = box.vol();
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock) {
+        int c[3];
+        box_coords(box, t, c[0], c[1], c[2]);
+        const size_t o = lin3(cg, c[0], c[1], c[2]);
         const bool active = lab[o] == AVS_ACTIVE;
         const bool hit_face = liquid ? ((double)liquid[o] < occ_sdf) : active; // kind 0 at level 0: the SDF rule (cpp:907)
         if (!hit_face && !active) continue;
-        int c[3];
-        c[0] = (int)(o % cg.r[0]);
-        const size_t q = o / cg.r[0];
-        c[1] = (int)(q % cg.r[1]);
-        c[2] = (int)(q / cg.r[1]);
 #pragma unroll
         for (int axis = 0; axis < 3; ++axis) {
             if (hit_face)
                 for (int d = 0; d < 2; ++d) {
                     int f[3] = {c[0], c[1], c[2]};
                     f[axis] += d;
-                    T.occ[0][axis][tile_of(T.tg[0][axis], f[0], f[1], f[2])] = 1;
+                    if (in_launch(T.tg[0][axis], f[0], f[1], f[2])) T.occ[0][axis][tile_of(T.tg[0][axis], f[0], f[1], f[2])] = 1;
                 }
             if (active)
                 for (int ei = 0; ei < 4; ++ei) {
                     int e[3] = {c[0], c[1], c[2]};
                     if (ei & 1) ++e[(axis + 1) % 3];
                     if (ei & 2) ++e[(axis + 2) % 3];
-                    T.occ[1][axis][tile_of(T.tg[1][axis], e[0], e[1], e[2])] = 1;
+                    if (in_launch(T.tg[1][axis], e[0], e[1], e[2])) T.occ[1][axis][tile_of(T.tg[1][axis], e[0], e[1], e[2])] = 1;
                 }
         }
     }
@@ -448,8 +499,9 @@ __global__ __launch_bounds__(kBlock) void k_mark_tiles_all(const int8_t *__restr
 // (39 GB of fills at 1024^3, 11 ms, for a sheet that occupies one tile in ten).
 __global__ __launch_bounds__(kBlock) void k_reset_tiles(int32_t *__restrict__ out, Grid3 fg, TileGrid tg, const uint8_t *__restrict__ occ)
 {
-    if (!occ[blockIdx.x]) return;
-    const int tile_x = blockIdx.x % tg.tr[0], tile_y = (blockIdx.x / tg.tr[0]) % tg.tr[1], tile_z = blockIdx.x / (tg.tr[0] * tg.tr[1]);
+    const unsigned tb = launch_tile(tg, blockIdx.x);
+    if (!occ[tb]) return;
+    const int tile_x = tb % tg.tr[0], tile_y = (tb / tg.tr[0]) % tg.tr[1], tile_z = tb / (tg.tr[0] * tg.tr[1]);
     const int i = tile_x * kTile + (threadIdx.x & (kTile - 1)), j = tile_y * kTile + (threadIdx.x >> 4);
     if (i >= fg.r[0] || j >= fg.r[1]) return;
     for (int z = 0; z < kTile && tile_z * kTile + z < fg.r[2]; ++z) out[lin3(fg, i, j, tile_z * kTile + z)] = AVS_UNASSIGNED;
@@ -472,8 +524,9 @@ __global__ __launch_bounds__(kBlock) void k_classify_velocity(ClassifyArgs A, Gr
     const Grid3 c0{{A.n[0], A.n[1], A.n[2]}};
     // one workgroup per 16^3 tile of the lattice; the lattice was pre-filled with AVS_UNASSIGNED and a tile nobody marked
     // keeps that value ("constant tiles are never visited", cpp:1197): it is neither read nor written here
-    if (!occ[blockIdx.x]) return;
-    const int tile_x = blockIdx.x % tg.tr[0], tile_y = (blockIdx.x / tg.tr[0]) % tg.tr[1], tile_z = blockIdx.x / (tg.tr[0] * tg.tr[1]);
+    const unsigned tb = launch_tile(tg, blockIdx.x);
+    if (!occ[tb]) return;
+    const int tile_x = tb % tg.tr[0], tile_y = (tb / tg.tr[0]) % tg.tr[1], tile_z = tb / (tg.tr[0] * tg.tr[1]);
     const int vi_ = tile_x * kTile + (threadIdx.x & (kTile - 1)), vj_ = tile_y * kTile + (threadIdx.x >> 4);
     if (vi_ >= fg.r[0] || vj_ >= fg.r[1]) return;
     for (int vz_ = 0; vz_ < kTile && tile_z * kTile + vz_ < fg.r[2]; ++vz_) {
@@ -526,8 +579,9 @@ __global__ __launch_bounds__(kBlock) void k_classify_regular(ClassifyArgs A, Gri
     const Grid3 c0{{A.n[0], A.n[1], A.n[2]}};
     // one workgroup per 16^3 tile of the lattice; the lattice was pre-filled with AVS_UNASSIGNED and a tile nobody marked
     // keeps that value ("constant tiles are never visited", cpp:1197): it is neither read nor written here
-    if (!occ[blockIdx.x]) return;
-    const int tile_x = blockIdx.x % tg.tr[0], tile_y = (blockIdx.x / tg.tr[0]) % tg.tr[1], tile_z = blockIdx.x / (tg.tr[0] * tg.tr[1]);
+    const unsigned tb = launch_tile(tg, blockIdx.x);
+    if (!occ[tb]) return;
+    const int tile_x = tb % tg.tr[0], tile_y = (tb / tg.tr[0]) % tg.tr[1], tile_z = tb / (tg.tr[0] * tg.tr[1]);
     const int vi_ = tile_x * kTile + (threadIdx.x & (kTile - 1)), vj_ = tile_y * kTile + (threadIdx.x >> 4);
     if (vi_ >= fg.r[0] || vj_ >= fg.r[1]) return;
     for (int vz_ = 0; vz_ < kTile && tile_z * kTile + vz_ < fg.r[2]; ++vz_) {
@@ -568,8 +622,9 @@ __global__ __launch_bounds__(kBlock) void k_classify_edges(ClassifyArgs A, Grid3
     const Grid3 cg{{A.n[0] >> l, A.n[1] >> l, A.n[2] >> l}};
     // one workgroup per 16^3 tile of the lattice; the lattice was pre-filled with AVS_UNASSIGNED and a tile nobody marked
     // keeps that value ("constant tiles are never visited", cpp:1197): it is neither read nor written here
-    if (!occ[blockIdx.x]) return;
-    const int tile_x = blockIdx.x % tg.tr[0], tile_y = (blockIdx.x / tg.tr[0]) % tg.tr[1], tile_z = blockIdx.x / (tg.tr[0] * tg.tr[1]);
+    const unsigned tb = launch_tile(tg, blockIdx.x);
+    if (!occ[tb]) return;
+    const int tile_x = tb % tg.tr[0], tile_y = (tb / tg.tr[0]) % tg.tr[1], tile_z = tb / (tg.tr[0] * tg.tr[1]);
     const int vi_ = tile_x * kTile + (threadIdx.x & (kTile - 1)), vj_ = tile_y * kTile + (threadIdx.x >> 4);
     if (vi_ >= eg.r[0] || vj_ >= eg.r[1]) return;
     for (int vz_ = 0; vz_ < kTile && tile_z * kTile + vz_ < eg.r[2]; ++vz_) {
@@ -610,8 +665,9 @@ __global__ __launch_bounds__(kBlock) void k_center_tiles(const uint8_t *__restri
 __global__ __launch_bounds__(kBlock) void k_classify_centers_tiled(const int8_t *__restrict__ lab, const float *__restrict__ centerw, int level, Grid3 cg,
                                                                    TileGrid tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out)
 {
-    if (!occ[blockIdx.x]) return;
-    const int tile_x = blockIdx.x % tg.tr[0], tile_y = (blockIdx.x / tg.tr[0]) % tg.tr[1], tile_z = blockIdx.x / (tg.tr[0] * tg.tr[1]);
+    const unsigned tb = launch_tile(tg, blockIdx.x);
+    if (!occ[tb]) return;
+    const int tile_x = tb % tg.tr[0], tile_y = (tb / tg.tr[0]) % tg.tr[1], tile_z = tb / (tg.tr[0] * tg.tr[1]);
     const int i = tile_x * kTile + (threadIdx.x & (kTile - 1)), j = tile_y * kTile + (threadIdx.x >> 4);
     if (i >= cg.r[0] || j >= cg.r[1]) return;
     for (int z = 0; z < kTile && tile_z * kTile + z < cg.r[2]; ++z) {
@@ -690,10 +746,31 @@ __device__ __forceinline__ NumLattice batch_lattice(const NumStarts &S, const Nu
     return B->lat[li];
 }
 
-__global__ __launch_bounds__(kBlock) void k_tile_counts(NumStarts S, const NumBatch *__restrict__ B, int32_t *__restrict__ tile_count)
+// Slab-local pre-pass (round 6): several ranks classify a tile that straddles their windows (identically: the classification is
+// deterministic); ONE of them -- the rank whose slab holds the tile's first plane along the cut axis -- reports its count, the others
+// report 0, and the sum over the ranks gives every rank the count of every tile.
+struct SlabOwn {
+    int on, axis, world, rank;
+    int cuts[kMaxRanks + 1]; // fine cells along the cut axis: rank r owns [cuts[r], cuts[r + 1])
+};
+__device__ __forceinline__ bool slab_owns_tile(const SlabOwn &own, const NumLattice &Lt, int tile)
+{
+    const int tc = own.axis == 0 ? tile % Lt.ntx : (own.axis == 1 ? (tile / Lt.ntx) % Lt.nty : tile / (Lt.ntx * Lt.nty));
+    long long pos = ((long long)tc * kTile) << (Lt.tag & 0xff);
+    if (pos > own.cuts[own.world] - 1) pos = own.cuts[own.world] - 1; // (the extra last tile of a face lattice)
+    int r = 0;
+    while (r + 1 < own.world && pos >= own.cuts[r + 1]) ++r;
+    return r == own.rank;
+}
+
+__global__ __launch_bounds__(kBlock) void k_tile_counts(NumStarts S, const NumBatch *__restrict__ B, int32_t *__restrict__ tile_count, SlabOwn own)
 {
     const NumLattice Lt = batch_lattice(S, B, (int)blockIdx.x);
     const int tile = (int)blockIdx.x - Lt.tile0;
+    if (own.on && !slab_owns_tile(own, Lt, tile)) {
+        if (threadIdx.x == 0) tile_count[blockIdx.x] = 0;
+        return;
+    }
     // a tile the classification never visited (occupancy flag clear) holds no DOF: not read at all -- on a thin sheet that is
     // nine tiles in ten
     if (Lt.occ && !Lt.occ[tile]) {
@@ -720,6 +797,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_ids(NumStarts S, const NumBatch
     if (tile_off[blockIdx.x + 1] == tile_off[blockIdx.x]) return; // no DOF in this tile: nothing to read, nothing to write
     const NumLattice Lt = batch_lattice(S, B, (int)blockIdx.x);
     const int tile = (int)blockIdx.x - Lt.tile0;
+    if (Lt.occ && !Lt.occ[tile]) return; // (slab-local pre-pass: a tile of another rank's window -- counted there, not classified here)
     __shared__ int cnt[kTile * (kBlock / 64)]; // flagged voxels of (step z, wave w), then their exclusive prefix
     size_t first, zs;
     const unsigned bits = tile_flags(Lt.grid, Lt.g, Lt.ntx, Lt.nty, &first, &zs, tile);
@@ -754,6 +832,34 @@ __global__ __launch_bounds__(kBlock) void k_tile_ids(NumStarts S, const NumBatch
             Lt.grid[first + (size_t)z * zs] = id;
             if (table && id < cap) reinterpret_cast<int4 *>(table)[id] = make_int4(Lt.tag, ti, tj, tk + z);
         }
+}
+
+// Window lists (slab-local pre-pass): the ids of the DOFs in the tiles this rank classified, ascending -- what the rank's index-only
+// assembly sweeps instead of 0 .. n.  A tile's DOFs are the consecutive ids tile_off[t] .. tile_off[t + 1].
+__global__ __launch_bounds__(kBlock) void k_win_counts(NumStarts S, const NumBatch *__restrict__ B, const int32_t *__restrict__ tile_off, int tiles,
+                                                       int32_t *__restrict__ wcnt)
+{
+    const int t = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (t >= tiles) return;
+    const NumLattice Lt = batch_lattice(S, B, t);
+    wcnt[t] = (!Lt.occ || Lt.occ[t - Lt.tile0]) ? tile_off[t + 1] - tile_off[t] : 0;
+}
+__global__ __launch_bounds__(kBlock) void k_win_fill(const int32_t *__restrict__ tile_off, const int32_t *__restrict__ wcnt,
+                                                     const int32_t *__restrict__ woff, int32_t *__restrict__ list)
+{
+    const int t = (int)blockIdx.x;
+    const int c = wcnt[t];
+    for (int i = threadIdx.x; i < c; i += kBlock) list[woff[t] + i] = tile_off[t] + i;
+}
+// 32-bit fill of a sub-box of a lattice (the window of an index lattice -> AVS_UNASSIGNED)
+__global__ __launch_bounds__(kBlock) void k_fill_box_i32(int32_t *__restrict__ out, Grid3 g, Box3 box, int32_t value)
+{
+    const size_t n = box.vol();
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < n; t += (size_t)gridDim.x * kBlock) {
+        int i, j, k;
+        box_coords(box, t, i, j, k);
+        out[lin3(g, i, j, k)] = value;
+    }
 }
 
 } // namespace avs
@@ -793,6 +899,14 @@ struct avs_prepass {
     bool dof_valid[3] = {false, false, false}; // ... and complete (the count did not outgrow the capacity)
     int64_t prev_counts[3] = {0, 0, 0};
     bool temporal = true; // AVS_PREPASS_TEMPORAL=0: every run fills everything (measurement / tests)
+    // slab-local mode (avs_prepass_set_slab)
+    avs::SlabWindow slab;
+    avs_allreduce_i32_fn slab_fn = nullptr;
+    void *slab_user = nullptr;
+    uint64_t slab_sig = 0, state_sig = 0; // temporal-reuse records describe fillings of ONE window: a new window voids them
+    SharedBuf<int32_t> wlist[3];          // ids of the DOFs inside the window (velocity, edge, centre), ascending
+    int64_t n_window[3] = {0, 0, 0};
+    const float *liq = nullptr, *sol = nullptr; // the SDFs of the running call (the caller's device arrays in slab mode, else the copies above)
     int64_t counts[4] = {0, 0, 0, 0}; // velocity, edge, centre, regular
     double ms[4] = {0, 0, 0, 0};
     bool ready = false;
@@ -822,6 +936,18 @@ static void sub_consts(int n, bool centered, int s, int *di, float *fr)
 }
 
 // all seven weight fields in one launch: bricks cover the largest lattice (n + 1 samples per axis)
+static Box3 full_box(const int r[3]) { return Box3{{0, 0, 0}, {r[0], r[1], r[2]}}; }
+// [lo, hi) along `axis`, everything across
+static Box3 slab_box(const int r[3], int axis, int lo, int hi)
+{
+    Box3 b = full_box(r);
+    if (lo < 0) lo = 0;
+    if (hi > r[axis]) hi = r[axis];
+    b.lo[axis] = lo;
+    b.n[axis] = hi > lo ? hi - lo : 0;
+    return b;
+}
+
 static avs_status run_weights(avs_prepass *p, WeightFields &F)
 {
     F.n = p->desc.n_super;
@@ -849,20 +975,31 @@ static avs_status run_weights(avs_prepass *p, WeightFields &F)
     AVS_TRY(p->brick_signs.reserve(nb));
     AVS_TRY(p->work_list.reserve(nb + 1));
     AVS_HIP(hipMemsetAsync(p->work_list.p, 0, sizeof(int32_t), p->stream));
-    hipLaunchKernelGGL(k_sdf_sign_blocks, dim3(grid_for((nb + 3) / 4 * kBlock, 1u << 15)), dim3(kBlock), 0, p->stream, p->liquid.p, g3(sr), bricks, p->brick_signs.p);
-    hipLaunchKernelGGL(k_brick_triage, dim3(grid_for(nb, 1u << 15)), dim3(kBlock), 0, p->stream, bricks, (const uint8_t *)p->brick_signs.p,
+    // slab-local mode: the bricks that hold the samples [win_lo - 1, win_hi + 1] of the level-0 window (the classification reads one
+    // entry beyond a tile), their neighbours' signs for the triage
+    Box3 tri = full_box(bricks.r), sgn = tri;
+    if (p->slab.on) {
+        const int a = p->slab.axis, bs = a == 0 ? kWBX : (a == 1 ? kWBY : kWBZ);
+        const int lo = (p->slab.win_lo[0] - 1 < 0 ? 0 : p->slab.win_lo[0] - 1) / bs;
+        const int hi_s = p->slab.win_hi[0] >= sr[a] ? sr[a] + 1 : p->slab.win_hi[0] + 2; // one past the last sample needed
+        const int hi = (hi_s + bs - 1) / bs;
+        tri = slab_box(bricks.r, a, lo, hi);
+        sgn = slab_box(bricks.r, a, lo - 1, hi + 1);
+    }
+    hipLaunchKernelGGL(k_sdf_sign_blocks, dim3(grid_for((sgn.vol() + 3) / 4 * kBlock, 1u << 15)), dim3(kBlock), 0, p->stream, p->liq, g3(sr), bricks, sgn, p->brick_signs.p);
+    hipLaunchKernelGGL(k_brick_triage, dim3(grid_for(tri.vol(), 1u << 15)), dim3(kBlock), 0, p->stream, bricks, tri, (const uint8_t *)p->brick_signs.p,
                        (const uint8_t *)ws->st.p, p->work_list.p);
     int32_t n_work = 0;
     AVS_HIP(hipMemcpyAsync(&n_work, p->work_list.p, sizeof(int32_t), hipMemcpyDeviceToHost, p->stream));
     AVS_HIP(hipStreamSynchronize(p->stream));
     if (n_work > 0)
-        hipLaunchKernelGGL(k_sdf_weights_far, dim3((unsigned)n_work), dim3(kWThreads), 0, p->stream, p->liquid.p, g3(sr), bricks, F, p->near_list.p, ws->st.p,
+        hipLaunchKernelGGL(k_sdf_weights_far, dim3((unsigned)n_work), dim3(kWThreads), 0, p->stream, p->liq, g3(sr), bricks, F, p->near_list.p, ws->st.p,
                            (const uint8_t *)p->brick_signs.p, (const int32_t *)p->work_list.p);
     int32_t n_near = 0;
     AVS_HIP(hipMemcpyAsync(&n_near, p->near_list.p, sizeof(int32_t), hipMemcpyDeviceToHost, p->stream));
     AVS_HIP(hipStreamSynchronize(p->stream));
     if (n_near > 0)
-        hipLaunchKernelGGL(k_sdf_weights, dim3((unsigned)n_near), dim3(kWThreads), 0, p->stream, p->liquid.p, g3(sr), bricks, F,
+        hipLaunchKernelGGL(k_sdf_weights, dim3((unsigned)n_near), dim3(kWThreads), 0, p->stream, p->liq, g3(sr), bricks, F,
                            (const int32_t *)p->near_list.p);
     AVS_HIP(hipGetLastError());
     return AVS_OK;
@@ -872,18 +1009,20 @@ static avs_status run_weights(avs_prepass *p, WeightFields &F)
 // the record to fill in once the classification is enqueued (remember_tiles); until then the record is void (id 0), so a run that
 // fails in between leaves no stale claim about the allocation.
 static avs_status unassign_lattice(avs_prepass *p, SharedBuf<int32_t> &buf, Grid3 g, TileGrid tg, size_t occ_cap, avs_prepass::TileState states[2],
-                                   avs_prepass::TileState **out)
+                                   avs_prepass::TileState **out, const Box3 *window = nullptr)
 {
     avs_prepass::TileState *ts = nullptr;
     for (int k = 0; k < 2 && !ts; ++k)
         if (p->temporal && states[k].id != 0 && states[k].id == buf.id && states[k].occ.n == occ_cap) ts = &states[k];
     if (ts) {
-        hipLaunchKernelGGL(k_reset_tiles, dim3((unsigned)tg.vol()), dim3(kBlock), 0, p->stream, buf.p, g, tg, (const uint8_t *)ts->occ.p);
+        if (tg.launch()) hipLaunchKernelGGL(k_reset_tiles, dim3((unsigned)tg.launch()), dim3(kBlock), 0, p->stream, buf.p, g, tg, (const uint8_t *)ts->occ.p);
     } else {
         const uint64_t other = buf.ids[buf.cur ^ 1];
         ts = &states[states[0].id == 0 ? 0 : (states[1].id == 0 ? 1 : (states[0].id == other ? 1 : 0))];
         AVS_TRY(ts->occ.alloc(occ_cap));
-        AVS_HIP(hipMemsetAsync(buf.p, 0xFF, g.vol() * sizeof(int32_t), p->stream));
+        if (window) { // slab-local mode: the rank's window of the lattice only (the rest is never read)
+            if (window->vol()) hipLaunchKernelGGL(k_fill_box_i32, dim3(grid_for(window->vol(), 1u << 16)), dim3(kBlock), 0, p->stream, buf.p, g, *window, (int32_t)AVS_UNASSIGNED);
+        } else AVS_HIP(hipMemsetAsync(buf.p, 0xFF, g.vol() * sizeof(int32_t), p->stream));
     }
     ts->id = 0;
     AVS_HIP(hipGetLastError());
@@ -947,6 +1086,51 @@ avs_status avs_prepass_create(const avs_prepass_desc *d, avs_prepass **out)
     return AVS_OK;
 }
 
+avs_status avs_prepass_set_slab(avs_prepass *p, int32_t cut_axis, const int32_t *cuts, int32_t world, int32_t rank, avs_allreduce_i32_fn fn, void *user)
+{
+    AVS_REQUIRE(p, AVS_EINVAL, "null argument");
+    if (!cuts || world <= 1) { // off
+        p->slab = avs::SlabWindow{};
+        p->slab_fn = nullptr;
+        p->slab_user = nullptr;
+        p->slab_sig = 0;
+        return AVS_OK;
+    }
+    AVS_REQUIRE(cut_axis >= 0 && cut_axis < 3 && world <= avs::kMaxRanks && rank >= 0 && rank < world && fn, AVS_EINVAL,
+                "slab: axis in 0..2, 2 <= world <= %d, 0 <= rank < world and an all-reduce callback are required", avs::kMaxRanks);
+    const int extent = cut_axis == 0 ? p->desc.nx : (cut_axis == 1 ? p->desc.ny : p->desc.nz);
+    AVS_REQUIRE(cuts[0] == 0 && cuts[world] == extent, AVS_EINVAL, "slab: cuts must run from 0 to the axis' extent (%d)", extent);
+    for (int r = 0; r < world; ++r) AVS_REQUIRE(cuts[r] <= cuts[r + 1], AVS_EINVAL, "slab: cuts must ascend");
+    avs::SlabWindow w;
+    w.on = true;
+    w.axis = cut_axis;
+    w.world = world;
+    w.rank = rank;
+    uint64_t sig = 1469598103934665603ull; // FNV-1a over what defines the window
+    auto mix = [&](uint64_t v) { sig = (sig ^ v) * 1099511628211ull; };
+    mix((uint64_t)cut_axis); mix((uint64_t)world); mix((uint64_t)rank);
+    for (int r = 0; r <= world; ++r) { w.cuts[r] = cuts[r]; mix((uint64_t)(uint32_t)cuts[r]); }
+    p->slab = w;
+    p->slab_fn = fn;
+    p->slab_user = user;
+    p->slab_sig = sig | 1ull;
+    return AVS_OK;
+}
+
+avs_status avs_prepass_get_window(avs_prepass *p, int32_t *lo, int32_t *hi, int64_t *n_window)
+{
+    AVS_REQUIRE(p, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(p->ready, AVS_ESTATE, "call avs_prepass_run first");
+    for (int l = 0; l < AVS_MAX_LEVELS; ++l) {
+        const int nl = l < p->max_levels ? ((p->slab.axis == 0 ? p->desc.nx : (p->slab.axis == 1 ? p->desc.ny : p->desc.nz)) >> l) : 0;
+        if (lo) lo[l] = p->slab.on ? p->slab.win_lo[l] : 0;
+        if (hi) hi[l] = p->slab.on ? p->slab.win_hi[l] : nl;
+    }
+    if (n_window)
+        for (int k = 0; k < 3; ++k) n_window[k] = p->slab.on ? p->n_window[k] : p->counts[k];
+    return AVS_OK;
+}
+
 void avs_prepass_destroy(avs_prepass *p)
 {
     if (!p) return;
@@ -992,10 +1176,93 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         AVS_HIP(hipStreamSynchronize(st)); // tmp dies here
         return AVS_OK;
     };
-    AVS_TRY(take(p->liquid, liquid));
+    // slab-local mode reads the caller's device arrays in place (they are only read while this call runs): a copy of the whole SDF is
+    // a full-lattice pass every rank would pay for a window it does not need
+    const bool alias = p->slab.on && where == AVS_MEM_DEVICE && !padded;
+    if (alias) p->liq = liquid;
+    else {
+        AVS_TRY(take(p->liquid, liquid));
+        p->liq = p->liquid.p;
+    }
     p->have_solid = solid != nullptr;
-    if (solid) AVS_TRY(take(p->solid, solid));
+    p->sol = nullptr;
+    if (solid) {
+        if (alias) p->sol = solid;
+        else {
+            AVS_TRY(take(p->solid, solid));
+            p->sol = p->solid.p;
+        }
+    }
     if (where == AVS_MEM_HOST) AVS_HIP(hipStreamSynchronize(st));
+
+    // ---- slab-local mode: the window of every level along the cut axis, and what the octree passes must cover for it -------------
+    const int L = p->max_levels;
+    const bool slab = p->slab.on;
+    const int sa = p->slab.axis;
+    int win_lo[AVS_MAX_LEVELS] = {}, win_hi[AVS_MAX_LEVELS] = {}; // index window (level-l cells; multiples of 16 / the level's end)
+    int nl_lo[AVS_MAX_LEVELS] = {}, nl_hi[AVS_MAX_LEVELS] = {};   // labels the classification of the window reads
+    int v_lo[AVS_MAX_LEVELS] = {}, v_hi[AVS_MAX_LEVELS] = {};     // labels valid before the level serves as children
+    int p1_lo[AVS_MAX_LEVELS] = {}, p1_hi[AVS_MAX_LEVELS] = {};   // parents of pass 1 at level l (pass 2 / 3: v_lo .. v_hi)
+    {
+        const int na = sa == 0 ? d.nx : (sa == 1 ? d.ny : d.nz);
+        for (int l = 0; l < L; ++l) {
+            const int nl = na >> l;
+            if (!slab) { win_lo[l] = nl_lo[l] = v_lo[l] = p1_lo[l] = 0; win_hi[l] = nl_hi[l] = v_hi[l] = p1_hi[l] = nl; continue; }
+            const int s_lo = p->slab.cuts[p->slab.rank] >> l, s_hi = (p->slab.cuts[p->slab.rank + 1] + (1 << l) - 1) >> l;
+            int lo = s_lo - kSlabIndexMargin, hi = s_hi + kSlabIndexMargin;
+            lo = lo < 0 ? 0 : lo / kTile * kTile;
+            hi = (hi + kTile - 1) / kTile * kTile;
+            if (hi > nl) hi = nl;
+            win_lo[l] = lo; win_hi[l] = hi;
+            nl_lo[l] = lo - 2 < 0 ? 0 : lo - 2;
+            nl_hi[l] = hi + 2 > nl ? nl : hi + 2;
+        }
+        if (slab) {
+            v_lo[L - 1] = nl_lo[L - 1]; v_hi[L - 1] = nl_hi[L - 1];
+            for (int l = L - 2; l >= 0; --l) { // pass 2 of a parent reads the face neighbours of its children AFTER their own parents' pass 1
+                const int np = na >> (l + 1);
+                int a = v_lo[l + 1] - 1, b = v_hi[l + 1] + 1;
+                if (nl_lo[l] / 2 < a) a = nl_lo[l] / 2;
+                if ((nl_hi[l] + 1) / 2 > b) b = (nl_hi[l] + 1) / 2;
+                p1_lo[l + 1] = a < 0 ? 0 : a;
+                p1_hi[l + 1] = b > np ? np : b;
+                v_lo[l] = 2 * p1_lo[l + 1];
+                v_hi[l] = 2 * p1_hi[l + 1];
+            }
+            for (int l = 0; l < AVS_MAX_LEVELS; ++l) { p->slab.win_lo[l] = l < L ? win_lo[l] : 0; p->slab.win_hi[l] = l < L ? win_hi[l] : 0; }
+            if (p->state_sig != p->slab_sig) { // the records of what the allocations hold describe another window: void
+                for (int l = 0; l < AVS_MAX_LEVELS; ++l)
+                    for (int k = 0; k < 2; ++k) {
+                        p->cstate[l][k].id = 0;
+                        for (int a = 0; a < 3; ++a) p->vstate[l][a][k].id = p->estate[l][a][k].id = 0;
+                    }
+                for (int a = 0; a < 3; ++a)
+                    for (int k = 0; k < 2; ++k) p->rstate[a][k].id = 0;
+                for (int k = 0; k < 2; ++k) memset(p->wstate[k].ids, 0, sizeof(p->wstate[k].ids));
+                p->state_sig = p->slab_sig;
+            }
+        }
+    }
+    // entries [lo, hi) of a lattice with extents gr along the cut axis that the window covers / the tiles of a launch over them
+    auto win_box = [&](const int gr[3], int l) {
+        if (!slab) return full_box(gr);
+        return slab_box(gr, sa, win_lo[l], win_hi[l] >= ((sa == 0 ? d.nx : (sa == 1 ? d.ny : d.nz)) >> l) ? gr[sa] : win_hi[l]);
+    };
+    auto win_tiles = [&](const int gr[3], int l) {
+        TileGrid t = tile_grid(gr);
+        if (slab) {
+            const Box3 b = win_box(gr, l);
+            t.lo[sa] = b.lo[sa] / kTile;
+            t.bn[sa] = (b.lo[sa] + b.n[sa] + kTile - 1) / kTile - t.lo[sa];
+            if (b.n[sa] <= 0) t.bn[sa] = 0;
+        }
+        return t;
+    };
+    auto cell_box = [&](int l, int lo, int hi) {
+        int r[3];
+        pp_res(d, 2, l, 0, r);
+        return slab ? slab_box(r, sa, lo, hi) : full_box(r);
+    };
 
     // ---- P1 weights ------------------------------------------------------------------------
     PhaseScope phase;
@@ -1028,38 +1295,43 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     // ---- P2 + P3 octree --------------------------------------------------------------------
     phase.next("Build Octree"); // cpp:874 (+ "Build Mask for Octree", cpp:813)
     t.start();
-    const int L = p->max_levels;
     AVS_TRY(p->mask.alloc(n0));
     for (int l = 0; l < L; ++l) {
         int r[3];
         pp_res(d, 2, l, 0, r);
         AVS_TRY(p->labels[l].alloc(g3(r).vol()));
-        AVS_HIP(hipMemsetAsync(p->labels[l].p, 0, g3(r).vol(), st)); // INACTIVE, oct.cpp:59,69
+        if (!slab || l > 0) AVS_HIP(hipMemsetAsync(p->labels[l].p, 0, g3(r).vol(), st)); // INACTIVE, oct.cpp:59,69 (slab mode: level 0 is written wherever it is read)
     }
-    hipLaunchKernelGGL(k_mask_labels, dim3(grid_for(n0)), dim3(kBlock), 0, st, p->liquid.p, solid ? p->solid.p : nullptr, n0, d.dx,
-                       extrapolation, p->mask.p, p->labels[0].p, g3(r0), g3(s0));
+    {
+        const Box3 b0 = cell_box(0, v_lo[0], v_hi[0]);
+        hipLaunchKernelGGL(k_mask_labels, dim3(grid_for(b0.vol())), dim3(kBlock), 0, st, p->liq, p->sol, b0, d.dx,
+                           extrapolation, p->mask.p, p->labels[0].p, g3(r0), g3(s0));
+    }
     for (int l = 0; l < L - 1; ++l) {
         int r[3], rp[3];
         pp_res(d, 2, l, 0, r);
         pp_res(d, 2, l + 1, 0, rp);
-        const unsigned g = grid_for(g3(rp).vol());
-        hipLaunchKernelGGL(k_oct_pass1, dim3(g), dim3(kBlock), 0, st, p->labels[l].p, g3(r), p->labels[l + 1].p, g3(rp));
-        hipLaunchKernelGGL(k_oct_pass2, dim3(g), dim3(kBlock), 0, st, p->labels[l].p, g3(r), p->labels[l + 1].p, g3(rp));
-        hipLaunchKernelGGL(k_oct_pass3, dim3(g), dim3(kBlock), 0, st, p->labels[l].p, g3(r), p->labels[l + 1].p, g3(rp));
+        const Box3 b1 = cell_box(l + 1, p1_lo[l + 1], p1_hi[l + 1]), b2 = cell_box(l + 1, v_lo[l + 1], v_hi[l + 1]);
+        hipLaunchKernelGGL(k_oct_pass1, dim3(grid_for(b1.vol())), dim3(kBlock), 0, st, p->labels[l].p, g3(r), p->labels[l + 1].p, g3(rp), b1);
+        hipLaunchKernelGGL(k_oct_pass2, dim3(grid_for(b2.vol())), dim3(kBlock), 0, st, p->labels[l].p, g3(r), p->labels[l + 1].p, g3(rp), b2);
+        hipLaunchKernelGGL(k_oct_pass3, dim3(grid_for(b2.vol())), dim3(kBlock), 0, st, p->labels[l].p, g3(r), p->labels[l + 1].p, g3(rp), b2);
     }
     {
         int r[3];
         pp_res(d, 2, L - 1, 0, r);
-        hipLaunchKernelGGL(k_oct_top, dim3(grid_for(g3(r).vol())), dim3(kBlock), 0, st, p->labels[L - 1].p, g3(r).vol());
+        const Box3 bt = cell_box(L - 1, v_lo[L - 1], v_hi[L - 1]);
+        hipLaunchKernelGGL(k_oct_top, dim3(grid_for(bt.vol())), dim3(kBlock), 0, st, p->labels[L - 1].p, g3(r), bt);
     }
-    // cap at the first level without ACTIVE cells, oct.cpp:198-211
+    // cap at the first level without ACTIVE cells, oct.cpp:198-211 (slab mode: a property of the WHOLE octree -- the flags of the
+    // rank's part travel with the tile counts, the cap is known after the exchange; until then every level is classified)
     DevBuf<int> flags;
     AVS_TRY(flags.alloc(AVS_MAX_LEVELS));
     AVS_HIP(hipMemsetAsync(flags.p, 0, AVS_MAX_LEVELS * sizeof(int), st));
     for (int l = 0; l < L; ++l) {
         int r[3];
         pp_res(d, 2, l, 0, r);
-        hipLaunchKernelGGL(k_any_active, dim3(grid_for(g3(r).vol(), 4096)), dim3(kBlock), 0, st, p->labels[l].p, g3(r).vol(), flags.p + l);
+        const Box3 bl = cell_box(l, nl_lo[l], nl_hi[l]);
+        hipLaunchKernelGGL(k_any_active, dim3(grid_for(bl.vol(), 4096)), dim3(kBlock), 0, st, p->labels[l].p, g3(r), bl, flags.p + l);
     }
     AVS_HIP(hipGetLastError());
     int hflags[AVS_MAX_LEVELS] = {};
@@ -1067,6 +1339,7 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     AVS_HIP(hipStreamSynchronize(st));
     int capped = 0;
     while (capped < L && hflags[capped]) ++capped;
+    if (slab) capped = L; // (see above)
     p->levels = capped;
     p->ms[1] = t.stop();
     for (int k = 0; k < 4; ++k) p->counts[k] = 0;
@@ -1096,13 +1369,16 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
             for (int a = 0; a < 3; ++a) {
                 int gr[3];
                 pp_res(d, kind, l, a, gr);
-                T.tg[kind][a] = TileGrid{{(gr[0] + kTile - 1) / kTile, (gr[1] + kTile - 1) / kTile, (gr[2] + kTile - 1) / kTile}};
+                T.tg[kind][a] = win_tiles(gr, l);
                 T.occ[kind][a] = ob + (size_t)(kind * 3 + a) * occ_cap;
                 if (l == 0 && kind == 0) tg0[a] = T.tg[kind][a];
             }
         AVS_HIP(hipMemsetAsync(ob, 0, 7 * occ_cap, st));
-        hipLaunchKernelGGL(k_mark_tiles_all, dim3(grid_for(g3(cr).vol())), dim3(kBlock), 0, st, p->labels[l].p, l == 0 ? p->liquid.p : nullptr, occ_sdf,
-                           g3(cr), T);
+        {   // (slab mode: the cells whose faces / edges can lie in a tile of the window)
+            const Box3 mb = cell_box(l, win_lo[l] - 1, win_hi[l]);
+            hipLaunchKernelGGL(k_mark_tiles_all, dim3(grid_for(mb.vol())), dim3(kBlock), 0, st, p->labels[l].p, l == 0 ? p->liq : nullptr, occ_sdf,
+                               g3(cr), mb, T);
+        }
         for (int a = 0; a < 3; ++a) {
             for (int kind = 0; kind < 2; ++kind) {
                 int gr[3];
@@ -1120,12 +1396,13 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
                 A.lab = p->labels[l].p;
                 A.centerw = p->centerw.p;
                 for (int b = 0; b < 3; ++b) A.edgew[b] = p->edgew[b].p;
-                A.solid = solid ? p->solid.p : nullptr;
+                A.solid = p->sol;
                 // AVS_UNASSIGNED everywhere (a memset, or -- temporal reuse -- a reset of the tiles this allocation's last classification visited); occupied tiles are classified
                 avs_prepass::TileState *ts = nullptr;
-                AVS_TRY(unassign_lattice(p, buf, g3(gr), tg, occ_cap, kind == 0 ? p->vstate[l][a] : p->estate[l][a], &ts));
-                if (kind == 0) hipLaunchKernelGGL(k_classify_velocity, dim3((unsigned)tg.vol()), dim3(kBlock), 0, st, A, g3(gr), tg, oc, buf.p);
-                else hipLaunchKernelGGL(k_classify_edges, dim3((unsigned)tg.vol()), dim3(kBlock), 0, st, A, g3(gr), tg, oc, buf.p);
+                const Box3 wb = win_box(gr, l);
+                AVS_TRY(unassign_lattice(p, buf, g3(gr), tg, occ_cap, kind == 0 ? p->vstate[l][a] : p->estate[l][a], &ts, slab ? &wb : nullptr));
+                if (tg.launch() && kind == 0) hipLaunchKernelGGL(k_classify_velocity, dim3((unsigned)tg.launch()), dim3(kBlock), 0, st, A, g3(gr), tg, oc, buf.p);
+                else if (tg.launch()) hipLaunchKernelGGL(k_classify_edges, dim3((unsigned)tg.launch()), dim3(kBlock), 0, st, A, g3(gr), tg, oc, buf.p);
                 AVS_HIP(hipGetLastError());
                 AVS_TRY(remember_tiles(p, ts, buf.id, oc, occ_cap));
             }
@@ -1133,13 +1410,15 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         AVS_TRY(p->cidx[l].alloc(g3(cr).vol()));
         if (g3(cr).vol() > max_vol) max_vol = g3(cr).vol();
         {
-            const TileGrid tc{{(cr[0] + kTile - 1) / kTile, (cr[1] + kTile - 1) / kTile, (cr[2] + kTile - 1) / kTile}};
+            const TileGrid tc = win_tiles(cr, l);
             uint8_t *occ_c = ob + 6 * occ_cap;
             hipLaunchKernelGGL(k_center_tiles, dim3(grid_for(tc.vol())), dim3(kBlock), 0, st, (const uint8_t *)T.occ[1][0], T.tg[1][0], tc, occ_c);
             avs_prepass::TileState *ts = nullptr;
-            AVS_TRY(unassign_lattice(p, p->cidx[l], g3(cr), tc, occ_cap, p->cstate[l], &ts));
-            hipLaunchKernelGGL(k_classify_centers_tiled, dim3((unsigned)tc.vol()), dim3(kBlock), 0, st, p->labels[l].p, p->centerw.p, l, g3(cr), tc,
-                               (const uint8_t *)occ_c, p->cidx[l].p);
+            const Box3 wb = win_box(cr, l);
+            AVS_TRY(unassign_lattice(p, p->cidx[l], g3(cr), tc, occ_cap, p->cstate[l], &ts, slab ? &wb : nullptr));
+            if (tc.launch())
+                hipLaunchKernelGGL(k_classify_centers_tiled, dim3((unsigned)tc.launch()), dim3(kBlock), 0, st, p->labels[l].p, p->centerw.p, l, g3(cr), tc,
+                                   (const uint8_t *)occ_c, p->cidx[l].p);
             AVS_HIP(hipGetLastError());
             AVS_TRY(remember_tiles(p, ts, p->cidx[l].id, occ_c, occ_cap));
         }
@@ -1158,10 +1437,12 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         A.lab = p->labels[0].p;
         A.centerw = p->centerw.p;
         for (int b = 0; b < 3; ++b) A.edgew[b] = p->edgew[b].p;
-        A.solid = solid ? p->solid.p : nullptr;
+        A.solid = p->sol;
         avs_prepass::TileState *ts = nullptr;
-        AVS_TRY(unassign_lattice(p, p->ridx[a], g3(gr), tg, occ_cap, p->rstate[a], &ts));
-        hipLaunchKernelGGL(k_classify_regular, dim3((unsigned)tg.vol()), dim3(kBlock), 0, st, A, g3(gr), tg, (const uint8_t *)(occ_all.p + (size_t)a * occ_cap), p->ridx[a].p);
+        const Box3 wb = win_box(gr, 0);
+        AVS_TRY(unassign_lattice(p, p->ridx[a], g3(gr), tg, occ_cap, p->rstate[a], &ts, slab ? &wb : nullptr));
+        if (tg.launch())
+            hipLaunchKernelGGL(k_classify_regular, dim3((unsigned)tg.launch()), dim3(kBlock), 0, st, A, g3(gr), tg, (const uint8_t *)(occ_all.p + (size_t)a * occ_cap), p->ridx[a].p);
         AVS_HIP(hipGetLastError());
         AVS_TRY(remember_tiles(p, ts, p->ridx[a].id, occ_all.p + (size_t)a * occ_cap, occ_cap));
     }
@@ -1176,14 +1457,12 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     (void)max_vol;
     AVS_TRY(base.alloc(4));
     AVS_HIP(hipMemsetAsync(base.p, 0, 4 * sizeof(long long), st));
-    for (int k = 0; k < 3; ++k) { // dof tables: room for the previous frame's count + 25 % (a first run has no estimate: the context builds them)
-        p->dof_valid[k] = false;
-        p->dof_cap[k] = (p->temporal && p->prev_counts[k] > 0) ? p->prev_counts[k] + p->prev_counts[k] / 4 + 4096 : 0;
-        if (p->dof_cap[k] > 0) AVS_TRY(p->dof[k].alloc((size_t)p->dof_cap[k] * 4));
-    }
     // one batch per counter: velocity faces, edges, centres (each over all levels, in numbering order), regular-grid faces (cpp:1486-1509:
-    // one counter over the three axes)
+    // one counter over the three axes).  The four count arrays lie behind each other in ONE buffer (+ the levels' flags in slab mode: what
+    // the ranks sum), the scans run per counter.
     NumBatch host_batches[4] = {}; // (alive until the synchronisation behind the last batch: they are the sources of asynchronous copies)
+    int64_t seg[5] = {0, 0, 0, 0, 0};      // first count of every batch in the buffer (each batch: tiles + 1 entries)
+    int level_tile0[4][AVS_MAX_LEVELS + 1]; // first tile of every level inside a batch (counters 0 .. 2)
     for (int counter = 0; counter < 4; ++counter) {
         NumBatch &B = host_batches[counter];
         int64_t tiles = 0;
@@ -1200,13 +1479,16 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         };
         if (counter < 3) {
             const int kind = counter;
-            for (int l = 0; l < capped; ++l)
+            for (int l = 0; l < capped; ++l) {
+                level_tile0[counter][l] = (int)tiles;
                 for (int a = 0; a < (kind == 2 ? 1 : 3); ++a) {
                     int gr[3];
                     pp_res(d, kind, l, a, gr);
                     const uint8_t *oc = occ_all.p + ((size_t)l * 7 + (kind == 2 ? 6 : (size_t)kind * 3 + a)) * occ_cap; // (centres: the cell tiles with an ACTIVE cell, k_center_tiles)
                     add(kind == 0 ? p->vidx[l][a].p : (kind == 1 ? p->eidx[l][a].p : p->cidx[l].p), gr, oc, l | (a << 8));
                 }
+            }
+            level_tile0[counter][capped] = (int)tiles;
         } else {
             for (int a = 0; a < 3; ++a) {
                 int gr[3];
@@ -1216,24 +1498,97 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         }
         AVS_REQUIRE(tiles < (1ll << 31) - 1, AVS_EINVAL, "too many tiles");
         B.total_tiles = (int)tiles;
-        AVS_TRY(fl.reserve((size_t)tiles + 1));
-        AVS_TRY(ids.reserve((size_t)tiles + 1));
+        seg[counter + 1] = seg[counter] + tiles + 1;
+    }
+    const int64_t n_exchange = seg[4] + AVS_MAX_LEVELS;
+    AVS_REQUIRE(n_exchange < (1ll << 31) - 1, AVS_EINVAL, "too many tiles");
+    AVS_TRY(fl.reserve((size_t)n_exchange));
+    AVS_TRY(ids.reserve((size_t)seg[4]));
+    AVS_TRY(p->num_batches.alloc(4));
+    SlabOwn own{};
+    if (slab) {
+        own.on = 1; own.axis = sa; own.world = p->slab.world; own.rank = p->slab.rank;
+        for (int r = 0; r <= p->slab.world; ++r) own.cuts[r] = p->slab.cuts[r];
+    }
+    NumStarts S[4];
+    for (int counter = 0; counter < 4; ++counter) {
+        const NumBatch &B = host_batches[counter];
+        const int64_t tiles = B.total_tiles;
         AVS_TRY(scan_tmp.reserve(scan_tmp_elems(tiles + 1)));
-        AVS_TRY(p->num_batches.alloc(4));
         AVS_HIP(hipMemcpyAsync(p->num_batches.p + counter, &B, sizeof(NumBatch), hipMemcpyHostToDevice, st)); // (pageable source: staged before the call returns)
-        const NumBatch *Bd = p->num_batches.p + counter;
-        NumStarts S;
-        for (int k = 0; k < kNumLattices; ++k) S.tile0[k] = k < B.count ? B.lat[k].tile0 : INT_MAX;
-        hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)tiles), dim3(kBlock), 0, st, S, Bd, fl.p);
-        AVS_TRY(exclusive_scan_i32(fl.p, ids.p, tiles, scan_tmp.p, scan_tmp.n, st));
-        const bool tab = counter < 3 && p->dof_cap[counter] > 0;
-        hipLaunchKernelGGL(k_tile_ids, dim3((unsigned)tiles), dim3(kBlock), 0, st, S, Bd, (const int32_t *)ids.p, tab ? p->dof[counter].p : (int32_t *)nullptr,
-                           tab ? p->dof_cap[counter] : 0ll, base.p + counter, (int)tiles);
+        for (int k = 0; k < kNumLattices; ++k) S[counter].tile0[k] = k < B.count ? B.lat[k].tile0 : INT_MAX;
+        if (tiles) hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)tiles), dim3(kBlock), 0, st, S[counter], p->num_batches.p + counter, fl.p + seg[counter], own);
     }
     AVS_HIP(hipGetLastError());
+    int eff_tiles[4]; // tiles of the levels below the cap (slab mode: the cap is only known now)
+    for (int c = 0; c < 4; ++c) eff_tiles[c] = host_batches[c].total_tiles;
+    if (slab) { // ONE exchange: every tile's count from the rank that owns it, every level's "has an ACTIVE cell" from whoever saw one
+        AVS_HIP(hipMemcpyAsync(fl.p + seg[4], flags.p, AVS_MAX_LEVELS * sizeof(int), hipMemcpyDeviceToDevice, st));
+        const avs_status ex = p->slab_fn(fl.p, n_exchange, (void *)st, p->slab_user);
+        AVS_REQUIRE(ex == AVS_OK, ex, "the all-reduce callback of avs_prepass_set_slab failed (%d)", (int)ex);
+        AVS_HIP(hipMemcpyAsync(hflags, fl.p + seg[4], sizeof(hflags), hipMemcpyDeviceToHost, st));
+        AVS_HIP(hipStreamSynchronize(st));
+        capped = 0;
+        while (capped < L && hflags[capped]) ++capped;
+        p->levels = capped;
+        if (capped == 0) {
+            p->ms[3] = t.stop();
+            for (int k = 0; k < 3; ++k) p->n_window[k] = 0;
+            p->ready = true;
+            return AVS_OK;
+        }
+        for (int c = 0; c < 3; ++c) eff_tiles[c] = level_tile0[c][capped]; // (levels are the outer order of a batch: the capped ones are its tail)
+    }
+    for (int counter = 0; counter < 4; ++counter)
+        AVS_TRY(exclusive_scan_i32(fl.p + seg[counter], ids.p + seg[counter], eff_tiles[counter], scan_tmp.p, scan_tmp.n, st));
+    // dof tables: slab mode sizes them exactly (the totals are read first); else room for the previous frame's count + 25 % (a first
+    // run has no estimate: the context builds them)
     long long hb[4] = {0, 0, 0, 0};
-    AVS_HIP(hipMemcpyAsync(hb, base.p, sizeof(hb), hipMemcpyDeviceToHost, st));
-    AVS_HIP(hipStreamSynchronize(st));
+    if (slab) {
+        int32_t tot[4];
+        for (int c = 0; c < 4; ++c) AVS_HIP(hipMemcpyAsync(&tot[c], ids.p + seg[c] + eff_tiles[c], sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        AVS_HIP(hipStreamSynchronize(st));
+        for (int c = 0; c < 4; ++c) {
+            AVS_REQUIRE(tot[c] >= 0, AVS_EINVAL, "DOF count exceeds int32");
+            hb[c] = tot[c];
+        }
+    }
+    for (int k = 0; k < 3; ++k) {
+        p->dof_valid[k] = false;
+        if (slab) p->dof_cap[k] = hb[k] > 0 ? hb[k] : 1;
+        else p->dof_cap[k] = (p->temporal && p->prev_counts[k] > 0) ? p->prev_counts[k] + p->prev_counts[k] / 4 + 4096 : 0;
+        if (p->dof_cap[k] > 0) AVS_TRY(p->dof[k].alloc((size_t)p->dof_cap[k] * 4));
+        if (slab) AVS_HIP(hipMemsetAsync(p->dof[k].p, 0xFF, (size_t)p->dof_cap[k] * 4 * sizeof(int32_t), st)); // entries outside the window stay recognisably void
+    }
+    for (int counter = 0; counter < 4; ++counter) {
+        const bool tab = counter < 3 && p->dof_cap[counter] > 0;
+        if (eff_tiles[counter])
+            hipLaunchKernelGGL(k_tile_ids, dim3((unsigned)eff_tiles[counter]), dim3(kBlock), 0, st, S[counter], p->num_batches.p + counter,
+                               (const int32_t *)(ids.p + seg[counter]), tab ? p->dof[counter].p : (int32_t *)nullptr,
+                               tab ? p->dof_cap[counter] : 0ll, base.p + counter, eff_tiles[counter]);
+    }
+    AVS_HIP(hipGetLastError());
+    if (slab) { // the window's DOFs of every kind, ascending: the tiles this rank classified, each a run of consecutive ids
+        DevBuf<int32_t> wcnt, woff;
+        for (int k = 0; k < 3; ++k) {
+            const int tiles = eff_tiles[k];
+            AVS_TRY(wcnt.alloc((size_t)tiles + 1));
+            AVS_TRY(woff.alloc((size_t)tiles + 1));
+            hipLaunchKernelGGL(k_win_counts, dim3(grid_for((size_t)tiles)), dim3(kBlock), 0, st, S[k], p->num_batches.p + k, (const int32_t *)(ids.p + seg[k]), tiles, wcnt.p);
+            AVS_TRY(exclusive_scan_i32(wcnt.p, woff.p, tiles, scan_tmp.p, scan_tmp.n, st));
+            int32_t nw = 0;
+            AVS_HIP(hipMemcpyAsync(&nw, woff.p + tiles, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            AVS_HIP(hipStreamSynchronize(st));
+            p->n_window[k] = nw;
+            AVS_TRY(p->wlist[k].alloc((size_t)(nw > 0 ? nw : 1)));
+            if (tiles && nw) hipLaunchKernelGGL(k_win_fill, dim3((unsigned)tiles), dim3(kBlock), 0, st, (const int32_t *)(ids.p + seg[k]), (const int32_t *)wcnt.p, (const int32_t *)woff.p, p->wlist[k].p);
+            AVS_HIP(hipGetLastError());
+            AVS_HIP(hipStreamSynchronize(st)); // wcnt / woff are reused
+        }
+    } else {
+        AVS_HIP(hipMemcpyAsync(hb, base.p, sizeof(hb), hipMemcpyDeviceToHost, st));
+        AVS_HIP(hipStreamSynchronize(st));
+    }
     for (int k = 0; k < 4; ++k) p->counts[k] = hb[k];
     for (int k = 0; k < 3; ++k) {
         p->dof_valid[k] = p->dof_cap[k] > 0 && hb[k] <= p->dof_cap[k];
@@ -1359,6 +1714,13 @@ avs_status avs_prepass_apply(avs_prepass *p, avs_ctx *ctx)
         loan.ridx[a] = p->ridx[a].handle();
     }
     for (int k = 0; k < 3; ++k) loan.counts[k] = p->counts[k];
+    if (p->slab.on) {
+        loan.slab = p->slab;
+        for (int k = 0; k < 3; ++k) {
+            loan.wlist[k] = p->wlist[k].handle();
+            loan.n_window[k] = p->n_window[k];
+        }
+    }
     if (p->dof_valid[0] && p->dof_valid[1] && p->dof_valid[2])
         for (int k = 0; k < 3; ++k) loan.dof[k] = p->dof[k].handle();
     for (int a = 0; a < 3; ++a) // the occupancy each regular-grid lattice was classified with: the context flags its transfer tiles without reading the rest

@@ -217,6 +217,22 @@ class ViscositySolve:
             self._hosted_connect()
         return info
 
+    def dist_bind_prepass(self, prepass, cuts, cut_axis=-1):
+        """The pre-pass object's next runs are slab-local: this rank's window of the lattices only, global ids through one all-reduce of
+        per-tile counts over this context's group (avs_dist_bind_prepass).  cuts: world + 1 fine-cell coordinates, or None (off)."""
+        if cuts is None:
+            capi.check(self.lib.avs_dist_bind_prepass(self.h, prepass.h, cut_axis, None))
+            return
+        c = np.ascontiguousarray(cuts, np.int32)
+        capi.check(self.lib.avs_dist_bind_prepass(self.h, prepass.h, cut_axis, c.ctypes.data))
+
+    def dist_cuts(self, world, which=0):
+        """(cut_axis, cuts[world + 1]) of the last avs_dist_assemble (which = 0) / what its weights suggest for the next frame (1)."""
+        cuts = np.empty(world + 1, np.int32)
+        ax = C.c_int32()
+        capi.check(self.lib.avs_dist_get_cuts(self.h, which, C.byref(ax), cuts.ctypes.data))
+        return ax.value, cuts
+
     def dist_solve(self, tol=1e-3, max_iters=2500):
         info = capi.SolveInfo()
         capi.check(self.lib.avs_dist_solve(self.h, float(tol), int(max_iters), C.byref(info)))
@@ -427,6 +443,33 @@ class DevicePrepass:
         capi.check(self.lib.avs_prepass_get_info(self.h, C.byref(info)))
         self.info = info
         return info
+
+    def set_slab(self, cut_axis, cuts, rank, allreduce):
+        """Slab-local mode with the caller's own all-reduce (a hosted group): allreduce(device_pointer, count, stream) sums `count` int32
+        in place over all ranks and returns when the result is there.  cuts None: off."""
+        if cuts is None:
+            self._slab_cb = None
+            capi.check(self.lib.avs_prepass_set_slab(self.h, 0, None, 1, 0, capi.ALLREDUCE_I32_FN(0), None))
+            return
+
+        def cb(ptr, count, stream, user):
+            try:
+                allreduce(ptr, count, stream)
+                return 0
+            except Exception:  # pragma: no cover
+                return capi.EINTERNAL if hasattr(capi, "EINTERNAL") else 7
+        self._slab_cb = capi.ALLREDUCE_I32_FN(cb)   # (kept alive with the object)
+        c = np.ascontiguousarray(cuts, np.int32)
+        capi.check(self.lib.avs_prepass_set_slab(self.h, int(cut_axis), c.ctypes.data, len(c) - 1, int(rank), self._slab_cb, None))
+
+    def window(self):
+        """(lo[levels], hi[levels], (n_velocity, n_edge, n_center) inside the window) of the last run."""
+        lo = np.zeros(8, np.int32)
+        hi = np.zeros(8, np.int32)
+        nw = np.zeros(3, np.int64)
+        capi.check(self.lib.avs_prepass_get_window(self.h, lo.ctypes.data, hi.ctypes.data, nw.ctypes.data))
+        L = self.info.levels if self.info is not None else 8
+        return lo[:L], hi[:L], tuple(int(v) for v in nw)
 
     def apply(self, solver):
         capi.check(self.lib.avs_prepass_apply(self.h, solver.h))

@@ -321,6 +321,21 @@ typedef struct {
     double weights_ms, octree_ms, classify_ms, number_ms;
 } avs_prepass_info;
 avs_status avs_prepass_create(const avs_prepass_desc *desc, avs_prepass **out);
+/* Slab-local pre-pass (round 6; SURVEY 8(e): "each GPU assembles the rows it owns from its slab of the pyramids plus a halo").  The
+ * reference's loops are row-local (classification / numbering cpp:1087-1715, octree oct.cpp:395-565), so a rank of a partitioned solve
+ * needs them on its slab only.  cuts[0 .. world]: fine-cell coordinates along cut_axis, cuts[0] = 0, cuts[world] = the axis' extent,
+ * ascending; rank r owns the faces whose position lies in [cuts[r], cuts[r + 1]).  avs_prepass_run then computes weights, mask, labels,
+ * classification and ids only inside the rank's WINDOW: at level l the slab +- 12 level-l cells, rounded out to whole 16-entry tiles
+ * (labels on as much more as the coarser levels' windows depend on).  The ids are the reference's GLOBAL ids (cpp:1566-1593 numbers tile
+ * after tile through the whole lattice): every tile is counted by the rank that owns its first plane, `allreduce` sums the per-tile counts
+ * of all ranks (ONE call per run, a few MB of int32 on the device, in place, enqueued on / synchronised with `stream`), and every rank scans
+ * the same array.  The levels cap (oct.cpp:198-211) rides in the same buffer.  Everything inside the window is bit-identical to the
+ * single-rank pre-pass; lattice entries outside it are unspecified.  world == 1 or cuts == NULL switches the mode off. */
+typedef avs_status (*avs_allreduce_i32_fn)(int32_t *device_data, int64_t count, void *stream, void *user);
+avs_status avs_prepass_set_slab(avs_prepass *pp, int32_t cut_axis, const int32_t *cuts, int32_t world_size, int32_t rank,
+                                avs_allreduce_i32_fn allreduce, void *user);
+/* the window of the last run along the cut axis: entries [lo[l], hi[l]) of the level-l lattices (hi == the level's cell count: to the end) */
+avs_status avs_prepass_get_window(avs_prepass *pp, int32_t *lo, int32_t *hi /* AVS_MAX_LEVELS each */, int64_t *n_window /* 3: velocity, edge, centre DOFs inside it */);
 void avs_prepass_destroy(avs_prepass *pp);
 avs_status avs_prepass_run(avs_prepass *pp, const float *liquid_sdf, const float *solid_sdf /* NULL: none */, avs_memspace where);
 avs_status avs_prepass_get_info(avs_prepass *pp, avs_prepass_info *info);
@@ -413,6 +428,20 @@ avs_status avs_dist_partition(avs_ctx *ctx, int32_t cut_axis);
  * global matrix exists afterwards: avs_get_csr / avs_solve are unavailable, avs_dist_solve / avs_dist_get_solution work
  * as after avs_dist_partition.  info->nnz is the LOCAL non-zero count. */
 avs_status avs_dist_assemble(avs_ctx *ctx, int32_t cut_axis, avs_assembly_info *info /* may be NULL */);
+/* Slab-local path (round 6): the pre-pass of THIS rank's window + the assembly of its rows, nothing swept over the whole octree.
+ *   avs_dist_bind_prepass(ctx, pp, cut_axis, cuts)   pp's next runs are slab-local (avs_prepass_set_slab with this rank, this group's
+ *                                                     all-reduce -- RCCL or the in-process group; a hosted group passes its own callback
+ *                                                     to avs_prepass_set_slab instead); cuts == NULL switches it off
+ *   avs_prepass_run(pp, ...) ; avs_prepass_apply(pp, ctx) ; avs_dist_assemble(ctx, ...)      on every rank, collectively
+ * The cuts must exist BEFORE anything is counted: take them from the previous frame -- avs_dist_get_cuts(ctx, 1, ...) returns the
+ * cuts the last assembly's per-plane weights (summed over the ranks) suggest for the next one, which = 0 the cuts it used -- or start
+ * from equal slabs.  avs_dist_assemble on such a context builds stencils for the stresses within 4 cells (of their level) of the
+ * slab, the rank's rows (bit-identical to the reference's rows), halo and send lists; for the same cuts every array equals what the
+ * replicated-index avs_dist_assemble produces.  Three lookup arrays indexed by DOF id (6 B per DOF, filled by memset) are the only
+ * global-sized work.  Entries that need the whole pyramid (avs_assemble, avs_dist_partition, the post-solve transfer) report
+ * AVS_ESTATE on a slab-local context. */
+avs_status avs_dist_bind_prepass(avs_ctx *ctx, avs_prepass *pp, int32_t cut_axis, const int32_t *cuts /* world_size + 1, or NULL */);
+avs_status avs_dist_get_cuts(avs_ctx *ctx, int32_t which, int32_t *cut_axis /* may be NULL */, int32_t *cuts /* world_size + 1 */);
 avs_status avs_dist_get_plan_sizes(avs_ctx *ctx, avs_plan_sizes *sizes);
 /* rows per SpMV tile (workgroup) of the solver's default kernel */
 int32_t avs_spmv_tile_rows(void);
