@@ -131,6 +131,7 @@ Options options_from_env()
     o.dist_selftest_rounds = env_int("AVS_DIST_SELFTEST_ROUNDS", 64);
     o.dist_split_rows = env_int("AVS_DIST_SPLIT_ROWS", 1) != 0;
     o.dist_plane_shift = env_int("AVS_DIST_PLANE_SHIFT", -1);
+    o.trace_phases = env_int("AVS_TRACE_PHASES", 0);
     if (const char *e = getenv("AVS_DIST_TIMEOUT_MS")) o.dist_timeout_ms = atoll(e) > 0 ? atoll(e) : 0;
     return o;
 }

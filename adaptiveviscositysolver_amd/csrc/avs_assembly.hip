@@ -1263,8 +1263,9 @@ avs_status assemble_rows(avs_ctx *c, const int32_t *ids, int64_t m, DevBuf<int32
     AVS_TRY(rawptr.reserve((size_t)n + 1));
     AVS_TRY(scan_tmp.reserve(scan_tmp_elems(n)));
     AVS_TRY(err.reserve(1));
-    AVS_TRY(rhs.alloc((size_t)n));
-    AVS_TRY(row_ptr.alloc((size_t)n + 1));
+    // (reserve, not alloc: the sizes change from frame to frame, and a hipFree + hipMalloc of the 100-MB arrays costs more than the rows)
+    AVS_TRY(rhs.reserve((size_t)n));
+    AVS_TRY(row_ptr.reserve((size_t)n + 1));
     AVS_HIP(hipMemsetAsync(err.p, 0, sizeof(int), st));
     PyramidView P = c->view();
     StencilView E = edge_view(c), C = center_view(c);
@@ -1304,8 +1305,8 @@ avs_status assemble_rows(avs_ctx *c, const int32_t *ids, int64_t m, DevBuf<int32
     AVS_REQUIRE(e == 0, AVS_EINTERNAL, "row assembly hit a reference assert (code %d): stencils and index pyramids disagree", e);
     AVS_REQUIRE(nnz >= 0, AVS_EINVAL, "non-zero count exceeds int32");
     if (nnz_out) *nnz_out = nnz;
-    AVS_TRY(col.alloc((size_t)nnz));
-    AVS_TRY(val.alloc((size_t)nnz));
+    AVS_TRY(col.reserve((size_t)nnz));
+    AVS_TRY(val.reserve((size_t)nnz));
     // K6b + K7: rank, fold, write the final CSR
     if (n && c->desc.precision == AVS_PRECISION_F32)
         hipLaunchKernelGGL(k_merge_rows<true>, dim3(grid_for(n)), dim3(kBlock), 0, st, n, (const int32_t *)rawptr.p, (const int32_t *)raw_col.p,

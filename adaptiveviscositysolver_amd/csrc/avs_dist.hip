@@ -83,6 +83,21 @@ struct PcgDist {
     // for the next frame (slab-local assembly: the pre-pass needs the cuts BEFORE anything is counted)
     std::vector<int32_t> cuts, next_cuts;
     int cut_axis = 0;
+    // the second set of the local arrays the [interior | halo-reading] row order is written to (swapped in; kept across frames: the
+    // allocation of 170 MB of columns and values cost 3.6 ms of a 9-ms slab assembly, 19 ms the first time)
+    // work arrays of the assembly (flags, scans, lookups, sort keys ...), kept across frames: twenty hipMalloc / hipFree pairs per
+    // assembly were 2 ms of a 7-ms slab assembly
+    struct Scratch {
+        DevBuf<uint32_t> keys_in, keys_out, needed_by, pm;
+        DevBuf<int32_t> dom, flag, pos, g2l, scan_tmp, ids, halo_tmp, tile_bnd, tile_int, tile_pos, w32;
+        DevBuf<uint8_t> owner, is_halo;
+        DevBuf<char> sort_tmp;
+        DevBuf<int> mark_err;
+        DevBuf<unsigned long long> weight;
+    } ws;
+    DevBuf<int32_t> alt_row_ptr, alt_col, alt_own, alt_ids, alt_new_of, alt_len;
+    DevBuf<double> alt_val, alt_rhs;
+    DevBuf<uint32_t> alt_nb;
 
     // direct transport (peer-mapped comm blocks), see avs_internal.hpp
     int transport = AVS_TRANSPORT_RCCL;
@@ -1116,6 +1131,16 @@ __global__ __launch_bounds__(256) void k_da_halo_ref(int64_t n, const int32_t *_
     if (l >= n_own) local_ref[l] = perm ? perm[g] : g;
 }
 
+// the ranks this rank exchanges with: the union of the rows' needed_by bits (the pattern is symmetric: whom I read from reads from me)
+__global__ __launch_bounds__(256) void k_da_peer_mask(int64_t n_own, const uint32_t *__restrict__ needed_by, uint32_t *__restrict__ mask)
+{
+    uint32_t m = 0u;
+    for (int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x; l < n_own; l += (int64_t)gridDim.x * 256) m |= needed_by[l];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m |= __shfl_xor(m, o, 64);
+    if ((threadIdx.x & 63) == 0 && m) atomicOr(mask, m);
+}
+
 __global__ __launch_bounds__(256) void k_da_flag_send(int64_t n_own, const uint32_t *__restrict__ needed_by, int q, int32_t *__restrict__ f)
 {
     const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1225,25 +1250,35 @@ static avs_status dist_assemble_tail(avs_ctx *c, PcgDist *d, DevBuf<int32_t> &id
     hipStream_t st = c->stream;
     const int rank = d->rank, world = d->world;
     const int64_t n = n_dom;
-    DevBuf<int32_t> halo_tmp;
-    DevBuf<uint32_t> needed_by;
-    DevBuf<int> mark_err;
-    AVS_TRY(mark_err.alloc(1));
+    DevBuf<int32_t> &halo_tmp = d->ws.halo_tmp;
+    DevBuf<uint32_t> &needed_by = d->ws.needed_by;
+    DevBuf<int> &mark_err = d->ws.mark_err;
+    AVS_TRY(mark_err.reserve(1));
     AVS_HIP(hipMemsetAsync(mark_err.p, 0, sizeof(int), st));
+    PhaseTrace tr(st, "tail", cur_opt().trace_phases != 0);
     // restriction (warm start, also the mass term of the right-hand side) and rows of this rank only;
     // columns still in the reference numbering
     AVS_TRY(build_initial_guess_rows(c, ids.p, n_own));
+    tr.mark("initial guess rows");
     int64_t nnz_local = 0;
     AVS_TRY(assemble_rows(c, ids.p, n_own, d->row_ptr, d->col, d->val, d->rhs, &nnz_local, nullptr));
-    AVS_TRY(needed_by.alloc((size_t)n_own));
+    tr.mark("assemble_rows");
+    AVS_TRY(needed_by.reserve((size_t)n_own));
     if (n_own) hipLaunchKernelGGL(k_da_mark, dim3(8192), dim3(256), 0, st, n_own, d->row_ptr.p, d->col.p, inv, owner.p, rank, is_halo.p,
                                   needed_by.p, mark_err.p);
+    uint32_t peer_mask = 0u; // (a slab talks to its neighbours: the per-rank scans below run for them only -- each is a scan + a host round trip)
     {
+        DevBuf<uint32_t> &pm = d->ws.pm;
+        AVS_TRY(pm.reserve(1));
+        AVS_HIP(hipMemsetAsync(pm.p, 0, sizeof(uint32_t), st));
+        if (n_own) hipLaunchKernelGGL(k_da_peer_mask, dim3(1024), dim3(256), 0, st, n_own, (const uint32_t *)needed_by.p, pm.p);
         int e = 0;
         AVS_HIP(hipMemcpyAsync(&e, mark_err.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        AVS_HIP(hipMemcpyAsync(&peer_mask, pm.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         AVS_HIP(hipStreamSynchronize(st));
         AVS_REQUIRE(e == 0, AVS_EINTERNAL, "slab-local assembly: a row reads a column outside the rank's window (index margin too small)");
     }
+    tr.mark("mark columns");
     bool split = world > 1;
     split = split && cur_opt().dist_split_rows != 0;
     // A slab the brick-structured form will serve keeps the plain ascending (brick-major) row order: its tiles are whole bricks, and the
@@ -1251,18 +1286,18 @@ static avs_status dist_assemble_tail(avs_ctx *c, PcgDist *d, DevBuf<int32_t> &id
     // [interior | halo-reading] split every brick next to a cut would fall into two part-filled tiles.
     if (dist_brick_wanted(c, n_own)) split = false;
     if (split && n_own) { // [interior | halo-reading] local row order (see k_da_new_index)
-        DevBuf<int32_t> new_of, len_new, rp2, col2, own2, ids2;
-        DevBuf<double> val2, rhs2;
-        DevBuf<uint32_t> nb2;
-        AVS_TRY(new_of.alloc((size_t)n_own));
-        AVS_TRY(len_new.alloc((size_t)n_own + 1));
-        AVS_TRY(rp2.alloc((size_t)n_own + 1));
-        AVS_TRY(col2.alloc((size_t)nnz_local));
-        AVS_TRY(val2.alloc((size_t)nnz_local));
-        AVS_TRY(own2.alloc((size_t)n_own));
-        AVS_TRY(ids2.alloc((size_t)n_own));
-        AVS_TRY(rhs2.alloc((size_t)n_own));
-        AVS_TRY(nb2.alloc((size_t)n_own));
+        DevBuf<int32_t> &new_of = d->alt_new_of, &len_new = d->alt_len, &rp2 = d->alt_row_ptr, &col2 = d->alt_col, &own2 = d->alt_own, &ids2 = d->alt_ids;
+        DevBuf<double> &val2 = d->alt_val, &rhs2 = d->alt_rhs;
+        DevBuf<uint32_t> &nb2 = d->alt_nb;
+        AVS_TRY(new_of.reserve((size_t)n_own));
+        AVS_TRY(len_new.reserve((size_t)n_own + 1));
+        AVS_TRY(rp2.reserve((size_t)n_own + 1));
+        AVS_TRY(col2.reserve((size_t)nnz_local));
+        AVS_TRY(val2.reserve((size_t)nnz_local));
+        AVS_TRY(own2.reserve((size_t)n_own));
+        AVS_TRY(ids2.reserve((size_t)n_own));
+        AVS_TRY(rhs2.reserve((size_t)n_own));
+        AVS_TRY(nb2.reserve((size_t)n_own));
         hipLaunchKernelGGL(k_da_flag_send, dim3(grid256(n_own)), dim3(256), 0, st, n_own, (const uint32_t *)needed_by.p, -1, flag.p); // q = -1: "reads nobody"
         int64_t n_interior = 0;
         AVS_TRY(scan_flags(flag.p, pos.p, n_own, scan_tmp, &n_interior, st));
@@ -1289,12 +1324,13 @@ static avs_status dist_assemble_tail(avs_ctx *c, PcgDist *d, DevBuf<int32_t> &id
         std::swap(needed_by.p, nb2.p); std::swap(needed_by.n, nb2.n);
     }
 
+    tr.mark("row order split");
     // halo numbering (grouped by owner, ascending) and send lists (ascending owned rows that read a DOF of q)
     std::vector<int64_t> recv_cnt((size_t)world, 0), send_cnt((size_t)world, 0);
-    AVS_TRY(halo_tmp.alloc((size_t)(n > 0 ? n : 1)));
+    AVS_TRY(halo_tmp.reserve((size_t)(n > 0 ? n : 1)));
     int64_t n_halo = 0, n_send = 0;
     for (int q = 0; q < world; ++q) {
-        if (q == rank) continue;
+        if (q == rank || !((peer_mask >> q) & 1u)) continue;
         hipLaunchKernelGGL(k_plan_flag_halo, dim3(grid256(n)), dim3(256), 0, st, n, is_halo.p, owner.p, q, flag.p, dom);
         AVS_TRY(scan_flags(flag.p, pos.p, n, scan_tmp, &recv_cnt[(size_t)q], st));
         if (recv_cnt[(size_t)q])
@@ -1303,13 +1339,13 @@ static avs_status dist_assemble_tail(avs_ctx *c, PcgDist *d, DevBuf<int32_t> &id
         n_halo += recv_cnt[(size_t)q];
     }
     for (int q = 0; q < world; ++q) {
-        if (q == rank || !n_own) continue;
+        if (q == rank || !n_own || !((peer_mask >> q) & 1u)) continue;
         hipLaunchKernelGGL(k_da_flag_send, dim3(grid256(n_own)), dim3(256), 0, st, n_own, needed_by.p, q, flag.p);
         AVS_TRY(scan_flags(flag.p, pos.p, n_own, scan_tmp, &send_cnt[(size_t)q], st));
         n_send += send_cnt[(size_t)q];
     }
-    AVS_TRY(d->send_idx.alloc((size_t)n_send));
-    AVS_TRY(d->sendbuf.alloc((size_t)n_send));
+    AVS_TRY(d->send_idx.reserve((size_t)n_send));
+    AVS_TRY(d->sendbuf.reserve((size_t)n_send));
     {
         int64_t off = 0;
         for (int q = 0; q < world; ++q) {
@@ -1331,38 +1367,40 @@ static avs_status dist_assemble_tail(avs_ctx *c, PcgDist *d, DevBuf<int32_t> &id
             d->recv_counts.push_back((int32_t)recv_cnt[(size_t)q]);
         }
 
+    tr.mark("halo + send lists");
     // local column ids + tile lists
     const int T = spmv_tile_rows();
     const int64_t ntiles = (n_own + T - 1) / T;
-    DevBuf<int32_t> tile_bnd, tile_int, tile_pos;
-    AVS_TRY(tile_bnd.alloc((size_t)ntiles + 1));
-    AVS_TRY(tile_int.alloc((size_t)ntiles + 1));
-    AVS_TRY(tile_pos.alloc((size_t)ntiles + 1));
+    DevBuf<int32_t> &tile_bnd = d->ws.tile_bnd, &tile_int = d->ws.tile_int, &tile_pos = d->ws.tile_pos;
+    AVS_TRY(tile_bnd.reserve((size_t)ntiles + 1));
+    AVS_TRY(tile_int.reserve((size_t)ntiles + 1));
+    AVS_TRY(tile_pos.reserve((size_t)ntiles + 1));
     AVS_HIP(hipMemsetAsync(tile_bnd.p, 0, ((size_t)ntiles + 1) * 4, st));
     if (n_own) hipLaunchKernelGGL(k_da_localize, dim3(8192), dim3(256), 0, st, n_own, d->row_ptr.p, d->col.p, g2l.p, T, tile_bnd.p);
     int64_t n_bnd = 0, n_int = 0;
     AVS_TRY(scan_flags(tile_bnd.p, tile_pos.p, ntiles, scan_tmp, &n_bnd, st));
-    AVS_TRY(d->tiles_bnd.alloc((size_t)n_bnd));
+    AVS_TRY(d->tiles_bnd.reserve((size_t)n_bnd));
     if (n_bnd)
         hipLaunchKernelGGL(k_plan_scatter, dim3(grid256(ntiles)), dim3(256), 0, st, ntiles, tile_bnd.p, tile_pos.p, (const int32_t *)nullptr,
                            d->tiles_bnd.p, (int32_t *)nullptr, 0);
     if (ntiles) hipLaunchKernelGGL(k_plan_not, dim3(grid256(ntiles)), dim3(256), 0, st, ntiles, tile_bnd.p, tile_int.p);
     AVS_TRY(scan_flags(tile_int.p, tile_pos.p, ntiles, scan_tmp, &n_int, st));
-    AVS_TRY(d->tiles_int.alloc((size_t)n_int));
+    AVS_TRY(d->tiles_int.reserve((size_t)n_int));
     if (n_int)
         hipLaunchKernelGGL(k_plan_scatter, dim3(grid256(ntiles)), dim3(256), 0, st, ntiles, tile_int.p, tile_pos.p, (const int32_t *)nullptr,
                            d->tiles_int.p, (int32_t *)nullptr, 0);
 
     // reference ids behind the local columns (owned: the assembled rows' DOFs; halo: through the brick-major permutation)
-    AVS_TRY(d->local_ref.alloc((size_t)(n_own + n_halo)));
+    AVS_TRY(d->local_ref.reserve((size_t)(n_own + n_halo)));
     if (n_own) AVS_HIP(hipMemcpyAsync(d->local_ref.p, ids.p, (size_t)n_own * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     if (n_halo) hipLaunchKernelGGL(k_da_halo_ref, dim3(grid256(n)), dim3(256), 0, st, n, (const int32_t *)g2l.p, perm, n_own, d->local_ref.p, dom);
     // warm start of the owned DOFs
-    AVS_TRY(d->x0.alloc((size_t)n_own));
-    AVS_TRY(d->x.alloc((size_t)n_own));
+    AVS_TRY(d->x0.reserve((size_t)n_own));
+    AVS_TRY(d->x.reserve((size_t)n_own));
     if (n_own) hipLaunchKernelGGL(k_gather_i<double>, dim3(grid256(n_own)), dim3(256), 0, st, c->x0.p, ids.p, d->x0.p, n_own);
     AVS_HIP(hipGetLastError());
     AVS_HIP(hipStreamSynchronize(st)); // temporaries die here
+    tr.mark("localize, tiles, x0");
     d->n_tiles_int = (int)n_int;
     d->n_tiles_bnd = (int)n_bnd;
     d->n_own = n_own;
@@ -1465,24 +1503,26 @@ static avs_status dist_assemble_window(avs_ctx *c, PcgDist *d)
     const int extent = axis == 0 ? c->desc.nx : (axis == 1 ? c->desc.ny : c->desc.nz);
     d->cuts.assign(W.cuts, W.cuts + world + 1);
     d->cut_axis = axis;
+    PhaseTrace tr(st, "window", cur_opt().trace_phases != 0);
 
     // the window's velocity DOFs in brick-major order
-    DevBuf<uint32_t> keys_in, keys_out;
-    DevBuf<int32_t> dom, flag, pos, g2l, scan_tmp, ids;
-    DevBuf<uint8_t> owner, is_halo;
-    DevBuf<char> sort_tmp;
-    AVS_TRY(keys_in.alloc((size_t)(n_w > 0 ? n_w : 1)));
-    AVS_TRY(keys_out.alloc((size_t)(n_w > 0 ? n_w : 1)));
-    AVS_TRY(dom.alloc((size_t)(n_w > 0 ? n_w : 1)));
-    AVS_TRY(flag.alloc((size_t)n_w + 1));
-    AVS_TRY(pos.alloc((size_t)n_w + 1));
-    AVS_TRY(scan_tmp.alloc(scan_tmp_elems(n_w + 1)));
-    AVS_TRY(g2l.alloc((size_t)(n > 0 ? n : 1)));
-    AVS_TRY(owner.alloc((size_t)(n > 0 ? n : 1)));
-    AVS_TRY(is_halo.alloc((size_t)(n > 0 ? n : 1)));
+    DevBuf<uint32_t> &keys_in = d->ws.keys_in, &keys_out = d->ws.keys_out;
+    DevBuf<int32_t> &dom = d->ws.dom, &flag = d->ws.flag, &pos = d->ws.pos, &g2l = d->ws.g2l, &scan_tmp = d->ws.scan_tmp, &ids = d->ws.ids;
+    DevBuf<uint8_t> &owner = d->ws.owner, &is_halo = d->ws.is_halo;
+    DevBuf<char> &sort_tmp = d->ws.sort_tmp;
+    AVS_TRY(keys_in.reserve((size_t)(n_w > 0 ? n_w : 1)));
+    AVS_TRY(keys_out.reserve((size_t)(n_w > 0 ? n_w : 1)));
+    AVS_TRY(dom.reserve((size_t)(n_w > 0 ? n_w : 1)));
+    AVS_TRY(flag.reserve((size_t)n_w + 1));
+    AVS_TRY(pos.reserve((size_t)n_w + 1));
+    AVS_TRY(scan_tmp.reserve(scan_tmp_elems(n_w + 1)));
+    AVS_TRY(g2l.reserve((size_t)(n > 0 ? n : 1)));
+    AVS_TRY(owner.reserve((size_t)(n > 0 ? n : 1)));
+    AVS_TRY(is_halo.reserve((size_t)(n > 0 ? n : 1)));
     AVS_HIP(hipMemsetAsync(g2l.p, 0xFF, (size_t)n * sizeof(int32_t), st));
     AVS_HIP(hipMemsetAsync(owner.p, 0xFF, (size_t)n, st));
     AVS_HIP(hipMemsetAsync(is_halo.p, 0, (size_t)n, st));
+    tr.mark("alloc + memsets");
     int interleave = cur_opt().brick_interleave;
     {
         const int bs = c->brick_shift;
@@ -1494,22 +1534,25 @@ static avs_status dist_assemble_window(avs_ctx *c, PcgDist *d)
                            c->brick_shift, interleave, keys_in.p);
         size_t tmp_bytes = 0;
         AVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in.p, keys_out.p, c->wlist[0].p, dom.p, (size_t)n_w, 0, 32, st));
-        AVS_TRY(sort_tmp.alloc(tmp_bytes > 0 ? tmp_bytes : 1));
+        AVS_TRY(sort_tmp.reserve(tmp_bytes > 0 ? tmp_bytes : 1));
         AVS_HIP(rocprim::radix_sort_pairs(sort_tmp.p, tmp_bytes, keys_in.p, keys_out.p, c->wlist[0].p, dom.p, (size_t)n_w, 0, 32, st)); // stable
         CutTable T{};
         T.world = world;
         for (int r = 0; r <= world; ++r) T.cuts[r] = W.cuts[r];
         hipLaunchKernelGGL(k_win_owner, dim3(grid256(n_w)), dim3(256), 0, st, n_w, c->vdof.p, dom.p, axis, extent, T, rank, owner.p, flag.p);
     }
+    tr.mark("keys, sort, owners");
     int64_t n_own = 0;
     AVS_TRY(scan_flags(flag.p, pos.p, n_w, scan_tmp, &n_own, st));
-    AVS_TRY(ids.alloc((size_t)(n_own > 0 ? n_own : 1)));
-    AVS_TRY(d->own_global.alloc((size_t)n_own));
+    AVS_TRY(ids.reserve((size_t)(n_own > 0 ? n_own : 1)));
+    AVS_TRY(d->own_global.reserve((size_t)n_own));
     if (n_own) {
         hipLaunchKernelGGL(k_plan_scatter, dim3(grid256(n_w)), dim3(256), 0, st, n_w, flag.p, pos.p, (const int32_t *)nullptr, ids.p, g2l.p, 0, dom.p);
         AVS_HIP(hipMemcpyAsync(d->own_global.p, ids.p, (size_t)n_own * sizeof(int32_t), hipMemcpyDeviceToDevice, st)); // (reference ids: avs_dist_get_solution scatters by them)
     }
+    tr.mark("own list");
     AVS_TRY(dist_assemble_tail(c, d, ids, n_own, n, dom.p, n_w, nullptr, nullptr, owner, is_halo, g2l, flag, pos, scan_tmp));
+    tr.mark("tail");
 
     // the cuts this frame's weights suggest for the next one: per-plane weights of the own rows, summed over the ranks
     d->next_cuts = d->cuts;
@@ -1518,10 +1561,10 @@ static avs_status dist_assemble_window(avs_ctx *c, PcgDist *d)
         if (cur_opt().dist_plane_shift >= 0) shift = cur_opt().dist_plane_shift < shift ? cur_opt().dist_plane_shift : shift;
         else if (shift > 2) shift = 2;
         const int nplanes = (extent + (1 << shift) - 1) >> shift;
-        DevBuf<unsigned long long> weight;
-        DevBuf<int32_t> w32;
-        AVS_TRY(weight.alloc((size_t)nplanes));
-        AVS_TRY(w32.alloc((size_t)nplanes));
+        DevBuf<unsigned long long> &weight = d->ws.weight;
+        DevBuf<int32_t> &w32 = d->ws.w32;
+        AVS_TRY(weight.reserve((size_t)nplanes));
+        AVS_TRY(w32.reserve((size_t)nplanes));
         AVS_HIP(hipMemsetAsync(weight.p, 0, (size_t)nplanes * sizeof(unsigned long long), st));
         if (n_own)
             hipLaunchKernelGGL(k_win_plane_weights, dim3(grid256(n_own)), dim3(256), 0, st, n_own, (const int32_t *)d->local_ref.p, c->vdof.p,

@@ -9,6 +9,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
+#include <cstdio>
 #include <memory>
 #include <string>
 #include <vector>
@@ -118,6 +120,7 @@ struct Options {
     int resident_coherent_fill = 1, resident_timers = 0, resident_verbose = 0;
     // multi-GPU
     int dist_standard_cg = 0, dist_overlap = 1, dist_loopback = 0, dist_host_plan = 0, dist_selftest_rounds = 64, dist_split_rows = 1, dist_plane_shift = -1;
+    int trace_phases = 0;        // AVS_TRACE_PHASES: wall time of the steps of the pre-pass' numbering and of avs_dist_assemble on stderr (diagnosis: synchronises)
     long long dist_timeout_ms = 0; // 0: the defaults (20 s between ranks, 2 s inside one device)
 };
 Options options_from_env();
@@ -528,6 +531,26 @@ struct SlabWindow {
     int axis = 0, world = 1, rank = 0;
     int cuts[33] = {};  // fine cells along `axis`: rank r owns the faces at positions [cuts[r], cuts[r + 1])
     int win_lo[AVS_MAX_LEVELS] = {}, win_hi[AVS_MAX_LEVELS] = {};
+};
+
+// AVS_TRACE_PHASES=1: wall time between marks, the stream synchronised at every mark (diagnosis only)
+struct PhaseTrace {
+    hipStream_t s;
+    const char *tag;
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    PhaseTrace(hipStream_t st, const char *tg, bool enabled) : s(st), tag(tg), on(enabled)
+    {
+        if (on) { (void)hipStreamSynchronize(s); t = std::chrono::steady_clock::now(); }
+    }
+    void mark(const char *what)
+    {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[avs %s] %-28s %8.3f ms\n", tag, what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
 };
 
 // what avs_prepass_apply hands to a context: references on the pre-pass's own allocations (no copy; see SharedBuf)

@@ -763,75 +763,102 @@ __device__ __forceinline__ bool slab_owns_tile(const SlabOwn &own, const NumLatt
     return r == own.rank;
 }
 
-__global__ __launch_bounds__(kBlock) void k_tile_counts(NumStarts S, const NumBatch *__restrict__ B, int32_t *__restrict__ tile_count, SlabOwn own)
+// Round 6: the tiles that can hold a DOF are LISTED first (one thread per tile: its occupancy flag, in slab mode its owner) and the
+// counting / numbering workgroups walk the list -- a workgroup per tile of the concatenated space was 376 k workgroups at 512^3 (2.9 M
+// at 1024^3), nine in ten of which found their tile's flag clear and left: dispatching them cost more than the occupied tiles' work.
+__global__ __launch_bounds__(kBlock) void k_tile_select(NumStarts S, const NumBatch *__restrict__ B, int tiles, SlabOwn own, int32_t *__restrict__ list /* [0]: count */)
 {
-    const NumLattice Lt = batch_lattice(S, B, (int)blockIdx.x);
-    const int tile = (int)blockIdx.x - Lt.tile0;
-    if (own.on && !slab_owns_tile(own, Lt, tile)) {
-        if (threadIdx.x == 0) tile_count[blockIdx.x] = 0;
-        return;
-    }
-    // a tile the classification never visited (occupancy flag clear) holds no DOF: not read at all -- on a thin sheet that is
-    // nine tiles in ten
-    if (Lt.occ && !Lt.occ[tile]) {
-        if (threadIdx.x == 0) tile_count[blockIdx.x] = 0;
-        return;
-    }
+    const int t = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (t >= tiles) return;
+    const NumLattice Lt = batch_lattice(S, B, t);
+    const int tile = t - Lt.tile0;
+    if (Lt.occ && !Lt.occ[tile]) return; // a tile the classification never visited holds no DOF (on a thin sheet: nine tiles in ten)
+    if (own.on && !slab_owns_tile(own, Lt, tile)) return;
+    list[1 + atomicAdd(list, 1)] = t; // (the order of the list does not matter)
+}
+// ... and, behind the scan, the tiles with a DOF that this rank classified
+__global__ __launch_bounds__(kBlock) void k_tile_select_ids(NumStarts S, const NumBatch *__restrict__ B, int tiles, const int32_t *__restrict__ tile_off,
+                                                            int32_t *__restrict__ list)
+{
+    const int t = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (t >= tiles) return;
+    if (tile_off[t + 1] == tile_off[t]) return;
+    const NumLattice Lt = batch_lattice(S, B, t);
+    if (Lt.occ && !Lt.occ[t - Lt.tile0]) return; // (slab-local pre-pass: a tile of another rank's window -- counted there, not classified here)
+    list[1 + atomicAdd(list, 1)] = t;
+}
+
+// tile_count is zero-filled; the listed tiles get their counts
+__global__ __launch_bounds__(kBlock) void k_tile_counts(NumStarts S, const NumBatch *__restrict__ B, int32_t *__restrict__ tile_count,
+                                                        const int32_t *__restrict__ list)
+{
     __shared__ int red[kBlock / 64];
-    size_t first, zs;
-    int cnt = __popc(tile_flags(Lt.grid, Lt.g, Lt.ntx, Lt.nty, &first, &zs, tile));
+    const int n_list = list[0];
+    for (int li = (int)blockIdx.x; li < n_list; li += (int)gridDim.x) {
+        const int gt = list[1 + li];
+        const NumLattice Lt = batch_lattice(S, B, gt);
+        const int tile = gt - Lt.tile0;
+        size_t first, zs;
+        int cnt = __popc(tile_flags(Lt.grid, Lt.g, Lt.ntx, Lt.nty, &first, &zs, tile));
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) tile_count[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) tile_count[gt] = red[0] + red[1] + red[2] + red[3];
+        __syncthreads();
+    }
 }
 
 // `table` (optional): the dof table of this kind -- record (level | axis << 8, i, j, k) of every id handed out, what the solver context
 // otherwise rebuilds with a sweep over every index lattice (k_dof_table: 5 ms per frame at 1024^3); ids beyond `cap` are not recorded
 // (the table was sized from the previous frame's count: the caller then discards it).  total: where the kind's DOF count goes.
 __global__ __launch_bounds__(kBlock) void k_tile_ids(NumStarts S, const NumBatch *__restrict__ B, const int32_t *__restrict__ tile_off,
-                                                     int32_t *__restrict__ table, long long cap, long long *__restrict__ total, int total_tiles)
+                                                     int32_t *__restrict__ table, long long cap, long long *__restrict__ total, int total_tiles,
+                                                     const int32_t *__restrict__ list)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) *total = (long long)tile_off[total_tiles];
-    if (tile_off[blockIdx.x + 1] == tile_off[blockIdx.x]) return; // no DOF in this tile: nothing to read, nothing to write
-    const NumLattice Lt = batch_lattice(S, B, (int)blockIdx.x);
-    const int tile = (int)blockIdx.x - Lt.tile0;
-    if (Lt.occ && !Lt.occ[tile]) return; // (slab-local pre-pass: a tile of another rank's window -- counted there, not classified here)
     __shared__ int cnt[kTile * (kBlock / 64)]; // flagged voxels of (step z, wave w), then their exclusive prefix
-    size_t first, zs;
-    const unsigned bits = tile_flags(Lt.grid, Lt.g, Lt.ntx, Lt.nty, &first, &zs, tile);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long below[kTile]; // ballot of step z restricted to the lanes below this one
+    const int n_list = list[0];
+    for (int li = (int)blockIdx.x; li < n_list; li += (int)gridDim.x) {
+        const int gt = list[1 + li];
+        const NumLattice Lt = batch_lattice(S, B, gt);
+        const int tile = gt - Lt.tile0;
+        size_t first, zs;
+        const unsigned bits = tile_flags(Lt.grid, Lt.g, Lt.ntx, Lt.nty, &first, &zs, tile);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        unsigned long long below[kTile]; // ballot of step z restricted to the lanes below this one
 #pragma unroll
-    for (int z = 0; z < kTile; ++z) {
-        const unsigned long long m = __ballot((bits >> z) & 1u);
-        if (lane == 0) cnt[z * (kBlock / 64) + wave] = __popcll(m);
-        below[z] = m & ((1ull << lane) - 1ull);
-    }
-    __syncthreads();
-    if (wave == 0) { // exclusive scan of the 64 (step, wave) counters, in sweep order
-        const int c = cnt[lane];
-        int incl = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int up = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += up;
+        for (int z = 0; z < kTile; ++z) {
+            const unsigned long long m = __ballot((bits >> z) & 1u);
+            if (lane == 0) cnt[z * (kBlock / 64) + wave] = __popcll(m);
+            below[z] = m & ((1ull << lane) - 1ull);
         }
-        cnt[lane] = incl - c;
-    }
-    __syncthreads();
-    if (!bits) return;
-    const int32_t id0 = tile_off[blockIdx.x];
-    const int ti = (tile % Lt.ntx) * kTile + (threadIdx.x & (kTile - 1)), tj = ((tile / Lt.ntx) % Lt.nty) * kTile + (threadIdx.x >> 4);
-    const int tk = (tile / (Lt.ntx * Lt.nty)) * kTile;
+        __syncthreads();
+        if (wave == 0) { // exclusive scan of the 64 (step, wave) counters, in sweep order
+            const int c = cnt[lane];
+            int incl = c;
 #pragma unroll
-    for (int z = 0; z < kTile; ++z)
-        if ((bits >> z) & 1u) {
-            const int32_t id = id0 + cnt[z * (kBlock / 64) + wave] + __popcll(below[z]);
-            Lt.grid[first + (size_t)z * zs] = id;
-            if (table && id < cap) reinterpret_cast<int4 *>(table)[id] = make_int4(Lt.tag, ti, tj, tk + z);
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += up;
+            }
+            cnt[lane] = incl - c;
         }
+        __syncthreads();
+        if (bits) {
+            const int32_t id0 = tile_off[gt];
+            const int ti = (tile % Lt.ntx) * kTile + (threadIdx.x & (kTile - 1)), tj = ((tile / Lt.ntx) % Lt.nty) * kTile + (threadIdx.x >> 4);
+            const int tk = (tile / (Lt.ntx * Lt.nty)) * kTile;
+#pragma unroll
+            for (int z = 0; z < kTile; ++z)
+                if ((bits >> z) & 1u) {
+                    const int32_t id = id0 + cnt[z * (kBlock / 64) + wave] + __popcll(below[z]);
+                    Lt.grid[first + (size_t)z * zs] = id;
+                    if (table && id < cap) reinterpret_cast<int4 *>(table)[id] = make_int4(Lt.tag, ti, tj, tk + z);
+                }
+        }
+        __syncthreads(); // cnt is reused by the next tile
+    }
 }
 
 // Window lists (slab-local pre-pass): the ids of the DOFs in the tiles this rank classified, ascending -- what the rank's index-only
@@ -885,6 +912,10 @@ struct avs_prepass {
     SharedBuf<int32_t> vidx[AVS_MAX_LEVELS][3], eidx[AVS_MAX_LEVELS][3], cidx[AVS_MAX_LEVELS], ridx[3];
     DevBuf<int32_t> near_list; // k_sdf_weights_far: [0] = count, then the bricks whose SDF window changes sign
     DevBuf<uint8_t> brick_signs; // k_sdf_sign_blocks: the signs inside every 32x4x4 brick of cells
+    DevBuf<uint8_t> occ_store;                             // tile occupancy of every lattice of the run (kept: an allocation + release per frame cost more than the flags' work)
+    DevBuf<int> lvl_flags;                                 // "level l has an ACTIVE cell"
+    DevBuf<int32_t> win_cnt, win_off;                      // window lists: DOFs per classified tile, their scan
+    DevBuf<int32_t> num_lists;                             // numbering: the tiles that can hold a DOF / that hold one, per batch
     DevBuf<int32_t> num_counts, num_offsets, num_scan_tmp; // numbering: DOFs per tile of the concatenated lattices of one kind, their exclusive scan
     DevBuf<long long> num_totals;                          // ... and the four DOF counts
     DevBuf<struct avs::NumBatch> num_batches;              // ... the lattice lists of the four batches
@@ -1324,8 +1355,8 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     }
     // cap at the first level without ACTIVE cells, oct.cpp:198-211 (slab mode: a property of the WHOLE octree -- the flags of the
     // rank's part travel with the tile counts, the cap is known after the exchange; until then every level is classified)
-    DevBuf<int> flags;
-    AVS_TRY(flags.alloc(AVS_MAX_LEVELS));
+    DevBuf<int> &flags = p->lvl_flags;
+    AVS_TRY(flags.reserve(AVS_MAX_LEVELS));
     AVS_HIP(hipMemsetAsync(flags.p, 0, AVS_MAX_LEVELS * sizeof(int), st));
     for (int l = 0; l < L; ++l) {
         int r[3];
@@ -1357,8 +1388,8 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     // tile-occupancy flags of the six lattices of the level being classified (one buffer each; the face lattices of level 0
     // are kept for the regular-grid classification below, which uses the same rule on the same lattices)
     const size_t occ_cap = (size_t)(d.nx / kTile + 2) * (size_t)(d.ny / kTile + 2) * (size_t)(d.nz / kTile + 2);
-    DevBuf<uint8_t> occ_all; // [level][kind][axis][occ_cap]: kept until the numbering, which skips the tiles nobody visited
-    AVS_TRY(occ_all.alloc((size_t)capped * 7 * occ_cap));
+    DevBuf<uint8_t> &occ_all = p->occ_store; // [level][kind][axis][occ_cap]: kept until the numbering, which skips the tiles nobody visited
+    AVS_TRY(occ_all.reserve((size_t)capped * 7 * occ_cap));
     TileGrid tg0[3];
     for (int l = 0; l < capped; ++l) {
         int cr[3];
@@ -1457,6 +1488,7 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     (void)max_vol;
     AVS_TRY(base.alloc(4));
     AVS_HIP(hipMemsetAsync(base.p, 0, 4 * sizeof(long long), st));
+    PhaseTrace tr(st, "numbering", avs::options_from_env().trace_phases != 0);
     // one batch per counter: velocity faces, edges, centres (each over all levels, in numbering order), regular-grid faces (cpp:1486-1509:
     // one counter over the three axes).  The four count arrays lie behind each other in ONE buffer (+ the levels' flags in slab mode: what
     // the ranks sum), the scans run per counter.
@@ -1504,6 +1536,8 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     AVS_REQUIRE(n_exchange < (1ll << 31) - 1, AVS_EINVAL, "too many tiles");
     AVS_TRY(fl.reserve((size_t)n_exchange));
     AVS_TRY(ids.reserve((size_t)seg[4]));
+    AVS_TRY(p->num_lists.reserve((size_t)seg[4] + 4)); // per batch: [count | tile ids]  (a batch's segment has tiles + 1 entries)
+    constexpr unsigned kNumGrid = 4096;                 // workgroups walking a list
     AVS_TRY(p->num_batches.alloc(4));
     SlabOwn own{};
     if (slab) {
@@ -1517,9 +1551,16 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         AVS_TRY(scan_tmp.reserve(scan_tmp_elems(tiles + 1)));
         AVS_HIP(hipMemcpyAsync(p->num_batches.p + counter, &B, sizeof(NumBatch), hipMemcpyHostToDevice, st)); // (pageable source: staged before the call returns)
         for (int k = 0; k < kNumLattices; ++k) S[counter].tile0[k] = k < B.count ? B.lat[k].tile0 : INT_MAX;
-        if (tiles) hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)tiles), dim3(kBlock), 0, st, S[counter], p->num_batches.p + counter, fl.p + seg[counter], own);
+        if (tiles) {
+            int32_t *list = p->num_lists.p + seg[counter];
+            AVS_HIP(hipMemsetAsync(list, 0, sizeof(int32_t), st));
+            AVS_HIP(hipMemsetAsync(fl.p + seg[counter], 0, (size_t)(tiles + 1) * sizeof(int32_t), st));
+            hipLaunchKernelGGL(k_tile_select, dim3(grid_for((size_t)tiles)), dim3(kBlock), 0, st, S[counter], p->num_batches.p + counter, (int)tiles, own, list);
+            hipLaunchKernelGGL(k_tile_counts, dim3(kNumGrid), dim3(kBlock), 0, st, S[counter], p->num_batches.p + counter, fl.p + seg[counter], (const int32_t *)list);
+        }
     }
     AVS_HIP(hipGetLastError());
+    tr.mark("tile counts");
     int eff_tiles[4]; // tiles of the levels below the cap (slab mode: the cap is only known now)
     for (int c = 0; c < 4; ++c) eff_tiles[c] = host_batches[c].total_tiles;
     if (slab) { // ONE exchange: every tile's count from the rank that owns it, every level's "has an ACTIVE cell" from whoever saw one
@@ -1539,6 +1580,7 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         }
         for (int c = 0; c < 3; ++c) eff_tiles[c] = level_tile0[c][capped]; // (levels are the outer order of a batch: the capped ones are its tail)
     }
+    tr.mark("exchange");
     for (int counter = 0; counter < 4; ++counter)
         AVS_TRY(exclusive_scan_i32(fl.p + seg[counter], ids.p + seg[counter], eff_tiles[counter], scan_tmp.p, scan_tmp.n, st));
     // dof tables: slab mode sizes them exactly (the totals are read first); else room for the previous frame's count + 25 % (a first
@@ -1562,18 +1604,24 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     }
     for (int counter = 0; counter < 4; ++counter) {
         const bool tab = counter < 3 && p->dof_cap[counter] > 0;
-        if (eff_tiles[counter])
-            hipLaunchKernelGGL(k_tile_ids, dim3((unsigned)eff_tiles[counter]), dim3(kBlock), 0, st, S[counter], p->num_batches.p + counter,
+        if (eff_tiles[counter]) {
+            int32_t *list = p->num_lists.p + seg[counter];
+            AVS_HIP(hipMemsetAsync(list, 0, sizeof(int32_t), st));
+            hipLaunchKernelGGL(k_tile_select_ids, dim3(grid_for((size_t)eff_tiles[counter])), dim3(kBlock), 0, st, S[counter], p->num_batches.p + counter,
+                               eff_tiles[counter], (const int32_t *)(ids.p + seg[counter]), list);
+            hipLaunchKernelGGL(k_tile_ids, dim3(kNumGrid), dim3(kBlock), 0, st, S[counter], p->num_batches.p + counter,
                                (const int32_t *)(ids.p + seg[counter]), tab ? p->dof[counter].p : (int32_t *)nullptr,
-                               tab ? p->dof_cap[counter] : 0ll, base.p + counter, eff_tiles[counter]);
+                               tab ? p->dof_cap[counter] : 0ll, base.p + counter, eff_tiles[counter], (const int32_t *)list);
+        }
     }
     AVS_HIP(hipGetLastError());
+    tr.mark("scans, tables, ids");
     if (slab) { // the window's DOFs of every kind, ascending: the tiles this rank classified, each a run of consecutive ids
-        DevBuf<int32_t> wcnt, woff;
+        DevBuf<int32_t> &wcnt = p->win_cnt, &woff = p->win_off;
         for (int k = 0; k < 3; ++k) {
             const int tiles = eff_tiles[k];
-            AVS_TRY(wcnt.alloc((size_t)tiles + 1));
-            AVS_TRY(woff.alloc((size_t)tiles + 1));
+            AVS_TRY(wcnt.reserve((size_t)tiles + 1));
+            AVS_TRY(woff.reserve((size_t)tiles + 1));
             hipLaunchKernelGGL(k_win_counts, dim3(grid_for((size_t)tiles)), dim3(kBlock), 0, st, S[k], p->num_batches.p + k, (const int32_t *)(ids.p + seg[k]), tiles, wcnt.p);
             AVS_TRY(exclusive_scan_i32(wcnt.p, woff.p, tiles, scan_tmp.p, scan_tmp.n, st));
             int32_t nw = 0;
@@ -1589,6 +1637,7 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         AVS_HIP(hipMemcpyAsync(hb, base.p, sizeof(hb), hipMemcpyDeviceToHost, st));
         AVS_HIP(hipStreamSynchronize(st));
     }
+    tr.mark("window lists");
     for (int k = 0; k < 4; ++k) p->counts[k] = hb[k];
     for (int k = 0; k < 3; ++k) {
         p->dof_valid[k] = p->dof_cap[k] > 0 && hb[k] <= p->dof_cap[k];
