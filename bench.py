@@ -52,6 +52,10 @@ HBM_PEAK_GBPS = 8000.0  # MI355X spec; 6290 GB/s is the measured-achievable copy
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--slab-local", action="store_true",
+                    help="with --gpus N: after the timed solves, one more frame through the slab-local path (avs_prepass_set_slab / "
+                         "avs_dist_bind_prepass + avs_dist_assemble on the rank's window only, cuts = what the first assembly's weights suggest), "
+                         "timed and solved; reported as dist.slab_local")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=4, choices=(3, 4, 5), help="BASELINE.json workload (see the docstring)")
@@ -451,6 +455,8 @@ def headline_of(full, extra_path=None):
         d = full["dist"]
         h["dist"] = _pick(d, ("transport", "resident_loop", "selftest_bad_entries"), 40)
         h["dist"]["verified"] = bool(d.get("verification") and d["verification"][-1].get("ok"))
+        if d.get("slab_local"):
+            h["dist"]["slab_local_ok"] = bool(d["slab_local"].get("ok"))
     ex = []
     for e in full.get("extra_workloads") or []:
         rr = e.get("roofline") or {}
@@ -770,6 +776,62 @@ def main():
                 torch.cuda.synchronize()
                 transfer_in_place_ms = (time.perf_counter() - t_tr) * 1e3
             del vel
+    slab_local = None
+    if use_dist and world > 1 and a.slab_local:
+        # One more frame, slab-local (round 6): every rank runs the pre-pass on its window only (global ids through one all-reduce of per-tile
+        # counts), lends the window to the context and assembles its rows without a sweep over the octree.  Collective: every rank takes
+        # part or the group hangs, so a failure on one rank is agreed on before the next collective step.
+        import ctypes as C
+        _, cuts = solver.dist_cuts(world, 1)
+        info_rep = solver.dist_solve(a.verify_tol, 4 * a.max_iters)
+        x_rep = dist_solution()
+        pp2 = DevicePrepass(sc.res, sc.dx, sc.levels, device=local_rank, field_res=sc.field_res)
+        cut_axis = solver.dist_cuts(world, 0)[0]
+        if a.one_device:   # hosted group: the all-reduce is this script's (torch.distributed on gloo, through a host copy)
+            class _DevI32:
+                def __init__(self, ptr, n):
+                    self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+
+            def allreduce(ptr, count, stream):
+                torch.cuda.synchronize()
+                t = torch.as_tensor(_DevI32(ptr, count), device=dev)
+                h = t.cpu()
+                torch.distributed.all_reduce(h)
+                t.copy_(h.to(dev))
+                torch.cuda.synchronize()
+            pp2.set_slab(cut_axis, cuts, rank, allreduce)
+        else:              # RCCL group: the library's own all-reduce
+            solver.dist_bind_prepass(pp2, cuts, cut_axis)
+        for _ in range(3):   # the third run is the steady state (both allocations of every lattice filled once)
+            pinfo2 = pp2.run(fsc.liquid, fsc.solid)
+        lo, hi, nw = pp2.window()
+        ok = agree(pinfo2.levels == levels and (pinfo2.n_velocity, pinfo2.n_edge, pinfo2.n_center) == (pinfo.n_velocity, pinfo.n_edge, pinfo.n_center))
+        slab_local = {"cuts": [int(v) for v in cuts], "cut_axis": int(cut_axis), "ok": bool(ok)}
+        if ok:
+            pp2.apply(solver)
+            solver.set_scene_fields(fsc)
+            solver.dist_assemble()        # warm-up of the slab-local code path
+            torch.cuda.synchronize()
+            t_sl = time.perf_counter()
+            ai2 = solver.dist_assemble()
+            torch.cuda.synchronize()
+            sl_wall = (time.perf_counter() - t_sl) * 1e3
+            info2 = solver.dist_solve(a.verify_tol, 4 * a.max_iters)
+            x2 = dist_solution()
+            rel = float(torch.linalg.norm(x2 - x_rep) / torch.linalg.norm(x_rep))
+            good = agree(bool(info2.converged) and abs(info2.iterations - info_rep.iterations) <= max(3, 0.01 * info_rep.iterations) and rel < max(1e-6, 100 * a.verify_tol))
+            mine_sl = [float(pinfo2.weights_ms + pinfo2.octree_ms + pinfo2.classify_ms + pinfo2.number_ms), float(ai2.stencil_ms + ai2.system_ms), float(sl_wall),
+                       float(nw[0]) / max(int(pinfo.n_velocity), 1)]
+            tn = torch.tensor(mine_sl, dtype=torch.float64, device=cdev)
+            allr = [torch.zeros_like(tn) for _ in range(world)]
+            torch.distributed.all_gather(allr, tn)
+            cols = list(zip(*[[float(v) for v in r.tolist()] for r in allr]))
+            slab_local.update(ok=bool(good), iterations=int(info2.iterations), iterations_replicated_cuts=int(info_rep.iterations), rel_l2_vs_replicated=rel,
+                              prepass_ms_per_rank=[round(v, 3) for v in cols[0]], prepass_ms_whole_octree=round(sum(prepass_ms.values()), 3),
+                              stencils_plus_rows_ms_per_rank=[round(v, 3) for v in cols[1]], assembly_wall_ms_per_rank=[round(v, 3) for v in cols[2]],
+                              assembly_wall_ms_replicated_index=round(assemble_wall_ms, 3), window_fraction_of_dofs_per_rank=[round(v, 4) for v in cols[3]],
+                              note="allocations stay full-size (a rank touches its window of them); the post-solve transfer is not slab-local")
+        pp2.close()
     nnz_total = None
     per_rank = None
     if use_dist:
@@ -828,6 +890,8 @@ def main():
         if use_dist:
             out["dist"] = {"per_rank": [dict(zip(("n_own", "n_halo", "nnz_local", "n_send", "n_peers"), r)) for r in per_rank],
                            **solver.dist_comm_info(), "resident_loop": bool(info.resident), "verification": verification}
+            if slab_local is not None:
+                out["dist"]["slab_local"] = slab_local
         if world == 1 and not a.no_cpu_baseline and not use_dist and a.precision == "f64":
             # CPU assembly baseline: the oracle's own assembly of the same scene at 256^3 (rows per second)
             asm_scene = None

@@ -26,11 +26,33 @@ def test_bench_gpus_n_on_one_device(ranks, vtol, built_lib):
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == ranks and out["value"] > 0 and out["scaling"] == "strong"
+    head = json.loads(lines[0])
+    assert head["n_gpus"] == ranks and head["value"] > 0 and head["scaling"] == "strong" and head["dist"]["verified"]
+    out = json.load(open(os.path.join(ROOT, head["full_record"])))   # (the stdout line is the <= 4 KB headline; the whole record is a file)
+    assert out["n_gpus"] == ranks and out["value"] == pytest.approx(head["value"], rel=1e-4)
     d = out["dist"]
     assert len(d["per_rank"]) == ranks and sum(r["n_own"] for r in d["per_rank"]) == out["config"]["n_dofs"]
     assert d["transport"] == "direct" and d["selftest_rounds"] > 0 and d["selftest_bad_entries"] == 0
     v = d["verification"][-1]
     assert v["ok"] and v["paranoid"] and len(v["solves"]) == 3
     assert all(s["converged"] and s["rel_l2_vs_single_gpu"] < max(1e-6, 100 * vtol) for s in v["solves"])
+
+
+def test_bench_slab_local_frame_on_one_device(built_lib):
+    """`bench.py --gpus 2 --one-device --slab-local`: after the timed solves one more frame runs through the slab-local path -- the pre-pass of
+    every rank's window with this script's own all-reduce (torch.distributed on gloo through avs_prepass_set_slab's callback), the window lent
+    to the context, avs_dist_assemble on it -- and its solve reproduces the solve on the replicated-index assembly."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-device", "--slab-local", "--n", "64", "--levels", "3",
+           "--steps", "1", "--warmup", "1", "--verify-tol", "1e-8", "--no-cpu-baseline", "--no-extra"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    head = json.loads(lines[-1])
+    assert head["dist"]["slab_local_ok"]
+    out = json.load(open(os.path.join(ROOT, head["full_record"])))
+    sl = out["dist"]["slab_local"]
+    assert sl["ok"] and sl["rel_l2_vs_replicated"] < 1e-6 and abs(sl["iterations"] - sl["iterations_replicated_cuts"]) <= 3
+    assert len(sl["prepass_ms_per_rank"]) == 2 and len(sl["cuts"]) == 3 and sl["cuts"][0] == 0 and sl["cuts"][-1] == 64
+    assert all(0 < f <= 1 for f in sl["window_fraction_of_dofs_per_rank"])
