@@ -293,31 +293,147 @@ __global__ __launch_bounds__(kWThreads) void k_sdf_weights(const float *__restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// P4: tile occupancy + classification
+// ---------------------------------------------------------------------------------------------
+struct TileGrid {
+    int tr[3];
+    // the tiles a launch covers (round 6, slab-local pre-pass: the tiles of the rank's window; full grid: bn == tr, lo == 0)
+    int lo[3], bn[3];
+    __host__ __device__ size_t vol() const { return (size_t)tr[0] * tr[1] * tr[2]; }
+    __host__ __device__ size_t launch() const { return (bn[0] > 0 && bn[1] > 0 && bn[2] > 0) ? (size_t)bn[0] * bn[1] * bn[2] : 0; }
+};
+static TileGrid tile_grid(const int gr[3])
+{
+    TileGrid t;
+    for (int a = 0; a < 3; ++a) {
+        t.tr[a] = (gr[a] + kTile - 1) / kTile;
+        t.lo[a] = 0;
+        t.bn[a] = t.tr[a];
+    }
+    return t;
+}
+// workgroup b of a tile kernel -> linear tile id on the full tile grid
+__device__ __forceinline__ unsigned launch_tile(const TileGrid &t, unsigned b)
+{
+    const int x = t.lo[0] + (int)(b % (unsigned)t.bn[0]), y = t.lo[1] + (int)((b / (unsigned)t.bn[0]) % (unsigned)t.bn[1]),
+              z = t.lo[2] + (int)(b / ((unsigned)t.bn[0] * (unsigned)t.bn[1]));
+    return (unsigned)x + (unsigned)t.tr[0] * ((unsigned)y + (unsigned)t.tr[1] * (unsigned)z);
+}
+__device__ __forceinline__ size_t tile_of(const TileGrid &t, int i, int j, int k)
+{
+    return (size_t)(i / kTile) + (size_t)t.tr[0] * ((size_t)(j / kTile) + (size_t)t.tr[1] * (size_t)(k / kTile));
+}
+
+// (slab-local pre-pass: a tile outside the launch box of its grid belongs to another rank's window and is never marked)
+__device__ __forceinline__ bool in_launch(const TileGrid &t, int i, int j, int k)
+{
+    const int x = i / kTile - t.lo[0], y = j / kTile - t.lo[1], z = k / kTile - t.lo[2];
+    return x >= 0 && x < t.bn[0] && y >= 0 && y < t.bn[1] && z >= 0 && z < t.bn[2];
+}
+// Tile occupancy.  Kind 0: faces (both directions along `axis`) of hit cells, cpp:887-1000; kind 1: the 4 `axis` edges of
+// ACTIVE cells, cpp:1003-1057.  All six occupancy grids of one level (3 face lattices, 3 edge lattices) come from ONE read of
+// the cell lattice: one launch per lattice re-read the level-0 SDF / labels nine times (2.5 ms of the 7.7 ms classification
+// at 512^3)
+struct TileSets {
+    TileGrid tg[2][3];  // [kind][axis]
+    uint8_t *occ[2][3];
+};
+// ---------------------------------------------------------------------------------------------
 // P2: mask + base labels
 // ---------------------------------------------------------------------------------------------
+// Marks of one group of V consecutive x cells (first cell (i, j, k), bit u of `hits`: cell i + u marks) on a lattice's tile occupancy:
+// the tiles of the entries cell + (0 | dx, 0 | dy, 0 | dz).  Round 6: a wave of 64 cells used to issue up to 18 one-byte stores per
+// marking cell, nearly all to the same two or three bytes (k_mark_tiles_all: 3.3 ms at 1024^3 for 5 GB of reads); now the tile of the
+// group itself is stored once per run of lanes that share it, and an offset entry only where it leaves that tile.
+__device__ __forceinline__ void mark_group(const TileGrid &tg, uint8_t *__restrict__ occ, int i, int j, int k, int V, unsigned hits, int dx, int dy, int dz)
+{
+    const bool any = hits != 0u;
+    const int key = (any && in_launch(tg, i, j, k)) ? (int)tile_of(tg, i, j, k) : -1;
+    const int prev = __shfl_up(key, 1, 64);
+    if (key >= 0 && ((threadIdx.x & 63) == 0 || prev != key)) occ[key] = 1;
+    if (!any) return;
+    // offsets that leave the group's tile (the group is aligned: only its last cell can leave along x)
+    const bool ox = dx && (((i + V) & (kTile - 1)) == 0) && ((hits >> (V - 1)) & 1u);
+    const bool oy = dy && (((j + 1) & (kTile - 1)) == 0);
+    const bool oz = dz && (((k + 1) & (kTile - 1)) == 0);
+    for (int m = 1; m < 8; ++m) {
+        const bool ux = m & 1, uy = m & 2, uz = m & 4;
+        if ((ux && !ox) || (uy && !oy) || (uz && !oz)) continue;
+        const int ei = ux ? i + V : i, ej = j + (uy ? 1 : 0), ek = k + (uz ? 1 : 0); // (any entry of the neighbouring tile names it)
+        if (in_launch(tg, ei, ej, ek)) occ[tile_of(tg, ei, ej, ek)] = 1;
+    }
+}
+
+// Level-0 labels and mask; V cells per thread along x (V = 4: one 16-B load, two 4-B stores -- one-byte stores per thread kept the kernel at
+// 2.7 TB/s).  `faces`: also marks the tiles of the level-0 face lattices by the SDF rule (cpp:907) -- the classification's occupancy pass
+// used to read the 4.3-GB SDF of a 1024^3 grid a second time for exactly this comparison.
+template <int V>
 __global__ __launch_bounds__(kBlock) void k_mask_labels(const float *__restrict__ liquid, const float *__restrict__ solid,
                                                         Box3 box, double dx, double extrapolation, int8_t *__restrict__ mask,
-                                                        int8_t *__restrict__ labels, Grid3 g, Grid3 sim)
+                                                        int8_t *__restrict__ labels, Grid3 g, Grid3 sim, TileSets T, double occ_sdf, int faces)
 {
     const double inner = dx * 2., outer = 3. * dx; // cpp:259-262 (fine bandwidth getter mismatch => 2)
-    const size_t n = box.vol();
-    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < n; t += (size_t)gridDim.x * kBlock) {
-        int ci, cj, ck;
-        box_coords(box, t, ci, cj, ck);
-        const size_t o = lin3(g, ci, cj, ck);
-        const double sdf = (double)liquid[o];
-        int m;
-        if (ci >= sim.r[0] || cj >= sim.r[1] || ck >= sim.r[2]) m = 1; // outside the simulation grid: stays INACTIVE (oct.cpp:375-379)
-        else if (sdf > 0 && sdf < outer) m = 0;
-        else if (sdf <= 0.) {
-            if (sdf > -inner) m = 0;
-            else {
-                const double s = solid ? (double)solid[o] : -1.0;
-                m = (s > (-inner - extrapolation)) ? 0 : -1;
+    Box3 bx = box;
+    bx.n[0] /= V; // groups of V cells
+    const size_t n = bx.vol();
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;; t += (size_t)gridDim.x * kBlock) {
+        if (t - (threadIdx.x & 63) >= n) break; // (whole waves stay: mark_group shuffles between neighbouring lanes)
+        const bool live = t < n;
+        int gi = 0, cj = 0, ck = 0;
+        if (live) {
+            gi = (int)(t % bx.n[0]);
+            const size_t q = t / bx.n[0];
+            cj = bx.lo[1] + (int)(q % bx.n[1]);
+            ck = bx.lo[2] + (int)(q / bx.n[1]);
+        }
+        const int ci = box.lo[0] + gi * V;
+        unsigned hits = 0u;
+        if (live) {
+            const size_t o = lin3(g, ci, cj, ck);
+            float sv[V], so[V];
+            if (V == 4) {
+                const float4 a = *reinterpret_cast<const float4 *>(liquid + o);
+                sv[0] = a.x; sv[1 % V] = a.y; sv[2 % V] = a.z; sv[3 % V] = a.w;
+                if (solid) {
+                    const float4 b = *reinterpret_cast<const float4 *>(solid + o);
+                    so[0] = b.x; so[1 % V] = b.y; so[2 % V] = b.z; so[3 % V] = b.w;
+                }
+            } else {
+                sv[0] = liquid[o];
+                if (solid) so[0] = solid[o];
             }
-        } else m = 1;
-        mask[o] = (int8_t)m;
-        labels[o] = (int8_t)(m == 0 ? AVS_ACTIVE : (m < 0 ? AVS_UP : AVS_INACTIVE)); // oct.cpp:383-388
+            int8_t mk[V], lb[V];
+#pragma unroll
+            for (int u = 0; u < V; ++u) {
+                const double sdf = (double)sv[u];
+                int m;
+                if (ci + u >= sim.r[0] || cj >= sim.r[1] || ck >= sim.r[2]) m = 1; // outside the simulation grid: stays INACTIVE (oct.cpp:375-379)
+                else if (sdf > 0 && sdf < outer) m = 0;
+                else if (sdf <= 0.) {
+                    if (sdf > -inner) m = 0;
+                    else {
+                        const double sd = solid ? (double)so[u] : -1.0;
+                        m = (sd > (-inner - extrapolation)) ? 0 : -1;
+                    }
+                } else m = 1;
+                mk[u] = (int8_t)m;
+                lb[u] = (int8_t)(m == 0 ? AVS_ACTIVE : (m < 0 ? AVS_UP : AVS_INACTIVE)); // oct.cpp:383-388
+                if (sdf < occ_sdf) hits |= 1u << u;
+            }
+            if (V == 4) {
+                *reinterpret_cast<uint32_t *>(mask + o) = (uint32_t)(uint8_t)mk[0] | ((uint32_t)(uint8_t)mk[1 % V] << 8) | ((uint32_t)(uint8_t)mk[2 % V] << 16) | ((uint32_t)(uint8_t)mk[3 % V] << 24);
+                *reinterpret_cast<uint32_t *>(labels + o) = (uint32_t)(uint8_t)lb[0] | ((uint32_t)(uint8_t)lb[1 % V] << 8) | ((uint32_t)(uint8_t)lb[2 % V] << 16) | ((uint32_t)(uint8_t)lb[3 % V] << 24);
+            } else {
+                mask[o] = mk[0];
+                labels[o] = lb[0];
+            }
+        }
+        if (faces) { // faces of hit cells, both directions along each axis (cpp:887-1000)
+            if (!live) hits = 0u;
+            mark_group(T.tg[0][0], T.occ[0][0], ci, cj, ck, V, hits, 1, 0, 0);
+            mark_group(T.tg[0][1], T.occ[0][1], ci, cj, ck, V, hits, 0, 1, 0);
+            mark_group(T.tg[0][2], T.occ[0][2], ci, cj, ck, V, hits, 0, 0, 1);
+        }
     }
 }
 
@@ -406,106 +522,81 @@ __global__ __launch_bounds__(kBlock) void k_oct_top(int8_t *__restrict__ lab, Gr
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_any_active(const int8_t *__restrict__ lab, Grid3 g, Box3 box, int *__restrict__ flag)
-{
-    bool any = false;
-    const size_t n = box.vol();
-    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < n; t += (size_t)gridDim.x * kBlock) {
-        int i, j, k;
-        box_coords(box, t, i, j, k);
-        any |= lab[lin3(g, i, j, k)] == AVS_ACTIVE;
-    }
-    if (__ballot(any) && (threadIdx.x & 63) == 0) *flag = 1; // benign race: every writer stores 1
-}
 
-// ---------------------------------------------------------------------------------------------
-// P4: tile occupancy + classification
-// ---------------------------------------------------------------------------------------------
-struct TileGrid {
-    int tr[3];
-    // the tiles a launch covers (round 6, slab-local pre-pass: the tiles of the rank's window; full grid: bn == tr, lo == 0)
-    int lo[3], bn[3];
-    __host__ __device__ size_t vol() const { return (size_t)tr[0] * tr[1] * tr[2]; }
-    __host__ __device__ size_t launch() const { return (bn[0] > 0 && bn[1] > 0 && bn[2] > 0) ? (size_t)bn[0] * bn[1] * bn[2] : 0; }
-};
-static TileGrid tile_grid(const int gr[3])
+// Tile occupancy of a level from its labels: the 4 `axis` edges of ACTIVE cells on the three edge lattices (cpp:1003-1057) and -- above
+// level 0, where the faces follow the labels too -- both faces along every axis (at level 0 the SDF rule marks them: k_mask_labels).
+// Also the level's "has an ACTIVE cell" flag (oct.cpp:198-211): k_any_active read every label lattice a second time for it.
+template <int V>
+__global__ __launch_bounds__(kBlock) void k_mark_tiles_all(const int8_t *__restrict__ lab, Grid3 cg, Box3 box, TileSets T, int faces, int *__restrict__ flag)
 {
-    TileGrid t;
-    for (int a = 0; a < 3; ++a) {
-        t.tr[a] = (gr[a] + kTile - 1) / kTile;
-        t.lo[a] = 0;
-        t.bn[a] = t.tr[a];
-    }
-    return t;
-}
-// workgroup b of a tile kernel -> linear tile id on the full tile grid
-__device__ __forceinline__ unsigned launch_tile(const TileGrid &t, unsigned b)
-{
-    const int x = t.lo[0] + (int)(b % (unsigned)t.bn[0]), y = t.lo[1] + (int)((b / (unsigned)t.bn[0]) % (unsigned)t.bn[1]),
-              z = t.lo[2] + (int)(b / ((unsigned)t.bn[0] * (unsigned)t.bn[1]));
-    return (unsigned)x + (unsigned)t.tr[0] * ((unsigned)y + (unsigned)t.tr[1] * (unsigned)z);
-}
-__device__ __forceinline__ size_t tile_of(const TileGrid &t, int i, int j, int k)
-{
-    return (size_t)(i / kTile) + (size_t)t.tr[0] * ((size_t)(j / kTile) + (size_t)t.tr[1] * (size_t)(k / kTile));
-}
-
-// (slab-local pre-pass: a tile outside the launch box of its grid belongs to another rank's window and is never marked)
-__device__ __forceinline__ bool in_launch(const TileGrid &t, int i, int j, int k)
-{
-    const int x = i / kTile - t.lo[0], y = j / kTile - t.lo[1], z = k / kTile - t.lo[2];
-    return x >= 0 && x < t.bn[0] && y >= 0 && y < t.bn[1] && z >= 0 && z < t.bn[2];
-}
-// Tile occupancy.  Kind 0: faces (both directions along `axis`) of hit cells, cpp:887-1000; kind 1: the 4 `axis` edges of
-// ACTIVE cells, cpp:1003-1057.  All six occupancy grids of one level (3 face lattices, 3 edge lattices) come from ONE read of
-// the cell lattice: one launch per lattice re-read the level-0 SDF / labels nine times (2.5 ms of the 7.7 ms classification
-// at 512^3)
-struct TileSets {
-    TileGrid tg[2][3];  // [kind][axis]
-    uint8_t *occ[2][3];
-};
-__global__ __launch_bounds__(kBlock) void k_mark_tiles_all(const int8_t *__restrict__ lab, const float *__restrict__ liquid, double occ_sdf,
-                                                           Grid3 cg, Box3 box, TileSets T)
-{
-    const size_t total = box.vol();
-    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock) {
-        int c[3];
-        box_coords(box, t, c[0], c[1], c[2]);
-        const size_t o = lin3(cg, c[0], c[1], c[2]);
-        const bool active = lab[o] == AVS_ACTIVE;
-        const bool hit_face = liquid ? ((double)liquid[o] < occ_sdf) : active; // kind 0 at level 0: the SDF rule (cpp:907)
-        if (!hit_face && !active) continue;
+    Box3 bx = box;
+    bx.n[0] /= V;
+    const size_t n = bx.vol();
+    bool seen = false;
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;; t += (size_t)gridDim.x * kBlock) {
+        if (t - (threadIdx.x & 63) >= n) break; // (whole waves stay: mark_group shuffles between neighbouring lanes)
+        const bool live = t < n;
+        int gi = 0, cj = 0, ck = 0;
+        if (live) {
+            gi = (int)(t % bx.n[0]);
+            const size_t q = t / bx.n[0];
+            cj = bx.lo[1] + (int)(q % bx.n[1]);
+            ck = bx.lo[2] + (int)(q / bx.n[1]);
+        }
+        const int ci = box.lo[0] + gi * V;
+        unsigned hits = 0u;
+        if (live) {
+            const size_t o = lin3(cg, ci, cj, ck);
+            if (V == 4) {
+                const uint32_t w = *reinterpret_cast<const uint32_t *>(lab + o);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if ((int8_t)((w >> (8 * u)) & 0xffu) == AVS_ACTIVE) hits |= 1u << u;
+            } else if (lab[o] == AVS_ACTIVE) hits = 1u;
+        }
+        seen |= hits != 0u;
+        if (!__ballot(hits != 0u)) continue; // nothing ACTIVE in the wave's 64 groups
 #pragma unroll
         for (int axis = 0; axis < 3; ++axis) {
-            if (hit_face)
-                for (int d = 0; d < 2; ++d) {
-                    int f[3] = {c[0], c[1], c[2]};
-                    f[axis] += d;
-                    if (in_launch(T.tg[0][axis], f[0], f[1], f[2])) T.occ[0][axis][tile_of(T.tg[0][axis], f[0], f[1], f[2])] = 1;
-                }
-            if (active)
-                for (int ei = 0; ei < 4; ++ei) {
-                    int e[3] = {c[0], c[1], c[2]};
-                    if (ei & 1) ++e[(axis + 1) % 3];
-                    if (ei & 2) ++e[(axis + 2) % 3];
-                    if (in_launch(T.tg[1][axis], e[0], e[1], e[2])) T.occ[1][axis][tile_of(T.tg[1][axis], e[0], e[1], e[2])] = 1;
-                }
+            if (faces) mark_group(T.tg[0][axis], T.occ[0][axis], ci, cj, ck, V, hits, axis == 0, axis == 1, axis == 2);
+            mark_group(T.tg[1][axis], T.occ[1][axis], ci, cj, ck, V, hits, axis != 0, axis != 1, axis != 2); // HDKcellToEdge: + 0 | 1 along the two other axes
         }
     }
+    if (__ballot(seen) && (threadIdx.x & 63) == 0) *flag = 1; // benign race: every writer stores 1
 }
 
 // Temporal reuse (round 5): an index lattice is AVS_UNASSIGNED outside the tiles its last classification visited, so the next frame
 // resets those tiles only -- `occ` is the occupancy the allocation was last classified with -- instead of a memset of the whole lattice
 // (39 GB of fills at 1024^3, 11 ms, for a sheet that occupies one tile in ten).
-__global__ __launch_bounds__(kBlock) void k_reset_tiles(int32_t *__restrict__ out, Grid3 fg, TileGrid tg, const uint8_t *__restrict__ occ)
+__device__ __forceinline__ void reset_tile(int32_t *__restrict__ out, const Grid3 &fg, const TileGrid &tg, unsigned tb)
 {
-    const unsigned tb = launch_tile(tg, blockIdx.x);
-    if (!occ[tb]) return;
     const int tile_x = tb % tg.tr[0], tile_y = (tb / tg.tr[0]) % tg.tr[1], tile_z = tb / (tg.tr[0] * tg.tr[1]);
     const int i = tile_x * kTile + (threadIdx.x & (kTile - 1)), j = tile_y * kTile + (threadIdx.x >> 4);
     if (i >= fg.r[0] || j >= fg.r[1]) return;
     for (int z = 0; z < kTile && tile_z * kTile + z < fg.r[2]; ++z) out[lin3(fg, i, j, tile_z * kTile + z)] = AVS_UNASSIGNED;
 }
+
+// Round 6: the tiles a classification has to touch -- occupied now (classified) or visited by the allocation's last classification (reset) --
+// are LISTED first, all lattices of a level in one launch (blockIdx.y), and the classification workgroups walk their lattice's list.  A
+// workgroup per tile was 274 k workgroups per lattice at 1024^3 -- twice (reset, classify), ten lattices at level 0 -- for a sheet that
+// occupies one tile in ten: the classification's 9 ms were mostly the dispatch of workgroups that left at once.
+constexpr int kWorkLattices = 7;
+struct WorkLists {
+    TileGrid tg[kWorkLattices];
+    const uint8_t *now[kWorkLattices], *prev[kWorkLattices]; // prev: null = the lattice was filled afresh
+    int32_t *list[kWorkLattices];                            // [0]: count (zeroed by the caller), then tile ids; null = lattice unused
+};
+__global__ __launch_bounds__(kBlock) void k_tile_worklists(WorkLists W)
+{
+    const int k = blockIdx.y;
+    if (!W.list[k]) return;
+    const TileGrid tg = W.tg[k];
+    const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= tg.launch()) return;
+    const unsigned tb = launch_tile(tg, (unsigned)t);
+    if (W.now[k][tb] || (W.prev[k] && W.prev[k][tb])) W.list[k][1 + atomicAdd(W.list[k], 1)] = (int32_t)tb; // (the order does not matter)
+}
+constexpr unsigned kListGrid = 8192; // workgroups walking a list
 
 struct ClassifyArgs {
     int n[3]; // level-0 resolution
@@ -516,16 +607,17 @@ struct ClassifyArgs {
 };
 
 // classifyOctreeVelocityFacesPartial, cpp:1167-1323
-__global__ __launch_bounds__(kBlock) void k_classify_velocity(ClassifyArgs A, Grid3 fg, TileGrid tg, const uint8_t *__restrict__ occ,
-                                                              int32_t *__restrict__ out)
+__device__ __forceinline__ void classify_velocity_tile(const ClassifyArgs &A, const Grid3 &fg, const TileGrid &tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, unsigned tb)
 {
     const int l = A.level, axis = A.axis;
     const Grid3 cg{{A.n[0] >> l, A.n[1] >> l, A.n[2] >> l}};
     const Grid3 c0{{A.n[0], A.n[1], A.n[2]}};
     // one workgroup per 16^3 tile of the lattice; the lattice was pre-filled with AVS_UNASSIGNED and a tile nobody marked
     // keeps that value ("constant tiles are never visited", cpp:1197): it is neither read nor written here
-    const unsigned tb = launch_tile(tg, blockIdx.x);
-    if (!occ[tb]) return;
+    if (!occ[tb]) { // listed because the allocation's LAST classification visited it: back to AVS_UNASSIGNED
+        reset_tile(out, fg, tg, tb);
+        return;
+    }
     const int tile_x = tb % tg.tr[0], tile_y = (tb / tg.tr[0]) % tg.tr[1], tile_z = tb / (tg.tr[0] * tg.tr[1]);
     const int vi_ = tile_x * kTile + (threadIdx.x & (kTile - 1)), vj_ = tile_y * kTile + (threadIdx.x >> 4);
     if (vi_ >= fg.r[0] || vj_ >= fg.r[1]) return;
@@ -570,17 +662,23 @@ __global__ __launch_bounds__(kBlock) void k_classify_velocity(ClassifyArgs A, Gr
         out[o] = v;
     }
 }
+__global__ __launch_bounds__(kBlock) void k_classify_velocity(ClassifyArgs A, Grid3 fg, TileGrid tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, const int32_t *__restrict__ list)
+{
+    const int n_list = list[0];
+    for (int li = (int)blockIdx.x; li < n_list; li += (int)gridDim.x) classify_velocity_tile(A, fg, tg, occ, out, (unsigned)list[1 + li]);
+}
 
 // classifyRegularVelocityFacesPartial, cpp:1087-1165 (no octree labels involved)
-__global__ __launch_bounds__(kBlock) void k_classify_regular(ClassifyArgs A, Grid3 fg, TileGrid tg, const uint8_t *__restrict__ occ,
-                                                             int32_t *__restrict__ out)
+__device__ __forceinline__ void classify_regular_tile(const ClassifyArgs &A, const Grid3 &fg, const TileGrid &tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, unsigned tb)
 {
     const int axis = A.axis;
     const Grid3 c0{{A.n[0], A.n[1], A.n[2]}};
     // one workgroup per 16^3 tile of the lattice; the lattice was pre-filled with AVS_UNASSIGNED and a tile nobody marked
     // keeps that value ("constant tiles are never visited", cpp:1197): it is neither read nor written here
-    const unsigned tb = launch_tile(tg, blockIdx.x);
-    if (!occ[tb]) return;
+    if (!occ[tb]) { // listed because the allocation's LAST classification visited it: back to AVS_UNASSIGNED
+        reset_tile(out, fg, tg, tb);
+        return;
+    }
     const int tile_x = tb % tg.tr[0], tile_y = (tb / tg.tr[0]) % tg.tr[1], tile_z = tb / (tg.tr[0] * tg.tr[1]);
     const int vi_ = tile_x * kTile + (threadIdx.x & (kTile - 1)), vj_ = tile_y * kTile + (threadIdx.x >> 4);
     if (vi_ >= fg.r[0] || vj_ >= fg.r[1]) return;
@@ -613,17 +711,23 @@ __global__ __launch_bounds__(kBlock) void k_classify_regular(ClassifyArgs A, Gri
         out[o] = v;
     }
 }
+__global__ __launch_bounds__(kBlock) void k_classify_regular(ClassifyArgs A, Grid3 fg, TileGrid tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, const int32_t *__restrict__ list)
+{
+    const int n_list = list[0];
+    for (int li = (int)blockIdx.x; li < n_list; li += (int)gridDim.x) classify_regular_tile(A, fg, tg, occ, out, (unsigned)list[1 + li]);
+}
 
 // classifyEdgeStressesPartial, cpp:1325-1405
-__global__ __launch_bounds__(kBlock) void k_classify_edges(ClassifyArgs A, Grid3 eg, TileGrid tg, const uint8_t *__restrict__ occ,
-                                                           int32_t *__restrict__ out)
+__device__ __forceinline__ void classify_edges_tile(const ClassifyArgs &A, const Grid3 &eg, const TileGrid &tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, unsigned tb)
 {
     const int l = A.level, axis = A.axis;
     const Grid3 cg{{A.n[0] >> l, A.n[1] >> l, A.n[2] >> l}};
     // one workgroup per 16^3 tile of the lattice; the lattice was pre-filled with AVS_UNASSIGNED and a tile nobody marked
     // keeps that value ("constant tiles are never visited", cpp:1197): it is neither read nor written here
-    const unsigned tb = launch_tile(tg, blockIdx.x);
-    if (!occ[tb]) return;
+    if (!occ[tb]) { // listed because the allocation's LAST classification visited it: back to AVS_UNASSIGNED
+        reset_tile(out, eg, tg, tb);
+        return;
+    }
     const int tile_x = tb % tg.tr[0], tile_y = (tb / tg.tr[0]) % tg.tr[1], tile_z = tb / (tg.tr[0] * tg.tr[1]);
     const int vi_ = tile_x * kTile + (threadIdx.x & (kTile - 1)), vj_ = tile_y * kTile + (threadIdx.x >> 4);
     if (vi_ >= eg.r[0] || vj_ >= eg.r[1]) return;
@@ -650,6 +754,11 @@ __global__ __launch_bounds__(kBlock) void k_classify_edges(ClassifyArgs A, Grid3
         out[o] = v;
     }
 }
+__global__ __launch_bounds__(kBlock) void k_classify_edges(ClassifyArgs A, Grid3 eg, TileGrid tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, const int32_t *__restrict__ list)
+{
+    const int n_list = list[0];
+    for (int li = (int)blockIdx.x; li < n_list; li += (int)gridDim.x) classify_edges_tile(A, eg, tg, occ, out, (unsigned)list[1 + li]);
+}
 
 // classifyCenterStressesPartial, cpp:1407-1443.  Round 5: the centre lattice by tiles, like the others.  A centre DOF needs an ACTIVE cell, and k_mark_tiles_all flags, for every ACTIVE
 // cell c, the tile of edge c of the axis-0 edge lattice -- whose tile COORDINATES are the cell's (c / 16 per axis; only the tile grid's
@@ -662,11 +771,12 @@ __global__ __launch_bounds__(kBlock) void k_center_tiles(const uint8_t *__restri
     const int tx = (int)(t % tc.tr[0]), ty = (int)((t / tc.tr[0]) % tc.tr[1]), tz = (int)(t / ((size_t)tc.tr[0] * tc.tr[1]));
     occ_c[t] = occ_edge0[(size_t)tx + (size_t)te.tr[0] * ((size_t)ty + (size_t)te.tr[1] * (size_t)tz)];
 }
-__global__ __launch_bounds__(kBlock) void k_classify_centers_tiled(const int8_t *__restrict__ lab, const float *__restrict__ centerw, int level, Grid3 cg,
-                                                                   TileGrid tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out)
+__device__ __forceinline__ void classify_centers_tiled_tile(const int8_t *__restrict__ lab, const float *__restrict__ centerw, int level, const Grid3 &cg, const TileGrid &tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, unsigned tb)
 {
-    const unsigned tb = launch_tile(tg, blockIdx.x);
-    if (!occ[tb]) return;
+    if (!occ[tb]) { // listed because the allocation's LAST classification visited it: back to AVS_UNASSIGNED
+        reset_tile(out, cg, tg, tb);
+        return;
+    }
     const int tile_x = tb % tg.tr[0], tile_y = (tb / tg.tr[0]) % tg.tr[1], tile_z = tb / (tg.tr[0] * tg.tr[1]);
     const int i = tile_x * kTile + (threadIdx.x & (kTile - 1)), j = tile_y * kTile + (threadIdx.x >> 4);
     if (i >= cg.r[0] || j >= cg.r[1]) return;
@@ -674,6 +784,11 @@ __global__ __launch_bounds__(kBlock) void k_classify_centers_tiled(const int8_t 
         const size_t o = lin3(cg, i, j, tile_z * kTile + z);
         out[o] = (lab[o] == AVS_ACTIVE && (level != 0 || centerw[o] > 0.f)) ? 0 : AVS_UNASSIGNED;
     }
+}
+__global__ __launch_bounds__(kBlock) void k_classify_centers_tiled(const int8_t *__restrict__ lab, const float *__restrict__ centerw, int level, Grid3 cg, TileGrid tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, const int32_t *__restrict__ list)
+{
+    const int n_list = list[0];
+    for (int li = (int)blockIdx.x; li < n_list; li += (int)gridDim.x) classify_centers_tiled_tile(lab, centerw, level, cg, tg, occ, out, (unsigned)list[1 + li]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -915,6 +1030,7 @@ struct avs_prepass {
     DevBuf<uint8_t> occ_store;                             // tile occupancy of every lattice of the run (kept: an allocation + release per frame cost more than the flags' work)
     DevBuf<int> lvl_flags;                                 // "level l has an ACTIVE cell"
     DevBuf<int32_t> win_cnt, win_off;                      // window lists: DOFs per classified tile, their scan
+    DevBuf<int32_t> work_lists;                            // classification: per lattice of the level [count | tiles to classify / reset]
     DevBuf<int32_t> num_lists;                             // numbering: the tiles that can hold a DOF / that hold one, per batch
     DevBuf<int32_t> num_counts, num_offsets, num_scan_tmp; // numbering: DOFs per tile of the concatenated lattices of one kind, their exclusive scan
     DevBuf<long long> num_totals;                          // ... and the four DOF counts
@@ -1040,13 +1156,17 @@ static avs_status run_weights(avs_prepass *p, WeightFields &F)
 // the record to fill in once the classification is enqueued (remember_tiles); until then the record is void (id 0), so a run that
 // fails in between leaves no stale claim about the allocation.
 static avs_status unassign_lattice(avs_prepass *p, SharedBuf<int32_t> &buf, Grid3 g, TileGrid tg, size_t occ_cap, avs_prepass::TileState states[2],
-                                   avs_prepass::TileState **out, const Box3 *window = nullptr)
+                                   avs_prepass::TileState **out, const Box3 *window, const uint8_t **prev_occ)
 {
+    // *prev_occ: the tiles the allocation's last classification visited (they go on the classification's work list and are reset by it),
+    // or null when the lattice was filled afresh here
     avs_prepass::TileState *ts = nullptr;
     for (int k = 0; k < 2 && !ts; ++k)
         if (p->temporal && states[k].id != 0 && states[k].id == buf.id && states[k].occ.n == occ_cap) ts = &states[k];
+    (void)tg;
+    *prev_occ = nullptr;
     if (ts) {
-        if (tg.launch()) hipLaunchKernelGGL(k_reset_tiles, dim3((unsigned)tg.launch()), dim3(kBlock), 0, p->stream, buf.p, g, tg, (const uint8_t *)ts->occ.p);
+        *prev_occ = ts->occ.p;
     } else {
         const uint64_t other = buf.ids[buf.cur ^ 1];
         ts = &states[states[0].id == 0 ? 0 : (states[1].id == 0 ? 1 : (states[0].id == other ? 1 : 0))];
@@ -1333,10 +1453,35 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         AVS_TRY(p->labels[l].alloc(g3(r).vol()));
         if (!slab || l > 0) AVS_HIP(hipMemsetAsync(p->labels[l].p, 0, g3(r).vol(), st)); // INACTIVE, oct.cpp:59,69 (slab mode: level 0 is written wherever it is read)
     }
+    // tile-occupancy flags of the lattices of every level ([level][kind][axis][occ_cap] + the cell tiles in slot 6), kept until the numbering,
+    // which skips the tiles nobody visited; the level-0 face lattices' flags are set by the mask kernel (the SDF rule, cpp:907) and serve the
+    // regular-grid classification too
+    const double occ_sdf = 2. * d.dx; // cpp:907
+    const size_t occ_cap = (size_t)(d.nx / kTile + 2) * (size_t)(d.ny / kTile + 2) * (size_t)(d.nz / kTile + 2);
+    DevBuf<uint8_t> &occ_all = p->occ_store;
+    AVS_TRY(occ_all.reserve((size_t)L * 7 * occ_cap));
+    AVS_HIP(hipMemsetAsync(occ_all.p, 0, (size_t)L * 7 * occ_cap, st));
+    auto tile_sets = [&](int l) {
+        TileSets T;
+        uint8_t *ob = occ_all.p + (size_t)l * 7 * occ_cap;
+        for (int kind = 0; kind < 2; ++kind)
+            for (int a = 0; a < 3; ++a) {
+                int gr[3];
+                pp_res(d, kind, l, a, gr);
+                T.tg[kind][a] = win_tiles(gr, l);
+                T.occ[kind][a] = ob + (size_t)(kind * 3 + a) * occ_cap;
+            }
+        return T;
+    };
     {
         const Box3 b0 = cell_box(0, v_lo[0], v_hi[0]);
-        hipLaunchKernelGGL(k_mask_labels, dim3(grid_for(b0.vol())), dim3(kBlock), 0, st, p->liq, p->sol, b0, d.dx,
-                           extrapolation, p->mask.p, p->labels[0].p, g3(r0), g3(s0));
+        const TileSets T0 = tile_sets(0);
+        if ((b0.lo[0] & 3) == 0 && (b0.n[0] & 3) == 0 && (r0[0] & 3) == 0)
+            hipLaunchKernelGGL(k_mask_labels<4>, dim3(grid_for(b0.vol() / 4)), dim3(kBlock), 0, st, p->liq, p->sol, b0, d.dx, extrapolation, p->mask.p,
+                               p->labels[0].p, g3(r0), g3(s0), T0, occ_sdf, 1);
+        else
+            hipLaunchKernelGGL(k_mask_labels<1>, dim3(grid_for(b0.vol())), dim3(kBlock), 0, st, p->liq, p->sol, b0, d.dx, extrapolation, p->mask.p,
+                               p->labels[0].p, g3(r0), g3(s0), T0, occ_sdf, 1);
     }
     for (int l = 0; l < L - 1; ++l) {
         int r[3], rp[3];
@@ -1358,67 +1503,67 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     DevBuf<int> &flags = p->lvl_flags;
     AVS_TRY(flags.reserve(AVS_MAX_LEVELS));
     AVS_HIP(hipMemsetAsync(flags.p, 0, AVS_MAX_LEVELS * sizeof(int), st));
-    for (int l = 0; l < L; ++l) {
-        int r[3];
-        pp_res(d, 2, l, 0, r);
-        const Box3 bl = cell_box(l, nl_lo[l], nl_hi[l]);
-        hipLaunchKernelGGL(k_any_active, dim3(grid_for(bl.vol(), 4096)), dim3(kBlock), 0, st, p->labels[l].p, g3(r), bl, flags.p + l);
-    }
     AVS_HIP(hipGetLastError());
     int hflags[AVS_MAX_LEVELS] = {};
-    AVS_HIP(hipMemcpyAsync(hflags, flags.p, sizeof(hflags), hipMemcpyDeviceToHost, st));
-    AVS_HIP(hipStreamSynchronize(st));
-    int capped = 0;
-    while (capped < L && hflags[capped]) ++capped;
-    if (slab) capped = L; // (see above)
-    p->levels = capped;
+    int capped = L; // every level is classified: the flags come out of the classification's occupancy pass (k_mark_tiles_all)
     p->ms[1] = t.stop();
     for (int k = 0; k < 4; ++k) p->counts[k] = 0;
-    if (capped == 0) { // no liquid in the refinement band: nothing to solve (the reference asserts here, oct.cpp:206)
-        p->ms[2] = p->ms[3] = 0.;
-        p->ready = true;
-        return AVS_OK;
-    }
 
     // ---- P4 classification -----------------------------------------------------------------
     phase.next("Build Octree Velocity and Stress Labels"); // cpp:360 (+ "Build Regular Grid Velocity Labels", cpp:306)
     t.start();
-    const double occ_sdf = 2. * d.dx; // cpp:907
     size_t max_vol = 0;
-    // tile-occupancy flags of the six lattices of the level being classified (one buffer each; the face lattices of level 0
-    // are kept for the regular-grid classification below, which uses the same rule on the same lattices)
-    const size_t occ_cap = (size_t)(d.nx / kTile + 2) * (size_t)(d.ny / kTile + 2) * (size_t)(d.nz / kTile + 2);
-    DevBuf<uint8_t> &occ_all = p->occ_store; // [level][kind][axis][occ_cap]: kept until the numbering, which skips the tiles nobody visited
-    AVS_TRY(occ_all.reserve((size_t)capped * 7 * occ_cap));
     TileGrid tg0[3];
     for (int l = 0; l < capped; ++l) {
         int cr[3];
         pp_res(d, 2, l, 0, cr);
         uint8_t *ob = occ_all.p + (size_t)l * 7 * occ_cap; // six lattices + the cell tiles (slot 6)
-        TileSets T;
-        for (int kind = 0; kind < 2; ++kind)
-            for (int a = 0; a < 3; ++a) {
-                int gr[3];
-                pp_res(d, kind, l, a, gr);
-                T.tg[kind][a] = win_tiles(gr, l);
-                T.occ[kind][a] = ob + (size_t)(kind * 3 + a) * occ_cap;
-                if (l == 0 && kind == 0) tg0[a] = T.tg[kind][a];
-            }
-        AVS_HIP(hipMemsetAsync(ob, 0, 7 * occ_cap, st));
+        const TileSets T = tile_sets(l);
+        if (l == 0)
+            for (int a = 0; a < 3; ++a) tg0[a] = T.tg[0][a];
         {   // (slab mode: the cells whose faces / edges can lie in a tile of the window)
             const Box3 mb = cell_box(l, win_lo[l] - 1, win_hi[l]);
-            hipLaunchKernelGGL(k_mark_tiles_all, dim3(grid_for(mb.vol())), dim3(kBlock), 0, st, p->labels[l].p, l == 0 ? p->liq : nullptr, occ_sdf,
-                               g3(cr), mb, T);
+            if ((mb.lo[0] & 3) == 0 && (mb.n[0] & 3) == 0 && (cr[0] & 3) == 0)
+                hipLaunchKernelGGL(k_mark_tiles_all<4>, dim3(grid_for(mb.vol() / 4)), dim3(kBlock), 0, st, p->labels[l].p, g3(cr), mb, T, l > 0 ? 1 : 0, flags.p + l);
+            else
+                hipLaunchKernelGGL(k_mark_tiles_all<1>, dim3(grid_for(mb.vol())), dim3(kBlock), 0, st, p->labels[l].p, g3(cr), mb, T, l > 0 ? 1 : 0, flags.p + l);
         }
-        for (int a = 0; a < 3; ++a) {
-            for (int kind = 0; kind < 2; ++kind) {
-                int gr[3];
-                pp_res(d, kind, l, a, gr);
-                SharedBuf<int32_t> &buf = kind == 0 ? p->vidx[l][a] : p->eidx[l][a];
-                AVS_TRY(buf.alloc(g3(gr).vol()));
-                if (g3(gr).vol() > max_vol) max_vol = g3(gr).vol();
-                const TileGrid tg = T.tg[kind][a];
-                const uint8_t *oc = T.occ[kind][a];
+        // the seven lattices of the level: fresh fill or the record of the last classification, ONE launch that lists the tiles to touch,
+        // then one classification launch per lattice over its list
+        WorkLists W{};
+        avs_prepass::TileState *tss[kWorkLattices] = {};
+        const TileGrid tc = win_tiles(cr, l);
+        uint8_t *occ_c = ob + 6 * occ_cap;
+        hipLaunchKernelGGL(k_center_tiles, dim3(grid_for(tc.vol())), dim3(kBlock), 0, st, (const uint8_t *)T.occ[1][0], T.tg[1][0], tc, occ_c);
+        AVS_TRY(p->work_lists.reserve((size_t)kWorkLattices * (occ_cap + 1)));
+        size_t max_launch = 0;
+        for (int k = 0; k < kWorkLattices; ++k) {
+            const int kind = k < 3 ? 0 : (k < 6 ? 1 : 2), a = k < 6 ? k % 3 : 0;
+            int gr[3];
+            pp_res(d, kind, l, a, gr);
+            SharedBuf<int32_t> &buf = kind == 0 ? p->vidx[l][a] : (kind == 1 ? p->eidx[l][a] : p->cidx[l]);
+            AVS_TRY(buf.alloc(g3(gr).vol()));
+            if (g3(gr).vol() > max_vol) max_vol = g3(gr).vol();
+            W.tg[k] = kind == 2 ? tc : T.tg[kind][a];
+            W.now[k] = kind == 2 ? occ_c : T.occ[kind][a];
+            W.list[k] = p->work_lists.p + (size_t)k * (occ_cap + 1);
+            const Box3 wb = win_box(gr, l);
+            AVS_TRY(unassign_lattice(p, buf, g3(gr), W.tg[k], occ_cap, kind == 0 ? p->vstate[l][a] : (kind == 1 ? p->estate[l][a] : p->cstate[l]), &tss[k],
+                                     slab ? &wb : nullptr, &W.prev[k]));
+            AVS_HIP(hipMemsetAsync(W.list[k], 0, sizeof(int32_t), st));
+            if (W.tg[k].launch() > max_launch) max_launch = W.tg[k].launch();
+        }
+        if (max_launch) hipLaunchKernelGGL(k_tile_worklists, dim3(grid_for(max_launch), kWorkLattices), dim3(kBlock), 0, st, W);
+        for (int k = 0; k < kWorkLattices && max_launch; ++k) {
+            const int kind = k < 3 ? 0 : (k < 6 ? 1 : 2), a = k < 6 ? k % 3 : 0;
+            int gr[3];
+            pp_res(d, kind, l, a, gr);
+            SharedBuf<int32_t> &buf = kind == 0 ? p->vidx[l][a] : (kind == 1 ? p->eidx[l][a] : p->cidx[l]);
+            const unsigned grid = (unsigned)(W.tg[k].launch() < kListGrid ? (W.tg[k].launch() ? W.tg[k].launch() : 1) : kListGrid);
+            if (kind == 2) {
+                hipLaunchKernelGGL(k_classify_centers_tiled, dim3(grid), dim3(kBlock), 0, st, p->labels[l].p, p->centerw.p, l, g3(gr), W.tg[k], W.now[k], buf.p,
+                                   (const int32_t *)W.list[k]);
+            } else {
                 ClassifyArgs A{};
                 A.n[0] = d.nx; A.n[1] = d.ny; A.n[2] = d.nz;
                 A.level = l;
@@ -1428,58 +1573,66 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
                 A.centerw = p->centerw.p;
                 for (int b = 0; b < 3; ++b) A.edgew[b] = p->edgew[b].p;
                 A.solid = p->sol;
-                // AVS_UNASSIGNED everywhere (a memset, or -- temporal reuse -- a reset of the tiles this allocation's last classification visited); occupied tiles are classified
-                avs_prepass::TileState *ts = nullptr;
-                const Box3 wb = win_box(gr, l);
-                AVS_TRY(unassign_lattice(p, buf, g3(gr), tg, occ_cap, kind == 0 ? p->vstate[l][a] : p->estate[l][a], &ts, slab ? &wb : nullptr));
-                if (tg.launch() && kind == 0) hipLaunchKernelGGL(k_classify_velocity, dim3((unsigned)tg.launch()), dim3(kBlock), 0, st, A, g3(gr), tg, oc, buf.p);
-                else if (tg.launch()) hipLaunchKernelGGL(k_classify_edges, dim3((unsigned)tg.launch()), dim3(kBlock), 0, st, A, g3(gr), tg, oc, buf.p);
-                AVS_HIP(hipGetLastError());
-                AVS_TRY(remember_tiles(p, ts, buf.id, oc, occ_cap));
+                if (kind == 0) hipLaunchKernelGGL(k_classify_velocity, dim3(grid), dim3(kBlock), 0, st, A, g3(gr), W.tg[k], W.now[k], buf.p, (const int32_t *)W.list[k]);
+                else hipLaunchKernelGGL(k_classify_edges, dim3(grid), dim3(kBlock), 0, st, A, g3(gr), W.tg[k], W.now[k], buf.p, (const int32_t *)W.list[k]);
             }
-        }
-        AVS_TRY(p->cidx[l].alloc(g3(cr).vol()));
-        if (g3(cr).vol() > max_vol) max_vol = g3(cr).vol();
-        {
-            const TileGrid tc = win_tiles(cr, l);
-            uint8_t *occ_c = ob + 6 * occ_cap;
-            hipLaunchKernelGGL(k_center_tiles, dim3(grid_for(tc.vol())), dim3(kBlock), 0, st, (const uint8_t *)T.occ[1][0], T.tg[1][0], tc, occ_c);
-            avs_prepass::TileState *ts = nullptr;
-            const Box3 wb = win_box(cr, l);
-            AVS_TRY(unassign_lattice(p, p->cidx[l], g3(cr), tc, occ_cap, p->cstate[l], &ts, slab ? &wb : nullptr));
-            if (tc.launch())
-                hipLaunchKernelGGL(k_classify_centers_tiled, dim3((unsigned)tc.launch()), dim3(kBlock), 0, st, p->labels[l].p, p->centerw.p, l, g3(cr), tc,
-                                   (const uint8_t *)occ_c, p->cidx[l].p);
             AVS_HIP(hipGetLastError());
-            AVS_TRY(remember_tiles(p, ts, p->cidx[l].id, occ_c, occ_cap));
+        }
+        for (int k = 0; k < kWorkLattices; ++k) { // (behind the classifications: the lists were built from the old records)
+            const int kind = k < 3 ? 0 : (k < 6 ? 1 : 2), a = k < 6 ? k % 3 : 0;
+            SharedBuf<int32_t> &buf = kind == 0 ? p->vidx[l][a] : (kind == 1 ? p->eidx[l][a] : p->cidx[l]);
+            AVS_TRY(remember_tiles(p, tss[k], buf.id, W.now[k], occ_cap));
         }
     }
-    for (int a = 0; a < 3; ++a) { // regular-grid faces, cpp:1457-1481
-        int gr[3], cr[3];
-        pp_res(d, 0, 0, a, gr);
-        pp_res(d, 2, 0, 0, cr);
-        AVS_TRY(p->ridx[a].alloc(g3(gr).vol()));
-        const TileGrid tg = tg0[a]; // occupancy of the level-0 face lattice: marked above by the same rule (kind 0, SDF)
-        ClassifyArgs A{};
-        A.n[0] = d.nx; A.n[1] = d.ny; A.n[2] = d.nz;
-        A.level = 0;
-        A.axis = a;
-        A.extrapolation = extrapolation;
-        A.lab = p->labels[0].p;
-        A.centerw = p->centerw.p;
-        for (int b = 0; b < 3; ++b) A.edgew[b] = p->edgew[b].p;
-        A.solid = p->sol;
-        avs_prepass::TileState *ts = nullptr;
-        const Box3 wb = win_box(gr, 0);
-        AVS_TRY(unassign_lattice(p, p->ridx[a], g3(gr), tg, occ_cap, p->rstate[a], &ts, slab ? &wb : nullptr));
-        if (tg.launch())
-            hipLaunchKernelGGL(k_classify_regular, dim3((unsigned)tg.launch()), dim3(kBlock), 0, st, A, g3(gr), tg, (const uint8_t *)(occ_all.p + (size_t)a * occ_cap), p->ridx[a].p);
-        AVS_HIP(hipGetLastError());
-        AVS_TRY(remember_tiles(p, ts, p->ridx[a].id, occ_all.p + (size_t)a * occ_cap, occ_cap));
+    { // regular-grid faces, cpp:1457-1481: the occupancy of the level-0 face lattices, marked above by the same rule (kind 0, SDF)
+        WorkLists W{};
+        avs_prepass::TileState *tss[3] = {};
+        size_t max_launch = 0;
+        for (int a = 0; a < 3; ++a) {
+            int gr[3];
+            pp_res(d, 0, 0, a, gr);
+            AVS_TRY(p->ridx[a].alloc(g3(gr).vol()));
+            W.tg[a] = tg0[a];
+            W.now[a] = occ_all.p + (size_t)a * occ_cap;
+            W.list[a] = p->work_lists.p + (size_t)a * (occ_cap + 1);
+            const Box3 wb = win_box(gr, 0);
+            AVS_TRY(unassign_lattice(p, p->ridx[a], g3(gr), W.tg[a], occ_cap, p->rstate[a], &tss[a], slab ? &wb : nullptr, &W.prev[a]));
+            AVS_HIP(hipMemsetAsync(W.list[a], 0, sizeof(int32_t), st));
+            if (W.tg[a].launch() > max_launch) max_launch = W.tg[a].launch();
+        }
+        if (max_launch) hipLaunchKernelGGL(k_tile_worklists, dim3(grid_for(max_launch), kWorkLattices), dim3(kBlock), 0, st, W);
+        for (int a = 0; a < 3 && max_launch; ++a) {
+            int gr[3];
+            pp_res(d, 0, 0, a, gr);
+            ClassifyArgs A{};
+            A.n[0] = d.nx; A.n[1] = d.ny; A.n[2] = d.nz;
+            A.level = 0;
+            A.axis = a;
+            A.extrapolation = extrapolation;
+            A.lab = p->labels[0].p;
+            A.centerw = p->centerw.p;
+            for (int b = 0; b < 3; ++b) A.edgew[b] = p->edgew[b].p;
+            A.solid = p->sol;
+            const unsigned grid = (unsigned)(W.tg[a].launch() < kListGrid ? (W.tg[a].launch() ? W.tg[a].launch() : 1) : kListGrid);
+            hipLaunchKernelGGL(k_classify_regular, dim3(grid), dim3(kBlock), 0, st, A, g3(gr), W.tg[a], W.now[a], p->ridx[a].p, (const int32_t *)W.list[a]);
+            AVS_HIP(hipGetLastError());
+        }
+        for (int a = 0; a < 3; ++a) AVS_TRY(remember_tiles(p, tss[a], p->ridx[a].id, W.now[a], occ_cap));
     }
-    AVS_HIP(hipStreamSynchronize(st)); // occ dies here
     AVS_HIP(hipGetLastError());
+    if (!slab) { // cap at the first level without ACTIVE cells, oct.cpp:198-211
+        AVS_HIP(hipMemcpyAsync(hflags, flags.p, sizeof(hflags), hipMemcpyDeviceToHost, st));
+        AVS_HIP(hipStreamSynchronize(st));
+        capped = 0;
+        while (capped < L && hflags[capped]) ++capped;
+    }
+    p->levels = capped;
     p->ms[2] = t.stop();
+    if (capped == 0) { // no liquid in the refinement band: nothing to solve (the reference asserts here, oct.cpp:206)
+        p->ms[3] = 0.;
+        p->ready = true;
+        return AVS_OK;
+    }
 
     // ---- P5 numbering ----------------------------------------------------------------------
     t.start();
