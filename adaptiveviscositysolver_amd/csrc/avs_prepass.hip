@@ -1327,9 +1327,9 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         AVS_HIP(hipStreamSynchronize(st)); // tmp dies here
         return AVS_OK;
     };
-    // slab-local mode reads the caller's device arrays in place (they are only read while this call runs): a copy of the whole SDF is
-    // a full-lattice pass every rank would pay for a window it does not need
-    const bool alias = p->slab.on && where == AVS_MEM_DEVICE && !padded;
+    // device arrays on the octree lattice are read in place (round 6; they are only read while this call runs): the copy was a 4.3-GB
+    // pass per SDF and frame at 1024^3 -- and in slab-local mode a full-lattice pass for a window
+    const bool alias = where == AVS_MEM_DEVICE && !padded;
     if (alias) p->liq = liquid;
     else {
         AVS_TRY(take(p->liquid, liquid));
@@ -1380,6 +1380,9 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
                 v_lo[l] = 2 * p1_lo[l + 1];
                 v_hi[l] = 2 * p1_hi[l + 1];
             }
+            // (the mask kernel is pointwise: its box may be any superset -- whole groups of four cells keep it on its vector path along x)
+            v_lo[0] = v_lo[0] / 4 * 4;
+            v_hi[0] = (v_hi[0] + 3) / 4 * 4 > na ? na : (v_hi[0] + 3) / 4 * 4;
             for (int l = 0; l < AVS_MAX_LEVELS; ++l) { p->slab.win_lo[l] = l < L ? win_lo[l] : 0; p->slab.win_hi[l] = l < L ? win_hi[l] : 0; }
             if (p->state_sig != p->slab_sig) { // the records of what the allocations hold describe another window: void
                 for (int l = 0; l < AVS_MAX_LEVELS; ++l)
@@ -1451,7 +1454,7 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         int r[3];
         pp_res(d, 2, l, 0, r);
         AVS_TRY(p->labels[l].alloc(g3(r).vol()));
-        if (!slab || l > 0) AVS_HIP(hipMemsetAsync(p->labels[l].p, 0, g3(r).vol(), st)); // INACTIVE, oct.cpp:59,69 (slab mode: level 0 is written wherever it is read)
+        if (l > 0) AVS_HIP(hipMemsetAsync(p->labels[l].p, 0, g3(r).vol(), st)); // INACTIVE, oct.cpp:59,69 (level 0 is written by the mask kernel wherever it is read)
     }
     // tile-occupancy flags of the lattices of every level ([level][kind][axis][occ_cap] + the cell tiles in slot 6), kept until the numbering,
     // which skips the tiles nobody visited; the level-0 face lattices' flags are set by the mask kernel (the SDF rule, cpp:907) and serve the

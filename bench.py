@@ -820,8 +820,14 @@ def main():
             x2 = dist_solution()
             rel = float(torch.linalg.norm(x2 - x_rep) / torch.linalg.norm(x_rep))
             good = agree(bool(info2.converged) and abs(info2.iterations - info_rep.iterations) <= max(3, 0.01 * info_rep.iterations) and rel < max(1e-6, 100 * a.verify_tol))
+            # lattice bytes (labels 1 B, seven index lattices 4 B per level; seven weight + three regular-index lattices at level 0): what the
+            # pre-pass object allocates -- full size -- and the part inside this rank's window, the only part it touches
+            cells = [float(np.prod([r >> l for r in sc.res])) for l in range(levels)]
+            n_ax = [sc.res[cut_axis] >> l for l in range(levels)]
+            alloc_b = sum(c * 29.0 for c in cells) + cells[0] * 40.0
+            win_b = sum(c * 29.0 * (int(hi[l]) - int(lo[l])) / n_ax[l] for l, c in enumerate(cells)) + cells[0] * 40.0 * (int(hi[0]) - int(lo[0])) / n_ax[0]
             mine_sl = [float(pinfo2.weights_ms + pinfo2.octree_ms + pinfo2.classify_ms + pinfo2.number_ms), float(ai2.stencil_ms + ai2.system_ms), float(sl_wall),
-                       float(nw[0]) / max(int(pinfo.n_velocity), 1)]
+                       float(nw[0]) / max(int(pinfo.n_velocity), 1), alloc_b / 1e6, win_b / 1e6]
             tn = torch.tensor(mine_sl, dtype=torch.float64, device=cdev)
             allr = [torch.zeros_like(tn) for _ in range(world)]
             torch.distributed.all_gather(allr, tn)
@@ -830,6 +836,7 @@ def main():
                               prepass_ms_per_rank=[round(v, 3) for v in cols[0]], prepass_ms_whole_octree=round(sum(prepass_ms.values()), 3),
                               stencils_plus_rows_ms_per_rank=[round(v, 3) for v in cols[1]], assembly_wall_ms_per_rank=[round(v, 3) for v in cols[2]],
                               assembly_wall_ms_replicated_index=round(assemble_wall_ms, 3), window_fraction_of_dofs_per_rank=[round(v, 4) for v in cols[3]],
+                              lattice_mb_allocated_per_rank=[round(v, 1) for v in cols[4]], lattice_mb_inside_window_per_rank=[round(v, 1) for v in cols[5]],
                               note="allocations stay full-size (a rank touches its window of them); the post-solve transfer is not slab-local")
         pp2.close()
     nnz_total = None

@@ -337,6 +337,7 @@ avs_status avs_prepass_set_slab(avs_prepass *pp, int32_t cut_axis, const int32_t
 /* the window of the last run along the cut axis: entries [lo[l], hi[l]) of the level-l lattices (hi == the level's cell count: to the end) */
 avs_status avs_prepass_get_window(avs_prepass *pp, int32_t *lo, int32_t *hi /* AVS_MAX_LEVELS each */, int64_t *n_window /* 3: velocity, edge, centre DOFs inside it */);
 void avs_prepass_destroy(avs_prepass *pp);
+/* (AVS_MEM_DEVICE arrays on a power-of-two grid are read in place while the call runs -- no copy; host arrays and padded grids are staged) */
 avs_status avs_prepass_run(avs_prepass *pp, const float *liquid_sdf, const float *solid_sdf /* NULL: none */, avs_memspace where);
 avs_status avs_prepass_get_info(avs_prepass *pp, avs_prepass_info *info);
 avs_status avs_prepass_get_labels(avs_prepass *pp, int32_t level, int8_t *out, avs_memspace where);

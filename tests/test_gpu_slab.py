@@ -171,6 +171,59 @@ def test_window_of_the_prepass_equals_the_single_rank_prepass(scene, world, axis
         assert max(r[-1][2][0] for r in res) < counts[1]
 
 
+def test_window_follows_moving_cuts_and_a_moving_liquid(built_lib):
+    """Frame after frame on ONE pre-pass object per rank: the cuts move (the records of what the allocations hold are voided), the liquid
+    moves (temporal reuse inside an unchanged window), the cuts move back -- every frame's window equals the single-rank pre-pass of that
+    frame's liquid."""
+    dev = torch.device("cuda:0")
+    world, axis = 3, 0
+    sA = scenes.to_device(scenes.sphere(64, 4, radius=0.30, device="cpu"), dev)
+    sB = scenes.to_device(scenes.sphere(64, 4, radius=0.34, device="cpu"), dev)
+    refs = {"A": _reference_arrays(sA), "B": _reference_arrays(sB)}
+    cuts1 = np.asarray([0, 20, 44, 64], np.int32)
+    cuts2 = np.asarray([0, 28, 36, 64], np.int32)
+    frames = [("A", cuts1), ("B", cuts1), ("B", cuts2), ("A", cuts2), ("A", cuts1), ("B", cuts1)]
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    barrier = threading.Barrier(world)
+    shared = {}
+    lock = threading.Lock()
+
+    def make_allreduce(rank):
+        def allreduce(ptr, count, stream):
+            assert hip.hipStreamSynchronize(C.c_void_p(stream)) == 0
+            mine = np.empty(count, np.int32)
+            assert hip.hipMemcpy(mine.ctypes.data, C.c_void_p(ptr), count * 4, 2) == 0
+            barrier.wait()
+            if rank == 0:
+                shared["sum"] = np.zeros(count, np.int64)
+            barrier.wait()
+            with lock:
+                shared["sum"] += mine
+            barrier.wait()
+            tot = shared["sum"].astype(np.int32)
+            assert hip.hipMemcpy(C.c_void_p(ptr), tot.ctypes.data, count * 4, 1) == 0
+            barrier.wait()
+        return allreduce
+
+    def rank_fn(r):
+        pp = DevicePrepass(sA.res, sA.dx, sA.levels)
+        ar = make_allreduce(r)
+        for which, cuts in frames:
+            sc = sA if which == "A" else sB
+            ref, counts = refs[which]
+            pp.set_slab(axis, cuts, r, ar)
+            info = pp.run(sc.liquid, sc.solid)
+            assert (info.levels, info.n_velocity, info.n_edge, info.n_center, info.n_regular) == counts, (r, which)
+            lo, hi, _ = pp.window()
+            _compare_window(pp, ref, info.levels, axis, lo, hi, sc.res)
+        pp.close()
+        return True
+
+    _run_threads(world, rank_fn)
+
+
 def _plan_arrays(s):
     sz = s.plan_sizes
     ti, tb = s.overlap_tiles
