@@ -126,11 +126,12 @@ avs_status build_reordered_system(avs_ctx *c, int brick_shift)
     AVS_TRY(len_new.reserve((size_t)n + 1));
     AVS_TRY(scan_tmp.reserve(scan_tmp_elems(n)));
     AVS_TRY(build_brick_permutation(c, brick_shift));
-    AVS_TRY(c->p_row_ptr.alloc((size_t)n + 1));
-    AVS_TRY(c->p_col.alloc((size_t)nnz));
-    AVS_TRY(c->p_val.alloc((size_t)nnz));
-    AVS_TRY(c->p_rhs.alloc((size_t)n));
-    AVS_TRY(c->p_x0.alloc((size_t)n));
+    // (reserve: a simulation's sizes change from frame to frame; an exact allocation was a hipFree + hipMalloc of 1.3 GB per frame at 512^3)
+    AVS_TRY(c->p_row_ptr.reserve((size_t)n + 1));
+    AVS_TRY(c->p_col.reserve((size_t)nnz));
+    AVS_TRY(c->p_val.reserve((size_t)nnz));
+    AVS_TRY(c->p_rhs.reserve((size_t)n));
+    AVS_TRY(c->p_x0.reserve((size_t)n));
     if (n == 0) { c->reordered = true; return AVS_OK; }
     hipLaunchKernelGGL(k_invert, dim3(grid_for(n)), dim3(kBlock), 0, st, c->perm.p, n, c->inv.p, c->row_ptr.p, len_new.p);
     AVS_TRY(exclusive_scan_i32(len_new.p, c->p_row_ptr.p, n, scan_tmp.p, scan_tmp.n, st));
