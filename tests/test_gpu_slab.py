@@ -310,3 +310,60 @@ def test_slab_local_assembly_equals_the_replicated_index_assembly(scene, world, 
     # the work of a rank is its window's: with thin slabs no rank sweeps the whole octree
     if world >= 4:
         assert max(l["window"][2][0] for l in loc) < n
+
+
+def test_slab_local_assembly_at_512(built_lib):
+    """The headline scene (512^3 fat beam, 7.4 M rows) cut four ways: the slab-local path -- four pre-pass objects, each on its window -- gives
+    every rank the plan arrays of the replicated-index assembly, entry for entry, and 60 iterations of the partitioned loop give the same bits."""
+    dev = torch.device("cuda:0")
+    sc = scenes.fat_beam(512, 4, device=dev)
+    world, axis = 4, 0
+    lib = capi.load()
+
+    def group_run(slab_cuts):
+        grp = C.c_void_p()
+        capi.check(lib.avs_local_group_create(world, C.byref(grp)))
+        pps = [DevicePrepass(sc.res, sc.dx, sc.levels) for _ in range(world if slab_cuts is not None else 1)]
+        if slab_cuts is None:
+            assert pps[0].run(sc.liquid, sc.solid).levels == sc.levels
+        solvers = []
+
+        def rank_fn(r):
+            s = ViscositySolve(sc.res, sc.dx, sc.dt, sc.levels, device=0)
+            s.dist_init_local(grp, r)
+            pp = pps[r] if slab_cuts is not None else pps[0]
+            if slab_cuts is not None:
+                s.dist_bind_prepass(pp, slab_cuts, axis)
+                info = pp.run(sc.liquid, sc.solid)
+                assert info.levels == sc.levels
+            pp.apply(s)
+            s.set_scene_fields(sc)
+            ai = s.dist_assemble(axis)
+            plan = _plan_arrays(s)
+            info = s.dist_solve(1e-30, 60)     # (never converges: 60 iterations of a deterministic loop)
+            x = s.dist_solution()
+            _, cuts = s.dist_cuts(world, 0)
+            solvers.append(s)
+            return dict(nnz=ai.nnz, plan=plan, it=info.iterations, x=x, cuts=cuts, window=pp.window() if slab_cuts is not None else None)
+
+        out = _run_threads(world, rank_fn)
+        for s in solvers:
+            s.close()
+        for pp in pps:
+            pp.close()
+        lib.avs_local_group_destroy(grp)
+        torch.cuda.empty_cache()
+        return out
+
+    rep = group_run(None)
+    loc = group_run(rep[0]["cuts"])
+    n = len(rep[0]["x"])
+    for r in range(world):
+        a, b = rep[r], loc[r]
+        assert a["plan"]["sizes"] == b["plan"]["sizes"] and a["nnz"] == b["nnz"] and a["it"] == b["it"] == 60
+        for k in ("row_ptr_local", "col_local", "send_idx", "peers", "send_counts", "recv_counts", "tiles_interior", "tiles_boundary"):
+            assert np.array_equal(a["plan"][k], b["plan"][k]), (r, k)
+        assert np.array_equal(a["x"], b["x"]), r
+        assert b["window"][2][0] < 0.45 * n      # a rank's window holds well under half of the DOFs (a quarter + the halo)
+    owned = np.concatenate([loc[r]["plan"]["own_global"] for r in range(world)])
+    assert len(owned) == n and np.array_equal(np.sort(owned), np.arange(n, dtype=np.int32))
