@@ -52,7 +52,7 @@ EXPORTED_SYMBOLS = [
     "avs_local_group_create", "avs_local_group_destroy", "avs_dist_init_local", "avs_dist_partition",
     "avs_spmv_tile_rows", "avs_dist_assemble", "avs_dist_get_plan_sizes", "avs_dist_get_overlap_tiles", "avs_dist_get_plan_arrays", "avs_dist_solve", "avs_dist_get_solution",
     "avs_dist_get_info", "avs_dist_init_hosted", "avs_dist_export_blob", "avs_dist_import_blobs",
-    "avs_prepass_set_slab", "avs_prepass_get_window", "avs_dist_bind_prepass", "avs_dist_get_cuts",
+    "avs_prepass_set_slab", "avs_prepass_get_window", "avs_dist_bind_prepass", "avs_dist_get_cuts", "avs_set_solution",
 ]
 # avs_allreduce_i32_fn: avs_status (*)(int32_t *device_data, int64_t count, void *stream, void *user)
 ALLREDUCE_I32_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
@@ -185,6 +185,7 @@ def load(probe=False):
     L.avs_get_matrix_format.argtypes = [vp, C.POINTER(MatrixFormat)]
     L.avs_get_solution.argtypes = [vp, vp, i64, i32]
     L.avs_get_initial_guess.argtypes = [vp, vp, i64, i32]
+    L.avs_set_solution.argtypes = [vp, vp, i64, i32]
     L.avs_get_csr.argtypes = [vp, vp, vp, vp, vp, i32]
     L.avs_get_edge_stencils.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32]
     L.avs_get_center_stencils.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32]

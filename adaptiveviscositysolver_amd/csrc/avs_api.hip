@@ -746,6 +746,20 @@ avs_status avs_get_solution(avs_ctx *c, double *x, int64_t n, avs_memspace where
     return get_vec(c, c->x.p, c->n_vel, x, n, where);
 }
 
+avs_status avs_set_solution(avs_ctx *c, const double *x, int64_t n, avs_memspace where)
+{
+    avs::OptScope opt_scope_(c);
+    AVS_REQUIRE(c && x, AVS_EINVAL, "null argument");
+    AVS_REQUIRE(c->n_vel >= 0 && n == c->n_vel, AVS_EINVAL, "vector length %lld does not match the %lld velocity DOFs", (long long)n, (long long)c->n_vel);
+    AVS_HIP(hipSetDevice(c->desc.device));
+    AVS_TRY(c->x.alloc((size_t)(n > 0 ? n : 1)));
+    AVS_HIP(copy_in(c->x.p, x, (size_t)n * sizeof(double), where, c->stream));
+    AVS_HIP(hipStreamSynchronize(c->stream));
+    narrow_solution_if_f32(c, c->x.p, n);
+    c->solved = true;
+    return AVS_OK;
+}
+
 avs_status avs_get_initial_guess(avs_ctx *c, double *x0, int64_t n, avs_memspace where)
 {
     avs::OptScope opt_scope_(c);

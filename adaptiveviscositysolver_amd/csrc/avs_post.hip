@@ -69,21 +69,25 @@ __device__ __forceinline__ float vel_clamped(const PyramidView &P, const PostVie
 }
 
 // T1 -----------------------------------------------------------------------------------------
+// (`ids`, here and below: the DOFs of a slab-local context's window -- the only ones its dof table describes -- instead of 0 .. n)
 __global__ __launch_bounds__(kBlock) void k_scatter_velocity(PyramidView P, PostView W, const int32_t *__restrict__ vdof, int64_t n,
-                                                            const double *__restrict__ x)
+                                                            const double *__restrict__ x, const int32_t *__restrict__ ids = nullptr)
 {
-    const int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (id >= n) return;
+    const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= n) return;
+    const int64_t id = ids ? ids[slot] : slot;
     const int4 rec = reinterpret_cast<const int4 *>(vdof)[id];
     const int level = rec.x & 0xff, axis = rec.x >> 8;
     W.vel[level][axis][lin(face_res(P, level, axis), I3{{rec.y, rec.z, rec.w}})] = (float)x[id]; // cpp:2808
 }
 
 // end of a transfer: the per-level face fields are all zero again (next transfer: no 4-B-per-face fill of every level)
-__global__ __launch_bounds__(kBlock) void k_unscatter_velocity(PyramidView P, PostView W, const int32_t *__restrict__ vdof, int64_t n)
+__global__ __launch_bounds__(kBlock) void k_unscatter_velocity(PyramidView P, PostView W, const int32_t *__restrict__ vdof, int64_t n,
+                                                              const int32_t *__restrict__ ids = nullptr)
 {
-    const int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (id >= n) return;
+    const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= n) return;
+    const int64_t id = ids ? ids[slot] : slot;
     const int4 rec = reinterpret_cast<const int4 *>(vdof)[id];
     const int level = rec.x & 0xff, axis = rec.x >> 8;
     W.vel[level][axis][lin(face_res(P, level, axis), I3{{rec.y, rec.z, rec.w}})] = 0.f;
@@ -209,14 +213,15 @@ __global__ __launch_bounds__(kBlock) void k_nodes_sample(PyramidView P, PostView
 // node the sweep rejects eight 1-byte label reads: measured, the two are equal at 18 nodes per DOF (512^3 beam: transfer 7.6 ms either
 // way) and the DOF-driven pass wins at 58 (1024^3 sheet with 18 M DOFs: 21.4 against 22.9 ms, 12.0 against 13.5 in place): it is
 // taken from 32 nodes per DOF on (AVS_POST_DOF_SAMPLE=0 / 1 forces either).
-__global__ __launch_bounds__(kBlock) void k_nodes_sample_dofs(PyramidView P, PostView W, const int32_t *__restrict__ vdof, int64_t n, NodeLists NL)
+__global__ __launch_bounds__(kBlock) void k_nodes_sample_dofs(PyramidView P, PostView W, const int32_t *__restrict__ vdof, int64_t n, NodeLists NL,
+                                                             const int32_t *__restrict__ ids = nullptr)
 {
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     bool won = false;
     int l = 0;
     size_t o = 0;
     if (t < 4 * n) {
-        const int4 rec = reinterpret_cast<const int4 *>(vdof)[t >> 2];
+        const int4 rec = reinterpret_cast<const int4 *>(vdof)[ids ? (int64_t)ids[t >> 2] : (t >> 2)];
         const int c = (int)(t & 3);
         const int fa = rec.x >> 8;
         l = rec.x & 0xff;
@@ -520,22 +525,25 @@ __global__ __launch_bounds__(kBlock) void k_ridx_tile_flags(const int32_t *__res
 
 __global__ __launch_bounds__(kBlock) void k_apply_regular_tiled(PyramidView P, PostView W, int axis, const int32_t *__restrict__ ridx,
                                                                 const uint8_t *__restrict__ flags, RTileGrid tg, const double *__restrict__ x,
-                                                                const float *__restrict__ vel_in, float vel_const, float *__restrict__ out, int in_place)
+                                                                const float *__restrict__ vel_in, float vel_const, float *__restrict__ out, int in_place,
+                                                                int s_axis = -1, int s_lo = 0, int s_hi = 0)
 {
+    // s_axis >= 0 (slab-local context): only the faces whose coordinate along s_axis lies in [s_lo, s_hi) are this rank's to write
     const I3 fr = face_res(P, 0, axis);
     const int t = blockIdx.x;
     const int tx = t % tg.t[0], ty = (t / tg.t[0]) % tg.t[1], tz = t / (tg.t[0] * tg.t[1]);
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
     const int xx = tx * kRtX + lx;
     if (xx >= fr[0]) return;
-    const bool occupied = flags[t] != 0;
+    bool occupied = flags[t] != 0;
+    if (s_axis == 0 && (xx < s_lo || xx >= s_hi)) occupied = false;
     const bool same = in_place != 0; // in-place update of the caller's field (what the reference does to `vel`): untouched faces need no store
     for (int k = 0; k < kRtZ; ++k)
         for (int j = ly; j < kRtY; j += kBlock / 64) {
             const int y = ty * kRtY + j, z = tz * kRtZ + k;
             if (y >= fr[1] || z >= fr[2]) continue;
             const size_t o = ((size_t)z * fr[1] + y) * fr[0] + xx;
-            if (!occupied) {
+            if (!occupied || (s_axis == 1 && (y < s_lo || y >= s_hi)) || (s_axis == 2 && (z < s_lo || z >= s_hi))) {
                 if (!same) out[o] = vel_in ? vel_in[o] : vel_const;
                 continue;
             }
@@ -654,7 +662,6 @@ static avs_status transfer_impl(avs_ctx *c, float *out_x, float *out_y, float *o
     avs::OptScope opt_scope_(c);
     AVS_REQUIRE(c && out_x && out_y && out_z, AVS_EINVAL, "null argument");
     AVS_REQUIRE(c->solved, AVS_ESTATE, "no solution: call avs_solve first");
-    AVS_REQUIRE(!c->slab.on, AVS_ESTATE, "the context holds a slab-local pre-pass (this rank's window only): the transfer needs the whole pyramid");
     AVS_REQUIRE(c->have_ridx[0] && c->have_ridx[1] && c->have_ridx[2], AVS_ESTATE, "regular-grid index fields missing (avs_set_regular_index_field)");
     AVS_REQUIRE(c->tables_ready, AVS_ESTATE, "dof tables missing");
     AVS_HIP(hipSetDevice(c->desc.device));
@@ -700,12 +707,24 @@ static avs_status transfer_impl(avs_ctx *c, float *out_x, float *out_y, float *o
             for (int a = 0; a < 3; ++a) AVS_HIP(hipMemsetAsync(c->post_nval[l][a].p, 0, nn * sizeof(float), st));
         }
     }
-    const int64_t n = c->n_vel;
-    if (n) hipLaunchKernelGGL(k_scatter_velocity, dim3(grid_for((size_t)n)), dim3(kBlock), 0, st, P, W, c->vdof.p, n, c->x.p);
+    // Slab-local context (round 6): the DOFs of the rank's window are scattered and sampled, the faces of the rank's slab are written -- the
+    // node values they read depend on faces <= 2 cells (of every level up to the top) away, well inside the window's 12-cell margin; the
+    // solution is the whole vector (avs_dist_get_solution gathers it on every rank: n doubles, the one global-sized piece of the frame)
+    const bool slab = c->slab.on;
+    const int32_t *ids = slab ? (const int32_t *)c->wlist[0].p : nullptr;
+    const int64_t n = slab ? c->n_window[0] : c->n_vel;
+    if (slab) AVS_REQUIRE(ids && c->x.n >= (size_t)c->n_vel, AVS_ESTATE, "slab-local transfer: gather the solution first (avs_dist_get_solution)");
+    int s_axis = -1, s_lo = 0, s_hi = 0;
+    if (slab) {
+        s_axis = c->slab.axis;
+        s_lo = c->slab.cuts[c->slab.rank];
+        s_hi = c->slab.rank == c->slab.world - 1 ? INT32_MAX : c->slab.cuts[c->slab.rank + 1]; // (the last rank takes the lattice's extra face)
+    }
+    if (n) hipLaunchKernelGGL(k_scatter_velocity, dim3(grid_for((size_t)n)), dim3(kBlock), 0, st, P, W, c->vdof.p, n, c->x.p, ids);
     auto nodes = [&](int l) { return (size_t)((c->desc.nx >> l) + 1) * ((c->desc.ny >> l) + 1) * ((c->desc.nz >> l) + 1); };
     // T2 lists the nodes it labels, per level, and the later passes walk the lists; sweeps over the node lattices remain for a context
     // without DOFs, node lattices beyond 2^32 entries, a list that overflows, or AVS_PREPASS_TEMPORAL=0
-    bool lists = temporal && n > 0 && nodes(0) < (1ull << 32);
+    bool lists = (temporal || slab) && n > 0 && nodes(0) < (1ull << 32);
     c->post_lists_valid = false;
     unsigned hcount[AVS_MAX_LEVELS] = {};
     if (lists) {
@@ -720,14 +739,16 @@ static avs_status transfer_impl(avs_ctx *c, float *out_x, float *out_y, float *o
             NL.cap[l] = (unsigned)(c->post_list[l].n < (1ull << 32) - 1 ? c->post_list[l].n : (1ull << 32) - 1);
         }
         const int ds = c->opt.post_dof_sample;
-        if (ds > 0 || (ds < 0 && nodes(0) >= (size_t)32 * (size_t)n)) // sparse: from the DOFs
-            hipLaunchKernelGGL(k_nodes_sample_dofs, dim3(grid_for((size_t)(4 * n), 1u << 30)), dim3(kBlock), 0, st, P, W, c->vdof.p, n, NL);
+        if (slab || ds > 0 || (ds < 0 && nodes(0) >= (size_t)32 * (size_t)n)) // sparse (and every slab-local context): from the DOFs
+            hipLaunchKernelGGL(k_nodes_sample_dofs, dim3(grid_for((size_t)(4 * n), 1u << 30)), dim3(kBlock), 0, st, P, W, c->vdof.p, n, NL, ids);
         else
             for (int l = 0; l < L; ++l) hipLaunchKernelGGL(k_nodes_sample, dim3(grid_for(nodes(l))), dim3(kBlock), 0, st, P, W, l, NL);
         AVS_HIP(hipMemcpyAsync(hcount, c->post_list_count.p, sizeof(hcount), hipMemcpyDeviceToHost, st));
         AVS_HIP(hipStreamSynchronize(st));
         for (int l = 0; l < L; ++l) lists = lists && hcount[l] <= NL.cap[l];
+        AVS_REQUIRE(lists || !slab, AVS_EINTERNAL, "slab-local transfer: a node list overflowed");
     } else {
+        AVS_REQUIRE(!slab, AVS_ESTATE, "slab-local transfer: no DOF inside the window / node lattice too large for the list-driven passes");
         for (int l = 0; l < L; ++l) hipLaunchKernelGGL(k_nodes_sample, dim3(grid_for(nodes(l))), dim3(kBlock), 0, st, P, W, l, NodeLists{});
     }
     if (lists) {
@@ -763,7 +784,8 @@ static avs_status transfer_impl(avs_ctx *c, float *out_x, float *out_y, float *o
         const RTileGrid tg = rtile_grid(fr);
         hipLaunchKernelGGL(k_apply_regular_tiled, dim3((unsigned)tg.vol()), dim3(kBlock), 0, st, P, W, a, (const int32_t *)c->ridx[a].p,
                            (const uint8_t *)c->ridx_tiles[a].p, tg, (const double *)c->x.p,
-                           c->vel[a].is_const ? (const float *)nullptr : (const float *)c->vel[a].buf.p, (float)c->vel[a].cval, work, inpl ? 1 : 0);
+                           c->vel[a].is_const ? (const float *)nullptr : (const float *)c->vel[a].buf.p, (float)c->vel[a].cval, work, inpl ? 1 : 0,
+                           s_axis, s_lo, s_hi);
         AVS_HIP(hipGetLastError());
         if (padded) { // hand back the simulation grid's faces only
             if (where == AVS_MEM_DEVICE) AVS_TRY(crop_lattice_f32(work, fr[0], fr[1], fr[2], outs[a], sr[0], sr[1], sr[2], st));
@@ -776,7 +798,7 @@ static avs_status transfer_impl(avs_ctx *c, float *out_x, float *out_y, float *o
             }
         } else if (where == AVS_MEM_HOST) AVS_HIP(copy_out(outs[a], work, nf * sizeof(float), where, st));
     }
-    if (n) hipLaunchKernelGGL(k_unscatter_velocity, dim3(grid_for((size_t)n)), dim3(kBlock), 0, st, P, W, c->vdof.p, n);
+    if (n) hipLaunchKernelGGL(k_unscatter_velocity, dim3(grid_for((size_t)n)), dim3(kBlock), 0, st, P, W, c->vdof.p, n, ids);
     AVS_HIP(hipGetLastError());
     AVS_HIP(hipStreamSynchronize(st));
     c->post_lists_valid = lists; // (the lists name every node whose label / values are non-zero now)

@@ -1930,7 +1930,7 @@ avs_status avs_prepass_apply(avs_prepass *p, avs_ctx *ctx)
         for (int k = 0; k < 3; ++k) loan.dof[k] = p->dof[k].handle();
     for (int a = 0; a < 3; ++a) // the occupancy each regular-grid lattice was classified with: the context flags its transfer tiles without reading the rest
         for (int k = 0; k < 2; ++k)
-            if (p->temporal && p->rstate[a][k].id != 0 && p->rstate[a][k].id == p->ridx[a].id) {
+            if ((p->temporal || p->slab.on) && p->rstate[a][k].id != 0 && p->rstate[a][k].id == p->ridx[a].id) { // (slab-local: the lattice is only defined inside those tiles)
                 int gr[3];
                 pp_res(p->desc, 0, 0, a, gr);
                 loan.ridx_occ[a] = p->rstate[a][k].occ.p;

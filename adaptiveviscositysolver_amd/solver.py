@@ -325,6 +325,11 @@ class ViscositySolve:
         capi.check(self.lib.avs_get_solution(self.h, x.ctypes.data, n, capi.MEM_HOST))
         return x
 
+    def set_solution(self, x):
+        """hand the context a solution vector (numpy float64 / torch float64, reference numbering) for the transfer"""
+        px, wx = capi.ptr_of(x)
+        capi.check(self.lib.avs_set_solution(self.h, px, len(x), wx))
+
     def initial_guess(self):
         n = self.info().n_velocity
         x = np.empty(n, np.float64)

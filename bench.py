@@ -826,8 +826,19 @@ def main():
             n_ax = [sc.res[cut_axis] >> l for l in range(levels)]
             alloc_b = sum(c * 29.0 for c in cells) + cells[0] * 40.0
             win_b = sum(c * 29.0 * (int(hi[l]) - int(lo[l])) / n_ax[l] for l, c in enumerate(cells)) + cells[0] * 40.0 * (int(hi[0]) - int(lo[0])) / n_ax[0]
+            # the post-solve transfer of the rank's window (in place, third call = steady state); dist_solution() left the gathered vector in the context
+            tr_ms = 0.0
+            if sc.field_res is None or tuple(sc.field_res) == tuple(sc.res):
+                vel2 = [v.clone() for v in fsc.velocity]
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t_tr2 = time.perf_counter()
+                    solver.transfer_to_regular_grid_in_place(vel2)
+                    torch.cuda.synchronize()
+                    tr_ms = (time.perf_counter() - t_tr2) * 1e3
+                del vel2
             mine_sl = [float(pinfo2.weights_ms + pinfo2.octree_ms + pinfo2.classify_ms + pinfo2.number_ms), float(ai2.stencil_ms + ai2.system_ms), float(sl_wall),
-                       float(nw[0]) / max(int(pinfo.n_velocity), 1), alloc_b / 1e6, win_b / 1e6]
+                       float(nw[0]) / max(int(pinfo.n_velocity), 1), alloc_b / 1e6, win_b / 1e6, float(tr_ms)]
             tn = torch.tensor(mine_sl, dtype=torch.float64, device=cdev)
             allr = [torch.zeros_like(tn) for _ in range(world)]
             torch.distributed.all_gather(allr, tn)
@@ -837,7 +848,8 @@ def main():
                               stencils_plus_rows_ms_per_rank=[round(v, 3) for v in cols[1]], assembly_wall_ms_per_rank=[round(v, 3) for v in cols[2]],
                               assembly_wall_ms_replicated_index=round(assemble_wall_ms, 3), window_fraction_of_dofs_per_rank=[round(v, 4) for v in cols[3]],
                               lattice_mb_allocated_per_rank=[round(v, 1) for v in cols[4]], lattice_mb_inside_window_per_rank=[round(v, 1) for v in cols[5]],
-                              note="allocations stay full-size (a rank touches its window of them); the post-solve transfer is not slab-local")
+                              transfer_in_place_ms_per_rank=[round(v, 3) for v in cols[6]],
+                              note="allocations stay full-size (a rank touches its window of them); the transfer reads the gathered solution (n doubles on every rank)")
         pp2.close()
     nnz_total = None
     per_rank = None

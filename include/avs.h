@@ -252,6 +252,11 @@ typedef struct avs_matrix_format {
 avs_status avs_get_matrix_format(avs_ctx *ctx, avs_matrix_format *fmt);
 avs_status avs_get_solution(avs_ctx *ctx, double *x, int64_t n, avs_memspace where);
 avs_status avs_get_initial_guess(avs_ctx *ctx, double *x0, int64_t n, avs_memspace where);
+/* hands the context a solution vector (reference DOF numbering, n_velocity entries) for the post-solve transfer: a hosted multi-GPU
+ * group's host program sums the per-rank vectors of avs_dist_get_solution itself and gives every rank the whole vector back; also a
+ * velocity computed elsewhere (tests: the same vector through two transfer paths).  The reference keeps its solution in `solution`
+ * between cpp:645 and cpp:655-707. */
+avs_status avs_set_solution(avs_ctx *ctx, const double *x, int64_t n, avs_memspace where);
 avs_status avs_get_csr(avs_ctx *ctx, int32_t *row_ptr /* n+1 */, int32_t *col, double *val,
                        double *rhs, avs_memspace where);
 /* SoA stencil records: entry k of stencil s lives at [k * count + s].
@@ -439,8 +444,10 @@ avs_status avs_dist_assemble(avs_ctx *ctx, int32_t cut_axis, avs_assembly_info *
  * from equal slabs.  avs_dist_assemble on such a context builds stencils for the stresses within 4 cells (of their level) of the
  * slab, the rank's rows (bit-identical to the reference's rows), halo and send lists; for the same cuts every array equals what the
  * replicated-index avs_dist_assemble produces.  Three lookup arrays indexed by DOF id (6 B per DOF, filled by memset) are the only
- * global-sized work.  Entries that need the whole pyramid (avs_assemble, avs_dist_partition, the post-solve transfer) report
- * AVS_ESTATE on a slab-local context. */
+ * global-sized work.  avs_transfer_to_regular_grid(_in_place) on a slab-local context scatters and samples the DOFs of the rank's window
+ * and writes the regular-grid faces whose position along the cut axis lies in the rank's slab (the others keep the input velocity);
+ * it reads the WHOLE solution vector: avs_dist_get_solution first (it gathers it on every rank; hosted group: avs_set_solution).
+ * Entries that need the whole pyramid (avs_assemble, avs_dist_partition) report AVS_ESTATE on a slab-local context. */
 avs_status avs_dist_bind_prepass(avs_ctx *ctx, avs_prepass *pp, int32_t cut_axis, const int32_t *cuts /* world_size + 1, or NULL */);
 avs_status avs_dist_get_cuts(avs_ctx *ctx, int32_t which, int32_t *cut_axis /* may be NULL */, int32_t *cuts /* world_size + 1 */);
 avs_status avs_dist_get_plan_sizes(avs_ctx *ctx, avs_plan_sizes *sizes);

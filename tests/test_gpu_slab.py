@@ -312,6 +312,76 @@ def test_slab_local_assembly_equals_the_replicated_index_assembly(scene, world, 
         assert max(l["window"][2][0] for l in loc) < n
 
 
+@pytest.mark.parametrize("scene,world,axis", [("beam64_L3", 2, 0), ("beam64_L3", 4, 1), ("sphere64_L4", 3, 2), ("tank64_L3", 3, 0), ("varvisc128_L4", 4, 0),
+                                              ("sheet128_L4", 4, 1), ("noncubic", 2, 0)])
+def test_slab_local_transfer_equals_the_whole_transfer_on_the_slab(scene, world, axis, built_lib):
+    """The whole frame slab-local: pre-pass of the window, assembly, partitioned solve, gathered solution, and the post-solve transfer of the
+    rank's window -- out of place and in place.  Reference: ONE context with the whole pyramid, handed the very same solution vector
+    (avs_set_solution).  On the faces of its slab a rank's result equals the whole transfer bit for bit; every other face keeps the input."""
+    dev = torch.device("cuda:0")
+    sc = scenes.to_device(SCENES[scene]("cpu"), dev)
+    lib = capi.load()
+    pp0 = DevicePrepass(sc.res, sc.dx, sc.levels)
+    lv = pp0.run(sc.liquid, sc.solid).levels
+    cuts = _uniform_cuts(sc.res[axis], world)
+    grp = C.c_void_p()
+    capi.check(lib.avs_local_group_create(world, C.byref(grp)))
+    keep = []
+
+    def rank_fn(r):
+        s = ViscositySolve(sc.res, sc.dx, sc.dt, lv, device=0)
+        s.dist_init_local(grp, r)
+        pp = DevicePrepass(sc.res, sc.dx, sc.levels)
+        s.dist_bind_prepass(pp, cuts, axis)
+        assert pp.run(sc.liquid, sc.solid).levels == lv
+        pp.apply(s)
+        s.set_scene_fields(sc)
+        s.dist_assemble(axis)
+        info = s.dist_solve(1e-8, 5000)
+        assert info.converged == 1
+        x = s.dist_solution()                       # gathers the whole vector on every rank (and keeps it in the context)
+        outs = s.transfer_to_regular_grid()
+        outs2 = s.transfer_to_regular_grid()        # a second transfer runs on the first one's temporal records
+        vel = [v.clone() for v in sc.velocity]
+        s.transfer_to_regular_grid_in_place(vel)
+        keep.append((s, pp))
+        return x, outs, outs2, [v.cpu().numpy() for v in vel]
+
+    res = _run_threads(world, rank_fn)
+    x = res[0][0]
+    assert all(np.array_equal(x, r[0]) for r in res)
+    ref = ViscositySolve(sc.res, sc.dx, sc.dt, lv, device=0)
+    pp0.apply(ref)
+    ref.set_scene_fields(sc)
+    ref.assemble()
+    ref.set_solution(x)
+    want = ref.transfer_to_regular_grid()
+    vin = [v.cpu().numpy() for v in sc.velocity]
+    n_ax = sc.res[axis]
+    changed = 0
+    for r in range(world):
+        lo, hi = int(cuts[r]), int(cuts[r + 1])
+        for a in range(3):
+            ext = want[a].shape[2 - axis]
+            e = ext if r == world - 1 else hi          # (the last rank takes the face lattice's extra entry along the cut axis)
+            inside = [slice(None)] * 3
+            inside[2 - axis] = slice(lo, e)
+            inside = tuple(inside)
+            for got in (res[r][1][a], res[r][2][a], res[r][3][a]):
+                assert np.array_equal(got[inside], want[a][inside]), (r, a)
+                mask = np.ones(got.shape, bool)
+                mask[inside] = False
+                assert np.array_equal(got[mask], vin[a][mask]), (r, a, "outside the slab")
+            changed += int(np.count_nonzero(want[a][inside] != vin[a][inside]))
+    assert changed > 0 and n_ax > 0
+    for s, pp in keep:
+        s.close()
+        pp.close()
+    ref.close()
+    pp0.close()
+    lib.avs_local_group_destroy(grp)
+
+
 def test_slab_local_assembly_at_512(built_lib):
     """The headline scene (512^3 fat beam, 7.4 M rows) cut four ways: the slab-local path -- four pre-pass objects, each on its window -- gives
     every rank the plan arrays of the replicated-index assembly, entry for entry, and 60 iterations of the partitioned loop give the same bits."""
