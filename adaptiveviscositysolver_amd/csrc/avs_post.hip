@@ -526,16 +526,19 @@ __global__ __launch_bounds__(kBlock) void k_ridx_tile_flags(const int32_t *__res
 __global__ __launch_bounds__(kBlock) void k_apply_regular_tiled(PyramidView P, PostView W, int axis, const int32_t *__restrict__ ridx,
                                                                 const uint8_t *__restrict__ flags, RTileGrid tg, const double *__restrict__ x,
                                                                 const float *__restrict__ vel_in, float vel_const, float *__restrict__ out, int in_place,
-                                                                int s_axis = -1, int s_lo = 0, int s_hi = 0)
+                                                                int s_axis = -1, int s_lo = 0, int s_hi = 0, int ntx_launch = 0)
 {
-    // s_axis >= 0 (slab-local context): only the faces whose coordinate along s_axis lies in [s_lo, s_hi) are this rank's to write
+    // s_axis >= 0 (slab-local context): only the faces whose coordinate along s_axis lies in [s_lo, s_hi) are this rank's to write.
+    // ntx_launch > 0 (a slab along x, in-place form): the workgroups' 64-face rows START at s_lo -- with tiles on the lattice's own
+    // 64-face grid a 72-face slab touched three tile columns and two of them ran their waves for four live lanes (2.25 of a 3.1-ms transfer)
     const I3 fr = face_res(P, 0, axis);
     const int t = blockIdx.x;
-    const int tx = t % tg.t[0], ty = (t / tg.t[0]) % tg.t[1], tz = t / (tg.t[0] * tg.t[1]);
+    const int ntx = ntx_launch > 0 ? ntx_launch : tg.t[0];
+    const int tx = t % ntx, ty = (t / ntx) % tg.t[1], tz = t / (ntx * tg.t[1]);
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-    const int xx = tx * kRtX + lx;
+    const int xx = (ntx_launch > 0 ? s_lo : 0) + tx * kRtX + lx;
     if (xx >= fr[0]) return;
-    bool occupied = flags[t] != 0;
+    bool occupied = flags[(size_t)(xx / kRtX) + (size_t)tg.t[0] * ((size_t)ty + (size_t)tg.t[1] * (size_t)tz)] != 0;
     if (s_axis == 0 && (xx < s_lo || xx >= s_hi)) occupied = false;
     const bool same = in_place != 0; // in-place update of the caller's field (what the reference does to `vel`): untouched faces need no store
     for (int k = 0; k < kRtZ; ++k)
@@ -782,10 +785,17 @@ static avs_status transfer_impl(avs_ctx *c, float *out_x, float *out_y, float *o
         // the regular velocity field is updated in place in the reference: untouched faces keep the input velocity (copied tile by tile
         // in the same pass: k_apply_regular_tiled)
         const RTileGrid tg = rtile_grid(fr);
-        hipLaunchKernelGGL(k_apply_regular_tiled, dim3((unsigned)tg.vol()), dim3(kBlock), 0, st, P, W, a, (const int32_t *)c->ridx[a].p,
+        int ntx_launch = 0;
+        size_t blocks = tg.vol();
+        if (slab && s_axis == 0 && inpl) { // (the in-place form writes nothing outside the slab: rows of 64 faces from the slab's first face)
+            const int hi = s_hi < fr[0] ? s_hi : fr[0];
+            ntx_launch = hi > s_lo ? (hi - s_lo + kRtX - 1) / kRtX : 1;
+            blocks = (size_t)ntx_launch * tg.t[1] * tg.t[2];
+        }
+        hipLaunchKernelGGL(k_apply_regular_tiled, dim3((unsigned)blocks), dim3(kBlock), 0, st, P, W, a, (const int32_t *)c->ridx[a].p,
                            (const uint8_t *)c->ridx_tiles[a].p, tg, (const double *)c->x.p,
                            c->vel[a].is_const ? (const float *)nullptr : (const float *)c->vel[a].buf.p, (float)c->vel[a].cval, work, inpl ? 1 : 0,
-                           s_axis, s_lo, s_hi);
+                           s_axis, s_lo, s_hi, ntx_launch);
         AVS_HIP(hipGetLastError());
         if (padded) { // hand back the simulation grid's faces only
             if (where == AVS_MEM_DEVICE) AVS_TRY(crop_lattice_f32(work, fr[0], fr[1], fr[2], outs[a], sr[0], sr[1], sr[2], st));
