@@ -90,3 +90,14 @@ def test_product_never_imports_the_oracle():
                     "import" not in "".join(l for l in text.splitlines() if "oracle" in l.lower()), f
     for line in open(os.path.join(ROOT, "include", "avs.h")):
         assert "oracle" not in line.lower()
+
+
+def test_slab_margins_in_the_header_match_the_source():
+    """include/avs.h promises the slab-local window (slab +- 12 cells of every level, stencils within 4): the constants of the source."""
+    hdr = open(os.path.join(ROOT, "include", "avs.h")).read()
+    src = open(os.path.join(ROOT, "adaptiveviscositysolver_amd", "csrc", "avs_internal.hpp")).read()
+    index_margin = int(re.search(r"kSlabIndexMargin\s*=\s*(\d+)", src).group(1))
+    stencil_margin = int(re.search(r"kSlabStencilMargin\s*=\s*(\d+)", src).group(1))
+    assert f"slab +- {index_margin} level-l cells" in hdr
+    assert f"within {stencil_margin} cells (of their level)" in hdr
+    assert index_margin >= 2 * (stencil_margin + 1) + 1     # a stencil of the next coarser level reads 2 (margin + 1) + 1 cells of this one
