@@ -584,17 +584,17 @@ constexpr int kWorkLattices = 7;
 struct WorkLists {
     TileGrid tg[kWorkLattices];
     const uint8_t *now[kWorkLattices], *prev[kWorkLattices]; // prev: null = the lattice was filled afresh
-    int32_t *list[kWorkLattices];                            // [0]: count (zeroed by the caller), then tile ids; null = lattice unused
+    int32_t *cnt[kWorkLattices], *items[kWorkLattices];      // count (the counters lie behind each other: one memset zeroes them) and tile ids; null = lattice unused
 };
 __global__ __launch_bounds__(kBlock) void k_tile_worklists(WorkLists W)
 {
     const int k = blockIdx.y;
-    if (!W.list[k]) return;
+    if (!W.items[k]) return;
     const TileGrid tg = W.tg[k];
     const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (t >= tg.launch()) return;
     const unsigned tb = launch_tile(tg, (unsigned)t);
-    if (W.now[k][tb] || (W.prev[k] && W.prev[k][tb])) W.list[k][1 + atomicAdd(W.list[k], 1)] = (int32_t)tb; // (the order does not matter)
+    if (W.now[k][tb] || (W.prev[k] && W.prev[k][tb])) W.items[k][atomicAdd(W.cnt[k], 1)] = (int32_t)tb; // (the order does not matter)
 }
 constexpr unsigned kListGrid = 8192; // workgroups walking a list
 
@@ -662,11 +662,6 @@ __device__ __forceinline__ void classify_velocity_tile(const ClassifyArgs &A, co
         out[o] = v;
     }
 }
-__global__ __launch_bounds__(kBlock) void k_classify_velocity(ClassifyArgs A, Grid3 fg, TileGrid tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, const int32_t *__restrict__ list)
-{
-    const int n_list = list[0];
-    for (int li = (int)blockIdx.x; li < n_list; li += (int)gridDim.x) classify_velocity_tile(A, fg, tg, occ, out, (unsigned)list[1 + li]);
-}
 
 // classifyRegularVelocityFacesPartial, cpp:1087-1165 (no octree labels involved)
 __device__ __forceinline__ void classify_regular_tile(const ClassifyArgs &A, const Grid3 &fg, const TileGrid &tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, unsigned tb)
@@ -711,11 +706,6 @@ __device__ __forceinline__ void classify_regular_tile(const ClassifyArgs &A, con
         out[o] = v;
     }
 }
-__global__ __launch_bounds__(kBlock) void k_classify_regular(ClassifyArgs A, Grid3 fg, TileGrid tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, const int32_t *__restrict__ list)
-{
-    const int n_list = list[0];
-    for (int li = (int)blockIdx.x; li < n_list; li += (int)gridDim.x) classify_regular_tile(A, fg, tg, occ, out, (unsigned)list[1 + li]);
-}
 
 // classifyEdgeStressesPartial, cpp:1325-1405
 __device__ __forceinline__ void classify_edges_tile(const ClassifyArgs &A, const Grid3 &eg, const TileGrid &tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, unsigned tb)
@@ -754,11 +744,6 @@ __device__ __forceinline__ void classify_edges_tile(const ClassifyArgs &A, const
         out[o] = v;
     }
 }
-__global__ __launch_bounds__(kBlock) void k_classify_edges(ClassifyArgs A, Grid3 eg, TileGrid tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, const int32_t *__restrict__ list)
-{
-    const int n_list = list[0];
-    for (int li = (int)blockIdx.x; li < n_list; li += (int)gridDim.x) classify_edges_tile(A, eg, tg, occ, out, (unsigned)list[1 + li]);
-}
 
 // classifyCenterStressesPartial, cpp:1407-1443.  Round 5: the centre lattice by tiles, like the others.  A centre DOF needs an ACTIVE cell, and k_mark_tiles_all flags, for every ACTIVE
 // cell c, the tile of edge c of the axis-0 edge lattice -- whose tile COORDINATES are the cell's (c / 16 per axis; only the tile grid's
@@ -785,10 +770,43 @@ __device__ __forceinline__ void classify_centers_tiled_tile(const int8_t *__rest
         out[o] = (lab[o] == AVS_ACTIVE && (level != 0 || centerw[o] > 0.f)) ? 0 : AVS_UNASSIGNED;
     }
 }
-__global__ __launch_bounds__(kBlock) void k_classify_centers_tiled(const int8_t *__restrict__ lab, const float *__restrict__ centerw, int level, Grid3 cg, TileGrid tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, const int32_t *__restrict__ list)
+
+// All lattices of a level in ONE launch (blockIdx.y names the lattice; round 6): a launch per lattice -- seven per level and three for the
+// regular grid, each with its own list-counter memset and occupancy copy -- made the classification of the reference's own scenes (304 x 80 x 80:
+// a dozen occupied tiles per lattice) a hundred launches of fixed cost.  The same launch keeps the occupancy the lattice was classified
+// with (`remember`: the record the NEXT frame's reset list is built from; nobody reads the old record any more once the lists exist).
+struct ClassifyBatch {
+    ClassifyArgs A;                  // level, labels, weights, solid; the axis comes per lattice
+    int kind[kWorkLattices];         // 0 velocity faces, 1 edges, 2 centres, 3 regular-grid faces, -1 unused
+    int axis[kWorkLattices];
+    Grid3 g[kWorkLattices];
+    TileGrid tg[kWorkLattices];
+    const uint8_t *occ[kWorkLattices];
+    uint8_t *remember[kWorkLattices];
+    int32_t *out[kWorkLattices];
+    const int32_t *cnt[kWorkLattices], *items[kWorkLattices];
+    unsigned occ_cap;
+};
+__global__ __launch_bounds__(kBlock) void k_classify_batch(ClassifyBatch B)
 {
-    const int n_list = list[0];
-    for (int li = (int)blockIdx.x; li < n_list; li += (int)gridDim.x) classify_centers_tiled_tile(lab, centerw, level, cg, tg, occ, out, (unsigned)list[1 + li]);
+    const int k = blockIdx.y;
+    const int kind = B.kind[k];
+    if (kind < 0) return;
+    ClassifyArgs A = B.A;
+    A.axis = B.axis[k];
+    const Grid3 g = B.g[k];
+    const TileGrid tg = B.tg[k];
+    const uint8_t *occ = B.occ[k];
+    int32_t *out = B.out[k];
+    const int n_list = *B.cnt[k];
+    for (int li = (int)blockIdx.x; li < n_list; li += (int)gridDim.x) {
+        const unsigned tb = (unsigned)B.items[k][li];
+        if (kind == 0) classify_velocity_tile(A, g, tg, occ, out, tb);
+        else if (kind == 1) classify_edges_tile(A, g, tg, occ, out, tb);
+        else if (kind == 2) classify_centers_tiled_tile(A.lab, A.centerw, A.level, g, tg, occ, out, tb);
+        else classify_regular_tile(A, g, tg, occ, out, tb);
+    }
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < B.occ_cap; i += gridDim.x * kBlock) B.remember[k][i] = occ[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1180,12 +1198,6 @@ static avs_status unassign_lattice(avs_prepass *p, SharedBuf<int32_t> &buf, Grid
     *out = ts;
     return AVS_OK;
 }
-static avs_status remember_tiles(avs_prepass *p, avs_prepass::TileState *ts, uint64_t id, const uint8_t *occ, size_t occ_cap)
-{
-    AVS_HIP(hipMemcpyAsync(ts->occ.p, occ, occ_cap, hipMemcpyDeviceToDevice, p->stream));
-    ts->id = id;
-    return AVS_OK;
-}
 
 struct EvTimer {
     hipEvent_t a = nullptr, b = nullptr;
@@ -1534,11 +1546,21 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         // the seven lattices of the level: fresh fill or the record of the last classification, ONE launch that lists the tiles to touch,
         // then one classification launch per lattice over its list
         WorkLists W{};
+        ClassifyBatch B{};
         avs_prepass::TileState *tss[kWorkLattices] = {};
         const TileGrid tc = win_tiles(cr, l);
         uint8_t *occ_c = ob + 6 * occ_cap;
         hipLaunchKernelGGL(k_center_tiles, dim3(grid_for(tc.vol())), dim3(kBlock), 0, st, (const uint8_t *)T.occ[1][0], T.tg[1][0], tc, occ_c);
-        AVS_TRY(p->work_lists.reserve((size_t)kWorkLattices * (occ_cap + 1)));
+        AVS_TRY(p->work_lists.reserve(8 + (size_t)kWorkLattices * occ_cap)); // [8 counters | 7 x tile ids]
+        AVS_HIP(hipMemsetAsync(p->work_lists.p, 0, 8 * sizeof(int32_t), st));
+        B.A.n[0] = d.nx; B.A.n[1] = d.ny; B.A.n[2] = d.nz;
+        B.A.level = l;
+        B.A.extrapolation = extrapolation;
+        B.A.lab = p->labels[l].p;
+        B.A.centerw = p->centerw.p;
+        for (int b2 = 0; b2 < 3; ++b2) B.A.edgew[b2] = p->edgew[b2].p;
+        B.A.solid = p->sol;
+        B.occ_cap = (unsigned)occ_cap;
         size_t max_launch = 0;
         for (int k = 0; k < kWorkLattices; ++k) {
             const int kind = k < 3 ? 0 : (k < 6 ? 1 : 2), a = k < 6 ? k % 3 : 0;
@@ -1549,78 +1571,64 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
             if (g3(gr).vol() > max_vol) max_vol = g3(gr).vol();
             W.tg[k] = kind == 2 ? tc : T.tg[kind][a];
             W.now[k] = kind == 2 ? occ_c : T.occ[kind][a];
-            W.list[k] = p->work_lists.p + (size_t)k * (occ_cap + 1);
+            W.cnt[k] = p->work_lists.p + k;
+            W.items[k] = p->work_lists.p + 8 + (size_t)k * occ_cap;
             const Box3 wb = win_box(gr, l);
             AVS_TRY(unassign_lattice(p, buf, g3(gr), W.tg[k], occ_cap, kind == 0 ? p->vstate[l][a] : (kind == 1 ? p->estate[l][a] : p->cstate[l]), &tss[k],
                                      slab ? &wb : nullptr, &W.prev[k]));
-            AVS_HIP(hipMemsetAsync(W.list[k], 0, sizeof(int32_t), st));
             if (W.tg[k].launch() > max_launch) max_launch = W.tg[k].launch();
+            B.kind[k] = kind; B.axis[k] = a; B.g[k] = g3(gr); B.tg[k] = W.tg[k]; B.occ[k] = W.now[k]; B.remember[k] = tss[k]->occ.p; B.out[k] = buf.p;
+            B.cnt[k] = W.cnt[k]; B.items[k] = W.items[k];
         }
         if (max_launch) hipLaunchKernelGGL(k_tile_worklists, dim3(grid_for(max_launch), kWorkLattices), dim3(kBlock), 0, st, W);
-        for (int k = 0; k < kWorkLattices && max_launch; ++k) {
-            const int kind = k < 3 ? 0 : (k < 6 ? 1 : 2), a = k < 6 ? k % 3 : 0;
-            int gr[3];
-            pp_res(d, kind, l, a, gr);
-            SharedBuf<int32_t> &buf = kind == 0 ? p->vidx[l][a] : (kind == 1 ? p->eidx[l][a] : p->cidx[l]);
-            const unsigned grid = (unsigned)(W.tg[k].launch() < kListGrid ? (W.tg[k].launch() ? W.tg[k].launch() : 1) : kListGrid);
-            if (kind == 2) {
-                hipLaunchKernelGGL(k_classify_centers_tiled, dim3(grid), dim3(kBlock), 0, st, p->labels[l].p, p->centerw.p, l, g3(gr), W.tg[k], W.now[k], buf.p,
-                                   (const int32_t *)W.list[k]);
-            } else {
-                ClassifyArgs A{};
-                A.n[0] = d.nx; A.n[1] = d.ny; A.n[2] = d.nz;
-                A.level = l;
-                A.axis = a;
-                A.extrapolation = extrapolation;
-                A.lab = p->labels[l].p;
-                A.centerw = p->centerw.p;
-                for (int b = 0; b < 3; ++b) A.edgew[b] = p->edgew[b].p;
-                A.solid = p->sol;
-                if (kind == 0) hipLaunchKernelGGL(k_classify_velocity, dim3(grid), dim3(kBlock), 0, st, A, g3(gr), W.tg[k], W.now[k], buf.p, (const int32_t *)W.list[k]);
-                else hipLaunchKernelGGL(k_classify_edges, dim3(grid), dim3(kBlock), 0, st, A, g3(gr), W.tg[k], W.now[k], buf.p, (const int32_t *)W.list[k]);
-            }
+        {   // (with no tile to launch over the occupancy is still remembered: the grid has at least one workgroup per lattice)
+            const unsigned grid = (unsigned)(max_launch < kListGrid ? (max_launch ? max_launch : 1) : kListGrid);
+            hipLaunchKernelGGL(k_classify_batch, dim3(grid, kWorkLattices), dim3(kBlock), 0, st, B);
             AVS_HIP(hipGetLastError());
         }
-        for (int k = 0; k < kWorkLattices; ++k) { // (behind the classifications: the lists were built from the old records)
+        for (int k = 0; k < kWorkLattices; ++k) { // the records describe these allocations from here on
             const int kind = k < 3 ? 0 : (k < 6 ? 1 : 2), a = k < 6 ? k % 3 : 0;
             SharedBuf<int32_t> &buf = kind == 0 ? p->vidx[l][a] : (kind == 1 ? p->eidx[l][a] : p->cidx[l]);
-            AVS_TRY(remember_tiles(p, tss[k], buf.id, W.now[k], occ_cap));
+            tss[k]->id = buf.id;
         }
     }
     { // regular-grid faces, cpp:1457-1481: the occupancy of the level-0 face lattices, marked above by the same rule (kind 0, SDF)
         WorkLists W{};
+        ClassifyBatch B{};
         avs_prepass::TileState *tss[3] = {};
         size_t max_launch = 0;
+        AVS_TRY(p->work_lists.reserve(8 + (size_t)kWorkLattices * occ_cap));
+        AVS_HIP(hipMemsetAsync(p->work_lists.p, 0, 8 * sizeof(int32_t), st));
+        B.A.n[0] = d.nx; B.A.n[1] = d.ny; B.A.n[2] = d.nz;
+        B.A.level = 0;
+        B.A.extrapolation = extrapolation;
+        B.A.lab = p->labels[0].p;
+        B.A.centerw = p->centerw.p;
+        for (int b2 = 0; b2 < 3; ++b2) B.A.edgew[b2] = p->edgew[b2].p;
+        B.A.solid = p->sol;
+        B.occ_cap = (unsigned)occ_cap;
+        for (int k = 0; k < kWorkLattices; ++k) B.kind[k] = -1;
         for (int a = 0; a < 3; ++a) {
             int gr[3];
             pp_res(d, 0, 0, a, gr);
             AVS_TRY(p->ridx[a].alloc(g3(gr).vol()));
             W.tg[a] = tg0[a];
             W.now[a] = occ_all.p + (size_t)a * occ_cap;
-            W.list[a] = p->work_lists.p + (size_t)a * (occ_cap + 1);
+            W.cnt[a] = p->work_lists.p + a;
+            W.items[a] = p->work_lists.p + 8 + (size_t)a * occ_cap;
             const Box3 wb = win_box(gr, 0);
             AVS_TRY(unassign_lattice(p, p->ridx[a], g3(gr), W.tg[a], occ_cap, p->rstate[a], &tss[a], slab ? &wb : nullptr, &W.prev[a]));
-            AVS_HIP(hipMemsetAsync(W.list[a], 0, sizeof(int32_t), st));
             if (W.tg[a].launch() > max_launch) max_launch = W.tg[a].launch();
+            B.kind[a] = 3; B.axis[a] = a; B.g[a] = g3(gr); B.tg[a] = W.tg[a]; B.occ[a] = W.now[a]; B.remember[a] = tss[a]->occ.p; B.out[a] = p->ridx[a].p;
+            B.cnt[a] = W.cnt[a]; B.items[a] = W.items[a];
         }
         if (max_launch) hipLaunchKernelGGL(k_tile_worklists, dim3(grid_for(max_launch), kWorkLattices), dim3(kBlock), 0, st, W);
-        for (int a = 0; a < 3 && max_launch; ++a) {
-            int gr[3];
-            pp_res(d, 0, 0, a, gr);
-            ClassifyArgs A{};
-            A.n[0] = d.nx; A.n[1] = d.ny; A.n[2] = d.nz;
-            A.level = 0;
-            A.axis = a;
-            A.extrapolation = extrapolation;
-            A.lab = p->labels[0].p;
-            A.centerw = p->centerw.p;
-            for (int b = 0; b < 3; ++b) A.edgew[b] = p->edgew[b].p;
-            A.solid = p->sol;
-            const unsigned grid = (unsigned)(W.tg[a].launch() < kListGrid ? (W.tg[a].launch() ? W.tg[a].launch() : 1) : kListGrid);
-            hipLaunchKernelGGL(k_classify_regular, dim3(grid), dim3(kBlock), 0, st, A, g3(gr), W.tg[a], W.now[a], p->ridx[a].p, (const int32_t *)W.list[a]);
+        {
+            const unsigned grid = (unsigned)(max_launch < kListGrid ? (max_launch ? max_launch : 1) : kListGrid);
+            hipLaunchKernelGGL(k_classify_batch, dim3(grid, kWorkLattices), dim3(kBlock), 0, st, B);
             AVS_HIP(hipGetLastError());
         }
-        for (int a = 0; a < 3; ++a) AVS_TRY(remember_tiles(p, tss[a], p->ridx[a].id, W.now[a], occ_cap));
+        for (int a = 0; a < 3; ++a) tss[a]->id = p->ridx[a].id;
     }
     AVS_HIP(hipGetLastError());
     if (!slab) { // cap at the first level without ACTIVE cells, oct.cpp:198-211
