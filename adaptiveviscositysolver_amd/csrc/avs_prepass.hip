@@ -5,17 +5,21 @@
 //                        reference tree: fraction of n^3 sub-samples with interpolated SDF < 0, defined in
 //                        oracle/avs_oracle.c and restated identically here, fp32, x then y then z); bricks whose SDF
 //                        window has one sign are finished by the first kernel, the surface bricks by the second
-//   P2 k_mask_labels     refinement mask + level-0 labels (cpp:815-867, oct.cpp:383-388)
+//   P2 k_mask_labels     refinement mask + level-0 labels (cpp:815-867, oct.cpp:383-388); marks the tiles of the level-0 face lattices
+//                        on the way (the SDF rule, cpp:907)
 //   P3 k_oct_*           label pyramid, three passes per level (oct.cpp:93-189) + top level (oct.cpp:843-875)
-//   P4 k_mark_tiles_all + k_classify_*  tile occupancy (six lattices of a level per launch) + face / edge / centre
-//                        classification (cpp:886-1443): lattices pre-filled with UNASSIGNED, occupied tiles classified
-//   P5 k_tile_counts + scan + k_tile_ids   serial numbering in HDK 16^3 tile order (cpp:1566-1593, 1635-1660,
-//                        1688-1712): per-tile counts, exclusive scan over the tiles, ranks inside a tile by wave ballots;
-//                        tiles the classification never visited are skipped
+//   P4 k_mark_tiles_all + k_tile_worklists + k_classify_batch  tile occupancy (all lattices of a level from one read of its labels; the
+//                        level's "has an ACTIVE cell" flag too) + face / edge / centre / regular-face classification (cpp:886-1443) of the
+//                        LISTED tiles -- occupied now, or visited by the allocation's last classification (reset) -- all lattices
+//                        of a level in one launch
+//   P5 k_tile_select + k_tile_counts + scan + k_tile_select_ids + k_tile_ids   serial numbering in HDK 16^3 tile order (cpp:1566-1593,
+//                        1635-1660, 1688-1712): counts of the listed tiles, exclusive scan over all tiles, ranks inside a tile by wave ballots
+//   slab-local mode (avs_prepass_set_slab): every step on the rank's window only (Box3 sweeps, TileGrid launch boxes),
+//                        the reference's GLOBAL ids through one all-reduce of the per-tile counts
 //
-// Every per-voxel rule is a gather from the finer / same level: one thread per output voxel (or per
-// parent cell), deterministic (the only atomic appends surface bricks to a list whose order does not matter).  All integer
-// outputs are bit-identical to the oracle and to the tensor-op restatement tests/prepass_torch.py (tests/test_gpu_prepass.py).
+// Every per-voxel rule is a gather from the finer / same level: one thread per output voxel (or per parent cell), deterministic (the
+// atomics append to lists -- surface bricks, tiles -- whose order does not matter).  All integer outputs are bit-identical to the oracle
+// and to the tensor-op restatement tests/prepass_torch.py (tests/test_gpu_prepass.py).
 #include <cmath>
 #include <climits>
 #include <new>
@@ -1171,7 +1175,7 @@ static avs_status run_weights(avs_prepass *p, WeightFields &F)
 }
 
 // Index lattice -> AVS_UNASSIGNED everywhere.  `states`: the two records of this lattice (one per allocation of its SharedBuf).  Returns
-// the record to fill in once the classification is enqueued (remember_tiles); until then the record is void (id 0), so a run that
+// the record the classification launch fills in (k_classify_batch keeps the occupancy; the id is set behind it); until then the record is void (id 0), so a run that
 // fails in between leaves no stale claim about the allocation.
 static avs_status unassign_lattice(avs_prepass *p, SharedBuf<int32_t> &buf, Grid3 g, TileGrid tg, size_t occ_cap, avs_prepass::TileState states[2],
                                    avs_prepass::TileState **out, const Box3 *window, const uint8_t **prev_occ)
