@@ -558,6 +558,7 @@ avs_status avs_assemble(avs_ctx *c, avs_assembly_info *info)
         c->brick_shift = c->opt.brick_shift;
         if (c->brick_shift >= 0) AVS_TRY(build_reordered_system(c, c->brick_shift));
         c->ainfo.csr_ms = t.stop();
+        if (c->opt.trace_phases) fprintf(stderr, "[avs assemble] stencils %.3f guess %.3f system %.3f csr %.3f ms\n", c->ainfo.stencil_ms, c->ainfo.guess_ms, c->ainfo.system_ms, c->ainfo.csr_ms);
     }
     c->ainfo.n_velocity = c->n_vel;
     c->ainfo.n_edge = c->n_edge;

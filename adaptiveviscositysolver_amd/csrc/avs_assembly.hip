@@ -1269,6 +1269,7 @@ avs_status assemble_rows(avs_ctx *c, const int32_t *ids, int64_t m, DevBuf<int32
     AVS_HIP(hipMemsetAsync(err.p, 0, sizeof(int), st));
     PyramidView P = c->view();
     StencilView E = edge_view(c), C = center_view(c);
+    PhaseTrace tr(st, "rows", cur_opt().trace_phases != 0);
     // K4 dry run -> raw triplet counts
     if (n) hipLaunchKernelGGL((k_rows<false>), dim3(grid_for(n)), dim3(kBlock), 0, st, P, c->vdof.p, n, E, C, c->x0.p,
                               (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr, row_count.p, (double *)nullptr, err.p, ids);
@@ -1284,6 +1285,7 @@ avs_status assemble_rows(avs_ctx *c, const int32_t *ids, int64_t m, DevBuf<int32
     int32_t nslots = 0;
     AVS_HIP(hipMemcpyAsync(&nslots, rawptr.p + nwaves, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     AVS_HIP(hipStreamSynchronize(st));
+    tr.mark("dry run, scans");
     AVS_REQUIRE(nraw >= 0 && nslots >= 0, AVS_EINVAL, "raw triplet count exceeds int32 (the scan reports -1 for any total above INT32_MAX)");
     if (nraw_out) *nraw_out = nraw;
     AVS_TRY(raw_col.reserve((size_t)nslots));
@@ -1302,6 +1304,7 @@ avs_status assemble_rows(avs_ctx *c, const int32_t *ids, int64_t m, DevBuf<int32
     AVS_HIP(hipMemcpyAsync(&nnz, row_ptr.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     int e = 0;
     AVS_TRY(read_err(err.p, st, &e));
+    tr.mark("emit, unique, scan");
     AVS_REQUIRE(e == 0, AVS_EINTERNAL, "row assembly hit a reference assert (code %d): stencils and index pyramids disagree", e);
     AVS_REQUIRE(nnz >= 0, AVS_EINVAL, "non-zero count exceeds int32");
     if (nnz_out) *nnz_out = nnz;
@@ -1316,6 +1319,7 @@ avs_status assemble_rows(avs_ctx *c, const int32_t *ids, int64_t m, DevBuf<int32
                            (const double *)raw_val.p, (const int32_t *)row_count.p, (const int32_t *)row_ptr.p, col.p, val.p);
     AVS_HIP(hipGetLastError());
     AVS_HIP(hipStreamSynchronize(st)); // the caller may read nnz-sized results right away; the raw buffers stay in the context
+    tr.mark("merge");
     return AVS_OK;
 }
 
