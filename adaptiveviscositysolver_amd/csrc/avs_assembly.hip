@@ -764,7 +764,8 @@ static constexpr int32_t kDupBit = (int32_t)0x80000000u; // rows of > 64 raw ent
 static constexpr int32_t kColMask = 0x7fffffff;
 
 __global__ __launch_bounds__(kBlock) void k_unique_rows(int64_t n, const int32_t *__restrict__ rawptr, int32_t *__restrict__ raw_col,
-                                                        const int32_t *__restrict__ row_count, int32_t *__restrict__ ucount)
+                                                        const int32_t *__restrict__ row_count, int32_t *__restrict__ ucount,
+                                                        int32_t *__restrict__ long_rows /* [0]: count (zeroed by the caller), then rows of > 64 raw entries */)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -778,11 +779,34 @@ __global__ __launch_bounds__(kBlock) void k_unique_rows(int64_t n, const int32_t
         load_cols(raw_col + wbase + lane, R, c);
         ucount[row] = __popc(first_mask_fast(c, R, wmax));
     }
-    unsigned long long todo = __ballot(row < n && R > 64);
-    while (todo) { // longer rows (a coarse face surrounded by finer ones; a handful per scene): 64 entries at a time against the
-        const int which = __ffsll((long long)todo) - 1; // earlier ones; every later duplicate gets the sign bit, so that
-        todo &= todo - 1;                               // k_merge_rows does not have to search for first occurrences again
+    // longer rows (a coarse face surrounded by finer ones) go on a list for k_unique_long: they are consecutive DOFs of the coarsest level,
+    // i.e. they all sat in the LAST waves of this launch, which walked them one after the other (R^2 steps each) while the rest of the
+    // GPU was done -- viscousBeam equivalent: 325 us for 469 k rows, a third of what 7.4 M rows take
+    if (row < n && R > 64) long_rows[1 + atomicAdd(long_rows, 1)] = (int32_t)row; // (the order of the list does not matter)
+    unsigned long long todo = __ballot(row < n && R > kFast && R <= 64);
+    while (todo) { // wave-uniform loop over the rows that need the whole wave
+        const int which = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
         const int Rr = __builtin_amdgcn_readlane(R, which);
+        const int32_t c_e = lane < Rr ? raw_col[wbase + (size_t)lane * kRawStride + which] : INT32_MAX;
+        const unsigned long long firsts = __ballot(coop_first(c_e, Rr, lane));
+        if (lane == which) ucount[row] = __popcll(firsts);
+    }
+}
+
+// one WAVE per listed row of more than 64 raw entries: 64 entries at a time against the earlier ones; every later duplicate gets the sign
+// bit, so that k_merge_long does not have to search for first occurrences again
+__global__ __launch_bounds__(kBlock) void k_unique_long(const int32_t *__restrict__ rawptr, int32_t *__restrict__ raw_col, const int32_t *__restrict__ row_count,
+                                                        int32_t *__restrict__ ucount, const int32_t *__restrict__ long_rows)
+{
+    const int lane = threadIdx.x & 63;
+    const int nw = (int)gridDim.x * (kBlock / 64);
+    const int n_list = long_rows[0];
+    for (int li = (int)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); li < n_list; li += nw) {
+        const int64_t row = long_rows[1 + li];
+        const int which = (int)(row & 63);
+        const size_t wbase = (size_t)rawptr[row >> 6];
+        const int Rr = row_count[row];
         int count = 0;
         for (int a0 = 0; a0 < Rr; a0 += 64) {
             const int e = a0 + lane;
@@ -800,19 +824,11 @@ __global__ __launch_bounds__(kBlock) void k_unique_rows(int64_t n, const int32_t
             if (e < Rr && !first) raw_col[at] = c_e | kDupBit;
             count += __popcll(__ballot(first));
         }
-        if (lane == which) ucount[row] = count;
-    }
-    todo = __ballot(row < n && R > kFast && R <= 64);
-    while (todo) { // wave-uniform loop over the rows that need the whole wave
-        const int which = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const int Rr = __builtin_amdgcn_readlane(R, which);
-        const int32_t c_e = lane < Rr ? raw_col[wbase + (size_t)lane * kRawStride + which] : INT32_MAX;
-        const unsigned long long firsts = __ballot(coop_first(c_e, Rr, lane));
-        if (lane == which) ucount[row] = __popcll(firsts);
+        if (lane == 0) ucount[row] = count;
     }
 }
 
+static constexpr unsigned kLongGrid = 512; // workgroups (four waves each) walking the list of long rows
 static constexpr int kMergeLds = 1088; // merged entries of one wave staged in LDS (64 rows x 17; interior rows have 15): 12.75 KiB per wave, 3 workgroups per CU
 
 // F32: the duplicates of SolveType = fpreal32 triplets are summed in float (Eigen::SparseMatrix<float>::setFromTriplets); the raw values
@@ -891,41 +907,8 @@ __global__ __launch_bounds__(kBlock) void k_merge_rows(int64_t n, const int32_t 
         }
         done = true;
     }
-    unsigned long long todo = __ballot(row < n && R > 64);
-    while (todo) { // rows of more than 64 raw entries, any length: the whole wave, 64 entries at a time against 64 at a time
-        const int which = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const int Rr = __builtin_amdgcn_readlane(R, which);
-        const int dr = __builtin_amdgcn_readlane(dst0, which);
-        for (int a0 = 0; a0 < Rr; a0 += 64) {
-            const int e = a0 + lane;
-            const size_t at = wbase + (size_t)e * kRawStride + which;
-            const int32_t craw = e < Rr ? raw_col[at] : INT32_MAX;   // sign bit: a later duplicate (k_unique_rows)
-            const bool first = e < Rr && craw >= 0;
-            const int32_t c_e = craw & kColMask;
-            double sum = e < Rr ? raw_val[at] : 0.;
-            int urank = 0;
-            for (int b0 = 0; b0 < Rr; b0 += 64) {
-                const int eb = b0 + lane;
-                const size_t bt = wbase + (size_t)eb * kRawStride + which;
-                const int32_t cb = eb < Rr ? raw_col[bt] : INT32_MAX;
-                const double vb = eb < Rr ? raw_val[bt] : 0.;
-                const int nb = Rr - b0 < 64 ? Rr - b0 : 64;
-                for (int q = 0; q < nb; ++q) {
-                    const int32_t cq = __builtin_amdgcn_readlane(cb, q);
-                    const double vq = lane_bcast(vb, q);
-                    if (cq >= 0 && cq < c_e) ++urank;                                   // first occurrences only
-                    if (first && b0 + q > e && (cq & kColMask) == c_e) sum = merge_add<F32>(sum, vq); // left fold in emission order
-                }
-            }
-            if (first) {
-                ocw[dr - ooff + urank] = c_e;
-                ovw[dr - ooff + urank] = sum;
-            }
-        }
-        if (lane == which) done = true;
-    }
-    todo = __ballot(!done);
+    if (R > 64) done = true; // (k_merge_long, one wave per such row, behind this launch)
+    unsigned long long todo = __ballot(!done);
     while (todo) { // rows of 33..64 raw entries: the whole wave, lane e = raw entry e
         const int which = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
@@ -955,6 +938,51 @@ __global__ __launch_bounds__(kBlock) void k_merge_rows(int64_t n, const int32_t 
             col[seg0 + e] = lcol[wv][e];
             val[seg0 + e] = lval[wv][e];
         }
+}
+
+// rows of more than 64 raw entries, any length: ONE WAVE per listed row, 64 entries at a time against 64 at a time, straight into the CSR
+// (launched behind k_merge_rows: where that kernel staged the wave's segment in LDS it copied these rows' slots unset)
+template <bool F32>
+__global__ __launch_bounds__(kBlock) void k_merge_long(const int32_t *__restrict__ rawptr, const int32_t *__restrict__ raw_col, const double *__restrict__ raw_val,
+                                                       const int32_t *__restrict__ row_count, const int32_t *__restrict__ row_ptr, int32_t *__restrict__ col,
+                                                       double *__restrict__ val, const int32_t *__restrict__ long_rows)
+{
+    const int lane = threadIdx.x & 63;
+    const int nw = (int)gridDim.x * (kBlock / 64);
+    const int n_list = long_rows[0];
+    for (int li = (int)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); li < n_list; li += nw) {
+        const int64_t row = long_rows[1 + li];
+        const int which = (int)(row & 63);
+        const size_t wbase = (size_t)rawptr[row >> 6];
+        const int Rr = row_count[row];
+        const int dr = row_ptr[row];
+        for (int a0 = 0; a0 < Rr; a0 += 64) {
+            const int e = a0 + lane;
+            const size_t at = wbase + (size_t)e * kRawStride + which;
+            const int32_t craw = e < Rr ? raw_col[at] : INT32_MAX;   // sign bit: a later duplicate (k_unique_long)
+            const bool first = e < Rr && craw >= 0;
+            const int32_t c_e = craw & kColMask;
+            double sum = e < Rr ? raw_val[at] : 0.;
+            int urank = 0;
+            for (int b0 = 0; b0 < Rr; b0 += 64) {
+                const int eb = b0 + lane;
+                const size_t bt = wbase + (size_t)eb * kRawStride + which;
+                const int32_t cb = eb < Rr ? raw_col[bt] : INT32_MAX;
+                const double vb = eb < Rr ? raw_val[bt] : 0.;
+                const int nb = Rr - b0 < 64 ? Rr - b0 : 64;
+                for (int q = 0; q < nb; ++q) {
+                    const int32_t cq = __builtin_amdgcn_readlane(cb, q);
+                    const double vq = lane_bcast(vb, q);
+                    if (cq >= 0 && cq < c_e) ++urank;                                   // first occurrences only
+                    if (first && b0 + q > e && (cq & kColMask) == c_e) sum = merge_add<F32>(sum, vq); // left fold in emission order
+                }
+            }
+            if (first) {
+                col[dr + urank] = c_e;
+                val[dr + urank] = sum;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1296,8 +1324,13 @@ avs_status assemble_rows(avs_ctx *c, const int32_t *ids, int64_t m, DevBuf<int32
     if (n) {
         hipLaunchKernelGGL((k_rows<true>), dim3(grid_for(n)), dim3(kBlock), 0, st, P, c->vdof.p, n, E, C, c->x0.p,
                            (const int32_t *)rawptr.p, raw_col.p, raw_val.p, row_count.p, rhs.p, err.p, ids);
+        DevBuf<int32_t> &long_rows = c->scratch.long_rows;
+        AVS_TRY(long_rows.reserve((size_t)n + 1));
+        AVS_HIP(hipMemsetAsync(long_rows.p, 0, sizeof(int32_t), st));
         hipLaunchKernelGGL(k_unique_rows, dim3(grid_for(n + 1)), dim3(kBlock), 0, st, n, (const int32_t *)rawptr.p, (int32_t *)raw_col.p,
-                           (const int32_t *)row_count.p, ucount.p);
+                           (const int32_t *)row_count.p, ucount.p, long_rows.p);
+        hipLaunchKernelGGL(k_unique_long, dim3(kLongGrid), dim3(kBlock), 0, st, (const int32_t *)rawptr.p, (int32_t *)raw_col.p, (const int32_t *)row_count.p,
+                           ucount.p, (const int32_t *)long_rows.p);
     }
     AVS_TRY(exclusive_scan_i32(ucount.p, row_ptr.p, n, scan_tmp.p, scan_tmp.n, st));
     int32_t nnz = 0;
@@ -1317,6 +1350,12 @@ avs_status assemble_rows(avs_ctx *c, const int32_t *ids, int64_t m, DevBuf<int32
     else if (n)
         hipLaunchKernelGGL(k_merge_rows<false>, dim3(grid_for(n)), dim3(kBlock), 0, st, n, (const int32_t *)rawptr.p, (const int32_t *)raw_col.p,
                            (const double *)raw_val.p, (const int32_t *)row_count.p, (const int32_t *)row_ptr.p, col.p, val.p);
+    if (n && c->desc.precision == AVS_PRECISION_F32)
+        hipLaunchKernelGGL(k_merge_long<true>, dim3(kLongGrid), dim3(kBlock), 0, st, (const int32_t *)rawptr.p, (const int32_t *)raw_col.p, (const double *)raw_val.p,
+                           (const int32_t *)row_count.p, (const int32_t *)row_ptr.p, col.p, val.p, (const int32_t *)c->scratch.long_rows.p);
+    else if (n)
+        hipLaunchKernelGGL(k_merge_long<false>, dim3(kLongGrid), dim3(kBlock), 0, st, (const int32_t *)rawptr.p, (const int32_t *)raw_col.p, (const double *)raw_val.p,
+                           (const int32_t *)row_count.p, (const int32_t *)row_ptr.p, col.p, val.p, (const int32_t *)c->scratch.long_rows.p);
     AVS_HIP(hipGetLastError());
     AVS_HIP(hipStreamSynchronize(st)); // the caller may read nnz-sized results right away; the raw buffers stay in the context
     tr.mark("merge");

@@ -795,7 +795,7 @@ struct avs_ctx {
     // scratch of the assembly kept between frames (raw triplets: 1.5 GB at 512^3 -- allocating and freeing it every call cost
     // several ms of host time; with 288 GB of HBM it simply stays)
     struct AsmScratch {
-        avs::DevBuf<int32_t> row_count, rawptr, scan_tmp, raw_col, len_new, ids_in, wave_slots, ucount, coarse_list;
+        avs::DevBuf<int32_t> row_count, rawptr, scan_tmp, raw_col, len_new, ids_in, wave_slots, ucount, coarse_list, long_rows;
         avs::DevBuf<double> raw_val;
         avs::DevBuf<uint32_t> keys_in, keys_out;
         avs::DevBuf<char> sort_tmp;
