@@ -413,8 +413,12 @@ def test_slab_local_assembly_at_512(built_lib):
             info = s.dist_solve(1e-30, 60)     # (never converges: 60 iterations of a deterministic loop)
             x = s.dist_solution()
             _, cuts = s.dist_cuts(world, 0)
+            vel = None
+            if slab_cuts is not None:   # the transfer of the rank's slab, in place (rows of 64 faces from the slab's first face)
+                vel = [v.clone() for v in sc.velocity]
+                s.transfer_to_regular_grid_in_place(vel)
             solvers.append(s)
-            return dict(nnz=ai.nnz, plan=plan, it=info.iterations, x=x, cuts=cuts, window=pp.window() if slab_cuts is not None else None)
+            return dict(nnz=ai.nnz, plan=plan, it=info.iterations, x=x, cuts=cuts, vel=vel, window=pp.window() if slab_cuts is not None else None)
 
         out = _run_threads(world, rank_fn)
         for s in solvers:
@@ -437,3 +441,26 @@ def test_slab_local_assembly_at_512(built_lib):
         assert b["window"][2][0] < 0.45 * n      # a rank's window holds well under half of the DOFs (a quarter + the halo)
     owned = np.concatenate([loc[r]["plan"]["own_global"] for r in range(world)])
     assert len(owned) == n and np.array_equal(np.sort(owned), np.arange(n, dtype=np.int32))
+    # the transfer: ONE context with the whole pyramid, handed the same vector, against every rank's slab
+    pp0 = DevicePrepass(sc.res, sc.dx, sc.levels)
+    pp0.run(sc.liquid, sc.solid)
+    ref = ViscositySolve(sc.res, sc.dx, sc.dt, sc.levels, device=0)
+    pp0.apply(ref)
+    ref.set_scene_fields(sc)
+    ref.assemble()
+    ref.set_solution(loc[0]["x"])
+    want = [v.clone() for v in sc.velocity]
+    ref.transfer_to_regular_grid_in_place(want)
+    cuts = rep[0]["cuts"]
+    changed = 0
+    for r in range(world):
+        lo, hi = int(cuts[r]), int(cuts[r + 1])
+        for a in range(3):
+            e = want[a].shape[2] if r == world - 1 else hi
+            got = loc[r]["vel"][a]
+            assert torch.equal(got[:, :, lo:e], want[a][:, :, lo:e]), (r, a)
+            assert torch.equal(got[:, :, :lo], sc.velocity[a][:, :, :lo]) and torch.equal(got[:, :, e:], sc.velocity[a][:, :, e:]), (r, a, "outside the slab")
+            changed += int((want[a][:, :, lo:e] != sc.velocity[a][:, :, lo:e]).sum())
+    assert changed > 1000000
+    ref.close()
+    pp0.close()
