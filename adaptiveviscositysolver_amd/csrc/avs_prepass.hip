@@ -12,8 +12,8 @@
 //                        level's "has an ACTIVE cell" flag too) + face / edge / centre / regular-face classification (cpp:886-1443) of the
 //                        LISTED tiles -- occupied now, or visited by the allocation's last classification (reset) -- all lattices
 //                        of a level in one launch
-//   P5 k_tile_select + k_tile_counts + scan + k_tile_select_ids + k_tile_ids   serial numbering in HDK 16^3 tile order (cpp:1566-1593,
-//                        1635-1660, 1688-1712): counts of the listed tiles, exclusive scan over all tiles, ranks inside a tile by wave ballots
+//   P5 scan + k_tile_select_ids + k_tile_ids   serial numbering in HDK 16^3 tile order (cpp:1566-1593, 1635-1660, 1688-1712): the per-tile
+//                        DOF counts come out of the classification launch, exclusive scan over all tiles, ranks inside a tile by wave ballots
 //   slab-local mode (avs_prepass_set_slab): every step on the rank's window only (Box3 sweeps, TileGrid launch boxes),
 //                        the reference's GLOBAL ids through one all-reduce of the per-tile counts
 //
@@ -611,7 +611,7 @@ struct ClassifyArgs {
 };
 
 // classifyOctreeVelocityFacesPartial, cpp:1167-1323
-__device__ __forceinline__ void classify_velocity_tile(const ClassifyArgs &A, const Grid3 &fg, const TileGrid &tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, unsigned tb)
+__device__ __forceinline__ int classify_velocity_tile(const ClassifyArgs &A, const Grid3 &fg, const TileGrid &tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, unsigned tb)
 {
     const int l = A.level, axis = A.axis;
     const Grid3 cg{{A.n[0] >> l, A.n[1] >> l, A.n[2] >> l}};
@@ -620,11 +620,12 @@ __device__ __forceinline__ void classify_velocity_tile(const ClassifyArgs &A, co
     // keeps that value ("constant tiles are never visited", cpp:1197): it is neither read nor written here
     if (!occ[tb]) { // listed because the allocation's LAST classification visited it: back to AVS_UNASSIGNED
         reset_tile(out, fg, tg, tb);
-        return;
+        return 0;
     }
     const int tile_x = tb % tg.tr[0], tile_y = (tb / tg.tr[0]) % tg.tr[1], tile_z = tb / (tg.tr[0] * tg.tr[1]);
     const int vi_ = tile_x * kTile + (threadIdx.x & (kTile - 1)), vj_ = tile_y * kTile + (threadIdx.x >> 4);
-    if (vi_ >= fg.r[0] || vj_ >= fg.r[1]) return;
+    if (vi_ >= fg.r[0] || vj_ >= fg.r[1]) return 0;
+    int cnt = 0; // the tile's DOFs (entries classified 0): what the numbering counts
     for (int vz_ = 0; vz_ < kTile && tile_z * kTile + vz_ < fg.r[2]; ++vz_) {
         int f[3] = {vi_, vj_, tile_z * kTile + vz_};
         const size_t o = lin3(fg, f[0], f[1], f[2]);
@@ -664,11 +665,13 @@ __device__ __forceinline__ void classify_velocity_tile(const ClassifyArgs &A, co
             }
         }
         out[o] = v;
+        cnt += v == 0;
     }
+    return cnt;
 }
 
 // classifyRegularVelocityFacesPartial, cpp:1087-1165 (no octree labels involved)
-__device__ __forceinline__ void classify_regular_tile(const ClassifyArgs &A, const Grid3 &fg, const TileGrid &tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, unsigned tb)
+__device__ __forceinline__ int classify_regular_tile(const ClassifyArgs &A, const Grid3 &fg, const TileGrid &tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, unsigned tb)
 {
     const int axis = A.axis;
     const Grid3 c0{{A.n[0], A.n[1], A.n[2]}};
@@ -676,11 +679,12 @@ __device__ __forceinline__ void classify_regular_tile(const ClassifyArgs &A, con
     // keeps that value ("constant tiles are never visited", cpp:1197): it is neither read nor written here
     if (!occ[tb]) { // listed because the allocation's LAST classification visited it: back to AVS_UNASSIGNED
         reset_tile(out, fg, tg, tb);
-        return;
+        return 0;
     }
     const int tile_x = tb % tg.tr[0], tile_y = (tb / tg.tr[0]) % tg.tr[1], tile_z = tb / (tg.tr[0] * tg.tr[1]);
     const int vi_ = tile_x * kTile + (threadIdx.x & (kTile - 1)), vj_ = tile_y * kTile + (threadIdx.x >> 4);
-    if (vi_ >= fg.r[0] || vj_ >= fg.r[1]) return;
+    if (vi_ >= fg.r[0] || vj_ >= fg.r[1]) return 0;
+    int cnt = 0; // the tile's DOFs (entries classified 0): what the numbering counts
     for (int vz_ = 0; vz_ < kTile && tile_z * kTile + vz_ < fg.r[2]; ++vz_) {
         int f[3] = {vi_, vj_, tile_z * kTile + vz_};
         const size_t o = lin3(fg, f[0], f[1], f[2]);
@@ -708,11 +712,13 @@ __device__ __forceinline__ void classify_regular_tile(const ClassifyArgs &A, con
             }
         }
         out[o] = v;
+        cnt += v == 0;
     }
+    return cnt;
 }
 
 // classifyEdgeStressesPartial, cpp:1325-1405
-__device__ __forceinline__ void classify_edges_tile(const ClassifyArgs &A, const Grid3 &eg, const TileGrid &tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, unsigned tb)
+__device__ __forceinline__ int classify_edges_tile(const ClassifyArgs &A, const Grid3 &eg, const TileGrid &tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, unsigned tb)
 {
     const int l = A.level, axis = A.axis;
     const Grid3 cg{{A.n[0] >> l, A.n[1] >> l, A.n[2] >> l}};
@@ -720,11 +726,12 @@ __device__ __forceinline__ void classify_edges_tile(const ClassifyArgs &A, const
     // keeps that value ("constant tiles are never visited", cpp:1197): it is neither read nor written here
     if (!occ[tb]) { // listed because the allocation's LAST classification visited it: back to AVS_UNASSIGNED
         reset_tile(out, eg, tg, tb);
-        return;
+        return 0;
     }
     const int tile_x = tb % tg.tr[0], tile_y = (tb / tg.tr[0]) % tg.tr[1], tile_z = tb / (tg.tr[0] * tg.tr[1]);
     const int vi_ = tile_x * kTile + (threadIdx.x & (kTile - 1)), vj_ = tile_y * kTile + (threadIdx.x >> 4);
-    if (vi_ >= eg.r[0] || vj_ >= eg.r[1]) return;
+    if (vi_ >= eg.r[0] || vj_ >= eg.r[1]) return 0;
+    int cnt = 0; // the tile's DOFs (entries classified 0): what the numbering counts
     for (int vz_ = 0; vz_ < kTile && tile_z * kTile + vz_ < eg.r[2]; ++vz_) {
         int e[3] = {vi_, vj_, tile_z * kTile + vz_};
         const size_t o = lin3(eg, e[0], e[1], e[2]);
@@ -746,7 +753,9 @@ __device__ __forceinline__ void classify_edges_tile(const ClassifyArgs &A, const
             if (active) v = (l == 0) ? ((A.edgew[axis][o] > 0.f) ? 0 : AVS_OUTSIDE) : 0;
         }
         out[o] = v;
+        cnt += v == 0;
     }
+    return cnt;
 }
 
 // classifyCenterStressesPartial, cpp:1407-1443.  Round 5: the centre lattice by tiles, like the others.  A centre DOF needs an ACTIVE cell, and k_mark_tiles_all flags, for every ACTIVE
@@ -760,19 +769,39 @@ __global__ __launch_bounds__(kBlock) void k_center_tiles(const uint8_t *__restri
     const int tx = (int)(t % tc.tr[0]), ty = (int)((t / tc.tr[0]) % tc.tr[1]), tz = (int)(t / ((size_t)tc.tr[0] * tc.tr[1]));
     occ_c[t] = occ_edge0[(size_t)tx + (size_t)te.tr[0] * ((size_t)ty + (size_t)te.tr[1] * (size_t)tz)];
 }
-__device__ __forceinline__ void classify_centers_tiled_tile(const int8_t *__restrict__ lab, const float *__restrict__ centerw, int level, const Grid3 &cg, const TileGrid &tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, unsigned tb)
+__device__ __forceinline__ int classify_centers_tiled_tile(const int8_t *__restrict__ lab, const float *__restrict__ centerw, int level, const Grid3 &cg, const TileGrid &tg, const uint8_t *__restrict__ occ, int32_t *__restrict__ out, unsigned tb)
 {
     if (!occ[tb]) { // listed because the allocation's LAST classification visited it: back to AVS_UNASSIGNED
         reset_tile(out, cg, tg, tb);
-        return;
+        return 0;
     }
     const int tile_x = tb % tg.tr[0], tile_y = (tb / tg.tr[0]) % tg.tr[1], tile_z = tb / (tg.tr[0] * tg.tr[1]);
     const int i = tile_x * kTile + (threadIdx.x & (kTile - 1)), j = tile_y * kTile + (threadIdx.x >> 4);
-    if (i >= cg.r[0] || j >= cg.r[1]) return;
+    if (i >= cg.r[0] || j >= cg.r[1]) return 0;
+    int cnt = 0; // the tile's DOFs (entries classified 0): what the numbering counts
     for (int z = 0; z < kTile && tile_z * kTile + z < cg.r[2]; ++z) {
         const size_t o = lin3(cg, i, j, tile_z * kTile + z);
-        out[o] = (lab[o] == AVS_ACTIVE && (level != 0 || centerw[o] > 0.f)) ? 0 : AVS_UNASSIGNED;
+        const int32_t v = (lab[o] == AVS_ACTIVE && (level != 0 || centerw[o] > 0.f)) ? 0 : AVS_UNASSIGNED;
+        out[o] = v;
+        cnt += v == 0;
     }
+    return cnt;
+}
+
+// Slab-local pre-pass (round 6): several ranks classify a tile that straddles their windows (identically: the classification is
+// deterministic); ONE of them -- the rank whose slab holds the tile's first plane along the cut axis -- reports its count, the others
+// report 0, and the sum over the ranks gives every rank the count of every tile.
+struct SlabOwn {
+    int on, axis, world, rank;
+    int cuts[kMaxRanks + 1]; // fine cells along the cut axis: rank r owns [cuts[r], cuts[r + 1])
+};
+__device__ __forceinline__ bool slab_owner_is_me(const SlabOwn &own, int tile_coord_along_axis, int level)
+{
+    long long pos = ((long long)tile_coord_along_axis * kTile) << level;
+    if (pos > own.cuts[own.world] - 1) pos = own.cuts[own.world] - 1; // (the extra last tile of a face lattice)
+    int r = 0;
+    while (r + 1 < own.world && pos >= own.cuts[r + 1]) ++r;
+    return r == own.rank;
 }
 
 // All lattices of a level in ONE launch (blockIdx.y names the lattice; round 6): a launch per lattice -- seven per level and three for the
@@ -789,6 +818,8 @@ struct ClassifyBatch {
     uint8_t *remember[kWorkLattices];
     int32_t *out[kWorkLattices];
     const int32_t *cnt[kWorkLattices], *items[kWorkLattices];
+    int32_t *dofs[kWorkLattices];    // per tile of the lattice: its DOF count, where the numbering's scan reads it (zero-filled by the caller)
+    SlabOwn own;                     // slab-local mode: a tile is counted by the rank that owns its first plane
     unsigned occ_cap;
 };
 __global__ __launch_bounds__(kBlock) void k_classify_batch(ClassifyBatch B)
@@ -805,10 +836,22 @@ __global__ __launch_bounds__(kBlock) void k_classify_batch(ClassifyBatch B)
     const int n_list = *B.cnt[k];
     for (int li = (int)blockIdx.x; li < n_list; li += (int)gridDim.x) {
         const unsigned tb = (unsigned)B.items[k][li];
-        if (kind == 0) classify_velocity_tile(A, g, tg, occ, out, tb);
-        else if (kind == 1) classify_edges_tile(A, g, tg, occ, out, tb);
-        else if (kind == 2) classify_centers_tiled_tile(A.lab, A.centerw, A.level, g, tg, occ, out, tb);
-        else classify_regular_tile(A, g, tg, occ, out, tb);
+        int c;
+        if (kind == 0) c = classify_velocity_tile(A, g, tg, occ, out, tb);
+        else if (kind == 1) c = classify_edges_tile(A, g, tg, occ, out, tb);
+        else if (kind == 2) c = classify_centers_tiled_tile(A.lab, A.centerw, A.level, g, tg, occ, out, tb);
+        else c = classify_regular_tile(A, g, tg, occ, out, tb);
+        // the tile's DOF count for the numbering (k_tile_counts read every occupied tile of every lattice a second time for it)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+        if ((threadIdx.x & 63) == 0 && c) {
+            bool mine = true;
+            if (B.own.on) {
+                const int tcoord = B.own.axis == 0 ? (int)(tb % tg.tr[0]) : (B.own.axis == 1 ? (int)((tb / tg.tr[0]) % tg.tr[1]) : (int)(tb / (tg.tr[0] * tg.tr[1])));
+                mine = slab_owner_is_me(B.own, tcoord, kind == 3 ? 0 : A.level);
+            }
+            if (mine) atomicAdd(&B.dofs[k][tb], c);
+        }
     }
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < B.occ_cap; i += gridDim.x * kBlock) B.remember[k][i] = occ[i];
 }
@@ -883,37 +926,15 @@ __device__ __forceinline__ NumLattice batch_lattice(const NumStarts &S, const Nu
     return B->lat[li];
 }
 
-// Slab-local pre-pass (round 6): several ranks classify a tile that straddles their windows (identically: the classification is
-// deterministic); ONE of them -- the rank whose slab holds the tile's first plane along the cut axis -- reports its count, the others
-// report 0, and the sum over the ranks gives every rank the count of every tile.
-struct SlabOwn {
-    int on, axis, world, rank;
-    int cuts[kMaxRanks + 1]; // fine cells along the cut axis: rank r owns [cuts[r], cuts[r + 1])
-};
 __device__ __forceinline__ bool slab_owns_tile(const SlabOwn &own, const NumLattice &Lt, int tile)
 {
     const int tc = own.axis == 0 ? tile % Lt.ntx : (own.axis == 1 ? (tile / Lt.ntx) % Lt.nty : tile / (Lt.ntx * Lt.nty));
-    long long pos = ((long long)tc * kTile) << (Lt.tag & 0xff);
-    if (pos > own.cuts[own.world] - 1) pos = own.cuts[own.world] - 1; // (the extra last tile of a face lattice)
-    int r = 0;
-    while (r + 1 < own.world && pos >= own.cuts[r + 1]) ++r;
-    return r == own.rank;
+    return slab_owner_is_me(own, tc, Lt.tag & 0xff);
 }
 
-// Round 6: the tiles that can hold a DOF are LISTED first (one thread per tile: its occupancy flag, in slab mode its owner) and the
-// counting / numbering workgroups walk the list -- a workgroup per tile of the concatenated space was 376 k workgroups at 512^3 (2.9 M
-// at 1024^3), nine in ten of which found their tile's flag clear and left: dispatching them cost more than the occupied tiles' work.
-__global__ __launch_bounds__(kBlock) void k_tile_select(NumStarts S, const NumBatch *__restrict__ B, int tiles, SlabOwn own, int32_t *__restrict__ list /* [0]: count */)
-{
-    const int t = (int)(blockIdx.x * kBlock + threadIdx.x);
-    if (t >= tiles) return;
-    const NumLattice Lt = batch_lattice(S, B, t);
-    const int tile = t - Lt.tile0;
-    if (Lt.occ && !Lt.occ[tile]) return; // a tile the classification never visited holds no DOF (on a thin sheet: nine tiles in ten)
-    if (own.on && !slab_owns_tile(own, Lt, tile)) return;
-    list[1 + atomicAdd(list, 1)] = t; // (the order of the list does not matter)
-}
-// ... and, behind the scan, the tiles with a DOF that this rank classified
+// Round 6: the per-tile DOF counts come out of the classification launch (k_classify_batch); behind the scan the tiles with a DOF that
+// this rank classified are LISTED and the numbering workgroups walk the list -- a workgroup per tile of the concatenated space was 376 k
+// workgroups at 512^3 (2.9 M at 1024^3), nine in ten of which found nothing to do and left: dispatching them cost more than the work.
 __global__ __launch_bounds__(kBlock) void k_tile_select_ids(NumStarts S, const NumBatch *__restrict__ B, int tiles, const int32_t *__restrict__ tile_off,
                                                             int32_t *__restrict__ list)
 {
@@ -923,27 +944,6 @@ __global__ __launch_bounds__(kBlock) void k_tile_select_ids(NumStarts S, const N
     const NumLattice Lt = batch_lattice(S, B, t);
     if (Lt.occ && !Lt.occ[t - Lt.tile0]) return; // (slab-local pre-pass: a tile of another rank's window -- counted there, not classified here)
     list[1 + atomicAdd(list, 1)] = t;
-}
-
-// tile_count is zero-filled; the listed tiles get their counts
-__global__ __launch_bounds__(kBlock) void k_tile_counts(NumStarts S, const NumBatch *__restrict__ B, int32_t *__restrict__ tile_count,
-                                                        const int32_t *__restrict__ list)
-{
-    __shared__ int red[kBlock / 64];
-    const int n_list = list[0];
-    for (int li = (int)blockIdx.x; li < n_list; li += (int)gridDim.x) {
-        const int gt = list[1 + li];
-        const NumLattice Lt = batch_lattice(S, B, gt);
-        const int tile = gt - Lt.tile0;
-        size_t first, zs;
-        int cnt = __popc(tile_flags(Lt.grid, Lt.g, Lt.ntx, Lt.nty, &first, &zs, tile));
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
-        __syncthreads();
-        if (threadIdx.x == 0) tile_count[gt] = red[0] + red[1] + red[2] + red[3];
-        __syncthreads();
-    }
 }
 
 // `table` (optional): the dof table of this kind -- record (level | axis << 8, i, j, k) of every id handed out, what the solver context
@@ -1532,6 +1532,42 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
     phase.next("Build Octree Velocity and Stress Labels"); // cpp:360 (+ "Build Regular Grid Velocity Labels", cpp:306)
     t.start();
     size_t max_vol = 0;
+    // The numbering's tile space, laid out now: the classification launch drops every tile's DOF count where the scan will read it.  One
+    // batch per counter -- velocity faces, edges, centres (each over ALL levels, level-major, then axis: numbering order), regular-grid
+    // faces (cpp:1486-1509: one counter over the three axes); the four count arrays lie behind each other in ONE buffer (+ the levels'
+    // flags in slab mode: what the ranks sum).  Levels beyond the cap are the tail of their batch: the scans stop before them.
+    DevBuf<int32_t> &fl = p->num_counts;
+    int64_t seg[5] = {0, 0, 0, 0, 0};          // first count of every batch in the buffer (each batch: tiles + 1 entries)
+    int level_tile0[4][AVS_MAX_LEVELS + 1];     // first tile of every level inside a batch (counters 0 .. 2)
+    int tile0_of[4][AVS_MAX_LEVELS][3] = {};    // first tile of every lattice inside its batch
+    for (int counter = 0; counter < 4; ++counter) {
+        int64_t tiles = 0;
+        auto add = [&](int kind, int l, int a) {
+            int gr[3];
+            pp_res(d, kind, l, a, gr);
+            tile0_of[counter][l][a] = (int)tiles;
+            tiles += (int64_t)((gr[0] + kTile - 1) / kTile) * ((gr[1] + kTile - 1) / kTile) * ((gr[2] + kTile - 1) / kTile);
+        };
+        if (counter < 3) {
+            for (int l = 0; l < L; ++l) {
+                level_tile0[counter][l] = (int)tiles;
+                for (int a = 0; a < (counter == 2 ? 1 : 3); ++a) add(counter, l, a);
+            }
+            level_tile0[counter][L] = (int)tiles;
+        } else
+            for (int a = 0; a < 3; ++a) add(0, 0, a);
+        AVS_REQUIRE(tiles < (1ll << 31) - 1, AVS_EINVAL, "too many tiles");
+        seg[counter + 1] = seg[counter] + tiles + 1;
+    }
+    const int64_t n_exchange = seg[4] + AVS_MAX_LEVELS;
+    AVS_REQUIRE(n_exchange < (1ll << 31) - 1, AVS_EINVAL, "too many tiles");
+    AVS_TRY(fl.reserve((size_t)n_exchange));
+    AVS_HIP(hipMemsetAsync(fl.p, 0, (size_t)n_exchange * sizeof(int32_t), st));
+    SlabOwn own{};
+    if (slab) {
+        own.on = 1; own.axis = sa; own.world = p->slab.world; own.rank = p->slab.rank;
+        for (int r = 0; r <= p->slab.world; ++r) own.cuts[r] = p->slab.cuts[r];
+    }
     TileGrid tg0[3];
     for (int l = 0; l < capped; ++l) {
         int cr[3];
@@ -1565,6 +1601,7 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         for (int b2 = 0; b2 < 3; ++b2) B.A.edgew[b2] = p->edgew[b2].p;
         B.A.solid = p->sol;
         B.occ_cap = (unsigned)occ_cap;
+        B.own = own;
         size_t max_launch = 0;
         for (int k = 0; k < kWorkLattices; ++k) {
             const int kind = k < 3 ? 0 : (k < 6 ? 1 : 2), a = k < 6 ? k % 3 : 0;
@@ -1583,6 +1620,7 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
             if (W.tg[k].launch() > max_launch) max_launch = W.tg[k].launch();
             B.kind[k] = kind; B.axis[k] = a; B.g[k] = g3(gr); B.tg[k] = W.tg[k]; B.occ[k] = W.now[k]; B.remember[k] = tss[k]->occ.p; B.out[k] = buf.p;
             B.cnt[k] = W.cnt[k]; B.items[k] = W.items[k];
+            B.dofs[k] = fl.p + seg[kind] + tile0_of[kind][l][a];
         }
         if (max_launch) hipLaunchKernelGGL(k_tile_worklists, dim3(grid_for(max_launch), kWorkLattices), dim3(kBlock), 0, st, W);
         {   // (with no tile to launch over the occupancy is still remembered: the grid has at least one workgroup per lattice)
@@ -1611,6 +1649,7 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
         for (int b2 = 0; b2 < 3; ++b2) B.A.edgew[b2] = p->edgew[b2].p;
         B.A.solid = p->sol;
         B.occ_cap = (unsigned)occ_cap;
+        B.own = own;
         for (int k = 0; k < kWorkLattices; ++k) B.kind[k] = -1;
         for (int a = 0; a < 3; ++a) {
             int gr[3];
@@ -1625,6 +1664,7 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
             if (W.tg[a].launch() > max_launch) max_launch = W.tg[a].launch();
             B.kind[a] = 3; B.axis[a] = a; B.g[a] = g3(gr); B.tg[a] = W.tg[a]; B.occ[a] = W.now[a]; B.remember[a] = tss[a]->occ.p; B.out[a] = p->ridx[a].p;
             B.cnt[a] = W.cnt[a]; B.items[a] = W.items[a];
+            B.dofs[a] = fl.p + seg[3] + tile0_of[3][0][a];
         }
         if (max_launch) hipLaunchKernelGGL(k_tile_worklists, dim3(grid_for(max_launch), kWorkLattices), dim3(kBlock), 0, st, W);
         {
@@ -1651,81 +1691,54 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
 
     // ---- P5 numbering ----------------------------------------------------------------------
     t.start();
-    DevBuf<int32_t> &fl = p->num_counts, &ids = p->num_offsets, &scan_tmp = p->num_scan_tmp; // (scratch kept across frames)
+    DevBuf<int32_t> &ids = p->num_offsets, &scan_tmp = p->num_scan_tmp; // (scratch kept across frames)
     DevBuf<long long> &base = p->num_totals;
     (void)max_vol;
     AVS_TRY(base.alloc(4));
     AVS_HIP(hipMemsetAsync(base.p, 0, 4 * sizeof(long long), st));
     PhaseTrace tr(st, "numbering", avs::options_from_env().trace_phases != 0);
-    // one batch per counter: velocity faces, edges, centres (each over all levels, in numbering order), regular-grid faces (cpp:1486-1509:
-    // one counter over the three axes).  The four count arrays lie behind each other in ONE buffer (+ the levels' flags in slab mode: what
-    // the ranks sum), the scans run per counter.
+    // the batches' lattice lists (the layout is the one the classification counted into: tile0_of, seg)
     NumBatch host_batches[4] = {}; // (alive until the synchronisation behind the last batch: they are the sources of asynchronous copies)
-    int64_t seg[5] = {0, 0, 0, 0, 0};      // first count of every batch in the buffer (each batch: tiles + 1 entries)
-    int level_tile0[4][AVS_MAX_LEVELS + 1]; // first tile of every level inside a batch (counters 0 .. 2)
     for (int counter = 0; counter < 4; ++counter) {
         NumBatch &B = host_batches[counter];
-        int64_t tiles = 0;
-        auto add = [&](int32_t *grid, const int gr[3], const uint8_t *occ, int tag) {
+        auto add = [&](int32_t *grid, const int gr[3], const uint8_t *occ, int tag, int tile0) {
             NumLattice &Lt = B.lat[B.count++];
             Lt.grid = grid;
             Lt.occ = occ;
             Lt.g = g3(gr);
             Lt.ntx = (gr[0] + kTile - 1) / kTile;
             Lt.nty = (gr[1] + kTile - 1) / kTile;
-            Lt.tile0 = (int)tiles;
+            Lt.tile0 = tile0;
             Lt.tag = tag;
-            tiles += (int64_t)Lt.ntx * Lt.nty * ((gr[2] + kTile - 1) / kTile);
         };
         if (counter < 3) {
             const int kind = counter;
-            for (int l = 0; l < capped; ++l) {
-                level_tile0[counter][l] = (int)tiles;
+            for (int l = 0; l < L; ++l)
                 for (int a = 0; a < (kind == 2 ? 1 : 3); ++a) {
                     int gr[3];
                     pp_res(d, kind, l, a, gr);
                     const uint8_t *oc = occ_all.p + ((size_t)l * 7 + (kind == 2 ? 6 : (size_t)kind * 3 + a)) * occ_cap; // (centres: the cell tiles with an ACTIVE cell, k_center_tiles)
-                    add(kind == 0 ? p->vidx[l][a].p : (kind == 1 ? p->eidx[l][a].p : p->cidx[l].p), gr, oc, l | (a << 8));
+                    add(kind == 0 ? p->vidx[l][a].p : (kind == 1 ? p->eidx[l][a].p : p->cidx[l].p), gr, oc, l | (a << 8), tile0_of[counter][l][a]);
                 }
-            }
-            level_tile0[counter][capped] = (int)tiles;
         } else {
             for (int a = 0; a < 3; ++a) {
                 int gr[3];
                 pp_res(d, 0, 0, a, gr);
-                add(p->ridx[a].p, gr, occ_all.p + (size_t)a * occ_cap, 0); // classified with the level-0 face occupancy
+                add(p->ridx[a].p, gr, occ_all.p + (size_t)a * occ_cap, 0, tile0_of[3][0][a]); // classified with the level-0 face occupancy
             }
         }
-        AVS_REQUIRE(tiles < (1ll << 31) - 1, AVS_EINVAL, "too many tiles");
-        B.total_tiles = (int)tiles;
-        seg[counter + 1] = seg[counter] + tiles + 1;
+        B.total_tiles = (int)(seg[counter + 1] - seg[counter] - 1);
     }
-    const int64_t n_exchange = seg[4] + AVS_MAX_LEVELS;
-    AVS_REQUIRE(n_exchange < (1ll << 31) - 1, AVS_EINVAL, "too many tiles");
-    AVS_TRY(fl.reserve((size_t)n_exchange));
     AVS_TRY(ids.reserve((size_t)seg[4]));
     AVS_TRY(p->num_lists.reserve((size_t)seg[4] + 4)); // per batch: [count | tile ids]  (a batch's segment has tiles + 1 entries)
     constexpr unsigned kNumGrid = 4096;                 // workgroups walking a list
     AVS_TRY(p->num_batches.alloc(4));
-    SlabOwn own{};
-    if (slab) {
-        own.on = 1; own.axis = sa; own.world = p->slab.world; own.rank = p->slab.rank;
-        for (int r = 0; r <= p->slab.world; ++r) own.cuts[r] = p->slab.cuts[r];
-    }
     NumStarts S[4];
     for (int counter = 0; counter < 4; ++counter) {
         const NumBatch &B = host_batches[counter];
-        const int64_t tiles = B.total_tiles;
-        AVS_TRY(scan_tmp.reserve(scan_tmp_elems(tiles + 1)));
+        AVS_TRY(scan_tmp.reserve(scan_tmp_elems((int64_t)B.total_tiles + 1)));
         AVS_HIP(hipMemcpyAsync(p->num_batches.p + counter, &B, sizeof(NumBatch), hipMemcpyHostToDevice, st)); // (pageable source: staged before the call returns)
         for (int k = 0; k < kNumLattices; ++k) S[counter].tile0[k] = k < B.count ? B.lat[k].tile0 : INT_MAX;
-        if (tiles) {
-            int32_t *list = p->num_lists.p + seg[counter];
-            AVS_HIP(hipMemsetAsync(list, 0, sizeof(int32_t), st));
-            AVS_HIP(hipMemsetAsync(fl.p + seg[counter], 0, (size_t)(tiles + 1) * sizeof(int32_t), st));
-            hipLaunchKernelGGL(k_tile_select, dim3(grid_for((size_t)tiles)), dim3(kBlock), 0, st, S[counter], p->num_batches.p + counter, (int)tiles, own, list);
-            hipLaunchKernelGGL(k_tile_counts, dim3(kNumGrid), dim3(kBlock), 0, st, S[counter], p->num_batches.p + counter, fl.p + seg[counter], (const int32_t *)list);
-        }
     }
     AVS_HIP(hipGetLastError());
     tr.mark("tile counts");
@@ -1746,8 +1759,8 @@ avs_status avs_prepass_run(avs_prepass *p, const float *liquid, const float *sol
             p->ready = true;
             return AVS_OK;
         }
-        for (int c = 0; c < 3; ++c) eff_tiles[c] = level_tile0[c][capped]; // (levels are the outer order of a batch: the capped ones are its tail)
     }
+    for (int c = 0; c < 3; ++c) eff_tiles[c] = level_tile0[c][capped]; // (levels are the outer order of a batch: the capped ones are its tail)
     tr.mark("exchange");
     for (int counter = 0; counter < 4; ++counter)
         AVS_TRY(exclusive_scan_i32(fl.p + seg[counter], ids.p + seg[counter], eff_tiles[counter], scan_tmp.p, scan_tmp.n, st));
