@@ -115,8 +115,6 @@ for case in range(cases):
             iref = ref_s.solve(1e-9, 8000)
             xref = ref_s.solution()
             nnz_ref = ref_s.info().nnz
-            ref_s.close()
-            pp0.close()
             grp = C.c_void_p()
             capi.check(lib.avs_local_group_create(world, C.byref(grp)))
             keep = []
@@ -132,8 +130,10 @@ for case in range(cases):
                 ai = s_.dist_assemble(axis)
                 info = s_.dist_solve(1e-9, 8000)
                 x = s_.dist_solution()
+                vel = [v.clone() for v in sc.velocity]
+                s_.transfer_to_regular_grid_in_place(vel)     # the rank's slab of the regular grid
                 keep.append((s_, pp))
-                return ai.nnz, s_.plan_sizes.n_own, info.iterations, info.converged, x
+                return ai.nnz, s_.plan_sizes.n_own, info.iterations, info.converged, x, vel
 
             out = T._run_threads(world, solve_fn)
             for s_, pp in keep:
@@ -144,7 +144,19 @@ for case in range(cases):
             for o in out:
                 assert o[3] == 1 and abs(o[2] - iref.iterations) <= max(3, iref.iterations // 100), (o[2], iref.iterations)
                 assert T_rel(o[4], xref) < 1e-7
-            msg = f"solve {out[0][2]} it (single {iref.iterations})"
+            # the transfer: the whole-pyramid context, handed the ranks' gathered vector, against every rank's slab (bit for bit)
+            ref_s.set_solution(out[0][4])
+            want = [v.clone() for v in sc.velocity]
+            ref_s.transfer_to_regular_grid_in_place(want)
+            for r, o in enumerate(out):
+                lo_, hi_ = int(cuts[r]), int(cuts[r + 1])
+                for a in range(3):
+                    sl = [slice(None)] * 3
+                    sl[2 - axis] = slice(lo_, want[a].shape[2 - axis] if r == world - 1 else hi_)
+                    assert torch.equal(o[5][a][tuple(sl)], want[a][tuple(sl)]), ("transfer", r, a)
+            ref_s.close()
+            pp0.close()
+            msg = f"solve {out[0][2]} it (single {iref.iterations}), transfer equal on every slab"
         print("ok  ", tag, "dofs", counts[1], msg, flush=True)
     except Exception as e:  # noqa: BLE001
         bad += 1
