@@ -440,8 +440,8 @@ avs_status avs_dist_assemble(avs_ctx *ctx, int32_t cut_axis, avs_assembly_info *
  *                                                     to avs_prepass_set_slab instead); cuts == NULL switches it off
  *   avs_prepass_run(pp, ...) ; avs_prepass_apply(pp, ctx) ; avs_dist_assemble(ctx, ...)      on every rank, collectively
  * The cuts must exist BEFORE anything is counted: take them from the previous frame -- avs_dist_get_cuts(ctx, 1, ...) returns the
- * cuts the last assembly's per-plane weights (summed over the ranks) suggest for the next one, which = 0 the cuts it used -- or start
- * from equal slabs.  avs_dist_assemble on such a context builds stencils for the stresses within 4 cells (of their level) of the
+ * cuts the last assembly's per-plane weights (summed over the ranks; a hosted group has no library-side exchange: it gets the cuts it
+ * used) suggest for the next one, which = 0 the cuts it used -- or start from equal slabs.  avs_dist_assemble on such a context builds stencils for the stresses within 4 cells (of their level) of the
  * slab, the rank's rows (bit-identical to the reference's rows), halo and send lists; for the same cuts every array equals what the
  * replicated-index avs_dist_assemble produces.  Three lookup arrays indexed by DOF id (6 B per DOF, filled by memset) are the only
  * global-sized work.  avs_transfer_to_regular_grid(_in_place) on a slab-local context scatters and samples the DOFs of the rank's window
