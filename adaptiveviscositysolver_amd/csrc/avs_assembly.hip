@@ -1368,9 +1368,9 @@ avs_status count_raw_rows(avs_ctx *c, DevBuf<int32_t> &counts)
     hipStream_t st = c->stream;
     AVS_REQUIRE(c->stencils_ready, AVS_ESTATE, "build the stencils first");
     const int64_t n = c->n_vel;
-    DevBuf<int> err;
-    AVS_TRY(err.alloc(1));
-    AVS_TRY(counts.alloc((size_t)n + 1));
+    DevBuf<int> &err = c->scratch.err;
+    AVS_TRY(err.reserve(1));
+    AVS_TRY(counts.reserve((size_t)n + 1));
     AVS_HIP(hipMemsetAsync(err.p, 0, sizeof(int), st));
     if (n) hipLaunchKernelGGL((k_rows<false>), dim3(grid_for(n)), dim3(kBlock), 0, st, c->view(), c->vdof.p, n, edge_view(c), center_view(c),
                               (const double *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr, counts.p,

@@ -89,7 +89,8 @@ struct PcgDist {
     // assembly were 2 ms of a 7-ms slab assembly
     struct Scratch {
         DevBuf<uint32_t> keys_in, keys_out, needed_by, pm;
-        DevBuf<int32_t> dom, flag, pos, g2l, scan_tmp, ids, halo_tmp, tile_bnd, tile_int, tile_pos, w32;
+        DevBuf<int32_t> dom, flag, pos, g2l, scan_tmp, ids, halo_tmp, tile_bnd, tile_int, tile_pos, w32, plane_owner, raw_count;
+        DevBuf<uint16_t> plane;
         DevBuf<uint8_t> owner, is_halo;
         DevBuf<char> sort_tmp;
         DevBuf<int> mark_err;
@@ -1600,24 +1601,23 @@ static avs_status dist_assemble_device(avs_ctx *c, PcgDist *d, int cut_axis, int
     AVS_REQUIRE(nplanes <= 65535, AVS_EINVAL, "too many cut planes");
 
     // global, index-only: raw triplet count per row (weights) and the brick-major permutation
-    DevBuf<int32_t> raw_count;
+    DevBuf<int32_t> &raw_count = d->ws.raw_count; // (work arrays kept across frames: see PcgDist::Scratch)
     AVS_TRY(count_raw_rows(c, raw_count));
     AVS_TRY(build_brick_permutation(c, c->brick_shift));
 
-    DevBuf<uint16_t> plane;
-    DevBuf<unsigned long long> weight;
-    DevBuf<int32_t> plane_owner, flag, pos, g2l, scan_tmp, halo_tmp, ids;
-    DevBuf<uint8_t> owner, is_halo;
-    DevBuf<uint32_t> needed_by;
-    AVS_TRY(plane.alloc((size_t)n));
-    AVS_TRY(weight.alloc((size_t)nplanes));
-    AVS_TRY(plane_owner.alloc((size_t)nplanes));
-    AVS_TRY(flag.alloc((size_t)n + 1));
-    AVS_TRY(pos.alloc((size_t)n + 1));
-    AVS_TRY(g2l.alloc((size_t)n));
-    AVS_TRY(scan_tmp.alloc(scan_tmp_elems(n + 1)));
-    AVS_TRY(owner.alloc((size_t)n));
-    AVS_TRY(is_halo.alloc((size_t)n));
+    DevBuf<uint16_t> &plane = d->ws.plane;
+    DevBuf<unsigned long long> &weight = d->ws.weight;
+    DevBuf<int32_t> &plane_owner = d->ws.plane_owner, &flag = d->ws.flag, &pos = d->ws.pos, &g2l = d->ws.g2l, &scan_tmp = d->ws.scan_tmp, &ids = d->ws.ids;
+    DevBuf<uint8_t> &owner = d->ws.owner, &is_halo = d->ws.is_halo;
+    AVS_TRY(plane.reserve((size_t)(n > 0 ? n : 1)));
+    AVS_TRY(weight.reserve((size_t)nplanes));
+    AVS_TRY(plane_owner.reserve((size_t)nplanes));
+    AVS_TRY(flag.reserve((size_t)n + 1));
+    AVS_TRY(pos.reserve((size_t)n + 1));
+    AVS_TRY(g2l.reserve((size_t)(n > 0 ? n : 1)));
+    AVS_TRY(scan_tmp.reserve(scan_tmp_elems(n + 1)));
+    AVS_TRY(owner.reserve((size_t)(n > 0 ? n : 1)));
+    AVS_TRY(is_halo.reserve((size_t)(n > 0 ? n : 1)));
     AVS_HIP(hipMemsetAsync(weight.p, 0, (size_t)nplanes * sizeof(unsigned long long), st));
     AVS_HIP(hipMemsetAsync(is_halo.p, 0, (size_t)n, st));
     AVS_HIP(hipMemsetAsync(g2l.p, 0xFF, (size_t)n * sizeof(int32_t), st));
@@ -1638,8 +1638,8 @@ static avs_status dist_assemble_device(avs_ctx *c, PcgDist *d, int cut_axis, int
     // owned rows (ascending brick-major id) and the DOFs behind them
     int64_t n_own = 0;
     AVS_TRY(scan_flags(flag.p, pos.p, n, scan_tmp, &n_own, st));
-    AVS_TRY(d->own_global.alloc((size_t)n_own));
-    AVS_TRY(ids.alloc((size_t)n_own));
+    AVS_TRY(d->own_global.reserve((size_t)n_own));
+    AVS_TRY(ids.reserve((size_t)(n_own > 0 ? n_own : 1)));
     hipLaunchKernelGGL(k_plan_scatter, dim3(grid256(n)), dim3(256), 0, st, n, flag.p, pos.p, (const int32_t *)nullptr, d->own_global.p,
                        g2l.p, 0);
     if (n_own) hipLaunchKernelGGL(k_gather_i<int32_t>, dim3(grid256(n_own)), dim3(256), 0, st, c->perm.p, d->own_global.p, ids.p, n_own);

@@ -94,8 +94,8 @@ avs_status build_brick_permutation(avs_ctx *c, int brick_shift)
     AVS_TRY(keys_in.reserve((size_t)n));
     AVS_TRY(keys_out.reserve((size_t)n));
     AVS_TRY(ids_in.reserve((size_t)n));
-    AVS_TRY(c->perm.alloc((size_t)n));
-    AVS_TRY(c->inv.alloc((size_t)n));
+    AVS_TRY(c->perm.reserve((size_t)(n > 0 ? n : 1)));
+    AVS_TRY(c->inv.reserve((size_t)(n > 0 ? n : 1)));
     if (n == 0) return AVS_OK;
     // cell-major order inside the bricks while brick id + cell bits fit the 32-bit sort key (AVS_BRICK_INTERLEAVE=0: axis-major, round 2)
     int interleave = cur_opt().brick_interleave;
